@@ -1,0 +1,122 @@
+"""Pins the oracle (oracle/*.py, CPU) before anything trusts it:
+  * CTC restatement  vs the warp-ctc known-answer vectors of the reference's tests/collections/asr/k2/test_ctc.py
+  * torch ctc_loss (the arithmetic the reference path actually runs, losses/ctc.py:77) vs the same vectors
+  * mel / encoder / loss restatement vs fixtures produced by the reference's own source files (oracle/make_golden.py)
+  * (build container only) restatement vs the reference files executed live through oracle/ref_shim.py
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import conformer_ref as R
+from oracle import ctc_ref
+
+
+def _load_ka(golden_dir):
+    with open(os.path.join(golden_dir, "ctc_known_answers.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", ["test_case_small", "test_case_small_blank_last", "test_case_big_tensor"])
+def test_ctc_restatement_matches_known_answers(golden_dir, name):
+    case = _load_ka(golden_dir)[name]
+    acts = np.array(case["acts"])
+    B, T, C = acts.shape
+    labels = case["labels"]
+    nll, gx = ctc_ref.ctc_loss_and_grad_wrt_logits(acts, labels, [T] * B, [len(l) for l in labels], case["blank"])
+    # tolerances of the reference test: rtol 1e-6 on cost, atol 1e-6 on grads (rtol 1e-3 for big_tensor)
+    assert np.allclose(nll if B > 1 else nll.sum(), case["expected_costs"], rtol=1e-6)
+    assert np.allclose(gx, np.array(case["expected_grads"]), atol=1e-6, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["test_case_small", "test_case_small_blank_last", "test_case_big_tensor"])
+def test_torch_ctc_matches_known_answers(golden_dir, name):
+    case = _load_ka(golden_dir)[name]
+    acts = torch.tensor(case["acts"], dtype=torch.float32, requires_grad=True)
+    B, T, C = acts.shape
+    labels = torch.tensor(case["labels"])
+    logp = torch.log_softmax(acts, -1)
+    loss, per = R.ctc_loss_mean_batch(logp, labels, torch.full((B,), T), torch.tensor([len(l) for l in case["labels"]]),
+                                      case["blank"])
+    per.sum().backward()
+    assert np.allclose(per.detach().numpy(), case["expected_costs"], rtol=1e-5)
+    assert np.allclose(acts.grad.numpy(), np.array(case["expected_grads"]), atol=2e-6, rtol=1e-3)
+
+
+def test_ctc_restatement_matches_torch_random():
+    rng = np.random.RandomState(0)
+    B, T, C, U = 3, 30, 7, 8
+    acts = rng.randn(B, T, C)
+    tgt = rng.randint(0, C - 1, size=(B, U))
+    tgt[0, 3] = tgt[0, 2]  # repeated label
+    in_len = np.array([30, 22, 17])
+    tl = np.array([8, 5, 8])
+    nll, g = ctc_ref.ctc_loss_and_grad_wrt_logits(acts, tgt, in_len, tl, blank=C - 1)
+    a = torch.tensor(acts, dtype=torch.float64, requires_grad=True)
+    _, per = R.ctc_loss_mean_batch(torch.log_softmax(a, -1), torch.tensor(tgt), torch.tensor(in_len), torch.tensor(tl), C - 1)
+    per.sum().backward()
+    assert np.allclose(nll, per.detach().numpy(), rtol=1e-9)
+    assert np.allclose(g, a.grad.numpy(), atol=1e-9)
+
+
+def test_ctc_infeasible_zero_infinity():
+    acts = np.random.RandomState(1).randn(1, 3, 4)
+    nll, g = ctc_ref.ctc_loss_and_grad_wrt_logits(acts, [[0, 0, 1]], [3], [3], blank=3)  # needs >= 4 frames
+    assert nll[0] == 0.0 and np.all(g == 0)
+
+
+def test_mel_restatement_matches_reference_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "ref_mel_b3.npz"))
+    assert np.array_equal(R.mel_filterbank(), z["fb"][0]), "Slaney filterbank restatement != reference buffer"
+    assert np.allclose(R.hann_window_sym(400).numpy(), z["window"], atol=1e-7)
+    mel, mel_len = R.log_mel_features(torch.from_numpy(z["audio"]), torch.from_numpy(z["audio_len"]))
+    assert mel.shape == z["mel"].shape
+    assert np.array_equal(mel_len.numpy(), z["mel_len"])
+    # north_star tolerance: 1e-3 relative fp32 -- the restatement is far inside it
+    assert np.allclose(mel.numpy(), z["mel"], rtol=1e-3, atol=2e-4)
+    assert np.abs(mel.numpy() - z["mel"]).max() < 2e-4
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_model_restatement_matches_reference_fixture(golden_dir, mode):
+    z = np.load(os.path.join(golden_dir, "ref_tiny_model.npz"))
+    cfg = R.ConformerCfg(d_model=32, n_heads=4, n_layers=2, vocab=16, dropout=0, dropout_att=0, dropout_pre_encoder=0)
+    P = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("P/")}
+    for k in R.trainable_keys(P):
+        P[k] = P[k].clone().requires_grad_(True)
+    out = R.model_forward(P, cfg, torch.from_numpy(z["audio"]), torch.from_numpy(z["audio_len"]),
+                          torch.from_numpy(z["tokens"]), torch.from_numpy(z["token_len"]),
+                          train=False, bn_training=(mode == "train"))
+    assert np.array_equal(out["enc_len"].numpy(), z[f"{mode}/enc_len"])
+    assert np.allclose(out["enc"].detach().numpy(), z[f"{mode}/enc"], atol=2e-5)
+    assert np.allclose(out["logp"].detach().numpy(), z[f"{mode}/logp"], atol=2e-5)
+    assert abs(out["loss"].item() - float(z[f"{mode}/loss"])) <= 1e-5 * abs(float(z[f"{mode}/loss"]))
+    out["loss"].backward()
+    for k in R.trainable_keys(P):
+        ref = z[f"{mode}/grad/{k}"]
+        scale = max(np.abs(ref).max(), 1e-4)
+        assert np.abs(P[k].grad.numpy() - ref).max() <= 1e-3 * scale + 1e-5, k  # analytically-zero grads (dw bias under BN, k bias) are pure rounding noise
+
+
+@pytest.mark.reference
+def test_restatement_matches_live_reference():
+    from oracle import ref_shim
+
+    if not ref_shim.reference_available():
+        pytest.skip("/root/reference not present (GPU box)")
+    torch.manual_seed(3)
+    m = ref_shim.ReferenceCTCModel(d_model=48, n_heads=4, n_layers=1, vocab=12)
+    m.eval()
+    cfg = R.ConformerCfg(d_model=48, n_heads=4, n_layers=1, vocab=12, dropout=0, dropout_att=0, dropout_pre_encoder=0)
+    P = {"encoder." + k: v for k, v in m.encoder.state_dict().items()}
+    P.update({"decoder.decoder_layers." + k: v for k, v in m.decoder_layers.state_dict().items()})
+    audio, alen, tok, tl = R.synthetic_batch(2, 0.8, vocab=12, seed=7)
+    alen = torch.tensor([12800, 9000])
+    loss, logp, enc, enc_len, mel, mel_len = m(audio, alen, tok, tl)
+    out = R.model_forward(P, cfg, audio, alen, tok, tl)
+    assert torch.allclose(out["mel"], mel, atol=1e-4)
+    assert torch.allclose(out["logp"], logp, atol=2e-5)
+    assert abs(out["loss"].item() - loss.item()) < 1e-4
