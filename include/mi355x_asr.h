@@ -1,0 +1,159 @@
+/* mi355x_asr.h -- C ABI of libmi355x_asr.so: the MI355X (gfx950 / CDNA4) kernels behind the drop-in
+ * Conformer-CTC training path (NeMo `EncDecCTCModel` + `ConformerEncoder`).
+ *
+ * The reference has NO C ABI on this path (its host code is Python calling ATen), so this boundary is defined
+ * here, directly under the Python NeuralModule classes.  Conventions:
+ *   - every entry point returns 0 on success, 1 = invalid argument (the Python binding raises ValueError, the
+ *     reference's convention: conformer_encoder.py:569-578, features.py:288-305), 2 = launch failure (RuntimeError);
+ *   - all pointers are DEVICE pointers owned by the caller (torch allocates; kernels never allocate or free);
+ *   - `stream` is a hipStream_t (0 = default stream); calls are asynchronous and re-entrant across streams;
+ *   - dtype codes: 0 = float32, 1 = bfloat16 (raw 16-bit); lengths are int64 like the reference's LengthsType tensors;
+ *   - activations are channels-last: [B, T, d] rows m = b*T + t; conv feature maps [B, T, F, C].
+ *
+ * Each declaration cites the reference interface (file:line under the NeMo tree) whose arithmetic it replaces.
+ */
+#ifndef MI355X_ASR_H
+#define MI355X_ASR_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355X_DT_F32 0
+#define MI355X_DT_BF16 1
+
+/* ---- GEMM with fused epilogues ------------------------------------------------------------------------------
+ * C[M,N] = epi( sum_k A(m,k) * B(n,k) ).  trans{A,B}=0: operand stored [rows][K] (K contiguous);
+ * =1: stored [K][rows] (reduction-major: wgrad / P@V).  Batched: z in [0,batch): z0 = z % nb0, z1 = z / nb0,
+ * operand offset = z0*s?0 + z1*s?1 (elements).  bf16 inputs run on MFMA, f32 inputs on an exact fp32 kernel.
+ * Replaces: F.linear / Conv1d(k=1) / matmul / conv2d-as-GEMM in conformer_modules.py:382-387,321,343;
+ * multi_head_attention.py:124-146,300-350; subsampling.py:231-253,431; conv_asr.py:445.                        */
+enum {
+  MI355X_EPI_STORE = 0,      /* C = alpha * dropout(acc + bias)                                                  */
+  MI355X_EPI_SWISH_DROP = 1, /* aux_out = acc + bias ; C = dropout(swish(acc + bias))          (FFN linear1)     */
+  MI355X_EPI_RESID = 2,      /* C(f32) = aux_in(f32) + alpha * dropout(acc + bias)             (residual branch) */
+  MI355X_EPI_DSWISH = 3,     /* C = acc * dropmask * swish'(aux_in)                            (FFN dgrad)       */
+  MI355X_EPI_RELU_MASK = 4,  /* C = relu(acc + bias) * [ (m % rows_per_b) / rows_inner < row_len[m / rows_per_b] ] */
+  MI355X_EPI_MUL_POS = 5     /* C = acc * (aux_in > 0)                                         (ReLU dgrad)      */
+};
+typedef struct mi355x_gemm_desc {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  long long lda, ldb, ldc;          /* row pitch (elements) of the stored matrices                               */
+  int transA, transB;
+  int in_dtype;                     /* dtype of A and B                                                          */
+  int c_dtype;                      /* dtype of C                                                                */
+  int batch, nb0;
+  long long sA0, sA1, sB0, sB1, sC0, sC1;
+  const void* bias;                 /* f32 [N] or NULL                                                           */
+  float alpha;
+  int epilogue;
+  int atomic;                       /* 1: atomicAdd into f32 C (required for splitk > 1)                         */
+  int splitk;
+  const void* aux_in; int aux_in_dtype;
+  void* aux_out; int aux_out_dtype;
+  long long ldaux;                  /* pitch of aux_in / aux_out (same batch offsets as C)                       */
+  unsigned drop_key, drop_threshold; float drop_scale;   /* threshold 0 = dropout off                            */
+  const void* row_len; int rows_per_b; int rows_inner;   /* EPI_RELU_MASK: int64 [B] valid lengths               */
+} mi355x_gemm_desc;
+int mi355x_gemm(const mi355x_gemm_desc* desc, void* stream);
+
+/* ---- log-mel front-end: FilterbankFeatures.forward, parts/preprocessing/features.py:423-502 --------------------
+ * audio f32 [B,S], audio_len i64 [B] -> out f32 [B,n_mels,T] = log(mel_power + log_guard), T = 1 + S/hop.
+ * fb_* = sparse rows of the (persistent) `fb` buffer: for mel m, weights fb_w[fb_off[m] .. +fb_len[m]) apply to FFT
+ * bins fb_start[m]...  n_fft must be 512 (Hann window `window[win]` is centred in the FFT frame like torch.stft). */
+int mi355x_logmel_fwd(const void* audio, const void* audio_len, const void* window, int win, int hop, int n_fft,
+                      const void* fb_start, const void* fb_len, const void* fb_off, const void* fb_w, int n_mels,
+                      float preemph, float dither, unsigned seed, float log_guard, void* out, int B, int S, int T,
+                      void* stream);
+/* normalize_batch(..., 'per_feature') + pad fill, features.py:59-93,490-493.  x f32 [B,n_mels,T] -> y (y_dtype) */
+int mi355x_feat_normalize(const void* x, const void* seq_len, void* y, int y_dtype, int B, int n_mels, int T,
+                          int normalize, float pad_value, void* stream);
+
+/* ---- convolution sub-sampling pieces: ConvSubsampling.forward, parts/submodules/subsampling.py:385-436,725-759 - */
+int mi355x_subsample_conv1_fwd(const void* mel /*f32 [B,F,T]*/, const void* w /*[C,1,3,3]*/, const void* bias,
+                               void* out /*[B,T1,F1,C]*/, int out_dtype, const void* len0, const void* len1, int B, int F,
+                               int T, int C, void* stream);
+int mi355x_subsample_conv1_bwd(const void* dout, int dtype, const void* mel, const void* len0, void* dw, void* db, int B,
+                               int F, int T, int C, void* stream);
+int mi355x_im2col_3x3s2(const void* in /*[B,T1,F1,C]*/, void* col /*[B*T2*F2, 9C]*/, int dtype, int B, int T1, int F1, int C,
+                        void* stream);
+int mi355x_col2im_3x3s2_relu(const void* dcol, const void* act, void* din, int dtype, int B, int T1, int F1, int C,
+                             void* stream);
+
+/* ---- LayerNorm (torch.nn.LayerNorm x5 per layer, conformer_modules.py:174-215) -------------------------------- */
+int mi355x_layernorm_fwd(const void* x, int x_dtype, const void* gamma, const void* beta, void* y, int y_dtype, void* mean,
+                         void* rstd, int M, int d, float eps, void* stream);
+/* dres (f32 [M,d]) = (accumulate ? dres : 0) + dLN/dx ; dgamma/dbeta (f32 [d], may be NULL) are accumulated (+=)   */
+int mi355x_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const void* gamma, const void* mean,
+                         const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d, void* stream);
+/* out[n] += alpha * sum_m x[m,n]  (bias / pos_bias gradients) */
+int mi355x_colsum(const void* x, int x_dtype, long long ld, void* out, int M, int N, float alpha, void* stream);
+
+/* ---- decoder log-softmax: conv_asr.py:468 ---------------------------------------------------------------------- */
+int mi355x_log_softmax_fwd(const void* logits, long long ld_in, void* logp, long long ld_out, int M, int C, void* stream);
+int mi355x_log_softmax_bwd(const void* dlogp, const void* logp, long long ld, void* dlogits, int out_dtype, long long ld_out,
+                           int M, int C, float scale, void* stream);
+
+/* ---- Conformer block glue (conformer_modules.py:324-331; multi_head_attention.py:259-270,305-307,343-346,137-140) */
+int mi355x_glu_fwd(const void* in /*[M,2d]*/, void* out /*[M,d]*/, int dtype, const void* len, int T, long long M, int d,
+                   void* stream);
+int mi355x_glu_bwd(const void* in, const void* dout, void* din, int dtype, const void* len, int T, long long M, int d,
+                   void* stream);
+int mi355x_drop_scale_cast(const void* in, int in_dtype, void* out, int out_dtype, long long n, float alpha,
+                           unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream);
+int mi355x_qbias(const void* qkv, long long ldq, const void* u, const void* v, void* qu, void* qv, int dtype, long long M,
+                 int d, void* stream);
+int mi355x_add2(const void* a, const void* b, int in_dtype, void* out, int out_dtype, long long ldo, long long M, int d,
+                void* stream);
+/* ac f32 [H,B,T,Tp], bdf f32 [H,B,T,Pp] (bd before rel_shift) -> s (softmax, masked) and pd = dropout(s), pitch Tp   */
+int mi355x_relpos_softmax_fwd(const void* ac, const void* bdf, void* s_out, void* pd_out, int out_dtype, const void* len,
+                              int H, int B, int T, int Tp, int Pp, float scale, unsigned drop_key, unsigned drop_threshold,
+                              float drop_scale, void* stream);
+int mi355x_relpos_softmax_bwd(const void* dpd, int dpd_dtype, const void* s_in, void* dscore, void* dbdf, int s_dtype, int H,
+                              int B, int T, int Tp, int Pp, float scale, unsigned drop_key, unsigned drop_threshold,
+                              float drop_scale, void* stream);
+
+/* ---- convolution module: depthwise conv + BatchNorm + Swish (conformer_modules.py:333-342, causal_convs.py:130-147) */
+int mi355x_dwconv_fwd(const void* x, const void* w /*[d,1,k]*/, const void* bias, void* y, int dtype,
+                      void* stats /*f64 [2,d] += (sum, sumsq) or NULL*/, int B, int T, int d, int ksize, void* stream);
+int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dtype, int B, int T,
+                      int d, int ksize, void* stream);
+int mi355x_bn_finalize(const void* stats, double count, void* mean, void* rstd, void* running_mean, void* running_var,
+                       float momentum, float eps, int d, void* stream);
+int mi355x_bn_eval_stats(const void* running_mean, const void* running_var, void* mean, void* rstd, float eps, int d,
+                         void* stream);
+int mi355x_bn_swish_fwd(const void* x, const void* mean, const void* rstd, const void* gamma, const void* beta, void* y,
+                        int dtype, long long M, int d, void* stream);
+int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
+                               const void* beta, void* sums /*f64 [2,d] +=*/, int dtype, long long M, int d, void* stream);
+int mi355x_bn_swish_bwd_apply(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
+                              const void* beta, const void* sums, double count, int training, void* dx, int dtype,
+                              long long M, int d, void* stream);
+int mi355x_bn_param_grad(const void* sums, void* dgamma, void* dbeta, int d, void* stream);
+
+/* ---- CTC loss: CTCLoss.forward, losses/ctc.py:68-82 (torch ctc_loss, blank = V, zero_infinity) ------------------
+ * logp f32 [B,Tmax,C]; targets i64 [B,Umax]; workspaces f32 [B,Tmax,2*Umax+1] each; nll f32 [B];
+ * grad f32 [B,Tmax,C] = grad_scale * d(sum_b nll_b)/d logp  (may be NULL for loss only).                          */
+int mi355x_ctc_loss(const void* logp, const void* targets, const void* in_len, const void* tgt_len, void* alpha_ws,
+                    void* beta_ws, void* nll, void* grad, int B, int Tmax, int C, int Umax, int blank, float grad_scale,
+                    int zero_infinity, void* stream);
+
+/* ---- optimizer / weight packing (modelPT.py:650-823 AdamW; no reference analogue for packing) ------------------ */
+int mi355x_adamw_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, long long n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+typedef struct mi355x_pack_entry {
+  const void* src; void* dst;       /* src f32; dst[r*pitch + c] = src[r1*sr1 + r2*sr2 + c1*sc1 + c2*sc2]              */
+  int rows, cols, nr2, nc2;         /* r = r1*nr2 + r2 ; c = c1*nc2 + c2                                              */
+  long long sr1, sr2, sc1, sc2, pitch;
+  long long tile_begin;             /* exclusive prefix sum of ceil(rows/32)*ceil(cols/32)                            */
+} mi355x_pack_entry;
+int mi355x_pack_weights(const void* table_dev, int n_entries, long long total_tiles, int out_dtype, void* stream);
+int mi355x_fill_f32(void* p, long long n, float value, void* stream);
+
+/* library / build information */
+const char* mi355x_asr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_ASR_H */

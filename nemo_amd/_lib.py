@@ -1,0 +1,113 @@
+"""ctypes binding of libmi355x_asr.so (the C ABI declared in include/mi355x_asr.h).
+
+The library is the product: there is NO fallback.  If it is missing or an entry point is absent, importing
+this module raises, and every wrapper in `nemo_amd.ops` fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("MI355X_ASR_LIB", os.path.join(_HERE, "lib", "libmi355x_asr.so"))
+
+vp, i32, i64, f32, f64, u32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_uint
+
+
+class GemmDesc(C.Structure):
+    """mirror of `mi355x_gemm_desc` (include/mi355x_asr.h)"""
+    _fields_ = [
+        ("A", vp), ("B", vp), ("C", vp),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("lda", i64), ("ldb", i64), ("ldc", i64),
+        ("transA", i32), ("transB", i32),
+        ("in_dtype", i32), ("c_dtype", i32),
+        ("batch", i32), ("nb0", i32),
+        ("sA0", i64), ("sA1", i64), ("sB0", i64), ("sB1", i64), ("sC0", i64), ("sC1", i64),
+        ("bias", vp), ("alpha", f32),
+        ("epilogue", i32), ("atomic", i32), ("splitk", i32),
+        ("aux_in", vp), ("aux_in_dtype", i32),
+        ("aux_out", vp), ("aux_out_dtype", i32),
+        ("ldaux", i64),
+        ("drop_key", u32), ("drop_threshold", u32), ("drop_scale", f32),
+        ("row_len", vp), ("rows_per_b", i32), ("rows_inner", i32),
+    ]
+
+
+class PackEntry(C.Structure):
+    """mirror of `mi355x_pack_entry`"""
+    _fields_ = [
+        ("src", vp), ("dst", vp),
+        ("rows", i32), ("cols", i32), ("nr2", i32), ("nc2", i32),
+        ("sr1", i64), ("sr2", i64), ("sc1", i64), ("sc2", i64), ("pitch", i64),
+        ("tile_begin", i64),
+    ]
+
+
+# name -> argtypes (return type is always int, except the version string)
+SIGNATURES = {
+    "mi355x_gemm": [C.POINTER(GemmDesc), vp],
+    "mi355x_logmel_fwd": [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, f32, u32, f32, vp, i32, i32, i32, vp],
+    "mi355x_feat_normalize": [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp],
+    "mi355x_subsample_conv1_fwd": [vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "mi355x_subsample_conv1_bwd": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mi355x_im2col_3x3s2": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "mi355x_col2im_3x3s2_relu": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mi355x_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp],
+    "mi355x_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp],
+    "mi355x_colsum": [vp, i32, i64, vp, i32, i32, f32, vp],
+    "mi355x_log_softmax_fwd": [vp, i64, vp, i64, i32, i32, vp],
+    "mi355x_log_softmax_bwd": [vp, vp, i64, vp, i32, i64, i32, i32, f32, vp],
+    "mi355x_glu_fwd": [vp, vp, i32, vp, i32, i64, i32, vp],
+    "mi355x_glu_bwd": [vp, vp, vp, i32, vp, i32, i64, i32, vp],
+    "mi355x_drop_scale_cast": [vp, i32, vp, i32, i64, f32, u32, u32, f32, vp],
+    "mi355x_qbias": [vp, i64, vp, vp, vp, vp, i32, i64, i32, vp],
+    "mi355x_add2": [vp, vp, i32, vp, i32, i64, i64, i32, vp],
+    "mi355x_relpos_softmax_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
+    "mi355x_relpos_softmax_bwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
+    "mi355x_dwconv_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp],
+    "mi355x_dwconv_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mi355x_bn_finalize": [vp, f64, vp, vp, vp, vp, f32, f32, i32, vp],
+    "mi355x_bn_eval_stats": [vp, vp, vp, vp, f32, i32, vp],
+    "mi355x_bn_swish_fwd": [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
+    "mi355x_bn_swish_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
+    "mi355x_bn_swish_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, f64, i32, vp, i32, i64, i32, vp],
+    "mi355x_bn_param_grad": [vp, vp, vp, i32, vp],
+    "mi355x_ctc_loss": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
+    "mi355x_adamw_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
+    "mi355x_pack_weights": [vp, i32, i64, i32, vp],
+    "mi355x_fill_f32": [vp, i64, f32, vp],
+}
+
+EXPORTED_SYMBOLS = sorted(list(SIGNATURES) + ["mi355x_asr_version"])
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m nemo_amd.build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU / PyTorch fallback for the MI355X kernels.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
+        fn.argtypes = argtypes
+        fn.restype = i32
+    lib.mi355x_asr_version.restype = C.c_char_p
+    lib.mi355x_asr_version.argtypes = []
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = ""):
+    """0 ok; 1 -> ValueError (the reference's convention for bad shapes/args); 2 -> RuntimeError."""
+    if rc == 0:
+        return
+    if rc == 1:
+        raise ValueError(f"libmi355x_asr: invalid argument in {what}")
+    raise RuntimeError(f"libmi355x_asr: kernel launch failed in {what} (rc={rc})")
+
+
+def version() -> str:
+    return lib.mi355x_asr_version().decode()

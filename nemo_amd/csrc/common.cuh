@@ -1,0 +1,122 @@
+// Shared device helpers for the MI355X (gfx950 / CDNA4) Conformer-CTC kernels.
+// wave = 64 lanes everywhere; no CUDA-compat paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MI_OK 0
+#define MI_ERR_ARG 1
+#define MI_ERR_LAUNCH 2
+
+#define MI_DT_F32 0
+#define MI_DT_BF16 1
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+static inline int mi_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MI_OK : MI_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- bf16 <-> f32
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// typed load/store helpers (T = float or bf16_t)
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 4-wide vector access (16 B for f32, 8 B for bf16); pointers must be aligned accordingly
+template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&v)[4]) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+  uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+}
+
+// ---------------------------------------------------------------- wave / block reductions (wave64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum; `red` = __shared__ float[>= blockDim.x/64]; result broadcast to all threads
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// ---------------------------------------------------------------- activations
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float swish_grad(float x) {  // d/dx x*sigmoid(x)
+  float s = sigmoidf_(x);
+  return s * (1.f + x * (1.f - s));
+}
+
+// ---------------------------------------------------------------- counter-based dropout RNG
+// keep(idx) is a pure function of (seed, site, element index): forward epilogues and backward kernels
+// regenerate the identical mask, nothing is stored.  2-round 32-bit avalanche hash ("lowbias32" finaliser);
+// dropout needs decorrelation, not crypto quality, and Philox4x32-10 per element would cost as much VALU
+// time as the FFN GEMM it is fused into.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+struct DropCfg {
+  uint32_t key;        // mix of (seed, site)
+  uint32_t threshold;  // keep iff hash >= threshold ; threshold = p * 2^32 ; 0 => dropout off
+  float scale;         // 1/(1-p)
+};
+__device__ __forceinline__ float drop_mask(const DropCfg& d, uint32_t idx) {
+  if (d.threshold == 0u) return 1.f;
+  uint32_t h = mix32(mix32(idx ^ d.key) + 0x9E3779B9u * (d.key | 1u));
+  return h >= d.threshold ? d.scale : 0.f;
+}
+// standard normal from a counter (Box-Muller on two hashed uniforms) -- dither noise in the mel front-end
+__device__ __forceinline__ float hash_normal(uint32_t key, uint32_t idx) {
+  uint32_t a = mix32(mix32(idx ^ key) + 0x9E3779B9u);
+  uint32_t b = mix32(a ^ 0x85ebca6bU ^ (key * 0xc2b2ae35U));
+  float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777217.0f);  // (0,1)
+  float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+  return sqrtf(-2.f * __logf(u1)) * __cosf(6.28318530718f * u2);
+}

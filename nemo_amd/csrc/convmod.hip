@@ -1,0 +1,319 @@
+// Conformer convolution module, memory-bound part: depthwise Conv1d(k) along time on the [B,T,d] (channels-last)
+// activation layout + training-mode BatchNorm1d statistics, BN-apply + Swish, and their backward passes.
+//
+// Replaces on the reference path (nemo/collections/asr/parts/submodules/conformer_modules.py:333-342):
+//   CausalConv1D(d, d, k=31, groups=d, padding 15/15) (causal_convs.py:130-147) -> nn.BatchNorm1d -> Swish
+// BN statistics are taken over all B*T positions (padded frames included) exactly as torch BatchNorm1d does on the
+// reference's [B,d,T] tensor; sums are accumulated in f64 so SyncBN (all-reduce of the raw sums) is exact.
+#include "common.cuh"
+#include "mi355x_asr.h"
+
+#define DISPATCH_DT(dt, T, ...)                                      \
+  if ((dt) == MI_DT_F32) { typedef float T; __VA_ARGS__; }           \
+  else { typedef bf16_t T; __VA_ARGS__; }
+
+#define DW_CH 64     // channels per block
+#define DW_TT 64     // time steps per tile
+#define DW_TQ 16     // outputs per thread (4 time groups x 16)
+#define DW_MAXK 31
+
+__device__ __forceinline__ float round_as(float v, float) { return v; }
+__device__ __forceinline__ float round_as(float v, bf16_t) { return bf2f(f2bf(v)); }
+
+// ------------------------------------------------------------------------------------------------ forward
+// x [B,T,d] -> y[b,t,c] = bias[c] + sum_k w[c,k] * x[b, t+k-pad, c]  (zero outside [0,T));  stats[0][c] += sum y, stats[1][c] += sum y^2
+template <typename TT, int KS>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const TT* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, TT* __restrict__ y,
+                                                         double* __restrict__ stats, int B, int T, int d) {
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int ROWS = DW_TT + KS - 1;
+  __shared__ float tile[ROWS][DW_CH];
+  __shared__ float red[2][4][DW_CH];
+  const int c_l = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int c = blockIdx.x * DW_CH + c_l;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.y * DW_TT;
+  const bool cv = c < d;
+  // stage rows t0-PAD .. t0+DW_TT+PAD-1
+  for (int r = tg; r < ROWS; r += 4) {
+    const int t = t0 - PAD + r;
+    float v = 0.f;
+    if (cv && t >= 0 && t < T) v = ld(x + ((long long)b * T + t) * d + c);
+    tile[r][c_l] = v;
+  }
+  float wk[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) wk[k] = cv ? w[c * KS + k] : 0.f;
+  const float bs = (cv && bias) ? bias[c] : 0.f;
+  __syncthreads();
+  float in[DW_TQ + KS - 1];
+#pragma unroll
+  for (int i = 0; i < DW_TQ + KS - 1; ++i) in[i] = tile[tg * DW_TQ + i][c_l];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int o = 0; o < DW_TQ; ++o) {
+    float a = bs;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) a = fmaf(wk[k], in[o + k], a);
+    const int t = t0 + tg * DW_TQ + o;
+    if (cv && t < T) {
+      st(y + ((long long)b * T + t) * d + c, a);
+      const float ar = round_as(a, TT());
+      s1 += ar; s2 += ar * ar;
+    }
+  }
+  if (stats) {
+    red[0][tg][c_l] = s1; red[1][tg][c_l] = s2;
+    __syncthreads();
+    if (tg == 0 && cv) {
+      atomicAdd(stats + c, (double)((red[0][0][c_l] + red[0][1][c_l]) + (red[0][2][c_l] + red[0][3][c_l])));
+      atomicAdd(stats + d + c, (double)((red[1][0][c_l] + red[1][1][c_l]) + (red[1][2][c_l] + red[1][3][c_l])));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// dy [B,T,d], x [B,T,d]:  dx[t] = sum_k w[k] * dy[t + pad - k] ;  dw[c,k] += sum_{b,t} dy[t] * x[t+k-pad] ; dbias[c] += sum dy
+// grid (d/64, B): one block walks all time tiles of its (batch, channel chunk) so the atomics are 1 per (c,k) per block.
+template <typename TT, int KS>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
+                                                         const float* __restrict__ w, TT* __restrict__ dx,
+                                                         float* __restrict__ dw, float* __restrict__ dbias, int B, int T, int d) {
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int ROWS = DW_TT + KS - 1;
+  __shared__ float tdy[ROWS][DW_CH];
+  __shared__ float tx[ROWS][DW_CH];
+  __shared__ float red[4][DW_CH];
+  const int c_l = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int c = blockIdx.x * DW_CH + c_l;
+  const int b = blockIdx.y;
+  const bool cv = c < d;
+  float wk[KS], gw[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) { wk[k] = cv ? w[c * KS + k] : 0.f; gw[k] = 0.f; }
+  float gb = 0.f;
+  for (int t0 = 0; t0 < T; t0 += DW_TT) {
+    __syncthreads();
+    for (int r = tg; r < ROWS; r += 4) {
+      const int t = t0 - PAD + r;
+      float a = 0.f, e = 0.f;
+      if (cv && t >= 0 && t < T) {
+        const long long o = ((long long)b * T + t) * d + c;
+        a = ld(dy + o); e = ld(x + o);
+      }
+      tdy[r][c_l] = a; tx[r][c_l] = e;
+    }
+    __syncthreads();
+    float vdy[DW_TQ + KS - 1], vx[DW_TQ + KS - 1];
+#pragma unroll
+    for (int i = 0; i < DW_TQ + KS - 1; ++i) { vdy[i] = tdy[tg * DW_TQ + i][c_l]; vx[i] = tx[tg * DW_TQ + i][c_l]; }
+#pragma unroll
+    for (int o = 0; o < DW_TQ; ++o) {
+      // local index of time t is (t - t0 + PAD) = tg*16 + o + PAD  -> vdy[o + PAD] ; dy[t + PAD - k] -> vdy[o + 2*PAD - k]
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) a = fmaf(wk[k], vdy[o + 2 * PAD - k], a);
+      const int t = t0 + tg * DW_TQ + o;
+      if (cv && t < T) st(dx + ((long long)b * T + t) * d + c, a);
+      const float g = vdy[o + PAD];  // zero when t >= T (staging zero-fills)
+      gb += g;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) gw[k] = fmaf(g, vx[o + k], gw[k]);
+    }
+  }
+  // reduce the 4 time groups, one atomic per (c,k) per block
+#pragma unroll
+  for (int k = 0; k <= KS; ++k) {
+    __syncthreads();
+    red[tg][c_l] = (k < KS) ? gw[k < KS ? k : 0] : gb;
+    __syncthreads();
+    if (tg == 0 && cv) {
+      const float v = (red[0][c_l] + red[1][c_l]) + (red[2][c_l] + red[3][c_l]);
+      if (k < KS) atomicAdd(dw + c * KS + k, v);
+      else if (dbias) atomicAdd(dbias + c, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm
+// stats (f64 [2][d]: sum, sum of squares over `count` positions) -> mean, rstd (biased var), running stats update
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, float* __restrict__ mean,
+                                   float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, float eps, int d) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  const double mu = stats[c] / count;
+  double var = stats[d + c] / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+  if (running_var) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+// eval-mode helper: rstd = 1/sqrt(running_var + eps), mean = running_mean
+__global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                     float* __restrict__ mean, float* __restrict__ rstd, float eps, int d) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  mean[c] = running_mean[c];
+  rstd[c] = rsqrtf(running_var[c] + eps);
+}
+
+// y = swish(gamma * (x - mean) * rstd + beta)
+template <typename TT>
+__global__ __launch_bounds__(256) void bn_swish_fwd_kernel(const TT* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, TT* __restrict__ y, long long M, int d) {
+  const long long nv = M * (d >> 2);
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+    const long long m = i / (d >> 2);
+    const int c = (int)(i - m * (d >> 2)) * 4;
+    float v[4], mu[4], rs[4], g[4], b[4], o[4];
+    ld4(x + m * d + c, v); ld4(mean + c, mu); ld4(rstd + c, rs); ld4(gamma + c, g); ld4(beta + c, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = swishf_(g[j] * (v[j] - mu[j]) * rs[j] + b[j]);
+    st4(y + m * d + c, o);
+  }
+}
+// backward phase 1: sums[0][c] += sum dz, sums[1][c] += sum dz*xhat  with dz = dy * swish'(z)
+template <typename TT>
+__global__ __launch_bounds__(256) void bn_swish_bwd_reduce_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  double* __restrict__ sums, long long M, int d) {
+  __shared__ float sa[4][64], sb[4][64];
+  const int c_l = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + c_l;
+  const long long r0 = (long long)blockIdx.y * 256, r1 = min(M, r0 + 256);
+  float a1 = 0.f, a2 = 0.f;
+  if (c < d) {
+    const float mu = mean[c], rs = rstd[c], g = gamma[c], bt = beta[c];
+    for (long long r = r0 + rl; r < r1; r += 4) {
+      const float xh = (ld(x + r * d + c) - mu) * rs;
+      const float dz = ld(dy + r * d + c) * swish_grad(g * xh + bt);
+      a1 += dz; a2 += dz * xh;
+    }
+  }
+  sa[rl][c_l] = a1; sb[rl][c_l] = a2;
+  __syncthreads();
+  if (rl == 0 && c < d) {
+    atomicAdd(sums + c, (double)((sa[0][c_l] + sa[1][c_l]) + (sa[2][c_l] + sa[3][c_l])));
+    atomicAdd(sums + d + c, (double)((sb[0][c_l] + sb[1][c_l]) + (sb[2][c_l] + sb[3][c_l])));
+  }
+}
+// backward phase 2: dx = gamma*rstd*(dz - [training] (S1/n + xhat*S2/n)) ; S = global sums (all ranks), n = global count
+template <typename TT>
+__global__ __launch_bounds__(256) void bn_swish_bwd_apply_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const double* __restrict__ sums, double count, int training,
+                                                                 TT* __restrict__ dx, long long M, int d) {
+  const long long nv = M * (d >> 2);
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+    const long long m = i / (d >> 2);
+    const int c = (int)(i - m * (d >> 2)) * 4;
+    float v[4], e[4], mu[4], rs[4], g[4], b[4], o[4];
+    ld4(x + m * d + c, v); ld4(dy + m * d + c, e); ld4(mean + c, mu); ld4(rstd + c, rs); ld4(gamma + c, g); ld4(beta + c, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (v[j] - mu[j]) * rs[j];
+      float dz = e[j] * swish_grad(g[j] * xh + b[j]);
+      if (training) dz -= (float)(sums[c + j] / count) + xh * (float)(sums[d + c + j] / count);
+      o[j] = g[j] * rs[j] * dz;
+    }
+    st4(dx + m * d + c, o);
+  }
+}
+// dgamma += S2_local, dbeta += S1_local  (local sums: DDP averages parameter grads afterwards)
+__global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int d) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  dbeta[c] += (float)sums[c];
+  dgamma[c] += (float)sums[d + c];
+}
+
+// =================================================================================================
+static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+
+extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias, void* y, int dt, void* stats, int B, int T,
+                                 int d, int ksize, void* stream) {
+  if (!x || !w || !y || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
+  dim3 grid((d + DW_CH - 1) / DW_CH, (T + DW_TT - 1) / DW_TT, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DW_FWD(KS) DISPATCH_DT(dt, TT, hipLaunchKernelGGL((dwconv_fwd_kernel<TT, KS>), grid, block, 0, s, (const TT*)x, \
+    (const float*)w, (const float*)bias, (TT*)y, (double*)stats, B, T, d))
+  switch (ksize) {
+    case 31: DW_FWD(31); break;
+    case 9: DW_FWD(9); break;
+    case 5: DW_FWD(5); break;
+    default: return MI_ERR_ARG;
+  }
+  return mi_check_launch();
+}
+extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dt, int B,
+                                 int T, int d, int ksize, void* stream) {
+  if (!dy || !x || !w || !dx || !dw || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
+  dim3 grid((d + DW_CH - 1) / DW_CH, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DW_BWD(KS) DISPATCH_DT(dt, TT, hipLaunchKernelGGL((dwconv_bwd_kernel<TT, KS>), grid, block, 0, s, (const TT*)dy, \
+    (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, B, T, d))
+  switch (ksize) {
+    case 31: DW_BWD(31); break;
+    case 9: DW_BWD(9); break;
+    case 5: DW_BWD(5); break;
+    default: return MI_ERR_ARG;
+  }
+  return mi_check_launch();
+}
+extern "C" int mi355x_bn_finalize(const void* stats, double count, void* mean, void* rstd, void* running_mean,
+                                  void* running_var, float momentum, float eps, int d, void* stream) {
+  if (!stats || !mean || !rstd || d <= 0 || count <= 0) return MI_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)stats, count,
+                     (float*)mean, (float*)rstd, (float*)running_mean, (float*)running_var, momentum, eps, d);
+  return mi_check_launch();
+}
+extern "C" int mi355x_bn_eval_stats(const void* running_mean, const void* running_var, void* mean, void* rstd, float eps, int d,
+                                    void* stream) {
+  if (!running_mean || !running_var || !mean || !rstd || d <= 0) return MI_ERR_ARG;
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)running_mean,
+                     (const float*)running_var, (float*)mean, (float*)rstd, eps, d);
+  return mi_check_launch();
+}
+extern "C" int mi355x_bn_swish_fwd(const void* x, const void* mean, const void* rstd, const void* gamma, const void* beta, void* y,
+                                   int dt, long long M, int d, void* stream) {
+  if (!x || !mean || !rstd || !gamma || !beta || !y || M <= 0 || (d & 3)) return MI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_fwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)x,
+                                         (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta, (TT*)y, M, d));
+  return mi_check_launch();
+}
+extern "C" int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
+                                          const void* beta, void* sums, int dt, long long M, int d, void* stream) {
+  if (!dy || !x || !sums || M <= 0 || d <= 0) return MI_ERR_ARG;
+  dim3 grid((d + 63) / 64, (unsigned)((M + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_bwd_reduce_kernel<TT>), grid, block, 0, s, (const TT*)dy, (const TT*)x,
+                                         (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta,
+                                         (double*)sums, M, d));
+  return mi_check_launch();
+}
+extern "C" int mi355x_bn_swish_bwd_apply(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
+                                         const void* beta, const void* sums, double count, int training, void* dx, int dt,
+                                         long long M, int d, void* stream) {
+  if (!dy || !x || !sums || !dx || M <= 0 || (d & 3) || count <= 0) return MI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_bwd_apply_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s,
+                                         (const TT*)dy, (const TT*)x, (const float*)mean, (const float*)rstd, (const float*)gamma,
+                                         (const float*)beta, (const double*)sums, count, training, (TT*)dx, M, d));
+  return mi_check_launch();
+}
+extern "C" int mi355x_bn_param_grad(const void* sums, void* dgamma, void* dbeta, int d, void* stream) {
+  if (!sums || !dgamma || !dbeta || d <= 0) return MI_ERR_ARG;
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)sums,
+                     (float*)dgamma, (float*)dbeta, d);
+  return mi_check_launch();
+}

@@ -1,0 +1,132 @@
+// CTC loss + gradient w.r.t. log-probabilities, one workgroup per utterance.
+//   phase 1: alpha (waves 0-1) and beta (waves 2-3) recursions run CONCURRENTLY in log space over the blank-extended
+//            label sequence (S = 2U+1 states, previous time-step row double-buffered in LDS, one barrier per step);
+//            full lattices are written to a workspace [B, T, S] each.
+//   phase 2: grad[t,c] = -exp(alpha+beta - logp + nll) summed over the states carrying class c, scaled by grad_scale
+//            (1/B for 'mean_batch'); one wave per time-step, per-wave class accumulators in LDS (ds_add_f32).
+// zero_infinity: an infeasible utterance gets loss 0 and zero gradient.
+//
+// Replaces on the reference path: torch.nn.functional.ctc_loss forward+backward called by
+//   nemo/collections/asr/losses/ctc.py:68-82 (CTCLoss(blank=V, reduction='none', zero_infinity=True) + mean_batch).
+#include "common.cuh"
+#include "mi355x_asr.h"
+
+#define NEGINF (-INFINITY)
+
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  const float m = fmaxf(a, fmaxf(b, c));
+  if (m == NEGINF) return NEGINF;
+  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+// logp [B, Tmax, C] f32 ; targets [B, Umax] i64 ; alpha/beta workspaces [B, Tmax, Smax]; grad [B, Tmax, C]
+__global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logp, const long long* __restrict__ targets,
+                                                  const long long* __restrict__ in_len, const long long* __restrict__ tgt_len,
+                                                  float* __restrict__ alpha_ws, float* __restrict__ beta_ws,
+                                                  float* __restrict__ nll_out, float* __restrict__ grad, int Tmax, int C,
+                                                  int Umax, int Smax, int blank, float grad_scale, int zero_infinity) {
+  extern __shared__ float sm[];
+  int* ext = (int*)sm;                 // [Smax]
+  float* prev_a = sm + Smax;           // [2][Smax]
+  float* prev_b = prev_a + 2 * Smax;   // [2][Smax]
+  float* acc = prev_b + 2 * Smax;      // [4][C]
+  __shared__ float s_nll;
+
+  const int b = blockIdx.x;
+  const int T = (int)min((long long)Tmax, in_len[b]);
+  const int U = (int)min((long long)Umax, tgt_len[b]);
+  const int S = 2 * U + 1;
+  const float* lp = logp + (long long)b * Tmax * C;
+  float* aw = alpha_ws + (long long)b * Tmax * Smax;
+  float* bw = beta_ws + (long long)b * Tmax * Smax;
+  float* g = grad ? grad + (long long)b * Tmax * C : nullptr;
+  const int tid = threadIdx.x;
+
+  for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? (int)targets[(long long)b * Umax + (s >> 1)] : blank;
+  // zero the gradient rows up front (frames >= T stay zero)
+  if (g) for (int i = tid; i < Tmax * C; i += 256) g[i] = 0.f;
+  __syncthreads();
+
+  if (T <= 0) {  // empty input: feasible only for an empty target
+    if (tid == 0) nll_out[b] = (U == 0) ? 0.f : (zero_infinity ? 0.f : INFINITY);
+    return;
+  }
+
+  // ---------------- phase 1: alpha on threads [0,128), beta on threads [128,256)
+  const bool is_beta = tid >= 128;
+  const int ht = tid & 127;
+  float* prev = is_beta ? prev_b : prev_a;
+  float* ws = is_beta ? bw : aw;
+  for (int step = 0; step < T; ++step) {
+    const int t = is_beta ? (T - 1 - step) : step;
+    float* cur = prev + ((step & 1) ? Smax : 0);
+    const float* old = prev + ((step & 1) ? 0 : Smax);
+    for (int s = ht; s < S; s += 128) {
+      float v;
+      const int cls = ext[s];
+      if (step == 0) {
+        if (!is_beta) v = (s < 2) ? lp[cls] : NEGINF;
+        else v = (s >= S - 2) ? lp[(long long)t * C + cls] : NEGINF;
+      } else {
+        float a = old[s], bb, c = NEGINF;
+        if (!is_beta) {
+          bb = (s >= 1) ? old[s - 1] : NEGINF;
+          if (s >= 2 && cls != blank && cls != ext[s - 2]) c = old[s - 2];
+        } else {
+          bb = (s + 1 < S) ? old[s + 1] : NEGINF;
+          if (s + 2 < S && cls != blank && cls != ext[s + 2]) c = old[s + 2];
+        }
+        const float m = lse3(a, bb, c);
+        v = (m == NEGINF) ? NEGINF : m + lp[(long long)t * C + cls];
+      }
+      cur[s] = v;
+      ws[(long long)t * Smax + s] = v;
+    }
+    __syncthreads();
+  }
+  // log-likelihood from the last alpha row (= row (T-1)&1 of prev_a)
+  if (tid == 0) {
+    const float* last = prev_a + (((T - 1) & 1) ? Smax : 0);
+    const float l1 = last[S - 1], l2 = (S > 1) ? last[S - 2] : NEGINF;
+    const float m = fmaxf(l1, l2);
+    float ll = (m == NEGINF) ? NEGINF : m + logf(expf(l1 - m) + expf(l2 - m));
+    s_nll = -ll;
+    float out = -ll;
+    if (out == INFINITY && zero_infinity) out = 0.f;
+    nll_out[b] = out;
+  }
+  __syncthreads();
+  const float nll = s_nll;
+  if (!g || nll == INFINITY) return;  // infeasible: zero gradient (zero_infinity) -- rows already zeroed
+
+  // ---------------- phase 2: gradient rows, one wave per time-step
+  const int wave = tid >> 6, lane = tid & 63;
+  float* wacc = acc + wave * C;
+  for (int t = wave; t < T; t += 4) {
+    for (int c = lane; c < C; c += 64) wacc[c] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS zeroing visible before the adds of this wave
+    for (int s = lane; s < S; s += 64) {
+      const float ab = aw[(long long)t * Smax + s] + bw[(long long)t * Smax + s];
+      if (ab != NEGINF) {
+        const int cls = ext[s];
+        atomicAdd(&wacc[cls], expf(ab - lp[(long long)t * C + cls] + nll));
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for (int c = lane; c < C; c += 64) g[(long long)t * C + c] = -grad_scale * wacc[c];
+  }
+}
+
+extern "C" int mi355x_ctc_loss(const void* logp, const void* targets, const void* in_len, const void* tgt_len, void* alpha_ws,
+                               void* beta_ws, void* nll, void* grad, int B, int Tmax, int C, int Umax, int blank,
+                               float grad_scale, int zero_infinity, void* stream) {
+  if (!logp || !targets || !in_len || !tgt_len || !alpha_ws || !beta_ws || !nll) return MI_ERR_ARG;
+  if (B <= 0 || Tmax <= 0 || C <= 0 || Umax < 0 || blank < 0 || blank >= C) return MI_ERR_ARG;
+  const int Smax = 2 * Umax + 1;
+  const size_t shm = sizeof(float) * ((size_t)Smax * 5 + 4 * (size_t)C);
+  if (shm > 60 * 1024) return MI_ERR_ARG;
+  hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(256), shm, (hipStream_t)stream, (const float*)logp, (const long long*)targets,
+                     (const long long*)in_len, (const long long*)tgt_len, (float*)alpha_ws, (float*)beta_ws, (float*)nll,
+                     (float*)grad, Tmax, C, Umax, Smax, blank, grad_scale, zero_infinity);
+  return mi_check_launch();
+}

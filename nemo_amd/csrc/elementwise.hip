@@ -1,0 +1,266 @@
+// HBM-bound glue kernels of the Conformer block (all vectorised 4-wide, wave64 shuffle reductions):
+//   GLU(+pad mask), dropout-scale-cast, (q+u | q+v) bias broadcast, rel-pos score assembly + masked softmax (+dropout)
+//   and its backward (including the "un-skew" of the rel_shift), small add kernels.
+//
+// Replaces on the reference path:
+//   nn.functional.glu + masked_fill            conformer_modules.py:324-331
+//   nn.Dropout on branch outputs               conformer_modules.py:177,192,207,212  (mask regenerated, never stored)
+//   q + pos_bias_u / q + pos_bias_v            multi_head_attention.py:305-307
+//   rel_shift + (ac+bd)/sqrt(dk) + masked softmax + dropout     multi_head_attention.py:259-270,343-346,137-140
+#include "common.cuh"
+#include "mi355x_asr.h"
+
+#define DISPATCH_DT(dt, T, ...)                                      \
+  if ((dt) == MI_DT_F32) { typedef float T; __VA_ARGS__; }           \
+  else { typedef bf16_t T; __VA_ARGS__; }
+
+// ------------------------------------------------------------------------------------------------ GLU
+// in [M, 2d] -> out [M, d] = a * sigmoid(b) * (t < len[b]);  rows m = b*T + t
+template <typename T>
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                      const long long* __restrict__ len, int Tt, long long M, int d) {
+  const long long nv = M * (d >> 2);
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+    const long long m = i / (d >> 2);
+    const int c = (int)(i - m * (d >> 2)) * 4;
+    const int b = (int)(m / Tt), t = (int)(m - (long long)b * Tt);
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!len || t < len[b]) {
+      float a[4], g[4];
+      ld4(in + m * 2 * d + c, a); ld4(in + m * 2 * d + d + c, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = a[j] * sigmoidf_(g[j]);
+    }
+    st4(out + m * d + c, o);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ in, const T* __restrict__ dout, T* __restrict__ din,
+                                                      const long long* __restrict__ len, int Tt, long long M, int d) {
+  const long long nv = M * (d >> 2);
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+    const long long m = i / (d >> 2);
+    const int c = (int)(i - m * (d >> 2)) * 4;
+    const int b = (int)(m / Tt), t = (int)(m - (long long)b * Tt);
+    float da[4] = {0.f, 0.f, 0.f, 0.f}, dg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!len || t < len[b]) {
+      float a[4], g[4], e[4];
+      ld4(in + m * 2 * d + c, a); ld4(in + m * 2 * d + d + c, g); ld4(dout + m * d + c, e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = sigmoidf_(g[j]);
+        da[j] = e[j] * s;
+        dg[j] = e[j] * a[j] * s * (1.f - s);
+      }
+    }
+    st4(din + m * 2 * d + c, da); st4(din + m * 2 * d + d + c, dg);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dropout-scale-cast
+// out[m,n] = alpha * dropmask(m*N+n) * in[m,n]     (in f32 [M,N] dense, out T dense)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void drop_scale_cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long long n4,
+                                                              float alpha, DropCfg drop) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float v[4];
+    ld4(in + i * 4, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= alpha * drop_mask(drop, (uint32_t)(i * 4 + j));
+    st4(out + i * 4, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ q + u, q + v
+// qkv [M, ldq] (q in the first d columns) ; u, v f32 [d] ; qu, qv [M, d]
+template <typename T>
+__global__ __launch_bounds__(256) void qbias_kernel(const T* __restrict__ qkv, long long ldq, const float* __restrict__ u,
+                                                    const float* __restrict__ v, T* __restrict__ qu, T* __restrict__ qv,
+                                                    long long M, int d) {
+  const long long nv = M * (d >> 2);
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+    const long long m = i / (d >> 2);
+    const int c = (int)(i - m * (d >> 2)) * 4;
+    float q[4], a[4], b[4], o1[4], o2[4];
+    ld4(qkv + m * ldq + c, q); ld4(u + c, a); ld4(v + c, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o1[j] = q[j] + a[j]; o2[j] = q[j] + b[j]; }
+    st4(qu + m * d + c, o1); st4(qv + m * d + c, o2);
+  }
+}
+// out[m, 0:d] (pitch ldo) = a[m,:] + b[m,:]
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void add2_kernel(const TI* __restrict__ a, const TI* __restrict__ b, TO* __restrict__ out,
+                                                   long long ldo, long long M, int d) {
+  const long long nv = M * (d >> 2);
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+    const long long m = i / (d >> 2);
+    const int c = (int)(i - m * (d >> 2)) * 4;
+    float x[4], y[4];
+    ld4(a + m * d + c, x); ld4(b + m * d + c, y);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] += y[j];
+    st4(out + m * ldo + c, x);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ rel-pos softmax
+// One wave per score row (h, b, i).  ac [H,B,T,Tp] f32, bdf [H,B,T,Pp] f32 (bd_full before rel_shift),
+//   score[j] = (ac[j] + bdf[T-1+j-i]) * scale ; masked (i or j beyond len[b]) -> -10000 ; softmax ; masked -> 0
+// s (pre-dropout, kept for backward) and pd = dropout(s) are written with pitch Tp, pad columns zeroed.
+#define SM_MAXV 16  // supports T <= 64*16 = 1024 frames after subsampling (40 s of audio)
+template <typename TO>
+__global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __restrict__ ac, const float* __restrict__ bdf,
+                                                                 TO* __restrict__ s_out, TO* __restrict__ pd_out,
+                                                                 const long long* __restrict__ len, int H, int B, int T, int Tp,
+                                                                 int Pp, float scale, DropCfg drop) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (row >= (long long)H * B * T) return;
+  const int i = (int)(row % T);
+  const int b = (int)((row / T) % B);
+  const int L = (int)min((long long)T, len[b]);
+  const float* acr = ac + row * Tp;
+  const float* bdr = bdf + row * Pp + (T - 1 - i);
+  const bool row_valid = i < L;
+  float v[SM_MAXV];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < SM_MAXV; ++k) {
+    const int j = lane + k * 64;
+    float sc = -INFINITY;
+    if (j < T) sc = (row_valid && j < L) ? (acr[j] + bdr[j]) * scale : -10000.f;
+    v[k] = sc;
+    mx = fmaxf(mx, sc);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < SM_MAXV; ++k) {
+    const int j = lane + k * 64;
+    float e = (j < T) ? __expf(v[k] - mx) : 0.f;
+    v[k] = e;
+    sum += e;
+  }
+  const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+  for (int k = 0; k < SM_MAXV; ++k) {
+    const int j = lane + k * 64;
+    if (j < Tp) {
+      float p = (j < T && row_valid && j < L) ? v[k] * inv : 0.f;
+      st(s_out + row * Tp + j, p);
+      if (pd_out) st(pd_out + row * Tp + j, p * drop_mask(drop, (uint32_t)(row * Tp + j)));
+    }
+  }
+}
+
+// backward: dpd [H,B,T,Tp] (d loss / d dropout(s)), s -> dscore [H,B,T,Tp] (= d ac) and dbdf [H,B,T,Pp] (un-skewed d bd)
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const TD* __restrict__ dpd, const TS* __restrict__ s_in,
+                                                                 TS* __restrict__ dscore, TS* __restrict__ dbdf, int H, int B,
+                                                                 int T, int Tp, int Pp, float scale, DropCfg drop) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (row >= (long long)H * B * T) return;
+  const int i = (int)(row % T);
+  float sv[SM_MAXV], dp[SM_MAXV];
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < SM_MAXV; ++k) {
+    const int j = lane + k * 64;
+    float s = 0.f, g = 0.f;
+    if (j < T) {
+      s = ld(s_in + row * Tp + j);
+      g = ld(dpd + row * Tp + j) * drop_mask(drop, (uint32_t)(row * Tp + j));
+    }
+    sv[k] = s; dp[k] = g;
+    dot += s * g;
+  }
+  dot = wave_sum(dot);
+  // zero the un-skewed row first (only T of its Pp entries are non-zero: c in [T-1-i, 2T-2-i])
+  TS* dbr = dbdf + row * Pp;
+  const int c_lo = T - 1 - i;
+  for (int c = lane; c < Pp; c += 64)
+    if (c < c_lo || c >= c_lo + T) st(dbr + c, 0.f);
+#pragma unroll
+  for (int k = 0; k < SM_MAXV; ++k) {
+    const int j = lane + k * 64;
+    if (j < Tp) {
+      const float ds = (j < T) ? sv[k] * (dp[k] - dot) * scale : 0.f;
+      st(dscore + row * Tp + j, ds);
+      if (j < T) st(dbr + c_lo + j, ds);
+    }
+  }
+}
+
+// =================================================================================================
+static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+
+extern "C" int mi355x_glu_fwd(const void* in, void* out, int dt, const void* len, int T, long long M, int d, void* stream) {
+  if (!in || !out || M <= 0 || d <= 0 || (d & 3) || T <= 0) return MI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((glu_fwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)in,
+                                         (TT*)out, (const long long*)len, T, M, d));
+  return mi_check_launch();
+}
+extern "C" int mi355x_glu_bwd(const void* in, const void* dout, void* din, int dt, const void* len, int T, long long M, int d,
+                              void* stream) {
+  if (!in || !dout || !din || M <= 0 || d <= 0 || (d & 3) || T <= 0) return MI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((glu_bwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)in,
+                                         (const TT*)dout, (TT*)din, (const long long*)len, T, M, d));
+  return mi_check_launch();
+}
+extern "C" int mi355x_drop_scale_cast(const void* in, int in_dt, void* out, int out_dt, long long n, float alpha,
+                                      unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
+  if (!in || !out || n <= 0 || (n & 3)) return MI_ERR_ARG;
+  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(in_dt, TI, DISPATCH_DT(out_dt, TO,
+    hipLaunchKernelGGL((drop_scale_cast_kernel<TI, TO>), dim3(grid_for(n >> 2)), dim3(256), 0, s, (const TI*)in, (TO*)out,
+                       n >> 2, alpha, dc)));
+  return mi_check_launch();
+}
+extern "C" int mi355x_qbias(const void* qkv, long long ldq, const void* u, const void* v, void* qu, void* qv, int dt,
+                            long long M, int d, void* stream) {
+  if (!qkv || !u || !v || !qu || !qv || M <= 0 || (d & 3) || (ldq & 3)) return MI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((qbias_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)qkv, ldq,
+                                         (const float*)u, (const float*)v, (TT*)qu, (TT*)qv, M, d));
+  return mi_check_launch();
+}
+extern "C" int mi355x_add2(const void* a, const void* b, int in_dt, void* out, int out_dt, long long ldo, long long M, int d,
+                           void* stream) {
+  if (!a || !b || !out || M <= 0 || (d & 3) || (ldo & 3)) return MI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(in_dt, TI, DISPATCH_DT(out_dt, TO,
+    hipLaunchKernelGGL((add2_kernel<TI, TO>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TI*)a, (const TI*)b,
+                       (TO*)out, ldo, M, d)));
+  return mi_check_launch();
+}
+extern "C" int mi355x_relpos_softmax_fwd(const void* ac, const void* bdf, void* s_out, void* pd_out, int out_dt, const void* len,
+                                         int H, int B, int T, int Tp, int Pp, float scale, unsigned drop_key,
+                                         unsigned drop_threshold, float drop_scale, void* stream) {
+  if (!ac || !bdf || !s_out || !len || T <= 0 || T > 64 * SM_MAXV || Tp < T || Tp > 64 * SM_MAXV || Pp < 2 * T - 1)
+    return MI_ERR_ARG;
+  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  const long long rows = (long long)H * B * T;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(out_dt, TO, hipLaunchKernelGGL((relpos_softmax_fwd_kernel<TO>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+                                             (const float*)ac, (const float*)bdf, (TO*)s_out, (TO*)pd_out,
+                                             (const long long*)len, H, B, T, Tp, Pp, scale, dc));
+  return mi_check_launch();
+}
+extern "C" int mi355x_relpos_softmax_bwd(const void* dpd, int dpd_dt, const void* s_in, void* dscore, void* dbdf, int s_dt, int H,
+                                         int B, int T, int Tp, int Pp, float scale, unsigned drop_key, unsigned drop_threshold,
+                                         float drop_scale, void* stream) {
+  if (!dpd || !s_in || !dscore || !dbdf || T <= 0 || T > 64 * SM_MAXV || Tp < T || Tp > 64 * SM_MAXV || Pp < 2 * T - 1)
+    return MI_ERR_ARG;
+  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  const long long rows = (long long)H * B * T;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(s_dt, TS, DISPATCH_DT(dpd_dt, TD,
+    hipLaunchKernelGGL((relpos_softmax_bwd_kernel<TS, TD>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const TD*)dpd,
+                       (const TS*)s_in, (TS*)dscore, (TS*)dbdf, H, B, T, Tp, Pp, scale, dc)));
+  return mi_check_launch();
+}

@@ -1,0 +1,355 @@
+// GEMM kernels for the Conformer-CTC hot path on MI355X (gfx950).
+//
+//   C[M,N] = epilogue( sum_k opA(m,k) * opB(n,k) )          (optionally batched / split-K)
+//
+// * bf16 path: MFMA `v_mfma_f32_32x32x16_bf16`, 128x128x64 block tile, 4 waves (2x2), each wave a 64x64
+//   sub-tile = 2x2 MFMA tiles; operands staged global -> VGPR -> LDS (double-buffered, one barrier per K tile,
+//   next tile's global loads in flight under the current tile's MFMAs); LDS rows are 128 B with a 16-B-chunk XOR
+//   swizzle  chunk ^= (row>>1)&7  so that the ds_read_b128 fragment reads of 32 consecutive rows are
+//   bank-conflict-free.  An operand may be stored "reduction-major" ([K][rows], used by wgrad = TN and by
+//   P@V = NN); it is then transposed on its way into LDS (4 k-rows packed per ds_write_b64), so the MFMA loop is
+//   the same for NT / NN / TN.  Tile -> workgroup mapping is XCD-aware (bijective chunking of the tile list over
+//   the 8 XCDs so that tiles sharing an A row-panel hit the same L2).
+// * f32 path: exact-fp32 VALU tile kernel with arbitrary strides (parity / fp32 configuration).
+// Both share one epilogue (bias, Swish+dropout, residual, Swish-grad, ReLU+time-mask, ReLU-grad, atomic split-K).
+//
+// Replaces on the reference path: torch.nn.functional.linear / conv1d(k=1) / matmul / conv2d (im2col form) calls in
+//   nemo/collections/asr/parts/submodules/conformer_modules.py:382-387 (FFN), :321,343 (pointwise convs),
+//   multi_head_attention.py:124-146,300-350 (q/k/v/pos/out projections, QK^T, PV),
+//   subsampling.py:431 (out Linear), :231-253 (conv2), modules/conv_asr.py:445 (decoder).
+#include "common.cuh"
+#include "mi355x_asr.h"
+
+enum {
+  EPI_STORE = 0,       // C = alpha*dropout(acc+bias)
+  EPI_SWISH_DROP = 1,  // aux_out = acc+bias ; C = dropout(swish(acc+bias))
+  EPI_RESID = 2,       // C(f32) = aux_in(f32) + alpha*dropout(acc+bias)
+  EPI_DSWISH = 3,      // C = acc * dropmask * swish'(aux_in)
+  EPI_RELU_MASK = 4,   // C = relu(acc+bias) * (t(m) < len[b(m)])
+  EPI_MUL_POS = 5,     // C = acc * (aux_in > 0)
+};
+
+struct GemmP {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  long long lda, ldb, ldc;
+  int transA, transB;                 // 1: operand stored [K][rows] (reduction-major)
+  int batch, nb0;                     // z -> z0 = z % nb0, z1 = z / nb0
+  long long sA0, sA1, sB0, sB1, sC0, sC1;
+  const float* bias; float alpha;
+  int epi; int c_dt; int atomic;
+  const void* aux_in; int auxin_dt; void* aux_out; int auxout_dt; long long ldaux;
+  DropCfg drop;
+  const long long* row_len; int rows_per_b; int rows_inner;
+  int splitk; int ktiles_per_split;
+};
+
+__device__ __forceinline__ float ldx(const void* p, long long i, int dt) {
+  return dt == MI_DT_F32 ? ((const float*)p)[i] : bf2f(((const bf16_t*)p)[i]);
+}
+__device__ __forceinline__ void stx(void* p, long long i, int dt, float v) {
+  if (dt == MI_DT_F32) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = f2bf(v);
+}
+
+__device__ __forceinline__ void epilogue(const GemmP& p, int z, long long coff, int m, int n, float acc) {
+  const long long ci = coff + (long long)m * p.ldc + n;
+  const long long ai = coff + (long long)m * p.ldaux + n;  // aux shares the batch offset convention of C
+  float v = acc;
+  if (p.bias) v += p.bias[n];
+  const uint32_t didx = (uint32_t)z * (uint32_t)(p.M * p.N) + (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+  switch (p.epi) {
+    case EPI_STORE: v *= p.alpha * drop_mask(p.drop, didx); break;
+    case EPI_SWISH_DROP:
+      stx(p.aux_out, ai, p.auxout_dt, v);
+      v = swishf_(v) * drop_mask(p.drop, didx);
+      break;
+    case EPI_RESID:
+      v = ((const float*)p.aux_in)[ai] + p.alpha * v * drop_mask(p.drop, didx);
+      break;
+    case EPI_DSWISH: v = v * drop_mask(p.drop, didx) * swish_grad(ldx(p.aux_in, ai, p.auxin_dt)); break;
+    case EPI_RELU_MASK: {
+      int b = m / p.rows_per_b;
+      int t = (m - b * p.rows_per_b) / p.rows_inner;
+      v = (v > 0.f && (long long)t < p.row_len[b]) ? v : 0.f;
+    } break;
+    case EPI_MUL_POS: v = ldx(p.aux_in, ai, p.auxin_dt) > 0.f ? v : 0.f; break;
+  }
+  if (p.atomic) atomicAdd(&((float*)p.C)[ci], v);
+  else stx(p.C, ci, p.c_dt, v);
+}
+
+// =================================================================================================
+// bf16 MFMA kernel
+// =================================================================================================
+#define BM 128
+#define BN 128
+#define BK 64
+
+__device__ __forceinline__ int lds_off(int r, int chunk) {  // element offset of 8-element chunk `chunk` of row r
+  return r * BK + ((chunk ^ ((r >> 1) & 7)) << 3);
+}
+
+// ---- staging of a [rows][K] (K-contiguous) operand tile: 128 rows x 64 k = 1024 16-B chunks, 4 per thread
+struct StageN { u32x4 v[4]; };
+__device__ __forceinline__ void load_n(StageN& s, const bf16_t* base, long long ld, int row0, int rows, int k0, int K) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = threadIdx.x + i * 256;
+    const int r = q >> 3, ck = q & 7;
+    const int gr = row0 + r, gk = k0 + ck * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (gr < rows && gk < K) v = *reinterpret_cast<const u32x4*>(base + (long long)gr * ld + gk);
+    s.v[i] = v;
+  }
+}
+__device__ __forceinline__ void store_n(const StageN& s, bf16_t* lds) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = threadIdx.x + i * 256;
+    const int r = q >> 3, ck = q & 7;
+    *reinterpret_cast<u32x4*>(lds + lds_off(r, ck)) = s.v[i];
+  }
+}
+// ---- staging of a [K][rows] (reduction-major) operand tile: 64 k-rows x 128 cols; thread = (k-group of 4, 8-col chunk)
+struct StageT { u32x4 v[4]; };
+__device__ __forceinline__ void load_t(StageT& s, const bf16_t* base, long long ld, int col0, int cols, int k0, int K) {
+  const int g = threadIdx.x & 15, c = threadIdx.x >> 4;
+  const int gc = col0 + c * 8;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gk = k0 + g * 4 + j;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (gk < K && gc < cols) v = *reinterpret_cast<const u32x4*>(base + (long long)gk * ld + gc);
+    s.v[j] = v;
+  }
+}
+__device__ __forceinline__ void store_t(const StageT& s, bf16_t* lds) {
+  const int g = threadIdx.x & 15, c = threadIdx.x >> 4;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {  // column 8c+e holds k = 4g..4g+3
+    const int w = e >> 1, hi = e & 1;
+    uint32_t x0 = s.v[0][w], x1 = s.v[1][w], x2 = s.v[2][w], x3 = s.v[3][w];
+    uint32_t lo01, lo23;
+    if (hi) { lo01 = (x0 >> 16) | (x1 & 0xffff0000u); lo23 = (x2 >> 16) | (x3 & 0xffff0000u); }
+    else    { lo01 = (x0 & 0xffffu) | (x1 << 16);     lo23 = (x2 & 0xffffu) | (x3 << 16); }
+    const int r = c * 8 + e;
+    const int k = g * 4;
+    u32x2 o = {lo01, lo23};
+    *reinterpret_cast<u32x2*>(lds + lds_off(r, k >> 3) + (k & 7)) = o;
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];  // 64 KiB
+  // layout: A buf0 | A buf1 | B buf0 | B buf1
+#define SA(buf) (smem + (buf) * (BM * BK))
+#define SB(buf) (smem + 2 * BM * BK + (buf) * (BN * BK))
+
+  // ---- XCD-aware tile mapping (bijective)
+  const int tn = (p.N + BN - 1) / BN, tm = (p.M + BM - 1) / BM;
+  const int ntiles = tm * tn;
+  const int bid = blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tile_m = logical / tn, tile_n = logical - tile_m * tn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int z = blockIdx.z;
+  const int z0 = z % p.nb0, z1 = z / p.nb0;
+  const bf16_t* A = (const bf16_t*)p.A + z0 * p.sA0 + z1 * p.sA1;
+  const bf16_t* B = (const bf16_t*)p.B + z0 * p.sB0 + z1 * p.sB1;
+  const long long coff = z0 * p.sC0 + z1 * p.sC1;
+
+  const int nk_total = (p.K + BK - 1) / BK;
+  int kt_begin = 0, kt_end = nk_total;
+  if (p.splitk > 1) {
+    kt_begin = blockIdx.y * p.ktiles_per_split;
+    kt_end = min(nk_total, kt_begin + p.ktiles_per_split);
+    if (kt_begin >= kt_end) return;
+  }
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  StageN an, bn; StageT at, bt;
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+    if (TA) load_t(at, A, p.lda, m0, p.M, k0, p.K); else load_n(an, A, p.lda, m0, p.M, k0, p.K);
+    if (TB) load_t(bt, B, p.ldb, n0, p.N, k0, p.K); else load_n(bn, B, p.ldb, n0, p.N, k0, p.K);
+  };
+  auto store_tiles = [&](int buf) {
+    if (TA) store_t(at, SA(buf)); else store_n(an, SA(buf));
+    if (TB) store_t(bt, SB(buf)); else store_n(bn, SB(buf));
+  };
+
+  load_tiles(kt_begin);
+  store_tiles(0);
+  __syncthreads();
+
+  const int lr = lane & 31, lh = lane >> 5;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    const bool more = (kt + 1 < kt_end);
+    if (more) load_tiles(kt + 1);
+    const bf16_t* a_s = SA(cur);
+    const bf16_t* b_s = SB(cur);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + lr;
+        af[i] = *reinterpret_cast<const bf16x8*>(a_s + lds_off(ra, kk * 2 + lh));
+        const int rb = wn * 64 + i * 32 + lr;
+        bfr[i] = *reinterpret_cast<const bf16x8*>(b_s + lds_off(rb, kk * 2 + lh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.M && n < p.N) epilogue(p, z, coff, m, n, acc[i][j][r]);
+      }
+    }
+}
+
+// =================================================================================================
+// exact fp32 VALU kernel, arbitrary strides: 64x64x16 tile, 256 threads, 4x4 per thread
+// =================================================================================================
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
+  __shared__ float As[16][64 + 4];
+  __shared__ float Bs[16][64 + 4];
+  const int tn = (p.N + 63) / 64;
+  const int tile_m = blockIdx.x / tn, tile_n = blockIdx.x - tile_m * tn;
+  const int m0 = tile_m * 64, n0 = tile_n * 64;
+  const int z = blockIdx.z, z0 = z % p.nb0, z1 = z / p.nb0;
+  const float* A = (const float*)p.A + z0 * p.sA0 + z1 * p.sA1;
+  const float* B = (const float*)p.B + z0 * p.sB0 + z1 * p.sB1;
+  const long long coff = z0 * p.sC0 + z1 * p.sC1;
+  // element (row, k) strides
+  const long long sar = p.transA ? 1 : p.lda, sak = p.transA ? p.lda : 1;
+  const long long sbr = p.transB ? 1 : p.ldb, sbk = p.transB ? p.ldb : 1;
+  int k_begin = 0, k_end = p.K;
+  if (p.splitk > 1) {
+    k_begin = blockIdx.y * p.ktiles_per_split * BK;
+    k_end = min(p.K, k_begin + p.ktiles_per_split * BK);
+    if (k_begin >= k_end) return;
+  }
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  float acc[4][4] = {};
+  for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = threadIdx.x + i * 256;
+      int r, k;
+      if (p.transA) { r = e & 63; k = e >> 6; } else { k = e & 15; r = e >> 4; }
+      float v = 0.f;
+      if (m0 + r < p.M && k0 + k < k_end) v = A[(long long)(m0 + r) * sar + (long long)(k0 + k) * sak];
+      As[k][r] = v;
+      if (p.transB) { r = e & 63; k = e >> 6; } else { k = e & 15; r = e >> 4; }
+      v = 0.f;
+      if (n0 + r < p.N && k0 + k < k_end) v = B[(long long)(n0 + r) * sbr + (long long)(k0 + k) * sbk];
+      Bs[k][r] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; b[i] = Bs[k][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+      if (m < p.M && n < p.N) epilogue(p, z, coff, m, n, acc[i][j]);
+    }
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0) return MI_ERR_ARG;
+  if (d->in_dtype != MI_DT_F32 && d->in_dtype != MI_DT_BF16) return MI_ERR_ARG;
+  GemmP p;
+  p.A = d->A; p.B = d->B; p.C = d->C;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+  p.transA = d->transA; p.transB = d->transB;
+  p.batch = d->batch > 0 ? d->batch : 1; p.nb0 = d->nb0 > 0 ? d->nb0 : p.batch;
+  p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
+  p.bias = (const float*)d->bias; p.alpha = d->alpha;
+  p.epi = d->epilogue; p.c_dt = d->c_dtype; p.atomic = d->atomic;
+  p.aux_in = d->aux_in; p.auxin_dt = d->aux_in_dtype; p.aux_out = d->aux_out; p.auxout_dt = d->aux_out_dtype;
+  p.ldaux = d->ldaux;
+  p.drop.key = d->drop_key; p.drop.threshold = d->drop_threshold; p.drop.scale = d->drop_scale;
+  p.row_len = (const long long*)d->row_len; p.rows_per_b = d->rows_per_b > 0 ? d->rows_per_b : 1;
+  p.rows_inner = d->rows_inner > 0 ? d->rows_inner : 1;
+  if (p.epi < EPI_STORE || p.epi > EPI_MUL_POS) return MI_ERR_ARG;
+  if (p.atomic && p.c_dt != MI_DT_F32) return MI_ERR_ARG;
+  if ((p.epi == EPI_RESID || p.epi == EPI_DSWISH || p.epi == EPI_MUL_POS) && !p.aux_in) return MI_ERR_ARG;
+  if (p.epi == EPI_SWISH_DROP && !p.aux_out) return MI_ERR_ARG;
+  if (p.epi == EPI_RELU_MASK && !p.row_len) return MI_ERR_ARG;
+  const int nk = (p.K + BK - 1) / BK;
+  int sk = d->splitk > 1 ? d->splitk : 1;
+  if (sk > nk) sk = nk;
+  if (sk > 1 && !p.atomic) return MI_ERR_ARG;
+  p.ktiles_per_split = (nk + sk - 1) / sk;
+  sk = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
+  p.splitk = sk;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->in_dtype == MI_DT_BF16) {
+    // 16-byte alignment contract of the vector loads
+    if ((p.lda & 7) || (p.ldb & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return MI_ERR_ARG;
+    if ((p.sA0 & 7) || (p.sA1 & 7) || (p.sB0 & 7) || (p.sB1 & 7)) return MI_ERR_ARG;
+    // K-contiguous operands are read in 8-element chunks: K must be a multiple of 8 (pad with zeros).
+    // Reduction-major operands need only pitch >= roundup8(rows): a partial chunk's extra columns feed
+    // output rows/cols >= M/N that are never stored.
+    if ((!p.transA || !p.transB) && (p.K & 7)) return MI_ERR_ARG;
+    if (p.transA && p.lda < ((p.M + 7) & ~7)) return MI_ERR_ARG;
+    if (p.transB && p.ldb < ((p.N + 7) & ~7)) return MI_ERR_ARG;
+    const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    dim3 grid(tm * tn, sk, p.batch);
+    if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, s, p);
+    else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, s, p);
+    else if (p.transA && p.transB) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(256), 0, s, p);
+  } else {
+    const int tm = (p.M + 63) / 64, tn = (p.N + 63) / 64;
+    dim3 grid(tm * tn, sk, p.batch);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, p);
+  }
+  return mi_check_launch();
+}

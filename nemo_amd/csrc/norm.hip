@@ -1,0 +1,221 @@
+// LayerNorm / log-softmax / column-reduction kernels (HBM-bound; wave64 shuffle reductions, 16-B vector access).
+//
+// Replaces on the reference path: torch.nn.LayerNorm x5 per ConformerLayer
+// (nemo/collections/asr/parts/submodules/conformer_modules.py:98,102,115,152,157 used at :174-215),
+// log_softmax of the decoder (nemo/collections/asr/modules/conv_asr.py:468) and the bias-gradient column sums
+// autograd produces for every Linear / Conv1d on the path.
+#include "common.cuh"
+#include "mi355x_asr.h"
+
+#define DISPATCH_DT(dt, T, ...)                                      \
+  if ((dt) == MI_DT_F32) { typedef float T; __VA_ARGS__; }           \
+  else { typedef bf16_t T; __VA_ARGS__; }
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row, 4 rows per 256-thread block.  Two-pass (mean, then centred variance) on
+// register-resident data when d <= 64*4*VPL, else re-read.  Statistics saved for backward.
+// ------------------------------------------------------------------------------------------------
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, TY* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int d,
+                                                     float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const TX* xr = x + (long long)row * d;
+  TY* yr = y + (long long)row * d;
+  const int nv = d >> 2;  // d % 4 == 0 guaranteed by the launcher
+  float s = 0.f;
+  for (int i = lane; i < nv; i += 64) {
+    float v[4]; ld4(xr + i * 4, v);
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  const float mu = wave_sum(s) / (float)d;
+  float q = 0.f;
+  for (int i = lane; i < nv; i += 64) {
+    float v[4]; ld4(xr + i * 4, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { float c = v[j] - mu; q += c * c; }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
+  for (int i = lane; i < nv; i += 64) {
+    float v[4], g[4], b[4], o[4];
+    ld4(xr + i * 4, v); ld4(gamma + i * 4, g); ld4(beta + i * 4, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (v[j] - mu) * rs * g[j] + b[j];
+    st4(yr + i * 4, o);
+  }
+  if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+}
+
+// LayerNorm backward wrt input: dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dres (+)= dx
+template <typename TX, typename TDY>
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float* __restrict__ dres,
+                                                        int accumulate, int M, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const TX* xr = x + (long long)row * d;
+  const TDY* dyr = dy + (long long)row * d;
+  float* dr = dres + (long long)row * d;
+  const float mu = mean[row], rs = rstd[row];
+  const int nv = d >> 2;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lane; i < nv; i += 64) {
+    float v[4], g[4], e[4];
+    ld4(xr + i * 4, v); ld4(gamma + i * 4, g); ld4(dyr + i * 4, e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { float gd = g[j] * e[j]; s1 += gd; s2 += gd * (v[j] - mu) * rs; }
+  }
+  s1 = wave_sum(s1) / (float)d;
+  s2 = wave_sum(s2) / (float)d;
+  for (int i = lane; i < nv; i += 64) {
+    float v[4], g[4], e[4], o[4];
+    ld4(xr + i * 4, v); ld4(gamma + i * 4, g); ld4(dyr + i * 4, e);
+    if (accumulate) ld4(dr + i * 4, o); else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] += rs * (g[j] * e[j] - s1 - (v[j] - mu) * rs * s2);
+    st4(dr + i * 4, o);
+  }
+}
+
+// dgamma[n] += sum_m dy*xhat ; dbeta[n] += sum_m dy.   Block = 64 columns x 4 row-lanes, ROWS_PER_BLOCK rows.
+#define CR_ROWS 256
+template <typename TX, typename TDY>
+__global__ __launch_bounds__(256) void ln_bwd_param_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                           int d) {
+  __shared__ float sg[4][64], sb[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * CR_ROWS, r1 = min(M, r0 + CR_ROWS);
+  float ag = 0.f, ab = 0.f;
+  if (c < d)
+    for (int r = r0 + rl; r < r1; r += 4) {
+      float e = ld(dy + (long long)r * d + c);
+      float xh = (ld(x + (long long)r * d + c) - mean[r]) * rstd[r];
+      ag += e * xh; ab += e;
+    }
+  sg[rl][threadIdx.x & 63] = ag; sb[rl][threadIdx.x & 63] = ab;
+  __syncthreads();
+  if (rl == 0 && c < d) {
+    const int t = threadIdx.x;
+    atomicAdd(dgamma + c, (sg[0][t] + sg[1][t]) + (sg[2][t] + sg[3][t]));
+    atomicAdd(dbeta + c, (sb[0][t] + sb[1][t]) + (sb[2][t] + sb[3][t]));
+  }
+}
+
+// out[n] += alpha * sum_m x[m, n]   (bias gradients, pos_bias_u/v gradients)
+template <typename TX>
+__global__ __launch_bounds__(256) void colsum_kernel(const TX* __restrict__ x, long long ldx_, float* __restrict__ out,
+                                                     int M, int N, float alpha) {
+  __shared__ float sa[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * CR_ROWS, r1 = min(M, r0 + CR_ROWS);
+  float a = 0.f;
+  if (c < N)
+    for (int r = r0 + rl; r < r1; r += 4) a += ld(x + (long long)r * ldx_ + c);
+  sa[rl][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    const int t = threadIdx.x;
+    atomicAdd(out + c, alpha * ((sa[0][t] + sa[1][t]) + (sa[2][t] + sa[3][t])));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// log-softmax over the class axis (C = V+1 = 129): one wave per row; logits f32 with pitch ld
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const float* __restrict__ x, long long ldx_, float* __restrict__ y,
+                                                              long long ldy, int M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + row * ldx_;
+  float mx = -INFINITY;
+  for (int i = lane; i < C; i += 64) mx = fmaxf(mx, xr[i]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int i = lane; i < C; i += 64) s += expf(xr[i] - mx);
+  const float lse = mx + logf(wave_sum(s));
+  for (int i = lane; i < C; i += 64) y[row * ldy + i] = xr[i] - lse;
+}
+// dx = dy - exp(y) * sum(dy); output in `TO` with pitch ldo (pad columns [C, ldo) are zero-filled so the buffer can
+// be used directly as a K-padded GEMM operand)
+template <typename TO>
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              long long ldy, TO* __restrict__ dx, long long ldo, int M, int C,
+                                                              float scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float s = 0.f;
+  for (int i = lane; i < C; i += 64) s += dy[row * ldy + i];
+  s = wave_sum(s);
+  for (int i = lane; i < (int)ldo; i += 64) {
+    float v = 0.f;
+    if (i < C) v = scale * (dy[row * ldy + i] - expf(y[row * ldy + i]) * s);
+    st(dx + row * ldo + i, v);
+  }
+}
+
+// =================================================================================================
+extern "C" int mi355x_layernorm_fwd(const void* x, int x_dt, const void* gamma, const void* beta, void* y, int y_dt,
+                                    void* mean, void* rstd, int M, int d, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || M <= 0 || d <= 0 || (d & 3)) return MI_ERR_ARG;
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(x_dt, TX, DISPATCH_DT(y_dt, TY,
+    hipLaunchKernelGGL((ln_fwd_kernel<TX, TY>), grid, block, 0, s, (const TX*)x, (const float*)gamma, (const float*)beta,
+                       (TY*)y, (float*)mean, (float*)rstd, M, d, eps)));
+  return mi_check_launch();
+}
+
+extern "C" int mi355x_layernorm_bwd(const void* dy, int dy_dt, const void* x, int x_dt, const void* gamma, const void* mean,
+                                    const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d,
+                                    void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dres || M <= 0 || d <= 0 || (d & 3)) return MI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 block(256);
+  if (dgamma && dbeta) {
+    dim3 gp((d + 63) / 64, (M + CR_ROWS - 1) / CR_ROWS);
+    DISPATCH_DT(x_dt, TX, DISPATCH_DT(dy_dt, TDY,
+      hipLaunchKernelGGL((ln_bwd_param_kernel<TX, TDY>), gp, block, 0, s, (const TDY*)dy, (const TX*)x, (const float*)mean,
+                         (const float*)rstd, (float*)dgamma, (float*)dbeta, M, d)));
+  }
+  dim3 grid((M + 3) / 4);
+  DISPATCH_DT(x_dt, TX, DISPATCH_DT(dy_dt, TDY,
+    hipLaunchKernelGGL((ln_bwd_dx_kernel<TX, TDY>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, (const float*)gamma,
+                       (const float*)mean, (const float*)rstd, (float*)dres, accumulate, M, d)));
+  return mi_check_launch();
+}
+
+extern "C" int mi355x_colsum(const void* x, int x_dt, long long ld, void* out, int M, int N, float alpha, void* stream) {
+  if (!x || !out || M <= 0 || N <= 0) return MI_ERR_ARG;
+  dim3 grid((N + 63) / 64, (M + CR_ROWS - 1) / CR_ROWS), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(x_dt, TX, hipLaunchKernelGGL((colsum_kernel<TX>), grid, block, 0, s, (const TX*)x, ld, (float*)out, M, N, alpha));
+  return mi_check_launch();
+}
+
+extern "C" int mi355x_log_softmax_fwd(const void* logits, long long ld_in, void* logp, long long ld_out, int M, int C,
+                                      void* stream) {
+  if (!logits || !logp || M <= 0 || C <= 0) return MI_ERR_ARG;
+  hipLaunchKernelGGL(log_softmax_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)logits,
+                     ld_in, (float*)logp, ld_out, M, C);
+  return mi_check_launch();
+}
+
+extern "C" int mi355x_log_softmax_bwd(const void* dlogp, const void* logp, long long ld, void* dlogits, int out_dt,
+                                      long long ld_out, int M, int C, float scale, void* stream) {
+  if (!dlogp || !logp || !dlogits || M <= 0 || C <= 0 || ld_out < C) return MI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(out_dt, TO, hipLaunchKernelGGL((log_softmax_bwd_kernel<TO>), dim3((M + 3) / 4), dim3(256), 0, s,
+                                             (const float*)dlogp, (const float*)logp, ld, (TO*)dlogits, ld_out, M, C, scale));
+  return mi_check_launch();
+}

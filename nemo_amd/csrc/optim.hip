@@ -1,0 +1,104 @@
+// Optimizer + weight-packing kernels (HBM-bound, flat buffers sized for 288 GB HBM: one launch per step each).
+//   * fused AdamW over the flat fp32 parameter / gradient / moment buffers (decoupled weight decay, bias correction,
+//     optional global grad scale = 1/world for the data-parallel average)  -- replaces torch.optim.AdamW stepping
+//     646+ tensors (nemo/core/classes/modelPT.py:650-823, optim registry nemo/core/optim/optimizers.py:33)
+//   * descriptor-driven "pack" kernel that produces every bf16 GEMM operand image of the weights in one launch:
+//     plain casts, transposes (for dgrad), q|k|v concatenation, conv2 [co,ci,3,3] -> [co][(kh,kw,ci)], and the
+//     out-Linear column permutation (c*F2+f -> f*C+c) required by the channels-last conv layout.
+#include "common.cuh"
+#include "mi355x_asr.h"
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n4, float lr, float beta1, float beta2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float grad_scale) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float pp[4], gg[4], mm[4], vv[4];
+    ld4(p + i * 4, pp); ld4(g + i * 4, gg); ld4(m + i * 4, mm); ld4(v + i * 4, vv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = gg[j] * grad_scale;
+      pp[j] *= (1.f - lr * wd);
+      mm[j] = beta1 * mm[j] + (1.f - beta1) * gr;
+      vv[j] = beta2 * vv[j] + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+      pp[j] -= (lr / bc1) * (mm[j] / denom);
+    }
+    st4(p + i * 4, pp); st4(m + i * 4, mm); st4(v + i * 4, vv);
+  }
+}
+
+// dst[r*pitch + c] = cast( src[r1*sr1 + r2*sr2 + c1*sc1 + c2*sc2] ),  r = r1*nr2 + r2,  c = c1*nc2 + c2
+struct PackEntry {
+  const float* src; void* dst;
+  int rows, cols, nr2, nc2;
+  long long sr1, sr2, sc1, sc2, pitch;
+  long long tile_begin;  // prefix sum of 32x32 tiles
+};
+__global__ __launch_bounds__(256) void pack_kernel(const PackEntry* __restrict__ tab, int n_entries, int out_dt) {
+  __shared__ float tile[32][33];
+  // locate entry by binary search on tile_begin
+  int lo = 0, hi = n_entries - 1;
+  const long long bid = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].tile_begin <= bid) lo = mid; else hi = mid - 1;
+  }
+  const PackEntry e = tab[lo];
+  const int tiles_c = (e.cols + 31) / 32;
+  const int local = (int)(bid - e.tile_begin);
+  const int tr = local / tiles_c, tc = local - tr * tiles_c;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  // read: choose the thread-fast axis that is contiguous in the source
+  const bool col_fast = (e.sc2 == 1 && e.nc2 > 1) || (e.nc2 == 1 && e.sc1 == 1);
+  for (int i = ty; i < 32; i += 8) {
+    const int rr = col_fast ? i : tx, cc = col_fast ? tx : i;
+    const int r = tr * 32 + rr, c = tc * 32 + cc;
+    float v = 0.f;
+    if (r < e.rows && c < e.cols) {
+      const int r1 = r / e.nr2, r2 = r - r1 * e.nr2, c1 = c / e.nc2, c2 = c - c1 * e.nc2;
+      v = e.src[r1 * e.sr1 + r2 * e.sr2 + c1 * e.sc1 + c2 * e.sc2];
+    }
+    tile[rr][cc] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int r = tr * 32 + i, c = tc * 32 + tx;
+    if (r < e.rows && c < e.cols) {
+      const float v = tile[i][tx];
+      if (out_dt == MI_DT_F32) ((float*)e.dst)[r * e.pitch + c] = v;
+      else ((bf16_t*)e.dst)[r * e.pitch + c] = f2bf(v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long long n, float value) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = value;
+}
+
+extern "C" int mi355x_adamw_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, long long n, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                 void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || (n & 3) || step < 1) return MI_ERR_ARG;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  long long nb = ((n >> 2) + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (float*)params, (const float*)grads,
+                     (float*)exp_avg, (float*)exp_avg_sq, n >> 2, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+  return mi_check_launch();
+}
+
+extern "C" int mi355x_pack_weights(const void* table_dev, int n_entries, long long total_tiles, int out_dtype, void* stream) {
+  if (!table_dev || n_entries <= 0 || total_tiles <= 0) return MI_ERR_ARG;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev,
+                     n_entries, out_dtype);
+  return mi_check_launch();
+}
+
+extern "C" int mi355x_fill_f32(void* p, long long n, float value, void* stream) {
+  if (!p || n <= 0) return MI_ERR_ARG;
+  long long nb = (n + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (float*)p, n, value);
+  return mi_check_launch();
+}

@@ -1,0 +1,210 @@
+// Convolution sub-sampling (x4, 'striding'), memory-bound part.  Activation layout is channels-last:
+//   mel [B,F,T] f32 (the preprocessor's layout; no transpose is ever materialised)
+//   out1 [B,T1,F1,C]   = mask1 * ReLU(Conv2d(1->C, 3x3, s2, p1)(mask0 * mel^T))      direct kernel (K = 9, write-bound)
+//   col  [B*T2*F2, 9C] = im2col(out1), k = (kh*3+kw)*C + ci                         feeds the MFMA GEMM for conv2
+//   out2 [B,T2,F2,C]   = mask2 * ReLU(col @ W2p^T + b2)                              (GEMM epilogue EPI_RELU_MASK)
+// and the matching backward pieces (conv1 weight/bias grads, col2im with the ReLU gate).
+//
+// Replaces on the reference path: ConvSubsampling.forward / MaskedConvSequential
+//   (nemo/collections/asr/parts/submodules/subsampling.py:385-436, 725-759) = F.conv2d x2 + 4 mask multiplies.
+#include "common.cuh"
+#include "mi355x_asr.h"
+
+#define DISPATCH_DT(dt, T, ...)                                      \
+  if ((dt) == MI_DT_F32) { typedef float T; __VA_ARGS__; }           \
+  else { typedef bf16_t T; __VA_ARGS__; }
+
+#define C1_FB 8  // f1 positions per block
+
+// ------------------------------------------------------------------------------------------------ conv1 forward
+// grid (ceil(F1/8), T1, B); 256 threads over channels
+template <typename TO>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ mel, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, TO* __restrict__ out,
+                                                        const long long* __restrict__ len0, const long long* __restrict__ len1,
+                                                        int B, int F, int T, int T1, int F1, int C) {
+  __shared__ float patch[3][2 * C1_FB + 1];
+  const int b = blockIdx.z, t1 = blockIdx.y, f1_0 = blockIdx.x * C1_FB;
+  const bool tvalid = t1 < len1[b];
+  const int nf = 2 * C1_FB + 1;
+  if (threadIdx.x < 3 * nf) {
+    const int kh = threadIdx.x / nf, fi = threadIdx.x - kh * nf;
+    const int t = 2 * t1 + kh - 1, f = 2 * f1_0 + fi - 1;
+    float v = 0.f;
+    if (t >= 0 && t < T && t < len0[b] && f >= 0 && f < F) v = mel[((long long)b * F + f) * T + t];
+    patch[kh][fi] = v;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
+    const float bs = bias[c];
+#pragma unroll
+    for (int j = 0; j < C1_FB; ++j) {
+      const int f1 = f1_0 + j;
+      if (f1 < F1) {
+        float a = bs;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) a = fmaf(wk[kh * 3 + kw], patch[kh][2 * j + kw], a);
+        a = (tvalid && a > 0.f) ? a : 0.f;
+        st(out + (((long long)b * T1 + t1) * F1 + f1) * C + c, a);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ conv1 backward (params only)
+// dout1 [B,T1,F1,C] (already gated by ReLU and masks) : dw[c,kh,kw] += sum dout1 * x ; db[c] += sum dout1
+// grid (ceil(T1/16), B); threads over channels; each block walks 16 t1 x all f1
+#define C1_TB 16
+template <typename TO>
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const TO* __restrict__ dout, const float* __restrict__ mel,
+                                                        const long long* __restrict__ len0, float* __restrict__ dw,
+                                                        float* __restrict__ db, int B, int F, int T, int T1, int F1, int C) {
+  extern __shared__ float rows[];  // [3][F + 2]  (freq index shifted by +1; zero borders)
+  const int b = blockIdx.y;
+  const int t1_0 = blockIdx.x * C1_TB;
+  const int FW = F + 2;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + threadIdx.x;
+    float gw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gb = 0.f;
+    for (int t1 = t1_0; t1 < min(T1, t1_0 + C1_TB); ++t1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < 3 * FW; i += 256) {
+        const int kh = i / FW, f = i - kh * FW - 1;
+        const int t = 2 * t1 + kh - 1;
+        float v = 0.f;
+        if (t >= 0 && t < T && t < len0[b] && f >= 0 && f < F) v = mel[((long long)b * F + f) * T + t];
+        rows[i] = v;
+      }
+      __syncthreads();
+      if (c < C) {
+        for (int f1 = 0; f1 < F1; ++f1) {
+          const float g = ld(dout + (((long long)b * T1 + t1) * F1 + f1) * C + c);
+          gb += g;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) gw[kh * 3 + kw] = fmaf(g, rows[kh * FW + 2 * f1 + kw], gw[kh * 3 + kw]);
+        }
+      }
+    }
+    if (c < C) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) atomicAdd(dw + c * 9 + k, gw[k]);
+      atomicAdd(db + c, gb);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ im2col / col2im (3x3, s2, p1)
+// in [B,T1,F1,C] -> col [(b,t2,f2), (kh,kw,ci)]; one thread = one 8-channel (or 4 for f32) vector
+template <typename TT>
+__global__ __launch_bounds__(256) void im2col_kernel(const TT* __restrict__ in, TT* __restrict__ col, int B, int T1, int F1,
+                                                     int T2, int F2, int C) {
+  constexpr int V = sizeof(TT) == 2 ? 8 : 4;
+  const int cv = C / V;
+  const long long total = (long long)B * T2 * F2 * 9 * cv;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cv);
+    long long r = i / cv;
+    const int tap = (int)(r % 9); r /= 9;
+    const int f2 = (int)(r % F2); r /= F2;
+    const int t2 = (int)(r % T2);
+    const int b = (int)(r / T2);
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int t1 = 2 * t2 + kh - 1, f1 = 2 * f2 + kw - 1;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (t1 >= 0 && t1 < T1 && f1 >= 0 && f1 < F1)
+      v = *reinterpret_cast<const u32x4*>(in + (((long long)b * T1 + t1) * F1 + f1) * C + c * V);
+    *reinterpret_cast<u32x4*>(col + ((((long long)b * T2 + t2) * F2 + f2) * 9 + tap) * C + c * V) = v;
+  }
+}
+// din[b,t1,f1,ci] = (act[b,t1,f1,ci] > 0) * sum_{valid taps} dcol[(b,t2,f2), (kh,kw,ci)]
+template <typename TT>
+__global__ __launch_bounds__(256) void col2im_relu_kernel(const TT* __restrict__ dcol, const TT* __restrict__ act,
+                                                          TT* __restrict__ din, int B, int T1, int F1, int T2, int F2, int C) {
+  const int cv = C >> 2;
+  const long long total = (long long)B * T1 * F1 * cv;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cv) * 4;
+    long long r = i / cv;
+    const int f1 = (int)(r % F1); r /= F1;
+    const int t1 = (int)(r % T1);
+    const int b = (int)(r / T1);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int tn = t1 + 1 - kh;
+      if (tn < 0 || (tn & 1)) continue;
+      const int t2 = tn >> 1;
+      if (t2 >= T2) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int fn = f1 + 1 - kw;
+        if (fn < 0 || (fn & 1)) continue;
+        const int f2 = fn >> 1;
+        if (f2 >= F2) continue;
+        float v[4];
+        ld4(dcol + ((((long long)b * T2 + t2) * F2 + f2) * 9 + kh * 3 + kw) * C + c, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j];
+      }
+    }
+    float a[4];
+    const long long o = (((long long)b * T1 + t1) * F1 + f1) * C + c;
+    ld4(act + o, a);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = a[j] > 0.f ? acc[j] : 0.f;
+    st4(din + o, acc);
+  }
+}
+
+// =================================================================================================
+static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g)); }
+
+extern "C" int mi355x_subsample_conv1_fwd(const void* mel, const void* w, const void* bias, void* out, int out_dt,
+                                          const void* len0, const void* len1, int B, int F, int T, int C, void* stream) {
+  if (!mel || !w || !bias || !out || !len0 || !len1 || B <= 0 || F <= 0 || T <= 0 || C <= 0) return MI_ERR_ARG;
+  const int T1 = (T + 2 - 3) / 2 + 1, F1 = (F + 2 - 3) / 2 + 1;
+  dim3 grid((F1 + C1_FB - 1) / C1_FB, T1, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(out_dt, TO, hipLaunchKernelGGL((conv1_fwd_kernel<TO>), grid, block, 0, s, (const float*)mel, (const float*)w,
+                                             (const float*)bias, (TO*)out, (const long long*)len0, (const long long*)len1, B, F,
+                                             T, T1, F1, C));
+  return mi_check_launch();
+}
+extern "C" int mi355x_subsample_conv1_bwd(const void* dout, int dt, const void* mel, const void* len0, void* dw, void* db, int B,
+                                          int F, int T, int C, void* stream) {
+  if (!dout || !mel || !len0 || !dw || !db || B <= 0 || F <= 0 || T <= 0 || C <= 0) return MI_ERR_ARG;
+  const int T1 = (T + 2 - 3) / 2 + 1, F1 = (F + 2 - 3) / 2 + 1;
+  dim3 grid((T1 + C1_TB - 1) / C1_TB, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t shm = 3 * (F + 2) * sizeof(float);
+  DISPATCH_DT(dt, TO, hipLaunchKernelGGL((conv1_bwd_kernel<TO>), grid, block, shm, s, (const TO*)dout, (const float*)mel,
+                                         (const long long*)len0, (float*)dw, (float*)db, B, F, T, T1, F1, C));
+  return mi_check_launch();
+}
+extern "C" int mi355x_im2col_3x3s2(const void* in, void* col, int dt, int B, int T1, int F1, int C, void* stream) {
+  if (!in || !col || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || (C & 7)) return MI_ERR_ARG;
+  const int T2 = (T1 + 2 - 3) / 2 + 1, F2 = (F1 + 2 - 3) / 2 + 1;
+  const long long total = (long long)B * T2 * F2 * 9 * (C / (dt == MI_DT_BF16 ? 8 : 4));
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((im2col_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, s, (const TT*)in, (TT*)col, B,
+                                         T1, F1, T2, F2, C));
+  return mi_check_launch();
+}
+extern "C" int mi355x_col2im_3x3s2_relu(const void* dcol, const void* act, void* din, int dt, int B, int T1, int F1, int C,
+                                        void* stream) {
+  if (!dcol || !act || !din || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || (C & 3)) return MI_ERR_ARG;
+  const int T2 = (T1 + 2 - 3) / 2 + 1, F2 = (F1 + 2 - 3) / 2 + 1;
+  const long long total = (long long)B * T1 * F1 * (C >> 2);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((col2im_relu_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, s, (const TT*)dcol,
+                                         (const TT*)act, (TT*)din, B, T1, F1, T2, F2, C));
+  return mi_check_launch();
+}

@@ -1,0 +1,235 @@
+"""Drop-in for `nemo.collections.asr.modules.AudioToMelSpectrogramPreprocessor`
+(nemo/collections/asr/modules/audio_preprocessing.py:111-330) and its `FilterbankFeatures` featurizer
+(parts/preprocessing/features.py:246-502), executing on the fused HIP front-end (csrc/mel.hip).
+
+Same constructor kwargs, typed I/O, attributes callers touch (`_sample_rate`, `featurizer.dither`, `featurizer.pad_to`,
+`filter_banks`) and persistent buffers (`featurizer.window`, `featurizer.fb`) so a reference `.nemo` state-dict loads.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..core import AudioSignal, LengthsType, MelSpectrogramType, NeuralModule, NeuralType, typecheck
+
+CONSTANT = 1e-5
+
+
+def _hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-30) / 1000.0) * 27.0 / np.log(6.4), f * 3.0 / 200.0)
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    return np.where(m >= 15.0, 1000.0 * np.exp((m - 15.0) * np.log(6.4) / 27.0), m * 200.0 / 3.0)
+
+
+def slaney_mel_filterbank(sr, n_fft, n_mels, fmin=0.0, fmax=None, norm="slaney") -> np.ndarray:
+    """= librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk=False, norm) (third-party, librosa>=0.10.1; the reference
+    calls it at features.py:338-344).  Slaney scale, triangular weights on rfftfreq, area normalisation."""
+    fmax = sr / 2.0 if fmax is None else fmax
+    edges = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+    bins = np.fft.rfftfreq(n_fft, 1.0 / sr)
+    fb = np.zeros((n_mels, bins.size))
+    for i in range(n_mels):
+        up = (bins - edges[i]) / (edges[i + 1] - edges[i])
+        down = (edges[i + 2] - bins) / (edges[i + 2] - edges[i + 1])
+        fb[i] = np.maximum(0.0, np.minimum(up, down))
+        if norm == "slaney":
+            fb[i] *= 2.0 / (edges[i + 2] - edges[i])
+    return fb.astype(np.float32)
+
+
+def sparsify_filterbank(fb: torch.Tensor):
+    """fb [n_mels, n_bins] -> (start i32 [n_mels], len i32, offset i32, weights f32): per-row non-zero span."""
+    fbn = fb.detach().float().cpu().numpy().reshape(fb.shape[-2], fb.shape[-1])
+    starts, lens, offs, ws = [], [], [], []
+    o = 0
+    for row in fbn:
+        nz = np.nonzero(row)[0]
+        if nz.size == 0:
+            s, n = 0, 0
+        else:
+            s, n = int(nz[0]), int(nz[-1] - nz[0] + 1)
+        starts.append(s); lens.append(n); offs.append(o)
+        ws.append(row[s: s + n])
+        o += n
+    w = np.concatenate(ws) if o > 0 else np.zeros(1, np.float32)
+    return (torch.tensor(starts, dtype=torch.int32), torch.tensor(lens, dtype=torch.int32),
+            torch.tensor(offs, dtype=torch.int32), torch.from_numpy(w.astype(np.float32)))
+
+
+class FilterbankFeatures(nn.Module):
+    """features.py:246 -- same ctor arguments; `forward(x, seq_len)` -> (features [B, nfilt, T], seq_len)."""
+
+    def __init__(self, sample_rate=16000, n_window_size=320, n_window_stride=160, window="hann", normalize="per_feature",
+                 n_fft=None, preemph=0.97, nfilt=64, lowfreq=0, highfreq=None, log=True, log_zero_guard_type="add",
+                 log_zero_guard_value=2 ** -24, dither=CONSTANT, pad_to=16, max_duration=16.7, frame_splicing=1,
+                 exact_pad=False, pad_value=0, mag_power=2.0, use_grads=False, rng=None, nb_augmentation_prob=0.0,
+                 nb_max_freq=4000, mel_norm="slaney", stft_exact_pad=False, stft_conv=False):
+        super().__init__()
+        if exact_pad and n_window_stride % 2 == 1:
+            raise NotImplementedError(f"{self} received exact_pad == True, but hop_size was odd.")
+        if (n_window_size is None or n_window_stride is None or not isinstance(n_window_size, int)
+                or not isinstance(n_window_stride, int) or n_window_size <= 0 or n_window_stride <= 0):
+            raise ValueError(f"{self} got an invalid value for either n_window_size or n_window_stride. "
+                             f"Both must be positive ints.")
+        if log_zero_guard_type not in ["add", "clamp"]:
+            raise ValueError(f"{self} received {log_zero_guard_type} for the log_zero_guard_type parameter. "
+                             f"It must be either 'add' or 'clamp'.")
+        # what the fused HIP front-end implements (everything the Conformer-CTC configs use)
+        unsupported = []
+        if exact_pad: unsupported.append("exact_pad=True")
+        if frame_splicing != 1: unsupported.append("frame_splicing>1")
+        if mag_power != 2.0: unsupported.append("mag_power!=2")
+        if not log or log_zero_guard_type != "add": unsupported.append("log=False / clamp guard")
+        if nb_augmentation_prob > 0: unsupported.append("nb_augmentation_prob>0")
+        if use_grads: unsupported.append("use_grads=True")
+        if normalize not in ("per_feature", None, False): unsupported.append(f"normalize={normalize}")
+        if window not in ("hann", "hamming", "blackman", "bartlett", "none", None): unsupported.append(f"window={window}")
+        if unsupported:
+            raise NotImplementedError("MI355X front-end does not implement: " + ", ".join(unsupported))
+        self.log_zero_guard_value = log_zero_guard_value
+        self.sample_rate = sample_rate
+        self.win_length = n_window_size
+        self.hop_length = n_window_stride
+        self.n_fft = n_fft or 2 ** math.ceil(math.log2(self.win_length))
+        if self.n_fft != 512:
+            raise NotImplementedError("MI355X front-end is specialised for n_fft = 512")
+        self.stft_pad_amount = None
+        self.exact_pad = False
+        windows = {"hann": torch.hann_window, "hamming": torch.hamming_window, "blackman": torch.blackman_window,
+                   "bartlett": torch.bartlett_window, "none": None, None: None}
+        fn = windows.get(window)
+        win = fn(self.win_length, periodic=False) if fn else torch.ones(self.win_length)
+        self.register_buffer("window", win)
+        self.normalize = normalize
+        self.log = log
+        self.dither = dither
+        self.frame_splicing = frame_splicing
+        self.nfilt = nfilt
+        self.preemph = preemph
+        self.pad_to = pad_to
+        highfreq = highfreq or sample_rate / 2
+        fb = torch.tensor(slaney_mel_filterbank(sample_rate, self.n_fft, nfilt, lowfreq, highfreq, mel_norm)).unsqueeze(0)
+        self.register_buffer("fb", fb)
+        max_length = int(self.get_seq_len(torch.tensor(max_duration * sample_rate, dtype=torch.float)))
+        max_pad = pad_to - (max_length % pad_to) if pad_to > 0 else 0
+        self.max_length = max_length + max_pad
+        self.pad_value = pad_value
+        self.mag_power = mag_power
+        self.log_zero_guard_type = log_zero_guard_type
+        self._sparse = None
+        self._sparse_key = None
+        self._seed = 0
+
+    def get_seq_len(self, seq_len):
+        pad_amount = self.n_fft // 2 * 2
+        return torch.floor_divide(seq_len + pad_amount - self.n_fft, self.hop_length).to(dtype=torch.long)
+
+    @property
+    def filter_banks(self):
+        return self.fb
+
+    def _fb_sparse(self):
+        key = (self.fb.data_ptr(), self.fb._version, str(self.fb.device))
+        if self._sparse is None or self._sparse_key != key:
+            self._sparse = tuple(t.to(self.fb.device) for t in sparsify_filterbank(self.fb))
+            self._sparse_key = key
+        return self._sparse
+
+    @torch.no_grad()
+    def forward(self, x, seq_len, linear_spec=False, out_dtype=torch.float32):
+        from .. import ops
+
+        if linear_spec:
+            raise NotImplementedError("linear_spec=True is not on the Conformer-CTC path")
+        seq_len_unfixed = self.get_seq_len(seq_len)
+        out_len = torch.where(seq_len == 0, torch.zeros_like(seq_len_unfixed), seq_len_unfixed)
+        x = x.contiguous()
+        dither = self.dither if (self.training and self.dither > 0) else 0.0
+        self._seed = (self._seed + 1) & 0x7FFFFFFF
+        lg = self.log_zero_guard_value
+        if isinstance(lg, str):
+            lg = torch.finfo(torch.float32).tiny if lg == "tiny" else torch.finfo(torch.float32).eps
+        raw = ops.logmel(x, seq_len.to(torch.int64), self.window.float(), self._fb_sparse(), self.nfilt,
+                         hop=self.hop_length, n_fft=self.n_fft, preemph=self.preemph, dither=dither, seed=self._seed,
+                         log_guard=float(lg))
+        feat = ops.feat_normalize(raw, out_len, normalize=bool(self.normalize), pad_value=float(self.pad_value),
+                                  out_dtype=out_dtype)
+        pad_to = self.pad_to
+        if pad_to == "max":
+            feat = nn.functional.pad(feat, (0, self.max_length - feat.size(-1)), value=self.pad_value)
+        elif pad_to > 0:
+            pad_amt = feat.size(-1) % pad_to
+            if pad_amt != 0:
+                feat = nn.functional.pad(feat, (0, pad_to - pad_amt), value=self.pad_value)
+        return feat, out_len
+
+
+class AudioToMelSpectrogramPreprocessor(NeuralModule):
+    """audio_preprocessing.py:111 -- identical kwargs (:214-244) and typed I/O (:188-212)."""
+
+    @property
+    def input_types(self):
+        return OrderedDict({"input_signal": NeuralType(("B", "T"), AudioSignal(freq=self._sample_rate)),
+                            "length": NeuralType(tuple("B"), LengthsType())})
+
+    @property
+    def output_types(self):
+        return OrderedDict({"processed_signal": NeuralType(("B", "D", "T"), MelSpectrogramType()),
+                            "processed_length": NeuralType(tuple("B"), LengthsType())})
+
+    def __init__(self, sample_rate=16000, window_size=0.02, window_stride=0.01, n_window_size=None, n_window_stride=None,
+                 window="hann", normalize="per_feature", n_fft=None, preemph=0.97, features=64, lowfreq=0, highfreq=None,
+                 log=True, log_zero_guard_type="add", log_zero_guard_value=2 ** -24, dither=1e-5, pad_to=16,
+                 frame_splicing=1, exact_pad=False, pad_value=0, mag_power=2.0, rng=None, nb_augmentation_prob=0.0,
+                 nb_max_freq=4000, use_torchaudio: bool = False, mel_norm="slaney", stft_exact_pad=False, stft_conv=False):
+        super().__init__()
+        self._sample_rate = sample_rate
+        if window_size and n_window_size:
+            raise ValueError(f"{self} received both window_size and n_window_size. Only one should be specified.")
+        if window_stride and n_window_stride:
+            raise ValueError(f"{self} received both window_stride and n_window_stride. Only one should be specified.")
+        if window_size:
+            n_window_size = int(window_size * self._sample_rate)
+        if window_stride:
+            n_window_stride = int(window_stride * self._sample_rate)
+        if use_torchaudio:
+            raise NotImplementedError("use_torchaudio=True is not supported by the MI355X front-end")
+        self.win_length = n_window_size
+        self.hop_length = n_window_stride
+        self.register_buffer("dtype_sentinel_tensor", torch.tensor((), dtype=torch.float32), persistent=False)
+        self.featurizer = FilterbankFeatures(
+            sample_rate=self._sample_rate, n_window_size=n_window_size, n_window_stride=n_window_stride, window=window,
+            normalize=normalize, n_fft=n_fft, preemph=preemph, nfilt=features, lowfreq=lowfreq, highfreq=highfreq, log=log,
+            log_zero_guard_type=log_zero_guard_type, log_zero_guard_value=log_zero_guard_value, dither=dither, pad_to=pad_to,
+            frame_splicing=frame_splicing, exact_pad=exact_pad, pad_value=pad_value, mag_power=mag_power, rng=rng,
+            nb_augmentation_prob=nb_augmentation_prob, nb_max_freq=nb_max_freq, mel_norm=mel_norm,
+            stft_exact_pad=stft_exact_pad, stft_conv=stft_conv)
+
+    @typecheck()
+    @torch.no_grad()
+    def forward(self, input_signal, length):
+        # the reference casts a non-fp32 input to fp32 with a warning (audio_preprocessing.py:95-101)
+        feats, out_len = self.featurizer(input_signal.to(torch.float32), length)
+        return feats.to(self.dtype_sentinel_tensor.dtype), out_len
+
+    def get_features(self, input_signal, length):
+        return self.featurizer(input_signal, length)
+
+    @property
+    def filter_banks(self):
+        return self.featurizer.filter_banks
+
+    def input_example(self, max_batch: int = 8, max_dim: int = 32000, min_length: int = 200):
+        dev = self.filter_banks.device
+        signals = torch.randn(size=[max_batch, max_dim], device=dev)
+        lengths = torch.randint(low=min_length, high=max_dim, size=[max_batch], device=dev)
+        lengths[0] = max_dim
+        return signals, lengths

@@ -1,0 +1,255 @@
+"""Thin Python wrappers over the C ABI (include/mi355x_asr.h): torch tensors in, device pointers + sizes out.
+
+torch is used for device memory, streams and torch.distributed only.  Every function launches on
+`torch.cuda.current_stream()` and returns immediately.  No CPU / eager fallbacks exist: a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from ._lib import GemmDesc, PackEntry, check, lib
+
+F32, BF16 = 0, 1
+EPI_STORE, EPI_SWISH_DROP, EPI_RESID, EPI_DSWISH, EPI_RELU_MASK, EPI_MUL_POS = range(6)
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t) -> int:
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise ValueError(f"unsupported dtype {t.dtype if isinstance(t, torch.Tensor) else t}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise RuntimeError("nemo_amd kernels run on MI355X only: got a CPU tensor (there is no CPU fallback)")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Dropout:
+    """(key, threshold, scale) triple understood by the kernels; p == 0 -> off."""
+    __slots__ = ("key", "threshold", "scale")
+
+    def __init__(self, p: float = 0.0, seed: int = 0, site: int = 0):
+        if p <= 0.0:
+            self.key, self.threshold, self.scale = 0, 0, 1.0
+        else:
+            self.key = (seed * 0x9E3779B1 + site * 0x85EBCA77 + 0x1234567) & 0xFFFFFFFF
+            self.threshold = max(1, min(0xFFFFFFFF, int(p * 4294967296.0)))
+            self.scale = 1.0 / (1.0 - p)
+
+
+NO_DROP = Dropout()
+
+
+def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=False, transB=False, in_dtype=None, c_dtype=None, batch=1, nb0=0,
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, alpha=1.0, epi=EPI_STORE, atomic=False, splitk=1, aux_in=None,
+         aux_out=None, ldaux=0, drop: Dropout = NO_DROP, row_len=None, rows_per_b=1, rows_inner=1,
+         a_off=0, b_off=0, c_off=0):
+    """C[M,N] = epi(A @ B^T) -- see mi355x_gemm.  A/B/Cm are tensors whose storage holds the (strided) operands;
+    *_off are element offsets into them (head / column slices)."""
+    d = GemmDesc()
+    esA, esC = A.element_size(), Cm.element_size()
+    d.A = _ptr(A) + a_off * esA
+    d.B = _ptr(B) + b_off * B.element_size()
+    d.C = _ptr(Cm) + c_off * esC
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.transA, d.transB = int(transA), int(transB)
+    d.in_dtype = dt(A) if in_dtype is None else in_dtype
+    d.c_dtype = dt(Cm) if c_dtype is None else c_dtype
+    d.batch, d.nb0 = batch, (nb0 if nb0 > 0 else batch)
+    d.sA0, d.sA1 = sA
+    d.sB0, d.sB1 = sB
+    d.sC0, d.sC1 = sC
+    d.bias = _ptr(bias)
+    d.alpha = alpha
+    d.epilogue, d.atomic, d.splitk = epi, int(atomic), splitk
+    d.aux_in = _ptr(aux_in)
+    d.aux_in_dtype = dt(aux_in) if aux_in is not None else 0
+    d.aux_out = _ptr(aux_out)
+    d.aux_out_dtype = dt(aux_out) if aux_out is not None else 0
+    d.ldaux = ldaux if ldaux else ldc
+    d.drop_key, d.drop_threshold, d.drop_scale = drop.key, drop.threshold, drop.scale
+    d.row_len = _ptr(row_len)
+    d.rows_per_b, d.rows_inner = rows_per_b, rows_inner
+    check(lib.mi355x_gemm(C.byref(d), _stream()), "gemm")
+
+
+# ------------------------------------------------------------------------------------------------ front-end
+def logmel(audio, audio_len, window, fb_sparse, n_mels, *, hop=160, n_fft=512, preemph=0.97, dither=0.0, seed=0,
+           log_guard=2.0 ** -24, out=None):
+    B, S = audio.shape
+    T = 1 + S // hop
+    if out is None:
+        out = torch.empty(B, n_mels, T, device=audio.device, dtype=torch.float32)
+    st, ln, off, w = fb_sparse
+    check(lib.mi355x_logmel_fwd(_ptr(audio), _ptr(audio_len), _ptr(window), window.numel(), hop, n_fft, _ptr(st), _ptr(ln),
+                                _ptr(off), _ptr(w), n_mels, preemph if preemph is not None else 0.0, dither, seed & 0xFFFFFFFF,
+                                log_guard, _ptr(out), B, S, T, _stream()), "logmel_fwd")
+    return out
+
+
+def feat_normalize(x, seq_len, out=None, normalize=True, pad_value=0.0, out_dtype=torch.float32):
+    B, n_mels, T = x.shape
+    if out is None:
+        out = torch.empty(B, n_mels, T, device=x.device, dtype=out_dtype)
+    check(lib.mi355x_feat_normalize(_ptr(x), _ptr(seq_len), _ptr(out), dt(out), B, n_mels, T, int(normalize), pad_value,
+                                    _stream()), "feat_normalize")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ sub-sampling
+def conv1_fwd(mel, w, bias, out, len0, len1, C_):
+    B, F, T = mel.shape
+    check(lib.mi355x_subsample_conv1_fwd(_ptr(mel), _ptr(w), _ptr(bias), _ptr(out), dt(out), _ptr(len0), _ptr(len1), B, F, T,
+                                         C_, _stream()), "subsample_conv1_fwd")
+
+
+def conv1_bwd(dout, mel, len0, dw, db, C_):
+    B, F, T = mel.shape
+    check(lib.mi355x_subsample_conv1_bwd(_ptr(dout), dt(dout), _ptr(mel), _ptr(len0), _ptr(dw), _ptr(db), B, F, T, C_,
+                                         _stream()), "subsample_conv1_bwd")
+
+
+def im2col(x, col, B, T1, F1, C_):
+    check(lib.mi355x_im2col_3x3s2(_ptr(x), _ptr(col), dt(x), B, T1, F1, C_, _stream()), "im2col")
+
+
+def col2im_relu(dcol, act, din, B, T1, F1, C_):
+    check(lib.mi355x_col2im_3x3s2_relu(_ptr(dcol), _ptr(act), _ptr(din), dt(dcol), B, T1, F1, C_, _stream()), "col2im")
+
+
+# ------------------------------------------------------------------------------------------------ norms / reductions
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d, eps=1e-5):
+    check(lib.mi355x_layernorm_fwd(_ptr(x), dt(x), _ptr(gamma), _ptr(beta), _ptr(y), dt(y), _ptr(mean), _ptr(rstd), M, d, eps,
+                                   _stream()), "layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, accumulate, dgamma, dbeta, M, d):
+    check(lib.mi355x_layernorm_bwd(_ptr(dy), dt(dy), _ptr(x), dt(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
+                                   int(accumulate), _ptr(dgamma), _ptr(dbeta), M, d, _stream()), "layernorm_bwd")
+
+
+def colsum(x, out, M, N, ld=None, alpha=1.0, x_off=0):
+    check(lib.mi355x_colsum(_ptr(x) + x_off * x.element_size(), dt(x), ld if ld is not None else N, _ptr(out), M, N, alpha,
+                            _stream()), "colsum")
+
+
+def log_softmax_fwd(logits, ld_in, logp, ld_out, M, C_):
+    check(lib.mi355x_log_softmax_fwd(_ptr(logits), ld_in, _ptr(logp), ld_out, M, C_, _stream()), "log_softmax_fwd")
+
+
+def log_softmax_bwd(dlogp, logp, ld, dlogits, ld_out, M, C_, scale=1.0):
+    check(lib.mi355x_log_softmax_bwd(_ptr(dlogp), _ptr(logp), ld, _ptr(dlogits), dt(dlogits), ld_out, M, C_, scale, _stream()),
+          "log_softmax_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ block glue
+def glu_fwd(x, out, lens, T, M, d):
+    check(lib.mi355x_glu_fwd(_ptr(x), _ptr(out), dt(x), _ptr(lens), T, M, d, _stream()), "glu_fwd")
+
+
+def glu_bwd(x, dout, din, lens, T, M, d):
+    check(lib.mi355x_glu_bwd(_ptr(x), _ptr(dout), _ptr(din), dt(x), _ptr(lens), T, M, d, _stream()), "glu_bwd")
+
+
+def drop_scale_cast(x, out, n, alpha=1.0, drop: Dropout = NO_DROP):
+    check(lib.mi355x_drop_scale_cast(_ptr(x), dt(x), _ptr(out), dt(out), n, alpha, drop.key, drop.threshold, drop.scale,
+                                     _stream()), "drop_scale_cast")
+
+
+def qbias(qkv, ldq, u, v, qu, qv, M, d):
+    check(lib.mi355x_qbias(_ptr(qkv), ldq, _ptr(u), _ptr(v), _ptr(qu), _ptr(qv), dt(qkv), M, d, _stream()), "qbias")
+
+
+def add2(a, b, out, ldo, M, d, out_off=0):
+    check(lib.mi355x_add2(_ptr(a), _ptr(b), dt(a), _ptr(out) + out_off * out.element_size(), dt(out), ldo, M, d, _stream()),
+          "add2")
+
+
+def relpos_softmax_fwd(ac, bdf, s_out, pd_out, lens, H, B, T, Tp, Pp, scale, drop: Dropout = NO_DROP):
+    check(lib.mi355x_relpos_softmax_fwd(_ptr(ac), _ptr(bdf), _ptr(s_out), _ptr(pd_out), dt(s_out), _ptr(lens), H, B, T, Tp, Pp,
+                                        scale, drop.key, drop.threshold, drop.scale, _stream()), "relpos_softmax_fwd")
+
+
+def relpos_softmax_bwd(dpd, s_in, dscore, dbdf, H, B, T, Tp, Pp, scale, drop: Dropout = NO_DROP):
+    check(lib.mi355x_relpos_softmax_bwd(_ptr(dpd), dt(dpd), _ptr(s_in), _ptr(dscore), _ptr(dbdf), dt(s_in), H, B, T, Tp, Pp,
+                                        scale, drop.key, drop.threshold, drop.scale, _stream()), "relpos_softmax_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ conv module
+def dwconv_fwd(x, w, bias, y, stats, B, T, d, k):
+    check(lib.mi355x_dwconv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), dt(x), _ptr(stats), B, T, d, k, _stream()), "dwconv_fwd")
+
+
+def dwconv_bwd(dy, x, w, dx, dw, dbias, B, T, d, k):
+    check(lib.mi355x_dwconv_bwd(_ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(dbias), dt(x), B, T, d, k, _stream()),
+          "dwconv_bwd")
+
+
+def bn_finalize(stats, count, mean, rstd, running_mean, running_var, momentum, eps, d):
+    check(lib.mi355x_bn_finalize(_ptr(stats), float(count), _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var),
+                                 momentum, eps, d, _stream()), "bn_finalize")
+
+
+def bn_eval_stats(running_mean, running_var, mean, rstd, eps, d):
+    check(lib.mi355x_bn_eval_stats(_ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(rstd), eps, d, _stream()),
+          "bn_eval_stats")
+
+
+def bn_swish_fwd(x, mean, rstd, gamma, beta, y, M, d):
+    check(lib.mi355x_bn_swish_fwd(_ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(y), dt(x), M, d, _stream()),
+          "bn_swish_fwd")
+
+
+def bn_swish_bwd_reduce(dy, x, mean, rstd, gamma, beta, sums, M, d):
+    check(lib.mi355x_bn_swish_bwd_reduce(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums), dt(x),
+                                         M, d, _stream()), "bn_swish_bwd_reduce")
+
+
+def bn_swish_bwd_apply(dy, x, mean, rstd, gamma, beta, sums, count, training, dx, M, d):
+    check(lib.mi355x_bn_swish_bwd_apply(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums),
+                                        float(count), int(training), _ptr(dx), dt(x), M, d, _stream()), "bn_swish_bwd_apply")
+
+
+def bn_param_grad(sums, dgamma, dbeta, d):
+    check(lib.mi355x_bn_param_grad(_ptr(sums), _ptr(dgamma), _ptr(dbeta), d, _stream()), "bn_param_grad")
+
+
+# ------------------------------------------------------------------------------------------------ loss / optimizer
+def ctc_loss(logp, targets, in_len, tgt_len, blank, grad=None, grad_scale=1.0, zero_infinity=True):
+    """logp f32 [B,T,C] contiguous; returns per-utterance nll [B]; fills `grad` (same shape as logp) if given."""
+    B, T, C_ = logp.shape
+    U = targets.shape[1]
+    S = 2 * U + 1
+    alpha = torch.empty(B, T, S, device=logp.device, dtype=torch.float32)
+    beta = torch.empty(B, T, S, device=logp.device, dtype=torch.float32)
+    nll = torch.empty(B, device=logp.device, dtype=torch.float32)
+    check(lib.mi355x_ctc_loss(_ptr(logp), _ptr(targets), _ptr(in_len), _ptr(tgt_len), _ptr(alpha), _ptr(beta), _ptr(nll),
+                              _ptr(grad), B, T, C_, U, blank, grad_scale, int(zero_infinity), _stream()), "ctc_loss")
+    return nll
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    check(lib.mi355x_adamw_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), lr, beta1, beta2,
+                                eps, weight_decay, step, grad_scale, _stream()), "adamw_step")
+
+
+def pack_weights(table_dev, n_entries, total_tiles, out_dtype):
+    check(lib.mi355x_pack_weights(_ptr(table_dev), n_entries, total_tiles, out_dtype, _stream()), "pack_weights")
+
+
+def fill_f32(t, value=0.0):
+    check(lib.mi355x_fill_f32(_ptr(t), t.numel(), value, _stream()), "fill_f32")

@@ -1,0 +1,470 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against the CPU oracle (plain torch fp32 / numpy restatements)
+on the same seeded inputs.  Tolerances: fp32 kernels 1e-4..1e-3 relative (north_star: 1e-3 rel fp32); bf16 MFMA
+kernels are compared against an fp32 computation on the bf16-rounded operands (so only accumulation order differs)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import conformer_ref as R
+from oracle import ctc_ref
+
+dev = "cuda"
+
+
+def ops():
+    from nemo_amd import ops as _ops
+    return _ops
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("shape", [(300, 200, 136), (1000, 512, 512), (130, 129, 64)])
+def test_gemm_layouts(dtype, layout, shape):
+    o = ops()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(N, K, generator=g)  # asymmetric on purpose (transpose-detecting)
+    Aq, Bq = A.to(dtype), Bm.to(dtype)
+    ref = Aq.float() @ Bq.float().t()
+    tA, tB = layout[0] == "T", layout[1] == "N"  # "NN": B stored [K][N]; "TN": A stored [K][M], B stored [K][N]
+    pad8 = lambda n: (n + 7) // 8 * 8
+    if tA:
+        Ast = torch.zeros(K, pad8(M), dtype=dtype); Ast[:, :M] = Aq.t(); lda = pad8(M)
+    else:
+        Ast = Aq.contiguous(); lda = K
+    if tB:
+        Bst = torch.zeros(K, pad8(N), dtype=dtype); Bst[:, :N] = Bq.t(); ldb = pad8(N)
+    else:
+        Bst = Bq.contiguous(); ldb = K
+    Cd = torch.full((M, N), float("nan"), device=dev)
+    o.gemm(Ast.to(dev), Bst.to(dev), Cd, M, N, K, lda, ldb, N, transA=tA, transB=tB)
+    torch.cuda.synchronize()
+    assert rel_err(Cd, ref) < (2e-5 if dtype == torch.float32 else 1e-4), (layout, shape, rel_err(Cd, ref))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(dtype):
+    o = ops()
+    M, N, K = 260, 384, 192
+    g = torch.Generator().manual_seed(2)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) * 0.1).to(dtype)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    acc = A.float() @ W.float().t() + bias
+    Ad, Wd, bd, resd = A.to(dev), W.to(dev), bias.to(dev), res.to(dev)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    # STORE with alpha, bf16/f32 out
+    out = torch.empty(M, N, device=dev, dtype=dtype)
+    o.gemm(Ad, Wd, out, M, N, K, K, K, N, bias=bd, alpha=0.5)
+    assert rel_err(out, 0.5 * acc) < tol
+    # SWISH_DROP (no dropout): aux_out = pre-act, C = swish
+    h = torch.empty(M, N, device=dev, dtype=dtype)
+    a = torch.empty(M, N, device=dev, dtype=dtype)
+    o.gemm(Ad, Wd, a, M, N, K, K, K, N, bias=bd, epi=o.EPI_SWISH_DROP, aux_out=h)
+    assert rel_err(h, acc) < tol and rel_err(a, acc * torch.sigmoid(acc)) < tol
+    # RESID: C(f32) = res + alpha*(acc)
+    r2 = torch.empty(M, N, device=dev)
+    o.gemm(Ad, Wd, r2, M, N, K, K, K, N, bias=bd, alpha=0.5, epi=o.EPI_RESID, aux_in=resd)
+    assert rel_err(r2, res + 0.5 * acc) < tol
+    # RESID in place
+    r3 = resd.clone()
+    o.gemm(Ad, Wd, r3, M, N, K, K, K, N, bias=bd, alpha=1.0, epi=o.EPI_RESID, aux_in=r3)
+    assert rel_err(r3, res + acc) < tol
+    # DSWISH: C = acc * swish'(aux)
+    pre = torch.randn(M, N, generator=g)
+    sg = torch.sigmoid(pre)
+    o.gemm(Ad, Wd, out, M, N, K, K, K, N, epi=o.EPI_DSWISH, aux_in=pre.to(dev).to(dtype))
+    pre_q = pre.to(dtype).float(); sg = torch.sigmoid(pre_q)
+    assert rel_err(out, (acc - bias) * (sg * (1 + pre_q * (1 - sg)))) < tol
+    # MUL_POS
+    o.gemm(Ad, Wd, out, M, N, K, K, K, N, epi=o.EPI_MUL_POS, aux_in=pre.to(dev).to(dtype))
+    assert rel_err(out, (acc - bias) * (pre_q > 0)) < tol
+    # RELU_MASK: rows m = (b, t, f) with 4 inner rows; lens per b
+    rows_per_b, inner = 52, 4  # 5 batches x 13 t x 4
+    lens = torch.tensor([13, 7, 1, 0, 10], dtype=torch.int64)
+    o.gemm(Ad, Wd, out, M, N, K, K, K, N, bias=bd, epi=o.EPI_RELU_MASK, row_len=lens.to(dev), rows_per_b=rows_per_b,
+           rows_inner=inner)
+    m = torch.arange(M)
+    keep = ((m % rows_per_b) // inner) < lens[m // rows_per_b]
+    assert rel_err(out, torch.relu(acc) * keep[:, None]) < tol
+    # atomic split-K accumulate on top of existing content
+    base = torch.ones(M, N, device=dev)
+    o.gemm(Ad, Wd, base, M, N, K, K, K, N, atomic=True, splitk=3)
+    assert rel_err(base, 1.0 + (acc - bias)) < tol
+    torch.cuda.synchronize()
+
+
+def test_gemm_batched_strided_bf16():
+    """attention-style: q [B*T, 3d] head slices, scores [H,B,T,Tp] -- two-level batch strides."""
+    o = ops()
+    Bn, H, T, dk = 3, 4, 77, 32
+    d = H * dk
+    Tp = 128
+    g = torch.Generator().manual_seed(3)
+    qkv = bf(torch.randn(Bn * T, 3 * d, generator=g))
+    ref = torch.einsum("bihe,bjhe->hbij", qkv[:, :d].float().view(Bn, T, H, dk), qkv[:, d:2 * d].float().view(Bn, T, H, dk))
+    out = torch.zeros(H, Bn, T, Tp, device=dev)
+    qd = qkv.to(dev)
+    o.gemm(qd, qd, out, T, T, dk, 3 * d, 3 * d, Tp, batch=H * Bn, nb0=Bn, sA=(T * 3 * d, dk), sB=(T * 3 * d, dk),
+           sC=(T * Tp, Bn * T * Tp), b_off=d)
+    torch.cuda.synchronize()
+    assert rel_err(out[..., :T], ref) < 1e-4
+    # P @ V  (NN): probs [H,B,T,Tp] bf16 @ v -> ctx [B*T, d] written strided
+    p = bf(torch.rand(H, Bn, T, Tp, generator=g)); p[..., T:] = 0
+    ctx = torch.zeros(Bn * T, d, device=dev, dtype=torch.bfloat16)
+    o.gemm(p.to(dev), qd, ctx, T, dk, Tp, Tp, 3 * d, d, transB=True, batch=H * Bn, nb0=Bn, sA=(T * Tp, Bn * T * Tp),
+           sB=(T * 3 * d, dk), sC=(T * d, dk), b_off=2 * d)
+    v = qkv[:, 2 * d:].float().view(Bn, T, H, dk)
+    ref2 = torch.einsum("hbij,bjhe->bihe", p.float()[..., :T], v).reshape(Bn * T, d)
+    torch.cuda.synchronize()
+    assert rel_err(ctx, ref2) < 1e-2
+
+
+def test_gemm_dropout_consistency():
+    """EPI_SWISH_DROP forward mask == mask regenerated by drop_scale_cast (same key, idx = m*N+n)."""
+    o = ops()
+    M, N, K = 128, 256, 64
+    A = torch.ones(M, K, device=dev); W = torch.ones(N, K, device=dev) / K
+    drop = o.Dropout(0.25, seed=7, site=3)
+    h = torch.empty(M, N, device=dev); a = torch.empty(M, N, device=dev)
+    o.gemm(A, W, a, M, N, K, K, K, N, epi=o.EPI_SWISH_DROP, aux_out=h, drop=drop)
+    ones = torch.ones(M, N, device=dev); m2 = torch.empty(M, N, device=dev)
+    o.drop_scale_cast(ones, m2, M * N, 1.0, drop)
+    torch.cuda.synchronize()
+    sw = 1.0 * torch.sigmoid(torch.tensor(1.0)).item()
+    assert torch.allclose(a, m2 * sw, rtol=1e-5)
+    keep = (m2 > 0).float().mean().item()
+    assert abs(keep - 0.75) < 0.02, keep
+    assert torch.allclose(m2[m2 > 0], torch.tensor(1 / 0.75, device=dev))
+
+
+# ---------------------------------------------------------------------------------------------- LayerNorm etc.
+@pytest.mark.parametrize("d", [176, 512])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16)])
+def test_layernorm(d, xdt, ydt):
+    o = ops()
+    M = 333
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(M, d, generator=g) * 2 + 0.5
+    gamma = torch.randn(d, generator=g); beta = torch.randn(d, generator=g)
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    y_ref = F.layer_norm(xr, (d,), gr, br, 1e-5)
+    dy = torch.randn(M, d, generator=g).to(ydt)
+    y_ref.backward(dy.float())
+    xd = x.to(dev); y = torch.empty(M, d, device=dev, dtype=ydt)
+    mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+    o.layernorm_fwd(xd, gamma.to(dev), beta.to(dev), y, mean, rstd, M, d)
+    assert rel_err(y, y_ref) < (1e-5 if ydt == torch.float32 else 5e-3)
+    dres = torch.ones(M, d, device=dev)
+    dg = torch.zeros(d, device=dev); db = torch.zeros(d, device=dev)
+    o.layernorm_bwd(dy.to(dev), xd, gamma.to(dev), mean, rstd, dres, True, dg, db, M, d)
+    torch.cuda.synchronize()
+    assert rel_err(dres - 1.0, xr.grad) < 1e-4
+    assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+
+
+def test_colsum_logsoftmax():
+    o = ops()
+    M, C_ = 700, 129
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, 136, generator=g)
+    out = torch.ones(C_, device=dev)
+    o.colsum(x.to(dev), out, M, C_, ld=136, alpha=2.0)
+    assert rel_err(out, 1 + 2 * x[:, :C_].sum(0)) < 1e-5
+    logits = x[:, :C_].contiguous().requires_grad_(True)
+    lp_ref = torch.log_softmax(logits, -1)
+    dl = torch.randn(M, C_, generator=g)
+    lp_ref.backward(dl)
+    lp = torch.empty(M, C_, device=dev)
+    o.log_softmax_fwd(x.to(dev), 136, lp, C_, M, C_)
+    assert rel_err(lp, lp_ref) < 1e-5
+    dx = torch.full((M, 136), float("nan"), device=dev)
+    o.log_softmax_bwd(dl.to(dev), lp, C_, dx, 136, M, C_, 1.0)
+    torch.cuda.synchronize()
+    assert rel_err(dx[:, :C_], logits.grad) < 1e-5
+    assert torch.all(dx[:, C_:] == 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_glu(dtype):
+    o = ops()
+    Bn, T, d = 3, 50, 64
+    lens = torch.tensor([50, 31, 7])
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(Bn * T, 2 * d, generator=g).to(dtype)
+    xr = x.float().requires_grad_(True)
+    valid = (torch.arange(T)[None] < lens[:, None]).reshape(-1, 1).float()
+    ref = xr[:, :d] * torch.sigmoid(xr[:, d:]) * valid
+    dout = torch.randn(Bn * T, d, generator=g).to(dtype)
+    ref.backward(dout.float())
+    out = torch.empty(Bn * T, d, device=dev, dtype=dtype)
+    o.glu_fwd(x.to(dev), out, lens.to(dev), T, Bn * T, d)
+    din = torch.empty(Bn * T, 2 * d, device=dev, dtype=dtype)
+    o.glu_bwd(x.to(dev), dout.to(dev), din, lens.to(dev), T, Bn * T, d)
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(out, ref) < tol and rel_err(din, xr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_relpos_softmax(dtype):
+    o = ops()
+    H, Bn, T = 2, 3, 45
+    Tp, Pp = 64, 96
+    lens = torch.tensor([45, 30, 1])
+    g = torch.Generator().manual_seed(7)
+    ac = torch.randn(H, Bn, T, Tp, generator=g).requires_grad_(True)
+    bdf = torch.randn(H, Bn, T, Pp, generator=g).requires_grad_(True)
+    scale = 0.3
+    ii = torch.arange(T)[:, None]; jj = torch.arange(T)[None]
+    bd = bdf[:, :, ii, T - 1 + jj - ii]
+    scores = (ac[..., :T] + bd) * scale
+    valid = torch.arange(T)[None] < lens[:, None]
+    masked = ~(valid[:, :, None] & valid[:, None, :])
+    sc = scores.masked_fill(masked[None], -10000.0)
+    s_ref = torch.softmax(sc, -1).masked_fill(masked[None], 0.0)
+    dpd = torch.randn(H, Bn, T, Tp, generator=g)
+    (s_ref * dpd[..., :T]).sum().backward()
+    s = torch.full((H, Bn, T, Tp), float("nan"), device=dev, dtype=dtype)
+    o.relpos_softmax_fwd(ac.detach().to(dev), bdf.detach().to(dev), s, None, lens.to(dev), H, Bn, T, Tp, Pp, scale)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(s[..., :T], s_ref) < tol
+    assert torch.all(s[..., T:] == 0)
+    dscore = torch.full((H, Bn, T, Tp), float("nan"), device=dev, dtype=dtype)
+    dbdf = torch.full((H, Bn, T, Pp), float("nan"), device=dev, dtype=dtype)
+    o.relpos_softmax_bwd(dpd.to(dev), s, dscore, dbdf, H, Bn, T, Tp, Pp, scale)
+    torch.cuda.synchronize()
+    assert rel_err(dscore[..., :T], ac.grad[..., :T]) < 3 * tol
+    assert rel_err(dbdf, bdf.grad) < 3 * tol
+    assert torch.all(dscore[..., T:] == 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dwconv_bn_swish(dtype):
+    o = ops()
+    Bn, T, d, k = 3, 150, 80, 31
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(Bn, T, d, generator=g).to(dtype)
+    w = torch.randn(d, 1, k, generator=g) * 0.2
+    bias = torch.randn(d, generator=g)
+    gamma = torch.rand(d, generator=g) + 0.5; beta = torch.randn(d, generator=g) * 0.1
+    xr = x.float().requires_grad_(True); wr = w.clone().requires_grad_(True); br = bias.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True); ber = beta.clone().requires_grad_(True)
+    c_ref = F.conv1d(F.pad(xr.transpose(1, 2), (15, 15)), wr, br, groups=d)  # [B,d,T]
+    c_q = c_ref.to(dtype).float() if dtype == torch.bfloat16 else c_ref
+    mean = c_q.mean((0, 2)); var = c_q.var((0, 2), unbiased=False)
+    z = (c_ref - mean[None, :, None]) * torch.rsqrt(var[None, :, None] + 1e-5) * gr[None, :, None] + ber[None, :, None]
+    y_ref = (z * torch.sigmoid(z)).transpose(1, 2)
+    dy = torch.randn(Bn, T, d, generator=g).to(dtype)
+    y_ref.backward(dy.float())
+    # device
+    xd = x.to(dev); c = torch.empty(Bn, T, d, device=dev, dtype=dtype)
+    stats = torch.zeros(2, d, device=dev, dtype=torch.float64)
+    o.dwconv_fwd(xd, w.to(dev), bias.to(dev), c, stats, Bn, T, d, k)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(c, c_ref.transpose(1, 2)) < tol
+    mu = torch.empty(d, device=dev); rs = torch.empty(d, device=dev)
+    rm = torch.zeros(d, device=dev); rv = torch.ones(d, device=dev)
+    n = Bn * T
+    o.bn_finalize(stats, n, mu, rs, rm, rv, 0.1, 1e-5, d)
+    assert rel_err(mu, mean) < 1e-3 and rel_err(rs, torch.rsqrt(var + 1e-5)) < 1e-3
+    assert rel_err(rm, 0.1 * mean) < 1e-3 and rel_err(rv, 0.9 + 0.1 * var * n / (n - 1)) < 1e-3
+    y = torch.empty(Bn, T, d, device=dev, dtype=dtype)
+    o.bn_swish_fwd(c, mu, rs, gamma.to(dev), beta.to(dev), y, n, d)
+    assert rel_err(y, y_ref) < 2 * tol
+    sums = torch.zeros(2, d, device=dev, dtype=torch.float64)
+    o.bn_swish_bwd_reduce(dy.to(dev), c, mu, rs, gamma.to(dev), beta.to(dev), sums, n, d)
+    dc = torch.empty(Bn, T, d, device=dev, dtype=dtype)
+    o.bn_swish_bwd_apply(dy.to(dev), c, mu, rs, gamma.to(dev), beta.to(dev), sums, n, True, dc, n, d)
+    dgam = torch.zeros(d, device=dev); dbet = torch.zeros(d, device=dev)
+    o.bn_param_grad(sums, dgam, dbet, d)
+    assert rel_err(dgam, gr.grad) < 5 * tol and rel_err(dbet, ber.grad) < 5 * tol
+    dx = torch.empty(Bn, T, d, device=dev, dtype=dtype)
+    dw = torch.zeros(d, 1, k, device=dev); dbias = torch.zeros(d, device=dev)
+    o.dwconv_bwd(dc, xd, w.to(dev), dx, dw, dbias, Bn, T, d, k)
+    torch.cuda.synchronize()
+    assert rel_err(dx, xr.grad) < 5 * tol, rel_err(dx, xr.grad)
+    assert rel_err(dw, wr.grad) < 5 * tol, rel_err(dw, wr.grad)
+    # dbias is analytically ~0 under batch-stat BN; compare absolutely against the scale of dw
+    assert (dbias.cpu() - br.grad).abs().max() < 5 * tol * wr.grad.abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_subsampling_pieces(dtype):
+    o = ops()
+    Bn, Fq, T, C_ = 2, 80, 61, 32
+    g = torch.Generator().manual_seed(9)
+    mel = torch.randn(Bn, Fq, T, generator=g)
+    len0 = torch.tensor([61, 40]); len1 = R.conv_out_len(len0, 1)
+    w1 = torch.randn(C_, 1, 3, 3, generator=g) * 0.3; b1 = torch.randn(C_, generator=g) * 0.1
+    T1, F1 = (T - 1) // 2 + 1, (Fq - 1) // 2 + 1
+    x = mel.transpose(1, 2).unsqueeze(1)
+    tm0 = (torch.arange(T)[None] < len0[:, None]).float().view(Bn, 1, T, 1)
+    tm1 = (torch.arange(T1)[None] < len1[:, None]).float().view(Bn, 1, T1, 1)
+    w1r = w1.clone().requires_grad_(True); b1r = b1.clone().requires_grad_(True)
+    o1_ref = torch.relu(F.conv2d(x * tm0, w1r, b1r, stride=2, padding=1)) * tm1  # [B,C,T1,F1]
+    out1 = torch.empty(Bn, T1, F1, C_, device=dev, dtype=dtype)
+    o.conv1_fwd(mel.to(dev), w1.to(dev), b1.to(dev), out1, len0.to(dev), len1.to(dev), C_)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(out1, o1_ref.permute(0, 2, 3, 1)) < tol
+    # conv1 backward (params): feed a gated upstream grad
+    dout1 = (torch.randn(Bn, T1, F1, C_, generator=g) * (o1_ref.permute(0, 2, 3, 1) > 0)).to(dtype)
+    o1_ref.backward(dout1.float().permute(0, 3, 1, 2))
+    dw = torch.zeros(C_, 1, 3, 3, device=dev); db = torch.zeros(C_, device=dev)
+    o.conv1_bwd(dout1.to(dev), mel.to(dev), len0.to(dev), dw, db, C_)
+    assert rel_err(dw, w1r.grad) < 5 * tol and rel_err(db, b1r.grad) < 5 * tol
+    # im2col + GEMM == conv2d
+    T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+    col = torch.empty(Bn * T2 * F2, 9 * C_, device=dev, dtype=dtype)
+    o.im2col(out1, col, Bn, T1, F1, C_)
+    w2 = torch.randn(C_, C_, 3, 3, generator=g) * 0.1
+    w2p = w2.permute(0, 2, 3, 1).reshape(C_, 9 * C_).to(dtype)
+    out2 = torch.empty(Bn * T2 * F2, C_, device=dev, dtype=torch.float32)
+    o.gemm(col, w2p.to(dev), out2, Bn * T2 * F2, C_, 9 * C_, 9 * C_, 9 * C_, C_)
+    o1q = out1.float().cpu().permute(0, 3, 1, 2)
+    ref2 = F.conv2d(o1q, w2.to(dtype).float(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, C_)
+    assert rel_err(out2, ref2) < (1e-4 if dtype == torch.float32 else 2e-3)
+    # col2im with relu gate == conv2d input-gradient * (act > 0)
+    dcol = torch.randn(Bn * T2 * F2, 9 * C_, generator=g).to(dtype)
+    din = torch.empty(Bn, T1, F1, C_, device=dev, dtype=dtype)
+    o.col2im_relu(dcol.to(dev), out1, din, Bn, T1, F1, C_)
+    cols = dcol.float().view(Bn, T2 * F2, 9, C_).permute(0, 3, 2, 1).reshape(Bn, C_ * 9, T2 * F2)  # fold wants (C*kh*kw)
+    fold = F.fold(cols, (T1, F1), kernel_size=3, stride=2, padding=1)  # [B,C,T1,F1]
+    ref_din = fold.permute(0, 2, 3, 1) * (out1.float().cpu() > 0)
+    torch.cuda.synchronize()
+    assert rel_err(din, ref_din) < 2 * tol
+
+
+# ---------------------------------------------------------------------------------------------- mel front-end
+def _fb_sparse(fb):
+    from nemo_amd.modules.audio_preprocessing import sparsify_filterbank
+    return tuple(t.to(dev) for t in sparsify_filterbank(fb))
+
+
+def test_logmel_vs_reference_fixture(golden_dir):
+    o = ops()
+    z = np.load(os.path.join(golden_dir, "ref_mel_b3.npz"))
+    audio = torch.from_numpy(z["audio"]); alen = torch.from_numpy(z["audio_len"])
+    fb = torch.from_numpy(z["fb"][0]); win = torch.from_numpy(z["window"])
+    raw = o.logmel(audio.to(dev), alen.to(dev), win.to(dev), _fb_sparse(fb), 80)
+    seq = torch.from_numpy(z["mel_len"]).to(dev)
+    feat = o.feat_normalize(raw, seq)
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(z["mel"])
+    err = (feat.cpu() - ref).abs().max().item()
+    # north_star: mel features within 1e-3 relative fp32 of the reference CPU path (features are O(1) after normalisation)
+    assert err < 1e-3 * max(1.0, ref.abs().max().item()), err
+    assert np.allclose(feat.cpu().numpy(), z["mel"], rtol=1e-3, atol=1e-3)
+
+
+def test_logmel_ragged_and_padding_invariance():
+    o = ops()
+    g = torch.Generator().manual_seed(11)
+    S = 16000 + 37
+    audio = 0.1 * torch.randn(2, S, generator=g)
+    alen = torch.tensor([S, 4000])
+    fb = torch.from_numpy(R.mel_filterbank()); win = R.hann_window_sym(400)
+    ref, ref_len = R.log_mel_features(audio, alen)
+    raw = o.logmel(audio.to(dev), alen.to(dev), win.to(dev), _fb_sparse(fb), 80)
+    feat = o.feat_normalize(raw, ref_len.to(dev))
+    assert (feat.cpu() - ref).abs().max() < 1e-3
+    # right-padding the batch must not change valid frames (reference test_padding_and_batch_size_invariance.py:22-45)
+    audio2 = torch.cat([audio, torch.zeros(2, 3200)], 1)
+    raw2 = o.logmel(audio2.to(dev), alen.to(dev), win.to(dev), _fb_sparse(fb), 80)
+    feat2 = o.feat_normalize(raw2, ref_len.to(dev))
+    torch.cuda.synchronize()
+    T = feat.shape[-1]
+    assert (feat2[..., : int(ref_len[1])][1] - feat[..., : int(ref_len[1])][1]).abs().max() < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- CTC
+@pytest.mark.parametrize("name", ["test_case_small", "test_case_small_blank_last", "test_case_big_tensor"])
+def test_ctc_known_answers(golden_dir, name):
+    o = ops()
+    case = json.load(open(os.path.join(golden_dir, "ctc_known_answers.json")))[name]
+    acts = torch.tensor(case["acts"], dtype=torch.float32)
+    Bn, T, C_ = acts.shape
+    labels = torch.tensor(case["labels"], dtype=torch.int64)
+    logp = torch.log_softmax(acts, -1).to(dev).contiguous()
+    grad = torch.empty_like(logp)
+    nll = o.ctc_loss(logp, labels.to(dev), torch.full((Bn,), T, dtype=torch.int64, device=dev),
+                     torch.tensor([len(l) for l in case["labels"]], device=dev), case["blank"], grad=grad)
+    torch.cuda.synchronize()
+    assert np.allclose(nll.cpu().numpy(), case["expected_costs"], rtol=1e-5)
+    g = grad.cpu()
+    gx = g - torch.exp(logp.cpu()) * g.sum(-1, keepdim=True)  # log-softmax backward of the reference harness
+    assert np.allclose(gx.numpy(), np.array(case["expected_grads"]), atol=2e-6, rtol=1e-3)
+
+
+def test_ctc_random_ragged_vs_oracle():
+    o = ops()
+    rng = np.random.RandomState(0)
+    Bn, T, C_, U = 5, 60, 17, 12
+    acts = rng.randn(Bn, T, C_).astype(np.float32)
+    tgt = rng.randint(0, C_ - 1, size=(Bn, U))
+    tgt[0, 3] = tgt[0, 2]
+    in_len = np.array([60, 41, 25, 13, 8]); tl = np.array([12, 9, 12, 6, 7])  # last one infeasible (7 labels w/ repeats?)
+    tgt[4, :7] = [1, 1, 1, 1, 1, 1, 1]  # needs 13 frames > 8 -> infinite -> zero_infinity
+    logp = torch.log_softmax(torch.from_numpy(acts), -1)
+    nll_ref, g_ref = ctc_ref.ctc_loss_and_grad(logp.numpy().astype(np.float64), tgt, in_len, tl, blank=C_ - 1)
+    grad = torch.empty(Bn, T, C_, device=dev)
+    nll = o.ctc_loss(logp.to(dev).contiguous(), torch.from_numpy(tgt).to(dev), torch.from_numpy(in_len).to(dev),
+                     torch.from_numpy(tl).to(dev), C_ - 1, grad=grad, grad_scale=0.5)
+    torch.cuda.synchronize()
+    assert nll_ref[4] == 0.0
+    assert np.allclose(nll.cpu().numpy(), nll_ref, rtol=1e-4, atol=1e-5)
+    assert np.allclose(grad.cpu().numpy(), 0.5 * g_ref, rtol=1e-3, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------- optimizer / packing
+def test_adamw_matches_torch():
+    o = ops()
+    n = 4096 + 64
+    g = torch.Generator().manual_seed(12)
+    p0 = torch.randn(n, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-3)
+    p = p0.to(dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        pr.grad = gr.clone(); opt.step()
+        o.adamw_step(p, (gr * 2).to(dev), m, v, 1e-2, 0.9, 0.98, 1e-8, 1e-3, step, grad_scale=0.5)
+    torch.cuda.synchronize()
+    assert rel_err(p, pr) < 1e-5
+
+
+def test_pack_weights():
+    from nemo_amd.packing import PackPlan
+    g = torch.Generator().manual_seed(13)
+    W = torch.randn(70, 45, generator=g).to(dev)
+    W2 = torch.randn(16, 8, 3, 3, generator=g).to(dev)
+    plan = PackPlan(torch.bfloat16, dev)
+    a = plan.add_matrix("w", W)                       # [70, 48] (K padded to 8)
+    at = plan.add_matrix("wt", W, transpose=True)     # [45, 72]
+    c2 = plan.add_conv3x3("c2", W2)                   # [16, 72]: k = (kh*3+kw)*8 + ci
+    plan.finalize()
+    plan.run()
+    torch.cuda.synchronize()
+    assert torch.equal(plan["w"][:, :45].float().cpu(), W.to(torch.bfloat16).float().cpu())
+    assert torch.all(plan["w"][:, 45:] == 0)
+    assert torch.equal(plan["wt"][:, :70].float().cpu(), W.t().to(torch.bfloat16).float().cpu())
+    assert torch.equal(plan["c2"].float().cpu(), W2.permute(0, 2, 3, 1).reshape(16, 72).to(torch.bfloat16).float().cpu())
