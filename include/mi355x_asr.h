@@ -39,6 +39,7 @@ typedef struct mi355x_gemm_desc {
   const void* A; const void* B; void* C;
   int M, N, K;
   long long lda, ldb, ldc;          /* row pitch (elements) of the stored matrices                               */
+  long long c_col_stride;           /* column stride of C (0/1 = dense); lets wgrad write the reference's layouts  */
   int transA, transB;
   int in_dtype;                     /* dtype of A and B                                                          */
   int c_dtype;                      /* dtype of C                                                                */
@@ -137,6 +138,9 @@ int mi355x_bn_param_grad(const void* sums, void* dgamma, void* dbeta, int d, voi
 int mi355x_ctc_loss(const void* logp, const void* targets, const void* in_len, const void* tgt_len, void* alpha_ws,
                     void* beta_ws, void* nll, void* grad, int B, int Tmax, int C, int Umax, int blank, float grad_scale,
                     int zero_infinity, void* stream);
+
+/* x[r,:] *= vec[r] (f32): per-utterance upstream gradient applied to the CTC gradient (autograd of losses/ctc.py:52-66) */
+int mi355x_row_scale(void* x, const void* vec, long long rows, long long cols, void* stream);
 
 /* ---- optimizer / weight packing (modelPT.py:650-823 AdamW; no reference analogue for packing) ------------------ */
 int mi355x_adamw_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, long long n, float lr, float beta1,

@@ -19,7 +19,7 @@ class GemmDesc(C.Structure):
     _fields_ = [
         ("A", vp), ("B", vp), ("C", vp),
         ("M", i32), ("N", i32), ("K", i32),
-        ("lda", i64), ("ldb", i64), ("ldc", i64),
+        ("lda", i64), ("ldb", i64), ("ldc", i64), ("c_col_stride", i64),
         ("transA", i32), ("transB", i32),
         ("in_dtype", i32), ("c_dtype", i32),
         ("batch", i32), ("nb0", i32),
@@ -74,6 +74,7 @@ SIGNATURES = {
     "mi355x_bn_swish_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, f64, i32, vp, i32, i64, i32, vp],
     "mi355x_bn_param_grad": [vp, vp, vp, i32, vp],
     "mi355x_ctc_loss": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
+    "mi355x_row_scale": [vp, vp, i64, i64, vp],
     "mi355x_adamw_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
     "mi355x_pack_weights": [vp, i32, i64, i32, vp],
     "mi355x_fill_f32": [vp, i64, f32, vp],

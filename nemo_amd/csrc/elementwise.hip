@@ -193,6 +193,13 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const TD* __res
   }
 }
 
+// x[r, :] *= vec[r]   (per-utterance upstream gradient of the CTC loss)
+__global__ __launch_bounds__(256) void row_scale_kernel(float* __restrict__ x, const float* __restrict__ vec, long long rows,
+                                                        long long cols) {
+  const long long n = rows * cols;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] *= vec[i / cols];
+}
+
 // =================================================================================================
 static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
@@ -262,5 +269,11 @@ extern "C" int mi355x_relpos_softmax_bwd(const void* dpd, int dpd_dt, const void
   DISPATCH_DT(s_dt, TS, DISPATCH_DT(dpd_dt, TD,
     hipLaunchKernelGGL((relpos_softmax_bwd_kernel<TS, TD>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const TD*)dpd,
                        (const TS*)s_in, (TS*)dscore, (TS*)dbdf, H, B, T, Tp, Pp, scale, dc)));
+  return mi_check_launch();
+}
+extern "C" int mi355x_row_scale(void* x, const void* vec, long long rows, long long cols, void* stream) {
+  if (!x || !vec || rows <= 0 || cols <= 0) return MI_ERR_ARG;
+  hipLaunchKernelGGL(row_scale_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, (float*)x,
+                     (const float*)vec, rows, cols);
   return mi_check_launch();
 }

@@ -32,7 +32,7 @@ enum {
 struct GemmP {
   const void* A; const void* B; void* C;
   int M, N, K;
-  long long lda, ldb, ldc;
+  long long lda, ldb, ldc, csc;       // csc: column stride of C (1 = dense rows)
   int transA, transB;                 // 1: operand stored [K][rows] (reduction-major)
   int batch, nb0;                     // z -> z0 = z % nb0, z1 = z / nb0
   long long sA0, sA1, sB0, sB1, sC0, sC1;
@@ -52,7 +52,7 @@ __device__ __forceinline__ void stx(void* p, long long i, int dt, float v) {
 }
 
 __device__ __forceinline__ void epilogue(const GemmP& p, int z, long long coff, int m, int n, float acc) {
-  const long long ci = coff + (long long)m * p.ldc + n;
+  const long long ci = coff + (long long)m * p.ldc + (long long)n * p.csc;
   const long long ai = coff + (long long)m * p.ldaux + n;  // aux shares the batch offset convention of C
   float v = acc;
   if (p.bias) v += p.bias[n];
@@ -306,7 +306,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   GemmP p;
   p.A = d->A; p.B = d->B; p.C = d->C;
   p.M = d->M; p.N = d->N; p.K = d->K;
-  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.csc = d->c_col_stride > 0 ? d->c_col_stride : 1;
   p.transA = d->transA; p.transB = d->transB;
   p.batch = d->batch > 0 ? d->batch : 1; p.nb0 = d->nb0 > 0 ? d->nb0 : p.batch;
   p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
@@ -334,10 +334,12 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
     // 16-byte alignment contract of the vector loads
     if ((p.lda & 7) || (p.ldb & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return MI_ERR_ARG;
     if ((p.sA0 & 7) || (p.sA1 & 7) || (p.sB0 & 7) || (p.sB1 & 7)) return MI_ERR_ARG;
-    // K-contiguous operands are read in 8-element chunks: K must be a multiple of 8 (pad with zeros).
-    // Reduction-major operands need only pitch >= roundup8(rows): a partial chunk's extra columns feed
-    // output rows/cols >= M/N that are never stored.
-    if ((!p.transA || !p.transB) && (p.K & 7)) return MI_ERR_ARG;
+    // K-contiguous operands are read in 8-element chunks: their pitch must cover roundup8(K) and the pad elements
+    // k in [K, roundup8(K)) must be finite (zero) in memory.  Reduction-major operands need pitch >= roundup8(rows):
+    // a partial chunk's extra columns only feed output rows/cols >= M/N, which are never stored.
+    const int K8 = (p.K + 7) & ~7;
+    if (!p.transA && p.lda < K8) return MI_ERR_ARG;
+    if (!p.transB && p.ldb < K8) return MI_ERR_ARG;
     if (p.transA && p.lda < ((p.M + 7) & ~7)) return MI_ERR_ARG;
     if (p.transB && p.ldb < ((p.N + 7) & ~7)) return MI_ERR_ARG;
     const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;

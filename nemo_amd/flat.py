@@ -1,0 +1,84 @@
+"""Flat parameter / gradient storage for the drop-in modules.
+
+Every trainable parameter of a module tree stays an ordinary `nn.Parameter` with the reference's name and shape (the
+`.nemo` state-dict ABI), but its storage is a view into ONE contiguous fp32 buffer and its `.grad` a view into ONE
+contiguous fp32 gradient buffer.  That is what lets the MI355X path run a single fused AdamW launch per step, zero the
+gradients with one fill, write wgrad results straight into their final location, and all-reduce gradients bucket by
+bucket over RCCL without a gather copy (reference: 646+ separate tensors through torch DDP buckets / torch AdamW).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+from torch import nn
+
+ALIGN = 64  # elements; keeps every parameter 256-B aligned for the 16-B vector loads of the kernels
+
+
+class FlatParams:
+    def __init__(self, module: nn.Module):
+        self.module = module
+        self.flat: torch.Tensor = None
+        self.grad: torch.Tensor = None
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        self.order: List[str] = []
+        self.generation = 0  # bumped on every (re)build: dependants (packed weight plans, optimizer state) key on it
+
+    def _params(self):
+        return [(n, p) for n, p in self.module.named_parameters() if p.dtype == torch.float32]
+
+    def is_valid(self) -> bool:
+        if self.flat is None:
+            return False
+        base, gbase = self.flat.data_ptr(), self.grad.data_ptr()
+        for n, p in self._params():
+            off = self.offsets.get(n)
+            if off is None or p.data_ptr() != base + off[0] * 4:
+                return False
+            if p.grad is None or p.grad.data_ptr() != gbase + off[0] * 4:
+                return False
+        return True
+
+    def build(self, device=None) -> None:
+        params = self._params()
+        if not params:
+            raise ValueError("module has no fp32 parameters")
+        device = device or params[0][1].device
+        total = 0
+        self.offsets, self.order = {}, []
+        for n, p in params:
+            self.offsets[n] = (total, p.numel())
+            self.order.append(n)
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        grad = torch.zeros(total, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for n, p in params:
+                off, num = self.offsets[n]
+                view = flat[off: off + num].view(p.shape)
+                view.copy_(p.data.to(device))
+                gview = grad[off: off + num].view(p.shape)
+                if p.grad is not None:
+                    gview.copy_(p.grad.to(device))
+                p.data = view
+                p.grad = gview
+        self.flat, self.grad = flat, grad
+        self.generation += 1
+
+    def ensure(self, device=None) -> None:
+        if not self.is_valid():
+            self.build(device)
+
+    def range_of(self, prefix: str) -> Tuple[int, int]:
+        """[start, end) element range (aligned) covering every parameter whose name starts with `prefix`."""
+        names = [n for n in self.order if n.startswith(prefix)]
+        if not names:
+            raise KeyError(prefix)
+        start = min(self.offsets[n][0] for n in names)
+        end = max((self.offsets[n][0] + self.offsets[n][1] + ALIGN - 1) // ALIGN * ALIGN for n in names)
+        return start, end
+
+    def zero_grad(self) -> None:
+        from . import ops
+        ops.fill_f32(self.grad, 0.0)

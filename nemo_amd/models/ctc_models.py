@@ -1,0 +1,171 @@
+"""Drop-in for `nemo.collections.asr.models.EncDecCTCModel` (models/ctc_models.py:49) restricted to the training hot
+path: config-driven construction of preprocessor / encoder / decoder / loss (ctc_models.py:52-85), `forward`
+(:495-546), `training_step` (:549-604, returns {'loss', 'log'}), optimizer set-up from the `optim` config section
+(modelPT.py:650-823 -> fused AdamW + NoamAnnealing) and `.nemo` save / restore (modelPT.py:395,436).
+
+Lightning is not required: `fit_step()` is the body Lightning's loop would run per batch (zero_grad -> training_step ->
+backward with bucketed RCCL gradient all-reduce overlapped on a side stream -> optimizer + scheduler step)."""
+from __future__ import annotations
+
+import copy
+from typing import Any, Dict, Optional
+
+import torch
+from torch import nn
+
+from ..core import NeuralModule, Serialization, load_nemo, resolve_target, save_nemo
+from ..modules import AudioToMelSpectrogramPreprocessor, ConformerEncoder, ConvASRDecoder, CTCLoss
+from ..optim import FusedAdamW, NoamAnnealing
+from ..parallel import GradSync
+
+_DEFAULT_TARGETS = {
+    "preprocessor": "nemo.collections.asr.modules.AudioToMelSpectrogramPreprocessor",
+    "encoder": "nemo.collections.asr.modules.ConformerEncoder",
+    "decoder": "nemo.collections.asr.modules.ConvASRDecoder",
+}
+
+
+def _build(section: str, cfg: Dict[str, Any]):
+    cfg = dict(cfg)
+    cfg.setdefault("_target_", _DEFAULT_TARGETS[section])
+    return Serialization.from_config_dict(cfg)
+
+
+class EncDecCTCModel(nn.Module):
+    def __init__(self, cfg: Dict[str, Any], trainer=None):
+        super().__init__()
+        cfg = copy.deepcopy(dict(cfg))
+        self._cfg = cfg
+        self.trainer = trainer
+        self.world_size = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world_size = torch.distributed.get_world_size()
+        self.preprocessor = _build("preprocessor", cfg["preprocessor"])
+        self.encoder = _build("encoder", cfg["encoder"])
+        dec = dict(cfg["decoder"])
+        if dec.get("feat_in") is None:  # ctc_models.py:65-67
+            dec["feat_in"] = self.encoder._feat_out
+        if not dec.get("feat_in"):
+            raise ValueError("param feat_in of the decoder's config is not set!")
+        if dec.get("num_classes", -1) < 1 and dec.get("vocabulary") is not None:  # ctc_models.py:71-77
+            dec["num_classes"] = len(dec["vocabulary"])
+        self.decoder = _build("decoder", dec)
+        self.loss = CTCLoss(num_classes=self.decoder.num_classes_with_blank - 1, zero_infinity=True,
+                            reduction=cfg.get("ctc_reduction", "mean_batch"))
+        sa = cfg.get("spec_augment")
+        if sa and (sa.get("freq_masks", 0) or sa.get("time_masks", 0)):
+            raise NotImplementedError("SpectrogramAugmentation is the next row of the scope table (SURVEY.md 8f rank 1)")
+        self.spec_augmentation = None
+        self._optimizer: Optional[FusedAdamW] = None
+        self._scheduler: Optional[NoamAnnealing] = None
+        self._syncs = None
+        self.global_step = 0
+
+    # ------------------------------------------------------------------ forward (ctc_models.py:495-546)
+    def forward(self, input_signal=None, input_signal_length=None, processed_signal=None, processed_signal_length=None):
+        has_input_signal = input_signal is not None and input_signal_length is not None
+        has_processed_signal = processed_signal is not None and processed_signal_length is not None
+        if (has_input_signal ^ has_processed_signal) is False:
+            raise ValueError(f"{self} Arguments ``input_signal`` and ``input_signal_length`` are mutually exclusive "
+                             " with ``processed_signal`` and ``processed_signal_len`` arguments.")
+        if not has_processed_signal:
+            processed_signal, processed_signal_length = self.preprocessor(input_signal=input_signal, length=input_signal_length)
+        encoded, encoded_len = self.encoder(audio_signal=processed_signal, length=processed_signal_length)
+        log_probs = self.decoder(encoder_output=encoded)
+        greedy_predictions = log_probs.argmax(dim=-1, keepdim=False)
+        return log_probs, encoded_len, greedy_predictions
+
+    # ------------------------------------------------------------------ training_step (ctc_models.py:549-604)
+    def training_step(self, batch, batch_nb=0):
+        signal, signal_len, transcript, transcript_len = batch
+        log_probs, encoded_len, predictions = self.forward(input_signal=signal, input_signal_length=signal_len)
+        loss_value = self.loss(log_probs=log_probs, targets=transcript, input_lengths=encoded_len,
+                               target_lengths=transcript_len)
+        logs = {"train_loss": loss_value.detach(), "global_step": self.global_step}
+        if self._scheduler is not None:
+            logs["learning_rate"] = self._scheduler.get_last_lr()
+        return {"loss": loss_value, "log": logs}
+
+    # ------------------------------------------------------------------ optimisation
+    def flats(self):
+        return [self.encoder.flat_parameters(), self.decoder.flat_parameters()]
+
+    def setup_optimization(self, optim_config: Optional[Dict[str, Any]] = None):
+        oc = dict(optim_config if optim_config is not None else self._cfg.get("optim", {}))
+        name = oc.get("name", "adamw")
+        if name != "adamw":
+            raise NotImplementedError(f"optimizer '{name}': the Conformer-CTC recipes use adamw")
+        self._optimizer = FusedAdamW(self.flats(), lr=oc.get("lr", 1e-3), betas=tuple(oc.get("betas", (0.9, 0.999))),
+                                     eps=oc.get("eps", 1e-8), weight_decay=oc.get("weight_decay", 0.0))
+        sched = oc.get("sched")
+        if sched:
+            if sched.get("name") != "NoamAnnealing":
+                raise NotImplementedError(f"scheduler '{sched.get('name')}'")
+            self._scheduler = NoamAnnealing(oc.get("lr", 1e-3), d_model=sched["d_model"], warmup_steps=sched.get("warmup_steps"),
+                                            warmup_ratio=sched.get("warmup_ratio"), max_steps=sched.get("max_steps"),
+                                            min_lr=sched.get("min_lr", 0.0))
+        return self._optimizer, self._scheduler
+
+    def _grad_syncs(self):
+        if self._syncs is None:
+            self._syncs = []
+            for mod in (self.encoder, self.decoder):
+                gs = GradSync(mod.flat_parameters().grad)
+                mod.grad_ready_hook = gs.ready
+                self._syncs.append(gs)
+        return self._syncs
+
+    def fit_step(self, batch):
+        """one optimizer step = what Lightning's loop does per batch with trainer.strategy=ddp"""
+        if self._optimizer is None:
+            self.setup_optimization()
+        syncs = self._grad_syncs() if self.world_size > 1 else []
+        self._optimizer.zero_grad()
+        out = self.training_step(batch, self.global_step)
+        out["loss"].backward()
+        scale = 1.0
+        for gs in syncs:
+            scale = gs.wait()
+        lr = self._scheduler.step() if self._scheduler is not None else None
+        self._optimizer.step(lr=lr, grad_scale=scale)
+        self.global_step += 1
+        return out
+
+    # ------------------------------------------------------------------ .nemo (modelPT.py:395,436)
+    def save_to(self, save_path: str):
+        save_nemo(save_path, dict(self._cfg, target=f"{type(self).__module__}.{type(self).__name__}"), self.state_dict())
+
+    @classmethod
+    def restore_from(cls, restore_path: str, map_location=None, strict: bool = True):
+        cfg, sd = load_nemo(restore_path)
+        cfg.pop("target", None)
+        model = cls(cfg)
+        if map_location is not None:
+            model = model.to(map_location)
+        model.load_state_dict(sd, strict=strict)
+        model.encoder.weights_updated(); model.decoder.weights_updated()
+        return model
+
+
+def conformer_ctc_config(size: str = "large", vocab_size: int = 128, **encoder_overrides) -> Dict[str, Any]:
+    """model section of examples/asr/conf/conformer/conformer_ctc_bpe.yaml (:44-192) for the sizes of its table (:7-17);
+    spec_augment off (next row), tokenizer replaced by an explicit vocabulary size."""
+    sizes = {"small": (176, 4, 16), "medium": (256, 4, 18), "large": (512, 8, 18)}
+    d_model, n_heads, n_layers = sizes[size]
+    enc = dict(feat_in=80, feat_out=-1, n_layers=n_layers, d_model=d_model, subsampling="striding", subsampling_factor=4,
+               subsampling_conv_channels=-1, causal_downsampling=False, ff_expansion_factor=4, self_attention_model="rel_pos",
+               n_heads=n_heads, att_context_size=[-1, -1], att_context_style="regular", xscaling=True, untie_biases=True,
+               pos_emb_max_len=5000, conv_kernel_size=31, conv_norm_type="batch_norm", conv_context_size=None, dropout=0.1,
+               dropout_pre_encoder=0.1, dropout_emb=0.0, dropout_att=0.1, stochastic_depth_drop_prob=0.0,
+               stochastic_depth_mode="linear", stochastic_depth_start_layer=1)
+    enc.update(encoder_overrides)
+    return {
+        "sample_rate": 16000, "ctc_reduction": "mean_batch", "skip_nan_grad": False,
+        "preprocessor": dict(sample_rate=16000, normalize="per_feature", window_size=0.025, window_stride=0.01, window="hann",
+                             features=80, n_fft=512, log=True, frame_splicing=1, dither=1e-5, pad_to=0, pad_value=0.0),
+        "spec_augment": None,
+        "encoder": enc,
+        "decoder": dict(feat_in=None, num_classes=vocab_size, vocabulary=None),
+        "optim": dict(name="adamw", lr=2.0, betas=[0.9, 0.98], weight_decay=1e-3,
+                      sched=dict(name="NoamAnnealing", d_model=d_model, warmup_steps=10000, warmup_ratio=None, min_lr=1e-6)),
+    }

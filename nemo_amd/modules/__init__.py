@@ -1,1 +1,4 @@
 from .audio_preprocessing import AudioToMelSpectrogramPreprocessor, FilterbankFeatures  # noqa: F401
+from .conformer_encoder import ConformerEncoder  # noqa: F401
+from .conv_asr import ConvASRDecoder  # noqa: F401
+from .ctc import CTCLoss  # noqa: F401

@@ -1,0 +1,633 @@
+"""Drop-in for `nemo.collections.asr.modules.ConformerEncoder` (modules/conformer_encoder.py:62) on MI355X.
+
+Same constructor kwargs (:289-329), typed I/O (:221-260), attributes callers touch (`_feat_out`, `subsampling_factor`,
+`pre_encode`, `layers`, `pos_enc`, `set_max_audio_length`, ...) and -- the on-disk ABI -- the same parameter / buffer
+names and shapes, so a reference `.nemo` state-dict loads with strict=True.  The arithmetic is NOT torch's: forward and
+backward are sequenced here in Python over the hand-written HIP kernels of libmi355x_asr.so (one autograd node for the
+whole encoder; activations are channels-last [B*T, d]; gradients are written straight into the flat gradient buffer).
+
+Implemented configuration = what the Conformer-CTC recipes use (examples/asr/conf/conformer/conformer_ctc_bpe.yaml):
+subsampling='striding' (x4), self_attention_model='rel_pos', untied biases, xscaling, batch_norm conv module, full
+attention context.  Anything else raises NotImplementedError at construction (there is no fallback path).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..core import (AcousticEncodedRepresentation, ChannelType, LengthsType, NeuralModule, NeuralType, SpectrogramType,
+                    typecheck)
+from ..flat import FlatParams
+from ..packing import PackPlan
+
+INF_VAL = 10000.0
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------------------------------ parameter containers
+class _FeedForward(nn.Module):  # conformer_modules.py:366 ConformerFeedForward
+    def __init__(self, d_model, d_ff, use_bias=True):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, d_ff, bias=use_bias)
+        self.linear2 = nn.Linear(d_ff, d_model, bias=use_bias)
+
+
+class _Convolution(nn.Module):  # conformer_modules.py:236 ConformerConvolution
+    def __init__(self, d_model, kernel_size):
+        super().__init__()
+        self.pointwise_conv1 = nn.Conv1d(d_model, d_model * 2, kernel_size=1)
+        self.depthwise_conv = nn.Conv1d(d_model, d_model, kernel_size, groups=d_model, padding=0)
+        self.batch_norm = nn.BatchNorm1d(d_model)
+        self.pointwise_conv2 = nn.Conv1d(d_model, d_model, kernel_size=1)
+
+
+class _RelPosMHA(nn.Module):  # multi_head_attention.py:212 RelPositionMultiHeadAttention
+    def __init__(self, n_head, n_feat):
+        super().__init__()
+        self.h, self.d_k = n_head, n_feat // n_head
+        self.linear_q = nn.Linear(n_feat, n_feat)
+        self.linear_k = nn.Linear(n_feat, n_feat)
+        self.linear_v = nn.Linear(n_feat, n_feat)
+        self.linear_out = nn.Linear(n_feat, n_feat)
+        self.linear_pos = nn.Linear(n_feat, n_feat, bias=False)
+        self.pos_bias_u = nn.Parameter(torch.zeros(n_head, self.d_k))
+        self.pos_bias_v = nn.Parameter(torch.zeros(n_head, self.d_k))
+
+
+class ConformerLayer(nn.Module):  # conformer_modules.py:35 (parameter layout only; compute lives in ConformerEncoder)
+    def __init__(self, d_model, d_ff, n_heads, conv_kernel_size):
+        super().__init__()
+        self.fc_factor = 0.5
+        self.norm_feed_forward1 = nn.LayerNorm(d_model)
+        self.feed_forward1 = _FeedForward(d_model, d_ff)
+        self.norm_conv = nn.LayerNorm(d_model)
+        self.conv = _Convolution(d_model, conv_kernel_size)
+        self.norm_self_att = nn.LayerNorm(d_model)
+        self.self_attn = _RelPosMHA(n_heads, d_model)
+        self.norm_feed_forward2 = nn.LayerNorm(d_model)
+        self.feed_forward2 = _FeedForward(d_model, d_ff)
+        self.norm_out = nn.LayerNorm(d_model)
+
+
+class ConvSubsampling(nn.Module):  # subsampling.py:62 ('striding')
+    def __init__(self, subsampling_factor, feat_in, feat_out, conv_channels):
+        super().__init__()
+        self.subsampling_factor = subsampling_factor
+        self._conv_channels = conv_channels
+        self.conv = nn.Sequential(nn.Conv2d(1, conv_channels, 3, stride=2, padding=1), nn.ReLU(True),
+                                  nn.Conv2d(conv_channels, conv_channels, 3, stride=2, padding=1), nn.ReLU(True))
+        f = feat_in
+        for _ in range(2):
+            f = (f + 2 - 3) // 2 + 1
+        self._feat_after = f
+        self.out = nn.Linear(conv_channels * f, feat_out)
+
+
+class RelPositionalEncoding(nn.Module):  # multi_head_attention.py:1056
+    def __init__(self, d_model, dropout_rate, max_len=5000, xscale=None, dropout_rate_emb=0.0):
+        super().__init__()
+        self.d_model, self.xscale, self.max_len = d_model, xscale, max_len
+        self.dropout_rate, self.dropout_rate_emb = dropout_rate, dropout_rate_emb
+
+    def table(self, T: int, device, dtype) -> torch.Tensor:
+        """pos_emb [2T-1, d]: row r <-> relative position T-1-r (multi_head_attention.py:1015-1035,1067-1100)"""
+        d = self.d_model
+        pos = torch.arange(T - 1, -T, -1, dtype=torch.float32).unsqueeze(1)
+        div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(INF_VAL) / d))
+        pe = torch.zeros(2 * T - 1, d)
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        return pe.to(device=device, dtype=dtype).contiguous()
+
+
+class _Saved:
+    """plain attribute bag for activations kept for backward"""
+    pass
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mel, length, token, module):
+        out, enc_len, saved = module._forward_impl(mel, length, save=True)
+        ctx.module, ctx.saved = module, saved
+        ctx.mark_non_differentiable(enc_len)
+        return out, enc_len
+
+    @staticmethod
+    def backward(ctx, dout, _):
+        ctx.module._backward_impl(ctx.saved, dout)
+        ctx.saved = None
+        return None, None, None, None
+
+
+class ConformerEncoder(NeuralModule):
+    @property
+    def input_types(self):
+        return OrderedDict({
+            "audio_signal": NeuralType(("B", "D", "T"), SpectrogramType()),
+            "length": NeuralType(tuple("B"), LengthsType()),
+        })
+
+    @property
+    def output_types(self):
+        return OrderedDict({
+            "outputs": NeuralType(("B", "D", "T"), AcousticEncodedRepresentation()),
+            "encoded_lengths": NeuralType(tuple("B"), LengthsType()),
+        })
+
+    def __init__(self, feat_in, n_layers, d_model, feat_out=-1, causal_downsampling=False, subsampling="striding",
+                 subsampling_factor=4, subsampling_conv_chunking_factor=1, subsampling_conv_channels=-1, reduction=None,
+                 reduction_position=None, reduction_factor=1, ff_expansion_factor=4, self_attention_model="rel_pos",
+                 n_heads=4, att_context_size=None, att_context_probs=None, att_context_style="regular", xscaling=True,
+                 untie_biases=True, pos_emb_max_len=5000, conv_kernel_size=31, conv_norm_type="batch_norm",
+                 conv_context_size=None, use_bias=True, dropout=0.1, dropout_pre_encoder=0.1, dropout_emb=0.1,
+                 dropout_att=0.0, stochastic_depth_drop_prob: float = 0.0, stochastic_depth_mode: str = "linear",
+                 stochastic_depth_start_layer: int = 1, global_tokens: int = 0, global_tokens_spacing: int = 1,
+                 global_attn_separate: bool = False, use_pytorch_sdpa: bool = False, use_pytorch_sdpa_backends=None,
+                 sync_max_audio_length: bool = True, compute_dtype: Optional[torch.dtype] = None):
+        super().__init__()
+        bad = []
+        if subsampling != "striding" or subsampling_factor != 4: bad.append("subsampling != striding x4")
+        if causal_downsampling: bad.append("causal_downsampling")
+        if self_attention_model != "rel_pos": bad.append(f"self_attention_model={self_attention_model}")
+        if att_context_size not in (None, [-1, -1], (-1, -1)): bad.append("limited att_context_size")
+        if not untie_biases: bad.append("tied pos biases")
+        if conv_norm_type != "batch_norm": bad.append(f"conv_norm_type={conv_norm_type}")
+        if conv_context_size is not None: bad.append("conv_context_size")
+        if not use_bias: bad.append("use_bias=False")
+        if reduction: bad.append("reduction")
+        if stochastic_depth_drop_prob != 0.0: bad.append("stochastic depth")
+        if feat_out > 0 and feat_out != d_model: bad.append("feat_out projection")
+        if conv_kernel_size not in (5, 9, 31): bad.append(f"conv_kernel_size={conv_kernel_size}")
+        if d_model % n_heads or d_model % 4: bad.append("d_model not divisible by n_heads / 4")
+        if bad:
+            raise NotImplementedError("MI355X ConformerEncoder does not implement: " + ", ".join(bad))
+        d_ff = d_model * ff_expansion_factor
+        self.d_model, self.n_layers, self._feat_in = d_model, n_layers, feat_in
+        self.n_heads, self.d_k, self.d_ff = n_heads, d_model // n_heads, d_ff
+        self.conv_kernel_size = conv_kernel_size
+        self.subsampling_factor = subsampling_factor
+        self.att_context_style, self.self_attention_model = att_context_style, self_attention_model
+        self.att_context_size = [-1, -1]
+        self.sync_max_audio_length = sync_max_audio_length
+        self.xscale = math.sqrt(d_model) if xscaling else None
+        self.dropout, self.dropout_pre_encoder, self.dropout_att = dropout, dropout_pre_encoder, dropout_att
+        self.dropout_emb = dropout_emb
+        if subsampling_conv_channels == -1:
+            subsampling_conv_channels = d_model
+        self.pre_encode = ConvSubsampling(subsampling_factor, feat_in, d_model, subsampling_conv_channels)
+        self._feat_out = d_model
+        self.pos_emb_max_len = pos_emb_max_len
+        self.pos_enc = RelPositionalEncoding(d_model, dropout_pre_encoder, pos_emb_max_len, self.xscale, dropout_emb)
+        self.layers = nn.ModuleList([ConformerLayer(d_model, d_ff, n_heads, conv_kernel_size) for _ in range(n_layers)])
+        self.out_proj = None
+        self.max_audio_length = pos_emb_max_len
+        self.compute_dtype = compute_dtype  # None: bf16 under torch autocast(bf16), else fp32
+        # SyncBatchNorm semantics across data-parallel ranks (trainer.sync_batchnorm: true in the recipe)
+        self.sync_batchnorm = True
+        self.grad_ready_hook = None  # callable(start, end) on the flat gradient buffer (data-parallel bucketing)
+        # --- engine state (not part of the state-dict)
+        self._flatp = FlatParams(self)
+        self._plans = {}
+        self._ws = {}
+        self._pos_cache = {}
+        self._step_seed = 0
+        self._weights_version = -1
+        self._token = None
+
+    # ------------------------------------------------------------------ reference API surface
+    def set_max_audio_length(self, max_audio_length):
+        self.max_audio_length = max_audio_length
+
+    def update_max_seq_length(self, seq_length: int, device):
+        """conformer_encoder.py:761-779.  The reference all-reduces MAX + .item() (a host sync) every forward to size a
+        cached table; our positional table is built per T on demand, so only the bookkeeping remains."""
+        if seq_length > self.max_audio_length:
+            self.set_max_audio_length(seq_length)
+
+    def flat_parameters(self) -> FlatParams:
+        self._flatp.ensure()
+        return self._flatp
+
+    def weights_updated(self):
+        """call after an optimizer step / load_state_dict: GEMM operand images are re-packed on next forward"""
+        self._weights_version += 1
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.weights_updated()
+        return r
+
+    # ------------------------------------------------------------------ forward (typed)
+    @typecheck()
+    def forward(self, audio_signal, length, cache_last_channel=None, cache_last_time=None, cache_last_channel_len=None,
+                bypass_pre_encode=False):
+        if cache_last_channel is not None or bypass_pre_encode:
+            raise NotImplementedError("streaming caches / bypass_pre_encode are not on the training hot path")
+        if audio_signal.shape[-2] != self._feat_in:
+            raise ValueError(f"If bypass_pre_encode is False, audio_signal should have shape (batch, {self._feat_in}, "
+                             f"n_frame) but got last dimension {audio_signal.shape[-2]}.")  # conformer_encoder.py:569-578
+        if length is None:
+            length = audio_signal.new_full((audio_signal.size(0),), audio_signal.size(-1), dtype=torch.int64)
+        self._flatp.ensure(audio_signal.device)
+        if self._token is None or self._token.device != audio_signal.device:
+            self._token = torch.zeros(1, device=audio_signal.device, requires_grad=True)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if need_grad:
+            return _EncoderFn.apply(audio_signal, length, self._token, self)
+        out, enc_len, _ = self._forward_impl(audio_signal, length)
+        return out, enc_len
+
+    # ------------------------------------------------------------------ helpers
+    def _cdt(self):
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+            return torch.bfloat16
+        return torch.float32
+
+    def _buf(self, name, shape, dtype, device, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self._ws.get(key)
+        if t is None or t.device != device:
+            t = torch.zeros(shape, dtype=dtype, device=device) if zero else torch.empty(shape, dtype=dtype, device=device)
+            self._ws[key] = t
+        return t
+
+    def _plan(self, cdt, device):
+        key = (cdt, str(device), self._flatp.generation)
+        plan = self._plans.get(key)
+        if plan is None:
+            self._plans = {}  # parameters moved: drop images of the old storage
+            p = PackPlan(cdt, device)
+            pf = PackPlan(torch.float32, device)
+            srcs = []
+            pe = self.pre_encode
+            C_, F2 = pe._conv_channels, pe._feat_after
+            p.add_conv3x3("pre.w2", pe.conv[2].weight.data); p.add_conv3x3("pre.w2t", pe.conv[2].weight.data, transpose=True)
+            p.add_fc_permuted("pre.out", pe.out.weight.data, C_, F2)
+            p.add_fc_permuted("pre.outt", pe.out.weight.data, C_, F2, transpose=True)
+            for i, L in enumerate(self.layers):
+                for ff, m in (("ff1", L.feed_forward1), ("ff2", L.feed_forward2)):
+                    p.add_matrix(f"L{i}.{ff}.w1", m.linear1.weight.data); p.add_matrix(f"L{i}.{ff}.w1t", m.linear1.weight.data, True)
+                    p.add_matrix(f"L{i}.{ff}.w2", m.linear2.weight.data); p.add_matrix(f"L{i}.{ff}.w2t", m.linear2.weight.data, True)
+                a = L.self_attn
+                qkv = [a.linear_q.weight.data, a.linear_k.weight.data, a.linear_v.weight.data]
+                p.add_concat(f"L{i}.att.wqkv", qkv); p.add_concat(f"L{i}.att.wqkvt", qkv, transpose=True)
+                p.add_matrix(f"L{i}.att.wo", a.linear_out.weight.data); p.add_matrix(f"L{i}.att.wot", a.linear_out.weight.data, True)
+                p.add_matrix(f"L{i}.att.wpos", a.linear_pos.weight.data)
+                pf.new_image(f"L{i}.att.bqkv", 1, 3 * self.d_model)
+                for j, b in enumerate((a.linear_q.bias.data, a.linear_k.bias.data, a.linear_v.bias.data)):
+                    pf.add_block(f"L{i}.att.bqkv", b, 1, self.d_model, col_off=j * self.d_model, sr1=0, sc1=1)
+                c = L.conv
+                p.add_matrix(f"L{i}.conv.pw1", c.pointwise_conv1.weight.data); p.add_matrix(f"L{i}.conv.pw1t", c.pointwise_conv1.weight.data, True)
+                p.add_matrix(f"L{i}.conv.pw2", c.pointwise_conv2.weight.data); p.add_matrix(f"L{i}.conv.pw2t", c.pointwise_conv2.weight.data, True)
+            p.finalize(); pf.finalize()
+            plan = (p, pf, None, -2)
+            self._plans[key] = plan
+        if plan[3] != self._weights_version:
+            plan[0].run(); plan[1].run()
+            plan = (plan[0], plan[1], plan[2], self._weights_version)
+            self._plans[key] = plan
+        return plan[0], plan[1]
+
+    @staticmethod
+    def _splitk(tiles, K):
+        nk = (K + 63) // 64
+        return max(1, min(nk, 512 // max(tiles, 1)))
+
+    def _wgrad(self, dY, ldy, y_off, X, ldx, x_off, dW, n_out, n_in, rows, ldw=None, w_off=0, col_stride=1):
+        """dW[n_out, n_in] += dY[:, y_off:y_off+n_out]^T @ X[:, x_off:x_off+n_in]   (TN GEMM, atomic split-K)"""
+        t = 128 if dY.dtype == torch.bfloat16 else 64
+        tiles = ((n_out + t - 1) // t) * ((n_in + t - 1) // t)
+        ops.gemm(dY, X, dW, n_out, n_in, rows, ldy, ldx, ldw if ldw is not None else n_in, transA=True, transB=True,
+                 atomic=True, splitk=self._splitk(tiles, rows), a_off=y_off, b_off=x_off, c_off=w_off,
+                 c_col_stride=col_stride, c_dtype=ops.F32)
+
+    def _lens(self, length):
+        l0 = length.to(torch.int64)
+        l1 = torch.div(l0 - 1, 2, rounding_mode="floor") + 1  # floor((n + 2 - 3)/2) + 1, subsampling.py:576-586
+        l2 = torch.div(l1 - 1, 2, rounding_mode="floor") + 1
+        return l0.contiguous(), l1.clamp_(min=0).contiguous(), l2.clamp_(min=0).contiguous()
+
+    # ------------------------------------------------------------------ forward implementation
+    def _forward_impl(self, mel, length, save=False):
+        dev = mel.device
+        cdt = self._cdt()
+        training = self.training
+        W, Wf = self._plan(cdt, dev)
+        B, F_, T = mel.shape
+        mel = mel.to(torch.float32).contiguous()
+        d, H, dk, dff, C_ = self.d_model, self.n_heads, self.d_k, self.d_ff, self.pre_encode._conv_channels
+        T1, F1 = (T - 1) // 2 + 1, (F_ - 1) // 2 + 1
+        T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+        M = B * T2
+        len0, len1, len2 = self._lens(length)
+        self.update_max_seq_length(T2, dev)
+        if training:
+            self._step_seed = (self._step_seed + 1) & 0x3FFFFFFF
+        seed = self._step_seed
+
+        def drop(p, site):
+            return ops.Dropout(p if training else 0.0, seed, site)
+
+        S = _Saved()
+        S.dims = (B, F_, T, T1, F1, T2, F2, M, cdt, training, seed)
+        S.mel, S.len0, S.len2 = mel, len0, len2
+        pe = self.pre_encode
+        # ---- sub-sampling: conv1 (direct) -> im2col -> conv2 (MFMA GEMM, ReLU+mask epilogue) -> out Linear (+xscale, dropout)
+        S.out1 = torch.empty(B, T1, F1, C_, dtype=cdt, device=dev)
+        ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, S.out1, len0, len1, C_)
+        col = self._buf("col", (B * T2 * F2, 9 * C_), cdt, dev)
+        ops.im2col(S.out1, col, B, T1, F1, C_)
+        S.out2 = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
+        ops.gemm(col, W["pre.w2"], S.out2, B * T2 * F2, C_, 9 * C_, 9 * C_, W.pitch("pre.w2"), C_, bias=pe.conv[2].bias,
+                 epi=ops.EPI_RELU_MASK, row_len=len2, rows_per_b=T2 * F2, rows_inner=F2)
+        x = torch.empty(M, d, dtype=torch.float32, device=dev)
+        S.drop_pre = drop(self.dropout_pre_encoder, 100000)
+        ops.gemm(S.out2, W["pre.out"], x, M, d, F2 * C_, F2 * C_, W.pitch("pre.out"), d, bias=pe.out.bias,
+                 alpha=(self.xscale or 1.0), drop=S.drop_pre)
+        # ---- relative positional table (constant)
+        pkey = (T2, cdt, str(dev))
+        pos = self._pos_cache.get(pkey)
+        if pos is None:
+            pos = self.pos_enc.table(T2, dev, cdt)
+            self._pos_cache = {pkey: pos}
+        d_emb = drop(self.dropout_emb, 100001)
+        if d_emb.threshold:  # dropout on the positional table (multi_head_attention.py:1097-1098)
+            posd = torch.empty_like(pos)
+            ops.drop_scale_cast(pos, posd, pos.numel(), 1.0, d_emb)
+            pos = posd
+        S.pos = pos
+        S.layers = []
+        for i, L in enumerate(self.layers):
+            x, sl = self._layer_fwd(i, L, x, S, W, Wf, drop)
+            S.layers.append(sl)
+        out = x.view(B, T2, d).transpose(1, 2)
+        return out, len2, (S if save else None)
+
+    def _ln_fwd(self, ln, x, M, d, out_dtype, dev):
+        y = torch.empty(M, d, dtype=out_dtype, device=dev)
+        mean = torch.empty(M, dtype=torch.float32, device=dev)
+        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+        ops.layernorm_fwd(x, ln.weight, ln.bias, y, mean, rstd, M, d, ln.eps)
+        return y, mean, rstd
+
+    def _ffn_fwd(self, pfx, ff, x, ln, S, sl, W, drop, site, M, d, dff, cdt, dev, tag):
+        y, mean, rstd = self._ln_fwd(ln, x, M, d, cdt, dev)
+        h = torch.empty(M, dff, dtype=cdt, device=dev)
+        a = torch.empty(M, dff, dtype=cdt, device=dev)
+        d_in = drop(self.dropout, site)
+        d_res = drop(self.dropout, site + 1)
+        ops.gemm(y, W[pfx + ".w1"], a, M, dff, d, d, W.pitch(pfx + ".w1"), dff, bias=ff.linear1.bias, epi=ops.EPI_SWISH_DROP,
+                 aux_out=h, drop=d_in)
+        r = torch.empty(M, d, dtype=torch.float32, device=dev)
+        ops.gemm(a, W[pfx + ".w2"], r, M, d, dff, dff, W.pitch(pfx + ".w2"), d, bias=ff.linear2.bias, alpha=0.5,
+                 epi=ops.EPI_RESID, aux_in=x, drop=d_res)
+        setattr(sl, tag, (x, y, mean, rstd, h, a, d_in, d_res))
+        return r
+
+    def _layer_fwd(self, i, L, x, S, W, Wf, drop):
+        B, F_, T, T1, F1, T2, F2, M, cdt, training, seed = S.dims
+        dev = x.device
+        d, H, dk, dff = self.d_model, self.n_heads, self.d_k, self.d_ff
+        P = 2 * T2 - 1
+        Tp, Pp = _pad8(T2), _pad8(P)
+        sl = _Saved()
+        site = i * 16
+        # ---- macaron FFN 1
+        r1 = self._ffn_fwd(f"L{i}.ff1", L.feed_forward1, x, L.norm_feed_forward1, S, sl, W, drop, site, M, d, dff, cdt, dev, "ff1")
+        # ---- rel-pos multi-head self-attention
+        a = L.self_attn
+        y2, mean2, rstd2 = self._ln_fwd(L.norm_self_att, r1, M, d, cdt, dev)
+        qkv = torch.empty(M, 3 * d, dtype=cdt, device=dev)
+        ops.gemm(y2, W[f"L{i}.att.wqkv"], qkv, M, 3 * d, d, d, W.pitch(f"L{i}.att.wqkv"), 3 * d, bias=Wf[f"L{i}.att.bqkv"])
+        p = torch.empty(P, d, dtype=cdt, device=dev)
+        ops.gemm(S.pos, W[f"L{i}.att.wpos"], p, P, d, d, d, W.pitch(f"L{i}.att.wpos"), d)
+        qu = torch.empty(M, d, dtype=cdt, device=dev)
+        qv = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.qbias(qkv, 3 * d, a.pos_bias_u, a.pos_bias_v, qu, qv, M, d)
+        ac = self._buf("ac", (H, B, T2, Tp), torch.float32, dev)
+        bdf = self._buf("bdf", (H, B, T2, Pp), torch.float32, dev)
+        # ac[h,b] = qu_bh @ k_bh^T ; bdf[h,b] = qv_bh @ p_h^T      (z0 = b, z1 = h)
+        ops.gemm(qu, qkv, ac, T2, T2, dk, d, 3 * d, Tp, batch=H * B, nb0=B, sA=(T2 * d, dk), sB=(T2 * 3 * d, dk),
+                 sC=(T2 * Tp, B * T2 * Tp), b_off=d)
+        ops.gemm(qv, p, bdf, T2, P, dk, d, d, Pp, batch=H * B, nb0=B, sA=(T2 * d, dk), sB=(0, dk), sC=(T2 * Pp, B * T2 * Pp))
+        s_ = torch.empty(H, B, T2, Tp, dtype=cdt, device=dev)
+        d_att = drop(self.dropout_att, site + 2)
+        pd = torch.empty(H, B, T2, Tp, dtype=cdt, device=dev) if d_att.threshold else None
+        ops.relpos_softmax_fwd(ac, bdf, s_, pd, S.len2, H, B, T2, Tp, Pp, 1.0 / math.sqrt(dk), d_att)
+        if pd is None:
+            pd = s_
+        ctx = torch.empty(M, d, dtype=cdt, device=dev)
+        # ctx_bh = pd_bh [T,T] @ v_bh [T,dk]   (NN: v is reduction-major inside qkv)
+        ops.gemm(pd, qkv, ctx, T2, dk, T2, Tp, 3 * d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Tp, B * T2 * Tp),
+                 sB=(T2 * 3 * d, dk), sC=(T2 * d, dk), b_off=2 * d)
+        r2 = torch.empty(M, d, dtype=torch.float32, device=dev)
+        d_ares = drop(self.dropout, site + 3)
+        ops.gemm(ctx, W[f"L{i}.att.wo"], r2, M, d, d, d, W.pitch(f"L{i}.att.wo"), d, bias=a.linear_out.bias, epi=ops.EPI_RESID,
+                 aux_in=r1, drop=d_ares)
+        sl.att = (r1, y2, mean2, rstd2, qkv, p, qu, qv, s_, pd, ctx, d_att, d_ares)
+        # ---- convolution module
+        c = L.conv
+        k = self.conv_kernel_size
+        y3, mean3, rstd3 = self._ln_fwd(L.norm_conv, r2, M, d, cdt, dev)
+        pw1 = torch.empty(M, 2 * d, dtype=cdt, device=dev)
+        ops.gemm(y3, W[f"L{i}.conv.pw1"], pw1, M, 2 * d, d, d, W.pitch(f"L{i}.conv.pw1"), 2 * d, bias=c.pointwise_conv1.bias)
+        g = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.glu_fwd(pw1, g, S.len2, T2, M, d)
+        cc = torch.empty(M, d, dtype=cdt, device=dev)
+        bn = c.batch_norm
+        bmean = torch.empty(d, dtype=torch.float32, device=dev)
+        brstd = torch.empty(d, dtype=torch.float32, device=dev)
+        count = float(M)
+        if training:
+            stats = torch.zeros(2, d, dtype=torch.float64, device=dev)
+            ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T2, d, k)
+            count = self._sync_stats(stats, count)
+            ops.bn_finalize(stats, count, bmean, brstd, bn.running_mean, bn.running_var, bn.momentum, bn.eps, d)
+            bn.num_batches_tracked += 1
+        else:
+            ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
+            ops.bn_eval_stats(bn.running_mean, bn.running_var, bmean, brstd, bn.eps, d)
+        z = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, M, d)
+        r3 = torch.empty(M, d, dtype=torch.float32, device=dev)
+        d_cres = drop(self.dropout, site + 4)
+        ops.gemm(z, W[f"L{i}.conv.pw2"], r3, M, d, d, d, W.pitch(f"L{i}.conv.pw2"), d, bias=c.pointwise_conv2.bias,
+                 epi=ops.EPI_RESID, aux_in=r2, drop=d_cres)
+        sl.conv = (r2, y3, mean3, rstd3, pw1, g, cc, bmean, brstd, count, z, d_cres)
+        # ---- macaron FFN 2 + output norm
+        r4 = self._ffn_fwd(f"L{i}.ff2", L.feed_forward2, r3, L.norm_feed_forward2, S, sl, W, drop, site + 5, M, d, dff, cdt, dev, "ff2")
+        xo, mean5, rstd5 = self._ln_fwd(L.norm_out, r4, M, d, torch.float32, dev)
+        sl.out = (r4, mean5, rstd5)
+        return xo, sl
+
+    def _sync_stats(self, stats, count):
+        """SyncBatchNorm: all-reduce the raw f64 sums over the data-parallel group (torch.nn.SyncBatchNorm semantics)."""
+        if self.sync_batchnorm and torch.distributed.is_available() and torch.distributed.is_initialized():
+            ws = torch.distributed.get_world_size()
+            if ws > 1:
+                torch.distributed.all_reduce(stats)
+                return count * ws
+        return count
+
+    # ------------------------------------------------------------------ backward implementation
+    def _backward_impl(self, S, dout):
+        B, F_, T, T1, F1, T2, F2, M, cdt, training, seed = S.dims
+        dev = dout.device
+        d, C_ = self.d_model, self.pre_encode._conv_channels
+        W, Wf = self._plan(cdt, dev)
+        fp = self._flatp
+        dx = dout.transpose(1, 2).contiguous().view(M, d).to(torch.float32)  # no copy when dout is a [B,T,d] view
+        for i in range(self.n_layers - 1, -1, -1):
+            dx = self._layer_bwd(i, self.layers[i], dx, S, S.layers[i], W, Wf)
+            S.layers[i] = None
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(*fp.range_of(f"layers.{i}."))
+        # ---- sub-sampling backward
+        pe = self.pre_encode
+        dxs = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.drop_scale_cast(dx, dxs, M * d, (self.xscale or 1.0), S.drop_pre)
+        ops.colsum(dxs, pe.out.bias.grad, M, d)
+        # d out.weight in the reference's (c, f) column order: batch over f, C column stride F2
+        t = 128 if cdt == torch.bfloat16 else 64
+        tiles = ((d + t - 1) // t) * ((C_ + t - 1) // t) * F2
+        ops.gemm(dxs, S.out2, pe.out.weight.grad, d, C_, M, d, F2 * C_, C_ * F2, transA=True, transB=True, atomic=True,
+                 splitk=self._splitk(tiles, M), batch=F2, nb0=F2, sB=(C_, 0), sC=(1, 0), c_col_stride=F2, c_dtype=ops.F32)
+        dout2 = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
+        ops.gemm(dxs, W["pre.outt"], dout2, M, F2 * C_, d, d, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=S.out2)
+        M2 = B * T2 * F2
+        ops.colsum(dout2, pe.conv[2].bias.grad, M2, C_)
+        col = self._buf("col", (M2, 9 * C_), cdt, dev)
+        ops.im2col(S.out1, col, B, T1, F1, C_)  # recomputed (cheaper than keeping 3 GB alive through the encoder)
+        # d conv2.weight [co, ci, 3, 3]: batch over the 9 taps, column stride 9
+        tiles = ((C_ + t - 1) // t) ** 2 * 9
+        ops.gemm(dout2, col, pe.conv[2].weight.grad, C_, C_, M2, C_, 9 * C_, 9 * C_, transA=True, transB=True, atomic=True,
+                 splitk=self._splitk(tiles, M2), batch=9, nb0=9, sB=(C_, 0), sC=(1, 0), c_col_stride=9, c_dtype=ops.F32)
+        dcol = col  # reuse: col is dead after the wgrad above (stream order)
+        ops.gemm(dout2, W["pre.w2t"], dcol, M2, 9 * C_, C_, C_, W.pitch("pre.w2t"), 9 * C_)
+        dout1 = self._buf("dout1", (B, T1, F1, C_), cdt, dev)
+        ops.col2im_relu(dcol, S.out1, dout1, B, T1, F1, C_)
+        ops.conv1_bwd(dout1, S.mel, S.len0, pe.conv[0].weight.grad, pe.conv[0].bias.grad, C_)
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(*fp.range_of("pre_encode."))
+
+    def _ffn_bwd(self, pfx, ff, ln, saved, dr, W, M, d, dff, cdt, dev):
+        x, y, mean, rstd, h, a, d_in, d_res = saved
+        df = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.drop_scale_cast(dr, df, M * d, 0.5, d_res)
+        ops.colsum(df, ff.linear2.bias.grad, M, d)
+        self._wgrad(df, d, 0, a, dff, 0, ff.linear2.weight.grad, d, dff, M)
+        dh = torch.empty(M, dff, dtype=cdt, device=dev)
+        ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, d, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH, aux_in=h, drop=d_in)
+        ops.colsum(dh, ff.linear1.bias.grad, M, dff)
+        self._wgrad(dh, dff, 0, y, d, 0, ff.linear1.weight.grad, dff, d, M)
+        dy = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.gemm(dh, W[pfx + ".w1t"], dy, M, d, dff, dff, W.pitch(pfx + ".w1t"), d)
+        ops.layernorm_bwd(dy, x, ln.weight, mean, rstd, dr, True, ln.weight.grad, ln.bias.grad, M, d)
+        return dr
+
+    def _layer_bwd(self, i, L, dxo, S, sl, W, Wf):
+        B, F_, T, T1, F1, T2, F2, M, cdt, training, seed = S.dims
+        dev = dxo.device
+        d, H, dk, dff = self.d_model, self.n_heads, self.d_k, self.d_ff
+        P = 2 * T2 - 1
+        Tp, Pp = _pad8(T2), _pad8(P)
+        scale = 1.0 / math.sqrt(dk)
+        # ---- norm_out: dr = dLN(dxo)
+        r4, mean5, rstd5 = sl.out
+        dr = torch.empty(M, d, dtype=torch.float32, device=dev)
+        ln = L.norm_out
+        ops.layernorm_bwd(dxo, r4, ln.weight, mean5, rstd5, dr, False, ln.weight.grad, ln.bias.grad, M, d)
+        # ---- FFN 2
+        dr = self._ffn_bwd(f"L{i}.ff2", L.feed_forward2, L.norm_feed_forward2, sl.ff2, dr, W, M, d, dff, cdt, dev)
+        # ---- convolution module
+        c = L.conv
+        bn = c.batch_norm
+        k = self.conv_kernel_size
+        r2, y3, mean3, rstd3, pw1, g, cc, bmean, brstd, count, z, d_cres = sl.conv
+        db = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.drop_scale_cast(dr, db, M * d, 1.0, d_cres)
+        ops.colsum(db, c.pointwise_conv2.bias.grad, M, d)
+        self._wgrad(db, d, 0, z, d, 0, c.pointwise_conv2.weight.grad, d, d, M)
+        dz = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.gemm(db, W[f"L{i}.conv.pw2t"], dz, M, d, d, d, W.pitch(f"L{i}.conv.pw2t"), d)
+        sums = torch.zeros(2, d, dtype=torch.float64, device=dev)
+        ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, M, d)
+        ops.bn_param_grad(sums, bn.weight.grad, bn.bias.grad, d)
+        if training:
+            self._sync_stats(sums, 0.0)
+        dcc = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, M, d)
+        dg = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.dwconv_bwd(dcc, g, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
+        dpw1 = torch.empty(M, 2 * d, dtype=cdt, device=dev)
+        ops.glu_bwd(pw1, dg, dpw1, S.len2, T2, M, d)
+        ops.colsum(dpw1, c.pointwise_conv1.bias.grad, M, 2 * d)
+        self._wgrad(dpw1, 2 * d, 0, y3, d, 0, c.pointwise_conv1.weight.grad, 2 * d, d, M)
+        dy3 = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.gemm(dpw1, W[f"L{i}.conv.pw1t"], dy3, M, d, 2 * d, 2 * d, W.pitch(f"L{i}.conv.pw1t"), d)
+        ln = L.norm_conv
+        ops.layernorm_bwd(dy3, r2, ln.weight, mean3, rstd3, dr, True, ln.weight.grad, ln.bias.grad, M, d)
+        # ---- self-attention
+        a = L.self_attn
+        r1, y2, mean2, rstd2, qkv, p, qu, qv, s_, pd, ctx, d_att, d_ares = sl.att
+        dao = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.drop_scale_cast(dr, dao, M * d, 1.0, d_ares)
+        ops.colsum(dao, a.linear_out.bias.grad, M, d)
+        self._wgrad(dao, d, 0, ctx, d, 0, a.linear_out.weight.grad, d, d, M)
+        dctx = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.gemm(dao, W[f"L{i}.att.wot"], dctx, M, d, d, d, W.pitch(f"L{i}.att.wot"), d)
+        dqkv = torch.empty(M, 3 * d, dtype=cdt, device=dev)
+        # dpd[h,b] = dctx_bh @ v_bh^T  -> reuse the f32 score workspace
+        dpd = self._buf("ac", (H, B, T2, Tp), torch.float32, dev)
+        ops.gemm(dctx, qkv, dpd, T2, T2, dk, d, 3 * d, Tp, batch=H * B, nb0=B, sA=(T2 * d, dk), sB=(T2 * 3 * d, dk),
+                 sC=(T2 * Tp, B * T2 * Tp), b_off=2 * d)
+        # dv_bh[j,e] = sum_i pd[i,j] dctx[i,e]
+        ops.gemm(pd, dctx, dqkv, T2, dk, T2, Tp, d, 3 * d, transA=True, transB=True, batch=H * B, nb0=B,
+                 sA=(T2 * Tp, B * T2 * Tp), sB=(T2 * d, dk), sC=(T2 * 3 * d, dk), c_off=2 * d)
+        dscore = self._buf("dscore", (H, B, T2, Tp), cdt, dev)
+        dbdf = self._buf("dbdf", (H, B, T2, Pp), cdt, dev)
+        ops.relpos_softmax_bwd(dpd, s_, dscore, dbdf, H, B, T2, Tp, Pp, scale, d_att)
+        dqu = torch.empty(M, d, dtype=cdt, device=dev)
+        dqv = torch.empty(M, d, dtype=cdt, device=dev)
+        # dqu_bh = dscore_bh [T,T] @ k_bh [T,dk]  (NN)
+        ops.gemm(dscore, qkv, dqu, T2, dk, T2, Tp, 3 * d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Tp, B * T2 * Tp),
+                 sB=(T2 * 3 * d, dk), sC=(T2 * d, dk), b_off=d)
+        # dk_bh[j,e] = sum_i dscore[i,j] qu[i,e]
+        ops.gemm(dscore, qu, dqkv, T2, dk, T2, Tp, d, 3 * d, transA=True, transB=True, batch=H * B, nb0=B,
+                 sA=(T2 * Tp, B * T2 * Tp), sB=(T2 * d, dk), sC=(T2 * 3 * d, dk), c_off=d)
+        # dqv_bh = dbdf_bh [T,P] @ p_h [P,dk]  (NN)
+        ops.gemm(dbdf, p, dqv, T2, dk, P, Pp, d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Pp, B * T2 * Pp),
+                 sB=(0, dk), sC=(T2 * d, dk))
+        # dp_h[c,e] = sum_{b,i} dbdf[h,b,i,c] qv[b,i,h,e]   (reduction over all B*T rows of head h)
+        dp = torch.zeros(P, d, dtype=torch.float32, device=dev)
+        t = 128 if cdt == torch.bfloat16 else 64
+        tiles = ((P + t - 1) // t) * H
+        ops.gemm(dbdf, qv, dp, P, dk, B * T2, Pp, d, d, transA=True, transB=True, atomic=True,
+                 splitk=self._splitk(tiles, B * T2), batch=H, nb0=H, sA=(B * T2 * Pp, 0), sB=(dk, 0), sC=(dk, 0))
+        dpc = torch.empty(P, d, dtype=cdt, device=dev)
+        ops.drop_scale_cast(dp, dpc, P * d, 1.0)
+        self._wgrad(dpc, d, 0, S.pos, d, 0, a.linear_pos.weight.grad, d, d, P)
+        ops.colsum(dqu, a.pos_bias_u.grad, M, d)
+        ops.colsum(dqv, a.pos_bias_v.grad, M, d)
+        ops.add2(dqu, dqv, dqkv, 3 * d, M, d)
+        for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
+            ops.colsum(dqkv, lin.bias.grad, M, d, ld=3 * d, x_off=j * d)
+            self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M)
+        dy2 = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.gemm(dqkv, W[f"L{i}.att.wqkvt"], dy2, M, d, 3 * d, 3 * d, W.pitch(f"L{i}.att.wqkvt"), d)
+        ln = L.norm_self_att
+        ops.layernorm_bwd(dy2, r1, ln.weight, mean2, rstd2, dr, True, ln.weight.grad, ln.bias.grad, M, d)
+        # ---- FFN 1
+        dr = self._ffn_bwd(f"L{i}.ff1", L.feed_forward1, L.norm_feed_forward1, sl.ff1, dr, W, M, d, dff, cdt, dev)
+        return dr

@@ -56,7 +56,7 @@ NO_DROP = Dropout()
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=False, transB=False, in_dtype=None, c_dtype=None, batch=1, nb0=0,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, alpha=1.0, epi=EPI_STORE, atomic=False, splitk=1, aux_in=None,
          aux_out=None, ldaux=0, drop: Dropout = NO_DROP, row_len=None, rows_per_b=1, rows_inner=1,
-         a_off=0, b_off=0, c_off=0):
+         a_off=0, b_off=0, c_off=0, c_col_stride=1):
     """C[M,N] = epi(A @ B^T) -- see mi355x_gemm.  A/B/Cm are tensors whose storage holds the (strided) operands;
     *_off are element offsets into them (head / column slices)."""
     d = GemmDesc()
@@ -66,6 +66,7 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=False, transB=False, in_dty
     d.C = _ptr(Cm) + c_off * esC
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.c_col_stride = c_col_stride
     d.transA, d.transB = int(transA), int(transB)
     d.in_dtype = dt(A) if in_dtype is None else in_dtype
     d.c_dtype = dt(Cm) if c_dtype is None else c_dtype
@@ -240,6 +241,10 @@ def ctc_loss(logp, targets, in_len, tgt_len, blank, grad=None, grad_scale=1.0, z
     check(lib.mi355x_ctc_loss(_ptr(logp), _ptr(targets), _ptr(in_len), _ptr(tgt_len), _ptr(alpha), _ptr(beta), _ptr(nll),
                               _ptr(grad), B, T, C_, U, blank, grad_scale, int(zero_infinity), _stream()), "ctc_loss")
     return nll
+
+
+def row_scale(x, vec, rows, cols):
+    check(lib.mi355x_row_scale(_ptr(x), _ptr(vec), rows, cols, _stream()), "row_scale")
 
 
 def adamw_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):

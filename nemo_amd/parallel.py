@@ -1,0 +1,77 @@
+"""Data-parallel gradient exchange for the flat gradient buffers: one process per GPU, torch.distributed (backend
+"nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference gets this from Lightning `DDPStrategy` -> torch DDP (25 MB buckets, autograd hooks; trainer.strategy: ddp,
+examples/asr/conf/conformer/conformer_ctc_bpe.yaml:201).  Here the backward pass is sequenced by our own host code, so
+no hooks are needed: when the backward of a layer finishes, its parameters' gradients are final and CONTIGUOUS in the
+flat buffer; `GradSync.ready(start, end)` accumulates such ranges into ~bucket_bytes buckets and launches
+`all_reduce` for each full bucket on a side HIP stream (event-ordered after the producing kernels), overlapping the
+exchange with the rest of backward.  `wait()` joins the side stream before the optimizer.  The sum is turned into a
+mean inside the fused AdamW kernel (`grad_scale = 1/world`), so no extra pass over the gradients is made.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large buckets beat many small ones, hence the 64 MiB
+default (121.5 M fp32 gradients = 486 MB -> 8 buckets).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, grad: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, use_side_stream: Optional[bool] = None):
+        self.grad = grad
+        self.bucket_elems = max(1, bucket_bytes // grad.element_size())
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._pending: List[Tuple[int, int]] = []
+        self._pending_elems = 0
+        self._works = []
+        self._reduced: List[Tuple[int, int]] = []
+        cuda = grad.is_cuda
+        self.use_side_stream = cuda if use_side_stream is None else (use_side_stream and cuda)
+        self._stream = torch.cuda.Stream(device=grad.device) if self.use_side_stream else None
+
+    # ---- called by the backward sequencer (ranges arrive in reverse-layer order, adjacent ranges are merged)
+    def ready(self, start: int, end: int) -> None:
+        if self.world <= 1 or end <= start:
+            return
+        if self._pending and self._pending[-1][0] == end:          # grows downwards (reverse layer order)
+            self._pending[-1] = (start, self._pending[-1][1])
+        elif self._pending and self._pending[-1][1] == start:
+            self._pending[-1] = (self._pending[-1][0], end)
+        else:
+            self._pending.append((start, end))
+        self._pending_elems += end - start
+        if self._pending_elems >= self.bucket_elems:
+            self.flush()
+
+    def flush(self) -> None:
+        if self.world <= 1:
+            self._pending, self._pending_elems = [], 0
+            return
+        for (s, e) in self._pending:
+            view = self.grad[s:e]
+            if self._stream is not None:
+                self._stream.wait_stream(torch.cuda.current_stream(self.grad.device))
+                with torch.cuda.stream(self._stream):
+                    self._works.append(dist.all_reduce(view, group=self.group, async_op=True))
+            else:
+                self._works.append(dist.all_reduce(view, group=self.group, async_op=True))
+            self._reduced.append((s, e))
+        self._pending, self._pending_elems = [], 0
+
+    def wait(self) -> float:
+        """join all outstanding reductions; returns the factor that turns the sum into the mean"""
+        self.flush()
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self._stream is not None:
+            torch.cuda.current_stream(self.grad.device).wait_stream(self._stream)
+        self._reduced = []
+        return 1.0 / self.world
+
+    def reduced_ranges(self):
+        return list(self._reduced)

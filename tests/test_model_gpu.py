@@ -1,0 +1,176 @@
+"""-m gpu: the drop-in modules end to end (preprocessor -> encoder -> decoder -> CTC loss, forward AND backward through
+the C ABI) against (a) fixtures produced by the reference's own source files (tests/golden/ref_tiny_model.npz,
+oracle/make_golden.py) and (b) the CPU oracle on fresh seeded inputs.  north_star tolerance: 1e-3 relative fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import conformer_ref as R
+
+dev = "cuda"
+
+
+def _model(cfg_over, vocab, size="small", **kw):
+    from nemo_amd.models import EncDecCTCModel, conformer_ctc_config
+    cfg = conformer_ctc_config(size, vocab_size=vocab, **cfg_over)
+    cfg["preprocessor"]["dither"] = 0.0
+    cfg.update(kw)
+    return EncDecCTCModel(cfg)
+
+
+def _load(model, P):
+    sd = {}
+    for k, v in P.items():
+        if k.startswith("encoder.") or k.startswith("decoder."):
+            sd[k] = v.detach().clone()
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(m.startswith("preprocessor.") for m in missing), missing
+
+
+def _grads(model):
+    g = {}
+    for n, p in model.named_parameters():
+        g[n] = p.grad.detach().float().cpu().clone()
+    return g
+
+
+# gradients that are analytically ZERO (depthwise bias under batch-statistics BatchNorm; key bias under softmax shift
+# invariance): both sides hold pure summation-rounding noise, so they are compared absolutely against the global scale
+ZERO_GRADS = ("depthwise_conv.bias", "linear_k.bias")
+
+
+def _cmp_grads(got, ref, rtol, floor):
+    """relative to each tensor's own scale, with an absolute floor for analytically-zero gradients"""
+    worst = ("", 0.0)
+    gmax = max(torch.as_tensor(r).abs().max().item() for r in ref.values())
+    for k, r in ref.items():
+        r = torch.as_tensor(r).float()
+        e = (got[k] - r).abs().max().item()
+        s = max(r.abs().max().item(), floor)
+        if k.endswith(ZERO_GRADS):
+            s = max(s, 1e-2 * gmax)
+        if e / s > worst[1]:
+            worst = (k, e / s)
+    assert worst[1] < rtol, worst
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_tiny_model_matches_reference_fixture(golden_dir, mode):
+    z = np.load(os.path.join(golden_dir, "ref_tiny_model.npz"))
+    P = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("P/")}
+    over = dict(d_model=32, n_heads=4, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0)
+    model = _model(over, vocab=16)
+    _load(model, P)
+    model = model.to(dev)
+    model.train(mode == "train")
+    batch = [torch.from_numpy(z[k]).to(dev) for k in ("audio", "audio_len", "tokens", "token_len")]
+    for fp in model.flats():
+        fp.zero_grad()
+    out = model.training_step(batch)
+    logp, enc_len, _ = model.forward(input_signal=batch[0], input_signal_length=batch[1]) if mode == "eval" else (None, None, None)
+    loss = out["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_loss = float(z[f"{mode}/loss"])
+    assert abs(loss.item() - ref_loss) <= 1e-3 * abs(ref_loss), (loss.item(), ref_loss)
+    if logp is not None:
+        assert np.array_equal(enc_len.cpu().numpy(), z["eval/enc_len"])
+        assert np.abs(logp.detach().cpu().numpy() - z["eval/logp"]).max() < 2e-3
+    ref = {k[len(mode) + 6:]: z[k] for k in z.files if k.startswith(f"{mode}/grad/")}
+    _cmp_grads(_grads(model), ref, rtol=2e-3, floor=1e-3)
+
+
+def test_ragged_batch_matches_cpu_oracle_fp32():
+    """d=64, 4 heads, 2 layers, B=3 ragged lengths, training-mode BatchNorm, fp32 compute: loss + every gradient."""
+    cfg = R.ConformerCfg(d_model=64, n_heads=4, n_layers=2, vocab=20, dropout=0, dropout_att=0, dropout_pre_encoder=0)
+    P = R.init_params(cfg, seed=5)
+    audio, _, tok, _ = R.synthetic_batch(3, 1.3, vocab=20, seed=99)
+    alen = torch.tensor([20800, 15000, 7777]); tl = torch.tensor([3, 2, 3])
+    Pr = {k: (v.clone().requires_grad_(True) if k in R.trainable_keys(P) else v) for k, v in P.items()}
+    ref = R.model_forward(Pr, cfg, audio, alen, tok, tl, train=False, bn_training=True)
+    ref["loss"].backward()
+    over = dict(d_model=64, n_heads=4, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0)
+    model = _model(over, vocab=20)
+    _load(model, P)
+    model = model.to(dev).train()
+    out = model.training_step([audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)])
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert abs(out["loss"].item() - ref["loss"].item()) <= 1e-3 * abs(ref["loss"].item())
+    refg = {k: Pr[k].grad for k in R.trainable_keys(P)}
+    _cmp_grads(_grads(model), refg, rtol=2e-3, floor=1e-3)
+    # running statistics of BatchNorm follow torch (momentum 0.1, unbiased running_var)
+    stats = {}
+    R.model_forward(P, cfg, audio, alen, tok, tl, train=False, bn_training=True, bn_stats_out=stats)
+    m0, v0 = stats["encoder.layers.0.conv."]
+    bn = model.encoder.layers[0].conv.batch_norm
+    assert torch.allclose(bn.running_mean.cpu(), 0.1 * m0, atol=1e-4)
+    assert torch.allclose(bn.running_var.cpu(), 0.9 + 0.1 * v0, atol=1e-4)
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_bf16_mfma_path_close_to_fp32_oracle():
+    """bf16 compute (MFMA GEMMs, bf16 activations): loss within 2 %, gradient direction cos > 0.98 per big tensor."""
+    cfg = R.ConformerCfg(d_model=64, n_heads=2, n_layers=2, vocab=20, dropout=0, dropout_att=0, dropout_pre_encoder=0)
+    P = R.init_params(cfg, seed=6)
+    audio, alen, tok, tl = R.synthetic_batch(4, 1.0, vocab=20, seed=17)
+    Pr = {k: (v.clone().requires_grad_(True) if k in R.trainable_keys(P) else v) for k, v in P.items()}
+    ref = R.model_forward(Pr, cfg, audio, alen, tok, tl, train=False, bn_training=True)
+    ref["loss"].backward()
+    over = dict(d_model=64, n_heads=2, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0,
+                compute_dtype=torch.bfloat16)
+    model = _model(over, vocab=20)
+    model.decoder.compute_dtype = torch.bfloat16
+    _load(model, P)
+    model = model.to(dev).train()
+    out = model.training_step([audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)])
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert abs(out["loss"].item() - ref["loss"].item()) <= 2e-2 * abs(ref["loss"].item()), (out["loss"].item(), ref["loss"].item())
+    g = _grads(model)
+    for k in R.trainable_keys(P):
+        r = Pr[k].grad.flatten()
+        if r.numel() < 1024 or r.norm() < 1e-3:
+            continue
+        cos = torch.dot(g[k].flatten(), r) / (g[k].norm() * r.norm() + 1e-20)
+        assert cos > 0.98, (k, cos.item())
+
+
+def test_dropout_training_runs_and_is_stochastic():
+    over = dict(d_model=64, n_heads=4, n_layers=2)
+    model = _model(over, vocab=20).to(dev).train()
+    model.preprocessor.featurizer.dither = 1e-5
+    audio, alen, tok, tl = R.synthetic_batch(2, 1.0, vocab=20, seed=3)
+    batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+    l1 = model.training_step(batch)["loss"]
+    l1.backward()
+    l2 = model.training_step(batch)["loss"]
+    torch.cuda.synchronize()
+    assert torch.isfinite(l1) and torch.isfinite(l2) and l1.item() != l2.item()
+    for n, p in model.named_parameters():
+        assert torch.isfinite(p.grad).all(), n
+
+
+def test_fit_steps_reduce_loss_and_nemo_roundtrip(tmp_path):
+    from nemo_amd.models import EncDecCTCModel
+    over = dict(d_model=64, n_heads=4, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0)
+    model = _model(over, vocab=20).to(dev).train()
+    model.setup_optimization(dict(name="adamw", lr=2e-3, betas=[0.9, 0.98], weight_decay=1e-3))
+    audio, alen, tok, tl = R.synthetic_batch(4, 1.0, vocab=20, seed=8)
+    batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+    losses = [model.fit_step(batch)["loss"].item() for _ in range(12)]
+    assert losses[-1] < 0.8 * losses[0], losses
+    path = str(tmp_path / "m.nemo")
+    model.eval()
+    lp1, _, _ = model.forward(input_signal=batch[0], input_signal_length=batch[1])
+    model.save_to(path)
+    m2 = EncDecCTCModel.restore_from(path, map_location=dev).eval()
+    lp2, _, _ = m2.forward(input_signal=batch[0], input_signal_length=batch[1])
+    torch.cuda.synchronize()
+    assert torch.allclose(lp1, lp2, atol=1e-5)
+    assert set(m2.state_dict().keys()) == set(model.state_dict().keys())
