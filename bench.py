@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio-sec/s training throughput, Conformer-CTC-Large (BASELINE.json), MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one full optimizer step of the drop-in EncDecCTCModel on a synthetic batch resident in HBM:
+log-mel front-end -> conv sub-sampling -> 18 Conformer blocks -> decoder -> CTC loss -> full backward -> bucketed RCCL
+gradient all-reduce (N > 1, overlapped on a side stream) -> fused AdamW + Noam step; train mode (dropout, dither,
+batch-statistics BatchNorm with SyncBN across ranks), bf16 compute with fp32 master weights.  Per-GPU batch is fixed
+(weak scaling): 32 x 20 s clips of 16 kHz audio, 60 target tokens each, vocab 128 + blank.
+Prints ONE JSON line (rank 0) -- see the README/DESIGN.md for the fields; `roofline` is measured live with HIP events
+around every launch of the dominant GEMM kernel in one extra step, `cpu_baseline` times the CPU oracle (oracle/) on the
+host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", default="large", choices=["small", "medium", "large"])
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--secs", type=float, default=20.0)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(size, secs, vocab, batch, steps):
+    """the CPU oracle (oracle/conformer_ref.py, plain PyTorch fp32) forward+backward+AdamW on the host cores, train mode"""
+    from oracle import conformer_ref as R
+    cfg = getattr(R.ConformerCfg, size)(vocab=vocab)
+    P = R.init_params(cfg, seed=0, nonzero_pos_bias=False)
+    keys = R.trainable_keys(P)
+    for k in keys:
+        P[k].requires_grad_(True)
+    opt = torch.optim.AdamW([P[k] for k in keys], lr=1e-4, betas=(0.9, 0.98), weight_decay=1e-3)
+    audio, alen, tok, tl = R.synthetic_batch(batch, secs, vocab=vocab, seed=1234)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        noise = torch.randn_like(audio)
+        out = R.model_forward(P, cfg, audio, alen, tok, tl, train=True, noise=noise, dither=1e-5)
+        out["loss"].backward()
+        opt.step()
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(batch * secs / med, 2), "unit": "audio-sec/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"Conformer-CTC-{size} fp32 train step (fwd+bwd+AdamW), B={batch}x{secs:g}s, median of {len(times)} after 1 warm-up"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    from nemo_amd import ops
+    from nemo_amd.models import EncDecCTCModel, conformer_ctc_config
+    from oracle import conformer_ref as R  # synthetic-batch generator only, not on the measured path
+
+    vocab = 128
+    cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    cfg = conformer_ctc_config(a.size, vocab_size=vocab, compute_dtype=cdt)
+    torch.manual_seed(0)
+    model = EncDecCTCModel(cfg)
+    model.decoder.compute_dtype = cdt
+    model = model.to(dev).train()
+    model.setup_optimization()
+    audio, alen, tok, tl = R.synthetic_batch(a.batch, a.secs, vocab=vocab, seed=1234 + rank)
+    batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(a.warmup):
+        loss = model.fit_step(batch)["loss"]
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = model.fit_step(batch)["loss"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / a.steps * 1e3
+    value = world * a.batch * a.secs / (dt / a.steps)
+    final_loss = float(loss.item())
+
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        ops.GEMM_PROFILE = []
+        model.fit_step(batch)
+        torch.cuda.synchronize()
+        agg = {}
+        for (variant, M, N, K, nb, e0, e1) in ops.GEMM_PROFILE:
+            g = agg.setdefault(variant, [0.0, 0.0, 0])
+            g[0] += 2.0 * M * N * K * nb
+            g[1] += e0.elapsed_time(e1) * 1e-3
+            g[2] += 1
+        ops.GEMM_PROFILE = None
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        flops, secs_, cnt = dom[1]
+        peak = 2500.0 if a.dtype == "bf16" else 157.3
+        roof = {"bound": "mfma", "kernel": f"gemm_{dom[0]}", "achieved": round(flops / secs_ / 1e12, 1), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(flops / secs_ / 1e12 / peak, 4), "traffic": None,
+                "launches_per_step": cnt, "avg_launch_us": round(secs_ / cnt * 1e6, 1),
+                "gemm_time_share_of_step": round(sum(v[1] for v in agg.values()) * 1e3 / ms, 3),
+                "all_variants": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 2), "launches": v[2]}
+                                 for k, v in agg.items()}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.size, a.secs, vocab, a.cpu_batch, a.cpu_steps)
+
+    if rank == 0:
+        line = {
+            "metric": "audio-sec/s training throughput, Conformer-CTC-Large @ 1/2/4/8 MI355X" if a.size == "large"
+            else f"audio-sec/s training throughput, Conformer-CTC-{a.size}",
+            "value": round(value, 1), "unit": "audio-sec/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"Conformer-CTC-{a.size.capitalize()} {a.dtype}, batch={a.batch}x{a.secs:g}s synthetic 16 kHz "
+                                   f"clips per GPU, {world}xMI355X (BASELINE.json configs[{1 if world == 1 else 2}])",
+                       "global_batch": world * a.batch, "clip_seconds": a.secs, "parallelism": f"dp{world}",
+                       "step": "fwd+CTC+bwd+grad-allreduce+AdamW, train mode (dropout, dither, SyncBN)",
+                       "final_loss": round(final_loss, 4)},
+        }
+        if roof is not None:
+            line["roofline"] = roof
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+            line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

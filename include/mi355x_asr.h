@@ -4,7 +4,8 @@
  * The reference has NO C ABI on this path (its host code is Python calling ATen), so this boundary is defined
  * here, directly under the Python NeuralModule classes.  Conventions:
  *   - every entry point returns 0 on success, 1 = invalid argument (the Python binding raises ValueError, the
- *     reference's convention: conformer_encoder.py:569-578, features.py:288-305), 2 = launch failure (RuntimeError);
+ *     reference's convention: conformer_encoder.py:569-578, features.py:288-305), 1000 + hipError_t = launch failure
+ *     (RuntimeError);
  *   - all pointers are DEVICE pointers owned by the caller (torch allocates; kernels never allocate or free);
  *   - `stream` is a hipStream_t (0 = default stream); calls are asynchronous and re-entrant across streams;
  *   - dtype codes: 0 = float32, 1 = bfloat16 (raw 16-bit); lengths are int64 like the reference's LengthsType tensors;

@@ -102,12 +102,12 @@ lib = _load()
 
 
 def check(rc: int, what: str = ""):
-    """0 ok; 1 -> ValueError (the reference's convention for bad shapes/args); 2 -> RuntimeError."""
+    """0 ok; 1 -> ValueError (the reference's convention for bad shapes/args); 1000+hipError_t -> RuntimeError."""
     if rc == 0:
         return
     if rc == 1:
         raise ValueError(f"libmi355x_asr: invalid argument in {what}")
-    raise RuntimeError(f"libmi355x_asr: kernel launch failed in {what} (rc={rc})")
+    raise RuntimeError(f"libmi355x_asr: kernel launch failed in {what} (hipError_t={rc - 1000 if rc >= 1000 else rc})")
 
 
 def version() -> str:

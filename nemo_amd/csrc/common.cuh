@@ -18,9 +18,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
+// Launch-error protocol: entry points call mi_clear_errors() first (hipGetLastError is sticky per host thread, so an
+// unrelated earlier failure -- e.g. inside the framework that owns the stream -- must not be blamed on our launch), and
+// return 0 or 1000 + hipError_t of their own launch.
+static inline void mi_clear_errors() { (void)hipGetLastError(); }
 static inline int mi_check_launch() {
   hipError_t e = hipGetLastError();
-  return e == hipSuccess ? MI_OK : MI_ERR_LAUNCH;
+  return e == hipSuccess ? MI_OK : 1000 + (int)e;
 }
 
 // ---------------------------------------------------------------- bf16 <-> f32

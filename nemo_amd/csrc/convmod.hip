@@ -241,6 +241,7 @@ static inline int grid_for(long long n) { long long g = (n + 255) / 256; return 
 
 extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias, void* y, int dt, void* stats, int B, int T,
                                  int d, int ksize, void* stream) {
+  mi_clear_errors();
   if (!x || !w || !y || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
   dim3 grid((d + DW_CH - 1) / DW_CH, (T + DW_TT - 1) / DW_TT, B), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -256,6 +257,7 @@ extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias,
 }
 extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dt, int B,
                                  int T, int d, int ksize, void* stream) {
+  mi_clear_errors();
   if (!dy || !x || !w || !dx || !dw || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
   dim3 grid((d + DW_CH - 1) / DW_CH, B), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -271,6 +273,7 @@ extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, v
 }
 extern "C" int mi355x_bn_finalize(const void* stats, double count, void* mean, void* rstd, void* running_mean,
                                   void* running_var, float momentum, float eps, int d, void* stream) {
+  mi_clear_errors();
   if (!stats || !mean || !rstd || d <= 0 || count <= 0) return MI_ERR_ARG;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)stats, count,
                      (float*)mean, (float*)rstd, (float*)running_mean, (float*)running_var, momentum, eps, d);
@@ -278,6 +281,7 @@ extern "C" int mi355x_bn_finalize(const void* stats, double count, void* mean, v
 }
 extern "C" int mi355x_bn_eval_stats(const void* running_mean, const void* running_var, void* mean, void* rstd, float eps, int d,
                                     void* stream) {
+  mi_clear_errors();
   if (!running_mean || !running_var || !mean || !rstd || d <= 0) return MI_ERR_ARG;
   hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)running_mean,
                      (const float*)running_var, (float*)mean, (float*)rstd, eps, d);
@@ -285,6 +289,7 @@ extern "C" int mi355x_bn_eval_stats(const void* running_mean, const void* runnin
 }
 extern "C" int mi355x_bn_swish_fwd(const void* x, const void* mean, const void* rstd, const void* gamma, const void* beta, void* y,
                                    int dt, long long M, int d, void* stream) {
+  mi_clear_errors();
   if (!x || !mean || !rstd || !gamma || !beta || !y || M <= 0 || (d & 3)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_fwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)x,
@@ -293,6 +298,7 @@ extern "C" int mi355x_bn_swish_fwd(const void* x, const void* mean, const void* 
 }
 extern "C" int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
                                           const void* beta, void* sums, int dt, long long M, int d, void* stream) {
+  mi_clear_errors();
   if (!dy || !x || !sums || M <= 0 || d <= 0) return MI_ERR_ARG;
   dim3 grid((d + 63) / 64, (unsigned)((M + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -304,6 +310,7 @@ extern "C" int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const v
 extern "C" int mi355x_bn_swish_bwd_apply(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
                                          const void* beta, const void* sums, double count, int training, void* dx, int dt,
                                          long long M, int d, void* stream) {
+  mi_clear_errors();
   if (!dy || !x || !sums || !dx || M <= 0 || (d & 3) || count <= 0) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_bwd_apply_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s,
@@ -312,6 +319,7 @@ extern "C" int mi355x_bn_swish_bwd_apply(const void* dy, const void* x, const vo
   return mi_check_launch();
 }
 extern "C" int mi355x_bn_param_grad(const void* sums, void* dgamma, void* dbeta, int d, void* stream) {
+  mi_clear_errors();
   if (!sums || !dgamma || !dbeta || d <= 0) return MI_ERR_ARG;
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)sums,
                      (float*)dgamma, (float*)dbeta, d);

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logp
 extern "C" int mi355x_ctc_loss(const void* logp, const void* targets, const void* in_len, const void* tgt_len, void* alpha_ws,
                                void* beta_ws, void* nll, void* grad, int B, int Tmax, int C, int Umax, int blank,
                                float grad_scale, int zero_infinity, void* stream) {
+  mi_clear_errors();
   if (!logp || !targets || !in_len || !tgt_len || !alpha_ws || !beta_ws || !nll) return MI_ERR_ARG;
   if (B <= 0 || Tmax <= 0 || C <= 0 || Umax < 0 || blank < 0 || blank >= C) return MI_ERR_ARG;
   const int Smax = 2 * Umax + 1;

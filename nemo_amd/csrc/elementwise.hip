@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void row_scale_kernel(float* __restrict__ x, c
 static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
 extern "C" int mi355x_glu_fwd(const void* in, void* out, int dt, const void* len, int T, long long M, int d, void* stream) {
+  mi_clear_errors();
   if (!in || !out || M <= 0 || d <= 0 || (d & 3) || T <= 0) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(dt, TT, hipLaunchKernelGGL((glu_fwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)in,
@@ -212,6 +213,7 @@ extern "C" int mi355x_glu_fwd(const void* in, void* out, int dt, const void* len
 }
 extern "C" int mi355x_glu_bwd(const void* in, const void* dout, void* din, int dt, const void* len, int T, long long M, int d,
                               void* stream) {
+  mi_clear_errors();
   if (!in || !dout || !din || M <= 0 || d <= 0 || (d & 3) || T <= 0) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(dt, TT, hipLaunchKernelGGL((glu_bwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)in,
@@ -220,6 +222,7 @@ extern "C" int mi355x_glu_bwd(const void* in, const void* dout, void* din, int d
 }
 extern "C" int mi355x_drop_scale_cast(const void* in, int in_dt, void* out, int out_dt, long long n, float alpha,
                                       unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
+  mi_clear_errors();
   if (!in || !out || n <= 0 || (n & 3)) return MI_ERR_ARG;
   DropCfg dc{drop_key, drop_threshold, drop_scale};
   hipStream_t s = (hipStream_t)stream;
@@ -230,6 +233,7 @@ extern "C" int mi355x_drop_scale_cast(const void* in, int in_dt, void* out, int 
 }
 extern "C" int mi355x_qbias(const void* qkv, long long ldq, const void* u, const void* v, void* qu, void* qv, int dt,
                             long long M, int d, void* stream) {
+  mi_clear_errors();
   if (!qkv || !u || !v || !qu || !qv || M <= 0 || (d & 3) || (ldq & 3)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(dt, TT, hipLaunchKernelGGL((qbias_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)qkv, ldq,
@@ -238,6 +242,7 @@ extern "C" int mi355x_qbias(const void* qkv, long long ldq, const void* u, const
 }
 extern "C" int mi355x_add2(const void* a, const void* b, int in_dt, void* out, int out_dt, long long ldo, long long M, int d,
                            void* stream) {
+  mi_clear_errors();
   if (!a || !b || !out || M <= 0 || (d & 3) || (ldo & 3)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(in_dt, TI, DISPATCH_DT(out_dt, TO,
@@ -248,6 +253,7 @@ extern "C" int mi355x_add2(const void* a, const void* b, int in_dt, void* out, i
 extern "C" int mi355x_relpos_softmax_fwd(const void* ac, const void* bdf, void* s_out, void* pd_out, int out_dt, const void* len,
                                          int H, int B, int T, int Tp, int Pp, float scale, unsigned drop_key,
                                          unsigned drop_threshold, float drop_scale, void* stream) {
+  mi_clear_errors();
   if (!ac || !bdf || !s_out || !len || T <= 0 || T > 64 * SM_MAXV || Tp < T || Tp > 64 * SM_MAXV || Pp < 2 * T - 1)
     return MI_ERR_ARG;
   DropCfg dc{drop_key, drop_threshold, drop_scale};
@@ -261,6 +267,7 @@ extern "C" int mi355x_relpos_softmax_fwd(const void* ac, const void* bdf, void* 
 extern "C" int mi355x_relpos_softmax_bwd(const void* dpd, int dpd_dt, const void* s_in, void* dscore, void* dbdf, int s_dt, int H,
                                          int B, int T, int Tp, int Pp, float scale, unsigned drop_key, unsigned drop_threshold,
                                          float drop_scale, void* stream) {
+  mi_clear_errors();
   if (!dpd || !s_in || !dscore || !dbdf || T <= 0 || T > 64 * SM_MAXV || Tp < T || Tp > 64 * SM_MAXV || Pp < 2 * T - 1)
     return MI_ERR_ARG;
   DropCfg dc{drop_key, drop_threshold, drop_scale};
@@ -272,6 +279,7 @@ extern "C" int mi355x_relpos_softmax_bwd(const void* dpd, int dpd_dt, const void
   return mi_check_launch();
 }
 extern "C" int mi355x_row_scale(void* x, const void* vec, long long rows, long long cols, void* stream) {
+  mi_clear_errors();
   if (!x || !vec || rows <= 0 || cols <= 0) return MI_ERR_ARG;
   hipLaunchKernelGGL(row_scale_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, (float*)x,
                      (const float*)vec, rows, cols);

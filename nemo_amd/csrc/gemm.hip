@@ -42,6 +42,7 @@ struct GemmP {
   DropCfg drop;
   const long long* row_len; int rows_per_b; int rows_inner;
   int splitk; int ktiles_per_split;
+  int vec_ok;                          // C / aux rows are 8-element aligned & dense: vectorised epilogue allowed
 };
 
 __device__ __forceinline__ float ldx(const void* p, long long i, int dt) {
@@ -76,6 +77,81 @@ __device__ __forceinline__ void epilogue(const GemmP& p, int z, long long coff, 
   }
   if (p.atomic) atomicAdd(&((float*)p.C)[ci], v);
   else stx(p.C, ci, p.c_dt, v);
+}
+
+// ---- 8-wide epilogue (one thread = 8 consecutive columns of one row; 16-B / 32-B global accesses)
+__device__ __forceinline__ void ld8x(const void* p, long long i, int dt, float (&v)[8]) {
+  if (dt == MI_DT_F32) {
+    const float4 a = *reinterpret_cast<const float4*>((const float*)p + i);
+    const float4 b = *reinterpret_cast<const float4*>((const float*)p + i + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    const u32x4 t = *reinterpret_cast<const u32x4*>((const bf16_t*)p + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(t[j] << 16); v[2 * j + 1] = __uint_as_float(t[j] & 0xffff0000u); }
+  }
+}
+__device__ __forceinline__ void st8x(void* p, long long i, int dt, const float (&v)[8]) {
+  if (dt == MI_DT_F32) {
+    *reinterpret_cast<float4*>((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>((float*)p + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    *reinterpret_cast<u32x4*>((bf16_t*)p + i) = t;
+  }
+}
+__device__ __forceinline__ void epilogue8(const GemmP& p, int z, long long coff, int m, int n, float (&v)[8]) {
+  const long long ci = coff + (long long)m * p.ldc + n;
+  const long long ai = coff + (long long)m * p.ldaux + n;
+  if (p.bias) {
+    float b[8];
+    ld8x(p.bias, n, MI_DT_F32, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += b[j];
+  }
+  const uint32_t didx = (uint32_t)z * (uint32_t)(p.M * p.N) + (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+  switch (p.epi) {
+    case EPI_STORE:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= p.alpha * drop_mask(p.drop, didx + j);
+      break;
+    case EPI_SWISH_DROP:
+      st8x(p.aux_out, ai, p.auxout_dt, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * drop_mask(p.drop, didx + j);
+      break;
+    case EPI_RESID: {
+      float r[8];
+      ld8x(p.aux_in, ai, MI_DT_F32, r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = r[j] + p.alpha * v[j] * drop_mask(p.drop, didx + j);
+    } break;
+    case EPI_DSWISH: {
+      float h[8];
+      ld8x(p.aux_in, ai, p.auxin_dt, h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * drop_mask(p.drop, didx + j) * swish_grad(h[j]);
+    } break;
+    case EPI_RELU_MASK: {
+      const int b = m / p.rows_per_b;
+      const int t = (m - b * p.rows_per_b) / p.rows_inner;
+      const bool ok = (long long)t < p.row_len[b];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (ok && v[j] > 0.f) ? v[j] : 0.f;
+    } break;
+    case EPI_MUL_POS: {
+      float h[8];
+      ld8x(p.aux_in, ai, p.auxin_dt, h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = h[j] > 0.f ? v[j] : 0.f;
+    } break;
+  }
+  if (p.atomic) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&((float*)p.C)[ci + j], v[j]);
+  } else {
+    st8x(p.C, ci, p.c_dt, v);
+  }
 }
 
 // =================================================================================================
@@ -223,18 +299,52 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // ---- epilogue through LDS: accumulators (C/D layout of the 32x32 MFMA: col = lane&31,
+  // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) are transposed into row-major f32 tiles of 64 x 128 so that every
+  // thread owns 8 consecutive columns of a row: bias / aux loads and the C store are 16-32 B per lane, 256-512 B per row.
+  constexpr int LDS_C = BN + 4;
+  float* sC = reinterpret_cast<float*>(smem);  // 64 x 132 floats = 33 KiB (the staging buffers are dead now)
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();
+    if (wm == half) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + lr;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < p.M && n < p.N) epilogue(p, z, coff, m, n, acc[i][j][r]);
+          for (int r = 0; r < 16; ++r) {
+            const int row_l = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sC[row_l * LDS_C + wn * 64 + j * 32 + lr] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    if (p.atomic) {
+      // split-K accumulation: lane-contiguous columns so that each atomic instruction covers whole 256-B row segments
+      for (int e = threadIdx.x; e < 64 * BN; e += 256) {
+        const int row_l = e >> 7, col = e & (BN - 1);
+        const int m = m0 + half * 64 + row_l, n = n0 + col;
+        if (m < p.M && n < p.N) epilogue(p, z, coff, m, n, sC[row_l * LDS_C + col]);
+      }
+      continue;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row_l = (threadIdx.x >> 4) + 16 * it;
+      const int c8 = (threadIdx.x & 15) * 8;
+      const int m = m0 + half * 64 + row_l, n = n0 + c8;
+      if (m < p.M && n < p.N) {
+        float v[8];
+        const float4 a = *reinterpret_cast<const float4*>(sC + row_l * LDS_C + c8);
+        const float4 b = *reinterpret_cast<const float4*>(sC + row_l * LDS_C + c8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        if (p.vec_ok && n + 8 <= p.N) epilogue8(p, z, coff, m, n, v);
+        else {
+          for (int j = 0; j < 8; ++j)
+            if (n + j < p.N) epilogue(p, z, coff, m, n + j, v[j]);
+        }
       }
     }
+  }
 }
 
 // =================================================================================================
@@ -301,6 +411,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 // C ABI
 // =================================================================================================
 extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
+  mi_clear_errors();
   if (!d || !d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0) return MI_ERR_ARG;
   if (d->in_dtype != MI_DT_F32 && d->in_dtype != MI_DT_BF16) return MI_ERR_ARG;
   GemmP p;
@@ -329,6 +440,13 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   p.ktiles_per_split = (nk + sk - 1) / sk;
   sk = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
   p.splitk = sk;
+  {
+    bool ok = p.csc == 1 && !(p.ldc & 7) && !((uintptr_t)p.C & 31) && !(p.sC0 & 7) && !(p.sC1 & 7);
+    if (p.aux_in) ok = ok && !(p.ldaux & 7) && !((uintptr_t)p.aux_in & 31);
+    if (p.aux_out) ok = ok && !(p.ldaux & 7) && !((uintptr_t)p.aux_out & 31);
+    if (p.bias) ok = ok && !((uintptr_t)p.bias & 31);
+    p.vec_ok = ok ? 1 : 0;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (d->in_dtype == MI_DT_BF16) {
     // 16-byte alignment contract of the vector loads

@@ -177,6 +177,7 @@ extern "C" int mi355x_logmel_fwd(const void* audio, const void* audio_len, const
                                  const void* fb_start, const void* fb_len, const void* fb_off, const void* fb_w, int n_mels,
                                  float preemph, float dither, unsigned seed, float log_guard, void* out, int B, int S, int T,
                                  void* stream) {
+  mi_clear_errors();
   if (!audio || !audio_len || !window || !fb_start || !fb_len || !fb_off || !fb_w || !out) return MI_ERR_ARG;
   if (n_fft != NFFT || win <= 0 || win > NFFT || hop <= 0 || hop > NFFT || n_mels <= 0 || B <= 0 || S <= 0) return MI_ERR_ARG;
   if (T != 1 + S / hop) return MI_ERR_ARG;
@@ -184,7 +185,10 @@ extern "C" int mi355x_logmel_fwd(const void* audio, const void* audio_len, const
   const size_t shm = sizeof(float) * (((seg + 3) & ~3) + NFFT + 2 * NH + 4 * 2 * NH * 2 + 4 * 260 + (size_t)n_mels * (MEL_FR + 1));
   if (shm > 160 * 1024) return MI_ERR_ARG;
   dim3 grid((T + MEL_FR - 1) / MEL_FR, B), block(256);
-  hipFuncSetAttribute((const void*)logmel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  if (hipFuncSetAttribute((const void*)logmel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {
+    (void)hipGetLastError();
+    return MI_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(logmel_kernel, grid, block, shm, (hipStream_t)stream, (const float*)audio, (const long long*)audio_len,
                      (const float*)window, win, hop, (const int*)fb_start, (const int*)fb_len, (const int*)fb_off,
                      (const float*)fb_w, n_mels, preemph, dither, seed, log_guard, (float*)out, B, S, T);
@@ -193,6 +197,7 @@ extern "C" int mi355x_logmel_fwd(const void* audio, const void* audio_len, const
 
 extern "C" int mi355x_feat_normalize(const void* x, const void* seq_len, void* y, int y_dt, int B, int n_mels, int T,
                                      int normalize, float pad_value, void* stream) {
+  mi_clear_errors();
   if (!x || !seq_len || !y || B <= 0 || n_mels <= 0 || T <= 0) return MI_ERR_ARG;
   const int rows = B * n_mels;
   hipStream_t s = (hipStream_t)stream;

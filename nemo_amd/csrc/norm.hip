@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
 // =================================================================================================
 extern "C" int mi355x_layernorm_fwd(const void* x, int x_dt, const void* gamma, const void* beta, void* y, int y_dt,
                                     void* mean, void* rstd, int M, int d, float eps, void* stream) {
+  mi_clear_errors();
   if (!x || !gamma || !beta || !y || M <= 0 || d <= 0 || (d & 3)) return MI_ERR_ARG;
   dim3 grid((M + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -179,6 +180,7 @@ extern "C" int mi355x_layernorm_fwd(const void* x, int x_dt, const void* gamma, 
 extern "C" int mi355x_layernorm_bwd(const void* dy, int dy_dt, const void* x, int x_dt, const void* gamma, const void* mean,
                                     const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d,
                                     void* stream) {
+  mi_clear_errors();
   if (!dy || !x || !gamma || !mean || !rstd || !dres || M <= 0 || d <= 0 || (d & 3)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 block(256);
@@ -196,6 +198,7 @@ extern "C" int mi355x_layernorm_bwd(const void* dy, int dy_dt, const void* x, in
 }
 
 extern "C" int mi355x_colsum(const void* x, int x_dt, long long ld, void* out, int M, int N, float alpha, void* stream) {
+  mi_clear_errors();
   if (!x || !out || M <= 0 || N <= 0) return MI_ERR_ARG;
   dim3 grid((N + 63) / 64, (M + CR_ROWS - 1) / CR_ROWS), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -205,6 +208,7 @@ extern "C" int mi355x_colsum(const void* x, int x_dt, long long ld, void* out, i
 
 extern "C" int mi355x_log_softmax_fwd(const void* logits, long long ld_in, void* logp, long long ld_out, int M, int C,
                                       void* stream) {
+  mi_clear_errors();
   if (!logits || !logp || M <= 0 || C <= 0) return MI_ERR_ARG;
   hipLaunchKernelGGL(log_softmax_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)logits,
                      ld_in, (float*)logp, ld_out, M, C);
@@ -213,6 +217,7 @@ extern "C" int mi355x_log_softmax_fwd(const void* logits, long long ld_in, void*
 
 extern "C" int mi355x_log_softmax_bwd(const void* dlogp, const void* logp, long long ld, void* dlogits, int out_dt,
                                       long long ld_out, int M, int C, float scale, void* stream) {
+  mi_clear_errors();
   if (!dlogp || !logp || !dlogits || M <= 0 || C <= 0 || ld_out < C) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(out_dt, TO, hipLaunchKernelGGL((log_softmax_bwd_kernel<TO>), dim3((M + 3) / 4), dim3(256), 0, s,

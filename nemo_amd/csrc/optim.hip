@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long l
 extern "C" int mi355x_adamw_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, long long n, float lr,
                                  float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                                  void* stream) {
+  mi_clear_errors();
   if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || (n & 3) || step < 1) return MI_ERR_ARG;
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
@@ -89,6 +90,7 @@ extern "C" int mi355x_adamw_step(void* params, const void* grads, void* exp_avg,
 }
 
 extern "C" int mi355x_pack_weights(const void* table_dev, int n_entries, long long total_tiles, int out_dtype, void* stream) {
+  mi_clear_errors();
   if (!table_dev || n_entries <= 0 || total_tiles <= 0) return MI_ERR_ARG;
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev,
                      n_entries, out_dtype);
@@ -96,6 +98,7 @@ extern "C" int mi355x_pack_weights(const void* table_dev, int n_entries, long lo
 }
 
 extern "C" int mi355x_fill_f32(void* p, long long n, float value, void* stream) {
+  mi_clear_errors();
   if (!p || n <= 0) return MI_ERR_ARG;
   long long nb = (n + 255) / 256;
   if (nb > 8192) nb = 8192;

@@ -169,6 +169,7 @@ static inline int grid_for(long long n) { long long g = (n + 255) / 256; return 
 
 extern "C" int mi355x_subsample_conv1_fwd(const void* mel, const void* w, const void* bias, void* out, int out_dt,
                                           const void* len0, const void* len1, int B, int F, int T, int C, void* stream) {
+  mi_clear_errors();
   if (!mel || !w || !bias || !out || !len0 || !len1 || B <= 0 || F <= 0 || T <= 0 || C <= 0) return MI_ERR_ARG;
   const int T1 = (T + 2 - 3) / 2 + 1, F1 = (F + 2 - 3) / 2 + 1;
   dim3 grid((F1 + C1_FB - 1) / C1_FB, T1, B), block(256);
@@ -180,6 +181,7 @@ extern "C" int mi355x_subsample_conv1_fwd(const void* mel, const void* w, const 
 }
 extern "C" int mi355x_subsample_conv1_bwd(const void* dout, int dt, const void* mel, const void* len0, void* dw, void* db, int B,
                                           int F, int T, int C, void* stream) {
+  mi_clear_errors();
   if (!dout || !mel || !len0 || !dw || !db || B <= 0 || F <= 0 || T <= 0 || C <= 0) return MI_ERR_ARG;
   const int T1 = (T + 2 - 3) / 2 + 1, F1 = (F + 2 - 3) / 2 + 1;
   dim3 grid((T1 + C1_TB - 1) / C1_TB, B), block(256);
@@ -190,6 +192,7 @@ extern "C" int mi355x_subsample_conv1_bwd(const void* dout, int dt, const void* 
   return mi_check_launch();
 }
 extern "C" int mi355x_im2col_3x3s2(const void* in, void* col, int dt, int B, int T1, int F1, int C, void* stream) {
+  mi_clear_errors();
   if (!in || !col || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || (C & 7)) return MI_ERR_ARG;
   const int T2 = (T1 + 2 - 3) / 2 + 1, F2 = (F1 + 2 - 3) / 2 + 1;
   const long long total = (long long)B * T2 * F2 * 9 * (C / (dt == MI_DT_BF16 ? 8 : 4));
@@ -200,6 +203,7 @@ extern "C" int mi355x_im2col_3x3s2(const void* in, void* col, int dt, int B, int
 }
 extern "C" int mi355x_col2im_3x3s2_relu(const void* dcol, const void* act, void* din, int dt, int B, int T1, int F1, int C,
                                         void* stream) {
+  mi_clear_errors();
   if (!dcol || !act || !din || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || (C & 3)) return MI_ERR_ARG;
   const int T2 = (T1 + 2 - 3) / 2 + 1, F2 = (F1 + 2 - 3) / 2 + 1;
   const long long total = (long long)B * T1 * F1 * (C >> 2);

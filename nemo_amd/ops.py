@@ -52,6 +52,9 @@ class Dropout:
 
 NO_DROP = Dropout()
 
+# when set to a list, every gemm() appends (variant, M, N, K, batch, start_event, end_event): bench.py's roofline pass
+GEMM_PROFILE = None
+
 
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=False, transB=False, in_dtype=None, c_dtype=None, batch=1, nb0=0,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, alpha=1.0, epi=EPI_STORE, atomic=False, splitk=1, aux_in=None,
@@ -85,7 +88,15 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=False, transB=False, in_dty
     d.drop_key, d.drop_threshold, d.drop_scale = drop.key, drop.threshold, drop.scale
     d.row_len = _ptr(row_len)
     d.rows_per_b, d.rows_inner = rows_per_b, rows_inner
+    if GEMM_PROFILE is None:
+        check(lib.mi355x_gemm(C.byref(d), _stream()), "gemm")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib.mi355x_gemm(C.byref(d), _stream()), "gemm")
+    e1.record()
+    variant = ("bf16" if d.in_dtype == BF16 else "f32") + "_" + ("T" if transA else "N") + ("N" if transB else "T")
+    GEMM_PROFILE.append((variant, M, N, K, batch, e0, e1))
 
 
 # ------------------------------------------------------------------------------------------------ front-end

@@ -1,0 +1,58 @@
+"""micro-benchmark of mi355x_gemm on the Conformer-CTC-Large shapes (per-launch HIP-event timing)"""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nemo_amd import ops
+
+dev = "cuda"
+bf = torch.bfloat16
+iters = int(os.environ.get("ITERS", "20"))
+only = os.environ.get("ONLY")
+
+def timeit(fn):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+def run(name, M, N, K, epi="store", out=bf, layout="NT", splitk=1):
+    if only and only not in name: return
+    g = torch.Generator(device=dev).manual_seed(0)
+    tA, tB = layout[0] == "T", layout[1] == "N"
+    A = torch.randn((K, M) if tA else (M, K), device=dev, generator=g).to(bf)
+    B = torch.randn((K, N) if tB else (N, K), device=dev, generator=g).to(bf)
+    C = torch.zeros(M, N, device=dev, dtype=out)
+    bias = torch.randn(N, device=dev, generator=g)
+    kw = dict(transA=tA, transB=tB)
+    lda = M if tA else K; ldb = N if tB else K
+    if epi == "store": f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, bias=bias, **kw)
+    elif epi == "nobias": f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, **kw)
+    elif epi == "swish":
+        H = torch.empty(M, N, device=dev, dtype=bf); d = ops.Dropout(0.1, 1, 1)
+        f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, bias=bias, epi=ops.EPI_SWISH_DROP, aux_out=H, drop=d, **kw)
+    elif epi == "resid":
+        R = torch.randn(M, N, device=dev); C = torch.empty(M, N, device=dev); d = ops.Dropout(0.1, 1, 2)
+        f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, bias=bias, alpha=0.5, epi=ops.EPI_RESID, aux_in=R, drop=d, **kw)
+    elif epi == "atomic":
+        C = torch.zeros(M, N, device=dev)
+        f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, atomic=True, splitk=splitk, **kw)
+    t = timeit(f)
+    print(f"{name:34s} {layout} M={M:7d} N={N:5d} K={K:6d} epi={epi:7s} {t*1e6:9.1f} us  {2.0*M*N*K/t/1e12:8.1f} TFLOP/s", flush=True)
+
+M = 16032
+run("ffn1_fwd", M, 2048, 512, "swish")
+run("ffn1_fwd_store", M, 2048, 512, "store")
+run("ffn1_fwd_nobias", M, 2048, 512, "nobias")
+run("ffn2_fwd", M, 512, 2048, "resid")
+run("ffn2_fwd_store", M, 512, 2048, "store")
+run("qkv_fwd", M, 1536, 512, "store")
+run("proj_fwd", M, 512, 512, "store")
+run("conv2_fwd", 320640, 512, 4608, "store")
+run("big_square", 8192, 8192, 8192, "nobias")
+run("ffn1_wgrad", 2048, 512, M, "atomic", torch.float32, "TN", splitk=8)
+run("ffn2_wgrad", 512, 2048, M, "atomic", torch.float32, "TN", splitk=8)
+run("proj_wgrad", 512, 512, M, "atomic", torch.float32, "TN", splitk=32)
+run("pv_like_NN", 4096, 4096, 4096, "nobias", bf, "NN")
