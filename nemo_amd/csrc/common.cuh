@@ -108,13 +108,33 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 }
 struct DropCfg {
   uint32_t key;        // mix of (seed, site)
-  uint32_t threshold;  // keep iff hash >= threshold ; threshold = p * 2^32 ; 0 => dropout off
+  uint32_t threshold;  // keep iff rnd >= threshold ; threshold = p * 2^32 ; 0 => dropout off
   float scale;         // 1/(1-p)
 };
-__device__ __forceinline__ float drop_mask(const DropCfg& d, uint32_t idx) {
+// Elements are hashed in groups of 8 consecutive indices: one strong 32-bit hash per group seeds a xorshift32 stream
+// whose (e+1)-th output decides element e.  v_mul_lo_u32 runs at quarter rate on CDNA4, so hashing every element
+// (4 multiplies) cost as many VALU cycles as the MFMA main loop of a K=512 GEMM; the xorshift steps are full-rate ops.
+__device__ __forceinline__ uint32_t xorshift32(uint32_t s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+__device__ __forceinline__ uint32_t drop_group_seed(const DropCfg& d, uint32_t group) {
+  return mix32(mix32(group ^ d.key) + 0x9E3779B9u * (d.key | 1u)) | 1u;  // non-zero state
+}
+__device__ __forceinline__ float drop_mask(const DropCfg& d, uint32_t idx) {  // scalar form (defines the function)
   if (d.threshold == 0u) return 1.f;
-  uint32_t h = mix32(mix32(idx ^ d.key) + 0x9E3779B9u * (d.key | 1u));
-  return h >= d.threshold ? d.scale : 0.f;
+  uint32_t s = drop_group_seed(d, idx >> 3);
+  const uint32_t e = idx & 7u;
+  for (uint32_t j = 0; j <= e; ++j) s = xorshift32(s);
+  return s >= d.threshold ? d.scale : 0.f;
+}
+// masks of the 8 elements idx8 .. idx8+7 (idx8 % 8 == 0)
+__device__ __forceinline__ void drop_mask8(const DropCfg& d, uint32_t idx8, float (&m)[8]) {
+  if (d.threshold == 0u) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = 1.f;
+    return;
+  }
+  uint32_t s = drop_group_seed(d, idx8 >> 3);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s = xorshift32(s); m[j] = s >= d.threshold ? d.scale : 0.f; }
 }
 // standard normal from a counter (Box-Muller on two hashed uniforms) -- dither noise in the mel front-end
 __device__ __forceinline__ float hash_normal(uint32_t key, uint32_t idx) {

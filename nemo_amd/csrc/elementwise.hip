@@ -60,14 +60,15 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ in, 
 // ------------------------------------------------------------------------------------------------ dropout-scale-cast
 // out[m,n] = alpha * dropmask(m*N+n) * in[m,n]     (in f32 [M,N] dense, out T dense)
 template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void drop_scale_cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long long n4,
+__global__ __launch_bounds__(256) void drop_scale_cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long long n8,
                                                               float alpha, DropCfg drop) {
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    float v[4];
-    ld4(in + i * 4, v);
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float a[4], b[4], m[8];
+    ld4(in + i * 8, a); ld4(in + i * 8 + 4, b);
+    drop_mask8(drop, (uint32_t)(i * 8), m);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] *= alpha * drop_mask(drop, (uint32_t)(i * 4 + j));
-    st4(out + i * 4, v);
+    for (int j = 0; j < 4; ++j) { a[j] *= alpha * m[j]; b[j] *= alpha * m[j + 4]; }
+    st4(out + i * 8, a); st4(out + i * 8 + 4, b);
   }
 }
 
@@ -223,12 +224,12 @@ extern "C" int mi355x_glu_bwd(const void* in, const void* dout, void* din, int d
 extern "C" int mi355x_drop_scale_cast(const void* in, int in_dt, void* out, int out_dt, long long n, float alpha,
                                       unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
   mi_clear_errors();
-  if (!in || !out || n <= 0 || (n & 3)) return MI_ERR_ARG;
+  if (!in || !out || n <= 0 || (n & 7)) return MI_ERR_ARG;
   DropCfg dc{drop_key, drop_threshold, drop_scale};
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(in_dt, TI, DISPATCH_DT(out_dt, TO,
-    hipLaunchKernelGGL((drop_scale_cast_kernel<TI, TO>), dim3(grid_for(n >> 2)), dim3(256), 0, s, (const TI*)in, (TO*)out,
-                       n >> 2, alpha, dc)));
+    hipLaunchKernelGGL((drop_scale_cast_kernel<TI, TO>), dim3(grid_for(n >> 3)), dim3(256), 0, s, (const TI*)in, (TO*)out,
+                       n >> 3, alpha, dc)));
   return mi_check_launch();
 }
 extern "C" int mi355x_qbias(const void* qkv, long long ldq, const void* u, const void* v, void* qu, void* qv, int dt,

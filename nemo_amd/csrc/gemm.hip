@@ -42,6 +42,7 @@ struct GemmP {
   DropCfg drop;
   const long long* row_len; int rows_per_b; int rows_inner;
   int splitk; int ktiles_per_split;
+  float* colsum_out;                   // transA only: colsum_out[m] += sum_k A(k, m)  (bias gradient fused into wgrad)
   int vec_ok;                          // C / aux rows are 8-element aligned & dense: vectorised epilogue allowed
 };
 
@@ -110,27 +111,33 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, int z, long long coff,
     for (int j = 0; j < 8; ++j) v[j] += b[j];
   }
   const uint32_t didx = (uint32_t)z * (uint32_t)(p.M * p.N) + (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+  float dm[8];
+  if ((didx & 7u) == 0u) drop_mask8(p.drop, didx, dm);
+  else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dm[j] = drop_mask(p.drop, didx + j);
+  }
   switch (p.epi) {
     case EPI_STORE:
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] *= p.alpha * drop_mask(p.drop, didx + j);
+      for (int j = 0; j < 8; ++j) v[j] *= p.alpha * dm[j];
       break;
     case EPI_SWISH_DROP:
       st8x(p.aux_out, ai, p.auxout_dt, v);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * drop_mask(p.drop, didx + j);
+      for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * dm[j];
       break;
     case EPI_RESID: {
       float r[8];
       ld8x(p.aux_in, ai, MI_DT_F32, r);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = r[j] + p.alpha * v[j] * drop_mask(p.drop, didx + j);
+      for (int j = 0; j < 8; ++j) v[j] = r[j] + p.alpha * v[j] * dm[j];
     } break;
     case EPI_DSWISH: {
       float h[8];
       ld8x(p.aux_in, ai, p.auxin_dt, h);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = v[j] * drop_mask(p.drop, didx + j) * swish_grad(h[j]);
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * dm[j] * swish_grad(h[j]);
     } break;
     case EPI_RELU_MASK: {
       const int b = m / p.rows_per_b;
@@ -184,6 +191,28 @@ __device__ __forceinline__ void store_n(const StageN& s, bf16_t* lds) {
     const int q = threadIdx.x + i * 256;
     const int r = q >> 3, ck = q & 7;
     *reinterpret_cast<u32x4*>(lds + lds_off(r, ck)) = s.v[i];
+  }
+}
+// ---- LDS-DMA staging of a [rows][K] operand tile (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR / ds_write
+// round trip).  The LDS image is lane-linear, so the bank swizzle is applied to the SOURCE chunk: LDS[r][c] <- global
+// chunk c ^ ((r>>1)&7); the fragment reads use the same involution (lds_off).  Rows past the matrix are clamped (their
+// results are never stored); k-chunks past K read a zero page.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+__device__ __forceinline__ void glds_n(const bf16_t* base, long long ld, int row0, int rows, int k0, int K, bf16_t* lds_tile) {
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = threadIdx.x + i * 256;
+    const int r = q >> 3, ck = q & 7;
+    const int gck = ck ^ ((r >> 1) & 7);
+    int gr = row0 + r;
+    gr = gr < rows ? gr : rows - 1;
+    const int gk = k0 + gck * 8;
+    const bf16_t* src = (gk < K) ? base + (long long)gr * ld + gk : reinterpret_cast<const bf16_t*>(g_zero16);
+    bf16_t* dst = lds_tile + (wave * 64 + i * 256) * 8;  // wave-uniform; lane l lands at dst + 16*l bytes
+    __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
   }
 }
 // ---- staging of a [K][rows] (reduction-major) operand tile: 64 k-rows x 128 cols; thread = (k-group of 4, 8-col chunk)
@@ -257,26 +286,39 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  StageN an, bn; StageT at, bt;
-  auto load_tiles = [&](int kt) {
+  // K-contiguous operands go global -> LDS by DMA (glds_n); reduction-major operands are transposed through registers.
+  StageT at, bt;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = TA && p.colsum_out != nullptr && tile_n == 0;
+  auto issue_loads = [&](int kt, int buf) {
     const int k0 = kt * BK;
-    if (TA) load_t(at, A, p.lda, m0, p.M, k0, p.K); else load_n(an, A, p.lda, m0, p.M, k0, p.K);
-    if (TB) load_t(bt, B, p.ldb, n0, p.N, k0, p.K); else load_n(bn, B, p.ldb, n0, p.N, k0, p.K);
+    if (TA) load_t(at, A, p.lda, m0, p.M, k0, p.K); else glds_n(A, p.lda, m0, p.M, k0, p.K, SA(buf));
+    if (TB) load_t(bt, B, p.ldb, n0, p.N, k0, p.K); else glds_n(B, p.ldb, n0, p.N, k0, p.K, SB(buf));
   };
-  auto store_tiles = [&](int buf) {
-    if (TA) store_t(at, SA(buf)); else store_n(an, SA(buf));
-    if (TB) store_t(bt, SB(buf)); else store_n(bn, SB(buf));
+  auto finish_loads = [&](int buf) {
+    if (TA && do_colsum) {  // this thread holds A rows k = 4g..4g+3, columns 8c..8c+7 of the tile (zero-filled outside)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          csum[2 * w] += __uint_as_float(at.v[j][w] << 16);
+          csum[2 * w + 1] += __uint_as_float(at.v[j][w] & 0xffff0000u);
+        }
+    }
+    if (TA) store_t(at, SA(buf));
+    if (TB) store_t(bt, SB(buf));
+    if (!TA || !TB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
-  load_tiles(kt_begin);
-  store_tiles(0);
+  issue_loads(kt_begin, 0);
+  finish_loads(0);
   __syncthreads();
 
   const int lr = lane & 31, lh = lane >> 5;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int cur = (kt - kt_begin) & 1;
     const bool more = (kt + 1 < kt_end);
-    if (more) load_tiles(kt + 1);
+    if (more) issue_loads(kt + 1, cur ^ 1);
     const bf16_t* a_s = SA(cur);
     const bf16_t* b_s = SB(cur);
 #pragma unroll
@@ -295,8 +337,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tiles(cur ^ 1);
+    if (more) finish_loads(cur ^ 1);
     __syncthreads();
+  }
+
+  if (TA && do_colsum) {  // reduce over the 16 k-groups (16 consecutive lanes share the column chunk), 1 atomic / column
+    const int c = threadIdx.x >> 4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = csum[e];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+      const int m = m0 + c * 8 + e;
+      if ((threadIdx.x & 15) == 0 && m < p.M) atomicAdd(p.colsum_out + m, v);
+    }
   }
 
   // ---- epilogue through LDS: accumulators (C/D layout of the 32x32 MFMA: col = lane&31,
@@ -426,6 +479,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   p.aux_in = d->aux_in; p.auxin_dt = d->aux_in_dtype; p.aux_out = d->aux_out; p.auxout_dt = d->aux_out_dtype;
   p.ldaux = d->ldaux;
   p.drop.key = d->drop_key; p.drop.threshold = d->drop_threshold; p.drop.scale = d->drop_scale;
+  p.colsum_out = (float*)d->colsum_out;
   p.row_len = (const long long*)d->row_len; p.rows_per_b = d->rows_per_b > 0 ? d->rows_per_b : 1;
   p.rows_inner = d->rows_inner > 0 ? d->rows_inner : 1;
   if (p.epi < EPI_STORE || p.epi > EPI_MUL_POS) return MI_ERR_ARG;
@@ -433,6 +487,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   if ((p.epi == EPI_RESID || p.epi == EPI_DSWISH || p.epi == EPI_MUL_POS) && !p.aux_in) return MI_ERR_ARG;
   if (p.epi == EPI_SWISH_DROP && !p.aux_out) return MI_ERR_ARG;
   if (p.epi == EPI_RELU_MASK && !p.row_len) return MI_ERR_ARG;
+  if (p.colsum_out && (!p.transA || d->in_dtype != MI_DT_BF16 || p.batch != 1)) return MI_ERR_ARG;
   const int nk = (p.K + BK - 1) / BK;
   int sk = d->splitk > 1 ? d->splitk : 1;
   if (sk > nk) sk = nk;

@@ -82,6 +82,79 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const TDY* __restrict__ 
   }
 }
 
+// Fused LayerNorm backward: dx (as above) AND the parameter gradients in one pass over dy / x.  A block walks LNB_ROWS rows
+// (wave w takes rows w, w+4, ...); every lane owns the same NV 4-column groups for all its rows, so dgamma / dbeta
+// partials live in registers, are combined across the 4 waves through LDS and leave as one atomic per column per block.
+#define LNB_ROWS 64
+template <typename TX, typename TDY, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ dres,
+                                                           int accumulate, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int M, int d) {
+  __shared__ float red[4][2][NV * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = d >> 2;
+  float g[NV][4], ag[NV][4], ab[NV][4];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = lane + 64 * k;
+    if (i < nv) ld4(gamma + i * 4, g[k]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ag[k][j] = 0.f; ab[k][j] = 0.f; }
+  }
+  const int r0 = blockIdx.x * LNB_ROWS, r1 = min(M, r0 + LNB_ROWS);
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const TX* xr = x + (long long)row * d;
+    const TDY* dyr = dy + (long long)row * d;
+    float* dr = dres + (long long)row * d;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NV][4], e[NV][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane + 64 * k;
+      if (i < nv) {
+        float v[4];
+        ld4(xr + i * 4, v); ld4(dyr + i * 4, e[k]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[k][j] = (v[j] - mu) * rs;
+          const float gd = g[k][j] * e[k][j];
+          s1 += gd; s2 += gd * xh[k][j];
+          ag[k][j] += e[k][j] * xh[k][j]; ab[k][j] += e[k][j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane + 64 * k;
+      if (i < nv) {
+        float o[4];
+        if (accumulate) ld4(dr + i * 4, o); else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += rs * (g[k][j] * e[k][j] - s1 - xh[k][j] * s2);
+        st4(dr + i * 4, o);
+      }
+    }
+  }
+  if (!dgamma) return;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[wave][0][(lane + 64 * k) * 4 + j] = ag[k][j];
+      red[wave][1][(lane + 64 * k) * 4 + j] = ab[k][j];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    atomicAdd(dgamma + c, (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]));
+    atomicAdd(dbeta + c, (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]));
+  }
+}
+
 // dgamma[n] += sum_m dy*xhat ; dbeta[n] += sum_m dy.   Block = 64 columns x 4 row-lanes, ROWS_PER_BLOCK rows.
 #define CR_ROWS 256
 template <typename TX, typename TDY>
@@ -184,6 +257,21 @@ extern "C" int mi355x_layernorm_bwd(const void* dy, int dy_dt, const void* x, in
   if (!dy || !x || !gamma || !mean || !rstd || !dres || M <= 0 || d <= 0 || (d & 3)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 block(256);
+  if (d <= 1024 && ((dgamma && dbeta) || (!dgamma && !dbeta))) {
+    dim3 gridf((M + LNB_ROWS - 1) / LNB_ROWS);
+    const int nvv = (d / 4 + 63) / 64;
+#define LN_FUSED(NV) DISPATCH_DT(x_dt, TX, DISPATCH_DT(dy_dt, TDY, \
+      hipLaunchKernelGGL((ln_bwd_fused_kernel<TX, TDY, NV>), gridf, block, 0, s, (const TDY*)dy, (const TX*)x, \
+                         (const float*)gamma, (const float*)mean, (const float*)rstd, (float*)dres, accumulate, \
+                         (float*)dgamma, (float*)dbeta, M, d)))
+    switch (nvv) {
+      case 1: LN_FUSED(1); break;
+      case 2: LN_FUSED(2); break;
+      case 3: LN_FUSED(3); break;
+      default: LN_FUSED(4); break;
+    }
+    return mi_check_launch();
+  }
   if (dgamma && dbeta) {
     dim3 gp((d + 63) / 64, (M + CR_ROWS - 1) / CR_ROWS);
     DISPATCH_DT(x_dt, TX, DISPATCH_DT(dy_dt, TDY,

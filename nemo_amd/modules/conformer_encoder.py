@@ -304,13 +304,17 @@ class ConformerEncoder(NeuralModule):
         nk = (K + 63) // 64
         return max(1, min(nk, 512 // max(tiles, 1)))
 
-    def _wgrad(self, dY, ldy, y_off, X, ldx, x_off, dW, n_out, n_in, rows, ldw=None, w_off=0, col_stride=1):
-        """dW[n_out, n_in] += dY[:, y_off:y_off+n_out]^T @ X[:, x_off:x_off+n_in]   (TN GEMM, atomic split-K)"""
-        t = 128 if dY.dtype == torch.bfloat16 else 64
+    def _wgrad(self, dY, ldy, y_off, X, ldx, x_off, dW, n_out, n_in, rows, bias_grad=None):
+        """dW[n_out, n_in] += dY[:, y_off:y_off+n_out]^T @ X[:, x_off:x_off+n_in]   (TN GEMM, atomic split-K);
+        bias_grad[n_out] += column sums of dY -- fused into the same kernel on the bf16 path."""
+        bf16 = dY.dtype == torch.bfloat16
+        t = 128 if bf16 else 64
         tiles = ((n_out + t - 1) // t) * ((n_in + t - 1) // t)
-        ops.gemm(dY, X, dW, n_out, n_in, rows, ldy, ldx, ldw if ldw is not None else n_in, transA=True, transB=True,
-                 atomic=True, splitk=self._splitk(tiles, rows), a_off=y_off, b_off=x_off, c_off=w_off,
-                 c_col_stride=col_stride, c_dtype=ops.F32)
+        if bias_grad is not None and not bf16:
+            ops.colsum(dY, bias_grad, rows, n_out, ld=ldy, x_off=y_off)
+        ops.gemm(dY, X, dW, n_out, n_in, rows, ldy, ldx, n_in, transA=True, transB=True, atomic=True,
+                 splitk=self._splitk(tiles, rows), a_off=y_off, b_off=x_off, c_dtype=ops.F32,
+                 colsum_out=bias_grad if bf16 else None)
 
     def _lens(self, length):
         l0 = length.to(torch.int64)
@@ -525,12 +529,10 @@ class ConformerEncoder(NeuralModule):
         x, y, mean, rstd, h, a, d_in, d_res = saved
         df = torch.empty(M, d, dtype=cdt, device=dev)
         ops.drop_scale_cast(dr, df, M * d, 0.5, d_res)
-        ops.colsum(df, ff.linear2.bias.grad, M, d)
-        self._wgrad(df, d, 0, a, dff, 0, ff.linear2.weight.grad, d, dff, M)
+        self._wgrad(df, d, 0, a, dff, 0, ff.linear2.weight.grad, d, dff, M, bias_grad=ff.linear2.bias.grad)
         dh = torch.empty(M, dff, dtype=cdt, device=dev)
         ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, d, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH, aux_in=h, drop=d_in)
-        ops.colsum(dh, ff.linear1.bias.grad, M, dff)
-        self._wgrad(dh, dff, 0, y, d, 0, ff.linear1.weight.grad, dff, d, M)
+        self._wgrad(dh, dff, 0, y, d, 0, ff.linear1.weight.grad, dff, d, M, bias_grad=ff.linear1.bias.grad)
         dy = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(dh, W[pfx + ".w1t"], dy, M, d, dff, dff, W.pitch(pfx + ".w1t"), d)
         ops.layernorm_bwd(dy, x, ln.weight, mean, rstd, dr, True, ln.weight.grad, ln.bias.grad, M, d)
@@ -557,8 +559,7 @@ class ConformerEncoder(NeuralModule):
         r2, y3, mean3, rstd3, pw1, g, cc, bmean, brstd, count, z, d_cres = sl.conv
         db = torch.empty(M, d, dtype=cdt, device=dev)
         ops.drop_scale_cast(dr, db, M * d, 1.0, d_cres)
-        ops.colsum(db, c.pointwise_conv2.bias.grad, M, d)
-        self._wgrad(db, d, 0, z, d, 0, c.pointwise_conv2.weight.grad, d, d, M)
+        self._wgrad(db, d, 0, z, d, 0, c.pointwise_conv2.weight.grad, d, d, M, bias_grad=c.pointwise_conv2.bias.grad)
         dz = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(db, W[f"L{i}.conv.pw2t"], dz, M, d, d, d, W.pitch(f"L{i}.conv.pw2t"), d)
         sums = torch.zeros(2, d, dtype=torch.float64, device=dev)
@@ -572,8 +573,7 @@ class ConformerEncoder(NeuralModule):
         ops.dwconv_bwd(dcc, g, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
         dpw1 = torch.empty(M, 2 * d, dtype=cdt, device=dev)
         ops.glu_bwd(pw1, dg, dpw1, S.len2, T2, M, d)
-        ops.colsum(dpw1, c.pointwise_conv1.bias.grad, M, 2 * d)
-        self._wgrad(dpw1, 2 * d, 0, y3, d, 0, c.pointwise_conv1.weight.grad, 2 * d, d, M)
+        self._wgrad(dpw1, 2 * d, 0, y3, d, 0, c.pointwise_conv1.weight.grad, 2 * d, d, M, bias_grad=c.pointwise_conv1.bias.grad)
         dy3 = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(dpw1, W[f"L{i}.conv.pw1t"], dy3, M, d, 2 * d, 2 * d, W.pitch(f"L{i}.conv.pw1t"), d)
         ln = L.norm_conv
@@ -583,8 +583,7 @@ class ConformerEncoder(NeuralModule):
         r1, y2, mean2, rstd2, qkv, p, qu, qv, s_, pd, ctx, d_att, d_ares = sl.att
         dao = torch.empty(M, d, dtype=cdt, device=dev)
         ops.drop_scale_cast(dr, dao, M * d, 1.0, d_ares)
-        ops.colsum(dao, a.linear_out.bias.grad, M, d)
-        self._wgrad(dao, d, 0, ctx, d, 0, a.linear_out.weight.grad, d, d, M)
+        self._wgrad(dao, d, 0, ctx, d, 0, a.linear_out.weight.grad, d, d, M, bias_grad=a.linear_out.bias.grad)
         dctx = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(dao, W[f"L{i}.att.wot"], dctx, M, d, d, d, W.pitch(f"L{i}.att.wot"), d)
         dqkv = torch.empty(M, 3 * d, dtype=cdt, device=dev)
@@ -622,8 +621,7 @@ class ConformerEncoder(NeuralModule):
         ops.colsum(dqv, a.pos_bias_v.grad, M, d)
         ops.add2(dqu, dqv, dqkv, 3 * d, M, d)
         for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
-            ops.colsum(dqkv, lin.bias.grad, M, d, ld=3 * d, x_off=j * d)
-            self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M)
+            self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M, bias_grad=lin.bias.grad)
         dy2 = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(dqkv, W[f"L{i}.att.wqkvt"], dy2, M, d, 3 * d, 3 * d, W.pitch(f"L{i}.att.wqkvt"), d)
         ln = L.norm_self_att

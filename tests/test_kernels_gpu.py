@@ -139,6 +139,21 @@ def test_gemm_batched_strided_bf16():
     assert rel_err(ctx, ref2) < 1e-2
 
 
+def test_gemm_wgrad_fused_bias_grad():
+    """TN wgrad with the bias-gradient column sums riding along (colsum_out), split-K atomics, M tail"""
+    o = ops()
+    rows, n_out, n_in = 1000, 200, 136
+    g = torch.Generator().manual_seed(21)
+    dY = bf(torch.randn(rows, 208, generator=g)); dY[:, 200:] = 0
+    X = bf(torch.randn(rows, n_in, generator=g))
+    dW = torch.ones(n_out, n_in, device=dev); db = torch.ones(n_out, device=dev)
+    o.gemm(dY.to(dev), X.to(dev), dW, n_out, n_in, rows, 208, n_in, n_in, transA=True, transB=True, atomic=True, splitk=4,
+           colsum_out=db)
+    torch.cuda.synchronize()
+    assert rel_err(dW, 1 + dY[:, :200].float().t() @ X.float()) < 1e-4
+    assert rel_err(db, 1 + dY[:, :200].float().sum(0)) < 1e-4
+
+
 def test_gemm_dropout_consistency():
     """EPI_SWISH_DROP forward mask == mask regenerated by drop_scale_cast (same key, idx = m*N+n)."""
     o = ops()
