@@ -1,0 +1,186 @@
+"""CPU-side checks (run without a GPU): the C-ABI library loads and exports every symbol include/mi355x_asr.h declares,
+the ctypes structures mirror the C structs, the drop-in classes keep the reference's constructor / state-dict / typing
+contract, flat parameter storage + packing plans are consistent, LR schedule and config plumbing behave like the
+reference.  No kernel is launched here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nemo_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mi355x_asr.h")).read()
+    declared = set(re.findall(r"\b(mi355x_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert _lib.version().startswith("mi355x_asr")
+
+
+def test_struct_layouts_match_the_header():
+    """compile a tiny C program against the header and compare sizeof/offsetof with the ctypes mirrors"""
+    from nemo_amd._lib import GemmDesc, PackEntry
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "mi355x_asr.h"
+int main(){
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(mi355x_gemm_desc), offsetof(mi355x_gemm_desc, c_col_stride),
+         offsetof(mi355x_gemm_desc, bias), offsetof(mi355x_gemm_desc, aux_in), offsetof(mi355x_gemm_desc, drop_key),
+         offsetof(mi355x_gemm_desc, row_len), offsetof(mi355x_gemm_desc, colsum_out));
+  printf("%zu %zu\n", sizeof(mi355x_pack_entry), offsetof(mi355x_pack_entry, tile_begin));
+  return 0; }'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        c = os.path.join(tmp, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(tmp, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split()
+    vals = list(map(int, out))
+    G = GemmDesc
+    assert vals[:7] == [ctypes.sizeof(G), G.c_col_stride.offset, G.bias.offset, G.aux_in.offset, G.drop_key.offset,
+                        G.row_len.offset, G.colsum_out.offset]
+    assert vals[7:] == [ctypes.sizeof(PackEntry), PackEntry.tile_begin.offset]
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    """argument validation happens before any launch: rc 1 -> ValueError (the reference raises ValueError for bad shapes)"""
+    from nemo_amd import _lib
+    d = _lib.GemmDesc()  # all-zero descriptor
+    assert _lib.lib.mi355x_gemm(ctypes.byref(d), None) == 1
+    with pytest.raises(ValueError):
+        _lib.check(1, "gemm")
+    with pytest.raises(RuntimeError):
+        _lib.check(1000 + 98, "gemm")
+    assert _lib.lib.mi355x_ctc_loss(None, None, None, None, None, None, None, None, 1, 1, 1, 1, 0, 1.0, 1, None) == 1
+    assert _lib.lib.mi355x_layernorm_fwd(None, 0, None, None, None, 0, None, None, 4, 6, 1e-5, None) == 1
+
+
+def test_cpu_tensors_fail_loudly():
+    from nemo_amd import ops
+    x = torch.zeros(4, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.layernorm_fwd(x, torch.ones(8), torch.zeros(8), x.clone(), torch.zeros(4), torch.zeros(4), 4, 8)
+
+
+def test_encoder_state_dict_is_the_reference_abi(golden_dir):
+    """keys / shapes identical to the reference ConformerEncoder's state_dict (fixture written by the reference classes)"""
+    from nemo_amd.modules import ConformerEncoder, ConvASRDecoder
+    z = np.load(os.path.join(golden_dir, "ref_tiny_model.npz"))
+    ref = {k[len("P/encoder."):]: z[k].shape for k in z.files if k.startswith("P/encoder.")}
+    enc = ConformerEncoder(feat_in=80, n_layers=2, d_model=32, n_heads=4)
+    mine = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    assert mine == {k: tuple(v) for k, v in ref.items()}
+    dec = ConvASRDecoder(feat_in=32, num_classes=16)
+    assert {k: tuple(v.shape) for k, v in dec.state_dict().items()} == {
+        "decoder_layers.0.weight": (17, 32, 1), "decoder_layers.0.bias": (17,)}
+    assert dec.num_classes_with_blank == 17 and dec._feat_in == 32 and enc._feat_out == 32 and enc.subsampling_factor == 4
+
+
+def test_preprocessor_buffers_and_seq_len(golden_dir):
+    from nemo_amd.modules import AudioToMelSpectrogramPreprocessor
+    z = np.load(os.path.join(golden_dir, "ref_mel_b3.npz"))
+    p = AudioToMelSpectrogramPreprocessor(sample_rate=16000, window_size=0.025, window_stride=0.01, features=80, n_fft=512,
+                                          pad_to=0, dither=1e-5)
+    sd = p.state_dict()
+    assert set(sd) == {"featurizer.window", "featurizer.fb"}  # persistent buffers of the reference (features.py:327,344)
+    assert np.array_equal(sd["featurizer.fb"].numpy(), z["fb"])
+    assert np.allclose(sd["featurizer.window"].numpy(), z["window"], atol=1e-7)
+    assert p.featurizer.dither == 1e-5 and p.featurizer.pad_to == 0 and p._sample_rate == 16000
+    # get_seq_len: features.py:413-417 / test_asr_filterbankfeatures_seq_len.py
+    assert p.featurizer.get_seq_len(torch.from_numpy(z["audio_len"])).tolist() == z["mel_len"].tolist()
+    with pytest.raises(ValueError):
+        AudioToMelSpectrogramPreprocessor(window_size=0.02, n_window_size=320)
+
+
+def test_typecheck_contract():
+    from nemo_amd.core import typecheck
+    from nemo_amd.modules import ConvASRDecoder, CTCLoss
+    dec = ConvASRDecoder(feat_in=8, num_classes=4)
+    with pytest.raises(TypeError, match="kwargs only"):
+        dec(torch.zeros(1, 8, 3))
+    with pytest.raises(TypeError, match="no corresponding input_type"):
+        dec(encoder_outputs=torch.zeros(1, 8, 3))
+    with pytest.raises(TypeError, match="shape mismatch"):
+        dec(encoder_output=torch.zeros(8, 3))
+    with pytest.raises(ValueError):
+        CTCLoss(num_classes=4, reduction="bogus")
+    assert list(dec.input_types) == ["encoder_output"] and list(dec.output_types) == ["logprobs"]
+
+
+def test_unsupported_configurations_raise():
+    from nemo_amd.modules import ConformerEncoder
+    for kw in (dict(subsampling="dw_striding"), dict(self_attention_model="abs_pos"), dict(conv_norm_type="layer_norm"),
+               dict(att_context_size=[128, 0])):
+        with pytest.raises(NotImplementedError):
+            ConformerEncoder(feat_in=80, n_layers=1, d_model=32, n_heads=4, **kw)
+
+
+def test_from_config_dict_resolves_reference_targets():
+    from nemo_amd.core import Serialization
+    from nemo_amd.modules import ConformerEncoder
+    enc = Serialization.from_config_dict({"_target_": "nemo.collections.asr.modules.ConformerEncoder", "feat_in": 80,
+                                          "n_layers": 1, "d_model": 32, "n_heads": 4})
+    assert isinstance(enc, ConformerEncoder) and enc.to_config_dict()["d_model"] == 32
+    with pytest.raises(ValueError):
+        Serialization.from_config_dict({"_target_": "os.system"})
+
+
+def test_noam_annealing_matches_reference_formula():
+    from nemo_amd.optim import NoamAnnealing
+    s = NoamAnnealing(base_lr=2.0, d_model=512, warmup_steps=10000, min_lr=1e-6)
+    for step in (1, 10, 9999, 10000, 10001, 400000):
+        ref = 2.0 * 512 ** -0.5 * min(step ** -0.5, step * 10000 ** -1.5)
+        if step > 10000:
+            ref = max(ref, 1e-6)
+        assert abs(s.lr_at(step) - ref) < 1e-12
+    assert s.step() == s.lr_at(1)
+
+
+def test_flat_params_alias_parameters_and_grads():
+    from nemo_amd.flat import FlatParams
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.LayerNorm(7))
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    fp = FlatParams(m)
+    fp.ensure()
+    for n, p in m.named_parameters():
+        off, num = fp.offsets[n]
+        assert off % 64 == 0 and torch.equal(p.detach(), before[n])
+        assert p.data_ptr() == fp.flat.data_ptr() + 4 * off and p.grad.data_ptr() == fp.grad.data_ptr() + 4 * off
+    fp.flat.zero_()
+    assert all(float(p.abs().sum()) == 0 for p in m.parameters())
+    s, e = fp.range_of("1.")
+    assert (s, e) == (fp.offsets["1.weight"][0], fp.offsets["1.bias"][0] + 64)
+    gen = fp.generation
+    m.to(torch.float32)
+    fp.ensure()
+    assert fp.generation == gen  # still valid: no rebuild
+
+
+def test_model_config_and_nemo_file_roundtrip(tmp_path):
+    from nemo_amd.core import load_nemo
+    from nemo_amd.models import EncDecCTCModel, conformer_ctc_config
+    cfg = conformer_ctc_config("small", vocab_size=16, n_layers=1, d_model=32)
+    m = EncDecCTCModel(cfg)
+    assert m.loss.blank == 16 and m.decoder._feat_in == 32
+    path = str(tmp_path / "x.nemo")
+    m.save_to(path)
+    cfg2, sd = load_nemo(path)
+    assert cfg2["encoder"]["d_model"] == 32 and set(sd) == set(m.state_dict())
+    m2 = EncDecCTCModel.restore_from(path)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    with pytest.raises(NotImplementedError):
+        bad = conformer_ctc_config("small", vocab_size=16, n_layers=1, d_model=32)
+        bad["spec_augment"] = {"freq_masks": 2, "time_masks": 10}
+        EncDecCTCModel(bad)
