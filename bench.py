@@ -128,6 +128,17 @@ def main():
             g[0] += 2.0 * M * N * K * nb
             g[1] += e0.elapsed_time(e1) * 1e-3
             g[2] += 1
+        table_path = os.environ.get("BENCH_GEMM_TABLE")
+        if table_path:
+            shapes = {}
+            for (variant, M, N, K, nb, e0, e1) in ops.GEMM_PROFILE:
+                g = shapes.setdefault((variant, M, N, K, nb), [0.0, 0])
+                g[0] += e0.elapsed_time(e1) * 1e-3
+                g[1] += 1
+            with open(table_path, "w") as f:
+                f.write("variant M N K batch launches total_ms avg_us TFLOP/s\n")
+                for (variant, M, N, K, nb), (t, c) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
+                    f.write(f"{variant} {M} {N} {K} {nb} {c} {t*1e3:.3f} {t/c*1e6:.1f} {2.0*M*N*K*nb*c/t/1e12:.1f}\n")
         ops.GEMM_PROFILE = None
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         flops, secs_, cnt = dom[1]

@@ -117,6 +117,23 @@ int mi355x_relpos_softmax_bwd(const void* dpd, int dpd_dtype, const void* s_in, 
                               int B, int T, int Tp, int Pp, float scale, unsigned drop_key, unsigned drop_threshold,
                               float drop_scale, void* stream);
 
+/* ---- fused rel-pos attention (bf16, d_k = 64): RelPositionMultiHeadAttention.forward, multi_head_attention.py:272-354.
+ * qkv [B*T, ldq = 3d] (q|k|v), pos = linear_pos(pos_emb) [2T-1, ldp], bias_u/v f32 [H*d_k], len i64 [B]
+ * -> ctx [B*T, ldo] bf16, lse f32 [B,H,T] (log-sum-exp of the masked scaled scores, kept for backward).
+ * Dropout index of probability (b,h,i,j) = ((h*B+b)*T + i)*Tp + j.                                                   */
+int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, long long ldp, const void* bias_u,
+                            const void* bias_v, const void* len, void* ctx, long long ldo, void* lse, int B, int H, int T,
+                            int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold, float drop_scale,
+                            void* stream);
+
+/* backward of the fused attention.  delta[b,h,i] = sum_dv dO*O.  dq kernel: qu = q+u, qv = q+v ([B*T,d] bf16, from
+ * mi355x_qbias), recomputes P from lse, returns dQu and dQv ([B*T,d] bf16; dq = dQu+dQv, d pos_bias_{u,v} = column sums). */
+int mi355x_attn_delta(const void* dO, const void* O, void* delta, int B, int H, int T, int d, void* stream);
+int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos, long long ldp,
+                               const void* len, const void* dO, const void* lse, const void* delta, void* dqu, void* dqv,
+                               int B, int H, int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold,
+                               float drop_scale, void* stream);
+
 /* ---- convolution module: depthwise conv + BatchNorm + Swish (conformer_modules.py:333-342, causal_convs.py:130-147) */
 int mi355x_dwconv_fwd(const void* x, const void* w /*[d,1,k]*/, const void* bias, void* y, int dtype,
                       void* stats /*f64 [2,d] += (sum, sumsq) or NULL*/, int B, int T, int d, int ksize, void* stream);

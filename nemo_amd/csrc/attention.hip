@@ -1,0 +1,485 @@
+// Fused relative-position multi-head self-attention for MI355X (bf16, d_k = 64), flash-style: the [B,H,T,T] score matrix
+// and the [B,H,T,2T-1] positional matrix of the reference are never materialised in HBM.
+//
+//   score[i,j] = ((q_i + u_h) . k_j + (q_i + v_h) . p_{T-1+j-i}) / sqrt(d_k)   (rel_shift == the index map c = T-1+j-i)
+//   masked keys / queries (>= len[b]) excluded, softmax, dropout, context = P @ V
+//
+// Every product keeps "lane = query": S^T = K Qu^T, G^T = P_band Qv^T, O^T = V^T P^T (mfma_f32_32x32x16_bf16, C/D layout
+// col = lane&31 = query, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).  Consequences:
+//   * row max / row sum of the online softmax are an in-lane reduction over 16 registers + one xor-32 shuffle;
+//   * the running rescale alpha is a per-lane scalar applied to the lane's own O^T registers;
+//   * the rel_shift becomes a PER-LANE CONSTANT row offset into G^T (c - c_min = key_row + 31 - q), resolved through a
+//     wave-private LDS tile [32 queries][66] (stride 65 between lanes: conflict-free reads);
+//   * P^T is consumed as the MFMA B operand straight from the S^T accumulator registers (the k-slot <-> key mapping of
+//     an MFMA is arbitrary as long as A and B agree), V^T fragments come from ds_read_b64_tr_b16 on the [key][dv] tile.
+// K / V / P-band tiles are staged by LDS-DMA (global_load_lds_dwordx4).  62 KiB LDS -> two workgroups per CU.
+//
+// Replaces on the reference path: RelPositionMultiHeadAttention.forward + MultiHeadAttention.forward_attention
+//   (nemo/collections/asr/parts/submodules/multi_head_attention.py:272-354, 124-146): two batched matmuls, pad/view/slice
+//   rel_shift, two masked_fill, softmax, dropout, matmul.
+#include "common.cuh"
+#include "mi355x_asr.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+#define ADK 64           // head dim
+#define ABQ 128          // queries per workgroup (4 waves x 32)
+#define ABK 32           // keys per step
+#define ABAND (ABQ + ABK)  // positional band rows staged per step (159 needed)
+#define SG_LD 66
+
+__device__ __forceinline__ int a_off(int r, int chunk) { return r * ADK + ((chunk ^ ((r >> 1) & 7)) << 3); }
+
+// rows [row0, row0+nrows) x 64 columns (col offset applied by caller) -> LDS image [nrows][64] with the (row>>1)&7 swizzle
+// applied on the source side; rows are clamped into [0, rmax]
+__device__ __forceinline__ void stage_rows(const bf16_t* base, long long ld, int row0, int rmax, bf16_t* lds, int nchunks) {
+  const int wave = threadIdx.x >> 6;
+  for (int q0 = 0; q0 < nchunks; q0 += 256) {
+    const int q = q0 + threadIdx.x;
+    if (q0 + wave * 64 < nchunks) {  // wave-uniform
+      const int r = q >> 3, ck = q & 7;
+      const int gck = ck ^ ((r >> 1) & 7);
+      int gr = row0 + r;
+      gr = gr < 0 ? 0 : (gr > rmax ? rmax : gr);
+      const bf16_t* src = base + (long long)gr * ld + gck * 8;
+      bf16_t* dst = lds + (q0 + wave * 64) * 8;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+    }
+  }
+}
+// V tile [32 keys][64 dv] kept exactly as in memory (for the transpose read), chunk swizzle c ^= (k&3)<<1
+__device__ __forceinline__ void stage_v(const bf16_t* base, long long ld, int row0, int rmax, bf16_t* lds) {
+  const int wave = threadIdx.x >> 6;
+  const int q = threadIdx.x;  // 256 chunks
+  const int k = q >> 3, cp = q & 7;
+  const int c = cp ^ ((k & 3) << 1);
+  int gr = row0 + k;
+  gr = gr > rmax ? rmax : gr;
+  const bf16_t* src = base + (long long)gr * ld + c * 8;
+  bf16_t* dst = lds + (wave * 64) * 8;
+  __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+}
+// A fragment of V^T for the P.V product: lane (dv = dv0 + (lane&31)) gets V[key slots of (s, half)][dv]
+__device__ __forceinline__ bf16x8 vt_frag(const bf16_t* vt, int dv0, int s, int lane) {
+  const int t = lane & 15, g4 = (lane >> 4) & 1, lh = lane >> 5;
+  const int col = dv0 + g4 * 16 + (t & 3) * 4;
+  union { bf16x8 v; s16x4 h[2]; } u;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int krow = 16 * s + 8 * r + 4 * lh + (t >> 2);  // keys (4*lh + 0..3) and (8 + 4*lh + 0..3) of K16 step s
+    const int off = krow * ADK + (((col >> 3) ^ ((krow & 3) << 1)) << 3) + (col & 7);
+    u.h[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vt + off));
+  }
+  return u.v;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  union { bf16x8 v; uint32_t w[4]; } u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) u.w[j] = pack_bf2(v[2 * j], v[2 * j + 1]);
+  return u.v;
+}
+
+// q fragments (B operand): lane holds (q + bias)[query = lane&31][dk = kk*16 + (lane>>5)*8 + e]
+__device__ __forceinline__ void load_q(const bf16_t* qrow, const float* bias, bf16x8 (&out)[4], bool valid, int lh) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    float v[8];
+    const int k0 = kk * 16 + lh * 8;
+    if (valid) {
+      const u32x4 t = *reinterpret_cast<const u32x4*>(qrow + k0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(t[j] << 16); v[2 * j + 1] = __uint_as_float(t[j] & 0xffff0000u); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += bias[k0 + j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    out[kk] = pack8(v);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* __restrict__ qkv, long long ldq,
+                                                                  const bf16_t* __restrict__ pos, long long ldp,
+                                                                  const float* __restrict__ bias_u, const float* __restrict__ bias_v,
+                                                                  const long long* __restrict__ len, bf16_t* __restrict__ ctx,
+                                                                  long long ldo, float* __restrict__ lse, int B, int H, int T,
+                                                                  int Tp, float scale, DropCfg drop) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_k[ABK * ADK];       // 4 KiB
+  __shared__ __attribute__((aligned(16))) bf16_t s_v[ABK * ADK];       // 4 KiB
+  __shared__ __attribute__((aligned(16))) bf16_t s_p[ABAND * ADK];     // 20 KiB
+  __shared__ __attribute__((aligned(16))) float s_g[4][32 * SG_LD];    // 33 KiB
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int i0_blk = blockIdx.x * ABQ;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane & 31, lh = lane >> 5;
+  const int i = i0_blk + wave * 32 + q;  // this lane's query
+  const int L = (int)min((long long)T, len[b]);
+  const bool qvalid = i < L;
+  const int P = 2 * T - 1;
+
+  const bf16_t* qbase = qkv + ((long long)b * T) * ldq + h * ADK;
+  const bf16_t* kbase = qbase + (ldq / 3);
+  const bf16_t* vbase = qbase + 2 * (ldq / 3);
+  const bf16_t* pbase = pos + h * ADK;
+
+  bf16x8 qu[4], qv[4];
+  load_q(qbase + (long long)(i < T ? i : T - 1) * ldq, bias_u + h * ADK, qu, i < T, lh);
+  load_q(qbase + (long long)(i < T ? i : T - 1) * ldq, bias_v + h * ADK, qv, i < T, lh);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+  float* sg = s_g[wave];
+  const uint32_t drow = (uint32_t)(((long long)h * B + b) * T + (i < T ? i : 0)) * (uint32_t)Tp;
+
+  const int nkt = (L + ABK - 1) / ABK;  // key tiles that contain at least one valid key
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int j0 = kt * ABK;
+    __syncthreads();  // previous step's LDS reads are done
+    stage_rows(kbase, ldq, j0, T - 1, s_k, ABK * 8);
+    stage_v(vbase, ldq, j0, T - 1, s_v);
+    const int c_base = T - 1 + j0 - (i0_blk + ABQ - 1);  // band row of local row 0
+    stage_rows(pbase, ldp, c_base, P - 1, s_p, ABAND * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- S^T = K . Qu^T  and  G^T = P_band . Qv^T
+    f32x16 acc_s, acc_g[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_s[r] = 0.f; acc_g[0][r] = 0.f; acc_g[1][r] = 0.f; }
+    const int prow0 = (ABQ - 32) - 32 * wave;  // local band row of this wave's c_min
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s_k + a_off(q, kk * 2 + lh));
+      acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[kk], acc_s, 0, 0, 0);
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt) {
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off(prow0 + 32 * gt + q, kk * 2 + lh));
+        acc_g[gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qv[kk], acc_g[gt], 0, 0, 0);
+      }
+    }
+    // ---- rel_shift through the wave-private LDS tile: G^T[c_local][q] -> sg[q][c_local]; bd[key row] = sg[q][row + 31 - q]
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sg[q * SG_LD + 32 * gt + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc_g[gt][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float s[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float bd = sg[q * SG_LD + rho + 31 - q];
+      const bool ok = qvalid && (j0 + rho) < L;
+      s[r] = ok ? (acc_s[r] + bd) * scale : -INFINITY;
+      mx = fmaxf(mx, s[r]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_use);  // m_run = -inf -> 0
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_use); rs += s[r]; }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+    // ---- dropout on the probabilities (mask index = ((h*B+b)*T + i)*Tp + j, same function as the unfused path)
+    if (drop.threshold != 0u) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float dm[8];
+        drop_mask8(drop, drow + (uint32_t)(j0 + 8 * g), dm);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[4 * g + e] *= dm[4 * lh + e];
+      }
+    }
+    // ---- O^T += V^T . P^T : B operand = this lane's probabilities (registers 8s..8s+7 <-> key slots of K16 step s)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const bf16x8 pb = pack8(&s[8 * st]);
+#pragma unroll
+      for (int dvt = 0; dvt < 2; ++dvt) {
+        const bf16x8 vf = vt_frag(s_v, dvt * 32, st, lane);
+        o[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[dvt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise, transpose O^T -> O through LDS (per wave: [32 queries][64 dv] f32, pitch 66) and store rows
+  const float inv = (qvalid && l_run > 0.f) ? 1.f / l_run : 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int dvt = 0; dvt < 2; ++dvt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sg[q * SG_LD + dvt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = o[dvt][r] * inv;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lse && lh == 0 && i < T) lse[((long long)b * H + h) * T + i] = qvalid ? m_run + __logf(l_run) : 0.f;
+  // 32 rows x 64 dv: lane -> (row = it*8 + lane/8, 8-column chunk = lane%8)
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+    const int ii = i0_blk + wave * 32 + row;
+    if (ii < T) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = sg[row * SG_LD + c8 + j];
+      u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+      *reinterpret_cast<u32x4*>(ctx + ((long long)b * T + ii) * ldo + h * ADK + c8) = t;
+    }
+  }
+}
+
+// =================================================================================================
+// backward
+// =================================================================================================
+// delta[b,h,i] = sum_dv dO[i,h,dv] * O[i,h,dv]   (one wave per row of [M, d]; 8 lanes per head at d_k = 64)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
+                                                         float* __restrict__ delta, int B, int H, int T, int d) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (row >= (long long)B * T) return;
+  const int b = (int)(row / T), i = (int)(row - (long long)b * T);
+  for (int c0 = 0; c0 < d; c0 += 512) {
+    const int c = c0 + lane * 8;
+    float acc = 0.f;
+    if (c < d) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(dO + row * d + c);
+      const u32x4 o = *reinterpret_cast<const u32x4*>(O + row * d + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc += __uint_as_float(a[j] << 16) * __uint_as_float(o[j] << 16);
+        acc += __uint_as_float(a[j] & 0xffff0000u) * __uint_as_float(o[j] & 0xffff0000u);
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+    const int h = c / ADK;
+    if ((lane & 7) == 0 && c < d) delta[((long long)b * H + h) * T + i] = acc;
+  }
+}
+
+// fragment (8 k-slots) for an MFMA A operand taken TRANSPOSED out of a row-major [row][64] image with the (row>>1)&7
+// chunk swizzle: slots 0-3 <- rows ra..ra+3, slots 4-7 <- rows rb..rb+3, all at column col0 + (lane&31)
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int ra, int rb, int col0, int lane) {
+  const int t = lane & 15, g4 = (lane >> 4) & 1;
+  const int col = col0 + g4 * 16 + (t & 3) * 4;
+  union { bf16x8 v; s16x4 h[2]; } u;
+  const int r0 = ra + (t >> 2), r1 = rb + (t >> 2);
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + r0 * ADK + ((((col >> 3) ^ ((r0 >> 1) & 7))) << 3) + (col & 7)));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + r1 * ADK + ((((col >> 3) ^ ((r1 >> 1) & 7))) << 3) + (col & 7)));
+  return u.v;
+}
+// plain row fragments of a [M, d] bf16 matrix as MFMA B operand: lane holds x[row][col0 + kk*16 + (lane>>5)*8 + e]
+__device__ __forceinline__ void load_rows(const bf16_t* rowp, bf16x8 (&out)[4], bool valid, int lh) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    union { bf16x8 v; u32x4 w; } u;
+    u.w = (u32x4){0u, 0u, 0u, 0u};
+    if (valid) u.w = *reinterpret_cast<const u32x4*>(rowp + kk * 16 + lh * 8);
+    out[kk] = u.v;
+  }
+}
+
+// dQu / dQv for one 128-query tile (lane = query, same structure as the forward)
+__global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
+    const bf16_t* __restrict__ qu_g, const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ qkv, long long ldq,
+    const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
+    const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqu_out,
+    bf16_t* __restrict__ dqv_out, int B, int H, int T, int Tp, int d, float scale, DropCfg drop) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_k[ABK * ADK];
+  __shared__ __attribute__((aligned(16))) bf16_t s_v[ABK * ADK];
+  __shared__ __attribute__((aligned(16))) bf16_t s_p[ABAND * ADK];
+  __shared__ __attribute__((aligned(16))) float s_g[4][32 * SG_LD];
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int i0_blk = blockIdx.x * ABQ;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane & 31, lh = lane >> 5;
+  const int i = i0_blk + wave * 32 + q;
+  const int L = (int)min((long long)T, len[b]);
+  const bool qvalid = i < L;
+  const int P = 2 * T - 1;
+  const long long rowi = (long long)b * T + (i < T ? i : T - 1);
+
+  const bf16_t* kbase = qkv + ((long long)b * T) * ldq + h * ADK + (ldq / 3);
+  const bf16_t* vbase = kbase + (ldq / 3);
+  const bf16_t* pbase = pos + h * ADK;
+
+  bf16x8 qu[4], qv[4], dof[4];
+  load_rows(qu_g + rowi * d + h * ADK, qu, i < T, lh);
+  load_rows(qv_g + rowi * d + h * ADK, qv, i < T, lh);
+  load_rows(dO + rowi * d + h * ADK, dof, i < T, lh);
+  const float lse_i = qvalid ? lse[((long long)b * H + h) * T + i] : 0.f;
+  const float dlt_i = qvalid ? delta[((long long)b * H + h) * T + i] : 0.f;
+
+  f32x16 dqu[2], dqv[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dqu[0][r] = 0.f; dqu[1][r] = 0.f; dqv[0][r] = 0.f; dqv[1][r] = 0.f; }
+  float* sg = s_g[wave];
+  const uint32_t drow = (uint32_t)(((long long)h * B + b) * T + (i < T ? i : 0)) * (uint32_t)Tp;
+  const int prow0 = (ABQ - 32) - 32 * wave;
+
+  const int nkt = (L + ABK - 1) / ABK;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int j0 = kt * ABK;
+    __syncthreads();
+    stage_rows(kbase, ldq, j0, T - 1, s_k, ABK * 8);
+    stage_rows(vbase, ldq, j0, T - 1, s_v, ABK * 8);
+    const int c_base = T - 1 + j0 - (i0_blk + ABQ - 1);
+    stage_rows(pbase, ldp, c_base, P - 1, s_p, ABAND * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 acc_s, acc_g[2], acc_dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_s[r] = 0.f; acc_g[0][r] = 0.f; acc_g[1][r] = 0.f; acc_dp[r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s_k + a_off(q, kk * 2 + lh));
+      acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[kk], acc_s, 0, 0, 0);
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(s_v + a_off(q, kk * 2 + lh));
+      acc_dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], acc_dp, 0, 0, 0);  // dP^T[key][query] = V . dO^T
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt) {
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off(prow0 + 32 * gt + q, kk * 2 + lh));
+        acc_g[gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qv[kk], acc_g[gt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sg[q * SG_LD + 32 * gt + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc_g[gt][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float bd = sg[q * SG_LD + rho + 31 - q];
+      const bool ok = qvalid && (j0 + rho) < L;
+      ds[r] = ok ? __expf((acc_s[r] + bd) * scale - lse_i) : 0.f;  // P[i, j]
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // dS = P * (dropmask * dP - delta) * scale
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float dm[8];
+      drop_mask8(drop, drow + (uint32_t)(j0 + 8 * g), dm);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        ds[r] = ds[r] * (acc_dp[r] * dm[4 * lh + e] - dlt_i) * scale;
+      }
+    }
+    // ---- dQu^T += K^T . dS^T
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const bf16x8 db = pack8(&ds[8 * st]);
+#pragma unroll
+      for (int dkt = 0; dkt < 2; ++dkt) {
+        const bf16x8 kt_f = tr_frag(s_k, 16 * st + 4 * lh, 16 * st + 8 + 4 * lh, dkt * 32, lane);
+        dqu[dkt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt_f, db, dqu[dkt], 0, 0, 0);
+      }
+    }
+    // ---- un-skew dS into the band: sg[q][c_local] = dS[q][key = c_local - 31 + q]  (zero outside)
+    {
+      const float2 z = make_float2(0.f, 0.f);  // rows are 264 B apart: 8-byte aligned only
+#pragma unroll
+      for (int w2 = 0; w2 < 16; ++w2) *reinterpret_cast<float2*>(sg + q * SG_LD + 32 * lh + 2 * w2) = z;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sg[q * SG_LD + (r & 3) + 8 * (r >> 2) + 4 * lh + 31 - q] = ds[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- dQv^T += P_band^T . dG^T   (k-slots: c_local = 16*s4 + 8*lh + e)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      float gv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gv[e] = sg[q * SG_LD + 16 * s4 + 8 * lh + e];
+      const bf16x8 gb = pack8(gv);
+#pragma unroll
+      for (int dkt = 0; dkt < 2; ++dkt) {
+        const int ra = prow0 + 16 * s4 + 8 * lh;
+        const bf16x8 pt_f = tr_frag(s_p, ra, ra + 4, dkt * 32, lane);
+        dqv[dkt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pt_f, gb, dqv[dkt], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // ---- write dQu, dQv rows (transpose through the wave-private LDS tile)
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    bf16_t* outp = pass == 0 ? dqu_out : dqv_out;
+#pragma unroll
+    for (int dkt = 0; dkt < 2; ++dkt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sg[q * SG_LD + dkt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = qvalid ? (pass == 0 ? dqu[dkt][r] : dqv[dkt][r]) : 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+      const int ii = i0_blk + wave * 32 + row;
+      if (ii < T) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = sg[row * SG_LD + c8 + j];
+        u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *reinterpret_cast<u32x4*>(outp + ((long long)b * T + ii) * d + h * ADK + c8) = t;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+extern "C" int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, long long ldp, const void* bias_u,
+                                       const void* bias_v, const void* len, void* ctx, long long ldo, void* lse, int B, int H,
+                                       int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold,
+                                       float drop_scale, void* stream) {
+  mi_clear_errors();
+  if (!qkv || !pos || !bias_u || !bias_v || !len || !ctx || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
+  if (dk != ADK || (ldq % 24) || (ldp & 7) || (ldo & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)pos & 15) || ((uintptr_t)ctx & 15))
+    return MI_ERR_ARG;
+  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  dim3 grid((T + ABQ - 1) / ABQ, H, B);
+  hipLaunchKernelGGL(relpos_flash_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldq,
+                     (const bf16_t*)pos, ldp, (const float*)bias_u, (const float*)bias_v, (const long long*)len, (bf16_t*)ctx,
+                     ldo, (float*)lse, B, H, T, Tp, scale, dc);
+  return mi_check_launch();
+}
+
+extern "C" int mi355x_attn_delta(const void* dO, const void* O, void* delta, int B, int H, int T, int d, void* stream) {
+  mi_clear_errors();
+  if (!dO || !O || !delta || B <= 0 || H <= 0 || T <= 0 || d != H * ADK) return MI_ERR_ARG;
+  const long long rows = (long long)B * T;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dO, (const bf16_t*)O, (float*)delta, B, H, T, d);
+  return mi_check_launch();
+}
+
+extern "C" int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos,
+                                          long long ldp, const void* len, const void* dO, const void* lse, const void* delta,
+                                          void* dqu, void* dqv, int B, int H, int T, int dk, int Tp, float scale,
+                                          unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
+  mi_clear_errors();
+  if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || !dqu || !dqv || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
+  if (dk != ADK || (ldq % 24) || (ldp & 7)) return MI_ERR_ARG;
+  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  dim3 grid((T + ABQ - 1) / ABQ, H, B);
+  hipLaunchKernelGGL(relpos_flash_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu, (const bf16_t*)qv,
+                     (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len, (const bf16_t*)dO,
+                     (const float*)lse, (const float*)delta, (bf16_t*)dqu, (bf16_t*)dqv, B, H, T, Tp, H * ADK, scale, dc);
+  return mi_check_launch();
+}

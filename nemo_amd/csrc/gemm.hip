@@ -17,6 +17,7 @@
 //   nemo/collections/asr/parts/submodules/conformer_modules.py:382-387 (FFN), :321,343 (pointwise convs),
 //   multi_head_attention.py:124-146,300-350 (q/k/v/pos/out projections, QK^T, PV),
 //   subsampling.py:431 (out Linear), :231-253 (conv2), modules/conv_asr.py:445 (decoder).
+#include <stdlib.h>
 #include "common.cuh"
 #include "mi355x_asr.h"
 
@@ -401,6 +402,206 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 }
 
 // =================================================================================================
+// Second structure (large GEMMs, all layouts): 256x128x64 block tile, 8 waves (4x2, each 64x64), THREE LDS stages filled
+// by LDS-DMA two K-tiles ahead, one raw s_barrier per K-tile with a COUNTED vmcnt (the newest tile's DMA stays in flight
+// across the barrier; __syncthreads() would drain it).  144 KiB LDS -> one workgroup per CU, two waves per SIMD.
+//   * K-contiguous operand  ([rows][K]):  LDS image [rows][64] (128-B rows), chunk swizzle c ^= (row>>1)&7, ds_read_b128.
+//   * reduction-major operand ([K][rows], wgrad / P.V): LDS image [64][rows] exactly as in memory (so it can be DMA'd),
+//     chunk swizzle c ^= (k&3)<<2, fragments fetched with ds_read_b64_tr_b16 -- the hardware transpose read: lane t of
+//     a 16-lane group supplies &img[k0 + t/4][col0 + (t%4)*4] and receives img[k0..k0+3][col0 + t] (probed on gfx950,
+//     tools/probe/tr_probe.hip).  No register transpose, no ds_write.
+// =================================================================================================
+#define BM2 256
+#define NT2_STAGE ((BM2 + BN) * BK)  // elements per stage (A 256x64 | B 128x64) = 48 KiB
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+template <bool T, int R>
+__device__ __forceinline__ void stage_v2(const bf16_t* base, long long ld, int row0, int rows, int k0, int K, bf16_t* lds_tile) {
+  const int wave = threadIdx.x >> 6;
+  constexpr int PER = R * 8 / 512;  // 16-B chunks per thread
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int q = threadIdx.x + i * 512;
+    const bf16_t* src;
+    if (!T) {
+      const int r = q >> 3, ck = q & 7;
+      const int gck = ck ^ ((r >> 1) & 7);
+      int gr = row0 + r;
+      gr = gr < rows ? gr : rows - 1;
+      const int gk = k0 + gck * 8;
+      src = (gk < K) ? base + (long long)gr * ld + gk : reinterpret_cast<const bf16_t*>(g_zero16);
+    } else {
+      constexpr int CPR = R / 8;  // chunks per k-row
+      const int k = q / CPR, cp = q % CPR;
+      const int c = cp ^ ((k & 3) << 2);
+      const int gk = k0 + k, gc = row0 + c * 8;
+      src = (gk < K && gc < rows) ? base + (long long)gk * ld + gc : reinterpret_cast<const bf16_t*>(g_zero16);
+    }
+    bf16_t* dst = lds_tile + (wave * 64 + i * 512) * 8;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+  }
+}
+
+template <bool T, int R>
+__device__ __forceinline__ bf16x8 frag_v2(const bf16_t* tile, int row_tile, int kk, int lane) {
+  if (!T) {
+    return *reinterpret_cast<const bf16x8*>(tile + lds_off(row_tile + (lane & 31), kk * 2 + (lane >> 5)));
+  } else {
+    const int t = lane & 15, g4 = (lane >> 4) & 1, lh = lane >> 5;
+    const int col = row_tile + g4 * 16 + (t & 3) * 4;
+    union { bf16x8 v; s16x4 h[2]; } u;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int krow = kk * 16 + lh * 8 + r * 4 + (t >> 2);
+      const int off = krow * R + ((((col >> 3) ^ ((t >> 2) << 2))) << 3) + (col & 7);
+      u.h[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + off));
+    }
+    return u.v;
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem2[];  // 3 stages x 48 KiB
+  const int tn = (p.N + BN - 1) / BN, tm = (p.M + BM2 - 1) / BM2;
+  const int ntiles = tm * tn;
+  const int bid = blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tile_m = logical / tn, tile_n = logical - tile_m * tn;
+  const int m0 = tile_m * BM2, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  const int z0 = z % p.nb0, z1 = z / p.nb0;
+  const bf16_t* A = (const bf16_t*)p.A + z0 * p.sA0 + z1 * p.sA1;
+  const bf16_t* B = (const bf16_t*)p.B + z0 * p.sB0 + z1 * p.sB1;
+  const long long coff = z0 * p.sC0 + z1 * p.sC1;
+  const int nk_total = (p.K + BK - 1) / BK;
+  int kt0 = 0, kt1 = nk_total;
+  if (p.splitk > 1) {
+    kt0 = blockIdx.y * p.ktiles_per_split;
+    kt1 = min(nk_total, kt0 + p.ktiles_per_split);
+    if (kt0 >= kt1) return;
+  }
+  const int nk = kt1 - kt0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto issue = [&](int it) {  // it = local tile index
+    bf16_t* st = smem2 + (it % 3) * NT2_STAGE;
+    stage_v2<TA, BM2>(A, p.lda, m0, p.M, (kt0 + it) * BK, p.K, st);
+    stage_v2<TB, BN>(B, p.ldb, n0, p.N, (kt0 + it) * BK, p.K, st + BM2 * BK);
+  };
+  // bias gradient riding along with wgrad: column sums of the A tile, read back from LDS (8 B per lane per k-row group)
+  const bool do_colsum = TA && p.colsum_out != nullptr && tile_n == 0;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int it = 0; it < nk; ++it) {
+    if (it + 2 < nk) issue(it + 2);  // overwrites the stage of tile it-1: every wave passed the barrier after reading it
+    const bf16_t* a_s = smem2 + (it % 3) * NT2_STAGE;
+    const bf16_t* b_s = a_s + BM2 * BK;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = frag_v2<TA, BM2>(a_s, wm * 64 + i * 32, kk, lane);
+        bfr[i] = frag_v2<TB, BN>(b_s, wn * 64 + i * 32, kk, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (TA && do_colsum) {  // thread -> (k-group of 8 rows = wave, 4 consecutive columns = lane): 8 x ds_read_b64
+      const int col = lane * 4;
+#pragma unroll
+      for (int kr = 0; kr < 8; ++kr) {
+        const int krow = wave * 8 + kr;
+        const int off = krow * BM2 + (((col >> 3) ^ ((krow & 3) << 2)) << 3) + (col & 7);
+        const u32x2 v = *reinterpret_cast<const u32x2*>(a_s + off);
+        csum[0] += __uint_as_float(v[0] << 16); csum[1] += __uint_as_float(v[0] & 0xffff0000u);
+        csum[2] += __uint_as_float(v[1] << 16); csum[3] += __uint_as_float(v[1] & 0xffff0000u);
+      }
+    }
+    // tile it+1 must have landed (this wave's share) before the barrier publishes it; tile it+2 may stay in flight
+    if (it + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  float* sC = reinterpret_cast<float*>(smem2);
+  if (TA && do_colsum) {  // combine the 8 k-groups (waves) through LDS: 8 x 256 floats
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sC[wave * BM2 + lane * 4 + e] = csum[e];
+    __syncthreads();
+    if (threadIdx.x < BM2) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += sC[w * BM2 + threadIdx.x];
+      const int m = m0 + threadIdx.x;
+      if (m < p.M) atomicAdd(p.colsum_out + m, v);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue through LDS: the whole 256x128 f32 tile (132 KiB of the 144 KiB) in one pass, then every thread owns 8
+  // consecutive columns of a row (16/32-B global accesses).
+  constexpr int LDS_C = BN + 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row_l = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        sC[row_l * LDS_C + wn * 64 + j * 32 + lr] = acc[i][j][r];
+      }
+  __syncthreads();
+  if (p.atomic) {
+    for (int e = threadIdx.x; e < BM2 * BN; e += 512) {
+      const int row_l = e >> 7, col = e & (BN - 1);
+      const int m = m0 + row_l, n = n0 + col;
+      if (m < p.M && n < p.N) epilogue(p, z, coff, m, n, sC[row_l * LDS_C + col]);
+    }
+    return;
+  }
+#pragma unroll 2
+  for (int it = 0; it < 8; ++it) {
+    const int row_l = (threadIdx.x >> 4) + 32 * it;
+    const int c8 = (threadIdx.x & 15) * 8;
+    const int m = m0 + row_l, n = n0 + c8;
+    if (m < p.M && n < p.N) {
+      float v[8];
+      const float4 a = *reinterpret_cast<const float4*>(sC + row_l * LDS_C + c8);
+      const float4 b = *reinterpret_cast<const float4*>(sC + row_l * LDS_C + c8 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      if (p.vec_ok && n + 8 <= p.N) epilogue8(p, z, coff, m, n, v);
+      else {
+        for (int j = 0; j < 8; ++j)
+          if (n + j < p.N) epilogue(p, z, coff, m, n + j, v[j]);
+      }
+    }
+  }
+}
+
+// =================================================================================================
 // exact fp32 VALU kernel, arbitrary strides: 64x64x16 tile, 256 threads, 4x4 per thread
 // =================================================================================================
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
@@ -517,6 +718,27 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
     if (p.transB && p.ldb < ((p.N + 7) & ~7)) return MI_ERR_ARG;
     const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     dim3 grid(tm * tn, sk, p.batch);
+    static int use_v2 = -1;
+    if (use_v2 < 0) { const char* e = getenv("MI355X_GEMM_V2"); use_v2 = (e && e[0] == '0') ? 0 : 1; }
+    if (use_v2 && p.M >= 192 && p.N >= 96 && !(p.transA && !p.transB)) {
+      const int tm2 = (p.M + BM2 - 1) / BM2;
+      const int shm = 3 * NT2_STAGE * 2;
+      static bool attr_set = false;
+      if (!attr_set) {
+        bool ok = hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, shm) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, shm) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<true, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, shm) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
+        attr_set = true;
+      }
+      dim3 grid2(tm2 * tn, sk, p.batch);
+      if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_bf16_v2_kernel<false, false>), grid2, dim3(512), shm, s, p);
+      else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_bf16_v2_kernel<false, true>), grid2, dim3(512), shm, s, p);
+      else hipLaunchKernelGGL((gemm_bf16_v2_kernel<true, true>), grid2, dim3(512), shm, s, p);
+    } else
     if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, s, p);
     else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, s, p);
     else if (p.transA && p.transB) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, s, p);

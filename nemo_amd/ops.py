@@ -202,6 +202,23 @@ def relpos_softmax_bwd(dpd, s_in, dscore, dbdf, H, B, T, Tp, Pp, scale, drop: Dr
                                         scale, drop.key, drop.threshold, drop.scale, _stream()), "relpos_softmax_bwd")
 
 
+def relpos_flash_fwd(qkv, ldq, pos, ldp, bias_u, bias_v, lens, ctx, ldo, lse, B, H, T, dk, Tp, scale, drop: Dropout = NO_DROP):
+    check(lib.mi355x_relpos_flash_fwd(_ptr(qkv), ldq, _ptr(pos), ldp, _ptr(bias_u), _ptr(bias_v), _ptr(lens), _ptr(ctx), ldo,
+                                      _ptr(lse), B, H, T, dk, Tp, scale, drop.key, drop.threshold, drop.scale, _stream()),
+          "relpos_flash_fwd")
+
+
+def attn_delta(dO, O, delta, B, H, T, d):
+    check(lib.mi355x_attn_delta(_ptr(dO), _ptr(O), _ptr(delta), B, H, T, d, _stream()), "attn_delta")
+
+
+def relpos_flash_bwd_dq(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqu, dqv, B, H, T, dk, Tp, scale,
+                        drop: Dropout = NO_DROP):
+    check(lib.mi355x_relpos_flash_bwd_dq(_ptr(qu), _ptr(qv), _ptr(qkv), ldq, _ptr(pos), ldp, _ptr(lens), _ptr(dO), _ptr(lse),
+                                         _ptr(delta), _ptr(dqu), _ptr(dqv), B, H, T, dk, Tp, scale, drop.key, drop.threshold,
+                                         drop.scale, _stream()), "relpos_flash_bwd_dq")
+
+
 # ------------------------------------------------------------------------------------------------ conv module
 def dwconv_fwd(x, w, bias, y, stats, B, T, d, k):
     check(lib.mi355x_dwconv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), dt(x), _ptr(stats), B, T, d, k, _stream()), "dwconv_fwd")

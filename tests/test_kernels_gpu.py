@@ -273,6 +273,113 @@ def test_relpos_softmax(dtype):
     assert torch.all(dscore[..., T:] == 0)
 
 
+def _attn_ref(qkv, pos, u, v, lens, B, H, T, dk):
+    """fp32 reference of multi_head_attention.py:272-354 on the (bf16-rounded) inputs; returns ctx [B*T, d], lse [B,H,T]"""
+    d = H * dk
+    q = qkv[:, :d].float().view(B, T, H, dk); k = qkv[:, d:2 * d].float().view(B, T, H, dk).transpose(1, 2)
+    vv = qkv[:, 2 * d:].float().view(B, T, H, dk).transpose(1, 2)
+    p = pos.float().view(2 * T - 1, H, dk).transpose(0, 1)
+    qu = bf(q + u.view(H, dk)).float().transpose(1, 2); qv = bf(q + v.view(H, dk)).float().transpose(1, 2)
+    ac = qu @ k.transpose(-1, -2)
+    bdf = qv @ p.transpose(-1, -2).unsqueeze(0)
+    ii = torch.arange(T)[:, None]; jj = torch.arange(T)[None]
+    sc = (ac + bdf[:, :, ii, T - 1 + jj - ii]) / math.sqrt(dk)
+    valid = torch.arange(T)[None] < lens[:, None]
+    masked = ~(valid[:, :, None] & valid[:, None, :])[:, None]
+    sc = sc.masked_fill(masked, -10000.0)
+    attn = torch.softmax(sc, -1).masked_fill(masked, 0.0)
+    lse = torch.logsumexp(sc.masked_fill(masked, -float("inf")), -1)
+    ctx = (attn @ vv).transpose(1, 2).reshape(B * T, d)
+    return ctx, lse, attn
+
+
+@pytest.mark.parametrize("T", [45, 160, 501])
+def test_relpos_flash_attention_fwd(T):
+    o = ops()
+    B, H, dk = 3, 2, 64
+    d = H * dk
+    g = torch.Generator().manual_seed(31)
+    qkv = bf(torch.randn(B * T, 3 * d, generator=g))
+    pos = bf(torch.randn(2 * T - 1, d, generator=g))
+    u = torch.randn(d, generator=g) * 0.5; v = torch.randn(d, generator=g) * 0.5
+    lens = torch.tensor([T, max(1, T // 2 + 3), 1])
+    ctx_ref, lse_ref, _ = _attn_ref(qkv, pos, u, v, lens, B, H, T, dk)
+    ctx = torch.full((B * T, d), float("nan"), device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, T, device=dev)
+    Tp = (T + 7) // 8 * 8
+    o.relpos_flash_fwd(qkv.to(dev), 3 * d, pos.to(dev), d, u.to(dev), v.to(dev), lens.to(dev), ctx, d, lse, B, H, T, dk, Tp,
+                       1.0 / math.sqrt(dk))
+    torch.cuda.synchronize()
+    assert torch.isfinite(ctx.float()).all()
+    assert rel_err(ctx, ctx_ref) < 2e-2, rel_err(ctx, ctx_ref)
+    for b in range(B):
+        n = int(lens[b])
+        assert (lse[b, :, :n].cpu() - lse_ref[b, :, :n]).abs().max() < 2e-2
+        assert torch.all(ctx.view(B, T, d)[b, n:] == 0)
+
+
+def _attn_ref_grads(qkv, pos, u, v, lens, dO, B, H, T, dk):
+    """autograd of the fp32 reference wrt qu, qv, k, v, p (inputs bf16-rounded like the kernels see them)"""
+    d = H * dk
+    q = qkv[:, :d].float().view(B, T, H, dk)
+    qu = bf(q + u.view(H, dk)).float().requires_grad_(True)
+    qv = bf(q + v.view(H, dk)).float().requires_grad_(True)
+    k = qkv[:, d:2 * d].float().view(B, T, H, dk).clone().requires_grad_(True)
+    vv = qkv[:, 2 * d:].float().view(B, T, H, dk).clone().requires_grad_(True)
+    p = pos.float().view(2 * T - 1, H, dk).clone().requires_grad_(True)
+    ac = qu.transpose(1, 2) @ k.transpose(1, 2).transpose(-1, -2)
+    bdf = qv.transpose(1, 2) @ p.transpose(0, 1).transpose(-1, -2).unsqueeze(0)
+    ii = torch.arange(T)[:, None]; jj = torch.arange(T)[None]
+    sc = (ac + bdf[:, :, ii, T - 1 + jj - ii]) / math.sqrt(dk)
+    valid = torch.arange(T)[None] < lens[:, None]
+    masked = ~(valid[:, :, None] & valid[:, None, :])[:, None]
+    attn = torch.softmax(sc.masked_fill(masked, -10000.0), -1).masked_fill(masked, 0.0)
+    ctx = (attn @ vv.transpose(1, 2)).transpose(1, 2).reshape(B * T, d)
+    ctx.backward(dO.float())
+    return dict(ctx=ctx.detach(), dqu=qu.grad.reshape(B * T, d), dqv=qv.grad.reshape(B * T, d), dk=k.grad.reshape(B * T, d),
+                dv=vv.grad.reshape(B * T, d), dp=p.grad.reshape(2 * T - 1, d))
+
+
+@pytest.mark.parametrize("T", [45, 160, 501])
+def test_relpos_flash_attention_bwd(T):
+    o = ops()
+    B, H, dk = 3, 2, 64
+    d = H * dk
+    g = torch.Generator().manual_seed(32)
+    qkv = bf(torch.randn(B * T, 3 * d, generator=g) * 0.7)
+    pos = bf(torch.randn(2 * T - 1, d, generator=g) * 0.7)
+    u = torch.randn(d, generator=g) * 0.3; v = torch.randn(d, generator=g) * 0.3
+    lens = torch.tensor([T, max(1, T // 2 + 3), 1])
+    dO = bf(torch.randn(B * T, d, generator=g))
+    ref = _attn_ref_grads(qkv, pos, u, v, lens, dO, B, H, T, dk)
+    Tp = (T + 7) // 8 * 8
+    scale = 1.0 / math.sqrt(dk)
+    qkv_d, pos_d, lens_d, dO_d = qkv.to(dev), pos.to(dev), lens.to(dev), dO.to(dev)
+    ctx = torch.empty(B * T, d, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, T, device=dev)
+    o.relpos_flash_fwd(qkv_d, 3 * d, pos_d, d, u.to(dev), v.to(dev), lens_d, ctx, d, lse, B, H, T, dk, Tp, scale)
+    qu = torch.empty(B * T, d, device=dev, dtype=torch.bfloat16); qv = torch.empty_like(qu)
+    o.qbias(qkv_d, 3 * d, u.to(dev), v.to(dev), qu, qv, B * T, d)
+    delta = torch.zeros(B, H, T, device=dev)
+    o.attn_delta(dO_d, ctx, delta, B, H, T, d)
+    dqu = torch.full((B * T, d), float("nan"), device=dev, dtype=torch.bfloat16); dqv = torch.full_like(dqu, float("nan"))
+    o.relpos_flash_bwd_dq(qu, qv, qkv_d, 3 * d, pos_d, d, lens_d, dO_d, lse, delta, dqu, dqv, B, H, T, dk, Tp, scale)
+    torch.cuda.synchronize()
+    assert rel_err(dqu, ref["dqu"]) < 3e-2, rel_err(dqu, ref["dqu"])
+    assert rel_err(dqv, ref["dqv"]) < 3e-2, rel_err(dqv, ref["dqv"])
+    if hasattr(o, "relpos_flash_bwd_dkv"):
+        dqkv = torch.full((B * T, 3 * d), float("nan"), device=dev, dtype=torch.bfloat16)
+        o.relpos_flash_bwd_dkv(qu, qv, qkv_d, 3 * d, pos_d, d, lens_d, dO_d, lse, delta, dqkv, 3 * d, B, H, T, dk, Tp, scale)
+        torch.cuda.synchronize()
+        assert rel_err(dqkv[:, d:2 * d], ref["dk"]) < 3e-2, rel_err(dqkv[:, d:2 * d], ref["dk"])
+        assert rel_err(dqkv[:, 2 * d:], ref["dv"]) < 3e-2, rel_err(dqkv[:, 2 * d:], ref["dv"])
+    if hasattr(o, "relpos_flash_bwd_dpos"):
+        dp = torch.zeros(2 * T - 1, d, device=dev)
+        o.relpos_flash_bwd_dpos(qu, qv, qkv_d, 3 * d, pos_d, d, lens_d, dO_d, lse, delta, dp, B, H, T, dk, Tp, scale)
+        torch.cuda.synchronize()
+        assert rel_err(dp, ref["dp"]) < 3e-2, rel_err(dp, ref["dp"])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_dwconv_bn_swish(dtype):
     o = ops()
