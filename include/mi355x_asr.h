@@ -134,6 +134,18 @@ int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const void* qkv, 
                                int B, int H, int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold,
                                float drop_scale, void* stream);
 
+/* dK and dV rows written into the k / v column blocks of dqkv [B*T, ldd = 3d] */
+int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos, long long ldp,
+                                const void* len, const void* dO, const void* lse, const void* delta, void* dqkv, long long ldd,
+                                int B, int H, int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold,
+                                float drop_scale, void* stream);
+
+/* dpos f32 [2T-1, ldd] += gradient w.r.t. pos = linear_pos(pos_emb) (summed over the batch) */
+int mi355x_relpos_flash_bwd_dpos(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos, long long ldp,
+                                 const void* len, const void* dO, const void* lse, const void* delta, void* dpos, long long ldd,
+                                 int B, int H, int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold,
+                                 float drop_scale, void* stream);
+
 /* ---- convolution module: depthwise conv + BatchNorm + Swish (conformer_modules.py:333-342, causal_convs.py:130-147) */
 int mi355x_dwconv_fwd(const void* x, const void* w /*[d,1,k]*/, const void* bias, void* y, int dtype,
                       void* stats /*f64 [2,d] += (sum, sumsq) or NULL*/, int B, int T, int d, int ksize, void* stream);

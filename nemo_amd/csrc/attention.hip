@@ -31,6 +31,23 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 #define ABAND (ABQ + ABK)  // positional band rows staged per step (159 needed)
 #define SG_LD 66
 
+// Dropout of attention probabilities: keep(b,h,i,j) from full-rate integer ops only (v_mul_u32_u24, shifts, xors) so that
+// it costs the same whether a lane walks keys (forward / dQ: lane = query) or queries (dK/dV: lane = key).  `akey` is a
+// strong hash of (seed, site, b, h) computed once per workgroup.
+__device__ __forceinline__ uint32_t attn_key(const DropCfg& d, int b, int h) {
+  return mix32(mix32(d.key ^ (uint32_t)(b * 0x632BE5AB)) + (uint32_t)h * 0x9E3779B9u);
+}
+__device__ __forceinline__ float attn_drop(const DropCfg& d, uint32_t akey, int i, int j) {
+  if (d.threshold == 0u) return 1.f;
+  uint32_t x = __umul24((uint32_t)j + 0x1234u, 0x9E3779u) ^ (__umul24((uint32_t)i + 0x4321u, 0x7FEB35u) << 3) ^ akey;
+  x ^= x >> 15;
+  x = __umul24(x & 0xFFFFFFu, 0x846CA7u) ^ (x >> 9) ^ (x << 7);
+  x ^= x >> 13;
+  x = __umul24(x & 0xFFFFFFu, 0x2C1B3Cu) + (x >> 11);
+  x ^= x >> 16; x ^= x << 11;
+  return x >= d.threshold ? d.scale : 0.f;
+}
+
 __device__ __forceinline__ int a_off(int r, int chunk) { return r * ADK + ((chunk ^ ((r >> 1) & 7)) << 3); }
 
 // rows [row0, row0+nrows) x 64 columns (col offset applied by caller) -> LDS image [nrows][64] with the (row>>1)&7 swizzle
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
   float* sg = s_g[wave];
-  const uint32_t drow = (uint32_t)(((long long)h * B + b) * T + (i < T ? i : 0)) * (uint32_t)Tp;
+  const uint32_t akey = attn_key(drop, b, h);
 
   const int nkt = (L + ABK - 1) / ABK;  // key tiles that contain at least one valid key
   for (int kt = 0; kt < nkt; ++kt) {
@@ -194,15 +211,10 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
     m_run = m_new;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-    // ---- dropout on the probabilities (mask index = ((h*B+b)*T + i)*Tp + j, same function as the unfused path)
+    // ---- dropout on the probabilities
     if (drop.threshold != 0u) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float dm[8];
-        drop_mask8(drop, drow + (uint32_t)(j0 + 8 * g), dm);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[4 * g + e] *= dm[4 * lh + e];
-      }
+      for (int r = 0; r < 16; ++r) s[r] *= attn_drop(drop, akey, i, j0 + (r & 3) + 8 * (r >> 2) + 4 * lh);
     }
     // ---- O^T += V^T . P^T : B operand = this lane's probabilities (registers 8s..8s+7 <-> key slots of K16 step s)
 #pragma unroll
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dqu[0][r] = 0.f; dqu[1][r] = 0.f; dqv[0][r] = 0.f; dqv[1][r] = 0.f; }
   float* sg = s_g[wave];
-  const uint32_t drow = (uint32_t)(((long long)h * B + b) * T + (i < T ? i : 0)) * (uint32_t)Tp;
+  const uint32_t akey = attn_key(drop, b, h);
   const int prow0 = (ABQ - 32) - 32 * wave;
 
   const int nkt = (L + ABK - 1) / ABK;
@@ -371,14 +383,9 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // dS = P * (dropmask * dP - delta) * scale
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float dm[8];
-      drop_mask8(drop, drow + (uint32_t)(j0 + 8 * g), dm);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        ds[r] = ds[r] * (acc_dp[r] * dm[4 * lh + e] - dlt_i) * scale;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const float dm = attn_drop(drop, akey, i, j0 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+      ds[r] = ds[r] * (acc_dp[r] * dm - dlt_i) * scale;
     }
     // ---- dQu^T += K^T . dS^T
 #pragma unroll
@@ -444,6 +451,284 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   }
 }
 
+// dK / dV for one 128-key tile (lane = key): S = Qu K^T, G = Qv P^T with the rel_shift resolved by a lane rotation
+// (bd[query rho][key q] = G[rho][31 + q - rho]: a compile-time shift per register), dV^T += dO^T Pd, dK^T += Qu^T dS.
+__global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
+    const bf16_t* __restrict__ qu_g, const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ qkv, long long ldq,
+    const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
+    const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqkv, long long ldd, int B, int H,
+    int T, int Tp, int d, float scale, DropCfg drop) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_qu[32 * ADK];
+  __shared__ __attribute__((aligned(16))) bf16_t s_qv[32 * ADK];
+  __shared__ __attribute__((aligned(16))) bf16_t s_do[32 * ADK];
+  __shared__ __attribute__((aligned(16))) bf16_t s_p[ABAND * ADK];
+  __shared__ float s_lse[32], s_dlt[32];
+  __shared__ __attribute__((aligned(16))) float s_t[4][32 * SG_LD];
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int j0_blk = blockIdx.x * ABQ;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane & 31, lh = lane >> 5;
+  const int j = j0_blk + wave * 32 + q;  // this lane's key
+  const int L = (int)min((long long)T, len[b]);
+  const bool kvalid = j < L;
+  const int P = 2 * T - 1;
+  const long long rowj = (long long)b * T + (j < T ? j : T - 1);
+  const bf16_t* kbase = qkv + (ldq / 3) + h * ADK;
+  const bf16_t* pbase = pos + h * ADK;
+  const uint32_t akey = attn_key(drop, b, h);
+
+  bf16x8 kf[4], vf[4];
+  load_rows(kbase + rowj * ldq, kf, j < T, lh);
+  load_rows(kbase + (ldq / 3) + rowj * ldq, vf, j < T, lh);
+
+  f32x16 dk_acc[2], dv_acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk_acc[0][r] = 0.f; dk_acc[1][r] = 0.f; dv_acc[0][r] = 0.f; dv_acc[1][r] = 0.f; }
+
+  const int nqt = (L + 31) / 32;
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int i0 = qt * 32;
+    __syncthreads();
+    stage_rows(qu_g + ((long long)b * T) * d + h * ADK, d, i0, T - 1, s_qu, 32 * 8);
+    stage_rows(qv_g + ((long long)b * T) * d + h * ADK, d, i0, T - 1, s_qv, 32 * 8);
+    stage_rows(dO + ((long long)b * T) * d + h * ADK, d, i0, T - 1, s_do, 32 * 8);
+    const int c_base = T - 1 + j0_blk - i0 - 31;
+    stage_rows(pbase, ldp, c_base, P - 1, s_p, ABAND * 8);
+    if (threadIdx.x < 32) {
+      const int ii = i0 + threadIdx.x;
+      s_lse[threadIdx.x] = ii < L ? lse[((long long)b * H + h) * T + ii] : 0.f;
+      s_dlt[threadIdx.x] = ii < L ? delta[((long long)b * H + h) * T + ii] : 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 acc_s, acc_g[2], acc_dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_s[r] = 0.f; acc_g[0][r] = 0.f; acc_g[1][r] = 0.f; acc_dp[r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 quf = *reinterpret_cast<const bf16x8*>(s_qu + a_off(q, kk * 2 + lh));
+      acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(quf, kf[kk], acc_s, 0, 0, 0);     // S[query][key]
+      const bf16x8 dof = *reinterpret_cast<const bf16x8*>(s_do + a_off(q, kk * 2 + lh));
+      acc_dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf[kk], acc_dp, 0, 0, 0);   // dP[query][key]
+      const bf16x8 qvf = *reinterpret_cast<const bf16x8*>(s_qv + a_off(q, kk * 2 + lh));
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off(32 * wave + 32 * ct + q, kk * 2 + lh));
+        acc_g[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qvf, pf, acc_g[ct], 0, 0, 0);  // G[query][c_local]
+      }
+    }
+    float pd[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;  // query row of this register
+      const int sl = 31 + q - rho;                      // column of G that holds c(i, j)
+      const float g0 = __shfl(acc_g[0][r], lh * 32 + (sl & 31), 64);
+      const float g1 = __shfl(acc_g[1][r], lh * 32 + (sl & 31), 64);
+      const float bd = sl < 32 ? g0 : g1;
+      const int ii = i0 + rho;
+      const bool ok = kvalid && ii < L;
+      const float p = ok ? __expf((acc_s[r] + bd) * scale - s_lse[rho]) : 0.f;
+      const float dm = attn_drop(drop, akey, ii, j);
+      pd[r] = p * dm;
+      ds[r] = p * (acc_dp[r] * dm - s_dlt[rho]) * scale;
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const bf16x8 pb = pack8(&pd[8 * st]);
+      const bf16x8 db = pack8(&ds[8 * st]);
+      const int ra = 16 * st + 4 * lh, rb = 16 * st + 8 + 4 * lh;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const bf16x8 dot_f = tr_frag(s_do, ra, rb, t2 * 32, lane);   // dO^T[dv][query slots]
+        dv_acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_f, pb, dv_acc[t2], 0, 0, 0);
+        const bf16x8 qut_f = tr_frag(s_qu, ra, rb, t2 * 32, lane);   // Qu^T[dk][query slots]
+        dk_acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qut_f, db, dk_acc[t2], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- write dK, dV rows of this wave's 32 keys
+  float* st_ = s_t[wave];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        st_[q * SG_LD + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = pass == 0 ? dk_acc[t2][r] : dv_acc[t2][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+      const int jj = j0_blk + wave * 32 + row;
+      if (jj < T) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = st_[row * SG_LD + c8 + e];
+        u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *reinterpret_cast<u32x4*>(dqkv + ((long long)b * T + jj) * ldd + (pass + 1) * (ldd / 3) + h * ADK + c8) = t;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// d linear_pos output: dp[c, h, dk] += sum_{b,i} dS[b,h,i, j = c-(T-1)+i] * Qv[b,i,h,dk].  One workgroup walks ONE DIAGONAL of
+// 32x32 (query-tile, key-tile) pairs (jt - it = const): the 64-row positional band is then the same for every pair, so the
+// band fragments stay in registers and dp accumulates in MFMA accumulators across all pairs and batch entries of the
+// workgroup; a single pass of atomics per workgroup leaves at the end.  lane = query, structure as in the dQ kernel.
+__global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
+    const bf16_t* __restrict__ qu_g, const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ qkv, long long ldq,
+    const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
+    const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dpos, long long ldd, int B, int H,
+    int T, int d, int bchunk, float scale, DropCfg drop) {
+  __shared__ __attribute__((aligned(16))) float s_g[4][32 * SG_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t s_qv[4][32 * ADK];
+  __shared__ float s_red[64 * 65];
+
+  const int nT = (T + 31) / 32;
+  const int delta_t = (int)blockIdx.x - (nT - 1);  // jt - it
+  const int h = blockIdx.y;
+  const int b_begin = blockIdx.z * bchunk, b_end = min(B, b_begin + bchunk);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane & 31, lh = lane >> 5;
+  const int P = 2 * T - 1;
+  const int cmin = T - 1 + 32 * delta_t - 31;
+  const int it_lo = max(0, -delta_t), it_hi = min(nT, nT - delta_t);  // it in [it_lo, it_hi)
+  float* sg = s_g[wave];
+  bf16_t* sqv = s_qv[wave];
+
+  for (int e = threadIdx.x; e < 64 * 65; e += 256) s_red[e] = 0.f;
+
+  // positional band fragments (A operand of G^T = P_band Qv^T): rows cmin + 32*gt + (lane&31), clamped
+  bf16x8 pf[2][4];
+#pragma unroll
+  for (int gt = 0; gt < 2; ++gt) {
+    int c = cmin + 32 * gt + q;
+    c = c < 0 ? 0 : (c > P - 1 ? P - 1 : c);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      pf[gt][kk] = *reinterpret_cast<const bf16x8*>(pos + (long long)c * ldp + h * ADK + kk * 16 + lh * 8);
+  }
+  f32x16 dp_acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dp_acc[0][0][r] = 0.f; dp_acc[0][1][r] = 0.f; dp_acc[1][0][r] = 0.f; dp_acc[1][1][r] = 0.f; }
+
+  const int npairs = it_hi - it_lo;
+  const int nitems = (b_end - b_begin) * npairs;
+  for (int item = wave; item < nitems; item += 4) {
+    const int b = b_begin + item / npairs;
+    const int it = it_lo + item % npairs, jt = it + delta_t;
+    const int L = (int)min((long long)T, len[b]);
+    if (32 * it >= L || 32 * jt >= L) continue;  // wave-uniform
+    const int i = 32 * it + q;
+    const bool qvalid = i < L;
+    const long long rowi = (long long)b * T + (i < T ? i : T - 1);
+    const uint32_t akey = attn_key(drop, b, h);
+    // this wave's Qv tile -> LDS (row-major, (row>>1)&7 swizzle): B operand of G^T (b128 reads) and, transposed, of dp
+    {
+      const bf16_t* base = qv_g + ((long long)b * T) * d + h * ADK;
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int cq = k4 * 64 + lane;
+        const int r = cq >> 3, ck = cq & 7;
+        int gr = 32 * it + r;
+        gr = gr > T - 1 ? T - 1 : gr;
+        const bf16_t* src = base + (long long)gr * d + ((ck ^ ((r >> 1) & 7)) << 3);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(sqv + k4 * 512), 16, 0, 0);
+      }
+    }
+    bf16x8 qu[4], dof[4];
+    load_rows(qu_g + rowi * d + h * ADK, qu, i < T, lh);
+    load_rows(dO + rowi * d + h * ADK, dof, i < T, lh);
+    const float lse_i = qvalid ? lse[((long long)b * H + h) * T + i] : 0.f;
+    const float dlt_i = qvalid ? delta[((long long)b * H + h) * T + i] : 0.f;
+    int jr = 32 * jt + q;
+    jr = jr > T - 1 ? T - 1 : jr;
+    const bf16_t* krow = qkv + ((long long)b * T + jr) * ldq + (ldq / 3) + h * ADK;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    f32x16 acc_s, acc_g[2], acc_dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_s[r] = 0.f; acc_g[0][r] = 0.f; acc_g[1][r] = 0.f; acc_dp[r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + kk * 16 + lh * 8);
+      acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[kk], acc_s, 0, 0, 0);
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(krow + (ldq / 3) + kk * 16 + lh * 8);
+      acc_dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], acc_dp, 0, 0, 0);
+      const bf16x8 qvf = *reinterpret_cast<const bf16x8*>(sqv + a_off(q, kk * 2 + lh));
+      acc_g[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[0][kk], qvf, acc_g[0], 0, 0, 0);
+      acc_g[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[1][kk], qvf, acc_g[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sg[q * SG_LD + 32 * gt + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc_g[gt][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float bd = sg[q * SG_LD + rho + 31 - q];
+      const int j = 32 * jt + rho;
+      const bool ok = qvalid && j < L;
+      const float p = ok ? __expf((acc_s[r] + bd) * scale - lse_i) : 0.f;
+      const float dm = attn_drop(drop, akey, i, j);
+      ds[r] = p * (acc_dp[r] * dm - dlt_i) * scale;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const float2 z = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int w2 = 0; w2 < 16; ++w2) *reinterpret_cast<float2*>(sg + q * SG_LD + 32 * lh + 2 * w2) = z;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sg[q * SG_LD + (r & 3) + 8 * (r >> 2) + 4 * lh + 31 - q] = ds[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // dp[c_local][dk] += sum_q dG[q][c_local] * Qv[q][dk]: A[i = c_local][k-slot = q], B[k-slot = q][j = dk]
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      bf16x8 af[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float gv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = sg[(16 * st + 8 * lh + e) * SG_LD + 32 * ct + q];
+        af[ct] = pack8(gv);
+      }
+#pragma unroll
+      for (int dkt = 0; dkt < 2; ++dkt) {
+        const int ra = 16 * st + 8 * lh;
+        const bf16x8 bq = tr_frag(sqv, ra, ra + 4, dkt * 32, lane);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          dp_acc[ct][dkt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct], bq, dp_acc[ct][dkt], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // ---- combine the 4 waves in LDS, then one pass of global atomics (rows c = cmin + 0..63, cols dk = 0..63)
+  __syncthreads();
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int dkt = 0; dkt < 2; ++dkt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        atomicAdd(&s_red[(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 65 + dkt * 32 + q], dp_acc[ct][dkt][r]);
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int cl = e >> 6, dk = e & 63;
+    const int c = cmin + cl;
+    if (c >= 0 && c < P) atomicAdd(dpos + (long long)c * ldd + h * ADK + dk, s_red[cl * 65 + dk]);
+  }
+}
+
 extern "C" int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, long long ldp, const void* bias_u,
                                        const void* bias_v, const void* len, void* ctx, long long ldo, void* lse, int B, int H,
                                        int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold,
@@ -481,5 +766,38 @@ extern "C" int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const 
   hipLaunchKernelGGL(relpos_flash_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu, (const bf16_t*)qv,
                      (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len, (const bf16_t*)dO,
                      (const float*)lse, (const float*)delta, (bf16_t*)dqu, (bf16_t*)dqv, B, H, T, Tp, H * ADK, scale, dc);
+  return mi_check_launch();
+}
+
+extern "C" int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos,
+                                           long long ldp, const void* len, const void* dO, const void* lse, const void* delta,
+                                           void* dqkv, long long ldd, int B, int H, int T, int dk, int Tp, float scale,
+                                           unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
+  mi_clear_errors();
+  if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || !dqkv || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
+  if (dk != ADK || (ldq % 24) || (ldp & 7) || (ldd % 24)) return MI_ERR_ARG;
+  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  dim3 grid((T + ABQ - 1) / ABQ, H, B);
+  hipLaunchKernelGGL(relpos_flash_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu,
+                     (const bf16_t*)qv, (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len,
+                     (const bf16_t*)dO, (const float*)lse, (const float*)delta, (bf16_t*)dqkv, ldd, B, H, T, Tp, H * ADK, scale, dc);
+  return mi_check_launch();
+}
+
+extern "C" int mi355x_relpos_flash_bwd_dpos(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos,
+                                            long long ldp, const void* len, const void* dO, const void* lse, const void* delta,
+                                            void* dpos, long long ldd, int B, int H, int T, int dk, int Tp, float scale,
+                                            unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
+  mi_clear_errors();
+  if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || !dpos || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
+  if (dk != ADK || (ldq % 24) || (ldp & 7)) return MI_ERR_ARG;
+  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  const int nT = (T + 31) / 32;
+  const int bchunk = B >= 8 ? 4 : 1;
+  dim3 grid(2 * nT - 1, H, (B + bchunk - 1) / bchunk);
+  hipLaunchKernelGGL(relpos_flash_bwd_dpos_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu,
+                     (const bf16_t*)qv, (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len,
+                     (const bf16_t*)dO, (const float*)lse, (const float*)delta, (float*)dpos, ldd, B, H, T, H * ADK, bchunk,
+                     scale, dc);
   return mi_check_launch();
 }

@@ -193,6 +193,7 @@ class ConformerEncoder(NeuralModule):
         self.compute_dtype = compute_dtype  # None: bf16 under torch autocast(bf16), else fp32
         # SyncBatchNorm semantics across data-parallel ranks (trainer.sync_batchnorm: true in the recipe)
         self.sync_batchnorm = True
+        self.use_flash_attention = True  # bf16 + d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
         self.grad_ready_hook = None  # callable(start, end) on the flat gradient buffer (data-parallel bucketing)
         # --- engine state (not part of the state-dict)
         self._flatp = FlatParams(self)
@@ -416,30 +417,39 @@ class ConformerEncoder(NeuralModule):
         ops.gemm(y2, W[f"L{i}.att.wqkv"], qkv, M, 3 * d, d, d, W.pitch(f"L{i}.att.wqkv"), 3 * d, bias=Wf[f"L{i}.att.bqkv"])
         p = torch.empty(P, d, dtype=cdt, device=dev)
         ops.gemm(S.pos, W[f"L{i}.att.wpos"], p, P, d, d, d, W.pitch(f"L{i}.att.wpos"), d)
-        qu = torch.empty(M, d, dtype=cdt, device=dev)
-        qv = torch.empty(M, d, dtype=cdt, device=dev)
-        ops.qbias(qkv, 3 * d, a.pos_bias_u, a.pos_bias_v, qu, qv, M, d)
-        ac = self._buf("ac", (H, B, T2, Tp), torch.float32, dev)
-        bdf = self._buf("bdf", (H, B, T2, Pp), torch.float32, dev)
-        # ac[h,b] = qu_bh @ k_bh^T ; bdf[h,b] = qv_bh @ p_h^T      (z0 = b, z1 = h)
-        ops.gemm(qu, qkv, ac, T2, T2, dk, d, 3 * d, Tp, batch=H * B, nb0=B, sA=(T2 * d, dk), sB=(T2 * 3 * d, dk),
-                 sC=(T2 * Tp, B * T2 * Tp), b_off=d)
-        ops.gemm(qv, p, bdf, T2, P, dk, d, d, Pp, batch=H * B, nb0=B, sA=(T2 * d, dk), sB=(0, dk), sC=(T2 * Pp, B * T2 * Pp))
-        s_ = torch.empty(H, B, T2, Tp, dtype=cdt, device=dev)
         d_att = drop(self.dropout_att, site + 2)
-        pd = torch.empty(H, B, T2, Tp, dtype=cdt, device=dev) if d_att.threshold else None
-        ops.relpos_softmax_fwd(ac, bdf, s_, pd, S.len2, H, B, T2, Tp, Pp, 1.0 / math.sqrt(dk), d_att)
-        if pd is None:
-            pd = s_
         ctx = torch.empty(M, d, dtype=cdt, device=dev)
-        # ctx_bh = pd_bh [T,T] @ v_bh [T,dk]   (NN: v is reduction-major inside qkv)
-        ops.gemm(pd, qkv, ctx, T2, dk, T2, Tp, 3 * d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Tp, B * T2 * Tp),
-                 sB=(T2 * 3 * d, dk), sC=(T2 * d, dk), b_off=2 * d)
+        flash = self.use_flash_attention and cdt == torch.bfloat16 and dk == 64
+        if flash:
+            # fused rel-pos flash attention: scores / positional matrix never touch HBM; only the log-sum-exp is kept
+            lse = torch.empty(B, H, T2, dtype=torch.float32, device=dev)
+            ops.relpos_flash_fwd(qkv, 3 * d, p, d, a.pos_bias_u, a.pos_bias_v, S.len2, ctx, d, lse, B, H, T2, dk, Tp,
+                                 1.0 / math.sqrt(dk), d_att)
+            qu = qv = s_ = pd = None
+        else:
+            lse = None
+            qu = torch.empty(M, d, dtype=cdt, device=dev)
+            qv = torch.empty(M, d, dtype=cdt, device=dev)
+            ops.qbias(qkv, 3 * d, a.pos_bias_u, a.pos_bias_v, qu, qv, M, d)
+            ac = self._buf("ac", (H, B, T2, Tp), torch.float32, dev)
+            bdf = self._buf("bdf", (H, B, T2, Pp), torch.float32, dev)
+            # ac[h,b] = qu_bh @ k_bh^T ; bdf[h,b] = qv_bh @ p_h^T      (z0 = b, z1 = h)
+            ops.gemm(qu, qkv, ac, T2, T2, dk, d, 3 * d, Tp, batch=H * B, nb0=B, sA=(T2 * d, dk), sB=(T2 * 3 * d, dk),
+                     sC=(T2 * Tp, B * T2 * Tp), b_off=d)
+            ops.gemm(qv, p, bdf, T2, P, dk, d, d, Pp, batch=H * B, nb0=B, sA=(T2 * d, dk), sB=(0, dk), sC=(T2 * Pp, B * T2 * Pp))
+            s_ = torch.empty(H, B, T2, Tp, dtype=cdt, device=dev)
+            pd = torch.empty(H, B, T2, Tp, dtype=cdt, device=dev) if d_att.threshold else None
+            ops.relpos_softmax_fwd(ac, bdf, s_, pd, S.len2, H, B, T2, Tp, Pp, 1.0 / math.sqrt(dk), d_att)
+            if pd is None:
+                pd = s_
+            # ctx_bh = pd_bh [T,T] @ v_bh [T,dk]   (NN: v is reduction-major inside qkv)
+            ops.gemm(pd, qkv, ctx, T2, dk, T2, Tp, 3 * d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Tp, B * T2 * Tp),
+                     sB=(T2 * 3 * d, dk), sC=(T2 * d, dk), b_off=2 * d)
         r2 = torch.empty(M, d, dtype=torch.float32, device=dev)
         d_ares = drop(self.dropout, site + 3)
         ops.gemm(ctx, W[f"L{i}.att.wo"], r2, M, d, d, d, W.pitch(f"L{i}.att.wo"), d, bias=a.linear_out.bias, epi=ops.EPI_RESID,
                  aux_in=r1, drop=d_ares)
-        sl.att = (r1, y2, mean2, rstd2, qkv, p, qu, qv, s_, pd, ctx, d_att, d_ares)
+        sl.att = (r1, y2, mean2, rstd2, qkv, p, qu, qv, s_, pd, ctx, d_att, d_ares, lse)
         # ---- convolution module
         c = L.conv
         k = self.conv_kernel_size
@@ -580,40 +590,50 @@ class ConformerEncoder(NeuralModule):
         ops.layernorm_bwd(dy3, r2, ln.weight, mean3, rstd3, dr, True, ln.weight.grad, ln.bias.grad, M, d)
         # ---- self-attention
         a = L.self_attn
-        r1, y2, mean2, rstd2, qkv, p, qu, qv, s_, pd, ctx, d_att, d_ares = sl.att
+        r1, y2, mean2, rstd2, qkv, p, qu, qv, s_, pd, ctx, d_att, d_ares, lse = sl.att
         dao = torch.empty(M, d, dtype=cdt, device=dev)
         ops.drop_scale_cast(dr, dao, M * d, 1.0, d_ares)
         self._wgrad(dao, d, 0, ctx, d, 0, a.linear_out.weight.grad, d, d, M, bias_grad=a.linear_out.bias.grad)
         dctx = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(dao, W[f"L{i}.att.wot"], dctx, M, d, d, d, W.pitch(f"L{i}.att.wot"), d)
         dqkv = torch.empty(M, 3 * d, dtype=cdt, device=dev)
-        # dpd[h,b] = dctx_bh @ v_bh^T  -> reuse the f32 score workspace
-        dpd = self._buf("ac", (H, B, T2, Tp), torch.float32, dev)
-        ops.gemm(dctx, qkv, dpd, T2, T2, dk, d, 3 * d, Tp, batch=H * B, nb0=B, sA=(T2 * d, dk), sB=(T2 * 3 * d, dk),
-                 sC=(T2 * Tp, B * T2 * Tp), b_off=2 * d)
-        # dv_bh[j,e] = sum_i pd[i,j] dctx[i,e]
-        ops.gemm(pd, dctx, dqkv, T2, dk, T2, Tp, d, 3 * d, transA=True, transB=True, batch=H * B, nb0=B,
-                 sA=(T2 * Tp, B * T2 * Tp), sB=(T2 * d, dk), sC=(T2 * 3 * d, dk), c_off=2 * d)
-        dscore = self._buf("dscore", (H, B, T2, Tp), cdt, dev)
-        dbdf = self._buf("dbdf", (H, B, T2, Pp), cdt, dev)
-        ops.relpos_softmax_bwd(dpd, s_, dscore, dbdf, H, B, T2, Tp, Pp, scale, d_att)
         dqu = torch.empty(M, d, dtype=cdt, device=dev)
         dqv = torch.empty(M, d, dtype=cdt, device=dev)
-        # dqu_bh = dscore_bh [T,T] @ k_bh [T,dk]  (NN)
-        ops.gemm(dscore, qkv, dqu, T2, dk, T2, Tp, 3 * d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Tp, B * T2 * Tp),
-                 sB=(T2 * 3 * d, dk), sC=(T2 * d, dk), b_off=d)
-        # dk_bh[j,e] = sum_i dscore[i,j] qu[i,e]
-        ops.gemm(dscore, qu, dqkv, T2, dk, T2, Tp, d, 3 * d, transA=True, transB=True, batch=H * B, nb0=B,
-                 sA=(T2 * Tp, B * T2 * Tp), sB=(T2 * d, dk), sC=(T2 * 3 * d, dk), c_off=d)
-        # dqv_bh = dbdf_bh [T,P] @ p_h [P,dk]  (NN)
-        ops.gemm(dbdf, p, dqv, T2, dk, P, Pp, d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Pp, B * T2 * Pp),
-                 sB=(0, dk), sC=(T2 * d, dk))
-        # dp_h[c,e] = sum_{b,i} dbdf[h,b,i,c] qv[b,i,h,e]   (reduction over all B*T rows of head h)
         dp = torch.zeros(P, d, dtype=torch.float32, device=dev)
-        t = 128 if cdt == torch.bfloat16 else 64
-        tiles = ((P + t - 1) // t) * H
-        ops.gemm(dbdf, qv, dp, P, dk, B * T2, Pp, d, d, transA=True, transB=True, atomic=True,
-                 splitk=self._splitk(tiles, B * T2), batch=H, nb0=H, sA=(B * T2 * Pp, 0), sB=(dk, 0), sC=(dk, 0))
+        if lse is not None:
+            qu = torch.empty(M, d, dtype=cdt, device=dev)
+            qv = torch.empty(M, d, dtype=cdt, device=dev)
+            ops.qbias(qkv, 3 * d, a.pos_bias_u, a.pos_bias_v, qu, qv, M, d)
+            dlt = torch.empty(B, H, T2, dtype=torch.float32, device=dev)
+            ops.attn_delta(dctx, ctx, dlt, B, H, T2, d)
+            ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * d, p, d, S.len2, dctx, lse, dlt, dqu, dqv, B, H, T2, dk, Tp, scale, d_att)
+            ops.relpos_flash_bwd_dkv(qu, qv, qkv, 3 * d, p, d, S.len2, dctx, lse, dlt, dqkv, 3 * d, B, H, T2, dk, Tp, scale, d_att)
+            ops.relpos_flash_bwd_dpos(qu, qv, qkv, 3 * d, p, d, S.len2, dctx, lse, dlt, dp, B, H, T2, dk, Tp, scale, d_att)
+        else:
+            # dpd[h,b] = dctx_bh @ v_bh^T  -> reuse the f32 score workspace
+            dpd = self._buf("ac", (H, B, T2, Tp), torch.float32, dev)
+            ops.gemm(dctx, qkv, dpd, T2, T2, dk, d, 3 * d, Tp, batch=H * B, nb0=B, sA=(T2 * d, dk), sB=(T2 * 3 * d, dk),
+                     sC=(T2 * Tp, B * T2 * Tp), b_off=2 * d)
+            # dv_bh[j,e] = sum_i pd[i,j] dctx[i,e]
+            ops.gemm(pd, dctx, dqkv, T2, dk, T2, Tp, d, 3 * d, transA=True, transB=True, batch=H * B, nb0=B,
+                     sA=(T2 * Tp, B * T2 * Tp), sB=(T2 * d, dk), sC=(T2 * 3 * d, dk), c_off=2 * d)
+            dscore = self._buf("dscore", (H, B, T2, Tp), cdt, dev)
+            dbdf = self._buf("dbdf", (H, B, T2, Pp), cdt, dev)
+            ops.relpos_softmax_bwd(dpd, s_, dscore, dbdf, H, B, T2, Tp, Pp, scale, d_att)
+            # dqu_bh = dscore_bh [T,T] @ k_bh [T,dk]  (NN)
+            ops.gemm(dscore, qkv, dqu, T2, dk, T2, Tp, 3 * d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Tp, B * T2 * Tp),
+                     sB=(T2 * 3 * d, dk), sC=(T2 * d, dk), b_off=d)
+            # dk_bh[j,e] = sum_i dscore[i,j] qu[i,e]
+            ops.gemm(dscore, qu, dqkv, T2, dk, T2, Tp, d, 3 * d, transA=True, transB=True, batch=H * B, nb0=B,
+                     sA=(T2 * Tp, B * T2 * Tp), sB=(T2 * d, dk), sC=(T2 * 3 * d, dk), c_off=d)
+            # dqv_bh = dbdf_bh [T,P] @ p_h [P,dk]  (NN)
+            ops.gemm(dbdf, p, dqv, T2, dk, P, Pp, d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Pp, B * T2 * Pp),
+                     sB=(0, dk), sC=(T2 * d, dk))
+            # dp_h[c,e] = sum_{b,i} dbdf[h,b,i,c] qv[b,i,h,e]   (reduction over all B*T rows of head h)
+            t = 128 if cdt == torch.bfloat16 else 64
+            tiles = ((P + t - 1) // t) * H
+            ops.gemm(dbdf, qv, dp, P, dk, B * T2, Pp, d, d, transA=True, transB=True, atomic=True,
+                     splitk=self._splitk(tiles, B * T2), batch=H, nb0=H, sA=(B * T2 * Pp, 0), sB=(dk, 0), sC=(dk, 0))
         dpc = torch.empty(P, d, dtype=cdt, device=dev)
         ops.drop_scale_cast(dp, dpc, P * d, 1.0)
         self._wgrad(dpc, d, 0, S.pos, d, 0, a.linear_pos.weight.grad, d, d, P)

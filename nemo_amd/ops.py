@@ -219,6 +219,20 @@ def relpos_flash_bwd_dq(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqu, d
                                          drop.scale, _stream()), "relpos_flash_bwd_dq")
 
 
+def relpos_flash_bwd_dkv(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqkv, ldd, B, H, T, dk, Tp, scale,
+                         drop: Dropout = NO_DROP):
+    check(lib.mi355x_relpos_flash_bwd_dkv(_ptr(qu), _ptr(qv), _ptr(qkv), ldq, _ptr(pos), ldp, _ptr(lens), _ptr(dO), _ptr(lse),
+                                          _ptr(delta), _ptr(dqkv), ldd, B, H, T, dk, Tp, scale, drop.key, drop.threshold,
+                                          drop.scale, _stream()), "relpos_flash_bwd_dkv")
+
+
+def relpos_flash_bwd_dpos(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dpos, B, H, T, dk, Tp, scale,
+                          drop: Dropout = NO_DROP):
+    check(lib.mi355x_relpos_flash_bwd_dpos(_ptr(qu), _ptr(qv), _ptr(qkv), ldq, _ptr(pos), ldp, _ptr(lens), _ptr(dO), _ptr(lse),
+                                           _ptr(delta), _ptr(dpos), dpos.shape[-1], B, H, T, dk, Tp, scale, drop.key,
+                                           drop.threshold, drop.scale, _stream()), "relpos_flash_bwd_dpos")
+
+
 # ------------------------------------------------------------------------------------------------ conv module
 def dwconv_fwd(x, w, bias, y, stats, B, T, d, k):
     check(lib.mi355x_dwconv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), dt(x), _ptr(stats), B, T, d, k, _stream()), "dwconv_fwd")

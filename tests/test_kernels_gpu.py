@@ -380,6 +380,71 @@ def test_relpos_flash_attention_bwd(T):
         assert rel_err(dp, ref["dp"]) < 3e-2, rel_err(dp, ref["dp"])
 
 
+def test_relpos_flash_attention_dropout_consistency():
+    """With one-hot V (T <= d_k) the context IS the dropped probability matrix, so the forward mask can be read out and
+    every backward kernel checked against the same mask (masks are regenerated, never stored)."""
+    o = ops()
+    B, H, dk, T = 2, 2, 64, 45
+    d = H * dk
+    g = torch.Generator().manual_seed(33)
+    qkv = torch.randn(B * T, 3 * d, generator=g) * 0.5
+    eye = torch.zeros(T, dk); eye[torch.arange(T), torch.arange(T)] = 1.0
+    qkv[:, 2 * d:] = eye.repeat(B, H)  # V[b, j, h, :] = e_j
+    qkv = bf(qkv)
+    pos = bf(torch.randn(2 * T - 1, d, generator=g) * 0.5)
+    u = torch.randn(d, generator=g) * 0.3; v = torch.randn(d, generator=g) * 0.3
+    lens = torch.tensor([T, 30])
+    _, _, attn = _attn_ref(qkv, pos, u, v, lens, B, H, T, dk)          # [B,H,T,T] undropped probabilities
+    pdrop = 0.25
+    drop = o.Dropout(pdrop, seed=5, site=9)
+    Tp = (T + 7) // 8 * 8
+    scale = 1.0 / math.sqrt(dk)
+    qkv_d, pos_d, lens_d = qkv.to(dev), pos.to(dev), lens.to(dev)
+    ctx = torch.empty(B * T, d, device=dev, dtype=torch.bfloat16); lse = torch.zeros(B, H, T, device=dev)
+    o.relpos_flash_fwd(qkv_d, 3 * d, pos_d, d, u.to(dev), v.to(dev), lens_d, ctx, d, lse, B, H, T, dk, Tp, scale, drop)
+    torch.cuda.synchronize()
+    Pd = ctx.float().cpu().view(B, T, H, dk)[..., :T].permute(0, 2, 1, 3)  # [B,H,T(i),T(j)]
+    keep = Pd > 0.5 * attn / (1 - pdrop) * (attn > 1e-3)
+    big = attn > 1e-3
+    assert torch.all(((Pd - attn / (1 - pdrop)).abs() < 0.02 + 0.02 * attn)[keep & big])
+    assert torch.all(Pd[~keep & big].abs() < 1e-3)
+    rate = keep[big].float().mean().item()
+    assert abs(rate - (1 - pdrop)) < 0.04, rate
+    # backward with the SAME mask: reference gradients from the extracted mask
+    mask = torch.where(keep | ~big, torch.tensor(1.0 / (1 - pdrop)), torch.tensor(0.0))
+    dO = bf(torch.randn(B * T, d, generator=g))
+    q = qkv[:, :d].float().view(B, T, H, dk)
+    qu = bf(q + u.view(H, dk)).float().requires_grad_(True); qv = bf(q + v.view(H, dk)).float().requires_grad_(True)
+    k = qkv[:, d:2 * d].float().view(B, T, H, dk).clone().requires_grad_(True)
+    vv = qkv[:, 2 * d:].float().view(B, T, H, dk).clone().requires_grad_(True)
+    pp = pos.float().view(2 * T - 1, H, dk).clone().requires_grad_(True)
+    ac = qu.transpose(1, 2) @ k.transpose(1, 2).transpose(-1, -2)
+    bdf = qv.transpose(1, 2) @ pp.transpose(0, 1).transpose(-1, -2).unsqueeze(0)
+    ii = torch.arange(T)[:, None]; jj = torch.arange(T)[None]
+    sc = (ac + bdf[:, :, ii, T - 1 + jj - ii]) * scale
+    valid = torch.arange(T)[None] < lens[:, None]
+    masked = ~(valid[:, :, None] & valid[:, None, :])[:, None]
+    a2 = torch.softmax(sc.masked_fill(masked, -10000.0), -1).masked_fill(masked, 0.0) * mask
+    c2 = (a2 @ vv.transpose(1, 2)).transpose(1, 2).reshape(B * T, d)
+    c2.backward(dO.float())
+    quq = torch.empty(B * T, d, device=dev, dtype=torch.bfloat16); qvq = torch.empty_like(quq)
+    o.qbias(qkv_d, 3 * d, u.to(dev), v.to(dev), quq, qvq, B * T, d)
+    delta = torch.zeros(B, H, T, device=dev)
+    o.attn_delta(dO.to(dev), ctx, delta, B, H, T, d)
+    dqu = torch.empty_like(quq); dqv = torch.empty_like(quq)
+    o.relpos_flash_bwd_dq(quq, qvq, qkv_d, 3 * d, pos_d, d, lens_d, dO.to(dev), lse, delta, dqu, dqv, B, H, T, dk, Tp, scale, drop)
+    dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
+    o.relpos_flash_bwd_dkv(quq, qvq, qkv_d, 3 * d, pos_d, d, lens_d, dO.to(dev), lse, delta, dqkv, 3 * d, B, H, T, dk, Tp, scale, drop)
+    dp = torch.zeros(2 * T - 1, d, device=dev)
+    o.relpos_flash_bwd_dpos(quq, qvq, qkv_d, 3 * d, pos_d, d, lens_d, dO.to(dev), lse, delta, dp, B, H, T, dk, Tp, scale, drop)
+    torch.cuda.synchronize()
+    assert rel_err(dqu, qu.grad.reshape(B * T, d)) < 4e-2
+    assert rel_err(dqv, qv.grad.reshape(B * T, d)) < 4e-2
+    assert rel_err(dqkv[:, d:2 * d], k.grad.reshape(B * T, d)) < 4e-2
+    assert rel_err(dqkv[:, 2 * d:], vv.grad.reshape(B * T, d)) < 4e-2
+    assert rel_err(dp, pp.grad.reshape(2 * T - 1, d)) < 4e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_dwconv_bn_swish(dtype):
     o = ops()
