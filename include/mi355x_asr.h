@@ -131,8 +131,8 @@ int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, lon
 int mi355x_attn_delta(const void* dO, const void* O, void* delta, int B, int H, int T, int d, void* stream);
 int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos, long long ldp,
                                const void* len, const void* dO, const void* lse, const void* delta, void* dqu, void* dqv,
-                               int B, int H, int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold,
-                               float drop_scale, void* stream);
+                               void* ds_out /* optional [H,B,T,Tp] bf16 */, int B, int H, int T, int dk, int Tp, float scale,
+                               unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream);
 
 /* dK and dV rows written into the k / v column blocks of dqkv [B*T, ldd = 3d] */
 int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos, long long ldp,
@@ -140,11 +140,12 @@ int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const void* qkv,
                                 int B, int H, int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold,
                                 float drop_scale, void* stream);
 
-/* dpos f32 [2T-1, ldd] += gradient w.r.t. pos = linear_pos(pos_emb) (summed over the batch) */
-int mi355x_relpos_flash_bwd_dpos(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos, long long ldp,
-                                 const void* len, const void* dO, const void* lse, const void* delta, void* dpos, long long ldd,
-                                 int B, int H, int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold,
-                                 float drop_scale, void* stream);
+/* dpos f32 [2T-1, ldd] += gradient w.r.t. pos = linear_pos(pos_emb), summed over the batch, from the dS tiles
+ * ([H,B,T,Tp] bf16, Tp >= roundup32(T)) written by mi355x_relpos_flash_bwd_dq (ds_out) */
+int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len, void* dpos, long long ldd,
+                                 void* partial /* optional f32 scratch >= ceil(B/4)*(2*ceil(T/32)-1)*H*4096: deterministic
+                                                  two-stage reduction instead of atomics */, long long partial_elems,
+                                 int B, int H, int T, int dk, int Tp, void* stream);
 
 /* ---- convolution module: depthwise conv + BatchNorm + Swish (conformer_modules.py:333-342, causal_convs.py:130-147) */
 int mi355x_dwconv_fwd(const void* x, const void* w /*[d,1,k]*/, const void* bias, void* y, int dtype,

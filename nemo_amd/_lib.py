@@ -68,9 +68,9 @@ SIGNATURES = {
     "mi355x_relpos_softmax_bwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_relpos_flash_fwd": [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_attn_delta": [vp, vp, vp, i32, i32, i32, i32, vp],
-    "mi355x_relpos_flash_bwd_dq": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
+    "mi355x_relpos_flash_bwd_dq": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_relpos_flash_bwd_dkv": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
-    "mi355x_relpos_flash_bwd_dpos": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
+    "mi355x_relpos_flash_bwd_dpos": [vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
     "mi355x_dwconv_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp],
     "mi355x_dwconv_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mi355x_bn_finalize": [vp, f64, vp, vp, vp, vp, f32, f32, i32, vp],

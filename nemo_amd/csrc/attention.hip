@@ -17,6 +17,7 @@
 // Replaces on the reference path: RelPositionMultiHeadAttention.forward + MultiHeadAttention.forward_attention
 //   (nemo/collections/asr/parts/submodules/multi_head_attention.py:272-354, 124-146): two batched matmuls, pad/view/slice
 //   rel_shift, two masked_fill, softmax, dropout, matmul.
+#include <stdlib.h>
 #include "common.cuh"
 #include "mi355x_asr.h"
 
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     const bf16_t* __restrict__ qu_g, const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ qkv, long long ldq,
     const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqu_out,
-    bf16_t* __restrict__ dqv_out, int B, int H, int T, int Tp, int d, float scale, DropCfg drop) {
+    bf16_t* __restrict__ dqv_out, bf16_t* __restrict__ ds_out, int B, int H, int T, int Tp, int d, float scale,
+    DropCfg drop) {
   __shared__ __attribute__((aligned(16))) bf16_t s_k[ABK * ADK];
   __shared__ __attribute__((aligned(16))) bf16_t s_v[ABK * ADK];
   __shared__ __attribute__((aligned(16))) bf16_t s_p[ABAND * ADK];
@@ -386,6 +388,25 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     for (int r = 0; r < 16; ++r) {
       const float dm = attn_drop(drop, akey, i, j0 + (r & 3) + 8 * (r >> 2) + 4 * lh);
       ds[r] = ds[r] * (acc_dp[r] * dm - dlt_i) * scale;
+    }
+    // ---- dS tile [32 queries][32 keys] -> HBM (bf16, [H,B,T,Tp]) for the linear_pos gradient kernel
+    if (ds_out) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sg[q * SG_LD + (r & 3) + 8 * (r >> 2) + 4 * lh] = ds[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it2 = 0; it2 < 2; ++it2) {
+        const int row = it2 * 16 + (lane >> 2), c8 = (lane & 3) * 8;
+        const int ii = i0_blk + wave * 32 + row;
+        float v8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v8[e] = sg[row * SG_LD + c8 + e];
+        if (ii < T) {
+          u32x4 t = {pack_bf2(v8[0], v8[1]), pack_bf2(v8[2], v8[3]), pack_bf2(v8[4], v8[5]), pack_bf2(v8[6], v8[7])};
+          *reinterpret_cast<u32x4*>(ds_out + (((long long)h * B + b) * T + ii) * Tp + j0 + c8) = t;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // ---- dQu^T += K^T . dS^T
 #pragma unroll
@@ -575,18 +596,17 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   }
 }
 
-// d linear_pos output: dp[c, h, dk] += sum_{b,i} dS[b,h,i, j = c-(T-1)+i] * Qv[b,i,h,dk].  One workgroup walks ONE DIAGONAL of
-// 32x32 (query-tile, key-tile) pairs (jt - it = const): the 64-row positional band is then the same for every pair, so the
-// band fragments stay in registers and dp accumulates in MFMA accumulators across all pairs and batch entries of the
-// workgroup; a single pass of atomics per workgroup leaves at the end.  lane = query, structure as in the dQ kernel.
+// d linear_pos output: dp[c, h, dk] += sum_{b,i} dS[b,h,i, j = c-(T-1)+i] * Qv[b,i,h,dk], from the dS tiles the dQ kernel left
+// in HBM.  One workgroup walks ONE DIAGONAL of 32x32 (query-tile, key-tile) pairs (jt - it = const): the 64-row positional
+// band is the same for every pair, so dp accumulates in MFMA accumulators across all pairs / batch entries of the
+// workgroup and leaves with a single pass of atomics.  Per pair: 2 KB of dS + 4 KB of Qv by LDS-DMA, 8 MFMAs:
+//   D[c_local][dk] += sum_q A[c_local][q] B[q][dk],  A = un-skewed dS (gathered from LDS: dS[q][c_local - 31 + q]),
+//   B = Qv^T fragments via ds_read_b64_tr_b16.
 __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
-    const bf16_t* __restrict__ qu_g, const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ qkv, long long ldq,
-    const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
-    const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dpos, long long ldd, int B, int H,
-    int T, int d, int bchunk, float scale, DropCfg drop) {
-  __shared__ __attribute__((aligned(16))) float s_g[4][32 * SG_LD];
-  __shared__ __attribute__((aligned(16))) bf16_t s_qv[4][32 * ADK];
-  __shared__ float s_red[64 * 65];
+    const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ ds_g, const long long* __restrict__ len,
+    float* __restrict__ dpos, long long ldd, float* __restrict__ partial, int B, int H, int T, int Tp, int d, int bchunk) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_ds[4][2][32 * 32];   // per wave, double-buffered
+  __shared__ __attribute__((aligned(16))) bf16_t s_qv[4][2][32 * ADK];
 
   const int nT = (T + 31) / 32;
   const int delta_t = (int)blockIdx.x - (nT - 1);  // jt - it
@@ -596,109 +616,67 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
   const int q = lane & 31, lh = lane >> 5;
   const int P = 2 * T - 1;
   const int cmin = T - 1 + 32 * delta_t - 31;
-  const int it_lo = max(0, -delta_t), it_hi = min(nT, nT - delta_t);  // it in [it_lo, it_hi)
-  float* sg = s_g[wave];
-  bf16_t* sqv = s_qv[wave];
+  const int it_lo = max(0, -delta_t), it_hi = min(nT, nT - delta_t);
 
-  for (int e = threadIdx.x; e < 64 * 65; e += 256) s_red[e] = 0.f;
-
-  // positional band fragments (A operand of G^T = P_band Qv^T): rows cmin + 32*gt + (lane&31), clamped
-  bf16x8 pf[2][4];
-#pragma unroll
-  for (int gt = 0; gt < 2; ++gt) {
-    int c = cmin + 32 * gt + q;
-    c = c < 0 ? 0 : (c > P - 1 ? P - 1 : c);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      pf[gt][kk] = *reinterpret_cast<const bf16x8*>(pos + (long long)c * ldp + h * ADK + kk * 16 + lh * 8);
-  }
   f32x16 dp_acc[2][2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dp_acc[0][0][r] = 0.f; dp_acc[0][1][r] = 0.f; dp_acc[1][0][r] = 0.f; dp_acc[1][1][r] = 0.f; }
 
   const int npairs = it_hi - it_lo;
   const int nitems = (b_end - b_begin) * npairs;
-  for (int item = wave; item < nitems; item += 4) {
+  // 6 LDS-DMA instructions per item (2 KB of dS + 4 KB of Qv); issued one item ahead, waited with a counted vmcnt
+  auto issue = [&](int item, int buf) {
+    const int b = b_begin + item / npairs;
+    const int it = it_lo + item % npairs, jt = it + delta_t;
+    const bf16_t* base = ds_g + (((long long)h * B + b) * T) * Tp + 32 * jt;
+    bf16_t* sds = s_ds[wave][buf];
+    bf16_t* sqv = s_qv[wave][buf];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const int cq = k2 * 64 + lane;
+      int gr = 32 * it + (cq >> 2);
+      gr = gr > T - 1 ? T - 1 : gr;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(base + (long long)gr * Tp + (cq & 3) * 8), (lds_void_t*)(sds + k2 * 512),
+                                       16, 0, 0);
+    }
+    const bf16_t* qb = qv_g + ((long long)b * T) * d + h * ADK;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int cq = k4 * 64 + lane;
+      const int r = cq >> 3, ck = cq & 7;
+      int gr = 32 * it + r;
+      gr = gr > T - 1 ? T - 1 : gr;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(qb + (long long)gr * d + ((ck ^ ((r >> 1) & 7)) << 3)),
+                                       (lds_void_t*)(sqv + k4 * 512), 16, 0, 0);
+    }
+  };
+  if (wave < nitems) issue(wave, 0);
+  int buf = 0;
+  for (int item = wave; item < nitems; item += 4, buf ^= 1) {
+    if (item + 4 < nitems) { issue(item + 4, buf ^ 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int b = b_begin + item / npairs;
     const int it = it_lo + item % npairs, jt = it + delta_t;
     const int L = (int)min((long long)T, len[b]);
-    if (32 * it >= L || 32 * jt >= L) continue;  // wave-uniform
-    const int i = 32 * it + q;
-    const bool qvalid = i < L;
-    const long long rowi = (long long)b * T + (i < T ? i : T - 1);
-    const uint32_t akey = attn_key(drop, b, h);
-    // this wave's Qv tile -> LDS (row-major, (row>>1)&7 swizzle): B operand of G^T (b128 reads) and, transposed, of dp
-    {
-      const bf16_t* base = qv_g + ((long long)b * T) * d + h * ADK;
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const int cq = k4 * 64 + lane;
-        const int r = cq >> 3, ck = cq & 7;
-        int gr = 32 * it + r;
-        gr = gr > T - 1 ? T - 1 : gr;
-        const bf16_t* src = base + (long long)gr * d + ((ck ^ ((r >> 1) & 7)) << 3);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(sqv + k4 * 512), 16, 0, 0);
-      }
-    }
-    bf16x8 qu[4], dof[4];
-    load_rows(qu_g + rowi * d + h * ADK, qu, i < T, lh);
-    load_rows(dO + rowi * d + h * ADK, dof, i < T, lh);
-    const float lse_i = qvalid ? lse[((long long)b * H + h) * T + i] : 0.f;
-    const float dlt_i = qvalid ? delta[((long long)b * H + h) * T + i] : 0.f;
-    int jr = 32 * jt + q;
-    jr = jr > T - 1 ? T - 1 : jr;
-    const bf16_t* krow = qkv + ((long long)b * T + jr) * ldq + (ldq / 3) + h * ADK;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    f32x16 acc_s, acc_g[2], acc_dp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc_s[r] = 0.f; acc_g[0][r] = 0.f; acc_g[1][r] = 0.f; acc_dp[r] = 0.f; }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + kk * 16 + lh * 8);
-      acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[kk], acc_s, 0, 0, 0);
-      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(krow + (ldq / 3) + kk * 16 + lh * 8);
-      acc_dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], acc_dp, 0, 0, 0);
-      const bf16x8 qvf = *reinterpret_cast<const bf16x8*>(sqv + a_off(q, kk * 2 + lh));
-      acc_g[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[0][kk], qvf, acc_g[0], 0, 0, 0);
-      acc_g[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[1][kk], qvf, acc_g[1], 0, 0, 0);
-    }
-#pragma unroll
-    for (int gt = 0; gt < 2; ++gt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sg[q * SG_LD + 32 * gt + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc_g[gt][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    float ds[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float bd = sg[q * SG_LD + rho + 31 - q];
-      const int j = 32 * jt + rho;
-      const bool ok = qvalid && j < L;
-      const float p = ok ? __expf((acc_s[r] + bd) * scale - lse_i) : 0.f;
-      const float dm = attn_drop(drop, akey, i, j);
-      ds[r] = p * (acc_dp[r] * dm - dlt_i) * scale;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {
-      const float2 z = make_float2(0.f, 0.f);
-#pragma unroll
-      for (int w2 = 0; w2 < 16; ++w2) *reinterpret_cast<float2*>(sg + q * SG_LD + 32 * lh + 2 * w2) = z;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sg[q * SG_LD + (r & 3) + 8 * (r >> 2) + 4 * lh + 31 - q] = ds[r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // dp[c_local][dk] += sum_q dG[q][c_local] * Qv[q][dk]: A[i = c_local][k-slot = q], B[k-slot = q][j = dk]
+    if (32 * it >= L || 32 * jt >= L) continue;  // wave-uniform: tiles the dQ kernel never produced (data ignored)
+    const bf16_t* sds = s_ds[wave][buf];
+    const bf16_t* sqv = s_qv[wave][buf];
+    const int nq = min(32, T - 32 * it);  // valid query rows of this tile
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       bf16x8 af[2];
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        float gv[8];
+        union { bf16x8 v; uint16_t u[8]; } a;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) gv[e] = sg[(16 * st + 8 * lh + e) * SG_LD + 32 * ct + q];
-        af[ct] = pack8(gv);
+        for (int e = 0; e < 8; ++e) {
+          const int qq = 16 * st + 8 * lh + e;
+          const int rho = 32 * ct + q - 31 + qq;  // key column of dS that maps to this lane's c_local
+          uint16_t val = 0;
+          if (rho >= 0 && rho < 32 && qq < nq) val = sds[qq * 32 + rho];
+          a.u[e] = val;
+        }
+        af[ct] = a.v;
       }
 #pragma unroll
       for (int dkt = 0; dkt < 2; ++dkt) {
@@ -712,20 +690,73 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
-  // ---- combine the 4 waves in LDS, then one pass of global atomics (rows c = cmin + 0..63, cols dk = 0..63)
+  // ---- combine the 4 waves with plain LDS traffic (ds_add_f32 atomics measured ~10 us per workgroup here): waves 2,3 park
+  // their accumulators in two slabs, waves 0,1 add them, wave 1 parks, wave 0 adds and owns the result.
   __syncthreads();
+  float* slab = reinterpret_cast<float*>(&s_qv[0][0][0]);  // 32 KiB = 2 slabs of 64 x 64 floats
+  if (wave >= 2) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int dkt = 0; dkt < 2; ++dkt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(wave - 2) * 4096 + ((ct * 2 + dkt) * 16 + r) * 64 + lane] = dp_acc[ct][dkt][r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int dkt = 0; dkt < 2; ++dkt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp_acc[ct][dkt][r] += slab[wave * 4096 + ((ct * 2 + dkt) * 16 + r) * 64 + lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int dkt = 0; dkt < 2; ++dkt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[((ct * 2 + dkt) * 16 + r) * 64 + lane] = dp_acc[ct][dkt][r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  float* out_slab = partial ? partial + (((long long)blockIdx.z * gridDim.x + blockIdx.x) * H + h) * 4096 : nullptr;
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
     for (int dkt = 0; dkt < 2; ++dkt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        atomicAdd(&s_red[(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 65 + dkt * 32 + q], dp_acc[ct][dkt][r]);
-  __syncthreads();
-  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+      for (int r = 0; r < 16; ++r) {
+        const float v = dp_acc[ct][dkt][r] + slab[((ct * 2 + dkt) * 16 + r) * 64 + lane];
+        const int cl = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, dk = dkt * 32 + q;
+        if (out_slab) out_slab[cl * 64 + dk] = v;  // deterministic two-stage reduction (dpos_reduce_kernel)
+        else {
+          const int c = cmin + cl;
+          if (c >= 0 && c < P) atomicAdd(dpos + (long long)c * ldd + h * ADK + dk, v);
+        }
+      }
+}
+
+// stage 2: row group g (32 rows starting at T-1+32*(g-nT+1)-31) = tile 0 of diagonal g + tile 1 of diagonal g-1, over all z
+__global__ __launch_bounds__(256) void dpos_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dpos, long long ldd,
+                                                          int H, int T, int nz) {
+  const int nT = (T + 31) / 32, ndiag = 2 * nT - 1;
+  const int g = blockIdx.x, h = blockIdx.y;
+  const int P = 2 * T - 1;
+  const int c0 = T - 1 + 32 * (g - nT + 1) - 31;
+  {
+    const int e = blockIdx.z * 256 + threadIdx.x;  // 8 blocks of 256 threads cover the 32 x 64 group
     const int cl = e >> 6, dk = e & 63;
-    const int c = cmin + cl;
-    if (c >= 0 && c < P) atomicAdd(dpos + (long long)c * ldd + h * ADK + dk, s_red[cl * 65 + dk]);
+    const int c = c0 + cl;
+    if (c < 0 || c >= P) return;
+    float acc = 0.f;
+    for (int z = 0; z < nz; ++z) {
+      if (g < ndiag) acc += partial[(((long long)z * ndiag + g) * H + h) * 4096 + cl * 64 + dk];
+      if (g >= 1) acc += partial[(((long long)z * ndiag + (g - 1)) * H + h) * 4096 + (32 + cl) * 64 + dk];
+    }
+    dpos[(long long)c * ldd + h * ADK + dk] += acc;
   }
 }
 
@@ -756,16 +787,17 @@ extern "C" int mi355x_attn_delta(const void* dO, const void* O, void* delta, int
 
 extern "C" int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos,
                                           long long ldp, const void* len, const void* dO, const void* lse, const void* delta,
-                                          void* dqu, void* dqv, int B, int H, int T, int dk, int Tp, float scale,
+                                          void* dqu, void* dqv, void* ds_out, int B, int H, int T, int dk, int Tp, float scale,
                                           unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
   mi_clear_errors();
   if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || !dqu || !dqv || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
   if (dk != ADK || (ldq % 24) || (ldp & 7)) return MI_ERR_ARG;
+  if (ds_out && ((Tp & 7) || Tp < ((T + 31) / 32) * 32)) return MI_ERR_ARG;
   DropCfg dc{drop_key, drop_threshold, drop_scale};
   dim3 grid((T + ABQ - 1) / ABQ, H, B);
   hipLaunchKernelGGL(relpos_flash_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu, (const bf16_t*)qv,
                      (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len, (const bf16_t*)dO,
-                     (const float*)lse, (const float*)delta, (bf16_t*)dqu, (bf16_t*)dqv, B, H, T, Tp, H * ADK, scale, dc);
+                     (const float*)lse, (const float*)delta, (bf16_t*)dqu, (bf16_t*)dqv, (bf16_t*)ds_out, B, H, T, Tp, H * ADK, scale, dc);
   return mi_check_launch();
 }
 
@@ -784,20 +816,22 @@ extern "C" int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const
   return mi_check_launch();
 }
 
-extern "C" int mi355x_relpos_flash_bwd_dpos(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos,
-                                            long long ldp, const void* len, const void* dO, const void* lse, const void* delta,
-                                            void* dpos, long long ldd, int B, int H, int T, int dk, int Tp, float scale,
-                                            unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
+extern "C" int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len, void* dpos, long long ldd,
+                                            void* partial, long long partial_elems, int B, int H, int T, int dk, int Tp,
+                                            void* stream) {
   mi_clear_errors();
-  if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || !dpos || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
-  if (dk != ADK || (ldq % 24) || (ldp & 7)) return MI_ERR_ARG;
-  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  if (!qv || !ds || !len || !dpos || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
+  if (dk != ADK || (Tp & 7) || Tp < ((T + 31) / 32) * 32) return MI_ERR_ARG;
   const int nT = (T + 31) / 32;
-  const int bchunk = B >= 8 ? 4 : 1;
-  dim3 grid(2 * nT - 1, H, (B + bchunk - 1) / bchunk);
-  hipLaunchKernelGGL(relpos_flash_bwd_dpos_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu,
-                     (const bf16_t*)qv, (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len,
-                     (const bf16_t*)dO, (const float*)lse, (const float*)delta, (float*)dpos, ldd, B, H, T, H * ADK, bchunk,
-                     scale, dc);
+  int bchunk = B >= 8 ? 4 : 1;
+  if (const char* e = getenv("MI355X_DPOS_BCHUNK")) bchunk = atoi(e) > 0 ? atoi(e) : bchunk;
+  const int nz = (B + bchunk - 1) / bchunk;
+  if (partial && partial_elems < (long long)nz * (2 * nT - 1) * H * 4096) return MI_ERR_ARG;
+  dim3 grid(2 * nT - 1, H, nz);
+  hipLaunchKernelGGL(relpos_flash_bwd_dpos_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qv,
+                     (const bf16_t*)ds, (const long long*)len, (float*)dpos, ldd, (float*)partial, B, H, T, Tp, H * ADK, bchunk);
+  if (partial)
+    hipLaunchKernelGGL(dpos_reduce_kernel, dim3(2 * nT, H, 8), dim3(256), 0, (hipStream_t)stream, (const float*)partial,
+                       (float*)dpos, ldd, H, T, nz);
   return mi_check_launch();
 }

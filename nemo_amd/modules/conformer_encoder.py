@@ -606,9 +606,12 @@ class ConformerEncoder(NeuralModule):
             ops.qbias(qkv, 3 * d, a.pos_bias_u, a.pos_bias_v, qu, qv, M, d)
             dlt = torch.empty(B, H, T2, dtype=torch.float32, device=dev)
             ops.attn_delta(dctx, ctx, dlt, B, H, T2, d)
-            ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * d, p, d, S.len2, dctx, lse, dlt, dqu, dqv, B, H, T2, dk, Tp, scale, d_att)
+            Tp32 = (T2 + 31) // 32 * 32
+            dS = self._buf("dS", (H, B, T2, Tp32), cdt, dev)  # transient: dQ kernel -> linear_pos gradient kernel
+            ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * d, p, d, S.len2, dctx, lse, dlt, dqu, dqv, B, H, T2, dk, Tp32, scale, d_att,
+                                    ds_out=dS)
             ops.relpos_flash_bwd_dkv(qu, qv, qkv, 3 * d, p, d, S.len2, dctx, lse, dlt, dqkv, 3 * d, B, H, T2, dk, Tp, scale, d_att)
-            ops.relpos_flash_bwd_dpos(qu, qv, qkv, 3 * d, p, d, S.len2, dctx, lse, dlt, dp, B, H, T2, dk, Tp, scale, d_att)
+            ops.relpos_flash_bwd_dpos(qv, dS, S.len2, dp, B, H, T2, dk, Tp32)
         else:
             # dpd[h,b] = dctx_bh @ v_bh^T  -> reuse the f32 score workspace
             dpd = self._buf("ac", (H, B, T2, Tp), torch.float32, dev)

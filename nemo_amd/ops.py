@@ -213,10 +213,10 @@ def attn_delta(dO, O, delta, B, H, T, d):
 
 
 def relpos_flash_bwd_dq(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqu, dqv, B, H, T, dk, Tp, scale,
-                        drop: Dropout = NO_DROP):
+                        drop: Dropout = NO_DROP, ds_out=None):
     check(lib.mi355x_relpos_flash_bwd_dq(_ptr(qu), _ptr(qv), _ptr(qkv), ldq, _ptr(pos), ldp, _ptr(lens), _ptr(dO), _ptr(lse),
-                                         _ptr(delta), _ptr(dqu), _ptr(dqv), B, H, T, dk, Tp, scale, drop.key, drop.threshold,
-                                         drop.scale, _stream()), "relpos_flash_bwd_dq")
+                                         _ptr(delta), _ptr(dqu), _ptr(dqv), _ptr(ds_out), B, H, T, dk, Tp, scale, drop.key,
+                                         drop.threshold, drop.scale, _stream()), "relpos_flash_bwd_dq")
 
 
 def relpos_flash_bwd_dkv(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqkv, ldd, B, H, T, dk, Tp, scale,
@@ -226,11 +226,18 @@ def relpos_flash_bwd_dkv(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqkv,
                                           drop.scale, _stream()), "relpos_flash_bwd_dkv")
 
 
-def relpos_flash_bwd_dpos(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dpos, B, H, T, dk, Tp, scale,
-                          drop: Dropout = NO_DROP):
-    check(lib.mi355x_relpos_flash_bwd_dpos(_ptr(qu), _ptr(qv), _ptr(qkv), ldq, _ptr(pos), ldp, _ptr(lens), _ptr(dO), _ptr(lse),
-                                           _ptr(delta), _ptr(dpos), dpos.shape[-1], B, H, T, dk, Tp, scale, drop.key,
-                                           drop.threshold, drop.scale, _stream()), "relpos_flash_bwd_dpos")
+_DPOS_SCRATCH = {}
+
+
+def relpos_flash_bwd_dpos(qv, ds, lens, dpos, B, H, T, dk, Tp):
+    n = ((B + 3) // 4 if B >= 8 else B) * (2 * ((T + 31) // 32) - 1) * H * 4096
+    key = (str(dpos.device), n)
+    scratch = _DPOS_SCRATCH.get(key)
+    if scratch is None:
+        _DPOS_SCRATCH.clear()
+        scratch = _DPOS_SCRATCH[key] = torch.empty(n, dtype=torch.float32, device=dpos.device)
+    check(lib.mi355x_relpos_flash_bwd_dpos(_ptr(qv), _ptr(ds), _ptr(lens), _ptr(dpos), dpos.shape[-1], _ptr(scratch), n, B, H, T,
+                                           dk, Tp, _stream()), "relpos_flash_bwd_dpos")
 
 
 # ------------------------------------------------------------------------------------------------ conv module
