@@ -56,7 +56,8 @@ typedef struct mi355x_gemm_desc {
   long long ldaux;                  /* pitch of aux_in / aux_out (same batch offsets as C)                       */
   unsigned drop_key, drop_threshold; float drop_scale;   /* threshold 0 = dropout off                            */
   const void* row_len; int rows_per_b; int rows_inner;   /* EPI_RELU_MASK: int64 [B] valid lengths               */
-  void* colsum_out;                 /* optional (bf16, transA=1, batch=1): f32 [M] += sum_k A(k,m) -- the bias gradient
+  long long colsum_stride;          /* batch stride of colsum_out (elements)                                       */
+  void* colsum_out;                 /* optional (bf16, transA=1, single-level batch): f32 [M] += sum_k A(k,m) -- the bias gradient
                                        of a Linear rides along with its weight-gradient GEMM                       */
 } mi355x_gemm_desc;
 int mi355x_gemm(const mi355x_gemm_desc* desc, void* stream);

@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ("ldaux", i64),
         ("drop_key", u32), ("drop_threshold", u32), ("drop_scale", f32),
         ("row_len", vp), ("rows_per_b", i32), ("rows_inner", i32),
-        ("colsum_out", vp),
+        ("colsum_stride", i64), ("colsum_out", vp),
     ]
 
 

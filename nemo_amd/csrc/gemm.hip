@@ -43,6 +43,7 @@ struct GemmP {
   DropCfg drop;
   const long long* row_len; int rows_per_b; int rows_inner;
   int splitk; int ktiles_per_split;
+  long long colsum_stride;             // batch stride (z0) of colsum_out
   float* colsum_out;                   // transA only: colsum_out[m] += sum_k A(k, m)  (bias gradient fused into wgrad)
   int vec_ok;                          // C / aux rows are 8-element aligned & dense: vectorised epilogue allowed
 };
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
       float v = csum[e];
       v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
       const int m = m0 + c * 8 + e;
-      if ((threadIdx.x & 15) == 0 && m < p.M) atomicAdd(p.colsum_out + m, v);
+      if ((threadIdx.x & 15) == 0 && m < p.M) atomicAdd(p.colsum_out + z0 * p.colsum_stride + m, v);
     }
   }
 
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
 #pragma unroll
       for (int w = 0; w < 8; ++w) v += sC[w * BM2 + threadIdx.x];
       const int m = m0 + threadIdx.x;
-      if (m < p.M) atomicAdd(p.colsum_out + m, v);
+      if (m < p.M) atomicAdd(p.colsum_out + z0 * p.colsum_stride + m, v);
     }
     __syncthreads();
   }
@@ -680,7 +681,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   p.aux_in = d->aux_in; p.auxin_dt = d->aux_in_dtype; p.aux_out = d->aux_out; p.auxout_dt = d->aux_out_dtype;
   p.ldaux = d->ldaux;
   p.drop.key = d->drop_key; p.drop.threshold = d->drop_threshold; p.drop.scale = d->drop_scale;
-  p.colsum_out = (float*)d->colsum_out;
+  p.colsum_out = (float*)d->colsum_out; p.colsum_stride = d->colsum_stride;
   p.row_len = (const long long*)d->row_len; p.rows_per_b = d->rows_per_b > 0 ? d->rows_per_b : 1;
   p.rows_inner = d->rows_inner > 0 ? d->rows_inner : 1;
   if (p.epi < EPI_STORE || p.epi > EPI_MUL_POS) return MI_ERR_ARG;
@@ -688,7 +689,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   if ((p.epi == EPI_RESID || p.epi == EPI_DSWISH || p.epi == EPI_MUL_POS) && !p.aux_in) return MI_ERR_ARG;
   if (p.epi == EPI_SWISH_DROP && !p.aux_out) return MI_ERR_ARG;
   if (p.epi == EPI_RELU_MASK && !p.row_len) return MI_ERR_ARG;
-  if (p.colsum_out && (!p.transA || d->in_dtype != MI_DT_BF16 || p.batch != 1)) return MI_ERR_ARG;
+  if (p.colsum_out && (!p.transA || d->in_dtype != MI_DT_BF16 || p.nb0 != p.batch)) return MI_ERR_ARG;
   const int nk = (p.K + BK - 1) / BK;
   int sk = d->splitk > 1 ? d->splitk : 1;
   if (sk > nk) sk = nk;

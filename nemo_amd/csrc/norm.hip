@@ -86,13 +86,15 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const TDY* __restrict__ 
 // (wave w takes rows w, w+4, ...); every lane owns the same NV 4-column groups for all its rows, so dgamma / dbeta
 // partials live in registers, are combined across the 4 waves through LDS and leave as one atomic per column per block.
 #define LNB_ROWS 64
+#define LNB_WAVES 16  // 1024-thread workgroups: 16 rows in flight per CU, ONE atomic per column per 64 rows (the
+                      // parameter-gradient atomics all hit the same 2*d addresses: fewer, fatter workgroups win)
 template <typename TX, typename TDY, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_fused_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float* __restrict__ dres,
                                                            int accumulate, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int M, int d) {
-  __shared__ float red[4][2][NV * 256];
+  __shared__ float red[LNB_WAVES][2][NV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = d >> 2;
   float g[NV][4], ag[NV][4], ab[NV][4];
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const TDY* __restrict
     for (int j = 0; j < 4; ++j) { ag[k][j] = 0.f; ab[k][j] = 0.f; }
   }
   const int r0 = blockIdx.x * LNB_ROWS, r1 = min(M, r0 + LNB_ROWS);
-  for (int row = r0 + wave; row < r1; row += 4) {
+  for (int row = r0 + wave; row < r1; row += LNB_WAVES) {
     const TX* xr = x + (long long)row * d;
     const TDY* dyr = dy + (long long)row * d;
     float* dr = dres + (long long)row * d;
@@ -149,9 +151,12 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const TDY* __restrict
       red[wave][1][(lane + 64 * k) * 4 + j] = ab[k][j];
     }
   __syncthreads();
-  for (int c = threadIdx.x; c < d; c += 256) {
-    atomicAdd(dgamma + c, (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]));
-    atomicAdd(dbeta + c, (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]));
+  for (int c = threadIdx.x; c < d; c += 64 * LNB_WAVES) {
+    float sg_ = 0.f, sb_ = 0.f;
+#pragma unroll
+    for (int w = 0; w < LNB_WAVES; ++w) { sg_ += red[w][0][c]; sb_ += red[w][1][c]; }
+    atomicAdd(dgamma + c, sg_);
+    atomicAdd(dbeta + c, sb_);
   }
 }
 
@@ -259,9 +264,10 @@ extern "C" int mi355x_layernorm_bwd(const void* dy, int dy_dt, const void* x, in
   dim3 block(256);
   if (d <= 1024 && ((dgamma && dbeta) || (!dgamma && !dbeta))) {
     dim3 gridf((M + LNB_ROWS - 1) / LNB_ROWS);
+    dim3 blockf(64 * LNB_WAVES);
     const int nvv = (d / 4 + 63) / 64;
 #define LN_FUSED(NV) DISPATCH_DT(x_dt, TX, DISPATCH_DT(dy_dt, TDY, \
-      hipLaunchKernelGGL((ln_bwd_fused_kernel<TX, TDY, NV>), gridf, block, 0, s, (const TDY*)dy, (const TX*)x, \
+      hipLaunchKernelGGL((ln_bwd_fused_kernel<TX, TDY, NV>), gridf, blockf, 0, s, (const TDY*)dy, (const TX*)x, \
                          (const float*)gamma, (const float*)mean, (const float*)rstd, (float*)dres, accumulate, \
                          (float*)dgamma, (float*)dbeta, M, d)))
     switch (nvv) {

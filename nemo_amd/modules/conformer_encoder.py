@@ -302,15 +302,19 @@ class ConformerEncoder(NeuralModule):
 
     @staticmethod
     def _splitk(tiles, K):
+        """split-K factor: aim at one workgroup per CU (256) for the 144-KiB-LDS GEMM, at least 4 K tiles per split"""
         nk = (K + 63) // 64
-        return max(1, min(nk, 512 // max(tiles, 1)))
+        return max(1, min(nk // 4 if nk >= 8 else 1, max(1, 256 // max(tiles, 1))))
+
+    @staticmethod
+    def _tiles(n_out, n_in, bf16):
+        return ((n_out + 255) // 256) * ((n_in + 127) // 128) if bf16 else ((n_out + 63) // 64) * ((n_in + 63) // 64)
 
     def _wgrad(self, dY, ldy, y_off, X, ldx, x_off, dW, n_out, n_in, rows, bias_grad=None):
         """dW[n_out, n_in] += dY[:, y_off:y_off+n_out]^T @ X[:, x_off:x_off+n_in]   (TN GEMM, atomic split-K);
         bias_grad[n_out] += column sums of dY -- fused into the same kernel on the bf16 path."""
         bf16 = dY.dtype == torch.bfloat16
-        t = 128 if bf16 else 64
-        tiles = ((n_out + t - 1) // t) * ((n_in + t - 1) // t)
+        tiles = self._tiles(n_out, n_in, bf16)
         if bias_grad is not None and not bf16:
             ops.colsum(dY, bias_grad, rows, n_out, ld=ldy, x_off=y_off)
         ops.gemm(dY, X, dW, n_out, n_in, rows, ldy, ldx, n_in, transA=True, transB=True, atomic=True,
@@ -513,8 +517,7 @@ class ConformerEncoder(NeuralModule):
         ops.drop_scale_cast(dx, dxs, M * d, (self.xscale or 1.0), S.drop_pre)
         ops.colsum(dxs, pe.out.bias.grad, M, d)
         # d out.weight in the reference's (c, f) column order: batch over f, C column stride F2
-        t = 128 if cdt == torch.bfloat16 else 64
-        tiles = ((d + t - 1) // t) * ((C_ + t - 1) // t) * F2
+        tiles = self._tiles(d, C_, cdt == torch.bfloat16) * F2
         ops.gemm(dxs, S.out2, pe.out.weight.grad, d, C_, M, d, F2 * C_, C_ * F2, transA=True, transB=True, atomic=True,
                  splitk=self._splitk(tiles, M), batch=F2, nb0=F2, sB=(C_, 0), sC=(1, 0), c_col_stride=F2, c_dtype=ops.F32)
         dout2 = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
@@ -524,7 +527,7 @@ class ConformerEncoder(NeuralModule):
         col = self._buf("col", (M2, 9 * C_), cdt, dev)
         ops.im2col(S.out1, col, B, T1, F1, C_)  # recomputed (cheaper than keeping 3 GB alive through the encoder)
         # d conv2.weight [co, ci, 3, 3]: batch over the 9 taps, column stride 9
-        tiles = ((C_ + t - 1) // t) ** 2 * 9
+        tiles = self._tiles(C_, C_, cdt == torch.bfloat16) * 9
         ops.gemm(dout2, col, pe.conv[2].weight.grad, C_, C_, M2, C_, 9 * C_, 9 * C_, transA=True, transB=True, atomic=True,
                  splitk=self._splitk(tiles, M2), batch=9, nb0=9, sB=(C_, 0), sC=(1, 0), c_col_stride=9, c_dtype=ops.F32)
         dcol = col  # reuse: col is dead after the wgrad above (stream order)
@@ -633,8 +636,7 @@ class ConformerEncoder(NeuralModule):
             ops.gemm(dbdf, p, dqv, T2, dk, P, Pp, d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Pp, B * T2 * Pp),
                      sB=(0, dk), sC=(T2 * d, dk))
             # dp_h[c,e] = sum_{b,i} dbdf[h,b,i,c] qv[b,i,h,e]   (reduction over all B*T rows of head h)
-            t = 128 if cdt == torch.bfloat16 else 64
-            tiles = ((P + t - 1) // t) * H
+            tiles = self._tiles(P, dk, cdt == torch.bfloat16) * H
             ops.gemm(dbdf, qv, dp, P, dk, B * T2, Pp, d, d, transA=True, transB=True, atomic=True,
                      splitk=self._splitk(tiles, B * T2), batch=H, nb0=H, sA=(B * T2 * Pp, 0), sB=(dk, 0), sC=(dk, 0))
         dpc = torch.empty(P, d, dtype=cdt, device=dev)
@@ -643,8 +645,19 @@ class ConformerEncoder(NeuralModule):
         ops.colsum(dqu, a.pos_bias_u.grad, M, d)
         ops.colsum(dqv, a.pos_bias_v.grad, M, d)
         ops.add2(dqu, dqv, dqkv, 3 * d, M, d)
-        for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
-            self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M, bias_grad=lin.bias.grad)
+        gq, gk, gv = a.linear_q.weight.grad, a.linear_k.weight.grad, a.linear_v.weight.grad
+        sw = (gk.data_ptr() - gq.data_ptr()) // 4
+        sb = (a.linear_k.bias.grad.data_ptr() - a.linear_q.bias.grad.data_ptr()) // 4
+        if (cdt == torch.bfloat16 and sw > 0 and (gv.data_ptr() - gk.data_ptr()) // 4 == sw
+                and (a.linear_v.bias.grad.data_ptr() - a.linear_k.bias.grad.data_ptr()) // 4 == sb):
+            # q, k, v weight (and bias) gradients as ONE batched TN GEMM: the three gradients are equally spaced in the
+            # flat gradient buffer, the three dY column blocks equally spaced in dqkv
+            ops.gemm(dqkv, y2, gq, d, d, M, 3 * d, d, d, transA=True, transB=True, atomic=True,
+                     splitk=self._splitk(3 * self._tiles(d, d, True), M), batch=3, nb0=3, sA=(d, 0), sC=(sw, 0),
+                     c_dtype=ops.F32, colsum_out=a.linear_q.bias.grad, colsum_stride=sb)
+        else:
+            for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
+                self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M, bias_grad=lin.bias.grad)
         dy2 = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(dqkv, W[f"L{i}.att.wqkvt"], dy2, M, d, 3 * d, 3 * d, W.pitch(f"L{i}.att.wqkvt"), d)
         ln = L.norm_self_att

@@ -162,11 +162,10 @@ class ConvASRDecoder(NeuralModule):
                             1.0 / self.temperature if self.temperature != 1.0 else 1.0)
         ops.colsum(dlogits, conv.bias.grad, M, V1, ld=Vp)
         # d weight [V1, d] += dlogits^T @ x
-        t = 128 if cdt == torch.bfloat16 else 64
-        tiles = ((V1 + t - 1) // t) * ((d + t - 1) // t)
+        tiles = ((V1 + 255) // 256) * ((d + 127) // 128) if cdt == torch.bfloat16 else ((V1 + 63) // 64) * ((d + 63) // 64)
         nk = (M + 63) // 64
         ops.gemm(dlogits, xc, conv.weight.grad, V1, d, M, Vp, d, d, transA=True, transB=True, atomic=True,
-                 splitk=max(1, min(nk, 512 // tiles)), c_dtype=ops.F32)
+                 splitk=max(1, min(max(1, nk // 4), 256 // tiles)), c_dtype=ops.F32)
         denc = torch.empty(B, T, d, dtype=torch.float32, device=dev)
         ops.gemm(dlogits, W["dec.wt"], denc, M, d, Vp, Vp, W.pitch("dec.wt"), d)
         if self.grad_ready_hook is not None:

@@ -59,7 +59,7 @@ GEMM_PROFILE = None
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=False, transB=False, in_dtype=None, c_dtype=None, batch=1, nb0=0,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, alpha=1.0, epi=EPI_STORE, atomic=False, splitk=1, aux_in=None,
          aux_out=None, ldaux=0, drop: Dropout = NO_DROP, row_len=None, rows_per_b=1, rows_inner=1,
-         a_off=0, b_off=0, c_off=0, c_col_stride=1, colsum_out=None, colsum_off=0):
+         a_off=0, b_off=0, c_off=0, c_col_stride=1, colsum_out=None, colsum_off=0, colsum_stride=0):
     """C[M,N] = epi(A @ B^T) -- see mi355x_gemm.  A/B/Cm are tensors whose storage holds the (strided) operands;
     *_off are element offsets into them (head / column slices)."""
     d = GemmDesc()
@@ -89,6 +89,7 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=False, transB=False, in_dty
     d.row_len = _ptr(row_len)
     d.rows_per_b, d.rows_inner = rows_per_b, rows_inner
     d.colsum_out = (_ptr(colsum_out) + 4 * colsum_off) if colsum_out is not None else 0
+    d.colsum_stride = colsum_stride
     if GEMM_PROFILE is None:
         check(lib.mi355x_gemm(C.byref(d), _stream()), "gemm")
         return

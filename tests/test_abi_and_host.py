@@ -37,6 +37,7 @@ int main(){
   printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(mi355x_gemm_desc), offsetof(mi355x_gemm_desc, c_col_stride),
          offsetof(mi355x_gemm_desc, bias), offsetof(mi355x_gemm_desc, aux_in), offsetof(mi355x_gemm_desc, drop_key),
          offsetof(mi355x_gemm_desc, row_len), offsetof(mi355x_gemm_desc, colsum_out));
+  printf("%zu\n", offsetof(mi355x_gemm_desc, colsum_stride));
   printf("%zu %zu\n", sizeof(mi355x_pack_entry), offsetof(mi355x_pack_entry, tile_begin));
   return 0; }'''
     import tempfile
@@ -50,7 +51,8 @@ int main(){
     G = GemmDesc
     assert vals[:7] == [ctypes.sizeof(G), G.c_col_stride.offset, G.bias.offset, G.aux_in.offset, G.drop_key.offset,
                         G.row_len.offset, G.colsum_out.offset]
-    assert vals[7:] == [ctypes.sizeof(PackEntry), PackEntry.tile_begin.offset]
+    assert vals[7] == G.colsum_stride.offset
+    assert vals[8:] == [ctypes.sizeof(PackEntry), PackEntry.tile_begin.offset]
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():
