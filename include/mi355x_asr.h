@@ -79,7 +79,8 @@ int mi355x_subsample_conv1_fwd(const void* mel /*f32 [B,F,T]*/, const void* w /*
                                void* out /*[B,T1,F1,C]*/, int out_dtype, const void* len0, const void* len1, int B, int F,
                                int T, int C, void* stream);
 int mi355x_subsample_conv1_bwd(const void* dout, int dtype, const void* mel, const void* len0, void* dw, void* db, int B,
-                               int F, int T, int C, void* stream);
+                               int F, int T, int C, void* scratch /* optional f32 [ceil(T1/32)*B*10*C]: two-stage reduction */,
+                               long long scratch_elems, void* stream);
 int mi355x_im2col_3x3s2(const void* in /*[B,T1,F1,C]*/, void* col /*[B*T2*F2, 9C]*/, int dtype, int B, int T1, int F1, int C,
                         void* stream);
 int mi355x_col2im_3x3s2_relu(const void* dcol, const void* act, void* din, int dtype, int B, int T1, int F1, int C,
@@ -152,7 +153,8 @@ int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len
 int mi355x_dwconv_fwd(const void* x, const void* w /*[d,1,k]*/, const void* bias, void* y, int dtype,
                       void* stats /*f64 [2,d] += (sum, sumsq) or NULL*/, int B, int T, int d, int ksize, void* stream);
 int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dtype, int B, int T,
-                      int d, int ksize, void* stream);
+                      int d, int ksize, void* scratch /* optional f32 [4*B*(ksize+1)*d]: two-stage reduction, no atomics */,
+                      long long scratch_elems, void* stream);
 int mi355x_bn_finalize(const void* stats, double count, void* mean, void* rstd, void* running_mean, void* running_var,
                        float momentum, float eps, int d, void* stream);
 int mi355x_bn_eval_stats(const void* running_mean, const void* running_var, void* mean, void* rstd, float eps, int d,

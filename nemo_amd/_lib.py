@@ -51,7 +51,7 @@ SIGNATURES = {
     "mi355x_logmel_fwd": [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, f32, u32, f32, vp, i32, i32, i32, vp],
     "mi355x_feat_normalize": [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp],
     "mi355x_subsample_conv1_fwd": [vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp],
-    "mi355x_subsample_conv1_bwd": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mi355x_subsample_conv1_bwd": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp],
     "mi355x_im2col_3x3s2": [vp, vp, i32, i32, i32, i32, i32, vp],
     "mi355x_col2im_3x3s2_relu": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mi355x_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp],
@@ -72,7 +72,7 @@ SIGNATURES = {
     "mi355x_relpos_flash_bwd_dkv": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_relpos_flash_bwd_dpos": [vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
     "mi355x_dwconv_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp],
-    "mi355x_dwconv_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mi355x_dwconv_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp],
     "mi355x_bn_finalize": [vp, f64, vp, vp, vp, vp, f32, f32, i32, vp],
     "mi355x_bn_eval_stats": [vp, vp, vp, vp, f32, i32, vp],
     "mi355x_bn_swish_fwd": [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],

@@ -90,7 +90,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // ---------------------------------------------------------------- activations
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 VALU instructions): the Swish epilogues are VALU-bound
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float swish_grad(float x) {  // d/dx x*sigmoid(x)
   float s = sigmoidf_(x);
@@ -143,4 +144,52 @@ __device__ __forceinline__ float hash_normal(uint32_t key, uint32_t idx) {
   float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777217.0f);  // (0,1)
   float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
   return sqrtf(-2.f * __logf(u1)) * __cosf(6.28318530718f * u2);
+}
+
+// 16-byte vector I/O of activations, converted to/from f32 registers
+template <typename TT> struct VecIO;
+template <> struct VecIO<bf16_t> {
+  static constexpr int V = 8;
+  static __device__ __forceinline__ void load(const bf16_t* p, float* dst) {
+    const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dst[2 * j] = __uint_as_float(t[j] << 16); dst[2 * j + 1] = __uint_as_float(t[j] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+    u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    *reinterpret_cast<u32x4*>(p) = t;
+  }
+};
+template <> struct VecIO<float> {
+  static constexpr int V = 4;
+  static __device__ __forceinline__ void load(const float* p, float* dst) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
+// Second stage of the two-stage "taps x channels" weight-gradient reductions (depthwise conv, conv1 of the sub-sampling):
+//   dw[c*KS + k] += sum_p partial[p][k][c]  (k < KS),   dbias[c] += sum_p partial[p][KS][c]
+// grid (ceil((KS+1)*d/256), nsplit): each y-slice sums a contiguous range of parts, so only nsplit-way atomics remain.
+static __global__ __launch_bounds__(256) void tap_reduce_kernel(const float* __restrict__ partial, int nparts, int KS, int d,
+                                                                float* __restrict__ dw, float* __restrict__ dbias) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= (KS + 1) * d) return;
+  const int k = e / d, c = e - k * d;
+  const int per = (nparts + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = min(nparts, p0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const long long ps = (long long)(KS + 1) * d;
+  const float* src = partial + (long long)k * d + c;
+  int p = p0;
+  for (; p + 4 <= p1; p += 4) {
+    a0 += src[(p + 0) * ps]; a1 += src[(p + 1) * ps]; a2 += src[(p + 2) * ps]; a3 += src[(p + 3) * ps];
+  }
+  for (; p < p1; ++p) a0 += src[p * ps];
+  const float acc = (a0 + a1) + (a2 + a3);
+  if (k < KS) atomicAdd(dw + c * KS + k, acc);
+  else if (dbias) atomicAdd(dbias + c, acc);
 }

@@ -5,6 +5,7 @@
 //   CausalConv1D(d, d, k=31, groups=d, padding 15/15) (causal_convs.py:130-147) -> nn.BatchNorm1d -> Swish
 // BN statistics are taken over all B*T positions (padded frames included) exactly as torch BatchNorm1d does on the
 // reference's [B,d,T] tensor; sums are accumulated in f64 so SyncBN (all-reduce of the raw sums) is exact.
+#include <stdlib.h>
 #include "common.cuh"
 #include "mi355x_asr.h"
 
@@ -16,9 +17,45 @@
 #define DW_TT 64     // time steps per tile
 #define DW_TQ 16     // outputs per thread (4 time groups x 16)
 #define DW_MAXK 31
+#define DW_LD (DW_CH + 4)  // LDS row pitch: +4 floats keeps float4 alignment and staggers rows across banks
 
 __device__ __forceinline__ float round_as(float v, float) { return v; }
 __device__ __forceinline__ float round_as(float v, bf16_t) { return bf2f(f2bf(v)); }
+
+// 16-B (bf16: 8 channels) / 16-B (f32: 4 channels) global accesses: a tile row of 64 channels is 128 B (bf16) of contiguous
+// memory; 2-byte-per-lane loads / stores run at a fraction of the HBM rate on this chip (measured on the first GEMM
+// epilogue), so tiles move between HBM and LDS in vector chunks and are converted to f32 on the LDS side.
+// rows [t_first, t_first + nrows) x channels [c0, c0+64) of x[b] -> tile[nrows][DW_CH] (f32), zero outside [0,T) x [0,d)
+template <typename TT>
+__device__ __forceinline__ void stage_tile(const TT* xb, int T, int d, int t_first, int nrows, int c0, float (*tile)[DW_LD]) {
+  constexpr int V = VecIO<TT>::V, CPR = DW_CH / V;
+  for (int q = threadIdx.x; q < nrows * CPR; q += 256) {
+    const int r = q / CPR, cc = (q - r * CPR) * V;
+    const int t = t_first + r, c = c0 + cc;
+    float v[V];
+    if (t >= 0 && t < T && c + V <= d) VecIO<TT>::load(xb + (long long)t * d + c, v);
+    else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = (t >= 0 && t < T && c + j < d) ? ld(xb + (long long)t * d + c + j) : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < V; j += 4) *reinterpret_cast<float4*>(&tile[r][cc + j]) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+  }
+}
+// tile[DW_TT][DW_CH] (f32) -> rows [t0, t0+DW_TT) x channels [c0, c0+64) of y[b]
+template <typename TT>
+__device__ __forceinline__ void unstage_tile(TT* yb, int T, int d, int t0, int c0, float (*tile)[DW_LD]) {
+  constexpr int V = VecIO<TT>::V, CPR = DW_CH / V;
+  for (int q = threadIdx.x; q < DW_TT * CPR; q += 256) {
+    const int r = q / CPR, cc = (q - r * CPR) * V;
+    const int t = t0 + r, c = c0 + cc;
+    if (t >= T) continue;
+    if (c + V <= d) VecIO<TT>::store(yb + (long long)t * d + c, &tile[r][cc]);
+    else {
+      for (int j = 0; j < V; ++j) if (c + j < d) st(yb + (long long)t * d + c + j, tile[r][cc + j]);
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------ forward
 // x [B,T,d] -> y[b,t,c] = bias[c] + sum_k w[c,k] * x[b, t+k-pad, c]  (zero outside [0,T));  stats[0][c] += sum y, stats[1][c] += sum y^2
@@ -28,20 +65,16 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const TT* __restrict__ 
                                                          double* __restrict__ stats, int B, int T, int d) {
   constexpr int PAD = (KS - 1) / 2;
   constexpr int ROWS = DW_TT + KS - 1;
-  __shared__ float tile[ROWS][DW_CH];
+  __shared__ __attribute__((aligned(16))) float tile[ROWS][DW_LD];
+  __shared__ __attribute__((aligned(16))) float otile[DW_TT][DW_LD];
   __shared__ float red[2][4][DW_CH];
   const int c_l = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  const int c = blockIdx.x * DW_CH + c_l;
+  const int c0 = blockIdx.x * DW_CH;
+  const int c = c0 + c_l;
   const int b = blockIdx.z;
   const int t0 = blockIdx.y * DW_TT;
   const bool cv = c < d;
-  // stage rows t0-PAD .. t0+DW_TT+PAD-1
-  for (int r = tg; r < ROWS; r += 4) {
-    const int t = t0 - PAD + r;
-    float v = 0.f;
-    if (cv && t >= 0 && t < T) v = ld(x + ((long long)b * T + t) * d + c);
-    tile[r][c_l] = v;
-  }
+  stage_tile<TT>(x + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tile);
   float wk[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) wk[k] = cv ? w[c * KS + k] : 0.f;
@@ -57,82 +90,90 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const TT* __restrict__ 
 #pragma unroll
     for (int k = 0; k < KS; ++k) a = fmaf(wk[k], in[o + k], a);
     const int t = t0 + tg * DW_TQ + o;
+    otile[tg * DW_TQ + o][c_l] = a;
     if (cv && t < T) {
-      st(y + ((long long)b * T + t) * d + c, a);
       const float ar = round_as(a, TT());
       s1 += ar; s2 += ar * ar;
     }
   }
-  if (stats) {
-    red[0][tg][c_l] = s1; red[1][tg][c_l] = s2;
-    __syncthreads();
-    if (tg == 0 && cv) {
-      atomicAdd(stats + c, (double)((red[0][0][c_l] + red[0][1][c_l]) + (red[0][2][c_l] + red[0][3][c_l])));
-      atomicAdd(stats + d + c, (double)((red[1][0][c_l] + red[1][1][c_l]) + (red[1][2][c_l] + red[1][3][c_l])));
-    }
+  if (stats) { red[0][tg][c_l] = s1; red[1][tg][c_l] = s2; }
+  __syncthreads();
+  unstage_tile<TT>(y + (long long)b * T * d, T, d, t0, c0, otile);
+  if (stats && tg == 0 && cv) {
+    atomicAdd(stats + c, (double)((red[0][0][c_l] + red[0][1][c_l]) + (red[0][2][c_l] + red[0][3][c_l])));
+    atomicAdd(stats + d + c, (double)((red[1][0][c_l] + red[1][1][c_l]) + (red[1][2][c_l] + red[1][3][c_l])));
   }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
 // dy [B,T,d], x [B,T,d]:  dx[t] = sum_k w[k] * dy[t + pad - k] ;  dw[c,k] += sum_{b,t} dy[t] * x[t+k-pad] ; dbias[c] += sum dy
-// grid (d/64, B): one block walks all time tiles of its (batch, channel chunk) so the atomics are 1 per (c,k) per block.
+// grid (d/64, DW_SEG, B): one block walks the time tiles of its segment, one atomic per (c,k) per block at the end.
+#define DW_SEG 4
 template <typename TT, int KS>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
                                                          const float* __restrict__ w, TT* __restrict__ dx,
-                                                         float* __restrict__ dw, float* __restrict__ dbias, int B, int T, int d) {
+                                                         float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ partial, int B, int T, int d) {
   constexpr int PAD = (KS - 1) / 2;
   constexpr int ROWS = DW_TT + KS - 1;
-  __shared__ float tdy[ROWS][DW_CH];
-  __shared__ float tx[ROWS][DW_CH];
-  __shared__ float red[4][DW_CH];
+  __shared__ __attribute__((aligned(16))) float big[2][ROWS][DW_LD];  // dy tile | x tile (also the final reduction buffer)
+  float (*tdy)[DW_LD] = big[0];
+  float (*tx)[DW_LD] = big[1];
+  __shared__ __attribute__((aligned(16))) float otile[DW_TT][DW_LD];
+  static_assert(4 * (KS + 1) * DW_CH <= 2 * ROWS * DW_CH, "reduction buffer must fit in the tile storage");
   const int c_l = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  const int c = blockIdx.x * DW_CH + c_l;
-  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * DW_CH;
+  const int c = c0 + c_l;
+  const int b = blockIdx.z;
   const bool cv = c < d;
+  const int ntile = (T + DW_TT - 1) / DW_TT;
+  const int per = (ntile + DW_SEG - 1) / DW_SEG;
+  const int tile_lo = blockIdx.y * per, tile_hi = min(ntile, tile_lo + per);
   float wk[KS], gw[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) { wk[k] = cv ? w[c * KS + k] : 0.f; gw[k] = 0.f; }
   float gb = 0.f;
-  for (int t0 = 0; t0 < T; t0 += DW_TT) {
+  for (int ti = tile_lo; ti < tile_hi; ++ti) {
+    const int t0 = ti * DW_TT;
     __syncthreads();
-    for (int r = tg; r < ROWS; r += 4) {
-      const int t = t0 - PAD + r;
-      float a = 0.f, e = 0.f;
-      if (cv && t >= 0 && t < T) {
-        const long long o = ((long long)b * T + t) * d + c;
-        a = ld(dy + o); e = ld(x + o);
-      }
-      tdy[r][c_l] = a; tx[r][c_l] = e;
-    }
+    stage_tile<TT>(dy + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tdy);
+    stage_tile<TT>(x + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tx);
     __syncthreads();
     float vdy[DW_TQ + KS - 1], vx[DW_TQ + KS - 1];
 #pragma unroll
     for (int i = 0; i < DW_TQ + KS - 1; ++i) { vdy[i] = tdy[tg * DW_TQ + i][c_l]; vx[i] = tx[tg * DW_TQ + i][c_l]; }
 #pragma unroll
     for (int o = 0; o < DW_TQ; ++o) {
-      // local index of time t is (t - t0 + PAD) = tg*16 + o + PAD  -> vdy[o + PAD] ; dy[t + PAD - k] -> vdy[o + 2*PAD - k]
       float a = 0.f;
 #pragma unroll
       for (int k = 0; k < KS; ++k) a = fmaf(wk[k], vdy[o + 2 * PAD - k], a);
-      const int t = t0 + tg * DW_TQ + o;
-      if (cv && t < T) st(dx + ((long long)b * T + t) * d + c, a);
+      otile[tg * DW_TQ + o][c_l] = a;
       const float g = vdy[o + PAD];  // zero when t >= T (staging zero-fills)
       gb += g;
 #pragma unroll
       for (int k = 0; k < KS; ++k) gw[k] = fmaf(g, vx[o + k], gw[k]);
     }
+    __syncthreads();
+    unstage_tile<TT>(dx + (long long)b * T * d, T, d, t0, c0, otile);
   }
-  // reduce the 4 time groups, one atomic per (c,k) per block
+  // one LDS round for all KS+1 partial sums: [4 time groups][KS+1][64 channels] (re-uses the dy tile), then 2 atomics/thread
+  __syncthreads();
+  float* rbuf = &big[0][0][0];
 #pragma unroll
-  for (int k = 0; k <= KS; ++k) {
-    __syncthreads();
-    red[tg][c_l] = (k < KS) ? gw[k < KS ? k : 0] : gb;
-    __syncthreads();
-    if (tg == 0 && cv) {
-      const float v = (red[0][c_l] + red[1][c_l]) + (red[2][c_l] + red[3][c_l]);
-      if (k < KS) atomicAdd(dw + c * KS + k, v);
-      else if (dbias) atomicAdd(dbias + c, v);
-    }
+  for (int k = 0; k < KS; ++k) rbuf[(tg * (KS + 1) + k) * DW_CH + c_l] = gw[k];
+  rbuf[(tg * (KS + 1) + KS) * DW_CH + c_l] = gb;
+  __syncthreads();
+  // Same-address float atomics from 128 workgroups cost 90 us here (measured); with a scratch buffer every workgroup
+  // stores its [KS+1][64] partial sums and reduce_partials_kernel adds them up (deterministic as a bonus).
+  float* pslab = partial ? partial + ((long long)(blockIdx.z * DW_SEG + blockIdx.y) * (KS + 1)) * d : nullptr;
+  for (int e = threadIdx.x; e < (KS + 1) * DW_CH; e += 256) {
+    const int k = e / DW_CH, cl = e - k * DW_CH;
+    const int cc = c0 + cl;
+    if (cc >= d) continue;
+    const float v = (rbuf[(0 * (KS + 1) + k) * DW_CH + cl] + rbuf[(1 * (KS + 1) + k) * DW_CH + cl]) +
+                    (rbuf[(2 * (KS + 1) + k) * DW_CH + cl] + rbuf[(3 * (KS + 1) + k) * DW_CH + cl]);
+    if (pslab) pslab[(long long)k * d + cc] = v;
+    else if (k < KS) atomicAdd(dw + cc * KS + k, v);
+    else if (dbias) atomicAdd(dbias + cc, v);
   }
 }
 
@@ -256,19 +297,24 @@ extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias,
   return mi_check_launch();
 }
 extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dt, int B,
-                                 int T, int d, int ksize, void* stream) {
+                                 int T, int d, int ksize, void* scratch, long long scratch_elems, void* stream) {
   mi_clear_errors();
   if (!dy || !x || !w || !dx || !dw || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
-  dim3 grid((d + DW_CH - 1) / DW_CH, B), block(256);
+  dim3 grid((d + DW_CH - 1) / DW_CH, DW_SEG, B), block(256);
   hipStream_t s = (hipStream_t)stream;
+  const int nparts = B * DW_SEG;
+  if (scratch && scratch_elems < (long long)nparts * (ksize + 1) * d) return MI_ERR_ARG;
 #define DW_BWD(KS) DISPATCH_DT(dt, TT, hipLaunchKernelGGL((dwconv_bwd_kernel<TT, KS>), grid, block, 0, s, (const TT*)dy, \
-    (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, B, T, d))
+    (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d))
   switch (ksize) {
     case 31: DW_BWD(31); break;
     case 9: DW_BWD(9); break;
     case 5: DW_BWD(5); break;
     default: return MI_ERR_ARG;
   }
+  if (scratch)
+    hipLaunchKernelGGL(tap_reduce_kernel, dim3(((ksize + 1) * d + 255) / 256, 4), dim3(256), 0, s, (const float*)scratch, nparts,
+                       ksize, d, (float*)dw, (float*)dbias);
   return mi_check_launch();
 }
 extern "C" int mi355x_bn_finalize(const void* stats, double count, void* mean, void* rstd, void* running_mean,

@@ -205,6 +205,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TX* __restrict__ x, l
     atomicAdd(out + c, alpha * ((sa[0][t] + sa[1][t]) + (sa[2][t] + sa[3][t])));
   }
 }
+// bf16, 8 columns (16 B) per lane: block = 512 columns x 4 row lanes, 64 rows per block
+#define CSV_ROWS 64
+__global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16_t* __restrict__ x, long long ldx_, float* __restrict__ out,
+                                                            int M, int N, float alpha) {
+  __shared__ float sa[4][512];
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 512 + lane * 8;
+  const int r0 = blockIdx.y * CSV_ROWS, r1 = min(M, r0 + CSV_ROWS);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < N) {
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const u32x4 t = *reinterpret_cast<const u32x4*>(x + (long long)r * ldx_ + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[2 * j] += __uint_as_float(t[j] << 16); a[2 * j + 1] += __uint_as_float(t[j] & 0xffff0000u); }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sa[rl][lane * 8 + j] = a[j];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int cc = blockIdx.x * 512 + e;
+    if (cc < N) atomicAdd(out + cc, alpha * ((sa[0][e] + sa[1][e]) + (sa[2][e] + sa[3][e])));
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // log-softmax over the class axis (C = V+1 = 129): one wave per row; logits f32 with pitch ld
@@ -294,8 +319,13 @@ extern "C" int mi355x_layernorm_bwd(const void* dy, int dy_dt, const void* x, in
 extern "C" int mi355x_colsum(const void* x, int x_dt, long long ld, void* out, int M, int N, float alpha, void* stream) {
   mi_clear_errors();
   if (!x || !out || M <= 0 || N <= 0) return MI_ERR_ARG;
-  dim3 grid((N + 63) / 64, (M + CR_ROWS - 1) / CR_ROWS), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (x_dt == MI_DT_BF16 && !(N & 7) && !(ld & 7) && !((uintptr_t)x & 15)) {
+    dim3 grid((N + 511) / 512, (M + CSV_ROWS - 1) / CSV_ROWS);
+    hipLaunchKernelGGL(colsum_bf16x8_kernel, grid, dim3(256), 0, s, (const bf16_t*)x, ld, (float*)out, M, N, alpha);
+    return mi_check_launch();
+  }
+  dim3 grid((N + 63) / 64, (M + CR_ROWS - 1) / CR_ROWS), block(256);
   DISPATCH_DT(x_dt, TX, hipLaunchKernelGGL((colsum_kernel<TX>), grid, block, 0, s, (const TX*)x, ld, (float*)out, M, N, alpha));
   return mi_check_launch();
 }

@@ -59,44 +59,80 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------ conv1 backward (params only)
 // dout1 [B,T1,F1,C] (already gated by ReLU and masks) : dw[c,kh,kw] += sum dout1 * x ; db[c] += sum dout1
 // grid (ceil(T1/16), B); threads over channels; each block walks 16 t1 x all f1
-#define C1_TB 16
+#define C1_TB 32
 template <typename TO>
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(const TO* __restrict__ dout, const float* __restrict__ mel,
                                                         const long long* __restrict__ len0, float* __restrict__ dw,
-                                                        float* __restrict__ db, int B, int F, int T, int T1, int F1, int C) {
-  extern __shared__ float rows[];  // [3][F + 2]  (freq index shifted by +1; zero borders)
+                                                        float* __restrict__ db, float* __restrict__ partial, int B, int F, int T,
+                                                        int T1, int F1, int C) {
+  // dout [B,T1,F1,C] is 1.3 GB at the Large shape: the kernel is a pure stream over it.  Lane = V consecutive channels
+  // (one 16-byte load per (t1,f1)), wave = every 4th output row; the 3x3 input patch comes from an LDS image of the
+  // mel rows this block touches (uniform-address reads).
+  constexpr int V = VecIO<TO>::V;
+  extern __shared__ float smem[];
+  const int TW = 2 * C1_TB + 1, FW = F + 2;
+  float* mel_s = smem;                    // [FW][TW]: (f+1, t - tbase), zero borders / beyond len0
+  float* red = smem + FW * TW;            // [4][64*V]
   const int b = blockIdx.y;
-  const int t1_0 = blockIdx.x * C1_TB;
-  const int FW = F + 2;
-  for (int c0 = 0; c0 < C; c0 += 256) {
-    const int c = c0 + threadIdx.x;
-    float gw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float gb = 0.f;
-    for (int t1 = t1_0; t1 < min(T1, t1_0 + C1_TB); ++t1) {
-      __syncthreads();
-      for (int i = threadIdx.x; i < 3 * FW; i += 256) {
-        const int kh = i / FW, f = i - kh * FW - 1;
-        const int t = 2 * t1 + kh - 1;
-        float v = 0.f;
-        if (t >= 0 && t < T && t < len0[b] && f >= 0 && f < F) v = mel[((long long)b * F + f) * T + t];
-        rows[i] = v;
-      }
-      __syncthreads();
-      if (c < C) {
+  const int t1_0 = blockIdx.x * C1_TB, t1_end = min(T1, t1_0 + C1_TB);
+  const int tbase = 2 * t1_0 - 1;
+  const int tlim = (int)min((long long)T, len0[b]);
+  for (int i = threadIdx.x; i < FW * TW; i += 256) {
+    const int fi = i / TW, tt = i - fi * TW;
+    const int f = fi - 1, t = tbase + tt;
+    float v = 0.f;
+    if (f >= 0 && f < F && t >= 0 && t < tlim) v = mel[((long long)b * F + f) * T + t];
+    mel_s[i] = v;
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int part = blockIdx.y * gridDim.x + blockIdx.x;
+  for (int c0 = 0; c0 < C; c0 += 64 * V) {
+    const int c = c0 + lane * V;
+    float gw[9][V], gb[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      gb[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) gw[k][j] = 0.f;
+    }
+    if (c < C) {
+      for (int t1 = t1_0 + wave; t1 < t1_end; t1 += 4) {
+        const float* mrow = mel_s + 2 * (t1 - t1_0);
+        const TO* gp = dout + ((long long)b * T1 + t1) * F1 * C + c;
+#pragma unroll 4
         for (int f1 = 0; f1 < F1; ++f1) {
-          const float g = ld(dout + (((long long)b * T1 + t1) * F1 + f1) * C + c);
-          gb += g;
+          float g[V];
+          VecIO<TO>::load(gp + (long long)f1 * C, g);
+          float m[9];
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) gw[kh * 3 + kw] = fmaf(g, rows[kh * FW + 2 * f1 + kw], gw[kh * 3 + kw]);
+            for (int kw = 0; kw < 3; ++kw) m[kh * 3 + kw] = mrow[(2 * f1 + kw) * TW + kh];
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            gb[j] += g[j];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) gw[k][j] = fmaf(g[j], m[k], gw[k][j]);
+          }
         }
       }
     }
-    if (c < C) {
+    // cross-wave sum, one tap per round; then one plain store per (tap, channel) into this block's slab
 #pragma unroll
-      for (int k = 0; k < 9; ++k) atomicAdd(dw + c * 9 + k, gw[k]);
-      atomicAdd(db + c, gb);
+    for (int k = 0; k < 10; ++k) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < V; ++j) red[wave * 64 * V + lane * V + j] = k < 9 ? gw[k < 9 ? k : 0][j] : gb[j];
+      __syncthreads();
+      for (int e = threadIdx.x; e < 64 * V; e += 256) {
+        const int cc = c0 + e;
+        if (cc >= C) continue;
+        const float v = (red[e] + red[64 * V + e]) + (red[2 * 64 * V + e] + red[3 * 64 * V + e]);
+        if (partial) partial[((long long)part * 10 + k) * C + cc] = v;
+        else if (k < 9) atomicAdd(dw + cc * 9 + k, v);
+        else atomicAdd(db + cc, v);
+      }
     }
   }
 }
@@ -180,15 +216,22 @@ extern "C" int mi355x_subsample_conv1_fwd(const void* mel, const void* w, const 
   return mi_check_launch();
 }
 extern "C" int mi355x_subsample_conv1_bwd(const void* dout, int dt, const void* mel, const void* len0, void* dw, void* db, int B,
-                                          int F, int T, int C, void* stream) {
+                                          int F, int T, int C, void* scratch, long long scratch_elems, void* stream) {
   mi_clear_errors();
-  if (!dout || !mel || !len0 || !dw || !db || B <= 0 || F <= 0 || T <= 0 || C <= 0) return MI_ERR_ARG;
+  if (!dout || !mel || !len0 || !dw || !db || B <= 0 || F <= 0 || T <= 0 || C <= 0 || (C & 7)) return MI_ERR_ARG;
   const int T1 = (T + 2 - 3) / 2 + 1, F1 = (F + 2 - 3) / 2 + 1;
   dim3 grid((T1 + C1_TB - 1) / C1_TB, B), block(256);
+  const int nparts = grid.x * grid.y;
+  if (scratch && scratch_elems < (long long)nparts * 10 * C) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const size_t shm = 3 * (F + 2) * sizeof(float);
+  const int V = dt == MI_DT_BF16 ? 8 : 4;
+  const size_t shm = ((size_t)(F + 2) * (2 * C1_TB + 1) + 4 * 64 * V) * sizeof(float);
+  if (shm > 64 * 1024) return MI_ERR_ARG;
   DISPATCH_DT(dt, TO, hipLaunchKernelGGL((conv1_bwd_kernel<TO>), grid, block, shm, s, (const TO*)dout, (const float*)mel,
-                                         (const long long*)len0, (float*)dw, (float*)db, B, F, T, T1, F1, C));
+                                         (const long long*)len0, (float*)dw, (float*)db, (float*)scratch, B, F, T, T1, F1, C));
+  if (scratch)
+    hipLaunchKernelGGL(tap_reduce_kernel, dim3((10 * C + 255) / 256, 16), dim3(256), 0, s, (const float*)scratch, nparts, 9, C,
+                       (float*)dw, (float*)db);
   return mi_check_launch();
 }
 extern "C" int mi355x_im2col_3x3s2(const void* in, void* col, int dt, int B, int T1, int F1, int C, void* stream) {

@@ -304,7 +304,7 @@ class ConformerEncoder(NeuralModule):
     def _splitk(tiles, K):
         """split-K factor: aim at one workgroup per CU (256) for the 144-KiB-LDS GEMM, at least 4 K tiles per split"""
         nk = (K + 63) // 64
-        return max(1, min(nk // 4 if nk >= 8 else 1, max(1, 256 // max(tiles, 1))))
+        return max(1, min(nk // 4 if nk >= 8 else 1, max(1, 256 // max(tiles, 1)), 16))
 
     @staticmethod
     def _tiles(n_out, n_in, bf16):

@@ -133,8 +133,11 @@ def conv1_fwd(mel, w, bias, out, len0, len1, C_):
 
 def conv1_bwd(dout, mel, len0, dw, db, C_):
     B, F, T = mel.shape
+    T1 = (T - 1) // 2 + 1
+    n = ((T1 + 31) // 32) * B * 10 * C_
+    sc = _scratch("conv1_bwd", n, dout.device)
     check(lib.mi355x_subsample_conv1_bwd(_ptr(dout), dt(dout), _ptr(mel), _ptr(len0), _ptr(dw), _ptr(db), B, F, T, C_,
-                                         _stream()), "subsample_conv1_bwd")
+                                         _ptr(sc), n, _stream()), "subsample_conv1_bwd")
 
 
 def im2col(x, col, B, T1, F1, C_):
@@ -246,9 +249,22 @@ def dwconv_fwd(x, w, bias, y, stats, B, T, d, k):
     check(lib.mi355x_dwconv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), dt(x), _ptr(stats), B, T, d, k, _stream()), "dwconv_fwd")
 
 
+_SCRATCH = {}
+
+
+def _scratch(name, n, device):
+    key = (name, str(device))
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < n:
+        t = _SCRATCH[key] = torch.empty(n, dtype=torch.float32, device=device)
+    return t
+
+
 def dwconv_bwd(dy, x, w, dx, dw, dbias, B, T, d, k):
-    check(lib.mi355x_dwconv_bwd(_ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(dbias), dt(x), B, T, d, k, _stream()),
-          "dwconv_bwd")
+    n = 4 * B * (k + 1) * d
+    sc = _scratch("dwconv_bwd", n, dy.device)
+    check(lib.mi355x_dwconv_bwd(_ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(dbias), dt(x), B, T, d, k, _ptr(sc), n,
+                                _stream()), "dwconv_bwd")
 
 
 def bn_finalize(stats, count, mean, rstd, running_mean, running_var, momentum, eps, d):

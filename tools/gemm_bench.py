@@ -56,3 +56,9 @@ run("ffn1_wgrad", 2048, 512, M, "atomic", torch.float32, "TN", splitk=8)
 run("ffn2_wgrad", 512, 2048, M, "atomic", torch.float32, "TN", splitk=8)
 run("proj_wgrad", 512, 512, M, "atomic", torch.float32, "TN", splitk=32)
 run("pv_like_NN", 4096, 4096, 4096, "nobias", bf, "NN")
+run("tn_big_store", 4096, 4096, 4096, "nobias", bf, "TN")
+run("ffn1_wgrad_sk4", 2048, 512, M, "atomic", torch.float32, "TN", splitk=4)
+run("ffn1_wgrad_sk16", 2048, 512, M, "atomic", torch.float32, "TN", splitk=16)
+run("ffn1_wgrad_sk1_store", 2048, 512, M, "nobias", torch.float32, "TN")
+run("proj_wgrad_sk16", 512, 512, M, "atomic", torch.float32, "TN", splitk=16)
+run("proj_wgrad_sk64", 512, 512, M, "atomic", torch.float32, "TN", splitk=64)
