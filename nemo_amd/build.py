@@ -22,7 +22,7 @@ LIB = os.path.join(LIBDIR, "libmi355x_asr.so")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-I", INCLUDE, "-I", CSRC,
-         "-Wno-unused-result"]
+         "-Wno-unused-result"] + os.environ.get("MI355X_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def sources():

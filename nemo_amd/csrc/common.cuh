@@ -29,15 +29,16 @@ static inline int mi_check_launch() {
 
 // ---------------------------------------------------------------- bf16 <-> f32
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// gfx950 converts in hardware: v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN) -- one instruction per pair
+// instead of the ~6-op integer sequence per element, which showed up in every bf16-writing epilogue.
+typedef __attribute__((ext_vector_type(2))) float mi_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 mi_bf16x2;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const mi_f32x2 v = {lo, hi};
+  const mi_bf16x2 b = __builtin_convertvector(v, mi_bf16x2);
+  return __builtin_bit_cast(uint32_t, b);
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 // typed load/store helpers (T = float or bf16_t)
 template <typename T> __device__ __forceinline__ float ld(const T* p);

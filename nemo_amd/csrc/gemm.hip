@@ -30,6 +30,10 @@ enum {
   EPI_MUL_POS = 5,     // C = acc * (aux_in > 0)
 };
 
+#define BM 128
+#define BN 128
+#define BK 64
+
 struct GemmP {
   const void* A; const void* B; void* C;
   int M, N, K;
@@ -163,12 +167,86 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, int z, long long coff,
   }
 }
 
+
+// ---- streamlined epilogue of a full-width tile whose f32 image sits in LDS ([rows][BN+4]).  One thread = 8 consecutive
+// columns of ROWS_IT rows; the epilogue kind is a compile-time constant, bias is loaded once, all aux_in loads are issued
+// before the first LDS read.  Same arithmetic as epilogue8() (bit-identical results).
+template <int EPI, int ITERS, int ROW_STEP>
+__device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, int z, long long coff, int m_first, int n0,
+                                              int row_l0) {
+  constexpr int LDS_C = BN + 4;
+  constexpr bool AUX_IN = EPI == EPI_RESID || EPI == EPI_DSWISH || EPI == EPI_MUL_POS;
+  const int c8 = (threadIdx.x & 15) * 8;
+  const int n = n0 + c8;
+  float b8[8];
+  if (p.bias) ld8x(p.bias, n, MI_DT_F32, b8);
+  else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b8[j] = 0.f;
+  }
+  const uint32_t dbase = (uint32_t)z * (uint32_t)(p.M * p.N) + (uint32_t)n;
+  float aux[AUX_IN ? ITERS : 1][8];
+  if (AUX_IN) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int m = m_first + it * ROW_STEP;
+      if (m < p.M) ld8x(p.aux_in, coff + (long long)m * p.ldaux + n, EPI == EPI_RESID ? MI_DT_F32 : p.auxin_dt, aux[it]);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int m = m_first + it * ROW_STEP;
+    if (m >= p.M) continue;
+    const float* src = sC + (row_l0 + it * ROW_STEP) * LDS_C + c8;
+    const float4 a = *reinterpret_cast<const float4*>(src);
+    const float4 b = *reinterpret_cast<const float4*>(src + 4);
+    float v[8] = {a.x + b8[0], a.y + b8[1], a.z + b8[2], a.w + b8[3], b.x + b8[4], b.y + b8[5], b.z + b8[6], b.w + b8[7]};
+    float dm[8];
+    drop_mask8(p.drop, dbase + (uint32_t)m * (uint32_t)p.N, dm);
+    const long long ci = coff + (long long)m * p.ldc + n;
+    const long long ai = coff + (long long)m * p.ldaux + n;
+    if (EPI == EPI_STORE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= p.alpha * dm[j];
+    } else if (EPI == EPI_SWISH_DROP) {
+      st8x(p.aux_out, ai, p.auxout_dt, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * dm[j];
+    } else if (EPI == EPI_RESID) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = aux[AUX_IN ? it : 0][j] + p.alpha * v[j] * dm[j];
+    } else if (EPI == EPI_DSWISH) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * dm[j] * swish_grad(aux[AUX_IN ? it : 0][j]);
+    } else if (EPI == EPI_RELU_MASK) {
+      const int bb = m / p.rows_per_b;
+      const int t = (m - bb * p.rows_per_b) / p.rows_inner;
+      const bool ok = (long long)t < p.row_len[bb];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (ok && v[j] > 0.f) ? v[j] : 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = aux[AUX_IN ? it : 0][j] > 0.f ? v[j] : 0.f;
+    }
+    st8x(p.C, ci, p.c_dt, v);
+  }
+}
+template <int ITERS, int ROW_STEP>
+__device__ __forceinline__ void fast_epilogue_any(const GemmP& p, const float* sC, int z, long long coff, int m_first, int n0,
+                                                  int row_l0) {
+  switch (p.epi) {
+    case EPI_STORE: fast_epilogue<EPI_STORE, ITERS, ROW_STEP>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_SWISH_DROP: fast_epilogue<EPI_SWISH_DROP, ITERS, ROW_STEP>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_RESID: fast_epilogue<EPI_RESID, ITERS, ROW_STEP>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_DSWISH: fast_epilogue<EPI_DSWISH, ITERS, ROW_STEP>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_RELU_MASK: fast_epilogue<EPI_RELU_MASK, ITERS, ROW_STEP>(p, sC, z, coff, m_first, n0, row_l0); break;
+    default: fast_epilogue<EPI_MUL_POS, ITERS, ROW_STEP>(p, sC, z, coff, m_first, n0, row_l0); break;
+  }
+}
+
 // =================================================================================================
 // bf16 MFMA kernel
 // =================================================================================================
-#define BM 128
-#define BN 128
-#define BK 64
 
 __device__ __forceinline__ int lds_off(int r, int chunk) {  // element offset of 8-element chunk `chunk` of row r
   return r * BK + ((chunk ^ ((r >> 1) & 7)) << 3);
@@ -392,7 +470,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
         const float4 a = *reinterpret_cast<const float4*>(sC + row_l * LDS_C + c8);
         const float4 b = *reinterpret_cast<const float4*>(sC + row_l * LDS_C + c8 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        if (p.vec_ok && n + 8 <= p.N) epilogue8(p, z, coff, m, n, v);
+        if ((p.vec_ok & 1) && n + 8 <= p.N) epilogue8(p, z, coff, m, n, v);
         else {
           for (int j = 0; j < 8; ++j)
             if (n + j < p.N) epilogue(p, z, coff, m, n + j, v[j]);
@@ -417,28 +495,47 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
+// Per-thread LDS-DMA sources of one operand, computed once per tile: the K loop only adds the k-tile step.
+template <int R> struct DmaSrc {
+  static constexpr int PER = R * 8 / 512;
+  const bf16_t* ptr[PER];  // source of chunk i at k-tile 0 (nullptr-equivalent handled by `ok`)
+  int kin[PER];            // k offset of the chunk inside a k-tile (K-tail test)
+  bool ok[PER];            // column (reduction-major) inside the matrix
+  long long step;          // elements per k-tile
+};
 template <bool T, int R>
-__device__ __forceinline__ void stage_v2(const bf16_t* base, long long ld, int row0, int rows, int k0, int K, bf16_t* lds_tile) {
-  const int wave = threadIdx.x >> 6;
-  constexpr int PER = R * 8 / 512;  // 16-B chunks per thread
+__device__ __forceinline__ void dma_setup(DmaSrc<R>& d, const bf16_t* base, long long ld, int row0, int rows, int kbase) {
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
+  for (int i = 0; i < DmaSrc<R>::PER; ++i) {
     const int q = threadIdx.x + i * 512;
-    const bf16_t* src;
     if (!T) {
       const int r = q >> 3, ck = q & 7;
       const int gck = ck ^ ((r >> 1) & 7);
       int gr = row0 + r;
       gr = gr < rows ? gr : rows - 1;
-      const int gk = k0 + gck * 8;
-      src = (gk < K) ? base + (long long)gr * ld + gk : reinterpret_cast<const bf16_t*>(g_zero16);
+      d.ptr[i] = base + (long long)gr * ld + kbase + gck * 8;
+      d.kin[i] = gck * 8;
+      d.ok[i] = true;
     } else {
-      constexpr int CPR = R / 8;  // chunks per k-row
+      constexpr int CPR = R / 8;
       const int k = q / CPR, cp = q % CPR;
       const int c = cp ^ ((k & 3) << 2);
-      const int gk = k0 + k, gc = row0 + c * 8;
-      src = (gk < K && gc < rows) ? base + (long long)gk * ld + gc : reinterpret_cast<const bf16_t*>(g_zero16);
+      const int gc = row0 + c * 8;
+      d.ok[i] = gc < rows;
+      d.ptr[i] = base + (long long)(kbase + k) * ld + (d.ok[i] ? gc : 0);
+      d.kin[i] = k;
     }
+  }
+  d.step = T ? (long long)BK * ld : (long long)BK;
+}
+template <int R>
+__device__ __forceinline__ void dma_issue(const DmaSrc<R>& d, int it, int k0, int K, bool ktail, bf16_t* lds_tile) {
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < DmaSrc<R>::PER; ++i) {
+    bool ok = d.ok[i];
+    if (ktail) ok = ok && (k0 + d.kin[i] < K);
+    const bf16_t* src = ok ? d.ptr[i] + (long long)it * d.step : reinterpret_cast<const bf16_t*>(g_zero16);
     bf16_t* dst = lds_tile + (wave * 64 + i * 512) * 8;
     __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
   }
@@ -485,7 +582,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
     kt1 = min(nk_total, kt0 + p.ktiles_per_split);
     if (kt0 >= kt1) return;
   }
+#ifdef GEMM_ABLATE
+  const int dbg = p.vec_ok >> 8;
+  const int nk = (dbg & 2) ? 0 : kt1 - kt0;
+#else
   const int nk = kt1 - kt0;
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
@@ -498,37 +600,59 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  DmaSrc<BM2> dA;
+  DmaSrc<BN> dB;
+  dma_setup<TA, BM2>(dA, A, p.lda, m0, p.M, kt0 * BK);
+  dma_setup<TB, BN>(dB, B, p.ldb, n0, p.N, kt0 * BK);
+  const bool ktail = (p.K & (BK - 1)) != 0;
   auto issue = [&](int it) {  // it = local tile index
     bf16_t* st = smem2 + (it % 3) * NT2_STAGE;
-    stage_v2<TA, BM2>(A, p.lda, m0, p.M, (kt0 + it) * BK, p.K, st);
-    stage_v2<TB, BN>(B, p.ldb, n0, p.N, (kt0 + it) * BK, p.K, st + BM2 * BK);
+    dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
+    dma_issue<BN>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
   // bias gradient riding along with wgrad: column sums of the A tile, read back from LDS (8 B per lane per k-row group)
   const bool do_colsum = TA && p.colsum_out != nullptr && tile_n == 0;
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
+#ifdef GEMM_ABLATE
+  if (nk > 0)
+#endif
   issue(0);
   if (nk > 1) issue(1);
   if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   for (int it = 0; it < nk; ++it) {
+#ifdef GEMM_ABLATE
+    if (!(dbg & 8))
+#endif
     if (it + 2 < nk) issue(it + 2);  // overwrites the stage of tile it-1: every wave passed the barrier after reading it
     const bf16_t* a_s = smem2 + (it % 3) * NT2_STAGE;
     const bf16_t* b_s = a_s + BM2 * BK;
+    // all 16 fragment reads of the K-tile go out back to back (the LDS only reaches its rate on long bursts); the
+    // MFMAs of step kk then wait for exactly their operands (in-order returns -> counted lgkmcnt)
+    bf16x8 af[4][2], bfr[4][2];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 af[2], bfr[2];
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        af[i] = frag_v2<TA, BM2>(a_s, wm * 64 + i * 32, kk, lane);
-        bfr[i] = frag_v2<TB, BN>(b_s, wn * 64 + i * 32, kk, lane);
+        af[kk][i] = frag_v2<TA, BM2>(a_s, wm * 64 + i * 32, kk, lane);
+        bfr[kk][i] = frag_v2<TB, BN>(b_s, wn * 64 + i * 32, kk, lane);
       }
+    __builtin_amdgcn_sched_barrier(0);  // keep the burst: the scheduler would sink the reads back next to their MFMAs
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#ifdef GEMM_ABLATE
+      if (dbg & 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { asm volatile("" :: "v"(af[kk][i])); asm volatile("" :: "v"(bfr[kk][i])); }
+      } else
+#endif
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
     }
     if (TA && do_colsum) {  // thread -> (k-group of 8 rows = wave, 4 consecutive columns = lane): 8 x ds_read_b64
       const int col = lane * 4;
@@ -548,6 +672,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
   }
 
   float* sC = reinterpret_cast<float*>(smem2);
+#ifdef GEMM_ABLATE
+  if (dbg & 1) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 123.456f) ((float*)p.C)[0] = sacc;
+    return;
+  }
+#endif
   if (TA && do_colsum) {  // combine the 8 k-groups (waves) through LDS: 8 x 256 floats
 #pragma unroll
     for (int e = 0; e < 4; ++e) sC[wave * BM2 + lane * 4 + e] = csum[e];
@@ -583,6 +720,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
     }
     return;
   }
+  if ((p.vec_ok & 1) && !(p.N & 7) && n0 + BN <= p.N) {
+    fast_epilogue_any<8, 32>(p, sC, z, coff, m0 + (threadIdx.x >> 4), n0, threadIdx.x >> 4);
+    return;
+  }
 #pragma unroll 2
   for (int it = 0; it < 8; ++it) {
     const int row_l = (threadIdx.x >> 4) + 32 * it;
@@ -593,7 +734,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
       const float4 a = *reinterpret_cast<const float4*>(sC + row_l * LDS_C + c8);
       const float4 b = *reinterpret_cast<const float4*>(sC + row_l * LDS_C + c8 + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-      if (p.vec_ok && n + 8 <= p.N) epilogue8(p, z, coff, m, n, v);
+      if ((p.vec_ok & 1) && n + 8 <= p.N) epilogue8(p, z, coff, m, n, v);
       else {
         for (int j = 0; j < 8; ++j)
           if (n + j < p.N) epilogue(p, z, coff, m, n + j, v[j]);
@@ -703,6 +844,9 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
     if (p.aux_out) ok = ok && !(p.ldaux & 7) && !((uintptr_t)p.aux_out & 31);
     if (p.bias) ok = ok && !((uintptr_t)p.bias & 31);
     p.vec_ok = ok ? 1 : 0;
+#ifdef GEMM_ABLATE
+    { const char* e = getenv("MI355X_GEMM_DBG"); if (e) p.vec_ok |= atoi(e) << 8; }
+#endif
   }
   hipStream_t s = (hipStream_t)stream;
   if (d->in_dtype == MI_DT_BF16) {
