@@ -38,15 +38,35 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 __device__ __forceinline__ uint32_t attn_key(const DropCfg& d, int b, int h) {
   return mix32(mix32(d.key ^ (uint32_t)(b * 0x632BE5AB)) + (uint32_t)h * 0x9E3779B9u);
 }
+// Dropout on the attention probabilities, counter-based and two-level so that it costs ~10 VALU ops per element instead
+// of ~22 (the forward / dQ / dKV loops are VALU-bound, and a full hash per element was 45 % of their VALU work):
+//   * every 4x4 block (i>>2, j>>2) of the [T,T] matrix gets a seed = one mixing round over akey ^ rowcode ^ colcode,
+//     where the row / column codes are two 24-bit multiplies each (the lane-constant one is hoisted out of the loop);
+//   * element (i&3, j&3) of the block finishes with add - xorshift - multiply on seed + e * golden.
+// Every kernel walks whole blocks per lane (4 consecutive keys in "lane = query" layouts, 4 consecutive queries in the
+// "lane = key" layout), so each lane needs one seed per 4 elements.  attn_drop() is the scalar definition.
+__device__ __forceinline__ uint32_t adrop_rcode(uint32_t bi) {
+  return __umul24(bi + 0x1234u, 0x9E3779u) ^ (__umul24(bi + 0x4321u, 0x7FEB35u) << 8);
+}
+__device__ __forceinline__ uint32_t adrop_ccode(uint32_t bj) {
+  return __umul24(bj + 0x2345u, 0x85EBCBu) ^ (__umul24(bj + 0x5432u, 0xC2B2AFu) << 5);
+}
+__device__ __forceinline__ uint32_t adrop_seed(uint32_t x) {  // x = akey ^ rowcode ^ colcode
+  x ^= x >> 15;
+  x = __umul24(x, 0x846CA7u) ^ (x >> 9) ^ (x << 7);
+  x ^= x >> 13;
+  return x;
+}
+#define ADROP_G 0x9E3779B9u
+__device__ __forceinline__ float adrop_elem(const DropCfg& d, uint32_t y) {  // y = seed + ((i&3)*4 + (j&3)) * ADROP_G
+  y ^= y >> 15;
+  y = __umul24(y, 0x2C1B3Du);
+  return y >= d.threshold ? d.scale : 0.f;
+}
 __device__ __forceinline__ float attn_drop(const DropCfg& d, uint32_t akey, int i, int j) {
   if (d.threshold == 0u) return 1.f;
-  uint32_t x = __umul24((uint32_t)j + 0x1234u, 0x9E3779u) ^ (__umul24((uint32_t)i + 0x4321u, 0x7FEB35u) << 3) ^ akey;
-  x ^= x >> 15;
-  x = __umul24(x & 0xFFFFFFu, 0x846CA7u) ^ (x >> 9) ^ (x << 7);
-  x ^= x >> 13;
-  x = __umul24(x & 0xFFFFFFu, 0x2C1B3Cu) + (x >> 11);
-  x ^= x >> 16; x ^= x << 11;
-  return x >= d.threshold ? d.scale : 0.f;
+  const uint32_t seed = adrop_seed(akey ^ adrop_rcode((uint32_t)i >> 2) ^ adrop_ccode((uint32_t)j >> 2));
+  return adrop_elem(d, seed + (uint32_t)((i & 3) * 4 + (j & 3)) * ADROP_G);
 }
 
 __device__ __forceinline__ int a_off(int r, int chunk) { return r * ADK + ((chunk ^ ((r >> 1) & 7)) << 3); }
@@ -156,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
   float m_run = -INFINITY, l_run = 0.f;
   float* sg = s_g[wave];
   const uint32_t akey = attn_key(drop, b, h);
+  const uint32_t arow = akey ^ adrop_rcode((uint32_t)i >> 2), erow = (uint32_t)(i & 3) * (4u * ADROP_G);
 
   const int nkt = (L + ABK - 1) / ABK;  // key tiles that contain at least one valid key
   for (int kt = 0; kt < nkt; ++kt) {
@@ -215,7 +236,11 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
     // ---- dropout on the probabilities
     if (drop.threshold != 0u) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] *= attn_drop(drop, akey, i, j0 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 = keys 4*bj .. 4*bj+3 of this lane's query
+        const uint32_t seed = adrop_seed(arow ^ adrop_ccode((uint32_t)(j0 >> 2) + 2 * g + lh)) + erow;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[4 * g + c] *= adrop_elem(drop, seed + c * ADROP_G);
+      }
     }
     // ---- O^T += V^T . P^T : B operand = this lane's probabilities (registers 8s..8s+7 <-> key slots of K16 step s)
 #pragma unroll
@@ -341,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   for (int r = 0; r < 16; ++r) { dqu[0][r] = 0.f; dqu[1][r] = 0.f; dqv[0][r] = 0.f; dqv[1][r] = 0.f; }
   float* sg = s_g[wave];
   const uint32_t akey = attn_key(drop, b, h);
+  const uint32_t arow = akey ^ adrop_rcode((uint32_t)i >> 2), erow = (uint32_t)(i & 3) * (4u * ADROP_G);
   const int prow0 = (ABQ - 32) - 32 * wave;
 
   const int nkt = (L + ABK - 1) / ABK;
@@ -384,9 +410,14 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // dS = P * (dropmask * dP - delta) * scale
+    uint32_t seed_g = 0u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float dm = attn_drop(drop, akey, i, j0 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+      float dm = 1.f;
+      if (drop.threshold != 0u) {
+        if ((r & 3) == 0) seed_g = adrop_seed(arow ^ adrop_ccode((uint32_t)(j0 >> 2) + 2 * (r >> 2) + lh)) + erow;
+        dm = adrop_elem(drop, seed_g + (r & 3) * ADROP_G);
+      }
       ds[r] = ds[r] * (acc_dp[r] * dm - dlt_i) * scale;
     }
     // ---- dS tile [32 queries][32 keys] -> HBM (bf16, [H,B,T,Tp]) for the linear_pos gradient kernel
@@ -498,6 +529,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   const bf16_t* kbase = qkv + (ldq / 3) + h * ADK;
   const bf16_t* pbase = pos + h * ADK;
   const uint32_t akey = attn_key(drop, b, h);
+  const uint32_t acol = akey ^ adrop_ccode((uint32_t)j >> 2), ecol = (uint32_t)(j & 3) * ADROP_G;
 
   bf16x8 kf[4], vf[4];
   load_rows(kbase + rowj * ldq, kf, j < T, lh);
@@ -541,6 +573,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
       }
     }
     float pd[16], ds[16];
+    uint32_t seed_g = 0u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;  // query row of this register
@@ -551,7 +584,11 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
       const int ii = i0 + rho;
       const bool ok = kvalid && ii < L;
       const float p = ok ? __expf((acc_s[r] + bd) * scale - s_lse[rho]) : 0.f;
-      const float dm = attn_drop(drop, akey, ii, j);
+      float dm = 1.f;
+      if (drop.threshold != 0u) {
+        if ((r & 3) == 0) seed_g = adrop_seed(acol ^ adrop_rcode((uint32_t)(i0 >> 2) + 2 * (r >> 2) + lh)) + ecol;
+        dm = adrop_elem(drop, seed_g + (r & 3) * (4u * ADROP_G));
+      }
       pd[r] = p * dm;
       ds[r] = p * (acc_dp[r] * dm - s_dlt[rho]) * scale;
     }

@@ -355,8 +355,12 @@ class ConformerEncoder(NeuralModule):
         # ---- sub-sampling: conv1 (direct) -> im2col -> conv2 (MFMA GEMM, ReLU+mask epilogue) -> out Linear (+xscale, dropout)
         S.out1 = torch.empty(B, T1, F1, C_, dtype=cdt, device=dev)
         ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, S.out1, len0, len1, C_)
+        # the 3 GB im2col image stays alive until the conv2 weight gradient (1 % of the 288 GB HBM; recomputing it in
+        # backward cost 0.83 ms per step)
         col = self._buf("col", (B * T2 * F2, 9 * C_), cdt, dev)
         ops.im2col(S.out1, col, B, T1, F1, C_)
+        self._col_gen = getattr(self, "_col_gen", 0) + 1
+        S.col, S.col_gen = (col if save else None), self._col_gen
         S.out2 = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
         ops.gemm(col, W["pre.w2"], S.out2, B * T2 * F2, C_, 9 * C_, 9 * C_, W.pitch("pre.w2"), C_, bias=pe.conv[2].bias,
                  epi=ops.EPI_RELU_MASK, row_len=len2, rows_per_b=T2 * F2, rows_inner=F2)
@@ -524,13 +528,15 @@ class ConformerEncoder(NeuralModule):
         ops.gemm(dxs, W["pre.outt"], dout2, M, F2 * C_, d, d, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=S.out2)
         M2 = B * T2 * F2
         ops.colsum(dout2, pe.conv[2].bias.grad, M2, C_)
-        col = self._buf("col", (M2, 9 * C_), cdt, dev)
-        ops.im2col(S.out1, col, B, T1, F1, C_)  # recomputed (cheaper than keeping 3 GB alive through the encoder)
+        col = S.col
+        if S.col_gen != self._col_gen:  # another forward has reused the workspace since: rebuild the image
+            ops.im2col(S.out1, col, B, T1, F1, C_)
+            self._col_gen += 1
         # d conv2.weight [co, ci, 3, 3]: batch over the 9 taps, column stride 9
         tiles = self._tiles(C_, C_, cdt == torch.bfloat16) * 9
         ops.gemm(dout2, col, pe.conv[2].weight.grad, C_, C_, M2, C_, 9 * C_, 9 * C_, transA=True, transB=True, atomic=True,
                  splitk=self._splitk(tiles, M2), batch=9, nb0=9, sB=(C_, 0), sC=(1, 0), c_col_stride=9, c_dtype=ops.F32)
-        dcol = col  # reuse: col is dead after the wgrad above (stream order)
+        dcol = self._buf("dcol", (M2, 9 * C_), cdt, dev)
         ops.gemm(dout2, W["pre.w2t"], dcol, M2, 9 * C_, C_, C_, W.pitch("pre.w2t"), 9 * C_)
         dout1 = self._buf("dout1", (B, T1, F1, C_), cdt, dev)
         ops.col2im_relu(dcol, S.out1, dout1, B, T1, F1, C_)
