@@ -205,71 +205,111 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, con
 }
 
 // y = swish(gamma * (x - mean) * rstd + beta)
+// thread = V consecutive channels (fixed for the whole kernel: the per-channel coefficients are loaded once) x a strided
+// set of rows
 template <typename TT>
 __global__ __launch_bounds__(256) void bn_swish_fwd_kernel(const TT* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, TT* __restrict__ y, long long M, int d) {
-  const long long nv = M * (d >> 2);
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
-    const long long m = i / (d >> 2);
-    const int c = (int)(i - m * (d >> 2)) * 4;
-    float v[4], mu[4], rs[4], g[4], b[4], o[4];
-    ld4(x + m * d + c, v); ld4(mean + c, mu); ld4(rstd + c, rs); ld4(gamma + c, g); ld4(beta + c, b);
+  constexpr int V = VecIO<TT>::V;
+  const int CP = min(d / V, 256), RS = 256 / CP;
+  const int ck = threadIdx.x % CP, rsub = threadIdx.x / CP;
+  if (rsub >= RS) return;
+  for (int c = ck * V; c < d; c += CP * V) {
+    float mu[V], rs[V], g[V], bt[V];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = swishf_(g[j] * (v[j] - mu[j]) * rs[j] + b[j]);
-    st4(y + m * d + c, o);
+    for (int j = 0; j < V; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; g[j] = gamma[c + j]; bt[j] = beta[c + j]; }
+    for (long long m = (long long)blockIdx.x * RS + rsub; m < M; m += (long long)gridDim.x * RS) {
+      float v[V], o[V];
+      VecIO<TT>::load(x + m * d + c, v);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = swishf_(g[j] * (v[j] - mu[j]) * rs[j] + bt[j]);
+      VecIO<TT>::store(y + m * d + c, o);
+    }
   }
 }
-// backward phase 1: sums[0][c] += sum dz, sums[1][c] += sum dz*xhat  with dz = dy * swish'(z)
+#define BNR_ROWS 128  // rows per workgroup
 template <typename TT>
 __global__ __launch_bounds__(256) void bn_swish_bwd_reduce_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   double* __restrict__ sums, long long M, int d) {
-  __shared__ float sa[4][64], sb[4][64];
-  const int c_l = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + c_l;
-  const long long r0 = (long long)blockIdx.y * 256, r1 = min(M, r0 + 256);
-  float a1 = 0.f, a2 = 0.f;
-  if (c < d) {
-    const float mu = mean[c], rs = rstd[c], g = gamma[c], bt = beta[c];
-    for (long long r = r0 + rl; r < r1; r += 4) {
-      const float xh = (ld(x + r * d + c) - mu) * rs;
-      const float dz = ld(dy + r * d + c) * swish_grad(g * xh + bt);
-      a1 += dz; a2 += dz * xh;
+  // thread = V consecutive channels (one 16-byte load per tensor per row) x every RS-th row of the workgroup's row block
+  constexpr int V = VecIO<TT>::V;
+  __shared__ float sred[2][256 * V];
+  const int CP = min(d / V, 256);          // channel chunks per pass
+  const int RS = 256 / CP;                 // rows in flight per pass
+  const int ck = threadIdx.x % CP, rsub = threadIdx.x / CP;
+  const long long r0 = (long long)blockIdx.y * BNR_ROWS, r1 = min(M, r0 + BNR_ROWS);
+  for (int c0 = blockIdx.x * CP * V; c0 < d; c0 += gridDim.x * CP * V) {
+    const int c = c0 + ck * V;
+    float a1[V], a2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+    if (rsub < RS && c < d) {
+      float mu[V], rs[V], g[V], bt[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; g[j] = gamma[c + j]; bt[j] = beta[c + j]; }
+#pragma unroll 4
+      for (long long r = r0 + rsub; r < r1; r += RS) {
+        float xv[V], dv[V];
+        VecIO<TT>::load(x + r * d + c, xv);
+        VecIO<TT>::load(dy + r * d + c, dv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float xh = (xv[j] - mu[j]) * rs[j];
+          const float dz = dv[j] * swish_grad(g[j] * xh + bt[j]);
+          a1[j] += dz; a2[j] += dz * xh;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sred[0][threadIdx.x * V + j] = a1[j]; sred[1][threadIdx.x * V + j] = a2[j]; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < CP * V; e += 256) {  // e = channel inside this pass
+      float t1 = 0.f, t2 = 0.f;
+      for (int q = 0; q < RS; ++q) { t1 += sred[0][q * CP * V + e]; t2 += sred[1][q * CP * V + e]; }
+      if (c0 + e < d) {
+        atomicAdd(sums + c0 + e, (double)t1);
+        atomicAdd(sums + d + c0 + e, (double)t2);
+      }
     }
   }
-  sa[rl][c_l] = a1; sb[rl][c_l] = a2;
-  __syncthreads();
-  if (rl == 0 && c < d) {
-    atomicAdd(sums + c, (double)((sa[0][c_l] + sa[1][c_l]) + (sa[2][c_l] + sa[3][c_l])));
-    atomicAdd(sums + d + c, (double)((sb[0][c_l] + sb[1][c_l]) + (sb[2][c_l] + sb[3][c_l])));
-  }
 }
-// backward phase 2: dx = gamma*rstd*(dz - [training] (S1/n + xhat*S2/n)) ; S = global sums (all ranks), n = global count
 template <typename TT>
 __global__ __launch_bounds__(256) void bn_swish_bwd_apply_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const double* __restrict__ sums, double count, int training,
                                                                  TT* __restrict__ dx, long long M, int d) {
-  const long long nv = M * (d >> 2);
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
-    const long long m = i / (d >> 2);
-    const int c = (int)(i - m * (d >> 2)) * 4;
-    float v[4], e[4], mu[4], rs[4], g[4], b[4], o[4];
-    ld4(x + m * d + c, v); ld4(dy + m * d + c, e); ld4(mean + c, mu); ld4(rstd + c, rs); ld4(gamma + c, g); ld4(beta + c, b);
+  constexpr int V = VecIO<TT>::V;
+  const int CP = min(d / V, 256), RS = 256 / CP;
+  const int ck = threadIdx.x % CP, rsub = threadIdx.x / CP;
+  if (rsub >= RS) return;
+  for (int c = ck * V; c < d; c += CP * V) {
+    float mu[V], rs[V], g[V], bt[V], k1[V], k2[V];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float xh = (v[j] - mu[j]) * rs[j];
-      float dz = e[j] * swish_grad(g[j] * xh + b[j]);
-      if (training) dz -= (float)(sums[c + j] / count) + xh * (float)(sums[d + c + j] / count);
-      o[j] = g[j] * rs[j] * dz;
+    for (int j = 0; j < V; ++j) {
+      mu[j] = mean[c + j]; rs[j] = rstd[c + j]; g[j] = gamma[c + j]; bt[j] = beta[c + j];
+      k1[j] = training ? (float)(sums[c + j] / count) : 0.f;
+      k2[j] = training ? (float)(sums[d + c + j] / count) : 0.f;
     }
-    st4(dx + m * d + c, o);
+    for (long long m = (long long)blockIdx.x * RS + rsub; m < M; m += (long long)gridDim.x * RS) {
+      float v[V], e[V], o[V];
+      VecIO<TT>::load(x + m * d + c, v);
+      VecIO<TT>::load(dy + m * d + c, e);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float xh = (v[j] - mu[j]) * rs[j];
+        float dz = e[j] * swish_grad(g[j] * xh + bt[j]);
+        dz -= k1[j] + xh * k2[j];
+        o[j] = g[j] * rs[j] * dz;
+      }
+      VecIO<TT>::store(dx + m * d + c, o);
+    }
   }
 }
-// dgamma += S2_local, dbeta += S1_local  (local sums: DDP averages parameter grads afterwards)
 __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int d) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d) return;
@@ -278,6 +318,13 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __r
 }
 
 // =================================================================================================
+// row-strided elementwise BN kernels: ~8 rows per thread
+static inline int bn_grid(long long M, int d, int dt) {
+  const int V = dt == MI_DT_BF16 ? 8 : 4;
+  const int CP = d / V < 256 ? d / V : 256, RS = 256 / CP;
+  long long g = (M + (long long)RS * 8 - 1) / ((long long)RS * 8);
+  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
 static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
 extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias, void* y, int dt, void* stats, int B, int T,
@@ -336,9 +383,9 @@ extern "C" int mi355x_bn_eval_stats(const void* running_mean, const void* runnin
 extern "C" int mi355x_bn_swish_fwd(const void* x, const void* mean, const void* rstd, const void* gamma, const void* beta, void* y,
                                    int dt, long long M, int d, void* stream) {
   mi_clear_errors();
-  if (!x || !mean || !rstd || !gamma || !beta || !y || M <= 0 || (d & 3)) return MI_ERR_ARG;
+  if (!x || !mean || !rstd || !gamma || !beta || !y || M <= 0 || d <= 0 || d % (dt == MI_DT_BF16 ? 8 : 4)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_fwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)x,
+  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_fwd_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256), 0, s, (const TT*)x,
                                          (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta, (TT*)y, M, d));
   return mi_check_launch();
 }
@@ -346,7 +393,9 @@ extern "C" int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const v
                                           const void* beta, void* sums, int dt, long long M, int d, void* stream) {
   mi_clear_errors();
   if (!dy || !x || !sums || M <= 0 || d <= 0) return MI_ERR_ARG;
-  dim3 grid((d + 63) / 64, (unsigned)((M + 255) / 256)), block(256);
+  const int V = dt == MI_DT_BF16 ? 8 : 4;
+  if (d % V) return MI_ERR_ARG;
+  dim3 grid(1, (unsigned)((M + BNR_ROWS - 1) / BNR_ROWS)), block(256);
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_bwd_reduce_kernel<TT>), grid, block, 0, s, (const TT*)dy, (const TT*)x,
                                          (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta,
@@ -357,9 +406,9 @@ extern "C" int mi355x_bn_swish_bwd_apply(const void* dy, const void* x, const vo
                                          const void* beta, const void* sums, double count, int training, void* dx, int dt,
                                          long long M, int d, void* stream) {
   mi_clear_errors();
-  if (!dy || !x || !sums || !dx || M <= 0 || (d & 3) || count <= 0) return MI_ERR_ARG;
+  if (!dy || !x || !sums || !dx || M <= 0 || d <= 0 || d % (dt == MI_DT_BF16 ? 8 : 4) || count <= 0) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_bwd_apply_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s,
+  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_bwd_apply_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256), 0, s,
                                          (const TT*)dy, (const TT*)x, (const float*)mean, (const float*)rstd, (const float*)gamma,
                                          (const float*)beta, (const double*)sums, count, training, (TT*)dx, M, d));
   return mi_check_launch();

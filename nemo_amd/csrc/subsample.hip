@@ -14,43 +14,64 @@
   if ((dt) == MI_DT_F32) { typedef float T; __VA_ARGS__; }           \
   else { typedef bf16_t T; __VA_ARGS__; }
 
-#define C1_FB 8  // f1 positions per block
 
 // ------------------------------------------------------------------------------------------------ conv1 forward
 // grid (ceil(F1/8), T1, B); 256 threads over channels
+#define C1_TR 4  // output rows (t1) per block
 template <typename TO>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ mel, const float* __restrict__ w,
                                                         const float* __restrict__ bias, TO* __restrict__ out,
                                                         const long long* __restrict__ len0, const long long* __restrict__ len1,
                                                         int B, int F, int T, int T1, int F1, int C) {
-  __shared__ float patch[3][2 * C1_FB + 1];
-  const int b = blockIdx.z, t1 = blockIdx.y, f1_0 = blockIdx.x * C1_FB;
-  const bool tvalid = t1 < len1[b];
-  const int nf = 2 * C1_FB + 1;
-  if (threadIdx.x < 3 * nf) {
-    const int kh = threadIdx.x / nf, fi = threadIdx.x - kh * nf;
-    const int t = 2 * t1 + kh - 1, f = 2 * f1_0 + fi - 1;
+  // thread = V consecutive output channels (one 16-byte store per (t1, f1); 2-byte stores run at a fraction of the HBM
+  // rate) x every 4th f1; the 9 x V weights stay in registers for the block's C1_TR output rows.
+  constexpr int V = VecIO<TO>::V;
+  extern __shared__ float patch[];  // [2*C1_TR + 1][F + 2]: mel rows 2*t1_0-1 .., freq shifted by +1, zero borders
+  const int FW = F + 2, NR = 2 * C1_TR + 1;
+  const int b = blockIdx.y, t1_0 = blockIdx.x * C1_TR;
+  const int tlim = (int)min((long long)T, len0[b]);
+  for (int i = threadIdx.x; i < NR * FW; i += 256) {
+    const int rr = i / FW, fi = i - rr * FW;
+    const int t = 2 * t1_0 - 1 + rr, f = fi - 1;
     float v = 0.f;
-    if (t >= 0 && t < T && t < len0[b] && f >= 0 && f < F) v = mel[((long long)b * F + f) * T + t];
-    patch[kh][fi] = v;
+    if (t >= 0 && t < tlim && f >= 0 && f < F) v = mel[((long long)b * F + f) * T + t];
+    patch[i] = v;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float wk[9];
+  const int CP = C / V;                       // channel chunks
+  const int FS = 256 / CP;                    // f1 positions in flight (the launcher enforces CP <= 256)
+  const int ck = threadIdx.x % CP, fs = threadIdx.x / CP;
+  if (fs >= FS) return;
+  const int l1 = (int)min((long long)T1, len1[b]);
+  {
+    const int c = ck * V;
+    float wk[9][V], bs[V];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
-    const float bs = bias[c];
+    for (int j = 0; j < V; ++j) {
+      bs[j] = bias[c + j];
 #pragma unroll
-    for (int j = 0; j < C1_FB; ++j) {
-      const int f1 = f1_0 + j;
-      if (f1 < F1) {
-        float a = bs;
+      for (int k = 0; k < 9; ++k) wk[k][j] = w[(c + j) * 9 + k];
+    }
+    for (int tr = 0; tr < C1_TR; ++tr) {
+      const int t1 = t1_0 + tr;
+      if (t1 >= T1) break;
+      const bool tvalid = t1 < l1;
+      const float* prow = patch + 2 * tr * FW;
+      for (int f1 = fs; f1 < F1; f1 += FS) {
+        float m[9];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) a = fmaf(wk[kh * 3 + kw], patch[kh][2 * j + kw], a);
-        a = (tvalid && a > 0.f) ? a : 0.f;
-        st(out + (((long long)b * T1 + t1) * F1 + f1) * C + c, a);
+          for (int kw = 0; kw < 3; ++kw) m[kh * 3 + kw] = prow[kh * FW + 2 * f1 + kw];
+        float o[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          float a = bs[j];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) a = fmaf(wk[k][j], m[k], a);
+          o[j] = (tvalid && a > 0.f) ? a : 0.f;
+        }
+        VecIO<TO>::store(out + (((long long)b * T1 + t1) * F1 + f1) * C + c, o);
       }
     }
   }
@@ -208,9 +229,12 @@ extern "C" int mi355x_subsample_conv1_fwd(const void* mel, const void* w, const 
   mi_clear_errors();
   if (!mel || !w || !bias || !out || !len0 || !len1 || B <= 0 || F <= 0 || T <= 0 || C <= 0) return MI_ERR_ARG;
   const int T1 = (T + 2 - 3) / 2 + 1, F1 = (F + 2 - 3) / 2 + 1;
-  dim3 grid((F1 + C1_FB - 1) / C1_FB, T1, B), block(256);
+  const int V = out_dt == MI_DT_BF16 ? 8 : 4;
+  if (C % V || C / V > 256) return MI_ERR_ARG;
+  dim3 grid((T1 + C1_TR - 1) / C1_TR, B), block(256);
+  const size_t shm = (size_t)(2 * C1_TR + 1) * (F + 2) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(out_dt, TO, hipLaunchKernelGGL((conv1_fwd_kernel<TO>), grid, block, 0, s, (const float*)mel, (const float*)w,
+  DISPATCH_DT(out_dt, TO, hipLaunchKernelGGL((conv1_fwd_kernel<TO>), grid, block, shm, s, (const float*)mel, (const float*)w,
                                              (const float*)bias, (TO*)out, (const long long*)len0, (const long long*)len1, B, F,
                                              T, T1, F1, C));
   return mi_check_launch();
