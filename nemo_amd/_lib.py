@@ -64,6 +64,7 @@ SIGNATURES = {
     "mi355x_drop_scale_cast": [vp, i32, vp, i32, i64, f32, u32, u32, f32, vp],
     "mi355x_qbias": [vp, i64, vp, vp, vp, vp, i32, i64, i32, vp],
     "mi355x_add2": [vp, vp, i32, vp, i32, i64, i64, i32, vp],
+    "mi355x_add2_colsum": [vp, vp, vp, i64, i64, i32, vp, vp, i64, vp],
     "mi355x_relpos_softmax_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_relpos_softmax_bwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_relpos_flash_fwd": [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
@@ -76,7 +77,7 @@ SIGNATURES = {
     "mi355x_bn_finalize": [vp, f64, vp, vp, vp, vp, f32, f32, i32, vp],
     "mi355x_bn_eval_stats": [vp, vp, vp, vp, f32, i32, vp],
     "mi355x_bn_swish_fwd": [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
-    "mi355x_bn_swish_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
+    "mi355x_bn_swish_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, i64, vp],
     "mi355x_bn_swish_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, f64, i32, vp, i32, i64, i32, vp],
     "mi355x_bn_param_grad": [vp, vp, vp, i32, vp],
     "mi355x_ctc_loss": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],

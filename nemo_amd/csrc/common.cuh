@@ -194,3 +194,22 @@ static __global__ __launch_bounds__(256) void tap_reduce_kernel(const float* __r
   if (k < KS) atomicAdd(dw + c * KS + k, acc);
   else if (dbias) atomicAdd(dbias + c, acc);
 }
+
+// Second stage of the two-stage column reductions: out[i] += sum_p partial[p*n + i]  (TOut = float or double);
+// grid (ceil(n/256), nsplit): nsplit-way atomics only.
+template <typename TOut>
+static __global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ partial, int nparts, int n,
+                                                                     TOut* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int per = (nparts + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = min(nparts, p0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int p = p0;
+  for (; p + 4 <= p1; p += 4) {
+    a0 += partial[(long long)(p + 0) * n + i]; a1 += partial[(long long)(p + 1) * n + i];
+    a2 += partial[(long long)(p + 2) * n + i]; a3 += partial[(long long)(p + 3) * n + i];
+  }
+  for (; p < p1; ++p) a0 += partial[(long long)p * n + i];
+  atomicAdd(out + i, (TOut)((a0 + a1) + (a2 + a3)));
+}

@@ -228,12 +228,13 @@ __global__ __launch_bounds__(256) void bn_swish_fwd_kernel(const TT* __restrict_
     }
   }
 }
-#define BNR_ROWS 128  // rows per workgroup
+#define BNR_ROWS 16  // rows per workgroup (1002 workgroups at the Large shape; partial sums go through a scratch slab)
 template <typename TT>
 __global__ __launch_bounds__(256) void bn_swish_bwd_reduce_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                  double* __restrict__ sums, long long M, int d) {
+                                                                  double* __restrict__ sums, float* __restrict__ partial,
+                                                                  long long M, int d) {
   // thread = V consecutive channels (one 16-byte load per tensor per row) x every RS-th row of the workgroup's row block
   constexpr int V = VecIO<TT>::V;
   __shared__ float sred[2][256 * V];
@@ -271,8 +272,13 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_reduce_kernel(const TT* __re
       float t1 = 0.f, t2 = 0.f;
       for (int q = 0; q < RS; ++q) { t1 += sred[0][q * CP * V + e]; t2 += sred[1][q * CP * V + e]; }
       if (c0 + e < d) {
-        atomicAdd(sums + c0 + e, (double)t1);
-        atomicAdd(sums + d + c0 + e, (double)t2);
+        if (partial) {
+          partial[((long long)blockIdx.y * 2 + 0) * d + c0 + e] = t1;
+          partial[((long long)blockIdx.y * 2 + 1) * d + c0 + e] = t2;
+        } else {
+          atomicAdd(sums + c0 + e, (double)t1);
+          atomicAdd(sums + d + c0 + e, (double)t2);
+        }
       }
     }
   }
@@ -318,12 +324,12 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __r
 }
 
 // =================================================================================================
-// row-strided elementwise BN kernels: ~8 rows per thread
+// row-strided elementwise BN kernels: ~2 rows per thread (these streams only reach the HBM rate at high occupancy)
 static inline int bn_grid(long long M, int d, int dt) {
   const int V = dt == MI_DT_BF16 ? 8 : 4;
   const int CP = d / V < 256 ? d / V : 256, RS = 256 / CP;
-  long long g = (M + (long long)RS * 8 - 1) / ((long long)RS * 8);
-  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+  long long g = (M + (long long)RS * 2 - 1) / ((long long)RS * 2);
+  return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
 }
 static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
@@ -390,16 +396,22 @@ extern "C" int mi355x_bn_swish_fwd(const void* x, const void* mean, const void* 
   return mi_check_launch();
 }
 extern "C" int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
-                                          const void* beta, void* sums, int dt, long long M, int d, void* stream) {
+                                          const void* beta, void* sums, int dt, long long M, int d, void* scratch,
+                                          long long scratch_elems, void* stream) {
   mi_clear_errors();
   if (!dy || !x || !sums || M <= 0 || d <= 0) return MI_ERR_ARG;
   const int V = dt == MI_DT_BF16 ? 8 : 4;
   if (d % V) return MI_ERR_ARG;
-  dim3 grid(1, (unsigned)((M + BNR_ROWS - 1) / BNR_ROWS)), block(256);
+  const unsigned nblk = (unsigned)((M + BNR_ROWS - 1) / BNR_ROWS);
+  if (scratch && scratch_elems < (long long)nblk * 2 * d) return MI_ERR_ARG;
+  dim3 grid(1, nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_bwd_reduce_kernel<TT>), grid, block, 0, s, (const TT*)dy, (const TT*)x,
                                          (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta,
-                                         (double*)sums, M, d));
+                                         (double*)sums, (float*)scratch, M, d));
+  if (scratch)
+    hipLaunchKernelGGL((partials_reduce_kernel<double>), dim3((2 * d + 255) / 256, 8), dim3(256), 0, s, (const float*)scratch,
+                       (int)nblk, 2 * d, (double*)sums);
   return mi_check_launch();
 }
 extern "C" int mi355x_bn_swish_bwd_apply(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,

@@ -241,6 +241,60 @@ extern "C" int mi355x_qbias(const void* qkv, long long ldq, const void* u, const
                                          (const float*)u, (const float*)v, (TT*)qu, (TT*)qv, M, d));
   return mi_check_launch();
 }
+// out[m, 0:d] = a + b (row pitch ldo) and the column sums of a and of b in the same pass (dq = dqu + dqv together with the
+// pos_bias_u / pos_bias_v gradients, multi_head_attention.py:288-291).  Thread = 8 channels x every 4th row of a 16-row
+// block; per-block column sums go to a scratch slab and partials_reduce_kernel adds the slabs (no same-address atomics).
+#define A2C_ROWS 16
+__global__ __launch_bounds__(256) void add2_colsum_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                          bf16_t* __restrict__ out, long long ldo, long long M, int d,
+                                                          float* __restrict__ partial) {
+  __shared__ float sred[2][256 * 8];
+  const int CP = min(d / 8, 256), RS = 256 / CP;
+  const int ck = threadIdx.x % CP, rsub = threadIdx.x / CP;
+  const long long r0 = (long long)blockIdx.x * A2C_ROWS, r1 = min(M, r0 + A2C_ROWS);
+  for (int c0 = 0; c0 < d; c0 += CP * 8) {
+    const int c = c0 + ck * 8;
+    float sa[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sa[j] = 0.f; sb[j] = 0.f; }
+    if (rsub < RS && c < d) {
+#pragma unroll 4
+      for (long long r = r0 + rsub; r < r1; r += RS) {
+        float x[8], y[8];
+        VecIO<bf16_t>::load(a + r * d + c, x);
+        VecIO<bf16_t>::load(b + r * d + c, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sa[j] += x[j]; sb[j] += y[j]; x[j] += y[j]; }
+        VecIO<bf16_t>::store(out + r * ldo + c, x);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sred[0][threadIdx.x * 8 + j] = sa[j]; sred[1][threadIdx.x * 8 + j] = sb[j]; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < CP * 8; e += 256) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int q = 0; q < RS; ++q) { t1 += sred[0][q * CP * 8 + e]; t2 += sred[1][q * CP * 8 + e]; }
+      if (c0 + e < d) {
+        partial[((long long)blockIdx.x * 2 + 0) * d + c0 + e] = t1;
+        partial[((long long)blockIdx.x * 2 + 1) * d + c0 + e] = t2;
+      }
+    }
+  }
+}
+extern "C" int mi355x_add2_colsum(const void* a, const void* b, void* out, long long ldo, long long M, int d, void* sum_ab,
+                                  void* scratch, long long scratch_elems, void* stream) {
+  mi_clear_errors();
+  if (!a || !b || !out || !sum_ab || !scratch || M <= 0 || d <= 0 || (d & 7) || (ldo & 7)) return MI_ERR_ARG;
+  const int nblk = (int)((M + A2C_ROWS - 1) / A2C_ROWS);
+  if (scratch_elems < (long long)nblk * 2 * d) return MI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(add2_colsum_kernel, dim3(nblk), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, ldo, M,
+                     d, (float*)scratch);
+  hipLaunchKernelGGL((partials_reduce_kernel<float>), dim3((2 * d + 255) / 256, 8), dim3(256), 0, s, (const float*)scratch, nblk,
+                     2 * d, (float*)sum_ab);
+  return mi_check_launch();
+}
 extern "C" int mi355x_add2(const void* a, const void* b, int in_dt, void* out, int out_dt, long long ldo, long long M, int d,
                            void* stream) {
   mi_clear_errors();

@@ -17,8 +17,12 @@ ALIGN = 64  # elements; keeps every parameter 256-B aligned for the 16-B vector 
 
 
 class FlatParams:
-    def __init__(self, module: nn.Module):
+    def __init__(self, module: nn.Module, tail=None):
+        """`tail(name) -> bool` selects parameters that are laid out AFTER all others, contiguously in module order
+        (e.g. one equally-shaped weight per layer whose gradients are produced by one batched GEMM at the end of
+        backward); `range_of` ignores them, `tail_range` covers them."""
         self.module = module
+        self._tail = tail or (lambda name: False)
         self.flat: torch.Tensor = None
         self.grad: torch.Tensor = None
         self.offsets: Dict[str, Tuple[int, int]] = {}
@@ -26,7 +30,8 @@ class FlatParams:
         self.generation = 0  # bumped on every (re)build: dependants (packed weight plans, optimizer state) key on it
 
     def _params(self):
-        return [(n, p) for n, p in self.module.named_parameters() if p.dtype == torch.float32]
+        ps = [(n, p) for n, p in self.module.named_parameters() if p.dtype == torch.float32]
+        return [x for x in ps if not self._tail(x[0])] + [x for x in ps if self._tail(x[0])]
 
     def is_valid(self) -> bool:
         if self.flat is None:
@@ -72,9 +77,17 @@ class FlatParams:
 
     def range_of(self, prefix: str) -> Tuple[int, int]:
         """[start, end) element range (aligned) covering every parameter whose name starts with `prefix`."""
-        names = [n for n in self.order if n.startswith(prefix)]
+        names = [n for n in self.order if n.startswith(prefix) and not self._tail(n)]
         if not names:
             raise KeyError(prefix)
+        start = min(self.offsets[n][0] for n in names)
+        end = max((self.offsets[n][0] + self.offsets[n][1] + ALIGN - 1) // ALIGN * ALIGN for n in names)
+        return start, end
+
+    def tail_range(self) -> Tuple[int, int]:
+        names = [n for n in self.order if self._tail(n)]
+        if not names:
+            return 0, 0
         start = min(self.offsets[n][0] for n in names)
         end = max((self.offsets[n][0] + self.offsets[n][1] + ALIGN - 1) // ALIGN * ALIGN for n in names)
         return start, end

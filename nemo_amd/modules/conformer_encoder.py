@@ -196,7 +196,8 @@ class ConformerEncoder(NeuralModule):
         self.use_flash_attention = True  # bf16 + d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
         self.grad_ready_hook = None  # callable(start, end) on the flat gradient buffer (data-parallel bucketing)
         # --- engine state (not part of the state-dict)
-        self._flatp = FlatParams(self)
+        # linear_pos weights of all layers sit together at the tail: their gradients come from ONE batched GEMM
+        self._flatp = FlatParams(self, tail=lambda n: n.endswith("self_attn.linear_pos.weight"))
         self._plans = {}
         self._ws = {}
         self._pos_cache = {}
@@ -380,6 +381,7 @@ class ConformerEncoder(NeuralModule):
             ops.drop_scale_cast(pos, posd, pos.numel(), 1.0, d_emb)
             pos = posd
         S.pos = pos
+        S.p_all = self._pos_proj_fwd(pos, W, cdt, dev)
         S.layers = []
         for i, L in enumerate(self.layers):
             x, sl = self._layer_fwd(i, L, x, S, W, Wf, drop)
@@ -408,6 +410,37 @@ class ConformerEncoder(NeuralModule):
         setattr(sl, tag, (x, y, mean, rstd, h, a, d_in, d_res))
         return r
 
+    def _pos_proj_fwd(self, pos, W, cdt, dev):
+        """p_l = linear_pos_l(pos_emb) for all layers (multi_head_attention.py:309): the input is the same table, so the
+        18 [2T-1, d] x [d, d] products are one batched GEMM (288 tiles) instead of 18 launches of 16 tiles."""
+        nl, d = self.n_layers, self.d_model
+        P = pos.shape[0]
+        p_all = torch.empty(nl, P, d, dtype=cdt, device=dev)
+        es = W["L0.att.wpos"].element_size()
+        stride = (W["L1.att.wpos"].data_ptr() - W["L0.att.wpos"].data_ptr()) // es if nl > 1 else 0
+        uniform = all(W[f"L{i}.att.wpos"].data_ptr() - W["L0.att.wpos"].data_ptr() == i * stride * es for i in range(nl))
+        if uniform and stride >= 0:
+            ops.gemm(pos, W["L0.att.wpos"], p_all, P, d, d, d, W.pitch("L0.att.wpos"), d, batch=nl, nb0=nl,
+                     sB=(stride, 0), sC=(P * d, 0))
+        else:
+            for i in range(nl):
+                ops.gemm(pos, W[f"L{i}.att.wpos"], p_all[i], P, d, d, d, W.pitch(f"L{i}.att.wpos"), d)
+        return p_all
+
+    def _pos_proj_wgrad(self, dp_all, pos, P, cdt):
+        """d linear_pos_l.weight += dp_l^T @ pos_emb for all layers: one batched TN GEMM into the tail of the flat
+        gradient buffer (FlatParams(tail=...) keeps the 18 gradients equally spaced)."""
+        nl, d = self.n_layers, self.d_model
+        grads = [L.self_attn.linear_pos.weight.grad for L in self.layers]
+        stride = (grads[1].data_ptr() - grads[0].data_ptr()) // 4 if nl > 1 else 0
+        uniform = all(g.data_ptr() - grads[0].data_ptr() == i * stride * 4 for i, g in enumerate(grads))
+        if uniform and stride >= 0:
+            ops.gemm(dp_all, pos, grads[0], d, d, P, d, d, d, transA=True, transB=True, atomic=True, batch=nl, nb0=nl,
+                     sA=(P * d, 0), sC=(stride, 0), c_dtype=ops.F32)
+        else:
+            for i in range(nl):
+                self._wgrad(dp_all[i], d, 0, pos, d, 0, grads[i], d, d, P)
+
     def _layer_fwd(self, i, L, x, S, W, Wf, drop):
         B, F_, T, T1, F1, T2, F2, M, cdt, training, seed = S.dims
         dev = x.device
@@ -423,8 +456,7 @@ class ConformerEncoder(NeuralModule):
         y2, mean2, rstd2 = self._ln_fwd(L.norm_self_att, r1, M, d, cdt, dev)
         qkv = torch.empty(M, 3 * d, dtype=cdt, device=dev)
         ops.gemm(y2, W[f"L{i}.att.wqkv"], qkv, M, 3 * d, d, d, W.pitch(f"L{i}.att.wqkv"), 3 * d, bias=Wf[f"L{i}.att.bqkv"])
-        p = torch.empty(P, d, dtype=cdt, device=dev)
-        ops.gemm(S.pos, W[f"L{i}.att.wpos"], p, P, d, d, d, W.pitch(f"L{i}.att.wpos"), d)
+        p = S.p_all[i]  # linear_pos(pos_emb) of every layer was computed by one batched GEMM (same input, 18 weights)
         d_att = drop(self.dropout_att, site + 2)
         ctx = torch.empty(M, d, dtype=cdt, device=dev)
         flash = self.use_flash_attention and cdt == torch.bfloat16 and dk == 64
@@ -510,11 +542,16 @@ class ConformerEncoder(NeuralModule):
         W, Wf = self._plan(cdt, dev)
         fp = self._flatp
         dx = dout.transpose(1, 2).contiguous().view(M, d).to(torch.float32)  # no copy when dout is a [B,T,d] view
+        P = 2 * T2 - 1
+        S.dp_all = self._buf("dp_all", (self.n_layers, P, d), cdt, dev)
         for i in range(self.n_layers - 1, -1, -1):
             dx = self._layer_bwd(i, self.layers[i], dx, S, S.layers[i], W, Wf)
             S.layers[i] = None
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook(*fp.range_of(f"layers.{i}."))
+        self._pos_proj_wgrad(S.dp_all, S.pos, P, cdt)
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(*fp.tail_range())
         # ---- sub-sampling backward
         pe = self.pre_encode
         dxs = torch.empty(M, d, dtype=cdt, device=dev)
@@ -645,12 +682,14 @@ class ConformerEncoder(NeuralModule):
             tiles = self._tiles(P, dk, cdt == torch.bfloat16) * H
             ops.gemm(dbdf, qv, dp, P, dk, B * T2, Pp, d, d, transA=True, transB=True, atomic=True,
                      splitk=self._splitk(tiles, B * T2), batch=H, nb0=H, sA=(B * T2 * Pp, 0), sB=(dk, 0), sC=(dk, 0))
-        dpc = torch.empty(P, d, dtype=cdt, device=dev)
-        ops.drop_scale_cast(dp, dpc, P * d, 1.0)
-        self._wgrad(dpc, d, 0, S.pos, d, 0, a.linear_pos.weight.grad, d, d, P)
-        ops.colsum(dqu, a.pos_bias_u.grad, M, d)
-        ops.colsum(dqv, a.pos_bias_v.grad, M, d)
-        ops.add2(dqu, dqv, dqkv, 3 * d, M, d)
+        ops.drop_scale_cast(dp, S.dp_all[i], P * d, 1.0)  # linear_pos weight gradients: one batched GEMM after the loop
+        gu, gv_ = a.pos_bias_u.grad, a.pos_bias_v.grad
+        if cdt == torch.bfloat16 and gv_.data_ptr() - gu.data_ptr() == 4 * d:
+            ops.add2_colsum(dqu, dqv, dqkv, 3 * d, M, d, gu)  # dq = dqu + dqv and both bias gradients in one pass
+        else:
+            ops.colsum(dqu, gu, M, d)
+            ops.colsum(dqv, gv_, M, d)
+            ops.add2(dqu, dqv, dqkv, 3 * d, M, d)
         gq, gk, gv = a.linear_q.weight.grad, a.linear_k.weight.grad, a.linear_v.weight.grad
         sw = (gk.data_ptr() - gq.data_ptr()) // 4
         sb = (a.linear_k.bias.grad.data_ptr() - a.linear_q.bias.grad.data_ptr()) // 4

@@ -191,6 +191,13 @@ def qbias(qkv, ldq, u, v, qu, qv, M, d):
     check(lib.mi355x_qbias(_ptr(qkv), ldq, _ptr(u), _ptr(v), _ptr(qu), _ptr(qv), dt(qkv), M, d, _stream()), "qbias")
 
 
+def add2_colsum(a, b, out, ldo, M, d, sum_ab):
+    """out[:, :d] = a + b; sum_ab[0:d] += colsum(a), sum_ab[d:2d] += colsum(b)   (bf16 in/out, f32 sums)"""
+    n = ((M + 15) // 16) * 2 * d
+    sc = _scratch("add2_colsum", n, a.device)
+    check(lib.mi355x_add2_colsum(_ptr(a), _ptr(b), _ptr(out), ldo, M, d, _ptr(sum_ab), _ptr(sc), n, _stream()), "add2_colsum")
+
+
 def add2(a, b, out, ldo, M, d, out_off=0):
     check(lib.mi355x_add2(_ptr(a), _ptr(b), dt(a), _ptr(out) + out_off * out.element_size(), dt(out), ldo, M, d, _stream()),
           "add2")
@@ -283,8 +290,10 @@ def bn_swish_fwd(x, mean, rstd, gamma, beta, y, M, d):
 
 
 def bn_swish_bwd_reduce(dy, x, mean, rstd, gamma, beta, sums, M, d):
+    n = ((M + 15) // 16) * 2 * d
+    sc = _scratch("bn_swish_bwd_reduce", n, dy.device)
     check(lib.mi355x_bn_swish_bwd_reduce(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums), dt(x),
-                                         M, d, _stream()), "bn_swish_bwd_reduce")
+                                         M, d, _ptr(sc), n, _stream()), "bn_swish_bwd_reduce")
 
 
 def bn_swish_bwd_apply(dy, x, mean, rstd, gamma, beta, sums, count, training, dx, M, d):

@@ -219,6 +219,22 @@ def test_colsum_logsoftmax():
     assert torch.all(dx[:, C_:] == 0)
 
 
+@pytest.mark.parametrize("M,d", [(700, 64), (1003, 512), (130, 176)])
+def test_add2_colsum(M, d):
+    """dq = dqu + dqv fused with the pos_bias_u / pos_bias_v gradients (multi_head_attention.py:288-291)"""
+    o = ops()
+    g = torch.Generator().manual_seed(11)
+    a = bf(torch.randn(M, d, generator=g)); b = bf(torch.randn(M, d, generator=g))
+    out = torch.full((M, 3 * d), float("nan"), device=dev, dtype=torch.bfloat16)
+    sums = torch.ones(2 * d, device=dev)
+    o.add2_colsum(a.to(dev), b.to(dev), out, 3 * d, M, d, sums)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :d].float().cpu(), bf(a.float() + b.float()).float())
+    assert torch.isnan(out[:, d:].float()).all()
+    assert rel_err(sums[:d], 1 + a.float().sum(0)) < 1e-5
+    assert rel_err(sums[d:], 1 + b.float().sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_glu(dtype):
     o = ops()
