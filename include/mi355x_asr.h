@@ -114,7 +114,7 @@ int mi355x_add2(const void* a, const void* b, int in_dtype, void* out, int out_d
 /* out[m, 0:d] = a + b (bf16, row pitch ldo) and, in the same pass, sum_ab[0:d] += column sums of a, sum_ab[d:2d] +=
  * column sums of b (f32).  Used for dq = dqu + dqv with the pos_bias_u / pos_bias_v gradients
  * (multi_head_attention.py:288-291): pos_bias_u.grad and pos_bias_v.grad must be adjacent ([2, d]).
- * scratch: f32 [ceil(M/16) * 2 * d] (two-stage reduction, no same-address atomics). */
+ * scratch: f32 [ceil(M/32) * 2 * d] (two-stage reduction, no same-address atomics). */
 int mi355x_add2_colsum(const void* a, const void* b, void* out, long long ldo, long long M, int d, void* sum_ab, void* scratch,
                        long long scratch_elems, void* stream);
 /* ac f32 [H,B,T,Tp], bdf f32 [H,B,T,Pp] (bd before rel_shift) -> s (softmax, masked) and pd = dropout(s), pitch Tp   */
@@ -169,7 +169,7 @@ int mi355x_bn_swish_fwd(const void* x, const void* mean, const void* rstd, const
                         int dtype, long long M, int d, void* stream);
 int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
                                const void* beta, void* sums /*f64 [2,d] +=*/, int dtype, long long M, int d,
-                               void* scratch /* optional f32 [ceil(M/16)*2*d]: two-stage reduction */, long long scratch_elems,
+                               void* scratch /* optional f32 [ceil(M/32)*2*d]: two-stage reduction */, long long scratch_elems,
                                void* stream);
 int mi355x_bn_swish_bwd_apply(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
                               const void* beta, const void* sums, double count, int training, void* dx, int dtype,

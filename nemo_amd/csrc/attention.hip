@@ -82,7 +82,9 @@ __device__ __forceinline__ void stage_rows(const bf16_t* base, long long ld, int
       const int gck = ck ^ ((r >> 1) & 7);
       int gr = row0 + r;
       gr = gr < 0 ? 0 : (gr > rmax ? rmax : gr);
-      const bf16_t* src = base + (long long)gr * ld + gck * 8;
+      // rows and pitches are far below 2^24 (the batch offset is in `base`): one full-rate 24-bit multiply instead of the
+      // 64-bit sequence (2 quarter-rate v_mul_lo_u32 + v_mad_u64_u32) per address
+      const bf16_t* src = base + __mul24(gr, (int)ld) + gck * 8;
       bf16_t* dst = lds + (q0 + wave * 64) * 8;
       __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
     }
@@ -96,7 +98,7 @@ __device__ __forceinline__ void stage_v(const bf16_t* base, long long ld, int ro
   const int c = cp ^ ((k & 3) << 1);
   int gr = row0 + k;
   gr = gr > rmax ? rmax : gr;
-  const bf16_t* src = base + (long long)gr * ld + c * 8;
+  const bf16_t* src = base + __mul24(gr, (int)ld) + c * 8;
   bf16_t* dst = lds + (wave * 64) * 8;
   __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
 }
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // dS = P * (dropmask * dP - delta) * scale
-    uint32_t seed_g = 0u;
+    uint32_t seed_g = 0u;  // (kept in this per-element form: the kernel sits at 256 VGPRs and the grouped form spills)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float dm = 1.f;
@@ -573,9 +575,14 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
       }
     }
     float pd[16], ds[16];
-    uint32_t seed_g = 0u;
+    float dm4[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      if ((r & 3) == 0 && drop.threshold != 0u) {  // registers 4g..4g+3 = queries 4*bi .. 4*bi+3 against this lane's key
+        const uint32_t seed = adrop_seed(acol ^ adrop_rcode((uint32_t)(i0 >> 2) + 2 * (r >> 2) + lh)) + ecol;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dm4[c] = adrop_elem(drop, seed + c * (4u * ADROP_G));
+      }
       const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;  // query row of this register
       const int sl = 31 + q - rho;                      // column of G that holds c(i, j)
       const float g0 = __shfl(acc_g[0][r], lh * 32 + (sl & 31), 64);
@@ -584,11 +591,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
       const int ii = i0 + rho;
       const bool ok = kvalid && ii < L;
       const float p = ok ? __expf((acc_s[r] + bd) * scale - s_lse[rho]) : 0.f;
-      float dm = 1.f;
-      if (drop.threshold != 0u) {
-        if ((r & 3) == 0) seed_g = adrop_seed(acol ^ adrop_rcode((uint32_t)(i0 >> 2) + 2 * (r >> 2) + lh)) + ecol;
-        dm = adrop_elem(drop, seed_g + (r & 3) * (4u * ADROP_G));
-      }
+      const float dm = dm4[r & 3];
       pd[r] = p * dm;
       ds[r] = p * (acc_dp[r] * dm - s_dlt[rho]) * scale;
     }
@@ -662,9 +665,10 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
   const int npairs = it_hi - it_lo;
   const int nitems = (b_end - b_begin) * npairs;
   // 6 LDS-DMA instructions per item (2 KB of dS + 4 KB of Qv); issued one item ahead, waited with a counted vmcnt
-  auto issue = [&](int item, int buf) {
-    const int b = b_begin + item / npairs;
-    const int it = it_lo + item % npairs, jt = it + delta_t;
+  // (utterance, tile) of an item advance incrementally (4 items per step: one per wave) -- no integer divisions, and all
+  // address products fit 24-bit multiplies (batch / head offsets are folded into 64-bit bases once per item)
+  auto issue = [&](int b, int it, int buf) {
+    const int jt = it + delta_t;
     const bf16_t* base = ds_g + (((long long)h * B + b) * T) * Tp + 32 * jt;
     bf16_t* sds = s_ds[wave][buf];
     bf16_t* sqv = s_qv[wave][buf];
@@ -673,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
       const int cq = k2 * 64 + lane;
       int gr = 32 * it + (cq >> 2);
       gr = gr > T - 1 ? T - 1 : gr;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(base + (long long)gr * Tp + (cq & 3) * 8), (lds_void_t*)(sds + k2 * 512),
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(base + __mul24(gr, Tp) + (cq & 3) * 8), (lds_void_t*)(sds + k2 * 512),
                                        16, 0, 0);
     }
     const bf16_t* qb = qv_g + ((long long)b * T) * d + h * ADK;
@@ -683,17 +687,27 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
       const int r = cq >> 3, ck = cq & 7;
       int gr = 32 * it + r;
       gr = gr > T - 1 ? T - 1 : gr;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(qb + (long long)gr * d + ((ck ^ ((r >> 1) & 7)) << 3)),
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(qb + __mul24(gr, d) + ((ck ^ ((r >> 1) & 7)) << 3)),
                                        (lds_void_t*)(sqv + k4 * 512), 16, 0, 0);
     }
   };
-  if (wave < nitems) issue(wave, 0);
+  auto advance = [&](int& b, int& it, int steps) {  // steps <= 4 < npairs is not guaranteed: loop
+    it += steps;
+    while (it >= it_hi) { it -= npairs; ++b; }
+  };
+  int cb = b_begin, cit = it_lo;      // item being computed by this wave
+  advance(cb, cit, wave);
+  int nb = cb, nit = cit;             // item being prefetched
+  if (wave < nitems) issue(cb, cit, 0);
   int buf = 0;
-  for (int item = wave; item < nitems; item += 4, buf ^= 1) {
-    if (item + 4 < nitems) { issue(item + 4, buf ^ 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int b = b_begin + item / npairs;
-    const int it = it_lo + item % npairs, jt = it + delta_t;
+  for (int item = wave; item < nitems; item += 4, buf ^= 1, advance(cb, cit, 4)) {
+    if (item + 4 < nitems) {
+      nb = cb; nit = cit; advance(nb, nit, 4);
+      issue(nb, nit, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int b = cb;
+    const int it = cit, jt = it + delta_t;
     const int L = (int)min((long long)T, len[b]);
     if (32 * it >= L || 32 * jt >= L) continue;  // wave-uniform: tiles the dQ kernel never produced (data ignored)
     const bf16_t* sds = s_ds[wave][buf];

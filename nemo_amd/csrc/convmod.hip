@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void bn_swish_fwd_kernel(const TT* __restrict_
     }
   }
 }
-#define BNR_ROWS 16  // rows per workgroup (1002 workgroups at the Large shape; partial sums go through a scratch slab)
+#define BNR_ROWS 32  // rows per workgroup (501 workgroups at the Large shape; partial sums go through a scratch slab)
 template <typename TT>
 __global__ __launch_bounds__(256) void bn_swish_bwd_reduce_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -289,7 +289,17 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_apply_kernel(const TT* __res
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const double* __restrict__ sums, double count, int training,
                                                                  TT* __restrict__ dx, long long M, int d) {
+  // per-channel coefficients are built once per workgroup in LDS (the f64 mean-of-sums included), so a thread's set-up is
+  // six 16/32-byte LDS reads however few rows it handles
   constexpr int V = VecIO<TT>::V;
+  extern __shared__ float coef[];  // [6][d]: mean, rstd, gamma, beta, k1 = sum(dz)/n, k2 = sum(dz*xhat)/n
+  const double inv_count = 1.0 / count;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    coef[c] = mean[c]; coef[d + c] = rstd[c]; coef[2 * d + c] = gamma[c]; coef[3 * d + c] = beta[c];
+    coef[4 * d + c] = training ? (float)(sums[c] * inv_count) : 0.f;
+    coef[5 * d + c] = training ? (float)(sums[d + c] * inv_count) : 0.f;
+  }
+  __syncthreads();
   const int CP = min(d / V, 256), RS = 256 / CP;
   const int ck = threadIdx.x % CP, rsub = threadIdx.x / CP;
   if (rsub >= RS) return;
@@ -297,10 +307,10 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_apply_kernel(const TT* __res
     float mu[V], rs[V], g[V], bt[V], k1[V], k2[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      mu[j] = mean[c + j]; rs[j] = rstd[c + j]; g[j] = gamma[c + j]; bt[j] = beta[c + j];
-      k1[j] = training ? (float)(sums[c + j] / count) : 0.f;
-      k2[j] = training ? (float)(sums[d + c + j] / count) : 0.f;
+      mu[j] = coef[c + j]; rs[j] = coef[d + c + j]; g[j] = coef[2 * d + c + j]; bt[j] = coef[3 * d + c + j];
+      k1[j] = coef[4 * d + c + j]; k2[j] = coef[5 * d + c + j];
     }
+#pragma unroll 2
     for (long long m = (long long)blockIdx.x * RS + rsub; m < M; m += (long long)gridDim.x * RS) {
       float v[V], e[V], o[V];
       VecIO<TT>::load(x + m * d + c, v);
@@ -324,7 +334,7 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __r
 }
 
 // =================================================================================================
-// row-strided elementwise BN kernels: ~2 rows per thread (these streams only reach the HBM rate at high occupancy)
+// row-strided elementwise BN kernels: ~2 rows per thread
 static inline int bn_grid(long long M, int d, int dt) {
   const int V = dt == MI_DT_BF16 ? 8 : 4;
   const int CP = d / V < 256 ? d / V : 256, RS = 256 / CP;
@@ -410,7 +420,7 @@ extern "C" int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const v
                                          (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta,
                                          (double*)sums, (float*)scratch, M, d));
   if (scratch)
-    hipLaunchKernelGGL((partials_reduce_kernel<double>), dim3((2 * d + 255) / 256, 8), dim3(256), 0, s, (const float*)scratch,
+    hipLaunchKernelGGL((partials_reduce_kernel<double>), dim3((2 * d + 255) / 256, 32), dim3(256), 0, s, (const float*)scratch,
                        (int)nblk, 2 * d, (double*)sums);
   return mi_check_launch();
 }
@@ -420,7 +430,9 @@ extern "C" int mi355x_bn_swish_bwd_apply(const void* dy, const void* x, const vo
   mi_clear_errors();
   if (!dy || !x || !sums || !dx || M <= 0 || d <= 0 || d % (dt == MI_DT_BF16 ? 8 : 4) || count <= 0) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_bwd_apply_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256), 0, s,
+  if ((size_t)d * 6 * sizeof(float) > 64 * 1024) return MI_ERR_ARG;
+  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_bwd_apply_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256),
+                                         (size_t)d * 6 * sizeof(float), s,
                                          (const TT*)dy, (const TT*)x, (const float*)mean, (const float*)rstd, (const float*)gamma,
                                          (const float*)beta, (const double*)sums, count, training, (TT*)dx, M, d));
   return mi_check_launch();

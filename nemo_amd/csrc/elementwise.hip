@@ -242,9 +242,9 @@ extern "C" int mi355x_qbias(const void* qkv, long long ldq, const void* u, const
   return mi_check_launch();
 }
 // out[m, 0:d] = a + b (row pitch ldo) and the column sums of a and of b in the same pass (dq = dqu + dqv together with the
-// pos_bias_u / pos_bias_v gradients, multi_head_attention.py:288-291).  Thread = 8 channels x every 4th row of a 16-row
+// pos_bias_u / pos_bias_v gradients, multi_head_attention.py:288-291).  Thread = 8 channels x every 4th row of a 32-row
 // block; per-block column sums go to a scratch slab and partials_reduce_kernel adds the slabs (no same-address atomics).
-#define A2C_ROWS 16
+#define A2C_ROWS 32
 __global__ __launch_bounds__(256) void add2_colsum_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                           bf16_t* __restrict__ out, long long ldo, long long M, int d,
                                                           float* __restrict__ partial) {
@@ -291,7 +291,7 @@ extern "C" int mi355x_add2_colsum(const void* a, const void* b, void* out, long 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(add2_colsum_kernel, dim3(nblk), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, ldo, M,
                      d, (float*)scratch);
-  hipLaunchKernelGGL((partials_reduce_kernel<float>), dim3((2 * d + 255) / 256, 8), dim3(256), 0, s, (const float*)scratch, nblk,
+  hipLaunchKernelGGL((partials_reduce_kernel<float>), dim3((2 * d + 255) / 256, 32), dim3(256), 0, s, (const float*)scratch, nblk,
                      2 * d, (float*)sum_ab);
   return mi_check_launch();
 }

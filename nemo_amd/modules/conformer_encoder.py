@@ -382,10 +382,14 @@ class ConformerEncoder(NeuralModule):
             pos = posd
         S.pos = pos
         S.p_all = self._pos_proj_fwd(pos, W, cdt, dev)
+        # per-layer f64 BatchNorm sums: one allocation + one fill for all layers (18 tiny fill launches otherwise)
+        S.bn_stats = torch.zeros(self.n_layers, 2, d, dtype=torch.float64, device=dev) if training else None
         S.layers = []
         for i, L in enumerate(self.layers):
             x, sl = self._layer_fwd(i, L, x, S, W, Wf, drop)
             S.layers.append(sl)
+        if training:  # nn.BatchNorm1d bookkeeping, one multi-tensor launch
+            torch._foreach_add_([L.conv.batch_norm.num_batches_tracked for L in self.layers], 1)
         out = x.view(B, T2, d).transpose(1, 2)
         return out, len2, (S if save else None)
 
@@ -504,11 +508,10 @@ class ConformerEncoder(NeuralModule):
         brstd = torch.empty(d, dtype=torch.float32, device=dev)
         count = float(M)
         if training:
-            stats = torch.zeros(2, d, dtype=torch.float64, device=dev)
+            stats = S.bn_stats[i]
             ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T2, d, k)
             count = self._sync_stats(stats, count)
             ops.bn_finalize(stats, count, bmean, brstd, bn.running_mean, bn.running_var, bn.momentum, bn.eps, d)
-            bn.num_batches_tracked += 1
         else:
             ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
             ops.bn_eval_stats(bn.running_mean, bn.running_var, bmean, brstd, bn.eps, d)
@@ -544,6 +547,8 @@ class ConformerEncoder(NeuralModule):
         dx = dout.transpose(1, 2).contiguous().view(M, d).to(torch.float32)  # no copy when dout is a [B,T,d] view
         P = 2 * T2 - 1
         S.dp_all = self._buf("dp_all", (self.n_layers, P, d), cdt, dev)
+        S.bn_sums = torch.zeros(self.n_layers, 2, d, dtype=torch.float64, device=dev)
+        S.dpos_f32 = torch.zeros(self.n_layers, P, d, dtype=torch.float32, device=dev)
         for i in range(self.n_layers - 1, -1, -1):
             dx = self._layer_bwd(i, self.layers[i], dx, S, S.layers[i], W, Wf)
             S.layers[i] = None
@@ -618,7 +623,7 @@ class ConformerEncoder(NeuralModule):
         self._wgrad(db, d, 0, z, d, 0, c.pointwise_conv2.weight.grad, d, d, M, bias_grad=c.pointwise_conv2.bias.grad)
         dz = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(db, W[f"L{i}.conv.pw2t"], dz, M, d, d, d, W.pitch(f"L{i}.conv.pw2t"), d)
-        sums = torch.zeros(2, d, dtype=torch.float64, device=dev)
+        sums = S.bn_sums[i]
         ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, M, d)
         ops.bn_param_grad(sums, bn.weight.grad, bn.bias.grad, d)
         if training:
@@ -645,7 +650,7 @@ class ConformerEncoder(NeuralModule):
         dqkv = torch.empty(M, 3 * d, dtype=cdt, device=dev)
         dqu = torch.empty(M, d, dtype=cdt, device=dev)
         dqv = torch.empty(M, d, dtype=cdt, device=dev)
-        dp = torch.zeros(P, d, dtype=torch.float32, device=dev)
+        dp = S.dpos_f32[i]
         if lse is not None:
             qu = torch.empty(M, d, dtype=cdt, device=dev)
             qv = torch.empty(M, d, dtype=cdt, device=dev)

@@ -193,7 +193,7 @@ def qbias(qkv, ldq, u, v, qu, qv, M, d):
 
 def add2_colsum(a, b, out, ldo, M, d, sum_ab):
     """out[:, :d] = a + b; sum_ab[0:d] += colsum(a), sum_ab[d:2d] += colsum(b)   (bf16 in/out, f32 sums)"""
-    n = ((M + 15) // 16) * 2 * d
+    n = ((M + 31) // 32) * 2 * d
     sc = _scratch("add2_colsum", n, a.device)
     check(lib.mi355x_add2_colsum(_ptr(a), _ptr(b), _ptr(out), ldo, M, d, _ptr(sum_ab), _ptr(sc), n, _stream()), "add2_colsum")
 
@@ -290,7 +290,7 @@ def bn_swish_fwd(x, mean, rstd, gamma, beta, y, M, d):
 
 
 def bn_swish_bwd_reduce(dy, x, mean, rstd, gamma, beta, sums, M, d):
-    n = ((M + 15) // 16) * 2 * d
+    n = ((M + 31) // 32) * 2 * d
     sc = _scratch("bn_swish_bwd_reduce", n, dy.device)
     check(lib.mi355x_bn_swish_bwd_reduce(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums), dt(x),
                                          M, d, _ptr(sc), n, _stream()), "bn_swish_bwd_reduce")
