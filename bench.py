@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--secs", type=float, default=20.0)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-spec-augment", action="store_true", help="drop the recipe's SpecAugment (on by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -86,7 +87,7 @@ def main():
 
     vocab = 128
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    cfg = conformer_ctc_config(a.size, vocab_size=vocab, compute_dtype=cdt)
+    cfg = conformer_ctc_config(a.size, vocab_size=vocab, spec_augment=not a.no_spec_augment, compute_dtype=cdt)
     torch.manual_seed(0)
     model = EncDecCTCModel(cfg)
     model.decoder.compute_dtype = cdt
@@ -164,7 +165,8 @@ def main():
             "config": {"workload": f"Conformer-CTC-{a.size.capitalize()} {a.dtype}, batch={a.batch}x{a.secs:g}s synthetic 16 kHz "
                                    f"clips per GPU, {world}xMI355X (BASELINE.json configs[{1 if world == 1 else 2}])",
                        "global_batch": world * a.batch, "clip_seconds": a.secs, "parallelism": f"dp{world}",
-                       "step": "fwd+CTC+bwd+grad-allreduce+AdamW, train mode (dropout, dither, SyncBN)",
+                       "step": "fwd+CTC+bwd+grad-allreduce+AdamW, train mode (dropout, dither, SyncBN"
+                               + (")" if a.no_spec_augment else ", SpecAugment)"),
                        "final_loss": round(final_loss, 4)},
         }
         if roof is not None:

@@ -201,6 +201,11 @@ int mi355x_fill_f32(void* p, long long n, float value, void* stream);
 /* library / build information */
 const char* mi355x_asr_version(void);
 
+/* SpectrogramAugmentation (nemo/collections/asr/modules/audio_preprocessing.py:443-553; SpecAugment._apply_masks
+ * parts/submodules/spectr_augment.py:153-215, SpecCutout.forward :245-261): x[b, f0:f1, t0:t1] = value for n rectangles
+ * rects[n][5] = (b, f0, f1, t0, t1) (int32, device memory; clipped to the tensor).  x: f32 [B, F, T], in place. */
+int mi355x_fill_rects(void* x, const void* rects, int n, int B, int F, int T, float value, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,7 @@ class typecheck:
 # module-path aliases so the reference's own YAML `_target_` strings resolve to the drop-in classes
 TARGET_ALIASES = {
     "nemo.collections.asr.modules.AudioToMelSpectrogramPreprocessor": "nemo_amd.modules.AudioToMelSpectrogramPreprocessor",
+    "nemo.collections.asr.modules.SpectrogramAugmentation": "nemo_amd.modules.SpectrogramAugmentation",
     "nemo.collections.asr.modules.ConformerEncoder": "nemo_amd.modules.ConformerEncoder",
     "nemo.collections.asr.modules.ConvASRDecoder": "nemo_amd.modules.ConvASRDecoder",
     "nemo.collections.asr.losses.ctc.CTCLoss": "nemo_amd.modules.CTCLoss",

@@ -340,3 +340,29 @@ extern "C" int mi355x_row_scale(void* x, const void* vec, long long rows, long l
                      (const float*)vec, rows, cols);
   return mi_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------ SpecAugment / SpecCutout
+// x[b, f0:f1, t0:t1] = value for a device-resident list of rectangles (b, f0, f1, t0, t1) -- the time masks, frequency
+// masks and cut-out rectangles of SpectrogramAugmentation (spectr_augment.py:134-215, 245-261) applied in ONE launch
+// that touches only the masked elements (the reference materialises a full boolean mask and runs masked_fill twice).
+// grid (rects, 64 row-blocks): one workgroup row-block per 'f' group, threads along t.
+__global__ __launch_bounds__(256) void fill_rects_kernel(float* __restrict__ x, const int* __restrict__ rects, int n, int B, int F,
+                                                         int T, float value) {
+  const int r = blockIdx.x;
+  if (r >= n) return;
+  const int b = rects[5 * r], f0 = max(rects[5 * r + 1], 0), f1 = min(rects[5 * r + 2], F);
+  const int t0 = max(rects[5 * r + 3], 0), t1 = min(rects[5 * r + 4], T);
+  if (b < 0 || b >= B || f0 >= f1 || t0 >= t1) return;
+  for (int f = f0 + blockIdx.y; f < f1; f += gridDim.y) {
+    float* row = x + ((long long)b * F + f) * T;
+    for (int t = t0 + threadIdx.x; t < t1; t += 256) row[t] = value;
+  }
+}
+extern "C" int mi355x_fill_rects(void* x, const void* rects, int n, int B, int F, int T, float value, void* stream) {
+  mi_clear_errors();
+  if (!x || B <= 0 || F <= 0 || T <= 0 || n < 0 || (n > 0 && !rects)) return MI_ERR_ARG;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fill_rects_kernel, dim3(n, F < 64 ? F : 64), dim3(256), 0, (hipStream_t)stream, (float*)x, (const int*)rects,
+                     n, B, F, T, value);
+  return mi_check_launch();
+}

@@ -22,6 +22,7 @@ _DEFAULT_TARGETS = {
     "preprocessor": "nemo.collections.asr.modules.AudioToMelSpectrogramPreprocessor",
     "encoder": "nemo.collections.asr.modules.ConformerEncoder",
     "decoder": "nemo.collections.asr.modules.ConvASRDecoder",
+    "spec_augment": "nemo.collections.asr.modules.SpectrogramAugmentation",
 }
 
 
@@ -52,10 +53,8 @@ class EncDecCTCModel(nn.Module):
         self.decoder = _build("decoder", dec)
         self.loss = CTCLoss(num_classes=self.decoder.num_classes_with_blank - 1, zero_infinity=True,
                             reduction=cfg.get("ctc_reduction", "mean_batch"))
-        sa = cfg.get("spec_augment")
-        if sa and (sa.get("freq_masks", 0) or sa.get("time_masks", 0)):
-            raise NotImplementedError("SpectrogramAugmentation is the next row of the scope table (SURVEY.md 8f rank 1)")
-        self.spec_augmentation = None
+        sa = cfg.get("spec_augment")  # ctc_models.py:86-89
+        self.spec_augmentation = _build("spec_augment", sa) if sa else None
         self._optimizer: Optional[FusedAdamW] = None
         self._scheduler: Optional[NoamAnnealing] = None
         self._syncs = None
@@ -70,6 +69,8 @@ class EncDecCTCModel(nn.Module):
                              " with ``processed_signal`` and ``processed_signal_len`` arguments.")
         if not has_processed_signal:
             processed_signal, processed_signal_length = self.preprocessor(input_signal=input_signal, length=input_signal_length)
+        if self.spec_augmentation is not None and self.training:  # ctc_models.py:532-533
+            processed_signal = self.spec_augmentation(input_spec=processed_signal, length=processed_signal_length)
         encoded, encoded_len = self.encoder(audio_signal=processed_signal, length=processed_signal_length)
         log_probs = self.decoder(encoder_output=encoded)
         greedy_predictions = log_probs.argmax(dim=-1, keepdim=False)
@@ -147,9 +148,11 @@ class EncDecCTCModel(nn.Module):
         return model
 
 
-def conformer_ctc_config(size: str = "large", vocab_size: int = 128, **encoder_overrides) -> Dict[str, Any]:
+def conformer_ctc_config(size: str = "large", vocab_size: int = 128, spec_augment: bool = False,
+                         **encoder_overrides) -> Dict[str, Any]:
     """model section of examples/asr/conf/conformer/conformer_ctc_bpe.yaml (:44-192) for the sizes of its table (:7-17);
-    spec_augment off (next row), tokenizer replaced by an explicit vocabulary size."""
+    tokenizer replaced by an explicit vocabulary size.  `spec_augment=True` adds the recipe's section (:108-114:
+    2 frequency masks of width <= 27, 10 time masks of width <= 5 % of the utterance)."""
     sizes = {"small": (176, 4, 16), "medium": (256, 4, 18), "large": (512, 8, 18)}
     d_model, n_heads, n_layers = sizes[size]
     enc = dict(feat_in=80, feat_out=-1, n_layers=n_layers, d_model=d_model, subsampling="striding", subsampling_factor=4,
@@ -163,7 +166,8 @@ def conformer_ctc_config(size: str = "large", vocab_size: int = 128, **encoder_o
         "sample_rate": 16000, "ctc_reduction": "mean_batch", "skip_nan_grad": False,
         "preprocessor": dict(sample_rate=16000, normalize="per_feature", window_size=0.025, window_stride=0.01, window="hann",
                              features=80, n_fft=512, log=True, frame_splicing=1, dither=1e-5, pad_to=0, pad_value=0.0),
-        "spec_augment": None,
+        "spec_augment": dict(_target_="nemo.collections.asr.modules.SpectrogramAugmentation", freq_masks=2,
+                             time_masks=10, freq_width=27, time_width=0.05) if spec_augment else None,
         "encoder": enc,
         "decoder": dict(feat_in=None, num_classes=vocab_size, vocabulary=None),
         "optim": dict(name="adamw", lr=2.0, betas=[0.9, 0.98], weight_decay=1e-3,

@@ -1,4 +1,5 @@
-from .audio_preprocessing import AudioToMelSpectrogramPreprocessor, FilterbankFeatures  # noqa: F401
+from .audio_preprocessing import (AudioToMelSpectrogramPreprocessor, FilterbankFeatures,  # noqa: F401
+                                  SpectrogramAugmentation)
 from .conformer_encoder import ConformerEncoder  # noqa: F401
 from .conv_asr import ConvASRDecoder  # noqa: F401
 from .ctc import CTCLoss  # noqa: F401

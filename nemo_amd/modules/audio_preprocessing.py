@@ -14,7 +14,8 @@ import numpy as np
 import torch
 from torch import nn
 
-from ..core import AudioSignal, LengthsType, MelSpectrogramType, NeuralModule, NeuralType, typecheck
+from ..core import (AudioSignal, LengthsType, MelSpectrogramType, NeuralModule, NeuralType, SpectrogramType,
+                    typecheck)
 
 CONSTANT = 1e-5
 
@@ -233,3 +234,110 @@ class AudioToMelSpectrogramPreprocessor(NeuralModule):
         lengths = torch.randint(low=min_length, high=max_dim, size=[max_batch], device=dev)
         lengths[0] = max_dim
         return signals, lengths
+
+
+class SpectrogramAugmentation(NeuralModule):
+    """audio_preprocessing.py:443-553 -- same kwargs, typed I/O and random streams.
+
+    The mask PARAMETERS are drawn exactly as the reference draws them (vectorised mode: four `torch.rand((B, n))` calls on
+    the spectrogram's device, time masks first -- spectr_augment.py:134-215; legacy mode and SpecCutout: the python
+    `random.Random` stream -- :99-132, :245-261), so a seeded run masks the same cells.  The masks are then applied by ONE
+    `mi355x_fill_rects` launch that writes only the masked cells (the reference builds a full boolean mask and runs
+    `masked_fill` over the whole spectrogram twice).  The Numba kernel option is accepted and ignored (same result).
+    """
+
+    @property
+    def input_types(self):
+        return OrderedDict({"input_spec": NeuralType(("B", "D", "T"), SpectrogramType()),
+                            "length": NeuralType(tuple("B"), LengthsType())})
+
+    @property
+    def output_types(self):
+        return OrderedDict({"augmented_spec": NeuralType(("B", "D", "T"), SpectrogramType())})
+
+    def __init__(self, freq_masks=0, time_masks=0, freq_width=10, time_width=10, rect_masks=0, rect_time=5, rect_freq=20,
+                 rng=None, mask_value=0.0, use_vectorized_spec_augment: bool = True, use_numba_spec_augment: bool = False):
+        super().__init__()
+        import random as _random
+        self._rng = _random.Random() if rng is None else rng
+        self.freq_masks, self.time_masks = int(freq_masks), int(time_masks)
+        self.freq_width, self.time_width = freq_width, time_width
+        self.rect_masks, self.rect_time, self.rect_freq = int(rect_masks), rect_time, rect_freq
+        self.mask_value = float(mask_value)
+        self.use_vectorized_code = bool(use_vectorized_spec_augment)
+        if not isinstance(time_width, int) and (time_width > 1.0 or time_width < 0.0):
+            raise ValueError("If `time_width` is a float value, must be in range [0, 1]")
+
+    # ---- mask parameters (device-agnostic torch / python code: runs on CPU tensors in the tests)
+    def _vectorized_rects(self, B, F, T, length, device):
+        rows = []
+        bidx = torch.arange(B, device=device).unsqueeze(1)
+        for num, width, is_time in ((self.time_masks, self.time_width, True), (self.freq_masks, self.freq_width, False)):
+            axis_length = T if is_time else F
+            if is_time and isinstance(width, float):
+                width = torch.clamp(width * length, max=axis_length).unsqueeze(1)
+            mask_width = (torch.rand((B, num), device=device, dtype=torch.float32) * width).long()
+            mask_start = torch.rand((B, num), device=device, dtype=torch.float32)
+            mask_start = (mask_start * ((length.unsqueeze(1) if is_time else axis_length) - mask_width)).long()
+            mask_end = mask_start + mask_width
+            z = torch.zeros_like(mask_start)
+            if num == 0:
+                continue
+            if is_time:
+                rows.append(torch.stack([bidx.expand_as(z), z, z + F, mask_start, mask_end], -1).reshape(-1, 5))
+            else:
+                rows.append(torch.stack([bidx.expand_as(z), mask_start, mask_end, z, z + T], -1).reshape(-1, 5))
+        return torch.cat(rows, 0) if rows else torch.zeros(0, 5, dtype=torch.long, device=device)
+
+    def _legacy_rects(self, B, F, T, length):
+        lengths = [int(v) for v in length.tolist()]  # host sync, as in the reference (:101)
+        rows = []
+        for idx in range(B):
+            for _ in range(self.freq_masks):
+                start = self._rng.randint(0, F - self.freq_width)
+                width = self._rng.randint(0, self.freq_width)
+                rows.append((idx, start, start + width, 0, T))
+            tw = max(1, int(lengths[idx] * self.time_width)) if isinstance(self.time_width, float) else self.time_width
+            upper = max(1, lengths[idx] - tw)
+            for _ in range(self.time_masks):
+                start = self._rng.randint(0, upper)
+                width = self._rng.randint(0, tw)
+                rows.append((idx, 0, F, start, start + width))
+        return torch.tensor(rows, dtype=torch.long).reshape(-1, 5)
+
+    def _cutout_rects(self, B, F, T):
+        rows = []
+        for idx in range(B):
+            for _ in range(self.rect_masks):
+                x = self._rng.randint(0, F - self.rect_freq)
+                y = self._rng.randint(0, T - self.rect_time)
+                w_x = self._rng.randint(0, self.rect_freq)
+                w_y = self._rng.randint(0, self.rect_time)
+                rows.append((idx, x, x + w_x, y, y + w_y))
+        return torch.tensor(rows, dtype=torch.long).reshape(-1, 5)
+
+    def mask_rects(self, B, F, T, length, device):
+        """[(rects int64 [n,5], value)] in application order: cut-out rectangles (zeros), then SpecAugment (mask_value)"""
+        out = []
+        if self.rect_masks > 0:
+            out.append((self._cutout_rects(B, F, T).to(device), 0.0))
+        if self.freq_masks + self.time_masks > 0:
+            r = self._vectorized_rects(B, F, T, length.to(device), device) if self.use_vectorized_code \
+                else self._legacy_rects(B, F, T, length).to(device)
+            out.append((r, self.mask_value))
+        return out
+
+    @typecheck()
+    @torch.no_grad()
+    def forward(self, input_spec, length):
+        B, F, T = input_spec.shape
+        groups = self.mask_rects(B, F, T, length, input_spec.device)
+        if not groups:
+            return input_spec
+        out = input_spec.to(torch.float32).clone() if self.rect_masks == 0 else input_spec.to(torch.float32)
+        out = out.contiguous()
+        from .. import ops
+        for rects, value in groups:  # SpecCutout writes in place in the reference, SpecAugment returns a new tensor
+            ops.fill_rects(out, rects.to(torch.int32).contiguous(), value)
+        return out.to(input_spec.dtype)
+

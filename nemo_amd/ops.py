@@ -191,6 +191,15 @@ def qbias(qkv, ldq, u, v, qu, qv, M, d):
     check(lib.mi355x_qbias(_ptr(qkv), ldq, _ptr(u), _ptr(v), _ptr(qu), _ptr(qv), dt(qkv), M, d, _stream()), "qbias")
 
 
+def fill_rects(x, rects, value=0.0):
+    """x[b, f0:f1, t0:t1] = value for rects [n,5] int32 = (b, f0, f1, t0, t1); x f32 [B,F,T], in place"""
+    B, F, T = x.shape
+    n = int(rects.shape[0])
+    if n:
+        check(lib.mi355x_fill_rects(_ptr(x), _ptr(rects), n, B, F, T, float(value), _stream()), "fill_rects")
+    return x
+
+
 def add2_colsum(a, b, out, ldo, M, d, sum_ab):
     """out[:, :d] = a + b; sum_ab[0:d] += colsum(a), sum_ab[d:2d] += colsum(b)   (bf16 in/out, f32 sums)"""
     n = ((M + 31) // 32) * 2 * d

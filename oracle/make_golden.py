@@ -116,7 +116,44 @@ def make_reference_fixtures():
     print("tiny model fixture:", {k: float(fix[k]) for k in ("eval/loss", "train/loss")})
 
 
+def make_specaug_fixture():
+    """the reference's SpecAugment / SpecCutout classes (spectr_augment.py, loaded through the shim) on a seeded CPU input:
+    vectorised mode (torch generator), legacy mode and cut-out (python random.Random) -> tests/golden/ref_specaug.npz"""
+    import importlib
+    import random
+    from oracle import ref_shim
+    ref_shim.install()
+    sa = importlib.import_module("nemo.collections.asr.parts.submodules.spectr_augment")
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(4, 80, 523, generator=g)
+    length = torch.tensor([523, 400, 77, 250])
+    fix = {"x": x.numpy(), "length": length.numpy()}
+    # (1) vectorised, adaptive time width (conformer_ctc_bpe.yaml:123-128: freq 2 x 27, time 10 x 0.05)
+    torch.manual_seed(2024)
+    fix["vec_adaptive"] = sa.SpecAugment(freq_masks=2, time_masks=10, freq_width=27, time_width=0.05)(
+        input_spec=x.clone(), length=length).numpy()
+    # (2) vectorised, integer time width, non-zero mask value
+    torch.manual_seed(2025)
+    fix["vec_int"] = sa.SpecAugment(freq_masks=3, time_masks=4, freq_width=15, time_width=40, mask_value=-1.5)(
+        input_spec=x.clone(), length=length).numpy()
+    # (3) legacy (python rng), adaptive width
+    fix["legacy"] = sa.SpecAugment(freq_masks=2, time_masks=5, freq_width=27, time_width=0.05, rng=random.Random(7),
+                                   use_vectorized_code=False)(input_spec=x.clone(), length=length).numpy()
+    # (4) cut-out followed by SpecAugment, one shared rng (SpectrogramAugmentation.__init__ passes the same rng to both)
+    rng = random.Random(11)
+    y = sa.SpecCutout(rect_masks=5, rect_time=60, rect_freq=20, rng=rng)(input_spec=x.clone())
+    fix["cutout_then_legacy"] = sa.SpecAugment(freq_masks=1, time_masks=2, freq_width=10, time_width=25, rng=rng,
+                                               use_vectorized_code=False)(input_spec=y, length=length).numpy()
+    # stored compactly: the input, and per case the bit-packed set of cells that changed (they hold the mask value)
+    out = {"x": fix["x"], "length": fix["length"]}
+    for k in ("vec_adaptive", "vec_int", "legacy", "cutout_then_legacy"):
+        out[k + "_mask"] = np.packbits(fix[k] != fix["x"])
+    np.savez_compressed(os.path.join(GOLD, "ref_specaug.npz"), **out)
+    print("specaug fixture: masked cells", {k: int((fix[k] != fix["x"]).sum()) for k in fix if k not in ("x", "length")})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     extract_ctc_known_answers()
     make_reference_fixtures()
+    make_specaug_fixture()

@@ -182,7 +182,48 @@ def test_model_config_and_nemo_file_roundtrip(tmp_path):
     m2 = EncDecCTCModel.restore_from(path)
     for k, v in m.state_dict().items():
         assert torch.equal(v, m2.state_dict()[k]), k
-    with pytest.raises(NotImplementedError):
-        bad = conformer_ctc_config("small", vocab_size=16, n_layers=1, d_model=32)
-        bad["spec_augment"] = {"freq_masks": 2, "time_masks": 10}
-        EncDecCTCModel(bad)
+    # the recipe's spec_augment section instantiates the drop-in SpectrogramAugmentation (ctc_models.py:86-89)
+    aug = conformer_ctc_config("small", vocab_size=16, n_layers=1, d_model=32)
+    aug["spec_augment"] = {"_target_": "nemo.collections.asr.modules.SpectrogramAugmentation", "freq_masks": 2,
+                           "time_masks": 10, "freq_width": 27, "time_width": 0.05}
+    m3 = EncDecCTCModel(aug)
+    assert type(m3.spec_augmentation).__name__ == "SpectrogramAugmentation" and m3.spec_augmentation.time_masks == 10
+    assert set(m3.state_dict()) == set(m.state_dict())  # no parameters / buffers of its own
+
+
+# ---------------------------------------------------------------------------------------------- SpecAugment host logic
+def test_specaug_module_draws_the_reference_masks(golden_dir):
+    """the drop-in module's mask parameters (device-agnostic host code, here on CPU tensors) reproduce the cells the
+    reference classes masked at the same seeds -- vectorised (torch generator), legacy and cut-out (python rng) modes"""
+    import random
+    import numpy as np
+    from nemo_amd.modules import SpectrogramAugmentation
+    from oracle import specaug_ref as SR
+    z = np.load(os.path.join(golden_dir, "ref_specaug.npz"))
+    x, length = torch.from_numpy(z["x"]), torch.from_numpy(z["length"])
+    B, F, T = x.shape
+
+    def masked(groups):
+        y = x
+        for rects, value in groups:
+            y = SR.apply_rects(y, rects, value)
+        return (y != x).numpy()
+
+    def want(name):
+        return np.unpackbits(z[name + "_mask"])[: x.numel()].reshape(tuple(x.shape)).astype(bool)
+
+    torch.manual_seed(2024)
+    m = SpectrogramAugmentation(freq_masks=2, time_masks=10, freq_width=27, time_width=0.05)
+    assert np.array_equal(masked(m.mask_rects(B, F, T, length, "cpu")), want("vec_adaptive"))
+    torch.manual_seed(2025)
+    m = SpectrogramAugmentation(freq_masks=3, time_masks=4, freq_width=15, time_width=40, mask_value=-1.5)
+    assert np.array_equal(masked(m.mask_rects(B, F, T, length, "cpu")), want("vec_int"))
+    m = SpectrogramAugmentation(freq_masks=2, time_masks=5, freq_width=27, time_width=0.05, rng=random.Random(7),
+                                use_vectorized_spec_augment=False)
+    assert np.array_equal(masked(m.mask_rects(B, F, T, length, "cpu")), want("legacy"))
+    m = SpectrogramAugmentation(freq_masks=1, time_masks=2, freq_width=10, time_width=25, rect_masks=5, rect_time=60,
+                                rect_freq=20, rng=random.Random(11), use_vectorized_spec_augment=False)
+    assert np.array_equal(masked(m.mask_rects(B, F, T, length, "cpu")), want("cutout_then_legacy"))
+    with pytest.raises(ValueError):
+        SpectrogramAugmentation(time_masks=1, time_width=1.5)
+

@@ -219,6 +219,43 @@ def test_colsum_logsoftmax():
     assert torch.all(dx[:, C_:] == 0)
 
 
+def test_specaug_fill_rects_and_module(golden_dir):
+    """mi355x_fill_rects against the oracle's slice assignment (incl. clipped / empty / overlapping rectangles), and the
+    drop-in SpectrogramAugmentation on the GPU: same cells as its own parameter draw at the same device seed, input intact"""
+    from nemo_amd.modules import SpectrogramAugmentation
+    from oracle import specaug_ref as SR
+    o = ops()
+    z = np.load(os.path.join(golden_dir, "ref_specaug.npz"))
+    x = torch.from_numpy(z["x"]); length = torch.from_numpy(z["length"])
+    B, F, T = x.shape
+    rects = torch.tensor([[0, 0, F, 10, 60], [1, 5, 32, 0, T], [1, 20, 40, 100, 90], [2, -3, 4, T - 5, T + 9],
+                          [3, 79, 200, 0, 1], [3, 0, F, 0, T], [0, 7, 7, 0, T], [2, 10, 12, 300, 301]], dtype=torch.long)
+    want = SR.apply_rects(x, rects, -2.0)
+    got = o.fill_rects(x.clone().to(dev), rects.to(torch.int32).to(dev), -2.0)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), want)
+    # reference-generated rectangles (legacy stream) through the kernel reproduce the reference's output cells
+    import random
+    r2 = SR.legacy_rects(random.Random(7), B, F, T, length, 2, 5, 27, 0.05)
+    got = o.fill_rects(x.clone().to(dev), r2.to(torch.int32).to(dev), 0.0).cpu()
+    mask = np.unpackbits(z["legacy_mask"])[: x.numel()].reshape(tuple(x.shape)).astype(bool)
+    assert np.array_equal((got != x).numpy(), mask) and torch.all(got[torch.from_numpy(mask)] == 0)
+    # module on the device
+    m = SpectrogramAugmentation(freq_masks=2, time_masks=10, freq_width=27, time_width=0.05)
+    xd, ld = x.to(dev), length.to(dev)
+    torch.manual_seed(5)
+    groups = m.mask_rects(B, F, T, ld, xd.device)
+    torch.manual_seed(5)
+    y = m(input_spec=xd, length=ld)
+    torch.cuda.synchronize()
+    ref = x
+    for r, v in groups:
+        ref = SR.apply_rects(ref, r.cpu(), v)
+    assert torch.equal(y.cpu(), ref) and torch.equal(xd.cpu(), x)
+    masked_frac = (y.cpu() != x).float().mean().item()
+    assert 0.05 < masked_frac < 0.9
+
+
 @pytest.mark.parametrize("M,d", [(700, 64), (1003, 512), (130, 176)])
 def test_add2_colsum(M, d):
     """dq = dqu + dqv fused with the pos_bias_u / pos_bias_v gradients (multi_head_attention.py:288-291)"""

@@ -156,6 +156,39 @@ def test_dropout_training_runs_and_is_stochastic():
         assert torch.isfinite(p.grad).all(), n
 
 
+def test_spec_augment_in_training_step_matches_oracle_on_masked_features():
+    """ctc_models.py:532-533: SpecAugment sits between the preprocessor and the encoder, in training mode only.  With
+    dropout/dither off, the loss of a training step with augmentation equals the loss of the un-augmented model fed the
+    oracle-masked features (same device seed -> same rectangles)."""
+    from oracle import specaug_ref as SR
+    over = dict(d_model=64, n_heads=4, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0, dropout_emb=0.0)
+    sa = {"_target_": "nemo.collections.asr.modules.SpectrogramAugmentation", "freq_masks": 2, "time_masks": 4,
+          "freq_width": 20, "time_width": 0.05}
+    model = _model(over, vocab=20, spec_augment=sa).to(dev)
+    audio, alen, tok, tl = R.synthetic_batch(3, 1.5, vocab=20, seed=21)
+    batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+    model.eval()
+    feats, flen = model.preprocessor(input_signal=batch[0], length=batch[1])
+    lp_eval, _, _ = model.forward(input_signal=batch[0], input_signal_length=batch[1])
+    lp_feat, _, _ = model.forward(processed_signal=feats, processed_signal_length=flen)
+    assert torch.equal(lp_eval, lp_feat)  # no augmentation outside training
+    B, F, T = feats.shape
+    torch.manual_seed(77)
+    rects = model.spec_augmentation.mask_rects(B, F, T, flen, feats.device)
+    masked = feats.cpu()
+    for r, v in rects:
+        masked = SR.apply_rects(masked, r.cpu(), v)
+    assert (masked != feats.cpu()).float().mean() > 0.02
+    model.train()
+    torch.manual_seed(77)
+    l_aug = model.training_step(batch)["loss"]
+    model.spec_augmentation = None
+    lp, enc_len, _ = model.forward(processed_signal=masked.to(dev), processed_signal_length=flen)
+    l_ref = model.loss(log_probs=lp, targets=batch[2], input_lengths=enc_len, target_lengths=batch[3])
+    torch.cuda.synchronize()
+    assert abs(l_aug.item() - l_ref.item()) <= 1e-5 * abs(l_ref.item()), (l_aug.item(), l_ref.item())
+
+
 def test_fit_steps_reduce_loss_and_nemo_roundtrip(tmp_path):
     from nemo_amd.models import EncDecCTCModel
     over = dict(d_model=64, n_heads=4, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0)

@@ -120,3 +120,51 @@ def test_restatement_matches_live_reference():
     assert torch.allclose(out["mel"], mel, atol=1e-4)
     assert torch.allclose(out["logp"], logp, atol=2e-5)
     assert abs(out["loss"].item() - loss.item()) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- SpecAugment
+def _specaug_cases():
+    """(name, kwargs, seeding) exactly as oracle/make_golden.py:make_specaug_fixture ran the reference classes"""
+    import random
+    return [
+        ("vec_adaptive", dict(freq_masks=2, time_masks=10, freq_width=27, time_width=0.05, mask_value=0.0), ("torch", 2024)),
+        ("vec_int", dict(freq_masks=3, time_masks=4, freq_width=15, time_width=40, mask_value=-1.5), ("torch", 2025)),
+        ("legacy", dict(freq_masks=2, time_masks=5, freq_width=27, time_width=0.05, mask_value=0.0), ("py", random.Random(7))),
+    ]
+
+
+def _unpack(z, name):
+    x = z["x"]
+    return np.unpackbits(z[name + "_mask"])[: x.size].reshape(x.shape).astype(bool)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_specaug_restatement_matches_reference_fixture(golden_dir, case):
+    from oracle import specaug_ref as SR
+    z = np.load(os.path.join(golden_dir, "ref_specaug.npz"))
+    x, length = torch.from_numpy(z["x"]), torch.from_numpy(z["length"])
+    B, F, T = x.shape
+    name, kw, (kind, seed) = _specaug_cases()[case]
+    value = kw.pop("mask_value")
+    if kind == "torch":
+        torch.manual_seed(seed)
+        rects = SR.vectorized_rects(B, F, T, length, **kw)
+    else:
+        rects = SR.legacy_rects(seed, B, F, T, length, **kw)
+    out = SR.apply_rects(x, rects, value)
+    mask = _unpack(z, name)
+    assert np.array_equal((out != x).numpy(), mask)
+    assert torch.all(out[torch.from_numpy(mask)] == value)
+
+
+def test_specaug_cutout_restatement_matches_reference_fixture(golden_dir):
+    import random
+    from oracle import specaug_ref as SR
+    z = np.load(os.path.join(golden_dir, "ref_specaug.npz"))
+    x, length = torch.from_numpy(z["x"]), torch.from_numpy(z["length"])
+    B, F, T = x.shape
+    rng = random.Random(11)
+    y = SR.apply_rects(x, SR.cutout_rects(rng, B, F, T, 5, 60, 20), 0.0)
+    y = SR.apply_rects(y, SR.legacy_rects(rng, B, F, T, length, 1, 2, 10, 25), 0.0)
+    assert np.array_equal((y != x).numpy(), _unpack(z, "cutout_then_legacy"))
+
