@@ -171,12 +171,12 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, int z, long long coff,
 // ---- streamlined epilogue of a full-width tile whose f32 image sits in LDS ([rows][BN+4]).  One thread = 8 consecutive
 // columns of ROWS_IT rows; the epilogue kind is a compile-time constant, bias is loaded once, all aux_in loads are issued
 // before the first LDS read.  Same arithmetic as epilogue8() (bit-identical results).
-template <int EPI, int ITERS, int ROW_STEP>
+template <int EPI, int ITERS, int ROW_STEP, int TW = BN>
 __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, int z, long long coff, int m_first, int n0,
                                               int row_l0) {
-  constexpr int LDS_C = BN + 4;
+  constexpr int LDS_C = TW + 4;
   constexpr bool AUX_IN = EPI == EPI_RESID || EPI == EPI_DSWISH || EPI == EPI_MUL_POS;
-  const int c8 = (threadIdx.x & 15) * 8;
+  const int c8 = (threadIdx.x & (TW / 8 - 1)) * 8;
   const int n = n0 + c8;
   float b8[8];
   if (p.bias) ld8x(p.bias, n, MI_DT_F32, b8);
@@ -231,16 +231,16 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
     st8x(p.C, ci, p.c_dt, v);
   }
 }
-template <int ITERS, int ROW_STEP>
+template <int ITERS, int ROW_STEP, int TW = BN>
 __device__ __forceinline__ void fast_epilogue_any(const GemmP& p, const float* sC, int z, long long coff, int m_first, int n0,
                                                   int row_l0) {
   switch (p.epi) {
-    case EPI_STORE: fast_epilogue<EPI_STORE, ITERS, ROW_STEP>(p, sC, z, coff, m_first, n0, row_l0); break;
-    case EPI_SWISH_DROP: fast_epilogue<EPI_SWISH_DROP, ITERS, ROW_STEP>(p, sC, z, coff, m_first, n0, row_l0); break;
-    case EPI_RESID: fast_epilogue<EPI_RESID, ITERS, ROW_STEP>(p, sC, z, coff, m_first, n0, row_l0); break;
-    case EPI_DSWISH: fast_epilogue<EPI_DSWISH, ITERS, ROW_STEP>(p, sC, z, coff, m_first, n0, row_l0); break;
-    case EPI_RELU_MASK: fast_epilogue<EPI_RELU_MASK, ITERS, ROW_STEP>(p, sC, z, coff, m_first, n0, row_l0); break;
-    default: fast_epilogue<EPI_MUL_POS, ITERS, ROW_STEP>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_STORE: fast_epilogue<EPI_STORE, ITERS, ROW_STEP, TW>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_SWISH_DROP: fast_epilogue<EPI_SWISH_DROP, ITERS, ROW_STEP, TW>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_RESID: fast_epilogue<EPI_RESID, ITERS, ROW_STEP, TW>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_DSWISH: fast_epilogue<EPI_DSWISH, ITERS, ROW_STEP, TW>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_RELU_MASK: fast_epilogue<EPI_RELU_MASK, ITERS, ROW_STEP, TW>(p, sC, z, coff, m_first, n0, row_l0); break;
+    default: fast_epilogue<EPI_MUL_POS, ITERS, ROW_STEP, TW>(p, sC, z, coff, m_first, n0, row_l0); break;
   }
 }
 
@@ -744,6 +744,179 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
 }
 
 // =================================================================================================
+// Third structure, for problems with enough 256x256 tiles (N >= 1024 outputs, conv2, split-K wgrad): 256x256x64 block
+// tile, 8 waves as 2(M) x 4(N), each 128x64 (8 accumulators).  The 256x128 structure above is bound by its LDS traffic --
+// measured: 48 KiB of LDS-DMA landings (64 B/clk) + 128 KiB of fragment reads per K-tile against 1024 MFMA cycles --
+// and this tile moves 2/3 of the DMA bytes and 3/4 of the fragment bytes per MFMA.  Two 64-KiB LDS stages (128 KiB): the
+// DMA of K-tile it+1 is issued before the MFMAs of tile it and drained (vmcnt(0)) at the barrier that ends the step.
+// Same LDS images / swizzles / transpose reads as above; epilogue through a [64][260] f32 window in four rounds.
+// =================================================================================================
+#define BN4 256
+#define NT4_STAGE ((BM2 + BN4) * BK)  // 64 KiB
+
+// one epilogue round of the 256x256 tile: window row rl (0..63) is tile row (rl >> 5) * 128 + i * 32 + (rl & 31)
+__device__ __forceinline__ void v4_round_out(const GemmP& p, const float* sC, int z, long long coff, int m0, int n0, int i,
+                                          bool fast) {
+  constexpr int LDS_C = BN4 + 4;
+  if (fast) {
+    // 512 threads = 16 rows x 32 column chunks per pass
+    const int rl0 = threadIdx.x >> 5;
+    fast_epilogue_any<2, 16, BN4>(p, sC, z, coff, m0 + i * 32 + rl0, n0, rl0);
+    fast_epilogue_any<2, 16, BN4>(p, sC + 32 * LDS_C, z, coff, m0 + 128 + i * 32 + rl0, n0, rl0);
+  } else if (p.atomic) {
+    for (int e = threadIdx.x; e < 64 * BN4; e += 512) {
+      const int rl = e >> 8, col = e & (BN4 - 1);
+      const int m = m0 + (rl >> 5) * 128 + i * 32 + (rl & 31), n = n0 + col;
+      if (m < p.M && n < p.N) epilogue(p, z, coff, m, n, sC[rl * LDS_C + col]);
+    }
+  } else {
+    for (int it = 0; it < 4; ++it) {
+      const int rl = (threadIdx.x >> 5) + 16 * it;
+      const int c8 = (threadIdx.x & 31) * 8;
+      const int m = m0 + (rl >> 5) * 128 + i * 32 + (rl & 31), n = n0 + c8;
+      if (m < p.M && n < p.N) {
+        float v[8];
+        const float4 a = *reinterpret_cast<const float4*>(sC + rl * LDS_C + c8);
+        const float4 b = *reinterpret_cast<const float4*>(sC + rl * LDS_C + c8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        if ((p.vec_ok & 1) && n + 8 <= p.N) epilogue8(p, z, coff, m, n, v);
+        else {
+          for (int j = 0; j < 8; ++j)
+            if (n + j < p.N) epilogue(p, z, coff, m, n + j, v[j]);
+        }
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem4[];  // 2 stages x 64 KiB
+  const int tn = (p.N + BN4 - 1) / BN4, tm = (p.M + BM2 - 1) / BM2;
+  const int ntiles = tm * tn;
+  const int bid = blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tile_m = logical / tn, tile_n = logical - tile_m * tn;
+  const int m0 = tile_m * BM2, n0 = tile_n * BN4;
+  const int z = blockIdx.z;
+  const int z0 = z % p.nb0, z1 = z / p.nb0;
+  const bf16_t* A = (const bf16_t*)p.A + z0 * p.sA0 + z1 * p.sA1;
+  const bf16_t* B = (const bf16_t*)p.B + z0 * p.sB0 + z1 * p.sB1;
+  const long long coff = z0 * p.sC0 + z1 * p.sC1;
+  const int nk_total = (p.K + BK - 1) / BK;
+  int kt0 = 0, kt1 = nk_total;
+  if (p.splitk > 1) {
+    kt0 = blockIdx.y * p.ktiles_per_split;
+    kt1 = min(nk_total, kt0 + p.ktiles_per_split);
+    if (kt0 >= kt1) return;
+  }
+  const int nk = kt1 - kt0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  DmaSrc<BM2> dA;
+  DmaSrc<BN4> dB;
+  dma_setup<TA, BM2>(dA, A, p.lda, m0, p.M, kt0 * BK);
+  dma_setup<TB, BN4>(dB, B, p.ldb, n0, p.N, kt0 * BK);
+  const bool ktail = (p.K & (BK - 1)) != 0;
+  auto issue = [&](int it) {
+    bf16_t* st = smem4 + (it & 1) * NT4_STAGE;
+    dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
+    dma_issue<BN4>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
+  };
+  const bool do_colsum = TA && p.colsum_out != nullptr && tile_n == 0;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int it = 0; it < nk; ++it) {
+    if (it + 1 < nk) issue(it + 1);  // other stage: every wave passed the barrier after its last read of it
+    const bf16_t* a_s = smem4 + (it & 1) * NT4_STAGE;
+    const bf16_t* b_s = a_s + BM2 * BK;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = frag_v2<TB, BN4>(b_s, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = frag_v2<TA, BM2>(a_s, wm * 128 + i * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (TA && do_colsum) {  // thread -> (k-group of 8 rows = wave, 4 consecutive columns = lane)
+      const int col = lane * 4;
+#pragma unroll
+      for (int kr = 0; kr < 8; ++kr) {
+        const int krow = wave * 8 + kr;
+        const int off = krow * BM2 + (((col >> 3) ^ ((krow & 3) << 2)) << 3) + (col & 7);
+        const u32x2 v = *reinterpret_cast<const u32x2*>(a_s + off);
+        csum[0] += __uint_as_float(v[0] << 16); csum[1] += __uint_as_float(v[0] & 0xffff0000u);
+        csum[2] += __uint_as_float(v[1] << 16); csum[3] += __uint_as_float(v[1] & 0xffff0000u);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  float* sC = reinterpret_cast<float*>(smem4);
+  if (TA && do_colsum) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sC[wave * BM2 + lane * 4 + e] = csum[e];
+    __syncthreads();
+    if (threadIdx.x < BM2) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += sC[w * BM2 + threadIdx.x];
+      const int m = m0 + threadIdx.x;
+      if (m < p.M) atomicAdd(p.colsum_out + z0 * p.colsum_stride + m, v);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: four rounds through a [64][BN4+4] f32 window (round i = the i-th 32-row block of every wave)
+  constexpr int LDS_C = BN4 + 4;
+  const bool fast = (p.vec_ok & 1) && !(p.N & 7) && n0 + BN4 <= p.N && !p.atomic;
+  // the rounds are a real loop (the epilogue code exists once); the round's two accumulators are selected by a uniform
+  // switch so that acc[][] is never indexed dynamically (that would put all 128 accumulator registers in scratch memory)
+#pragma nounroll
+  for (int i = 0; i < 4; ++i) {
+    f32x16 t0, t1;
+    switch (i) {
+      case 0: t0 = acc[0][0]; t1 = acc[0][1]; break;
+      case 1: t0 = acc[1][0]; t1 = acc[1][1]; break;
+      case 2: t0 = acc[2][0]; t1 = acc[2][1]; break;
+      default: t0 = acc[3][0]; t1 = acc[3][1]; break;
+    }
+    if (i) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row_l = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      sC[row_l * LDS_C + wn * 64 + lr] = t0[r];
+      sC[row_l * LDS_C + wn * 64 + 32 + lr] = t1[r];
+    }
+    __syncthreads();
+    v4_round_out(p, sC, z, coff, m0, n0, i, fast);
+  }
+}
+
+// =================================================================================================
 // exact fp32 VALU kernel, arbitrary strides: 64x64x16 tile, 256 threads, 4x4 per thread
 // =================================================================================================
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
@@ -880,6 +1053,34 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
         attr_set = true;
       }
       dim3 grid2(tm2 * tn, sk, p.batch);
+      // 256x256 structure when the problem still fills the chip with the larger tile
+      static int v4_mode = -1;  // MI355X_GEMM_V4: 0 = never, 1 = heuristic (default), 2 = whenever N >= 129
+      if (v4_mode < 0) { const char* e = getenv("MI355X_GEMM_V4"); v4_mode = e ? atoi(e) : 1; }
+      const int tn4 = (p.N + BN4 - 1) / BN4;
+      const long long blocks4 = (long long)tm2 * tn4 * sk * p.batch;
+      const bool waste_ok = (long long)tn4 * BN4 * 8 <= (long long)p.N * 9;  // <= 12.5 % padded columns
+      // wave quantisation: workgroups / (rounds x 256 CUs) must not fall behind the 256x128 tiling by more than 10 %
+      const long long blocks2 = (long long)tm2 * tn * sk * p.batch;
+      const double eff4 = (double)blocks4 / (double)(((blocks4 + 255) / 256) * 256);
+      const double eff2 = (double)blocks2 / (double)(((blocks2 + 255) / 256) * 256);
+      if ((v4_mode == 2 && p.N > 128) || (v4_mode == 1 && blocks4 >= 224 && waste_ok && eff4 >= 0.9 * eff2)) {
+        const int shm4 = 2 * NT4_STAGE * 2;
+        static bool attr4_set = false;
+        if (!attr4_set) {
+          bool ok = hipFuncSetAttribute((const void*)gemm_bf16_v4_kernel<false, false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, shm4) == hipSuccess;
+          ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v4_kernel<false, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, shm4) == hipSuccess;
+          ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v4_kernel<true, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, shm4) == hipSuccess;
+          if (!ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
+          attr4_set = true;
+        }
+        dim3 grid4(tm2 * tn4, sk, p.batch);
+        if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_bf16_v4_kernel<false, false>), grid4, dim3(512), shm4, s, p);
+        else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_bf16_v4_kernel<false, true>), grid4, dim3(512), shm4, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_v4_kernel<true, true>), grid4, dim3(512), shm4, s, p);
+      } else
       if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_bf16_v2_kernel<false, false>), grid2, dim3(512), shm, s, p);
       else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_bf16_v2_kernel<false, true>), grid2, dim3(512), shm, s, p);
       else hipLaunchKernelGGL((gemm_bf16_v2_kernel<true, true>), grid2, dim3(512), shm, s, p);

@@ -62,3 +62,7 @@ run("ffn1_wgrad_sk16", 2048, 512, M, "atomic", torch.float32, "TN", splitk=16)
 run("ffn1_wgrad_sk1_store", 2048, 512, M, "nobias", torch.float32, "TN")
 run("proj_wgrad_sk16", 512, 512, M, "atomic", torch.float32, "TN", splitk=16)
 run("proj_wgrad_sk64", 512, 512, M, "atomic", torch.float32, "TN", splitk=64)
+run("ffn1_dgrad_dswish", M, 2048, 512, "store")
+run("conv2_dgrad", 320640, 4608, 512, "nobias")
+run("qkv_wgrad_like", 1536, 512, M, "atomic", torch.float32, "TN", splitk=8)
+run("conv2_wgrad_like", 512, 4608, 320640 // 4, "atomic", torch.float32, "TN", splitk=8)
