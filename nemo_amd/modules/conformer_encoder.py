@@ -13,6 +13,7 @@ attention context.  Anything else raises NotImplementedError at construction (th
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Optional
 
@@ -198,6 +199,8 @@ class ConformerEncoder(NeuralModule):
         # --- engine state (not part of the state-dict)
         # linear_pos weights of all layers sit together at the tail: their gradients come from ONE batched GEMM
         self._flatp = FlatParams(self, tail=lambda n: n.endswith("self_attn.linear_pos.weight"))
+        self.wgrad_side_stream = os.environ.get("MI355X_WGRAD_STREAM", "1") != "0"
+        self._wg_stream = None
         self._plans = {}
         self._ws = {}
         self._pos_cache = {}
@@ -316,11 +319,32 @@ class ConformerEncoder(NeuralModule):
         bias_grad[n_out] += column sums of dY -- fused into the same kernel on the bf16 path."""
         bf16 = dY.dtype == torch.bfloat16
         tiles = self._tiles(n_out, n_in, bf16)
-        if bias_grad is not None and not bf16:
-            ops.colsum(dY, bias_grad, rows, n_out, ld=ldy, x_off=y_off)
-        ops.gemm(dY, X, dW, n_out, n_in, rows, ldy, ldx, n_in, transA=True, transB=True, atomic=True,
-                 splitk=self._splitk(tiles, rows), a_off=y_off, b_off=x_off, c_dtype=ops.F32,
-                 colsum_out=bias_grad if bf16 else None)
+        with self._wgrad_scope(dY, X):
+            if bias_grad is not None and not bf16:
+                ops.colsum(dY, bias_grad, rows, n_out, ld=ldy, x_off=y_off)
+            ops.gemm(dY, X, dW, n_out, n_in, rows, ldy, ldx, n_in, transA=True, transB=True, atomic=True,
+                     splitk=self._splitk(tiles, rows), a_off=y_off, b_off=x_off, c_dtype=ops.F32,
+                     colsum_out=bias_grad if bf16 else None)
+
+    # ---- weight gradients on a side stream.  Nothing downstream in backward depends on a weight gradient, and most wgrad
+    # launches leave half the CUs idle (8-32 output tiles x split-K); on their own stream they run next to the HBM-bound
+    # kernels of the main chain (LayerNorm backward, dropout casts, conv-module elementwise) instead of in line with them.
+    def _wgrad_scope(self, *tensors):
+        import contextlib
+        if not self.wgrad_side_stream or not tensors[0].is_cuda:
+            return contextlib.nullcontext()
+        dev = tensors[0].device
+        if self._wg_stream is None or self._wg_stream.device != dev:
+            self._wg_stream = torch.cuda.Stream(device=dev)
+        side = self._wg_stream
+        side.wait_stream(torch.cuda.current_stream(dev))  # operands are produced on the main stream
+        for t in tensors:
+            t.record_stream(side)  # the caching allocator must not hand the storage out again before the side stream is done
+        return torch.cuda.stream(side)
+
+    def _wgrad_join(self):
+        if self._wg_stream is not None:
+            torch.cuda.current_stream(self._wg_stream.device).wait_stream(self._wg_stream)
 
     def _lens(self, length):
         l0 = length.to(torch.int64)
@@ -553,6 +577,7 @@ class ConformerEncoder(NeuralModule):
             dx = self._layer_bwd(i, self.layers[i], dx, S, S.layers[i], W, Wf)
             S.layers[i] = None
             if self.grad_ready_hook is not None:
+                self._wgrad_join()  # the layer's gradients are final only when its side-stream wgrads have run
                 self.grad_ready_hook(*fp.range_of(f"layers.{i}."))
         self._pos_proj_wgrad(S.dp_all, S.pos, P, cdt)
         if self.grad_ready_hook is not None:
@@ -583,6 +608,7 @@ class ConformerEncoder(NeuralModule):
         dout1 = self._buf("dout1", (B, T1, F1, C_), cdt, dev)
         ops.col2im_relu(dcol, S.out1, dout1, B, T1, F1, C_)
         ops.conv1_bwd(dout1, S.mel, S.len0, pe.conv[0].weight.grad, pe.conv[0].bias.grad, C_)
+        self._wgrad_join()
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(*fp.range_of("pre_encode."))
 
@@ -702,9 +728,10 @@ class ConformerEncoder(NeuralModule):
                 and (a.linear_v.bias.grad.data_ptr() - a.linear_k.bias.grad.data_ptr()) // 4 == sb):
             # q, k, v weight (and bias) gradients as ONE batched TN GEMM: the three gradients are equally spaced in the
             # flat gradient buffer, the three dY column blocks equally spaced in dqkv
-            ops.gemm(dqkv, y2, gq, d, d, M, 3 * d, d, d, transA=True, transB=True, atomic=True,
-                     splitk=self._splitk(3 * self._tiles(d, d, True), M), batch=3, nb0=3, sA=(d, 0), sC=(sw, 0),
-                     c_dtype=ops.F32, colsum_out=a.linear_q.bias.grad, colsum_stride=sb)
+            with self._wgrad_scope(dqkv, y2):
+                ops.gemm(dqkv, y2, gq, d, d, M, 3 * d, d, d, transA=True, transB=True, atomic=True,
+                         splitk=self._splitk(3 * self._tiles(d, d, True), M), batch=3, nb0=3, sA=(d, 0), sC=(sw, 0),
+                         c_dtype=ops.F32, colsum_out=a.linear_q.bias.grad, colsum_stride=sb)
         else:
             for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
                 self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M, bias_grad=lin.bias.grad)
