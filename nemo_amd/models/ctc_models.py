@@ -113,6 +113,9 @@ class EncDecCTCModel(nn.Module):
             for mod in (self.encoder, self.decoder):
                 gs = GradSync(mod.flat_parameters().grad)
                 mod.grad_ready_hook = gs.ready
+                if gs.use_side_stream and hasattr(mod, "_wg_stream"):  # weight gradients are produced on their own stream
+                    gs.producer_streams = (lambda m=mod: [m._wg_stream] if m._wg_stream is not None else [])
+                    mod._wgrad_join_per_layer = False
                 self._syncs.append(gs)
         return self._syncs
 

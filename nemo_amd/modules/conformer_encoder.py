@@ -201,6 +201,7 @@ class ConformerEncoder(NeuralModule):
         self._flatp = FlatParams(self, tail=lambda n: n.endswith("self_attn.linear_pos.weight"))
         self.wgrad_side_stream = os.environ.get("MI355X_WGRAD_STREAM", "1") != "0"
         self._wg_stream = None
+        self._wgrad_join_per_layer = True
         self._plans = {}
         self._ws = {}
         self._pos_cache = {}
@@ -577,7 +578,10 @@ class ConformerEncoder(NeuralModule):
             dx = self._layer_bwd(i, self.layers[i], dx, S, S.layers[i], W, Wf)
             S.layers[i] = None
             if self.grad_ready_hook is not None:
-                self._wgrad_join()  # the layer's gradients are final only when its side-stream wgrads have run
+                # the layer's gradients are final only when its side-stream wgrads have run: either the consumer waits for
+                # that stream itself (GradSync.producer_streams) or the backward chain joins here
+                if self._wgrad_join_per_layer:
+                    self._wgrad_join()
                 self.grad_ready_hook(*fp.range_of(f"layers.{i}."))
         self._pos_proj_wgrad(S.dp_all, S.pos, P, cdt)
         if self.grad_ready_hook is not None:

@@ -32,6 +32,9 @@ class GradSync:
         cuda = grad.is_cuda
         self.use_side_stream = cuda if use_side_stream is None else (use_side_stream and cuda)
         self._stream = torch.cuda.Stream(device=grad.device) if self.use_side_stream else None
+        # streams other than the current one that also write gradients (the encoder's weight-gradient stream): the
+        # exchange stream waits for them too, the backward chain itself never does
+        self.producer_streams = lambda: []
 
     # ---- called by the backward sequencer (ranges arrive in reverse-layer order, adjacent ranges are merged)
     def ready(self, start: int, end: int) -> None:
@@ -55,6 +58,8 @@ class GradSync:
             view = self.grad[s:e]
             if self._stream is not None:
                 self._stream.wait_stream(torch.cuda.current_stream(self.grad.device))
+                for ps in self.producer_streams():
+                    self._stream.wait_stream(ps)
                 with torch.cuda.stream(self._stream):
                     self._works.append(dist.all_reduce(view, group=self.group, async_op=True))
             else:
