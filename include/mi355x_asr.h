@@ -189,6 +189,15 @@ int mi355x_row_scale(void* x, const void* vec, long long rows, long long cols, v
 /* ---- optimizer / weight packing (modelPT.py:650-823 AdamW; no reference analogue for packing) ------------------ */
 int mi355x_adamw_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, long long n, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* AdamW with (a) an optional DEVICE scalar clip_coef[0] multiplied into the gradient -- global-norm clipping
+ * (trainer.gradient_clip_val -> torch.nn.utils.clip_grad_norm_) without a host sync -- and (b) an optional EMA of the
+ * weights updated in the same pass: ema = decay*ema + (1-decay)*w_new (nemo/collections/common/callbacks/ema.py:150-157). */
+int mi355x_adamw_step_ex(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, long long n, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int step, float grad_scale, const void* clip_coef,
+                         void* ema, float ema_decay, void* stream);
+/* out_f64[0] += sum(grads^2) ; coef[0] = min(1, max_norm / (scale*sqrt(sum_i sumsq[i]) + 1e-6)), coef[1] = the norm */
+int mi355x_grad_sumsq(const void* grads, long long n, void* out_f64, void* stream);
+int mi355x_clip_coef(const void* sumsq_f64, int nbuf, float scale, float max_norm, void* coef_f32x2, void* stream);
 typedef struct mi355x_pack_entry {
   const void* src; void* dst;       /* src f32; dst[r*pitch + c] = src[r1*sr1 + r2*sr2 + c1*sc1 + c2*sc2]              */
   int rows, cols, nr2, nc2;         /* r = r1*nr2 + r2 ; c = c1*nc2 + c2                                              */

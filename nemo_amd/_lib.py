@@ -84,6 +84,9 @@ SIGNATURES = {
     "mi355x_ctc_loss": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
     "mi355x_row_scale": [vp, vp, i64, i64, vp],
     "mi355x_adamw_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
+    "mi355x_adamw_step_ex": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, vp, f32, vp],
+    "mi355x_grad_sumsq": [vp, i64, vp, vp],
+    "mi355x_clip_coef": [vp, i32, f32, f32, vp, vp],
     "mi355x_pack_weights": [vp, i32, i64, i32, vp],
     "mi355x_fill_f32": [vp, i64, f32, vp],
 }

@@ -8,15 +8,19 @@
 #include "common.cuh"
 #include "mi355x_asr.h"
 
+// gclip: optional device scalar multiplied into the gradient (global-norm clipping coefficient, no host sync);
+// ema: optional exponential moving average of the weights, updated in the same pass (ema.py:150-157)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long long n4, float lr, float beta1, float beta2,
-                                                    float eps, float wd, float bc1, float bc2_sqrt, float grad_scale) {
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float grad_scale,
+                                                    const float* __restrict__ gclip, float* __restrict__ ema, float ema_decay) {
+  const float gs = gclip ? grad_scale * gclip[0] : grad_scale;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     float pp[4], gg[4], mm[4], vv[4];
     ld4(p + i * 4, pp); ld4(g + i * 4, gg); ld4(m + i * 4, mm); ld4(v + i * 4, vv);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float gr = gg[j] * grad_scale;
+      const float gr = gg[j] * gs;
       pp[j] *= (1.f - lr * wd);
       mm[j] = beta1 * mm[j] + (1.f - beta1) * gr;
       vv[j] = beta2 * vv[j] + (1.f - beta2) * gr * gr;
@@ -24,7 +28,35 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       pp[j] -= (lr / bc1) * (mm[j] / denom);
     }
     st4(p + i * 4, pp); st4(m + i * 4, mm); st4(v + i * 4, vv);
+    if (ema) {
+      float ee[4];
+      ld4(ema + i * 4, ee);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ee[j] = ee[j] * ema_decay + (1.f - ema_decay) * pp[j];
+      st4(ema + i * 4, ee);
+    }
   }
+}
+// sum of squares of a flat gradient buffer -> out[0] += (f64); block partials in f32, one f64 atomic per block
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n4, double* __restrict__ out) {
+  __shared__ float red[8];
+  float a = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float x[4];
+    ld4(g + i * 4, x);
+    a += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+  }
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) atomicAdd(out, (double)a);
+}
+// torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (scale * sqrt(sum of the buffers' sums) + 1e-6))
+__global__ void clip_coef_kernel(const double* __restrict__ sumsq, int nbuf, float scale, float max_norm, float* __restrict__ coef) {
+  double t = 0.0;
+  for (int i = 0; i < nbuf; ++i) t += sumsq[i];
+  const float norm = scale * (float)sqrt(t);
+  const float c = max_norm / (norm + 1e-6f);
+  coef[0] = c < 1.f ? c : 1.f;
+  coef[1] = norm;
 }
 
 // dst[r*pitch + c] = cast( src[r1*sr1 + r2*sr2 + c1*sc1 + c2*sc2] ),  r = r1*nr2 + r2,  c = c1*nc2 + c2
@@ -75,17 +107,48 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long l
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = value;
 }
 
-extern "C" int mi355x_adamw_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, long long n, float lr,
-                                 float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                                 void* stream) {
-  mi_clear_errors();
+static int adamw_launch(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, long long n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int step, float grad_scale, const void* gclip, void* ema,
+                        float ema_decay, void* stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || (n & 3) || step < 1) return MI_ERR_ARG;
+  if (ema && !(ema_decay >= 0.f && ema_decay <= 1.f)) return MI_ERR_ARG;
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   long long nb = ((n >> 2) + 255) / 256;
   if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (float*)params, (const float*)grads,
-                     (float*)exp_avg, (float*)exp_avg_sq, n >> 2, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+                     (float*)exp_avg, (float*)exp_avg_sq, n >> 2, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale,
+                     (const float*)gclip, (float*)ema, ema_decay);
+  return mi_check_launch();
+}
+extern "C" int mi355x_adamw_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, long long n, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                 void* stream) {
+  mi_clear_errors();
+  return adamw_launch(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr,
+                      nullptr, 0.f, stream);
+}
+extern "C" int mi355x_adamw_step_ex(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, long long n, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                    const void* clip_coef, void* ema, float ema_decay, void* stream) {
+  mi_clear_errors();
+  return adamw_launch(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, clip_coef,
+                      ema, ema_decay, stream);
+}
+extern "C" int mi355x_grad_sumsq(const void* grads, long long n, void* out_f64, void* stream) {
+  mi_clear_errors();
+  if (!grads || !out_f64 || n <= 0 || (n & 3)) return MI_ERR_ARG;
+  long long nb = ((n >> 2) + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float*)grads, n >> 2,
+                     (double*)out_f64);
+  return mi_check_launch();
+}
+extern "C" int mi355x_clip_coef(const void* sumsq_f64, int nbuf, float scale, float max_norm, void* coef_f32x2, void* stream) {
+  mi_clear_errors();
+  if (!sumsq_f64 || !coef_f32x2 || nbuf <= 0 || !(max_norm > 0.f)) return MI_ERR_ARG;
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const double*)sumsq_f64, nbuf, scale, max_norm,
+                     (float*)coef_f32x2);
   return mi_check_launch();
 }
 

@@ -96,8 +96,13 @@ class EncDecCTCModel(nn.Module):
         name = oc.get("name", "adamw")
         if name != "adamw":
             raise NotImplementedError(f"optimizer '{name}': the Conformer-CTC recipes use adamw")
+        # `gradient_clip_val` is the trainer's key (conformer_ctc_bpe.yaml:204), `ema.decay` the EMA callback's
+        # (exp_manager.ema, nemo/collections/common/callbacks/ema.py:27-62); both ride inside the fused AdamW launch
+        ema = oc.get("ema") or {}
         self._optimizer = FusedAdamW(self.flats(), lr=oc.get("lr", 1e-3), betas=tuple(oc.get("betas", (0.9, 0.999))),
-                                     eps=oc.get("eps", 1e-8), weight_decay=oc.get("weight_decay", 0.0))
+                                     eps=oc.get("eps", 1e-8), weight_decay=oc.get("weight_decay", 0.0),
+                                     max_grad_norm=oc.get("gradient_clip_val") or None,
+                                     ema_decay=ema.get("decay") if ema.get("enable", bool(ema)) else None)
         sched = oc.get("sched")
         if sched:
             if sched.get("name") != "NoamAnnealing":

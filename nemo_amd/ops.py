@@ -332,9 +332,25 @@ def row_scale(x, vec, rows, cols):
     check(lib.mi355x_row_scale(_ptr(x), _ptr(vec), rows, cols, _stream()), "row_scale")
 
 
-def adamw_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
-    check(lib.mi355x_adamw_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), lr, beta1, beta2,
-                                eps, weight_decay, step, grad_scale, _stream()), "adamw_step")
+def adamw_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0,
+               clip_coef=None, ema=None, ema_decay=0.0):
+    if clip_coef is None and ema is None:
+        check(lib.mi355x_adamw_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), lr, beta1,
+                                    beta2, eps, weight_decay, step, grad_scale, _stream()), "adamw_step")
+    else:
+        check(lib.mi355x_adamw_step_ex(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), lr, beta1,
+                                       beta2, eps, weight_decay, step, grad_scale, _ptr(clip_coef), _ptr(ema), ema_decay,
+                                       _stream()), "adamw_step_ex")
+
+
+def grad_sumsq(grads, out_f64):
+    check(lib.mi355x_grad_sumsq(_ptr(grads), grads.numel(), _ptr(out_f64), _stream()), "grad_sumsq")
+
+
+def clip_coef(sumsq_f64, scale, max_norm, coef):
+    check(lib.mi355x_clip_coef(_ptr(sumsq_f64), int(sumsq_f64.numel()), float(scale), float(max_norm), _ptr(coef), _stream()),
+          "clip_coef")
+
 
 
 def pack_weights(table_dev, n_entries, total_tiles, out_dtype):

@@ -46,11 +46,23 @@ class NoamAnnealing:
 
 
 class FusedAdamW:
-    def __init__(self, flats: List[FlatParams], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    """`max_grad_norm` = trainer.gradient_clip_val (global L2 norm over every flat buffer, computed and applied on the
+    device); `ema_decay` = the EMA callback's decay (nemo/collections/common/callbacks/ema.py): the average is updated inside
+    the AdamW launch, `swap_ema_weights()` is the reference's context manager of the same name (ema.py:295-318)."""
+
+    def __init__(self, flats: List[FlatParams], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None,
+                 ema_decay=None):
         self.flats = flats
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = float(max_grad_norm) if max_grad_norm else None
+        if ema_decay is not None and not (0.0 <= ema_decay <= 1.0):
+            raise ValueError("EMA decay value must be between 0 and 1")  # ema.py:49-50
+        self.ema_decay = ema_decay
         self.step_count = 0
         self._state = {}
+        self._ema = {}
+        self._clip = None
+        self.last_grad_norm = None  # device tensor [1] after a clipped step
 
     def _moments(self, fp: FlatParams):
         key = (id(fp), fp.generation)
@@ -61,6 +73,17 @@ class FusedAdamW:
             self._state[key] = st
         return st
 
+    def _ema_of(self, fp: FlatParams):
+        if self.ema_decay is None:
+            return None
+        key = (id(fp), fp.generation)
+        e = self._ema.get(key)
+        if e is None:
+            e = fp.flat.detach().clone()  # the average starts at the current weights (ema.py:263-266)
+            self._ema = {k: v for k, v in self._ema.items() if k[0] != id(fp)}
+            self._ema[key] = e
+        return e
+
     def zero_grad(self):
         for fp in self.flats:
             fp.ensure()
@@ -69,13 +92,66 @@ class FusedAdamW:
     def step(self, lr: float = None, grad_scale: float = 1.0):
         self.step_count += 1
         lr = self.lr if lr is None else lr
+        coef = None
+        if self.max_grad_norm:
+            dev = self.flats[0].flat.device
+            if self._clip is None or self._clip[0].device != dev:
+                self._clip = (torch.zeros(len(self.flats), dtype=torch.float64, device=dev),
+                              torch.zeros(2, dtype=torch.float32, device=dev))
+            sumsq, coef = self._clip
+            sumsq.zero_()
+            for i, fp in enumerate(self.flats):
+                ops.grad_sumsq(fp.grad, sumsq[i:i + 1])
+            ops.clip_coef(sumsq, grad_scale, self.max_grad_norm, coef)
+            self.last_grad_norm = coef[1:2]
         for fp in self.flats:
             m, v = self._moments(fp)
             ops.adamw_step(fp.flat, fp.grad, m, v, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                           self.step_count, grad_scale)
+                           self.step_count, grad_scale, clip_coef=coef, ema=self._ema_of(fp),
+                           ema_decay=self.ema_decay or 0.0)
         for fp in self.flats:
             if hasattr(fp.module, "weights_updated"):
                 fp.module.weights_updated()
 
+    def swap_ema_weights(self):
+        """context manager: the modules' parameters hold the EMA weights inside the block (evaluation / checkpointing)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            if self.ema_decay is None:
+                yield
+                return
+            pairs = [(fp, self._ema_of(fp)) for fp in self.flats]
+
+            def swap():
+                for fp, e in pairs:
+                    tmp = fp.flat.detach().clone()
+                    fp.flat.copy_(e)
+                    e.copy_(tmp)
+                    if hasattr(fp.module, "weights_updated"):
+                        fp.module.weights_updated()
+            swap()
+            try:
+                yield
+            finally:
+                swap()
+        return ctx()
+
     def state_dict(self):
-        return {"step": self.step_count, "moments": [tuple(t.clone() for t in self._moments(fp)) for fp in self.flats]}
+        sd = {"step": self.step_count, "moments": [tuple(t.clone() for t in self._moments(fp)) for fp in self.flats]}
+        if self.ema_decay is not None:
+            sd["ema"] = [self._ema_of(fp).clone() for fp in self.flats]
+            sd["decay"] = self.ema_decay
+        return sd
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        for fp, (m, v) in zip(self.flats, sd["moments"]):
+            fp.ensure()
+            mm, vv = self._moments(fp)
+            mm.copy_(m); vv.copy_(v)
+        if self.ema_decay is not None and "ema" in sd:
+            for fp, e in zip(self.flats, sd["ema"]):
+                self._ema_of(fp).copy_(e)
+

@@ -697,6 +697,44 @@ def test_adamw_matches_torch():
     assert rel_err(p, pr) < 1e-5
 
 
+def test_adamw_clip_and_ema_match_torch():
+    """gradient_clip_val + EMA inside the fused launch: against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW +
+    the reference's ema_update (_foreach_mul_/_foreach_add_, ema.py:150-157) over several steps and two flat buffers"""
+    from nemo_amd.flat import FlatParams
+    from nemo_amd.optim import FusedAdamW
+    torch.manual_seed(4)
+    mods = [torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.Linear(96, 32)).to(dev), torch.nn.Linear(32, 8).to(dev)]
+    refs = [torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.Linear(96, 32)).to(dev), torch.nn.Linear(32, 8).to(dev)]
+    for a, b in zip(mods, refs):
+        b.load_state_dict(a.state_dict())
+    flats = [FlatParams(m) for m in mods]
+    for fp in flats:
+        fp.build(dev)
+    opt = FusedAdamW(flats, lr=3e-3, betas=(0.9, 0.98), weight_decay=1e-2, max_grad_norm=0.7, ema_decay=0.9)
+    rparams = [p for r in refs for p in r.parameters()]
+    ropt = torch.optim.AdamW(rparams, lr=3e-3, betas=(0.9, 0.98), weight_decay=1e-2)
+    ema_ref = [p.detach().clone() for p in rparams]
+    g = torch.Generator(device=dev).manual_seed(9)
+    for step in range(5):
+        opt.zero_grad(); ropt.zero_grad()
+        grads = [torch.randn(p.shape, device=dev, generator=g) * (3.0 if step % 2 == 0 else 0.01) for p in rparams]
+        for p, q_, gr in zip([p for m in mods for p in m.parameters()], rparams, grads):
+            p.grad.copy_(gr); q_.grad = gr.clone()
+        total = torch.nn.utils.clip_grad_norm_(rparams, 0.7)
+        ropt.step()
+        torch._foreach_mul_(ema_ref, 0.9); torch._foreach_add_(ema_ref, [p.detach() for p in rparams], alpha=0.1)
+        opt.step()
+        torch.cuda.synchronize()
+        assert abs(opt.last_grad_norm.item() - total.item()) <= 1e-5 * total.item()
+    for p, q_ in zip([p for m in mods for p in m.parameters()], rparams):
+        assert rel_err(p, q_) < 2e-6
+    with opt.swap_ema_weights():
+        for p, e in zip([p for m in mods for p in m.parameters()], ema_ref):
+            assert rel_err(p, e) < 2e-6
+    for p, q_ in zip([p for m in mods for p in m.parameters()], rparams):
+        assert rel_err(p, q_) < 2e-6  # swapped back
+
+
 def test_pack_weights():
     from nemo_amd.packing import PackPlan
     g = torch.Generator().manual_seed(13)
