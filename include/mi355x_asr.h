@@ -59,7 +59,16 @@ typedef struct mi355x_gemm_desc {
   long long colsum_stride;          /* batch stride of colsum_out (elements)                                       */
   void* colsum_out;                 /* optional (bf16, transA=1, single-level batch): f32 [M] += sum_k A(k,m) -- the bias gradient
                                        of a Linear rides along with its weight-gradient GEMM                       */
+  /* Implicit-GEMM convolution on channels-last feature maps (Conv2d of ConvSubsampling, subsampling.py:385-436, without
+   * an im2col buffer).  gather (bf16, transA = 0, batch = 1, C % 64 == 0): row m = (b*nI + i)*nJ + j of A is gathered,
+   * for K index tap*C + c, from A[b][i*si + di[tap]][j*sj + dj[tap]][c] of a [.., SI, SJ, C] grid (zero outside);
+   * K must equal ntaps*C; lda is ignored.  rowmap: row m = (b*nI + i)*nJ + j of C and of aux_in/aux_out is stored at row
+   * (b*OI + i*si + oi)*OJ + j*sj + oj (the dgrad of a strided conv writes one parity class of positions per launch). */
+  const struct mi355x_conv_gather* gather;   /* NULL = dense A */
+  const struct mi355x_row_map* rowmap;       /* NULL = dense C rows */
 } mi355x_gemm_desc;
+typedef struct mi355x_conv_gather { int nI, nJ, SI, SJ, C, si, sj, ntaps; int di[9], dj[9]; } mi355x_conv_gather;
+typedef struct mi355x_row_map { int nI, nJ, OI, OJ, si, sj, oi, oj; } mi355x_row_map;
 int mi355x_gemm(const mi355x_gemm_desc* desc, void* stream);
 
 /* ---- log-mel front-end: FilterbankFeatures.forward, parts/preprocessing/features.py:423-502 --------------------

@@ -32,7 +32,17 @@ class GemmDesc(C.Structure):
         ("drop_key", u32), ("drop_threshold", u32), ("drop_scale", f32),
         ("row_len", vp), ("rows_per_b", i32), ("rows_inner", i32),
         ("colsum_stride", i64), ("colsum_out", vp),
+        ("gather", vp), ("rowmap", vp),
     ]
+
+
+class ConvGather(C.Structure):  # mirrors mi355x_conv_gather
+    _fields_ = [("nI", i32), ("nJ", i32), ("SI", i32), ("SJ", i32), ("C", i32), ("si", i32), ("sj", i32), ("ntaps", i32),
+                ("di", i32 * 9), ("dj", i32 * 9)]
+
+
+class RowMap(C.Structure):  # mirrors mi355x_row_map
+    _fields_ = [("nI", i32), ("nJ", i32), ("OI", i32), ("OJ", i32), ("si", i32), ("sj", i32), ("oi", i32), ("oj", i32)]
 
 
 class PackEntry(C.Structure):

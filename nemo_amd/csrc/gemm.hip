@@ -50,7 +50,22 @@ struct GemmP {
   long long colsum_stride;             // batch stride (z0) of colsum_out
   float* colsum_out;                   // transA only: colsum_out[m] += sum_k A(k, m)  (bias gradient fused into wgrad)
   int vec_ok;                          // C / aux rows are 8-element aligned & dense: vectorised epilogue allowed
+  // implicit-GEMM convolution (channels-last): A row m = (b, i, j) on an [nI x nJ] grid gathers, for K index tap*C + c,
+  // src[b][i*si + di[tap]][j*sj + dj[tap]][c] of a [SI x SJ x C] source grid (zero outside)
+  int g_on, g_nI, g_nJ, g_SI, g_SJ, g_C, g_si, g_sj, g_ntaps;
+  signed char g_di[12], g_dj[12];
+  // output row map: C / aux row of m = (b, i, j) is ((b*OI + i*si + oi)*OJ + j*sj + oj)
+  int r_on, r_nI, r_nJ, r_OI, r_OJ, r_si, r_sj, r_oi, r_oj;
 };
+
+// storage row (C / aux) of logical row m
+__device__ __forceinline__ long long crow(const GemmP& p, int m) {
+  if (!p.r_on) return m;
+  const int per_b = p.r_nI * p.r_nJ;
+  const int b = m / per_b, r = m - b * per_b;
+  const int i = r / p.r_nJ, j = r - i * p.r_nJ;
+  return ((long long)b * p.r_OI + i * p.r_si + p.r_oi) * p.r_OJ + j * p.r_sj + p.r_oj;
+}
 
 __device__ __forceinline__ float ldx(const void* p, long long i, int dt) {
   return dt == MI_DT_F32 ? ((const float*)p)[i] : bf2f(((const bf16_t*)p)[i]);
@@ -60,8 +75,9 @@ __device__ __forceinline__ void stx(void* p, long long i, int dt, float v) {
 }
 
 __device__ __forceinline__ void epilogue(const GemmP& p, int z, long long coff, int m, int n, float acc) {
-  const long long ci = coff + (long long)m * p.ldc + (long long)n * p.csc;
-  const long long ai = coff + (long long)m * p.ldaux + n;  // aux shares the batch offset convention of C
+  const long long mr = crow(p, m);
+  const long long ci = coff + mr * p.ldc + (long long)n * p.csc;
+  const long long ai = coff + mr * p.ldaux + n;  // aux shares the batch offset convention of C
   float v = acc;
   if (p.bias) v += p.bias[n];
   const uint32_t didx = (uint32_t)z * (uint32_t)(p.M * p.N) + (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
@@ -108,8 +124,9 @@ __device__ __forceinline__ void st8x(void* p, long long i, int dt, const float (
   }
 }
 __device__ __forceinline__ void epilogue8(const GemmP& p, int z, long long coff, int m, int n, float (&v)[8]) {
-  const long long ci = coff + (long long)m * p.ldc + n;
-  const long long ai = coff + (long long)m * p.ldaux + n;
+  const long long mr = crow(p, m);
+  const long long ci = coff + mr * p.ldc + n;
+  const long long ai = coff + mr * p.ldaux + n;
   if (p.bias) {
     float b[8];
     ld8x(p.bias, n, MI_DT_F32, b);
@@ -190,7 +207,7 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int m = m_first + it * ROW_STEP;
-      if (m < p.M) ld8x(p.aux_in, coff + (long long)m * p.ldaux + n, EPI == EPI_RESID ? MI_DT_F32 : p.auxin_dt, aux[it]);
+      if (m < p.M) ld8x(p.aux_in, coff + crow(p, m) * p.ldaux + n, EPI == EPI_RESID ? MI_DT_F32 : p.auxin_dt, aux[it]);
     }
   }
 #pragma unroll
@@ -203,8 +220,9 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
     float v[8] = {a.x + b8[0], a.y + b8[1], a.z + b8[2], a.w + b8[3], b.x + b8[4], b.y + b8[5], b.z + b8[6], b.w + b8[7]};
     float dm[8];
     drop_mask8(p.drop, dbase + (uint32_t)m * (uint32_t)p.N, dm);
-    const long long ci = coff + (long long)m * p.ldc + n;
-    const long long ai = coff + (long long)m * p.ldaux + n;
+    const long long mr = crow(p, m);
+    const long long ci = coff + mr * p.ldc + n;
+    const long long ai = coff + mr * p.ldaux + n;
     if (EPI == EPI_STORE) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= p.alpha * dm[j];
@@ -528,6 +546,45 @@ __device__ __forceinline__ void dma_setup(DmaSrc<R>& d, const bf16_t* base, long
   }
   d.step = T ? (long long)BK * ld : (long long)BK;
 }
+// implicit-GEMM gather of a K-contiguous operand: the chunk's row is a conv output position, its pointer the channel
+// vector at the position's origin; per K-tile only the (uniform) tap offset and the bounds test change
+template <int R> struct DmaGather {
+  static constexpr int PER = R * 8 / 512;
+  const bf16_t* org[PER];  // &src[b][i*si][j*sj][chunk*8]
+  int gi[PER], gj[PER];    // i*si, j*sj
+};
+template <int R>
+__device__ __forceinline__ void gather_setup(DmaGather<R>& g, const GemmP& p, const bf16_t* base, int row0) {
+#pragma unroll
+  for (int i = 0; i < DmaGather<R>::PER; ++i) {
+    const int q = threadIdx.x + i * 512;
+    const int r = q >> 3, ck = q & 7;
+    const int gck = ck ^ ((r >> 1) & 7);
+    int m = row0 + r;
+    m = m < p.M ? m : p.M - 1;
+    const int per_b = p.g_nI * p.g_nJ;
+    const int b = m / per_b, rr = m - b * per_b;
+    const int oi = rr / p.g_nJ, oj = rr - oi * p.g_nJ;
+    g.gi[i] = oi * p.g_si; g.gj[i] = oj * p.g_sj;
+    g.org[i] = base + (((long long)b * p.g_SI + g.gi[i]) * p.g_SJ + g.gj[i]) * p.g_C + gck * 8;
+  }
+}
+template <int R>
+__device__ __forceinline__ void gather_issue(const DmaGather<R>& g, const GemmP& p, int kt, bf16_t* lds_tile) {
+  const int wave = threadIdx.x >> 6;
+  const int k0 = kt * BK;
+  const int tap = k0 / p.g_C, c0 = k0 - tap * p.g_C;  // uniform; C % 64 == 0 keeps a K-tile inside one tap
+  const int di = p.g_di[tap], dj = p.g_dj[tap];
+  const long long toff = ((long long)di * p.g_SJ + dj) * p.g_C + c0;
+#pragma unroll
+  for (int i = 0; i < DmaGather<R>::PER; ++i) {
+    const bool ok = (unsigned)(g.gi[i] + di) < (unsigned)p.g_SI && (unsigned)(g.gj[i] + dj) < (unsigned)p.g_SJ;
+    const bf16_t* src = ok ? g.org[i] + toff : reinterpret_cast<const bf16_t*>(g_zero16);
+    bf16_t* dst = lds_tile + (wave * 64 + i * 512) * 8;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+  }
+}
+
 template <int R>
 __device__ __forceinline__ void dma_issue(const DmaSrc<R>& d, int it, int k0, int K, bool ktail, bf16_t* lds_tile) {
   const int wave = threadIdx.x >> 6;
@@ -602,12 +659,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
 
   DmaSrc<BM2> dA;
   DmaSrc<BN> dB;
-  dma_setup<TA, BM2>(dA, A, p.lda, m0, p.M, kt0 * BK);
+  DmaGather<BM2> gA;
+  const bool gatherA = !TA && p.g_on == 1;
+  if (gatherA) gather_setup<BM2>(gA, p, A, m0);
+  else dma_setup<TA, BM2>(dA, A, p.lda, m0, p.M, kt0 * BK);
   dma_setup<TB, BN>(dB, B, p.ldb, n0, p.N, kt0 * BK);
   const bool ktail = (p.K & (BK - 1)) != 0;
   auto issue = [&](int it) {  // it = local tile index
     bf16_t* st = smem2 + (it % 3) * NT2_STAGE;
-    dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
+    if (gatherA) gather_issue<BM2>(gA, p, kt0 + it, st);
+    else dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
     dma_issue<BN>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
   // bias gradient riding along with wgrad: column sums of the A tile, read back from LDS (8 B per lane per k-row group)
@@ -827,12 +888,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
 
   DmaSrc<BM2> dA;
   DmaSrc<BN4> dB;
-  dma_setup<TA, BM2>(dA, A, p.lda, m0, p.M, kt0 * BK);
+  DmaGather<BM2> gA;
+  const bool gatherA = !TA && p.g_on == 1;
+  if (gatherA) gather_setup<BM2>(gA, p, A, m0);
+  else dma_setup<TA, BM2>(dA, A, p.lda, m0, p.M, kt0 * BK);
   dma_setup<TB, BN4>(dB, B, p.ldb, n0, p.N, kt0 * BK);
   const bool ktail = (p.K & (BK - 1)) != 0;
   auto issue = [&](int it) {
     bf16_t* st = smem4 + (it & 1) * NT4_STAGE;
-    dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
+    if (gatherA) gather_issue<BM2>(gA, p, kt0 + it, st);
+    else dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
     dma_issue<BN4>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
   const bool do_colsum = TA && p.colsum_out != nullptr && tile_n == 0;
@@ -996,6 +1061,22 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   p.ldaux = d->ldaux;
   p.drop.key = d->drop_key; p.drop.threshold = d->drop_threshold; p.drop.scale = d->drop_scale;
   p.colsum_out = (float*)d->colsum_out; p.colsum_stride = d->colsum_stride;
+  p.g_on = 0; p.r_on = 0;
+  if (d->gather) {
+    const mi355x_conv_gather& g = *d->gather;
+    if (d->in_dtype != MI_DT_BF16 || d->transA || p.batch != 1 || g.C <= 0 || (g.C & 63) || g.ntaps < 1 || g.ntaps > 9 ||
+        g.nI <= 0 || g.nJ <= 0 || g.SI <= 0 || g.SJ <= 0 || d->K != g.ntaps * g.C || d->M % (g.nI * g.nJ) != 0)
+      return MI_ERR_ARG;
+    p.g_on = 1; p.g_nI = g.nI; p.g_nJ = g.nJ; p.g_SI = g.SI; p.g_SJ = g.SJ; p.g_C = g.C; p.g_si = g.si; p.g_sj = g.sj;
+    p.g_ntaps = g.ntaps;
+    for (int t = 0; t < g.ntaps; ++t) { p.g_di[t] = (signed char)g.di[t]; p.g_dj[t] = (signed char)g.dj[t]; }
+  }
+  if (d->rowmap) {
+    const mi355x_row_map& r = *d->rowmap;
+    if (r.nI <= 0 || r.nJ <= 0 || r.OI <= 0 || r.OJ <= 0 || d->M % (r.nI * r.nJ) != 0 || p.batch != 1) return MI_ERR_ARG;
+    p.r_on = 1; p.r_nI = r.nI; p.r_nJ = r.nJ; p.r_OI = r.OI; p.r_OJ = r.OJ; p.r_si = r.si; p.r_sj = r.sj; p.r_oi = r.oi;
+    p.r_oj = r.oj;
+  }
   p.row_len = (const long long*)d->row_len; p.rows_per_b = d->rows_per_b > 0 ? d->rows_per_b : 1;
   p.rows_inner = d->rows_inner > 0 ? d->rows_inner : 1;
   if (p.epi < EPI_STORE || p.epi > EPI_MUL_POS) return MI_ERR_ARG;
@@ -1030,7 +1111,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
     // k in [K, roundup8(K)) must be finite (zero) in memory.  Reduction-major operands need pitch >= roundup8(rows):
     // a partial chunk's extra columns only feed output rows/cols >= M/N, which are never stored.
     const int K8 = (p.K + 7) & ~7;
-    if (!p.transA && p.lda < K8) return MI_ERR_ARG;
+    if (!p.transA && !p.g_on && p.lda < K8) return MI_ERR_ARG;
     if (!p.transB && p.ldb < K8) return MI_ERR_ARG;
     if (p.transA && p.lda < ((p.M + 7) & ~7)) return MI_ERR_ARG;
     if (p.transB && p.ldb < ((p.N + 7) & ~7)) return MI_ERR_ARG;
@@ -1038,6 +1119,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
     dim3 grid(tm * tn, sk, p.batch);
     static int use_v2 = -1;
     if (use_v2 < 0) { const char* e = getenv("MI355X_GEMM_V2"); use_v2 = (e && e[0] == '0') ? 0 : 1; }
+    if (p.g_on && !(use_v2 && p.M >= 192 && p.N >= 96)) return MI_ERR_ARG;  // the gather lives in the LDS-DMA structures
     if (use_v2 && p.M >= 192 && p.N >= 96 && !(p.transA && !p.transB)) {
       const int tm2 = (p.M + BM2 - 1) / BM2;
       const int shm = 3 * NT2_STAGE * 2;

@@ -10,7 +10,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import GemmDesc, PackEntry, check, lib
+from ._lib import ConvGather, GemmDesc, PackEntry, RowMap, check, lib
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_SWISH_DROP, EPI_RESID, EPI_DSWISH, EPI_RELU_MASK, EPI_MUL_POS = range(6)
@@ -59,7 +59,8 @@ GEMM_PROFILE = None
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=False, transB=False, in_dtype=None, c_dtype=None, batch=1, nb0=0,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, alpha=1.0, epi=EPI_STORE, atomic=False, splitk=1, aux_in=None,
          aux_out=None, ldaux=0, drop: Dropout = NO_DROP, row_len=None, rows_per_b=1, rows_inner=1,
-         a_off=0, b_off=0, c_off=0, c_col_stride=1, colsum_out=None, colsum_off=0, colsum_stride=0):
+         a_off=0, b_off=0, c_off=0, c_col_stride=1, colsum_out=None, colsum_off=0, colsum_stride=0, gather=None,
+         rowmap=None):
     """C[M,N] = epi(A @ B^T) -- see mi355x_gemm.  A/B/Cm are tensors whose storage holds the (strided) operands;
     *_off are element offsets into them (head / column slices)."""
     d = GemmDesc()
@@ -90,6 +91,20 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=False, transB=False, in_dty
     d.rows_per_b, d.rows_inner = rows_per_b, rows_inner
     d.colsum_out = (_ptr(colsum_out) + 4 * colsum_off) if colsum_out is not None else 0
     d.colsum_stride = colsum_stride
+    keep = []
+    if gather is not None:  # dict(nI, nJ, SI, SJ, C, si, sj, taps=[(di, dj), ...]): implicit-GEMM gather of the A operand
+        g = ConvGather()
+        g.nI, g.nJ, g.SI, g.SJ, g.C, g.si, g.sj = (gather[k] for k in ("nI", "nJ", "SI", "SJ", "C", "si", "sj"))
+        g.ntaps = len(gather["taps"])
+        for t, (di, dj) in enumerate(gather["taps"]):
+            g.di[t], g.dj[t] = di, dj
+        keep.append(g)
+        d.gather = C.cast(C.pointer(g), C.c_void_p)
+    if rowmap is not None:  # dict(nI, nJ, OI, OJ, si, sj, oi, oj): scattered C / aux rows
+        r = RowMap()
+        r.nI, r.nJ, r.OI, r.OJ, r.si, r.sj, r.oi, r.oj = (rowmap[k] for k in ("nI", "nJ", "OI", "OJ", "si", "sj", "oi", "oj"))
+        keep.append(r)
+        d.rowmap = C.cast(C.pointer(r), C.c_void_p)
     if GEMM_PROFILE is None:
         check(lib.mi355x_gemm(C.byref(d), _stream()), "gemm")
         return

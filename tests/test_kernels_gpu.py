@@ -599,6 +599,51 @@ def test_subsampling_pieces(dtype):
     assert rel_err(din, ref_din) < 2 * tol
 
 
+@pytest.mark.parametrize("T1,F1", [(61, 40), (38, 17)])
+def test_conv2_implicit_gemm_forward_and_dgrad(T1, F1):
+    """Conv2d(C->C, 3x3, stride 2, pad 1) of ConvSubsampling as an implicit GEMM (gathered A operand, no im2col) and its
+    input gradient as four parity-class implicit GEMMs with scattered output rows + ReLU gate (no col2im), against
+    torch conv2d / autograd on the same bf16-rounded operands."""
+    o = ops()
+    Bn, C_ = 3, 128  # (the gather lives in the LDS-DMA GEMM structures: N >= 96)
+    g = torch.Generator().manual_seed(17)
+    T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+    x = bf(torch.relu(torch.randn(Bn, T1, F1, C_, generator=g)))               # post-ReLU activations: ~half are zero
+    w2 = bf(torch.randn(C_, C_, 3, 3, generator=g) * 0.1)
+    b2 = torch.randn(C_, generator=g) * 0.1
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.conv2d(xr, w2.float(), b2, stride=2, padding=1)                     # [B,C,T2,F2]
+    # forward: gather taps (kh-1, kw-1), K order (kh, kw, ci) = the packed weight image [co][(kh,kw,ci)]
+    w2p = w2.permute(0, 2, 3, 1).reshape(C_, 9 * C_).contiguous()
+    M2 = Bn * T2 * F2
+    out2 = torch.empty(M2, C_, device=dev, dtype=torch.float32)
+    taps = [(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]
+    o.gemm(x.to(dev), w2p.to(dev), out2, M2, C_, 9 * C_, C_, 9 * C_, C_, bias=b2.to(dev),
+           gather=dict(nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2, taps=taps))
+    assert rel_err(out2, ref.permute(0, 2, 3, 1).reshape(M2, C_)) < 2e-3
+    # dgrad: dx[b,t1,f1,ci] = (x > 0) * sum_{taps of the parity class} dy[b, i+dt, j+df, :] . W[:, ci, kh, kw]
+    dy = bf(torch.randn(Bn, T2, F2, C_, generator=g))
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    ref_dx = xr.grad.permute(0, 2, 3, 1) * (x.float() > 0)
+    dx = torch.full((Bn, T1, F1, C_), float("nan"), device=dev, dtype=torch.bfloat16)
+    xd, dyd = x.to(dev), dy.to(dev)
+    for pt in (0, 1):
+        for pf in (0, 1):
+            nI, nJ = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
+            khs = [1] if pt == 0 else [0, 2]
+            kws = [1] if pf == 0 else [0, 2]
+            slots = [(kh, kw) for kh in khs for kw in kws]
+            taps_d = [(1 if kh == 0 else 0, 1 if kw == 0 else 0) for kh, kw in slots]
+            wimg = torch.cat([w2[:, :, kh, kw].t() for kh, kw in slots], dim=1).contiguous()   # [ci][(slot, co)]
+            K = len(slots) * C_
+            o.gemm(dyd, wimg.to(dev), dx, Bn * nI * nJ, C_, K, C_, K, C_, epi=o.EPI_MUL_POS, aux_in=xd, ldaux=C_,
+                   gather=dict(nI=nI, nJ=nJ, SI=T2, SJ=F2, C=C_, si=1, sj=1, taps=taps_d),
+                   rowmap=dict(nI=nI, nJ=nJ, OI=T1, OJ=F1, si=2, sj=2, oi=pt, oj=pf))
+    torch.cuda.synchronize()
+    assert not torch.isnan(dx.float()).any()
+    assert rel_err(dx, ref_dx) < 1e-2
+
+
 # ---------------------------------------------------------------------------------------------- mel front-end
 def _fb_sparse(fb):
     from nemo_amd.modules.audio_preprocessing import sparsify_filterbank
