@@ -120,9 +120,14 @@ def main():
 
     roof = None
     if rank == 0 and not a.no_roofline:
+        # per-launch durations need the kernels one after another: the weight-gradient side stream (which overlaps wgrad
+        # GEMMs with the HBM-bound kernels in the timed steps above) is switched off for this one instrumented step
+        side = getattr(model.encoder, "wgrad_side_stream", False)
+        model.encoder.wgrad_side_stream = False
         ops.GEMM_PROFILE = []
         model.fit_step(batch)
         torch.cuda.synchronize()
+        model.encoder.wgrad_side_stream = side
         agg = {}
         for (variant, M, N, K, nb, e0, e1) in ops.GEMM_PROFILE:
             g = agg.setdefault(variant, [0.0, 0.0, 0])
