@@ -23,14 +23,12 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
 __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logp, const long long* __restrict__ targets,
                                                   const long long* __restrict__ in_len, const long long* __restrict__ tgt_len,
                                                   float* __restrict__ alpha_ws, float* __restrict__ beta_ws,
-                                                  float* __restrict__ nll_out, float* __restrict__ grad, int Tmax, int C,
-                                                  int Umax, int Smax, int blank, float grad_scale, int zero_infinity) {
+                                                  float* __restrict__ nll_out, int Tmax, int C, int Umax, int Smax, int blank,
+                                                  int zero_infinity) {
   extern __shared__ float sm[];
   int* ext = (int*)sm;                 // [Smax]
   float* prev_a = sm + Smax;           // [2][Smax]
   float* prev_b = prev_a + 2 * Smax;   // [2][Smax]
-  float* acc = prev_b + 2 * Smax;      // [4][C]
-  __shared__ float s_nll;
 
   const int b = blockIdx.x;
   const int T = (int)min((long long)Tmax, in_len[b]);
@@ -39,12 +37,9 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logp
   const float* lp = logp + (long long)b * Tmax * C;
   float* aw = alpha_ws + (long long)b * Tmax * Smax;
   float* bw = beta_ws + (long long)b * Tmax * Smax;
-  float* g = grad ? grad + (long long)b * Tmax * C : nullptr;
   const int tid = threadIdx.x;
 
   for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? (int)targets[(long long)b * Umax + (s >> 1)] : blank;
-  // zero the gradient rows up front (frames >= T stay zero)
-  if (g) for (int i = tid; i < Tmax * C; i += 256) g[i] = 0.f;
   __syncthreads();
 
   if (T <= 0) {  // empty input: feasible only for an empty target
@@ -57,32 +52,50 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logp
   const int ht = tid & 127;
   float* prev = is_beta ? prev_b : prev_a;
   float* ws = is_beta ? bw : aw;
-  for (int step = 0; step < T; ++step) {
+  // The emission term lp[t, ext[s]] does not depend on the recursion: it is fetched four time-steps ahead into a register
+  // ring (a global load per step on the critical path was ~1 us x 501 steps = the whole kernel).  Ring slot = step & 3;
+  // the loop is unrolled by 4 so that the slot is a compile-time register.
+  const int cls0 = (ht < S) ? ext[ht] : blank;
+  auto emit = [&](int step) -> float {
     const int t = is_beta ? (T - 1 - step) : step;
-    float* cur = prev + ((step & 1) ? Smax : 0);
-    const float* old = prev + ((step & 1) ? 0 : Smax);
-    for (int s = ht; s < S; s += 128) {
-      float v;
-      const int cls = ext[s];
-      if (step == 0) {
-        if (!is_beta) v = (s < 2) ? lp[cls] : NEGINF;
-        else v = (s >= S - 2) ? lp[(long long)t * C + cls] : NEGINF;
-      } else {
-        float a = old[s], bb, c = NEGINF;
-        if (!is_beta) {
-          bb = (s >= 1) ? old[s - 1] : NEGINF;
-          if (s >= 2 && cls != blank && cls != ext[s - 2]) c = old[s - 2];
-        } else {
-          bb = (s + 1 < S) ? old[s + 1] : NEGINF;
-          if (s + 2 < S && cls != blank && cls != ext[s + 2]) c = old[s + 2];
+    return (step < T && ht < S) ? lp[(long long)t * C + cls0] : 0.f;
+  };
+  float ring[4] = {emit(0), emit(1), emit(2), emit(3)};
+  for (int step0 = 0; step0 < T; step0 += 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int step = step0 + k;
+      if (step < T) {  // uniform over the workgroup
+        const float e0 = ring[k];
+        ring[k] = emit(step + 4);
+        const int t = is_beta ? (T - 1 - step) : step;
+        float* cur = prev + ((step & 1) ? Smax : 0);
+        const float* old = prev + ((step & 1) ? 0 : Smax);
+        for (int s = ht; s < S; s += 128) {
+          float v;
+          const int cls = (s == ht) ? cls0 : ext[s];
+          const float e = (s == ht) ? e0 : lp[(long long)t * C + cls];
+          if (step == 0) {
+            if (!is_beta) v = (s < 2) ? e : NEGINF;
+            else v = (s >= S - 2) ? e : NEGINF;
+          } else {
+            float a = old[s], bb, c = NEGINF;
+            if (!is_beta) {
+              bb = (s >= 1) ? old[s - 1] : NEGINF;
+              if (s >= 2 && cls != blank && cls != ext[s - 2]) c = old[s - 2];
+            } else {
+              bb = (s + 1 < S) ? old[s + 1] : NEGINF;
+              if (s + 2 < S && cls != blank && cls != ext[s + 2]) c = old[s + 2];
+            }
+            const float m = lse3(a, bb, c);
+            v = (m == NEGINF) ? NEGINF : m + e;
+          }
+          cur[s] = v;
+          ws[(long long)t * Smax + s] = v;
         }
-        const float m = lse3(a, bb, c);
-        v = (m == NEGINF) ? NEGINF : m + lp[(long long)t * C + cls];
+        __syncthreads();
       }
-      cur[s] = v;
-      ws[(long long)t * Smax + s] = v;
     }
-    __syncthreads();
   }
   // log-likelihood from the last alpha row (= row (T-1)&1 of prev_a)
   if (tid == 0) {
@@ -90,25 +103,49 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logp
     const float l1 = last[S - 1], l2 = (S > 1) ? last[S - 2] : NEGINF;
     const float m = fmaxf(l1, l2);
     float ll = (m == NEGINF) ? NEGINF : m + logf(expf(l1 - m) + expf(l2 - m));
-    s_nll = -ll;
     float out = -ll;
     if (out == INFINITY && zero_infinity) out = 0.f;
     nll_out[b] = out;
   }
-  __syncthreads();
-  const float nll = s_nll;
-  if (!g || nll == INFINITY) return;  // infeasible: zero gradient (zero_infinity) -- rows already zeroed
+}
 
-  // ---------------- phase 2: gradient rows, one wave per time-step
-  const int wave = tid >> 6, lane = tid & 63;
+// ---------------- phase 2: gradient rows.  Its own launch: the lattice phase is sequential in T and occupies one workgroup per
+// utterance (32 CUs at the headline batch), the gradient rows are independent -- grid (time blocks, B), one wave per time-step.
+#define CTC_GT 8  // time-steps per workgroup (4 waves x 2)
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ logp, const long long* __restrict__ targets,
+                                                       const long long* __restrict__ in_len, const long long* __restrict__ tgt_len,
+                                                       const float* __restrict__ alpha_ws, const float* __restrict__ beta_ws,
+                                                       float* __restrict__ grad, int Tmax, int C, int Umax, int Smax, int blank,
+                                                       float grad_scale) {
+  extern __shared__ float acc[];  // [4][C]
+  const int b = blockIdx.y;
+  const int T = (int)min((long long)Tmax, in_len[b]);
+  const int U = (int)min((long long)Umax, tgt_len[b]);
+  const int S = 2 * U + 1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* lp = logp + (long long)b * Tmax * C;
+  const float* aw = alpha_ws + (long long)b * Tmax * Smax;
+  float nll = INFINITY;  // the un-clamped negative log-likelihood, from the last alpha row (same arithmetic as phase 1)
+  if (T > 0) {
+    const float l1 = aw[(long long)(T - 1) * Smax + S - 1], l2 = (S > 1) ? aw[(long long)(T - 1) * Smax + S - 2] : NEGINF;
+    const float m = fmaxf(l1, l2);
+    nll = -((m == NEGINF) ? NEGINF : m + logf(expf(l1 - m) + expf(l2 - m)));
+  }
+  const float* bw = beta_ws + (long long)b * Tmax * Smax;
+  float* g = grad + (long long)b * Tmax * C;
   float* wacc = acc + wave * C;
-  for (int t = wave; t < T; t += 4) {
+  const bool feasible = T > 0 && nll != INFINITY;  // infeasible (zero_infinity) / empty: zero rows
+  for (int t = blockIdx.x * CTC_GT + wave; t < min(Tmax, (int)(blockIdx.x + 1) * CTC_GT); t += 4) {
+    if (t >= T || !feasible) {  // frames beyond the utterance stay zero
+      for (int c = lane; c < C; c += 64) g[(long long)t * C + c] = 0.f;
+      continue;
+    }
     for (int c = lane; c < C; c += 64) wacc[c] = 0.f;
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS zeroing visible before the adds of this wave
     for (int s = lane; s < S; s += 64) {
       const float ab = aw[(long long)t * Smax + s] + bw[(long long)t * Smax + s];
       if (ab != NEGINF) {
-        const int cls = ext[s];
+        const int cls = (s & 1) ? (int)targets[(long long)b * Umax + (s >> 1)] : blank;
         atomicAdd(&wacc[cls], expf(ab - lp[(long long)t * C + cls] + nll));
       }
     }
@@ -124,10 +161,15 @@ extern "C" int mi355x_ctc_loss(const void* logp, const void* targets, const void
   if (!logp || !targets || !in_len || !tgt_len || !alpha_ws || !beta_ws || !nll) return MI_ERR_ARG;
   if (B <= 0 || Tmax <= 0 || C <= 0 || Umax < 0 || blank < 0 || blank >= C) return MI_ERR_ARG;
   const int Smax = 2 * Umax + 1;
-  const size_t shm = sizeof(float) * ((size_t)Smax * 5 + 4 * (size_t)C);
-  if (shm > 60 * 1024) return MI_ERR_ARG;
+  const size_t shm = sizeof(float) * ((size_t)Smax * 5);
+  if (shm > 60 * 1024 || sizeof(float) * 4 * (size_t)C > 60 * 1024) return MI_ERR_ARG;
   hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(256), shm, (hipStream_t)stream, (const float*)logp, (const long long*)targets,
-                     (const long long*)in_len, (const long long*)tgt_len, (float*)alpha_ws, (float*)beta_ws, (float*)nll,
-                     (float*)grad, Tmax, C, Umax, Smax, blank, grad_scale, zero_infinity);
+                     (const long long*)in_len, (const long long*)tgt_len, (float*)alpha_ws, (float*)beta_ws, (float*)nll, Tmax,
+                     C, Umax, Smax, blank, zero_infinity);
+  if (grad)
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3((Tmax + CTC_GT - 1) / CTC_GT, B), dim3(256), sizeof(float) * 4 * (size_t)C,
+                       (hipStream_t)stream, (const float*)logp, (const long long*)targets, (const long long*)in_len,
+                       (const long long*)tgt_len, (const float*)alpha_ws, (const float*)beta_ws, (float*)grad, Tmax, C, Umax,
+                       Smax, blank, grad_scale);
   return mi_check_launch();
 }

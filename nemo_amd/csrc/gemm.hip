@@ -672,7 +672,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
     dma_issue<BN>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
   // bias gradient riding along with wgrad: column sums of the A tile, read back from LDS (8 B per lane per k-row group)
-  const bool do_colsum = TA && p.colsum_out != nullptr && tile_n == 0;
+  // The tn workgroups of one (tile_m, K slice) stage the same A tile: its 64 k-rows are dealt round-robin to (up to 8 of)
+  // them, so the column-sum work is spread evenly instead of making the tile_n == 0 workgroups the stragglers.
+  const int cs_step = tn < 8 ? tn : 8;
+  const bool do_colsum = TA && p.colsum_out != nullptr && tile_n < cs_step;
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
 #ifdef GEMM_ABLATE
@@ -717,8 +720,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
     }
     if (TA && do_colsum) {  // thread -> (k-group of 8 rows = wave, 4 consecutive columns = lane): 8 x ds_read_b64
       const int col = lane * 4;
-#pragma unroll
-      for (int kr = 0; kr < 8; ++kr) {
+      for (int kr = tile_n; kr < 8; kr += cs_step) {
         const int krow = wave * 8 + kr;
         const int off = krow * BM2 + (((col >> 3) ^ ((krow & 3) << 2)) << 3) + (col & 7);
         const u32x2 v = *reinterpret_cast<const u32x2*>(a_s + off);
@@ -900,7 +902,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
     else dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
     dma_issue<BN4>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
-  const bool do_colsum = TA && p.colsum_out != nullptr && tile_n == 0;
+  const int cs_step = tn < 8 ? tn : 8;  // column-sum rows dealt round-robin to the workgroups sharing this A tile
+  const bool do_colsum = TA && p.colsum_out != nullptr && tile_n < cs_step;
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
   issue(0);
@@ -926,8 +929,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
     }
     if (TA && do_colsum) {  // thread -> (k-group of 8 rows = wave, 4 consecutive columns = lane)
       const int col = lane * 4;
-#pragma unroll
-      for (int kr = 0; kr < 8; ++kr) {
+      for (int kr = tile_n; kr < 8; kr += cs_step) {
         const int krow = wave * 8 + kr;
         const int off = krow * BM2 + (((col >> 3) ^ ((krow & 3) << 2)) << 3) + (col & 7);
         const u32x2 v = *reinterpret_cast<const u32x2*>(a_s + off);
