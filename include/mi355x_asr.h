@@ -70,6 +70,10 @@ typedef struct mi355x_gemm_desc {
 typedef struct mi355x_conv_gather { int nI, nJ, SI, SJ, C, si, sj, ntaps; int di[9], dj[9]; } mi355x_conv_gather;
 typedef struct mi355x_row_map { int nI, nJ, OI, OJ, si, sj, oi, oj; } mi355x_row_map;
 int mi355x_gemm(const mi355x_gemm_desc* desc, void* stream);
+/* Up to 12 independent weight-gradient problems in one launch: every desc must be bf16, transA = transB = 1, atomic
+ * f32 C with dense columns, no bias / aux / epilogue, and share K (the token count); descs[0].splitk applies to all.
+ * colsum_out (the bias gradient) is honoured per problem.  See csrc/gemm.hip: gemm_bf16_grouped_tn_kernel. */
+int mi355x_gemm_grouped(const mi355x_gemm_desc* descs, int n, void* stream);
 
 /* ---- log-mel front-end: FilterbankFeatures.forward, parts/preprocessing/features.py:423-502 --------------------
  * audio f32 [B,S], audio_len i64 [B] -> out f32 [B,n_mels,T] = log(mel_power + log_guard), T = 1 + S/hop.

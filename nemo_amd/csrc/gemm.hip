@@ -616,18 +616,16 @@ __device__ __forceinline__ bf16x8 frag_v2(const bf16_t* tile, int row_tile, int 
   }
 }
 
+// body of the 256x128 structure: workgroup `bid` of the problem's tile grid, K slice `kslice`, batch index `z`
 template <bool TA, bool TB>
-__global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) bf16_t smem2[];  // 3 stages x 48 KiB
+__device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, const int bid, const int kslice, const int z) {
   const int tn = (p.N + BN - 1) / BN, tm = (p.M + BM2 - 1) / BM2;
   const int ntiles = tm * tn;
-  const int bid = blockIdx.x;
   const int q8 = ntiles >> 3, r8 = ntiles & 7;
   const int xcd = bid & 7, idx = bid >> 3;
   const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   const int tile_m = logical / tn, tile_n = logical - tile_m * tn;
   const int m0 = tile_m * BM2, n0 = tile_n * BN;
-  const int z = blockIdx.z;
   const int z0 = z % p.nb0, z1 = z / p.nb0;
   const bf16_t* A = (const bf16_t*)p.A + z0 * p.sA0 + z1 * p.sA1;
   const bf16_t* B = (const bf16_t*)p.B + z0 * p.sB0 + z1 * p.sB1;
@@ -635,7 +633,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
   const int nk_total = (p.K + BK - 1) / BK;
   int kt0 = 0, kt1 = nk_total;
   if (p.splitk > 1) {
-    kt0 = blockIdx.y * p.ktiles_per_split;
+    kt0 = kslice * p.ktiles_per_split;
     kt1 = min(nk_total, kt0 + p.ktiles_per_split);
     if (kt0 >= kt1) return;
   }
@@ -776,10 +774,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
       }
   __syncthreads();
   if (p.atomic) {
-    for (int e = threadIdx.x; e < BM2 * BN; e += 512) {
-      const int row_l = e >> 7, col = e & (BN - 1);
-      const int m = m0 + row_l, n = n0 + col;
-      if (m < p.M && n < p.N) epilogue(p, z, coff, m, n, sC[row_l * LDS_C + col]);
+    // split-K accumulation.  The plain case (no bias / scale / dropout / row map: every weight gradient) is a bare
+    // atomicAdd per element -- the generic per-element epilogue costs ~4x the instructions of the add itself
+    const bool plain = p.epi == EPI_STORE && !p.bias && p.alpha == 1.f && p.drop.threshold == 0u && !p.r_on;
+    if (plain) {
+      float* Cb = (float*)p.C + coff;
+#pragma unroll 4
+      for (int e = threadIdx.x; e < BM2 * BN; e += 512) {
+        const int row_l = e >> 7, col = e & (BN - 1);
+        const int m = m0 + row_l, n = n0 + col;
+        if (m < p.M && n < p.N) atomicAdd(Cb + (long long)m * p.ldc + (long long)n * p.csc, sC[row_l * LDS_C + col]);
+      }
+    } else {
+      for (int e = threadIdx.x; e < BM2 * BN; e += 512) {
+        const int row_l = e >> 7, col = e & (BN - 1);
+        const int m = m0 + row_l, n = n0 + col;
+        if (m < p.M && n < p.N) epilogue(p, z, coff, m, n, sC[row_l * LDS_C + col]);
+      }
     }
     return;
   }
@@ -806,6 +817,44 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
   }
 }
 
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem2[];  // 3 stages x 48 KiB
+  gemm_v2_body<TA, TB>(p, smem2, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- grouped weight gradients: up to GRP_MAX independent TN problems (same K = token count, f32 atomic accumulation)
+// in ONE launch.  A layer's eight weight gradients are 8-32 output tiles each: launched one by one they need split-K 8-16
+// to fill the chip (8-16 atomic passes over every gradient, half-empty launches for the 512x512 ones); together they are
+// 184 tiles, so split-K 4 fills three rounds of the 256 CUs with twice as long K loops and half the atomic traffic.
+#define GRP_MAX 12
+struct GroupP {
+  const void* A[GRP_MAX]; const void* B[GRP_MAX]; void* C[GRP_MAX]; float* colsum[GRP_MAX];
+  int M[GRP_MAX], N[GRP_MAX];
+  long long lda[GRP_MAX], ldb[GRP_MAX], ldc[GRP_MAX];
+  int tile_begin[GRP_MAX + 1];  // prefix sums of the problems' 256x128 tile counts
+  int n, K, splitk, ktiles_per_split;
+};
+__global__ __launch_bounds__(512) void gemm_bf16_grouped_tn_kernel(GroupP g) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem2[];
+  int pi = 0;
+  while (pi + 1 < g.n && (int)blockIdx.x >= g.tile_begin[pi + 1]) ++pi;  // uniform
+  GemmP p;
+  p.A = g.A[pi]; p.B = g.B[pi]; p.C = g.C[pi];
+  p.M = g.M[pi]; p.N = g.N[pi]; p.K = g.K;
+  p.lda = g.lda[pi]; p.ldb = g.ldb[pi]; p.ldc = g.ldc[pi]; p.csc = 1;
+  p.transA = 1; p.transB = 1; p.batch = 1; p.nb0 = 1;
+  p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = 0;
+  p.bias = nullptr; p.alpha = 1.f; p.epi = EPI_STORE; p.c_dt = MI_DT_F32; p.atomic = 1;
+  p.aux_in = nullptr; p.auxin_dt = 0; p.aux_out = nullptr; p.auxout_dt = 0; p.ldaux = 0;
+  p.drop.key = 0u; p.drop.threshold = 0u; p.drop.scale = 1.f;
+  p.row_len = nullptr; p.rows_per_b = 1; p.rows_inner = 1;
+  p.splitk = g.splitk; p.ktiles_per_split = g.ktiles_per_split;
+  p.colsum_stride = 0; p.colsum_out = g.colsum[pi];
+  p.vec_ok = 0; p.g_on = 0; p.r_on = 0;
+  gemm_v2_body<true, true>(p, smem2, (int)blockIdx.x - g.tile_begin[pi], blockIdx.y, 0);
+}
+
 // =================================================================================================
 // Third structure, for problems with enough 256x256 tiles (N >= 1024 outputs, conv2, split-K wgrad): 256x256x64 block
 // tile, 8 waves as 2(M) x 4(N), each 128x64 (8 accumulators).  The 256x128 structure above is bound by its LDS traffic --
@@ -827,10 +876,16 @@ __device__ __forceinline__ void v4_round_out(const GemmP& p, const float* sC, in
     fast_epilogue_any<2, 16, BN4>(p, sC, z, coff, m0 + i * 32 + rl0, n0, rl0);
     fast_epilogue_any<2, 16, BN4>(p, sC + 32 * LDS_C, z, coff, m0 + 128 + i * 32 + rl0, n0, rl0);
   } else if (p.atomic) {
+    const bool plain = p.epi == EPI_STORE && !p.bias && p.alpha == 1.f && p.drop.threshold == 0u && !p.r_on;
+    float* Cb = (float*)p.C + coff;
+#pragma unroll 4
     for (int e = threadIdx.x; e < 64 * BN4; e += 512) {
       const int rl = e >> 8, col = e & (BN4 - 1);
       const int m = m0 + (rl >> 5) * 128 + i * 32 + (rl & 31), n = n0 + col;
-      if (m < p.M && n < p.N) epilogue(p, z, coff, m, n, sC[rl * LDS_C + col]);
+      if (m < p.M && n < p.N) {
+        if (plain) atomicAdd(Cb + (long long)m * p.ldc + (long long)n * p.csc, sC[rl * LDS_C + col]);
+        else epilogue(p, z, coff, m, n, sC[rl * LDS_C + col]);
+      }
     }
   } else {
     for (int it = 0; it < 4; ++it) {
@@ -1180,3 +1235,41 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   }
   return mi_check_launch();
 }
+
+extern "C" int mi355x_gemm_grouped(const mi355x_gemm_desc* descs, int n, void* stream) {
+  mi_clear_errors();
+  if (!descs || n < 1 || n > GRP_MAX) return MI_ERR_ARG;
+  GroupP g;
+  g.n = n; g.K = descs[0].K;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const mi355x_gemm_desc& d = descs[i];
+    if (!d.A || !d.B || !d.C || d.M <= 0 || d.N <= 0 || d.K != g.K || d.K <= 0) return MI_ERR_ARG;
+    if (d.in_dtype != MI_DT_BF16 || d.c_dtype != MI_DT_F32 || !d.transA || !d.transB || !d.atomic) return MI_ERR_ARG;
+    if (d.batch > 1 || d.bias || d.aux_in || d.aux_out || d.gather || d.rowmap || d.epilogue != EPI_STORE) return MI_ERR_ARG;
+    if (d.alpha != 1.f || d.c_col_stride > 1 || d.drop_threshold != 0u) return MI_ERR_ARG;
+    if ((d.lda & 7) || (d.ldb & 7) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) return MI_ERR_ARG;
+    if (d.lda < ((d.M + 7) & ~7) || d.ldb < ((d.N + 7) & ~7)) return MI_ERR_ARG;
+    g.A[i] = d.A; g.B[i] = d.B; g.C[i] = d.C; g.colsum[i] = (float*)d.colsum_out;
+    g.M[i] = d.M; g.N[i] = d.N; g.lda[i] = d.lda; g.ldb[i] = d.ldb; g.ldc[i] = d.ldc;
+    g.tile_begin[i] = tiles;
+    tiles += ((d.M + BM2 - 1) / BM2) * ((d.N + BN - 1) / BN);
+  }
+  for (int i = n; i <= GRP_MAX; ++i) g.tile_begin[i] = tiles;
+  const int nk = (g.K + BK - 1) / BK;
+  int sk = descs[0].splitk > 1 ? descs[0].splitk : 1;
+  if (sk > nk) sk = nk;
+  g.ktiles_per_split = (nk + sk - 1) / sk;
+  sk = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
+  g.splitk = sk;
+  const int shm = 3 * NT2_STAGE * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_bf16_grouped_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm) !=
+        hipSuccess) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_grouped_tn_kernel, dim3(tiles, sk, 1), dim3(512), shm, (hipStream_t)stream, g);
+  return mi_check_launch();
+}
+

@@ -202,6 +202,8 @@ class ConformerEncoder(NeuralModule):
         self.wgrad_side_stream = os.environ.get("MI355X_WGRAD_STREAM", "1") != "0"
         self._wg_stream = None
         self._wgrad_join_per_layer = True
+        self.wgrad_grouped = os.environ.get("MI355X_WGRAD_GROUPED", "1") != "0"
+        self._wg_pending, self._wg_rows = None, None
         self.conv2_fwd_implicit = os.environ.get("MI355X_CONV2_FWD_IMPLICIT", "0") == "1"
         self._plans = {}
         self._ws = {}
@@ -338,6 +340,14 @@ class ConformerEncoder(NeuralModule):
         """dW[n_out, n_in] += dY[:, y_off:y_off+n_out]^T @ X[:, x_off:x_off+n_in]   (TN GEMM, atomic split-K);
         bias_grad[n_out] += column sums of dY -- fused into the same kernel on the bf16 path."""
         bf16 = dY.dtype == torch.bfloat16
+        if (self._wg_pending is not None and bf16 and n_out >= 192 and n_in >= 96 and ldy % 8 == 0 and ldx % 8 == 0
+                and (self._wg_rows is None or self._wg_rows == rows)):
+            # deferred: all weight gradients of the layer go out as ONE grouped launch (_wgrad_flush)
+            self._wg_pending.append((dY, ldy, y_off, X, ldx, x_off, dW, n_out, n_in, bias_grad))
+            self._wg_rows = rows
+            if len(self._wg_pending) == 12:
+                self._wgrad_flush()
+            return
         tiles = self._tiles(n_out, n_in, bf16)
         with self._wgrad_scope(dY, X):
             if bias_grad is not None and not bf16:
@@ -361,6 +371,21 @@ class ConformerEncoder(NeuralModule):
         for t in tensors:
             t.record_stream(side)  # the caching allocator must not hand the storage out again before the side stream is done
         return torch.cuda.stream(side)
+
+    def _wgrad_flush(self):
+        """launch the collected weight gradients of a layer as one grouped TN GEMM (side stream)"""
+        pend = self._wg_pending
+        if not pend:
+            return
+        rows = self._wg_rows
+        tiles = sum(((q[7] + 255) // 256) * ((q[8] + 127) // 128) for q in pend)
+        nk = (rows + 63) // 64
+        # split-K: about three rounds of the 256 CUs, at least 16 K-tiles per workgroup
+        sk = max(1, min(nk // 16, (3 * 256 + tiles - 1) // tiles, 16))
+        tensors = [t for q in pend for t in (q[0], q[3])]
+        with self._wgrad_scope(*tensors):
+            ops.wgrad_grouped(pend, rows, sk)
+        self._wg_pending, self._wg_rows = [], None
 
     def _wgrad_join(self):
         if self._wg_stream is not None:
@@ -602,8 +627,10 @@ class ConformerEncoder(NeuralModule):
         S.dp_all = self._buf("dp_all", (self.n_layers, P, d), cdt, dev)
         S.bn_sums = torch.zeros(self.n_layers, 2, d, dtype=torch.float64, device=dev)
         S.dpos_f32 = torch.zeros(self.n_layers, P, d, dtype=torch.float32, device=dev)
+        self._wg_pending = [] if (self.wgrad_grouped and cdt == torch.bfloat16) else None
         for i in range(self.n_layers - 1, -1, -1):
             dx = self._layer_bwd(i, self.layers[i], dx, S, S.layers[i], W, Wf)
+            self._wgrad_flush()
             S.layers[i] = None
             if self.grad_ready_hook is not None:
                 # the layer's gradients are final only when its side-stream wgrads have run: either the consumer waits for
@@ -611,6 +638,7 @@ class ConformerEncoder(NeuralModule):
                 if self._wgrad_join_per_layer:
                     self._wgrad_join()
                 self.grad_ready_hook(*fp.range_of(f"layers.{i}."))
+        self._wg_pending = None  # (the remaining weight gradients have their own shapes / layouts)
         self._pos_proj_wgrad(S.dp_all, S.pos, P, cdt)
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(*fp.tail_range())
@@ -774,10 +802,14 @@ class ConformerEncoder(NeuralModule):
                 and (a.linear_v.bias.grad.data_ptr() - a.linear_k.bias.grad.data_ptr()) // 4 == sb):
             # q, k, v weight (and bias) gradients as ONE batched TN GEMM: the three gradients are equally spaced in the
             # flat gradient buffer, the three dY column blocks equally spaced in dqkv
-            with self._wgrad_scope(dqkv, y2):
-                ops.gemm(dqkv, y2, gq, d, d, M, 3 * d, d, d, transA=True, transB=True, atomic=True,
-                         splitk=self._splitk(3 * self._tiles(d, d, True), M), batch=3, nb0=3, sA=(d, 0), sC=(sw, 0),
-                         c_dtype=ops.F32, colsum_out=a.linear_q.bias.grad, colsum_stride=sb)
+            if self._wg_pending is not None:  # three more problems of the layer's grouped launch
+                for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
+                    self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M, bias_grad=lin.bias.grad)
+            else:
+                with self._wgrad_scope(dqkv, y2):
+                    ops.gemm(dqkv, y2, gq, d, d, M, 3 * d, d, d, transA=True, transB=True, atomic=True,
+                             splitk=self._splitk(3 * self._tiles(d, d, True), M), batch=3, nb0=3, sA=(d, 0), sC=(sw, 0),
+                             c_dtype=ops.F32, colsum_out=a.linear_q.bias.grad, colsum_stride=sb)
         else:
             for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
                 self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M, bias_grad=lin.bias.grad)

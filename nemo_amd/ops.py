@@ -56,6 +56,27 @@ NO_DROP = Dropout()
 GEMM_PROFILE = None
 
 
+def wgrad_grouped(problems, rows, splitk):
+    """problems: list of (dY, ldy, y_off, X, ldx, x_off, dW, n_out, n_in, bias_grad_or_None);
+    dW[n_out, n_in] += dY[:, y_off:+n_out]^T @ X[:, x_off:+n_in] for all of them in ONE launch (bf16 in, f32 atomics)."""
+    n = len(problems)
+    arr = (GemmDesc * n)()
+    for d, (dY, ldy, y_off, X, ldx, x_off, dW, n_out, n_in, bias_grad) in zip(arr, problems):
+        d.A = _ptr(dY) + y_off * dY.element_size()
+        d.B = _ptr(X) + x_off * X.element_size()
+        d.C = _ptr(dW)
+        d.M, d.N, d.K = n_out, n_in, rows
+        d.lda, d.ldb, d.ldc = ldy, ldx, n_in
+        d.c_col_stride = 1
+        d.transA = d.transB = 1
+        d.in_dtype, d.c_dtype = BF16, F32
+        d.batch = d.nb0 = 1
+        d.alpha = 1.0
+        d.epilogue, d.atomic, d.splitk = EPI_STORE, 1, splitk
+        d.colsum_out = _ptr(bias_grad) if bias_grad is not None else 0
+    check(lib.mi355x_gemm_grouped(arr, n, _stream()), "gemm_grouped")
+
+
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=False, transB=False, in_dtype=None, c_dtype=None, batch=1, nb0=0,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, alpha=1.0, epi=EPI_STORE, atomic=False, splitk=1, aux_in=None,
          aux_out=None, ldaux=0, drop: Dropout = NO_DROP, row_len=None, rows_per_b=1, rows_inner=1,

@@ -154,6 +154,34 @@ def test_gemm_wgrad_fused_bias_grad():
     assert rel_err(db, 1 + dY[:, :200].float().sum(0)) < 1e-4
 
 
+def test_gemm_grouped_weight_gradients():
+    """several weight-gradient problems (dW += dY^T X, bias gradient riding along) in ONE launch == one by one"""
+    o = ops()
+    g = torch.Generator().manual_seed(23)
+    rows = 1500
+    shapes = [(512, 256), (256, 512), (192, 128), (640, 96), (256, 256)]
+    probs, refs = [], []
+    dYall = bf(torch.randn(rows, 1024, generator=g)).to(dev)  # two problems slice columns of one matrix (q/k/v style)
+    for i, (n_out, n_in) in enumerate(shapes):
+        X = bf(torch.randn(rows, n_in, generator=g)).to(dev)
+        if i < 2:
+            dY, ldy, off = dYall, 1024, i * 512
+            dYv = dYall[:, off:off + n_out]
+        else:
+            dY = bf(torch.randn(rows, n_out, generator=g)).to(dev); ldy, off = n_out, 0
+            dYv = dY
+        dW = torch.randn(n_out, n_in, generator=g).to(dev)          # accumulate onto existing content
+        db = torch.randn(n_out, generator=g).to(dev) if i % 2 == 0 else None
+        refs.append((dW.clone() + dYv.float().t() @ X.float(), None if db is None else db.clone() + dYv.float().sum(0)))
+        probs.append((dY, ldy, off, X, n_in, 0, dW, n_out, n_in, db))
+    o.wgrad_grouped(probs, rows, 3)
+    torch.cuda.synchronize()
+    for (dY, ldy, off, X, ldx, xo, dW, n_out, n_in, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dW, rw) < 2e-5, (n_out, n_in)
+        if db is not None:
+            assert rel_err(db, rb) < 2e-5, (n_out, n_in)
+
+
 def test_gemm_dropout_consistency():
     """EPI_SWISH_DROP forward mask == mask regenerated by drop_scale_cast (same key, idx = m*N+n)."""
     o = ops()
