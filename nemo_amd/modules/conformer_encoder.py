@@ -380,8 +380,20 @@ class ConformerEncoder(NeuralModule):
         rows = self._wg_rows
         tiles = sum(((q[7] + 255) // 256) * ((q[8] + 127) // 128) for q in pend)
         nk = (rows + 63) // 64
-        # split-K: about three rounds of the 256 CUs, at least 16 K-tiles per workgroup
-        sk = max(1, min(nk // 16, (3 * 256 + tiles - 1) // tiles, 16))
+        # split-K: the factor in [2, 8] (>= 16 K-tiles per workgroup) that fills whole rounds of the 256 CUs best
+        env = os.environ.get("MI355X_WGRAD_SK")
+        if env:
+            sk = int(env)
+        else:
+            best = (0.0, 1)
+            for c in range(1, 9):
+                if c > 1 and nk // c < 16:
+                    break
+                blocks = tiles * c
+                eff = blocks / (((blocks + 255) // 256) * 256)
+                if blocks >= 256 and eff > best[0] + 0.02:
+                    best = (eff, c)
+            sk = best[1] if best[0] > 0 else max(1, min(nk // 16, (256 + tiles - 1) // tiles))
         tensors = [t for q in pend for t in (q[0], q[3])]
         with self._wgrad_scope(*tensors):
             ops.wgrad_grouped(pend, rows, sk)
