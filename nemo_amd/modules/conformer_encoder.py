@@ -327,10 +327,23 @@ class ConformerEncoder(NeuralModule):
         return cdt == torch.bfloat16 and C_ % 64 == 0 and C_ >= 96 and M2 >= 192
 
     @staticmethod
-    def _splitk(tiles, K):
-        """split-K factor: aim at one workgroup per CU (256) for the 144-KiB-LDS GEMM, at least 4 K tiles per split"""
+    def _splitk(tiles, K, strided_c=False):
+        """split-K factor for `tiles` output tiles: the factor (<= 16, at least 16 K-tiles per workgroup) whose workgroup
+        count fills whole rounds of the 256 CUs best, smaller factors preferred (every extra slice is one more atomic
+        pass over the output)"""
         nk = (K + 63) // 64
-        return max(1, min(nk // 4 if nk >= 8 else 1, max(1, 256 // max(tiles, 1)), 16))
+        if strided_c:  # atomics into a column-strided C (reference weight layouts) are expensive: only fill the chip once
+            return max(1, min(nk // 4 if nk >= 8 else 1, 256 // max(tiles, 1), 16))
+        best, best_score = 1, -1.0
+        for c in range(1, 17):
+            if c > 1 and nk // c < 16:
+                break
+            blocks = tiles * c
+            eff = blocks / (((blocks + 255) // 256) * 256)
+            score = eff - 0.01 * c
+            if score > best_score + 1e-9:
+                best, best_score = c, score
+        return best
 
     @staticmethod
     def _tiles(n_out, n_in, bf16):
@@ -380,20 +393,8 @@ class ConformerEncoder(NeuralModule):
         rows = self._wg_rows
         tiles = sum(((q[7] + 255) // 256) * ((q[8] + 127) // 128) for q in pend)
         nk = (rows + 63) // 64
-        # split-K: the factor in [2, 8] (>= 16 K-tiles per workgroup) that fills whole rounds of the 256 CUs best
         env = os.environ.get("MI355X_WGRAD_SK")
-        if env:
-            sk = int(env)
-        else:
-            best = (0.0, 1)
-            for c in range(1, 9):
-                if c > 1 and nk // c < 16:
-                    break
-                blocks = tiles * c
-                eff = blocks / (((blocks + 255) // 256) * 256)
-                if blocks >= 256 and eff > best[0] + 0.02:
-                    best = (eff, c)
-            sk = best[1] if best[0] > 0 else max(1, min(nk // 16, (256 + tiles - 1) // tiles))
+        sk = int(env) if env else self._splitk(tiles, rows)
         tensors = [t for q in pend for t in (q[0], q[3])]
         with self._wgrad_scope(*tensors):
             ops.wgrad_grouped(pend, rows, sk)
@@ -662,7 +663,8 @@ class ConformerEncoder(NeuralModule):
         # d out.weight in the reference's (c, f) column order: batch over f, C column stride F2
         tiles = self._tiles(d, C_, cdt == torch.bfloat16) * F2
         ops.gemm(dxs, S.out2, pe.out.weight.grad, d, C_, M, d, F2 * C_, C_ * F2, transA=True, transB=True, atomic=True,
-                 splitk=self._splitk(tiles, M), batch=F2, nb0=F2, sB=(C_, 0), sC=(1, 0), c_col_stride=F2, c_dtype=ops.F32)
+                 splitk=self._splitk(tiles, M, strided_c=True), batch=F2, nb0=F2, sB=(C_, 0), sC=(1, 0), c_col_stride=F2,
+                 c_dtype=ops.F32)
         dout2 = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
         ops.gemm(dxs, W["pre.outt"], dout2, M, F2 * C_, d, d, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=S.out2)
         M2 = B * T2 * F2
