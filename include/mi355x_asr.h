@@ -215,7 +215,7 @@ typedef struct mi355x_pack_entry {
   const void* src; void* dst;       /* src f32; dst[r*pitch + c] = src[r1*sr1 + r2*sr2 + c1*sc1 + c2*sc2]              */
   int rows, cols, nr2, nc2;         /* r = r1*nr2 + r2 ; c = c1*nc2 + c2                                              */
   long long sr1, sr2, sc1, sc2, pitch;
-  long long tile_begin;             /* exclusive prefix sum of ceil(rows/32)*ceil(cols/32)                            */
+  long long tile_begin;             /* exclusive prefix sum of ceil(rows/64)*ceil(cols/64); dst 16-B aligned           */
 } mi355x_pack_entry;
 int mi355x_pack_weights(const void* table_dev, int n_entries, long long total_tiles, int out_dtype, void* stream);
 int mi355x_fill_f32(void* p, long long n, float value, void* stream);

@@ -66,25 +66,27 @@ struct PackEntry {
   long long sr1, sr2, sc1, sc2, pitch;
   long long tile_begin;  // prefix sum of 32x32 tiles
 };
+#define PK_T 64  // tile edge; tile_begin counts 64x64 tiles
 __global__ __launch_bounds__(256) void pack_kernel(const PackEntry* __restrict__ tab, int n_entries, int out_dt) {
-  __shared__ float tile[32][33];
-  // locate entry by binary search on tile_begin
+  // 64x64 tiles through LDS: reads run along whichever axis is contiguous in the fp32 source (256-B wave segments),
+  // writes are 8 consecutive image columns per lane (16-B bf16 / 32-B f32 stores; 2-byte stores crawl on this chip)
+  __shared__ float tile[PK_T][PK_T + 1];
   int lo = 0, hi = n_entries - 1;
   const long long bid = blockIdx.x;
-  while (lo < hi) {
+  while (lo < hi) {  // locate the entry by binary search on tile_begin
     const int mid = (lo + hi + 1) >> 1;
     if (tab[mid].tile_begin <= bid) lo = mid; else hi = mid - 1;
   }
   const PackEntry e = tab[lo];
-  const int tiles_c = (e.cols + 31) / 32;
+  const int tiles_c = (e.cols + PK_T - 1) / PK_T;
   const int local = (int)(bid - e.tile_begin);
   const int tr = local / tiles_c, tc = local - tr * tiles_c;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  // read: choose the thread-fast axis that is contiguous in the source
   const bool col_fast = (e.sc2 == 1 && e.nc2 > 1) || (e.nc2 == 1 && e.sc1 == 1);
-  for (int i = ty; i < 32; i += 8) {
-    const int rr = col_fast ? i : tx, cc = col_fast ? tx : i;
-    const int r = tr * 32 + rr, c = tc * 32 + cc;
+#pragma unroll 4
+  for (int k = 0; k < PK_T * PK_T / 256; ++k) {
+    const int q = threadIdx.x + k * 256;
+    const int rr = col_fast ? (q >> 6) : (q & 63), cc = col_fast ? (q & 63) : (q >> 6);
+    const int r = tr * PK_T + rr, c = tc * PK_T + cc;
     float v = 0.f;
     if (r < e.rows && c < e.cols) {
       const int r1 = r / e.nr2, r2 = r - r1 * e.nr2, c1 = c / e.nc2, c2 = c - c1 * e.nc2;
@@ -93,12 +95,24 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackEntry* __restrict__
     tile[rr][cc] = v;
   }
   __syncthreads();
-  for (int i = ty; i < 32; i += 8) {
-    const int r = tr * 32 + i, c = tc * 32 + tx;
+  // image pitch is a multiple of 8 and >= roundup8(cols): whole 8-column groups can be written (zeros past `cols`)
+#pragma unroll
+  for (int k = 0; k < PK_T * PK_T / 8 / 256; ++k) {
+    const int q = threadIdx.x + k * 256;
+    const int rr = q >> 3, c8 = (q & 7) * 8;
+    const int r = tr * PK_T + rr, c = tc * PK_T + c8;
     if (r < e.rows && c < e.cols) {
-      const float v = tile[i][tx];
-      if (out_dt == MI_DT_F32) ((float*)e.dst)[r * e.pitch + c] = v;
-      else ((bf16_t*)e.dst)[r * e.pitch + c] = f2bf(v);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tile[rr][c8 + j];
+      if (out_dt == MI_DT_F32) {
+        float* d = (float*)e.dst + (long long)r * e.pitch + c;
+        *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *reinterpret_cast<u32x4*>((bf16_t*)e.dst + (long long)r * e.pitch + c) = t;
+      }
     }
   }
 }

@@ -111,11 +111,12 @@ class PackPlan:
             assert ro + rows <= irows and co + cols <= pitch, name
             e = entries[i]
             e.src = src.data_ptr()
+            assert co % 8 == 0, name  # the kernel writes whole 8-column groups (16 / 32-byte stores)
             e.dst = base + (off + ro * pitch + co) * es
             e.rows, e.cols, e.nr2, e.nc2 = rows, cols, nr2, nc2
             e.sr1, e.sr2, e.sc1, e.sc2, e.pitch = sr1, sr2, sc1, sc2, pitch
             e.tile_begin = tiles
-            tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
+            tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
         raw = bytes(entries)
         self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
         self._n, self._tiles = len(self._pending), tiles
