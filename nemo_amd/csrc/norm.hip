@@ -15,6 +15,18 @@
 // LayerNorm forward: one wave per row, 4 rows per 256-thread block.  Two-pass (mean, then centred variance) on
 // register-resident data when d <= 64*4*VPL, else re-read.  Statistics saved for backward.
 // ------------------------------------------------------------------------------------------------
+// 8 consecutive elements <-> f32 registers (bf16: one 16-byte access, f32: two)
+__device__ __forceinline__ void ld8g(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8g(const bf16_t* p, float (&v)[8]) { VecIO<bf16_t>::load(p, v); }
+__device__ __forceinline__ void st8g(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void st8g(bf16_t* p, const float (&v)[8]) { VecIO<bf16_t>::store(p, v); }
+
 template <typename TX, typename TY>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, TY* __restrict__ y,
@@ -268,15 +280,61 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
 }
 
 // =================================================================================================
+// Register-resident variant for d % 512 == 0, d <= 2048: one wave per row, lane = 8 consecutive elements per 512-wide
+// chunk (32-byte loads, 16-byte bf16 / 32-byte f32 stores), the row is read from memory exactly once.
+template <typename TX, typename TY, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, TY* __restrict__ y,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, int M, int d,
+                                                         float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const TX* xr = x + (long long)row * d;
+  TY* yr = y + (long long)row * d;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    ld8g(xr + c * 512 + lane * 8, v[c]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[c][j];
+  }
+  const float mu = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mu; q += t * t; }
+  const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    float g[8], b[8], o[8];
+    ld8g(gamma + c * 512 + lane * 8, g); ld8g(beta + c * 512 + lane * 8, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mu) * rs * g[j] + b[j];
+    st8g(yr + c * 512 + lane * 8, o);
+  }
+  if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+}
+
 extern "C" int mi355x_layernorm_fwd(const void* x, int x_dt, const void* gamma, const void* beta, void* y, int y_dt,
                                     void* mean, void* rstd, int M, int d, float eps, void* stream) {
   mi_clear_errors();
   if (!x || !gamma || !beta || !y || M <= 0 || d <= 0 || (d & 3)) return MI_ERR_ARG;
   dim3 grid((M + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
+  const bool aligned = !((uintptr_t)x & 31) && !((uintptr_t)y & 31) && !((uintptr_t)gamma & 31) && !((uintptr_t)beta & 31);
+#define LN_REG(NCH) DISPATCH_DT(x_dt, TX, DISPATCH_DT(y_dt, TY, hipLaunchKernelGGL((ln_fwd_reg_kernel<TX, TY, NCH>), grid, \
+    block, 0, s, (const TX*)x, (const float*)gamma, (const float*)beta, (TY*)y, (float*)mean, (float*)rstd, M, d, eps)))
+  if (aligned && d == 512) { LN_REG(1); }
+  else if (aligned && d == 1024) { LN_REG(2); }
+  else if (aligned && d == 2048) { LN_REG(4); }
+  else
   DISPATCH_DT(x_dt, TX, DISPATCH_DT(y_dt, TY,
     hipLaunchKernelGGL((ln_fwd_kernel<TX, TY>), grid, block, 0, s, (const TX*)x, (const float*)gamma, (const float*)beta,
                        (TY*)y, (float*)mean, (float*)rstd, M, d, eps)));
+#undef LN_REG
   return mi_check_launch();
 }
 
