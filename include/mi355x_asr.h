@@ -67,7 +67,12 @@ typedef struct mi355x_gemm_desc {
   const struct mi355x_conv_gather* gather;   /* NULL = dense A */
   const struct mi355x_row_map* rowmap;       /* NULL = dense C rows */
 } mi355x_gemm_desc;
-typedef struct mi355x_conv_gather { int nI, nJ, SI, SJ, C, si, sj, ntaps; int di[9], dj[9]; } mi355x_conv_gather;
+typedef struct mi355x_conv_gather {
+  int nI, nJ, SI, SJ, C, si, sj, ntaps; int di[9], dj[9];
+  int operand;   /* 0: A rows gathered as described above.  1: weight gradient -- B (transB = 1) is gathered instead: K runs
+                    over the positions m = (b*nI + i)*nJ + j, N = C channels, batch index z (0..ntaps-1) selects the tap;
+                    B points at the source grid, ldb / sB are ignored, transA must be 1 */
+} mi355x_conv_gather;
 typedef struct mi355x_row_map { int nI, nJ, OI, OJ, si, sj, oi, oj; } mi355x_row_map;
 int mi355x_gemm(const mi355x_gemm_desc* desc, void* stream);
 /* Up to 12 independent weight-gradient problems in one launch: every desc must be bf16, transA = transB = 1, atomic

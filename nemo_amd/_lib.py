@@ -38,7 +38,7 @@ class GemmDesc(C.Structure):
 
 class ConvGather(C.Structure):  # mirrors mi355x_conv_gather
     _fields_ = [("nI", i32), ("nJ", i32), ("SI", i32), ("SJ", i32), ("C", i32), ("si", i32), ("sj", i32), ("ntaps", i32),
-                ("di", i32 * 9), ("dj", i32 * 9)]
+                ("di", i32 * 9), ("dj", i32 * 9), ("operand", i32)]
 
 
 class RowMap(C.Structure):  # mirrors mi355x_row_map

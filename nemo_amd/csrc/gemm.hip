@@ -585,6 +585,55 @@ __device__ __forceinline__ void gather_issue(const DmaGather<R>& g, const GemmP&
   }
 }
 
+// implicit-GEMM gather of a REDUCTION-MAJOR operand (the conv weight gradient: K runs over the output positions, the
+// operand's columns are the input channels of one tap).  A chunk is (k-row of the K-tile, 8 channels); its position
+// (b, i, j) advances by 64 rows per K-tile and is updated incrementally.
+template <int R> struct DmaGatherT {
+  static constexpr int PER = R * 8 / 512;
+  int b[PER], i[PER], j[PER];  // output position of the chunk's row at the current K-tile
+  int col[PER];                // channel offset (already including the tile's first column), -1 = outside
+};
+template <int R>
+__device__ __forceinline__ void gatherT_setup(DmaGatherT<R>& g, const GemmP& p, int col0, int ncols, int kbase) {
+  constexpr int CPR = R / 8;
+#pragma unroll
+  for (int c = 0; c < DmaGatherT<R>::PER; ++c) {
+    const int q = threadIdx.x + c * 512;
+    const int k = q / CPR, cp = q % CPR;
+    const int ch = cp ^ ((k & 3) << 2);
+    const int gc = col0 + ch * 8;
+    g.col[c] = gc < ncols ? gc : -1;
+    const int m = kbase + k;
+    const int per_b = p.g_nI * p.g_nJ;
+    g.b[c] = m / per_b;
+    const int rr = m - g.b[c] * per_b;
+    g.i[c] = rr / p.g_nJ;
+    g.j[c] = rr - g.i[c] * p.g_nJ;
+  }
+}
+template <int R>
+__device__ __forceinline__ void gatherT_issue(DmaGatherT<R>& g, const GemmP& p, const bf16_t* base, int tap, int kt,
+                                              bf16_t* lds_tile) {
+  const int wave = threadIdx.x >> 6;
+  constexpr int CPR = R / 8;
+  const int di = p.g_di[tap], dj = p.g_dj[tap];
+#pragma unroll
+  for (int c = 0; c < DmaGatherT<R>::PER; ++c) {
+    const int q = threadIdx.x + c * 512;
+    const int m = kt * BK + q / CPR;
+    const int si = g.i[c] * p.g_si + di, sj = g.j[c] * p.g_sj + dj;
+    const bool ok = g.col[c] >= 0 && m < p.K && (unsigned)si < (unsigned)p.g_SI && (unsigned)sj < (unsigned)p.g_SJ;
+    const bf16_t* src = ok ? base + (((long long)g.b[c] * p.g_SI + si) * p.g_SJ + sj) * p.g_C + g.col[c]
+                           : reinterpret_cast<const bf16_t*>(g_zero16);
+    bf16_t* dst = lds_tile + (wave * 64 + c * 512) * 8;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+    // advance the position by one K-tile (64 rows of the output grid)
+    g.j[c] += BK;
+    while (g.j[c] >= p.g_nJ) { g.j[c] -= p.g_nJ; ++g.i[c]; }
+    while (g.i[c] >= p.g_nI) { g.i[c] -= p.g_nI; ++g.b[c]; }
+  }
+}
+
 template <int R>
 __device__ __forceinline__ void dma_issue(const DmaSrc<R>& d, int it, int k0, int K, bool ktail, bf16_t* lds_tile) {
   const int wave = threadIdx.x >> 6;
@@ -661,13 +710,17 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
   const bool gatherA = !TA && p.g_on == 1;
   if (gatherA) gather_setup<BM2>(gA, p, A, m0);
   else dma_setup<TA, BM2>(dA, A, p.lda, m0, p.M, kt0 * BK);
-  dma_setup<TB, BN>(dB, B, p.ldb, n0, p.N, kt0 * BK);
+  DmaGatherT<BN> gB;
+  const bool gatherB = TB && p.g_on == 2;  // tap = batch index z0; p.B is the un-batched source grid
+  if (gatherB) gatherT_setup<BN>(gB, p, n0, p.N, kt0 * BK);
+  else dma_setup<TB, BN>(dB, B, p.ldb, n0, p.N, kt0 * BK);
   const bool ktail = (p.K & (BK - 1)) != 0;
-  auto issue = [&](int it) {  // it = local tile index
+  auto issue = [&](int it) {  // it = local tile index (issued in increasing order: the gathers advance incrementally)
     bf16_t* st = smem2 + (it % 3) * NT2_STAGE;
     if (gatherA) gather_issue<BM2>(gA, p, kt0 + it, st);
     else dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
-    dma_issue<BN>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
+    if (gatherB) gatherT_issue<BN>(gB, p, (const bf16_t*)p.B, z0, kt0 + it, st + BM2 * BK);
+    else dma_issue<BN>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
   // bias gradient riding along with wgrad: column sums of the A tile, read back from LDS (8 B per lane per k-row group)
   // The tn workgroups of one (tile_m, K slice) stage the same A tile: its 64 k-rows are dealt round-robin to (up to 8 of)
@@ -949,13 +1002,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
   const bool gatherA = !TA && p.g_on == 1;
   if (gatherA) gather_setup<BM2>(gA, p, A, m0);
   else dma_setup<TA, BM2>(dA, A, p.lda, m0, p.M, kt0 * BK);
-  dma_setup<TB, BN4>(dB, B, p.ldb, n0, p.N, kt0 * BK);
+  DmaGatherT<BN4> gB;
+  const bool gatherB = TB && p.g_on == 2;
+  if (gatherB) gatherT_setup<BN4>(gB, p, n0, p.N, kt0 * BK);
+  else dma_setup<TB, BN4>(dB, B, p.ldb, n0, p.N, kt0 * BK);
   const bool ktail = (p.K & (BK - 1)) != 0;
   auto issue = [&](int it) {
     bf16_t* st = smem4 + (it & 1) * NT4_STAGE;
     if (gatherA) gather_issue<BM2>(gA, p, kt0 + it, st);
     else dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
-    dma_issue<BN4>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
+    if (gatherB) gatherT_issue<BN4>(gB, p, (const bf16_t*)p.B, z0, kt0 + it, st + BM2 * BK);
+    else dma_issue<BN4>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
   const int cs_step = tn < 8 ? tn : 8;  // column-sum rows dealt round-robin to the workgroups sharing this A tile
   const bool do_colsum = TA && p.colsum_out != nullptr && tile_n < cs_step;
@@ -1121,10 +1178,17 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   p.g_on = 0; p.r_on = 0;
   if (d->gather) {
     const mi355x_conv_gather& g = *d->gather;
-    if (d->in_dtype != MI_DT_BF16 || d->transA || p.batch != 1 || g.C <= 0 || (g.C & 63) || g.ntaps < 1 || g.ntaps > 9 ||
-        g.nI <= 0 || g.nJ <= 0 || g.SI <= 0 || g.SJ <= 0 || d->K != g.ntaps * g.C || d->M % (g.nI * g.nJ) != 0)
+    if (d->in_dtype != MI_DT_BF16 || g.C <= 0 || (g.C & 7) || g.ntaps < 1 || g.ntaps > 9 || g.nI <= 0 || g.nJ <= 0 ||
+        g.SI <= 0 || g.SJ <= 0 || (g.operand != 0 && g.operand != 1))
       return MI_ERR_ARG;
-    p.g_on = 1; p.g_nI = g.nI; p.g_nJ = g.nJ; p.g_SI = g.SI; p.g_SJ = g.SJ; p.g_C = g.C; p.g_si = g.si; p.g_sj = g.sj;
+    if (g.operand == 0) {  // gathered A rows (forward / dgrad)
+      if (d->transA || p.batch != 1 || (g.C & 63) || d->K != g.ntaps * g.C || d->M % (g.nI * g.nJ) != 0) return MI_ERR_ARG;
+    } else {               // gathered reduction-major B (weight gradient): K = positions, N = channels, batch = taps
+      if (!d->transA || !d->transB || p.batch != g.ntaps || p.nb0 != p.batch || d->N != g.C || d->K % (g.nI * g.nJ) != 0 ||
+          ((uintptr_t)d->B & 15))
+        return MI_ERR_ARG;
+    }
+    p.g_on = 1 + g.operand; p.g_nI = g.nI; p.g_nJ = g.nJ; p.g_SI = g.SI; p.g_SJ = g.SJ; p.g_C = g.C; p.g_si = g.si; p.g_sj = g.sj;
     p.g_ntaps = g.ntaps;
     for (int t = 0; t < g.ntaps; ++t) { p.g_di[t] = (signed char)g.di[t]; p.g_dj[t] = (signed char)g.dj[t]; }
   }
@@ -1171,7 +1235,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
     if (!p.transA && !p.g_on && p.lda < K8) return MI_ERR_ARG;
     if (!p.transB && p.ldb < K8) return MI_ERR_ARG;
     if (p.transA && p.lda < ((p.M + 7) & ~7)) return MI_ERR_ARG;
-    if (p.transB && p.ldb < ((p.N + 7) & ~7)) return MI_ERR_ARG;
+    if (p.transB && p.g_on != 2 && p.ldb < ((p.N + 7) & ~7)) return MI_ERR_ARG;
     const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     dim3 grid(tm * tn, sk, p.batch);
     static int use_v2 = -1;

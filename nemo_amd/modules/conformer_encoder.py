@@ -204,7 +204,7 @@ class ConformerEncoder(NeuralModule):
         self._wgrad_join_per_layer = True
         self.wgrad_grouped = os.environ.get("MI355X_WGRAD_GROUPED", "1") != "0"
         self._wg_pending, self._wg_rows = None, None
-        self.conv2_fwd_implicit = os.environ.get("MI355X_CONV2_FWD_IMPLICIT", "0") == "1"
+        self.conv2_implicit = os.environ.get("MI355X_CONV2_IMPLICIT", "1") != "0"
         self._plans = {}
         self._ws = {}
         self._pos_cache = {}
@@ -440,15 +440,17 @@ class ConformerEncoder(NeuralModule):
         ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, S.out1, len0, len1, C_)
         # the 3 GB im2col image stays alive until the conv2 weight gradient (1 % of the 288 GB HBM; recomputing it in
         # backward cost 0.83 ms per step)
-        col = self._buf("col", (B * T2 * F2, 9 * C_), cdt, dev)
-        ops.im2col(S.out1, col, B, T1, F1, C_)
-        self._col_gen = getattr(self, "_col_gen", 0) + 1
-        S.col, S.col_gen = (col if save else None), self._col_gen
+        implicit = self.conv2_implicit and self._conv2_implicit(cdt, C_, B * T2 * F2)
+        S.col = None
+        if not implicit:
+            col = self._buf("col", (B * T2 * F2, 9 * C_), cdt, dev)
+            ops.im2col(S.out1, col, B, T1, F1, C_)
+            self._col_gen = getattr(self, "_col_gen", 0) + 1
+            S.col, S.col_gen = (col if save else None), self._col_gen
         S.out2 = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
-        if self.conv2_fwd_implicit and self._conv2_implicit(cdt, C_, B * T2 * F2):
-            # implicit GEMM: the A rows are gathered from out1 by the LDS-DMA (tap (kh-1, kw-1) per 512-wide K block).
-            # Off by default while the weight gradient still consumes the im2col image: with the image at hand the dense
-            # read is 11 % faster (1.56 vs 1.75 ms) than the gather.
+        if implicit:
+            # implicit GEMM: the A rows are gathered from out1 by the LDS-DMA (tap (kh-1, kw-1) per 512-wide K block);
+            # forward, weight gradient and input gradient all gather -- no im2col image, no col2im pass
             ops.gemm(S.out1, W["pre.w2"], S.out2, B * T2 * F2, C_, 9 * C_, C_, W.pitch("pre.w2"), C_, bias=pe.conv[2].bias,
                      epi=ops.EPI_RELU_MASK, row_len=len2, rows_per_b=T2 * F2, rows_inner=F2,
                      gather=dict(nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2,
@@ -669,16 +671,24 @@ class ConformerEncoder(NeuralModule):
         ops.gemm(dxs, W["pre.outt"], dout2, M, F2 * C_, d, d, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=S.out2)
         M2 = B * T2 * F2
         ops.colsum(dout2, pe.conv[2].bias.grad, M2, C_)
-        col = S.col
-        if S.col_gen != self._col_gen:  # another forward has reused the workspace since: rebuild the image
-            ops.im2col(S.out1, col, B, T1, F1, C_)
-            self._col_gen += 1
+        implicit = self.conv2_implicit and self._conv2_implicit(cdt, C_, M2) and S.col is None
         # d conv2.weight [co, ci, 3, 3]: batch over the 9 taps, column stride 9
         tiles = self._tiles(C_, C_, cdt == torch.bfloat16) * 9
-        ops.gemm(dout2, col, pe.conv[2].weight.grad, C_, C_, M2, C_, 9 * C_, 9 * C_, transA=True, transB=True, atomic=True,
-                 splitk=self._splitk(tiles, M2), batch=9, nb0=9, sB=(C_, 0), sC=(1, 0), c_col_stride=9, c_dtype=ops.F32)
+        if implicit:
+            ops.gemm(dout2, S.out1, pe.conv[2].weight.grad, C_, C_, M2, C_, C_, 9 * C_, transA=True, transB=True, atomic=True,
+                     splitk=self._splitk(tiles, M2), batch=9, nb0=9, sC=(1, 0), c_col_stride=9, c_dtype=ops.F32,
+                     gather=dict(operand=1, nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2,
+                                 taps=[(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]))
+        else:
+            col = S.col
+            if S.col_gen != self._col_gen:  # another forward has reused the workspace since: rebuild the image
+                ops.im2col(S.out1, col, B, T1, F1, C_)
+                self._col_gen += 1
+            ops.gemm(dout2, col, pe.conv[2].weight.grad, C_, C_, M2, C_, 9 * C_, 9 * C_, transA=True, transB=True,
+                     atomic=True, splitk=self._splitk(tiles, M2), batch=9, nb0=9, sB=(C_, 0), sC=(1, 0), c_col_stride=9,
+                     c_dtype=ops.F32)
         dout1 = self._buf("dout1", (B, T1, F1, C_), cdt, dev)
-        if self._conv2_implicit(cdt, C_, M2):
+        if self.conv2_implicit and self._conv2_implicit(cdt, C_, M2):
             # four implicit GEMMs (one per parity class of (t1, f1)) gather dout2 and write the class's rows of dout1 with
             # the ReLU gate of conv1's output in the epilogue: no 3 GB dcol image, no col2im pass
             for pt in (0, 1):

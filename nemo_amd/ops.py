@@ -117,6 +117,7 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=False, transB=False, in_dty
         g = ConvGather()
         g.nI, g.nJ, g.SI, g.SJ, g.C, g.si, g.sj = (gather[k] for k in ("nI", "nJ", "SI", "SJ", "C", "si", "sj"))
         g.ntaps = len(gather["taps"])
+        g.operand = int(gather.get("operand", 0))
         for t, (di, dj) in enumerate(gather["taps"]):
             g.di[t], g.dj[t] = di, dj
         keep.append(g)

@@ -633,7 +633,7 @@ def test_conv2_implicit_gemm_forward_and_dgrad(T1, F1):
     input gradient as four parity-class implicit GEMMs with scattered output rows + ReLU gate (no col2im), against
     torch conv2d / autograd on the same bf16-rounded operands."""
     o = ops()
-    Bn, C_ = 3, 128  # (the gather lives in the LDS-DMA GEMM structures: N >= 96)
+    Bn, C_ = 3, 256  # (the gather lives in the LDS-DMA GEMM structures: M >= 192, N >= 96)
     g = torch.Generator().manual_seed(17)
     T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
     x = bf(torch.relu(torch.randn(Bn, T1, F1, C_, generator=g)))               # post-ReLU activations: ~half are zero
@@ -670,6 +670,18 @@ def test_conv2_implicit_gemm_forward_and_dgrad(T1, F1):
     torch.cuda.synchronize()
     assert not torch.isnan(dx.float()).any()
     assert rel_err(dx, ref_dx) < 1e-2
+    # wgrad: dW[co, ci, kh, kw] += sum_m dy[m, co] * x[b, 2*t2+kh-1, 2*f2+kw-1, ci]  (B operand gathered, batch = tap,
+    # written straight into the reference's [co, ci, 3, 3] layout: column stride 9, batch offset 1)
+    w2r = w2.float().clone().requires_grad_(True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), w2r, None, stride=2, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    dW = torch.ones(C_, C_, 3, 3, device=dev)
+    for sk in (1, 3):
+        dW.fill_(1.0)
+        o.gemm(dyd, xd, dW, C_, C_, M2, C_, C_, 9 * C_, transA=True, transB=True, atomic=True, splitk=sk, batch=9, nb0=9,
+               sC=(1, 0), c_col_stride=9, c_dtype=o.F32,
+               gather=dict(operand=1, nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2, taps=taps))
+        torch.cuda.synchronize()
+        assert rel_err(dW - 1.0, w2r.grad) < 2e-3, sk
 
 
 # ---------------------------------------------------------------------------------------------- mel front-end
