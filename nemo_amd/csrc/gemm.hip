@@ -590,8 +590,10 @@ __device__ __forceinline__ void gather_issue(const DmaGather<R>& g, const GemmP&
 // (b, i, j) advances by 64 rows per K-tile and is updated incrementally.
 template <int R> struct DmaGatherT {
   static constexpr int PER = R * 8 / 512;
-  int b[PER], i[PER], j[PER];  // output position of the chunk's row at the current K-tile
-  int col[PER];                // channel offset (already including the tile's first column), -1 = outside
+  int i[PER], j[PER];          // output position (within its utterance) of the chunk's row at the current K-tile
+  int off[PER];                // element offset of the position's origin src[b][i*si][j*sj][col] (< 2^31 by contract)
+  int row[PER];                // the row index m itself (K-tail test)
+  bool colok[PER];
 };
 template <int R>
 __device__ __forceinline__ void gatherT_setup(DmaGatherT<R>& g, const GemmP& p, int col0, int ncols, int kbase) {
@@ -602,35 +604,37 @@ __device__ __forceinline__ void gatherT_setup(DmaGatherT<R>& g, const GemmP& p, 
     const int k = q / CPR, cp = q % CPR;
     const int ch = cp ^ ((k & 3) << 2);
     const int gc = col0 + ch * 8;
-    g.col[c] = gc < ncols ? gc : -1;
+    g.colok[c] = gc < ncols;
     const int m = kbase + k;
     const int per_b = p.g_nI * p.g_nJ;
-    g.b[c] = m / per_b;
-    const int rr = m - g.b[c] * per_b;
+    const int b = m / per_b;
+    const int rr = m - b * per_b;
     g.i[c] = rr / p.g_nJ;
     g.j[c] = rr - g.i[c] * p.g_nJ;
+    g.row[c] = m;
+    g.off[c] = ((b * p.g_SI + g.i[c] * p.g_si) * p.g_SJ + g.j[c] * p.g_sj) * p.g_C + (g.colok[c] ? gc : 0);
   }
 }
 template <int R>
-__device__ __forceinline__ void gatherT_issue(DmaGatherT<R>& g, const GemmP& p, const bf16_t* base, int tap, int kt,
+__device__ __forceinline__ void gatherT_issue(DmaGatherT<R>& g, const GemmP& p, const bf16_t* base, int tap,
                                               bf16_t* lds_tile) {
   const int wave = threadIdx.x >> 6;
-  constexpr int CPR = R / 8;
   const int di = p.g_di[tap], dj = p.g_dj[tap];
+  const int toff = (di * p.g_SJ + dj) * p.g_C;                                   // uniform
+  const int step_j = BK * p.g_sj * p.g_C;                                        // one K-tile = 64 positions further
+  const int wrap_j = p.g_si * p.g_SJ * p.g_C - p.g_nJ * p.g_sj * p.g_C;          // j -= nJ, i += 1
+  const int wrap_i = p.g_SI * p.g_SJ * p.g_C - p.g_nI * p.g_si * p.g_SJ * p.g_C; // i -= nI, b += 1
 #pragma unroll
   for (int c = 0; c < DmaGatherT<R>::PER; ++c) {
-    const int q = threadIdx.x + c * 512;
-    const int m = kt * BK + q / CPR;
     const int si = g.i[c] * p.g_si + di, sj = g.j[c] * p.g_sj + dj;
-    const bool ok = g.col[c] >= 0 && m < p.K && (unsigned)si < (unsigned)p.g_SI && (unsigned)sj < (unsigned)p.g_SJ;
-    const bf16_t* src = ok ? base + (((long long)g.b[c] * p.g_SI + si) * p.g_SJ + sj) * p.g_C + g.col[c]
-                           : reinterpret_cast<const bf16_t*>(g_zero16);
+    const bool ok = g.colok[c] && g.row[c] < p.K && (unsigned)si < (unsigned)p.g_SI && (unsigned)sj < (unsigned)p.g_SJ;
+    const bf16_t* src = ok ? base + (g.off[c] + toff) : reinterpret_cast<const bf16_t*>(g_zero16);
     bf16_t* dst = lds_tile + (wave * 64 + c * 512) * 8;
     __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
-    // advance the position by one K-tile (64 rows of the output grid)
-    g.j[c] += BK;
-    while (g.j[c] >= p.g_nJ) { g.j[c] -= p.g_nJ; ++g.i[c]; }
-    while (g.i[c] >= p.g_nI) { g.i[c] -= p.g_nI; ++g.b[c]; }
+    // advance by one K-tile
+    g.row[c] += BK; g.j[c] += BK; g.off[c] += step_j;
+    while (g.j[c] >= p.g_nJ) { g.j[c] -= p.g_nJ; ++g.i[c]; g.off[c] += wrap_j; }
+    while (g.i[c] >= p.g_nI) { g.i[c] -= p.g_nI; g.off[c] += wrap_i; }
   }
 }
 
@@ -719,7 +723,7 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
     bf16_t* st = smem2 + (it % 3) * NT2_STAGE;
     if (gatherA) gather_issue<BM2>(gA, p, kt0 + it, st);
     else dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
-    if (gatherB) gatherT_issue<BN>(gB, p, (const bf16_t*)p.B, z0, kt0 + it, st + BM2 * BK);
+    if (gatherB) gatherT_issue<BN>(gB, p, (const bf16_t*)p.B, z0, st + BM2 * BK);
     else dma_issue<BN>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
   // bias gradient riding along with wgrad: column sums of the A tile, read back from LDS (8 B per lane per k-row group)
@@ -1011,7 +1015,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
     bf16_t* st = smem4 + (it & 1) * NT4_STAGE;
     if (gatherA) gather_issue<BM2>(gA, p, kt0 + it, st);
     else dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
-    if (gatherB) gatherT_issue<BN4>(gB, p, (const bf16_t*)p.B, z0, kt0 + it, st + BM2 * BK);
+    if (gatherB) gatherT_issue<BN4>(gB, p, (const bf16_t*)p.B, z0, st + BM2 * BK);
     else dma_issue<BN4>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
   const int cs_step = tn < 8 ? tn : 8;  // column-sum rows dealt round-robin to the workgroups sharing this A tile
@@ -1184,6 +1188,8 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
     if (g.operand == 0) {  // gathered A rows (forward / dgrad)
       if (d->transA || p.batch != 1 || (g.C & 63) || d->K != g.ntaps * g.C || d->M % (g.nI * g.nJ) != 0) return MI_ERR_ARG;
     } else {               // gathered reduction-major B (weight gradient): K = positions, N = channels, batch = taps
+      const long long src_elems = (long long)(d->K / (g.nI * g.nJ)) * g.SI * g.SJ * g.C;
+      if (src_elems >= (1LL << 31)) return MI_ERR_ARG;
       if (!d->transA || !d->transB || p.batch != g.ntaps || p.nb0 != p.batch || d->N != g.C || d->K % (g.nI * g.nJ) != 0 ||
           ((uintptr_t)d->B & 15))
         return MI_ERR_ARG;

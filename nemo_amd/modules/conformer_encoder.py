@@ -440,7 +440,8 @@ class ConformerEncoder(NeuralModule):
         ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, S.out1, len0, len1, C_)
         # the 3 GB im2col image stays alive until the conv2 weight gradient (1 % of the 288 GB HBM; recomputing it in
         # backward cost 0.83 ms per step)
-        implicit = self.conv2_implicit and self._conv2_implicit(cdt, C_, B * T2 * F2)
+        implicit = (self.conv2_implicit and self._conv2_implicit(cdt, C_, B * T2 * F2)
+                    and B * T1 * F1 * C_ < 2 ** 31)  # the gathered weight gradient addresses the grid with 32-bit offsets
         S.col = None
         if not implicit:
             col = self._buf("col", (B * T2 * F2, 9 * C_), cdt, dev)
