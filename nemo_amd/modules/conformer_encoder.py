@@ -324,7 +324,7 @@ class ConformerEncoder(NeuralModule):
 
     def _conv2_implicit(self, cdt, C_, M2):
         """implicit-GEMM conv2 (gathered A operand) needs the bf16 LDS-DMA GEMM structures and whole K-tiles per tap"""
-        return cdt == torch.bfloat16 and C_ % 64 == 0 and C_ >= 96 and M2 >= 192
+        return cdt == torch.bfloat16 and C_ % 64 == 0 and C_ >= 192 and M2 >= 192  # (C is also the wgrad's M and N)
 
     @staticmethod
     def _splitk(tiles, K, strided_c=False):

@@ -114,15 +114,19 @@ def test_ragged_batch_matches_cpu_oracle_fp32():
     assert int(bn.num_batches_tracked) == 1
 
 
-def test_bf16_mfma_path_close_to_fp32_oracle():
-    """bf16 compute (MFMA GEMMs, bf16 activations): loss within 2 %, gradient direction cos > 0.98 per big tensor."""
-    cfg = R.ConformerCfg(d_model=64, n_heads=2, n_layers=2, vocab=20, dropout=0, dropout_att=0, dropout_pre_encoder=0)
+@pytest.mark.parametrize("d_model,n_heads", [(64, 2), (256, 4)])
+def test_bf16_mfma_path_close_to_fp32_oracle(d_model, n_heads):
+    """bf16 compute (MFMA GEMMs, bf16 activations): loss within 2 %, gradient direction cos > 0.98 per big tensor.
+    d_model = 256 (d_k = 64) takes the production paths the tiny configurations skip: fused flash attention, implicit-GEMM
+    conv2 (forward / weight / input gradient), grouped weight gradients on the side stream, 256x256 GEMM tiles."""
+    cfg = R.ConformerCfg(d_model=d_model, n_heads=n_heads, n_layers=2, vocab=20, dropout=0, dropout_att=0,
+                         dropout_pre_encoder=0)
     P = R.init_params(cfg, seed=6)
-    audio, alen, tok, tl = R.synthetic_batch(4, 1.0, vocab=20, seed=17)
+    audio, alen, tok, tl = R.synthetic_batch(4, 1.0 if d_model == 64 else 2.5, vocab=20, seed=17)
     Pr = {k: (v.clone().requires_grad_(True) if k in R.trainable_keys(P) else v) for k, v in P.items()}
     ref = R.model_forward(Pr, cfg, audio, alen, tok, tl, train=False, bn_training=True)
     ref["loss"].backward()
-    over = dict(d_model=64, n_heads=2, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0,
+    over = dict(d_model=d_model, n_heads=n_heads, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0,
                 compute_dtype=torch.bfloat16)
     model = _model(over, vocab=20)
     model.decoder.compute_dtype = torch.bfloat16
