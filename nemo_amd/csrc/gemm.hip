@@ -1,21 +1,24 @@
 // GEMM kernels for the Conformer-CTC hot path on MI355X (gfx950).
 //
-//   C[M,N] = epilogue( sum_k opA(m,k) * opB(n,k) )          (optionally batched / split-K)
+//   C[M,N] = epilogue( sum_k opA(m,k) * opB(n,k) )          (optionally batched / split-K / gathered / grouped)
 //
-// * bf16 path: MFMA `v_mfma_f32_32x32x16_bf16`, 128x128x64 block tile, 4 waves (2x2), each wave a 64x64
-//   sub-tile = 2x2 MFMA tiles; operands staged global -> VGPR -> LDS (double-buffered, one barrier per K tile,
-//   next tile's global loads in flight under the current tile's MFMAs); LDS rows are 128 B with a 16-B-chunk XOR
-//   swizzle  chunk ^= (row>>1)&7  so that the ds_read_b128 fragment reads of 32 consecutive rows are
-//   bank-conflict-free.  An operand may be stored "reduction-major" ([K][rows], used by wgrad = TN and by
-//   P@V = NN); it is then transposed on its way into LDS (4 k-rows packed per ds_write_b64), so the MFMA loop is
-//   the same for NT / NN / TN.  Tile -> workgroup mapping is XCD-aware (bijective chunking of the tile list over
-//   the 8 XCDs so that tiles sharing an A row-panel hit the same L2).
-// * f32 path: exact-fp32 VALU tile kernel with arbitrary strides (parity / fp32 configuration).
-// Both share one epilogue (bias, Swish+dropout, residual, Swish-grad, ReLU+time-mask, ReLU-grad, atomic split-K).
+// bf16 (MFMA `v_mfma_f32_32x32x16_bf16`), four structures behind one descriptor (`mi355x_gemm`):
+//   * gemm_bf16_v2_kernel   256x128x64 tile, 8 waves x (64x64), three LDS stages filled by LDS-DMA two K-tiles ahead
+//                           (counted vmcnt, raw s_barrier), ds_read_b128 / ds_read_b64_tr_b16 fragments  -- the default
+//   * gemm_bf16_v4_kernel   256x256x64 tile, 8 waves x (128x64), two LDS stages -- when the larger tile still fills the chip
+//   * gemm_bf16_grouped_tn_kernel   up to 12 weight-gradient problems in one launch of the v2 body (`mi355x_gemm_grouped`)
+//   * gemm_bf16_kernel      128x128x64 tile, 4 waves, register-staged -- small problems and the TN / K-contiguous-B layout
+// An operand may be stored "reduction-major" ([K][rows]: both wgrad operands); it is DMA'd as it lies in memory and
+// transposed by the LDS read.  Operand A (forward / dgrad) or the reduction-major B (wgrad) of a convolution can be
+// GATHERED from a channels-last grid by the LDS-DMA (implicit GEMM), and output rows can be scattered (row map).
+// Tile -> workgroup mapping is XCD-aware (bijective chunking of the tile list over the 8 XCDs so that tiles sharing an
+// operand panel hit the same L2).
+// f32 path: exact-fp32 VALU tile kernel with arbitrary strides (parity / fp32 configuration).
+// All share the epilogue kinds below (bias, Swish+dropout, residual, Swish-grad, ReLU+time-mask, ReLU-grad, atomic split-K).
 //
-// Replaces on the reference path: torch.nn.functional.linear / conv1d(k=1) / matmul / conv2d (im2col form) calls in
+// Replaces on the reference path: torch.nn.functional.linear / conv1d(k=1) / matmul / conv2d calls in
 //   nemo/collections/asr/parts/submodules/conformer_modules.py:382-387 (FFN), :321,343 (pointwise convs),
-//   multi_head_attention.py:124-146,300-350 (q/k/v/pos/out projections, QK^T, PV),
+//   multi_head_attention.py:124-146,300-350 (q/k/v/pos/out projections; QK^T, PV on the fp32 path),
 //   subsampling.py:431 (out Linear), :231-253 (conv2), modules/conv_asr.py:445 (decoder).
 #include <stdlib.h>
 #include "common.cuh"

@@ -435,11 +435,10 @@ class ConformerEncoder(NeuralModule):
         S.dims = (B, F_, T, T1, F1, T2, F2, M, cdt, training, seed)
         S.mel, S.len0, S.len2 = mel, len0, len2
         pe = self.pre_encode
-        # ---- sub-sampling: conv1 (direct) -> im2col -> conv2 (MFMA GEMM, ReLU+mask epilogue) -> out Linear (+xscale, dropout)
+        # ---- sub-sampling: conv1 (direct) -> conv2 (implicit MFMA GEMM, ReLU+mask epilogue) -> out Linear (+xscale, dropout)
         S.out1 = torch.empty(B, T1, F1, C_, dtype=cdt, device=dev)
         ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, S.out1, len0, len1, C_)
-        # the 3 GB im2col image stays alive until the conv2 weight gradient (1 % of the 288 GB HBM; recomputing it in
-        # backward cost 0.83 ms per step)
+        # (channel counts the gather does not cover fall back to an im2col image, kept alive for the weight gradient)
         implicit = (self.conv2_implicit and self._conv2_implicit(cdt, C_, B * T2 * F2)
                     and B * T1 * F1 * C_ < 2 ** 31)  # the gathered weight gradient addresses the grid with 32-bit offsets
         S.col = None
