@@ -228,6 +228,13 @@ int mi355x_fill_f32(void* p, long long n, float value, void* stream);
 /* library / build information */
 const char* mi355x_asr_version(void);
 
+/* Greedy CTC decoding on the device (GreedyCTCInfer._greedy_decode_logprobs, parts/submodules/ctc_greedy_decoding.py:333-361,
+ * + the CTC collapse of AbstractCTCDecoding.decode_hypothesis, parts/submodules/ctc_decoding.py:545-575):
+ * logp f32 [B,T,C], lens i64 [B] (NULL = T) -> tokens i32 [B,T] (folded, blank-free, -1 padded), out_len i32 [B],
+ * score f32 [B] = sum of the arg-max log-probs of the non-blank frames. */
+int mi355x_ctc_greedy_decode(const void* logp, const void* lens, void* tokens, void* out_len, void* score, int B, int T, int C,
+                             int blank, void* stream);
+
 /* SpectrogramAugmentation (nemo/collections/asr/modules/audio_preprocessing.py:443-553; SpecAugment._apply_masks
  * parts/submodules/spectr_augment.py:153-215, SpecCutout.forward :245-261): x[b, f0:f1, t0:t1] = value for n rectangles
  * rects[n][5] = (b, f0, f1, t0, t1) (int32, device memory; clipped to the tensor).  x: f32 [B, F, T], in place. */

@@ -173,3 +173,63 @@ extern "C" int mi355x_ctc_loss(const void* logp, const void* targets, const void
                        Smax, blank, grad_scale);
   return mi_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------ greedy CTC decoding
+// GreedyCTCInfer._greedy_decode_logprobs (parts/submodules/ctc_greedy_decoding.py:333-361) + the CTC collapse of
+// AbstractCTCDecoding.decode_hypothesis (parts/submodules/ctc_decoding.py:545-575), one workgroup per utterance, no host
+// round trip: per-frame argmax (first maximum, like torch.max) and its log-probability, score = sum of the log-probs of
+// the non-blank frames, tokens = labels with repeats folded and blanks removed (wave ballot + prefix popcount compaction).
+__global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict__ logp, const long long* __restrict__ lens,
+                                                         int* __restrict__ tokens, int* __restrict__ out_len,
+                                                         float* __restrict__ score, int Tmax, int C, int blank) {
+  extern __shared__ int s_lab[];  // [Tmax] labels ; then [Tmax] log-probs (as float)
+  float* s_lp = reinterpret_cast<float*>(s_lab + Tmax);
+  const int b = blockIdx.x;
+  const int T = (int)min((long long)Tmax, lens ? lens[b] : (long long)Tmax);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* lp = logp + (long long)b * Tmax * C;
+  for (int t = wave; t < T; t += 4) {
+    float best = -INFINITY; int arg = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+      const float v = lp[(long long)t * C + c];
+      if (v > best) { best = v; arg = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64); const int oa = __shfl_xor(arg, o, 64);
+      if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    if (lane == 0) { s_lab[t] = arg; s_lp[t] = best; }
+  }
+  __syncthreads();
+  int* tok = tokens + (long long)b * Tmax;
+  if (wave == 0) {
+    int base = 0; float sc = 0.f;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int t = t0 + lane;
+      const int cur = t < T ? s_lab[t] : blank;
+      const int prev = (t > 0 && t < T) ? s_lab[t - 1] : blank;
+      const bool nonblank = t < T && cur != blank;
+      const bool keep = nonblank && cur != prev;
+      if (nonblank) sc += s_lp[t];
+      const unsigned long long m = __ballot(keep);
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (keep) tok[pos] = cur;
+      base += __popcll(m);
+    }
+    sc = wave_sum(sc);
+    if (lane == 0) { out_len[b] = base; score[b] = sc; }
+    for (int t = base + lane; t < Tmax; t += 64) tok[t] = -1;  // padding
+  }
+}
+extern "C" int mi355x_ctc_greedy_decode(const void* logp, const void* lens, void* tokens, void* out_len, void* score, int B,
+                                        int Tmax, int C, int blank, void* stream) {
+  mi_clear_errors();
+  if (!logp || !tokens || !out_len || !score || B <= 0 || Tmax <= 0 || C <= 0 || blank < 0 || blank > C) return MI_ERR_ARG;
+  const size_t shm = (size_t)Tmax * 8;
+  if (shm > 64 * 1024) return MI_ERR_ARG;
+  hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), shm, (hipStream_t)stream, (const float*)logp, (const long long*)lens,
+                     (int*)tokens, (int*)out_len, (float*)score, Tmax, C, blank);
+  return mi_check_launch();
+}
+

@@ -228,6 +228,17 @@ def qbias(qkv, ldq, u, v, qu, qv, M, d):
     check(lib.mi355x_qbias(_ptr(qkv), ldq, _ptr(u), _ptr(v), _ptr(qu), _ptr(qv), dt(qkv), M, d, _stream()), "qbias")
 
 
+def ctc_greedy_decode(logp, lens, blank):
+    """logp f32 [B,T,C] -> (tokens i32 [B,T] folded / blank-free / -1 padded, out_len i32 [B], score f32 [B])"""
+    B, T, C_ = logp.shape
+    tokens = torch.empty(B, T, dtype=torch.int32, device=logp.device)
+    out_len = torch.empty(B, dtype=torch.int32, device=logp.device)
+    score = torch.empty(B, dtype=torch.float32, device=logp.device)
+    check(lib.mi355x_ctc_greedy_decode(_ptr(logp), _ptr(lens), _ptr(tokens), _ptr(out_len), _ptr(score), B, T, C_, blank,
+                                       _stream()), "ctc_greedy_decode")
+    return tokens, out_len, score
+
+
 def fill_rects(x, rects, value=0.0):
     """x[b, f0:f1, t0:t1] = value for rects [n,5] int32 = (b, f0, f1, t0, t1); x f32 [B,F,T], in place"""
     B, F, T = x.shape

@@ -766,6 +766,40 @@ def test_ctc_random_ragged_vs_oracle():
 
 
 # ---------------------------------------------------------------------------------------------- optimizer / packing
+def test_ctc_greedy_decode_vs_oracle():
+    """mi355x_ctc_greedy_decode against the restated reference loop on random ragged log-probs (with ties and long
+    repeats), and the text / WER plumbing of the drop-in decoder"""
+    from nemo_amd.modules import GreedyCTCDecoder, WER
+    from oracle import decode_ref as D
+    o = ops()
+    g = torch.Generator().manual_seed(41)
+    B, T, V = 5, 301, 28
+    x = torch.randn(B, T, V + 1, generator=g)
+    x[:, :, V] += 1.5                                   # plenty of blanks
+    x[1, 40:90] = x[1, 40:41]                           # a long repeat
+    x[2, :, :] = torch.round(x[2] * 2) / 2              # exact ties: the first maximum wins (torch.max)
+    logp = torch.log_softmax(x, -1)
+    lens = torch.tensor([T, 250, 301, 0, 17])
+    ref = D.greedy_decode(logp, lens, blank=V)
+    tok, olen, score = o.ctc_greedy_decode(logp.to(dev), lens.to(dev), V)
+    torch.cuda.synchronize()
+    tok, olen, score = tok.cpu(), olen.cpu(), score.cpu()
+    for b, (rt, rs) in enumerate(ref):
+        assert int(olen[b]) == len(rt), b
+        assert tok[b, : len(rt)].tolist() == rt, b
+        assert torch.all(tok[b, len(rt):] == -1)
+        assert abs(score[b].item() - rs) <= 1e-4 * max(1.0, abs(rs)), b
+    vocab = [chr(ord("a") + i) for i in range(26)] + [" ", "'"]
+    dec = GreedyCTCDecoder(vocab)
+    texts = dec(logp.to(dev), lens.to(dev))
+    assert texts == [D.tokens_to_text(rt, vocab) for rt, _ in ref]
+    wer = WER(dec)
+    tgt = torch.randint(0, V, (B, 12), generator=g); tl = torch.tensor([12, 10, 12, 3, 5])
+    wer.update(logp.to(dev), lens.to(dev), tgt.to(dev), tl.to(dev))
+    refs = [D.tokens_to_text(tgt[b, : int(tl[b])].tolist(), vocab) for b in range(B)]
+    assert abs(wer.compute()[0] - D.word_error_rate(texts, refs)) < 1e-12
+
+
 def test_adamw_matches_torch():
     o = ops()
     n = 4096 + 64

@@ -168,3 +168,35 @@ def test_specaug_cutout_restatement_matches_reference_fixture(golden_dir):
     y = SR.apply_rects(y, SR.legacy_rects(rng, B, F, T, length, 1, 2, 10, 25), 0.0)
     assert np.array_equal((y != x).numpy(), _unpack(z, "cutout_then_legacy"))
 
+
+# ---------------------------------------------------------------------------------------------- greedy decode / WER (8f-5)
+def test_wer_restatement_matches_reference_test_vectors():
+    """tests/collections/asr/test_asr_metrics.py:119-124 (the reference's own word_error_rate assertions)"""
+    from oracle import decode_ref as D
+    from nemo_amd.modules.ctc_decoding import word_error_rate
+    for fn in (D.word_error_rate, word_error_rate):
+        assert fn(hypotheses=['cat'], references=['cot']) == 1.0
+        assert fn(hypotheses=['GPU'], references=['G P U']) == 1.0
+        assert fn(hypotheses=['G P U'], references=['GPU']) == 3.0
+        assert fn(hypotheses=['ducati motorcycle'], references=['motorcycle']) == 1.0
+        assert fn(hypotheses=['ducati motorcycle'], references=['ducuti motorcycle']) == 0.5
+        assert fn(hypotheses=['a B c'], references=['a b c']) == 1.0 / 3.0
+        assert fn(hypotheses=['cat'], references=['cot'], use_cer=True) == 1.0 / 3.0
+        with pytest.raises(ValueError):
+            fn(hypotheses=['a'], references=['a', 'b'])
+
+
+def test_greedy_decode_restatement_folds_like_the_reference_loop():
+    from oracle import decode_ref as D
+    V = 5  # blank = 5
+    labels = [5, 1, 1, 5, 1, 2, 2, 2, 5, 5, 3, 3, 4, 5]
+    logp = torch.full((1, len(labels), V + 1), -5.0)
+    for t, c in enumerate(labels):
+        logp[0, t, c] = -0.1 * (t + 1)
+    (toks, score), = D.greedy_decode(logp, torch.tensor([len(labels)]), blank=V)
+    assert toks == [1, 1, 2, 3, 4]
+    assert abs(score - sum(-0.1 * (t + 1) for t, c in enumerate(labels) if c != V)) < 1e-5
+    (toks, _), = D.greedy_decode(logp, torch.tensor([6]), blank=V)  # out_len truncates before decoding
+    assert toks == [1, 1, 2]
+    assert D.tokens_to_text([0, 1, 2], ["a", "b", "c"]) == "abc"
+
