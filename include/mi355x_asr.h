@@ -110,6 +110,13 @@ int mi355x_layernorm_fwd(const void* x, int x_dtype, const void* gamma, const vo
 /* dres (f32 [M,d]) = (accumulate ? dres : 0) + dLN/dx ; dgamma/dbeta (f32 [d], may be NULL) are accumulated (+=)   */
 int mi355x_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const void* gamma, const void* mean,
                          const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d, void* stream);
+/* Same, and in the same pass cast_out (bf16 [M,d]) = cast_scale * dropmask * dres_new: the operand of the NEXT sub-block's
+ * output-projection gradient GEMMs (the residual-branch gradient through that sub-block's dropout), which otherwise costs a
+ * separate read of the fp32 gradient (mi355x_drop_scale_cast).  M*d % 8 == 0. */
+int mi355x_layernorm_bwd_cast(const void* dy, int dy_dtype, const void* x, int x_dtype, const void* gamma, const void* mean,
+                              const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d,
+                              void* cast_out, float cast_scale, unsigned drop_key, unsigned drop_threshold, float drop_scale,
+                              void* stream);
 /* out[n] += alpha * sum_m x[m,n]  (bias / pos_bias gradients) */
 int mi355x_colsum(const void* x, int x_dtype, long long ld, void* out, int M, int N, float alpha, void* stream);
 

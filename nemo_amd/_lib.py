@@ -67,6 +67,7 @@ SIGNATURES = {
     "mi355x_col2im_3x3s2_relu": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mi355x_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp],
     "mi355x_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp],
+    "mi355x_layernorm_bwd_cast": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, f32, u32, u32, f32, vp],
     "mi355x_colsum": [vp, i32, i64, vp, i32, i32, f32, vp],
     "mi355x_log_softmax_fwd": [vp, i64, vp, i64, i32, i32, vp],
     "mi355x_log_softmax_bwd": [vp, vp, i64, vp, i32, i64, i32, i32, f32, vp],

@@ -338,13 +338,147 @@ extern "C" int mi355x_layernorm_fwd(const void* x, int x_dt, const void* gamma, 
   return mi_check_launch();
 }
 
+// 8-wide variant for d = 512 / 1024: lane = 8 consecutive elements per 512-wide chunk (16-byte bf16 / 32-byte f32
+// accesses).  It can also emit, in the same pass, the NEXT consumer's operand: cast_out = bf16(scale * dropmask * dres_new)
+// -- the residual-branch gradient that the following sub-block's output GEMMs read (conformer_modules.py:205-231 backward;
+// saves one read of the fp32 gradient and one launch per sub-block).  Dropout groups = 8 consecutive elements = one lane chunk.
+template <typename TX, typename TDY, int NCH>
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_fused8_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dres,
+                                                            int accumulate, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int M, int d,
+                                                            bf16_t* __restrict__ cast_out, float cast_scale, DropCfg cast_drop) {
+  __shared__ float red[LNB_WAVES][2][NCH * 512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float g[NCH][8], ag[NCH][8], ab[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    ld8g(gamma + c * 512 + lane * 8, g[c]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ag[c][j] = 0.f; ab[c][j] = 0.f; }
+  }
+  const int r0 = blockIdx.x * LNB_ROWS, r1 = min(M, r0 + LNB_ROWS);
+  for (int row = r0 + wave; row < r1; row += LNB_WAVES) {
+    const TX* xr = x + (long long)row * d;
+    const TDY* dyr = dy + (long long)row * d;
+    float* dr = dres + (long long)row * d;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NCH][8], e[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float v[8];
+      ld8g(xr + c * 512 + lane * 8, v); ld8g(dyr + c * 512 + lane * 8, e[c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[c][j] = (v[j] - mu) * rs;
+        const float gd = g[c][j] * e[c][j];
+        s1 += gd; s2 += gd * xh[c][j];
+        ag[c][j] += e[c][j] * xh[c][j]; ab[c][j] += e[c][j];
+      }
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float o[8];
+      if (accumulate) ld8g(dr + c * 512 + lane * 8, o);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += rs * (g[c][j] * e[c][j] - s1 - xh[c][j] * s2);
+      st8g(dr + c * 512 + lane * 8, o);
+      if (cast_out) {
+        float m[8];
+        drop_mask8(cast_drop, (uint32_t)row * (uint32_t)d + (uint32_t)(c * 512 + lane * 8), m);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] *= cast_scale * m[j];
+        st8g(cast_out + (long long)row * d + c * 512 + lane * 8, o);
+      }
+    }
+  }
+  if (!dgamma) return;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[wave][0][c * 512 + lane * 8 + j] = ag[c][j];
+      red[wave][1][c * 512 + lane * 8 + j] = ab[c][j];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 64 * LNB_WAVES) {
+    float sg_ = 0.f, sb_ = 0.f;
+#pragma unroll
+    for (int w = 0; w < LNB_WAVES; ++w) { sg_ += red[w][0][c]; sb_ += red[w][1][c]; }
+    atomicAdd(dgamma + c, sg_);
+    atomicAdd(dbeta + c, sb_);
+  }
+}
+
+static int layernorm_bwd_impl(const void* dy, int dy_dt, const void* x, int x_dt, const void* gamma, const void* mean,
+                              const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d,
+                              void* cast_out, float cast_scale, DropCfg cast_drop, void* stream);
 extern "C" int mi355x_layernorm_bwd(const void* dy, int dy_dt, const void* x, int x_dt, const void* gamma, const void* mean,
                                     const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d,
                                     void* stream) {
   mi_clear_errors();
+  DropCfg nodrop; nodrop.key = 0u; nodrop.threshold = 0u; nodrop.scale = 1.f;
+  return layernorm_bwd_impl(dy, dy_dt, x, x_dt, gamma, mean, rstd, dres, accumulate, dgamma, dbeta, M, d, nullptr, 1.f, nodrop,
+                            stream);
+}
+extern "C" int mi355x_layernorm_bwd_cast(const void* dy, int dy_dt, const void* x, int x_dt, const void* gamma, const void* mean,
+                                         const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d,
+                                         void* cast_out, float cast_scale, unsigned drop_key, unsigned drop_threshold,
+                                         float drop_scale, void* stream) {
+  mi_clear_errors();
+  if (!cast_out || ((uintptr_t)cast_out & 15)) return MI_ERR_ARG;
+  DropCfg dc; dc.key = drop_key; dc.threshold = drop_threshold; dc.scale = drop_scale;
+  return layernorm_bwd_impl(dy, dy_dt, x, x_dt, gamma, mean, rstd, dres, accumulate, dgamma, dbeta, M, d, cast_out, cast_scale, dc,
+                            stream);
+}
+__global__ __launch_bounds__(256) void ln_cast_after_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long n8,
+                                                            float alpha, DropCfg drop) {  // fallback: separate cast pass
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float a[8], m[8];
+    ld8g(in + i * 8, a);
+    drop_mask8(drop, (uint32_t)(i * 8), m);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] *= alpha * m[j];
+    st8g(out + i * 8, a);
+  }
+}
+static int layernorm_bwd_impl(const void* dy, int dy_dt, const void* x, int x_dt, const void* gamma, const void* mean,
+                              const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d,
+                              void* cast_out, float cast_scale, DropCfg cast_drop, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dres || M <= 0 || d <= 0 || (d & 3)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 block(256);
+  const bool al = !((uintptr_t)dy & 15) && !((uintptr_t)x & 31) && !((uintptr_t)dres & 31) && !((uintptr_t)gamma & 31);
+  if (al && (d == 512 || d == 1024) && ((dgamma && dbeta) || (!dgamma && !dbeta))) {
+    dim3 gridf((M + LNB_ROWS - 1) / LNB_ROWS);
+    dim3 blockf(64 * LNB_WAVES);
+#define LN_F8(NCH) DISPATCH_DT(x_dt, TX, DISPATCH_DT(dy_dt, TDY, \
+      hipLaunchKernelGGL((ln_bwd_fused8_kernel<TX, TDY, NCH>), gridf, blockf, 0, s, (const TDY*)dy, (const TX*)x, \
+                         (const float*)gamma, (const float*)mean, (const float*)rstd, (float*)dres, accumulate, \
+                         (float*)dgamma, (float*)dbeta, M, d, (bf16_t*)cast_out, cast_scale, cast_drop)))
+    if (d == 512) { LN_F8(1); } else { LN_F8(2); }
+#undef LN_F8
+    return mi_check_launch();
+  }
+  struct CastAfter {  // any other path: run the plain kernels, then the cast as its own pass
+    void* out; float scale; DropCfg drop; const void* in; long long n; hipStream_t s;
+    ~CastAfter() {
+      if (out && (n & 7) == 0) {
+        long long nb = (n / 8 + 255) / 256; if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(ln_cast_after_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)in, (bf16_t*)out, n / 8,
+                           scale, drop);
+      }
+    }
+  } cast_after{cast_out, cast_scale, cast_drop, dres, (long long)M * d, s};
+  if (cast_out && (((long long)M * d) & 7)) return MI_ERR_ARG;
   if (d <= 1024 && ((dgamma && dbeta) || (!dgamma && !dbeta))) {
     dim3 gridf((M + LNB_ROWS - 1) / LNB_ROWS);
     dim3 blockf(64 * LNB_WAVES);

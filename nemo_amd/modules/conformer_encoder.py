@@ -205,6 +205,7 @@ class ConformerEncoder(NeuralModule):
         self.wgrad_grouped = os.environ.get("MI355X_WGRAD_GROUPED", "1") != "0"
         self._wg_pending, self._wg_rows = None, None
         self.conv2_implicit = os.environ.get("MI355X_CONV2_IMPLICIT", "1") != "0"
+        self.ln_cast_fuse = os.environ.get("MI355X_LN_CAST_FUSE", "1") != "0"
         self._plans = {}
         self._ws = {}
         self._pos_cache = {}
@@ -710,18 +711,32 @@ class ConformerEncoder(NeuralModule):
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(*fp.range_of("pre_encode."))
 
-    def _ffn_bwd(self, pfx, ff, ln, saved, dr, W, M, d, dff, cdt, dev):
+    def _ffn_bwd(self, pfx, ff, ln, saved, dr, W, M, d, dff, cdt, dev, df=None, next_cast=None):
+        """`df` = the already cast / dropped / scaled residual-branch gradient when the previous LayerNorm backward produced
+        it in its own pass; `next_cast` = (scale, Dropout) of the sub-block that follows in backward order: this block's
+        LayerNorm backward then emits that operand too.  Returns (dr, cast_for_next_or_None)."""
         x, y, mean, rstd, h, a, d_in, d_res = saved
-        df = torch.empty(M, d, dtype=cdt, device=dev)
-        ops.drop_scale_cast(dr, df, M * d, 0.5, d_res)
+        if df is None:
+            df = torch.empty(M, d, dtype=cdt, device=dev)
+            ops.drop_scale_cast(dr, df, M * d, 0.5, d_res)
         self._wgrad(df, d, 0, a, dff, 0, ff.linear2.weight.grad, d, dff, M, bias_grad=ff.linear2.bias.grad)
         dh = torch.empty(M, dff, dtype=cdt, device=dev)
         ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, d, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH, aux_in=h, drop=d_in)
         self._wgrad(dh, dff, 0, y, d, 0, ff.linear1.weight.grad, dff, d, M, bias_grad=ff.linear1.bias.grad)
         dy = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(dh, W[pfx + ".w1t"], dy, M, d, dff, dff, W.pitch(pfx + ".w1t"), d)
-        ops.layernorm_bwd(dy, x, ln.weight, mean, rstd, dr, True, ln.weight.grad, ln.bias.grad, M, d)
-        return dr
+        nxt = self._cast_buf(next_cast, M, d, cdt, dev)
+        ops.layernorm_bwd(dy, x, ln.weight, mean, rstd, dr, True, ln.weight.grad, ln.bias.grad, M, d, cast_out=nxt,
+                          cast_scale=next_cast[0] if nxt is not None else 1.0,
+                          cast_drop=next_cast[1] if nxt is not None else None)
+        return dr, nxt
+
+    def _cast_buf(self, next_cast, M, d, cdt, dev):
+        """bf16 operand buffer for a fused LayerNorm-backward cast (bf16 compute only; d must be one the 8-wide kernel covers
+        or the C side falls back to a separate pass -- still correct)"""
+        if next_cast is None or cdt != torch.bfloat16 or (M * d) % 8 or not self.ln_cast_fuse:
+            return None
+        return torch.empty(M, d, dtype=cdt, device=dev)
 
     def _layer_bwd(self, i, L, dxo, S, sl, W, Wf):
         B, F_, T, T1, F1, T2, F2, M, cdt, training, seed = S.dims
@@ -734,16 +749,24 @@ class ConformerEncoder(NeuralModule):
         r4, mean5, rstd5 = sl.out
         dr = torch.empty(M, d, dtype=torch.float32, device=dev)
         ln = L.norm_out
-        ops.layernorm_bwd(dxo, r4, ln.weight, mean5, rstd5, dr, False, ln.weight.grad, ln.bias.grad, M, d)
+        # every LayerNorm backward also emits the bf16 (scaled, dropped) copy of the new residual gradient that the next
+        # sub-block's output GEMMs consume -- one read of the fp32 gradient and one launch less per sub-block
+        nc = (0.5, sl.ff2[7])
+        df2 = self._cast_buf(nc, M, d, cdt, dev)
+        ops.layernorm_bwd(dxo, r4, ln.weight, mean5, rstd5, dr, False, ln.weight.grad, ln.bias.grad, M, d, cast_out=df2,
+                          cast_scale=0.5, cast_drop=nc[1] if df2 is not None else None)
         # ---- FFN 2
-        dr = self._ffn_bwd(f"L{i}.ff2", L.feed_forward2, L.norm_feed_forward2, sl.ff2, dr, W, M, d, dff, cdt, dev)
+        dr, db_pre = self._ffn_bwd(f"L{i}.ff2", L.feed_forward2, L.norm_feed_forward2, sl.ff2, dr, W, M, d, dff, cdt, dev,
+                                   df=df2, next_cast=(1.0, sl.conv[11]))
         # ---- convolution module
         c = L.conv
         bn = c.batch_norm
         k = self.conv_kernel_size
         r2, y3, mean3, rstd3, pw1, g, cc, bmean, brstd, count, z, d_cres = sl.conv
-        db = torch.empty(M, d, dtype=cdt, device=dev)
-        ops.drop_scale_cast(dr, db, M * d, 1.0, d_cres)
+        db = db_pre
+        if db is None:
+            db = torch.empty(M, d, dtype=cdt, device=dev)
+            ops.drop_scale_cast(dr, db, M * d, 1.0, d_cres)
         self._wgrad(db, d, 0, z, d, 0, c.pointwise_conv2.weight.grad, d, d, M, bias_grad=c.pointwise_conv2.bias.grad)
         dz = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(db, W[f"L{i}.conv.pw2t"], dz, M, d, d, d, W.pitch(f"L{i}.conv.pw2t"), d)
@@ -762,12 +785,17 @@ class ConformerEncoder(NeuralModule):
         dy3 = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(dpw1, W[f"L{i}.conv.pw1t"], dy3, M, d, 2 * d, 2 * d, W.pitch(f"L{i}.conv.pw1t"), d)
         ln = L.norm_conv
-        ops.layernorm_bwd(dy3, r2, ln.weight, mean3, rstd3, dr, True, ln.weight.grad, ln.bias.grad, M, d)
+        nc = (1.0, sl.att[12])
+        dao_pre = self._cast_buf(nc, M, d, cdt, dev)
+        ops.layernorm_bwd(dy3, r2, ln.weight, mean3, rstd3, dr, True, ln.weight.grad, ln.bias.grad, M, d, cast_out=dao_pre,
+                          cast_scale=1.0, cast_drop=nc[1] if dao_pre is not None else None)
         # ---- self-attention
         a = L.self_attn
         r1, y2, mean2, rstd2, qkv, p, qu, qv, s_, pd, ctx, d_att, d_ares, lse = sl.att
-        dao = torch.empty(M, d, dtype=cdt, device=dev)
-        ops.drop_scale_cast(dr, dao, M * d, 1.0, d_ares)
+        dao = dao_pre
+        if dao is None:
+            dao = torch.empty(M, d, dtype=cdt, device=dev)
+            ops.drop_scale_cast(dr, dao, M * d, 1.0, d_ares)
         self._wgrad(dao, d, 0, ctx, d, 0, a.linear_out.weight.grad, d, d, M, bias_grad=a.linear_out.bias.grad)
         dctx = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(dao, W[f"L{i}.att.wot"], dctx, M, d, d, d, W.pitch(f"L{i}.att.wot"), d)
@@ -840,7 +868,10 @@ class ConformerEncoder(NeuralModule):
         dy2 = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(dqkv, W[f"L{i}.att.wqkvt"], dy2, M, d, 3 * d, 3 * d, W.pitch(f"L{i}.att.wqkvt"), d)
         ln = L.norm_self_att
-        ops.layernorm_bwd(dy2, r1, ln.weight, mean2, rstd2, dr, True, ln.weight.grad, ln.bias.grad, M, d)
+        nc = (0.5, sl.ff1[7])
+        df1 = self._cast_buf(nc, M, d, cdt, dev)
+        ops.layernorm_bwd(dy2, r1, ln.weight, mean2, rstd2, dr, True, ln.weight.grad, ln.bias.grad, M, d, cast_out=df1,
+                          cast_scale=0.5, cast_drop=nc[1] if df1 is not None else None)
         # ---- FFN 1
-        dr = self._ffn_bwd(f"L{i}.ff1", L.feed_forward1, L.norm_feed_forward1, sl.ff1, dr, W, M, d, dff, cdt, dev)
+        dr, _ = self._ffn_bwd(f"L{i}.ff1", L.feed_forward1, L.norm_feed_forward1, sl.ff1, dr, W, M, d, dff, cdt, dev, df=df1)
         return dr

@@ -191,9 +191,17 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d, eps=1e-5):
                                    _stream()), "layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, accumulate, dgamma, dbeta, M, d):
-    check(lib.mi355x_layernorm_bwd(_ptr(dy), dt(dy), _ptr(x), dt(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
-                                   int(accumulate), _ptr(dgamma), _ptr(dbeta), M, d, _stream()), "layernorm_bwd")
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, accumulate, dgamma, dbeta, M, d, cast_out=None, cast_scale=1.0,
+                  cast_drop: "Dropout" = None):
+    """cast_out (bf16 [M,d], optional) = cast_scale * dropmask(cast_drop) * dres_new, written in the same pass"""
+    if cast_out is None:
+        check(lib.mi355x_layernorm_bwd(_ptr(dy), dt(dy), _ptr(x), dt(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
+                                       int(accumulate), _ptr(dgamma), _ptr(dbeta), M, d, _stream()), "layernorm_bwd")
+    else:
+        dr = cast_drop if cast_drop is not None else NO_DROP
+        check(lib.mi355x_layernorm_bwd_cast(_ptr(dy), dt(dy), _ptr(x), dt(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
+                                            int(accumulate), _ptr(dgamma), _ptr(dbeta), M, d, _ptr(cast_out), cast_scale,
+                                            dr.key, dr.threshold, dr.scale, _stream()), "layernorm_bwd_cast")
 
 
 def colsum(x, out, M, N, ld=None, alpha=1.0, x_off=0):
