@@ -206,6 +206,7 @@ class ConformerEncoder(NeuralModule):
         self._wg_pending, self._wg_rows = None, None
         self.conv2_implicit = os.environ.get("MI355X_CONV2_IMPLICIT", "1") != "0"
         self.ln_cast_fuse = os.environ.get("MI355X_LN_CAST_FUSE", "1") != "0"
+        self.dpos_side_stream = os.environ.get("MI355X_DPOS_STREAM", "1") != "0"
         self._plans = {}
         self._ws = {}
         self._pos_cache = {}
@@ -655,6 +656,7 @@ class ConformerEncoder(NeuralModule):
                     self._wgrad_join()
                 self.grad_ready_hook(*fp.range_of(f"layers.{i}."))
         self._wg_pending = None  # (the remaining weight gradients have their own shapes / layouts)
+        self._wgrad_join()       # dp_all may have been produced on the side stream
         self._pos_proj_wgrad(S.dp_all, S.pos, P, cdt)
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(*fp.tail_range())
@@ -810,11 +812,21 @@ class ConformerEncoder(NeuralModule):
             dlt = torch.empty(B, H, T2, dtype=torch.float32, device=dev)
             ops.attn_delta(dctx, ctx, dlt, B, H, T2, d)
             Tp32 = (T2 + 31) // 32 * 32
-            dS = self._buf("dS", (H, B, T2, Tp32), cdt, dev)  # transient: dQ kernel -> linear_pos gradient kernel
+            # transient dS: dQ kernel -> linear_pos gradient kernel.  The latter feeds only the (batched, end-of-backward)
+            # linear_pos weight gradient, so with the side stream it leaves the critical path; dS then comes from the
+            # caching allocator (record_stream keeps the next layer's dQ kernel from overwriting it too early).
+            side_pos = self.dpos_side_stream and self.wgrad_side_stream
+            dS = (torch.empty(H, B, T2, Tp32, dtype=cdt, device=dev) if side_pos
+                  else self._buf("dS", (H, B, T2, Tp32), cdt, dev))
             ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * d, p, d, S.len2, dctx, lse, dlt, dqu, dqv, B, H, T2, dk, Tp32, scale, d_att,
                                     ds_out=dS)
+            if side_pos:
+                with self._wgrad_scope(qv, dS):
+                    ops.relpos_flash_bwd_dpos(qv, dS, S.len2, dp, B, H, T2, dk, Tp32)
+                    ops.drop_scale_cast(dp, S.dp_all[i], P * d, 1.0)
             ops.relpos_flash_bwd_dkv(qu, qv, qkv, 3 * d, p, d, S.len2, dctx, lse, dlt, dqkv, 3 * d, B, H, T2, dk, Tp, scale, d_att)
-            ops.relpos_flash_bwd_dpos(qv, dS, S.len2, dp, B, H, T2, dk, Tp32)
+            if not side_pos:
+                ops.relpos_flash_bwd_dpos(qv, dS, S.len2, dp, B, H, T2, dk, Tp32)
         else:
             # dpd[h,b] = dctx_bh @ v_bh^T  -> reuse the f32 score workspace
             dpd = self._buf("ac", (H, B, T2, Tp), torch.float32, dev)
@@ -839,7 +851,8 @@ class ConformerEncoder(NeuralModule):
             tiles = self._tiles(P, dk, cdt == torch.bfloat16) * H
             ops.gemm(dbdf, qv, dp, P, dk, B * T2, Pp, d, d, transA=True, transB=True, atomic=True,
                      splitk=self._splitk(tiles, B * T2), batch=H, nb0=H, sA=(B * T2 * Pp, 0), sB=(dk, 0), sC=(dk, 0))
-        ops.drop_scale_cast(dp, S.dp_all[i], P * d, 1.0)  # linear_pos weight gradients: one batched GEMM after the loop
+        if not (lse is not None and self.dpos_side_stream and self.wgrad_side_stream):
+            ops.drop_scale_cast(dp, S.dp_all[i], P * d, 1.0)  # linear_pos weight gradients: one batched GEMM after the loop
         gu, gv_ = a.pos_bias_u.grad, a.pos_bias_v.grad
         if cdt == torch.bfloat16 and gv_.data_ptr() - gu.data_ptr() == 4 * d:
             ops.add2_colsum(dqu, dqv, dqkv, 3 * d, M, d, gu)  # dq = dqu + dqv and both bias gradients in one pass
