@@ -207,6 +207,7 @@ class ConformerEncoder(NeuralModule):
         self.conv2_implicit = os.environ.get("MI355X_CONV2_IMPLICIT", "1") != "0"
         self.ln_cast_fuse = os.environ.get("MI355X_LN_CAST_FUSE", "1") != "0"
         self.dpos_side_stream = os.environ.get("MI355X_DPOS_STREAM", "1") != "0"
+        self.sub_wgrad_side_stream = os.environ.get("MI355X_SUB_WGRAD_STREAM", "1") != "0"
         self._plans = {}
         self._ws = {}
         self._pos_cache = {}
@@ -386,6 +387,11 @@ class ConformerEncoder(NeuralModule):
         for t in tensors:
             t.record_stream(side)  # the caching allocator must not hand the storage out again before the side stream is done
         return torch.cuda.stream(side)
+
+    def _sub_wgrad_scope(self, *tensors):
+        """the sub-sampling weight gradients also go to the side stream (they overlap conv1's HBM-bound backward)"""
+        import contextlib
+        return self._wgrad_scope(*tensors) if self.sub_wgrad_side_stream else contextlib.nullcontext()
 
     def _wgrad_flush(self):
         """launch the collected weight gradients of a layer as one grouped TN GEMM (side stream)"""
@@ -667,9 +673,10 @@ class ConformerEncoder(NeuralModule):
         ops.colsum(dxs, pe.out.bias.grad, M, d)
         # d out.weight in the reference's (c, f) column order: batch over f, C column stride F2
         tiles = self._tiles(d, C_, cdt == torch.bfloat16) * F2
-        ops.gemm(dxs, S.out2, pe.out.weight.grad, d, C_, M, d, F2 * C_, C_ * F2, transA=True, transB=True, atomic=True,
-                 splitk=self._splitk(tiles, M, strided_c=True), batch=F2, nb0=F2, sB=(C_, 0), sC=(1, 0), c_col_stride=F2,
-                 c_dtype=ops.F32)
+        with self._sub_wgrad_scope(dxs, S.out2):
+            ops.gemm(dxs, S.out2, pe.out.weight.grad, d, C_, M, d, F2 * C_, C_ * F2, transA=True, transB=True, atomic=True,
+                     splitk=self._splitk(tiles, M, strided_c=True), batch=F2, nb0=F2, sB=(C_, 0), sC=(1, 0), c_col_stride=F2,
+                     c_dtype=ops.F32)
         dout2 = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
         ops.gemm(dxs, W["pre.outt"], dout2, M, F2 * C_, d, d, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=S.out2)
         M2 = B * T2 * F2
@@ -678,10 +685,12 @@ class ConformerEncoder(NeuralModule):
         # d conv2.weight [co, ci, 3, 3]: batch over the 9 taps, column stride 9
         tiles = self._tiles(C_, C_, cdt == torch.bfloat16) * 9
         if implicit:
-            ops.gemm(dout2, S.out1, pe.conv[2].weight.grad, C_, C_, M2, C_, C_, 9 * C_, transA=True, transB=True, atomic=True,
-                     splitk=self._splitk(tiles, M2), batch=9, nb0=9, sC=(1, 0), c_col_stride=9, c_dtype=ops.F32,
-                     gather=dict(operand=1, nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2,
-                                 taps=[(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]))
+            with self._sub_wgrad_scope(dout2, S.out1):
+                ops.gemm(dout2, S.out1, pe.conv[2].weight.grad, C_, C_, M2, C_, C_, 9 * C_, transA=True, transB=True,
+                         atomic=True, splitk=self._splitk(tiles, M2), batch=9, nb0=9, sC=(1, 0), c_col_stride=9,
+                         c_dtype=ops.F32,
+                         gather=dict(operand=1, nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2,
+                                     taps=[(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]))
         else:
             col = S.col
             if S.col_gen != self._col_gen:  # another forward has reused the workspace since: rebuild the image
