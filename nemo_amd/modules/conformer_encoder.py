@@ -670,7 +670,8 @@ class ConformerEncoder(NeuralModule):
         pe = self.pre_encode
         dxs = torch.empty(M, d, dtype=cdt, device=dev)
         ops.drop_scale_cast(dx, dxs, M * d, (self.xscale or 1.0), S.drop_pre)
-        ops.colsum(dxs, pe.out.bias.grad, M, d)
+        with self._sub_wgrad_scope(dxs):
+            ops.colsum(dxs, pe.out.bias.grad, M, d)
         # d out.weight in the reference's (c, f) column order: batch over f, C column stride F2
         tiles = self._tiles(d, C_, cdt == torch.bfloat16) * F2
         with self._sub_wgrad_scope(dxs, S.out2):
@@ -680,7 +681,8 @@ class ConformerEncoder(NeuralModule):
         dout2 = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
         ops.gemm(dxs, W["pre.outt"], dout2, M, F2 * C_, d, d, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=S.out2)
         M2 = B * T2 * F2
-        ops.colsum(dout2, pe.conv[2].bias.grad, M2, C_)
+        with self._sub_wgrad_scope(dout2):
+            ops.colsum(dout2, pe.conv[2].bias.grad, M2, C_)  # 328 MB stream: next to the GEMMs, not in line with them
         implicit = self.conv2_implicit and self._conv2_implicit(cdt, C_, M2) and S.col is None
         # d conv2.weight [co, ci, 3, 3]: batch over the 9 taps, column stride 9
         tiles = self._tiles(C_, C_, cdt == torch.bfloat16) * 9

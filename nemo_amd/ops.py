@@ -74,7 +74,15 @@ def wgrad_grouped(problems, rows, splitk):
         d.alpha = 1.0
         d.epilogue, d.atomic, d.splitk = EPI_STORE, 1, splitk
         d.colsum_out = _ptr(bias_grad) if bias_grad is not None else 0
+    if GEMM_PROFILE is None:
+        check(lib.mi355x_gemm_grouped(arr, n, _stream()), "gemm_grouped")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib.mi355x_gemm_grouped(arr, n, _stream()), "gemm_grouped")
+    e1.record()
+    # recorded as one launch of the TN variant: sum of the problems' M*N, shared K
+    GEMM_PROFILE.append(("bf16_TN", sum(q[7] * q[8] for q in problems), 1, rows, 1, e0, e1))
 
 
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=False, transB=False, in_dtype=None, c_dtype=None, batch=1, nb0=0,
