@@ -227,3 +227,52 @@ def test_specaug_module_draws_the_reference_masks(golden_dir):
     with pytest.raises(ValueError):
         SpectrogramAugmentation(time_masks=1, time_width=1.5)
 
+
+# ---------------------------------------------------------------------------------------------- flat buffers / launch planning
+def test_flat_params_tail_region_and_ranges():
+    """FlatParams(tail=...): selected parameters are laid out contiguously AFTER all others (equal strides across layers ->
+    one batched GEMM writes all their gradients), `range_of` skips them, `tail_range` covers exactly them."""
+    from nemo_amd.flat import FlatParams
+
+    class Layer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(8, 16)
+            self.special = torch.nn.Linear(16, 16, bias=False)
+            self.b = torch.nn.Linear(16, 8)
+
+    net = torch.nn.ModuleDict({"layers": torch.nn.ModuleList([Layer() for _ in range(3)]), "head": torch.nn.Linear(8, 4)})
+    ref = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    fp = FlatParams(net, tail=lambda n: n.endswith("special.weight"))
+    fp.build("cpu")
+    assert fp.is_valid()
+    for k, v in net.state_dict().items():            # values and names untouched (state-dict ABI)
+        assert torch.equal(v, ref[k])
+    offs = [fp.offsets[f"layers.{i}.special.weight"][0] for i in range(3)]
+    assert offs[1] - offs[0] == offs[2] - offs[1] == 256            # equally spaced, 64-element aligned
+    lo, hi = fp.tail_range()
+    assert lo == offs[0] and hi == offs[2] + 256 and hi == fp.flat.numel()
+    others_end = max(o + n for k, (o, n) in fp.offsets.items() if not k.endswith("special.weight"))
+    assert others_end <= lo
+    for i in range(3):                                # a layer's range is contiguous and excludes the tail parameters
+        s0, s1 = fp.range_of(f"layers.{i}.")
+        assert s1 <= lo and s1 - s0 == sum(-(-n // 64) * 64 for k, (o, n) in fp.offsets.items()
+                                            if k.startswith(f"layers.{i}.") and not k.endswith("special.weight"))
+    # gradients are views of ONE buffer too
+    net["layers"][1].special.weight.grad.fill_(2.0)
+    assert torch.all(fp.grad[offs[1]: offs[1] + 256] == 2.0)
+
+
+def test_splitk_chooser_fills_rounds_of_the_cus():
+    from nemo_amd.modules.conformer_encoder import ConformerEncoder
+    f = ConformerEncoder._splitk
+    for tiles, K in [(184, 16032), (32, 16032), (72, 320640), (8, 16032), (16, 16032), (300, 16032), (1, 64 * 40)]:
+        c = f(tiles, K)
+        nk = (K + 63) // 64
+        assert 1 <= c <= 16 and (c == 1 or nk // c >= 16)
+        blocks = tiles * c
+        eff = blocks / (-(-blocks // 256) * 256)
+        assert eff >= 0.70 or c == 1 or nk // (c + 1) < 16, (tiles, K, c, eff)
+    assert f(184, 16032) == 4 and f(32, 16032) == 8 and f(72, 320640) == 7
+    assert f(160, 16032, strided_c=True) == 1      # column-strided outputs: a single round, no extra atomic passes
+
