@@ -42,6 +42,17 @@ def parse():
     return ap.parse_args()
 
 
+def synthetic_batch(B, secs, vocab=128, seed=1234):
+    """SURVEY.md section 8(d) synthetic inputs: audio 0.1*randn (the reference's OOMptimizer batch construction), tokens
+    randint(0, vocab), U = 3*secs, full lengths.  (Restated here: the measured leg does not touch oracle/.)"""
+    g = torch.Generator().manual_seed(seed)
+    S = int(round(16000 * secs))
+    audio = 0.1 * torch.randn(B, S, generator=g)
+    U = max(1, int(3 * secs))
+    tokens = torch.randint(0, vocab, (B, U), generator=g)
+    return audio, torch.full((B,), S, dtype=torch.int64), tokens, torch.full((B,), U, dtype=torch.int64)
+
+
 def cpu_baseline(size, secs, vocab, batch, steps):
     """the CPU oracle (oracle/conformer_ref.py, plain PyTorch fp32) forward+backward+AdamW on the host cores, train mode"""
     from oracle import conformer_ref as R
@@ -83,7 +94,6 @@ def main():
 
     from nemo_amd import ops
     from nemo_amd.models import EncDecCTCModel, conformer_ctc_config
-    from oracle import conformer_ref as R  # synthetic-batch generator only, not on the measured path
 
     vocab = 128
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -93,7 +103,7 @@ def main():
     model.decoder.compute_dtype = cdt
     model = model.to(dev).train()
     model.setup_optimization()
-    audio, alen, tok, tl = R.synthetic_batch(a.batch, a.secs, vocab=vocab, seed=1234 + rank)
+    audio, alen, tok, tl = synthetic_batch(a.batch, a.secs, vocab=vocab, seed=1234 + rank)
     batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
 
     def barrier():
