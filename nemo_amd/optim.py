@@ -89,6 +89,51 @@ class FusedAdamW:
             fp.ensure()
             fp.zero_grad()
 
+    # ---- optimizer step in pieces, while backward is still running.  `begin_step` fixes this step's constants;
+    # `step_range(fp, lo, hi)` updates one contiguous slice of a flat buffer as soon as its gradients are final (the
+    # backward sequencer / the gradient exchange call it on THEIR stream: the weight-gradient stream on one GPU, the RCCL
+    # stream after a bucket's all-reduce in data-parallel runs); `finish_step` updates whatever is left.  AdamW is
+    # HBM-bound and the rest of backward is MFMA-bound, so the update disappears behind it.  Not used with gradient
+    # clipping (the global norm needs every gradient first).
+    def begin_step(self, lr: float = None, grad_scale: float = 1.0):
+        self.step_count += 1
+        self._cur = (self.lr if lr is None else lr, grad_scale)
+        self._done = {id(fp): [] for fp in self.flats}
+        for fp in self.flats:  # state is created here, on the caller's stream, not on whichever stream steps first
+            fp.ensure()
+            self._moments(fp)
+            self._ema_of(fp)
+        return self.max_grad_norm is None
+
+    def step_range(self, fp: FlatParams, lo: int, hi: int):
+        if getattr(self, "_cur", None) is None or self.max_grad_norm is not None or hi <= lo:
+            return
+        lr, grad_scale = self._cur
+        m, v = self._moments(fp)
+        ema = self._ema_of(fp)
+        ops.adamw_step(fp.flat[lo:hi], fp.grad[lo:hi], m[lo:hi], v[lo:hi], lr, self.betas[0], self.betas[1], self.eps,
+                       self.weight_decay, self.step_count, grad_scale, ema=None if ema is None else ema[lo:hi],
+                       ema_decay=self.ema_decay or 0.0)
+        self._done[id(fp)].append((lo, hi))
+
+    def finish_step(self):
+        lr, grad_scale = self._cur
+        for fp in self.flats:
+            done = sorted(self._done[id(fp)])
+            pos, rest = 0, []
+            for lo, hi in done:
+                if lo > pos:
+                    rest.append((pos, lo))
+                pos = max(pos, hi)
+            if pos < fp.flat.numel():
+                rest.append((pos, fp.flat.numel()))
+            for lo, hi in rest:
+                self.step_range(fp, lo, hi)
+        self._cur = None
+        for fp in self.flats:
+            if hasattr(fp.module, "weights_updated"):
+                fp.module.weights_updated()
+
     def step(self, lr: float = None, grad_scale: float = 1.0):
         self.step_count += 1
         lr = self.lr if lr is None else lr

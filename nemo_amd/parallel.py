@@ -35,6 +35,9 @@ class GradSync:
         # streams other than the current one that also write gradients (the encoder's weight-gradient stream): the
         # exchange stream waits for them too, the backward chain itself never does
         self.producer_streams = lambda: []
+        # called as after_reduce(start, end) on the exchange stream right after a range's all-reduce has been enqueued
+        # (stream-ordered behind it): the optimizer updates that slice while backward continues
+        self.after_reduce = None
 
     # ---- called by the backward sequencer (ranges arrive in reverse-layer order, adjacent ranges are merged)
     def ready(self, start: int, end: int) -> None:
@@ -61,9 +64,19 @@ class GradSync:
                 for ps in self.producer_streams():
                     self._stream.wait_stream(ps)
                 with torch.cuda.stream(self._stream):
-                    self._works.append(dist.all_reduce(view, group=self.group, async_op=True))
+                    work = dist.all_reduce(view, group=self.group, async_op=True)
+                    if self.after_reduce is not None:
+                        work.wait()  # stream-level: the exchange stream waits for the collective, the host does not
+                        self.after_reduce(s, e)
+                    else:
+                        self._works.append(work)
             else:
-                self._works.append(dist.all_reduce(view, group=self.group, async_op=True))
+                work = dist.all_reduce(view, group=self.group, async_op=True)
+                if self.after_reduce is not None:
+                    work.wait()
+                    self.after_reduce(s, e)
+                else:
+                    self._works.append(work)
             self._reduced.append((s, e))
         self._pending, self._pending_elems = [], 0
 

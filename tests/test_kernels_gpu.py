@@ -816,6 +816,49 @@ def test_adamw_matches_torch():
     assert rel_err(p, pr) < 1e-5
 
 
+def test_adamw_in_pieces_is_bit_identical_to_one_step():
+    """begin_step / step_range / finish_step (the optimizer running behind backward, slice by slice, in any order)
+    against step() on the same gradients: same kernel per element, so the weights, moments and EMA are bit-identical"""
+    from nemo_amd.flat import FlatParams
+    from nemo_amd.optim import FusedAdamW
+    torch.manual_seed(5)
+    def make():
+        torch.manual_seed(5)
+        ms = [torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.Linear(96, 160), torch.nn.Linear(160, 32)).to(dev),
+              torch.nn.Linear(32, 8).to(dev)]
+        fl = [FlatParams(m) for m in ms]
+        for fp in fl:
+            fp.build(dev)
+        return ms, fl, FusedAdamW(fl, lr=3e-3, betas=(0.9, 0.98), weight_decay=1e-2, ema_decay=0.99)
+    ma, fa, oa = make()
+    mb, fb, ob = make()
+    g = torch.Generator(device=dev).manual_seed(3)
+    side = torch.cuda.Stream()
+    for step in range(4):
+        oa.zero_grad(); ob.zero_grad()
+        for x, y in zip(fa, fb):
+            gr = torch.randn(x.grad.shape, device=dev, generator=g)
+            x.grad.copy_(gr); y.grad.copy_(gr)
+        oa.step(lr=1e-3 * (step + 1), grad_scale=0.5)
+        assert ob.begin_step(lr=1e-3 * (step + 1), grad_scale=0.5)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # reverse order, a gap left for finish_step, second buffer untouched until then
+            hi = fb[0].range_of("2.")
+            ob.step_range(fb[0], *hi)
+            ob.step_range(fb[0], *fb[0].range_of("0."))
+        torch.cuda.current_stream().wait_stream(side)
+        ob.finish_step()
+    torch.cuda.synchronize()
+    assert oa.step_count == ob.step_count == 4
+    for x, y in zip(fa, fb):
+        assert torch.equal(x.flat, y.flat)
+        assert torch.equal(oa._moments(x)[0], ob._moments(y)[0]) and torch.equal(oa._moments(x)[1], ob._moments(y)[1])
+        assert torch.equal(oa._ema_of(x), ob._ema_of(y))
+    # with clipping the global norm needs every gradient first: the piecewise mode declines
+    oc = FusedAdamW(fb, lr=1e-3, max_grad_norm=1.0)
+    assert not oc.begin_step()
+
+
 def test_adamw_clip_and_ema_match_torch():
     """gradient_clip_val + EMA inside the fused launch: against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW +
     the reference's ema_update (_foreach_mul_/_foreach_add_, ema.py:150-157) over several steps and two flat buffers"""

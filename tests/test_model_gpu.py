@@ -211,3 +211,26 @@ def test_fit_steps_reduce_loss_and_nemo_roundtrip(tmp_path):
     torch.cuda.synchronize()
     assert torch.allclose(lp1, lp2, atol=1e-5)
     assert set(m2.state_dict().keys()) == set(model.state_dict().keys())
+
+
+def test_optimizer_behind_backward_follows_the_plain_step():
+    """fit_step with the optimizer running slice by slice behind backward (weight-gradient stream) against the plain
+    zero_grad -> backward -> step order: the update rule per element is the same kernel, the only difference allowed is
+    the float-atomic order inside the split-K weight gradients, so the loss curves agree to 1e-3"""
+    over = dict(d_model=64, n_heads=4, n_layers=3, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0)
+    audio, alen, tok, tl = R.synthetic_batch(4, 1.0, vocab=20, seed=8)
+    batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+    curves = []
+    for early in (True, False):
+        torch.manual_seed(21)
+        model = _model(over, vocab=20).to(dev).train()
+        model.optimizer_in_backward = early
+        model.setup_optimization(dict(name="adamw", lr=1e-3, betas=[0.9, 0.98], weight_decay=1e-3,
+                                      ema=dict(enable=True, decay=0.9)))
+        curves.append([model.fit_step(batch)["loss"].item() for _ in range(8)])
+        assert model._optimizer.step_count == 8
+        assert (model.encoder.grad_ready_hook is not None) == early
+    a, b = curves
+    assert a[-1] < 0.9 * a[0]
+    for x, y in zip(a, b):
+        assert abs(x - y) <= 1e-3 * abs(y), (a, b)

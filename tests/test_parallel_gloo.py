@@ -53,6 +53,74 @@ def test_bucketed_grad_sync_world2_gloo():
     assert dict(ret) == {0: True, 1: True}
 
 
+def _torch_adamw(p, g, m, v, lr, b1, b2, eps, wd, step, grad_scale=1.0, clip_coef=None, ema=None, ema_decay=0.0):
+    """host stand-in for the HIP launch (same update rule, adamw_kernel in csrc/optim.hip) so the slice bookkeeping of
+    the optimizer-behind-backward path can run on CPU"""
+    gr = g * grad_scale
+    p.mul_(1 - lr * wd)
+    m.mul_(b1).add_(gr, alpha=1 - b1)
+    v.mul_(b2).addcmul_(gr, gr, value=1 - b2)
+    p.sub_((lr / (1 - b1 ** step)) * m / (v.sqrt() / (1 - b2 ** step) ** 0.5 + eps))
+    if ema is not None:
+        ema.mul_(ema_decay).add_(p, alpha=1 - ema_decay)
+
+
+def _worker_opt(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nemo_amd import ops
+        from nemo_amd.flat import FlatParams
+        from nemo_amd.optim import FusedAdamW
+        from nemo_amd.parallel import GradSync
+        ops.adamw_step = _torch_adamw
+        torch.manual_seed(0)
+        layers = 6
+        mod = torch.nn.Sequential(*[torch.nn.Linear(32, 32) for _ in range(layers)])
+        ref = torch.nn.Sequential(*[torch.nn.Linear(32, 32) for _ in range(layers)])
+        ref.load_state_dict(mod.state_dict())
+        fp = FlatParams(mod); fp.build(torch.device("cpu"))
+        opt = FusedAdamW([fp], lr=1e-2, betas=(0.9, 0.98), weight_decay=1e-2)
+        ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, betas=(0.9, 0.98), weight_decay=1e-2)
+        gs = GradSync(fp.grad, bucket_bytes=4 * 2200)  # ~2 layers per bucket
+        calls = []
+        gs.after_reduce = lambda lo, hi: (calls.append((lo, hi)), opt.step_range(fp, lo, hi))
+        for step in range(3):
+            fp.grad.zero_(); ropt.zero_grad()  # (FusedAdamW.zero_grad is a HIP fill)
+            assert opt.begin_step(lr=1e-2, grad_scale=1.0 / world)
+            gens = [torch.Generator().manual_seed(100 * step + r) for r in range(world)]
+            per_rank = [[torch.randn(p.shape, generator=g) for p in ref.parameters()] for g in gens]
+            for q, *gr in zip(ref.parameters(), *per_rank):
+                q.grad = sum(gr) / world
+            mine = dict(zip([n for n, _ in mod.named_parameters()], per_rank[rank]))
+            for i in range(layers - 1, -1, -1):  # reverse-layer order, like the backward sequencer
+                for n, p in mod.named_parameters():
+                    if n.startswith(f"{i}."):
+                        p.grad.copy_(mine[n])
+                gs.ready(*fp.range_of(f"{i}."))
+            n_before_wait = len(calls)
+            gs.wait()
+            opt.finish_step()
+            ropt.step()
+            assert n_before_wait >= 2  # slices were updated while "backward" was still producing gradients
+        err = max((p.detach() - q.detach()).abs().max().item() for p, q in zip(mod.parameters(), ref.parameters()))
+        flat = fp.flat.clone()
+        dist.all_reduce(flat)
+        same = torch.allclose(flat, fp.flat * world, rtol=0, atol=1e-6)  # the replicas stay in lock-step
+        ret[rank] = bool(err < 1e-5 and same and opt.step_count == 3)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_optimizer_behind_the_exchange_world2_gloo():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_opt, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
 def test_grad_sync_is_a_noop_for_world1():
     from nemo_amd.parallel import GradSync
     g = torch.ones(128)
