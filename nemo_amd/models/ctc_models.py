@@ -171,6 +171,99 @@ class EncDecCTCModel(nn.Module):
             enc.grad_ready_hook = hook
             enc._wgrad_join_per_layer = False  # the hook orders itself behind both streams
 
+    # ------------------------------------------------------------------ data (ctc_models.py:303-380, 382-470)
+    def _dataset_from_config(self, config: Dict[str, Any]):
+        """audio_to_text_dataset.get_char_dataset / get_bpe_dataset (audio_to_text_dataset.py:132-163, 215-243): a
+        `tokenizer` entry (an object with `text_to_ids`, or {'model_path': <sentencepiece .model>}) selects the BPE dataset
+        (EncDecCTCModelBPE), `labels` the character dataset"""
+        from ..data import AudioToBPEDataset, AudioToCharDataset, SentencePieceTokenizer
+        config.setdefault("sample_rate", self._cfg.get("sample_rate", 16000))  # inject_dataloader_value_from_model_config
+        if config.get("labels") is None and self._cfg.get("labels") is not None:
+            config["labels"] = self._cfg["labels"]
+        tok = config.get("tokenizer", getattr(self, "tokenizer", None))
+        if tok is not None:
+            if isinstance(tok, dict):
+                tok = SentencePieceTokenizer(tok["model_path"])
+            self.tokenizer = tok
+            return AudioToBPEDataset(
+                manifest_filepath=config["manifest_filepath"], tokenizer=tok, sample_rate=config["sample_rate"],
+                int_values=config.get("int_values", False), max_duration=config.get("max_duration"),
+                min_duration=config.get("min_duration"), max_utts=config.get("max_utts", 0),
+                trim=config.get("trim_silence", False), use_start_end_token=config.get("use_start_end_token", True),
+                return_sample_id=config.get("return_sample_id", False), channel_selector=config.get("channel_selector"))
+        return AudioToCharDataset(
+            manifest_filepath=config["manifest_filepath"], labels=config.get("labels"), sample_rate=config["sample_rate"],
+            int_values=config.get("int_values", False), max_duration=config.get("max_duration"),
+            min_duration=config.get("min_duration"), max_utts=config.get("max_utts", 0),
+            blank_index=config.get("blank_index", -1), unk_index=config.get("unk_index", -1),
+            normalize=config.get("normalize_transcripts", False), trim=config.get("trim_silence", False),
+            parser=config.get("parser", "base"), return_sample_id=config.get("return_sample_id", False),
+            channel_selector=config.get("channel_selector"))
+
+    def _setup_dataloader_from_config(self, config: Dict[str, Any]):
+        from ..data import SemiSortBatchSampler
+        config = dict(config)
+        if config.get("manifest_filepath") is None:
+            return None
+        dataset = self._dataset_from_config(config)
+        rank = torch.distributed.get_rank() if self.world_size > 1 else 0
+        shuffle, sampler, batch_size = config["shuffle"], None, config["batch_size"]
+        drop_last = config.get("drop_last", False)
+        if config.get("use_semi_sorted_batching", False):
+            # batches are shaped by duration and dealt to the ranks by the sampler; automatic batching is off
+            # (ctc_models.py:355-366, asr_batching.py:204-240)
+            sampler = SemiSortBatchSampler(global_rank=rank, world_size=self.world_size, durations=dataset.durations,
+                                           batch_size=batch_size, batch_shuffle=config.get("shuffle", True),
+                                           drop_last=drop_last, randomization_factor=config.get("randomization_factor"),
+                                           seed=config.get("semi_sort_sampler_seed", 42),
+                                           synced_rng=config.get("semi_sort_synced_rng", False))
+            batch_size, drop_last, shuffle = None, False, False
+        elif self.world_size > 1:  # what Lightning injects under trainer.strategy=ddp
+            sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=self.world_size, rank=rank,
+                                                                      shuffle=shuffle, drop_last=drop_last)
+            shuffle = False
+        return torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, sampler=sampler, batch_sampler=None,
+                                           collate_fn=dataset._collate_fn, drop_last=drop_last, shuffle=shuffle,
+                                           num_workers=config.get("num_workers", 0), pin_memory=False)
+
+    def setup_training_data(self, train_data_config: Dict[str, Any]):
+        train_data_config = dict(train_data_config)
+        train_data_config.setdefault("shuffle", True)
+        self._cfg["train_ds"] = {k: v for k, v in train_data_config.items() if k != "tokenizer" or isinstance(v, dict)}
+        self._train_dl = self._setup_dataloader_from_config(train_data_config)
+        return self._train_dl
+
+    def setup_validation_data(self, val_data_config: Dict[str, Any]):
+        val_data_config = dict(val_data_config)
+        val_data_config.setdefault("shuffle", False)
+        self._cfg["validation_ds"] = {k: v for k, v in val_data_config.items() if k != "tokenizer" or isinstance(v, dict)}
+        self._validation_dl = self._setup_dataloader_from_config(val_data_config)
+        return self._validation_dl
+
+    def train_dataloader(self):
+        return getattr(self, "_train_dl", None)
+
+    def fit(self, max_steps: int, max_epochs: int = 1 << 30, log_every: int = 0):
+        """the trainer loop for this path: batches staged through pinned memory and copied on their own HIP stream while
+        the previous step computes (`data.DeviceBatchLoader`), then `fit_step`.  Returns the per-step losses (device
+        scalars: nothing here synchronises the host with the GPU unless `log_every` asks for a printout)."""
+        from ..data import DeviceBatchLoader
+        dl = self.train_dataloader()
+        if dl is None:
+            raise RuntimeError("call setup_training_data() first")
+        device = next(self.parameters()).device
+        losses = []
+        for epoch in range(max_epochs):
+            if hasattr(dl.sampler, "set_epoch"):
+                dl.sampler.set_epoch(epoch)
+            for batch in DeviceBatchLoader(dl, device):
+                losses.append(self.fit_step(list(batch[:4]))["loss"].detach())
+                if log_every and len(losses) % log_every == 0:
+                    print(f"step {len(losses)} loss {losses[-1].item():.4f}", flush=True)
+                if len(losses) >= max_steps:
+                    return losses
+        return losses
+
     # ------------------------------------------------------------------ .nemo (modelPT.py:395,436)
     def save_to(self, save_path: str):
         save_nemo(save_path, dict(self._cfg, target=f"{type(self).__module__}.{type(self).__name__}"), self.state_dict())

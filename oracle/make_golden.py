@@ -152,8 +152,109 @@ def make_specaug_fixture():
     print("specaug fixture: masked cells", {k: int((fix[k] != fix["x"]).sum()) for k in fix if k not in ("x", "length")})
 
 
+def _reference_function(rel_path, name, namespace):
+    """compile ONE top-level function of a reference source file (read in place, executed, never copied) in `namespace`:
+    for modules whose import needs packages this image does not have (webdataset, lhotse, soundfile ...)"""
+    src = open(os.path.join(REF, rel_path)).read()
+    tree = ast.parse(src)
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    mod = ast.Module(body=[node], type_ignores=[])
+    exec(compile(mod, os.path.join(REF, rel_path), "exec"), namespace)
+    return namespace[name]
+
+
+def make_data_fixture():
+    """the reference's input-pipeline pieces run here on seeded inputs -> tests/golden/ref_data_pipeline.json:
+      * SemiSortBatchSampler (asr_batching.py, imported through the shim with its two heavy imports stubbed): the batches
+        of every rank for several world sizes / drop_last / shuffle settings, numpy's global generator seeded per call;
+      * _speech_collate_fn (audio_to_text.py:52-110, the function alone): ragged 4- and 5-field batches;
+      * CharParser (parsers.py) on transcripts with OOV symbols, special labels and blanks;
+      * manifest.item_iter on a manifest with every text / path spelling the parser accepts."""
+    import importlib
+    import sys
+    import tempfile
+    import types
+    import json as js
+    from oracle import ref_shim
+    ref_shim.install()
+    fake = types.ModuleType("nemo.collections.asr.data.audio_to_text")
+    fake.AudioToBPEDataset = fake.AudioToCharDataset = type("D", (), {})
+    sys.modules.setdefault("nemo.collections.asr.data", types.ModuleType("nemo.collections.asr.data"))
+    sys.modules["nemo.collections.asr.data.audio_to_text"] = fake
+    fm = types.ModuleType("nemo.collections.asr.models.asr_model")
+    fm.ASRModel = type("ASRModel", (), {})
+    sys.modules["nemo.collections.asr.models.asr_model"] = fm
+    ab = importlib.import_module("nemo.collections.asr.parts.utils.asr_batching")
+    out = {"sampler": [], "collate": [], "parser": [], "manifest": []}
+    rs = np.random.RandomState(5)
+    durations = np.round(rs.uniform(1.0, 30.0, size=157), 2).tolist()
+    for world, bs, drop_last, shuffle, rf, seed in [(1, 8, False, True, None, 42), (2, 8, False, True, 0.2, 42),
+                                                    (4, 6, True, True, 0.1, 7), (8, 4, False, False, 0.0, 3),
+                                                    (4, 64, False, True, 0.1, 1)]:
+        case = dict(world=world, batch_size=bs, drop_last=drop_last, shuffle=shuffle, randomization_factor=rf, seed=seed,
+                    np_seed=1000 + world, epochs=[])
+        for epoch in (0, 1):
+            ranks = []
+            for rank in range(world):
+                sm = ab.SemiSortBatchSampler(rank, world, durations, bs, shuffle, drop_last, rf, seed)
+                sm.set_epoch(epoch)
+                np.random.seed(case["np_seed"] + epoch)  # what seed_everything gives every rank
+                ranks.append([[int(i) for i in b] for b in sm])
+            case["epochs"].append(ranks)
+        out["sampler"].append(case)
+    out["durations"] = durations
+
+    collate = _reference_function("nemo/collections/asr/data/audio_to_text.py", "_speech_collate_fn", {"torch": torch})
+    g = torch.Generator().manual_seed(3)
+    for with_ids, pad_id in ((False, 0), (True, 7)):
+        lens, tls = [160, 91, 160, 37], [5, 1, 9, 0]
+        batch = []
+        for i, (n, tl) in enumerate(zip(lens, tls)):
+            item = (torch.randn(n, generator=g), torch.tensor(n).long(), torch.randint(1, 30, (tl,), generator=g).long(),
+                    torch.tensor(tl).long())
+            batch.append(item + (100 + i,) if with_ids else item)
+        res = collate(batch, pad_id)
+        out["collate"].append(dict(pad_id=pad_id, with_ids=with_ids, signals=[b[0].tolist() for b in batch],
+                                   tokens=[b[2].tolist() for b in batch],
+                                   out=[r.tolist() for r in res], out_dtypes=[str(r.dtype) for r in res]))
+
+    sys.modules.setdefault("text_unidecode", types.SimpleNamespace(unidecode=lambda x: x))
+    sys.modules.setdefault("inflect", types.SimpleNamespace(engine=lambda: None))
+    parsers = importlib.import_module("nemo.collections.common.parts.preprocessing.parsers")
+    labels = [" ", "a", "b", "c", "d", "e", "<unk>", "'", "zh"]
+    for kw in (dict(), dict(unk_id=6), dict(unk_id=9, blank_id=9), dict(do_lowercase=False), dict(do_normalize=False)):
+        p = parsers.CharParser(labels, **kw)
+        texts = ["  A bad CAB ", "abc xyz de", "zh ab zh", "<unk> a'b", "", "a  b"]
+        out["parser"].append(dict(labels=labels, kwargs=kw, texts=texts, ids=[p(t) for t in texts]))
+
+    manifest = importlib.import_module("nemo.collections.common.parts.preprocessing.manifest")
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "wavs"))
+        open(os.path.join(d, "wavs", "a.wav"), "wb").close()
+        open(os.path.join(d, "t.txt"), "w").write("from a\nfile\n")
+        lines = [dict(audio_filepath="wavs/a.wav", duration=1.5, text="hello"),
+                 dict(audio_filename="wavs/missing.wav", duration=2.0, normalized_text="norm", offset=0.25),
+                 dict(audio_filepath="/abs/x.wav", duration=3.0, text_filepath=os.path.join(d, "t.txt"), speaker=4,
+                      orig_sample_rate=8000, lang="en"),
+                 dict(audio_filepath="wavs/a.wav", duration=0.5, token_labels=[3, 4, 5])]
+        mpath = os.path.join(d, "m.json")
+        with open(mpath, "w") as f:
+            for ln in lines:
+                f.write(js.dumps(ln) + "\n")
+            f.write("\n")
+        keys = ("audio_file", "duration", "text", "offset", "speaker", "orig_sr", "token_labels", "lang", "id")
+        items = [{k: it[k] for k in keys} for it in manifest.item_iter(mpath)]
+        for it in items:
+            it["audio_file"] = it["audio_file"].replace(d, "<DIR>")
+        out["manifest"] = dict(lines=[js.dumps(ln).replace(d, "<DIR>") for ln in lines], items=items)
+    with open(os.path.join(GOLD, "ref_data_pipeline.json"), "w") as f:
+        js.dump(out, f)
+    print("data fixture:", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     extract_ctc_known_answers()
     make_reference_fixtures()
     make_specaug_fixture()
+    make_data_fixture()

@@ -234,3 +234,54 @@ def test_optimizer_behind_backward_follows_the_plain_step():
     assert a[-1] < 0.9 * a[0]
     for x, y in zip(a, b):
         assert abs(x - y) <= 1e-3 * abs(y), (a, b)
+
+
+def _wav_corpus(tmp_path, n, vocab, seed=0, sr=16000):
+    import json, wave
+    rs = np.random.RandomState(seed)
+    lines = []
+    for i in range(n):
+        ns = int(rs.randint(int(0.6 * sr), int(1.4 * sr)))
+        x = (rs.randn(ns) * 2000).astype(np.int16)
+        with wave.open(str(tmp_path / f"u{i}.wav"), "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr); f.writeframes(x.tobytes())
+        text = "".join(rs.choice(vocab[1:], size=rs.randint(3, 9)))
+        lines.append(dict(audio_filepath=f"u{i}.wav", duration=ns / sr, text=text))
+    m = str(tmp_path / "train.json")
+    with open(m, "w") as f:
+        for ln in lines:
+            f.write(json.dumps(ln) + "\n")
+    return m
+
+
+def test_device_batch_loader_overlapped_copies_deliver_the_host_batches():
+    from nemo_amd.data import DeviceBatchLoader
+    g = torch.Generator().manual_seed(0)
+    host = [(torch.randn(3, 4000 + 977 * (i % 5), generator=g), torch.tensor([4000, 17, 300 + i]),
+             torch.randint(0, 9, (3, 2 + i % 3), generator=g), torch.tensor([2, 1, 2])) for i in range(11)]
+    burn = torch.randn(2048, 2048, device=dev)
+    n = 0
+    for want, got in zip(host, DeviceBatchLoader(host, dev, prefetch=2)):
+        burn = burn @ burn.clamp(-1e-3, 1e-3)  # compute-stream work for the copies to overlap with
+        assert all(t.is_cuda for t in got)
+        for a, b in zip(want, got):
+            assert torch.equal(a, b.cpu())
+        n += 1
+    assert n == len(host)
+
+
+def test_fit_from_a_manifest_with_semi_sorted_batches(tmp_path):
+    """manifest -> AudioToCharDataset -> SemiSortBatchSampler -> collate -> pinned staging + copy stream -> fit_step"""
+    vocab = [" "] + list("abcdefghijklmnopqrs")
+    m = _wav_corpus(tmp_path, 24, vocab)
+    over = dict(d_model=64, n_heads=4, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0)
+    torch.manual_seed(3)
+    model = _model(over, vocab=len(vocab), labels=vocab).to(dev).train()
+    model.setup_optimization(dict(name="adamw", lr=2e-3, betas=[0.9, 0.98], weight_decay=1e-3))
+    dl = model.setup_training_data(dict(manifest_filepath=m, batch_size=4, use_semi_sorted_batching=True,
+                                        semi_sort_synced_rng=True, num_workers=0))
+    assert len(dl) == 6
+    losses = torch.stack(model.fit(max_steps=18)).tolist()  # three epochs
+    assert len(losses) == 18 and all(np.isfinite(losses))
+    assert np.mean(losses[-6:]) < 0.9 * np.mean(losses[:6]), losses
+    assert model._cfg["train_ds"]["manifest_filepath"] == m

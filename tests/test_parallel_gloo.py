@@ -121,6 +121,59 @@ def test_optimizer_behind_the_exchange_world2_gloo():
     assert dict(ret) == {0: True, 1: True}
 
 
+def _worker_data(rank, world, port, ret, manifest, vocab):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nemo_amd.models import EncDecCTCModel, conformer_ctc_config
+        cfg = conformer_ctc_config("small", vocab_size=len(vocab), d_model=32, n_heads=2, n_layers=1)
+        cfg["labels"] = vocab
+        model = EncDecCTCModel(cfg)
+        ok = model.world_size == world
+        out = {}
+        for name, extra in (("ssb", dict(use_semi_sorted_batching=True, semi_sort_synced_rng=True)), ("ddp", dict())):
+            dl = model.setup_training_data(dict(manifest_filepath=manifest, batch_size=4, return_sample_id=True,
+                                                shuffle=True, **extra))
+            ids, lens = [], []
+            for sig, sl, tok, tl, sid in dl:
+                ids.append(sid.tolist()); lens.append(int(sl.max()))
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (ids, lens))
+            out[name] = gathered
+        n = 26
+        ssb_ids = [i for r in out["ssb"] for b in r[0] for i in b]
+        ok = ok and set(ssb_ids) == set(range(n)) and len(ssb_ids) - n < world * 4
+        ok = ok and len(out["ssb"][0][0]) == len(out["ssb"][1][0])          # same number of steps
+        # step k of both ranks is padded to (nearly) the same length
+        ok = ok and all(abs(a - b) <= 0.15 * max(a, b) for a, b in zip(out["ssb"][0][1], out["ssb"][1][1]))
+        ddp_ids = [i for r in out["ddp"] for b in r[0] for i in b]
+        ok = ok and set(ddp_ids) == set(range(n)) and len(ddp_ids) == n  # DistributedSampler: 13 each
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_data_is_partitioned_across_ranks_world2_gloo(tmp_path):
+    import json
+    import wave
+    import numpy as np
+    vocab = [" "] + list("abcdefg")
+    rs = np.random.RandomState(1)
+    with open(tmp_path / "m.json", "w") as mf:
+        for i in range(26):
+            ns = int(rs.randint(1600, 16000))
+            with wave.open(str(tmp_path / f"u{i}.wav"), "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+                f.writeframes((rs.randn(ns) * 1000).astype(np.int16).tobytes())
+            mf.write(json.dumps(dict(audio_filepath=f"u{i}.wav", duration=ns / 16000, text="ab cd")) + "\n")
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_data, args=(world, _free_port(), ret, str(tmp_path / "m.json"), vocab), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
 def test_grad_sync_is_a_noop_for_world1():
     from nemo_amd.parallel import GradSync
     g = torch.ones(128)
