@@ -129,15 +129,18 @@ def main():
     final_loss = float(loss.item())
 
     roof = None
-    if rank == 0 and not a.no_roofline:
+    if not a.no_roofline:
         # per-launch durations need the kernels one after another: the weight-gradient side stream (which overlaps wgrad
-        # GEMMs with the HBM-bound kernels in the timed steps above) is switched off for this one instrumented step
+        # GEMMs with the HBM-bound kernels in the timed steps above) is switched off for this one instrumented step.
+        # EVERY rank runs the step (it contains the SyncBN and gradient collectives); only rank 0 records and reports.
         side = getattr(model.encoder, "wgrad_side_stream", False)
         model.encoder.wgrad_side_stream = False
-        ops.GEMM_PROFILE = []
+        if rank == 0:
+            ops.GEMM_PROFILE = []
         model.fit_step(batch)
-        torch.cuda.synchronize()
+        barrier()
         model.encoder.wgrad_side_stream = side
+    if rank == 0 and not a.no_roofline:
         agg = {}
         for (variant, M, N, K, nb, e0, e1) in ops.GEMM_PROFILE:
             g = agg.setdefault(variant, [0.0, 0.0, 0])
