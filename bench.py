@@ -86,11 +86,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # BENCH_DEVICE / BENCH_DIST_BACKEND exist to rehearse the N > 1 control flow on a one-GPU box (all ranks on device 0,
+    # gloo moving the CUDA tensors through the host); the driver's runs use neither: rank -> its own GPU, RCCL
+    local_rank = int(os.environ.get("BENCH_DEVICE", local_rank))
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     from nemo_amd import ops
     from nemo_amd.models import EncDecCTCModel, conformer_ctc_config

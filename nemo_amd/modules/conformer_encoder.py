@@ -422,6 +422,11 @@ class ConformerEncoder(NeuralModule):
     def _forward_impl(self, mel, length, save=False):
         dev = mel.device
         cdt = self._cdt()
+        if cdt == torch.bfloat16 and (self.d_k % 8 or self.d_model % 8):
+            # the bf16 operand path moves 16-byte pieces: a head must start on an 8-element boundary.  The recipe table's
+            # Small (d=176, 4 heads, d_k=44) therefore runs in fp32 here; Medium / Large (d_k=64) take the bf16 path.
+            raise NotImplementedError(f"bf16 compute needs d_model and d_model/n_heads divisible by 8 (got d_model="
+                                      f"{self.d_model}, d_k={self.d_k}); use compute_dtype=torch.float32 for this geometry")
         training = self.training
         W, Wf = self._plan(cdt, dev)
         B, F_, T = mel.shape

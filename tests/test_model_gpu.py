@@ -285,3 +285,70 @@ def test_fit_from_a_manifest_with_semi_sorted_batches(tmp_path):
     assert len(losses) == 18 and all(np.isfinite(losses))
     assert np.mean(losses[-6:]) < 0.9 * np.mean(losses[:6]), losses
     assert model._cfg["train_ds"]["manifest_filepath"] == m
+
+
+def _dp_worker(rank, world, port, out_dir, over, vocab):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks on the one GPU; gloo stages through the host
+    try:
+        torch.cuda.set_device(0)
+        torch.manual_seed(5)
+        model = _model(over, vocab=vocab).to(dev).train()
+        model.setup_optimization(dict(name="adamw", lr=1e-3, betas=[0.9, 0.98], weight_decay=0.0))
+        audio, alen, tok, tl = R.synthetic_batch(4, 1.0, vocab=vocab, seed=8)
+        sl = slice(2 * rank, 2 * rank + 2)
+        batch = [audio[sl].to(dev), alen[sl].to(dev), tok[sl].to(dev), tl[sl].to(dev)]
+        # what fit_step does up to the optimizer: zero_grad, forward, backward with the bucketed exchange, join
+        syncs = model._grad_syncs()
+        model._optimizer.zero_grad()
+        loss = model.training_step(batch)["loss"]
+        loss.backward()
+        scale = 1.0
+        for gs in syncs:
+            scale = gs.wait()
+        torch.cuda.synchronize()
+        grads = [fp.grad.detach().cpu() * scale for fp in model.flats()]
+        bn = model.encoder.layers[0].conv.batch_norm.running_mean.detach().cpu()
+        # then two complete steps (optimizer behind the exchange on the second) must leave the replicas identical
+        model.fit_step(batch)
+        model.optimizer_in_backward = True
+        model.fit_step(batch)
+        torch.cuda.synchronize()
+        torch.save(dict(grads=grads, loss=loss.detach().cpu(), bn=bn, flat=[fp.flat.detach().cpu() for fp in model.flats()]),
+                   os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_equal_one_process_on_the_joint_batch(tmp_path):
+    """the N > 1 path on real kernels (two processes share the GPU, gloo carries the collectives): bucketed gradient
+    all-reduce on the side stream + SyncBN statistics + mean over ranks must reproduce the gradient of ONE process run on
+    the concatenated batch (DDP + SyncBatchNorm semantics), and the replicas stay bit-identical
+    after optimizer steps"""
+    import socket
+    import torch.multiprocessing as mp
+    over = dict(d_model=64, n_heads=4, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0)
+    vocab = 20
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), over, vocab), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
+    torch.manual_seed(5)
+    model = _model(over, vocab=vocab).to(dev).train()
+    model.setup_optimization(dict(name="adamw", lr=1e-3, betas=[0.9, 0.98], weight_decay=0.0))
+    audio, alen, tok, tl = R.synthetic_batch(4, 1.0, vocab=vocab, seed=8)
+    batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+    model._optimizer.zero_grad()
+    loss = model.training_step(batch)["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(0.5 * (r0["loss"] + r1["loss"]).item() - loss.item()) <= 1e-5 * abs(loss.item())
+    for g0, g1, fp in zip(r0["grads"], r1["grads"], model.flats()):
+        assert torch.equal(g0, g1)                              # the all-reduce left both ranks with the same buffer
+        ref = fp.grad.detach().cpu()
+        assert (g0 - ref).norm() <= 2e-4 * ref.norm(), ((g0 - ref).norm() / ref.norm())
+    bn = model.encoder.layers[0].conv.batch_norm.running_mean.detach().cpu()
+    assert torch.allclose(r0["bn"], bn, atol=1e-5) and torch.equal(r0["bn"], r1["bn"])  # SyncBN: global statistics
+    for a, b in zip(r0["flat"], r1["flat"]):
+        assert torch.equal(a, b)
