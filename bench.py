@@ -171,17 +171,19 @@ def main():
         peak = 2500.0 if a.dtype == "bf16" else 157.3
         # HBM bytes per launch of that kernel family from the TCC counters: collected off-line (PMC passes serialise the
         # kernels, so they cannot run inside the timed benchmark) and committed with its method under profiles/
-        traffic = None
+        traffic = mfma_busy = None
         try:
             with open(os.path.join(ROOT, "profiles", "r1_gemm_traffic.json")) as f:
                 tj = json.load(f)
             if tj.get("kernel") == f"gemm_{dom[0]}" and a.size == "large" and a.batch == 32 and a.dtype == "bf16":
                 traffic = tj["traffic_bytes_per_launch"]
+                mfma_busy = tj.get("mfma_busy_frac")
         except (OSError, ValueError, KeyError):
             traffic = None
         roof = {"bound": "mfma", "kernel": f"gemm_{dom[0]}", "achieved": round(flops / secs_ / 1e12, 1), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(flops / secs_ / 1e12 / peak, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_hbm_traffic.md)",
+                "mfma_busy_frac_pmc": mfma_busy,  # SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE), profiles/r1_pmc_mfma_utilisation.md
                 "launches_per_step": cnt, "avg_launch_us": round(secs_ / cnt * 1e6, 1),
                 "gemm_time_share_of_step": round(sum(v[1] for v in agg.values()) * 1e3 / ms, 3),
                 "all_variants": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 2), "launches": v[2]}
