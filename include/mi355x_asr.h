@@ -247,6 +247,19 @@ int mi355x_ctc_greedy_decode(const void* logp, const void* lens, void* tokens, v
  * rects[n][5] = (b, f0, f1, t0, t1) (int32, device memory; clipped to the tensor).  x: f32 [B, F, T], in place. */
 int mi355x_fill_rects(void* x, const void* rects, int n, int B, int F, int T, float value, void* stream);
 
+/* ---- RNN-Transducer loss (FastConformer-Transducer, cfg 4) --------------------------------
+ * Replaces the Numba-CUDA kernels behind RNNTLossNumba (nemo/collections/asr/parts/numba/rnnt_loss/rnnt_pytorch.py:39-98 ->
+ * utils/cuda_utils/gpu_rnnt.py:125-231 -> gpu_rnnt_kernel.py:74-407 alphas / betas / grads, reduce.py denominator,
+ * rnnt_helper.py:107-116 costs).  acts f32 [B,T,U1,V1] = joint LOGITS (the log-softmax is fused, as in the reference's
+ * GPU path); labels i64 [B,U1-1] (padded); act_lens, label_lens i64 [B]; costs f32 [B] = -(1+fastemit_lambda) * log P(y|x);
+ * grads f32 [B,T,U1,V1] (NULL = loss only) = grad_scale * d cost / d acts with the FastEmit term (gpu_rnnt_kernel.py:364-376)
+ * and clamp (> 0: clip to [-clamp, clamp], :392-396); cells beyond an utterance's (T_b, U_b+1) are written as zeros.
+ * workspace f32, at least mi355x_rnnt_workspace_elems(B,T,U1) elements.  U1 <= 1024.                                     */
+int mi355x_rnnt_workspace_elems(int B, int T, int U1, long long* elems);
+int mi355x_rnnt_loss(const void* acts, const void* labels, const void* act_lens, const void* label_lens, int B, int T, int U1,
+                     int V1, int blank, float fastemit_lambda, float clamp, float grad_scale, void* costs, void* grads,
+                     void* workspace, long long workspace_elems, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

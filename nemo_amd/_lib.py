@@ -102,6 +102,8 @@ SIGNATURES = {
     "mi355x_clip_coef": [vp, i32, f32, f32, vp, vp],
     "mi355x_pack_weights": [vp, i32, i64, i32, vp],
     "mi355x_fill_f32": [vp, i64, f32, vp],
+    "mi355x_rnnt_workspace_elems": [i32, i32, i32, vp],
+    "mi355x_rnnt_loss": [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, i64, vp],
 }
 
 EXPORTED_SYMBOLS = sorted(list(SIGNATURES) + ["mi355x_asr_version"])

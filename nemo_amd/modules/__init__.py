@@ -4,3 +4,4 @@ from .conformer_encoder import ConformerEncoder  # noqa: F401
 from .conv_asr import ConvASRDecoder  # noqa: F401
 from .ctc import CTCLoss  # noqa: F401
 from .ctc_decoding import GreedyCTCDecoder, WER, word_error_rate  # noqa: F401
+from .rnnt_loss import RNNTLoss, RNNTLossNumba  # noqa: F401

@@ -392,6 +392,17 @@ def ctc_loss(logp, targets, in_len, tgt_len, blank, grad=None, grad_scale=1.0, z
     return nll
 
 
+def rnnt_loss(acts, labels, act_lens, label_lens, blank, grads=None, fastemit_lambda=0.0, clamp=0.0, grad_scale=1.0):
+    """acts f32 [B,T,U1,V1] logits (contiguous); labels i64 [B,U1-1]; returns costs f32 [B]; fills `grads` if given"""
+    B, T, U1, V1 = acts.shape
+    n = 5 * B * T * U1 + 2 * B
+    ws = torch.empty(n, device=acts.device, dtype=torch.float32)
+    costs = torch.empty(B, device=acts.device, dtype=torch.float32)
+    check(lib.mi355x_rnnt_loss(_ptr(acts), _ptr(labels), _ptr(act_lens), _ptr(label_lens), B, T, U1, V1, blank,
+                               fastemit_lambda, clamp, grad_scale, _ptr(costs), _ptr(grads), _ptr(ws), n, _stream()), "rnnt_loss")
+    return costs
+
+
 def row_scale(x, vec, rows, cols):
     check(lib.mi355x_row_scale(_ptr(x), _ptr(vec), rows, cols, _stream()), "row_scale")
 

@@ -252,9 +252,43 @@ def make_data_fixture():
     print("data fixture:", {k: len(v) for k, v in out.items()})
 
 
+def extract_rnnt_known_answers():
+    """literal inputs and expected costs / gradients of the reference's own RNN-T tests
+    (tests/collections/asr/numba/rnnt_loss/test_rnnt_pytorch.py: test_case_small, test_case_big_tensor,
+    test_case_small_clamp) -> tests/golden/rnnt_known_answers.json"""
+    src = open(os.path.join(REF, "tests/collections/asr/numba/rnnt_loss/test_rnnt_pytorch.py")).read()
+    tree = ast.parse(src)
+    want = {"test_case_small": {}, "test_case_big_tensor": {}, "test_case_small_clamp": {}}
+    consts = {}
+    for node in tree.body:  # module-level constants such as GRAD_CLAMP
+        if isinstance(node, ast.Assign) and isinstance(node.value, ast.Constant) and isinstance(node.targets[0], ast.Name):
+            consts[node.targets[0].id] = node.value.value
+    for cls in [n for n in tree.body if isinstance(n, ast.ClassDef)]:
+        for fn in [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in want and not want[n.name]]:
+            vals = {}
+            for st in ast.walk(fn):
+                if isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Name):
+                    name = st.targets[0].id
+                    if name in ("acts", "activations", "labels", "expected_cost", "expected_costs", "expected_grads",
+                                "GRAD_CLAMP"):
+                        node = st.value
+                        while isinstance(node, ast.Call) and getattr(node.func, "attr", "") in ("astype", "array"):
+                            node = node.func.value if node.func.attr == "astype" else node.args[0]
+                        try:
+                            vals.setdefault(name, _literal(node))
+                        except Exception:
+                            pass
+            want[fn.name] = vals
+    out = {"cases": want}
+    with open(os.path.join(GOLD, "rnnt_known_answers.json"), "w") as f:
+        json.dump(out, f)
+    print("rnnt known answers:", {k: sorted(v) for k, v in want.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     extract_ctc_known_answers()
     make_reference_fixtures()
     make_specaug_fixture()
     make_data_fixture()
+    extract_rnnt_known_answers()

@@ -913,3 +913,89 @@ def test_pack_weights():
     assert torch.all(plan["w"][:, 45:] == 0)
     assert torch.equal(plan["wt"][:, :70].float().cpu(), W.t().to(torch.bfloat16).float().cpu())
     assert torch.equal(plan["c2"].float().cpu(), W2.permute(0, 2, 3, 1).reshape(16, 72).to(torch.bfloat16).float().cpu())
+
+
+# ------------------------------------------------------------------ RNN-T loss
+def _rnnt_known():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "rnnt_known_answers.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_rnnt_loss_known_answers_of_the_reference_tests():
+    from nemo_amd.modules import RNNTLoss
+    cases = _rnnt_known()
+
+    def run(acts, labels, **kw):
+        a = torch.tensor(acts, dtype=torch.float32, device=dev).requires_grad_(True)
+        lab = torch.tensor(labels, device=dev)
+        B, T = a.shape[:2]
+        lens = torch.full((B,), T, device=dev, dtype=torch.int64)
+        ll = torch.full((B,), lab.shape[1], device=dev, dtype=torch.int64)
+        cost = RNNTLoss(blank=0, **kw)(a, lab, lens, ll)
+        cost.sum().backward()
+        return cost.detach().cpu().numpy(), a.grad.cpu().numpy()
+    c = cases["test_case_small"]
+    cost, grads = run(c["acts"], c["labels"], reduction="sum")
+    assert np.allclose(cost, c["expected_cost"], atol=1e-5) and np.allclose(grads, np.array(c["expected_grads"]), atol=1e-6, rtol=1e-4)
+    for lam in (1.0, 0.01, 0.00001):  # test_case_small_fastemit_clamp: the cost scales by (1 + lambda)
+        cf, _ = run(c["acts"], c["labels"], reduction="sum", fastemit_lambda=lam, clamp=0.1)
+        assert np.allclose(cf, c["expected_cost"] * (1 + lam), rtol=1e-5)
+    c = cases["test_case_small_clamp"]
+    cost, grads = run(c["acts"], c["labels"], reduction="sum", clamp=c["GRAD_CLAMP"])
+    assert np.allclose(cost, c["expected_cost"], atol=1e-5) and np.allclose(grads, np.array(c["expected_grads"]), atol=1e-6, rtol=1e-4)
+    c = cases["test_case_big_tensor"]
+    cost, grads = run(c["activations"], c["labels"], reduction="sum")
+    assert np.allclose(cost, sum(c["expected_costs"]), atol=1e-5)
+    assert np.allclose(grads, np.array(c["expected_grads"]), atol=1e-6, rtol=1e-3)
+    cost, _ = run(c["activations"], c["labels"], reduction="none")
+    assert np.allclose(cost, np.array(c["expected_costs"]), atol=1e-5)
+
+
+@pytest.mark.parametrize("B,T,U1,V1,blank", [(3, 9, 6, 7, 0), (4, 33, 17, 29, 28), (2, 70, 70, 1025, 1024), (5, 12, 1, 8, 3)])
+def test_rnnt_loss_matches_the_oracle_on_ragged_batches(B, T, U1, V1, blank):
+    """fused log-softmax + lattice + gradient kernels against oracle/rnnt_ref.py (float64): ragged T and U, U1 beyond one
+    wave, vector (V1 % 4 == 0) and scalar row paths, an empty-label utterance, FastEmit and clamp, all reductions"""
+    from oracle import rnnt_ref as RR
+    from nemo_amd.modules import RNNTLoss
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    acts = torch.randn(B, T, U1, V1, generator=g) * 2.0
+    lens = torch.randint(max(1, T // 2), T + 1, (B,), generator=g); lens[0] = T
+    ll = torch.randint(0, U1, (B,), generator=g) if U1 > 1 else torch.zeros(B, dtype=torch.int64)
+    ll[-1] = U1 - 1
+    if B > 2 and U1 > 1:
+        ll[1] = 0
+    labels = torch.randint(0, V1 - 1, (B, max(U1 - 1, 0)), generator=g)
+    labels = labels + (labels >= blank).long()
+    for kw in (dict(reduction="sum"), dict(reduction="mean", fastemit_lambda=0.3), dict(reduction="none", clamp=0.05),
+               dict(reduction="mean", fastemit_lambda=0.01, clamp=0.2)):
+        a = acts.to(dev).requires_grad_(True)
+        cost = RNNTLoss(blank=blank, **kw)(a, labels.to(dev), lens.to(dev), ll.to(dev))
+        up = torch.linspace(0.5, 1.5, cost.numel(), device=dev)  # a non-trivial upstream gradient
+        (cost * up).sum().backward()
+        rc, rg = RR.rnnt_loss_and_grad(acts, labels, lens, ll, blank=blank, fastemit_lambda=kw.get("fastemit_lambda", 0.0),
+                                       clamp=kw.get("clamp", 0.0), reduction=kw["reduction"])
+        upc = up.cpu().double()
+        rg = rg * (upc.view(-1, 1, 1, 1) if kw["reduction"] == "none" else upc)
+        assert torch.allclose(cost.detach().cpu().double(), rc, rtol=2e-5, atol=1e-4), (kw, cost, rc)
+        err = (a.grad.cpu().double() - rg).abs().max().item()
+        # fp32 lattice values reach |alpha| ~ (T+U) * log V (~ 1e3 for the large case: ulp 6e-5), so exp(alpha+beta-ll) carries
+        # ~1e-4 relative error there -- the reference's own big-tensor test allows rtol 1e-3 (test_rnnt_pytorch.py:306-309)
+        tol = 2e-5 if T + U1 < 64 else 1e-3
+        assert err <= tol * max(1.0, rg.abs().max().item()), (kw, err)
+
+
+def test_rnnt_loss_argument_checks():
+    from nemo_amd.modules import RNNTLoss
+    a = torch.randn(2, 5, 3, 4, device=dev)
+    lab = torch.ones(2, 2, dtype=torch.int64, device=dev)
+    lens = torch.tensor([5, 4], device=dev); ll = torch.tensor([2, 1], device=dev)
+    RNNTLoss()(a, lab, lens, ll)
+    with pytest.raises(ValueError):  # T must equal max(lengths)  (rnnt_numpy.py:92-95)
+        RNNTLoss()(a, lab, torch.tensor([4, 4], device=dev), ll)
+    with pytest.raises(ValueError):  # U must equal max(label_lengths) + 1
+        RNNTLoss()(a, lab, lens, torch.tensor([1, 1], device=dev))
+    with pytest.raises(TypeError):
+        RNNTLoss()(a, lab.int(), lens, ll)
+    with pytest.raises(RuntimeError):
+        RNNTLoss()(a.cpu(), lab.cpu(), lens.cpu(), ll.cpu())

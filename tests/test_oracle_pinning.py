@@ -200,3 +200,57 @@ def test_greedy_decode_restatement_folds_like_the_reference_loop():
     assert toks == [1, 1, 2]
     assert D.tokens_to_text([0, 1, 2], ["a", "b", "c"]) == "abc"
 
+
+
+# ------------------------------------------------------------------ RNN-T loss oracle
+def _rnnt_cases():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "rnnt_known_answers.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_rnnt_oracle_reproduces_the_reference_known_answers():
+    """costs and gradients written into the reference's own tests (test_rnnt_pytorch.py:82-128, 190-310, 358-402)"""
+    from oracle import rnnt_ref as RR
+    cases = _rnnt_cases()
+    c = cases["test_case_small"]
+    acts = torch.tensor(c["acts"], dtype=torch.float32)
+    labels = torch.tensor(c["labels"])
+    lens, ll = torch.tensor([acts.shape[1]]), torch.tensor([labels.shape[1]])
+    cost, grads = RR.rnnt_loss_and_grad(acts, labels, lens, ll, blank=0, reduction="sum")
+    assert abs(cost.item() - c["expected_cost"]) < 1e-6
+    assert np.allclose(grads.numpy(), np.array(c["expected_grads"]), atol=1e-7, rtol=1e-5)
+    # FastEmit scales the cost by (1 + lambda) (test_case_small_fastemit_clamp, :436-439)
+    for lam in (1.0, 0.01, 0.00001):
+        cf, _ = RR.rnnt_loss_and_grad(acts, labels, lens, ll, blank=0, fastemit_lambda=lam, reduction="sum")
+        assert abs(cf.item() - c["expected_cost"] * (1 + lam)) < 1e-6 * (1 + lam)
+    c = cases["test_case_small_clamp"]
+    cost, grads = RR.rnnt_loss_and_grad(acts, labels, lens, ll, blank=0, clamp=c["GRAD_CLAMP"], reduction="sum")
+    assert abs(cost.item() - c["expected_cost"]) < 1e-6
+    assert np.allclose(grads.numpy(), np.array(c["expected_grads"]), atol=1e-7, rtol=1e-5)
+    c = cases["test_case_big_tensor"]
+    acts = torch.tensor(c["activations"], dtype=torch.float32)
+    labels = torch.tensor(c["labels"])
+    B, T = acts.shape[:2]
+    lens, ll = torch.full((B,), T), torch.full((B,), labels.shape[1])
+    costs, grads = RR.rnnt_loss_and_grad(acts, labels, lens, ll, blank=0, reduction="none")
+    assert np.allclose(costs.numpy(), np.array(c["expected_costs"]), atol=1e-6)
+    assert np.allclose(grads.numpy(), np.array(c["expected_grads"]), atol=1e-6, rtol=1e-3)
+
+
+def test_rnnt_oracle_closed_form_gradient_is_the_derivative():
+    """the fused closed form (gpu_rnnt_kernel.py:355-396) against autograd through log-softmax + the alpha recursion,
+    on a ragged random batch, any blank position"""
+    from oracle import rnnt_ref as RR
+    g = torch.Generator().manual_seed(3)
+    B, T, U1, V1 = 3, 7, 5, 6
+    acts = torch.randn(B, T, U1, V1, generator=g)
+    lens, ll = torch.tensor([7, 4, 6]), torch.tensor([4, 2, 0])
+    for blank in (0, V1 - 1, 2):
+        labels = torch.randint(0, V1 - 1, (B, U1 - 1), generator=g)
+        labels = labels + (labels >= blank).long()  # never the blank
+        cost, grads = RR.rnnt_loss_and_grad(acts, labels, lens, ll, blank=blank, reduction="sum")
+        nll, ag = RR.rnnt_nll_autograd(acts, labels, lens, ll, blank=blank)
+        assert abs(cost.item() - nll.item()) < 1e-9 * abs(nll.item())
+        assert (grads - ag).abs().max() < 1e-10
+        assert grads[1, 4:].abs().max() == 0 and grads[2, :, 1:].abs().max() == 0  # padded cells carry no gradient
