@@ -519,10 +519,9 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 // Per-thread LDS-DMA sources of one operand, computed once per tile: the K loop only adds the k-tile step.
 template <int R> struct DmaSrc {
   static constexpr int PER = R * 8 / 512;
-  const bf16_t* ptr[PER];  // source of chunk i at k-tile 0 (nullptr-equivalent handled by `ok`)
-  int kin[PER];            // k offset of the chunk inside a k-tile (K-tail test)
-  bool ok[PER];            // column (reduction-major) inside the matrix
-  long long step;          // elements per k-tile
+  const bf16_t* ptr[PER];  // source of chunk i at k-tile 0; a chunk outside the matrix points at the zero page ...
+  int kin[PER];            // k offset of the chunk inside a k-tile (K-tail test, last k-tile only)
+  int step[PER];           // ... and advances by 0 elements per k-tile instead of BK (* ld): the issue has no select
 };
 template <bool T, int R>
 __device__ __forceinline__ void dma_setup(DmaSrc<R>& d, const bf16_t* base, long long ld, int row0, int rows, int kbase) {
@@ -536,18 +535,18 @@ __device__ __forceinline__ void dma_setup(DmaSrc<R>& d, const bf16_t* base, long
       gr = gr < rows ? gr : rows - 1;
       d.ptr[i] = base + (long long)gr * ld + kbase + gck * 8;
       d.kin[i] = gck * 8;
-      d.ok[i] = true;
+      d.step[i] = BK;
     } else {
       constexpr int CPR = R / 8;
       const int k = q / CPR, cp = q % CPR;
       const int c = cp ^ ((k & 3) << 2);
       const int gc = row0 + c * 8;
-      d.ok[i] = gc < rows;
-      d.ptr[i] = base + (long long)(kbase + k) * ld + (d.ok[i] ? gc : 0);
+      const bool ok = gc < rows;
+      d.ptr[i] = ok ? base + (long long)(kbase + k) * ld + gc : reinterpret_cast<const bf16_t*>(g_zero16);
       d.kin[i] = k;
+      d.step[i] = ok ? (int)(BK * ld) : 0;  // BK * ld < 2^31 is checked by the host entry
     }
   }
-  d.step = T ? (long long)BK * ld : (long long)BK;
 }
 // implicit-GEMM gather of a K-contiguous operand: the chunk's row is a conv output position, its pointer the channel
 // vector at the position's origin; per K-tile only the (uniform) tap offset and the bounds test change
@@ -644,11 +643,12 @@ __device__ __forceinline__ void gatherT_issue(DmaGatherT<R>& g, const GemmP& p, 
 template <int R>
 __device__ __forceinline__ void dma_issue(const DmaSrc<R>& d, int it, int k0, int K, bool ktail, bf16_t* lds_tile) {
   const int wave = threadIdx.x >> 6;
+  const bool tail = ktail && (k0 + BK > K);  // uniform: only the last k-tile of a ragged K tests its chunks
+  const unsigned long long zero = (unsigned long long)(const void*)g_zero16;
 #pragma unroll
   for (int i = 0; i < DmaSrc<R>::PER; ++i) {
-    bool ok = d.ok[i];
-    if (ktail) ok = ok && (k0 + d.kin[i] < K);
-    const bf16_t* src = ok ? d.ptr[i] + (long long)it * d.step : reinterpret_cast<const bf16_t*>(g_zero16);
+    unsigned long long src = (unsigned long long)(const void*)(d.ptr[i] + (long long)it * d.step[i]);
+    if (tail) src = (k0 + d.kin[i] < K) ? src : zero;  // integer select (v_cndmask), not a divergent branch
     bf16_t* dst = lds_tile + (wave * 64 + i * 512) * 8;
     __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
   }
@@ -736,6 +736,79 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
   const bool do_colsum = TA && p.colsum_out != nullptr && tile_n < cs_step;
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
+  // ---- K loop.  Two schedules, chosen per operand layout by measurement (same box, old | new, us):
+  //   * both operands reduction-major (weight gradients; 32 ds_read_b64_tr_b16 per K-tile): software-pipelined at half-K-tile
+  //     granularity -- the reads are two bursts of 8 fragments (k-steps 0-1 | 2-3), each issued right before the 8 MFMAs of
+  //     the OTHER half, so they run under matrix work inside every wave: FFN wgrad 77.2 -> 70.4, conv2-like wgrad 869 -> 805;
+  //   * otherwise (16 ds_read_b128 per K-tile): all fragment reads of the K-tile in ONE burst, then the 16 MFMAs -- the
+  //     LDS, not the MFMA pipe, bounds this loop and only reaches its rate on long bursts (pipelined: FFN2 forward 53.8 ->
+  //     56.9, 4096^3 NN 140.7 -> 147.6).
+  constexpr bool PIPELINED = TA && TB;
+  if constexpr (PIPELINED) {
+  // Pipelined schedule:
+  //   on entry to iteration it:  F[0..1] = first half of tile it (read during iteration it-1, after its barrier)
+  //   A  issue the DMA of tile it+2 (stage of tile it-1: its last reads completed before the barrier of iteration it-1)
+  //   B  read the second half of tile it -> F[2..3]          C  MFMAs of F[0..1]
+  //   D  my share of tile it+1 has landed (counted vmcnt), my reads are done (lgkmcnt 0), barrier -> tile it+1 visible
+  //   E  read the first half of tile it+1 -> F[0..1]         F  MFMAs of F[2..3]
+  bf16x8 af[4][2], bfr[4][2];
+  auto read_half = [&](const bf16_t* a_s, const bf16_t* b_s, const int h) {
+#pragma unroll
+    for (int kk = 2 * h; kk < 2 * h + 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[kk][i] = frag_v2<TA, BM2>(a_s, wm * 64 + i * 32, kk, lane);
+        bfr[kk][i] = frag_v2<TB, BN>(b_s, wn * 64 + i * 32, kk, lane);
+      }
+  };
+  auto mfma_half = [&](const int h) {
+#pragma unroll
+    for (int kk = 2 * h; kk < 2 * h + 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+  };
+  if (nk > 0) {
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_half(smem2, smem2 + BM2 * BK, 0);
+  }
+  for (int it = 0; it < nk; ++it) {
+    if (it + 2 < nk) issue(it + 2);
+    const bf16_t* a_s = smem2 + (it % 3) * NT2_STAGE;
+    const bf16_t* b_s = a_s + BM2 * BK;
+    __builtin_amdgcn_sched_barrier(0);
+    read_half(a_s, b_s, 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the burst ahead of the MFMAs: the scheduler would sink the reads to their uses
+    mfma_half(0);
+    if (TA && do_colsum) {  // thread -> (k-group of 8 rows = wave, 4 consecutive columns = lane): 8 x ds_read_b64
+      const int col = lane * 4;
+      for (int kr = tile_n; kr < 8; kr += cs_step) {
+        const int krow = wave * 8 + kr;
+        const int off = krow * BM2 + (((col >> 3) ^ ((krow & 3) << 2)) << 3) + (col & 7);
+        const u32x2 v = *reinterpret_cast<const u32x2*>(a_s + off);
+        csum[0] += __uint_as_float(v[0] << 16); csum[1] += __uint_as_float(v[0] & 0xffff0000u);
+        csum[2] += __uint_as_float(v[1] << 16); csum[3] += __uint_as_float(v[1] & 0xffff0000u);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // tile it+1 must have landed (this wave's share) before the barrier publishes it; tile it+2 may stay in flight
+    if (it + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 1 < nk) {
+      const bf16_t* a_n = smem2 + ((it + 1) % 3) * NT2_STAGE;
+      read_half(a_n, a_n + BM2 * BK, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(1);
+  }
+
+  } else {
 #ifdef GEMM_ABLATE
   if (nk > 0)
 #endif
@@ -790,6 +863,8 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
     if (it + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+  }
+
   }
 
   float* sC = reinterpret_cast<float*>(smem2);
@@ -1169,6 +1244,8 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   mi_clear_errors();
   if (!d || !d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0) return MI_ERR_ARG;
   if (d->in_dtype != MI_DT_F32 && d->in_dtype != MI_DT_BF16) return MI_ERR_ARG;
+  // the LDS-DMA source of a reduction-major operand advances by BK * ld elements per k-tile, kept in 32 bits
+  if ((d->transA && d->lda * 64 >= (1LL << 31)) || (d->transB && d->ldb * 64 >= (1LL << 31))) return MI_ERR_ARG;
   GemmP p;
   p.A = d->A; p.B = d->B; p.C = d->C;
   p.M = d->M; p.N = d->N; p.K = d->K;
