@@ -59,6 +59,8 @@ class EncDecCTCModel(nn.Module):
         self._optimizer: Optional[FusedAdamW] = None
         self._scheduler: Optional[NoamAnnealing] = None
         self._syncs = None
+        self._wer = None
+        self.validation_step_outputs, self.test_step_outputs = [], []
         # optimizer slices behind backward (begin_step / step_range / finish_step): measured 46.66 vs 46.48 ms per step on
         # one GPU (the HBM-bound update competes with the HBM-bound halves of backward), so it is opt-in; it exists for
         # data-parallel runs where the update otherwise sits behind the last bucket's all-reduce
@@ -90,7 +92,143 @@ class EncDecCTCModel(nn.Module):
         logs = {"train_loss": loss_value.detach(), "global_step": self.global_step}
         if self._scheduler is not None:
             logs["learning_rate"] = self._scheduler.get_last_lr()
+        n = self._log_every_n_steps()
+        if n and (batch_nb + 1) % n == 0 and self.wer is not None:  # ctc_models.py:591-600 (the decode's D2H is the host sync)
+            self.wer.update(predictions=log_probs.detach(), predictions_lengths=encoded_len, targets=transcript,
+                            targets_lengths=transcript_len)
+            logs["training_batch_wer"] = self.wer.compute()[0]
+            self.wer.reset()
         return {"loss": loss_value, "log": logs}
+
+    def _log_every_n_steps(self):
+        """`trainer.log_every_n_steps` when a trainer is attached (ctc_models.py:567-570).  Without one the reference decodes
+        and scores EVERY step (a host sync per step); here that needs the explicit config key `log_every_n_steps`."""
+        if self.trainer is not None and getattr(self.trainer, "log_every_n_steps", None):
+            return int(self.trainer.log_every_n_steps)
+        return int(self._cfg.get("log_every_n_steps") or 0)
+
+    @property
+    def wer(self):
+        """greedy CTC decoding + WER over the decoder's vocabulary (ctc_models.py:91-105: CTCDecoding + WER(use_cer, ...))"""
+        if self._wer is None:
+            vocab = getattr(self.decoder, "vocabulary", None)
+            tok = getattr(self, "tokenizer", None)
+            if tok is not None and hasattr(tok, "vocab"):
+                vocab = tok.vocab
+            if vocab is None:
+                return None
+            from ..modules import WER, GreedyCTCDecoder
+            self._wer = WER(GreedyCTCDecoder(vocabulary=list(vocab)), use_cer=bool(self._cfg.get("use_cer", False)))
+        return self._wer
+
+    # ------------------------------------------------------------------ evaluation (ctc_models.py:604-700, asr_model.py:95-160)
+    @torch.no_grad()
+    def validation_pass(self, batch, batch_idx=0, dataloader_idx=0):
+        signal, signal_len, transcript, transcript_len = batch[:4]
+        log_probs, encoded_len, _ = self.forward(input_signal=signal, input_signal_length=signal_len)
+        loss_value = self.loss(log_probs=log_probs, targets=transcript, input_lengths=encoded_len, target_lengths=transcript_len)
+        metrics = {"val_loss": loss_value}
+        if self.wer is not None:
+            self.wer.update(predictions=log_probs, predictions_lengths=encoded_len, targets=transcript,
+                            targets_lengths=transcript_len)
+            wer, num, denom = self.wer.compute()
+            self.wer.reset()
+            metrics.update({"val_wer_num": num, "val_wer_denom": denom, "val_wer": wer})
+        return metrics
+
+    def validation_step(self, batch, batch_idx=0, dataloader_idx=0):
+        metrics = self.validation_pass(batch, batch_idx, dataloader_idx)
+        self.validation_step_outputs.append(metrics)
+        return metrics
+
+    def test_step(self, batch, batch_idx=0, dataloader_idx=0):
+        logs = self.validation_pass(batch, batch_idx, dataloader_idx)
+        logs = {name.replace("val_", "test_"): value for name, value in logs.items()}
+        self.test_step_outputs.append(logs)
+        return logs
+
+    def multi_validation_epoch_end(self, outputs, dataloader_idx: int = 0, prefix: str = "val"):
+        """asr_model.py:95-123: mean of the batch losses, WER = sum of edit distances / sum of reference words"""
+        loss_mean = torch.stack([x[f"{prefix}_loss"] for x in outputs]).mean()
+        logs = {f"{prefix}_loss": loss_mean}
+        if outputs and f"{prefix}_wer_num" in outputs[0]:
+            num = sum(x[f"{prefix}_wer_num"] for x in outputs)
+            denom = sum(x[f"{prefix}_wer_denom"] for x in outputs)
+            logs[f"{prefix}_wer"] = num / denom if denom else float("inf")
+        return {f"{prefix}_loss": loss_mean, "log": logs}
+
+    def multi_test_epoch_end(self, outputs, dataloader_idx: int = 0):
+        return self.multi_validation_epoch_end(outputs, dataloader_idx, prefix="test")
+
+    @torch.no_grad()
+    def validate(self, dataloader=None):
+        """one pass over the validation loader in eval mode (what the trainer's validation loop does)"""
+        from ..data import DeviceBatchLoader
+        dl = dataloader if dataloader is not None else getattr(self, "_validation_dl", None)
+        if dl is None:
+            raise RuntimeError("call setup_validation_data() first")
+        was_training = self.training
+        self.eval()
+        self.validation_step_outputs = []
+        device = next(self.parameters()).device
+        try:
+            for i, batch in enumerate(DeviceBatchLoader(dl, device)):
+                self.validation_step(list(batch), i)
+        finally:
+            self.train(was_training)
+        return self.multi_validation_epoch_end(self.validation_step_outputs)["log"]
+
+    @torch.no_grad()
+    def predict_step(self, batch, batch_idx=0, dataloader_idx=0):
+        signal, signal_len, _, _, sample_id = batch
+        log_probs, encoded_len, _ = self.forward(input_signal=signal, input_signal_length=signal_len)
+        texts = self.wer.decoding(log_probs, encoded_len)
+        if isinstance(sample_id, torch.Tensor):
+            sample_id = sample_id.cpu().numpy()
+        return list(zip(sample_id, texts))
+
+    @torch.no_grad()
+    def transcribe(self, audio, batch_size: int = 4, return_hypotheses: bool = False, num_workers: int = 0,
+                   channel_selector=None, verbose: bool = False):
+        """`ASRTranscriptionMixin.transcribe` (parts/mixins/transcription.py:184-290) for the greedy CTC path: `audio` is a
+        path, a list of paths, or a list of 1-D waveforms (numpy / torch, at the model's sample rate); returns one string
+        per input (or (text, token ids, score) triples with return_hypotheses).  Eval mode, dither and padding to 16 off
+        (ctc_models.py:760-790), inputs sorted nowhere: the order of the outputs is the order of the inputs."""
+        from ..data import load_audio
+        if self.wer is None:
+            raise RuntimeError("transcribe() needs a vocabulary (decoder.vocabulary or a tokenizer)")
+        if isinstance(audio, (str, bytes)) or not hasattr(audio, "__len__"):
+            audio = [audio]
+        sr = self._cfg.get("sample_rate", 16000)
+        device = next(self.parameters()).device
+        was_training = self.training
+        feat = self.preprocessor.featurizer
+        dither, pad_to = feat.dither, feat.pad_to
+        self.eval()
+        feat.dither, feat.pad_to = 0.0, 0
+        out = []
+        try:
+            for i in range(0, len(audio), batch_size):
+                waves = []
+                for a in audio[i:i + batch_size]:
+                    if isinstance(a, str):
+                        a = load_audio(a, sr, channel_selector=channel_selector)
+                    waves.append(torch.as_tensor(a, dtype=torch.float32).reshape(-1))
+                lens = torch.tensor([w.numel() for w in waves], dtype=torch.int64)
+                sig = torch.zeros(len(waves), int(lens.max()), dtype=torch.float32)
+                for r, w in enumerate(waves):
+                    sig[r, : w.numel()] = w
+                log_probs, enc_len, _ = self.forward(input_signal=sig.to(device), input_signal_length=lens.to(device))
+                tokens, out_len, score = self.wer.decoding.decode_ids(log_probs, enc_len)
+                tokens, out_len, score = tokens.cpu(), out_len.cpu(), score.cpu()
+                for r in range(len(waves)):
+                    ids = tokens[r, : int(out_len[r])].tolist()
+                    text = self.wer.decoding.ids_to_text(ids)
+                    out.append((text, ids, float(score[r])) if return_hypotheses else text)
+        finally:
+            feat.dither, feat.pad_to = dither, pad_to
+            self.train(was_training)
+        return out
 
     # ------------------------------------------------------------------ optimisation
     def flats(self):

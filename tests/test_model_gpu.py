@@ -352,3 +352,56 @@ def test_data_parallel_two_ranks_equal_one_process_on_the_joint_batch(tmp_path):
     assert torch.allclose(r0["bn"], bn, atol=1e-5) and torch.equal(r0["bn"], r1["bn"])  # SyncBN: global statistics
     for a, b in zip(r0["flat"], r1["flat"]):
         assert torch.equal(a, b)
+
+
+def test_training_wer_validation_and_transcribe(tmp_path):
+    """a13's periodic training WER (ctc_models.py:591-600), validation_pass / multi_validation_epoch_end (:633-676,
+    asr_model.py:95-123), predict_step (:604-631) and transcribe() on a synthetic WAV corpus"""
+    import wave
+    from nemo_amd.data import load_audio
+    vocab = [" "] + list("abcdefghijklmnopqrs")
+    m = _wav_corpus(tmp_path, 10, vocab, seed=4)
+    over = dict(d_model=64, n_heads=4, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0)
+    torch.manual_seed(9)
+    cfg_kw = dict(labels=vocab, log_every_n_steps=2)
+    model = _model(over, vocab=len(vocab), **cfg_kw)
+    model._cfg["decoder"]["vocabulary"] = vocab
+    from nemo_amd.models import EncDecCTCModel
+    model = EncDecCTCModel(model._cfg).to(dev).train()
+    model.setup_optimization(dict(name="adamw", lr=1e-3, betas=[0.9, 0.98], weight_decay=0.0))
+    dl = model.setup_training_data(dict(manifest_filepath=m, batch_size=5, shuffle=False))
+    logs = []
+    for i, b in enumerate(dl):
+        logs.append(model.training_step([t.to(dev) for t in b], i)["log"])
+    assert "training_batch_wer" not in logs[0] and "training_batch_wer" in logs[1]
+    assert 0.0 <= logs[1]["training_batch_wer"] < 50.0
+    # validation: loss mean over batches, WER = total edit distance / total reference words
+    model.setup_validation_data(dict(manifest_filepath=m, batch_size=4))
+    res = model.validate()
+    outs = model.validation_step_outputs
+    assert len(outs) == 3 and model.training
+    assert abs(res["val_loss"].item() - float(np.mean([o["val_loss"].item() for o in outs]))) < 1e-4
+    assert abs(res["val_wer"] - sum(o["val_wer_num"] for o in outs) / sum(o["val_wer_denom"] for o in outs)) < 1e-12
+    # transcribe: paths and waveforms give the same texts, in input order, equal to decode(forward(padded batch))
+    paths = [str(tmp_path / f"u{i}.wav") for i in (3, 0, 7, 5, 1)]
+    texts = model.transcribe(paths, batch_size=5)
+    waves = [load_audio(p_, 16000) for p_ in paths]
+    assert model.transcribe([w.numpy() for w in waves], batch_size=5) == texts and model.training
+    hyp = model.transcribe(paths[:2], batch_size=5, return_hypotheses=True)
+    assert [h[0] for h in hyp] == model.transcribe(paths[:2], batch_size=5) and all(isinstance(h[1], list) for h in hyp)
+    model.eval()
+    feat = model.preprocessor.featurizer
+    d0, feat.dither = feat.dither, 0.0
+    lens = torch.tensor([w.numel() for w in waves])
+    sig = torch.zeros(5, int(lens.max()))
+    for r, w in enumerate(waves):
+        sig[r, : w.numel()] = w
+    lp, el, _ = model.forward(input_signal=sig.to(dev), input_signal_length=lens.to(dev))
+    feat.dither = d0
+    assert model.wer.decoding(lp, el) == texts
+    # predict_step keeps the sample ids next to the texts
+    ds = dl.dataset
+    ds.return_sample_id = True
+    batch = ds._collate_fn([ds[i] for i in (2, 4)])
+    pred = model.predict_step([t.to(dev) if torch.is_tensor(t) else t for t in batch])
+    assert [int(i) for i, _ in pred] == [2, 4] and all(isinstance(t, str) for _, t in pred)
