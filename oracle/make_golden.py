@@ -285,6 +285,43 @@ def extract_rnnt_known_answers():
     print("rnnt known answers:", {k: sorted(v) for k, v in want.items()})
 
 
+def make_squeezeformer_fixture():
+    """the reference's SqueezeformerEncoder (squeezeformer_encoder.py, through the shim) on a tiny configuration that takes
+    every branch -- 'dw_striding' sub-sampling, adaptive scale/bias, Swish conv module on 2d channels, batch-statistics
+    BatchNorm, time reduction at layer 1 and recovery at layer 3, ragged lengths -> tests/golden/ref_squeezeformer_tiny.npz
+    (inputs, every parameter, output, and the gradient of a fixed linear functional w.r.t. input and parameters)"""
+    import importlib
+    from oracle import ref_shim
+    ref_shim.install()
+    m = importlib.import_module("nemo.collections.asr.modules.squeezeformer_encoder")
+    torch.manual_seed(11)
+    enc = m.SqueezeformerEncoder(feat_in=40, n_layers=4, d_model=32, subsampling="dw_striding", subsampling_factor=4,
+                                 subsampling_conv_channels=-1, ff_expansion_factor=4, n_heads=4, conv_kernel_size=9,
+                                 dropout=0.0, dropout_emb=0.0, dropout_att=0.0, adaptive_scale=True, time_reduce_idx=1,
+                                 time_recovery_idx=3)
+    with torch.no_grad():  # move the trivially-initialised parameters off their defaults
+        for n, p in enc.named_parameters():
+            if n.endswith("_scale.scale"):
+                p.add_(0.2 * torch.randn_like(p))
+            elif n.endswith("_scale.bias") or "pos_bias" in n or n.endswith("norm_conv.bias"):
+                p.add_(0.1 * torch.randn_like(p))
+    enc.train()  # dropout is 0 everywhere: train mode only selects batch statistics in BatchNorm
+    x = torch.randn(3, 40, 75, requires_grad=True)
+    length = torch.tensor([75, 52, 31])
+    y, yl = enc(audio_signal=x, length=length)
+    w = torch.randn_like(y)
+    valid = (torch.arange(y.shape[2]).unsqueeze(0) < yl.unsqueeze(1)).unsqueeze(1)
+    (y * w * valid).sum().backward()
+    out = {"x": x.detach().numpy(), "length": length.numpy(), "y": y.detach().numpy(), "y_len": yl.numpy(), "w": w.numpy(),
+           "dx": x.grad.numpy()}
+    for n, p in enc.state_dict().items():
+        out["P." + n] = p.detach().numpy()
+    for n, p in enc.named_parameters():
+        out["G." + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    np.savez_compressed(os.path.join(GOLD, "ref_squeezeformer_tiny.npz"), **out)
+    print("squeezeformer fixture:", y.shape, yl.tolist(), len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     extract_ctc_known_answers()
@@ -292,3 +329,4 @@ if __name__ == "__main__":
     make_specaug_fixture()
     make_data_fixture()
     extract_rnnt_known_answers()
+    make_squeezeformer_fixture()

@@ -254,3 +254,34 @@ def test_rnnt_oracle_closed_form_gradient_is_the_derivative():
         assert abs(cost.item() - nll.item()) < 1e-9 * abs(nll.item())
         assert (grads - ag).abs().max() < 1e-10
         assert grads[1, 4:].abs().max() == 0 and grads[2, :, 1:].abs().max() == 0  # padded cells carry no gradient
+
+
+# ------------------------------------------------------------------ Squeezeformer oracle (the HIP path is next)
+def test_squeezeformer_oracle_matches_the_reference_encoder():
+    """oracle/squeezeformer_ref.py against the reference SqueezeformerEncoder run in the build container
+    (tests/golden/ref_squeezeformer_tiny.npz): output, lengths, input gradient and every parameter gradient of a fixed
+    linear functional -- dw_striding sub-sampling, scale/bias layers, Swish conv module on 2d channels with batch-statistics
+    BatchNorm, time reduction + recovery, ragged lengths"""
+    from oracle import squeezeformer_ref as SQ
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_squeezeformer_tiny.npz"))
+    P = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("P.")}
+    train_keys = [k[2:] for k in z.files if k.startswith("G.")]
+    for k in train_keys:
+        P[k] = P[k].clone().requires_grad_(True)
+    cfg = SQ.SqueezeformerCfg(feat_in=40, d_model=32, n_heads=4, n_layers=4, conv_kernel=9, time_reduce_idx=1,
+                              time_recovery_idx=3)
+    x = torch.from_numpy(z["x"]).requires_grad_(True)
+    y, yl = SQ.encoder_forward(P, cfg, x, torch.from_numpy(z["length"]), bn_training=True)
+    assert yl.tolist() == z["y_len"].tolist() and tuple(y.shape) == z["y"].shape
+    ref = torch.from_numpy(z["y"])
+    assert (y - ref).abs().max() <= 2e-5 * ref.abs().max()
+    valid = (torch.arange(y.shape[2]).unsqueeze(0) < yl.unsqueeze(1)).unsqueeze(1)
+    (y * torch.from_numpy(z["w"]) * valid).sum().backward()
+    gref = torch.from_numpy(z["dx"])
+    assert (x.grad - gref).abs().max() <= 1e-4 * gref.abs().max()
+    for k in train_keys:
+        g, r = P[k].grad, torch.from_numpy(z["G." + k])
+        g = torch.zeros_like(r) if g is None else g
+        # absolute floor: the depthwise-conv bias (in front of batch-statistics BatchNorm) and the key bias (softmax shift)
+        # have analytically zero gradients -- both sides hold 1e-5-level rounding noise there
+        assert (g - r).abs().max().item() <= 2e-3 * r.abs().max().item() + 2e-4, k
