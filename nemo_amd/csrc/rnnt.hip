@@ -3,7 +3,7 @@
 //   acts [B, T, U1, V1] f32 logits (U1 = max label length + 1, V1 = vocabulary + blank)
 //   kernel 1  rnnt_denom:      per (b,t,u) row: denom = -logsumexp(row); also the two log-probabilities the lattice needs,
 //                              lp_blank = denom + row[blank], lp_label = denom + row[labels[b,u]] -- so the recursions never
-//                              touch the [B,T,U1,V1] tensor again (one wave per row, 16-byte loads, wave shuffles)
+//                              touch the [B,T,U1,V1] tensor again (one wave per row, 16-byte loads after an alignment peel, wave shuffles)
 //   kernel 2  rnnt_lattice:    alpha (blockIdx.y = 0) and beta (= 1) recursions over the (t,u) lattice, one workgroup per
 //                              utterance, thread = u, anti-diagonal sweep d = t + u: the left neighbour's value travels
 //                              through a double-buffered LDS row (one barrier per diagonal), the emission terms are
@@ -42,25 +42,26 @@ __global__ __launch_bounds__(256) void rnnt_denom_kernel(const float* __restrict
   const int Tb = (int)min((long long)T, xlen[b]), Ub = (int)min((long long)(U1 - 1), ylen[b]) + 1;
   if (t >= Tb || u >= Ub) return;  // never read
   const float* x = acts + row * V1;
+  // a row starts on a 4-byte boundary only (V1 = 1025 is the common case): up to 3 head scalars bring the walk to a 16-byte
+  // boundary, then float4 loads, then up to 3 tail scalars
+  const int head = min(V1, (int)((4u - (unsigned)(((unsigned long long)x >> 2) & 3u)) & 3u));
+  const int n4 = (V1 - head) >> 2;
+  const int tail0 = head + 4 * n4, ntail = V1 - tail0;
+  const float4* x4 = reinterpret_cast<const float4*>(x + head);
   float m = RNEG;
-  const bool vec = ((V1 & 3) == 0);
-  if (vec) {
-    for (int i = lane * 4; i < V1; i += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(x + i);
-      m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-    }
-  } else {
-    for (int i = lane; i < V1; i += 64) m = fmaxf(m, x[i]);
+  if (lane < head) m = x[lane];
+  if (lane < ntail) m = fmaxf(m, x[tail0 + lane]);
+  for (int i = lane; i < n4; i += 64) {
+    const float4 v = x4[i];
+    m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
   }
   m = wave_max(m);
   float s = 0.f;
-  if (vec) {
-    for (int i = lane * 4; i < V1; i += 256) {  // second pass hits L2 / the TA cache: the row is <= a few KiB
-      const float4 v = *reinterpret_cast<const float4*>(x + i);
-      s += (__expf(v.x - m) + __expf(v.y - m)) + (__expf(v.z - m) + __expf(v.w - m));
-    }
-  } else {
-    for (int i = lane; i < V1; i += 64) s += __expf(x[i] - m);
+  if (lane < head) s = __expf(x[lane] - m);
+  if (lane < ntail) s += __expf(x[tail0 + lane] - m);
+  for (int i = lane; i < n4; i += 64) {  // second pass hits L2 / the TA cache: the row is a few KiB
+    const float4 v = x4[i];
+    s += (__expf(v.x - m) + __expf(v.y - m)) + (__expf(v.z - m) + __expf(v.w - m));
   }
   s = wave_sum(s);
   if (lane == 0) {
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* __restrict_
                                                         const float* __restrict__ denom, const float* __restrict__ alphas,
                                                         const float* __restrict__ betas, const float* __restrict__ ll,
                                                         float* __restrict__ grads, long long rows, int T, int U1, int V1,
-                                                        int blank, float fastemit_lambda, float clamp, float scale) {
+                                                        int blank, float fastemit_lambda, float clamp, float scale, int same_align) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -167,13 +168,19 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* __restrict_
   const int b = (int)(bt / T);
   const int Tb = (int)min((long long)T, xlen[b]), Ub = (int)min((long long)(U1 - 1), ylen[b]) + 1;
   float* g = grads + row * V1;
-  const bool vec = ((V1 & 3) == 0);
+  const float* x = acts + row * V1;
+  // same head / float4 body / tail walk as the denominator kernel; rows of acts and grads share their alignment when the two
+  // base pointers do (checked by the host entry: otherwise `same_align` is 0 and the walk is scalar)
+  const int head = same_align ? min(V1, (int)((4u - (unsigned)(((unsigned long long)x >> 2) & 3u)) & 3u)) : V1;
+  const int n4 = (V1 - head) >> 2;
+  const int tail0 = head + 4 * n4, ntail = V1 - tail0;
   if (t >= Tb || u >= Ub) {  // padded cell: zero gradient (the reference starts from a zero-filled tensor)
-    if (vec) for (int i = lane * 4; i < V1; i += 256) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    else for (int i = lane; i < V1; i += 64) g[i] = 0.f;
+    for (int i = lane; i < head; i += 64) g[i] = 0.f;
+    if (lane < ntail) g[tail0 + lane] = 0.f;
+    float4* g4z = reinterpret_cast<float4*>(g + head);
+    for (int i = lane; i < n4; i += 64) g4z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
-  const float* x = acts + row * V1;
   const float dn = denom[row], a = alphas[row], be = betas[row], logll = ll[b];
   const int lab = (u < Ub - 1) ? (int)labels[(long long)b * (U1 - 1) + u] : -1;
   const float common = a + be + dn - logll;          // grad = exp(common + x[v]) ...
@@ -195,15 +202,16 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* __restrict_
     if (clamp > 0.f) gr = fminf(fmaxf(gr, -clamp), clamp);
     return gr * scale;
   };
-  if (vec) {
-    for (int i = lane * 4; i < V1; i += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(x + i);
-      float4 o;
-      o.x = one(i, v.x); o.y = one(i + 1, v.y); o.z = one(i + 2, v.z); o.w = one(i + 3, v.w);
-      *reinterpret_cast<float4*>(g + i) = o;
-    }
-  } else {
-    for (int i = lane; i < V1; i += 64) g[i] = one(i, x[i]);
+  for (int i = lane; i < head; i += 64) g[i] = one(i, x[i]);
+  if (lane < ntail) g[tail0 + lane] = one(tail0 + lane, x[tail0 + lane]);
+  const float4* x4 = reinterpret_cast<const float4*>(x + head);
+  float4* g4 = reinterpret_cast<float4*>(g + head);
+  for (int i = lane; i < n4; i += 64) {
+    const float4 v = x4[i];
+    const int e = head + 4 * i;
+    float4 o;
+    o.x = one(e, v.x); o.y = one(e + 1, v.y); o.z = one(e + 2, v.z); o.w = one(e + 3, v.w);
+    g4[i] = o;
   }
 }
 
@@ -252,7 +260,8 @@ extern "C" int mi355x_rnnt_loss(const void* acts, const void* labels_, const voi
                      label_lens, alphas, betas, ll, B, T, U1);
   if (grads)
     hipLaunchKernelGGL(rnnt_grad_kernel, dim3(nblk), dim3(256), 0, s, (const float*)acts, labels, act_lens, label_lens, denom,
-                       alphas, betas, ll, grads, rows, T, U1, V1, blank, fastemit_lambda, clamp, grad_scale);
+                       alphas, betas, ll, grads, rows, T, U1, V1, blank, fastemit_lambda, clamp, grad_scale,
+                       (int)((((unsigned long long)acts ^ (unsigned long long)grads) & 15ull) == 0ull));
   hipLaunchKernelGGL(rnnt_cost_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ll, costs, B, fastemit_lambda);
   return mi_check_launch();
 }
