@@ -322,6 +322,45 @@ def make_squeezeformer_fixture():
     print("squeezeformer fixture:", y.shape, yl.tolist(), len(out), "arrays")
 
 
+def make_transducer_fixture():
+    """the reference's RNNTDecoder + RNNTJoint (modules/rnnt.py through the shim) and its pure-torch loss
+    (losses/rnnt_pytorch.py) on a tiny ragged batch -> tests/golden/ref_transducer_tiny.npz: parameters, decoder output,
+    joint logits, per-batch loss, gradients w.r.t. the encoder output and every parameter"""
+    import importlib
+    from oracle import ref_shim
+    ref_shim.install()
+    m = importlib.import_module("nemo.collections.asr.modules.rnnt")
+    lp = importlib.import_module("nemo.collections.asr.losses.rnnt_pytorch")
+    torch.manual_seed(21)
+    V, H, D, J = 12, 16, 24, 20
+    dec = m.RNNTDecoder(prednet={"pred_hidden": H, "pred_rnn_layers": 2, "dropout": 0.0}, vocab_size=V,
+                        normalization_mode=None, random_state_sampling=False, blank_as_pad=True)
+    joint = m.RNNTJoint(jointnet={"encoder_hidden": D, "pred_hidden": H, "joint_hidden": J, "activation": "relu",
+                                  "dropout": 0.0}, num_classes=V)
+    B, T, U = 3, 9, 5
+    enc = torch.randn(B, D, T, requires_grad=True)
+    enc_len = torch.tensor([9, 7, 4])
+    tgt_len = torch.tensor([5, 3, 0])
+    tgt = torch.randint(0, V, (B, U))
+    for b in range(B):
+        tgt[b, tgt_len[b]:] = V  # padded with the blank id, as the collate function of the transducer models does
+    g, _, _ = dec(targets=tgt, target_length=tgt_len)
+    logits = joint(encoder_outputs=enc, decoder_outputs=g)
+    loss = lp.RNNTLossPytorch(blank=V, reduction="sum")(acts=logits, labels=tgt.clamp(max=V - 1), act_lens=enc_len,
+                                                         label_lens=tgt_len)
+    loss.backward()
+    out = {"enc": enc.detach().numpy(), "enc_len": enc_len.numpy(), "targets": tgt.numpy(), "tgt_len": tgt_len.numpy(),
+           "dec_out": g.detach().numpy(), "logits": logits.detach().numpy(), "loss": np.array(loss.item()),
+           "d_enc": enc.grad.numpy()}
+    for pre, mod in (("D.", dec), ("J.", joint)):
+        for n, p in mod.state_dict().items():
+            out["P." + pre + n] = p.detach().numpy()
+        for n, p in mod.named_parameters():
+            out["G." + pre + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    np.savez_compressed(os.path.join(GOLD, "ref_transducer_tiny.npz"), **out)
+    print("transducer fixture: logits", tuple(logits.shape), "loss", loss.item())
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     extract_ctc_known_answers()
@@ -330,3 +369,4 @@ if __name__ == "__main__":
     make_data_fixture()
     extract_rnnt_known_answers()
     make_squeezeformer_fixture()
+    make_transducer_fixture()

@@ -148,6 +148,7 @@ def install():
         ("nemo.collections.asr.parts", "collections/asr/parts"),
         ("nemo.collections.asr.modules", "collections/asr/modules"),
         ("nemo.collections.asr.models", "collections/asr/models"),
+        ("nemo.collections.asr.losses", "collections/asr/losses"),
         ("nemo.collections.asr.parts.submodules", "collections/asr/parts/submodules"),
         ("nemo.collections.asr.parts.submodules.adapters", "collections/asr/parts/submodules/adapters"),
         ("nemo.collections.asr.parts.utils", "collections/asr/parts/utils"),
@@ -231,6 +232,14 @@ def install():
           AdapterModuleMixin=AdapterModuleMixin)
     sys.modules["nemo.core.classes.mixins.adapter_mixins"] = am
     sys.modules["nemo.core.classes.mixins"].adapter_mixins = am
+    # what modules/rnnt.py and rnnt_abstract.py import from the package roots
+    sys.modules["nemo.core.classes"].adapter_mixins = am
+    sys.modules["nemo.core"].NeuralModule = NeuralModule
+
+    class Loss(nn.Module, Typing):  # nemo/core/classes/loss.py: an nn.Module with typed I/O
+        pass
+
+    sys.modules["nemo.core.classes"].Loss = Loss
 
     # ---- misc fakes ------------------------------------------------------------------------
     @dataclasses.dataclass

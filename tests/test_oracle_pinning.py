@@ -285,3 +285,40 @@ def test_squeezeformer_oracle_matches_the_reference_encoder():
         # absolute floor: the depthwise-conv bias (in front of batch-statistics BatchNorm) and the key bias (softmax shift)
         # have analytically zero gradients -- both sides hold 1e-5-level rounding noise there
         assert (g - r).abs().max().item() <= 2e-3 * r.abs().max().item() + 2e-4, k
+
+
+# ------------------------------------------------------------------ transducer head oracle
+def test_transducer_head_oracle_matches_the_reference_modules():
+    """oracle/transducer_ref.py (prediction network with a hand-written LSTM, joint) + oracle/rnnt_ref.py (loss, closed-form
+    gradient w.r.t. the logits) against the reference's RNNTDecoder / RNNTJoint / RNNTLossPytorch run in the build container
+    (tests/golden/ref_transducer_tiny.npz): decoder output, logits, loss, and the gradients w.r.t. the encoder output and
+    every parameter obtained by pushing the oracle's logit gradient back through the restated head"""
+    from oracle import rnnt_ref as RR
+    from oracle import transducer_ref as TR
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_transducer_tiny.npz"))
+    PD = {k[4:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("P.D.")}
+    PJ = {k[4:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("P.J.")}
+    enc = torch.from_numpy(z["enc"]).requires_grad_(True)
+    tgt, enc_len, tgt_len = torch.from_numpy(z["targets"]), torch.from_numpy(z["enc_len"]), torch.from_numpy(z["tgt_len"])
+    V = PD["prediction.embed.weight"].shape[0] - 1
+    g = TR.prediction_network(PD, tgt)
+    assert (g - torch.from_numpy(z["dec_out"])).abs().max() < 1e-6
+    logits = TR.joint_network(PJ, enc, g)
+    # on CPU the reference joint returns log_softmax(logits) (rnnt.py: `log_softmax=None` -> applied unless the tensor is on
+    # the GPU, where the loss fuses it); the restatement always returns the logits
+    ref_logp = torch.from_numpy(z["logits"])
+    assert (torch.log_softmax(logits, -1) - ref_logp).abs().max() <= 1e-5 * ref_logp.abs().max()
+    cost, dlogits = RR.rnnt_loss_and_grad(logits, tgt.clamp(max=V - 1), enc_len, tgt_len, blank=V, reduction="sum")
+    assert abs(cost.item() - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    logits.backward(dlogits.to(logits.dtype))  # the loss kernels hand out d cost / d logits; the head's backward does the rest
+    ref = torch.from_numpy(z["d_enc"])
+    assert (enc.grad - ref).abs().max() <= 1e-4 * ref.abs().max()
+    for pre, P in (("D.", PD), ("J.", PJ)):
+        for k, v in P.items():
+            if ("G." + pre + k) not in z.files:
+                continue
+            r = torch.from_numpy(z["G." + pre + k])
+            got = v.grad if v.grad is not None else torch.zeros_like(r)
+            assert (got - r).abs().max().item() <= 2e-4 * r.abs().max().item() + 1e-6, k
+    # the padding row of the embedding (the blank id) stays zero and receives no gradient
+    assert PD["prediction.embed.weight"][V].abs().max() == 0
