@@ -361,6 +361,38 @@ def make_transducer_fixture():
     print("transducer fixture: logits", tuple(logits.shape), "loss", loss.item())
 
 
+def make_fastconformer_fixture():
+    """the reference ConformerEncoder with 'dw_striding' x8 sub-sampling and depthwise kernel 9 (the FastConformer geometry)
+    -> tests/golden/ref_fastconformer_tiny.npz (inputs, parameters, output, gradients of a fixed linear functional)"""
+    from oracle import ref_shim
+    ref_shim.install()
+    import importlib
+    m = importlib.import_module("nemo.collections.asr.modules.conformer_encoder")
+    torch.manual_seed(31)
+    enc = m.ConformerEncoder(feat_in=40, n_layers=2, d_model=32, feat_out=-1, subsampling="dw_striding", subsampling_factor=8,
+                             subsampling_conv_channels=16, ff_expansion_factor=4, self_attention_model="rel_pos", n_heads=4,
+                             conv_kernel_size=9, dropout=0.0, dropout_pre_encoder=0.0, dropout_emb=0.0, dropout_att=0.0)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if "pos_bias" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    enc.train()
+    x = torch.randn(3, 40, 131, requires_grad=True)
+    length = torch.tensor([131, 90, 57])
+    y, yl = enc(audio_signal=x, length=length)
+    w = torch.randn_like(y)
+    valid = (torch.arange(y.shape[2]).unsqueeze(0) < yl.unsqueeze(1)).unsqueeze(1)
+    (y * w * valid).sum().backward()
+    out = {"x": x.detach().numpy(), "length": length.numpy(), "y": y.detach().numpy(), "y_len": yl.numpy(), "w": w.numpy(),
+           "dx": x.grad.numpy()}
+    for n, p in enc.state_dict().items():
+        out["P." + n] = p.detach().numpy()
+    for n, p in enc.named_parameters():
+        out["G." + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    np.savez_compressed(os.path.join(GOLD, "ref_fastconformer_tiny.npz"), **out)
+    print("fastconformer fixture:", tuple(y.shape), yl.tolist())
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     extract_ctc_known_answers()
@@ -370,3 +402,4 @@ if __name__ == "__main__":
     extract_rnnt_known_answers()
     make_squeezeformer_fixture()
     make_transducer_fixture()
+    make_fastconformer_fixture()

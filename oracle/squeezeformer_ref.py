@@ -50,7 +50,11 @@ def dw_striding_forward(P: Dict[str, Tensor], mel: Tensor, mel_len: Tensor, pfx=
         return (torch.arange(t.shape[2]).unsqueeze(0) < n.long().unsqueeze(1)).to(t.dtype).view(B, 1, -1, 1)
 
     C = P[pfx + "conv.0.weight"].shape[0]
-    stack = [("conv", "conv.0", 2, 1, 1), ("relu",), ("conv", "conv.2", 2, 1, C), ("conv", "conv.3", 1, 0, 1), ("relu",)]
+    stack = [("conv", "conv.0", 2, 1, 1), ("relu",)]
+    idx = 2
+    while f"{pfx}conv.{idx}.weight" in P:  # one (depthwise s2, pointwise, ReLU) group per further factor of 2 (x4: one, x8: two)
+        stack += [("conv", f"conv.{idx}", 2, 1, C), ("conv", f"conv.{idx + 1}", 1, 0, 1), ("relu",)]
+        idx += 3
     m = mask(x, cur)
     for layer in stack:
         x = x * m
