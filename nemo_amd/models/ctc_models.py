@@ -230,6 +230,46 @@ class EncDecCTCModel(nn.Module):
             self.train(was_training)
         return out
 
+    # ------------------------------------------------------------------ fine-tuning on another alphabet (ctc_models.py:190-262)
+    def change_vocabulary(self, new_vocabulary, decoding_cfg=None):
+        """replaces the decoder by a freshly initialised one over `new_vocabulary` (the encoder is kept), rebuilds the
+        loss (blank = len(new_vocabulary)) and the decoding / WER objects, and records the labels in the dataset configs;
+        optimizer state refers to the old decoder buffer, so `setup_optimization()` has to be called again"""
+        if self.decoder.vocabulary == new_vocabulary:
+            return
+        if new_vocabulary is None or len(new_vocabulary) == 0:
+            raise ValueError(f"New vocabulary must be non-empty list of chars. But I got: {new_vocabulary}")
+        dec = dict(self._cfg["decoder"])
+        dec.setdefault("_target_", _DEFAULT_TARGETS["decoder"])
+        dec["feat_in"] = self.decoder._feat_in
+        dec["vocabulary"] = list(new_vocabulary)
+        dec["num_classes"] = len(new_vocabulary)
+        device = next(self.decoder.parameters()).device
+        compute_dtype = getattr(self.decoder, "compute_dtype", None)
+        del self.decoder
+        self.decoder = _build("decoder", dec).to(device)
+        if compute_dtype is not None:
+            self.decoder.compute_dtype = compute_dtype
+        self.loss = CTCLoss(num_classes=self.decoder.num_classes_with_blank - 1, zero_infinity=True,
+                            reduction=self._cfg.get("ctc_reduction", "mean_batch"))
+        self._wer = None            # rebuilt lazily over the new vocabulary
+        self._optimizer = self._scheduler = self._syncs = None
+        self._cfg["decoder"] = dec
+        self._cfg["labels"] = list(new_vocabulary)
+        for key in ("train_ds", "validation_ds", "test_ds"):
+            if isinstance(self._cfg.get(key), dict):
+                self._cfg[key]["labels"] = list(new_vocabulary)
+
+    def setup_test_data(self, test_data_config: Dict[str, Any]):
+        test_data_config = dict(test_data_config)
+        test_data_config.setdefault("shuffle", False)
+        self._cfg["test_ds"] = {k: v for k, v in test_data_config.items() if k != "tokenizer" or isinstance(v, dict)}
+        self._test_dl = self._setup_dataloader_from_config(test_data_config)
+        return self._test_dl
+
+    def test_dataloader(self):
+        return getattr(self, "_test_dl", None)
+
     # ------------------------------------------------------------------ optimisation
     def flats(self):
         return [self.encoder.flat_parameters(), self.decoder.flat_parameters()]

@@ -276,3 +276,28 @@ def test_splitk_chooser_fills_rounds_of_the_cus():
     assert f(184, 16032) == 4 and f(32, 16032) == 8 and f(72, 320640) == 7
     assert f(160, 16032, strided_c=True) == 1      # column-strided outputs: a single round, no extra atomic passes
 
+
+
+def test_change_vocabulary_rebuilds_decoder_loss_and_decoding():
+    """EncDecCTCModel.change_vocabulary (ctc_models.py:190-262): new decoder over the new alphabet, blank = its length, the
+    encoder untouched, dataset configs updated; same vocabulary is a no-op; an empty one is a ValueError"""
+    from nemo_amd.models import EncDecCTCModel, conformer_ctc_config
+    cfg = conformer_ctc_config("small", vocab_size=5, d_model=32, n_heads=2, n_layers=1)
+    cfg["decoder"]["vocabulary"] = list("abcde")
+    cfg["train_ds"] = {"manifest_filepath": None, "labels": list("abcde")}
+    model = EncDecCTCModel(cfg)
+    enc_keys = {k: v.clone() for k, v in model.encoder.state_dict().items()}
+    old_dec = model.decoder
+    model.change_vocabulary(list("abcde"))
+    assert model.decoder is old_dec
+    with pytest.raises(ValueError):
+        model.change_vocabulary([])
+    new_vocab = [" ", "x", "y", "z", "q", "r", "s"]
+    model.change_vocabulary(new_vocab)
+    assert model.decoder is not old_dec and model.decoder.vocabulary == new_vocab
+    assert model.decoder.num_classes_with_blank == 8 and model.loss.blank == 7
+    assert tuple(model.decoder.state_dict()["decoder_layers.0.weight"].shape) == (8, 32, 1)
+    assert all(torch.equal(v, model.encoder.state_dict()[k]) for k, v in enc_keys.items())
+    assert model._cfg["decoder"]["num_classes"] == 7 and model._cfg["train_ds"]["labels"] == new_vocab
+    assert model.wer.decoding.blank_id == 7 and model.wer.decoding.vocabulary == new_vocab
+    assert model._optimizer is None
