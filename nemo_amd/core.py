@@ -119,6 +119,9 @@ TARGET_ALIASES = {
     "nemo.collections.asr.losses.ctc.CTCLoss": "nemo_amd.modules.CTCLoss",
     "nemo.collections.asr.losses.CTCLoss": "nemo_amd.modules.CTCLoss",
     "nemo.collections.asr.models.EncDecCTCModel": "nemo_amd.models.EncDecCTCModel",
+    "nemo.collections.asr.models.EncDecCTCModelBPE": "nemo_amd.models.EncDecCTCModelBPE",
+    "nemo.collections.asr.models.ctc_bpe_models.EncDecCTCModelBPE": "nemo_amd.models.EncDecCTCModelBPE",
+    "nemo.collections.asr.losses.rnnt.RNNTLoss": "nemo_amd.modules.RNNTLoss",
 }
 
 
@@ -176,10 +179,28 @@ MODEL_CONFIG_YAML = "model_config.yaml"
 MODEL_WEIGHTS = "model_weights.ckpt"
 
 
-def save_nemo(path: str, config: Dict[str, Any], state_dict: Dict[str, torch.Tensor]) -> None:
-    """save_restore_connector.py:49-91: tar (uncompressed) of model_config.yaml + model_weights.ckpt"""
+def save_nemo(path: str, config: Dict[str, Any], state_dict: Dict[str, torch.Tensor],
+              artifacts: Optional[Dict[str, str]] = None) -> None:
+    """save_restore_connector.py:49-91: tar (uncompressed) of model_config.yaml + model_weights.ckpt.  `artifacts` maps a
+    dotted config key (e.g. 'tokenizer.model_path') to a file: the file is packed as '<md5>_<basename>' and the config
+    entry becomes 'nemo:<that name>' -- `ModelPT.register_artifact` (modelPT.py:218-270, save_restore_connector.py:400-520)"""
+    import copy
+    import hashlib
+
     import yaml
 
+    config = copy.deepcopy(config)
+    packed = []
+    for key, src in (artifacts or {}).items():
+        with open(src, "rb") as f:
+            digest = hashlib.md5(f.read()).hexdigest()
+        arc = f"{digest}_{os.path.basename(src)}"
+        node = config
+        parts = key.split(".")
+        for k in parts[:-1]:
+            node = node[k]
+        node[parts[-1]] = "nemo:" + arc
+        packed.append((src, arc))
     with tempfile.TemporaryDirectory() as tmp:
         with open(os.path.join(tmp, MODEL_CONFIG_YAML), "w") as f:
             yaml.safe_dump(config, f)
@@ -187,14 +208,40 @@ def save_nemo(path: str, config: Dict[str, Any], state_dict: Dict[str, torch.Ten
         with tarfile.open(path, "w:") as tar:
             tar.add(os.path.join(tmp, MODEL_CONFIG_YAML), arcname=MODEL_CONFIG_YAML)
             tar.add(os.path.join(tmp, MODEL_WEIGHTS), arcname=MODEL_WEIGHTS)
+            for src, arc in packed:
+                tar.add(src, arcname=arc)
+
+
+_ARTIFACT_DIRS = []  # extracted artifacts live as long as the process (the tokenizer keeps its model file open lazily)
 
 
 def load_nemo(path: str):
-    """-> (config dict, state_dict); members are read by name (no path traversal: save_restore_connector.py:640)."""
+    """-> (config dict, state_dict); members are read by name (no path traversal: save_restore_connector.py:640).  Config
+    values of the form 'nemo:<member>' are extracted to a private directory and replaced by the extracted path."""
     import yaml
 
     with tarfile.open(path, "r:") as tar:
         names = {os.path.basename(m.name): m for m in tar.getmembers() if m.isfile()}
         cfg = yaml.safe_load(tar.extractfile(names[MODEL_CONFIG_YAML]).read())
         sd = torch.load(io.BytesIO(tar.extractfile(names[MODEL_WEIGHTS]).read()), map_location="cpu", weights_only=True)
+        out_dir = None
+
+        def resolve(node):
+            nonlocal out_dir
+            items = node.items() if isinstance(node, dict) else enumerate(node) if isinstance(node, list) else ()
+            for k, v in list(items):
+                if isinstance(v, (dict, list)):
+                    resolve(v)
+                elif isinstance(v, str) and v.startswith("nemo:"):
+                    member = os.path.basename(v[5:])
+                    if member not in names:
+                        raise FileNotFoundError(f"{path}: artifact '{member}' named by the config is not in the archive")
+                    if out_dir is None:
+                        out_dir = tempfile.mkdtemp(prefix="nemo_amd_artifacts_")
+                        _ARTIFACT_DIRS.append(out_dir)
+                    dst = os.path.join(out_dir, member)
+                    with open(dst, "wb") as f:
+                        f.write(tar.extractfile(names[member]).read())
+                    node[k] = dst
+        resolve(cfg)
     return cfg, sd

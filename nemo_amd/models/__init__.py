@@ -1,1 +1,1 @@
-from .ctc_models import EncDecCTCModel, conformer_ctc_config  # noqa: F401
+from .ctc_models import EncDecCTCModel, EncDecCTCModelBPE, conformer_ctc_config  # noqa: F401

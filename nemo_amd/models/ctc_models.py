@@ -443,8 +443,12 @@ class EncDecCTCModel(nn.Module):
         return losses
 
     # ------------------------------------------------------------------ .nemo (modelPT.py:395,436)
+    def _artifacts(self) -> Dict[str, str]:
+        return {}
+
     def save_to(self, save_path: str):
-        save_nemo(save_path, dict(self._cfg, target=f"{type(self).__module__}.{type(self).__name__}"), self.state_dict())
+        save_nemo(save_path, dict(self._cfg, target=f"{type(self).__module__}.{type(self).__name__}"), self.state_dict(),
+                  artifacts=self._artifacts())
 
     @classmethod
     def restore_from(cls, restore_path: str, map_location=None, strict: bool = True):
@@ -456,6 +460,60 @@ class EncDecCTCModel(nn.Module):
         model.load_state_dict(sd, strict=strict)
         model.encoder.weights_updated(); model.decoder.weights_updated()
         return model
+
+
+class EncDecCTCModelBPE(EncDecCTCModel):
+    """Drop-in for `nemo.collections.asr.models.EncDecCTCModelBPE` (ctc_bpe_models.py:39-110), the class the Conformer-CTC
+    BPE recipe instantiates (`examples/asr/asr_ctc/speech_to_text_ctc_bpe.py`): the `tokenizer` section ({dir, type: bpe} or
+    {model_path}) selects a SentencePiece model (`ASRBPEMixin._setup_tokenizer`, parts/mixins/mixins.py:60-190), whose
+    pieces in id order become the decoder vocabulary; a placeholder `num_classes` (< 1) is replaced by their number.
+    The tokenizer model travels inside the `.nemo` file as an artifact."""
+
+    def __init__(self, cfg: Dict[str, Any], trainer=None):
+        from ..data import SentencePieceTokenizer
+        cfg = copy.deepcopy(dict(cfg))
+        if "tokenizer" not in cfg:
+            raise ValueError("`cfg` must have `tokenizer` config to create a tokenizer !")
+        tok_cfg = dict(cfg["tokenizer"])
+        tok_type = str(tok_cfg.get("type", "bpe")).lower()
+        if tok_type not in ("bpe", "wpe"):
+            raise ValueError("`tokenizer.type` must be either `bpe` for SentencePiece tokenizer or `wpe` for BERT based "
+                             "tokenizer")
+        if tok_type == "wpe":
+            raise NotImplementedError("WordPiece (BERT) tokenizers: the Conformer-CTC recipes use SentencePiece `bpe`")
+        if tok_cfg.get("special_tokens") is not None:
+            raise ValueError("`special_tokens` are no longer supported for SentencePiece based tokenizers.")
+        model_path = tok_cfg.get("model_path") or os.path.join(tok_cfg["dir"], "tokenizer.model")
+        tokenizer = SentencePieceTokenizer(model_path)
+        vocabulary = tokenizer.vocab
+        dec = dict(cfg["decoder"])
+        dec["vocabulary"] = vocabulary
+        if dec.get("num_classes", -1) < 1:
+            dec["num_classes"] = len(vocabulary)
+        cfg["decoder"] = dec
+        cfg["tokenizer"] = dict(tok_cfg, model_path=model_path, type="bpe")
+        super().__init__(cfg, trainer=trainer)
+        self.tokenizer = tokenizer
+        self.tokenizer_type = "bpe"
+
+    def _artifacts(self):
+        return {"tokenizer.model_path": self._cfg["tokenizer"]["model_path"]}
+
+    def change_vocabulary(self, new_tokenizer_dir, new_tokenizer_type: str = "bpe", decoding_cfg=None):
+        """ctc_bpe_models.py:113-210: a new tokenizer directory instead of a list of labels"""
+        from ..data import SentencePieceTokenizer
+        if new_tokenizer_type.lower() != "bpe":
+            raise ValueError("New tokenizer type must be either `bpe` or `wpe`" if new_tokenizer_type.lower() != "wpe"
+                             else "WordPiece tokenizers are not provided")
+        model_path = new_tokenizer_dir if os.path.isfile(new_tokenizer_dir) else os.path.join(new_tokenizer_dir, "tokenizer.model")
+        if not os.path.isfile(model_path):
+            raise NotADirectoryError(f"New tokenizer dir must be non-empty path to a directory. But I got: {new_tokenizer_dir}")
+        tokenizer = SentencePieceTokenizer(model_path)
+        super().change_vocabulary(tokenizer.vocab)
+        self.tokenizer = tokenizer
+        self._wer = None
+        self._cfg["tokenizer"] = dict(self._cfg.get("tokenizer", {}), dir=os.path.dirname(model_path), model_path=model_path,
+                                      type="bpe")
 
 
 def conformer_ctc_config(size: str = "large", vocab_size: int = 128, spec_augment: bool = False,

@@ -301,3 +301,63 @@ def test_change_vocabulary_rebuilds_decoder_loss_and_decoding():
     assert model._cfg["decoder"]["num_classes"] == 7 and model._cfg["train_ds"]["labels"] == new_vocab
     assert model.wer.decoding.blank_id == 7 and model.wer.decoding.vocabulary == new_vocab
     assert model._optimizer is None
+
+
+def _train_spm(tmp_path, name, vocab_size, seed_words):
+    import sentencepiece as spm
+    corpus = tmp_path / f"{name}.txt"
+    rs = np.random.RandomState(len(seed_words))
+    with open(corpus, "w") as f:
+        for _ in range(400):
+            f.write(" ".join(rs.choice(seed_words, size=rs.randint(3, 9))) + "\n")
+    d = tmp_path / name
+    d.mkdir()
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(d / "tokenizer"), vocab_size=vocab_size,
+                                   model_type="bpe", character_coverage=1.0, bos_id=-1, eos_id=-1, minloglevel=2)
+    return str(d)
+
+
+def test_bpe_model_builds_from_a_tokenizer_dir_and_carries_it_in_the_nemo_file(tmp_path):
+    """EncDecCTCModelBPE (ctc_bpe_models.py:39-110): decoder vocabulary = the SentencePiece pieces in id order, placeholder
+    num_classes replaced, BPE dataset selected, tokenizer packed into / restored from the .nemo archive as an artifact
+    (modelPT.register_artifact), change_vocabulary with a new tokenizer directory"""
+    import tarfile
+    from nemo_amd.core import resolve_target
+    from nemo_amd.models import EncDecCTCModelBPE, conformer_ctc_config
+    words = ["speech", "recognition", "conformer", "attention", "the", "a", "of", "spectrogram", "frame", "token"]
+    tok_dir = _train_spm(tmp_path, "tok32", 32, words)
+    cfg = conformer_ctc_config("small", vocab_size=-1, d_model=32, n_heads=2, n_layers=1)
+    cfg["decoder"]["num_classes"] = -1
+    with pytest.raises(ValueError):
+        EncDecCTCModelBPE(cfg)
+    cfg["tokenizer"] = {"dir": tok_dir, "type": "bpe"}
+    assert resolve_target("nemo.collections.asr.models.EncDecCTCModelBPE") is EncDecCTCModelBPE
+    model = EncDecCTCModelBPE(cfg)
+    pieces = model.tokenizer.vocab
+    assert len(pieces) == 32 and model.decoder.vocabulary == pieces
+    assert model.decoder.num_classes_with_blank == 33 and model.loss.blank == 32
+    ids = model.tokenizer.text_to_ids("the conformer attention")
+    assert model.wer.decoding.ids_to_text(ids) == "the conformer attention"
+    # the BPE dataset is chosen and tokenises the transcripts
+    import json, wave
+    with wave.open(str(tmp_path / "u.wav"), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000); f.writeframes(np.zeros(1600, dtype=np.int16).tobytes())
+    with open(tmp_path / "m.json", "w") as f:
+        f.write(json.dumps(dict(audio_filepath="u.wav", duration=0.1, text="the frame of a token")) + "\n")
+    dl = model.setup_training_data(dict(manifest_filepath=str(tmp_path / "m.json"), batch_size=1, shuffle=False))
+    _, _, tok, tl = next(iter(dl))
+    assert tok[0, : int(tl[0])].tolist() == model.tokenizer.text_to_ids("the frame of a token")
+    # .nemo: three members, the tokenizer among them under a content-hash name; restore resolves it again
+    path = str(tmp_path / "bpe.nemo")
+    model.save_to(path)
+    with tarfile.open(path) as tar:
+        names = [m.name for m in tar.getmembers()]
+    assert len(names) == 3 and any(n.endswith("_tokenizer.model") for n in names)
+    m2 = EncDecCTCModelBPE.restore_from(path)
+    assert m2.tokenizer.vocab == pieces and m2._cfg["tokenizer"]["model_path"] != cfg["tokenizer"].get("model_path")
+    assert all(torch.equal(v, m2.state_dict()[k]) for k, v in model.state_dict().items())
+    # a new tokenizer: decoder / loss / decoding follow, the encoder stays
+    enc = {k: v.clone() for k, v in model.encoder.state_dict().items()}
+    model.change_vocabulary(_train_spm(tmp_path, "tok48", 48, words + ["transducer", "gradient"]))
+    assert model.decoder.num_classes_with_blank == 49 and model.loss.blank == 48 and len(model.tokenizer.vocab) == 48
+    assert all(torch.equal(v, model.encoder.state_dict()[k]) for k, v in enc.items())
