@@ -205,12 +205,28 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
     for (int j = 0; j < 8; ++j) b8[j] = 0.f;
   }
   const uint32_t dbase = (uint32_t)z * (uint32_t)(p.M * p.N) + (uint32_t)n;
+#ifdef MI355X_EXP_EPI_INCR
+  // EXPERIMENT (off by default, not yet measured; DESIGN.md worklist item 3): without a row map the rows of one thread are
+  // ROW_STEP apart, so every address is (per-thread base, computed once) + it * (uniform stride, scalar unit) instead of a
+  // 64-bit multiply-add per row and tensor (v_mad_u64_u32 + 2 x v_mul_lo_u32, quarter rate)
+  // (the row map is only ever combined with EPI_MUL_POS -- the four conv2 input-gradient GEMMs; for every other epilogue
+  // kind `lin` is a compile-time constant and the mapped path is not emitted at all)
+  const bool lin = (EPI != EPI_MUL_POS) || !p.r_on;
+  const long long ci_l = coff + (long long)m_first * p.ldc + n, ai_l = coff + (long long)m_first * p.ldaux + n;
+  const long long ci_s = (long long)ROW_STEP * p.ldc, ai_s = (long long)ROW_STEP * p.ldaux;
+  const uint32_t db_l = dbase + (uint32_t)m_first * (uint32_t)p.N, db_s = (uint32_t)ROW_STEP * (uint32_t)p.N;
+#endif
   float aux[AUX_IN ? ITERS : 1][8];
   if (AUX_IN) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int m = m_first + it * ROW_STEP;
+#ifdef MI355X_EXP_EPI_INCR
+      const long long ai0 = lin ? ai_l + it * ai_s : coff + crow(p, m) * p.ldaux + n;
+      if (m < p.M) ld8x(p.aux_in, ai0, EPI == EPI_RESID ? MI_DT_F32 : p.auxin_dt, aux[it]);
+#else
       if (m < p.M) ld8x(p.aux_in, coff + crow(p, m) * p.ldaux + n, EPI == EPI_RESID ? MI_DT_F32 : p.auxin_dt, aux[it]);
+#endif
     }
   }
 #pragma unroll
@@ -222,10 +238,16 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
     const float4 b = *reinterpret_cast<const float4*>(src + 4);
     float v[8] = {a.x + b8[0], a.y + b8[1], a.z + b8[2], a.w + b8[3], b.x + b8[4], b.y + b8[5], b.z + b8[6], b.w + b8[7]};
     float dm[8];
+#ifdef MI355X_EXP_EPI_INCR
+    drop_mask8(p.drop, db_l + (uint32_t)it * db_s, dm);
+    const long long ci = lin ? ci_l + it * ci_s : coff + crow(p, m) * p.ldc + n;
+    const long long ai = lin ? ai_l + it * ai_s : coff + crow(p, m) * p.ldaux + n;
+#else
     drop_mask8(p.drop, dbase + (uint32_t)m * (uint32_t)p.N, dm);
     const long long mr = crow(p, m);
     const long long ci = coff + mr * p.ldc + n;
     const long long ai = coff + mr * p.ldaux + n;
+#endif
     if (EPI == EPI_STORE) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= p.alpha * dm[j];
@@ -1108,6 +1130,32 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
     if (it + 1 < nk) issue(it + 1);  // other stage: every wave passed the barrier after its last read of it
     const bf16_t* a_s = smem4 + (it & 1) * NT4_STAGE;
     const bf16_t* b_s = a_s + BM2 * BK;
+#ifdef MI355X_EXP_V4_PIPE
+    // EXPERIMENT (off by default, not yet measured; DESIGN.md worklist item 2): the compiler's own schedule of the loop
+    // below issues the fragment reads 2-3 at a time right in front of the MFMAs that consume them.  Here the six reads
+    // of k-step kk+1 go out as one burst under the eight MFMAs of k-step kk (two fragment sets, +24 registers).
+    {
+      bf16x8 af[2][4], bfr[2][2];
+      auto rd = [&](const int kk, const int s_) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[s_][j] = frag_v2<TB, BN4>(b_s, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[s_][i] = frag_v2<TA, BM2>(a_s, wm * 128 + i * 32, kk, lane);
+      };
+      rd(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) rd(kk + 1, (kk + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#else
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 af[4], bfr[2];
@@ -1121,6 +1169,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
+#endif
     if (TA && do_colsum) {  // thread -> (k-group of 8 rows = wave, 4 consecutive columns = lane)
       const int col = lane * 4;
       for (int kr = tile_n; kr < 8; kr += cs_step) {
