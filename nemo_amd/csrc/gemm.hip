@@ -696,12 +696,20 @@ __device__ __forceinline__ bf16x8 frag_v2(const bf16_t* tile, int row_tile, int 
 
 // body of the 256x128 structure: workgroup `bid` of the problem's tile grid, K slice `kslice`, batch index `z`
 template <bool TA, bool TB>
-__device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, const int bid, const int kslice, const int z) {
+__device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, const int bid, const int kslice, const int z
+#ifdef MI355X_EXP_GROUPED_XCD
+                                             , const bool direct = false
+#endif
+) {
   const int tn = (p.N + BN - 1) / BN, tm = (p.M + BM2 - 1) / BM2;
   const int ntiles = tm * tn;
   const int q8 = ntiles >> 3, r8 = ntiles & 7;
   const int xcd = bid & 7, idx = bid >> 3;
+#ifdef MI355X_EXP_GROUPED_XCD
+  const int logical = direct ? bid : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+#else
   const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+#endif
   const int tile_m = logical / tn, tile_n = logical - tile_m * tn;
   const int m0 = tile_m * BM2, n0 = tile_n * BN;
   const int z0 = z % p.nb0, z1 = z / p.nb0;
@@ -995,7 +1003,23 @@ struct GroupP {
 __global__ __launch_bounds__(512) void gemm_bf16_grouped_tn_kernel(GroupP g) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem2[];
   int pi = 0;
+#ifdef MI355X_EXP_GROUPED_XCD
+  // EXPERIMENT (off by default, not yet measured; DESIGN.md worklist item 7): the launch reads 1.36 GB for ~0.5 GB of unique
+  // operands because the tiles of one (problem, K slice) -- which share both operand panels -- are dealt round-robin over
+  // the 8 XCDs (8 private L2s).  Here the (problem, K slice) groups are laid out one after the other and every XCD takes a
+  // contiguous eighth of that sequence: the tiles running together on an XCD belong to the same group.
+  const int tiles_total = g.tile_begin[g.n];
+  const int W = tiles_total * g.splitk;
+  const int L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;  // dispatch order: XCD = L % 8
+  const int q8w = W >> 3, r8w = W & 7, xw = L & 7;                   // bijection L -> w for any W (XCD x owns q8w or q8w+1 items)
+  const int w = (xw < r8w ? xw * (q8w + 1) : r8w * (q8w + 1) + (xw - r8w) * q8w) + (L >> 3);
+  while (pi + 1 < g.n && w >= g.splitk * g.tile_begin[pi + 1]) ++pi;  // uniform
+  const int ntile_p = g.tile_begin[pi + 1] - g.tile_begin[pi];
+  const int rel = w - g.splitk * g.tile_begin[pi];
+  const int exp_ks = rel / ntile_p, exp_tile = rel - exp_ks * ntile_p;
+#else
   while (pi + 1 < g.n && (int)blockIdx.x >= g.tile_begin[pi + 1]) ++pi;  // uniform
+#endif
   GemmP p;
   p.A = g.A[pi]; p.B = g.B[pi]; p.C = g.C[pi];
   p.M = g.M[pi]; p.N = g.N[pi]; p.K = g.K;
@@ -1009,7 +1033,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_grouped_tn_kernel(GroupP g) {
   p.splitk = g.splitk; p.ktiles_per_split = g.ktiles_per_split;
   p.colsum_stride = 0; p.colsum_out = g.colsum[pi];
   p.vec_ok = 0; p.g_on = 0; p.r_on = 0;
+#ifdef MI355X_EXP_GROUPED_XCD
+  gemm_v2_body<true, true>(p, smem2, exp_tile, exp_ks, 0, /*direct=*/true);
+#else
   gemm_v2_body<true, true>(p, smem2, (int)blockIdx.x - g.tile_begin[pi], blockIdx.y, 0);
+#endif
 }
 
 // =================================================================================================
