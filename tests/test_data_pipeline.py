@@ -208,3 +208,37 @@ def test_device_batch_loader_passes_batches_through_on_cpu_and_surfaces_errors()
     for k, _ in enumerate(DeviceBatchLoader(batches, "cpu", prefetch=1)):
         if k == 1:
             break
+
+
+def test_semi_sorted_sampler_invariants_for_arbitrary_sizes():
+    """property test over corpus size / world size / batch size / drop_last: every rank takes the same number of steps (the
+    all-reduce would dead-lock otherwise), only valid indices appear, nothing is lost beyond the dropped tail, and repeats
+    are bounded by the padding batches"""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=120, deadline=None)
+    @given(n=st.integers(1, 300), world=st.sampled_from([1, 2, 3, 4, 8]), bs=st.integers(1, 16), drop_last=st.booleans(),
+           seed=st.integers(0, 10_000))
+    def check(n, world, bs, drop_last, seed):
+        rs = np.random.RandomState(seed)
+        durations = rs.uniform(0.5, 30.0, size=n)
+        per_rank = []
+        for r in range(world):
+            sm = SemiSortBatchSampler(r, world, durations, bs, batch_shuffle=True, drop_last=drop_last, seed=seed,
+                                      synced_rng=True)
+            batches = list(sm)
+            assert len(batches) == len(sm)
+            per_rank.append(batches)
+        assert len({len(b) for b in per_rank}) == 1
+        flat = [i for b in per_rank for x in b for i in x]
+        assert all(0 <= i < n for i in flat)
+        kept = n - (n % bs if drop_last else 0)
+        if kept == 0:
+            assert flat == []
+            return
+        assert len(set(flat)) >= kept - 0 if not drop_last else len(set(flat)) <= n
+        if not drop_last:
+            assert set(flat) == set(range(n))
+        assert len(flat) - len(set(flat)) <= world * bs  # repeats come from the padding batches only
+        assert all(len(x) <= bs for b in per_rank for x in b)
+    check()
