@@ -194,6 +194,13 @@ class ConformerEncoder(NeuralModule):
         self.compute_dtype = compute_dtype  # None: bf16 under torch autocast(bf16), else fp32
         # SyncBatchNorm semantics across data-parallel ranks (trainer.sync_batchnorm: true in the recipe)
         self.sync_batchnorm = True
+        # The element count of the synchronised statistics is world x (this rank's B*T') -- exact when every rank holds the
+        # same padded length (the benchmark; batches padded to a common length).  With ragged ranks (SemiSortBatchSampler:
+        # the k-th batches differ by a few frames) set this (or MI355X_SYNCBN_EXACT_COUNTS=1): the counts are then summed
+        # over the ranks on the host through a gloo side group, once per forward (torch.nn.SyncBatchNorm gathers them too).
+        self.syncbn_exact_counts = os.environ.get("MI355X_SYNCBN_EXACT_COUNTS", "0") == "1"
+        self._bn_count_global = None
+        self._host_sum = None
         self.use_flash_attention = True  # bf16 + d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
         self.grad_ready_hook = None  # callable(start, end) on the flat gradient buffer (data-parallel bucketing)
         # --- engine state (not part of the state-dict)
@@ -435,6 +442,12 @@ class ConformerEncoder(NeuralModule):
         T1, F1 = (T - 1) // 2 + 1, (F_ - 1) // 2 + 1
         T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
         M = B * T2
+        self._bn_count_global = None
+        if training and self.sync_batchnorm and self.syncbn_exact_counts:
+            if self._host_sum is None:
+                from ..parallel import HostSum
+                self._host_sum = HostSum()
+            self._bn_count_global = self._host_sum(float(M))
         len0, len1, len2 = self._lens(length)
         self.update_max_seq_length(T2, dev)
         if training:
@@ -640,7 +653,7 @@ class ConformerEncoder(NeuralModule):
             ws = torch.distributed.get_world_size()
             if ws > 1:
                 torch.distributed.all_reduce(stats)
-                return count * ws
+                return self._bn_count_global if self._bn_count_global is not None else count * ws
         return count
 
     # ------------------------------------------------------------------ backward implementation

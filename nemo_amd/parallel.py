@@ -93,3 +93,22 @@ class GradSync:
 
     def reduced_ranges(self):
         return list(self._reduced)
+
+
+class HostSum:
+    """Sum of one host-side number over the data-parallel ranks without touching the GPU: a lazily created `gloo` group next
+    to the RCCL one (CPU tensors cannot travel over RCCL).  Used for the SyncBatchNorm element count when ranks hold
+    different padded lengths: the count is a launch ARGUMENT of the BatchNorm kernels, so it has to be known on the host,
+    and a device all-reduce + `.item()` would drain the launch queue every step."""
+
+    def __init__(self):
+        self._group = None
+
+    def __call__(self, value: float) -> float:
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return float(value)
+        if self._group is None:
+            self._group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        dist.all_reduce(t, group=self._group)
+        return float(t[0])

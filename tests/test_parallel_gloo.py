@@ -174,6 +174,29 @@ def test_training_data_is_partitioned_across_ranks_world2_gloo(tmp_path):
     assert dict(ret) == {0: True, 1: True}
 
 
+def _worker_hostsum(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nemo_amd.parallel import HostSum
+        hs = HostSum()
+        ret[rank] = [hs(100.0 + rank), hs(7.0 * (rank + 1))]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_host_sum_of_ragged_syncbn_counts_world2_gloo():
+    """the SyncBatchNorm element count with ragged ranks: per-rank B*T' summed on the host (no GPU round trip)"""
+    from nemo_amd.parallel import HostSum
+    assert HostSum()(5.0) == 5.0  # no process group: identity
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_hostsum, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: [201.0, 21.0], 1: [201.0, 21.0]}
+
+
 def test_grad_sync_is_a_noop_for_world1():
     from nemo_amd.parallel import GradSync
     g = torch.ones(128)
