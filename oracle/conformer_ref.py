@@ -50,6 +50,11 @@ class ConformerCfg:
     dropout_pre_encoder: float = 0.1
     dropout_att: float = 0.1
     xscaling: bool = True
+    # bf16 emulation: round (in fp32 arithmetic) at the points where the MI355X bf16 path keeps bf16 in HBM -- GEMM operand
+    # images of the weights, LayerNorm outputs, every saved activation between kernels -- and round the gradient flowing back
+    # through the same points.  Accumulation stays fp32 (as in the MFMA).  Lets a test separate "bf16 storage rounding" from
+    # "kernel error": tests/test_baseline_configs_gpu.py
+    emulate_bf16: bool = False
 
     @property
     def channels(self):
@@ -189,6 +194,39 @@ def rel_pos_table(T: int, d: int) -> Tensor:
     return pe
 
 
+class _RoundBF16(torch.autograd.Function):
+    """y = bf16(x) in value, and the gradient is rounded the same way on the way back (the HIP path stores both the
+    activation and its gradient as bf16 at these points)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundBF16Fwd(torch.autograd.Function):
+    """bf16 operand image of an fp32 master weight: rounded in the forward, gradient passed through in fp32"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _q(x: Tensor, cfg) -> Tensor:
+    return _RoundBF16.apply(x) if getattr(cfg, "emulate_bf16", False) else x
+
+
+def _qw(w: Tensor, cfg) -> Tensor:
+    return _RoundBF16Fwd.apply(w) if getattr(cfg, "emulate_bf16", False) else w
+
+
 def _drop(x: Tensor, p: float, train: bool) -> Tensor:
     return F.dropout(x, p, training=True) if (train and p > 0) else x
 
@@ -203,15 +241,15 @@ def subsampling_forward(P: Dict[str, Tensor], cfg: ConformerCfg, mel: Tensor, me
 
     l0 = mel_len.to(torch.int64)
     x = x * tmask(l0, T)
-    x = F.conv2d(x, P[pfx + "conv.0.weight"], P[pfx + "conv.0.bias"], stride=2, padding=1)
+    x = F.conv2d(x, P[pfx + "conv.0.weight"], P[pfx + "conv.0.bias"], stride=2, padding=1)  # (conv1 reads fp32 weights)
     l1 = conv_out_len(l0, 1)
-    x = torch.relu(x * tmask(l1, x.shape[2])) * tmask(l1, x.shape[2])
-    x = F.conv2d(x, P[pfx + "conv.2.weight"], P[pfx + "conv.2.bias"], stride=2, padding=1)
+    x = _q(torch.relu(x * tmask(l1, x.shape[2])) * tmask(l1, x.shape[2]), cfg)
+    x = F.conv2d(x, _qw(P[pfx + "conv.2.weight"], cfg), P[pfx + "conv.2.bias"], stride=2, padding=1)
     l2 = conv_out_len(l1, 1)
-    x = torch.relu(x * tmask(l2, x.shape[2])) * tmask(l2, x.shape[2])
+    x = _q(torch.relu(x * tmask(l2, x.shape[2])) * tmask(l2, x.shape[2]), cfg)
     b, c, t, f = x.shape
     x = x.transpose(1, 2).reshape(b, t, c * f)
-    x = F.linear(x, P[pfx + "out.weight"], P[pfx + "out.bias"])
+    x = F.linear(x, _qw(P[pfx + "out.weight"], cfg), P[pfx + "out.bias"])
     return x, l2
 
 
@@ -219,12 +257,12 @@ def rel_pos_attention(P, pfx, cfg: ConformerCfg, x: Tensor, pos_emb: Tensor, val
     """x [B,T,d] (already layer-normed); valid [B,T] bool.  score[b,h,i,j] = ((q_i+u)k_j + (q_i+v)p_{T-1+j-i})/sqrt(dk)."""
     B, T, d = x.shape
     H, dk = cfg.n_heads, cfg.d_k
-    q = F.linear(x, P[pfx + "linear_q.weight"], P[pfx + "linear_q.bias"]).view(B, T, H, dk)
-    k = F.linear(x, P[pfx + "linear_k.weight"], P[pfx + "linear_k.bias"]).view(B, T, H, dk).transpose(1, 2)
-    v = F.linear(x, P[pfx + "linear_v.weight"], P[pfx + "linear_v.bias"]).view(B, T, H, dk).transpose(1, 2)
-    p = F.linear(pos_emb, P[pfx + "linear_pos.weight"]).view(2 * T - 1, H, dk).transpose(0, 1)  # [H,2T-1,dk]
-    qu = (q + P[pfx + "pos_bias_u"]).transpose(1, 2)  # [B,H,T,dk]
-    qv = (q + P[pfx + "pos_bias_v"]).transpose(1, 2)
+    q = _q(F.linear(x, _qw(P[pfx + "linear_q.weight"], cfg), P[pfx + "linear_q.bias"]), cfg).view(B, T, H, dk)
+    k = _q(F.linear(x, _qw(P[pfx + "linear_k.weight"], cfg), P[pfx + "linear_k.bias"]), cfg).view(B, T, H, dk).transpose(1, 2)
+    v = _q(F.linear(x, _qw(P[pfx + "linear_v.weight"], cfg), P[pfx + "linear_v.bias"]), cfg).view(B, T, H, dk).transpose(1, 2)
+    p = _q(F.linear(_q(pos_emb, cfg), _qw(P[pfx + "linear_pos.weight"], cfg)), cfg).view(2 * T - 1, H, dk).transpose(0, 1)  # [H,2T-1,dk]
+    qu = _q(q + P[pfx + "pos_bias_u"], cfg).transpose(1, 2)  # [B,H,T,dk]
+    qv = _q(q + P[pfx + "pos_bias_v"], cfg).transpose(1, 2)
     ac = torch.matmul(qu, k.transpose(-2, -1))  # [B,H,T,T]
     bd_full = torch.matmul(qv, p.transpose(-2, -1).unsqueeze(0))  # [B,H,T,2T-1]
     # explicit index map instead of the pad/view trick: bd[i,j] = bd_full[i, T-1+j-i]
@@ -236,21 +274,22 @@ def rel_pos_attention(P, pfx, cfg: ConformerCfg, x: Tensor, pos_emb: Tensor, val
     masked = masked.unsqueeze(1)
     scores = scores.masked_fill(masked, -INF_VAL)
     attn = torch.softmax(scores, dim=-1).masked_fill(masked, 0.0)
-    attn = _drop(attn, cfg.dropout_att, train)
-    ctx = torch.matmul(attn, v).transpose(1, 2).reshape(B, T, d)
-    return F.linear(ctx, P[pfx + "linear_out.weight"], P[pfx + "linear_out.bias"])
+    attn = _q(_drop(attn, cfg.dropout_att, train), cfg)  # the probabilities are an MFMA operand
+    ctx = _q(torch.matmul(attn, v).transpose(1, 2).reshape(B, T, d), cfg)
+    return F.linear(ctx, _qw(P[pfx + "linear_out.weight"], cfg), P[pfx + "linear_out.bias"])
 
 
 def conv_module(P, pfx, cfg: ConformerCfg, x: Tensor, valid: Tensor, bn_training: bool,
                 bn_stats_out: Optional[dict] = None):
     """x [B,T,d] -> [B,T,d] (conformer_modules.py:320-350).  BN statistics over all B*T positions."""
     d = cfg.d_model
-    h = F.linear(x, P[pfx + "pointwise_conv1.weight"].squeeze(-1), P[pfx + "pointwise_conv1.bias"])  # [B,T,2d]
+    h = _q(F.linear(x, _qw(P[pfx + "pointwise_conv1.weight"], cfg).squeeze(-1), P[pfx + "pointwise_conv1.bias"]), cfg)  # [B,T,2d]
     g = h[..., :d] * torch.sigmoid(h[..., d:])
-    g = g * valid.unsqueeze(-1).to(g.dtype)
+    g = _q(g * valid.unsqueeze(-1).to(g.dtype), cfg)
     pad = (cfg.conv_kernel - 1) // 2
     c = F.conv1d(F.pad(g.transpose(1, 2), (pad, pad)), P[pfx + "depthwise_conv.weight"],
                  P[pfx + "depthwise_conv.bias"], groups=d)  # [B,d,T]
+    cq = _q(c, cfg)  # batch statistics come from the fp32 accumulators, the stored tensor is bf16
     if bn_training:
         mean = c.mean(dim=(0, 2))
         var = c.var(dim=(0, 2), unbiased=False)
@@ -259,16 +298,16 @@ def conv_module(P, pfx, cfg: ConformerCfg, x: Tensor, valid: Tensor, bn_training
             bn_stats_out[pfx] = (mean.detach(), (var * n / max(n - 1, 1)).detach())
     else:
         mean, var = P[pfx + "batch_norm.running_mean"], P[pfx + "batch_norm.running_var"]
-    c = (c - mean.view(1, d, 1)) * torch.rsqrt(var.view(1, d, 1) + 1e-5)
+    c = (cq - mean.view(1, d, 1)) * torch.rsqrt(var.view(1, d, 1) + 1e-5)
     c = c * P[pfx + "batch_norm.weight"].view(1, d, 1) + P[pfx + "batch_norm.bias"].view(1, d, 1)
-    c = c * torch.sigmoid(c)
-    return F.linear(c.transpose(1, 2), P[pfx + "pointwise_conv2.weight"].squeeze(-1), P[pfx + "pointwise_conv2.bias"])
+    c = _q(c * torch.sigmoid(c), cfg)
+    return F.linear(c.transpose(1, 2), _qw(P[pfx + "pointwise_conv2.weight"], cfg).squeeze(-1), P[pfx + "pointwise_conv2.bias"])
 
 
 def feed_forward(P, pfx, cfg, x, train):
-    h = F.linear(x, P[pfx + "linear1.weight"], P[pfx + "linear1.bias"])
-    h = _drop(h * torch.sigmoid(h), cfg.dropout, train)
-    return F.linear(h, P[pfx + "linear2.weight"], P[pfx + "linear2.bias"])
+    h = F.linear(x, _qw(P[pfx + "linear1.weight"], cfg), P[pfx + "linear1.bias"])
+    h = _q(_drop(h * torch.sigmoid(h), cfg.dropout, train), cfg)  # Swish on the fp32 accumulator, stored as bf16
+    return F.linear(h, _qw(P[pfx + "linear2.weight"], cfg), P[pfx + "linear2.bias"])
 
 
 def _ln(P, pfx, x):
@@ -276,10 +315,10 @@ def _ln(P, pfx, x):
 
 
 def conformer_layer(P, pfx, cfg: ConformerCfg, x, pos_emb, valid, train, bn_training, bn_stats_out=None):
-    r = x + 0.5 * _drop(feed_forward(P, pfx + "feed_forward1.", cfg, _ln(P, pfx + "norm_feed_forward1.", x), train), cfg.dropout, train)
-    r = r + _drop(rel_pos_attention(P, pfx + "self_attn.", cfg, _ln(P, pfx + "norm_self_att.", r), pos_emb, valid, train), cfg.dropout, train)
-    r = r + _drop(conv_module(P, pfx + "conv.", cfg, _ln(P, pfx + "norm_conv.", r), valid, bn_training, bn_stats_out), cfg.dropout, train)
-    r = r + 0.5 * _drop(feed_forward(P, pfx + "feed_forward2.", cfg, _ln(P, pfx + "norm_feed_forward2.", r), train), cfg.dropout, train)
+    r = x + 0.5 * _drop(feed_forward(P, pfx + "feed_forward1.", cfg, _q(_ln(P, pfx + "norm_feed_forward1.", x), cfg), train), cfg.dropout, train)
+    r = r + _drop(rel_pos_attention(P, pfx + "self_attn.", cfg, _q(_ln(P, pfx + "norm_self_att.", r), cfg), pos_emb, valid, train), cfg.dropout, train)
+    r = r + _drop(conv_module(P, pfx + "conv.", cfg, _q(_ln(P, pfx + "norm_conv.", r), cfg), valid, bn_training, bn_stats_out), cfg.dropout, train)
+    r = r + 0.5 * _drop(feed_forward(P, pfx + "feed_forward2.", cfg, _q(_ln(P, pfx + "norm_feed_forward2.", r), cfg), train), cfg.dropout, train)
     return _ln(P, pfx + "norm_out.", r)
 
 
@@ -292,16 +331,16 @@ def encoder_forward(P, cfg: ConformerCfg, mel, mel_len, train=False, bn_training
     if cfg.xscaling:
         x = x * math.sqrt(d)
     x = _drop(x, cfg.dropout_pre_encoder, train)
-    pos_emb = rel_pos_table(T, d)
+    pos_emb = rel_pos_table(T, d).to(x.dtype)  # (float64 when the oracle is run in double to bound fp32 noise)
     valid = torch.arange(T).unsqueeze(0) < enc_len.unsqueeze(1)
     for i in range(cfg.n_layers if n_layers is None else n_layers):
         x = conformer_layer(P, f"{pfx}layers.{i}.", cfg, x, pos_emb, valid, train, bn_training, bn_stats_out)
     return x.transpose(1, 2), enc_len
 
 
-def decoder_forward(P, enc, pfx="decoder_layers.0."):
+def decoder_forward(P, enc, pfx="decoder_layers.0.", cfg=None):
     """enc [B,d,T'] -> log-probs [B,T',V+1] (conv_asr.py:445-468)."""
-    logits = F.linear(enc.transpose(1, 2), P[pfx + "weight"].squeeze(-1), P[pfx + "bias"])
+    logits = F.linear(_q(enc.transpose(1, 2), cfg), _qw(P[pfx + "weight"], cfg).squeeze(-1), P[pfx + "bias"])
     return torch.log_softmax(logits, dim=-1)
 
 
@@ -323,7 +362,7 @@ def model_forward(P, cfg: ConformerCfg, audio, audio_len, tokens, token_len, tra
                                         noise=noise, dither=dither)
     enc, enc_len = encoder_forward(P, cfg, mel, mel_len, train=train, bn_training=bn_training, pfx="encoder.",
                                    bn_stats_out=bn_stats_out)
-    logp = decoder_forward(P, enc, "decoder.decoder_layers.0.")
+    logp = decoder_forward(P, enc, "decoder.decoder_layers.0.", cfg)
     loss, per_utt = ctc_loss_mean_batch(logp, tokens, enc_len, token_len, cfg.vocab)
     return dict(loss=loss, per_utt=per_utt, logp=logp, enc=enc, enc_len=enc_len, mel=mel, mel_len=mel_len)
 
@@ -399,3 +438,13 @@ def synthetic_batch(B: int, secs: float, vocab: int = 128, seed: int = 1234, len
     tokens = torch.randint(0, vocab, (B, U), generator=g)
     token_len = torch.full((B,), U, dtype=torch.int64)
     return audio, audio_len, tokens, token_len
+
+
+def grad_digest(name: str, g) -> np.ndarray:
+    """compact fingerprint of one gradient tensor for fixtures of configurations whose gradients are too large to commit
+    (Small: 13 M values): float64 (L2 norm, max |.|, projection on a fixed pseudo-random +-1 vector seeded by the name)"""
+    import zlib
+    g = np.asarray(g, dtype=np.float64).ravel()
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    sign = rs.randint(0, 2, size=g.size).astype(np.float64) * 2.0 - 1.0
+    return np.array([np.sqrt((g * g).sum()), np.abs(g).max() if g.size else 0.0, (g * sign).sum()])

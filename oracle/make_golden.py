@@ -393,8 +393,66 @@ def make_fastconformer_fixture():
     print("fastconformer fixture:", tuple(y.shape), yl.tolist())
 
 
+from oracle.conformer_ref import grad_digest  # noqa: E402  (3-number fingerprint of a gradient tensor)
+
+
+CFG1_FULL_GRADS = ("decoder.decoder_layers.0.weight", "decoder.decoder_layers.0.bias", "encoder.pre_encode.conv.0.weight",
+                   "encoder.layers.0.self_attn.pos_bias_u", "encoder.layers.0.self_attn.pos_bias_v",
+                   "encoder.layers.0.conv.depthwise_conv.weight", "encoder.layers.0.norm_out.weight",
+                   "encoder.layers.7.self_attn.linear_pos.weight", "encoder.layers.15.conv.depthwise_conv.weight",
+                   "encoder.layers.15.self_attn.pos_bias_u", "encoder.layers.15.conv.batch_norm.weight",
+                   "encoder.layers.15.feed_forward2.linear2.bias")
+
+
+def make_cfg1_fixture():
+    """BASELINE.json configs[0] itself (cfg 1): Conformer-CTC-Small (d=176, H=4 -> d_k=44, L=16, k=31),
+    B = 2 x 10 s synthetic clips (seed 1234), vocab 128, fp32, dropout 0 / dither 0, batch-statistics BatchNorm -- run through
+    the reference's own FilterbankFeatures + ConformerEncoder files on CPU -> tests/golden/ref_cfg1_small.npz.
+    Weights are NOT stored (13 M values): they are oracle.conformer_ref.init_params(ConformerCfg.small(), seed=0), a pure
+    function of torch's CPU generator; a checksum of them is stored so a generator change cannot pass silently.
+    Stored: loss, per-utterance nll, lengths, log-probs [2,251,129], every 7th mel frame + per-row mel sums, a 3-number
+    digest of EVERY gradient tensor and a dozen gradient tensors in full."""
+    from oracle.ref_shim import ReferenceCTCModel
+    from oracle import conformer_ref as R
+    cfg = R.ConformerCfg.small(vocab=128, dropout=0.0, dropout_att=0.0, dropout_pre_encoder=0.0)
+    P = R.init_params(cfg, seed=0)
+    m = ReferenceCTCModel(d_model=176, n_heads=4, n_layers=16, vocab=128)
+    sd = {k[len("encoder."):]: v for k, v in P.items() if k.startswith("encoder.")}
+    missing, unexpected = m.encoder.load_state_dict(sd, strict=False)
+    assert not unexpected and all("pos_enc" in k for k in missing), (missing, unexpected)
+    m.decoder_layers.load_state_dict({k[len("decoder.decoder_layers."):]: v for k, v in P.items() if k.startswith("decoder.")})
+    m.train()          # dropout is 0 everywhere: train mode selects batch statistics in BatchNorm
+    m.featurizer.eval()  # no dither
+    audio, alen, tok, tl = R.synthetic_batch(2, 10.0, vocab=128, seed=1234)
+    loss, logp, enc, enc_len, mel, mel_len = m(audio, alen, tok, tl)
+    per = m.ctc(logp.transpose(1, 0), tok.long(), enc_len.long(), tl.long())
+    m.zero_grad()
+    loss.backward()
+    fix = {"loss": np.array(loss.item(), dtype=np.float64), "per_utt": per.detach().numpy().astype(np.float64),
+           "enc_len": enc_len.numpy(), "mel_len": mel_len.numpy(), "logp": logp.detach().numpy(),
+           "mel_every7": mel.numpy()[:, :, ::7].copy(), "mel_rowsum": mel.numpy().astype(np.float64).sum(2),
+           "mel_rowsumsq": (mel.numpy().astype(np.float64) ** 2).sum(2),
+           "enc_every5": enc.detach().numpy()[:, :, ::5].copy(),
+           "param_checksum": np.array([sum(float(v.double().sum()) for k, v in sorted(P.items()) if v.is_floating_point()),
+                                       sum(float(v.double().abs().sum()) for k, v in sorted(P.items()) if v.is_floating_point())])}
+    grads = {"encoder." + n: p.grad for n, p in m.encoder.named_parameters()}
+    grads.update({"decoder.decoder_layers." + n: p.grad for n, p in m.decoder_layers.named_parameters()})
+    names = sorted(grads)
+    assert set(names) == set(R.trainable_keys(P)), set(names) ^ set(R.trainable_keys(P))
+    fix["grad_names"] = np.array(names)
+    fix["grad_digest"] = np.stack([grad_digest(n, grads[n].numpy()) for n in names])
+    for n in CFG1_FULL_GRADS:
+        fix["grad/" + n] = grads[n].numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "ref_cfg1_small.npz"), **fix)
+    print("cfg1 (Small, B=2x10s) fixture: loss", loss.item(), "mel", tuple(mel.shape), "logp", tuple(logp.shape),
+          "grad tensors", len(names))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg1":
+        make_cfg1_fixture()
+        sys.exit(0)
     extract_ctc_known_answers()
     make_reference_fixtures()
     make_specaug_fixture()
@@ -403,3 +461,4 @@ if __name__ == "__main__":
     make_squeezeformer_fixture()
     make_transducer_fixture()
     make_fastconformer_fixture()
+    make_cfg1_fixture()

@@ -351,3 +351,59 @@ def test_fastconformer_encoder_oracle_matches_the_reference_encoder():
         g, r = P[k].grad, torch.from_numpy(z["G." + k])
         g = torch.zeros_like(r) if g is None else g
         assert (g - r).abs().max().item() <= 2e-3 * r.abs().max().item() + 2e-4 * gmax, k
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE.json configs[0]
+def cfg1_case():
+    """SURVEY.md section 8(d) cfg 1 = BASELINE.json configs[0]: Conformer-CTC-Small (d=176, H=4, d_k=44, L=16, k=31),
+    B = 2 x 10 s, vocab 128, fp32, dropout / dither off, batch-statistics BatchNorm; weights = init_params(seed 0)"""
+    cfg = R.ConformerCfg.small(vocab=128, dropout=0.0, dropout_att=0.0, dropout_pre_encoder=0.0)
+    P = R.init_params(cfg, seed=0)
+    batch = R.synthetic_batch(2, 10.0, vocab=128, seed=1234)
+    return cfg, P, batch
+
+
+def test_cfg1_small_oracle_matches_reference_fixture(golden_dir):
+    """pins the restatement at the geometry BASELINE.json names (16 layers deep, d_k = 44, T' = 251) against the reference's
+    own files run through the shim (oracle/make_golden.py:make_cfg1_fixture): mel, log-probs, loss, EVERY gradient tensor
+    (norm / max / random projection) and a dozen gradients element by element"""
+    z = np.load(os.path.join(golden_dir, "ref_cfg1_small.npz"))
+    cfg, P, (audio, alen, tok, tl) = cfg1_case()
+    chk = np.array([sum(float(v.double().sum()) for k, v in sorted(P.items()) if v.is_floating_point()),
+                    sum(float(v.double().abs().sum()) for k, v in sorted(P.items()) if v.is_floating_point())])
+    assert np.allclose(chk, z["param_checksum"], rtol=1e-12), "init_params(seed=0) no longer reproduces the fixture's weights"
+    for k in R.trainable_keys(P):
+        P[k].requires_grad_(True)
+    out = R.model_forward(P, cfg, audio, alen, tok, tl, train=False, bn_training=True)
+    mel = out["mel"].numpy()
+    assert mel.shape == (2, 80, 1001) and np.array_equal(out["mel_len"].numpy(), z["mel_len"])
+    assert np.abs(mel[:, :, ::7] - z["mel_every7"]).max() < 2e-4
+    assert np.allclose(mel.astype(np.float64).sum(2), z["mel_rowsum"], rtol=1e-3, atol=2e-2)
+    assert np.allclose((mel.astype(np.float64) ** 2).sum(2), z["mel_rowsumsq"], rtol=1e-3)
+    assert np.array_equal(out["enc_len"].numpy(), z["enc_len"])
+    assert np.abs(out["enc"].detach().numpy()[:, :, ::5] - z["enc_every5"]).max() < 5e-4
+    assert np.abs(out["logp"].detach().numpy() - z["logp"]).max() < 5e-4
+    assert abs(out["loss"].item() - float(z["loss"])) <= 1e-5 * float(z["loss"])
+    assert np.allclose(out["per_utt"].detach().numpy(), z["per_utt"], rtol=1e-5)
+    out["loss"].backward()
+    names = [str(n) for n in z["grad_names"]]
+    assert sorted(names) == sorted(R.trainable_keys(P))
+    gmax = float(z["grad_digest"][:, 1].max())
+    for n, ref in zip(names, z["grad_digest"]):
+        got = R.grad_digest(n, P[n].grad.numpy())
+        numel = P[n].numel()
+        # norm and max to 1e-3 of themselves; the projection to 1e-3 of the norm x sqrt(numel) bound it lives under.
+        # analytically-zero gradients (depthwise bias under batch-statistics BN, key bias) are summation noise on both sides
+        floor = 1e-4 * gmax if n.endswith(("depthwise_conv.bias", "linear_k.bias")) else 1e-7 * gmax
+        assert abs(got[0] - ref[0]) <= 1e-3 * ref[0] + floor * np.sqrt(numel), (n, got, ref)
+        assert abs(got[1] - ref[1]) <= 2e-3 * ref[1] + floor, (n, got, ref)
+        assert abs(got[2] - ref[2]) <= 1e-3 * ref[0] + floor * np.sqrt(numel), (n, got, ref)
+    full = [k[5:] for k in z.files if k.startswith("grad/")]
+    assert len(full) >= 10
+    for n in full:
+        ref = z["grad/" + n]
+        # conv.0.weight = sum over 80 k positions of (gradient x mel): the first tensor of the network and the last of the
+        # backward chain, it carries the 2e-4 mel difference (rfft framing here, torch.stft there) plus 16 layers of fp32
+        # reordering noise (the oracle itself moves by 2e-4 relative between fp32 and fp64 arithmetic at this depth)
+        tol = 3e-3 if n.endswith("pre_encode.conv.0.weight") else 1e-3
+        assert np.abs(P[n].grad.numpy() - ref).max() <= tol * np.abs(ref).max(), n
