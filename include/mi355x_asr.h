@@ -188,6 +188,10 @@ int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, vo
                       long long scratch_elems, void* stream);
 int mi355x_bn_finalize(const void* stats, double count, void* mean, void* rstd, void* running_mean, void* running_var,
                        float momentum, float eps, int d, void* stream);
+/* same, the element count read from device memory (f64 scalar): under SyncBatchNorm (conformer_ctc_bpe.yaml:209,
+ * torch.nn.SyncBatchNorm gathers the per-rank counts) it is all-reduced together with the sums */
+int mi355x_bn_finalize_dev_count(const void* stats, const void* count_dev, void* mean, void* rstd, void* running_mean,
+                                 void* running_var, float momentum, float eps, int d, void* stream);
 int mi355x_bn_eval_stats(const void* running_mean, const void* running_var, void* mean, void* rstd, float eps, int d,
                          void* stream);
 int mi355x_bn_swish_fwd(const void* x, const void* mean, const void* rstd, const void* gamma, const void* beta, void* y,
@@ -199,6 +203,9 @@ int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const void* mean, 
 int mi355x_bn_swish_bwd_apply(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
                               const void* beta, const void* sums, double count, int training, void* dx, int dtype,
                               long long M, int d, void* stream);
+int mi355x_bn_swish_bwd_apply_dev_count(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
+                                        const void* beta, const void* sums, const void* count_dev, int training, void* dx,
+                                        int dtype, long long M, int d, void* stream);
 int mi355x_bn_param_grad(const void* sums, void* dgamma, void* dbeta, int d, void* stream);
 
 /* ---- CTC loss: CTCLoss.forward, losses/ctc.py:68-82 (torch ctc_loss, blank = V, zero_infinity) ------------------

@@ -89,10 +89,12 @@ SIGNATURES = {
     "mi355x_dwconv_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp],
     "mi355x_dwconv_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp],
     "mi355x_bn_finalize": [vp, f64, vp, vp, vp, vp, f32, f32, i32, vp],
+    "mi355x_bn_finalize_dev_count": [vp, vp, vp, vp, vp, vp, f32, f32, i32, vp],
     "mi355x_bn_eval_stats": [vp, vp, vp, vp, f32, i32, vp],
     "mi355x_bn_swish_fwd": [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
     "mi355x_bn_swish_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, i64, vp],
     "mi355x_bn_swish_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, f64, i32, vp, i32, i64, i32, vp],
+    "mi355x_bn_swish_bwd_apply_dev_count": [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp],
     "mi355x_bn_param_grad": [vp, vp, vp, i32, vp],
     "mi355x_ctc_loss": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
     "mi355x_row_scale": [vp, vp, i64, i64, vp],

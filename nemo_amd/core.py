@@ -220,7 +220,11 @@ def load_nemo(path: str):
     values of the form 'nemo:<member>' are extracted to a private directory and replaced by the extracted path."""
     import yaml
 
-    with tarfile.open(path, "r:") as tar:
+    try:  # plain tar first; older .nemo checkpoints are gzip-compressed (save_restore_connector.py:684-694 does the same)
+        tar = tarfile.open(path, "r:")
+    except tarfile.ReadError:
+        tar = tarfile.open(path, "r:gz")
+    with tar:
         names = {os.path.basename(m.name): m for m in tar.getmembers() if m.isfile()}
         cfg = yaml.safe_load(tar.extractfile(names[MODEL_CONFIG_YAML]).read())
         sd = torch.load(io.BytesIO(tar.extractfile(names[MODEL_WEIGHTS]).read()), map_location="cpu", weights_only=True)

@@ -179,11 +179,15 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------ BatchNorm
 // stats (f64 [2][d]: sum, sum of squares over `count` positions) -> mean, rstd (biased var), running stats update
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, float* __restrict__ mean,
+// `count_dev` (optional): the element count as a device f64 -- under SyncBatchNorm it is the (all-reduced) sum of the ranks'
+// own B*T' and travels in the same buffer as the sums, so ragged ranks need no host round trip
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const double* __restrict__ count_dev,
+                                   float* __restrict__ mean,
                                    float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, int d) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d) return;
+  if (count_dev) count = *count_dev;
   const double mu = stats[c] / count;
   double var = stats[d + c] / count - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -287,13 +291,14 @@ template <typename TT>
 __global__ __launch_bounds__(256) void bn_swish_bwd_apply_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 const double* __restrict__ sums, double count, int training,
+                                                                 const double* __restrict__ sums, double count,
+                                                                 const double* __restrict__ count_dev, int training,
                                                                  TT* __restrict__ dx, long long M, int d) {
   // per-channel coefficients are built once per workgroup in LDS (the f64 mean-of-sums included), so a thread's set-up is
   // six 16/32-byte LDS reads however few rows it handles
   constexpr int V = VecIO<TT>::V;
   extern __shared__ float coef[];  // [6][d]: mean, rstd, gamma, beta, k1 = sum(dz)/n, k2 = sum(dz*xhat)/n
-  const double inv_count = 1.0 / count;
+  const double inv_count = 1.0 / (count_dev ? *count_dev : count);
   for (int c = threadIdx.x; c < d; c += 256) {
     coef[c] = mean[c]; coef[d + c] = rstd[c]; coef[2 * d + c] = gamma[c]; coef[3 * d + c] = beta[c];
     coef[4 * d + c] = training ? (float)(sums[c] * inv_count) : 0.f;
@@ -380,13 +385,24 @@ extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, v
                        ksize, d, (float*)dw, (float*)dbias);
   return mi_check_launch();
 }
+static int bn_finalize_launch(const void* stats, double count, const void* count_dev, void* mean, void* rstd,
+                              void* running_mean, void* running_var, float momentum, float eps, int d, void* stream) {
+  mi_clear_errors();
+  if (!stats || !mean || !rstd || d <= 0 || (!count_dev && count <= 0)) return MI_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)stats, count,
+                     (const double*)count_dev, (float*)mean, (float*)rstd, (float*)running_mean, (float*)running_var, momentum,
+                     eps, d);
+  return mi_check_launch();
+}
 extern "C" int mi355x_bn_finalize(const void* stats, double count, void* mean, void* rstd, void* running_mean,
                                   void* running_var, float momentum, float eps, int d, void* stream) {
-  mi_clear_errors();
-  if (!stats || !mean || !rstd || d <= 0 || count <= 0) return MI_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)stats, count,
-                     (float*)mean, (float*)rstd, (float*)running_mean, (float*)running_var, momentum, eps, d);
-  return mi_check_launch();
+  return bn_finalize_launch(stats, count, nullptr, mean, rstd, running_mean, running_var, momentum, eps, d, stream);
+}
+extern "C" int mi355x_bn_finalize_dev_count(const void* stats, const void* count_dev, void* mean, void* rstd,
+                                            void* running_mean, void* running_var, float momentum, float eps, int d,
+                                            void* stream) {
+  if (!count_dev) return MI_ERR_ARG;
+  return bn_finalize_launch(stats, 0.0, count_dev, mean, rstd, running_mean, running_var, momentum, eps, d, stream);
 }
 extern "C" int mi355x_bn_eval_stats(const void* running_mean, const void* running_var, void* mean, void* rstd, float eps, int d,
                                     void* stream) {
@@ -424,17 +440,33 @@ extern "C" int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const v
                        (int)nblk, 2 * d, (double*)sums);
   return mi_check_launch();
 }
+static int bn_swish_bwd_apply_launch(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
+                                     const void* beta, const void* sums, double count, const void* count_dev, int training,
+                                     void* dx, int dt, long long M, int d, void* stream);
 extern "C" int mi355x_bn_swish_bwd_apply(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
                                          const void* beta, const void* sums, double count, int training, void* dx, int dt,
                                          long long M, int d, void* stream) {
+  return bn_swish_bwd_apply_launch(dy, x, mean, rstd, gamma, beta, sums, count, nullptr, training, dx, dt, M, d, stream);
+}
+extern "C" int mi355x_bn_swish_bwd_apply_dev_count(const void* dy, const void* x, const void* mean, const void* rstd,
+                                                   const void* gamma, const void* beta, const void* sums, const void* count_dev,
+                                                   int training, void* dx, int dt, long long M, int d, void* stream) {
+  if (!count_dev) return MI_ERR_ARG;
+  return bn_swish_bwd_apply_launch(dy, x, mean, rstd, gamma, beta, sums, 0.0, count_dev, training, dx, dt, M, d, stream);
+}
+static int bn_swish_bwd_apply_launch(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
+                                     const void* beta, const void* sums, double count, const void* count_dev, int training,
+                                     void* dx, int dt, long long M, int d, void* stream) {
   mi_clear_errors();
-  if (!dy || !x || !sums || !dx || M <= 0 || d <= 0 || d % (dt == MI_DT_BF16 ? 8 : 4) || count <= 0) return MI_ERR_ARG;
+  if (!dy || !x || !sums || !dx || M <= 0 || d <= 0 || d % (dt == MI_DT_BF16 ? 8 : 4) || (!count_dev && count <= 0))
+    return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if ((size_t)d * 6 * sizeof(float) > 64 * 1024) return MI_ERR_ARG;
   DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_bwd_apply_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256),
                                          (size_t)d * 6 * sizeof(float), s,
                                          (const TT*)dy, (const TT*)x, (const float*)mean, (const float*)rstd, (const float*)gamma,
-                                         (const float*)beta, (const double*)sums, count, training, (TT*)dx, M, d));
+                                         (const float*)beta, (const double*)sums, count, (const double*)count_dev, training,
+                                         (TT*)dx, M, d));
   return mi_check_launch();
 }
 extern "C" int mi355x_bn_param_grad(const void* sums, void* dgamma, void* dbeta, int d, void* stream) {

@@ -92,6 +92,23 @@ class FlatParams:
         end = max((self.offsets[n][0] + self.offsets[n][1] + ALIGN - 1) // ALIGN * ALIGN for n in names)
         return start, end
 
+    def trainable_ranges(self) -> List[Tuple[int, int]]:
+        """merged, aligned [start, end) element ranges of the parameters with requires_grad=True.  torch.optim.AdamW skips
+        parameters without a gradient (frozen ones): the fused optimizer steps these ranges only, so neither the update nor
+        the decoupled weight decay touches a frozen parameter.  One range (= one launch) when nothing is frozen."""
+        req = {n: p.requires_grad for n, p in self.module.named_parameters()}
+        out: List[Tuple[int, int]] = []
+        for n in self.order:
+            if not req.get(n, False):
+                continue
+            lo = self.offsets[n][0]
+            hi = lo + (self.offsets[n][1] + ALIGN - 1) // ALIGN * ALIGN
+            if out and out[-1][1] == lo:
+                out[-1] = (out[-1][0], hi)
+            else:
+                out.append((lo, hi))
+        return out
+
     def zero_grad(self) -> None:
         from . import ops
         ops.fill_f32(self.grad, 0.0)

@@ -39,9 +39,6 @@ class EncDecCTCModel(nn.Module):
         cfg = copy.deepcopy(dict(cfg))
         self._cfg = cfg
         self.trainer = trainer
-        self.world_size = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            self.world_size = torch.distributed.get_world_size()
         self.preprocessor = _build("preprocessor", cfg["preprocessor"])
         self.encoder = _build("encoder", cfg["encoder"])
         dec = dict(cfg["decoder"])
@@ -66,6 +63,14 @@ class EncDecCTCModel(nn.Module):
         # data-parallel runs where the update otherwise sits behind the last bucket's all-reduce
         self.optimizer_in_backward = os.environ.get("MI355X_OPT_IN_BACKWARD", "0") == "1"
         self.global_step = 0
+
+    @property
+    def world_size(self) -> int:
+        """queried when needed, not at construction: the process group may be initialised after the model is built (a
+        constructor-time snapshot would silently train unsynchronised replicas)"""
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_world_size()
+        return 1
 
     # ------------------------------------------------------------------ forward (ctc_models.py:495-546)
     def forward(self, input_signal=None, input_signal_length=None, processed_signal=None, processed_signal_length=None):
@@ -149,11 +154,22 @@ class EncDecCTCModel(nn.Module):
 
     def multi_validation_epoch_end(self, outputs, dataloader_idx: int = 0, prefix: str = "val"):
         """asr_model.py:95-123: mean of the batch losses, WER = sum of edit distances / sum of reference words"""
-        loss_mean = torch.stack([x[f"{prefix}_loss"] for x in outputs]).mean()
+        losses = torch.stack([x[f"{prefix}_loss"] for x in outputs])
+        has_wer = bool(outputs) and f"{prefix}_wer_num" in outputs[0]
+        num = float(sum(x[f"{prefix}_wer_num"] for x in outputs)) if has_wer else 0.0
+        denom = float(sum(x[f"{prefix}_wer_denom"] for x in outputs)) if has_wer else 0.0
+        loss_sum, count = losses.sum(), float(losses.numel())
+        if self.world_size > 1:
+            # the DistributedSampler shards the validation set: every rank must report the metric of the WHOLE set (the
+            # reference's WER torchmetric and Lightning's sync_dist loss both reduce over the ranks)
+            t = torch.stack([loss_sum.double(), torch.tensor(count, device=loss_sum.device, dtype=torch.float64),
+                             torch.tensor(num, device=loss_sum.device, dtype=torch.float64),
+                             torch.tensor(denom, device=loss_sum.device, dtype=torch.float64)])
+            torch.distributed.all_reduce(t)
+            loss_sum, count, num, denom = t[0].to(losses.dtype), float(t[1]), float(t[2]), float(t[3])
+        loss_mean = loss_sum / count
         logs = {f"{prefix}_loss": loss_mean}
-        if outputs and f"{prefix}_wer_num" in outputs[0]:
-            num = sum(x[f"{prefix}_wer_num"] for x in outputs)
-            denom = sum(x[f"{prefix}_wer_denom"] for x in outputs)
+        if has_wer:
             logs[f"{prefix}_wer"] = num / denom if denom else float("inf")
         return {f"{prefix}_loss": loss_mean, "log": logs}
 
@@ -296,7 +312,11 @@ class EncDecCTCModel(nn.Module):
         return self._optimizer, self._scheduler
 
     def _grad_syncs(self):
+        gens = tuple(m.flat_parameters().generation for m in (self.encoder, self.decoder))
+        if self._syncs is not None and getattr(self, "_syncs_gen", None) != gens:
+            self._syncs = None  # a flat buffer was rebuilt (model.to(), ...): the exchange must not reduce the stale one
         if self._syncs is None:
+            self._syncs_gen = gens
             self._syncs = []
             for mod in (self.encoder, self.decoder):
                 gs = GradSync(mod.flat_parameters().grad)
@@ -313,7 +333,9 @@ class EncDecCTCModel(nn.Module):
             self.setup_optimization()
         syncs = self._grad_syncs() if self.world_size > 1 else []
         self._optimizer.zero_grad()
-        lr = self._scheduler.step() if self._scheduler is not None else None
+        # Lightning order (optimizer.step(), then scheduler.step() with interval 'step'): optimizer step n runs with
+        # lr(max(1, n - 1)) of the Noam formula (lr_scheduler.py:518-576 reads `last_epoch` before it is advanced)
+        lr = self._scheduler.get_last_lr() if self._scheduler is not None else None
         scale = 1.0 / self.world_size
         early = self.optimizer_in_backward and self._optimizer.begin_step(lr=lr, grad_scale=scale)
         if early:  # slices of the flat buffers are updated as soon as their gradients are final (and reduced)
@@ -330,6 +352,8 @@ class EncDecCTCModel(nn.Module):
             if self.optimizer_in_backward:
                 self._optimizer.step_count -= 1  # begin_step counted it; step() counts again
             self._optimizer.step(lr=lr, grad_scale=scale)
+        if self._scheduler is not None:
+            self._scheduler.step()
         self.global_step += 1
         return out
 

@@ -194,13 +194,11 @@ class ConformerEncoder(NeuralModule):
         self.compute_dtype = compute_dtype  # None: bf16 under torch autocast(bf16), else fp32
         # SyncBatchNorm semantics across data-parallel ranks (trainer.sync_batchnorm: true in the recipe)
         self.sync_batchnorm = True
-        # The element count of the synchronised statistics is world x (this rank's B*T') -- exact when every rank holds the
-        # same padded length (the benchmark; batches padded to a common length).  With ragged ranks (SemiSortBatchSampler:
-        # the k-th batches differ by a few frames) set this (or MI355X_SYNCBN_EXACT_COUNTS=1): the counts are then summed
-        # over the ranks on the host through a gloo side group, once per forward (torch.nn.SyncBatchNorm gathers them too).
-        self.syncbn_exact_counts = os.environ.get("MI355X_SYNCBN_EXACT_COUNTS", "0") == "1"
-        self._bn_count_global = None
-        self._host_sum = None
+        # The element count of the synchronised statistics is the SUM of the ranks' own B*T' (torch.nn.SyncBatchNorm gathers
+        # the per-rank counts; ranks padded to different lengths hold different counts): it rides as one more f64 element
+        # behind the [2,d] sums through the same all-reduce and is read from device memory by the BatchNorm kernels
+        # (mi355x_bn_finalize_dev_count / mi355x_bn_swish_bwd_apply_dev_count) -- exact for ragged ranks, no host round trip.
+        self._syncbn_group = None
         self.use_flash_attention = True  # bf16 + d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
         self.grad_ready_hook = None  # callable(start, end) on the flat gradient buffer (data-parallel bucketing)
         # --- engine state (not part of the state-dict)
@@ -442,12 +440,6 @@ class ConformerEncoder(NeuralModule):
         T1, F1 = (T - 1) // 2 + 1, (F_ - 1) // 2 + 1
         T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
         M = B * T2
-        self._bn_count_global = None
-        if training and self.sync_batchnorm and self.syncbn_exact_counts:
-            if self._host_sum is None:
-                from ..parallel import HostSum
-                self._host_sum = HostSum()
-            self._bn_count_global = self._host_sum(float(M))
         len0, len1, len2 = self._lens(length)
         self.update_max_seq_length(T2, dev)
         if training:
@@ -502,7 +494,11 @@ class ConformerEncoder(NeuralModule):
         S.pos = pos
         S.p_all = self._pos_proj_fwd(pos, W, cdt, dev)
         # per-layer f64 BatchNorm sums: one allocation + one fill for all layers (18 tiny fill launches otherwise)
-        S.bn_stats = torch.zeros(self.n_layers, 2, d, dtype=torch.float64, device=dev) if training else None
+        # (row layout [sum | sum of squares | element count | pad]: under SyncBatchNorm the count travels with the sums)
+        S.bn_stats = torch.zeros(self.n_layers, 2 * d + 8, dtype=torch.float64, device=dev) if training else None
+        S.bn_world = self._syncbn_world() if training else 1
+        if training and S.bn_world > 1:
+            S.bn_stats[:, 2 * d] = float(M)
         S.layers = []
         for i, L in enumerate(self.layers):
             x, sl = self._layer_fwd(i, L, x, S, W, Wf, drop)
@@ -629,7 +625,9 @@ class ConformerEncoder(NeuralModule):
         if training:
             stats = S.bn_stats[i]
             ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T2, d, k)
-            count = self._sync_stats(stats, count)
+            if S.bn_world > 1:  # sums and count in one exchange; the global count stays on the device
+                self._sync_stats(stats[: 2 * d + 1])
+                count = stats[2 * d: 2 * d + 1]
             ops.bn_finalize(stats, count, bmean, brstd, bn.running_mean, bn.running_var, bn.momentum, bn.eps, d)
         else:
             ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
@@ -647,14 +645,22 @@ class ConformerEncoder(NeuralModule):
         sl.out = (r4, mean5, rstd5)
         return xo, sl
 
-    def _sync_stats(self, stats, count):
-        """SyncBatchNorm: all-reduce the raw f64 sums over the data-parallel group (torch.nn.SyncBatchNorm semantics)."""
+    def _syncbn_world(self):
         if self.sync_batchnorm and torch.distributed.is_available() and torch.distributed.is_initialized():
-            ws = torch.distributed.get_world_size()
-            if ws > 1:
-                torch.distributed.all_reduce(stats)
-                return self._bn_count_global if self._bn_count_global is not None else count * ws
-        return count
+            return torch.distributed.get_world_size()
+        return 1
+
+    def _sync_stats(self, stats):
+        """SyncBatchNorm: all-reduce the raw f64 sums (+ count) over the data-parallel ranks (torch.nn.SyncBatchNorm
+        semantics).  The exchanges go through their OWN process group = their own RCCL communicator and stream: on the
+        default group these 8-KB latency-bound calls would queue behind the 64-MiB gradient buckets that GradSync has
+        in flight during backward, and the backward chain (which needs the sums at once) would stall for a whole bucket."""
+        import torch.distributed as dist
+        if self._syncbn_group is None:
+            # every rank reaches its first training forward in the same order, so the collective new_group() call matches
+            self._syncbn_group = dist.new_group(backend=dist.get_backend()) if os.environ.get(
+                "MI355X_SYNCBN_OWN_GROUP", "1") != "0" else dist.group.WORLD
+        dist.all_reduce(stats, group=self._syncbn_group)
 
     # ------------------------------------------------------------------ backward implementation
     def _backward_impl(self, S, dout):
@@ -804,8 +810,8 @@ class ConformerEncoder(NeuralModule):
         sums = S.bn_sums[i]
         ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, M, d)
         ops.bn_param_grad(sums, bn.weight.grad, bn.bias.grad, d)
-        if training:
-            self._sync_stats(sums, 0.0)
+        if training and S.bn_world > 1:
+            self._sync_stats(sums)
         dcc = torch.empty(M, d, dtype=cdt, device=dev)
         ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, M, d)
         dg = torch.empty(M, d, dtype=cdt, device=dev)

@@ -348,6 +348,11 @@ def dwconv_bwd(dy, x, w, dx, dw, dbias, B, T, d, k):
 
 
 def bn_finalize(stats, count, mean, rstd, running_mean, running_var, momentum, eps, d):
+    """`count`: python number, or a device f64 scalar tensor (SyncBatchNorm: all-reduced with the sums)"""
+    if isinstance(count, torch.Tensor):
+        check(lib.mi355x_bn_finalize_dev_count(_ptr(stats), _ptr(count), _ptr(mean), _ptr(rstd), _ptr(running_mean),
+                                               _ptr(running_var), momentum, eps, d, _stream()), "bn_finalize_dev_count")
+        return
     check(lib.mi355x_bn_finalize(_ptr(stats), float(count), _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var),
                                  momentum, eps, d, _stream()), "bn_finalize")
 
@@ -370,6 +375,11 @@ def bn_swish_bwd_reduce(dy, x, mean, rstd, gamma, beta, sums, M, d):
 
 
 def bn_swish_bwd_apply(dy, x, mean, rstd, gamma, beta, sums, count, training, dx, M, d):
+    if isinstance(count, torch.Tensor):
+        check(lib.mi355x_bn_swish_bwd_apply_dev_count(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+                                                      _ptr(sums), _ptr(count), int(training), _ptr(dx), dt(x), M, d, _stream()),
+              "bn_swish_bwd_apply_dev_count")
+        return
     check(lib.mi355x_bn_swish_bwd_apply(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums),
                                         float(count), int(training), _ptr(dx), dt(x), M, d, _stream()), "bn_swish_bwd_apply")
 

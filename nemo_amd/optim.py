@@ -68,7 +68,16 @@ class FusedAdamW:
         key = (id(fp), fp.generation)
         st = self._state.get(key)
         if st is None:
-            st = (torch.zeros_like(fp.flat), torch.zeros_like(fp.flat))
+            old = [v for k, v in self._state.items() if k[0] == id(fp)]
+            if old and old[0][0].numel() == fp.flat.numel():
+                # the flat buffer was rebuilt (model.to(), zero_grad(set_to_none=True) ...): same parameters, same layout
+                # -> the Adam moments move with them instead of silently restarting from zero
+                st = tuple(t.to(fp.flat.device) for t in old[0])
+            elif old:
+                raise RuntimeError("FusedAdamW: the parameter set changed under the optimizer (flat buffer rebuilt with a "
+                                   "different size); call setup_optimization() again")
+            else:
+                st = (torch.zeros_like(fp.flat), torch.zeros_like(fp.flat))
             self._state = {k: v for k, v in self._state.items() if k[0] != id(fp)}
             self._state[key] = st
         return st
@@ -79,7 +88,11 @@ class FusedAdamW:
         key = (id(fp), fp.generation)
         e = self._ema.get(key)
         if e is None:
-            e = fp.flat.detach().clone()  # the average starts at the current weights (ema.py:263-266)
+            old = [v for k, v in self._ema.items() if k[0] == id(fp)]
+            if old and old[0].numel() == fp.flat.numel():
+                e = old[0].to(fp.flat.device)  # buffer rebuilt: the running average is kept
+            else:
+                e = fp.flat.detach().clone()  # the average starts at the current weights (ema.py:263-266)
             self._ema = {k: v for k, v in self._ema.items() if k[0] != id(fp)}
             self._ema[key] = e
         return e
@@ -111,9 +124,13 @@ class FusedAdamW:
         lr, grad_scale = self._cur
         m, v = self._moments(fp)
         ema = self._ema_of(fp)
-        ops.adamw_step(fp.flat[lo:hi], fp.grad[lo:hi], m[lo:hi], v[lo:hi], lr, self.betas[0], self.betas[1], self.eps,
-                       self.weight_decay, self.step_count, grad_scale, ema=None if ema is None else ema[lo:hi],
-                       ema_decay=self.ema_decay or 0.0)
+        for tlo, thi in fp.trainable_ranges():  # frozen parameters (requires_grad=False) are never stepped nor decayed
+            a, b = max(lo, tlo), min(hi, thi)
+            if a >= b:
+                continue
+            ops.adamw_step(fp.flat[a:b], fp.grad[a:b], m[a:b], v[a:b], lr, self.betas[0], self.betas[1], self.eps,
+                           self.weight_decay, self.step_count, grad_scale, ema=None if ema is None else ema[a:b],
+                           ema_decay=self.ema_decay or 0.0)
         self._done[id(fp)].append((lo, hi))
 
     def finish_step(self):
@@ -145,15 +162,20 @@ class FusedAdamW:
                               torch.zeros(2, dtype=torch.float32, device=dev))
             sumsq, coef = self._clip
             sumsq.zero_()
-            for i, fp in enumerate(self.flats):
-                ops.grad_sumsq(fp.grad, sumsq[i:i + 1])
+            for i, fp in enumerate(self.flats):  # (clip_grad_norm_ sees the gradients of trainable parameters only)
+                for lo, hi in fp.trainable_ranges():
+                    ops.grad_sumsq(fp.grad[lo:hi], sumsq[i:i + 1])
             ops.clip_coef(sumsq, grad_scale, self.max_grad_norm, coef)
             self.last_grad_norm = coef[1:2]
         for fp in self.flats:
             m, v = self._moments(fp)
-            ops.adamw_step(fp.flat, fp.grad, m, v, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                           self.step_count, grad_scale, clip_coef=coef, ema=self._ema_of(fp),
-                           ema_decay=self.ema_decay or 0.0)
+            ema = self._ema_of(fp)
+            # torch.optim.AdamW skips parameters whose grad is None: frozen parameters (requires_grad=False, .freeze())
+            # receive neither the update nor the decoupled weight decay.  One range = one launch when nothing is frozen.
+            for lo, hi in fp.trainable_ranges():
+                ops.adamw_step(fp.flat[lo:hi], fp.grad[lo:hi], m[lo:hi], v[lo:hi], lr, self.betas[0], self.betas[1], self.eps,
+                               self.weight_decay, self.step_count, grad_scale, clip_coef=coef,
+                               ema=None if ema is None else ema[lo:hi], ema_decay=self.ema_decay or 0.0)
         for fp in self.flats:
             if hasattr(fp.module, "weights_updated"):
                 fp.module.weights_updated()

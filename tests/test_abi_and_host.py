@@ -361,3 +361,52 @@ def test_bpe_model_builds_from_a_tokenizer_dir_and_carries_it_in_the_nemo_file(t
     model.change_vocabulary(_train_spm(tmp_path, "tok48", 48, words + ["transducer", "gradient"]))
     assert model.decoder.num_classes_with_blank == 49 and model.loss.blank == 48 and len(model.tokenizer.vocab) == 48
     assert all(torch.equal(v, model.encoder.state_dict()[k]) for k, v in enc.items())
+
+
+def test_trainable_ranges_skip_frozen_parameters():
+    """torch.optim.AdamW skips parameters without a gradient; the fused optimizer steps FlatParams.trainable_ranges() only:
+    frozen parameters (requires_grad=False / .freeze()) are excluded, adjacent trainable ones merge into one launch"""
+    from nemo_amd.flat import ALIGN, FlatParams
+    m = torch.nn.Sequential(torch.nn.Linear(70, 3), torch.nn.Linear(3, 5), torch.nn.Linear(5, 2))
+    fp = FlatParams(m)
+    fp.build()
+    total = fp.flat.numel()
+    assert fp.trainable_ranges() == [(0, total)]            # nothing frozen: one range, one launch
+    m[1].weight.requires_grad_(False)
+    r = fp.trainable_ranges()
+    lo, n = fp.offsets["1.weight"]
+    hi = lo + (n + ALIGN - 1) // ALIGN * ALIGN
+    assert r == [(0, lo), (hi, total)]
+    for p in m.parameters():
+        p.requires_grad_(False)
+    assert fp.trainable_ranges() == []                      # fully frozen module: no update, no weight decay
+
+
+def test_gzip_compressed_nemo_archives_load(tmp_path):
+    """older .nemo checkpoints are tar.gz (save_restore_connector.py:684-694 falls back from 'r:' to 'r:gz')"""
+    import io, tarfile, yaml
+    from nemo_amd.core import MODEL_CONFIG_YAML, MODEL_WEIGHTS, load_nemo
+    cfg = {"sample_rate": 16000, "encoder": {"d_model": 8}}
+    sd = {"w": torch.arange(6, dtype=torch.float32).view(2, 3)}
+    for mode, name in (("w:gz", "old.nemo"), ("w:", "new.nemo")):
+        path = str(tmp_path / name)
+        with tarfile.open(path, mode) as tar:
+            for member, blob in ((MODEL_CONFIG_YAML, yaml.safe_dump(cfg).encode()), (MODEL_WEIGHTS, None)):
+                if blob is None:
+                    b = io.BytesIO(); torch.save(sd, b); blob = b.getvalue()
+                ti = tarfile.TarInfo("./" + member); ti.size = len(blob)
+                tar.addfile(ti, io.BytesIO(blob))
+        c2, s2 = load_nemo(path)
+        assert c2 == cfg and torch.equal(s2["w"], sd["w"])
+
+
+def test_scheduler_follows_the_lightning_order():
+    """Lightning calls scheduler.step() AFTER optimizer.step(): optimizer step n runs with lr(max(1, n-1)) of the Noam
+    formula (the _LRScheduler constructor leaves last_epoch at 0, lr_scheduler.py:518-576 clamps the step to >= 1)"""
+    from nemo_amd.optim import NoamAnnealing
+    s = NoamAnnealing(2.0, d_model=512, warmup_steps=1000, min_lr=1e-6)
+    used = []
+    for _ in range(4):          # what fit_step does: read, (optimizer step), advance
+        used.append(s.get_last_lr())
+        s.step()
+    assert used == [s.lr_at(1), s.lr_at(1), s.lr_at(2), s.lr_at(3)]

@@ -405,3 +405,88 @@ def test_training_wer_validation_and_transcribe(tmp_path):
     batch = ds._collate_fn([ds[i] for i in (2, 4)])
     pred = model.predict_step([t.to(dev) if torch.is_tensor(t) else t for t in batch])
     assert [int(i) for i, _ in pred] == [2, 4] and all(isinstance(t, str) for _, t in pred)
+
+
+def _ragged_bn_worker(rank, world, port, out_dir, over, vocab, secs):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        torch.manual_seed(5)
+        model = _model(over, vocab=vocab).to(dev).train()
+        audio, alen, tok, tl = R.synthetic_batch(2, secs[rank], vocab=vocab, seed=40 + rank)
+        loss = model.training_step([audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)])["loss"]
+        loss.backward()
+        torch.cuda.synchronize()
+        bn = model.encoder.layers[0].conv.batch_norm
+        torch.save(dict(mean=bn.running_mean.detach().cpu(), var=bn.running_var.detach().cpu(),
+                        grad=model.encoder.layers[0].conv.depthwise_conv.weight.grad.detach().cpu()),
+                   os.path.join(out_dir, f"ragged{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_syncbn_counts_are_exact_for_ranks_with_different_padded_lengths(tmp_path):
+    """torch.nn.SyncBatchNorm divides the summed statistics by the SUM of the ranks' element counts.  Two ranks holding
+    batches padded to different lengths (1.0 s vs 0.6 s: T' = 26 vs 16): the first layer's synchronised mean / variance
+    must equal the count-weighted combination of the two ranks' own statistics (each measured in a one-process run)."""
+    import socket
+    import torch.multiprocessing as mp
+    over = dict(d_model=64, n_heads=4, n_layers=1, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0)
+    vocab, secs = 20, (1.0, 0.6)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ragged_bn_worker, args=(2, port, str(tmp_path), over, vocab, secs), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "ragged0.pt"); r1 = torch.load(tmp_path / "ragged1.pt")
+    assert torch.equal(r0["mean"], r1["mean"]) and torch.equal(r0["var"], r1["var"])
+    stats = []
+    for rank in (0, 1):  # the ranks' own statistics: one process, no group
+        torch.manual_seed(5)
+        model = _model(over, vocab=vocab).to(dev).train()
+        audio, alen, tok, tl = R.synthetic_batch(2, secs[rank], vocab=vocab, seed=40 + rank)
+        model.training_step([audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)])
+        torch.cuda.synchronize()
+        bn = model.encoder.layers[0].conv.batch_norm
+        n = 2 * (((audio.shape[1] // 160 + 1) - 1) // 2 // 2 + 1)  # B x T' (tensor length after the two stride-2 convs)
+        mean = bn.running_mean.double().cpu() / 0.1
+        var_unb = (bn.running_var.double().cpu() - 0.9) / 0.1
+        stats.append((n, mean, var_unb * (n - 1) / n + mean ** 2))  # (count, E[x], E[x^2])
+    (na, ma, qa), (nb, mb, qb) = stats
+    assert na != nb
+    n = na + nb
+    mean = (na * ma + nb * mb) / n
+    var = (na * qa + nb * qb) / n - mean ** 2
+    assert torch.allclose(r0["mean"].double(), 0.1 * mean, atol=1e-6, rtol=1e-5)
+    assert torch.allclose(r0["var"].double(), 0.9 + 0.1 * var * n / (n - 1), atol=1e-6, rtol=1e-5)
+    # with the old "count x world" rule rank 0 would have divided by 2*na and rank 1 by 2*nb
+    wrong = (na * ma + nb * mb) / (2 * na)
+    assert not torch.allclose(r0["mean"].double(), 0.1 * wrong, atol=1e-6, rtol=1e-4)
+
+
+def test_frozen_parameters_are_neither_updated_nor_decayed():
+    """requires_grad=False / freeze() must keep a parameter out of the fused AdamW (torch skips grad-less
+    parameters): a frozen tensor keeps its bits -- no update, no decoupled weight decay -- while the rest trains"""
+    over = dict(d_model=64, n_heads=4, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0)
+    torch.manual_seed(1)
+    model = _model(over, vocab=20).to(dev).train()
+    model.setup_optimization(dict(name="adamw", lr=1e-2, betas=[0.9, 0.98], weight_decay=0.1))
+    frozen = [model.encoder.layers[0].feed_forward1.linear1.weight, model.encoder.layers[1].norm_out.bias,
+              model.decoder.decoder_layers[0].bias]
+    for p in frozen:
+        p.requires_grad_(False)
+    model.flats()
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    audio, alen, tok, tl = R.synthetic_batch(2, 1.0, vocab=20, seed=8)
+    batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+    for _ in range(3):
+        model.fit_step(batch)
+    torch.cuda.synchronize()
+    ids = {id(p) for p in frozen}
+    moved = 0
+    for n, p in model.named_parameters():
+        if id(p) in ids:
+            assert torch.equal(p.detach(), before[n]), n
+        else:
+            moved += int(not torch.equal(p.detach(), before[n]))
+    assert moved > 50
