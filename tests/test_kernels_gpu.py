@@ -123,7 +123,11 @@ def test_gemm_batched_strided_bf16():
     qkv = bf(torch.randn(Bn * T, 3 * d, generator=g))
     ref = torch.einsum("bihe,bjhe->hbij", qkv[:, :d].float().view(Bn, T, H, dk), qkv[:, d:2 * d].float().view(Bn, T, H, dk))
     out = torch.zeros(H, Bn, T, Tp, device=dev)
-    qd = qkv.to(dev)
+    # the P.V product below runs with K = Tp > T: for the last utterance the reduction walks Tp - T rows past its own V rows
+    # (multiplied by the zero pad columns of P).  They must be finite memory of OUR allocation -- 0 x (whatever the
+    # allocator left behind, possibly NaN bits) made this test flaky -- so the device copy carries zero rows behind it
+    qd = torch.zeros(Bn * T + Tp, 3 * d, device=dev, dtype=torch.bfloat16)
+    qd[: Bn * T] = qkv.to(dev)
     o.gemm(qd, qd, out, T, T, dk, 3 * d, 3 * d, Tp, batch=H * Bn, nb0=Bn, sA=(T * 3 * d, dk), sB=(T * 3 * d, dk),
            sC=(T * Tp, Bn * T * Tp), b_off=d)
     torch.cuda.synchronize()
