@@ -1255,6 +1255,231 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
 }
 
 // =================================================================================================
+// Fifth structure: the FFN / projection GEMMs of the Conformer block (NT, K = 512 ... 2048, full-width epilogues).
+// The 256x128 / 256x256 structures above run K loop and epilogue strictly one after the other -- one workgroup owns the
+// CU and all workgroups move in step, so the HBM idles during the K loops and the matrix pipe during the epilogues; at
+// K = 512 the epilogue (LDS round trip + Swish / dropout VALU work + 130 MB of stores) costs twice the K loop.  Here:
+//   * PERSISTENT workgroups (one per CU, 512 threads), each walking its share of the 256x128 output tiles;
+//   * TWO accumulator sets per wave (64 + 64 registers): while tile t+1 runs its K loop, tile t's epilogue proceeds in
+//     eight 8-row ROUNDS, one per K-tile iteration;
+//   * the rounds go through a WAVE-PRIVATE LDS window (8 rows x 64 columns f32, XOR-swizzled so that ds_write_b32 and
+//     ds_read_b64 are conflict-free): accumulator layout (lane = column) -> row layout (lane = 8 consecutive columns), so
+//     global accesses are 16/32 B per lane and 128/256 B per row, no workgroup barrier involved;
+//   * the two wave halves run the iteration in OPPOSITE order -- waves 0-3: fragment reads + 16 MFMAs, then their epilogue
+//     round; waves 4-7: epilogue round first, then reads + MFMAs.  Waves w and w+4 share a SIMD, so at any time one of the
+//     pair feeds the matrix pipe while the other one uses the VALU / LDS / store path;
+//   * the LDS-DMA ring (three 48-KiB stages, two K-tiles ahead, counted vmcnt) runs ACROSS tile boundaries: the first two
+//     K-tiles of the next tile are in flight during the last two iterations of the current one.
+// LDS: 3 x 48 KiB + 8 x 2 KiB windows = exactly the 160 KiB of the CU.
+// Results are bit-identical to the 256x128 structure (same k order, same epilogue arithmetic).
+// =================================================================================================
+#define V5_WIN (8 * 64)                                    // floats per wave window
+#define V5_LDS_BYTES (3 * NT2_STAGE * 2 + 8 * V5_WIN * 4)  // 163 840
+
+// one 8-row epilogue round of a wave's 64x64 block of the PREVIOUS tile.  r = 0..7: accumulators [r>>2][*], registers
+// 4*(r&3) .. +3 of each  <->  block rows (r>>2)*32 + 8*(r&3) + 0..7
+template <int EPI>
+__device__ __forceinline__ void v5_round(const GemmP& p, float* win, const f32x16 (&acc)[2][2], const int r, const int m_blk,
+                                         const int n_blk, const float (&b8)[8], const int lane) {
+  const int lr = lane & 31, lh = lane >> 5;
+  f32x4 t0, t1;  // columns lr (j = 0) and 32 + lr (j = 1), rows 4*lh + 0..3 of the round
+#define V5_PICK(i, q)                                                                                       \
+  t0 = f32x4{acc[i][0][4 * q], acc[i][0][4 * q + 1], acc[i][0][4 * q + 2], acc[i][0][4 * q + 3]};         \
+  t1 = f32x4{acc[i][1][4 * q], acc[i][1][4 * q + 1], acc[i][1][4 * q + 2], acc[i][1][4 * q + 3]};
+  switch (r) {  // uniform: the accumulators are never indexed dynamically
+    case 0: V5_PICK(0, 0) break;
+    case 1: V5_PICK(0, 1) break;
+    case 2: V5_PICK(0, 2) break;
+    case 3: V5_PICK(0, 3) break;
+    case 4: V5_PICK(1, 0) break;
+    case 5: V5_PICK(1, 1) break;
+    case 6: V5_PICK(1, 2) break;
+    default: V5_PICK(1, 3) break;
+  }
+#undef V5_PICK
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int wr = 4 * lh + e, sw = 2 * (wr & 3);
+    win[wr * 64 + (lr ^ sw)] = t0[e];
+    win[wr * 64 + ((32 + lr) ^ sw)] = t1[e];
+  }
+  // row layout: lane -> window row lane>>3, columns 8*(lane&7) .. +7 (four conflict-free ds_read_b64)
+  const int wr = lane >> 3, c8 = (lane & 7) * 8, sw = 2 * (wr & 3);
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float2 x = *reinterpret_cast<const float2*>(win + wr * 64 + ((c8 + 2 * k) ^ sw));
+    v[2 * k] = x.x; v[2 * k + 1] = x.y;
+  }
+  const int m = m_blk + (r >> 2) * 32 + 8 * (r & 3) + wr;
+  if (m >= p.M) return;
+  const int n = n_blk + c8;
+  const long long ci = (long long)m * p.ldc + n, ai = (long long)m * p.ldaux + n;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] += b8[j];
+  float dm[8];
+  drop_mask8(p.drop, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, dm);
+  if (EPI == EPI_STORE) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= p.alpha * dm[j];
+  } else if (EPI == EPI_SWISH_DROP) {
+    st8x(p.aux_out, ai, p.auxout_dt, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * dm[j];
+  } else if (EPI == EPI_RESID) {
+    float a[8];
+    ld8x(p.aux_in, ai, MI_DT_F32, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a[j] + p.alpha * v[j] * dm[j];
+  } else {  // EPI_DSWISH
+    float a[8];
+    ld8x(p.aux_in, ai, p.auxin_dt, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * dm[j] * swish_grad(a[j]);
+  }
+  st8x(p.C, ci, p.c_dt, v);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_v5_kernel(GemmP p, const int ntiles, const int tn) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem5[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool epi_first = wave >= 4;  // the younger half runs its epilogue round ahead of its MFMAs
+  float* win = reinterpret_cast<float*>(smem5 + 3 * NT2_STAGE) + wave * V5_WIN;
+
+  // tiles of this workgroup: XCD x = blockIdx & 7 owns a contiguous chunk of the (row-major) tile list, its gridDim/8
+  // workgroups take the chunk's tiles round-robin -- the tiles in flight on one XCD are consecutive (same A panels, all of B)
+  const int nslot = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int chunkn = q8 + (xcd < r8 ? 1 : 0);
+  const int my_tiles = slot < chunkn ? (chunkn - slot + nslot - 1) / nslot : 0;
+  if (my_tiles == 0) return;
+  const int nk = (p.K + BK - 1) / BK;  // >= 8 by contract (one epilogue round per K-tile iteration)
+  const int total = my_tiles * nk;
+  const bool ktail = (p.K & (BK - 1)) != 0;
+  const bf16_t* A = (const bf16_t*)p.A;
+  const bf16_t* B = (const bf16_t*)p.B;
+
+  // ---- LDS-DMA cursor: runs two K-tiles ahead of the compute cursor, across tile boundaries
+  DmaSrc<BM2> dA;
+  DmaSrc<BN> dB;
+  int d_tile = 0, d_kt = 0, d_stage = 0;
+  auto dma_next = [&]() {
+    if (d_kt == 0) {
+      const int L = chunk0 + slot + d_tile * nslot;
+      const int tile_m = L / tn, tile_n = L - tile_m * tn;
+      dma_setup<false, BM2>(dA, A, p.lda, tile_m * BM2, p.M, 0);
+      dma_setup<false, BN>(dB, B, p.ldb, tile_n * BN, p.N, 0);
+    }
+    bf16_t* st = smem5 + d_stage * NT2_STAGE;
+    dma_issue<BM2>(dA, d_kt, d_kt * BK, p.K, ktail, st);
+    dma_issue<BN>(dB, d_kt, d_kt * BK, p.K, ktail, st + BM2 * BK);
+    d_stage = d_stage == 2 ? 0 : d_stage + 1;
+    if (++d_kt == nk) { d_kt = 0; ++d_tile; }
+  };
+
+  f32x16 acc[2][2], accP[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accP[i][j][r] = 0.f; }
+
+  dma_next();
+  if (total > 1) dma_next();
+  if (total > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int it = 0, c_tile = 0, c_stage = 0;
+  int m_cur, n_cur, m_prev = 0, n_prev = 0;
+  bool have_prev = false;
+  float b8[8];
+  {
+    const int L = chunk0 + slot;
+    const int tile_m = L / tn, tile_n = L - tile_m * tn;
+    m_cur = tile_m * BM2 + wm * 64; n_cur = tile_n * BN + wn * 64;
+  }
+  auto load_bias = [&](const int n_blk) {
+    if (p.bias) ld8x(p.bias, n_blk + (lane & 7) * 8, MI_DT_F32, b8);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b8[j] = 0.f;
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b8[j] = 0.f;
+
+  for (int g = 0; g < total; ++g) {
+    const bool more2 = g + 2 < total;
+    if (more2) dma_next();  // stage of iteration g-1: every wave passed the barrier after reading it
+    __builtin_amdgcn_sched_barrier(0);
+    const bool round = have_prev && it < 8;
+    if (round && epi_first) v5_round<EPI>(p, win, accP, it, m_prev, n_prev, b8, lane);
+    {
+      const bf16_t* a_s = smem5 + c_stage * NT2_STAGE;
+      const bf16_t* b_s = a_s + BM2 * BK;
+      bf16x8 af[4][2], bfr[4][2];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          af[kk][i] = frag_v2<false, BM2>(a_s, wm * 64 + i * 32, kk, lane);
+          bfr[kk][i] = frag_v2<false, BN>(b_s, wn * 64 + i * 32, kk, lane);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (round && !epi_first) v5_round<EPI>(p, win, accP, it, m_prev, n_prev, b8, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // tile g+1 must have landed (this wave's share) before the barrier publishes it.  vmcnt counts in order and counts
+    // stores: younger than that tile's DMA are at most the 6 DMA instructions of tile g+2 and this round's stores
+    // (waiting for fewer outstanding operations than strictly necessary is always safe)
+    if (more2) {
+      if (round) {
+        if (EPI == EPI_STORE || EPI == EPI_DSWISH) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // two stores per lane and round (aux_out + C, or f32 C)
+      } else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    c_stage = c_stage == 2 ? 0 : c_stage + 1;
+    if (++it == nk) {  // tile finished: its accumulators become the "previous" set, the next tile starts from zero
+      it = 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          accP[i][j] = acc[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+      m_prev = m_cur; n_prev = n_cur; have_prev = true;
+      load_bias(n_prev);
+      ++c_tile;
+      if (c_tile < my_tiles) {
+        const int L = chunk0 + slot + c_tile * nslot;
+        const int tile_m = L / tn, tile_n = L - tile_m * tn;
+        m_cur = tile_m * BM2 + wm * 64; n_cur = tile_n * BN + wn * 64;
+      }
+    }
+  }
+  // ---- the last tile's epilogue has nothing to hide behind
+#pragma unroll 1
+  for (int r = 0; r < 8; ++r) v5_round<EPI>(p, win, accP, r, m_prev, n_prev, b8, lane);
+}
+
+// =================================================================================================
 // exact fp32 VALU kernel, arbitrary strides: 64x64x16 tile, 256 threads, 4x4 per thread
 // =================================================================================================
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
@@ -1419,6 +1644,37 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
         attr_set = true;
       }
       dim3 grid2(tm2 * tn, sk, p.batch);
+      // persistent 256x128 structure with the epilogue overlapped into the next tile's K loop: the Conformer block's
+      // forward / dgrad GEMMs (dense NT, full-width vector epilogue, K >= 8 K-tiles, at least one tile per CU)
+      static int v5_mode = -1;  // MI355X_GEMM_V5: 0 = never, 1 = default
+      if (v5_mode < 0) { const char* e = getenv("MI355X_GEMM_V5"); v5_mode = e ? atoi(e) : 1; }
+      const bool v5_epi = p.epi == EPI_STORE || p.epi == EPI_SWISH_DROP || (p.epi == EPI_RESID && p.c_dt == MI_DT_F32) ||
+                          p.epi == EPI_DSWISH;
+      if (v5_mode && !p.transA && !p.transB && !p.g_on && !p.r_on && !p.atomic && p.batch == 1 && sk == 1 && (p.vec_ok & 1) &&
+          !(p.N % BN) && nk >= 8 && tm2 * tn >= 256 && v5_epi && !(p.epi == EPI_STORE && p.c_dt == MI_DT_F32 && false)) {
+        static bool attr5_set = false;
+        if (!attr5_set) {
+          bool ok = hipFuncSetAttribute((const void*)gemm_bf16_v5_kernel<EPI_STORE>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS_BYTES) == hipSuccess;
+          ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v5_kernel<EPI_SWISH_DROP>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS_BYTES) == hipSuccess;
+          ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v5_kernel<EPI_RESID>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS_BYTES) == hipSuccess;
+          ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v5_kernel<EPI_DSWISH>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS_BYTES) == hipSuccess;
+          if (!ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
+          attr5_set = true;
+        }
+        const int nt5 = tm2 * tn;
+        dim3 grid5(256);
+        switch (p.epi) {
+          case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_v5_kernel<EPI_STORE>), grid5, dim3(512), V5_LDS_BYTES, s, p, nt5, tn); break;
+          case EPI_SWISH_DROP: hipLaunchKernelGGL((gemm_bf16_v5_kernel<EPI_SWISH_DROP>), grid5, dim3(512), V5_LDS_BYTES, s, p, nt5, tn); break;
+          case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_v5_kernel<EPI_RESID>), grid5, dim3(512), V5_LDS_BYTES, s, p, nt5, tn); break;
+          default: hipLaunchKernelGGL((gemm_bf16_v5_kernel<EPI_DSWISH>), grid5, dim3(512), V5_LDS_BYTES, s, p, nt5, tn); break;
+        }
+        return mi_check_launch();
+      }
       // 256x256 structure when the problem still fills the chip with the larger tile
       static int v4_mode = -1;  // MI355X_GEMM_V4: 0 = never, 1 = heuristic (default), 2 = whenever N >= 129
       if (v4_mode < 0) { const char* e = getenv("MI355X_GEMM_V4"); v4_mode = e ? atoi(e) : 1; }

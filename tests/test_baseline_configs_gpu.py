@@ -153,7 +153,7 @@ def test_cfg1_small_fp32_matches_reference_fixture_and_oracle(golden_dir):
     assert not bad, bad[:10]
 
 
-BF16_SLACK = 3.0
+BF16_SLACK = 2.5  # measured (profiles/r2_parity_large_bf16_b2x20s.json): worst tensor 2.0x, median 1.5x
 
 
 def test_large_bf16_b2x20s_per_tensor_against_fp32_and_bf16_emulating_oracle():
@@ -186,8 +186,8 @@ def test_large_bf16_b2x20s_per_tensor_against_fp32_and_bf16_emulating_oracle():
             if got[n].abs().max().item() > 2e-2 * gmax:
                 bad.append((n, "zero-grad", got[n].abs().max().item()))
             continue
-        # every tensor, small ones included: no farther from fp32 than BF16_SLACK x the rounding-only error (+ a 1 % floor)
-        if e_hip > BF16_SLACK * e_emu + 1e-2:
+        # every tensor, small ones included: no farther from fp32 than BF16_SLACK x the rounding-only error (+ a 0.5 % floor)
+        if e_hip > BF16_SLACK * e_emu + 5e-3:
             bad.append((n, e_hip, e_emu))
     _report("parity_large_bf16_b2x20s.json", dict(config="Conformer-CTC-Large bf16, B=2x20s (BASELINE.json configs[1] geometry)",
                                                   loss_hip=l_hip, loss_fp32_oracle=l_32, loss_bf16_emulated=l_emu,
