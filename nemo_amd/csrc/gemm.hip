@@ -205,28 +205,22 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
     for (int j = 0; j < 8; ++j) b8[j] = 0.f;
   }
   const uint32_t dbase = (uint32_t)z * (uint32_t)(p.M * p.N) + (uint32_t)n;
-#ifdef MI355X_EXP_EPI_INCR
-  // EXPERIMENT (off by default, not yet measured; DESIGN.md worklist item 3): without a row map the rows of one thread are
+  // Without a row map the rows of one thread are
   // ROW_STEP apart, so every address is (per-thread base, computed once) + it * (uniform stride, scalar unit) instead of a
   // 64-bit multiply-add per row and tensor (v_mad_u64_u32 + 2 x v_mul_lo_u32, quarter rate)
   // (the row map is only ever combined with EPI_MUL_POS -- the four conv2 input-gradient GEMMs; for every other epilogue
-  // kind `lin` is a compile-time constant and the mapped path is not emitted at all)
+  // kind `lin` is a compile-time constant and the mapped path is not emitted at all).  Same-box A/B: -1 % on the FFN shapes.
   const bool lin = (EPI != EPI_MUL_POS) || !p.r_on;
   const long long ci_l = coff + (long long)m_first * p.ldc + n, ai_l = coff + (long long)m_first * p.ldaux + n;
   const long long ci_s = (long long)ROW_STEP * p.ldc, ai_s = (long long)ROW_STEP * p.ldaux;
   const uint32_t db_l = dbase + (uint32_t)m_first * (uint32_t)p.N, db_s = (uint32_t)ROW_STEP * (uint32_t)p.N;
-#endif
   float aux[AUX_IN ? ITERS : 1][8];
   if (AUX_IN) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int m = m_first + it * ROW_STEP;
-#ifdef MI355X_EXP_EPI_INCR
       const long long ai0 = lin ? ai_l + it * ai_s : coff + crow(p, m) * p.ldaux + n;
       if (m < p.M) ld8x(p.aux_in, ai0, EPI == EPI_RESID ? MI_DT_F32 : p.auxin_dt, aux[it]);
-#else
-      if (m < p.M) ld8x(p.aux_in, coff + crow(p, m) * p.ldaux + n, EPI == EPI_RESID ? MI_DT_F32 : p.auxin_dt, aux[it]);
-#endif
     }
   }
 #pragma unroll
@@ -238,16 +232,9 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
     const float4 b = *reinterpret_cast<const float4*>(src + 4);
     float v[8] = {a.x + b8[0], a.y + b8[1], a.z + b8[2], a.w + b8[3], b.x + b8[4], b.y + b8[5], b.z + b8[6], b.w + b8[7]};
     float dm[8];
-#ifdef MI355X_EXP_EPI_INCR
     drop_mask8(p.drop, db_l + (uint32_t)it * db_s, dm);
     const long long ci = lin ? ci_l + it * ci_s : coff + crow(p, m) * p.ldc + n;
     const long long ai = lin ? ai_l + it * ai_s : coff + crow(p, m) * p.ldaux + n;
-#else
-    drop_mask8(p.drop, dbase + (uint32_t)m * (uint32_t)p.N, dm);
-    const long long mr = crow(p, m);
-    const long long ci = coff + mr * p.ldc + n;
-    const long long ai = coff + mr * p.ldaux + n;
-#endif
     if (EPI == EPI_STORE) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= p.alpha * dm[j];
@@ -697,19 +684,13 @@ __device__ __forceinline__ bf16x8 frag_v2(const bf16_t* tile, int row_tile, int 
 // body of the 256x128 structure: workgroup `bid` of the problem's tile grid, K slice `kslice`, batch index `z`
 template <bool TA, bool TB>
 __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, const int bid, const int kslice, const int z
-#ifdef MI355X_EXP_GROUPED_XCD
                                              , const bool direct = false
-#endif
 ) {
   const int tn = (p.N + BN - 1) / BN, tm = (p.M + BM2 - 1) / BM2;
   const int ntiles = tm * tn;
   const int q8 = ntiles >> 3, r8 = ntiles & 7;
   const int xcd = bid & 7, idx = bid >> 3;
-#ifdef MI355X_EXP_GROUPED_XCD
   const int logical = direct ? bid : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-#else
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-#endif
   const int tile_m = logical / tn, tile_n = logical - tile_m * tn;
   const int m0 = tile_m * BM2, n0 = tile_n * BN;
   const int z0 = z % p.nb0, z1 = z / p.nb0;
@@ -1003,8 +984,7 @@ struct GroupP {
 __global__ __launch_bounds__(512) void gemm_bf16_grouped_tn_kernel(GroupP g) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem2[];
   int pi = 0;
-#ifdef MI355X_EXP_GROUPED_XCD
-  // EXPERIMENT (off by default, not yet measured; DESIGN.md worklist item 7): the launch reads 1.36 GB for ~0.5 GB of unique
+  // The launch read 1.36 GB for ~0.5 GB of unique
   // operands because the tiles of one (problem, K slice) -- which share both operand panels -- are dealt round-robin over
   // the 8 XCDs (8 private L2s).  Here the (problem, K slice) groups are laid out one after the other and every XCD takes a
   // contiguous eighth of that sequence: the tiles running together on an XCD belong to the same group.
@@ -1017,9 +997,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_grouped_tn_kernel(GroupP g) {
   const int ntile_p = g.tile_begin[pi + 1] - g.tile_begin[pi];
   const int rel = w - g.splitk * g.tile_begin[pi];
   const int exp_ks = rel / ntile_p, exp_tile = rel - exp_ks * ntile_p;
-#else
-  while (pi + 1 < g.n && (int)blockIdx.x >= g.tile_begin[pi + 1]) ++pi;  // uniform
-#endif
   GemmP p;
   p.A = g.A[pi]; p.B = g.B[pi]; p.C = g.C[pi];
   p.M = g.M[pi]; p.N = g.N[pi]; p.K = g.K;
@@ -1033,11 +1010,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_grouped_tn_kernel(GroupP g) {
   p.splitk = g.splitk; p.ktiles_per_split = g.ktiles_per_split;
   p.colsum_stride = 0; p.colsum_out = g.colsum[pi];
   p.vec_ok = 0; p.g_on = 0; p.r_on = 0;
-#ifdef MI355X_EXP_GROUPED_XCD
   gemm_v2_body<true, true>(p, smem2, exp_tile, exp_ks, 0, /*direct=*/true);
-#else
-  gemm_v2_body<true, true>(p, smem2, (int)blockIdx.x - g.tile_begin[pi], blockIdx.y, 0);
-#endif
 }
 
 // =================================================================================================
@@ -1092,7 +1065,9 @@ __device__ __forceinline__ void v4_round_out(const GemmP& p, const float* sC, in
   }
 }
 
-template <bool TA, bool TB>
+// G: 0 = dense operands, 1 = gathered A rows (conv forward / dgrad), 2 = gathered reduction-major B (conv weight gradient):
+// compile-time, so that each instantiation carries only its own DMA state (128 accumulator registers leave little room).
+template <bool TA, bool TB, int G>
 __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem4[];  // 2 stages x 64 KiB
   const int tn = (p.N + BN4 - 1) / BN4, tm = (p.M + BM2 - 1) / BM2;
@@ -1131,19 +1106,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
   DmaSrc<BM2> dA;
   DmaSrc<BN4> dB;
   DmaGather<BM2> gA;
-  const bool gatherA = !TA && p.g_on == 1;
-  if (gatherA) gather_setup<BM2>(gA, p, A, m0);
+  constexpr bool gatherA = !TA && G == 1;
+  if constexpr (gatherA) gather_setup<BM2>(gA, p, A, m0);
   else dma_setup<TA, BM2>(dA, A, p.lda, m0, p.M, kt0 * BK);
   DmaGatherT<BN4> gB;
-  const bool gatherB = TB && p.g_on == 2;
-  if (gatherB) gatherT_setup<BN4>(gB, p, n0, p.N, kt0 * BK);
+  constexpr bool gatherB = TB && G == 2;
+  if constexpr (gatherB) gatherT_setup<BN4>(gB, p, n0, p.N, kt0 * BK);
   else dma_setup<TB, BN4>(dB, B, p.ldb, n0, p.N, kt0 * BK);
   const bool ktail = (p.K & (BK - 1)) != 0;
   auto issue = [&](int it) {
     bf16_t* st = smem4 + (it & 1) * NT4_STAGE;
-    if (gatherA) gather_issue<BM2>(gA, p, kt0 + it, st);
+    if constexpr (gatherA) gather_issue<BM2>(gA, p, kt0 + it, st);
     else dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
-    if (gatherB) gatherT_issue<BN4>(gB, p, (const bf16_t*)p.B, z0, st + BM2 * BK);
+    if constexpr (gatherB) gatherT_issue<BN4>(gB, p, (const bf16_t*)p.B, z0, st + BM2 * BK);
     else dma_issue<BN4>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
   const int cs_step = tn < 8 ? tn : 8;  // column-sum rows dealt round-robin to the workgroups sharing this A tile
@@ -1158,32 +1133,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
     if (it + 1 < nk) issue(it + 1);  // other stage: every wave passed the barrier after its last read of it
     const bf16_t* a_s = smem4 + (it & 1) * NT4_STAGE;
     const bf16_t* b_s = a_s + BM2 * BK;
-#ifdef MI355X_EXP_V4_PIPE
-    // EXPERIMENT (off by default, not yet measured; DESIGN.md worklist item 2): the compiler's own schedule of the loop
-    // below issues the fragment reads 2-3 at a time right in front of the MFMAs that consume them.  Here the six reads
-    // of k-step kk+1 go out as one burst under the eight MFMAs of k-step kk (two fragment sets, +24 registers).
-    {
-      bf16x8 af[2][4], bfr[2][2];
-      auto rd = [&](const int kk, const int s_) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bfr[s_][j] = frag_v2<TB, BN4>(b_s, wn * 64 + j * 32, kk, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[s_][i] = frag_v2<TA, BM2>(a_s, wm * 128 + i * 32, kk, lane);
-      };
-      rd(0, 0);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        if (kk < 3) rd(kk + 1, (kk + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#else
+    // (measured: pipelining these reads one k-step ahead with inline-asm counted waits -- 12 reads in flight under the 8 MFMAs
+    //  of the previous k-step -- changes nothing, 1060 vs 1070 TFLOP/s at 8192^3: the loop is not bound by fragment-read
+    //  latency.  profiles/r2_gemm_structures.md)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 af[4], bfr[2];
@@ -1197,7 +1149,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-#endif
     if (TA && do_colsum) {  // thread -> (k-group of 8 rows = wave, 4 consecutive columns = lane)
       const int col = lane * 4;
       for (int kr = tile_n; kr < 8; kr += cs_step) {
@@ -1265,23 +1216,68 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
 //   * the rounds go through a WAVE-PRIVATE LDS window (8 rows x 64 columns f32, XOR-swizzled so that ds_write_b32 and
 //     ds_read_b64 are conflict-free): accumulator layout (lane = column) -> row layout (lane = 8 consecutive columns), so
 //     global accesses are 16/32 B per lane and 128/256 B per row, no workgroup barrier involved;
-//   * the two wave halves run the iteration in OPPOSITE order -- waves 0-3: fragment reads + 16 MFMAs, then their epilogue
-//     round; waves 4-7: epilogue round first, then reads + MFMAs.  Waves w and w+4 share a SIMD, so at any time one of the
-//     pair feeds the matrix pipe while the other one uses the VALU / LDS / store path;
+//   * fragment reads run one k-step ahead of the MFMAs (inline asm, counted lgkmcnt), aux_in (residual / pre-activation) of a
+//     round is fetched one iteration ahead by inline-asm loads covered by the iteration's counted vmcnt -- an ordinary load
+//     or a compiler-visible LDS read next to LDS-DMA in flight makes hipcc wait vmcnt(0) and drain the operand pipeline;
 //   * the LDS-DMA ring (three 48-KiB stages, two K-tiles ahead, counted vmcnt) runs ACROSS tile boundaries: the first two
 //     K-tiles of the next tile are in flight during the last two iterations of the current one.
-// LDS: 3 x 48 KiB + 8 x 2 KiB windows = exactly the 160 KiB of the CU.
-// Results are bit-identical to the 256x128 structure (same k order, same epilogue arithmetic).
+// LDS: 3 x 48 KiB + 8 x 2 KiB windows = exactly the 160 KiB of the CU.  Same products in the same k order as the tiled
+// structures; the bias enters the sum first (accumulators start from it) instead of last.
+// What it buys, measured same-box against the 256x256 / 256x128 structures (profiles/r2_gemm_structures.md): the window
+// transposition is free (hidden), the stores cost 4-9 us and the Swish / dropout arithmetic 19 us of a 63-us FFN1 launch
+// whether or not a SIMD's second wave is multiplying meanwhile (running the two wave halves in opposite order was 8 %
+// SLOWER); net -6 % on the Swish-gradient epilogue, -3 % on N = 1536 stores, +-0 on Swish forward, slower for K >= 1024
+// (its K loop runs at the 256x128 rate).  The dispatcher uses it where it wins.
 // =================================================================================================
 #define V5_WIN (8 * 64)                                    // floats per wave window
 #define V5_LDS_BYTES (3 * NT2_STAGE * 2 + 8 * V5_WIN * 4)  // 163 840
 
+// LDS byte addresses of a lane's window accesses (loop-invariant, 8 registers).  The window accesses are INLINE ASM: the
+// compiler orders every LDS read it can see behind ALL LDS-DMA in flight (it cannot tell the window from the operand
+// stages) and would put `s_waitcnt vmcnt(0)` in front of the window reads -- draining the operand pipeline every iteration.
+// One wave's DS operations execute in order, so its reads see its own writes without a wait in between.
+struct V5Win { uint32_t wa[4], ra[4]; int oc, oa, od; };  // + per-lane element offsets (row lane>>3, column chunk) into C / aux / index space
+__device__ __forceinline__ void v5_win_setup(V5Win& w, const GemmP& p, const float* win, const int lane) {
+  w.oc = (lane >> 3) * (int)p.ldc + (lane & 7) * 8;
+  w.oa = (lane >> 3) * (int)p.ldaux + (lane & 7) * 8;
+  w.od = (lane >> 3) * p.N + (lane & 7) * 8;
+  const uint32_t base = (uint32_t)(uintptr_t)(lds_void_t*)win;
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w.wa[e] = base + 4u * (uint32_t)((4 * lh + e) * 64 + (lr ^ (2 * e)));  // column 32 + lr: +128 B
+  const int wr = lane >> 3, c8 = (lane & 7) * 8, sw = 2 * (wr & 3);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w.ra[k] = base + 4u * (uint32_t)(wr * 64 + ((c8 + 2 * k) ^ sw));
+}
+
+// aux_in (residual stream, f32 / Swish pre-activation, bf16) of one round, fetched ONE ITERATION AHEAD by inline-asm loads:
+// an ordinary load would make the compiler wait `vmcnt(0)` at its first use inside the round -- draining the operand DMA.
+// The loads are issued ahead of the iteration's DMA, so the counted wait that ends the iteration covers them.
+template <int EPI>
+__device__ __forceinline__ void v5_aux_issue(const GemmP& p, u32x4 (&aux)[2], const int r, const int m_blk, const int n_blk,
+                                             const int lane) {
+  if (EPI != EPI_RESID && EPI != EPI_DSWISH) return;
+  // ONE unconditional issue site per variable, operands tied in/out ("+v"): the compiler believes an asm output is valid at
+  // the end of the statement, so any copy it makes of it (merging two issue sites, an exec-masked branch ...) happens BEFORE
+  // the data lands and leaves a register the load later overwrites (seen: memory faults).  Rows past M read row M-1.
+  int m = m_blk + (r >> 2) * 32 + 8 * (r & 3) + (lane >> 3);
+  m = m < p.M ? m : p.M - 1;
+  const long long ai = (long long)m * p.ldaux + n_blk + (lane & 7) * 8;
+  if (EPI == EPI_RESID) {
+    const float* src = (const float*)p.aux_in + ai;
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                 : "+v"(aux[0]), "+v"(aux[1]) : "v"(src) : "memory");
+  } else {
+    const bf16_t* src = (const bf16_t*)p.aux_in + ai;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(aux[0]) : "v"(src) : "memory");
+  }
+}
+
 // one 8-row epilogue round of a wave's 64x64 block of the PREVIOUS tile.  r = 0..7: accumulators [r>>2][*], registers
 // 4*(r&3) .. +3 of each  <->  block rows (r>>2)*32 + 8*(r&3) + 0..7
 template <int EPI>
-__device__ __forceinline__ void v5_round(const GemmP& p, float* win, const f32x16 (&acc)[2][2], const int r, const int m_blk,
-                                         const int n_blk, const float (&b8)[8], const int lane) {
-  const int lr = lane & 31, lh = lane >> 5;
+__device__ __forceinline__ void v5_round(const GemmP& p, const V5Win& w, const f32x16 (&acc)[2][2], const int r, const int m_blk,
+                                         const int n_blk, const u32x4 (&aux)[2], const int lane) {
   f32x4 t0, t1;  // columns lr (j = 0) and 32 + lr (j = 1), rows 4*lh + 0..3 of the round
 #define V5_PICK(i, q)                                                                                       \
   t0 = f32x4{acc[i][0][4 * q], acc[i][0][4 * q + 1], acc[i][0][4 * q + 2], acc[i][0][4 * q + 3]};         \
@@ -1299,26 +1295,27 @@ __device__ __forceinline__ void v5_round(const GemmP& p, float* win, const f32x1
 #undef V5_PICK
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int wr = 4 * lh + e, sw = 2 * (wr & 3);
-    win[wr * 64 + (lr ^ sw)] = t0[e];
-    win[wr * 64 + ((32 + lr) ^ sw)] = t1[e];
+    asm volatile("ds_write_b32 %0, %1" ::"v"(w.wa[e]), "v"(t0[e]) : "memory");
+    asm volatile("ds_write_b32 %0, %1 offset:128" ::"v"(w.wa[e]), "v"(t1[e]) : "memory");
   }
   // row layout: lane -> window row lane>>3, columns 8*(lane&7) .. +7 (four conflict-free ds_read_b64)
-  const int wr = lane >> 3, c8 = (lane & 7) * 8, sw = 2 * (wr & 3);
+  const int wr = lane >> 3, c8 = (lane & 7) * 8;
   float v[8];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float2 x = *reinterpret_cast<const float2*>(win + wr * 64 + ((c8 + 2 * k) ^ sw));
-    v[2 * k] = x.x; v[2 * k + 1] = x.y;
+  {
+    mi_f32x2 x0, x1, x2, x3;
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+                 : "v"(w.ra[0]), "v"(w.ra[1]), "v"(w.ra[2]), "v"(w.ra[3])
+                 : "memory");
+    v[0] = x0[0]; v[1] = x0[1]; v[2] = x1[0]; v[3] = x1[1]; v[4] = x2[0]; v[5] = x2[1]; v[6] = x3[0]; v[7] = x3[1];
   }
-  const int m = m_blk + (r >> 2) * 32 + 8 * (r & 3) + wr;
-  if (m >= p.M) return;
-  const int n = n_blk + c8;
-  const long long ci = (long long)m * p.ldc + n, ai = (long long)m * p.ldaux + n;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] += b8[j];
-  float dm[8];
-  drop_mask8(p.drop, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, dm);
+  // addresses: (uniform first row of the round) x pitch on the scalar unit + a loop-invariant per-lane offset -- no
+  // per-lane 64-bit multiplies (quarter rate); M x pitch < 2^31 by contract
+  const int mu = __builtin_amdgcn_readfirstlane(m_blk + (r >> 2) * 32 + 8 * (r & 3));
+  if (mu + wr >= p.M) return;
+  const long long ci = (long long)(mu * (int)p.ldc + n_blk + w.oc), ai = (long long)(mu * (int)p.ldaux + n_blk + w.oa);
+  float dm[8];  // (the bias is already in the accumulators: they start from it, see the tile switch)
+  drop_mask8(p.drop, (uint32_t)(mu * p.N + n_blk + w.od), dm);
   if (EPI == EPI_STORE) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= p.alpha * dm[j];
@@ -1327,15 +1324,14 @@ __device__ __forceinline__ void v5_round(const GemmP& p, float* win, const f32x1
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * dm[j];
   } else if (EPI == EPI_RESID) {
-    float a[8];
-    ld8x(p.aux_in, ai, MI_DT_F32, a);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = a[j] + p.alpha * v[j] * dm[j];
-  } else {  // EPI_DSWISH
-    float a[8];
-    ld8x(p.aux_in, ai, p.auxin_dt, a);
+    for (int j = 0; j < 8; ++j) v[j] = __uint_as_float(aux[j >> 2][j & 3]) + p.alpha * v[j] * dm[j];
+  } else {  // EPI_DSWISH (aux_in bf16)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = v[j] * dm[j] * swish_grad(a[j]);
+    for (int j = 0; j < 4; ++j) {
+      v[2 * j] = v[2 * j] * dm[2 * j] * swish_grad(__uint_as_float(aux[0][j] << 16));
+      v[2 * j + 1] = v[2 * j + 1] * dm[2 * j + 1] * swish_grad(__uint_as_float(aux[0][j] & 0xffff0000u));
+    }
   }
   st8x(p.C, ci, p.c_dt, v);
 }
@@ -1346,8 +1342,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_v5_kernel(GemmP p, const int nt
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const bool epi_first = wave >= 4;  // the younger half runs its epilogue round ahead of its MFMAs
-  float* win = reinterpret_cast<float*>(smem5 + 3 * NT2_STAGE) + wave * V5_WIN;
+  // store instructions per lane and round (16 bytes each): C, plus the pre-activation of the Swish epilogue
+  const int st_per_round = (p.c_dt == MI_DT_F32 ? 2 : 1) + (EPI == EPI_SWISH_DROP ? (p.auxout_dt == MI_DT_F32 ? 2 : 1) : 0);
+  V5Win W5;
+  v5_win_setup(W5, p, reinterpret_cast<const float*>(smem5 + 3 * NT2_STAGE) + wave * V5_WIN, lane);
+  // LDS byte addresses of the A fragment reads in stage 0 per k-step (XOR swizzle: non-affine in kk); B = A + pipe5_b
+  uint32_t pipe5[4];
+  const uint32_t pipe5_b = (uint32_t)(BM2 * BK * 2 + ((wn * 64) - (wm * 64)) * 128);
+  {
+    const uint32_t base = (uint32_t)(uintptr_t)(lds_void_t*)smem5;
+    const int lr = lane & 31, lh = lane >> 5, x = (lr >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) pipe5[kk] = base + (uint32_t)((wm * 64 + lr) * 128) + (uint32_t)(((kk * 2 + lh) ^ x) << 4);
+  }
 
   // tiles of this workgroup: XCD x = blockIdx & 7 owns a contiguous chunk of the (row-major) tile list, its gridDim/8
   // workgroups take the chunk's tiles round-robin -- the tiles in flight on one XCD are consecutive (same A panels, all of B)
@@ -1363,120 +1370,189 @@ __global__ __launch_bounds__(512) void gemm_bf16_v5_kernel(GemmP p, const int nt
   const bf16_t* A = (const bf16_t*)p.A;
   const bf16_t* B = (const bf16_t*)p.B;
 
-  // ---- LDS-DMA cursor: runs two K-tiles ahead of the compute cursor, across tile boundaries
-  DmaSrc<BM2> dA;
-  DmaSrc<BN> dB;
+  // ---- LDS-DMA cursor: runs two K-tiles ahead of the compute cursor, across tile boundaries.  Per thread only a 32-bit
+  // element offset per 16-byte chunk is kept (6 registers for both operands; M * K and N * K < 2^31 by contract)
+  int oA[4], oB[2];
   int d_tile = 0, d_kt = 0, d_stage = 0;
   auto dma_next = [&]() {
     if (d_kt == 0) {
       const int L = chunk0 + slot + d_tile * nslot;
       const int tile_m = L / tn, tile_n = L - tile_m * tn;
-      dma_setup<false, BM2>(dA, A, p.lda, tile_m * BM2, p.M, 0);
-      dma_setup<false, BN>(dB, B, p.ldb, tile_n * BN, p.N, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = threadIdx.x + i * 512;
+        const int r = q >> 3, gck = (q & 7) ^ ((r >> 1) & 7);
+        int gr = tile_m * BM2 + r;
+        gr = gr < p.M ? gr : p.M - 1;  // rows past the matrix are clamped (never stored)
+        oA[i] = gr * (int)p.lda + gck * 8;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = threadIdx.x + i * 512;
+        const int r = q >> 3, gck = (q & 7) ^ ((r >> 1) & 7);
+        oB[i] = (tile_n * BN + r) * (int)p.ldb + gck * 8;  // N % 128 == 0: every row exists
+      }
     }
     bf16_t* st = smem5 + d_stage * NT2_STAGE;
-    dma_issue<BM2>(dA, d_kt, d_kt * BK, p.K, ktail, st);
-    dma_issue<BN>(dB, d_kt, d_kt * BK, p.K, ktail, st + BM2 * BK);
+    const int k0 = d_kt * BK;
+    const bool tail = ktail && (k0 + BK > p.K);  // uniform: only the last K-tile of a ragged K tests its chunks
+    const int kin = (((threadIdx.x & 7) ^ ((threadIdx.x >> 4) & 7)) << 3);  // (q & 7) ^ ((r >> 1) & 7), same for every i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16_t* src = A + (long long)(oA[i] + k0);
+      if (tail) src = (k0 + kin < p.K) ? src : reinterpret_cast<const bf16_t*>(g_zero16);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(st + (wave * 64 + i * 512) * 8), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16_t* src = B + (long long)(oB[i] + k0);
+      if (tail) src = (k0 + kin < p.K) ? src : reinterpret_cast<const bf16_t*>(g_zero16);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(st + BM2 * BK + (wave * 64 + i * 512) * 8), 16, 0, 0);
+    }
     d_stage = d_stage == 2 ? 0 : d_stage + 1;
     if (++d_kt == nk) { d_kt = 0; ++d_tile; }
   };
 
-  f32x16 acc[2][2], accP[2][2];
+  // two accumulator sets in FIXED registers: the tile loop is unrolled by two with the roles swapped (a copy "previous =
+  // current" at the tile switch turns into register shuffling on every iteration: measured 18 VALU instructions per MFMA)
+  f32x16 accA[2][2], accB[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accP[i][j][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { accA[i][j][r] = 0.f; accB[i][j][r] = 0.f; }
 
   dma_next();
   if (total > 1) dma_next();
   if (total > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  int it = 0, c_tile = 0, c_stage = 0;
+  int g = 0, c_tile = 0, c_stage = 0;
   int m_cur, n_cur, m_prev = 0, n_prev = 0;
   bool have_prev = false;
-  float b8[8];
   {
     const int L = chunk0 + slot;
     const int tile_m = L / tn, tile_n = L - tile_m * tn;
     m_cur = tile_m * BM2 + wm * 64; n_cur = tile_n * BN + wn * 64;
   }
-  auto load_bias = [&](const int n_blk) {
-    if (p.bias) ld8x(p.bias, n_blk + (lane & 7) * 8, MI_DT_F32, b8);
-    else {
+  // The accumulators of a tile START from its bias (two values per lane in the accumulator layout: columns lr and 32 + lr
+  // of the wave's block) instead of zero: no bias registers in the epilogue.  The next tile's pair is loaded one iteration
+  // before the tile switch, ahead of that iteration's DMA.
+  float bz0 = 0.f, bz1 = 0.f;
+  if (p.bias) { bz0 = p.bias[n_cur + (lane & 31)]; bz1 = p.bias[n_cur + 32 + (lane & 31)]; }
+  u32x4 auxc[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, auxn[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+
+  // one tile: K loop into `acc`, the previous tile's epilogue rounds out of `accP`
+  auto tile_pass = [&](auto& acc, auto& accP) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) b8[j] = 0.f;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][0][r] = bz0; acc[i][1][r] = bz1; }
+    for (int it = 0; it < nk; ++it, ++g) {
+      const bool more2 = g + 2 < total;
+      // aux_in of the round that runs in the NEXT iteration: round it+1 of the previous tile, or round 0 of the tile that
+      // is finishing in this iteration
+      {
+        int ar = -1, am = 0, an = 0;
+        if (it + 1 == nk) { if (g + 1 < total) { ar = 0; am = m_cur; an = n_cur; } }
+        else if (have_prev && it + 1 < 8) { ar = it + 1; am = m_prev; an = n_prev; }
+        if (ar >= 0) v5_aux_issue<EPI>(p, auxn, ar, am, an, lane);
+      }
+      if (p.bias && it == nk - 1 && c_tile + 1 < my_tiles) {
+        const int L = chunk0 + slot + (c_tile + 1) * nslot;
+        const int nn = (L % tn) * BN + wn * 64 + (lane & 31);
+        bz0 = p.bias[nn]; bz1 = p.bias[nn + 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (the DMA count below assumes nothing slips behind the DMA issue)
+      if (more2) dma_next();  // stage of iteration g-1: every wave passed the barrier after reading it
+      __builtin_amdgcn_sched_barrier(0);
+      const bool round = have_prev && it < 8;
+      {
+        // fragment reads one k-step ahead of the MFMAs, inline asm with counted waits (see the 256x256 structure)
+        const uint32_t sb = (uint32_t)(c_stage * (NT2_STAGE * 2));
+        bf16x8 fa[2][2], fb[2][2];
+#define V5_RD(S, KK)                                                                                              \
+  {                                                                                                               \
+    const uint32_t aa = pipe5[KK] + sb, ab = aa + pipe5_b;                                                        \
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\tds_read_b128 %2, %5\n\t"              \
+                 "ds_read_b128 %3, %5 offset:4096"                                                                \
+                 : "=&v"(fa[S][0]), "=&v"(fa[S][1]), "=&v"(fb[S][0]), "=&v"(fb[S][1])                             \
+                 : "v"(aa), "v"(ab)                                                                               \
+                 : "memory");                                                                                     \
+  }
+#define V5_WAIT(N, S)                                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fb[S][0]), "+v"(fb[S][1]) : : "memory"); \
+  __builtin_amdgcn_sched_barrier(0)
+#define V5_MM(S)                                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i], fb[S][j], acc[i][j], 0, 0, 0);                \
+  __builtin_amdgcn_sched_barrier(0)
+        V5_RD(0, 0);
+        V5_RD(1, 1); V5_WAIT(4, 0); V5_MM(0);
+        V5_RD(0, 2); V5_WAIT(4, 1); V5_MM(1);
+        V5_RD(1, 3); V5_WAIT(4, 0); V5_MM(0);
+        V5_WAIT(0, 1); V5_MM(1);
+#undef V5_RD
+#undef V5_WAIT
+#undef V5_MM
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (round) v5_round<EPI>(p, W5, accP, it, m_prev, n_prev, auxc, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      // tile g+1 must have landed (this wave's share) before the barrier publishes it.  vmcnt counts in order and counts
+      // stores: younger than that tile's DMA are the 6 DMA instructions of tile g+2 (if issued) and the store
+      // instructions this wave issued in this iteration's round -- `nst` of them, none when the round's 8 rows lie past M
+      // (the branch around an all-inactive store is taken).  Waiting for FEWER outstanding operations than that is always
+      // safe, for more never.
+      {
+        const int nst = (round && m_prev + (it >> 2) * 32 + 8 * (it & 3) < p.M) ? st_per_round : 0;
+        if (more2) {
+          switch (nst) {
+            case 0: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+          }
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (EPI == EPI_RESID || EPI == EPI_DSWISH) {
+        // the prefetched aux_in has landed (it is older than the DMA just waited for); the asm touch pins the register
+        // copy behind the wait (a register-only move may otherwise be scheduled above an asm statement)
+        asm volatile("" : "+v"(auxn[0]), "+v"(auxn[1]));
+        auxc[0] = auxn[0]; auxc[1] = auxn[1];
+      }
+      __builtin_amdgcn_s_barrier();
+      c_stage = c_stage == 2 ? 0 : c_stage + 1;
+    }
+    // tile finished: its accumulators are the "previous" set of the next pass
+    m_prev = m_cur; n_prev = n_cur; have_prev = true;
+    ++c_tile;
+    if (c_tile < my_tiles) {
+      const int L = chunk0 + slot + c_tile * nslot;
+      const int tile_m = L / tn, tile_n = L - tile_m * tn;
+      m_cur = tile_m * BM2 + wm * 64; n_cur = tile_n * BN + wn * 64;
     }
   };
-#pragma unroll
-  for (int j = 0; j < 8; ++j) b8[j] = 0.f;
-
-  for (int g = 0; g < total; ++g) {
-    const bool more2 = g + 2 < total;
-    if (more2) dma_next();  // stage of iteration g-1: every wave passed the barrier after reading it
-    __builtin_amdgcn_sched_barrier(0);
-    const bool round = have_prev && it < 8;
-    if (round && epi_first) v5_round<EPI>(p, win, accP, it, m_prev, n_prev, b8, lane);
-    {
-      const bf16_t* a_s = smem5 + c_stage * NT2_STAGE;
-      const bf16_t* b_s = a_s + BM2 * BK;
-      bf16x8 af[4][2], bfr[4][2];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          af[kk][i] = frag_v2<false, BM2>(a_s, wm * 64 + i * 32, kk, lane);
-          bfr[kk][i] = frag_v2<false, BN>(b_s, wn * 64 + i * 32, kk, lane);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (round && !epi_first) v5_round<EPI>(p, win, accP, it, m_prev, n_prev, b8, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    // tile g+1 must have landed (this wave's share) before the barrier publishes it.  vmcnt counts in order and counts
-    // stores: younger than that tile's DMA are at most the 6 DMA instructions of tile g+2 and this round's stores
-    // (waiting for fewer outstanding operations than strictly necessary is always safe)
-    if (more2) {
-      if (round) {
-        if (EPI == EPI_STORE || EPI == EPI_DSWISH) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // two stores per lane and round (aux_out + C, or f32 C)
-      } else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    c_stage = c_stage == 2 ? 0 : c_stage + 1;
-    if (++it == nk) {  // tile finished: its accumulators become the "previous" set, the next tile starts from zero
-      it = 0;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          accP[i][j] = acc[i][j];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        }
-      m_prev = m_cur; n_prev = n_cur; have_prev = true;
-      load_bias(n_prev);
-      ++c_tile;
-      if (c_tile < my_tiles) {
-        const int L = chunk0 + slot + c_tile * nslot;
-        const int tile_m = L / tn, tile_n = L - tile_m * tn;
-        m_cur = tile_m * BM2 + wm * 64; n_cur = tile_n * BN + wn * 64;
-      }
-    }
-  }
   // ---- the last tile's epilogue has nothing to hide behind
+  auto tail = [&](auto& accP) __attribute__((always_inline)) {
 #pragma unroll 1
-  for (int r = 0; r < 8; ++r) v5_round<EPI>(p, win, accP, r, m_prev, n_prev, b8, lane);
+    for (int r = 0; r < 8; ++r) {
+      if (EPI == EPI_RESID || EPI == EPI_DSWISH) {
+        v5_aux_issue<EPI>(p, auxc, r, m_prev, n_prev, lane);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(auxc[0]), "+v"(auxc[1]) : : "memory");
+      }
+      v5_round<EPI>(p, W5, accP, r, m_prev, n_prev, auxc, lane);
+    }
+  };
+  while (true) {
+    tile_pass(accA, accB);
+    if (c_tile == my_tiles) { tail(accA); break; }
+    tile_pass(accB, accA);
+    if (c_tile == my_tiles) { tail(accB); break; }
+  }
 }
 
 // =================================================================================================
@@ -1542,6 +1618,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 // =================================================================================================
 // C ABI
 // =================================================================================================
+static int g_v5_mode = -1;  // MI355X_GEMM_V5 / mi355x_gemm_config(5, .): 0 = never use the persistent structure, 1 = default
+extern "C" int mi355x_gemm_config(int key, int value) {
+  if (key != 5) return -1;
+  const int old = g_v5_mode;
+  g_v5_mode = value;
+  return old;
+}
+
 extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   mi_clear_errors();
   if (!d || !d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0) return MI_ERR_ARG;
@@ -1646,12 +1730,16 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
       dim3 grid2(tm2 * tn, sk, p.batch);
       // persistent 256x128 structure with the epilogue overlapped into the next tile's K loop: the Conformer block's
       // forward / dgrad GEMMs (dense NT, full-width vector epilogue, K >= 8 K-tiles, at least one tile per CU)
-      static int v5_mode = -1;  // MI355X_GEMM_V5: 0 = never, 1 = default
-      if (v5_mode < 0) { const char* e = getenv("MI355X_GEMM_V5"); v5_mode = e ? atoi(e) : 1; }
-      const bool v5_epi = p.epi == EPI_STORE || p.epi == EPI_SWISH_DROP || (p.epi == EPI_RESID && p.c_dt == MI_DT_F32) ||
-                          p.epi == EPI_DSWISH;
+      if (g_v5_mode < 0) { const char* e = getenv("MI355X_GEMM_V5"); g_v5_mode = e ? atoi(e) : 1; }
+      const int v5_mode = g_v5_mode;
+      // v5_mode 1: where it measured faster than the tiled structures (K <= 576: Swish-gradient, residual, and stores at
+      // least 1536 columns wide); 2: every shape it can run (tests, A/B)
+      const bool v5_epi = (p.epi == EPI_STORE && (v5_mode == 2 || p.N >= 1536)) || (p.epi == EPI_SWISH_DROP && v5_mode == 2) ||
+                          (p.epi == EPI_RESID && p.c_dt == MI_DT_F32) || (p.epi == EPI_DSWISH && p.auxin_dt == MI_DT_BF16);
       if (v5_mode && !p.transA && !p.transB && !p.g_on && !p.r_on && !p.atomic && p.batch == 1 && sk == 1 && (p.vec_ok & 1) &&
-          !(p.N % BN) && nk >= 8 && tm2 * tn >= 256 && v5_epi && !(p.epi == EPI_STORE && p.c_dt == MI_DT_F32 && false)) {
+          !(p.N % BN) && nk >= 8 && (nk <= 9 || v5_mode == 2) && tm2 * tn >= 256 && v5_epi && (long long)p.M * p.lda < (1LL << 31) &&
+          (long long)p.N * p.ldb < (1LL << 31) && (long long)p.M * p.ldc < (1LL << 31) &&
+          (long long)p.M * p.ldaux < (1LL << 31)) {
         static bool attr5_set = false;
         if (!attr5_set) {
           bool ok = hipFuncSetAttribute((const void*)gemm_bf16_v5_kernel<EPI_STORE>,
@@ -1688,20 +1776,24 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
       if ((v4_mode == 2 && p.N > 128) || (v4_mode == 1 && blocks4 >= 224 && waste_ok && eff4 >= 0.9 * eff2)) {
         const int shm4 = 2 * NT4_STAGE * 2;
         static bool attr4_set = false;
+        typedef void (*v4_fn)(GemmP);
+        static const v4_fn v4_all[] = {gemm_bf16_v4_kernel<false, false, 0>, gemm_bf16_v4_kernel<false, false, 1>,
+                                       gemm_bf16_v4_kernel<false, true, 0>, gemm_bf16_v4_kernel<true, true, 0>,
+                                       gemm_bf16_v4_kernel<true, true, 2>};
         if (!attr4_set) {
-          bool ok = hipFuncSetAttribute((const void*)gemm_bf16_v4_kernel<false, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, shm4) == hipSuccess;
-          ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v4_kernel<false, true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, shm4) == hipSuccess;
-          ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v4_kernel<true, true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, shm4) == hipSuccess;
-          if (!ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
+          for (v4_fn f : v4_all)
+            if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, shm4) != hipSuccess) {
+              (void)hipGetLastError();
+              return MI_ERR_LAUNCH;
+            }
           attr4_set = true;
         }
         dim3 grid4(tm2 * tn4, sk, p.batch);
-        if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_bf16_v4_kernel<false, false>), grid4, dim3(512), shm4, s, p);
-        else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_bf16_v4_kernel<false, true>), grid4, dim3(512), shm4, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_v4_kernel<true, true>), grid4, dim3(512), shm4, s, p);
+        v4_fn fn;
+        if (!p.transA && !p.transB) fn = v4_all[p.g_on == 1 ? 1 : 0];
+        else if (!p.transA && p.transB) fn = v4_all[2];
+        else fn = v4_all[p.g_on == 2 ? 4 : 3];
+        hipLaunchKernelGGL(fn, grid4, dim3(512), shm4, s, p);
       } else
       if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_bf16_v2_kernel<false, false>), grid2, dim3(512), shm, s, p);
       else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_bf16_v2_kernel<false, true>), grid2, dim3(512), shm, s, p);

@@ -56,6 +56,11 @@ NO_DROP = Dropout()
 GEMM_PROFILE = None
 
 
+def gemm_config(key: int, value: int) -> int:
+    """kernel-structure knob (tests / A-B benchmarks): key 5 = persistent overlapped-epilogue GEMM, 0 off / 1 default"""
+    return lib.mi355x_gemm_config(key, value)
+
+
 def wgrad_grouped(problems, rows, splitk):
     """problems: list of (dY, ldy, y_off, X, ldx, x_off, dW, n_out, n_in, bias_grad_or_None);
     dW[n_out, n_in] += dY[:, y_off:+n_out]^T @ X[:, x_off:+n_in] for all of them in ONE launch (bf16 in, f32 atomics)."""

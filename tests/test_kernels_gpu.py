@@ -1003,3 +1003,67 @@ def test_rnnt_loss_argument_checks():
         RNNTLoss()(a, lab.int(), lens, ll)
     with pytest.raises(RuntimeError):
         RNNTLoss()(a.cpu(), lab.cpu(), lens.cpu(), ll.cpu())
+
+
+@pytest.mark.parametrize("M,N,K", [(8000, 1024, 512), (16032, 2048, 512), (8200, 1024, 584), (16032, 1024, 2048)])
+def test_gemm_persistent_structure_matches_the_tiled_one(M, N, K):
+    """gemm_bf16_v5_kernel (persistent workgroups, epilogue of tile t inside the K loop of tile t+1, wave-private LDS windows,
+    counted vmcnt across tiles, inline-asm fragment / aux loads) against gemm_bf16_v2/v4 on the same inputs INCLUDING the regenerated dropout masks, for the
+    four epilogues it carries; ragged M (last tile partly / rounds wholly past M), K tail (584 = 9 K-tiles + 8), K = 2048
+    (rounds only in the first 8 of 32 iterations).  Five launches per case must agree bit for bit (no atomics in this
+    structure: any run-to-run difference would be a race between DMA, window and barrier)."""
+    o = ops()
+    g = torch.Generator().manual_seed(M + K)
+    A = bf(torch.randn(M, K, generator=g)).to(dev)
+    W = bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    pre = bf(torch.randn(M, N, generator=g)).to(dev)
+    drop = o.Dropout(0.1, 7, 3)
+
+    def run(kind):
+        if kind == "store":
+            c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            o.gemm(A, W, c, M, N, K, K, K, N, bias=bias, alpha=0.5, drop=drop)
+            return (c,)
+        if kind == "store_f32":
+            c = torch.empty(M, N, device=dev)
+            o.gemm(A, W, c, M, N, K, K, K, N, bias=bias)
+            return (c,)
+        if kind == "swish":
+            h = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            a = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            o.gemm(A, W, a, M, N, K, K, K, N, bias=bias, epi=o.EPI_SWISH_DROP, aux_out=h, drop=drop)
+            return (h, a)
+        if kind == "resid":
+            c = torch.empty(M, N, device=dev)
+            o.gemm(A, W, c, M, N, K, K, K, N, bias=bias, alpha=0.5, epi=o.EPI_RESID, aux_in=res, drop=drop)
+            return (c,)
+        if kind == "resid_inplace":
+            c = res.clone()
+            o.gemm(A, W, c, M, N, K, K, K, N, bias=bias, alpha=0.5, epi=o.EPI_RESID, aux_in=c, drop=drop)
+            return (c,)
+        c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        o.gemm(A, W, c, M, N, K, K, K, N, epi=o.EPI_DSWISH, aux_in=pre, drop=drop)
+        return (c,)
+
+    old = o.gemm_config(5, 1)
+    try:
+        for kind in ("store", "store_f32", "swish", "resid", "resid_inplace", "dswish"):
+            o.gemm_config(5, 0)
+            want = [t.float() for t in run(kind)]
+            o.gemm_config(5, 2)  # 2 = wherever the persistent structure can run (1 = only where it measured faster)
+            first = run(kind)
+            torch.cuda.synchronize()
+            for t, w_ in zip(first, want):
+                assert torch.isfinite(t).all(), kind
+                # same products, same k order; the bias enters the sum first instead of last: fp32 re-association only
+                assert rel_err(t, w_) < (5e-6 if t.dtype == torch.float32 else 5e-3), (kind, rel_err(t, w_))
+                assert (t.float() - w_).abs().max() <= 0.02 * w_.abs().max() , kind
+            for _ in range(4):
+                again = run(kind)
+                torch.cuda.synchronize()
+                for t, f in zip(again, first):
+                    assert torch.equal(t, f), (kind, "run-to-run difference")
+    finally:
+        o.gemm_config(5, old if old >= 0 else 1)

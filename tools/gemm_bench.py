@@ -36,13 +36,60 @@ def run(name, M, N, K, epi="store", out=bf, layout="NT", splitk=1):
     elif epi == "resid":
         R = torch.randn(M, N, device=dev); C = torch.empty(M, N, device=dev); d = ops.Dropout(0.1, 1, 2)
         f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, bias=bias, alpha=0.5, epi=ops.EPI_RESID, aux_in=R, drop=d, **kw)
+    elif epi == "dswish":
+        H = torch.randn(M, N, device=dev, generator=g).to(bf); d = ops.Dropout(0.1, 1, 3)
+        f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, epi=ops.EPI_DSWISH, aux_in=H, drop=d, **kw)
     elif epi == "atomic":
         C = torch.zeros(M, N, device=dev)
         f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, atomic=True, splitk=splitk, **kw)
     t = timeit(f)
     print(f"{name:34s} {layout} M={M:7d} N={N:5d} K={K:6d} epi={epi:7s} {t*1e6:9.1f} us  {2.0*M*N*K/t/1e12:8.1f} TFLOP/s", flush=True)
 
+def run_grouped(name, M=16032, d=512, dff=2048, splitk=4):
+    """one Conformer layer's ten weight gradients as ONE grouped TN launch (what the backward sequencer issues per layer)"""
+    if only and only not in name: return
+    g = torch.Generator(device=dev).manual_seed(0)
+    mk = lambda n: torch.randn(M, n, device=dev, generator=g).to(bf)
+    shapes = [(d, dff), (dff, d), (d, dff), (dff, d), (d, d), (d, d), (d, d), (d, d), (2 * d, d), (d, d)]  # (n_out, n_in)
+    probs = []
+    for n_out, n_in in shapes:
+        dY, X = mk(n_out), mk(n_in)
+        dW = torch.zeros(n_out, n_in, device=dev)
+        db = torch.zeros(n_out, device=dev)
+        probs.append((dY, n_out, 0, X, n_in, 0, dW, n_out, n_in, db))
+    t = timeit(lambda: ops.wgrad_grouped(probs, M, splitk))
+    fl = sum(2.0 * M * a * b for a, b in shapes)
+    print(f"{name:34s} TN grouped x{len(shapes)} M={M} splitk={splitk} {t*1e6:9.1f} us  {fl/t/1e12:8.1f} TFLOP/s", flush=True)
+
+
 M = 16032
+if os.environ.get("WGRAD_AB"):
+    for rep in range(int(os.environ.get("REPS", "3"))):
+        run_grouped("layer_wgrad_grouped_sk4", splitk=4)
+        run("conv2_wgrad_like", 512, 4608, 320640 // 4, "atomic", torch.float32, "TN", splitk=8)
+        run("ffn1_fwd_swish", M, 2048, 512, "swish")
+        run("ffn2_fwd_resid", M, 512, 2048, "resid")
+        run("proj_fwd_resid", M, 512, 512, "resid")
+        run("ffn1_dgrad_store", M, 512, 2048, "store")
+    sys.exit(0)
+if os.environ.get("PMC_SHAPES"):  # two shapes for counter collection (structure chosen by the MI355X_GEMM_* environment)
+    run("big_square_bias", 8192, 8192, 8192, "store")
+    run("ffn1_fwd_swish", M, 2048, 512, "swish")
+    sys.exit(0)
+if os.environ.get("V5_AB"):  # persistent overlapped-epilogue structure on / off, same process, interleaved
+    for rep in range(int(os.environ.get("REPS", "3"))):
+        for mode in (0, 2):
+            ops.gemm_config(5, mode)
+            tag = f"v5={mode} "
+            run(tag + "ffn1_fwd_swish", M, 2048, 512, "swish")
+            run(tag + "ffn2_dgrad_dswish", M, 2048, 512, "dswish")
+            run(tag + "qkv_fwd_store", M, 1536, 512, "store")
+            run(tag + "pw1_fwd_store", M, 1024, 512, "store")
+            run(tag + "resid_n1024_k2048", M, 1024, 2048, "resid")
+            run(tag + "store_n2048_k2048", M, 2048, 2048, "store")
+            run(tag + "pw1_dgrad_store_k1024", M, 512, 1024, "store")
+            run(tag + "resid_n1024_k512", M, 1024, 512, "resid")
+    sys.exit(0)
 run("ffn1_fwd", M, 2048, 512, "swish")
 run("ffn1_fwd_store", M, 2048, 512, "store")
 run("ffn1_fwd_nobias", M, 2048, 512, "nobias")
