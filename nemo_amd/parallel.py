@@ -38,6 +38,12 @@ class GradSync:
         # called as after_reduce(start, end) on the exchange stream right after a range's all-reduce has been enqueued
         # (stream-ordered behind it): the optimizer updates that slice while backward continues
         self.after_reduce = None
+        # diagnostics (bench.py): number of all-reduce launches of the last step, and -- with `profile` -- a pair of events
+        # around the compute stream's wait for the exchange stream = the exposed (non-overlapped) exchange time
+        self.launches_last_step = 0
+        self._launches = 0
+        self.profile = False
+        self.exposed_events = None
 
     # ---- called by the backward sequencer (ranges arrive in reverse-layer order, adjacent ranges are merged)
     def ready(self, start: int, end: int) -> None:
@@ -78,6 +84,7 @@ class GradSync:
                 else:
                     self._works.append(work)
             self._reduced.append((s, e))
+            self._launches += 1
         self._pending, self._pending_elems = [], 0
 
     def wait(self) -> float:
@@ -87,8 +94,17 @@ class GradSync:
             w.wait()
         self._works = []
         if self._stream is not None:
-            torch.cuda.current_stream(self.grad.device).wait_stream(self._stream)
+            cur = torch.cuda.current_stream(self.grad.device)
+            if self.profile:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self._stream)
+                e1.record(cur)
+                self.exposed_events = (e0, e1)
+            else:
+                cur.wait_stream(self._stream)
         self._reduced = []
+        self.launches_last_step, self._launches = self._launches, 0
         return 1.0 / self.world
 
     def reduced_ranges(self):
