@@ -108,6 +108,15 @@ int mi355x_im2col_3x3s2(const void* in /*[B,T1,F1,C]*/, void* col /*[B*T2*F2, 9C
 int mi355x_col2im_3x3s2_relu(const void* dcol, const void* act, void* din, int dtype, int B, int T1, int F1, int C,
                              void* stream);
 
+/* 'dw_striding' sub-sampling (FastConformer x8, Squeezeformer x4; subsampling.py:142-215): depthwise Conv2d(C, C, 3, stride 2,
+ * padding 1, groups = C) on a channels-last map in [B,T1,F1,C] -> out [B,T2,F2,C] (+ bias); w f32 [C,1,3,3].  The pointwise
+ * convolution + ReLU + time mask that follow are mi355x_gemm (EPI_RELU_MASK).  Backward: din = (in > 0) * dgrad (the ReLU of the
+ * previous stage), dw / dbias accumulated (+=); scratch f32 [min(1024, ceil(B*T2*F2/64)) * 10 * C]. */
+int mi355x_dwconv2d_s2_fwd(const void* in, const void* w, const void* bias, void* out, int dtype, int B, int T1, int F1, int C,
+                           void* stream);
+int mi355x_dwconv2d_s2_bwd(const void* dout, const void* in, const void* w, void* din, void* dw, void* dbias, int dtype, int B,
+                           int T1, int F1, int C, void* scratch, long long scratch_elems, void* stream);
+
 /* ---- LayerNorm (torch.nn.LayerNorm x5 per layer, conformer_modules.py:174-215) -------------------------------- */
 int mi355x_layernorm_fwd(const void* x, int x_dtype, const void* gamma, const void* beta, void* y, int y_dtype, void* mean,
                          void* rstd, int M, int d, float eps, void* stream);

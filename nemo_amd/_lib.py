@@ -66,6 +66,8 @@ SIGNATURES = {
     "mi355x_subsample_conv1_bwd": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp],
     "mi355x_im2col_3x3s2": [vp, vp, i32, i32, i32, i32, i32, vp],
     "mi355x_col2im_3x3s2_relu": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mi355x_dwconv2d_s2_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mi355x_dwconv2d_s2_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp],
     "mi355x_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp],
     "mi355x_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp],
     "mi355x_layernorm_bwd_cast": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, f32, u32, u32, f32, vp],

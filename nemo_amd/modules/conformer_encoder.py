@@ -78,18 +78,31 @@ class ConformerLayer(nn.Module):  # conformer_modules.py:35 (parameter layout on
         self.norm_out = nn.LayerNorm(d_model)
 
 
-class ConvSubsampling(nn.Module):  # subsampling.py:62 ('striding')
-    def __init__(self, subsampling_factor, feat_in, feat_out, conv_channels):
+class ConvSubsampling(nn.Module):  # subsampling.py:62 ('striding' :217-253 and 'dw_striding' :142-215; parameter layout only)
+    def __init__(self, subsampling, subsampling_factor, feat_in, feat_out, conv_channels):
         super().__init__()
+        self._subsampling = subsampling
         self.subsampling_factor = subsampling_factor
         self._conv_channels = conv_channels
-        self.conv = nn.Sequential(nn.Conv2d(1, conv_channels, 3, stride=2, padding=1), nn.ReLU(True),
-                                  nn.Conv2d(conv_channels, conv_channels, 3, stride=2, padding=1), nn.ReLU(True))
+        self._sampling_num = int(math.log2(subsampling_factor))
+        C = conv_channels
+        layers = [nn.Conv2d(1, C, 3, stride=2, padding=1), nn.ReLU(True)]
+        for _ in range(self._sampling_num - 1):
+            if subsampling == "striding":
+                layers += [nn.Conv2d(C, C, 3, stride=2, padding=1), nn.ReLU(True)]
+            else:  # depthwise 3x3 stride 2 + pointwise 1x1: sequential indices 2,3,(4=ReLU), 5,6,(7) -- the reference's keys
+                layers += [nn.Conv2d(C, C, 3, stride=2, padding=1, groups=C), nn.Conv2d(C, C, 1), nn.ReLU(True)]
+        self.conv = nn.Sequential(*layers)
         f = feat_in
-        for _ in range(2):
+        for _ in range(self._sampling_num):
             f = (f + 2 - 3) // 2 + 1
         self._feat_after = f
         self.out = nn.Linear(conv_channels * f, feat_out)
+
+    def dw_stages(self):
+        """[(depthwise conv, pointwise conv)] of the 'dw_striding' stack"""
+        mods = list(self.conv)
+        return [(mods[i], mods[i + 1]) for i in range(2, len(mods), 3)]
 
 
 class RelPositionalEncoding(nn.Module):  # multi_head_attention.py:1056
@@ -156,7 +169,9 @@ class ConformerEncoder(NeuralModule):
                  sync_max_audio_length: bool = True, compute_dtype: Optional[torch.dtype] = None):
         super().__init__()
         bad = []
-        if subsampling != "striding" or subsampling_factor != 4: bad.append("subsampling != striding x4")
+        if not ((subsampling == "striding" and subsampling_factor == 4) or
+                (subsampling == "dw_striding" and subsampling_factor in (4, 8))):
+            bad.append(f"subsampling={subsampling} x{subsampling_factor} (implemented: striding x4, dw_striding x4 / x8)")
         if causal_downsampling: bad.append("causal_downsampling")
         if self_attention_model != "rel_pos": bad.append(f"self_attention_model={self_attention_model}")
         if att_context_size not in (None, [-1, -1], (-1, -1)): bad.append("limited att_context_size")
@@ -184,7 +199,8 @@ class ConformerEncoder(NeuralModule):
         self.dropout_emb = dropout_emb
         if subsampling_conv_channels == -1:
             subsampling_conv_channels = d_model
-        self.pre_encode = ConvSubsampling(subsampling_factor, feat_in, d_model, subsampling_conv_channels)
+        self.subsampling = subsampling
+        self.pre_encode = ConvSubsampling(subsampling, subsampling_factor, feat_in, d_model, subsampling_conv_channels)
         self._feat_out = d_model
         self.pos_emb_max_len = pos_emb_max_len
         self.pos_enc = RelPositionalEncoding(d_model, dropout_pre_encoder, pos_emb_max_len, self.xscale, dropout_emb)
@@ -289,17 +305,23 @@ class ConformerEncoder(NeuralModule):
             srcs = []
             pe = self.pre_encode
             C_, F2 = pe._conv_channels, pe._feat_after
-            p.add_conv3x3("pre.w2", pe.conv[2].weight.data); p.add_conv3x3("pre.w2t", pe.conv[2].weight.data, transpose=True)
-            # conv2 input-gradient as four implicit GEMMs, one per (t1, f1) parity class: image [ci][(slot, co)] of the taps
-            # that reach the class (a stride-2 3x3 conv touches an even position through k = 1 only, an odd one through 0, 2)
-            w2flat = pe.conv[2].weight.data.view(-1)
-            for par_t in (0, 1):
-                for par_f in (0, 1):
-                    slots = self._dgrad_slots(par_t, par_f)
-                    name = f"pre.w2d{par_t}{par_f}"
-                    p.new_image(name, C_, len(slots) * C_)
-                    for si_, (kh, kw) in enumerate(slots):
-                        p.add_block(name, w2flat[kh * 3 + kw:], C_, C_, col_off=si_ * C_, sr1=9, sc1=9 * C_)
+            if self.subsampling == "striding":
+                p.add_conv3x3("pre.w2", pe.conv[2].weight.data); p.add_conv3x3("pre.w2t", pe.conv[2].weight.data, transpose=True)
+                # conv2 input-gradient as four implicit GEMMs, one per (t1, f1) parity class: image [ci][(slot, co)] of the
+                # taps that reach the class (a stride-2 3x3 conv touches an even position through k = 1 only, an odd one
+                # through 0, 2)
+                w2flat = pe.conv[2].weight.data.view(-1)
+                for par_t in (0, 1):
+                    for par_f in (0, 1):
+                        slots = self._dgrad_slots(par_t, par_f)
+                        name = f"pre.w2d{par_t}{par_f}"
+                        p.new_image(name, C_, len(slots) * C_)
+                        for si_, (kh, kw) in enumerate(slots):
+                            p.add_block(name, w2flat[kh * 3 + kw:], C_, C_, col_off=si_ * C_, sr1=9, sc1=9 * C_)
+            else:  # 'dw_striding': the pointwise convolutions are plain [C, C] GEMM operands
+                for si_, (_, pw) in enumerate(pe.dw_stages()):
+                    p.add_matrix(f"pre.pw{si_}", pw.weight.data.view(C_, C_))
+                    p.add_matrix(f"pre.pw{si_}t", pw.weight.data.view(C_, C_), True)
             p.add_fc_permuted("pre.out", pe.out.weight.data, C_, F2)
             p.add_fc_permuted("pre.outt", pe.out.weight.data, C_, F2, transpose=True)
             for i, L in enumerate(self.layers):
@@ -417,11 +439,12 @@ class ConformerEncoder(NeuralModule):
         if self._wg_stream is not None:
             torch.cuda.current_stream(self._wg_stream.device).wait_stream(self._wg_stream)
 
-    def _lens(self, length):
-        l0 = length.to(torch.int64)
-        l1 = torch.div(l0 - 1, 2, rounding_mode="floor") + 1  # floor((n + 2 - 3)/2) + 1, subsampling.py:576-586
-        l2 = torch.div(l1 - 1, 2, rounding_mode="floor") + 1
-        return l0.contiguous(), l1.clamp_(min=0).contiguous(), l2.clamp_(min=0).contiguous()
+    def _lens(self, length, n_stages=2):
+        """valid lengths after 0, 1, ..., n stride-2 stages: floor((n + 2 - 3)/2) + 1 each, subsampling.py:576-586"""
+        out = [length.to(torch.int64).contiguous()]
+        for _ in range(n_stages):
+            out.append((torch.div(out[-1] - 1, 2, rounding_mode="floor") + 1).clamp_(min=0).contiguous())
+        return out
 
     # ------------------------------------------------------------------ forward implementation
     def _forward_impl(self, mel, length, save=False):
@@ -438,9 +461,12 @@ class ConformerEncoder(NeuralModule):
         mel = mel.to(torch.float32).contiguous()
         d, H, dk, dff, C_ = self.d_model, self.n_heads, self.d_k, self.d_ff, self.pre_encode._conv_channels
         T1, F1 = (T - 1) // 2 + 1, (F_ - 1) // 2 + 1
-        T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+        lens = self._lens(length, self.pre_encode._sampling_num)  # [len0, len1, ..., len_final]
+        len0, len1, len2 = lens[0], lens[1], lens[-1]                # (`len2` / `T2` / `F2` name the FINAL grid everywhere below)
+        T2, F2 = T, F_
+        for _ in range(self.pre_encode._sampling_num):
+            T2, F2 = (T2 - 1) // 2 + 1, (F2 - 1) // 2 + 1
         M = B * T2
-        len0, len1, len2 = self._lens(length)
         self.update_max_seq_length(T2, dev)
         if training:
             self._step_seed = (self._step_seed + 1) & 0x3FFFFFFF
@@ -453,33 +479,37 @@ class ConformerEncoder(NeuralModule):
         S.dims = (B, F_, T, T1, F1, T2, F2, M, cdt, training, seed)
         S.mel, S.len0, S.len2 = mel, len0, len2
         pe = self.pre_encode
-        # ---- sub-sampling: conv1 (direct) -> conv2 (implicit MFMA GEMM, ReLU+mask epilogue) -> out Linear (+xscale, dropout)
-        S.out1 = torch.empty(B, T1, F1, C_, dtype=cdt, device=dev)
-        ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, S.out1, len0, len1, C_)
-        # (channel counts the gather does not cover fall back to an im2col image, kept alive for the weight gradient)
-        implicit = (self.conv2_implicit and self._conv2_implicit(cdt, C_, B * T2 * F2)
-                    and B * T1 * F1 * C_ < 2 ** 31)  # the gathered weight gradient addresses the grid with 32-bit offsets
-        S.col = None
-        if not implicit:
-            col = self._buf("col", (B * T2 * F2, 9 * C_), cdt, dev)
-            ops.im2col(S.out1, col, B, T1, F1, C_)
-            self._col_gen = getattr(self, "_col_gen", 0) + 1
-            S.col, S.col_gen = (col if save else None), self._col_gen
-        S.out2 = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
-        if implicit:
-            # implicit GEMM: the A rows are gathered from out1 by the LDS-DMA (tap (kh-1, kw-1) per 512-wide K block);
-            # forward, weight gradient and input gradient all gather -- no im2col image, no col2im pass
-            ops.gemm(S.out1, W["pre.w2"], S.out2, B * T2 * F2, C_, 9 * C_, C_, W.pitch("pre.w2"), C_, bias=pe.conv[2].bias,
-                     epi=ops.EPI_RELU_MASK, row_len=len2, rows_per_b=T2 * F2, rows_inner=F2,
-                     gather=dict(nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2,
-                                 taps=[(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]))
-        else:
-            ops.gemm(col, W["pre.w2"], S.out2, B * T2 * F2, C_, 9 * C_, 9 * C_, W.pitch("pre.w2"), C_, bias=pe.conv[2].bias,
-                     epi=ops.EPI_RELU_MASK, row_len=len2, rows_per_b=T2 * F2, rows_inner=F2)
-        x = torch.empty(M, d, dtype=torch.float32, device=dev)
+        S.lens_all = lens
         S.drop_pre = drop(self.dropout_pre_encoder, 100000)
-        ops.gemm(S.out2, W["pre.out"], x, M, d, F2 * C_, F2 * C_, W.pitch("pre.out"), d, bias=pe.out.bias,
-                 alpha=(self.xscale or 1.0), drop=S.drop_pre)
+        if self.subsampling == "dw_striding":
+            x = self._sub_fwd_dw(S, mel, lens, W, cdt, save)
+        else:
+            # ---- sub-sampling: conv1 (direct) -> conv2 (implicit MFMA GEMM, ReLU+mask epilogue) -> out Linear (+xscale, dropout)
+            S.out1 = torch.empty(B, T1, F1, C_, dtype=cdt, device=dev)
+            ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, S.out1, len0, len1, C_)
+            # (channel counts the gather does not cover fall back to an im2col image, kept alive for the weight gradient)
+            implicit = (self.conv2_implicit and self._conv2_implicit(cdt, C_, B * T2 * F2)
+                        and B * T1 * F1 * C_ < 2 ** 31)  # the gathered weight gradient addresses the grid with 32-bit offsets
+            S.col = None
+            if not implicit:
+                col = self._buf("col", (B * T2 * F2, 9 * C_), cdt, dev)
+                ops.im2col(S.out1, col, B, T1, F1, C_)
+                self._col_gen = getattr(self, "_col_gen", 0) + 1
+                S.col, S.col_gen = (col if save else None), self._col_gen
+            S.out2 = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
+            if implicit:
+                # implicit GEMM: the A rows are gathered from out1 by the LDS-DMA (tap (kh-1, kw-1) per 512-wide K block);
+                # forward, weight gradient and input gradient all gather -- no im2col image, no col2im pass
+                ops.gemm(S.out1, W["pre.w2"], S.out2, B * T2 * F2, C_, 9 * C_, C_, W.pitch("pre.w2"), C_, bias=pe.conv[2].bias,
+                         epi=ops.EPI_RELU_MASK, row_len=len2, rows_per_b=T2 * F2, rows_inner=F2,
+                         gather=dict(nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2,
+                                     taps=[(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]))
+            else:
+                ops.gemm(col, W["pre.w2"], S.out2, B * T2 * F2, C_, 9 * C_, 9 * C_, W.pitch("pre.w2"), C_, bias=pe.conv[2].bias,
+                         epi=ops.EPI_RELU_MASK, row_len=len2, rows_per_b=T2 * F2, rows_inner=F2)
+            x = torch.empty(M, d, dtype=torch.float32, device=dev)
+            ops.gemm(S.out2, W["pre.out"], x, M, d, F2 * C_, F2 * C_, W.pitch("pre.out"), d, bias=pe.out.bias,
+                     alpha=(self.xscale or 1.0), drop=S.drop_pre)
         # ---- relative positional table (constant)
         pkey = (T2, cdt, str(dev))
         pos = self._pos_cache.get(pkey)
@@ -507,6 +537,76 @@ class ConformerEncoder(NeuralModule):
             torch._foreach_add_([L.conv.batch_norm.num_batches_tracked for L in self.layers], 1)
         out = x.view(B, T2, d).transpose(1, 2)
         return out, len2, (S if save else None)
+
+    # ------------------------------------------------------------------ 'dw_striding' sub-sampling (FastConformer, Squeezeformer)
+    def _sub_fwd_dw(self, S, mel, lens, W, cdt, save):
+        """conv(1->C, 3x3, s2) ReLU -> [depthwise 3x3 s2 -> pointwise 1x1 -> ReLU] x (log2(factor) - 1) -> Linear, every layer
+        on a time-masked input (subsampling.py:142-215, 385-436, 725-759).  conv1: the direct kernel of the 'striding' path;
+        depthwise: mi355x_dwconv2d_s2_*; pointwise: MFMA GEMM with the ReLU + time-mask epilogue; channels-last throughout."""
+        B, F_, T, T1, F1, T2, F2, M, _, training, seed = S.dims
+        dev = mel.device
+        pe = self.pre_encode
+        C_, d = pe._conv_channels, self.d_model
+        out0 = torch.empty(B, T1, F1, C_, dtype=cdt, device=dev)
+        ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, out0, lens[0], lens[1], C_)
+        cur, Tc, Fc = out0, T1, F1
+        S.dw = []
+        for si_, (dw, pw) in enumerate(pe.dw_stages()):
+            Tn, Fn = (Tc - 1) // 2 + 1, (Fc - 1) // 2 + 1
+            dwo = torch.empty(B * Tn * Fn, C_, dtype=cdt, device=dev)
+            ops.dwconv2d_s2_fwd(cur, dw.weight, dw.bias, dwo, B, Tc, Fc, C_)
+            pwo = torch.empty(B * Tn * Fn, C_, dtype=cdt, device=dev)
+            ops.gemm(dwo, W[f"pre.pw{si_}"], pwo, B * Tn * Fn, C_, C_, C_, W.pitch(f"pre.pw{si_}"), C_, bias=pw.bias,
+                     epi=ops.EPI_RELU_MASK, row_len=lens[si_ + 2], rows_per_b=Tn * Fn, rows_inner=Fn)
+            S.dw.append((cur, Tc, Fc, dwo, pwo, Tn, Fn))
+            cur, Tc, Fc = pwo, Tn, Fn
+        x = torch.empty(M, d, dtype=torch.float32, device=dev)
+        ops.gemm(cur, W["pre.out"], x, M, d, F2 * C_, F2 * C_, W.pitch("pre.out"), d, bias=pe.out.bias,
+                 alpha=(self.xscale or 1.0), drop=S.drop_pre)
+        S.out1, S.out2, S.col = out0, cur, None
+        return x
+
+    def _sub_bwd_dw(self, S, dx, W, cdt):
+        B, F_, T, T1, F1, T2, F2, M, _, training, seed = S.dims
+        dev = dx.device
+        pe = self.pre_encode
+        C_, d = pe._conv_channels, self.d_model
+        bf16 = cdt == torch.bfloat16
+        dxs = torch.empty(M, d, dtype=cdt, device=dev)
+        ops.drop_scale_cast(dx, dxs, M * d, (self.xscale or 1.0), S.drop_pre)
+        with self._sub_wgrad_scope(dxs):
+            ops.colsum(dxs, pe.out.bias.grad, M, d)
+        last = S.out2  # [B*T2*F2, C] = [M, F2*C]
+        tiles = self._tiles(d, C_, bf16) * F2
+        with self._sub_wgrad_scope(dxs, last):  # d out.weight in the reference's (c, f) column order (batch over f)
+            ops.gemm(dxs, last, pe.out.weight.grad, d, C_, M, d, F2 * C_, C_ * F2, transA=True, transB=True, atomic=True,
+                     splitk=self._splitk(tiles, M, strided_c=True), batch=F2, nb0=F2, sB=(C_, 0), sC=(1, 0), c_col_stride=F2,
+                     c_dtype=ops.F32)
+        dcur = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
+        ops.gemm(dxs, W["pre.outt"], dcur, M, F2 * C_, d, d, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=last)
+        for si_ in range(len(S.dw) - 1, -1, -1):
+            cur_in, Tc, Fc, dwo, pwo, Tn, Fn = S.dw[si_]
+            dw, pw = pe.dw_stages()[si_]
+            Ms = B * Tn * Fn
+            # pointwise conv: bias / weight gradients, then the gradient w.r.t. the depthwise output (no gate: no ReLU there)
+            if bf16 and C_ >= 192:
+                with self._sub_wgrad_scope(dcur, dwo):
+                    ops.gemm(dcur, dwo, pw.weight.grad, C_, C_, Ms, C_, C_, C_, transA=True, transB=True, atomic=True,
+                             splitk=self._splitk(self._tiles(C_, C_, True), Ms), c_dtype=ops.F32, colsum_out=pw.bias.grad)
+            else:
+                with self._sub_wgrad_scope(dcur, dwo):
+                    ops.colsum(dcur, pw.bias.grad, Ms, C_)
+                    ops.gemm(dcur, dwo, pw.weight.grad, C_, C_, Ms, C_, C_, C_, transA=True, transB=True, atomic=True,
+                             splitk=self._splitk(self._tiles(C_, C_, bf16), Ms), c_dtype=ops.F32)
+            ddw = torch.empty(Ms, C_, dtype=cdt, device=dev)
+            ops.gemm(dcur, W[f"pre.pw{si_}t"], ddw, Ms, C_, C_, C_, W.pitch(f"pre.pw{si_}t"), C_)
+            din = torch.empty(B * Tc * Fc, C_, dtype=cdt, device=dev)
+            ops.dwconv2d_s2_bwd(ddw, cur_in, dw.weight, din, dw.weight.grad, dw.bias.grad, B, Tc, Fc, C_)
+            dcur = din
+        ops.conv1_bwd(dcur, S.mel, S.len0, pe.conv[0].weight.grad, pe.conv[0].bias.grad, C_)
+        self._wgrad_join()
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(*self._flatp.range_of("pre_encode."))
 
     def _ln_fwd(self, ln, x, M, d, out_dtype, dev):
         y = torch.empty(M, d, dtype=out_dtype, device=dev)
@@ -692,6 +792,8 @@ class ConformerEncoder(NeuralModule):
             self.grad_ready_hook(*fp.tail_range())
         # ---- sub-sampling backward
         pe = self.pre_encode
+        if self.subsampling == "dw_striding":
+            return self._sub_bwd_dw(S, dx, W, cdt)
         dxs = torch.empty(M, d, dtype=cdt, device=dev)
         ops.drop_scale_cast(dx, dxs, M * d, (self.xscale or 1.0), S.drop_pre)
         with self._sub_wgrad_scope(dxs):

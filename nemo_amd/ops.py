@@ -198,6 +198,21 @@ def col2im_relu(dcol, act, din, B, T1, F1, C_):
     check(lib.mi355x_col2im_3x3s2_relu(_ptr(dcol), _ptr(act), _ptr(din), dt(dcol), B, T1, F1, C_, _stream()), "col2im")
 
 
+def dwconv2d_s2_fwd(x, w, bias, out, B, T1, F1, C_):
+    """depthwise 3x3 stride-2 conv on channels-last [B,T1,F1,C] -> [B,T2,F2,C]  ('dw_striding' sub-sampling)"""
+    check(lib.mi355x_dwconv2d_s2_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), dt(x), B, T1, F1, C_, _stream()), "dwconv2d_s2_fwd")
+
+
+def dwconv2d_s2_bwd(dout, x, w, din, dw, dbias, B, T1, F1, C_):
+    T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+    npos = B * T2 * F2
+    nblk = (npos + 63) // 64 if npos < 1024 * 64 else 1024
+    n = nblk * 10 * C_
+    sc = _scratch("dwconv2d_bwd", n, dout.device)
+    check(lib.mi355x_dwconv2d_s2_bwd(_ptr(dout), _ptr(x), _ptr(w), _ptr(din), _ptr(dw), _ptr(dbias), dt(x), B, T1, F1, C_,
+                                     _ptr(sc), n, _stream()), "dwconv2d_s2_bwd")
+
+
 # ------------------------------------------------------------------------------------------------ norms / reductions
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d, eps=1e-5):
     check(lib.mi355x_layernorm_fwd(_ptr(x), dt(x), _ptr(gamma), _ptr(beta), _ptr(y), dt(y), _ptr(mean), _ptr(rstd), M, d, eps,

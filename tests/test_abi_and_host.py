@@ -122,7 +122,7 @@ def test_typecheck_contract():
 
 def test_unsupported_configurations_raise():
     from nemo_amd.modules import ConformerEncoder
-    for kw in (dict(subsampling="dw_striding"), dict(self_attention_model="abs_pos"), dict(conv_norm_type="layer_norm"),
+    for kw in (dict(subsampling="vggnet"), dict(subsampling="striding", subsampling_factor=8), dict(self_attention_model="abs_pos"), dict(conv_norm_type="layer_norm"),
                dict(att_context_size=[128, 0])):
         with pytest.raises(NotImplementedError):
             ConformerEncoder(feat_in=80, n_layers=1, d_model=32, n_heads=4, **kw)
@@ -410,3 +410,17 @@ def test_scheduler_follows_the_lightning_order():
         used.append(s.get_last_lr())
         s.step()
     assert used == [s.lr_at(1), s.lr_at(1), s.lr_at(2), s.lr_at(3)]
+
+
+def test_dw_striding_encoder_state_dict_is_the_reference_abi(golden_dir):
+    """FastConformer / Squeezeformer sub-sampling ('dw_striding'): parameter names and shapes of the drop-in encoder equal the
+    reference ConformerEncoder's (the fixture holds the reference state-dict, tests/golden/ref_fastconformer_tiny.npz)"""
+    from nemo_amd.modules import ConformerEncoder
+    z = np.load(os.path.join(golden_dir, "ref_fastconformer_tiny.npz"))
+    enc = ConformerEncoder(feat_in=40, n_layers=2, d_model=32, subsampling="dw_striding", subsampling_factor=8,
+                           subsampling_conv_channels=16, n_heads=4, conv_kernel_size=9)
+    ours = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    ref = {k[2:]: tuple(z[k].shape) for k in z.files if k.startswith("P.") and "pos_enc" not in k}
+    assert ours == ref, (set(ours) ^ set(ref), [k for k in ours if k in ref and ours[k] != ref[k]])
+    with pytest.raises(NotImplementedError):
+        ConformerEncoder(feat_in=40, n_layers=1, d_model=32, subsampling="dw_striding", subsampling_factor=2)

@@ -490,3 +490,69 @@ def test_frozen_parameters_are_neither_updated_nor_decayed():
         else:
             moved += int(not torch.equal(p.detach(), before[n]))
     assert moved > 50
+
+
+def _encoder_vs_fixture(z, enc, rtol_y=2e-4, rtol_g=2e-3):
+    """drop-in encoder (train mode = batch-statistics BatchNorm, dropout 0) against a fixture made by the reference's own class:
+    output, lengths and every parameter gradient of the fixed linear functional sum(y * w * valid)"""
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("P.")}
+    missing, unexpected = enc.load_state_dict(sd, strict=False)
+    assert not unexpected and not [m for m in missing if "pos_enc" not in m], (missing, unexpected)
+    enc = enc.to(dev).train()
+    enc.flat_parameters().zero_grad()
+    x = torch.from_numpy(z["x"]).to(dev)
+    length = torch.from_numpy(z["length"]).to(dev)
+    y, yl = enc(audio_signal=x, length=length)
+    assert np.array_equal(yl.cpu().numpy(), z["y_len"])
+    yr = torch.from_numpy(z["y"])
+    valid = (torch.arange(yr.shape[2]).unsqueeze(0) < torch.from_numpy(z["y_len"]).unsqueeze(1)).unsqueeze(1)
+    err = ((y.detach().float().cpu() - yr) * valid).abs().max().item() / yr.abs().max().item()
+    assert err < rtol_y, err
+    w = torch.from_numpy(z["w"])
+    (y * (w * valid).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    got = {n: p.grad.detach().float().cpu() for n, p in enc.named_parameters()}
+    ref = {k[2:]: z[k] for k in z.files if k.startswith("G.")}
+    assert set(ref) == set(got), set(ref) ^ set(got)
+    _cmp_grads(got, ref, rtol=rtol_g, floor=1e-3)
+
+
+def test_fastconformer_encoder_dw_striding_x8_matches_reference_fixture(golden_dir):
+    """BASELINE.json configs[3]'s encoder geometry (FastConformer: 'dw_striding' x8 sub-sampling with its own channel count,
+    depthwise kernel 9) against tests/golden/ref_fastconformer_tiny.npz (the reference ConformerEncoder run through the
+    shim): depthwise stride-2 conv kernels forward / data-gradient / weight-gradient, pointwise GEMMs with ReLU + mask."""
+    from nemo_amd.modules import ConformerEncoder
+    z = np.load(os.path.join(golden_dir, "ref_fastconformer_tiny.npz"))
+    enc = ConformerEncoder(feat_in=40, n_layers=2, d_model=32, feat_out=-1, subsampling="dw_striding", subsampling_factor=8,
+                           subsampling_conv_channels=16, ff_expansion_factor=4, self_attention_model="rel_pos", n_heads=4,
+                           conv_kernel_size=9, dropout=0.0, dropout_pre_encoder=0.0, dropout_emb=0.0, dropout_att=0.0)
+    _encoder_vs_fixture(z, enc)
+
+
+def test_fastconformer_geometry_bf16_runs_the_production_paths():
+    """d = 256 / 4 heads (d_k = 64: fused flash attention), 256 sub-sampling channels, x8, kernel 9, bf16: finite loss and
+    gradients, and the loss of the bf16 path close to the fp32 path of the same model (same weights, same batch)"""
+    from nemo_amd.modules import ConformerEncoder
+    kw = dict(feat_in=80, n_layers=2, d_model=256, subsampling="dw_striding", subsampling_factor=8,
+              subsampling_conv_channels=256, n_heads=4, conv_kernel_size=9, dropout=0.0, dropout_pre_encoder=0.0,
+              dropout_emb=0.0, dropout_att=0.0)
+    torch.manual_seed(4)
+    e32 = ConformerEncoder(compute_dtype=torch.float32, **kw)
+    e16 = ConformerEncoder(compute_dtype=torch.bfloat16, **kw)
+    e16.load_state_dict(e32.state_dict())
+    e32, e16 = e32.to(dev).train(), e16.to(dev).train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 80, 640, generator=g).to(dev)
+    length = torch.tensor([640, 500, 333]).to(dev)
+    outs = []
+    for e in (e32, e16):
+        e.flat_parameters().zero_grad()
+        y, yl = e(audio_signal=x, length=length)
+        assert y.shape == (3, 256, 80) and yl.tolist() == [80, 63, 42]
+        (y.float() ** 2).mean().backward()
+        torch.cuda.synchronize()
+        outs.append((y.detach().float(), e.flat_parameters().grad.detach().clone()))
+        assert torch.isfinite(outs[-1][1]).all()
+    (y32, g32), (y16, g16) = outs
+    assert (y16 - y32).norm() / y32.norm() < 3e-2
+    assert torch.dot(g16, g32) / (g16.norm() * g32.norm()) > 0.99
