@@ -117,6 +117,30 @@ int mi355x_dwconv2d_s2_fwd(const void* in, const void* w, const void* bias, void
 int mi355x_dwconv2d_s2_bwd(const void* dout, const void* in, const void* w, void* din, void* dw, void* dbias, int dtype, int B,
                            int T1, int F1, int C, void* scratch, long long scratch_elems, void* stream);
 
+/* ---- transducer head (FastConformer-Transducer): RNNTDecoder.predict / RNNTJoint.joint_after_projection,
+ * nemo/collections/asr/modules/rnnt.py:700-830, 1640-1720; LSTM = common/parts/rnn.py:151-230 (torch gate order i,f,g,o).
+ * The gate / projection / output-layer contractions are mi355x_gemm; these are the pieces between them. */
+/* out (dtype) [U+1,B,H]: row 0 = zero start-of-sequence frame, row u+1 = emb[targets[b,u]] (blank id = padding row = 0) */
+int mi355x_embed_sos_fwd(const void* targets /*i64 [B,U]*/, const void* emb /*f32 [V+1,H]*/, void* out, int dtype, int B, int U,
+                         int H, int blank, void* stream);
+int mi355x_embed_sos_bwd(const void* targets, const void* dx /*[U+1,B,H]*/, int dtype, void* demb /*f32 +=*/, int B, int U, int H,
+                         int blank, void* stream);
+/* one LSTM step: z f32 [B,4H] holds x W_ih^T + b_ih + h_prev W_hh^T on entry and the ACTIVATED gates on exit; c_prev may be
+ * NULL (zero state); h is written in f32 and in the GEMM operand dtype */
+int mi355x_lstm_cell_fwd(void* z, const void* b_hh, const void* c_prev, void* c, void* h, void* h_lp, int lp_dtype, int B, int H,
+                         void* stream);
+/* dh f32 [B,H]; dc f32 [B,H] in = d/dc_t from step t+1, out = d/dc_{t-1}; dz (dtype) [B,4H] = pre-activation gradients */
+int mi355x_lstm_cell_bwd(const void* dh, void* dc, const void* act, const void* c, const void* c_prev, void* dz, int dz_dtype,
+                         int B, int H, void* stream);
+/* h [B,T,U1,J] = dropout(relu(f[b,t,:] + g[b,u,:])); backward: dh <- dh * (h > 0) * drop_scale in place, df [B,T,J] = sum_u */
+int mi355x_joint_combine_fwd(const void* f, const void* g, void* h, int dtype, unsigned drop_key, unsigned drop_threshold,
+                             float drop_scale, int B, int T, int U1, int J, void* stream);
+int mi355x_joint_combine_bwd(void* dh, const void* h, void* df, int dtype, float drop_scale, int B, int T, int U1, int J,
+                             void* stream);
+/* dst (dtype) [M, Np] (pitch ld_out) = alpha * src f32 [M, N] (pitch ld_in), columns N..Np-1 zero: GEMM operand rows */
+int mi355x_cast_rows(const void* src, long long ld_in, void* dst, int dst_dtype, long long ld_out, long long M, int N, int Np,
+                     float alpha, void* stream);
+
 /* ---- LayerNorm (torch.nn.LayerNorm x5 per layer, conformer_modules.py:174-215) -------------------------------- */
 int mi355x_layernorm_fwd(const void* x, int x_dtype, const void* gamma, const void* beta, void* y, int y_dtype, void* mean,
                          void* rstd, int M, int d, float eps, void* stream);

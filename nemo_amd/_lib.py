@@ -68,6 +68,13 @@ SIGNATURES = {
     "mi355x_col2im_3x3s2_relu": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mi355x_dwconv2d_s2_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mi355x_dwconv2d_s2_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp],
+    "mi355x_embed_sos_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mi355x_embed_sos_bwd": [vp, vp, i32, vp, i32, i32, i32, i32, vp],
+    "mi355x_lstm_cell_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "mi355x_lstm_cell_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "mi355x_joint_combine_fwd": [vp, vp, vp, i32, u32, u32, f32, i32, i32, i32, i32, vp],
+    "mi355x_joint_combine_bwd": [vp, vp, vp, i32, f32, i32, i32, i32, i32, vp],
+    "mi355x_cast_rows": [vp, i64, vp, i32, i64, i64, i32, i32, f32, vp],
     "mi355x_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp],
     "mi355x_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp],
     "mi355x_layernorm_bwd_cast": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, f32, u32, u32, f32, vp],

@@ -44,6 +44,7 @@ class AcousticEncodedRepresentation(ElementType): pass
 class LogprobsType(ElementType): pass
 class LabelsType(ElementType): pass
 class LossType(ElementType): pass
+class EmbeddedTextType(ElementType): pass
 class ChannelType(ElementType): pass
 
 
@@ -122,6 +123,10 @@ TARGET_ALIASES = {
     "nemo.collections.asr.models.EncDecCTCModelBPE": "nemo_amd.models.EncDecCTCModelBPE",
     "nemo.collections.asr.models.ctc_bpe_models.EncDecCTCModelBPE": "nemo_amd.models.EncDecCTCModelBPE",
     "nemo.collections.asr.losses.rnnt.RNNTLoss": "nemo_amd.modules.RNNTLoss",
+    "nemo.collections.asr.modules.RNNTDecoder": "nemo_amd.modules.RNNTDecoder",
+    "nemo.collections.asr.modules.RNNTJoint": "nemo_amd.modules.RNNTJoint",
+    "nemo.collections.asr.models.EncDecRNNTModel": "nemo_amd.models.EncDecRNNTModel",
+    "nemo.collections.asr.models.EncDecRNNTBPEModel": "nemo_amd.models.EncDecRNNTModel",
 }
 
 

@@ -5,3 +5,4 @@ from .conv_asr import ConvASRDecoder  # noqa: F401
 from .ctc import CTCLoss  # noqa: F401
 from .ctc_decoding import GreedyCTCDecoder, WER, word_error_rate  # noqa: F401
 from .rnnt_loss import RNNTLoss, RNNTLossNumba  # noqa: F401
+from .rnnt import RNNTDecoder, RNNTJoint  # noqa: F401

@@ -213,6 +213,38 @@ def dwconv2d_s2_bwd(dout, x, w, din, dw, dbias, B, T1, F1, C_):
                                      _ptr(sc), n, _stream()), "dwconv2d_s2_bwd")
 
 
+# ------------------------------------------------------------------------------------------------ transducer head
+def embed_sos_fwd(targets, emb, out, B, U, H, blank):
+    check(lib.mi355x_embed_sos_fwd(_ptr(targets), _ptr(emb), _ptr(out), dt(out), B, U, H, blank, _stream()), "embed_sos_fwd")
+
+
+def embed_sos_bwd(targets, dx, demb, B, U, H, blank):
+    check(lib.mi355x_embed_sos_bwd(_ptr(targets), _ptr(dx), dt(dx), _ptr(demb), B, U, H, blank, _stream()), "embed_sos_bwd")
+
+
+def lstm_cell_fwd(z, b_hh, c_prev, c, h, h_lp, B, H):
+    check(lib.mi355x_lstm_cell_fwd(_ptr(z), _ptr(b_hh), _ptr(c_prev), _ptr(c), _ptr(h), _ptr(h_lp), dt(h_lp), B, H, _stream()),
+          "lstm_cell_fwd")
+
+
+def lstm_cell_bwd(dh, dc, act, c, c_prev, dz, B, H):
+    check(lib.mi355x_lstm_cell_bwd(_ptr(dh), _ptr(dc), _ptr(act), _ptr(c), _ptr(c_prev), _ptr(dz), dt(dz), B, H, _stream()),
+          "lstm_cell_bwd")
+
+
+def joint_combine_fwd(f, g, h, B, T, U1, J, drop: Dropout = NO_DROP):
+    check(lib.mi355x_joint_combine_fwd(_ptr(f), _ptr(g), _ptr(h), dt(h), drop.key, drop.threshold, drop.scale, B, T, U1, J,
+                                       _stream()), "joint_combine_fwd")
+
+
+def joint_combine_bwd(dh, h, df, B, T, U1, J, drop_scale=1.0):
+    check(lib.mi355x_joint_combine_bwd(_ptr(dh), _ptr(h), _ptr(df), dt(h), drop_scale, B, T, U1, J, _stream()), "joint_combine_bwd")
+
+
+def cast_rows(src, ld_in, dst, ld_out, M, N, Np, alpha=1.0):
+    check(lib.mi355x_cast_rows(_ptr(src), ld_in, _ptr(dst), dt(dst), ld_out, M, N, Np, alpha, _stream()), "cast_rows")
+
+
 # ------------------------------------------------------------------------------------------------ norms / reductions
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d, eps=1e-5):
     check(lib.mi355x_layernorm_fwd(_ptr(x), dt(x), _ptr(gamma), _ptr(beta), _ptr(y), dt(y), _ptr(mean), _ptr(rstd), M, d, eps,

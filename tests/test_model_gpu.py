@@ -556,3 +556,59 @@ def test_fastconformer_geometry_bf16_runs_the_production_paths():
     (y32, g32), (y16, g16) = outs
     assert (y16 - y32).norm() / y32.norm() < 3e-2
     assert torch.dot(g16, g32) / (g16.norm() * g32.norm()) > 0.99
+
+
+def _transducer_head(z, fused, dtype=None):
+    from nemo_amd.modules import RNNTDecoder, RNNTJoint, RNNTLoss
+    V, H, D, J = 12, 16, 24, 20
+    dec = RNNTDecoder(prednet={"pred_hidden": H, "pred_rnn_layers": 2, "dropout": 0.0}, vocab_size=V, compute_dtype=dtype)
+    kw = dict(fuse_loss_wer=True, fused_batch_size=2) if fused else {}
+    joint = RNNTJoint(jointnet={"encoder_hidden": D, "pred_hidden": H, "joint_hidden": J, "activation": "relu", "dropout": 0.0},
+                      num_classes=V, compute_dtype=dtype, **kw)
+    dec.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("P.D.")})
+    joint.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("P.J.")})
+    loss = RNNTLoss(blank=V, reduction="sum")
+    if fused:
+        joint.set_loss(loss)
+    return dec.to(dev).train(), joint.to(dev).train(), loss
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_transducer_head_matches_reference_fixture(golden_dir, fused):
+    """RNNTDecoder (embedding + SOS frame + 2-layer LSTM) + RNNTJoint + RNN-T loss on a ragged batch (one empty label
+    sequence) against tests/golden/ref_transducer_tiny.npz, produced by the reference's RNNTDecoder / RNNTJoint /
+    RNNTLossPytorch: decoder output, logits, loss, gradient w.r.t. the encoder output and every parameter.  `fused` = the
+    recipe's training path (joint.fuse_loss_wer with sub-batches of 2: the logits never exist for the whole batch)."""
+    z = np.load(os.path.join(golden_dir, "ref_transducer_tiny.npz"))
+    dec, joint, loss_mod = _transducer_head(z, fused)
+    V = 12
+    enc = torch.from_numpy(z["enc"]).to(dev).requires_grad_(True)
+    enc_len = torch.from_numpy(z["enc_len"]).to(dev)
+    tgt = torch.from_numpy(z["targets"]).to(dev)
+    tgt_len = torch.from_numpy(z["tgt_len"]).to(dev)
+    for m in (dec, joint):
+        m.flat_parameters().zero_grad()
+    g, _, _ = dec(targets=tgt, target_length=tgt_len)
+    assert np.abs(g.detach().cpu().numpy() - z["dec_out"]).max() < 2e-5
+    if fused:
+        loss, _, _, _ = joint(encoder_outputs=enc, decoder_outputs=g, encoder_lengths=enc_len, transcripts=tgt,
+                              transcript_lengths=tgt_len)
+    else:
+        logits = joint(encoder_outputs=enc, decoder_outputs=g)
+        # (the fixture was produced on the CPU, where the reference joint applies log_softmax itself, rnnt.py:1700-1712; on
+        #  the GPU -- and here -- the joint returns logits and the loss fuses the normalisation)
+        assert np.abs(torch.log_softmax(logits.detach(), -1).cpu().numpy() - z["logits"]).max() < 5e-5
+        loss = loss_mod(logits, tgt.clamp(max=V - 1), enc_len, tgt_len)
+    assert abs(float(loss) - float(z["loss"])) <= 1e-4 * abs(float(z["loss"])), (float(loss), float(z["loss"]))
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    assert np.abs(enc.grad.cpu().numpy() - z["d_enc"]).max() <= 2e-4 * np.abs(z["d_enc"]).max() + 1e-6
+    got = {"D." + n: p.grad.detach().float().cpu() for n, p in dec.named_parameters()}
+    got.update({"J." + n: p.grad.detach().float().cpu() for n, p in joint.named_parameters()})
+    ref = {k[2:]: z[k] for k in z.files if k.startswith("G.")}
+    assert set(ref) == set(got), set(ref) ^ set(got)
+    for k, r in ref.items():
+        s = max(np.abs(r).max(), 1e-4)
+        assert np.abs(got[k].numpy() - r).max() <= 1e-3 * s, (k, np.abs(got[k].numpy() - r).max(), s)
+    # the padding row of the embedding receives no gradient (torch.nn.Embedding(padding_idx))
+    assert float(got["D.prediction.embed.weight"][V].abs().max()) == 0.0
