@@ -1,1 +1,2 @@
 from .ctc_models import EncDecCTCModel, EncDecCTCModelBPE, conformer_ctc_config  # noqa: F401
+from .rnnt_models import EncDecRNNTModel, fastconformer_transducer_config  # noqa: F401

@@ -287,8 +287,12 @@ class EncDecCTCModel(nn.Module):
         return getattr(self, "_test_dl", None)
 
     # ------------------------------------------------------------------ optimisation
+    def trainable_modules(self):
+        """the modules that own flat parameter buffers, in backward-completion order for the gradient exchange"""
+        return [self.encoder, self.decoder]
+
     def flats(self):
-        return [self.encoder.flat_parameters(), self.decoder.flat_parameters()]
+        return [m.flat_parameters() for m in self.trainable_modules()]
 
     def setup_optimization(self, optim_config: Optional[Dict[str, Any]] = None):
         oc = dict(optim_config if optim_config is not None else self._cfg.get("optim", {}))
@@ -312,13 +316,13 @@ class EncDecCTCModel(nn.Module):
         return self._optimizer, self._scheduler
 
     def _grad_syncs(self):
-        gens = tuple(m.flat_parameters().generation for m in (self.encoder, self.decoder))
+        gens = tuple(m.flat_parameters().generation for m in self.trainable_modules())
         if self._syncs is not None and getattr(self, "_syncs_gen", None) != gens:
             self._syncs = None  # a flat buffer was rebuilt (model.to(), ...): the exchange must not reduce the stale one
         if self._syncs is None:
             self._syncs_gen = gens
             self._syncs = []
-            for mod in (self.encoder, self.decoder):
+            for mod in self.trainable_modules():
                 gs = GradSync(mod.flat_parameters().grad)
                 mod.grad_ready_hook = gs.ready
                 if gs.use_side_stream and hasattr(mod, "_wg_stream"):  # weight gradients are produced on their own stream
@@ -360,7 +364,7 @@ class EncDecCTCModel(nn.Module):
     def _install_early_step(self, syncs):
         opt = self._optimizer
         if syncs:
-            for gs, mod in zip(syncs, (self.encoder, self.decoder)):
+            for gs, mod in zip(syncs, self.trainable_modules()):
                 fp = mod.flat_parameters()
                 gs.after_reduce = (lambda lo, hi, fp=fp: opt.step_range(fp, lo, hi))
         else:

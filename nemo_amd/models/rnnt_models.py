@@ -1,0 +1,148 @@
+"""Drop-in for `nemo.collections.asr.models.EncDecRNNTModel` / `EncDecRNNTBPEModel` (models/rnnt_models.py) restricted to the
+training hot path of FastConformer-Transducer (BASELINE.json configs[3]): config-driven construction of preprocessor /
+encoder / decoder (prediction network) / joint / loss (rnnt_models.py:50-120), `forward` (:630-690: audio -> encoder
+output), `training_step` (:692-760: decoder -> joint, fused with the loss when `joint.fuse_loss_wer`), and the optimizer /
+data-parallel machinery shared with the CTC model (`fit_step`, bucketed gradient exchange over the flat buffers of encoder,
+prediction network and joint).  Transducer decoding (greedy / beam search) and WER are outside the training hot path."""
+from __future__ import annotations
+
+import copy
+import os
+from typing import Any, Dict
+
+import torch
+
+from ..modules import RNNTLoss
+from .ctc_models import EncDecCTCModel, _build as _build_ctc
+
+_DEFAULT_TARGETS = {"decoder": "nemo.collections.asr.modules.RNNTDecoder", "joint": "nemo.collections.asr.modules.RNNTJoint"}
+
+
+def _build(section, cfg):
+    from ..core import Serialization
+    cfg = dict(cfg)
+    cfg.setdefault("_target_", _DEFAULT_TARGETS[section])
+    return Serialization.from_config_dict(cfg)
+
+
+class EncDecRNNTModel(EncDecCTCModel):
+    def __init__(self, cfg: Dict[str, Any], trainer=None):
+        torch.nn.Module.__init__(self)
+        cfg = copy.deepcopy(dict(cfg))
+        self._cfg = cfg
+        self.trainer = trainer
+        self.preprocessor = _build_ctc("preprocessor", cfg["preprocessor"])
+        self.encoder = _build_ctc("encoder", cfg["encoder"])
+        # rnnt_models.py:60-90: vocabulary size and hidden sizes are injected into the decoder / joint sections
+        vocab = cfg.get("labels")
+        n_cls = len(vocab) if vocab is not None else int(cfg["joint"].get("num_classes", cfg["decoder"].get("vocab_size", -1)))
+        if n_cls < 1:
+            raise ValueError("the vocabulary size must be given (`labels`, `joint.num_classes` or `decoder.vocab_size`)")
+        dec = dict(cfg["decoder"]); dec["vocab_size"] = n_cls
+        jnt = dict(cfg["joint"]); jnt["num_classes"] = n_cls
+        jnt["jointnet"] = dict(jnt["jointnet"])
+        jnt["jointnet"].setdefault("encoder_hidden", cfg.get("model_defaults", {}).get("enc_hidden", self.encoder._feat_out))
+        jnt["jointnet"].setdefault("pred_hidden", dec["prednet"]["pred_hidden"])
+        self.decoder = _build("decoder", dec)
+        self.joint = _build("joint", jnt)
+        lc = dict(cfg.get("loss") or {})
+        kw = dict(lc.get("warprnnt_numba_kwargs") or {})
+        self.loss = RNNTLoss(blank=n_cls, reduction=cfg.get("rnnt_reduction", "mean_batch"),
+                             fastemit_lambda=kw.get("fastemit_lambda", 0.0), clamp=kw.get("clamp", -1.0))
+        if self.joint.fuse_loss_wer:
+            self.joint.set_loss(self.loss)
+        sa = cfg.get("spec_augment")
+        self.spec_augmentation = _build_ctc("spec_augment", sa) if sa else None
+        self._optimizer = self._scheduler = self._syncs = None
+        self._wer = None
+        self.validation_step_outputs, self.test_step_outputs = [], []
+        self.optimizer_in_backward = False
+        self.global_step = 0
+
+    def trainable_modules(self):
+        return [self.encoder, self.decoder, self.joint]
+
+    @property
+    def wer(self):
+        return None  # transducer decoding is not part of this path
+
+    # ------------------------------------------------------------------ forward (rnnt_models.py:630-690)
+    def forward(self, input_signal=None, input_signal_length=None, processed_signal=None, processed_signal_length=None):
+        has_input_signal = input_signal is not None and input_signal_length is not None
+        has_processed_signal = processed_signal is not None and processed_signal_length is not None
+        if (has_input_signal ^ has_processed_signal) is False:
+            raise ValueError(f"{self} Arguments ``input_signal`` and ``input_signal_length`` are mutually exclusive "
+                             " with ``processed_signal`` and ``processed_signal_len`` arguments.")
+        if not has_processed_signal:
+            processed_signal, processed_signal_length = self.preprocessor(input_signal=input_signal, length=input_signal_length)
+        if self.spec_augmentation is not None and self.training:
+            processed_signal = self.spec_augmentation(input_spec=processed_signal, length=processed_signal_length)
+        return self.encoder(audio_signal=processed_signal, length=processed_signal_length)
+
+    # ------------------------------------------------------------------ training_step (rnnt_models.py:692-760)
+    def training_step(self, batch, batch_nb=0):
+        signal, signal_len, transcript, transcript_len = batch
+        encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
+        decoder, target_length, _ = self.decoder(targets=transcript, target_length=transcript_len)
+        if not self.joint.fuse_loss_wer:
+            joint = self.joint(encoder_outputs=encoded, decoder_outputs=decoder)
+            loss_value = self._reduce(self.loss(joint, transcript.clamp(max=self.loss.blank - 1).contiguous(),
+                                                encoded_len.to(torch.int64), target_length.to(torch.int64)), target_length)
+        else:
+            loss_value, _, _, _ = self.joint(encoder_outputs=encoded, decoder_outputs=decoder, encoder_lengths=encoded_len,
+                                             transcripts=transcript, transcript_lengths=transcript_len, compute_wer=False)
+        logs = {"train_loss": loss_value.detach(), "global_step": self.global_step}
+        if self._scheduler is not None:
+            logs["learning_rate"] = self._scheduler.get_last_lr()
+        return {"loss": loss_value, "log": logs}
+
+    def _reduce(self, losses, target_lengths):
+        red = self.loss.reduction  # losses/rnnt.py:333-420 (RNNTLoss.reduce)
+        if red == "mean_batch":
+            return losses.mean()
+        if red == "mean":
+            return torch.div(losses, target_lengths.clamp(min=1)).mean()
+        if red == "sum":
+            return losses.sum()
+        if red == "mean_volume":
+            return losses.sum() / target_lengths.sum()
+        return losses
+
+    def validation_pass(self, batch, batch_idx=0, dataloader_idx=0):
+        signal, signal_len, transcript, transcript_len = batch[:4]
+        with torch.no_grad():
+            was = self.joint.fuse_loss_wer
+            out = self.training_step((signal, signal_len, transcript, transcript_len))
+        return {"val_loss": out["loss"].detach()}
+
+
+def fastconformer_transducer_config(size: str = "large", vocab_size: int = 1024, spec_augment: bool = False,
+                                    **encoder_overrides) -> Dict[str, Any]:
+    """model section of examples/asr/conf/fastconformer/fast-conformer_transducer_bpe.yaml (sizes of its table: Large = 17
+    layers, d_model 512, 8 heads; x8 'dw_striding' sub-sampling with 256 channels, depthwise kernel 9; prediction network
+    one 640-wide LSTM layer, joint 640, both with dropout 0.2; fused joint + loss in sub-batches of 4); tokenizer replaced by
+    an explicit vocabulary size."""
+    sizes = {"small": (176, 4, 16), "medium": (256, 4, 16), "large": (512, 8, 17)}
+    d_model, n_heads, n_layers = sizes[size]
+    enc = dict(feat_in=80, feat_out=-1, n_layers=n_layers, d_model=d_model, subsampling="dw_striding", subsampling_factor=8,
+               subsampling_conv_channels=256, causal_downsampling=False, ff_expansion_factor=4, self_attention_model="rel_pos",
+               n_heads=n_heads, att_context_size=[-1, -1], att_context_style="regular", xscaling=True, untie_biases=True,
+               pos_emb_max_len=5000, conv_kernel_size=9, conv_norm_type="batch_norm", conv_context_size=None, dropout=0.1,
+               dropout_pre_encoder=0.1, dropout_emb=0.0, dropout_att=0.1, stochastic_depth_drop_prob=0.0)
+    enc.update(encoder_overrides)
+    return {
+        "sample_rate": 16000, "rnnt_reduction": "mean_batch",
+        "model_defaults": dict(enc_hidden=enc["d_model"], pred_hidden=640, joint_hidden=640),
+        "preprocessor": dict(sample_rate=16000, normalize="per_feature", window_size=0.025, window_stride=0.01, window="hann",
+                             features=80, n_fft=512, log=True, frame_splicing=1, dither=1e-5, pad_to=0, pad_value=0.0),
+        "spec_augment": dict(_target_="nemo.collections.asr.modules.SpectrogramAugmentation", freq_masks=2,
+                             time_masks=10, freq_width=27, time_width=0.05) if spec_augment else None,
+        "encoder": enc,
+        "decoder": dict(normalization_mode=None, random_state_sampling=False, blank_as_pad=True, vocab_size=vocab_size,
+                        prednet=dict(pred_hidden=640, pred_rnn_layers=1, t_max=None, dropout=0.2)),
+        "joint": dict(log_softmax=None, preserve_memory=False, fuse_loss_wer=True, fused_batch_size=4, num_classes=vocab_size,
+                      jointnet=dict(joint_hidden=640, activation="relu", dropout=0.2)),
+        "loss": dict(loss_name="default", warprnnt_numba_kwargs=dict(fastemit_lambda=0.0, clamp=-1.0)),
+        "optim": dict(name="adamw", lr=5.0, betas=[0.9, 0.98], weight_decay=1e-3,
+                      sched=dict(name="NoamAnnealing", d_model=d_model, warmup_steps=10000, warmup_ratio=None, min_lr=1e-6)),
+    }
