@@ -30,10 +30,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", default="large", choices=["small", "medium", "large"])
-    ap.add_argument("--model", default="ctc", choices=["ctc", "transducer"],
+    ap.add_argument("--size", default="large", choices=["xs", "small", "sm", "medium", "ml", "large"])
+    ap.add_argument("--model", default="ctc", choices=["ctc", "transducer", "squeezeformer"],
                     help="ctc = Conformer-CTC (BASELINE configs[1]/[2], the headline); transducer = FastConformer-Transducer "
-                         "(configs[3]: x8 dw_striding encoder, LSTM prediction network, fused joint + RNN-T loss)")
+                         "(configs[3]: x8 dw_striding encoder, LSTM prediction network, fused joint + RNN-T loss); squeezeformer = "
+                         "Squeezeformer-CTC (configs[4]: --size medium, SpecAugment on)")
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--secs", type=float, default=20.0)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -202,6 +203,13 @@ def main():
         model = EncDecRNNTModel(cfg)
         model.decoder.compute_dtype = model.joint.compute_dtype = cdt
         a.no_cpu_baseline = True  # (the CPU leg times the Conformer-CTC oracle)
+    elif a.model == "squeezeformer":
+        from nemo_amd.models import squeezeformer_ctc_config
+        vocab = 128
+        cfg = squeezeformer_ctc_config(a.size, vocab_size=vocab, spec_augment=not a.no_spec_augment, compute_dtype=cdt)
+        model = EncDecCTCModel(cfg)
+        model.decoder.compute_dtype = cdt
+        a.no_cpu_baseline = True  # (the CPU leg times the Conformer-CTC oracle)
     else:
         vocab = 128
         cfg = conformer_ctc_config(a.size, vocab_size=vocab, spec_augment=not a.no_spec_augment, compute_dtype=cdt)
@@ -332,17 +340,20 @@ def main():
         line = {
             "metric": ("audio-sec/s training throughput, Conformer-CTC-Large @ 1/2/4/8 MI355X" if a.size == "large"
                        else f"audio-sec/s training throughput, Conformer-CTC-{a.size}") if a.model == "ctc"
-            else f"audio-sec/s training throughput, FastConformer-Transducer-{a.size.capitalize()}",
+            else f"audio-sec/s training throughput, FastConformer-Transducer-{a.size.capitalize()}" if a.model == "transducer"
+            else f"audio-sec/s training throughput, Squeezeformer-CTC-{a.size.capitalize()}",
             "value": round(value, 1), "unit": "audio-sec/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": (f"Conformer-CTC-{a.size.capitalize()} {a.dtype}, batch={a.batch}x{a.secs:g}s synthetic 16 kHz "
                                     f"clips per GPU, {world}xMI355X (BASELINE.json configs[{1 if world == 1 else 2}])")
                        if a.model == "ctc" else
+                       (f"Squeezeformer-CTC-{a.size.capitalize()} {a.dtype} (dw_striding x4, time reduction / recovery), "
+                        f"batch={a.batch}x{a.secs:g}s per GPU, {world}xMI355X (BASELINE.json configs[4])") if a.model == "squeezeformer" else
                        (f"FastConformer-Transducer-{a.size.capitalize()} {a.dtype} (x8 dw_striding, LSTM prediction net, fused joint "
                         f"+ RNN-T loss, vocab 1024), batch={a.batch}x{a.secs:g}s per GPU, {world}xMI355X (BASELINE.json configs[3])"),
                        "global_batch": world * a.batch, "clip_seconds": a.secs, "parallelism": f"dp{world}",
-                       "step": ("fwd+CTC" if a.model == "ctc" else "fwd+joint+RNNT-loss") + "+bwd+grad-allreduce+AdamW, train mode (dropout, dither, SyncBN"
+                       "step": ("fwd+joint+RNNT-loss" if a.model == "transducer" else "fwd+CTC") + "+bwd+grad-allreduce+AdamW, train mode (dropout, dither, SyncBN"
                                + (")" if a.no_spec_augment else ", SpecAugment)"),
                        "final_loss": round(final_loss, 4)},
         }

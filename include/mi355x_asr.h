@@ -141,6 +141,33 @@ int mi355x_joint_combine_bwd(void* dh, const void* h, void* df, int dtype, float
 int mi355x_cast_rows(const void* src, long long ld_in, void* dst, int dst_dtype, long long ld_out, long long M, int N, int Np,
                      float alpha, void* stream);
 
+/* ---- Squeezeformer block glue (BASELINE.json configs[4]): squeezeformer_modules.py:30-57 (ScaleBiasLayer), :139-181 (post-LN
+ * block order), conformer_modules.py:267-275 ('swish' point-wise activation), subsampling.py:589-646 (TimeReductionModule),
+ * squeezeformer_encoder.py:352-361 (time recovery).  `ld` = row pitch of a produced GEMM operand (>= d, multiple of 4; columns
+ * [d, ld) are zero-filled) so that d_model % 8 != 0 (Medium: 324) still gives 16-byte aligned bf16 rows. */
+/* y (dtype) [M, ld] = x f32 [M, d] * scale + bias   (scale = bias = NULL: plain cast, adaptive_scale = False) */
+int mi355x_scale_bias_fwd(const void* x, const void* scale, const void* bias, void* y, int y_dtype, long long M, int d, int ld,
+                          void* stream);
+/* dres f32 [M, d] += dy * scale;  dscale[d] += colsum(dy * x);  dbias[d] += colsum(dy)   (dscale = dbias = NULL: skipped) */
+int mi355x_scale_bias_bwd(const void* dy, int dy_dtype, int ld, const void* x, const void* scale, void* dres, void* dscale,
+                          void* dbias, long long M, int d, void* stream);
+/* y (dtype) [M, ld] = alpha * dropmask(m*d + c) * x f32 [M, d]  -- the dropout mask of a GEMM epilogue with N = d */
+int mi355x_cast_pitched(const void* x, void* y, int y_dtype, long long M, int d, int ld, float alpha, unsigned drop_key,
+                        unsigned drop_threshold, float drop_scale, void* stream);
+/* out [M, C] = swish(in) * (t < len[b]),  rows m = b*T + t;  backward: din = dout * swish'(in) * mask */
+int mi355x_swish_mask_fwd(const void* in, void* out, int dtype, const void* len, int T, long long M, int C, void* stream);
+int mi355x_swish_mask_bwd(const void* in, const void* dout, void* din, int dtype, const void* len, int T, long long M, int C,
+                          void* stream);
+/* masked depthwise Conv1d(k=5, stride 2, pad 3) over time, cropped to ceil(T/2) frames: x f32 [B,T,d] -> out (dtype)
+ * [B*ceil(T/2), ld]; w f32 [d,1,5].  backward: dx f32 [B,T,d] +=, dw +=, dbias += */
+int mi355x_time_reduce_dwconv_fwd(const void* x, const void* len, const void* w, const void* bias, void* out, int out_dtype, int B,
+                                  int T, int d, int ld, void* stream);
+int mi355x_time_reduce_dwconv_bwd(const void* dout, int dout_dtype, int ld, const void* x, const void* len, const void* w, void* dx,
+                                  void* dw, void* dbias, int B, int T, int d, void* stream);
+/* out f32 [B,T,d] = skip + ys[b, t/2, :]  (ys f32 [B, ceil(T/2), d]);  backward: dys (dtype) [B*ceil(T/2), ld] = dx[2t'] + dx[2t'+1] */
+int mi355x_time_recover_fwd(const void* skip, const void* ys, void* out, int B, int T, int d, void* stream);
+int mi355x_time_recover_bwd(const void* dx, void* dys, int dys_dtype, int B, int T, int d, int ld, void* stream);
+
 /* ---- LayerNorm (torch.nn.LayerNorm x5 per layer, conformer_modules.py:174-215) -------------------------------- */
 int mi355x_layernorm_fwd(const void* x, int x_dtype, const void* gamma, const void* beta, void* y, int y_dtype, void* mean,
                          void* rstd, int M, int d, float eps, void* stream);

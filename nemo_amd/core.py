@@ -116,6 +116,7 @@ TARGET_ALIASES = {
     "nemo.collections.asr.modules.AudioToMelSpectrogramPreprocessor": "nemo_amd.modules.AudioToMelSpectrogramPreprocessor",
     "nemo.collections.asr.modules.SpectrogramAugmentation": "nemo_amd.modules.SpectrogramAugmentation",
     "nemo.collections.asr.modules.ConformerEncoder": "nemo_amd.modules.ConformerEncoder",
+    "nemo.collections.asr.modules.SqueezeformerEncoder": "nemo_amd.modules.SqueezeformerEncoder",
     "nemo.collections.asr.modules.ConvASRDecoder": "nemo_amd.modules.ConvASRDecoder",
     "nemo.collections.asr.losses.ctc.CTCLoss": "nemo_amd.modules.CTCLoss",
     "nemo.collections.asr.losses.CTCLoss": "nemo_amd.modules.CTCLoss",

@@ -242,7 +242,7 @@ extern "C" int mi355x_subsample_conv1_fwd(const void* mel, const void* w, const 
 extern "C" int mi355x_subsample_conv1_bwd(const void* dout, int dt, const void* mel, const void* len0, void* dw, void* db, int B,
                                           int F, int T, int C, void* scratch, long long scratch_elems, void* stream) {
   mi_clear_errors();
-  if (!dout || !mel || !len0 || !dw || !db || B <= 0 || F <= 0 || T <= 0 || C <= 0 || (C & 7)) return MI_ERR_ARG;
+  if (!dout || !mel || !len0 || !dw || !db || B <= 0 || F <= 0 || T <= 0 || C <= 0 || C % (dt == MI_DT_BF16 ? 8 : 4)) return MI_ERR_ARG;
   const int T1 = (T + 2 - 3) / 2 + 1, F1 = (F + 2 - 3) / 2 + 1;
   dim3 grid((T1 + C1_TB - 1) / C1_TB, B), block(256);
   const int nparts = grid.x * grid.y;

@@ -16,7 +16,7 @@ from torch import nn
 
 from ..core import NeuralModule, Serialization, load_nemo, resolve_target, save_nemo
 from ..modules import AudioToMelSpectrogramPreprocessor, ConformerEncoder, ConvASRDecoder, CTCLoss
-from ..optim import FusedAdamW, NoamAnnealing
+from ..optim import FusedAdamW, NoamAnnealing, NoamHoldAnnealing
 from ..parallel import GradSync
 
 _DEFAULT_TARGETS = {
@@ -308,6 +308,12 @@ class EncDecCTCModel(nn.Module):
                                      ema_decay=ema.get("decay") if ema.get("enable", bool(ema)) else None)
         sched = oc.get("sched")
         if sched:
+            if sched.get("name") == "NoamHoldAnnealing":  # the Squeezeformer recipe (squeezeformer_ctc_bpe.yaml:160-168)
+                self._scheduler = NoamHoldAnnealing(oc.get("lr", 1e-3), warmup_steps=sched.get("warmup_steps"),
+                                                    warmup_ratio=sched.get("warmup_ratio"), hold_steps=sched.get("hold_steps"),
+                                                    hold_ratio=sched.get("hold_ratio"), max_steps=sched.get("max_steps"),
+                                                    decay_rate=sched.get("decay_rate", 0.5), min_lr=sched.get("min_lr", 0.0))
+                return self._optimizer, self._scheduler
             if sched.get("name") != "NoamAnnealing":
                 raise NotImplementedError(f"scheduler '{sched.get('name')}'")
             self._scheduler = NoamAnnealing(oc.get("lr", 1e-3), d_model=sched["d_model"], warmup_steps=sched.get("warmup_steps"),
@@ -542,6 +548,33 @@ class EncDecCTCModelBPE(EncDecCTCModel):
         self._wer = None
         self._cfg["tokenizer"] = dict(self._cfg.get("tokenizer", {}), dir=os.path.dirname(model_path), model_path=model_path,
                                       type="bpe")
+
+
+def squeezeformer_ctc_config(size: str = "medium", vocab_size: int = 128, spec_augment: bool = False,
+                             **encoder_overrides) -> Dict[str, Any]:
+    """model section of examples/asr/conf/squeezeformer/squeezeformer_ctc_bpe.yaml (:22-168) for the sizes of its table (:9-16:
+    d_model, n_layers, n_heads, SpecAugment time masks, peak lr, time_reduce_idx); BASELINE.json configs[4] is 'medium'."""
+    sizes = {"xs": (144, 16, 4, 5, 2e-3, 7), "small": (196, 18, 4, 5, 2e-3, 8), "sm": (256, 16, 4, 5, 1.5e-3, 7),
+             "medium": (324, 20, 4, 7, 1.5e-3, 9), "ml": (512, 18, 8, 10, 1e-3, 8), "large": (640, 22, 8, 10, 5e-4, 10)}
+    d_model, n_layers, n_heads, time_masks, lr, reduce_idx = sizes[size]
+    enc = dict(_target_="nemo.collections.asr.modules.SqueezeformerEncoder", feat_in=80, feat_out=-1, n_layers=n_layers,
+               d_model=d_model, adaptive_scale=True, time_reduce_idx=reduce_idx, time_recovery_idx=None, subsampling="dw_striding",
+               subsampling_factor=4, subsampling_conv_channels=-1, ff_expansion_factor=4, self_attention_model="rel_pos",
+               n_heads=n_heads, att_context_size=[-1, -1], xscaling=True, untie_biases=True, pos_emb_max_len=5000,
+               conv_kernel_size=31, conv_norm_type="batch_norm", dropout=0.1, dropout_emb=0.0, dropout_att=0.1)
+    enc.update(encoder_overrides)
+    return {
+        "sample_rate": 16000, "ctc_reduction": "mean_batch", "skip_nan_grad": False,
+        "preprocessor": dict(sample_rate=16000, normalize="per_feature", window_size=0.025, window_stride=0.01, window="hann",
+                             features=80, n_fft=512, log=True, frame_splicing=1, dither=1e-5, pad_to=0, pad_value=0.0),
+        "spec_augment": dict(_target_="nemo.collections.asr.modules.SpectrogramAugmentation", freq_masks=2,
+                             time_masks=time_masks, freq_width=27, time_width=0.05) if spec_augment else None,
+        "encoder": enc,
+        "decoder": dict(feat_in=None, num_classes=vocab_size, vocabulary=None),
+        "optim": dict(name="adamw", lr=lr, betas=[0.9, 0.98], weight_decay=4e-5,
+                      sched=dict(name="NoamHoldAnnealing", warmup_steps=5000, warmup_ratio=None, hold_steps=40000,
+                                 hold_ratio=None, decay_rate=1.0, min_lr=1e-5)),
+    }
 
 
 def conformer_ctc_config(size: str = "large", vocab_size: int = 128, spec_augment: bool = False,

@@ -207,6 +207,10 @@ class ConformerEncoder(NeuralModule):
         self.layers = nn.ModuleList([ConformerLayer(d_model, d_ff, n_heads, conv_kernel_size) for _ in range(n_layers)])
         self.out_proj = None
         self.max_audio_length = pos_emb_max_len
+        self._init_engine(compute_dtype, tail=lambda n: n.endswith("self_attn.linear_pos.weight"))
+
+    def _init_engine(self, compute_dtype, tail=None):
+        """engine state shared by the encoders built on this class (not part of the state-dict)"""
         self.compute_dtype = compute_dtype  # None: bf16 under torch autocast(bf16), else fp32
         # SyncBatchNorm semantics across data-parallel ranks (trainer.sync_batchnorm: true in the recipe)
         self.sync_batchnorm = True
@@ -217,9 +221,8 @@ class ConformerEncoder(NeuralModule):
         self._syncbn_group = None
         self.use_flash_attention = True  # bf16 + d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
         self.grad_ready_hook = None  # callable(start, end) on the flat gradient buffer (data-parallel bucketing)
-        # --- engine state (not part of the state-dict)
         # linear_pos weights of all layers sit together at the tail: their gradients come from ONE batched GEMM
-        self._flatp = FlatParams(self, tail=lambda n: n.endswith("self_attn.linear_pos.weight"))
+        self._flatp = FlatParams(self, tail=tail)
         self.wgrad_side_stream = os.environ.get("MI355X_WGRAD_STREAM", "1") != "0"
         self._wg_stream = None
         self._wgrad_join_per_layer = True
@@ -573,7 +576,10 @@ class ConformerEncoder(NeuralModule):
         C_, d = pe._conv_channels, self.d_model
         bf16 = cdt == torch.bfloat16
         dxs = torch.empty(M, d, dtype=cdt, device=dev)
-        ops.drop_scale_cast(dx, dxs, M * d, (self.xscale or 1.0), S.drop_pre)
+        if (M * d) % 8:
+            ops.cast_pitched(dx, dxs, M, d, d, (self.xscale or 1.0), S.drop_pre)
+        else:
+            ops.drop_scale_cast(dx, dxs, M * d, (self.xscale or 1.0), S.drop_pre)
         with self._sub_wgrad_scope(dxs):
             ops.colsum(dxs, pe.out.bias.grad, M, d)
         last = S.out2  # [B*T2*F2, C] = [M, F2*C]
@@ -660,6 +666,99 @@ class ConformerEncoder(NeuralModule):
             for i in range(nl):
                 self._wgrad(dp_all[i], d, 0, pos, d, 0, grads[i], d, d, P)
 
+    # ------------------------------------------------------------------ rel-pos attention core (shared with Squeezeformer)
+    def _attn_fwd(self, qkv, p, bias_u, bias_v, lens, B, T, dA, dk, scale, d_att, cdt, dev):
+        """qkv [B*T, 3*dA] (q | k | v, heads of width dk = dA / H, possibly zero-padded heads), p [2T-1, dA] = linear_pos of
+        the table, bias_u / bias_v [dA] -> ctx [B*T, dA] and what backward needs.  `scale` = 1/sqrt(true d_k)."""
+        H = self.n_heads
+        M, P = B * T, 2 * T - 1
+        Tp, Pp = _pad8(T), _pad8(P)
+        ctx = torch.empty(M, dA, dtype=cdt, device=dev)
+        flash = self.use_flash_attention and cdt == torch.bfloat16 and dk == 64
+        if flash:
+            # fused rel-pos flash attention: scores / positional matrix never touch HBM; only the log-sum-exp is kept
+            lse = torch.empty(B, H, T, dtype=torch.float32, device=dev)
+            ops.relpos_flash_fwd(qkv, 3 * dA, p, dA, bias_u, bias_v, lens, ctx, dA, lse, B, H, T, dk, Tp, scale, d_att)
+            return ctx, (None, None, None, None, lse)
+        qu = torch.empty(M, dA, dtype=cdt, device=dev)
+        qv = torch.empty(M, dA, dtype=cdt, device=dev)
+        ops.qbias(qkv, 3 * dA, bias_u, bias_v, qu, qv, M, dA)
+        ac = self._buf("ac", (H, B, T, Tp), torch.float32, dev)
+        bdf = self._buf("bdf", (H, B, T, Pp), torch.float32, dev)
+        # ac[h,b] = qu_bh @ k_bh^T ; bdf[h,b] = qv_bh @ p_h^T      (z0 = b, z1 = h)
+        ops.gemm(qu, qkv, ac, T, T, dk, dA, 3 * dA, Tp, batch=H * B, nb0=B, sA=(T * dA, dk), sB=(T * 3 * dA, dk),
+                 sC=(T * Tp, B * T * Tp), b_off=dA)
+        ops.gemm(qv, p, bdf, T, P, dk, dA, dA, Pp, batch=H * B, nb0=B, sA=(T * dA, dk), sB=(0, dk), sC=(T * Pp, B * T * Pp))
+        s_ = torch.empty(H, B, T, Tp, dtype=cdt, device=dev)
+        pd = torch.empty(H, B, T, Tp, dtype=cdt, device=dev) if d_att.threshold else None
+        ops.relpos_softmax_fwd(ac, bdf, s_, pd, lens, H, B, T, Tp, Pp, scale, d_att)
+        if pd is None:
+            pd = s_
+        # ctx_bh = pd_bh [T,T] @ v_bh [T,dk]   (NN: v is reduction-major inside qkv)
+        ops.gemm(pd, qkv, ctx, T, dk, T, Tp, 3 * dA, dA, transB=True, batch=H * B, nb0=B, sA=(T * Tp, B * T * Tp),
+                 sB=(T * 3 * dA, dk), sC=(T * dA, dk), b_off=2 * dA)
+        return ctx, (qu, qv, s_, pd, None)
+
+    def _attn_bwd(self, saved, qkv, p, bias_u, bias_v, ctx, dctx, lens, B, T, dA, dk, scale, d_att, cdt, dev, dp, dp_cast):
+        """-> (dqkv [M, 3*dA] with the k and v thirds filled, dqu, dqv [M, dA]); dp f32 [2T-1, dA] += d linear_pos output,
+        dp_cast (compute dtype) = its GEMM-operand copy for the linear_pos weight gradient."""
+        qu, qv, s_, pd, lse = saved
+        H = self.n_heads
+        M, P = B * T, 2 * T - 1
+        Tp, Pp = _pad8(T), _pad8(P)
+        dqkv = torch.empty(M, 3 * dA, dtype=cdt, device=dev)
+        dqu = torch.empty(M, dA, dtype=cdt, device=dev)
+        dqv = torch.empty(M, dA, dtype=cdt, device=dev)
+        if lse is not None:
+            qu = torch.empty(M, dA, dtype=cdt, device=dev)
+            qv = torch.empty(M, dA, dtype=cdt, device=dev)
+            ops.qbias(qkv, 3 * dA, bias_u, bias_v, qu, qv, M, dA)
+            dlt = torch.empty(B, H, T, dtype=torch.float32, device=dev)
+            ops.attn_delta(dctx, ctx, dlt, B, H, T, dA)
+            Tp32 = (T + 31) // 32 * 32
+            # transient dS: dQ kernel -> linear_pos gradient kernel.  The latter feeds only the (batched, end-of-backward)
+            # linear_pos weight gradient, so with the side stream it leaves the critical path; dS then comes from the
+            # caching allocator (record_stream keeps the next layer's dQ kernel from overwriting it too early).
+            side_pos = self.dpos_side_stream and self.wgrad_side_stream
+            dS = (torch.empty(H, B, T, Tp32, dtype=cdt, device=dev) if side_pos
+                  else self._buf("dS", (H, B, T, Tp32), cdt, dev))
+            ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * dA, p, dA, lens, dctx, lse, dlt, dqu, dqv, B, H, T, dk, Tp32, scale, d_att,
+                                    ds_out=dS)
+            if side_pos:
+                with self._wgrad_scope(qv, dS):
+                    ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk, Tp32)
+                    ops.drop_scale_cast(dp, dp_cast, P * dA, 1.0)
+            ops.relpos_flash_bwd_dkv(qu, qv, qkv, 3 * dA, p, dA, lens, dctx, lse, dlt, dqkv, 3 * dA, B, H, T, dk, Tp, scale, d_att)
+            if not side_pos:
+                ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk, Tp32)
+                ops.drop_scale_cast(dp, dp_cast, P * dA, 1.0)
+            return dqkv, dqu, dqv
+        # dpd[h,b] = dctx_bh @ v_bh^T  -> reuse the f32 score workspace
+        dpd = self._buf("ac", (H, B, T, Tp), torch.float32, dev)
+        ops.gemm(dctx, qkv, dpd, T, T, dk, dA, 3 * dA, Tp, batch=H * B, nb0=B, sA=(T * dA, dk), sB=(T * 3 * dA, dk),
+                 sC=(T * Tp, B * T * Tp), b_off=2 * dA)
+        # dv_bh[j,e] = sum_i pd[i,j] dctx[i,e]
+        ops.gemm(pd, dctx, dqkv, T, dk, T, Tp, dA, 3 * dA, transA=True, transB=True, batch=H * B, nb0=B,
+                 sA=(T * Tp, B * T * Tp), sB=(T * dA, dk), sC=(T * 3 * dA, dk), c_off=2 * dA)
+        dscore = self._buf("dscore", (H, B, T, Tp), cdt, dev)
+        dbdf = self._buf("dbdf", (H, B, T, Pp), cdt, dev)
+        ops.relpos_softmax_bwd(dpd, s_, dscore, dbdf, H, B, T, Tp, Pp, scale, d_att)
+        # dqu_bh = dscore_bh [T,T] @ k_bh [T,dk]  (NN)
+        ops.gemm(dscore, qkv, dqu, T, dk, T, Tp, 3 * dA, dA, transB=True, batch=H * B, nb0=B, sA=(T * Tp, B * T * Tp),
+                 sB=(T * 3 * dA, dk), sC=(T * dA, dk), b_off=dA)
+        # dk_bh[j,e] = sum_i dscore[i,j] qu[i,e]
+        ops.gemm(dscore, qu, dqkv, T, dk, T, Tp, dA, 3 * dA, transA=True, transB=True, batch=H * B, nb0=B,
+                 sA=(T * Tp, B * T * Tp), sB=(T * dA, dk), sC=(T * 3 * dA, dk), c_off=dA)
+        # dqv_bh = dbdf_bh [T,P] @ p_h [P,dk]  (NN)
+        ops.gemm(dbdf, p, dqv, T, dk, P, Pp, dA, dA, transB=True, batch=H * B, nb0=B, sA=(T * Pp, B * T * Pp),
+                 sB=(0, dk), sC=(T * dA, dk))
+        # dp_h[c,e] = sum_{b,i} dbdf[h,b,i,c] qv[b,i,h,e]   (reduction over all B*T rows of head h)
+        tiles = self._tiles(P, dk, cdt == torch.bfloat16) * H
+        ops.gemm(dbdf, qv, dp, P, dk, B * T, Pp, dA, dA, transA=True, transB=True, atomic=True,
+                 splitk=self._splitk(tiles, B * T), batch=H, nb0=H, sA=(B * T * Pp, 0), sB=(dk, 0), sC=(dk, 0))
+        ops.drop_scale_cast(dp, dp_cast, P * dA, 1.0)  # linear_pos weight gradients: one batched GEMM after the loop
+        return dqkv, dqu, dqv
+
     def _layer_fwd(self, i, L, x, S, W, Wf, drop):
         B, F_, T, T1, F1, T2, F2, M, cdt, training, seed = S.dims
         dev = x.device
@@ -677,33 +776,8 @@ class ConformerEncoder(NeuralModule):
         ops.gemm(y2, W[f"L{i}.att.wqkv"], qkv, M, 3 * d, d, d, W.pitch(f"L{i}.att.wqkv"), 3 * d, bias=Wf[f"L{i}.att.bqkv"])
         p = S.p_all[i]  # linear_pos(pos_emb) of every layer was computed by one batched GEMM (same input, 18 weights)
         d_att = drop(self.dropout_att, site + 2)
-        ctx = torch.empty(M, d, dtype=cdt, device=dev)
-        flash = self.use_flash_attention and cdt == torch.bfloat16 and dk == 64
-        if flash:
-            # fused rel-pos flash attention: scores / positional matrix never touch HBM; only the log-sum-exp is kept
-            lse = torch.empty(B, H, T2, dtype=torch.float32, device=dev)
-            ops.relpos_flash_fwd(qkv, 3 * d, p, d, a.pos_bias_u, a.pos_bias_v, S.len2, ctx, d, lse, B, H, T2, dk, Tp,
-                                 1.0 / math.sqrt(dk), d_att)
-            qu = qv = s_ = pd = None
-        else:
-            lse = None
-            qu = torch.empty(M, d, dtype=cdt, device=dev)
-            qv = torch.empty(M, d, dtype=cdt, device=dev)
-            ops.qbias(qkv, 3 * d, a.pos_bias_u, a.pos_bias_v, qu, qv, M, d)
-            ac = self._buf("ac", (H, B, T2, Tp), torch.float32, dev)
-            bdf = self._buf("bdf", (H, B, T2, Pp), torch.float32, dev)
-            # ac[h,b] = qu_bh @ k_bh^T ; bdf[h,b] = qv_bh @ p_h^T      (z0 = b, z1 = h)
-            ops.gemm(qu, qkv, ac, T2, T2, dk, d, 3 * d, Tp, batch=H * B, nb0=B, sA=(T2 * d, dk), sB=(T2 * 3 * d, dk),
-                     sC=(T2 * Tp, B * T2 * Tp), b_off=d)
-            ops.gemm(qv, p, bdf, T2, P, dk, d, d, Pp, batch=H * B, nb0=B, sA=(T2 * d, dk), sB=(0, dk), sC=(T2 * Pp, B * T2 * Pp))
-            s_ = torch.empty(H, B, T2, Tp, dtype=cdt, device=dev)
-            pd = torch.empty(H, B, T2, Tp, dtype=cdt, device=dev) if d_att.threshold else None
-            ops.relpos_softmax_fwd(ac, bdf, s_, pd, S.len2, H, B, T2, Tp, Pp, 1.0 / math.sqrt(dk), d_att)
-            if pd is None:
-                pd = s_
-            # ctx_bh = pd_bh [T,T] @ v_bh [T,dk]   (NN: v is reduction-major inside qkv)
-            ops.gemm(pd, qkv, ctx, T2, dk, T2, Tp, 3 * d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Tp, B * T2 * Tp),
-                     sB=(T2 * 3 * d, dk), sC=(T2 * d, dk), b_off=2 * d)
+        ctx, (qu, qv, s_, pd, lse) = self._attn_fwd(qkv, p, a.pos_bias_u, a.pos_bias_v, S.len2, B, T2, d, dk, 1.0 / math.sqrt(dk),
+                                                    d_att, cdt, dev)
         r2 = torch.empty(M, d, dtype=torch.float32, device=dev)
         d_ares = drop(self.dropout, site + 3)
         ops.gemm(ctx, W[f"L{i}.att.wo"], r2, M, d, d, d, W.pitch(f"L{i}.att.wo"), d, bias=a.linear_out.bias, epi=ops.EPI_RESID,
@@ -938,58 +1012,8 @@ class ConformerEncoder(NeuralModule):
         self._wgrad(dao, d, 0, ctx, d, 0, a.linear_out.weight.grad, d, d, M, bias_grad=a.linear_out.bias.grad)
         dctx = torch.empty(M, d, dtype=cdt, device=dev)
         ops.gemm(dao, W[f"L{i}.att.wot"], dctx, M, d, d, d, W.pitch(f"L{i}.att.wot"), d)
-        dqkv = torch.empty(M, 3 * d, dtype=cdt, device=dev)
-        dqu = torch.empty(M, d, dtype=cdt, device=dev)
-        dqv = torch.empty(M, d, dtype=cdt, device=dev)
-        dp = S.dpos_f32[i]
-        if lse is not None:
-            qu = torch.empty(M, d, dtype=cdt, device=dev)
-            qv = torch.empty(M, d, dtype=cdt, device=dev)
-            ops.qbias(qkv, 3 * d, a.pos_bias_u, a.pos_bias_v, qu, qv, M, d)
-            dlt = torch.empty(B, H, T2, dtype=torch.float32, device=dev)
-            ops.attn_delta(dctx, ctx, dlt, B, H, T2, d)
-            Tp32 = (T2 + 31) // 32 * 32
-            # transient dS: dQ kernel -> linear_pos gradient kernel.  The latter feeds only the (batched, end-of-backward)
-            # linear_pos weight gradient, so with the side stream it leaves the critical path; dS then comes from the
-            # caching allocator (record_stream keeps the next layer's dQ kernel from overwriting it too early).
-            side_pos = self.dpos_side_stream and self.wgrad_side_stream
-            dS = (torch.empty(H, B, T2, Tp32, dtype=cdt, device=dev) if side_pos
-                  else self._buf("dS", (H, B, T2, Tp32), cdt, dev))
-            ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * d, p, d, S.len2, dctx, lse, dlt, dqu, dqv, B, H, T2, dk, Tp32, scale, d_att,
-                                    ds_out=dS)
-            if side_pos:
-                with self._wgrad_scope(qv, dS):
-                    ops.relpos_flash_bwd_dpos(qv, dS, S.len2, dp, B, H, T2, dk, Tp32)
-                    ops.drop_scale_cast(dp, S.dp_all[i], P * d, 1.0)
-            ops.relpos_flash_bwd_dkv(qu, qv, qkv, 3 * d, p, d, S.len2, dctx, lse, dlt, dqkv, 3 * d, B, H, T2, dk, Tp, scale, d_att)
-            if not side_pos:
-                ops.relpos_flash_bwd_dpos(qv, dS, S.len2, dp, B, H, T2, dk, Tp32)
-        else:
-            # dpd[h,b] = dctx_bh @ v_bh^T  -> reuse the f32 score workspace
-            dpd = self._buf("ac", (H, B, T2, Tp), torch.float32, dev)
-            ops.gemm(dctx, qkv, dpd, T2, T2, dk, d, 3 * d, Tp, batch=H * B, nb0=B, sA=(T2 * d, dk), sB=(T2 * 3 * d, dk),
-                     sC=(T2 * Tp, B * T2 * Tp), b_off=2 * d)
-            # dv_bh[j,e] = sum_i pd[i,j] dctx[i,e]
-            ops.gemm(pd, dctx, dqkv, T2, dk, T2, Tp, d, 3 * d, transA=True, transB=True, batch=H * B, nb0=B,
-                     sA=(T2 * Tp, B * T2 * Tp), sB=(T2 * d, dk), sC=(T2 * 3 * d, dk), c_off=2 * d)
-            dscore = self._buf("dscore", (H, B, T2, Tp), cdt, dev)
-            dbdf = self._buf("dbdf", (H, B, T2, Pp), cdt, dev)
-            ops.relpos_softmax_bwd(dpd, s_, dscore, dbdf, H, B, T2, Tp, Pp, scale, d_att)
-            # dqu_bh = dscore_bh [T,T] @ k_bh [T,dk]  (NN)
-            ops.gemm(dscore, qkv, dqu, T2, dk, T2, Tp, 3 * d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Tp, B * T2 * Tp),
-                     sB=(T2 * 3 * d, dk), sC=(T2 * d, dk), b_off=d)
-            # dk_bh[j,e] = sum_i dscore[i,j] qu[i,e]
-            ops.gemm(dscore, qu, dqkv, T2, dk, T2, Tp, d, 3 * d, transA=True, transB=True, batch=H * B, nb0=B,
-                     sA=(T2 * Tp, B * T2 * Tp), sB=(T2 * d, dk), sC=(T2 * 3 * d, dk), c_off=d)
-            # dqv_bh = dbdf_bh [T,P] @ p_h [P,dk]  (NN)
-            ops.gemm(dbdf, p, dqv, T2, dk, P, Pp, d, d, transB=True, batch=H * B, nb0=B, sA=(T2 * Pp, B * T2 * Pp),
-                     sB=(0, dk), sC=(T2 * d, dk))
-            # dp_h[c,e] = sum_{b,i} dbdf[h,b,i,c] qv[b,i,h,e]   (reduction over all B*T rows of head h)
-            tiles = self._tiles(P, dk, cdt == torch.bfloat16) * H
-            ops.gemm(dbdf, qv, dp, P, dk, B * T2, Pp, d, d, transA=True, transB=True, atomic=True,
-                     splitk=self._splitk(tiles, B * T2), batch=H, nb0=H, sA=(B * T2 * Pp, 0), sB=(dk, 0), sC=(dk, 0))
-        if not (lse is not None and self.dpos_side_stream and self.wgrad_side_stream):
-            ops.drop_scale_cast(dp, S.dp_all[i], P * d, 1.0)  # linear_pos weight gradients: one batched GEMM after the loop
+        dqkv, dqu, dqv = self._attn_bwd((qu, qv, s_, pd, lse), qkv, p, a.pos_bias_u, a.pos_bias_v, ctx, dctx, S.len2, B, T2, d,
+                                        dk, scale, d_att, cdt, dev, S.dpos_f32[i], S.dp_all[i])
         gu, gv_ = a.pos_bias_u.grad, a.pos_bias_v.grad
         if cdt == torch.bfloat16 and gv_.data_ptr() - gu.data_ptr() == 4 * d:
             ops.add2_colsum(dqu, dqv, dqkv, 3 * d, M, d, gu)  # dq = dqu + dqv and both bias gradients in one pass

@@ -287,6 +287,47 @@ def glu_bwd(x, dout, din, lens, T, M, d):
     check(lib.mi355x_glu_bwd(_ptr(x), _ptr(dout), _ptr(din), dt(x), _ptr(lens), T, M, d, _stream()), "glu_bwd")
 
 
+# ------------------------------------------------------------------------------------------------ Squeezeformer glue
+def scale_bias_fwd(x, scale, bias, y, M, d, ld):
+    check(lib.mi355x_scale_bias_fwd(_ptr(x), _ptr(scale), _ptr(bias), _ptr(y), dt(y), M, d, ld, _stream()), "scale_bias_fwd")
+
+
+def scale_bias_bwd(dy, ld, x, scale, dres, dscale, dbias, M, d):
+    check(lib.mi355x_scale_bias_bwd(_ptr(dy), dt(dy), ld, _ptr(x), _ptr(scale), _ptr(dres), _ptr(dscale), _ptr(dbias), M, d,
+                                    _stream()), "scale_bias_bwd")
+
+
+def cast_pitched(x, y, M, d, ld, alpha=1.0, drop: Dropout = NO_DROP):
+    check(lib.mi355x_cast_pitched(_ptr(x), _ptr(y), dt(y), M, d, ld, alpha, drop.key, drop.threshold, drop.scale, _stream()),
+          "cast_pitched")
+
+
+def swish_mask_fwd(x, out, lens, T, M, C_):
+    check(lib.mi355x_swish_mask_fwd(_ptr(x), _ptr(out), dt(x), _ptr(lens), T, M, C_, _stream()), "swish_mask_fwd")
+
+
+def swish_mask_bwd(x, dout, din, lens, T, M, C_):
+    check(lib.mi355x_swish_mask_bwd(_ptr(x), _ptr(dout), _ptr(din), dt(x), _ptr(lens), T, M, C_, _stream()), "swish_mask_bwd")
+
+
+def time_reduce_dwconv_fwd(x, lens, w, bias, out, B, T, d, ld):
+    check(lib.mi355x_time_reduce_dwconv_fwd(_ptr(x), _ptr(lens), _ptr(w), _ptr(bias), _ptr(out), dt(out), B, T, d, ld, _stream()),
+          "time_reduce_dwconv_fwd")
+
+
+def time_reduce_dwconv_bwd(dout, ld, x, lens, w, dx, dw, dbias, B, T, d):
+    check(lib.mi355x_time_reduce_dwconv_bwd(_ptr(dout), dt(dout), ld, _ptr(x), _ptr(lens), _ptr(w), _ptr(dx), _ptr(dw), _ptr(dbias),
+                                            B, T, d, _stream()), "time_reduce_dwconv_bwd")
+
+
+def time_recover_fwd(skip, ys, out, B, T, d):
+    check(lib.mi355x_time_recover_fwd(_ptr(skip), _ptr(ys), _ptr(out), B, T, d, _stream()), "time_recover_fwd")
+
+
+def time_recover_bwd(dx, dys, B, T, d, ld):
+    check(lib.mi355x_time_recover_bwd(_ptr(dx), _ptr(dys), dt(dys), B, T, d, ld, _stream()), "time_recover_bwd")
+
+
 def drop_scale_cast(x, out, n, alpha=1.0, drop: Dropout = NO_DROP):
     check(lib.mi355x_drop_scale_cast(_ptr(x), dt(x), _ptr(out), dt(out), n, alpha, drop.key, drop.threshold, drop.scale,
                                      _stream()), "drop_scale_cast")

@@ -45,6 +45,49 @@ class NoamAnnealing:
         return self.lr_at(self.last_epoch)
 
 
+class NoamHoldAnnealing:
+    """nemo/core/optim/lr_scheduler.py:153-228 (WarmupHoldPolicy.get_lr) + :429-435, 578-639: linear warm-up to the peak lr,
+    hold, then lr * warmup^rate / (step - hold)^rate (the Squeezeformer recipe: decay_rate 1.0).  Same step / get_last_lr
+    surface as NoamAnnealing."""
+
+    def __init__(self, base_lr: float, warmup_steps=None, warmup_ratio=None, hold_steps=None, hold_ratio=None, max_steps=None,
+                 decay_rate=0.5, min_lr=0.0):
+        assert not (warmup_steps is not None and warmup_ratio is not None), "Either use particular number of step or ratio"
+        assert not (hold_steps is not None and hold_ratio is not None), "Either use particular number of step or ratio"
+        assert hold_ratio is None or max_steps is not None, "If there is a ratio, there should be a total steps"
+        assert warmup_ratio is None or max_steps is not None, "If there is a ratio, there should be a total steps"
+        self.base_lr, self.min_lr, self.decay_rate, self.max_steps = base_lr, min_lr, decay_rate, max_steps
+        self.warmup_steps = warmup_steps if warmup_steps is not None else (int(warmup_ratio * max_steps) if warmup_ratio else 0)
+        if hold_steps is not None:
+            self.hold_steps = hold_steps + self.warmup_steps
+        elif hold_ratio is not None:
+            self.hold_steps = int(hold_ratio * max_steps) + self.warmup_steps
+        else:
+            self.hold_steps = 0
+        self.last_epoch = 0
+
+    def lr_at(self, step: int) -> float:
+        if step <= self.warmup_steps and self.warmup_steps > 0:
+            return self.base_lr * (step + 1) / (self.warmup_steps + 1)  # _get_warmup_lr (:138-140)
+        if self.warmup_steps <= step < self.hold_steps:
+            return self.base_lr
+        if self.max_steps is not None and step > self.max_steps:
+            return self.min_lr
+        if not self.warmup_steps:
+            raise ValueError("Noam scheduler cannot be used without warmup steps")
+        hold = self.hold_steps - self.warmup_steps if self.hold_steps > 0 else 0
+        t_warm = max(1, self.warmup_steps ** self.decay_rate)
+        t_hold = max(1, (step - hold) ** self.decay_rate)
+        return max(self.base_lr * t_warm / t_hold, self.min_lr)
+
+    def step(self) -> float:
+        self.last_epoch += 1
+        return self.lr_at(self.last_epoch)
+
+    def get_last_lr(self) -> float:
+        return self.lr_at(self.last_epoch)
+
+
 class FusedAdamW:
     """`max_grad_norm` = trainer.gradient_clip_val (global L2 norm over every flat buffer, computed and applied on the
     device); `ema_decay` = the EMA callback's decay (nemo/collections/common/callbacks/ema.py): the average is updated inside

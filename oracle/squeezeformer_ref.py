@@ -125,7 +125,7 @@ def encoder_forward(P: Dict[str, Tensor], cfg: SqueezeformerCfg, mel: Tensor, me
     B, T, d = x.shape
     if cfg.xscaling:
         x = x * math.sqrt(d)
-    pos_emb = R.rel_pos_table(T, d)
+    pos_emb = R.rel_pos_table(T, d).to(x.dtype)
     valid = torch.arange(T).unsqueeze(0) < enc_len.unsqueeze(1)
     x = R._ln(P, "pre_ln.", x)
     rec_idx = cfg.time_recovery_idx if cfg.time_recovery_idx is not None else cfg.n_layers - 1
@@ -134,7 +134,7 @@ def encoder_forward(P: Dict[str, Tensor], cfg: SqueezeformerCfg, mel: Tensor, me
         if cfg.time_reduce_idx is not None and i == cfg.time_reduce_idx:
             cache = (x, valid, pos_emb)
             x, valid = time_reduction(P, "time_reduce_layer.", x, valid)
-            pos_emb = R.rel_pos_table(x.shape[1], d)
+            pos_emb = R.rel_pos_table(x.shape[1], d).to(x.dtype)
         if cfg.time_reduce_idx is not None and i == rec_idx:
             x0, valid, pos_emb = cache
             x = torch.repeat_interleave(x, repeats=2, dim=1)[:, : x0.shape[1]]
