@@ -137,14 +137,20 @@ class ConvASRDecoder(NeuralModule):
         W = self._plan(cdt, dev)
         M, V1 = B * T, self._num_classes
         x = enc.transpose(1, 2).contiguous().view(M, d)  # no copy when enc is the encoder's [B,T,d] view
-        if x.dtype != cdt:
-            xc = torch.empty(M, d, dtype=cdt, device=dev)
-            ops.drop_scale_cast(x, xc, M * d, 1.0)
+        # bf16 operand rows start on 16-byte boundaries: a d_model that is not a multiple of 8 (Squeezeformer-Medium: 324)
+        # gets row pitch roundup8(d) with zero pad columns
+        ldx = _pad8(d) if cdt == torch.bfloat16 else d
+        if x.dtype != cdt or ldx != d:
+            xc = torch.empty(M, ldx, dtype=cdt, device=dev)
+            if ldx != d or (M * d) % 8:
+                ops.cast_pitched(x.float() if x.dtype != torch.float32 else x, xc, M, d, ldx)
+            else:
+                ops.drop_scale_cast(x, xc, M * d, 1.0)
         else:
             xc = x
         logits = torch.empty(M, V1, dtype=torch.float32, device=dev)
         conv = self.decoder_layers[0]
-        ops.gemm(xc, W["dec.w"], logits, M, V1, d, d, W.pitch("dec.w"), V1, bias=conv.bias,
+        ops.gemm(xc, W["dec.w"], logits, M, V1, d, ldx, W.pitch("dec.w"), V1, bias=conv.bias,
                  alpha=1.0 / self.temperature if self.temperature != 1.0 else 1.0)
         logp = torch.empty(B, T, V1, dtype=torch.float32, device=dev)
         ops.log_softmax_fwd(logits, V1, logp, V1, M, V1)
@@ -164,7 +170,7 @@ class ConvASRDecoder(NeuralModule):
         # d weight [V1, d] += dlogits^T @ x
         tiles = ((V1 + 255) // 256) * ((d + 127) // 128) if cdt == torch.bfloat16 else ((V1 + 63) // 64) * ((d + 63) // 64)
         nk = (M + 63) // 64
-        ops.gemm(dlogits, xc, conv.weight.grad, V1, d, M, Vp, d, d, transA=True, transB=True, atomic=True,
+        ops.gemm(dlogits, xc, conv.weight.grad, V1, d, M, Vp, xc.shape[1], d, transA=True, transB=True, atomic=True,
                  splitk=max(1, min(max(1, nk // 4), 256 // tiles)), c_dtype=ops.F32)
         denc = torch.empty(B, T, d, dtype=torch.float32, device=dev)
         ops.gemm(dlogits, W["dec.wt"], denc, M, d, Vp, Vp, W.pitch("dec.wt"), d)
