@@ -148,9 +148,10 @@ int mi355x_cast_rows(const void* src, long long ld_in, void* dst, int dst_dtype,
 /* y (dtype) [M, ld] = x f32 [M, d] * scale + bias   (scale = bias = NULL: plain cast, adaptive_scale = False) */
 int mi355x_scale_bias_fwd(const void* x, const void* scale, const void* bias, void* y, int y_dtype, long long M, int d, int ld,
                           void* stream);
-/* dres f32 [M, d] += dy * scale;  dscale[d] += colsum(dy * x);  dbias[d] += colsum(dy)   (dscale = dbias = NULL: skipped) */
+/* dres f32 [M, d] += dy * scale;  dscale[d] += colsum(dy * x);  dbias[d] += colsum(dy)   (dscale = dbias = NULL: skipped);
+ * scratch: f32 work space of at least min(M, 512) * 2 * d elements (per-workgroup partial column sums) */
 int mi355x_scale_bias_bwd(const void* dy, int dy_dtype, int ld, const void* x, const void* scale, void* dres, void* dscale,
-                          void* dbias, long long M, int d, void* stream);
+                          void* dbias, long long M, int d, void* scratch, long long scratch_elems, void* stream);
 /* y (dtype) [M, ld] = alpha * dropmask(m*d + c) * x f32 [M, d]  -- the dropout mask of a GEMM epilogue with N = d */
 int mi355x_cast_pitched(const void* x, void* y, int y_dtype, long long M, int d, int ld, float alpha, unsigned drop_key,
                         unsigned drop_threshold, float drop_scale, void* stream);

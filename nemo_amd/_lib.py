@@ -82,7 +82,7 @@ SIGNATURES = {
     "mi355x_log_softmax_fwd": [vp, i64, vp, i64, i32, i32, vp],
     "mi355x_log_softmax_bwd": [vp, vp, i64, vp, i32, i64, i32, i32, f32, vp],
     "mi355x_scale_bias_fwd": [vp, vp, vp, vp, i32, i64, i32, i32, vp],
-    "mi355x_scale_bias_bwd": [vp, i32, i32, vp, vp, vp, vp, vp, i64, i32, vp],
+    "mi355x_scale_bias_bwd": [vp, i32, i32, vp, vp, vp, vp, vp, i64, i32, vp, i64, vp],
     "mi355x_cast_pitched": [vp, vp, i32, i64, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_swish_mask_fwd": [vp, vp, i32, vp, i32, i64, i32, vp],
     "mi355x_swish_mask_bwd": [vp, vp, vp, i32, vp, i32, i64, i32, vp],

@@ -1072,13 +1072,33 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem4[];  // 2 stages x 64 KiB
   const int tn = (p.N + BN4 - 1) / BN4, tm = (p.M + BM2 - 1) / BM2;
   const int ntiles = tm * tn;
-  const int bid = blockIdx.x;
-  const int q8 = ntiles >> 3, r8 = ntiles & 7;
-  const int xcd = bid & 7, idx = bid >> 3;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  int logical, z, ks;
+  if constexpr (G == 2) {
+    // conv weight gradient (9 taps x 4 tiles x split-K): the workgroups of ONE K slice -- all taps, all tiles -- share the
+    // slice's rows of dY and its (overlapping, tap-shifted) rows of the activation grid, but the plain (x, y, z) order deals
+    // them to the 8 XCDs (8 private L2s) so that the workgroups resident on an XCD together belong to different K slices
+    // and share nothing (measured: 3.9 GB fetched for 1.6 GB of operands).  Here the (K slice, tap, tile) list is laid out
+    // slice-major and every XCD takes a contiguous eighth of it: co-resident workgroups work on the same slice.
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int Wt = gx * gy * gz;
+    const int L = (int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z);  // dispatch order: XCD = L % 8
+    const int q8w = Wt >> 3, r8w = Wt & 7, xw = L & 7;
+    const int w = (xw < r8w ? xw * (q8w + 1) : r8w * (q8w + 1) + (xw - r8w) * q8w) + (L >> 3);
+    const int ncombo = gx * gz;
+    ks = w / ncombo;
+    const int combo = w - ks * ncombo;
+    z = combo / gx;
+    logical = combo - z * gx;
+  } else {
+    const int bid = blockIdx.x;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    z = blockIdx.z;
+    ks = blockIdx.y;
+  }
   const int tile_m = logical / tn, tile_n = logical - tile_m * tn;
   const int m0 = tile_m * BM2, n0 = tile_n * BN4;
-  const int z = blockIdx.z;
   const int z0 = z % p.nb0, z1 = z / p.nb0;
   const bf16_t* A = (const bf16_t*)p.A + z0 * p.sA0 + z1 * p.sA1;
   const bf16_t* B = (const bf16_t*)p.B + z0 * p.sB0 + z1 * p.sB1;
@@ -1086,7 +1106,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
   const int nk_total = (p.K + BK - 1) / BK;
   int kt0 = 0, kt1 = nk_total;
   if (p.splitk > 1) {
-    kt0 = blockIdx.y * p.ktiles_per_split;
+    kt0 = ks * p.ktiles_per_split;
     kt1 = min(nk_total, kt0 + p.ktiles_per_split);
     if (kt0 >= kt1) return;
   }

@@ -577,8 +577,8 @@ class SqueezeformerEncoder(ConformerEncoder):
         dx = dout.transpose(1, 2).contiguous().view(M, d).to(torch.float32)
         C2 = 2 * d
         S.bn_sums = torch.zeros(self.n_layers, 2, C2, dtype=torch.float64, device=dev)
-        # grouped weight-gradient launches need 8-element aligned weight rows
-        self._wg_pending = [] if (self.wgrad_grouped and cdt == torch.bfloat16 and d % 8 == 0 and dkp == self.d_k) else None
+        # (the grouped launch takes any n_out / n_in: its operands are pitched, its epilogue is per-element atomics)
+        self._wg_pending = [] if (self.wgrad_grouped and cdt == torch.bfloat16) else None
         dskip = None
         for i in range(self.n_layers - 1, -1, -1):
             g = S.geos[i]

@@ -293,8 +293,9 @@ def scale_bias_fwd(x, scale, bias, y, M, d, ld):
 
 
 def scale_bias_bwd(dy, ld, x, scale, dres, dscale, dbias, M, d):
+    sc = _scratch("scale_bias_bwd", min(M, 512) * 2 * d, dy.device) if dscale is not None else None
     check(lib.mi355x_scale_bias_bwd(_ptr(dy), dt(dy), ld, _ptr(x), _ptr(scale), _ptr(dres), _ptr(dscale), _ptr(dbias), M, d,
-                                    _stream()), "scale_bias_bwd")
+                                    _ptr(sc), sc.numel() if sc is not None else 0, _stream()), "scale_bias_bwd")
 
 
 def cast_pitched(x, y, M, d, ld, alpha=1.0, drop: Dropout = NO_DROP):

@@ -104,6 +104,14 @@ def test_squeezeformer_medium_geometry_bf16_tracks_fp32():
     (y32, g32), (y16, g16) = outs
     assert _rel(y16, y32) < 3e-2
     assert torch.dot(g16, g32) / (g16.norm() * g32.norm()) > 0.99
+    fp32_, fp16_ = e32.flat_parameters(), e16.flat_parameters()
+    bad = {}
+    for n in fp32_.order:  # per tensor, not only the flat cosine: a wrong head / pad lane would hide in the aggregate
+        o, k = fp32_.offsets[n]
+        a, b = g16[o:o + k], g32[o:o + k]
+        if b.norm() > 1e-4 * g32.norm() and _rel(a, b) > 8e-2:
+            bad[n] = _rel(a, b)
+    assert not bad, bad
     kw.update(dropout=0.1, dropout_att=0.1)
     ed = SqueezeformerEncoder(compute_dtype=torch.bfloat16, **kw)
     ed.load_state_dict(e32.state_dict())

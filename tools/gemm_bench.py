@@ -72,6 +72,24 @@ if os.environ.get("WGRAD_AB"):
         run("proj_fwd_resid", M, 512, 512, "resid")
         run("ffn1_dgrad_store", M, 512, 2048, "store")
     sys.exit(0)
+if os.environ.get("CONV2_WGRAD"):  # the sub-sampling conv2 weight gradient exactly as the encoder issues it (gathered operand)
+    from nemo_amd.modules.conformer_encoder import ConformerEncoder as CE
+    B_, T1, F1, C_ = 32, 1001, 40, 512
+    T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+    M2 = B_ * T2 * F2
+    g = torch.Generator(device=dev).manual_seed(0)
+    dout2 = torch.randn(M2, C_, device=dev, generator=g).to(bf)
+    out1 = torch.randn(B_, T1, F1, C_, device=dev, generator=g).to(bf)
+    dW = torch.zeros(C_, C_, 3, 3, device=dev)
+    sk = CE._splitk(CE._tiles(C_, C_, True) * 9, M2)
+    f = lambda: ops.gemm(dout2, out1, dW, C_, C_, M2, C_, C_, 9 * C_, transA=True, transB=True, atomic=True, splitk=sk, batch=9,
+                         nb0=9, sC=(1, 0), c_col_stride=9, c_dtype=ops.F32,
+                         gather=dict(operand=1, nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2,
+                                     taps=[(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]))
+    for rep in range(int(os.environ.get("REPS", "3"))):
+        t = timeit(f)
+        print(f"conv2_wgrad_gathered splitk={sk} {t*1e6:9.1f} us  {2.0*M2*C_*9*C_/t/1e12:8.1f} TFLOP/s", flush=True)
+    sys.exit(0)
 if os.environ.get("PMC_SHAPES"):  # two shapes for counter collection (structure chosen by the MI355X_GEMM_* environment)
     run("big_square_bias", 8192, 8192, 8192, "store")
     run("ffn1_fwd_swish", M, 2048, 512, "swish")
