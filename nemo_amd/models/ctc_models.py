@@ -16,7 +16,7 @@ from torch import nn
 
 from ..core import NeuralModule, Serialization, load_nemo, resolve_target, save_nemo
 from ..modules import AudioToMelSpectrogramPreprocessor, ConformerEncoder, ConvASRDecoder, CTCLoss
-from ..optim import FusedAdamW, NoamAnnealing, NoamHoldAnnealing
+from ..optim import CosineAnnealing, FusedAdamW, NoamAnnealing, NoamHoldAnnealing
 from ..parallel import GradSync
 
 _DEFAULT_TARGETS = {
@@ -313,6 +313,20 @@ class EncDecCTCModel(nn.Module):
                                                     warmup_ratio=sched.get("warmup_ratio"), hold_steps=sched.get("hold_steps"),
                                                     hold_ratio=sched.get("hold_ratio"), max_steps=sched.get("max_steps"),
                                                     decay_rate=sched.get("decay_rate", 0.5), min_lr=sched.get("min_lr", 0.0))
+                return self._optimizer, self._scheduler
+            if sched.get("name") == "CosineAnnealing":  # the FastConformer recipes (fast-conformer_*_bpe.yaml)
+                max_steps = sched.get("max_steps") or (getattr(self.trainer, "max_steps", None) if self.trainer is not None else None)
+                if not max_steps or max_steps < 0:
+                    # modelPT.py prepare_lr_scheduler: without `max_steps` (or a dataloader to derive it from) the reference
+                    # logs a warning and trains WITHOUT a scheduler
+                    import warnings
+                    warnings.warn("CosineAnnealing needs `max_steps` (optim.sched.max_steps or trainer.max_steps): "
+                                  "scheduler will not be instantiated")
+                    self._scheduler = None
+                    return self._optimizer, self._scheduler
+                self._scheduler = CosineAnnealing(oc.get("lr", 1e-3), max_steps=max_steps, warmup_steps=sched.get("warmup_steps"),
+                                                  warmup_ratio=sched.get("warmup_ratio"), constant_steps=sched.get("constant_steps"),
+                                                  constant_ratio=sched.get("constant_ratio"), min_lr=sched.get("min_lr", 0.0))
                 return self._optimizer, self._scheduler
             if sched.get("name") != "NoamAnnealing":
                 raise NotImplementedError(f"scheduler '{sched.get('name')}'")

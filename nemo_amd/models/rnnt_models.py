@@ -35,6 +35,17 @@ class EncDecRNNTModel(EncDecCTCModel):
         self.encoder = _build_ctc("encoder", cfg["encoder"])
         # rnnt_models.py:60-90: vocabulary size and hidden sizes are injected into the decoder / joint sections
         vocab = cfg.get("labels")
+        self.tokenizer = None
+        tok_cfg = cfg.get("tokenizer")
+        if vocab is None and tok_cfg and (tok_cfg.get("dir") or tok_cfg.get("model_path")):
+            # EncDecRNNTBPEModel (rnnt_bpe_models.py:40-90): the SentencePiece pieces in id order are the vocabulary
+            from ..data import SentencePieceTokenizer
+            if str(tok_cfg.get("type", "bpe")).lower() != "bpe":
+                raise NotImplementedError("WordPiece (BERT) tokenizers: the transducer recipes use SentencePiece `bpe`")
+            model_path = tok_cfg.get("model_path") or os.path.join(tok_cfg["dir"], "tokenizer.model")
+            self.tokenizer = SentencePieceTokenizer(model_path)
+            vocab = self.tokenizer.vocab
+            cfg["tokenizer"] = dict(tok_cfg, model_path=model_path, type="bpe")
         n_cls = len(vocab) if vocab is not None else int(cfg["joint"].get("num_classes", cfg["decoder"].get("vocab_size", -1)))
         if n_cls < 1:
             raise ValueError("the vocabulary size must be given (`labels`, `joint.num_classes` or `decoder.vocab_size`)")
@@ -61,6 +72,9 @@ class EncDecRNNTModel(EncDecCTCModel):
 
     def trainable_modules(self):
         return [self.encoder, self.decoder, self.joint]
+
+    def _artifacts(self):
+        return {"tokenizer.model_path": self._cfg["tokenizer"]["model_path"]} if self.tokenizer is not None else {}
 
     @property
     def wer(self):

@@ -12,6 +12,8 @@ from typing import List
 import torch
 
 from . import ops
+import math
+
 from .flat import FlatParams
 
 
@@ -79,6 +81,50 @@ class NoamHoldAnnealing:
         t_warm = max(1, self.warmup_steps ** self.decay_rate)
         t_hold = max(1, (step - hold) ** self.decay_rate)
         return max(self.base_lr * t_warm / t_hold, self.min_lr)
+
+    def step(self) -> float:
+        self.last_epoch += 1
+        return self.lr_at(self.last_epoch)
+
+    def get_last_lr(self) -> float:
+        return self.lr_at(self.last_epoch)
+
+
+class CosineAnnealing:
+    """nemo/core/optim/lr_scheduler.py:273-385 (WarmupAnnealHoldPolicy.get_lr) + :387-414, 467-515 -- the FastConformer recipes'
+    schedule: linear warm-up (step + 1) / (warmup + 1), cosine decay to min_lr at max_steps; with `constant_steps` the
+    Megatron variant (warm-up step / warmup, decay over max_steps - warmup - constant, then min_lr)."""
+
+    def __init__(self, base_lr: float, max_steps: int, warmup_steps=None, warmup_ratio=None, constant_steps=None,
+                 constant_ratio=None, min_lr=0.0):
+        assert not (warmup_steps is not None and warmup_ratio is not None), "Either use particular number of step or ratio"
+        assert not (constant_steps is not None and constant_ratio is not None), "Either use constant_steps or constant_ratio"
+        if base_lr < min_lr:
+            raise ValueError("received an initial learning rate that was lower than the minimum learning rate.")
+        self.base_lr, self.min_lr, self.max_steps = base_lr, min_lr, max_steps
+        self.warmup_steps = warmup_steps if warmup_steps is not None else (int(warmup_ratio * max_steps) if warmup_ratio else 0)
+        self.constant_steps = constant_steps if constant_steps is not None else (
+            int(constant_ratio * max_steps) if constant_ratio else 0)
+        self.decay_steps = max_steps - (self.constant_steps + self.warmup_steps)
+        self.last_epoch = 0
+
+    def _megatron(self, step):
+        if self.warmup_steps > 0 and step <= self.warmup_steps:
+            return self.base_lr * float(step) / float(self.warmup_steps)
+        if step > self.warmup_steps + self.decay_steps:
+            return self.min_lr
+        ratio = float(step - self.warmup_steps) / float(self.decay_steps)
+        return self.min_lr + 0.5 * (math.cos(math.pi * ratio) + 1.0) * (self.base_lr - self.min_lr)
+
+    def lr_at(self, step: int) -> float:
+        if self.constant_steps:
+            return self._megatron(step) if step <= self.max_steps else self.min_lr
+        if self.warmup_steps > 0 and step <= self.warmup_steps:
+            return self.base_lr * (step + 1) / (self.warmup_steps + 1)
+        if step > self.max_steps:
+            return self.min_lr
+        mult = 0.5 * (1 + math.cos(math.pi * (step - self.warmup_steps) / (self.max_steps - self.warmup_steps)))
+        return (self.base_lr - self.min_lr) * mult + self.min_lr
 
     def step(self) -> float:
         self.last_epoch += 1

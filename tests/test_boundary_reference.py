@@ -1,0 +1,214 @@
+"""The drop-in boundary against the reference's own artefacts.  CPU-only, and only
+where the reference tree exists (the build container): (1) the reference's recipe YAMLs -- parsed with nemo_amd.config (PyYAML +
+the `${...}` / YAML-1.2-float / `???` behaviours of OmegaConf that the recipes rely on) -- build the drop-in models UNMODIFIED;
+(2) every typed port of the drop-in NeuralModules equals the port the reference class declares, compared with the reference's
+own `NeuralType.compare` (nemo/core/neural_types/neural_type.py, loaded through oracle/ref_shim.py)."""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+
+REF = os.environ.get("NEMO_REFERENCE_ROOT", "/root/reference")
+CONF = os.path.join(REF, "examples", "asr", "conf")
+pytestmark = pytest.mark.skipif(not os.path.isdir(CONF), reason="reference tree not present (GPU box)")
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _params(m):
+    return sum(p.numel() for p in m.parameters())
+
+
+@pytest.fixture(scope="module")
+def tok_dir(tmp_path_factory):
+    from test_abi_and_host import _train_spm
+    words = ["hello", "world", "speech", "model", "conformer", "audio", "signal", "frame", "token", "layer", "attention", "gradient"]
+    return _train_spm(tmp_path_factory.mktemp("tok"), "tok64", 64, words)
+
+
+def test_config_loader_matches_omegaconf_semantics_on_the_recipe():
+    from nemo_amd.config import MissingMandatoryValue, load_config, missing_keys, select
+    c = load_config(os.path.join(CONF, "conformer", "conformer_ctc_bpe.yaml"),
+                    overrides=["model.tokenizer.dir=/x/y", "+trainer.fast_dev_run=True", "model.optim.lr=1.5", "~model.interctc"])
+    m = c["model"]
+    assert m["encoder"]["feat_in"] == 80 and m["train_ds"]["sample_rate"] == 16000        # ${model.preprocessor.features}
+    assert m["optim"]["sched"]["d_model"] == 512                                          # ${model.encoder.d_model}
+    assert isinstance(m["optim"]["weight_decay"], float) and m["optim"]["weight_decay"] == 1e-3   # '1e-3': YAML 1.2 float
+    assert m["optim"]["sched"]["min_lr"] == 1e-6 and m["optim"]["lr"] == 1.5
+    assert c["trainer"]["fast_dev_run"] is True and "interctc" not in m
+    assert m["tokenizer"]["dir"] == "/x/y"
+    assert missing_keys(c) == ["model.train_ds.manifest_filepath", "model.validation_ds.manifest_filepath"]
+    with pytest.raises(MissingMandatoryValue):
+        select(c, "model.train_ds.manifest_filepath", throw_on_missing=True)
+    with pytest.raises(KeyError):
+        load_config(os.path.join(CONF, "conformer", "conformer_ctc_bpe.yaml"), overrides=["model.no_such_key=1"])
+
+
+@pytest.mark.parametrize("rel,cls_name,enc_name,n_params", [
+    ("conformer/conformer_ctc_bpe.yaml", "EncDecCTCModelBPE", "ConformerEncoder", None),
+    ("conformer/conformer_ctc_char.yaml", "EncDecCTCModel", "ConformerEncoder", None),
+    ("squeezeformer/squeezeformer_ctc_bpe.yaml", "EncDecCTCModelBPE", "SqueezeformerEncoder", None),
+    ("fastconformer/fast-conformer_ctc_bpe.yaml", "EncDecCTCModelBPE", "ConformerEncoder", None),
+    ("fastconformer/fast-conformer_transducer_bpe.yaml", "EncDecRNNTModel", "ConformerEncoder", None),
+])
+def test_reference_recipe_yaml_builds_the_drop_in_model_unmodified(rel, cls_name, enc_name, n_params, tok_dir):
+    """the `model:` section of the reference's recipe, `_target_` strings and all, goes into the drop-in class as is; the only
+    override is the one every user of the recipe has to give (`model.tokenizer.dir`)"""
+    import nemo_amd.models as M
+    from nemo_amd.config import load_config
+    ov = [f"model.tokenizer.dir={tok_dir}"] if "bpe" in rel else []
+    cfg = load_config(os.path.join(CONF, rel), overrides=ov)
+    model = getattr(M, cls_name)(cfg["model"])
+    enc_cfg = cfg["model"]["encoder"]
+    assert type(model.encoder).__name__ == enc_name
+    assert len(model.encoder.layers) == enc_cfg["n_layers"] and model.encoder.d_model == enc_cfg["d_model"]
+    assert model.encoder._feat_in == cfg["model"]["preprocessor"]["features"]
+    sd = model.state_dict()
+    if cls_name == "EncDecRNNTModel":
+        assert model.joint.fuse_loss_wer and model.decoder.vocab_size == 64
+        assert "decoder.prediction.embed.weight" in sd and "joint.joint_net.2.weight" in sd
+    else:
+        assert sd["decoder.decoder_layers.0.weight"].shape[0] == (65 if "bpe" in rel else len(cfg["model"]["labels"]) + 1)
+    if "conformer_ctc_bpe" in rel and "fast" not in rel:
+        # Conformer-CTC-Large: 18 x d=512 (the recipe's default size) -- parameter count of the reference model
+        assert abs(_params(model) - 121.4e6) < 0.3e6
+    oc = dict(cfg["model"]["optim"])
+    if oc["sched"]["name"] == "CosineAnnealing":  # max_steps comes from the trainer at run time (modelPT.py prepare_lr_scheduler)
+        oc["sched"] = dict(oc["sched"], max_steps=100000)
+    opt, sched = model.setup_optimization(oc)
+    assert opt is not None and sched is not None and sched.get_last_lr() > 0
+
+
+def _real_types():
+    from oracle import ref_shim
+    ref_shim.install()
+    return importlib.import_module("nemo.core.neural_types")
+
+
+def _to_real(nt_mod, mirror):
+    """the drop-in's declared port -> the reference's NeuralType of the same axes / element class name / optional flag"""
+    if mirror.elements_type is None:  # NeuralType(optional=True): the reference defaults to VoidType
+        return nt_mod.NeuralType(tuple(mirror.axes) if mirror.axes is not None else None, optional=mirror.optional)
+    el = getattr(nt_mod, type(mirror.elements_type).__name__)
+    kw = {}
+    if type(mirror.elements_type).__name__ == "AudioSignal" and getattr(mirror.elements_type, "freq", None) is not None:
+        kw["freq"] = mirror.elements_type.freq
+    return nt_mod.NeuralType(tuple(mirror.axes) if mirror.axes is not None else None, el(**kw), optional=mirror.optional)
+
+
+def _compare_ports(nt_mod, ours, ref, what):
+    SAME = nt_mod.NeuralTypeComparisonResult.SAME
+    ref = {k: v for k, v in ref.items()}
+    for name, mine in ours.items():
+        assert name in ref, f"{what}: port '{name}' is not declared by the reference ({list(ref)})"
+        theirs = ref[name]
+        if isinstance(theirs, (list, tuple)):
+            theirs = theirs[0]
+        assert theirs.compare(_to_real(nt_mod, mine)) == SAME, (what, name, str(theirs), str(mine))
+        assert bool(theirs.optional) == bool(mine.optional), (what, name)
+    mandatory = [k for k, v in ref.items() if not (v[0] if isinstance(v, (list, tuple)) else v).optional]
+    assert [k for k in mandatory if k not in ours] == [], f"{what}: mandatory reference ports missing"
+
+
+def test_typed_ports_equal_the_reference_declarations():
+    """input_types / output_types of the drop-in modules, port by port, against the reference classes instantiated through
+    the shim -- judged by the reference's own NeuralType.compare (axes kinds, element type, optional)."""
+    nt_mod = _real_types()
+    import nemo_amd.modules as A
+    ref_enc = importlib.import_module("nemo.collections.asr.modules.conformer_encoder").ConformerEncoder(
+        feat_in=16, n_layers=1, d_model=16, n_heads=2, conv_kernel_size=5)
+    ours = A.ConformerEncoder(feat_in=16, n_layers=1, d_model=16, n_heads=2, conv_kernel_size=5)
+    _compare_ports(nt_mod, ours.input_types, ref_enc.input_types, "ConformerEncoder.input_types")
+    _compare_ports(nt_mod, ours.output_types, ref_enc.output_types, "ConformerEncoder.output_types")
+    ref_sq = importlib.import_module("nemo.collections.asr.modules.squeezeformer_encoder").SqueezeformerEncoder(
+        feat_in=16, n_layers=1, d_model=16, n_heads=2, conv_kernel_size=5, subsampling="dw_striding")
+    ours = A.SqueezeformerEncoder(feat_in=16, n_layers=1, d_model=16, n_heads=2, conv_kernel_size=5)
+    _compare_ports(nt_mod, ours.input_types, ref_sq.input_types, "SqueezeformerEncoder.input_types")
+    _compare_ports(nt_mod, ours.output_types, ref_sq.output_types, "SqueezeformerEncoder.output_types")
+    conv_asr = importlib.import_module("nemo.collections.asr.modules.conv_asr")
+    ref_dec = conv_asr.ConvASRDecoder(feat_in=16, num_classes=5)
+    ours = A.ConvASRDecoder(feat_in=16, num_classes=5)
+    _compare_ports(nt_mod, ours.input_types, ref_dec.input_types, "ConvASRDecoder.input_types")
+    _compare_ports(nt_mod, ours.output_types, ref_dec.output_types, "ConvASRDecoder.output_types")
+    rn = importlib.import_module("nemo.collections.asr.modules.rnnt")
+    prednet = {"pred_hidden": 8, "pred_rnn_layers": 1, "dropout": 0.0}
+    ref_pred = rn.RNNTDecoder(prednet=prednet, vocab_size=5)
+    ours = A.RNNTDecoder(prednet=prednet, vocab_size=5)
+    _compare_ports(nt_mod, ours.input_types, ref_pred.input_types, "RNNTDecoder.input_types")
+    _compare_ports(nt_mod, ours.output_types, ref_pred.output_types, "RNNTDecoder.output_types")
+    jn = {"encoder_hidden": 8, "pred_hidden": 8, "joint_hidden": 8, "activation": "relu", "dropout": 0.0}
+    ref_joint = rn.RNNTJoint(jointnet=jn, num_classes=5)
+    ours = A.RNNTJoint(jointnet=jn, num_classes=5)
+    _compare_ports(nt_mod, ours.input_types, ref_joint.input_types, "RNNTJoint.input_types")
+    # (the reference's audio_preprocessing.py cannot be imported here: it pulls numba / hydra at module level; the
+    #  preprocessor's ports are [B,T] AudioSignal + [B] lengths -> [B,D,T] MelSpectrogramType + [B] lengths, checked against the
+    #  reference's *behaviour* by tests/test_oracle_pinning.py through FilterbankFeatures)
+
+
+def test_mirrored_element_types_exist_in_the_reference():
+    nt_mod = _real_types()
+    import nemo_amd.core as C
+    for name in dir(C):
+        obj = getattr(C, name)
+        if isinstance(obj, type) and issubclass(obj, C.ElementType) and obj is not C.ElementType:
+            assert hasattr(nt_mod, name), f"element type {name} does not exist in nemo.core.neural_types"
+            ref_bases = [b.__name__ for b in getattr(nt_mod, name).__mro__]
+            for b in obj.__mro__[1:]:
+                if b not in (C.ElementType, object):
+                    assert b.__name__ in ref_bases, (name, b.__name__)
+
+
+def test_with_nemo_core_importable_the_modules_are_real_neural_modules(tmp_path):
+    """nemo_amd.core switches to the installed NeMo's NeuralModule / NeuralType / typecheck when `nemo.core` is importable.
+    NeMo's dependencies are not installed here, so the switch is exercised in a subprocess against a package that has the
+    reference's REAL `nemo/core/neural_types` (linked from the reference tree) and a minimal stand-in for `nemo.core.classes`
+    that honours the real module's surface (`common._TYPECHECK_ENABLED`, `NeuralModule`, `typecheck`)."""
+    import subprocess
+    import textwrap
+    pkg = tmp_path / "nemo"
+    (pkg / "core" / "classes").mkdir(parents=True)
+    (pkg / "__init__.py").write_text("")
+    (pkg / "core" / "__init__.py").write_text("")
+    os.symlink(os.path.join(REF, "nemo", "core", "neural_types"), pkg / "core" / "neural_types")
+    (pkg / "utils").mkdir()
+    (pkg / "utils" / "__init__.py").write_text("")
+    (pkg / "core" / "classes" / "common.py").write_text("_TYPECHECK_ENABLED = True\n")
+    (pkg / "core" / "classes" / "__init__.py").write_text(textwrap.dedent("""
+        import torch
+        class NeuralModule(torch.nn.Module):
+            IS_REFERENCE_BASE = True
+        class typecheck:
+            def __init__(self, *a, **k): pass
+            def __call__(self, fn):
+                def wrapper(module, *args, **kwargs):
+                    if args:
+                        raise TypeError("All arguments must be passed by kwargs only for typed methods")
+                    for k, v in kwargs.items():
+                        nt = module.input_types[k]
+                        assert type(nt).__module__.startswith("nemo.core.neural_types"), type(nt)
+                    return fn(module, **kwargs)
+                return wrapper
+    """))
+    code = textwrap.dedent("""
+        import torch, nemo_amd.core as C
+        from nemo_amd.modules import ConformerEncoder, ConvASRDecoder
+        assert C.HAVE_NEMO_CORE
+        import nemo.core.neural_types as nt, nemo.core.classes as cl
+        enc = ConformerEncoder(feat_in=16, n_layers=1, d_model=16, n_heads=2, conv_kernel_size=5)
+        assert isinstance(enc, cl.NeuralModule) and enc.IS_REFERENCE_BASE
+        t = enc.input_types["audio_signal"]
+        assert isinstance(t, nt.NeuralType) and isinstance(t.elements_type, nt.SpectrogramType)
+        assert t.compare(nt.NeuralType(("B", "D", "T"), nt.SpectrogramType())) == nt.NeuralTypeComparisonResult.SAME
+        dec = ConvASRDecoder(feat_in=16, num_classes=5)
+        try:
+            dec(torch.zeros(1, 16, 4))
+            raise SystemExit("positional call was not rejected by the reference typecheck")
+        except TypeError:
+            pass
+        print("REAL-CORE-OK")
+    """)
+    env = dict(os.environ, PYTHONPATH=f"{tmp_path}:{os.path.dirname(os.path.dirname(os.path.abspath(__file__)))}")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert "REAL-CORE-OK" in r.stdout, r.stdout + r.stderr
