@@ -542,24 +542,40 @@ class ConformerEncoder(NeuralModule):
         return out, len2, (S if save else None)
 
     # ------------------------------------------------------------------ 'dw_striding' sub-sampling (FastConformer, Squeezeformer)
-    def _sub_fwd_dw(self, S, mel, lens, W, cdt, save):
+    def _sub_io(self, Wf, cdt, dev, backward=False):
+        """what the 'dw_striding' stack reads and where its gradients go: here the parameters and their `.grad` views.
+        (SqueezeformerEncoder substitutes zero-padded images / scratch gradients when the channel count is not a multiple of 8.)"""
+        pe = self.pre_encode
+        io = _Saved()
+        io.C = pe._conv_channels
+        io.c0w, io.c0b = pe.conv[0].weight, pe.conv[0].bias
+        io.dw = [(dw.weight, dw.bias, pw.bias) for dw, pw in pe.dw_stages()]
+        if backward:
+            io.g_c0w, io.g_c0b = pe.conv[0].weight.grad, pe.conv[0].bias.grad
+            io.g_dw = [(dw.weight.grad, dw.bias.grad, pw.weight.grad, pw.bias.grad) for dw, pw in pe.dw_stages()]
+            io.g_out = pe.out.weight.grad
+        io.finish = None
+        return io
+
+    def _sub_fwd_dw(self, S, mel, lens, W, cdt, save, Wf=None):
         """conv(1->C, 3x3, s2) ReLU -> [depthwise 3x3 s2 -> pointwise 1x1 -> ReLU] x (log2(factor) - 1) -> Linear, every layer
         on a time-masked input (subsampling.py:142-215, 385-436, 725-759).  conv1: the direct kernel of the 'striding' path;
         depthwise: mi355x_dwconv2d_s2_*; pointwise: MFMA GEMM with the ReLU + time-mask epilogue; channels-last throughout."""
         B, F_, T, T1, F1, T2, F2, M, _, training, seed = S.dims
         dev = mel.device
         pe = self.pre_encode
-        C_, d = pe._conv_channels, self.d_model
+        io = self._sub_io(Wf, cdt, dev)
+        C_, d = io.C, self.d_model
         out0 = torch.empty(B, T1, F1, C_, dtype=cdt, device=dev)
-        ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, out0, lens[0], lens[1], C_)
+        ops.conv1_fwd(mel, io.c0w, io.c0b, out0, lens[0], lens[1], C_)
         cur, Tc, Fc = out0, T1, F1
         S.dw = []
-        for si_, (dw, pw) in enumerate(pe.dw_stages()):
+        for si_, (dww, dwb, pwb) in enumerate(io.dw):
             Tn, Fn = (Tc - 1) // 2 + 1, (Fc - 1) // 2 + 1
             dwo = torch.empty(B * Tn * Fn, C_, dtype=cdt, device=dev)
-            ops.dwconv2d_s2_fwd(cur, dw.weight, dw.bias, dwo, B, Tc, Fc, C_)
+            ops.dwconv2d_s2_fwd(cur, dww, dwb, dwo, B, Tc, Fc, C_)
             pwo = torch.empty(B * Tn * Fn, C_, dtype=cdt, device=dev)
-            ops.gemm(dwo, W[f"pre.pw{si_}"], pwo, B * Tn * Fn, C_, C_, C_, W.pitch(f"pre.pw{si_}"), C_, bias=pw.bias,
+            ops.gemm(dwo, W[f"pre.pw{si_}"], pwo, B * Tn * Fn, C_, C_, C_, W.pitch(f"pre.pw{si_}"), C_, bias=pwb,
                      epi=ops.EPI_RELU_MASK, row_len=lens[si_ + 2], rows_per_b=Tn * Fn, rows_inner=Fn)
             S.dw.append((cur, Tc, Fc, dwo, pwo, Tn, Fn))
             cur, Tc, Fc = pwo, Tn, Fn
@@ -569,48 +585,53 @@ class ConformerEncoder(NeuralModule):
         S.out1, S.out2, S.col = out0, cur, None
         return x
 
-    def _sub_bwd_dw(self, S, dx, W, cdt):
+    def _sub_bwd_dw(self, S, dx, W, cdt, Wf=None):
         B, F_, T, T1, F1, T2, F2, M, _, training, seed = S.dims
         dev = dx.device
         pe = self.pre_encode
-        C_, d = pe._conv_channels, self.d_model
+        io = self._sub_io(Wf, cdt, dev, backward=True)
+        C_, d = io.C, self.d_model
         bf16 = cdt == torch.bfloat16
-        dxs = torch.empty(M, d, dtype=cdt, device=dev)
-        if (M * d) % 8:
-            ops.cast_pitched(dx, dxs, M, d, d, (self.xscale or 1.0), S.drop_pre)
+        ldx = _pad8(d) if bf16 else d  # (bf16 operand rows start on 16-byte boundaries)
+        dxs = torch.empty(M, ldx, dtype=cdt, device=dev)
+        if ldx != d or (M * d) % 8:
+            ops.cast_pitched(dx, dxs, M, d, ldx, (self.xscale or 1.0), S.drop_pre)
         else:
             ops.drop_scale_cast(dx, dxs, M * d, (self.xscale or 1.0), S.drop_pre)
         with self._sub_wgrad_scope(dxs):
-            ops.colsum(dxs, pe.out.bias.grad, M, d)
+            ops.colsum(dxs, pe.out.bias.grad, M, d, ld=ldx)
         last = S.out2  # [B*T2*F2, C] = [M, F2*C]
         tiles = self._tiles(d, C_, bf16) * F2
         with self._sub_wgrad_scope(dxs, last):  # d out.weight in the reference's (c, f) column order (batch over f)
-            ops.gemm(dxs, last, pe.out.weight.grad, d, C_, M, d, F2 * C_, C_ * F2, transA=True, transB=True, atomic=True,
+            ops.gemm(dxs, last, io.g_out, d, C_, M, ldx, F2 * C_, C_ * F2, transA=True, transB=True, atomic=True,
                      splitk=self._splitk(tiles, M, strided_c=True), batch=F2, nb0=F2, sB=(C_, 0), sC=(1, 0), c_col_stride=F2,
                      c_dtype=ops.F32)
         dcur = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
-        ops.gemm(dxs, W["pre.outt"], dcur, M, F2 * C_, d, d, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=last)
+        ops.gemm(dxs, W["pre.outt"], dcur, M, F2 * C_, d, ldx, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=last)
         for si_ in range(len(S.dw) - 1, -1, -1):
             cur_in, Tc, Fc, dwo, pwo, Tn, Fn = S.dw[si_]
-            dw, pw = pe.dw_stages()[si_]
+            dww, dwb, pwb = io.dw[si_]
+            g_dww, g_dwb, g_pww, g_pwb = io.g_dw[si_]
             Ms = B * Tn * Fn
             # pointwise conv: bias / weight gradients, then the gradient w.r.t. the depthwise output (no gate: no ReLU there)
             if bf16 and C_ >= 192:
                 with self._sub_wgrad_scope(dcur, dwo):
-                    ops.gemm(dcur, dwo, pw.weight.grad, C_, C_, Ms, C_, C_, C_, transA=True, transB=True, atomic=True,
-                             splitk=self._splitk(self._tiles(C_, C_, True), Ms), c_dtype=ops.F32, colsum_out=pw.bias.grad)
+                    ops.gemm(dcur, dwo, g_pww, C_, C_, Ms, C_, C_, C_, transA=True, transB=True, atomic=True,
+                             splitk=self._splitk(self._tiles(C_, C_, True), Ms), c_dtype=ops.F32, colsum_out=g_pwb)
             else:
                 with self._sub_wgrad_scope(dcur, dwo):
-                    ops.colsum(dcur, pw.bias.grad, Ms, C_)
-                    ops.gemm(dcur, dwo, pw.weight.grad, C_, C_, Ms, C_, C_, C_, transA=True, transB=True, atomic=True,
+                    ops.colsum(dcur, g_pwb, Ms, C_)
+                    ops.gemm(dcur, dwo, g_pww, C_, C_, Ms, C_, C_, C_, transA=True, transB=True, atomic=True,
                              splitk=self._splitk(self._tiles(C_, C_, bf16), Ms), c_dtype=ops.F32)
             ddw = torch.empty(Ms, C_, dtype=cdt, device=dev)
             ops.gemm(dcur, W[f"pre.pw{si_}t"], ddw, Ms, C_, C_, C_, W.pitch(f"pre.pw{si_}t"), C_)
             din = torch.empty(B * Tc * Fc, C_, dtype=cdt, device=dev)
-            ops.dwconv2d_s2_bwd(ddw, cur_in, dw.weight, din, dw.weight.grad, dw.bias.grad, B, Tc, Fc, C_)
+            ops.dwconv2d_s2_bwd(ddw, cur_in, dww, din, g_dww, g_dwb, B, Tc, Fc, C_)
             dcur = din
-        ops.conv1_bwd(dcur, S.mel, S.len0, pe.conv[0].weight.grad, pe.conv[0].bias.grad, C_)
+        ops.conv1_bwd(dcur, S.mel, S.len0, io.g_c0w, io.g_c0b, C_)
         self._wgrad_join()
+        if io.finish is not None:
+            io.finish()
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(*self._flatp.range_of("pre_encode."))
 

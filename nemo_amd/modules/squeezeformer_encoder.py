@@ -23,7 +23,10 @@ arithmetic is unchanged:
   * [M, d] bf16 activations that feed a GEMM have row pitch roundup8(d) with zero pad columns (the kernels of
     squeezeformer.hip take the pitch); weight gradients of the padded heads are produced per head by batched TN GEMMs whose
     batch strides step over the pad lanes;
-  * the sub-sampling stack (conv channels = d_model) runs in fp32 when its channel count is not a multiple of 8.
+  * the sub-sampling stack's channel count (= d_model by default) is padded the same way: zero-padded copies of its small
+    f32 weights / biases and zero rows / columns in the packed pointwise and output images make the pad channels exact
+    zeros through ReLU, depthwise and pointwise stages; weight gradients land in a zeroed scratch of the padded shapes and the
+    real part is added into the parameters' gradients (a handful of KB-sized adds per step).
 """
 from __future__ import annotations
 
@@ -189,9 +192,45 @@ class SqueezeformerEncoder(ConformerEncoder):
         dp, dkp = _pad8(self.d_model), _pad8(self.d_k)  # (same layout in fp32: one code path, exercised by the parity tests)
         return dp, dkp, self.n_heads * dkp
 
-    def _sub_dtype(self, cdt):
+    def _sub_channels(self, cdt):
+        """(real, padded) channel count of the sub-sampling stack"""
         C_ = self.pre_encode._conv_channels
-        return torch.float32 if (cdt == torch.bfloat16 and (C_ % 8 or self.d_model % 8)) else cdt
+        return C_, (_pad8(C_) if cdt == torch.bfloat16 else C_)
+
+    def _sub_io(self, Wf, cdt, dev, backward=False):
+        C_, Cp = self._sub_channels(cdt)
+        if Cp == C_:
+            return super()._sub_io(Wf, cdt, dev, backward)
+        pe = self.pre_encode
+        d, F2 = self.d_model, pe._feat_after
+        n = len(pe.dw_stages())
+        io = _Saved()
+        io.C = Cp
+        io.c0w, io.c0b = Wf["pre.c0w"], Wf["pre.c0b"]
+        io.dw = [(Wf[f"pre.dw{i}w"], Wf[f"pre.dw{i}b"], Wf[f"pre.pw{i}b"]) for i in range(n)]
+        io.finish = None
+        if backward:
+            sizes = [Cp * 9, Cp] + [Cp * 9, Cp, Cp * Cp, Cp] * n + [d * Cp * F2]
+            offs = [0]
+            for k in sizes:
+                offs.append(offs[-1] + (k + 63) // 64 * 64)
+            g = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
+            v = [g[offs[i]: offs[i] + sizes[i]] for i in range(len(sizes))]
+            io.g_c0w, io.g_c0b = v[0], v[1]
+            io.g_dw = [tuple(v[2 + 4 * i: 6 + 4 * i]) for i in range(n)]
+            io.g_out = v[-1]
+
+            def finish():  # real part of the padded gradients -> the parameters' gradients
+                pe.conv[0].weight.grad.view(-1).add_(io.g_c0w[: C_ * 9])
+                pe.conv[0].bias.grad.add_(io.g_c0b[:C_])
+                for (dw, pw), (gw, gb, gpw, gpb) in zip(pe.dw_stages(), io.g_dw):
+                    dw.weight.grad.view(-1).add_(gw[: C_ * 9])
+                    dw.bias.grad.add_(gb[:C_])
+                    pw.weight.grad.view(C_, C_).add_(gpw.view(Cp, Cp)[:C_, :C_])
+                    pw.bias.grad.add_(gpb[:C_])
+                pe.out.weight.grad.add_(io.g_out.view(d, Cp * F2)[:, : C_ * F2])
+            io.finish = finish
+        return io
 
     def _plan(self, cdt, device):
         key = (cdt, str(device), self._flatp.generation)
@@ -204,12 +243,29 @@ class SqueezeformerEncoder(ConformerEncoder):
             dp, dkp, dA = self._geometry(cdt)
             pe = self.pre_encode
             C_, F2 = pe._conv_channels, pe._feat_after
-            ps = pf if self._sub_dtype(cdt) != cdt else p
-            for si_, (_, pw) in enumerate(pe.dw_stages()):
-                ps.add_matrix(f"pre.pw{si_}", pw.weight.data.view(C_, C_))
-                ps.add_matrix(f"pre.pw{si_}t", pw.weight.data.view(C_, C_), True)
-            ps.add_fc_permuted("pre.out", pe.out.weight.data, C_, F2)
-            ps.add_fc_permuted("pre.outt", pe.out.weight.data, C_, F2, transpose=True)
+            Cs, Cp = self._sub_channels(cdt)
+            if Cp == Cs:
+                for si_, (_, pw) in enumerate(pe.dw_stages()):
+                    p.add_matrix(f"pre.pw{si_}", pw.weight.data.view(C_, C_))
+                    p.add_matrix(f"pre.pw{si_}t", pw.weight.data.view(C_, C_), True)
+                p.add_fc_permuted("pre.out", pe.out.weight.data, C_, F2)
+                p.add_fc_permuted("pre.outt", pe.out.weight.data, C_, F2, transpose=True)
+            else:  # zero-padded channels (see the module docstring): dense [Cp, 9] / [Cp] f32 copies + padded GEMM images
+                def dense(name, t, n_pad):
+                    pf.new_image(name, 1, n_pad)
+                    pf.add_block(name, t.view(-1), 1, t.numel(), sr1=0, sc1=1)
+                dense("pre.c0w", pe.conv[0].weight.data, Cp * 9); dense("pre.c0b", pe.conv[0].bias.data, Cp)
+                for si_, (dw, pw) in enumerate(pe.dw_stages()):
+                    dense(f"pre.dw{si_}w", dw.weight.data, Cp * 9); dense(f"pre.dw{si_}b", dw.bias.data, Cp)
+                    dense(f"pre.pw{si_}b", pw.bias.data, Cp)
+                    w = pw.weight.data.view(C_, C_)
+                    p.new_image(f"pre.pw{si_}", Cp, Cp); p.add_block(f"pre.pw{si_}", w, C_, C_, sr1=C_, sc1=1)
+                    p.new_image(f"pre.pw{si_}t", Cp, Cp); p.add_block(f"pre.pw{si_}t", w, C_, C_, sr1=1, sc1=C_)
+                wo_ = pe.out.weight.data  # [d, C*F2], column c*F2 + f  ->  image column f*Cp + c
+                p.new_image("pre.out", d, F2 * Cp); p.new_image("pre.outt", F2 * Cp, d)
+                for f in range(F2):
+                    p.add_block("pre.out", wo_.view(-1)[f:], d, C_, col_off=f * Cp, sr1=C_ * F2, sc1=F2)
+                    p.add_block("pre.outt", wo_.view(-1)[f:], C_, d, row_off=f * Cp, sr1=F2, sc1=C_ * F2)
 
             def heads_rows(name, w, row0):  # w [H*dk, d] -> rows row0 + h*dkp + (0..dk) of image [*, d]
                 for h in range(H):
@@ -300,8 +356,7 @@ class SqueezeformerEncoder(ConformerEncoder):
         S.dims = (B, F_, T, T1, F1, T2, F2, M, cdt, training, seed)
         S.mel, S.len0, S.len2, S.lens_all = mel, lens[0], lens[-1], lens
         S.drop_pre = drop(self.dropout_pre_encoder, 100000)
-        sdt = self._sub_dtype(cdt)
-        x = self._sub_fwd_dw(S, mel, lens, Wf if sdt != cdt else W, sdt, save)
+        x = self._sub_fwd_dw(S, mel, lens, W, cdt, save, Wf=Wf)
         # ---- pre_ln
         x0, pmean, prstd = self._ln_fwd(self.pre_ln, x, M, d, torch.float32, dev)
         S.pre_ln = (x, pmean, prstd)
@@ -624,5 +679,4 @@ class SqueezeformerEncoder(ConformerEncoder):
                     self.grad_ready_hook(*fp.range_of(pfx))
                 except KeyError:
                     pass
-        sdt = self._sub_dtype(cdt)
-        return self._sub_bwd_dw(S, dpre, Wf if sdt != cdt else W, sdt)
+        return self._sub_bwd_dw(S, dpre, W, cdt, Wf=Wf)
