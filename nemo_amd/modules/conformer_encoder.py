@@ -367,6 +367,10 @@ class ConformerEncoder(NeuralModule):
         nk = (K + 63) // 64
         if strided_c:  # atomics into a column-strided C (reference weight layouts) are expensive: only fill the chip once
             return max(1, min(nk // 4 if nk >= 8 else 1, 256 // max(tiles, 1), 16))
+        if tiles < 16:
+            # skinny problems (e.g. the [C, C] pointwise-conv weight gradients of 'dw_striding' over 320 000 positions: 2 tiles):
+            # 16 slices would leave them on 32 CUs (measured: 9.5 ms for 42 GFLOP); one round of the chip, >= 16 K-tiles each
+            return max(1, min(256 // max(tiles, 1), nk // 16, 128))
         best, best_score = 1, -1.0
         for c in range(1, 17):
             if c > 1 and nk // c < 16:

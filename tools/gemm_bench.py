@@ -90,6 +90,30 @@ if os.environ.get("CONV2_WGRAD"):  # the sub-sampling conv2 weight gradient exac
         t = timeit(f)
         print(f"conv2_wgrad_gathered splitk={sk} {t*1e6:9.1f} us  {2.0*M2*C_*9*C_/t/1e12:8.1f} TFLOP/s", flush=True)
     sys.exit(0)
+if os.environ.get("JOINT"):  # the transducer joint's output layer at fused_batch_size 4: n = 4 * 251 * 61 rows, V+1 = 1025, J = 640
+    n, V1, J = 4 * 251 * 61, 1025, 640
+    V1p = 1032
+    g = torch.Generator(device=dev).manual_seed(0)
+    h = torch.randn(n, J, device=dev, generator=g).to(bf)
+    w = torch.randn(V1, J, device=dev, generator=g).to(bf)
+    wt = torch.randn(J, V1p, device=dev, generator=g).to(bf)
+    logits = torch.empty(n, V1, device=dev)
+    dlog = torch.randn(n, V1p, device=dev, generator=g).to(bf); dlog[:, V1:] = 0
+    dh = torch.empty(n, J, device=dev, dtype=bf)
+    gW = torch.zeros(V1, J, device=dev)
+    for rep in range(2):
+        t = timeit(lambda: ops.gemm(h, w, logits, n, V1, J, J, J, V1))
+        print(f"joint fwd  NT {n}x{V1}x{J} f32 out ldc=1025  {t*1e6:8.1f} us {2.0*n*V1*J/t/1e12:7.1f} TF", flush=True)
+        t = timeit(lambda: ops.gemm(dlog, wt, dh, n, J, V1p, V1p, V1p, J))
+        print(f"joint dgrad NT {n}x{J}x{V1p}                  {t*1e6:8.1f} us {2.0*n*V1*J/t/1e12:7.1f} TF", flush=True)
+        for sk in (4, 10, 16):
+            t = timeit(lambda: ops.gemm(dlog, h, gW, V1, J, n, V1p, J, J, transA=True, transB=True, atomic=True, splitk=sk,
+                                        c_dtype=ops.F32))
+            print(f"joint wgrad TN {V1}x{J}x{n} splitk={sk:2d}        {t*1e6:8.1f} us {2.0*n*V1*J/t/1e12:7.1f} TF", flush=True)
+        t = timeit(lambda: ops.gemm(dlog, h, gW, 1024, J, n, V1p, J, J, transA=True, transB=True, atomic=True, splitk=10,
+                                    c_dtype=ops.F32))
+        print(f"   (M = 1024 instead of 1025, splitk=10)        {t*1e6:8.1f} us", flush=True)
+    sys.exit(0)
 if os.environ.get("PMC_SHAPES"):  # two shapes for counter collection (structure chosen by the MI355X_GEMM_* environment)
     run("big_square_bias", 8192, 8192, 8192, "store")
     run("ffn1_fwd_swish", M, 2048, 512, "swish")
