@@ -17,6 +17,7 @@ sigmoid joints, masking_prob, adapters, export) raise NotImplementedError.
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Any, Dict, List, Optional
 
@@ -234,6 +235,8 @@ class RNNTDecoder(_ModuleBase):
         g = out_f32.view(U1, B, H).permute(1, 2, 0)  # [B, H, U+1] (a view: the joint re-lays it out once)
         return g, ((tg, layers, B, U, cdt) if save else None)
 
+    _bptt_splitk = int(os.environ.get("MI355X_LSTM_BPTT_SPLITK", "8"))
+
     def _backward_impl(self, saved, dg):
         tg, layers, B, U, cdt = saved
         dev = dg.device
@@ -252,8 +255,10 @@ class RNNTDecoder(_ModuleBase):
                                   c_all[(t - 1) * B:t * B] if t > 0 else None, dz[t * B:(t + 1) * B], B, H)
                 if t > 0:  # dh_{t-1} += dz_t W_hh
                     prev = dh_all[(t - 1) * B:t * B]
+                    # [B, 4H] x [4H, H] with B = 32 rows: H / 128 output tiles only -- split-K (atomic accumulation into the
+                    # f32 gradient that is already there) spreads the 4H-long reduction over 8x as many workgroups
                     ops.gemm(dz[t * B:(t + 1) * B], W[f"l{l}.whht"], prev, B, H, 4 * H, 4 * H, W.pitch(f"l{l}.whht"), H,
-                             epi=ops.EPI_RESID, aux_in=prev)
+                             atomic=True, splitk=self._bptt_splitk, c_dtype=ops.F32)
             w_ih, w_hh = getattr(lstm, f"weight_ih_l{l}"), getattr(lstm, f"weight_hh_l{l}")
             b_ih, b_hh = getattr(lstm, f"bias_ih_l{l}"), getattr(lstm, f"bias_hh_l{l}")
             self._wgrad(dz, 4 * H, inp, H, w_ih.grad, 4 * H, H, U1 * B, bias_grad=b_ih.grad)
