@@ -331,6 +331,14 @@ int mi355x_rnnt_workspace_elems(int B, int T, int U1, long long* elems);
 int mi355x_rnnt_loss(const void* acts, const void* labels, const void* act_lens, const void* label_lens, int B, int T, int U1,
                      int V1, int blank, float fastemit_lambda, float clamp, float grad_scale, void* costs, void* grads,
                      void* workspace, long long workspace_elems, void* stream);
+/* Same, for the fused joint + loss path: logit rows with pitch ld_acts (>= V1; a multiple of 8 lets the joint GEMM store them
+ * with vector accesses although V+1 = 1025 is odd), and the gradient written in grads_dtype with row pitch ld_grads --
+ * MI355X_DT_BF16 with ld_grads % 8 == 0 is directly the K-contiguous operand of the joint's backward GEMMs (columns
+ * [V1, ld_grads) zero-filled): no f32 gradient tensor, no cast pass. */
+int mi355x_rnnt_loss_ex(const void* acts, long long ld_acts, const void* labels, const void* act_lens, const void* label_lens,
+                        int B, int T, int U1, int V1, int blank, float fastemit_lambda, float clamp, float grad_scale, void* costs,
+                        void* grads, int grads_dtype, long long ld_grads, void* workspace, long long workspace_elems,
+                        void* stream);
 
 #ifdef __cplusplus
 }

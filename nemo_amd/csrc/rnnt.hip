@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void rnnt_denom_kernel(const float* __restrict
                                                          const long long* __restrict__ xlen, const long long* __restrict__ ylen,
                                                          float* __restrict__ denom, float* __restrict__ lpb,
                                                          float* __restrict__ lpl, long long rows, int T, int U1, int V1,
-                                                         int blank) {
+                                                         int blank, long long ld) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void rnnt_denom_kernel(const float* __restrict
   const int b = (int)(bt / T);
   const int Tb = (int)min((long long)T, xlen[b]), Ub = (int)min((long long)(U1 - 1), ylen[b]) + 1;
   if (t >= Tb || u >= Ub) return;  // never read
-  const float* x = acts + row * V1;
+  const float* x = acts + row * ld;
   // a row starts on a 4-byte boundary only (V1 = 1025 is the common case): up to 3 head scalars bring the walk to a 16-byte
   // boundary, then float4 loads, then up to 3 tail scalars
   const int head = min(V1, (int)((4u - (unsigned)(((unsigned long long)x >> 2) & 3u)) & 3u));
@@ -152,13 +152,26 @@ __global__ void rnnt_lattice_kernel(const float* __restrict__ lpb, const float* 
   }
 }
 
-// ---- kernel 3: one wave per (b,t,u) row, 4 rows per workgroup
+// ---- kernel 3: one wave per (b,t,u) row, 4 rows per workgroup.  TG = float: the dense [rows, V1] gradient of the loss module's
+// contract (ldg = V1).  TG = bf16: the gradient as the K-contiguous operand of the joint's backward GEMMs, row pitch ldg
+// (a multiple of 8, columns [V1, ldg) zero) -- no f32 gradient tensor and no cast pass in the fused joint + loss path.
+__device__ __forceinline__ void rnnt_store4(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void rnnt_store4(bf16_t* p, float a, float b, float c, float d) {
+  const float v[4] = {a, b, c, d};
+  st4(p, v);
+}
+__device__ __forceinline__ void rnnt_store1(float* p, float a) { *p = a; }
+__device__ __forceinline__ void rnnt_store1(bf16_t* p, float a) { st(p, a); }
+template <typename TG>
 __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* __restrict__ acts, const long long* __restrict__ labels,
                                                         const long long* __restrict__ xlen, const long long* __restrict__ ylen,
                                                         const float* __restrict__ denom, const float* __restrict__ alphas,
                                                         const float* __restrict__ betas, const float* __restrict__ ll,
-                                                        float* __restrict__ grads, long long rows, int T, int U1, int V1,
-                                                        int blank, float fastemit_lambda, float clamp, float scale, int same_align) {
+                                                        TG* __restrict__ grads, long long rows, int T, int U1, int V1,
+                                                        int blank, float fastemit_lambda, float clamp, float scale, int same_align,
+                                                        long long ld, long long ldg) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -167,18 +180,18 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* __restrict_
   const int t = (int)(bt % T);
   const int b = (int)(bt / T);
   const int Tb = (int)min((long long)T, xlen[b]), Ub = (int)min((long long)(U1 - 1), ylen[b]) + 1;
-  float* g = grads + row * V1;
-  const float* x = acts + row * V1;
+  TG* g = grads + row * ldg;
+  const float* x = acts + row * ld;
+  for (int i = V1 + lane; i < ldg; i += 64) rnnt_store1(g + i, 0.f);  // pad columns of a pitched operand row
   // same head / float4 body / tail walk as the denominator kernel; rows of acts and grads share their alignment when the two
   // base pointers do (checked by the host entry: otherwise `same_align` is 0 and the walk is scalar)
   const int head = same_align ? min(V1, (int)((4u - (unsigned)(((unsigned long long)x >> 2) & 3u)) & 3u)) : V1;
   const int n4 = (V1 - head) >> 2;
   const int tail0 = head + 4 * n4, ntail = V1 - tail0;
   if (t >= Tb || u >= Ub) {  // padded cell: zero gradient (the reference starts from a zero-filled tensor)
-    for (int i = lane; i < head; i += 64) g[i] = 0.f;
-    if (lane < ntail) g[tail0 + lane] = 0.f;
-    float4* g4z = reinterpret_cast<float4*>(g + head);
-    for (int i = lane; i < n4; i += 64) g4z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = lane; i < head; i += 64) rnnt_store1(g + i, 0.f);
+    if (lane < ntail) rnnt_store1(g + tail0 + lane, 0.f);
+    for (int i = lane; i < n4; i += 64) rnnt_store4(g + head + 4 * i, 0.f, 0.f, 0.f, 0.f);
     return;
   }
   const float dn = denom[row], a = alphas[row], be = betas[row], logll = ll[b];
@@ -202,16 +215,13 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* __restrict_
     if (clamp > 0.f) gr = fminf(fmaxf(gr, -clamp), clamp);
     return gr * scale;
   };
-  for (int i = lane; i < head; i += 64) g[i] = one(i, x[i]);
-  if (lane < ntail) g[tail0 + lane] = one(tail0 + lane, x[tail0 + lane]);
+  for (int i = lane; i < head; i += 64) rnnt_store1(g + i, one(i, x[i]));
+  if (lane < ntail) rnnt_store1(g + tail0 + lane, one(tail0 + lane, x[tail0 + lane]));
   const float4* x4 = reinterpret_cast<const float4*>(x + head);
-  float4* g4 = reinterpret_cast<float4*>(g + head);
   for (int i = lane; i < n4; i += 64) {
     const float4 v = x4[i];
     const int e = head + 4 * i;
-    float4 o;
-    o.x = one(e, v.x); o.y = one(e + 1, v.y); o.z = one(e + 2, v.z); o.w = one(e + 3, v.w);
-    g4[i] = o;
+    rnnt_store4(g + e, one(e, v.x), one(e + 1, v.y), one(e + 2, v.z), one(e + 3, v.w));
   }
 }
 
@@ -229,18 +239,20 @@ extern "C" int mi355x_rnnt_workspace_elems(int B, int T, int U1, long long* elem
   return 0;
 }
 
-extern "C" int mi355x_rnnt_loss(const void* acts, const void* labels_, const void* act_lens_, const void* label_lens_, int B,
-                                int T, int U1, int V1, int blank, float fastemit_lambda, float clamp, float grad_scale,
-                                void* costs_, void* grads_, void* workspace_, long long workspace_elems, void* stream) {
+static int rnnt_loss_impl(const void* acts, long long ld, const void* labels_, const void* act_lens_, const void* label_lens_, int B,
+                          int T, int U1, int V1, int blank, float fastemit_lambda, float clamp, float grad_scale, void* costs_,
+                          void* grads_, int grads_dtype, long long ldg, void* workspace_, long long workspace_elems,
+                          void* stream) {
   mi_clear_errors();
   const long long* labels = (const long long*)labels_;
   const long long* act_lens = (const long long*)act_lens_;
   const long long* label_lens = (const long long*)label_lens_;
   float* costs = (float*)costs_;
-  float* grads = (float*)grads_;
   float* workspace = (float*)workspace_;
   if (!acts || (!labels && U1 > 1) || !act_lens || !label_lens || !costs || !workspace) return MI_ERR_ARG;
   if (B <= 0 || T <= 0 || U1 <= 0 || V1 <= 1 || blank < 0 || blank >= V1 || U1 > 1024) return MI_ERR_ARG;
+  if (ld < V1 || (grads_ && ldg < V1)) return MI_ERR_ARG;
+  if (grads_ && grads_dtype == MI_DT_BF16 && ((ldg & 7) || ((uintptr_t)grads_ & 15))) return MI_ERR_ARG;
   if (workspace_elems < rnnt_ws_elems(B, T, U1)) return MI_ERR_ARG;
   if (clamp < 0.f || fastemit_lambda < 0.f) return MI_ERR_ARG;
   const long long rows = (long long)B * T * U1;
@@ -254,14 +266,39 @@ extern "C" int mi355x_rnnt_loss(const void* acts, const void* labels_, const voi
   hipStream_t s = (hipStream_t)stream;
   const unsigned nblk = (unsigned)((rows + 3) / 4);
   hipLaunchKernelGGL(rnnt_denom_kernel, dim3(nblk), dim3(256), 0, s, (const float*)acts, labels, act_lens, label_lens, denom,
-                     lpb, lpl, rows, T, U1, V1, blank);
+                     lpb, lpl, rows, T, U1, V1, blank, ld);
   const int threads = ((U1 + 63) / 64) * 64;
   hipLaunchKernelGGL(rnnt_lattice_kernel, dim3(B, 2), dim3(threads), 2 * threads * sizeof(float), s, lpb, lpl, act_lens,
                      label_lens, alphas, betas, ll, B, T, U1);
-  if (grads)
-    hipLaunchKernelGGL(rnnt_grad_kernel, dim3(nblk), dim3(256), 0, s, (const float*)acts, labels, act_lens, label_lens, denom,
-                       alphas, betas, ll, grads, rows, T, U1, V1, blank, fastemit_lambda, clamp, grad_scale,
-                       (int)((((unsigned long long)acts ^ (unsigned long long)grads) & 15ull) == 0ull));
+  if (grads_ && grads_dtype == MI_DT_BF16) {
+    // vector walk when every logit row starts on a 16-byte boundary (then head = 0 and the 4-element groups of the bf16 row
+    // are 8-byte aligned as well)
+    const int aligned = (((unsigned long long)acts & 15ull) == 0ull && (ld & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((rnnt_grad_kernel<bf16_t>), dim3(nblk), dim3(256), 0, s, (const float*)acts, labels, act_lens, label_lens,
+                       denom, alphas, betas, ll, (bf16_t*)grads_, rows, T, U1, V1, blank, fastemit_lambda, clamp, grad_scale,
+                       aligned, ld, ldg);
+  } else if (grads_) {
+    const int same = ((((unsigned long long)acts ^ (unsigned long long)grads_) & 15ull) == 0ull && ((ld - ldg) & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((rnnt_grad_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)acts, labels, act_lens, label_lens,
+                       denom, alphas, betas, ll, (float*)grads_, rows, T, U1, V1, blank, fastemit_lambda, clamp, grad_scale, same,
+                       ld, ldg);
+  }
   hipLaunchKernelGGL(rnnt_cost_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ll, costs, B, fastemit_lambda);
   return mi_check_launch();
+}
+
+extern "C" int mi355x_rnnt_loss(const void* acts, const void* labels, const void* act_lens, const void* label_lens, int B, int T,
+                                int U1, int V1, int blank, float fastemit_lambda, float clamp, float grad_scale, void* costs,
+                                void* grads, void* workspace, long long workspace_elems, void* stream) {
+  return rnnt_loss_impl(acts, V1, labels, act_lens, label_lens, B, T, U1, V1, blank, fastemit_lambda, clamp, grad_scale, costs,
+                        grads, MI_DT_F32, V1, workspace, workspace_elems, stream);
+}
+
+extern "C" int mi355x_rnnt_loss_ex(const void* acts, long long ld_acts, const void* labels, const void* act_lens,
+                                   const void* label_lens, int B, int T, int U1, int V1, int blank, float fastemit_lambda,
+                                   float clamp, float grad_scale, void* costs, void* grads, int grads_dtype, long long ld_grads,
+                                   void* workspace, long long workspace_elems, void* stream) {
+  if (grads_dtype != MI_DT_F32 && grads_dtype != MI_DT_BF16) return MI_ERR_ARG;
+  return rnnt_loss_impl(acts, ld_acts, labels, act_lens, label_lens, B, T, U1, V1, blank, fastemit_lambda, clamp, grad_scale, costs,
+                        grads, grads_dtype, ld_grads, workspace, workspace_elems, stream);
 }

@@ -453,26 +453,32 @@ class RNNTJoint(_ModuleBase):
             return ops.NO_DROP
         return ops.Dropout(self.dropout, self._step_seed, 300 + sub)
 
-    def _sub_fwd(self, f, g, b0, nb, T, U1, W, cdt, drop):
+    def _sub_fwd(self, f, g, b0, nb, T, U1, W, cdt, drop, ld=None):
         J, V1 = self.joint_hidden, self._num_classes
         dev = f.device
         n = nb * T * U1
         h = torch.empty(n, J, dtype=cdt, device=dev)
         ops.joint_combine_fwd(f[b0 * T:], g[b0 * U1:], h, nb, T, U1, J, drop)
-        logits = torch.empty(nb, T, U1, V1, dtype=torch.float32, device=dev)
+        # `ld` = row pitch of the logits: V+1 (dense, the module's output contract) or, inside the fused joint + loss path,
+        # roundup8(V+1) so that the GEMM stores 32-byte vectors although V+1 = 1025 is odd
+        ld = ld or V1
+        logits = torch.empty(nb * T * U1, ld, dtype=torch.float32, device=dev) if ld != V1 else torch.empty(
+            nb, T, U1, V1, dtype=torch.float32, device=dev)
         out = self.joint_net[-1]
-        ops.gemm(h, W["out.w"], logits, n, V1, J, J, W.pitch("out.w"), V1, bias=out.bias,
+        ops.gemm(h, W["out.w"], logits, n, V1, J, J, W.pitch("out.w"), ld, bias=out.bias,
                  alpha=1.0 / self.temperature if self.temperature != 1.0 else 1.0)
         return h, logits
 
-    def _sub_bwd(self, dlogits, h, b0, nb, T, U1, W, cdt, drop, df, dg32, gW, gb):
-        """dlogits f32 [nb,T,U1,V1]: output-layer gradients into (gW, gb), dpre reductions into df (rows b0*T..) and dg32"""
+    def _sub_bwd(self, dlogits, h, b0, nb, T, U1, W, cdt, drop, df, dg32, gW, gb, dlog=None):
+        """dlogits f32 [nb,T,U1,V1] (or `dlog`: the same gradient already as the pitched GEMM operand [n, roundup8(V1)], scaled
+        by 1/temperature): output-layer gradients into (gW, gb), dpre reductions into df (rows b0*T..) and dg32"""
         J, V1 = self.joint_hidden, self._num_classes
         V1p = _pad8(V1)
         dev = h.device
         n = nb * T * U1
-        dlog = torch.empty(n, V1p, dtype=cdt, device=dev)
-        ops.cast_rows(dlogits, V1, dlog, V1p, n, V1, V1p, 1.0 / self.temperature if self.temperature != 1.0 else 1.0)
+        if dlog is None:
+            dlog = torch.empty(n, V1p, dtype=cdt, device=dev)
+            ops.cast_rows(dlogits, V1, dlog, V1p, n, V1, V1p, 1.0 / self.temperature if self.temperature != 1.0 else 1.0)
         self._wgrad(dlog, V1p, h, J, gW, V1, J, n, bias_grad=gb)
         dh = torch.empty(n, J, dtype=cdt, device=dev)
         ops.gemm(dlog, W["out.wt"], dh, n, J, V1p, V1p, W.pitch("out.wt"), J)
@@ -556,11 +562,26 @@ class RNNTJoint(_ModuleBase):
         for si, b0 in enumerate(range(0, B, fbs)):
             nb = min(fbs, B - b0)
             drop = self._drop(si)
+            fe = float(getattr(loss_mod, "fastemit_lambda", 0.0) or 0.0)
+            cl = float(getattr(loss_mod, "clamp", 0.0) or 0.0)
+            if cdt == torch.bfloat16:
+                # logits with row pitch roundup8(V+1) (vector stores from the GEMM); the loss kernel writes the logit gradient
+                # directly as the bf16 operand of the backward GEMMs: the f32 gradient tensor and its cast pass do not exist
+                V1 = self._num_classes
+                V1p = _pad8(V1)
+                h, logits = self._sub_fwd(f, g, b0, nb, T, U1, W, cdt, drop, ld=V1p)
+                dlog = torch.empty(nb * T * U1, V1p, dtype=cdt, device=dev)
+                c = ops.rnnt_loss_pitched(logits, V1p, nb, T, U1, V1, labels[b0:b0 + nb], el[b0:b0 + nb], tl[b0:b0 + nb],
+                                          self._vocab_size, dlog, V1p, fastemit_lambda=fe, clamp=cl,
+                                          grad_scale=scale / self.temperature if self.temperature != 1.0 else scale)
+                costs[b0:b0 + nb] = c
+                self._sub_bwd(None, h, b0, nb, T, U1, W, cdt, drop, df, dg32, gview(out.weight), gview(out.bias), dlog=dlog)
+                del h, logits, dlog
+                continue
             h, logits = self._sub_fwd(f, g, b0, nb, T, U1, W, cdt, drop)
             grads = torch.empty_like(logits)
             c = ops.rnnt_loss(logits, labels[b0:b0 + nb], el[b0:b0 + nb], tl[b0:b0 + nb], self._vocab_size, grads=grads,
-                              fastemit_lambda=float(getattr(loss_mod, "fastemit_lambda", 0.0) or 0.0),
-                              clamp=float(getattr(loss_mod, "clamp", 0.0) or 0.0), grad_scale=scale)
+                              fastemit_lambda=fe, clamp=cl, grad_scale=scale)
             costs[b0:b0 + nb] = c
             self._sub_bwd(grads, h, b0, nb, T, U1, W, cdt, drop, df, dg32, gview(out.weight), gview(out.bias))
             del h, logits, grads

@@ -507,6 +507,18 @@ def rnnt_loss(acts, labels, act_lens, label_lens, blank, grads=None, fastemit_la
     return costs
 
 
+def rnnt_loss_pitched(acts, ld_acts, B, T, U1, V1, labels, act_lens, label_lens, blank, grads, ld_grads, fastemit_lambda=0.0,
+                      clamp=0.0, grad_scale=1.0):
+    """acts f32, rows of pitch ld_acts; grads (f32 or bf16) rows of pitch ld_grads, pad columns zero-filled -> costs f32 [B]"""
+    n = 5 * B * T * U1 + 2 * B
+    ws = torch.empty(n, device=acts.device, dtype=torch.float32)
+    costs = torch.empty(B, device=acts.device, dtype=torch.float32)
+    check(lib.mi355x_rnnt_loss_ex(_ptr(acts), ld_acts, _ptr(labels), _ptr(act_lens), _ptr(label_lens), B, T, U1, V1, blank,
+                                  fastemit_lambda, clamp, grad_scale, _ptr(costs), _ptr(grads), dt(grads), ld_grads, _ptr(ws), n,
+                                  _stream()), "rnnt_loss_ex")
+    return costs
+
+
 def row_scale(x, vec, rows, cols):
     check(lib.mi355x_row_scale(_ptr(x), _ptr(vec), rows, cols, _stream()), "row_scale")
 

@@ -1067,3 +1067,34 @@ def test_gemm_persistent_structure_matches_the_tiled_one(M, N, K):
                     assert torch.equal(t, f), (kind, "run-to-run difference")
     finally:
         o.gemm_config(5, old if old >= 0 else 1)
+
+
+@pytest.mark.parametrize("V1,ldp", [(1025, 1032), (29, 32), (16, 16)])
+def test_rnnt_loss_pitched_rows_and_bf16_operand_gradient(V1, ldp):
+    """mi355x_rnnt_loss_ex (the fused joint + loss path): logits with a row pitch, gradient written as the pitched GEMM operand.
+    f32 pitched output equals the dense entry (to the ulp); bf16 output is its rounding; pad columns are zero."""
+    o = ops()
+    B, T, U1 = 3, 19, 7
+    g = torch.Generator().manual_seed(5)
+    acts = torch.randn(B, T, U1, V1, generator=g).to(dev)
+    labels = torch.randint(0, V1 - 1, (B, U1 - 1), generator=g).to(dev)
+    xl = torch.tensor([19, 13, 7]).to(dev)
+    yl = torch.tensor([6, 3, 0]).to(dev)
+    gd = torch.empty_like(acts)
+    cd = o.rnnt_loss(acts, labels, xl, yl, V1 - 1, grads=gd, fastemit_lambda=0.01, grad_scale=0.5)
+    n = B * T * U1
+    ap = torch.full((n, ldp), float("nan"), device=dev)
+    ap[:, :V1] = acts.view(n, V1)
+    for dtype in (torch.float32, torch.bfloat16):
+        gp = torch.full((n, ldp), 7.0, device=dev, dtype=dtype)
+        cp = o.rnnt_loss_pitched(ap, ldp, B, T, U1, V1, labels, xl, yl, V1 - 1, gp, ldp, fastemit_lambda=0.01, grad_scale=0.5)
+        torch.cuda.synchronize()
+        assert torch.equal(cp, cd)
+        assert (gp[:, V1:] == 0).all()
+        if dtype == torch.float32:
+            # (an element may go through the scalar head / tail site in one walk and the float4 site in the other: the
+            #  compiler contracts the two copies of the same expression differently -- 1 ulp)
+            assert torch.allclose(gp[:, :V1], gd.view(n, V1), rtol=3e-5, atol=1e-7)  # (blank column: difference of exponentials)
+            g32 = gp.clone()
+        else:
+            assert torch.equal(gp[:, :V1], g32[:, :V1].to(torch.bfloat16))  # same walk, rounded once
