@@ -366,6 +366,7 @@ class EncDecCTCModel(nn.Module):
             self._install_early_step(syncs)
         out = self.training_step(batch, self.global_step)
         out["loss"].backward()
+        self._after_backward()
         for gs in syncs:
             gs.wait()
         if early:
@@ -380,6 +381,9 @@ class EncDecCTCModel(nn.Module):
             self._scheduler.step()
         self.global_step += 1
         return out
+
+    def _after_backward(self):
+        """streams other than the current one that produced gradients are joined here (none in the CTC model)"""
 
     def _install_early_step(self, syncs):
         opt = self._optimizer

@@ -69,9 +69,17 @@ class EncDecRNNTModel(EncDecCTCModel):
         self.validation_step_outputs, self.test_step_outputs = [], []
         self.optimizer_in_backward = False
         self.global_step = 0
+        self.pred_side_stream = os.environ.get("MI355X_PRED_STREAM", "1") != "0"
+        self._pred_stream = None
 
     def trainable_modules(self):
         return [self.encoder, self.decoder, self.joint]
+
+    def _after_backward(self):
+        # the prediction network's backward ran on its own stream (autograd replays a node on the stream of its forward) and
+        # wrote its gradients straight into the flat buffer, not through AccumulateGrad: order the optimizer behind it explicitly
+        if self._pred_stream is not None:
+            torch.cuda.current_stream(self._pred_stream.device).wait_stream(self._pred_stream)
 
     def _artifacts(self):
         return {"tokenizer.model_path": self._cfg["tokenizer"]["model_path"]} if self.tokenizer is not None else {}
@@ -96,8 +104,23 @@ class EncDecRNNTModel(EncDecCTCModel):
     # ------------------------------------------------------------------ training_step (rnnt_models.py:692-760)
     def training_step(self, batch, batch_nb=0):
         signal, signal_len, transcript, transcript_len = batch
-        encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
-        decoder, target_length, _ = self.decoder(targets=transcript, target_length=transcript_len)
+        # The prediction network is 2 x (U+1) tiny dependent launches (recurrent GEMM + cell kernel per step): latency-bound and
+        # independent of the encoder until the joint.  It runs on its own stream next to the encoder forward; autograd replays
+        # a node's backward on the stream of its forward, so BPTT overlaps the encoder backward the same way.
+        if self.pred_side_stream and signal.is_cuda:
+            cur = torch.cuda.current_stream(signal.device)
+            if self._pred_stream is None or self._pred_stream.device != signal.device:
+                self._pred_stream = torch.cuda.Stream(device=signal.device)
+            self._pred_stream.wait_stream(cur)
+            with torch.cuda.stream(self._pred_stream):
+                decoder, target_length, _ = self.decoder(targets=transcript, target_length=transcript_len)
+            encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
+            cur.wait_stream(self._pred_stream)
+            decoder.record_stream(cur)
+            target_length.record_stream(cur)
+        else:
+            encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
+            decoder, target_length, _ = self.decoder(targets=transcript, target_length=transcript_len)
         if not self.joint.fuse_loss_wer:
             joint = self.joint(encoder_outputs=encoded, decoder_outputs=decoder)
             loss_value = self._reduce(self.loss(joint, transcript.clamp(max=self.loss.blank - 1).contiguous(),

@@ -427,7 +427,8 @@ _SCRATCH = {}
 
 
 def _scratch(name, n, device):
-    key = (name, str(device))
+    # one buffer per (kernel, device, STREAM): launches of the same kernel on two streams may overlap
+    key = (name, str(device), torch.cuda.current_stream(device).cuda_stream if torch.cuda.is_available() else 0)
     t = _SCRATCH.get(key)
     if t is None or t.numel() < n:
         t = _SCRATCH[key] = torch.empty(n, dtype=torch.float32, device=device)
