@@ -1733,7 +1733,16 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
     static int use_v2 = -1;
     if (use_v2 < 0) { const char* e = getenv("MI355X_GEMM_V2"); use_v2 = (e && e[0] == '0') ? 0 : 1; }
     if (p.g_on && !(use_v2 && p.M >= 192 && p.N >= 96)) return MI_ERR_ARG;  // the gather lives in the LDS-DMA structures
-    if (use_v2 && p.M >= 192 && p.N >= 96 && !(p.transA && !p.transB)) {
+    // few output tiles (e.g. M = 8032 rows x N = 512: 128 tiles of 256x128 on 256 CUs): the 128x128 structure doubles the
+    // workgroups and wins in isolation although its K loop is slower (FFN2 forward at M = 8032: 46.3 -> 39.5 us); inside a
+    // training step, next to the weight-gradient stream, it only paid off below ~100 tiles (Squeezeformer-Medium's N = 324
+    // launches at the reduced frame rate: step 47.95 -> 46.95 ms; FastConformer's 128-tile launches: 32.47 -> 32.67 ms)
+    static int few_mode = -1;
+    if (few_mode < 0) { const char* e = getenv("MI355X_GEMM_FEW_TILES"); few_mode = e ? atoi(e) : 100; }
+    const long long blocks256 = (long long)((p.M + BM2 - 1) / BM2) * tn * sk * p.batch;
+    const bool few_tiles = !p.g_on && !p.r_on && !p.atomic && blocks256 <= few_mode && p.N <= 1024 &&
+                           (long long)tm * tn * sk * p.batch > blocks256;
+    if (use_v2 && p.M >= 192 && p.N >= 96 && !(p.transA && !p.transB) && !few_tiles) {
       const int tm2 = (p.M + BM2 - 1) / BM2;
       const int shm = 3 * NT2_STAGE * 2;
       static bool attr_set = false;

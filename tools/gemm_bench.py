@@ -114,6 +114,15 @@ if os.environ.get("JOINT"):  # the transducer joint's output layer at fused_batc
                                     c_dtype=ops.F32))
         print(f"   (M = 1024 instead of 1025, splitk=10)        {t*1e6:8.1f} us", flush=True)
     sys.exit(0)
+if os.environ.get("HALF_M"):  # FastConformer x8 (M = 8032 rows): do the 256-row tiles still fill the chip?
+    Mh = 8032
+    for rep in range(2):
+        run("ffn2_fwd_resid_M8032", Mh, 512, 2048, "resid")
+        run("ffn1_fwd_swish_M8032", Mh, 2048, 512, "swish")
+        run("proj_resid_M8032", Mh, 512, 512, "resid")
+        run("qkv_store_M8032", Mh, 1536, 512, "store")
+        run("dgrad_store_M8032_k1536", Mh, 512, 1536, "store")
+    sys.exit(0)
 if os.environ.get("PMC_SHAPES"):  # two shapes for counter collection (structure chosen by the MI355X_GEMM_* environment)
     run("big_square_bias", 8192, 8192, 8192, "store")
     run("ffn1_fwd_swish", M, 2048, 512, "swish")
