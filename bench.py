@@ -125,6 +125,37 @@ def _source_hash():
     return h.hexdigest()[:16]
 
 
+def vendor_ceiling(dev):
+    """Calibration, not a leg of the product path: what the vendor library (hipBLASLt through torch.matmul) reaches on THIS box
+    for the dominant FFN shape with a plain store epilogue, next to mi355x_gemm on the same operands -- the practical MFMA
+    ceiling under the part's power limit for K = 512 (profiles/r2_gemm_structures.md section 5)."""
+    from nemo_amd import ops
+    M, N, K = 16032, 2048, 512
+    A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    B = torch.randn(N, K, device=dev).to(torch.bfloat16)
+    C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+
+    def t(f, iters=20):
+        for _ in range(3):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    try:
+        t_lib = t(lambda: torch.matmul(A, B.t(), out=C))
+    except Exception as e:  # the calibration must never break the benchmark line
+        return {"error": f"{type(e).__name__}: {e}"}
+    t_own = t(lambda: ops.gemm(A, B, C, M, N, K, K, K, N))
+    fl = 2.0 * M * N * K
+    return {"shape": [M, N, K], "epilogue": "plain bf16 store", "hipblaslt_tflops": round(fl / t_lib / 1e12, 1),
+            "hipblaslt_frac_of_peak": round(fl / t_lib / 1e12 / 2500.0, 4), "mi355x_gemm_tflops": round(fl / t_own / 1e12, 1)}
+
+
 def hbm_roofline(model, dev):
     """the HBM-bound half of the step, measured live with HIP events on the kernels' own stream: algorithmic bytes
     (compulsory reads + writes) / time for the three dominant HBM-bound kernels of the step at the
@@ -328,6 +359,9 @@ def main():
                 "gemm_time_share_of_step": round(sum(v[1] for v in agg.values()) * 1e3 / ms, 3),
                 "all_variants": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 2), "launches": v[2]}
                                  for k, v in agg.items()}}
+
+        if a.dtype == "bf16":
+            roof["vendor_library_same_box"] = vendor_ceiling(dev)
 
     roof_hbm = None
     if rank == 0 and not a.no_roofline and a.size == "large" and a.model == "ctc":
