@@ -396,7 +396,7 @@ def test_relpos_flash_attention_fwd(T):
                        1.0 / math.sqrt(dk))
     torch.cuda.synchronize()
     assert torch.isfinite(ctx.float()).all()
-    assert rel_err(ctx, ctx_ref) < 2e-2, rel_err(ctx, ctx_ref)
+    assert rel_err(ctx, ctx_ref) < 5e-3, rel_err(ctx, ctx_ref)  # (measured 1.3-1.9e-3: bf16 probabilities)
     for b in range(B):
         n = int(lens[b])
         assert (lse[b, :, :n].cpu() - lse_ref[b, :, :n]).abs().max() < 2e-2
@@ -452,19 +452,19 @@ def test_relpos_flash_attention_bwd(T):
     dS = torch.full((H, B, T, Tp32), float("nan"), device=dev, dtype=torch.bfloat16)
     o.relpos_flash_bwd_dq(qu, qv, qkv_d, 3 * d, pos_d, d, lens_d, dO_d, lse, delta, dqu, dqv, B, H, T, dk, Tp32, scale, ds_out=dS)
     torch.cuda.synchronize()
-    assert rel_err(dqu, ref["dqu"]) < 3e-2, rel_err(dqu, ref["dqu"])
-    assert rel_err(dqv, ref["dqv"]) < 3e-2, rel_err(dqv, ref["dqv"])
+    assert rel_err(dqu, ref["dqu"]) < 8e-3, rel_err(dqu, ref["dqu"])  # (measured 2.9-3.7e-3)
+    assert rel_err(dqv, ref["dqv"]) < 8e-3, rel_err(dqv, ref["dqv"])  # (measured 2.9-3.7e-3)
     if hasattr(o, "relpos_flash_bwd_dkv"):
         dqkv = torch.full((B * T, 3 * d), float("nan"), device=dev, dtype=torch.bfloat16)
         o.relpos_flash_bwd_dkv(qu, qv, qkv_d, 3 * d, pos_d, d, lens_d, dO_d, lse, delta, dqkv, 3 * d, B, H, T, dk, Tp, scale)
         torch.cuda.synchronize()
-        assert rel_err(dqkv[:, d:2 * d], ref["dk"]) < 3e-2, rel_err(dqkv[:, d:2 * d], ref["dk"])
-        assert rel_err(dqkv[:, 2 * d:], ref["dv"]) < 3e-2, rel_err(dqkv[:, 2 * d:], ref["dv"])
+        assert rel_err(dqkv[:, d:2 * d], ref["dk"]) < 8e-3, rel_err(dqkv[:, d:2 * d], ref["dk"])
+        assert rel_err(dqkv[:, 2 * d:], ref["dv"]) < 8e-3, rel_err(dqkv[:, 2 * d:], ref["dv"])
     if hasattr(o, "relpos_flash_bwd_dpos"):
         dp = torch.zeros(2 * T - 1, d, device=dev)
         o.relpos_flash_bwd_dpos(qv, dS, lens_d, dp, B, H, T, dk, Tp32)
         torch.cuda.synchronize()
-        assert rel_err(dp, ref["dp"]) < 3e-2, rel_err(dp, ref["dp"])
+        assert rel_err(dp, ref["dp"]) < 8e-3, rel_err(dp, ref["dp"])
 
 
 def test_relpos_flash_attention_dropout_consistency():
