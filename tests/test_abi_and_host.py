@@ -424,3 +424,60 @@ def test_dw_striding_encoder_state_dict_is_the_reference_abi(golden_dir):
     assert ours == ref, (set(ours) ^ set(ref), [k for k in ours if k in ref and ours[k] != ref[k]])
     with pytest.raises(NotImplementedError):
         ConformerEncoder(feat_in=40, n_layers=1, d_model=32, subsampling="dw_striding", subsampling_factor=2)
+
+
+def test_config_loader_interpolation_yaml12_floats_missing_and_overrides():
+    """nemo_amd.config on an inline document (runs everywhere; the reference's own recipe files are loaded by
+    tests/test_boundary_reference.py where the reference tree exists)"""
+    from nemo_amd.config import MissingMandatoryValue, apply_overrides, load_config, missing_keys, resolve, select
+    text = """
+name: demo
+model:
+  sample_rate: 16000
+  train_ds:
+    manifest_filepath: ???
+    sample_rate: ${model.sample_rate}
+    batch_size: 8
+  preprocessor: {features: 80, window_size: 0.025}
+  encoder: {feat_in: "${model.preprocessor.features}", d_model: 512, label: "d${model.encoder.d_model}_f${model.preprocessor.features}"}
+  optim: {lr: 2.0, weight_decay: 1e-3, sched: {d_model: "${model.encoder.d_model}", min_lr: 1e-6, warmup_ratio: null}}
+trainer: {devices: -1, precision: 32}
+"""
+    c = load_config(text=text)
+    m = c["model"]
+    assert m["train_ds"]["sample_rate"] == 16000 and m["encoder"]["feat_in"] == 80 and m["optim"]["sched"]["d_model"] == 512
+    assert m["encoder"]["label"] == "d512_f80"                       # interpolation inside a string
+    assert m["optim"]["weight_decay"] == 1e-3 and isinstance(m["optim"]["weight_decay"], float)   # YAML 1.2: no dot needed
+    assert m["optim"]["sched"]["min_lr"] == 1e-6 and m["optim"]["sched"]["warmup_ratio"] is None
+    assert c["trainer"]["devices"] == -1 and isinstance(c["trainer"]["precision"], int)
+    assert missing_keys(c) == ["model.train_ds.manifest_filepath"]
+    with pytest.raises(MissingMandatoryValue):
+        select(c, "model.train_ds.manifest_filepath", throw_on_missing=True)
+    c2 = load_config(text=text, overrides=["model.train_ds.manifest_filepath=/data/train.json", "model.encoder.d_model=256",
+                                           "+trainer.fast_dev_run=True", "~model.preprocessor.window_size", "model.optim.lr=1e-3"])
+    assert missing_keys(c2) == [] and c2["model"]["optim"]["sched"]["d_model"] == 256 and c2["model"]["encoder"]["label"] == "d256_f80"
+    assert c2["trainer"]["fast_dev_run"] is True and "window_size" not in c2["model"]["preprocessor"]
+    assert c2["model"]["optim"]["lr"] == 1e-3
+    with pytest.raises(KeyError):
+        load_config(text=text, overrides=["model.encoder.no_such=1"])      # Hydra: adding a key needs '+'
+    with pytest.raises(RecursionError):
+        resolve({"a": "${b}", "b": "${a}"})
+    assert apply_overrides({"a": {"b": 1}}, ["a.b=[1, 2]"])["a"]["b"] == [1, 2]
+
+
+def test_lr_schedules_of_the_neighbouring_recipes():
+    """NoamHoldAnnealing (Squeezeformer recipe) and CosineAnnealing (FastConformer recipes) against the closed forms of
+    nemo/core/optim/lr_scheduler.py:153-228, 387-414, 429-435"""
+    import math
+    from nemo_amd.optim import CosineAnnealing, NoamHoldAnnealing
+    s = NoamHoldAnnealing(1.5e-3, warmup_steps=100, hold_steps=400, decay_rate=1.0, min_lr=1e-5)
+    assert s.lr_at(0) == pytest.approx(1.5e-3 * 1 / 101) and s.lr_at(50) == pytest.approx(1.5e-3 * 51 / 101)
+    assert s.lr_at(100) == pytest.approx(1.5e-3) and s.lr_at(499) == 1.5e-3          # hold: [warmup, warmup + hold)
+    assert s.lr_at(600) == pytest.approx(1.5e-3 * 100 / (600 - 400))                  # lr * warmup^r / (step - hold)^r
+    assert s.lr_at(10 ** 7) == 1e-5
+    c = CosineAnnealing(1e-3, max_steps=1000, warmup_steps=100, min_lr=1e-4)
+    assert c.lr_at(10) == pytest.approx(1e-3 * 11 / 101)
+    assert c.lr_at(550) == pytest.approx(1e-4 + 9e-4 * 0.5 * (1 + math.cos(math.pi * 450 / 900)))
+    assert c.lr_at(1000) == pytest.approx(1e-4) and c.lr_at(2000) == 1e-4
+    lrs = [c.step() for _ in range(3)]
+    assert lrs == [c.lr_at(1), c.lr_at(2), c.lr_at(3)] and c.get_last_lr() == lrs[-1]
