@@ -287,17 +287,36 @@ def test_fit_from_a_manifest_with_semi_sorted_batches(tmp_path):
     assert model._cfg["train_ds"]["manifest_filepath"] == m
 
 
-def _dp_worker(rank, world, port, out_dir, over, vocab):
+def _dp_model(kind, over, vocab):
+    torch.manual_seed(5)
+    if kind == "rnnt":
+        return _rnnt_model(torch.float32, **over).to(dev).train()
+    if kind == "squeezeformer":
+        from nemo_amd.models import EncDecCTCModel, squeezeformer_ctc_config
+        cfg = squeezeformer_ctc_config("xs", vocab_size=vocab, compute_dtype=torch.float32, **over)
+        cfg["preprocessor"]["dither"] = 0.0
+        return EncDecCTCModel(cfg).to(dev).train()
+    return _model(over, vocab=vocab).to(dev).train()
+
+
+def _dp_batch(kind, vocab):
+    audio, alen, tok, tl = R.synthetic_batch(4, 1.0, vocab=vocab, seed=8)
+    if kind == "rnnt":  # ragged audio and label lengths through the fused joint + loss
+        tl = torch.tensor([3, 2, 3, 1])
+        alen = torch.tensor([16000, 12000, 14000, 9000])
+    return audio, alen, tok, tl
+
+
+def _dp_worker(rank, world, port, out_dir, over, vocab, kind="ctc"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks on the one GPU; gloo stages through the host
     try:
         torch.cuda.set_device(0)
-        torch.manual_seed(5)
-        model = _model(over, vocab=vocab).to(dev).train()
+        model = _dp_model(kind, over, vocab)
         model.setup_optimization(dict(name="adamw", lr=1e-3, betas=[0.9, 0.98], weight_decay=0.0))
-        audio, alen, tok, tl = R.synthetic_batch(4, 1.0, vocab=vocab, seed=8)
+        audio, alen, tok, tl = _dp_batch(kind, vocab)
         sl = slice(2 * rank, 2 * rank + 2)
         batch = [audio[sl].to(dev), alen[sl].to(dev), tok[sl].to(dev), tl[sl].to(dev)]
         # what fit_step does up to the optimizer: zero_grad, forward, backward with the bucketed exchange, join
@@ -305,6 +324,7 @@ def _dp_worker(rank, world, port, out_dir, over, vocab):
         model._optimizer.zero_grad()
         loss = model.training_step(batch)["loss"]
         loss.backward()
+        model._after_backward()
         scale = 1.0
         for gs in syncs:
             scale = gs.wait()
@@ -350,6 +370,63 @@ def test_data_parallel_two_ranks_equal_one_process_on_the_joint_batch(tmp_path):
         assert (g0 - ref).norm() <= 2e-4 * ref.norm(), ((g0 - ref).norm() / ref.norm())
     bn = model.encoder.layers[0].conv.batch_norm.running_mean.detach().cpu()
     assert torch.allclose(r0["bn"], bn, atol=1e-5) and torch.equal(r0["bn"], r1["bn"])  # SyncBN: global statistics
+    for a, b in zip(r0["flat"], r1["flat"]):
+        assert torch.equal(a, b)
+
+
+def test_data_parallel_transducer_two_ranks_equal_one_process_on_the_joint_batch(tmp_path):
+    """the same for EncDecRNNTModel: three flat buffers (encoder, prediction network, joint) exchanged in buckets, the
+    prediction network's backward on its own stream, joint gradients produced inside the fused forward -- two ranks (2 + 2
+    utterances, sub-batches of 2) against one process on the 4 utterances; replicas identical after optimizer steps"""
+    import socket
+    import torch.multiprocessing as mp
+    over = dict(d_model=64)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), over, 30, "rnnt"), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
+    model = _dp_model("rnnt", over, 30)
+    model.setup_optimization(dict(name="adamw", lr=1e-3, betas=[0.9, 0.98], weight_decay=0.0))
+    audio, alen, tok, tl = _dp_batch("rnnt", 30)
+    batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+    model._optimizer.zero_grad()
+    loss = model.training_step(batch)["loss"]
+    loss.backward()
+    model._after_backward()
+    torch.cuda.synchronize()
+    assert abs(0.5 * (r0["loss"] + r1["loss"]).item() - loss.item()) <= 1e-5 * abs(loss.item())
+    assert len(r0["grads"]) == 3
+    for g0, g1, fp in zip(r0["grads"], r1["grads"], model.flats()):
+        assert torch.equal(g0, g1)
+        ref = fp.grad.detach().cpu()
+        assert (g0 - ref).norm() <= 3e-4 * ref.norm(), ((g0 - ref).norm() / ref.norm())
+    for a, b in zip(r0["flat"], r1["flat"]):
+        assert torch.equal(a, b)
+
+
+def test_data_parallel_squeezeformer_two_ranks_equal_one_process_on_the_joint_batch(tmp_path):
+    """and for the Squeezeformer encoder (SyncBN on the 2*d-channel statistics, time reduction / recovery, padded heads:
+    d = 36, d_k = 9) under the same two-rank exchange"""
+    import socket
+    import torch.multiprocessing as mp
+    over = dict(d_model=36, n_heads=4, n_layers=3, time_reduce_idx=1, conv_kernel_size=5, dropout=0.0, dropout_att=0.0)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), over, 20, "squeezeformer"), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
+    model = _dp_model("squeezeformer", over, 20)
+    model.setup_optimization(dict(name="adamw", lr=1e-3, betas=[0.9, 0.98], weight_decay=0.0))
+    audio, alen, tok, tl = _dp_batch("squeezeformer", 20)
+    batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+    model._optimizer.zero_grad()
+    loss = model.training_step(batch)["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(0.5 * (r0["loss"] + r1["loss"]).item() - loss.item()) <= 1e-5 * abs(loss.item())
+    for g0, g1, fp in zip(r0["grads"], r1["grads"], model.flats()):
+        assert torch.equal(g0, g1)
+        ref = fp.grad.detach().cpu()
+        assert (g0 - ref).norm() <= 3e-4 * ref.norm(), ((g0 - ref).norm() / ref.norm())
+    bn = model.encoder.layers[0].conv.batch_norm.running_mean.detach().cpu()
+    assert torch.allclose(r0["bn"], bn, atol=1e-5) and torch.equal(r0["bn"], r1["bn"])
     for a, b in zip(r0["flat"], r1["flat"]):
         assert torch.equal(a, b)
 
