@@ -40,14 +40,17 @@ def _oracle_run(enc, cfg, x, length, w):
     return y.detach(), yl, {k: v.grad for k, v in P.items() if v.requires_grad and v.grad is not None}, valid
 
 
-@pytest.mark.parametrize("d_model,n_heads,T", [(36, 4, 83), (20, 2, 64)])
-def test_squeezeformer_odd_geometry_fp32_matches_oracle(d_model, n_heads, T):
+@pytest.mark.parametrize("d_model,n_heads,T,extra", [(36, 4, 83, {}), (20, 2, 64, {}),
+                                                     (24, 3, 70, dict(adaptive_scale=False, time_reduce_idx=None, time_recovery_idx=None)),
+                                                     (24, 3, 61, dict(time_reduce_idx=0, time_recovery_idx=None))])
+def test_squeezeformer_odd_geometry_fp32_matches_oracle(d_model, n_heads, T, extra):
     """d_k = 9 / 10 (padded to 16 inside the weight images), d_model % 8 != 0 (activation pitch 40 / 24), odd and even frame
     counts through the time reduction: forward and every parameter gradient against the float64 oracle."""
     from nemo_amd.modules import SqueezeformerEncoder
     torch.manual_seed(5)
     kw = dict(feat_in=24, n_layers=3, d_model=d_model, subsampling="dw_striding", subsampling_factor=4, n_heads=n_heads,
               conv_kernel_size=5, dropout=0.0, dropout_emb=0.0, dropout_att=0.0, time_reduce_idx=1, time_recovery_idx=2)
+    kw.update(extra)  # (also: fixed scale / bias buffers, no temporal U-Net, reduction at layer 0 with recovery at the last layer)
     enc = SqueezeformerEncoder(compute_dtype=torch.float32, **kw)
     with torch.no_grad():
         for n, p in enc.named_parameters():
@@ -55,8 +58,8 @@ def test_squeezeformer_odd_geometry_fp32_matches_oracle(d_model, n_heads, T):
                 p.add_(0.2 * torch.randn_like(p))
             elif n.endswith("_scale.bias") or "pos_bias" in n:
                 p.add_(0.1 * torch.randn_like(p))
-    cfg = SQ.SqueezeformerCfg(feat_in=24, d_model=d_model, n_heads=n_heads, n_layers=3, conv_kernel=5, time_reduce_idx=1,
-                              time_recovery_idx=2)
+    cfg = SQ.SqueezeformerCfg(feat_in=24, d_model=d_model, n_heads=n_heads, n_layers=3, conv_kernel=5,
+                              time_reduce_idx=kw["time_reduce_idx"], time_recovery_idx=kw["time_recovery_idx"])
     x = torch.randn(3, 24, T)
     length = torch.tensor([T, T - 17, T // 2])
     T2 = ((T - 1) // 2 + 1 - 1) // 2 + 1
