@@ -57,3 +57,18 @@ r = torch.empty(M, d, device=dev)
 b2f = b2.float()
 t_own = timeit(lambda: ops.gemm(a, w2, r, M, d, dff, dff, dff, d, bias=b2f, alpha=0.5, epi=ops.EPI_RESID, aux_in=res, drop=dr))
 print(f"FFN2 forward (Linear + bias + dropout + 0.5 x + fp32 residual): library {t_lib*1e6:.1f} us | fused mi355x_gemm {t_own*1e6:.1f} us")
+
+# weight-gradient (TN) shapes: dW[n_out, n_in] = dY[rows, n_out]^T @ X[rows, n_in], f32 output; ours with atomic split-K
+print("TN (weight gradient) shapes, f32 result:")
+for name, n_out, n_in, rows, sk in [("ffn_w1", 2048, 512, 16032, 8), ("ffn_w2", 512, 2048, 16032, 8), ("proj", 512, 512, 16032, 16),
+                                    ("conv2_like", 512, 4608, 80160, 8)]:
+    dY = torch.randn(rows, n_out, device=dev).to(bf)
+    X = torch.randn(rows, n_in, device=dev).to(bf)
+    out16 = torch.empty(n_out, n_in, device=dev, dtype=bf)
+    dW = torch.zeros(n_out, n_in, device=dev)
+    t_lib = timeit(lambda: torch.matmul(dY.t(), X, out=out16))
+    t_own = timeit(lambda: ops.gemm(dY, X, dW, n_out, n_in, rows, n_out, n_in, n_in, transA=True, transB=True, atomic=True, splitk=sk,
+                                    c_dtype=ops.F32))
+    fl = 2.0 * n_out * n_in * rows
+    print(f"{name:12s} {n_out:5d} x {n_in:5d} x {rows:6d}  hipBLASLt (bf16 out) {t_lib*1e6:9.1f} us {fl/t_lib/1e12:7.1f} TF | mi355x_gemm split-K {sk:2d} "
+          f"{t_own*1e6:9.1f} us {fl/t_own/1e12:7.1f} TF", flush=True)
