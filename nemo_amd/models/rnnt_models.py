@@ -147,8 +147,7 @@ class EncDecRNNTModel(EncDecCTCModel):
 
     def validation_pass(self, batch, batch_idx=0, dataloader_idx=0):
         signal, signal_len, transcript, transcript_len = batch[:4]
-        with torch.no_grad():
-            was = self.joint.fuse_loss_wer
+        with torch.no_grad():  # (the fused joint then computes the loss only)
             out = self.training_step((signal, signal_len, transcript, transcript_len))
         return {"val_loss": out["loss"].detach()}
 

@@ -423,6 +423,10 @@ class RNNTJoint(_ModuleBase):
             raise ValueError("`fuse_loss_wer` is set, therefore encoder and target lengths must be provided as well!")
         if compute_wer:
             raise NotImplementedError("fused WER (greedy transducer decoding) is outside the training hot path")
+        if not torch.is_grad_enabled():  # validation: the loss only, no backward GEMMs
+            loss = self._fused_fwd_bwd(encoder_outputs, decoder_outputs, encoder_lengths, transcripts, transcript_lengths,
+                                       need_grad=False)[0]
+            return loss, None, None, None
         loss = _FusedJointLossFn.apply(encoder_outputs, decoder_outputs, self._tok(encoder_outputs.device), self,
                                        encoder_lengths, transcripts, transcript_lengths)
         return loss, None, None, None
@@ -528,7 +532,7 @@ class RNNTJoint(_ModuleBase):
         return denc, ddec
 
     # -------------------------------------------------------------------------------------------- fused joint + loss
-    def _fused_fwd_bwd(self, enc, dec, enc_len, transcripts, t_len):
+    def _fused_fwd_bwd(self, enc, dec, enc_len, transcripts, t_len, need_grad=True):
         """rnnt.py:1518-1640: sub-batches of `fused_batch_size` utterances; per sub-batch joint -> loss -> joint backward.
         Returns (reduced loss, d loss / d enc, d loss / d dec, joint parameter gradients as a flat buffer) for an upstream
         gradient of 1 -- `_FusedJointLossFn.backward` scales them."""
@@ -544,7 +548,7 @@ class RNNTJoint(_ModuleBase):
         if self.training:
             self._step_seed = (self._step_seed + 1) & 0x3FFFFFFF
         fp = self._flatp
-        gtmp = torch.zeros_like(fp.flat)
+        gtmp = torch.zeros_like(fp.flat) if need_grad else None
 
         def gview(p):  # the slot of parameter p inside the temporary gradient buffer
             off = (p.data_ptr() - fp.flat.data_ptr()) // 4
@@ -552,8 +556,8 @@ class RNNTJoint(_ModuleBase):
 
         out = self.joint_net[-1]
         xe, xd, f, g = self._project(enc, dec, W, cdt)
-        df = torch.empty(B * T, J, dtype=cdt, device=dev)
-        dg32 = torch.zeros(B * U1, J, dtype=torch.float32, device=dev)
+        df = torch.empty(B * T, J, dtype=cdt, device=dev) if need_grad else None
+        dg32 = torch.zeros(B * U1, J, dtype=torch.float32, device=dev) if need_grad else None
         labels = transcripts.to(torch.int64).contiguous()
         el, tl = enc_len.to(torch.int64).contiguous(), t_len.to(torch.int64).contiguous()
         scale = 1.0 / B if red == "mean_batch" else 1.0
@@ -564,6 +568,12 @@ class RNNTJoint(_ModuleBase):
             drop = self._drop(si)
             fe = float(getattr(loss_mod, "fastemit_lambda", 0.0) or 0.0)
             cl = float(getattr(loss_mod, "clamp", 0.0) or 0.0)
+            if not need_grad:
+                h, logits = self._sub_fwd(f, g, b0, nb, T, U1, W, cdt, drop)
+                costs[b0:b0 + nb] = ops.rnnt_loss(logits, labels[b0:b0 + nb], el[b0:b0 + nb], tl[b0:b0 + nb], self._vocab_size,
+                                                  fastemit_lambda=fe, clamp=cl, grad_scale=scale)
+                del h, logits
+                continue
             if cdt == torch.bfloat16:
                 # logits with row pitch roundup8(V+1) (vector stores from the GEMM); the loss kernel writes the logit gradient
                 # directly as the bf16 operand of the backward GEMMs: the f32 gradient tensor and its cast pass do not exist
@@ -585,7 +595,9 @@ class RNNTJoint(_ModuleBase):
             costs[b0:b0 + nb] = c
             self._sub_bwd(grads, h, b0, nb, T, U1, W, cdt, drop, df, dg32, gview(out.weight), gview(out.bias))
             del h, logits, grads
+        loss = costs.sum() * scale
+        if not need_grad:
+            return loss, None, None, None
         denc, ddec = self._proj_bwd(xe, xd, df, dg32, W, cdt, B, T, U1, gview(self.enc.weight), gview(self.enc.bias),
                                     gview(self.pred.weight), gview(self.pred.bias))
-        loss = costs.sum() * scale
         return loss, denc.contiguous(), ddec.contiguous(), gtmp

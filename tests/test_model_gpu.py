@@ -731,6 +731,13 @@ def test_fastconformer_transducer_model_trains_and_bf16_tracks_fp32():
     assert abs(l16.item() - losses[0]) <= 1e-2 * abs(losses[0]), (l16.item(), losses[0])
     for n, p in m16.named_parameters():
         assert torch.isfinite(p.grad).all(), n
+    # validation: the fused joint computes the loss only (no backward GEMMs) -- same value as the training path in eval mode
+    m16.eval()
+    v = m16.validation_pass(batch)["val_loss"]
+    e = m16.training_step(batch)["loss"]
+    torch.cuda.synchronize()
+    assert torch.isfinite(v) and abs(v.item() - e.item()) <= 1e-5 * abs(e.item()), (v.item(), e.item())
+    m16.train()
     # dropout on (recipe values): runs, finite, stochastic
     torch.manual_seed(3)
     md = _rnnt_model(torch.bfloat16, d_model=256, dropout=0.1, dropout_att=0.1)
