@@ -227,9 +227,14 @@ int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, lon
 /* backward of the fused attention.  delta[b,h,i] = sum_dv dO*O.  dq kernel: qu = q+u, qv = q+v ([B*T,d] bf16, from
  * mi355x_qbias), recomputes P from lse, returns dQu and dQv ([B*T,d] bf16; dq = dQu+dQv, d pos_bias_{u,v} = column sums). */
 int mi355x_attn_delta(const void* dO, const void* O, void* delta, int B, int H, int T, int d, void* stream);
+/* ds_out (optional): the score gradient in the layout of the reference's matrix_bd BEFORE rel_shift
+ * (multi_head_attention.py:259-270), cut into 32 x 32 bf16 blocks for mi355x_relpos_flash_bwd_dpos:
+ * X[h][b][it][s][q][cl] = dS[b,h, i = 32*it+q, j] at position c = T-1+j-i = T-32+32*(s-it)+cl, it < ceil(T/32), s <= ceil(T/32);
+ * slots s <= ceil(len[b]/32) are written.  ds_elems = capacity of ds_out in elements, >= mi355x_relpos_ds_elems(B,H,T). */
+long long mi355x_relpos_ds_elems(int B, int H, int T);
 int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos, long long ldp,
                                const void* len, const void* dO, const void* lse, const void* delta, void* dqu, void* dqv,
-                               void* ds_out /* optional [H,B,T,Tp] bf16 */, int B, int H, int T, int dk, int Tp, float scale,
+                               void* ds_out, int B, int H, int T, int dk, long long ds_elems, float scale,
                                unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream);
 
 /* dK and dV rows written into the k / v column blocks of dqkv [B*T, ldd = 3d] */
@@ -238,12 +243,13 @@ int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const void* qkv,
                                 int B, int H, int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold,
                                 float drop_scale, void* stream);
 
-/* dpos f32 [2T-1, ldd] += gradient w.r.t. pos = linear_pos(pos_emb), summed over the batch, from the dS tiles
- * ([H,B,T,Tp] bf16, Tp >= roundup32(T)) written by mi355x_relpos_flash_bwd_dq (ds_out) */
-int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len, void* dpos, long long ldd,
-                                 void* partial /* optional f32 scratch >= ceil(B/4)*(2*ceil(T/32)-1)*H*4096: deterministic
-                                                  two-stage reduction instead of atomics */, long long partial_elems,
-                                 int B, int H, int T, int dk, int Tp, void* stream);
+/* dpos f32 [2T-1, ldd] += gradient w.r.t. pos = linear_pos(pos_emb) (multi_head_attention.py:296-300 backward), summed over
+ * the batch: dpos[c, h, :] += sum_{b,i} dS[b,h,i,c-(T-1)+i] * qv[b,i,h,:], from the blocks written by
+ * mi355x_relpos_flash_bwd_dq (ds_out).  partial (optional): f32 scratch of >= mi355x_relpos_dpos_partial_elems(B,H,T)
+ * elements -> deterministic two-stage reduction instead of atomics. */
+long long mi355x_relpos_dpos_partial_elems(int B, int H, int T);
+int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len, void* dpos, long long ldd, void* partial,
+                                 long long partial_elems, int B, int H, int T, int dk, long long ds_elems, void* stream);
 
 /* ---- convolution module: depthwise conv + BatchNorm + Swish (conformer_modules.py:333-342, causal_convs.py:130-147) */
 int mi355x_dwconv_fwd(const void* x, const void* w /*[d,1,k]*/, const void* bias, void* y, int dtype,

@@ -102,9 +102,11 @@ SIGNATURES = {
     "mi355x_relpos_softmax_bwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_relpos_flash_fwd": [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_attn_delta": [vp, vp, vp, i32, i32, i32, i32, vp],
-    "mi355x_relpos_flash_bwd_dq": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
+    "mi355x_relpos_flash_bwd_dq": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, f32, u32, u32, f32, vp],
     "mi355x_relpos_flash_bwd_dkv": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
-    "mi355x_relpos_flash_bwd_dpos": [vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
+    "mi355x_relpos_flash_bwd_dpos": [vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i64, vp],
+    "mi355x_relpos_ds_elems": [i32, i32, i32],
+    "mi355x_relpos_dpos_partial_elems": [i32, i32, i32],
     "mi355x_dwconv_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp],
     "mi355x_dwconv_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp],
     "mi355x_bn_finalize": [vp, f64, vp, vp, vp, vp, f32, f32, i32, vp],
@@ -142,6 +144,8 @@ def _load():
         fn.argtypes = argtypes
         fn.restype = i32
     lib.mi355x_asr_version.restype = C.c_char_p
+    lib.mi355x_relpos_ds_elems.restype = i64
+    lib.mi355x_relpos_dpos_partial_elems.restype = i64
     lib.mi355x_asr_version.argtypes = []
     return lib
 

@@ -335,16 +335,17 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     const bf16_t* __restrict__ qu_g, const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ qkv, long long ldq,
     const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqu_out,
-    bf16_t* __restrict__ dqv_out, bf16_t* __restrict__ ds_out, int B, int H, int T, int Tp, int d, float scale,
+    bf16_t* __restrict__ dqv_out, bf16_t* __restrict__ ds_out, int B, int H, int T, int d, float scale,
     DropCfg drop) {
   __shared__ __attribute__((aligned(16))) bf16_t s_k[ABK * ADK];
   __shared__ __attribute__((aligned(16))) bf16_t s_v[ABK * ADK];
   __shared__ __attribute__((aligned(16))) bf16_t s_p[ABAND * ADK];
   __shared__ __attribute__((aligned(16))) float s_g[4][32 * SG_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t s_carry[4][32 * 32];  // upper half of the previous step's band, per wave
 
   const int b = blockIdx.z, h = blockIdx.y;
   const int i0_blk = blockIdx.x * ABQ;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane & 31, lh = lane >> 5;
   const int i = i0_blk + wave * 32 + q;
   const int L = (int)min((long long)T, len[b]);
@@ -372,6 +373,12 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   const int prow0 = (ABQ - 32) - 32 * wave;
 
   const int nkt = (L + ABK - 1) / ABK;
+  // linear_pos gradient operand (see the end of the loop): tile `itile` of (h, b) owns nT+1 blocks of 32 x 32 bf16
+  const int nT = (T + 31) / 32, itile = blockIdx.x * 4 + wave;
+  const bool xw = ds_out != nullptr && itile < nT;  // wave-uniform
+  bf16_t* xbase = ds_out + ((((long long)h * B + b) * nT + itile) * (nT + 1)) * 1024;
+  u32x4* carry = reinterpret_cast<u32x4*>(s_carry[wave]);
+  if (xw) { carry[lane] = (u32x4){0u, 0u, 0u, 0u}; carry[64 + lane] = (u32x4){0u, 0u, 0u, 0u}; }
   for (int kt = 0; kt < nkt; ++kt) {
     const int j0 = kt * ABK;
     __syncthreads();
@@ -422,25 +429,6 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
       }
       ds[r] = ds[r] * (acc_dp[r] * dm - dlt_i) * scale;
     }
-    // ---- dS tile [32 queries][32 keys] -> HBM (bf16, [H,B,T,Tp]) for the linear_pos gradient kernel
-    if (ds_out) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sg[q * SG_LD + (r & 3) + 8 * (r >> 2) + 4 * lh] = ds[r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int it2 = 0; it2 < 2; ++it2) {
-        const int row = it2 * 16 + (lane >> 2), c8 = (lane & 3) * 8;
-        const int ii = i0_blk + wave * 32 + row;
-        float v8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v8[e] = sg[row * SG_LD + c8 + e];
-        if (ii < T) {
-          u32x4 t = {pack_bf2(v8[0], v8[1]), pack_bf2(v8[2], v8[3]), pack_bf2(v8[4], v8[5]), pack_bf2(v8[6], v8[7])};
-          *reinterpret_cast<u32x4*>(ds_out + (((long long)h * B + b) * T + ii) * Tp + j0 + c8) = t;
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
     // ---- dQu^T += K^T . dS^T
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -476,6 +464,31 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- the band (sg[q][c_local], exactly the operand of the product above) -> HBM for the linear_pos gradient kernel, in
+    // the un-shifted (pre-rel_shift) layout: block (it, s) = [32 queries][32 positions c = T-32+32*(s-it) + cl].  The lower
+    // half of this step's band (c_local < 32) completes block s = kt together with the upper half of step kt-1 (disjoint
+    // triangles: OR of the packed words); the upper half waits in the wave's carry image for step kt+1.  A lane owns the same
+    // two 16-byte chunks of the block and of the carry, so the stores are lane-linear (1 KiB per instruction).
+    if (xw) {
+#pragma unroll
+      for (int it2 = 0; it2 < 2; ++it2) {
+        const int row = it2 * 16 + (lane >> 2), c8 = (lane & 3) * 8;
+        float lo[8], hi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { lo[e] = sg[row * SG_LD + c8 + e]; hi[e] = sg[row * SG_LD + 32 + c8 + e]; }
+        const u32x4 cw = carry[it2 * 64 + lane];
+        u32x4 t = {pack_bf2(lo[0], lo[1]) | cw.x, pack_bf2(lo[2], lo[3]) | cw.y, pack_bf2(lo[4], lo[5]) | cw.z,
+                   pack_bf2(lo[6], lo[7]) | cw.w};
+        *reinterpret_cast<u32x4*>(xbase + (long long)kt * 1024 + it2 * 512 + lane * 8) = t;
+        carry[it2 * 64 + lane] = (u32x4){pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3]), pack_bf2(hi[4], hi[5]), pack_bf2(hi[6], hi[7])};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  if (xw) {  // last block of the tile: the upper half of the final step
+#pragma unroll
+    for (int it2 = 0; it2 < 2; ++it2)
+      *reinterpret_cast<u32x4*>(xbase + (long long)nkt * 1024 + it2 * 512 + lane * 8) = carry[it2 * 64 + lane];
   }
 
   // ---- write dQu, dQv rows (transpose through the wave-private LDS tile)
@@ -636,27 +649,44 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   }
 }
 
-// d linear_pos output: dp[c, h, dk] += sum_{b,i} dS[b,h,i, j = c-(T-1)+i] * Qv[b,i,h,dk], from the dS tiles the dQ kernel left
-// in HBM.  One workgroup walks ONE DIAGONAL of 32x32 (query-tile, key-tile) pairs (jt - it = const): the 64-row positional
-// band is the same for every pair, so dp accumulates in MFMA accumulators across all pairs / batch entries of the
-// workgroup and leaves with a single pass of atomics.  Per pair: 2 KB of dS + 4 KB of Qv by LDS-DMA, 8 MFMAs:
-//   D[c_local][dk] += sum_q A[c_local][q] B[q][dk],  A = un-skewed dS (gathered from LDS: dS[q][c_local - 31 + q]),
-//   B = Qv^T fragments via ds_read_b64_tr_b16.
+// 32 x 32 bf16 image [row = k][col = m] (pitch 32, no swizzle: the 4 rows x 32 columns a half-wave reads are 256 contiguous
+// bytes) -> MFMA A fragment A[m = lane&31][k-slots 0-3 <- rows ra..ra+3, 4-7 <- rows rb..rb+3] by the hardware transpose read
+__device__ __forceinline__ bf16x8 tr_frag32(const bf16_t* img, int ra, int rb, int lane) {
+  const int t = lane & 15, g4 = (lane >> 4) & 1;
+  const int col = g4 * 16 + (t & 3) * 4;
+  union { bf16x8 v; s16x4 h[2]; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + (ra + (t >> 2)) * 32 + col));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + (rb + (t >> 2)) * 32 + col));
+  return u.v;
+}
+
+typedef __attribute__((address_space(3))) const char lds_cchar_t;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_cchar_t*)p; }
+
+// d linear_pos output: dp[c, h, dk] += sum_{b,i} dS[b,h,i, j = c-(T-1)+i] * Qv[b,i,h,dk].  The dQ kernel leaves dS in the
+// UN-SHIFTED layout of the reference's matrix_bd before rel_shift (multi_head_attention.py:259-270), cut into blocks:
+// X[h][b][it][s] = [32 queries of tile it][32 positions c = T-32+32*(s-it) + cl], s = 0..nT.  That makes the gradient a plain
+// product with both operands staged as they lie in memory:
+//   D[c][dk] += sum_q X[q][c] * Qv[q][dk]     (A = X^T and B = Qv both through ds_read_b64_tr_b16, no gather, no masks)
+// One workgroup owns 64 consecutive positions (the block pair dg = s-it in {2x-(nT-1), +1}) of one head and walks every
+// (utterance of its chunk, query tile) that reaches them: 4 KiB of X (the two blocks are adjacent) + 4 KiB of Qv per item by
+// LDS-DMA one item ahead, 8 MFMAs; the four waves split the items and combine at the end.
 __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
-    const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ ds_g, const long long* __restrict__ len,
-    float* __restrict__ dpos, long long ldd, float* __restrict__ partial, int B, int H, int T, int Tp, int d, int bchunk) {
-  __shared__ __attribute__((aligned(16))) bf16_t s_ds[4][2][32 * 32];   // per wave, double-buffered
+    const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ x_g, const long long* __restrict__ len,
+    float* __restrict__ dpos, long long ldd, float* __restrict__ partial, int B, int H, int T, int d, int bchunk) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_x[4][2][2 * 1024];   // per wave, double-buffered
   __shared__ __attribute__((aligned(16))) bf16_t s_qv[4][2][32 * ADK];
 
   const int nT = (T + 31) / 32;
-  const int delta_t = (int)blockIdx.x - (nT - 1);  // jt - it
+  const int dg = 2 * (int)blockIdx.x - (nT - 1);  // s - it of the first block; the second is dg + 1
   const int h = blockIdx.y;
   const int b_begin = blockIdx.z * bchunk, b_end = min(B, b_begin + bchunk);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane & 31, lh = lane >> 5;
   const int P = 2 * T - 1;
-  const int cmin = T - 1 + 32 * delta_t - 31;
-  const int it_lo = max(0, -delta_t), it_hi = min(nT, nT - delta_t);
+  const int cmin = T - 32 + 32 * dg;
+  // query tiles with at least one of the slots it+dg, it+dg+1 inside [0, nT]
+  const int it_lo = max(0, -dg - 1), it_hi = min(nT, nT - dg + 1);
 
   f32x16 dp_acc[2][2];
 #pragma unroll
@@ -664,20 +694,18 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
 
   const int npairs = it_hi - it_lo;
   const int nitems = (b_end - b_begin) * npairs;
-  // 6 LDS-DMA instructions per item (2 KB of dS + 4 KB of Qv); issued one item ahead, waited with a counted vmcnt
-  // (utterance, tile) of an item advance incrementally (4 items per step: one per wave) -- no integer divisions, and all
-  // address products fit 24-bit multiplies (batch / head offsets are folded into 64-bit bases once per item)
+  // 8 LDS-DMA instructions per item; a slot outside [0, nT] is clamped for the load (always inside the tile's own blocks) and
+  // skipped in the product; batch / head offsets are folded into 64-bit bases once per item
   auto issue = [&](int b, int it, int buf) {
-    const int jt = it + delta_t;
-    const bf16_t* base = ds_g + (((long long)h * B + b) * T) * Tp + 32 * jt;
-    bf16_t* sds = s_ds[wave][buf];
+    const int s0 = it + dg;
+    const int sl0 = min(max(s0, 0), nT), sl1 = min(max(s0 + 1, 0), nT);
+    const bf16_t* base = x_g + ((((long long)h * B + b) * nT + it) * (nT + 1)) * 1024;
+    bf16_t* sx = s_x[wave][buf];
     bf16_t* sqv = s_qv[wave][buf];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
-      const int cq = k2 * 64 + lane;
-      int gr = 32 * it + (cq >> 2);
-      gr = gr > T - 1 ? T - 1 : gr;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(base + __mul24(gr, Tp) + (cq & 3) * 8), (lds_void_t*)(sds + k2 * 512),
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(base + sl0 * 1024 + k2 * 512 + lane * 8), (lds_void_t*)(sx + k2 * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(base + sl1 * 1024 + k2 * 512 + lane * 8), (lds_void_t*)(sx + 1024 + k2 * 512),
                                        16, 0, 0);
     }
     const bf16_t* qb = qv_g + ((long long)b * T) * d + h * ADK;
@@ -695,6 +723,21 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
     it += steps;
     while (it >= it_hi) { it -= npairs; ++b; }
   };
+  // per-lane LDS byte addresses of the transpose reads (tr_frag32 / tr_frag geometry), buffer 0
+  uint32_t xaddr, qaddr[2][2][2];
+  {
+    const int t = lane & 15, g4 = (lane >> 4) & 1;
+    xaddr = lds_addr(&s_x[wave][0][0]) + (uint32_t)(((8 * lh + (t >> 2)) * 32 + g4 * 16 + (t & 3) * 4) * 2);
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int dkt = 0; dkt < 2; ++dkt)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int r = 16 * st + 8 * lh + 4 * hf + (t >> 2), col = dkt * 32 + g4 * 16 + (t & 3) * 4;
+          qaddr[st][dkt][hf] = lds_addr(&s_qv[wave][0][0]) + (uint32_t)((r * ADK + (((col >> 3) ^ ((r >> 1) & 7)) << 3) + (col & 7)) * 2);
+        }
+  }
   int cb = b_begin, cit = it_lo;      // item being computed by this wave
   advance(cb, cit, wave);
   int nb = cb, nit = cit;             // item being prefetched
@@ -704,38 +747,42 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
     if (item + 4 < nitems) {
       nb = cb; nit = cit; advance(nb, nit, 4);
       issue(nb, nit, buf ^ 1);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int b = cb;
-    const int it = cit, jt = it + delta_t;
+    const int it = cit, s0 = it + dg;
     const int L = (int)min((long long)T, len[b]);
-    if (32 * it >= L || 32 * jt >= L) continue;  // wave-uniform: tiles the dQ kernel never produced (data ignored)
-    const bf16_t* sds = s_ds[wave][buf];
-    const bf16_t* sqv = s_qv[wave][buf];
-    const int nq = min(32, T - 32 * it);  // valid query rows of this tile
+    const int nkt = (L + 31) / 32;  // the dQ kernel wrote slots 0..nkt of every tile
+    const bool v0 = s0 >= 0 && s0 <= nkt, v1 = s0 + 1 >= 0 && s0 + 1 <= nkt;
+    if (32 * it >= L || !(v0 || v1)) continue;  // wave-uniform: tiles without valid queries are all zero, other slots unwritten
+    // fragment reads by inline asm: behind an LDS-DMA the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS read it
+    // emits itself, which would also wait for the NEXT item's eight loads (the counted vmcnt(8) above is the real condition)
+    const uint32_t m0 = v0 ? 0xffffffffu : 0u, m1 = v1 ? 0xffffffffu : 0u;  // a slot outside 0..nkt was never written
+    const uint32_t xa = xaddr + buf * 4096u, qoff = buf * 4096u;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      bf16x8 af[2];
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        union { bf16x8 v; uint16_t u[8]; } a;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int qq = 16 * st + 8 * lh + e;
-          const int rho = 32 * ct + q - 31 + qq;  // key column of dS that maps to this lane's c_local
-          uint16_t val = 0;
-          if (rho >= 0 && rho < 32 && qq < nq) val = sds[qq * 32 + rho];
-          a.u[e] = val;
-        }
-        af[ct] = a.v;
-      }
+      union { bf16x8 v; s16x4 h[2]; u32x4 w; } af[2], bq[2];
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %8\n\t"
+          "ds_read_b64_tr_b16 %1, %8 offset:256\n\t"
+          "ds_read_b64_tr_b16 %2, %8 offset:2048\n\t"
+          "ds_read_b64_tr_b16 %3, %8 offset:2304\n\t"
+          "ds_read_b64_tr_b16 %4, %9\n\t"
+          "ds_read_b64_tr_b16 %5, %10\n\t"
+          "ds_read_b64_tr_b16 %6, %11\n\t"
+          "ds_read_b64_tr_b16 %7, %12\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(af[0].h[0]), "=&v"(af[0].h[1]), "=&v"(af[1].h[0]), "=&v"(af[1].h[1]), "=&v"(bq[0].h[0]), "=&v"(bq[0].h[1]),
+            "=&v"(bq[1].h[0]), "=&v"(bq[1].h[1])
+          : "v"(xa + st * 1024u), "v"(qaddr[st][0][0] + qoff), "v"(qaddr[st][0][1] + qoff), "v"(qaddr[st][1][0] + qoff),
+            "v"(qaddr[st][1][1] + qoff)
+          : "memory");
+      af[0].w &= m0;
+      af[1].w &= m1;
 #pragma unroll
       for (int dkt = 0; dkt < 2; ++dkt) {
-        const int ra = 16 * st + 8 * lh;
-        const bf16x8 bq = tr_frag(sqv, ra, ra + 4, dkt * 32, lane);
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-          dp_acc[ct][dkt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct], bq, dp_acc[ct][dkt], 0, 0, 0);
+        dp_acc[0][dkt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0].v, bq[dkt].v, dp_acc[0][dkt], 0, 0, 0);
+        dp_acc[1][dkt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1].v, bq[dkt].v, dp_acc[1][dkt], 0, 0, 0);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -790,25 +837,19 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
       }
 }
 
-// stage 2: row group g (32 rows starting at T-1+32*(g-nT+1)-31) = tile 0 of diagonal g + tile 1 of diagonal g-1, over all z
+// stage 2: the 64 positions of block pair x (disjoint between pairs), summed over the utterance chunks z
 __global__ __launch_bounds__(256) void dpos_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dpos, long long ldd,
                                                           int H, int T, int nz) {
-  const int nT = (T + 31) / 32, ndiag = 2 * nT - 1;
-  const int g = blockIdx.x, h = blockIdx.y;
+  const int nT = (T + 31) / 32;
+  const int x = blockIdx.x, h = blockIdx.y;
   const int P = 2 * T - 1;
-  const int c0 = T - 1 + 32 * (g - nT + 1) - 31;
-  {
-    const int e = blockIdx.z * 256 + threadIdx.x;  // 8 blocks of 256 threads cover the 32 x 64 group
-    const int cl = e >> 6, dk = e & 63;
-    const int c = c0 + cl;
-    if (c < 0 || c >= P) return;
-    float acc = 0.f;
-    for (int z = 0; z < nz; ++z) {
-      if (g < ndiag) acc += partial[(((long long)z * ndiag + g) * H + h) * 4096 + cl * 64 + dk];
-      if (g >= 1) acc += partial[(((long long)z * ndiag + (g - 1)) * H + h) * 4096 + (32 + cl) * 64 + dk];
-    }
-    dpos[(long long)c * ldd + h * ADK + dk] += acc;
-  }
+  const int e = blockIdx.z * 256 + threadIdx.x;  // 16 blocks of 256 threads cover the 64 x 64 pair
+  const int cl = e >> 6, dk = e & 63;
+  const int c = T - 32 + 32 * (2 * x - (nT - 1)) + cl;
+  if (c < 0 || c >= P) return;
+  float acc = 0.f;
+  for (int z = 0; z < nz; ++z) acc += partial[(((long long)z * nT + x) * H + h) * 4096 + e];
+  dpos[(long long)c * ldd + h * ADK + dk] += acc;
 }
 
 extern "C" int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, long long ldp, const void* bias_u,
@@ -838,17 +879,17 @@ extern "C" int mi355x_attn_delta(const void* dO, const void* O, void* delta, int
 
 extern "C" int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos,
                                           long long ldp, const void* len, const void* dO, const void* lse, const void* delta,
-                                          void* dqu, void* dqv, void* ds_out, int B, int H, int T, int dk, int Tp, float scale,
-                                          unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
+                                          void* dqu, void* dqv, void* ds_out, int B, int H, int T, int dk, long long ds_elems,
+                                          float scale, unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
   mi_clear_errors();
   if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || !dqu || !dqv || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
   if (dk != ADK || (ldq % 24) || (ldp & 7)) return MI_ERR_ARG;
-  if (ds_out && ((Tp & 7) || Tp < ((T + 31) / 32) * 32)) return MI_ERR_ARG;
+  if (ds_out && (((uintptr_t)ds_out & 15) || ds_elems < mi355x_relpos_ds_elems(B, H, T))) return MI_ERR_ARG;
   DropCfg dc{drop_key, drop_threshold, drop_scale};
   dim3 grid((T + ABQ - 1) / ABQ, H, B);
   hipLaunchKernelGGL(relpos_flash_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu, (const bf16_t*)qv,
                      (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len, (const bf16_t*)dO,
-                     (const float*)lse, (const float*)delta, (bf16_t*)dqu, (bf16_t*)dqv, (bf16_t*)ds_out, B, H, T, Tp, H * ADK, scale, dc);
+                     (const float*)lse, (const float*)delta, (bf16_t*)dqu, (bf16_t*)dqv, (bf16_t*)ds_out, B, H, T, H * ADK, scale, dc);
   return mi_check_launch();
 }
 
@@ -867,22 +908,32 @@ extern "C" int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const
   return mi_check_launch();
 }
 
+extern "C" long long mi355x_relpos_ds_elems(int B, int H, int T) {
+  const long long nT = (T + 31) / 32;
+  return (long long)H * B * nT * (nT + 1) * 1024;
+}
+
+extern "C" long long mi355x_relpos_dpos_partial_elems(int B, int H, int T) {
+  const long long nT = (T + 31) / 32;
+  const int bchunk = B >= 8 ? 4 : 1;
+  return (long long)((B + bchunk - 1) / bchunk) * nT * H * 4096;
+}
+
 extern "C" int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len, void* dpos, long long ldd,
-                                            void* partial, long long partial_elems, int B, int H, int T, int dk, int Tp,
-                                            void* stream) {
+                                            void* partial, long long partial_elems, int B, int H, int T, int dk,
+                                            long long ds_elems, void* stream) {
   mi_clear_errors();
   if (!qv || !ds || !len || !dpos || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
-  if (dk != ADK || (Tp & 7) || Tp < ((T + 31) / 32) * 32) return MI_ERR_ARG;
+  if (dk != ADK || ((uintptr_t)ds & 15) || ds_elems < mi355x_relpos_ds_elems(B, H, T)) return MI_ERR_ARG;
   const int nT = (T + 31) / 32;
-  int bchunk = B >= 8 ? 4 : 1;
-  if (const char* e = getenv("MI355X_DPOS_BCHUNK")) bchunk = atoi(e) > 0 ? atoi(e) : bchunk;
+  const int bchunk = B >= 8 ? 4 : 1;
   const int nz = (B + bchunk - 1) / bchunk;
-  if (partial && partial_elems < (long long)nz * (2 * nT - 1) * H * 4096) return MI_ERR_ARG;
-  dim3 grid(2 * nT - 1, H, nz);
+  if (partial && partial_elems < mi355x_relpos_dpos_partial_elems(B, H, T)) return MI_ERR_ARG;
+  dim3 grid(nT, H, nz);
   hipLaunchKernelGGL(relpos_flash_bwd_dpos_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qv,
-                     (const bf16_t*)ds, (const long long*)len, (float*)dpos, ldd, (float*)partial, B, H, T, Tp, H * ADK, bchunk);
+                     (const bf16_t*)ds, (const long long*)len, (float*)dpos, ldd, (float*)partial, B, H, T, H * ADK, bchunk);
   if (partial)
-    hipLaunchKernelGGL(dpos_reduce_kernel, dim3(2 * nT, H, 8), dim3(256), 0, (hipStream_t)stream, (const float*)partial,
+    hipLaunchKernelGGL(dpos_reduce_kernel, dim3(nT, H, 16), dim3(256), 0, (hipStream_t)stream, (const float*)partial,
                        (float*)dpos, ldd, H, T, nz);
   return mi_check_launch();
 }

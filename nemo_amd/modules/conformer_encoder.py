@@ -740,22 +740,21 @@ class ConformerEncoder(NeuralModule):
             ops.qbias(qkv, 3 * dA, bias_u, bias_v, qu, qv, M, dA)
             dlt = torch.empty(B, H, T, dtype=torch.float32, device=dev)
             ops.attn_delta(dctx, ctx, dlt, B, H, T, dA)
-            Tp32 = (T + 31) // 32 * 32
-            # transient dS: dQ kernel -> linear_pos gradient kernel.  The latter feeds only the (batched, end-of-backward)
-            # linear_pos weight gradient, so with the side stream it leaves the critical path; dS then comes from the
-            # caching allocator (record_stream keeps the next layer's dQ kernel from overwriting it too early).
+            # transient dS (un-shifted 32 x 32 blocks): dQ kernel -> linear_pos gradient kernel.  The latter feeds only the
+            # (batched, end-of-backward) linear_pos weight gradient, so with the side stream it leaves the critical path; dS
+            # then comes from the caching allocator (record_stream keeps the next layer's dQ kernel from overwriting it too early).
             side_pos = self.dpos_side_stream and self.wgrad_side_stream
-            dS = (torch.empty(H, B, T, Tp32, dtype=cdt, device=dev) if side_pos
-                  else self._buf("dS", (H, B, T, Tp32), cdt, dev))
-            ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * dA, p, dA, lens, dctx, lse, dlt, dqu, dqv, B, H, T, dk, Tp32, scale, d_att,
+            n_ds = ops.lib.mi355x_relpos_ds_elems(B, H, T)
+            dS = (torch.empty(n_ds, dtype=cdt, device=dev) if side_pos else self._buf("dS", (n_ds,), cdt, dev))
+            ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * dA, p, dA, lens, dctx, lse, dlt, dqu, dqv, B, H, T, dk, scale, d_att,
                                     ds_out=dS)
             if side_pos:
                 with self._wgrad_scope(qv, dS):
-                    ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk, Tp32)
+                    ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk)
                     ops.drop_scale_cast(dp, dp_cast, P * dA, 1.0)
             ops.relpos_flash_bwd_dkv(qu, qv, qkv, 3 * dA, p, dA, lens, dctx, lse, dlt, dqkv, 3 * dA, B, H, T, dk, Tp, scale, d_att)
             if not side_pos:
-                ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk, Tp32)
+                ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk)
                 ops.drop_scale_cast(dp, dp_cast, P * dA, 1.0)
             return dqkv, dqu, dqv
         # dpd[h,b] = dctx_bh @ v_bh^T  -> reuse the f32 score workspace

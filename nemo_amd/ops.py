@@ -390,10 +390,20 @@ def attn_delta(dO, O, delta, B, H, T, d):
     check(lib.mi355x_attn_delta(_ptr(dO), _ptr(O), _ptr(delta), B, H, T, d, _stream()), "attn_delta")
 
 
-def relpos_flash_bwd_dq(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqu, dqv, B, H, T, dk, Tp, scale,
+def relpos_ds_buffer(B, H, T, device, fill=None):
+    """bf16 buffer for the dQ kernel's score-gradient blocks (un-shifted matrix_bd layout, see include/mi355x_asr.h)"""
+    n = lib.mi355x_relpos_ds_elems(B, H, T)
+    buf = torch.empty(n, dtype=torch.bfloat16, device=device)
+    if fill is not None:
+        buf.fill_(fill)
+    return buf
+
+
+def relpos_flash_bwd_dq(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqu, dqv, B, H, T, dk, scale,
                         drop: Dropout = NO_DROP, ds_out=None):
     check(lib.mi355x_relpos_flash_bwd_dq(_ptr(qu), _ptr(qv), _ptr(qkv), ldq, _ptr(pos), ldp, _ptr(lens), _ptr(dO), _ptr(lse),
-                                         _ptr(delta), _ptr(dqu), _ptr(dqv), _ptr(ds_out), B, H, T, dk, Tp, scale, drop.key,
+                                         _ptr(delta), _ptr(dqu), _ptr(dqv), _ptr(ds_out), B, H, T, dk,
+                                         0 if ds_out is None else ds_out.numel(), scale, drop.key,
                                          drop.threshold, drop.scale, _stream()), "relpos_flash_bwd_dq")
 
 
@@ -407,15 +417,15 @@ def relpos_flash_bwd_dkv(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqkv,
 _DPOS_SCRATCH = {}
 
 
-def relpos_flash_bwd_dpos(qv, ds, lens, dpos, B, H, T, dk, Tp):
-    n = ((B + 3) // 4 if B >= 8 else B) * (2 * ((T + 31) // 32) - 1) * H * 4096
+def relpos_flash_bwd_dpos(qv, ds, lens, dpos, B, H, T, dk):
+    n = lib.mi355x_relpos_dpos_partial_elems(B, H, T)
     key = (str(dpos.device), n)
     scratch = _DPOS_SCRATCH.get(key)
     if scratch is None:
         _DPOS_SCRATCH.clear()
         scratch = _DPOS_SCRATCH[key] = torch.empty(n, dtype=torch.float32, device=dpos.device)
     check(lib.mi355x_relpos_flash_bwd_dpos(_ptr(qv), _ptr(ds), _ptr(lens), _ptr(dpos), dpos.shape[-1], _ptr(scratch), n, B, H, T,
-                                           dk, Tp, _stream()), "relpos_flash_bwd_dpos")
+                                           dk, ds.numel(), _stream()), "relpos_flash_bwd_dpos")
 
 
 # ------------------------------------------------------------------------------------------------ conv module

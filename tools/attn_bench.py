@@ -32,8 +32,7 @@ def t(name, fn, flops):
 pair = 2.0 * B * H * T * T * dk  # one T x T x dk product
 t("fwd", lambda: ops.relpos_flash_fwd(qkv, 3 * d, pos, d, u, v, lens, ctx, d, lse, B, H, T, dk, Tp, scale, drop), 3 * pair)
 ops.qbias(qkv, 3 * d, u, v, qu, qv, B * T, d); ops.attn_delta(dO, ctx, dlt, B, H, T, d)
-Tp32 = (T + 31) // 32 * 32
-dS = torch.zeros(H, B, T, Tp32, device=dev, dtype=bf)
-t("bwd_dq", lambda: ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * d, pos, d, lens, dO, lse, dlt, dqu, dqv, B, H, T, dk, Tp32, scale, drop, ds_out=dS), 5 * pair)
+dS = ops.relpos_ds_buffer(B, H, T, dev, fill=0.0)
+t("bwd_dq", lambda: ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * d, pos, d, lens, dO, lse, dlt, dqu, dqv, B, H, T, dk, scale, drop, ds_out=dS), 5 * pair)
 t("bwd_dkv", lambda: ops.relpos_flash_bwd_dkv(qu, qv, qkv, 3 * d, pos, d, lens, dO, lse, dlt, dqkv, 3 * d, B, H, T, dk, Tp, scale, drop), 5 * pair)
-t("bwd_dpos", lambda: ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk, Tp32), 1 * pair)
+t("bwd_dpos", lambda: ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk), 1 * pair)
