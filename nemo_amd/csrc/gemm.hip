@@ -56,10 +56,17 @@ struct GemmP {
   // implicit-GEMM convolution (channels-last): A row m = (b, i, j) on an [nI x nJ] grid gathers, for K index tap*C + c,
   // src[b][i*si + di[tap]][j*sj + dj[tap]][c] of a [SI x SJ x C] source grid (zero outside)
   int g_on, g_nI, g_nJ, g_SI, g_SJ, g_C, g_si, g_sj, g_ntaps;
-  signed char g_di[12], g_dj[12];
+  // tap offsets, 4 bits per tap biased by 8 (|d| <= 7, <= 9 taps): decoded with scalar shifts.  (A byte table indexed by the
+  // K-tile's tap compiled to a VECTOR byte load of the kernel arguments + `s_waitcnt vmcnt(0)` inside the K loop -- which also
+  // waited for every LDS-DMA in flight: the conv2 loops ran without any prefetch overlap.)
+  unsigned long long g_dip, g_djp;
   // output row map: C / aux row of m = (b, i, j) is ((b*OI + i*si + oi)*OJ + j*sj + oj)
   int r_on, r_nI, r_nJ, r_OI, r_OJ, r_si, r_sj, r_oi, r_oj;
 };
+
+__device__ __forceinline__ int tap_delta(unsigned long long packed, int tap) {  // tap must be wave-uniform
+  return (int)((packed >> (__builtin_amdgcn_readfirstlane(tap) * 4)) & 15ull) - 8;
+}
 
 // storage row (C / aux) of logical row m
 __device__ __forceinline__ long long crow(const GemmP& p, int m) {
@@ -585,7 +592,7 @@ __device__ __forceinline__ void gather_issue(const DmaGather<R>& g, const GemmP&
   const int wave = threadIdx.x >> 6;
   const int k0 = kt * BK;
   const int tap = k0 / p.g_C, c0 = k0 - tap * p.g_C;  // uniform; C % 64 == 0 keeps a K-tile inside one tap
-  const int di = p.g_di[tap], dj = p.g_dj[tap];
+  const int di = tap_delta(p.g_dip, tap), dj = tap_delta(p.g_djp, tap);
   const long long toff = ((long long)di * p.g_SJ + dj) * p.g_C + c0;
 #pragma unroll
   for (int i = 0; i < DmaGather<R>::PER; ++i) {
@@ -630,7 +637,7 @@ template <int R>
 __device__ __forceinline__ void gatherT_issue(DmaGatherT<R>& g, const GemmP& p, const bf16_t* base, int tap,
                                               bf16_t* lds_tile) {
   const int wave = threadIdx.x >> 6;
-  const int di = p.g_di[tap], dj = p.g_dj[tap];
+  const int di = tap_delta(p.g_dip, tap), dj = tap_delta(p.g_djp, tap);
   const int toff = (di * p.g_SJ + dj) * p.g_C;                                   // uniform
   const int step_j = BK * p.g_sj * p.g_C;                                        // one K-tile = 64 positions further
   const int wrap_j = p.g_si * p.g_SJ * p.g_C - p.g_nJ * p.g_sj * p.g_C;          // j -= nJ, i += 1
@@ -679,6 +686,40 @@ __device__ __forceinline__ bf16x8 frag_v2(const bf16_t* tile, int row_tile, int 
     }
     return u.v;
   }
+}
+
+// ---- transpose reads by inline asm, for the loops whose operands are BOTH reduction-major (weight gradients).
+// hipcc puts `s_waitcnt vmcnt(0)` in front of a ds_read_b64_tr_b16 it emits itself whenever an LDS-DMA is in flight (it
+// cannot tell the stages apart), i.e. right after the prefetch of the next K-tiles has been issued: the counted vmcnt of
+// these loops never got to do its job and every K-tile paid a full memory latency.  Issued by hand the reads carry no such
+// wait; the price is that the compiler does not know when their destinations land -- every use sits behind an inline
+// `s_waitcnt lgkmcnt` that names the registers ("+v"), and tools/check_asm_loads.py lints the ISA for stray copies.
+typedef __attribute__((address_space(3))) const char lds_cchar_t;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_cchar_t*)p; }
+union FragU { bf16x8 v; s16x4 h[2]; };
+template <int OFF>
+__device__ __forceinline__ void tr_rd(s16x4& dst, uint32_t addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
+}
+// LDS byte address of the (kk = 0, r = 0) read of frag_v2<true, R>(tile, row_tile, ...): the swizzle term depends on
+// krow & 3 = (lane & 15) >> 2 only, so k-step kk / half r are the compile-time offset (kk * 16 + r * 4) * R * 2
+template <int R>
+__device__ __forceinline__ uint32_t tr_base(const bf16_t* tile, int row_tile, int lane) {
+  const int t = lane & 15, g4 = (lane >> 4) & 1, lh = lane >> 5;
+  const int col = row_tile + g4 * 16 + (t & 3) * 4;
+  const int krow = lh * 8 + (t >> 2);
+  return lds_addr(tile) + (uint32_t)((krow * R + ((((col >> 3) ^ ((t >> 2) << 2))) << 3) + (col & 7)) * 2);
+}
+template <int R, int KK>
+__device__ __forceinline__ void tr_frag_rd(FragU& f, uint32_t base) {
+  tr_rd<(KK * 16) * R * 2>(f.h[0], base);
+  tr_rd<(KK * 16 + 4) * R * 2>(f.h[1], base);
+}
+// bias-gradient read of the staged A tile (8 bytes), self-contained (issue + wait)
+__device__ __forceinline__ u32x2 lds_rd64_sync(uint32_t addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
 }
 
 // body of the 256x128 structure: workgroup `bid` of the problem's tile grid, K slice `kslice`, batch index `z`
@@ -762,16 +803,24 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
   //   B  read the second half of tile it -> F[2..3]          C  MFMAs of F[0..1]
   //   D  my share of tile it+1 has landed (counted vmcnt), my reads are done (lgkmcnt 0), barrier -> tile it+1 visible
   //   E  read the first half of tile it+1 -> F[0..1]         F  MFMAs of F[2..3]
-  bf16x8 af[4][2], bfr[4][2];
-  auto read_half = [&](const bf16_t* a_s, const bf16_t* b_s, const int h) {
+  FragU af[4][2], bfr[4][2];
+  uint32_t abase[2], bbase[2];  // per-lane read addresses in stage 0 (inline-asm reads: see tr_rd)
 #pragma unroll
-    for (int kk = 2 * h; kk < 2 * h + 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[kk][i] = frag_v2<TA, BM2>(a_s, wm * 64 + i * 32, kk, lane);
-        bfr[kk][i] = frag_v2<TB, BN>(b_s, wn * 64 + i * 32, kk, lane);
-      }
-  };
+  for (int i = 0; i < 2; ++i) {
+    abase[i] = tr_base<BM2>(smem2, wm * 64 + i * 32, lane);
+    bbase[i] = tr_base<BN>(smem2 + BM2 * BK, wn * 64 + i * 32, lane);
+  }
+#define V2_RD_HALF(SB, K0, K1)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                  \
+    tr_frag_rd<BM2, K0>(af[K0][i], abase[i] + (SB)); tr_frag_rd<BN, K0>(bfr[K0][i], bbase[i] + (SB)); \
+    tr_frag_rd<BM2, K1>(af[K1][i], abase[i] + (SB)); tr_frag_rd<BN, K1>(bfr[K1][i], bbase[i] + (SB)); \
+  }
+#define V2_WAIT_HALF(K0, K1)                                                                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                          \
+               : "+v"(af[K0][0].v), "+v"(af[K0][1].v), "+v"(bfr[K0][0].v), "+v"(bfr[K0][1].v), "+v"(af[K1][0].v), \
+                 "+v"(af[K1][1].v), "+v"(bfr[K1][0].v), "+v"(bfr[K1][1].v)                                      \
+               :                                                                                               \
+               : "memory")
   auto mfma_half = [&](const int h) {
 #pragma unroll
     for (int kk = 2 * h; kk < 2 * h + 2; ++kk)
@@ -779,29 +828,30 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i].v, bfr[kk][j].v, acc[i][j], 0, 0, 0);
   };
   if (nk > 0) {
     issue(0);
     if (nk > 1) issue(1);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    read_half(smem2, smem2 + BM2 * BK, 0);
+    V2_RD_HALF(0u, 0, 1);
+    V2_WAIT_HALF(0, 1);
   }
   for (int it = 0; it < nk; ++it) {
     if (it + 2 < nk) issue(it + 2);
-    const bf16_t* a_s = smem2 + (it % 3) * NT2_STAGE;
-    const bf16_t* b_s = a_s + BM2 * BK;
+    const uint32_t sb = (uint32_t)((it % 3) * (NT2_STAGE * 2));
     __builtin_amdgcn_sched_barrier(0);
-    read_half(a_s, b_s, 1);
+    V2_RD_HALF(sb, 2, 3);
     __builtin_amdgcn_sched_barrier(0);  // keep the burst ahead of the MFMAs: the scheduler would sink the reads to their uses
     mfma_half(0);
     if (TA && do_colsum) {  // thread -> (k-group of 8 rows = wave, 4 consecutive columns = lane): 8 x ds_read_b64
       const int col = lane * 4;
+      const uint32_t a_addr = lds_addr(smem2) + sb;
       for (int kr = tile_n; kr < 8; kr += cs_step) {
         const int krow = wave * 8 + kr;
         const int off = krow * BM2 + (((col >> 3) ^ ((krow & 3) << 2)) << 3) + (col & 7);
-        const u32x2 v = *reinterpret_cast<const u32x2*>(a_s + off);
+        const u32x2 v = lds_rd64_sync(a_addr + (uint32_t)(off * 2));
         csum[0] += __uint_as_float(v[0] << 16); csum[1] += __uint_as_float(v[0] & 0xffff0000u);
         csum[2] += __uint_as_float(v[1] << 16); csum[3] += __uint_as_float(v[1] & 0xffff0000u);
       }
@@ -809,15 +859,18 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
     __builtin_amdgcn_sched_barrier(0);
     // tile it+1 must have landed (this wave's share) before the barrier publishes it; tile it+2 may stay in flight
     if (it + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    V2_WAIT_HALF(2, 3);
     __builtin_amdgcn_s_barrier();
-    if (it + 1 < nk) {
-      const bf16_t* a_n = smem2 + ((it + 1) % 3) * NT2_STAGE;
-      read_half(a_n, a_n + BM2 * BK, 0);
-    }
+    // first half of tile it+1 (after the last tile: a harmless read of an idle stage -- an unconditional issue site keeps the
+    // compiler from merging the destinations through copies)
+    V2_RD_HALF((uint32_t)(((it + 1) % 3) * (NT2_STAGE * 2)), 0, 1);
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(1);
+    __builtin_amdgcn_sched_barrier(0);  // (the wait is no scheduling barrier for the MFMAs: it would be hoisted above them)
+    V2_WAIT_HALF(0, 1);  // landed under the 8 MFMAs above; nothing asm-loaded is in flight across the back edge
   }
+#undef V2_RD_HALF
+#undef V2_WAIT_HALF
 
   } else {
 #ifdef GEMM_ABLATE
@@ -1149,6 +1202,56 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  if constexpr (TA && TB) {
+  // both operands reduction-major: transpose reads by inline asm (see tr_rd), one k-step ahead of the MFMAs
+  FragU fa[2][4], fb[2][2];
+  uint32_t abase[4], bbase[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) abase[i] = tr_base<BM2>(smem4, wm * 128 + i * 32, lane);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bbase[j] = tr_base<BN4>(smem4 + BM2 * BK, wn * 64 + j * 32, lane);
+#define V4_RD(S, KK)                                                                              \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) tr_frag_rd<BN4, KK>(fb[S][j], bbase[j] + sb);     \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) tr_frag_rd<BM2, KK>(fa[S][i], abase[i] + sb)
+#define V4_WAIT(N, S)                                                                                          \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                     \
+               : "+v"(fa[S][0].v), "+v"(fa[S][1].v), "+v"(fa[S][2].v), "+v"(fa[S][3].v), "+v"(fb[S][0].v),     \
+                 "+v"(fb[S][1].v)                                                                              \
+               :                                                                                               \
+               : "memory");                                                                                    \
+  __builtin_amdgcn_sched_barrier(0)
+#define V4_MM(S)                                                                                               \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                  \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i].v, fb[S][j].v, acc[i][j], 0, 0, 0);         \
+  __builtin_amdgcn_sched_barrier(0)
+  for (int it = 0; it < nk; ++it) {
+    if (it + 1 < nk) issue(it + 1);  // other stage: every wave passed the barrier after its last read of it
+    const uint32_t sb = (uint32_t)((it & 1) * (NT4_STAGE * 2));
+    __builtin_amdgcn_sched_barrier(0);
+    V4_RD(0, 0);
+    V4_RD(1, 1); V4_WAIT(12, 0); V4_MM(0);
+    V4_RD(0, 2); V4_WAIT(12, 1); V4_MM(1);
+    V4_RD(1, 3); V4_WAIT(12, 0); V4_MM(0);
+    V4_WAIT(0, 1); V4_MM(1);
+    if (do_colsum) {  // thread -> (k-group of 8 rows = wave, 4 consecutive columns = lane)
+      const int col = lane * 4;
+      const uint32_t a_addr = lds_addr(smem4) + sb;
+      for (int kr = tile_n; kr < 8; kr += cs_step) {
+        const int krow = wave * 8 + kr;
+        const int off = krow * BM2 + (((col >> 3) ^ ((krow & 3) << 2)) << 3) + (col & 7);
+        const u32x2 v = lds_rd64_sync(a_addr + (uint32_t)(off * 2));
+        csum[0] += __uint_as_float(v[0] << 16); csum[1] += __uint_as_float(v[0] & 0xffff0000u);
+        csum[2] += __uint_as_float(v[1] << 16); csum[3] += __uint_as_float(v[1] & 0xffff0000u);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#undef V4_RD
+#undef V4_WAIT
+#undef V4_MM
+  } else {
   for (int it = 0; it < nk; ++it) {
     if (it + 1 < nk) issue(it + 1);  // other stage: every wave passed the barrier after its last read of it
     const bf16_t* a_s = smem4 + (it & 1) * NT4_STAGE;
@@ -1182,6 +1285,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+  }
+
   }
 
   float* sC = reinterpret_cast<float*>(smem4);
@@ -1682,7 +1787,12 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
     }
     p.g_on = 1 + g.operand; p.g_nI = g.nI; p.g_nJ = g.nJ; p.g_SI = g.SI; p.g_SJ = g.SJ; p.g_C = g.C; p.g_si = g.si; p.g_sj = g.sj;
     p.g_ntaps = g.ntaps;
-    for (int t = 0; t < g.ntaps; ++t) { p.g_di[t] = (signed char)g.di[t]; p.g_dj[t] = (signed char)g.dj[t]; }
+    p.g_dip = 0ull; p.g_djp = 0ull;
+    for (int t = 0; t < g.ntaps; ++t) {
+      if (g.di[t] < -7 || g.di[t] > 7 || g.dj[t] < -7 || g.dj[t] > 7) return MI_ERR_ARG;
+      p.g_dip |= (unsigned long long)(g.di[t] + 8) << (4 * t);
+      p.g_djp |= (unsigned long long)(g.dj[t] + 8) << (4 * t);
+    }
   }
   if (d->rowmap) {
     const mi355x_row_map& r = *d->rowmap;

@@ -3,7 +3,7 @@
 hipcc treats the destination of an inline-asm load as valid at the end of the asm statement (it does not model the load), so
 nothing may READ or WRITE that register between the load and the inline-asm `s_waitcnt` that covers it -- a compiler-made
 copy in that window moves stale data and leaves a register the load overwrites later (memory faults, wrong tiles).
-This checks every `ds_read_b128` / `ds_read_b64` / `global_load_dwordx4 v[..]` that sits inside an ASMSTART/ASMEND pair:
+This checks every `ds_read_b128` / `ds_read_b64` / `ds_read_b64_tr_b16` / `global_load_dwordx4 v[..]` that sits inside an ASMSTART/ASMEND pair:
 until the next inline-asm s_waitcnt of the matching counter, no other instruction mentions its destination registers.
 
     hipcc --offload-arch=gfx950 -O3 ... -S --cuda-device-only nemo_amd/csrc/gemm.hip -o gemm.s && python tools/check_asm_loads.py gemm.s
@@ -49,10 +49,14 @@ def main(path):
             if "vmcnt" in t:
                 pending = [p for p in pending if p[0] != "vm"]
             continue
-        if in_asm and op in ("ds_read_b128", "ds_read_b64", "global_load_dwordx4"):
+        if in_asm and op in ("ds_read_b128", "ds_read_b64", "ds_read_b64_tr_b16", "global_load_dwordx4"):
             if op == "global_load_dwordx4" and "lds" in t:
                 continue
             dst = regs(t.split()[1].rstrip(","))
+            srcs = all_vregs(t.split(",", 1)[1]) if "," in t else set()
+            for cnt, d0, ln, txt in pending:  # an address register that is itself the destination of an un-waited load
+                if srcs & d0:
+                    bad.append((i + 1, t, ln, txt))
             pending.append(("lgkm" if op.startswith("ds_") else "vm", dst, i + 1, t))
             checked += 1
             continue
