@@ -26,11 +26,34 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
+typedef __attribute__((address_space(3))) const char lds_cchar_t;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_cchar_t*)p; }
+
+// LDS-DMA by inline asm.  Behind a `__builtin_amdgcn_global_load_lds` hipcc puts `s_waitcnt vmcnt(0)` in front of LDS reads
+// it cannot tell apart from the DMA's target (transpose reads, merged reads, ...): a prefetch issued at the top of a step was
+// waited for at the step's first such read.  Issued by hand the compiler knows nothing about the transfer; every consumer in
+// this file sits behind an explicit `s_waitcnt vmcnt` + barrier anyway.  lds_base must be wave-uniform (lane i lands at
+// lds_base + 16 i).  M0 is not used by anything else in this translation unit.
+__device__ __forceinline__ void dma16(const void* src, const void* lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr(lds_base)))
+               : "memory");
+}
+
+__device__ __forceinline__ void dma4(const void* src, const void* lds_base) {  // lane i lands at lds_base + 4 i
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+               :
+               : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr(lds_base)))
+               : "memory");
+}
+
 #define ADK 64           // head dim
 #define ABQ 128          // queries per workgroup (4 waves x 32)
 #define ABK 32           // keys per step
 #define ABAND (ABQ + ABK)  // positional band rows staged per step (159 needed)
 #define SG_LD 66
+#define APRING 6         // positional-band ring: blocks of 32 rows (5 in use + 1 being staged)
 
 // Dropout of attention probabilities: keep(b,h,i,j) from full-rate integer ops only (v_mul_u32_u24, shifts, xors) so that
 // it costs the same whether a lane walks keys (forward / dQ: lane = query) or queries (dK/dV: lane = key).  `akey` is a
@@ -86,7 +109,7 @@ __device__ __forceinline__ void stage_rows(const bf16_t* base, long long ld, int
       // 64-bit sequence (2 quarter-rate v_mul_lo_u32 + v_mad_u64_u32) per address
       const bf16_t* src = base + __mul24(gr, (int)ld) + gck * 8;
       bf16_t* dst = lds + (q0 + wave * 64) * 8;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+      dma16(src, dst);
     }
   }
 }
@@ -100,7 +123,7 @@ __device__ __forceinline__ void stage_v(const bf16_t* base, long long ld, int ro
   gr = gr > rmax ? rmax : gr;
   const bf16_t* src = base + __mul24(gr, (int)ld) + c * 8;
   bf16_t* dst = lds + (wave * 64) * 8;
-  __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+  dma16(src, dst);
 }
 // A fragment of V^T for the P.V product: lane (dv = dv0 + (lane&31)) gets V[key slots of (s, half)][dv]
 __device__ __forceinline__ bf16x8 vt_frag(const bf16_t* vt, int dv0, int s, int lane) {
@@ -149,14 +172,14 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
                                                                   const long long* __restrict__ len, bf16_t* __restrict__ ctx,
                                                                   long long ldo, float* __restrict__ lse, int B, int H, int T,
                                                                   int Tp, float scale, DropCfg drop) {
-  __shared__ __attribute__((aligned(16))) bf16_t s_k[ABK * ADK];       // 4 KiB
-  __shared__ __attribute__((aligned(16))) bf16_t s_v[ABK * ADK];       // 4 KiB
-  __shared__ __attribute__((aligned(16))) bf16_t s_p[ABAND * ADK];     // 20 KiB
+  __shared__ __attribute__((aligned(16))) bf16_t s_k2[2][ABK * ADK];   // 2 x 4 KiB (double-buffered)
+  __shared__ __attribute__((aligned(16))) bf16_t s_v2[2][ABK * ADK];   // 2 x 4 KiB
+  __shared__ __attribute__((aligned(16))) bf16_t s_p[APRING * 32 * ADK];  // 24 KiB: ring of 6 blocks of 32 band rows
   __shared__ __attribute__((aligned(16))) float s_g[4][32 * SG_LD];    // 33 KiB
 
   const int b = blockIdx.z, h = blockIdx.y;
   const int i0_blk = blockIdx.x * ABQ;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane & 31, lh = lane >> 5;
   const int i = i0_blk + wave * 32 + q;  // this lane's query
   const int L = (int)min((long long)T, len[b]);
@@ -181,28 +204,41 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
   const uint32_t arow = akey ^ adrop_rcode((uint32_t)i >> 2), erow = (uint32_t)(i & 3) * (4u * ADROP_G);
 
   const int nkt = (L + ABK - 1) / ABK;  // key tiles that contain at least one valid key
+  // The positional band of step kt is rows c0 + 32*kt .. +159; consecutive steps share four of their five 32-row blocks, so
+  // the band lives in a ring of six blocks (block g -> slot g % 6) and a step stages ONE new block (4 KiB instead of 20).
+  // K / V tiles are double-buffered.  Everything a step needs is issued one step ahead (dma16: inline-asm LDS-DMA, so that the
+  // compiler does not wait for it in front of the step's own LDS reads), behind a single barrier per step.
+  const int c0 = T - 1 - (i0_blk + ABQ - 1);
+  if (nkt > 0) {
+    stage_rows(kbase, ldq, 0, T - 1, s_k2[0], ABK * 8);
+    stage_v(vbase, ldq, 0, T - 1, s_v2[0]);
+    stage_rows(pbase, ldp, c0, P - 1, s_p, ABAND * 8);
+  }
   for (int kt = 0; kt < nkt; ++kt) {
     const int j0 = kt * ABK;
-    __syncthreads();  // previous step's LDS reads are done
-    stage_rows(kbase, ldq, j0, T - 1, s_k, ABK * 8);
-    stage_v(vbase, ldq, j0, T - 1, s_v);
-    const int c_base = T - 1 + j0 - (i0_blk + ABQ - 1);  // band row of local row 0
-    stage_rows(pbase, ldp, c_base, P - 1, s_p, ABAND * 8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();  // tile kt has landed; every wave is done reading tile kt-1
+    if (kt + 1 < nkt) {
+      stage_rows(kbase, ldq, j0 + ABK, T - 1, s_k2[(kt + 1) & 1], ABK * 8);
+      stage_v(vbase, ldq, j0 + ABK, T - 1, s_v2[(kt + 1) & 1]);
+      stage_rows(pbase, ldp, c0 + 32 * (kt + 5), P - 1, s_p + ((kt + 5) % APRING) * (32 * ADK), 32 * 8);
+    }
+    const bf16_t* s_k = s_k2[kt & 1];
+    const bf16_t* s_v = s_v2[kt & 1];
+    // ring slots of this wave's two band blocks (blocks kt + 3 - wave + gt)
+    const int slot0 = (kt + 3 - wave) % APRING, slot1 = (kt + 4 - wave) % APRING;
 
     // ---- S^T = K . Qu^T  and  G^T = P_band . Qv^T
     f32x16 acc_s, acc_g[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc_s[r] = 0.f; acc_g[0][r] = 0.f; acc_g[1][r] = 0.f; }
-    const int prow0 = (ABQ - 32) - 32 * wave;  // local band row of this wave's c_min
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s_k + a_off(q, kk * 2 + lh));
       acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[kk], acc_s, 0, 0, 0);
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) {
-        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off(prow0 + 32 * gt + q, kk * 2 + lh));
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off((gt ? slot1 : slot0) * 32 + q, kk * 2 + lh));
         acc_g[gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qv[kk], acc_g[gt], 0, 0, 0);
       }
     }
@@ -337,9 +373,9 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqu_out,
     bf16_t* __restrict__ dqv_out, bf16_t* __restrict__ ds_out, int B, int H, int T, int d, float scale,
     DropCfg drop) {
-  __shared__ __attribute__((aligned(16))) bf16_t s_k[ABK * ADK];
-  __shared__ __attribute__((aligned(16))) bf16_t s_v[ABK * ADK];
-  __shared__ __attribute__((aligned(16))) bf16_t s_p[ABAND * ADK];
+  __shared__ __attribute__((aligned(16))) bf16_t s_k2[2][ABK * ADK];       // double-buffered (read until the end of a step)
+  __shared__ __attribute__((aligned(16))) bf16_t s_v[ABK * ADK];           // read in the first MFMA block only
+  __shared__ __attribute__((aligned(16))) bf16_t s_p[APRING * 32 * ADK];   // positional band: ring of 32-row blocks (see forward)
   __shared__ __attribute__((aligned(16))) float s_g[4][32 * SG_LD];
   __shared__ __attribute__((aligned(16))) bf16_t s_carry[4][32 * 32];  // upper half of the previous step's band, per wave
 
@@ -361,8 +397,12 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   load_rows(qu_g + rowi * d + h * ADK, qu, i < T, lh);
   load_rows(qv_g + rowi * d + h * ADK, qv, i < T, lh);
   load_rows(dO + rowi * d + h * ADK, dof, i < T, lh);
-  const float lse_i = qvalid ? lse[((long long)b * H + h) * T + i] : 0.f;
-  const float dlt_i = qvalid ? delta[((long long)b * H + h) * T + i] : 0.f;
+  float lse_i = qvalid ? lse[((long long)b * H + h) * T + i] : 0.f;
+  float dlt_i = qvalid ? delta[((long long)b * H + h) * T + i] : 0.f;
+  // (the compiler must wait for these register loads HERE, not at their first use inside the loop: see the dK/dV kernel)
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) { asm volatile("" : "+v"(qu[kk])); asm volatile("" : "+v"(qv[kk])); asm volatile("" : "+v"(dof[kk])); }
+  asm volatile("" : "+v"(lse_i), "+v"(dlt_i));
 
   f32x16 dqu[2], dqv[2];
 #pragma unroll
@@ -370,7 +410,6 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   float* sg = s_g[wave];
   const uint32_t akey = attn_key(drop, b, h);
   const uint32_t arow = akey ^ adrop_rcode((uint32_t)i >> 2), erow = (uint32_t)(i & 3) * (4u * ADROP_G);
-  const int prow0 = (ABQ - 32) - 32 * wave;
 
   const int nkt = (L + ABK - 1) / ABK;
   // linear_pos gradient operand (see the end of the loop): tile `itile` of (h, b) owns nT+1 blocks of 32 x 32 bf16
@@ -379,15 +418,24 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   bf16_t* xbase = ds_out + ((((long long)h * B + b) * nT + itile) * (nT + 1)) * 1024;
   u32x4* carry = reinterpret_cast<u32x4*>(s_carry[wave]);
   if (xw) { carry[lane] = (u32x4){0u, 0u, 0u, 0u}; carry[64 + lane] = (u32x4){0u, 0u, 0u, 0u}; }
+  // prefetch structure of the forward kernel: K double-buffered and the band's new block one step ahead; V (read in the first
+  // MFMA block only) is re-staged into its single buffer behind a second barrier as soon as every wave has read it
+  const int c0 = T - 1 - (i0_blk + ABQ - 1);
+  if (nkt > 0) {
+    stage_rows(kbase, ldq, 0, T - 1, s_k2[0], ABK * 8);
+    stage_rows(vbase, ldq, 0, T - 1, s_v, ABK * 8);
+    stage_rows(pbase, ldp, c0, P - 1, s_p, ABAND * 8);
+  }
   for (int kt = 0; kt < nkt; ++kt) {
     const int j0 = kt * ABK;
-    __syncthreads();
-    stage_rows(kbase, ldq, j0, T - 1, s_k, ABK * 8);
-    stage_rows(vbase, ldq, j0, T - 1, s_v, ABK * 8);
-    const int c_base = T - 1 + j0 - (i0_blk + ABQ - 1);
-    stage_rows(pbase, ldp, c_base, P - 1, s_p, ABAND * 8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();  // tile kt has landed; every wave is done with step kt-1
+    if (kt + 1 < nkt) {
+      stage_rows(kbase, ldq, j0 + ABK, T - 1, s_k2[(kt + 1) & 1], ABK * 8);
+      stage_rows(pbase, ldp, c0 + 32 * (kt + 5), P - 1, s_p + ((kt + 5) % APRING) * (32 * ADK), 32 * 8);
+    }
+    const bf16_t* s_k = s_k2[kt & 1];
+    const int slot0 = (kt + 3 - wave) % APRING, slot1 = (kt + 4 - wave) % APRING;  // this wave's two band blocks
 
     f32x16 acc_s, acc_g[2], acc_dp;
 #pragma unroll
@@ -400,9 +448,13 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
       acc_dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], acc_dp, 0, 0, 0);  // dP^T[key][query] = V . dO^T
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) {
-        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off(prow0 + 32 * gt + q, kk * 2 + lh));
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off((gt ? slot1 : slot0) * 32 + q, kk * 2 + lh));
         acc_g[gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qv[kk], acc_g[gt], 0, 0, 0);
       }
+    }
+    if (kt + 1 < nkt) {  // (block-uniform)
+      __syncthreads();   // every wave has its V fragments
+      stage_rows(vbase, ldq, j0 + ABK, T - 1, s_v, ABK * 8);
     }
 #pragma unroll
     for (int gt = 0; gt < 2; ++gt)
@@ -458,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
       const bf16x8 gb = pack8(gv);
 #pragma unroll
       for (int dkt = 0; dkt < 2; ++dkt) {
-        const int ra = prow0 + 16 * s4 + 8 * lh;
+        const int ra = (s4 < 2 ? slot0 : slot1) * 32 + 16 * (s4 & 1) + 8 * lh;
         const bf16x8 pt_f = tr_frag(s_p, ra, ra + 4, dkt * 32, lane);
         dqv[dkt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pt_f, gb, dqv[dkt], 0, 0, 0);
       }
@@ -525,16 +577,18 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
     const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqkv, long long ldd, int B, int H,
     int T, int Tp, int d, float scale, DropCfg drop) {
-  __shared__ __attribute__((aligned(16))) bf16_t s_qu[32 * ADK];
-  __shared__ __attribute__((aligned(16))) bf16_t s_qv[32 * ADK];
-  __shared__ __attribute__((aligned(16))) bf16_t s_do[32 * ADK];
-  __shared__ __attribute__((aligned(16))) bf16_t s_p[ABAND * ADK];
-  __shared__ float s_lse[32], s_dlt[32];
-  __shared__ __attribute__((aligned(16))) float s_t[4][32 * SG_LD];
+  // staging (double-buffered query tiles + the positional band as a ring of 32-row blocks, see the forward kernel) and the
+  // output transposition tile share one buffer: the latter is only used after the loop
+  constexpr int STAGE_BYTES = 2 * 3 * 32 * ADK * 2 + APRING * 32 * ADK * 2 + 2 * 2 * 32 * 4;  // 24 + 24 + 0.5 KiB
+  constexpr int OUT_BYTES = 4 * 32 * SG_LD * 4;
+  __shared__ __attribute__((aligned(16))) char s_raw[STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES];
+  bf16_t* const s_q3 = reinterpret_cast<bf16_t*>(s_raw);                                 // [2][qu | qv | dO][32 * ADK]
+  bf16_t* const s_p = reinterpret_cast<bf16_t*>(s_raw + 2 * 3 * 32 * ADK * 2);          // [APRING * 32][ADK]
+  float* const s_ld = reinterpret_cast<float*>(s_raw + 2 * 3 * 32 * ADK * 2 + APRING * 32 * ADK * 2);  // [2][lse | delta][32]
 
   const int b = blockIdx.z, h = blockIdx.y;
   const int j0_blk = blockIdx.x * ABQ;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane & 31, lh = lane >> 5;
   const int j = j0_blk + wave * 32 + q;  // this lane's key
   const int L = (int)min((long long)T, len[b]);
@@ -550,26 +604,51 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   load_rows(kbase + rowj * ldq, kf, j < T, lh);
   load_rows(kbase + (ldq / 3) + rowj * ldq, vf, j < T, lh);
 
+  // (the compiler must wait for these register loads HERE: inside the loop its `s_waitcnt vmcnt(0)` at their first use would
+  //  also wait, every step, for the prefetch it knows nothing about)
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) { asm volatile("" : "+v"(kf[kk])); asm volatile("" : "+v"(vf[kk])); }
   f32x16 dk_acc[2], dv_acc[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk_acc[0][r] = 0.f; dk_acc[1][r] = 0.f; dv_acc[0][r] = 0.f; dv_acc[1][r] = 0.f; }
 
   const int nqt = (L + 31) / 32;
+  const bf16_t* qub = qu_g + ((long long)b * T) * d + h * ADK;
+  const bf16_t* qvb = qv_g + ((long long)b * T) * d + h * ADK;
+  const bf16_t* dob = dO + ((long long)b * T) * d + h * ADK;
+  // band rows of step qt: cb0 - 32*qt .. +159 (blocks -qt .. -qt+4 of 32 rows, block g in ring slot (g mod 6)); the step after
+  // needs ONE new block at the low end.  Query tiles (Qu, Qv, dO) and their lse / delta (wave 0: lanes 0-31 | 32-63, 4 bytes
+  // each) are double-buffered.
+  const int cb0 = T - 1 + j0_blk - 31;
+  auto stage_q = [&](int i0, int buf) {
+    bf16_t* dst = s_q3 + buf * (3 * 32 * ADK);
+    stage_rows(qub, d, i0, T - 1, dst, 32 * 8);
+    stage_rows(qvb, d, i0, T - 1, dst + 32 * ADK, 32 * 8);
+    stage_rows(dob, d, i0, T - 1, dst + 2 * 32 * ADK, 32 * 8);
+    if (wave == 0) {
+      int ii = i0 + (lane & 31);
+      ii = ii < T ? ii : T - 1;  // (rows >= len are never used: p = 0 there)
+      dma4((lane < 32 ? lse : delta) + ((long long)b * H + h) * T + ii, s_ld + buf * 64);
+    }
+  };
+  if (nqt > 0) {
+    stage_q(0, 0);
+    stage_rows(pbase, ldp, cb0, P - 1, s_p, ABAND * 8);
+  }
   for (int qt = 0; qt < nqt; ++qt) {
     const int i0 = qt * 32;
-    __syncthreads();
-    stage_rows(qu_g + ((long long)b * T) * d + h * ADK, d, i0, T - 1, s_qu, 32 * 8);
-    stage_rows(qv_g + ((long long)b * T) * d + h * ADK, d, i0, T - 1, s_qv, 32 * 8);
-    stage_rows(dO + ((long long)b * T) * d + h * ADK, d, i0, T - 1, s_do, 32 * 8);
-    const int c_base = T - 1 + j0_blk - i0 - 31;
-    stage_rows(pbase, ldp, c_base, P - 1, s_p, ABAND * 8);
-    if (threadIdx.x < 32) {
-      const int ii = i0 + threadIdx.x;
-      s_lse[threadIdx.x] = ii < L ? lse[((long long)b * H + h) * T + ii] : 0.f;
-      s_dlt[threadIdx.x] = ii < L ? delta[((long long)b * H + h) * T + ii] : 0.f;
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();  // tile qt has landed; every wave is done with step qt-1
+    if (qt + 1 < nqt) {
+      stage_q(i0 + 32, (qt + 1) & 1);
+      stage_rows(pbase, ldp, cb0 - 32 * (qt + 1), P - 1, s_p + ((6 * 1024 - (qt + 1)) % APRING) * (32 * ADK), 32 * 8);
+    }
+    const bf16_t* s_qu = s_q3 + (qt & 1) * (3 * 32 * ADK);
+    const bf16_t* s_qv = s_qu + 32 * ADK;
+    const bf16_t* s_do = s_qu + 2 * 32 * ADK;
+    const float* s_lse = s_ld + (qt & 1) * 64;
+    const float* s_dlt = s_lse + 32;
+    const int slot0 = (6 * 1024 - qt + wave) % APRING, slot1 = (6 * 1024 - qt + wave + 1) % APRING;  // band blocks wave, wave + 1
 
     f32x16 acc_s, acc_g[2], acc_dp;
 #pragma unroll
@@ -583,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
       const bf16x8 qvf = *reinterpret_cast<const bf16x8*>(s_qv + a_off(q, kk * 2 + lh));
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off(32 * wave + 32 * ct + q, kk * 2 + lh));
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off((ct ? slot1 : slot0) * 32 + q, kk * 2 + lh));
         acc_g[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qvf, pf, acc_g[ct], 0, 0, 0);  // G[query][c_local]
       }
     }
@@ -622,9 +701,10 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
       }
     }
   }
+  __syncthreads();  // the transposition tile below overlays the staging buffers
 
   // ---- write dK, dV rows of this wave's 32 keys
-  float* st_ = s_t[wave];
+  float* st_ = reinterpret_cast<float*>(s_raw) + wave * (32 * SG_LD);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -659,9 +739,6 @@ __device__ __forceinline__ bf16x8 tr_frag32(const bf16_t* img, int ra, int rb, i
   u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + (rb + (t >> 2)) * 32 + col));
   return u.v;
 }
-
-typedef __attribute__((address_space(3))) const char lds_cchar_t;
-__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_cchar_t*)p; }
 
 // d linear_pos output: dp[c, h, dk] += sum_{b,i} dS[b,h,i, j = c-(T-1)+i] * Qv[b,i,h,dk].  The dQ kernel leaves dS in the
 // UN-SHIFTED layout of the reference's matrix_bd before rel_shift (multi_head_attention.py:259-270), cut into blocks:
@@ -704,9 +781,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
     bf16_t* sqv = s_qv[wave][buf];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(base + sl0 * 1024 + k2 * 512 + lane * 8), (lds_void_t*)(sx + k2 * 512), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(base + sl1 * 1024 + k2 * 512 + lane * 8), (lds_void_t*)(sx + 1024 + k2 * 512),
-                                       16, 0, 0);
+      dma16((base + sl0 * 1024 + k2 * 512 + lane * 8), (sx + k2 * 512));
+      dma16((base + sl1 * 1024 + k2 * 512 + lane * 8), (sx + 1024 + k2 * 512));
     }
     const bf16_t* qb = qv_g + ((long long)b * T) * d + h * ADK;
 #pragma unroll
@@ -715,8 +791,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
       const int r = cq >> 3, ck = cq & 7;
       int gr = 32 * it + r;
       gr = gr > T - 1 ? T - 1 : gr;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(qb + __mul24(gr, d) + ((ck ^ ((r >> 1) & 7)) << 3)),
-                                       (lds_void_t*)(sqv + k4 * 512), 16, 0, 0);
+      dma16((qb + __mul24(gr, d) + ((ck ^ ((r >> 1) & 7)) << 3)), (sqv + k4 * 512));
     }
   };
   auto advance = [&](int& b, int& it, int steps) {  // steps <= 4 < npairs is not guaranteed: loop

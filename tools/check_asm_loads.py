@@ -49,7 +49,7 @@ def main(path):
             if "vmcnt" in t:
                 pending = [p for p in pending if p[0] != "vm"]
             continue
-        if in_asm and op in ("ds_read_b128", "ds_read_b64", "ds_read_b64_tr_b16", "global_load_dwordx4"):
+        if in_asm and op in ("ds_read_b128", "ds_read_b64", "ds_read_b32", "ds_read_b64_tr_b16", "global_load_dwordx4"):
             if op == "global_load_dwordx4" and "lds" in t:
                 continue
             dst = regs(t.split()[1].rstrip(","))
