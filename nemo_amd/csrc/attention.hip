@@ -250,13 +250,24 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float s[16];
     float mx = -INFINITY;
+    if (j0 + ABK <= L) {
+      // every key of the tile is valid (all tiles but the last): no masks.  Lanes of padded queries run on finite numbers
+      // and are discarded at the end (inv = 0, lse = 0).
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float bd = sg[q * SG_LD + rho + 31 - q];
-      const bool ok = qvalid && (j0 + rho) < L;
-      s[r] = ok ? (acc_s[r] + bd) * scale : -INFINITY;
-      mx = fmaxf(mx, s[r]);
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        s[r] = (acc_s[r] + sg[q * SG_LD + rho + 31 - q]) * scale;
+        mx = fmaxf(mx, s[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float bd = sg[q * SG_LD + rho + 31 - q];
+        const bool ok = qvalid && (j0 + rho) < L;
+        s[r] = ok ? (acc_s[r] + bd) * scale : -INFINITY;
+        mx = fmaxf(mx, s[r]);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -397,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   load_rows(qu_g + rowi * d + h * ADK, qu, i < T, lh);
   load_rows(qv_g + rowi * d + h * ADK, qv, i < T, lh);
   load_rows(dO + rowi * d + h * ADK, dof, i < T, lh);
-  float lse_i = qvalid ? lse[((long long)b * H + h) * T + i] : 0.f;
+  float lse_i = qvalid ? lse[((long long)b * H + h) * T + i] : 1e30f;  // padded query: exp(. - 1e30) = 0
   float dlt_i = qvalid ? delta[((long long)b * H + h) * T + i] : 0.f;
   // (the compiler must wait for these register loads HERE, not at their first use inside the loop: see the dK/dV kernel)
 #pragma unroll
@@ -462,12 +473,19 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
       for (int r = 0; r < 16; ++r) sg[q * SG_LD + 32 * gt + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc_g[gt][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float ds[16];
+    if (j0 + ABK <= L) {  // every key valid; padded queries carry lse_i = +1e30 -> P = 0 without a mask
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float bd = sg[q * SG_LD + rho + 31 - q];
-      const bool ok = qvalid && (j0 + rho) < L;
-      ds[r] = ok ? __expf((acc_s[r] + bd) * scale - lse_i) : 0.f;  // P[i, j]
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        ds[r] = __expf((acc_s[r] + sg[q * SG_LD + rho + 31 - q]) * scale - lse_i);  // P[i, j]
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float bd = sg[q * SG_LD + rho + 31 - q];
+        ds[r] = (j0 + rho) < L ? __expf((acc_s[r] + bd) * scale - lse_i) : 0.f;
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // dS = P * (dropmask * dP - delta) * scale
