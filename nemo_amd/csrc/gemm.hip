@@ -774,13 +774,20 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
   if (gatherB) gatherT_setup<BN>(gB, p, n0, p.N, kt0 * BK);
   else dma_setup<TB, BN>(dB, B, p.ldb, n0, p.N, kt0 * BK);
   const bool ktail = (p.K & (BK - 1)) != 0;
-  auto issue = [&](int it) {  // it = local tile index (issued in increasing order: the gathers advance incrementally)
+  // it = local tile index (issued in increasing order: the gathers advance incrementally).  (Measured: issuing the two
+  // operands separately BETWEEN the MFMA groups of the tile being multiplied, instead of as one block behind the K-tile
+  // barrier where all eight waves are in phase, is 2-6 % slower on every Conformer shape -- profiles/r2_gemm_structures.md 6.)
+  auto issue_a = [&](int it) {
     bf16_t* st = smem2 + (it % 3) * NT2_STAGE;
     if (gatherA) gather_issue<BM2>(gA, p, kt0 + it, st);
     else dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
+  };
+  auto issue_b = [&](int it) {
+    bf16_t* st = smem2 + (it % 3) * NT2_STAGE;
     if (gatherB) gatherT_issue<BN>(gB, p, (const bf16_t*)p.B, z0, st + BM2 * BK);
     else dma_issue<BN>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
+  auto issue = [&](int it) { issue_a(it); issue_b(it); };
   // bias gradient riding along with wgrad: column sums of the A tile, read back from LDS (8 B per lane per k-row group)
   // The tn workgroups of one (tile_m, K slice) stage the same A tile: its 64 k-rows are dealt round-robin to (up to 8 of)
   // them, so the column-sum work is spread evenly instead of making the tile_n == 0 workgroups the stragglers.
@@ -1187,13 +1194,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
   if constexpr (gatherB) gatherT_setup<BN4>(gB, p, n0, p.N, kt0 * BK);
   else dma_setup<TB, BN4>(dB, B, p.ldb, n0, p.N, kt0 * BK);
   const bool ktail = (p.K & (BK - 1)) != 0;
-  auto issue = [&](int it) {
+  auto issue_a = [&](int it) {
     bf16_t* st = smem4 + (it & 1) * NT4_STAGE;
     if constexpr (gatherA) gather_issue<BM2>(gA, p, kt0 + it, st);
     else dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
+  };
+  auto issue_b = [&](int it) {
+    bf16_t* st = smem4 + (it & 1) * NT4_STAGE;
     if constexpr (gatherB) gatherT_issue<BN4>(gB, p, (const bf16_t*)p.B, z0, st + BM2 * BK);
     else dma_issue<BN4>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
+  auto issue = [&](int it) { issue_a(it); issue_b(it); };
   const int cs_step = tn < 8 ? tn : 8;  // column-sum rows dealt round-robin to the workgroups sharing this A tile
   const bool do_colsum = TA && p.colsum_out != nullptr && tile_n < cs_step;
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1225,8 +1236,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i].v, fb[S][j].v, acc[i][j], 0, 0, 0);         \
   __builtin_amdgcn_sched_barrier(0)
   for (int it = 0; it < nk; ++it) {
-    if (it + 1 < nk) issue(it + 1);  // other stage: every wave passed the barrier after its last read of it
+    // tile it+1 goes to the other stage: every wave passed the barrier after its last read of it
     const uint32_t sb = (uint32_t)((it & 1) * (NT4_STAGE * 2));
+    if (it + 1 < nk) issue(it + 1);
     __builtin_amdgcn_sched_barrier(0);
     V4_RD(0, 0);
     V4_RD(1, 1); V4_WAIT(12, 0); V4_MM(0);
