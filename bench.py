@@ -28,8 +28,8 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", default="large", choices=["xs", "small", "sm", "medium", "ml", "large"])
     ap.add_argument("--model", default="ctc", choices=["ctc", "transducer", "squeezeformer"],
                     help="ctc = Conformer-CTC (BASELINE configs[1]/[2], the headline); transducer = FastConformer-Transducer "
