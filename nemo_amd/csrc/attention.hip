@@ -12,7 +12,9 @@
 //     wave-private LDS tile [32 queries][66] (stride 65 between lanes: conflict-free reads);
 //   * P^T is consumed as the MFMA B operand straight from the S^T accumulator registers (the k-slot <-> key mapping of
 //     an MFMA is arbitrary as long as A and B agree), V^T fragments come from ds_read_b64_tr_b16 on the [key][dv] tile.
-// K / V / P-band tiles are staged by LDS-DMA (global_load_lds_dwordx4).  62 KiB LDS -> two workgroups per CU.
+// K / V tiles (double-buffered) and the positional band (a ring of six 32-row blocks: consecutive key steps share four of
+// their five blocks, a step stages one new block) are staged one step ahead by inline-asm LDS-DMA (dma16) behind a single
+// barrier per step.  73-77 KiB LDS -> two workgroups per CU.
 //
 // Replaces on the reference path: RelPositionMultiHeadAttention.forward + MultiHeadAttention.forward_attention
 //   (nemo/collections/asr/parts/submodules/multi_head_attention.py:272-354, 124-146): two batched matmuls, pad/view/slice
