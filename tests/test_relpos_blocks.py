@@ -120,11 +120,14 @@ def test_dq_kernel_writes_the_unshifted_blocks(T):
     assert np.all(np.isfinite(X[w])), "a block the gradient kernel reads was not written"
     assert np.all(np.isnan(X[~w])), "blocks past ceil(len/32) are never touched"
     err = np.linalg.norm(X[w] - X_ref[w]) / np.linalg.norm(X_ref[w])
-    assert err < 1e-2, err  # (bf16 storage of dS: ~3e-3)
+    print(f"[relpos blocks T={T}] dS blocks vs autograd: relative L2 error {err:.2e}")
+    assert err < 5e-3, err  # (measured 1.7e-3: bf16 storage of dS)
     # and the gradient kernel agrees with the plain product on the kernel's own blocks
     dp = torch.zeros(2 * T - 1, d, device=dev)
     o.relpos_flash_bwd_dpos(qv_d, dS, lens_d, dp, B, H, T, dk)
     torch.cuda.synchronize()
     want = RB.dpos_from_blocks(np.where(w, X, 0.0), written, qv.numpy(), T).reshape(2 * T - 1, d)
     got = dp.cpu().numpy()
-    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-3
+    e2 = np.linalg.norm(got - want) / np.linalg.norm(want)
+    print(f"[relpos blocks T={T}] gradient kernel vs plain product on its own blocks: {e2:.2e}")
+    assert e2 < 1e-5, e2  # (measured 4e-8: the same products in f32 instead of f64)
