@@ -57,45 +57,85 @@ def synthetic_batch(B, secs, vocab=128, seed=1234):
     return audio, torch.full((B,), S, dtype=torch.int64), tokens, torch.full((B,), U, dtype=torch.int64)
 
 
-def cpu_baseline(size, secs, vocab, batch, steps, budget_s=30.0):
-    """the CPU oracle (oracle/conformer_ref.py, plain PyTorch fp32) forward+backward+AdamW on the host cores, train mode.
-    Thread count and batch are SWEPT (128 threads on a B = 2 batch over-subscribe the host: round 1 reported 2.3 audio-s/s
-    on 128 cores, less than half of what 8 cores deliver): one probe step per (threads, batch) within a time budget, then
-    the median of >= 3 steps at the best point."""
+def cpu_baseline(size, secs, vocab, batch, steps, budget_s=40.0):
+    """The CPU leg: forward + backward + AdamW of Conformer-CTC in fp32, train mode, on the host cores.
+    kind "reference": the reference's OWN modules (FilterbankFeatures + ConformerEncoder loaded verbatim from /root/reference through
+    oracle/ref_shim.py, decoder / CTCLoss as the 3-line restatements of SURVEY.md section 8c) -- only where that tree exists (the build
+    container); kind "port": the oracle restatement (oracle/conformer_ref.py, pinned to the reference by tests/test_oracle_pinning.py)
+    -- the GPU box, where /root/reference does not exist.  (threads, batch) are SWEPT (over-subscribing the host costs more than
+    half: 128 threads on B = 2 measured 2.3 audio-s/s where 16 give 21): one probe step per point inside the budget, every batch
+    size gets at least one probe, then the median of >= 3 steps at the best point."""
     import os as _os
     from oracle import conformer_ref as R
+    from oracle import ref_shim
     cfg = getattr(R.ConformerCfg, size)(vocab=vocab)
     ncpu = _os.cpu_count() or 1
     t_start = time.perf_counter()
+    use_ref = ref_shim.reference_available() and _os.environ.get("BENCH_CPU_KIND", "auto") != "port"
 
     def make(batch_):
+        data = R.synthetic_batch(batch_, secs, vocab=vocab, seed=1234)
+        if use_ref:
+            torch.manual_seed(0)
+            m = ref_shim.ReferenceCTCModel(cfg.d_model, cfg.n_heads, cfg.n_layers, vocab=vocab, dropout=0.1, dropout_att=0.1,
+                                           dither=1e-5).train()
+            opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.98), weight_decay=1e-3)
+            return m, opt, data
         P = R.init_params(cfg, seed=0, nonzero_pos_bias=False)
         keys = R.trainable_keys(P)
         for k in keys:
             P[k].requires_grad_(True)
         opt = torch.optim.AdamW([P[k] for k in keys], lr=1e-4, betas=(0.9, 0.98), weight_decay=1e-3)
-        data = R.synthetic_batch(batch_, secs, vocab=vocab, seed=1234)
         return P, opt, data
 
     def step(P, opt, data):
         audio, alen, tok, tl = data
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
-        noise = torch.randn_like(audio)
-        out = R.model_forward(P, cfg, audio, alen, tok, tl, train=True, noise=noise, dither=1e-5)
-        out["loss"].backward()
+        if use_ref:
+            loss = P(audio, alen, tok, tl)[0]
+        else:
+            noise = torch.randn_like(audio)
+            loss = R.model_forward(P, cfg, audio, alen, tok, tl, train=True, noise=noise, dither=1e-5)["loss"]
+        loss.backward()
         opt.step()
         return time.perf_counter() - t0
 
-    threads = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} or {ncpu})  # (measured: 16 > 32 > 64 on a 256-CPU host)
+    threads = [t for t in (16, 32, 64) if t <= ncpu] or [ncpu]
     batches = sorted({batch, max(batch, 8)})
     probes, states = {}, {}
-    for b_ in batches:
+    # (the reference's logger writes INFO lines to stdout: this process's stdout carries exactly one JSON line, so the leg runs
+    # with fd 1 pointed at stderr)
+    sys.stdout.flush()
+    saved_fd = _os.dup(1)
+    _os.dup2(2, 1)
+    try:
+        best, times = _cpu_sweep(threads, batches, make, step, secs, budget_s, t_start, steps, probes, states)
+    finally:
+        sys.stdout.flush()
+        _os.dup2(saved_fd, 1)
+        _os.close(saved_fd)
+    th, b_ = best
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(b_ * secs / med, 2), "unit": "audio-sec/s", "cores": th, "threads": th, "host_cpus": ncpu,
+            "kind": "reference" if use_ref else "port",
+            "sample": f"Conformer-CTC-{size} fp32 train step (fwd+bwd+AdamW), B={b_}x{secs:g}s, median of {len(times)} steps at the best "
+                      f"of {len(probes)} (threads, batch) probes; "
+                      + ("the reference's own FilterbankFeatures + ConformerEncoder through oracle/ref_shim.py" if use_ref else
+                         "oracle/conformer_ref.py (the reference tree does not exist on this box)"),
+            "cpu_leg_seconds": round(time.perf_counter() - t_start, 1),
+            "sweep_audio_sec_per_s": {f"threads{t}_b{b}": round(v, 2) for (t, b), v in sorted(probes.items())}}
+
+
+def _cpu_sweep(threads, batches, make, step, secs, budget_s, t_start, steps, probes, states):
+    for bi, b_ in enumerate(batches):
         states[b_] = make(b_)
-        torch.set_num_threads(threads[-1] if threads[-1] <= 64 else 64)
+        torch.set_num_threads(threads[min(1, len(threads) - 1)])
         step(*states[b_])  # warm-up (allocator, thread pool)
-        for th in threads:
-            if time.perf_counter() - t_start > budget_s * 0.6 and probes:
+        share = budget_s * (bi + 1) / len(batches) * 0.7
+        for ti, th in enumerate(threads):
+            if ti > 0 and time.perf_counter() - t_start > share:
                 break
             torch.set_num_threads(th)
             probes[(th, b_)] = b_ * secs / step(*states[b_])
@@ -106,20 +146,14 @@ def cpu_baseline(size, secs, vocab, batch, steps, budget_s=30.0):
         times.append(step(*states[b_]))
         if time.perf_counter() - t_start > budget_s * 1.5 and len(times) >= 3:
             break
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(b_ * secs / med, 2), "unit": "audio-sec/s", "cores": th, "kind": "port",
-            "host_cpus": ncpu,
-            "sample": f"Conformer-CTC-{size} fp32 train step (fwd+bwd+AdamW), B={b_}x{secs:g}s, median of {len(times)} steps at the best "
-                      f"of {len(probes)} (threads, batch) probes",
-            "sweep_audio_sec_per_s": {f"t{t}_b{b}": round(v, 2) for (t, b), v in sorted(probes.items())}}
+    return (th, b_), times
 
 
 def _source_hash():
     """sha256 over the GEMM kernel sources: off-line PMC figures are only reported for the code they were measured on"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "common.cuh"):
+    for f in ("gemm.hip", "common.h"):
         with open(os.path.join(ROOT, "nemo_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -202,25 +236,63 @@ def hbm_roofline(model, dev):
             "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None, "per_kernel": out}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher around it (the reference gets its ranks from Lightning's own launcher:
+    `devices: -1, strategy: ddp`, examples/asr/conf/conformer/conformer_ctc_bpe.yaml:195-201): re-executes this script as N ranks through
+    torch.distributed.run on one node, rank -> its own GPU, RCCL.  Fewer visible GPUs than ranks is an error, never a silent N = 1
+    line (BENCH_DEVICE=<i> rehearses the control flow with all ranks on one GPU, BENCH_DIST_BACKEND=gloo then carries the collectives)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if "BENCH_DEVICE" not in os.environ and have < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) are visible -- refusing to report a smaller job under this flag")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL / tensor sharing across processes on this driver)
+    env["BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     # BENCH_DEVICE / BENCH_DIST_BACKEND exist to rehearse the N > 1 control flow on a one-GPU box (all ranks on device 0,
     # gloo moving the CUDA tensors through the host); the driver's runs use neither: rank -> its own GPU, RCCL
+    rehearsal = "BENCH_DEVICE" in os.environ
+    if not rehearsal and torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} (local {local_rank}) has no GPU of its own: {torch.cuda.device_count()} visible")
     local_rank = int(os.environ.get("BENCH_DEVICE", local_rank))
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
+        if torch.distributed.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py: process group has {torch.distributed.get_world_size()} ranks, --gpus {a.gpus}")
+        # which physical device every rank sits on (an all-gather of the device identities: N ranks on N distinct GPUs)
+        props = torch.cuda.get_device_properties(dev)
+        ident = str(getattr(props, "uuid", None) or f"{props.name}#{local_rank}")
+        seen = [None] * world
+        torch.distributed.all_gather_object(seen, {"rank": rank, "device": local_rank, "uuid": ident})
+        ranks_seen = seen
+        if not rehearsal and len({x["uuid"] for x in seen}) != world:
+            raise SystemExit(f"bench.py: {world} ranks share {len({x['uuid'] for x in seen})} GPU(s): {seen}")
 
     from nemo_amd import ops
     from nemo_amd.models import EncDecCTCModel, conformer_ctc_config
@@ -263,6 +335,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = model.fit_step(batch)["loss"]
+    host_s = time.perf_counter() - t0  # host time to ISSUE the K steps (the GPU may still be running the last ones)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -274,7 +347,9 @@ def main():
     final_loss = float(loss.item())
 
     # ---- what the gradient exchange looked like (diagnosable SCALE runs): collective library, buckets, exposed time
-    dist_info = {"world_size": world, "backend": backend if world > 1 else None}
+    dist_info = {"world_size": world, "backend": backend if world > 1 else None, "ranks_seen": ranks_seen,
+                 "launcher": "self (torch.distributed.run)" if os.environ.get("BENCH_SELF_LAUNCHED") else
+                 ("external" if world > 1 else None)}
     try:
         v = torch.cuda.nccl.version()
         dist_info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
@@ -297,7 +372,7 @@ def main():
             "bucket_bytes": int(syncs[0].bucket_elems * 4),
             "exposed_exchange_ms_max_over_ranks": round(float(t.item()), 3),
             "syncbn_allreduces_per_step": 2 * len(model.encoder.layers),
-            "syncbn_own_process_group": os.environ.get("MI355X_SYNCBN_OWN_GROUP", "1") != "0",
+            "syncbn_own_process_group": os.environ.get("MI355X_SYNCBN_OWN_GROUP", "0") == "1",
         })
 
     roof = None
@@ -395,6 +470,10 @@ def main():
             line["roofline"] = roof
         if roof_hbm is not None:
             line["roofline_hbm"] = roof_hbm
+        ginfo = model.encoder.graph_info() if hasattr(model.encoder, "graph_info") else []
+        line["launch"] = {"mode": "encoder forward/backward replayed from hipGraph segments (nemo_amd/graphs.py); front end, decoder, "
+                                  "loss and optimizer launched live" if ginfo else "every kernel launched live from the Python sequencer",
+                          "host_issue_ms_per_step": round(host_s / a.steps * 1e3, 2), "recorded": ginfo}
         line["distributed"] = dist_info
         if cpu is not None:
             line["cpu_baseline"] = cpu

@@ -313,6 +313,19 @@ int mi355x_fill_f32(void* p, long long n, float value, void* stream);
 /* library / build information */
 const char* mi355x_asr_version(void);
 
+/* Replayable launch sequences (the reference's analogue: nemo/utils/callbacks/cuda_graph.py:251, whole-step CUDA-graph capture).
+ * A training step captured into a hipGraph freezes every kernel argument, including the dropout keys (drop_key above is a
+ * by-value argument).  With a step word registered here, every kernel that takes a dropout key adds *dev_word (u32, device
+ * memory) to the key at entry; the host advances the word once per step in front of the forward graph, so forward and
+ * backward of one step regenerate the same masks and consecutive steps different ones.  The pointer is read when a launch is
+ * ISSUED (it becomes a kernel argument): set it around the capture, reset it to NULL afterwards; launches issued with NULL
+ * use their key as passed.  Process-wide. */
+int mi355x_set_step_counter(const void* dev_word);
+/* Measurement switch: with on = 1 every launch site of the library issues an EMPTY kernel on its stream instead of its own kernel
+ * (results are garbage): the host pays the per-launch cost of a step while the GPU stays idle, i.e. the pure issue time of the
+ * launch sequence (tools/host_phases.py).  Returns the previous value. */
+int mi355x_set_null_launch(int on);
+
 /* Greedy CTC decoding on the device (GreedyCTCInfer._greedy_decode_logprobs, parts/submodules/ctc_greedy_decoding.py:333-361,
  * + the CTC collapse of AbstractCTCDecoding.decode_hypothesis, parts/submodules/ctc_decoding.py:545-575):
  * logp f32 [B,T,C], lens i64 [B] (NULL = T) -> tokens i32 [B,T] (folded, blank-free, -1 padded), out_len i32 [B],

@@ -20,7 +20,7 @@
 //   (nemo/collections/asr/parts/submodules/multi_head_attention.py:272-354, 124-146): two batched matmuls, pad/view/slice
 //   rel_shift, two masked_fill, softmax, dropout, matmul.
 #include <stdlib.h>
-#include "common.cuh"
+#include "common.h"
 #include "mi355x_asr.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
                                                                   const long long* __restrict__ len, bf16_t* __restrict__ ctx,
                                                                   long long ldo, float* __restrict__ lse, int B, int H, int T,
                                                                   int Tp, float scale, DropCfg drop) {
+  drop_resolve(drop);
   __shared__ __attribute__((aligned(16))) bf16_t s_k2[2][ABK * ADK];   // 2 x 4 KiB (double-buffered)
   __shared__ __attribute__((aligned(16))) bf16_t s_v2[2][ABK * ADK];   // 2 x 4 KiB
   __shared__ __attribute__((aligned(16))) bf16_t s_p[APRING * 32 * ADK];  // 24 KiB: ring of 6 blocks of 32 band rows
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqu_out,
     bf16_t* __restrict__ dqv_out, bf16_t* __restrict__ ds_out, int B, int H, int T, int d, float scale,
     DropCfg drop) {
+  drop_resolve(drop);
   __shared__ __attribute__((aligned(16))) bf16_t s_k2[2][ABK * ADK];       // double-buffered (read until the end of a step)
   __shared__ __attribute__((aligned(16))) bf16_t s_v[ABK * ADK];           // read in the first MFMA block only
   __shared__ __attribute__((aligned(16))) bf16_t s_p[APRING * 32 * ADK];   // positional band: ring of 32-row blocks (see forward)
@@ -597,6 +599,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
     const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqkv, long long ldd, int B, int H,
     int T, int Tp, int d, float scale, DropCfg drop) {
+  drop_resolve(drop);
   // staging (double-buffered query tiles + the positional band as a ring of 32-row blocks, see the forward kernel) and the
   // output transposition tile share one buffer: the latter is only used after the loop
   constexpr int STAGE_BYTES = 2 * 3 * 32 * ADK * 2 + APRING * 32 * ADK * 2 + 2 * 2 * 32 * 4;  // 24 + 24 + 0.5 KiB
@@ -955,9 +958,9 @@ extern "C" int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const voi
   if (!qkv || !pos || !bias_u || !bias_v || !len || !ctx || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
   if (dk != ADK || (ldq % 24) || (ldp & 7) || (ldo & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)pos & 15) || ((uintptr_t)ctx & 15))
     return MI_ERR_ARG;
-  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   dim3 grid((T + ABQ - 1) / ABQ, H, B);
-  hipLaunchKernelGGL(relpos_flash_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldq,
+  MI_LAUNCH(relpos_flash_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldq,
                      (const bf16_t*)pos, ldp, (const float*)bias_u, (const float*)bias_v, (const long long*)len, (bf16_t*)ctx,
                      ldo, (float*)lse, B, H, T, Tp, scale, dc);
   return mi_check_launch();
@@ -967,7 +970,7 @@ extern "C" int mi355x_attn_delta(const void* dO, const void* O, void* delta, int
   mi_clear_errors();
   if (!dO || !O || !delta || B <= 0 || H <= 0 || T <= 0 || d != H * ADK) return MI_ERR_ARG;
   const long long rows = (long long)B * T;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+  MI_LAUNCH(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dO, (const bf16_t*)O, (float*)delta, B, H, T, d);
   return mi_check_launch();
 }
@@ -980,9 +983,9 @@ extern "C" int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const 
   if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || !dqu || !dqv || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
   if (dk != ADK || (ldq % 24) || (ldp & 7)) return MI_ERR_ARG;
   if (ds_out && (((uintptr_t)ds_out & 15) || ds_elems < mi355x_relpos_ds_elems(B, H, T))) return MI_ERR_ARG;
-  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   dim3 grid((T + ABQ - 1) / ABQ, H, B);
-  hipLaunchKernelGGL(relpos_flash_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu, (const bf16_t*)qv,
+  MI_LAUNCH(relpos_flash_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu, (const bf16_t*)qv,
                      (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len, (const bf16_t*)dO,
                      (const float*)lse, (const float*)delta, (bf16_t*)dqu, (bf16_t*)dqv, (bf16_t*)ds_out, B, H, T, H * ADK, scale, dc);
   return mi_check_launch();
@@ -995,9 +998,9 @@ extern "C" int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const
   mi_clear_errors();
   if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || !dqkv || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
   if (dk != ADK || (ldq % 24) || (ldp & 7) || (ldd % 24)) return MI_ERR_ARG;
-  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   dim3 grid((T + ABQ - 1) / ABQ, H, B);
-  hipLaunchKernelGGL(relpos_flash_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu,
+  MI_LAUNCH(relpos_flash_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu,
                      (const bf16_t*)qv, (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len,
                      (const bf16_t*)dO, (const float*)lse, (const float*)delta, (bf16_t*)dqkv, ldd, B, H, T, Tp, H * ADK, scale, dc);
   return mi_check_launch();
@@ -1025,10 +1028,10 @@ extern "C" int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, cons
   const int nz = (B + bchunk - 1) / bchunk;
   if (partial && partial_elems < mi355x_relpos_dpos_partial_elems(B, H, T)) return MI_ERR_ARG;
   dim3 grid(nT, H, nz);
-  hipLaunchKernelGGL(relpos_flash_bwd_dpos_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qv,
+  MI_LAUNCH(relpos_flash_bwd_dpos_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qv,
                      (const bf16_t*)ds, (const long long*)len, (float*)dpos, ldd, (float*)partial, B, H, T, H * ADK, bchunk);
   if (partial)
-    hipLaunchKernelGGL(dpos_reduce_kernel, dim3(nT, H, 16), dim3(256), 0, (hipStream_t)stream, (const float*)partial,
+    MI_LAUNCH(dpos_reduce_kernel, dim3(nT, H, 16), dim3(256), 0, (hipStream_t)stream, (const float*)partial,
                        (float*)dpos, ldd, H, T, nz);
   return mi_check_launch();
 }

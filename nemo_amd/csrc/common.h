@@ -27,6 +27,17 @@ static inline int mi_check_launch() {
   return e == hipSuccess ? MI_OK : 1000 + (int)e;
 }
 
+// Every kernel launch of the library goes through MI_LAUNCH.  With mi355x_set_null_launch(1) a launch site issues an EMPTY kernel on
+// the same stream instead of its own: the host then pays the same per-launch cost while the GPU has nothing to do, which is how
+// tools/host_phases.py measures the pure ISSUE time of a training step (no queue back-pressure from a busy GPU).
+extern "C" int mi355x_null_launch_flag;
+static __global__ void mi_null_kernel() {}
+#define MI_LAUNCH(kernel, grid, block, shm, stream, ...)                               \
+  do {                                                                                 \
+    if (mi355x_null_launch_flag) hipLaunchKernelGGL(mi_null_kernel, dim3(1), dim3(64), 0, stream); \
+    else hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);            \
+  } while (0)
+
 // ---------------------------------------------------------------- bf16 <-> f32
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // gfx950 converts in hardware: v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN) -- one instruction per pair
@@ -112,7 +123,24 @@ struct DropCfg {
   uint32_t key;        // mix of (seed, site)
   uint32_t threshold;  // keep iff rnd >= threshold ; threshold = p * 2^32 ; 0 => dropout off
   float scale;         // 1/(1-p)
+  // Device-side step word (mi355x_set_step_counter): when the launch sequence of a training step is replayed from a hipGraph the
+  // host cannot pass a fresh seed per step -- the kernel arguments are frozen in the graph -- so every dropout kernel adds
+  // the word it finds here to its key at entry (one scalar load).  The host advances the word once per step, before the
+  // forward graph; forward and backward of a step therefore regenerate the same masks.  NULL: the key is used as passed.
+  const uint32_t* step;
 };
+// the process-wide step word the launchers put into DropCfg::step (set by mi355x_set_step_counter; defined in version.hip)
+extern "C" const uint32_t* mi355x_step_counter_ptr;
+static inline DropCfg mi_drop(uint32_t key, uint32_t threshold, float scale) {
+  DropCfg d;
+  d.key = key; d.threshold = threshold; d.scale = scale;
+  d.step = threshold ? mi355x_step_counter_ptr : nullptr;
+  return d;
+}
+// kernel entry: fold the step word into the key (uniform pointer, no store precedes it -> one s_load_dword)
+__device__ __forceinline__ void drop_resolve(DropCfg& d) {
+  if (d.step) d.key += *d.step;
+}
 // Elements are hashed in groups of 8 consecutive indices: one strong 32-bit hash per group seeds a xorshift32 stream
 // whose (e+1)-th output decides element e.  v_mul_lo_u32 runs at quarter rate on CDNA4, so hashing every element
 // (4 multiplies) cost as many VALU cycles as the MFMA main loop of a K=512 GEMM; the xorshift steps are full-rate ops.

@@ -6,7 +6,7 @@
 // BN statistics are taken over all B*T positions (padded frames included) exactly as torch BatchNorm1d does on the
 // reference's [B,d,T] tensor; sums are accumulated in f64 so SyncBN (all-reduce of the raw sums) is exact.
 #include <stdlib.h>
-#include "common.cuh"
+#include "common.h"
 #include "mi355x_asr.h"
 
 #define DISPATCH_DT(dt, T, ...)                                      \
@@ -354,7 +354,7 @@ extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias,
   if (!x || !w || !y || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
   dim3 grid((d + DW_CH - 1) / DW_CH, (T + DW_TT - 1) / DW_TT, B), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define DW_FWD(KS) DISPATCH_DT(dt, TT, hipLaunchKernelGGL((dwconv_fwd_kernel<TT, KS>), grid, block, 0, s, (const TT*)x, \
+#define DW_FWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_fwd_kernel<TT, KS>), grid, block, 0, s, (const TT*)x, \
     (const float*)w, (const float*)bias, (TT*)y, (double*)stats, B, T, d))
   switch (ksize) {
     case 31: DW_FWD(31); break;
@@ -372,7 +372,7 @@ extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, v
   hipStream_t s = (hipStream_t)stream;
   const int nparts = B * DW_SEG;
   if (scratch && scratch_elems < (long long)nparts * (ksize + 1) * d) return MI_ERR_ARG;
-#define DW_BWD(KS) DISPATCH_DT(dt, TT, hipLaunchKernelGGL((dwconv_bwd_kernel<TT, KS>), grid, block, 0, s, (const TT*)dy, \
+#define DW_BWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS>), grid, block, 0, s, (const TT*)dy, \
     (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d))
   switch (ksize) {
     case 31: DW_BWD(31); break;
@@ -381,7 +381,7 @@ extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, v
     default: return MI_ERR_ARG;
   }
   if (scratch)
-    hipLaunchKernelGGL(tap_reduce_kernel, dim3(((ksize + 1) * d + 255) / 256, 4), dim3(256), 0, s, (const float*)scratch, nparts,
+    MI_LAUNCH(tap_reduce_kernel, dim3(((ksize + 1) * d + 255) / 256, 4), dim3(256), 0, s, (const float*)scratch, nparts,
                        ksize, d, (float*)dw, (float*)dbias);
   return mi_check_launch();
 }
@@ -389,7 +389,7 @@ static int bn_finalize_launch(const void* stats, double count, const void* count
                               void* running_mean, void* running_var, float momentum, float eps, int d, void* stream) {
   mi_clear_errors();
   if (!stats || !mean || !rstd || d <= 0 || (!count_dev && count <= 0)) return MI_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)stats, count,
+  MI_LAUNCH(bn_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)stats, count,
                      (const double*)count_dev, (float*)mean, (float*)rstd, (float*)running_mean, (float*)running_var, momentum,
                      eps, d);
   return mi_check_launch();
@@ -408,7 +408,7 @@ extern "C" int mi355x_bn_eval_stats(const void* running_mean, const void* runnin
                                     void* stream) {
   mi_clear_errors();
   if (!running_mean || !running_var || !mean || !rstd || d <= 0) return MI_ERR_ARG;
-  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)running_mean,
+  MI_LAUNCH(bn_eval_stats_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)running_mean,
                      (const float*)running_var, (float*)mean, (float*)rstd, eps, d);
   return mi_check_launch();
 }
@@ -417,7 +417,7 @@ extern "C" int mi355x_bn_swish_fwd(const void* x, const void* mean, const void* 
   mi_clear_errors();
   if (!x || !mean || !rstd || !gamma || !beta || !y || M <= 0 || d <= 0 || d % (dt == MI_DT_BF16 ? 8 : 4)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_fwd_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256), 0, s, (const TT*)x,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((bn_swish_fwd_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256), 0, s, (const TT*)x,
                                          (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta, (TT*)y, M, d));
   return mi_check_launch();
 }
@@ -432,11 +432,11 @@ extern "C" int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const v
   if (scratch && scratch_elems < (long long)nblk * 2 * d) return MI_ERR_ARG;
   dim3 grid(1, nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_bwd_reduce_kernel<TT>), grid, block, 0, s, (const TT*)dy, (const TT*)x,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((bn_swish_bwd_reduce_kernel<TT>), grid, block, 0, s, (const TT*)dy, (const TT*)x,
                                          (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta,
                                          (double*)sums, (float*)scratch, M, d));
   if (scratch)
-    hipLaunchKernelGGL((partials_reduce_kernel<double>), dim3((2 * d + 255) / 256, 32), dim3(256), 0, s, (const float*)scratch,
+    MI_LAUNCH((partials_reduce_kernel<double>), dim3((2 * d + 255) / 256, 32), dim3(256), 0, s, (const float*)scratch,
                        (int)nblk, 2 * d, (double*)sums);
   return mi_check_launch();
 }
@@ -462,7 +462,7 @@ static int bn_swish_bwd_apply_launch(const void* dy, const void* x, const void* 
     return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if ((size_t)d * 6 * sizeof(float) > 64 * 1024) return MI_ERR_ARG;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((bn_swish_bwd_apply_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256),
+  DISPATCH_DT(dt, TT, MI_LAUNCH((bn_swish_bwd_apply_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256),
                                          (size_t)d * 6 * sizeof(float), s,
                                          (const TT*)dy, (const TT*)x, (const float*)mean, (const float*)rstd, (const float*)gamma,
                                          (const float*)beta, (const double*)sums, count, (const double*)count_dev, training,
@@ -472,7 +472,7 @@ static int bn_swish_bwd_apply_launch(const void* dy, const void* x, const void* 
 extern "C" int mi355x_bn_param_grad(const void* sums, void* dgamma, void* dbeta, int d, void* stream) {
   mi_clear_errors();
   if (!sums || !dgamma || !dbeta || d <= 0) return MI_ERR_ARG;
-  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)sums,
+  MI_LAUNCH(bn_param_grad_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)sums,
                      (float*)dgamma, (float*)dbeta, d);
   return mi_check_launch();
 }

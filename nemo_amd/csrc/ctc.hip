@@ -8,7 +8,7 @@
 //
 // Replaces on the reference path: torch.nn.functional.ctc_loss forward+backward called by
 //   nemo/collections/asr/losses/ctc.py:68-82 (CTCLoss(blank=V, reduction='none', zero_infinity=True) + mean_batch).
-#include "common.cuh"
+#include "common.h"
 #include "mi355x_asr.h"
 
 #define NEGINF (-INFINITY)
@@ -163,11 +163,11 @@ extern "C" int mi355x_ctc_loss(const void* logp, const void* targets, const void
   const int Smax = 2 * Umax + 1;
   const size_t shm = sizeof(float) * ((size_t)Smax * 5);
   if (shm > 60 * 1024 || sizeof(float) * 4 * (size_t)C > 60 * 1024) return MI_ERR_ARG;
-  hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(256), shm, (hipStream_t)stream, (const float*)logp, (const long long*)targets,
+  MI_LAUNCH(ctc_kernel, dim3(B), dim3(256), shm, (hipStream_t)stream, (const float*)logp, (const long long*)targets,
                      (const long long*)in_len, (const long long*)tgt_len, (float*)alpha_ws, (float*)beta_ws, (float*)nll, Tmax,
                      C, Umax, Smax, blank, zero_infinity);
   if (grad)
-    hipLaunchKernelGGL(ctc_grad_kernel, dim3((Tmax + CTC_GT - 1) / CTC_GT, B), dim3(256), sizeof(float) * 4 * (size_t)C,
+    MI_LAUNCH(ctc_grad_kernel, dim3((Tmax + CTC_GT - 1) / CTC_GT, B), dim3(256), sizeof(float) * 4 * (size_t)C,
                        (hipStream_t)stream, (const float*)logp, (const long long*)targets, (const long long*)in_len,
                        (const long long*)tgt_len, (const float*)alpha_ws, (const float*)beta_ws, (float*)grad, Tmax, C, Umax,
                        Smax, blank, grad_scale);
@@ -228,7 +228,7 @@ extern "C" int mi355x_ctc_greedy_decode(const void* logp, const void* lens, void
   if (!logp || !tokens || !out_len || !score || B <= 0 || Tmax <= 0 || C <= 0 || blank < 0 || blank > C) return MI_ERR_ARG;
   const size_t shm = (size_t)Tmax * 8;
   if (shm > 64 * 1024) return MI_ERR_ARG;
-  hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), shm, (hipStream_t)stream, (const float*)logp, (const long long*)lens,
+  MI_LAUNCH(ctc_greedy_kernel, dim3(B), dim3(256), shm, (hipStream_t)stream, (const float*)logp, (const long long*)lens,
                      (int*)tokens, (int*)out_len, (float*)score, Tmax, C, blank);
   return mi_check_launch();
 }

@@ -8,8 +8,8 @@
 // (mi355x_gemm, EPI_RELU_MASK), so the mask between the two convolutions needs no pass of its own.
 // All three kernels are HBM-bound streams: lane = 8 (bf16) / 4 (f32) consecutive channels = one 16-byte access per tap;
 // the nine taps of neighbouring outputs overlap in L2.  Weight / bias gradients: per-workgroup partial sums, then the
-// shared second-stage reduction (tap_reduce_kernel, common.cuh) -- no same-address atomics.
-#include "common.cuh"
+// shared second-stage reduction (tap_reduce_kernel, common.h) -- no same-address atomics.
+#include "common.h"
 #include "mi355x_asr.h"
 
 #define DISPATCH_DT(dt, T, ...)                                      \
@@ -179,7 +179,7 @@ extern "C" int mi355x_dwconv2d_s2_fwd(const void* in, const void* w, const void*
   if (!in || !w || !bias || !out || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || C % V || C / V > 256) return MI_ERR_ARG;
   const int T2 = (T1 - 1) / 2 + 1, F2 = (F1 - 1) / 2 + 1;
   const int PS = 256 / (C / V);
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((dwconv2d_s2_fwd_kernel<TT>), dim3(dw2d_grid((long long)B * T2 * F2, PS)), dim3(256), 0,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv2d_s2_fwd_kernel<TT>), dim3(dw2d_grid((long long)B * T2 * F2, PS)), dim3(256), 0,
                                          (hipStream_t)stream, (const TT*)in, (const float*)w, (const float*)bias, (TT*)out, B, T1, F1,
                                          T2, F2, C));
   return mi_check_launch();
@@ -200,11 +200,11 @@ extern "C" int mi355x_dwconv2d_s2_bwd(const void* dout, const void* in, const vo
   hipStream_t s = (hipStream_t)stream;
   const size_t shm = (size_t)PS * C * sizeof(float);
   if (shm > 64 * 1024) return MI_ERR_ARG;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((dwconv2d_s2_bwd_data_kernel<TT>), dim3(dw2d_grid((long long)B * T1 * F1, PS)), dim3(256), 0,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv2d_s2_bwd_data_kernel<TT>), dim3(dw2d_grid((long long)B * T1 * F1, PS)), dim3(256), 0,
                                          s, (const TT*)dout, (const TT*)in, (const float*)w, (TT*)din, B, T1, F1, T2, F2, C));
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((dwconv2d_s2_bwd_w_kernel<TT>), dim3((unsigned)nblk), dim3(256), shm, s, (const TT*)dout,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv2d_s2_bwd_w_kernel<TT>), dim3((unsigned)nblk), dim3(256), shm, s, (const TT*)dout,
                                          (const TT*)in, (float*)scratch, B, T1, F1, T2, F2, C, per));
-  hipLaunchKernelGGL(tap_reduce_kernel, dim3((10 * C + 255) / 256, 16), dim3(256), 0, s, (const float*)scratch, (int)nblk, 9, C,
+  MI_LAUNCH(tap_reduce_kernel, dim3((10 * C + 255) / 256, 16), dim3(256), 0, s, (const float*)scratch, (int)nblk, 9, C,
                      (float*)dw, (float*)dbias);
   return mi_check_launch();
 }

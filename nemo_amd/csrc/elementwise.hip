@@ -7,7 +7,7 @@
 //   nn.Dropout on branch outputs               conformer_modules.py:177,192,207,212  (mask regenerated, never stored)
 //   q + pos_bias_u / q + pos_bias_v            multi_head_attention.py:305-307
 //   rel_shift + (ac+bd)/sqrt(dk) + masked softmax + dropout     multi_head_attention.py:259-270,343-346,137-140
-#include "common.cuh"
+#include "common.h"
 #include "mi355x_asr.h"
 
 #define DISPATCH_DT(dt, T, ...)                                      \
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ in, 
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void drop_scale_cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long long n8,
                                                               float alpha, DropCfg drop) {
+  drop_resolve(drop);
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
     float a[4], b[4], m[8];
     ld4(in + i * 8, a); ld4(in + i * 8 + 4, b);
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
                                                                  TO* __restrict__ s_out, TO* __restrict__ pd_out,
                                                                  const long long* __restrict__ len, int H, int B, int T, int Tp,
                                                                  int Pp, float scale, DropCfg drop) {
+  drop_resolve(drop);
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (row >= (long long)H * B * T) return;
@@ -160,6 +162,7 @@ template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const TD* __restrict__ dpd, const TS* __restrict__ s_in,
                                                                  TS* __restrict__ dscore, TS* __restrict__ dbdf, int H, int B,
                                                                  int T, int Tp, int Pp, float scale, DropCfg drop) {
+  drop_resolve(drop);
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (row >= (long long)H * B * T) return;
@@ -208,7 +211,7 @@ extern "C" int mi355x_glu_fwd(const void* in, void* out, int dt, const void* len
   mi_clear_errors();
   if (!in || !out || M <= 0 || d <= 0 || (d & 3) || T <= 0) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((glu_fwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)in,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((glu_fwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)in,
                                          (TT*)out, (const long long*)len, T, M, d));
   return mi_check_launch();
 }
@@ -217,7 +220,7 @@ extern "C" int mi355x_glu_bwd(const void* in, const void* dout, void* din, int d
   mi_clear_errors();
   if (!in || !dout || !din || M <= 0 || d <= 0 || (d & 3) || T <= 0) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((glu_bwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)in,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((glu_bwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)in,
                                          (const TT*)dout, (TT*)din, (const long long*)len, T, M, d));
   return mi_check_launch();
 }
@@ -225,10 +228,10 @@ extern "C" int mi355x_drop_scale_cast(const void* in, int in_dt, void* out, int 
                                       unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
   mi_clear_errors();
   if (!in || !out || n <= 0 || (n & 7)) return MI_ERR_ARG;
-  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(in_dt, TI, DISPATCH_DT(out_dt, TO,
-    hipLaunchKernelGGL((drop_scale_cast_kernel<TI, TO>), dim3(grid_for(n >> 3)), dim3(256), 0, s, (const TI*)in, (TO*)out,
+    MI_LAUNCH((drop_scale_cast_kernel<TI, TO>), dim3(grid_for(n >> 3)), dim3(256), 0, s, (const TI*)in, (TO*)out,
                        n >> 3, alpha, dc)));
   return mi_check_launch();
 }
@@ -237,7 +240,7 @@ extern "C" int mi355x_qbias(const void* qkv, long long ldq, const void* u, const
   mi_clear_errors();
   if (!qkv || !u || !v || !qu || !qv || M <= 0 || (d & 3) || (ldq & 3)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((qbias_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)qkv, ldq,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((qbias_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)qkv, ldq,
                                          (const float*)u, (const float*)v, (TT*)qu, (TT*)qv, M, d));
   return mi_check_launch();
 }
@@ -289,9 +292,9 @@ extern "C" int mi355x_add2_colsum(const void* a, const void* b, void* out, long 
   const int nblk = (int)((M + A2C_ROWS - 1) / A2C_ROWS);
   if (scratch_elems < (long long)nblk * 2 * d) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(add2_colsum_kernel, dim3(nblk), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, ldo, M,
+  MI_LAUNCH(add2_colsum_kernel, dim3(nblk), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, ldo, M,
                      d, (float*)scratch);
-  hipLaunchKernelGGL((partials_reduce_kernel<float>), dim3((2 * d + 255) / 256, 32), dim3(256), 0, s, (const float*)scratch, nblk,
+  MI_LAUNCH((partials_reduce_kernel<float>), dim3((2 * d + 255) / 256, 32), dim3(256), 0, s, (const float*)scratch, nblk,
                      2 * d, (float*)sum_ab);
   return mi_check_launch();
 }
@@ -301,7 +304,7 @@ extern "C" int mi355x_add2(const void* a, const void* b, int in_dt, void* out, i
   if (!a || !b || !out || M <= 0 || (d & 3) || (ldo & 3)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(in_dt, TI, DISPATCH_DT(out_dt, TO,
-    hipLaunchKernelGGL((add2_kernel<TI, TO>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TI*)a, (const TI*)b,
+    MI_LAUNCH((add2_kernel<TI, TO>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TI*)a, (const TI*)b,
                        (TO*)out, ldo, M, d)));
   return mi_check_launch();
 }
@@ -311,10 +314,10 @@ extern "C" int mi355x_relpos_softmax_fwd(const void* ac, const void* bdf, void* 
   mi_clear_errors();
   if (!ac || !bdf || !s_out || !len || T <= 0 || T > 64 * SM_MAXV || Tp < T || Tp > 64 * SM_MAXV || Pp < 2 * T - 1)
     return MI_ERR_ARG;
-  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   const long long rows = (long long)H * B * T;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(out_dt, TO, hipLaunchKernelGGL((relpos_softmax_fwd_kernel<TO>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+  DISPATCH_DT(out_dt, TO, MI_LAUNCH((relpos_softmax_fwd_kernel<TO>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
                                              (const float*)ac, (const float*)bdf, (TO*)s_out, (TO*)pd_out,
                                              (const long long*)len, H, B, T, Tp, Pp, scale, dc));
   return mi_check_launch();
@@ -325,18 +328,18 @@ extern "C" int mi355x_relpos_softmax_bwd(const void* dpd, int dpd_dt, const void
   mi_clear_errors();
   if (!dpd || !s_in || !dscore || !dbdf || T <= 0 || T > 64 * SM_MAXV || Tp < T || Tp > 64 * SM_MAXV || Pp < 2 * T - 1)
     return MI_ERR_ARG;
-  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   const long long rows = (long long)H * B * T;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(s_dt, TS, DISPATCH_DT(dpd_dt, TD,
-    hipLaunchKernelGGL((relpos_softmax_bwd_kernel<TS, TD>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const TD*)dpd,
+    MI_LAUNCH((relpos_softmax_bwd_kernel<TS, TD>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const TD*)dpd,
                        (const TS*)s_in, (TS*)dscore, (TS*)dbdf, H, B, T, Tp, Pp, scale, dc)));
   return mi_check_launch();
 }
 extern "C" int mi355x_row_scale(void* x, const void* vec, long long rows, long long cols, void* stream) {
   mi_clear_errors();
   if (!x || !vec || rows <= 0 || cols <= 0) return MI_ERR_ARG;
-  hipLaunchKernelGGL(row_scale_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, (float*)x,
+  MI_LAUNCH(row_scale_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, (float*)x,
                      (const float*)vec, rows, cols);
   return mi_check_launch();
 }
@@ -362,7 +365,7 @@ extern "C" int mi355x_fill_rects(void* x, const void* rects, int n, int B, int F
   mi_clear_errors();
   if (!x || B <= 0 || F <= 0 || T <= 0 || n < 0 || (n > 0 && !rects)) return MI_ERR_ARG;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(fill_rects_kernel, dim3(n, F < 64 ? F : 64), dim3(256), 0, (hipStream_t)stream, (float*)x, (const int*)rects,
+  MI_LAUNCH(fill_rects_kernel, dim3(n, F < 64 ? F : 64), dim3(256), 0, (hipStream_t)stream, (float*)x, (const int*)rects,
                      n, B, F, T, value);
   return mi_check_launch();
 }

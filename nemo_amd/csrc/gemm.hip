@@ -21,7 +21,8 @@
 //   multi_head_attention.py:124-146,300-350 (q/k/v/pos/out projections; QK^T, PV on the fp32 path),
 //   subsampling.py:431 (out Linear), :231-253 (conv2), modules/conv_asr.py:445 (decoder).
 #include <stdlib.h>
-#include "common.cuh"
+#include "common.h"
+#include <atomic>
 #include "mi355x_asr.h"
 
 enum {
@@ -363,6 +364,7 @@ __device__ __forceinline__ void store_t(const StageT& s, bf16_t* lds) {
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
+  drop_resolve(p.drop);
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];  // 64 KiB
   // layout: A buf0 | A buf1 | B buf0 | B buf1
 #define SA(buf) (smem + (buf) * (BM * BK))
@@ -1025,6 +1027,7 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
+  drop_resolve(p.drop);
   extern __shared__ __attribute__((aligned(16))) bf16_t smem2[];  // 3 stages x 48 KiB
   gemm_v2_body<TA, TB>(p, smem2, blockIdx.x, blockIdx.y, blockIdx.z);
 }
@@ -1065,7 +1068,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_grouped_tn_kernel(GroupP g) {
   p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = 0;
   p.bias = nullptr; p.alpha = 1.f; p.epi = EPI_STORE; p.c_dt = MI_DT_F32; p.atomic = 1;
   p.aux_in = nullptr; p.auxin_dt = 0; p.aux_out = nullptr; p.auxout_dt = 0; p.ldaux = 0;
-  p.drop.key = 0u; p.drop.threshold = 0u; p.drop.scale = 1.f;
+  p.drop.key = 0u; p.drop.threshold = 0u; p.drop.scale = 1.f; p.drop.step = nullptr;
   p.row_len = nullptr; p.rows_per_b = 1; p.rows_inner = 1;
   p.splitk = g.splitk; p.ktiles_per_split = g.ktiles_per_split;
   p.colsum_stride = 0; p.colsum_out = g.colsum[pi];
@@ -1129,6 +1132,7 @@ __device__ __forceinline__ void v4_round_out(const GemmP& p, const float* sC, in
 // compile-time, so that each instantiation carries only its own DMA state (128 accumulator registers leave little room).
 template <bool TA, bool TB, int G>
 __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
+  drop_resolve(p.drop);
   extern __shared__ __attribute__((aligned(16))) bf16_t smem4[];  // 2 stages x 64 KiB
   const int tn = (p.N + BN4 - 1) / BN4, tm = (p.M + BM2 - 1) / BM2;
   const int ntiles = tm * tn;
@@ -1475,6 +1479,7 @@ __device__ __forceinline__ void v5_round(const GemmP& p, const V5Win& w, const f
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_v5_kernel(GemmP p, const int ntiles, const int tn) {
+  drop_resolve(p.drop);
   extern __shared__ __attribute__((aligned(16))) bf16_t smem5[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1696,6 +1701,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v5_kernel(GemmP p, const int nt
 // exact fp32 VALU kernel, arbitrary strides: 64x64x16 tile, 256 threads, 4x4 per thread
 // =================================================================================================
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
+  drop_resolve(p.drop);
   __shared__ float As[16][64 + 4];
   __shared__ float Bs[16][64 + 4];
   const int tn = (p.N + 63) / 64;
@@ -1755,12 +1761,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 // =================================================================================================
 // C ABI
 // =================================================================================================
-static int g_v5_mode = -1;  // MI355X_GEMM_V5 / mi355x_gemm_config(5, .): 0 = never use the persistent structure, 1 = default
+// Dispatch knobs are read by the main thread AND by the autograd thread (backward launches): environment values are
+// function-local `static const` (initialised once, thread-safe since C++11), the one knob that can change at run time is atomic.
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
+}
+static std::atomic<int> g_v5_mode{-1};  // MI355X_GEMM_V5 / mi355x_gemm_config(5, .): 0 = never use the persistent structure, 1 = default
+static int v5_mode_now() {
+  int v = g_v5_mode.load(std::memory_order_relaxed);
+  if (v < 0) {
+    static const int from_env = env_int("MI355X_GEMM_V5", 1);
+    int expected = -1;
+    g_v5_mode.compare_exchange_strong(expected, from_env, std::memory_order_relaxed);
+    v = g_v5_mode.load(std::memory_order_relaxed);
+  }
+  return v;
+}
 extern "C" int mi355x_gemm_config(int key, int value) {
   if (key != 5) return -1;
-  const int old = g_v5_mode;
-  g_v5_mode = value;
-  return old;
+  return g_v5_mode.exchange(value, std::memory_order_relaxed);
 }
 
 extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
@@ -1780,7 +1800,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   p.epi = d->epilogue; p.c_dt = d->c_dtype; p.atomic = d->atomic;
   p.aux_in = d->aux_in; p.auxin_dt = d->aux_in_dtype; p.aux_out = d->aux_out; p.auxout_dt = d->aux_out_dtype;
   p.ldaux = d->ldaux;
-  p.drop.key = d->drop_key; p.drop.threshold = d->drop_threshold; p.drop.scale = d->drop_scale;
+  p.drop = mi_drop(d->drop_key, d->drop_threshold, d->drop_scale);
   p.colsum_out = (float*)d->colsum_out; p.colsum_stride = d->colsum_stride;
   p.g_on = 0; p.r_on = 0;
   if (d->gather) {
@@ -1852,37 +1872,33 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
     if (p.transB && p.g_on != 2 && p.ldb < ((p.N + 7) & ~7)) return MI_ERR_ARG;
     const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     dim3 grid(tm * tn, sk, p.batch);
-    static int use_v2 = -1;
-    if (use_v2 < 0) { const char* e = getenv("MI355X_GEMM_V2"); use_v2 = (e && e[0] == '0') ? 0 : 1; }
+    static const int use_v2 = env_int("MI355X_GEMM_V2", 1) ? 1 : 0;
     if (p.g_on && !(use_v2 && p.M >= 192 && p.N >= 96)) return MI_ERR_ARG;  // the gather lives in the LDS-DMA structures
     // few output tiles (e.g. M = 8032 rows x N = 512: 128 tiles of 256x128 on 256 CUs): the 128x128 structure doubles the
     // workgroups and wins in isolation although its K loop is slower (FFN2 forward at M = 8032: 46.3 -> 39.5 us); inside a
     // training step, next to the weight-gradient stream, it only paid off below ~100 tiles (Squeezeformer-Medium's N = 324
     // launches at the reduced frame rate: step 47.95 -> 46.95 ms; FastConformer's 128-tile launches: 32.47 -> 32.67 ms)
-    static int few_mode = -1;
-    if (few_mode < 0) { const char* e = getenv("MI355X_GEMM_FEW_TILES"); few_mode = e ? atoi(e) : 100; }
+    static const int few_mode = env_int("MI355X_GEMM_FEW_TILES", 100);
     const long long blocks256 = (long long)((p.M + BM2 - 1) / BM2) * tn * sk * p.batch;
     const bool few_tiles = !p.g_on && !p.r_on && !p.atomic && blocks256 <= few_mode && p.N <= 1024 &&
                            (long long)tm * tn * sk * p.batch > blocks256;
     if (use_v2 && p.M >= 192 && p.N >= 96 && !(p.transA && !p.transB) && !few_tiles) {
       const int tm2 = (p.M + BM2 - 1) / BM2;
       const int shm = 3 * NT2_STAGE * 2;
-      static bool attr_set = false;
-      if (!attr_set) {
+      static const bool attr_ok = [shm] {
         bool ok = hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, false>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, shm) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, shm) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<true, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, shm) == hipSuccess;
-        if (!ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
-        attr_set = true;
-      }
+        return ok;
+      }();
+      if (!attr_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
       dim3 grid2(tm2 * tn, sk, p.batch);
       // persistent 256x128 structure with the epilogue overlapped into the next tile's K loop: the Conformer block's
       // forward / dgrad GEMMs (dense NT, full-width vector epilogue, K >= 8 K-tiles, at least one tile per CU)
-      if (g_v5_mode < 0) { const char* e = getenv("MI355X_GEMM_V5"); g_v5_mode = e ? atoi(e) : 1; }
-      const int v5_mode = g_v5_mode;
+      const int v5_mode = v5_mode_now();
       // v5_mode 1: where it measured faster than the tiled structures (K <= 576: Swish-gradient, residual, and stores at
       // least 1536 columns wide); 2: every shape it can run (tests, A/B)
       const bool v5_epi = (p.epi == EPI_STORE && (v5_mode == 2 || p.N >= 1536)) || (p.epi == EPI_SWISH_DROP && v5_mode == 2) ||
@@ -1891,8 +1907,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
           !(p.N % BN) && nk >= 8 && (nk <= 9 || v5_mode == 2) && tm2 * tn >= 256 && v5_epi && (long long)p.M * p.lda < (1LL << 31) &&
           (long long)p.N * p.ldb < (1LL << 31) && (long long)p.M * p.ldc < (1LL << 31) &&
           (long long)p.M * p.ldaux < (1LL << 31)) {
-        static bool attr5_set = false;
-        if (!attr5_set) {
+        static const bool attr5_ok = [] {
           bool ok = hipFuncSetAttribute((const void*)gemm_bf16_v5_kernel<EPI_STORE>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS_BYTES) == hipSuccess;
           ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v5_kernel<EPI_SWISH_DROP>,
@@ -1901,22 +1916,21 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS_BYTES) == hipSuccess;
           ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v5_kernel<EPI_DSWISH>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS_BYTES) == hipSuccess;
-          if (!ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
-          attr5_set = true;
-        }
+          return ok;
+        }();
+        if (!attr5_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
         const int nt5 = tm2 * tn;
         dim3 grid5(256);
         switch (p.epi) {
-          case EPI_STORE: hipLaunchKernelGGL((gemm_bf16_v5_kernel<EPI_STORE>), grid5, dim3(512), V5_LDS_BYTES, s, p, nt5, tn); break;
-          case EPI_SWISH_DROP: hipLaunchKernelGGL((gemm_bf16_v5_kernel<EPI_SWISH_DROP>), grid5, dim3(512), V5_LDS_BYTES, s, p, nt5, tn); break;
-          case EPI_RESID: hipLaunchKernelGGL((gemm_bf16_v5_kernel<EPI_RESID>), grid5, dim3(512), V5_LDS_BYTES, s, p, nt5, tn); break;
-          default: hipLaunchKernelGGL((gemm_bf16_v5_kernel<EPI_DSWISH>), grid5, dim3(512), V5_LDS_BYTES, s, p, nt5, tn); break;
+          case EPI_STORE: MI_LAUNCH((gemm_bf16_v5_kernel<EPI_STORE>), grid5, dim3(512), V5_LDS_BYTES, s, p, nt5, tn); break;
+          case EPI_SWISH_DROP: MI_LAUNCH((gemm_bf16_v5_kernel<EPI_SWISH_DROP>), grid5, dim3(512), V5_LDS_BYTES, s, p, nt5, tn); break;
+          case EPI_RESID: MI_LAUNCH((gemm_bf16_v5_kernel<EPI_RESID>), grid5, dim3(512), V5_LDS_BYTES, s, p, nt5, tn); break;
+          default: MI_LAUNCH((gemm_bf16_v5_kernel<EPI_DSWISH>), grid5, dim3(512), V5_LDS_BYTES, s, p, nt5, tn); break;
         }
         return mi_check_launch();
       }
       // 256x256 structure when the problem still fills the chip with the larger tile
-      static int v4_mode = -1;  // MI355X_GEMM_V4: 0 = never, 1 = heuristic (default), 2 = whenever N >= 129
-      if (v4_mode < 0) { const char* e = getenv("MI355X_GEMM_V4"); v4_mode = e ? atoi(e) : 1; }
+      static const int v4_mode = env_int("MI355X_GEMM_V4", 1);  // 0 = never, 1 = heuristic (default), 2 = whenever N >= 129
       const int tn4 = (p.N + BN4 - 1) / BN4;
       const long long blocks4 = (long long)tm2 * tn4 * sk * p.batch;
       const bool waste_ok = (long long)tn4 * BN4 * 8 <= (long long)p.N * 9;  // <= 12.5 % padded columns
@@ -1926,38 +1940,35 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
       const double eff2 = (double)blocks2 / (double)(((blocks2 + 255) / 256) * 256);
       if ((v4_mode == 2 && p.N > 128) || (v4_mode == 1 && blocks4 >= 224 && waste_ok && eff4 >= 0.9 * eff2)) {
         const int shm4 = 2 * NT4_STAGE * 2;
-        static bool attr4_set = false;
         typedef void (*v4_fn)(GemmP);
         static const v4_fn v4_all[] = {gemm_bf16_v4_kernel<false, false, 0>, gemm_bf16_v4_kernel<false, false, 1>,
                                        gemm_bf16_v4_kernel<false, true, 0>, gemm_bf16_v4_kernel<true, true, 0>,
                                        gemm_bf16_v4_kernel<true, true, 2>};
-        if (!attr4_set) {
+        static const bool attr4_ok = [shm4] {
           for (v4_fn f : v4_all)
-            if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, shm4) != hipSuccess) {
-              (void)hipGetLastError();
-              return MI_ERR_LAUNCH;
-            }
-          attr4_set = true;
-        }
+            if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, shm4) != hipSuccess) return false;
+          return true;
+        }();
+        if (!attr4_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
         dim3 grid4(tm2 * tn4, sk, p.batch);
         v4_fn fn;
         if (!p.transA && !p.transB) fn = v4_all[p.g_on == 1 ? 1 : 0];
         else if (!p.transA && p.transB) fn = v4_all[2];
         else fn = v4_all[p.g_on == 2 ? 4 : 3];
-        hipLaunchKernelGGL(fn, grid4, dim3(512), shm4, s, p);
+        MI_LAUNCH(fn, grid4, dim3(512), shm4, s, p);
       } else
-      if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_bf16_v2_kernel<false, false>), grid2, dim3(512), shm, s, p);
-      else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_bf16_v2_kernel<false, true>), grid2, dim3(512), shm, s, p);
-      else hipLaunchKernelGGL((gemm_bf16_v2_kernel<true, true>), grid2, dim3(512), shm, s, p);
+      if (!p.transA && !p.transB) MI_LAUNCH((gemm_bf16_v2_kernel<false, false>), grid2, dim3(512), shm, s, p);
+      else if (!p.transA && p.transB) MI_LAUNCH((gemm_bf16_v2_kernel<false, true>), grid2, dim3(512), shm, s, p);
+      else MI_LAUNCH((gemm_bf16_v2_kernel<true, true>), grid2, dim3(512), shm, s, p);
     } else
-    if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, s, p);
-    else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, s, p);
-    else if (p.transA && p.transB) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(256), 0, s, p);
+    if (!p.transA && !p.transB) MI_LAUNCH((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, s, p);
+    else if (!p.transA && p.transB) MI_LAUNCH((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, s, p);
+    else if (p.transA && p.transB) MI_LAUNCH((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, s, p);
+    else MI_LAUNCH((gemm_bf16_kernel<true, false>), grid, dim3(256), 0, s, p);
   } else {
     const int tm = (p.M + 63) / 64, tn = (p.N + 63) / 64;
     dim3 grid(tm * tn, sk, p.batch);
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, p);
+    MI_LAUNCH(gemm_f32_kernel, grid, dim3(256), 0, s, p);
   }
   return mi_check_launch();
 }
@@ -1989,13 +2000,10 @@ extern "C" int mi355x_gemm_grouped(const mi355x_gemm_desc* descs, int n, void* s
   sk = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
   g.splitk = sk;
   const int shm = 3 * NT2_STAGE * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_grouped_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm) !=
-        hipSuccess) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gemm_bf16_grouped_tn_kernel, dim3(tiles, sk, 1), dim3(512), shm, (hipStream_t)stream, g);
+  static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_bf16_grouped_tn_kernel,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, shm) == hipSuccess;
+  if (!attr_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
+  MI_LAUNCH(gemm_bf16_grouped_tn_kernel, dim3(tiles, sk, 1), dim3(512), shm, (hipStream_t)stream, g);
   return mi_check_launch();
 }
 

@@ -10,7 +10,7 @@
 //   (nemo/collections/asr/parts/preprocessing/features.py:423-502, 59-93): torch.stft (hipFFT) + ~12 elementwise
 //   launches, complex [B,257,T] intermediate written/read three times.
 // Algorithmic HBM bytes: 4*S read + 4*n_mels*T written per utterance (= 96 KB per audio-second at 80 mels).
-#include "common.cuh"
+#include "common.h"
 #include "mi355x_asr.h"
 
 #define MEL_FR 32        // frames per workgroup (4 waves x 8 frames)
@@ -189,7 +189,7 @@ extern "C" int mi355x_logmel_fwd(const void* audio, const void* audio_len, const
     (void)hipGetLastError();
     return MI_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(logmel_kernel, grid, block, shm, (hipStream_t)stream, (const float*)audio, (const long long*)audio_len,
+  MI_LAUNCH(logmel_kernel, grid, block, shm, (hipStream_t)stream, (const float*)audio, (const long long*)audio_len,
                      (const float*)window, win, hop, (const int*)fb_start, (const int*)fb_len, (const int*)fb_off,
                      (const float*)fb_w, n_mels, preemph, dither, seed, log_guard, (float*)out, B, S, T);
   return mi_check_launch();
@@ -202,10 +202,10 @@ extern "C" int mi355x_feat_normalize(const void* x, const void* seq_len, void* y
   const int rows = B * n_mels;
   hipStream_t s = (hipStream_t)stream;
   if (y_dt == MI_DT_F32)
-    hipLaunchKernelGGL((feat_norm_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)x,
+    MI_LAUNCH((feat_norm_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)x,
                        (const long long*)seq_len, (float*)y, rows, n_mels, T, normalize, pad_value);
   else
-    hipLaunchKernelGGL((feat_norm_kernel<bf16_t>), dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)x,
+    MI_LAUNCH((feat_norm_kernel<bf16_t>), dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)x,
                        (const long long*)seq_len, (bf16_t*)y, rows, n_mels, T, normalize, pad_value);
   return mi_check_launch();
 }

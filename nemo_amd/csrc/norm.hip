@@ -4,7 +4,7 @@
 // (nemo/collections/asr/parts/submodules/conformer_modules.py:98,102,115,152,157 used at :174-215),
 // log_softmax of the decoder (nemo/collections/asr/modules/conv_asr.py:468) and the bias-gradient column sums
 // autograd produces for every Linear / Conv1d on the path.
-#include "common.cuh"
+#include "common.h"
 #include "mi355x_asr.h"
 
 #define DISPATCH_DT(dt, T, ...)                                      \
@@ -325,14 +325,14 @@ extern "C" int mi355x_layernorm_fwd(const void* x, int x_dt, const void* gamma, 
   dim3 grid((M + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool aligned = !((uintptr_t)x & 31) && !((uintptr_t)y & 31) && !((uintptr_t)gamma & 31) && !((uintptr_t)beta & 31);
-#define LN_REG(NCH) DISPATCH_DT(x_dt, TX, DISPATCH_DT(y_dt, TY, hipLaunchKernelGGL((ln_fwd_reg_kernel<TX, TY, NCH>), grid, \
+#define LN_REG(NCH) DISPATCH_DT(x_dt, TX, DISPATCH_DT(y_dt, TY, MI_LAUNCH((ln_fwd_reg_kernel<TX, TY, NCH>), grid, \
     block, 0, s, (const TX*)x, (const float*)gamma, (const float*)beta, (TY*)y, (float*)mean, (float*)rstd, M, d, eps)))
   if (aligned && d == 512) { LN_REG(1); }
   else if (aligned && d == 1024) { LN_REG(2); }
   else if (aligned && d == 2048) { LN_REG(4); }
   else
   DISPATCH_DT(x_dt, TX, DISPATCH_DT(y_dt, TY,
-    hipLaunchKernelGGL((ln_fwd_kernel<TX, TY>), grid, block, 0, s, (const TX*)x, (const float*)gamma, (const float*)beta,
+    MI_LAUNCH((ln_fwd_kernel<TX, TY>), grid, block, 0, s, (const TX*)x, (const float*)gamma, (const float*)beta,
                        (TY*)y, (float*)mean, (float*)rstd, M, d, eps)));
 #undef LN_REG
   return mi_check_launch();
@@ -349,6 +349,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_fused8_kernel(const TDY
                                                             int accumulate, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int M, int d,
                                                             bf16_t* __restrict__ cast_out, float cast_scale, DropCfg cast_drop) {
+  drop_resolve(cast_drop);
   __shared__ float red[LNB_WAVES][2][NCH * 512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float g[NCH][8], ag[NCH][8], ab[NCH][8];
@@ -425,7 +426,7 @@ extern "C" int mi355x_layernorm_bwd(const void* dy, int dy_dt, const void* x, in
                                     const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d,
                                     void* stream) {
   mi_clear_errors();
-  DropCfg nodrop; nodrop.key = 0u; nodrop.threshold = 0u; nodrop.scale = 1.f;
+  DropCfg nodrop = mi_drop(0u, 0u, 1.f);
   return layernorm_bwd_impl(dy, dy_dt, x, x_dt, gamma, mean, rstd, dres, accumulate, dgamma, dbeta, M, d, nullptr, 1.f, nodrop,
                             stream);
 }
@@ -435,12 +436,13 @@ extern "C" int mi355x_layernorm_bwd_cast(const void* dy, int dy_dt, const void* 
                                          float drop_scale, void* stream) {
   mi_clear_errors();
   if (!cast_out || ((uintptr_t)cast_out & 15)) return MI_ERR_ARG;
-  DropCfg dc; dc.key = drop_key; dc.threshold = drop_threshold; dc.scale = drop_scale;
+  DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   return layernorm_bwd_impl(dy, dy_dt, x, x_dt, gamma, mean, rstd, dres, accumulate, dgamma, dbeta, M, d, cast_out, cast_scale, dc,
                             stream);
 }
 __global__ __launch_bounds__(256) void ln_cast_after_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long n8,
-                                                            float alpha, DropCfg drop) {  // fallback: separate cast pass
+                                                            float alpha, DropCfg drop) {
+  drop_resolve(drop);  // fallback: separate cast pass
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
     float a[8], m[8];
     ld8g(in + i * 8, a);
@@ -461,7 +463,7 @@ static int layernorm_bwd_impl(const void* dy, int dy_dt, const void* x, int x_dt
     dim3 gridf((M + LNB_ROWS - 1) / LNB_ROWS);
     dim3 blockf(64 * LNB_WAVES);
 #define LN_F8(NCH) DISPATCH_DT(x_dt, TX, DISPATCH_DT(dy_dt, TDY, \
-      hipLaunchKernelGGL((ln_bwd_fused8_kernel<TX, TDY, NCH>), gridf, blockf, 0, s, (const TDY*)dy, (const TX*)x, \
+      MI_LAUNCH((ln_bwd_fused8_kernel<TX, TDY, NCH>), gridf, blockf, 0, s, (const TDY*)dy, (const TX*)x, \
                          (const float*)gamma, (const float*)mean, (const float*)rstd, (float*)dres, accumulate, \
                          (float*)dgamma, (float*)dbeta, M, d, (bf16_t*)cast_out, cast_scale, cast_drop)))
     if (d == 512) { LN_F8(1); } else { LN_F8(2); }
@@ -473,7 +475,7 @@ static int layernorm_bwd_impl(const void* dy, int dy_dt, const void* x, int x_dt
     ~CastAfter() {
       if (out && (n & 7) == 0) {
         long long nb = (n / 8 + 255) / 256; if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(ln_cast_after_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)in, (bf16_t*)out, n / 8,
+        MI_LAUNCH(ln_cast_after_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)in, (bf16_t*)out, n / 8,
                            scale, drop);
       }
     }
@@ -484,7 +486,7 @@ static int layernorm_bwd_impl(const void* dy, int dy_dt, const void* x, int x_dt
     dim3 blockf(64 * LNB_WAVES);
     const int nvv = (d / 4 + 63) / 64;
 #define LN_FUSED(NV) DISPATCH_DT(x_dt, TX, DISPATCH_DT(dy_dt, TDY, \
-      hipLaunchKernelGGL((ln_bwd_fused_kernel<TX, TDY, NV>), gridf, blockf, 0, s, (const TDY*)dy, (const TX*)x, \
+      MI_LAUNCH((ln_bwd_fused_kernel<TX, TDY, NV>), gridf, blockf, 0, s, (const TDY*)dy, (const TX*)x, \
                          (const float*)gamma, (const float*)mean, (const float*)rstd, (float*)dres, accumulate, \
                          (float*)dgamma, (float*)dbeta, M, d)))
     switch (nvv) {
@@ -498,12 +500,12 @@ static int layernorm_bwd_impl(const void* dy, int dy_dt, const void* x, int x_dt
   if (dgamma && dbeta) {
     dim3 gp((d + 63) / 64, (M + CR_ROWS - 1) / CR_ROWS);
     DISPATCH_DT(x_dt, TX, DISPATCH_DT(dy_dt, TDY,
-      hipLaunchKernelGGL((ln_bwd_param_kernel<TX, TDY>), gp, block, 0, s, (const TDY*)dy, (const TX*)x, (const float*)mean,
+      MI_LAUNCH((ln_bwd_param_kernel<TX, TDY>), gp, block, 0, s, (const TDY*)dy, (const TX*)x, (const float*)mean,
                          (const float*)rstd, (float*)dgamma, (float*)dbeta, M, d)));
   }
   dim3 grid((M + 3) / 4);
   DISPATCH_DT(x_dt, TX, DISPATCH_DT(dy_dt, TDY,
-    hipLaunchKernelGGL((ln_bwd_dx_kernel<TX, TDY>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, (const float*)gamma,
+    MI_LAUNCH((ln_bwd_dx_kernel<TX, TDY>), grid, block, 0, s, (const TDY*)dy, (const TX*)x, (const float*)gamma,
                        (const float*)mean, (const float*)rstd, (float*)dres, accumulate, M, d)));
   return mi_check_launch();
 }
@@ -514,11 +516,11 @@ extern "C" int mi355x_colsum(const void* x, int x_dt, long long ld, void* out, i
   hipStream_t s = (hipStream_t)stream;
   if (x_dt == MI_DT_BF16 && !(N & 7) && !(ld & 7) && !((uintptr_t)x & 15)) {
     dim3 grid((N + 511) / 512, (M + CSV_ROWS - 1) / CSV_ROWS);
-    hipLaunchKernelGGL(colsum_bf16x8_kernel, grid, dim3(256), 0, s, (const bf16_t*)x, ld, (float*)out, M, N, alpha);
+    MI_LAUNCH(colsum_bf16x8_kernel, grid, dim3(256), 0, s, (const bf16_t*)x, ld, (float*)out, M, N, alpha);
     return mi_check_launch();
   }
   dim3 grid((N + 63) / 64, (M + CR_ROWS - 1) / CR_ROWS), block(256);
-  DISPATCH_DT(x_dt, TX, hipLaunchKernelGGL((colsum_kernel<TX>), grid, block, 0, s, (const TX*)x, ld, (float*)out, M, N, alpha));
+  DISPATCH_DT(x_dt, TX, MI_LAUNCH((colsum_kernel<TX>), grid, block, 0, s, (const TX*)x, ld, (float*)out, M, N, alpha));
   return mi_check_launch();
 }
 
@@ -526,7 +528,7 @@ extern "C" int mi355x_log_softmax_fwd(const void* logits, long long ld_in, void*
                                       void* stream) {
   mi_clear_errors();
   if (!logits || !logp || M <= 0 || C <= 0) return MI_ERR_ARG;
-  hipLaunchKernelGGL(log_softmax_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)logits,
+  MI_LAUNCH(log_softmax_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)logits,
                      ld_in, (float*)logp, ld_out, M, C);
   return mi_check_launch();
 }
@@ -536,7 +538,7 @@ extern "C" int mi355x_log_softmax_bwd(const void* dlogp, const void* logp, long 
   mi_clear_errors();
   if (!dlogp || !logp || !dlogits || M <= 0 || C <= 0 || ld_out < C) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(out_dt, TO, hipLaunchKernelGGL((log_softmax_bwd_kernel<TO>), dim3((M + 3) / 4), dim3(256), 0, s,
+  DISPATCH_DT(out_dt, TO, MI_LAUNCH((log_softmax_bwd_kernel<TO>), dim3((M + 3) / 4), dim3(256), 0, s,
                                              (const float*)dlogp, (const float*)logp, ld, (TO*)dlogits, ld_out, M, C, scale));
   return mi_check_launch();
 }

@@ -5,7 +5,7 @@
 //   * descriptor-driven "pack" kernel that produces every bf16 GEMM operand image of the weights in one launch:
 //     plain casts, transposes (for dgrad), q|k|v concatenation, conv2 [co,ci,3,3] -> [co][(kh,kw,ci)], and the
 //     out-Linear column permutation (c*F2+f -> f*C+c) required by the channels-last conv layout.
-#include "common.cuh"
+#include "common.h"
 #include "mi355x_asr.h"
 
 // gclip: optional device scalar multiplied into the gradient (global-norm clipping coefficient, no host sync);
@@ -130,7 +130,7 @@ static int adamw_launch(void* params, const void* grads, void* exp_avg, void* ex
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   long long nb = ((n >> 2) + 255) / 256;
   if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (float*)params, (const float*)grads,
+  MI_LAUNCH(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (float*)params, (const float*)grads,
                      (float*)exp_avg, (float*)exp_avg_sq, n >> 2, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale,
                      (const float*)gclip, (float*)ema, ema_decay);
   return mi_check_launch();
@@ -154,14 +154,14 @@ extern "C" int mi355x_grad_sumsq(const void* grads, long long n, void* out_f64, 
   if (!grads || !out_f64 || n <= 0 || (n & 3)) return MI_ERR_ARG;
   long long nb = ((n >> 2) + 255) / 256;
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float*)grads, n >> 2,
+  MI_LAUNCH(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float*)grads, n >> 2,
                      (double*)out_f64);
   return mi_check_launch();
 }
 extern "C" int mi355x_clip_coef(const void* sumsq_f64, int nbuf, float scale, float max_norm, void* coef_f32x2, void* stream) {
   mi_clear_errors();
   if (!sumsq_f64 || !coef_f32x2 || nbuf <= 0 || !(max_norm > 0.f)) return MI_ERR_ARG;
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const double*)sumsq_f64, nbuf, scale, max_norm,
+  MI_LAUNCH(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const double*)sumsq_f64, nbuf, scale, max_norm,
                      (float*)coef_f32x2);
   return mi_check_launch();
 }
@@ -169,7 +169,7 @@ extern "C" int mi355x_clip_coef(const void* sumsq_f64, int nbuf, float scale, fl
 extern "C" int mi355x_pack_weights(const void* table_dev, int n_entries, long long total_tiles, int out_dtype, void* stream) {
   mi_clear_errors();
   if (!table_dev || n_entries <= 0 || total_tiles <= 0) return MI_ERR_ARG;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev,
+  MI_LAUNCH(pack_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev,
                      n_entries, out_dtype);
   return mi_check_launch();
 }
@@ -179,6 +179,6 @@ extern "C" int mi355x_fill_f32(void* p, long long n, float value, void* stream) 
   if (!p || n <= 0) return MI_ERR_ARG;
   long long nb = (n + 255) / 256;
   if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (float*)p, n, value);
+  MI_LAUNCH(fill_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (float*)p, n, value);
   return mi_check_launch();
 }

@@ -14,7 +14,7 @@
 // Replaces on the reference path (FastConformer-Transducer, cfg 4): the Numba-CUDA kernels
 //   nemo/collections/asr/parts/numba/rnnt_loss/utils/cuda_utils/gpu_rnnt_kernel.py:74-407 (alphas :74-183, betas :186-283,
 //   grads :286-407), reduce.py (denominator), rnnt_helper.compute_costs_data (:107-116), driven by gpu_rnnt.py:125-231.
-#include "common.cuh"
+#include "common.h"
 #include "mi355x_asr.h"
 
 #define RNEG (-INFINITY)
@@ -265,25 +265,25 @@ static int rnnt_loss_impl(const void* acts, long long ld, const void* labels_, c
   float* ll = betas + rows;
   hipStream_t s = (hipStream_t)stream;
   const unsigned nblk = (unsigned)((rows + 3) / 4);
-  hipLaunchKernelGGL(rnnt_denom_kernel, dim3(nblk), dim3(256), 0, s, (const float*)acts, labels, act_lens, label_lens, denom,
+  MI_LAUNCH(rnnt_denom_kernel, dim3(nblk), dim3(256), 0, s, (const float*)acts, labels, act_lens, label_lens, denom,
                      lpb, lpl, rows, T, U1, V1, blank, ld);
   const int threads = ((U1 + 63) / 64) * 64;
-  hipLaunchKernelGGL(rnnt_lattice_kernel, dim3(B, 2), dim3(threads), 2 * threads * sizeof(float), s, lpb, lpl, act_lens,
+  MI_LAUNCH(rnnt_lattice_kernel, dim3(B, 2), dim3(threads), 2 * threads * sizeof(float), s, lpb, lpl, act_lens,
                      label_lens, alphas, betas, ll, B, T, U1);
   if (grads_ && grads_dtype == MI_DT_BF16) {
     // vector walk when every logit row starts on a 16-byte boundary (then head = 0 and the 4-element groups of the bf16 row
     // are 8-byte aligned as well)
     const int aligned = (((unsigned long long)acts & 15ull) == 0ull && (ld & 3) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((rnnt_grad_kernel<bf16_t>), dim3(nblk), dim3(256), 0, s, (const float*)acts, labels, act_lens, label_lens,
+    MI_LAUNCH((rnnt_grad_kernel<bf16_t>), dim3(nblk), dim3(256), 0, s, (const float*)acts, labels, act_lens, label_lens,
                        denom, alphas, betas, ll, (bf16_t*)grads_, rows, T, U1, V1, blank, fastemit_lambda, clamp, grad_scale,
                        aligned, ld, ldg);
   } else if (grads_) {
     const int same = ((((unsigned long long)acts ^ (unsigned long long)grads_) & 15ull) == 0ull && ((ld - ldg) & 3) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((rnnt_grad_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)acts, labels, act_lens, label_lens,
+    MI_LAUNCH((rnnt_grad_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)acts, labels, act_lens, label_lens,
                        denom, alphas, betas, ll, (float*)grads_, rows, T, U1, V1, blank, fastemit_lambda, clamp, grad_scale, same,
                        ld, ldg);
   }
-  hipLaunchKernelGGL(rnnt_cost_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ll, costs, B, fastemit_lambda);
+  MI_LAUNCH(rnnt_cost_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ll, costs, B, fastemit_lambda);
   return mi_check_launch();
 }
 

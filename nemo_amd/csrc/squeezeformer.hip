@@ -9,7 +9,7 @@
 // Row pitches: bf16 GEMM operands must start every row on a 16-byte boundary, and Squeezeformer's d_model is not always a
 // multiple of 8 (Medium: 324).  Every kernel here that PRODUCES a K-contiguous GEMM operand therefore takes an explicit
 // output pitch `ld` >= d (a multiple of 4) and zero-fills the columns [d, ld).
-#include "common.cuh"
+#include "common.h"
 #include "mi355x_asr.h"
 
 #define DISPATCH_DT(dt, T, ...)                                      \
@@ -108,6 +108,7 @@ static __global__ __launch_bounds__(256) void sb_reduce_kernel(const float* __re
 template <typename TY>
 __global__ __launch_bounds__(256) void cast_pitched_kernel(const float* __restrict__ x, TY* __restrict__ y, long long M, int d, int ld,
                                                            float alpha, DropCfg drop) {
+  drop_resolve(drop);
   const int lv = ld >> 2;
   const long long nv = M * lv;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
@@ -322,7 +323,7 @@ extern "C" int mi355x_scale_bias_fwd(const void* x, const void* scale, const voi
   mi_clear_errors();
   if (!x || !y || M <= 0 || bad_pitch(d, ld) || (!scale) != (!bias)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(y_dtype, TY, hipLaunchKernelGGL((scale_bias_fwd_kernel<TY>), dim3(sgrid(M * (ld >> 2))), dim3(256), 0, s,
+  DISPATCH_DT(y_dtype, TY, MI_LAUNCH((scale_bias_fwd_kernel<TY>), dim3(sgrid(M * (ld >> 2))), dim3(256), 0, s,
                                               (const float*)x, (const float*)scale, (const float*)bias, (TY*)y, M, d, ld));
   return mi_check_launch();
 }
@@ -334,11 +335,11 @@ extern "C" int mi355x_scale_bias_bwd(const void* dy, int dy_dtype, int ld, const
   int rpb;
   const int nb = reduce_blocks(M, &rpb);
   if (dscale && (!scratch || scratch_elems < (long long)nb * 2 * d)) return MI_ERR_ARG;
-  DISPATCH_DT(dy_dtype, TD, hipLaunchKernelGGL((scale_bias_bwd_kernel<TD>), dim3(nb), dim3(256), 0, s, (const TD*)dy, ld,
+  DISPATCH_DT(dy_dtype, TD, MI_LAUNCH((scale_bias_bwd_kernel<TD>), dim3(nb), dim3(256), 0, s, (const TD*)dy, ld,
                                                (const float*)x, (const float*)scale, (float*)dres,
                                                dscale ? (float*)scratch : (float*)nullptr, M, d, rpb));
   if (dscale)
-    hipLaunchKernelGGL(sb_reduce_kernel, dim3((2 * d + 255) / 256, 8), dim3(256), 0, s, (const float*)scratch, nb, d, (float*)dscale,
+    MI_LAUNCH(sb_reduce_kernel, dim3((2 * d + 255) / 256, 8), dim3(256), 0, s, (const float*)scratch, nb, d, (float*)dscale,
                        (float*)dbias);
   return mi_check_launch();
 }
@@ -346,9 +347,9 @@ extern "C" int mi355x_cast_pitched(const void* x, void* y, int y_dtype, long lon
                                    unsigned drop_threshold, float drop_scale, void* stream) {
   mi_clear_errors();
   if (!x || !y || M <= 0 || bad_pitch(d, ld) || M * d >= (1LL << 32)) return MI_ERR_ARG;
-  DropCfg dc{drop_key, drop_threshold, drop_scale};
+  DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(y_dtype, TY, hipLaunchKernelGGL((cast_pitched_kernel<TY>), dim3(sgrid(M * (ld >> 2))), dim3(256), 0, s,
+  DISPATCH_DT(y_dtype, TY, MI_LAUNCH((cast_pitched_kernel<TY>), dim3(sgrid(M * (ld >> 2))), dim3(256), 0, s,
                                               (const float*)x, (TY*)y, M, d, ld, alpha, dc));
   return mi_check_launch();
 }
@@ -356,7 +357,7 @@ extern "C" int mi355x_swish_mask_fwd(const void* in, void* out, int dtype, const
   mi_clear_errors();
   if (!in || !out || M <= 0 || C <= 0 || (C & 3) || T <= 0) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dtype, TT, hipLaunchKernelGGL((swish_mask_fwd_kernel<TT>), dim3(sgrid(M * (C >> 2))), dim3(256), 0, s, (const TT*)in,
+  DISPATCH_DT(dtype, TT, MI_LAUNCH((swish_mask_fwd_kernel<TT>), dim3(sgrid(M * (C >> 2))), dim3(256), 0, s, (const TT*)in,
                                             (TT*)out, (const long long*)len, T, M, C));
   return mi_check_launch();
 }
@@ -365,7 +366,7 @@ extern "C" int mi355x_swish_mask_bwd(const void* in, const void* dout, void* din
   mi_clear_errors();
   if (!in || !dout || !din || M <= 0 || C <= 0 || (C & 3) || T <= 0) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dtype, TT, hipLaunchKernelGGL((swish_mask_bwd_kernel<TT>), dim3(sgrid(M * (C >> 2))), dim3(256), 0, s, (const TT*)in,
+  DISPATCH_DT(dtype, TT, MI_LAUNCH((swish_mask_bwd_kernel<TT>), dim3(sgrid(M * (C >> 2))), dim3(256), 0, s, (const TT*)in,
                                             (const TT*)dout, (TT*)din, (const long long*)len, T, M, C));
   return mi_check_launch();
 }
@@ -375,7 +376,7 @@ extern "C" int mi355x_time_reduce_dwconv_fwd(const void* x, const void* len, con
   if (!x || !w || !bias || !out || B <= 0 || T <= 0 || bad_pitch(d, ld)) return MI_ERR_ARG;
   const int Th = (T + 1) / 2;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(out_dtype, TY, hipLaunchKernelGGL((tr_dwconv_fwd_kernel<TY>), dim3(sgrid((long long)B * Th * (ld >> 2))), dim3(256), 0, s,
+  DISPATCH_DT(out_dtype, TY, MI_LAUNCH((tr_dwconv_fwd_kernel<TY>), dim3(sgrid((long long)B * Th * (ld >> 2))), dim3(256), 0, s,
                                                 (const float*)x, (const long long*)len, (const float*)w, (const float*)bias,
                                                 (TY*)out, B, T, Th, d, ld));
   return mi_check_launch();
@@ -389,16 +390,16 @@ extern "C" int mi355x_time_reduce_dwconv_bwd(const void* dout, int dout_dtype, i
   int rpb;
   const int nb = reduce_blocks((long long)B * Th, &rpb);
   DISPATCH_DT(dout_dtype, TY,
-              hipLaunchKernelGGL((tr_dwconv_bwd_data_kernel<TY>), dim3(sgrid((long long)B * T * (d >> 2))), dim3(256), 0, s,
+              MI_LAUNCH((tr_dwconv_bwd_data_kernel<TY>), dim3(sgrid((long long)B * T * (d >> 2))), dim3(256), 0, s,
                                  (const TY*)dout, ld, (const long long*)len, (const float*)w, (float*)dx, B, T, Th, d);
-              hipLaunchKernelGGL((tr_dwconv_bwd_w_kernel<TY>), dim3(nb), dim3(256), 0, s, (const TY*)dout, ld, (const float*)x,
+              MI_LAUNCH((tr_dwconv_bwd_w_kernel<TY>), dim3(nb), dim3(256), 0, s, (const TY*)dout, ld, (const float*)x,
                                  (const long long*)len, (float*)dw, (float*)dbias, B, T, Th, d, rpb));
   return mi_check_launch();
 }
 extern "C" int mi355x_time_recover_fwd(const void* skip, const void* ys, void* out, int B, int T, int d, void* stream) {
   mi_clear_errors();
   if (!skip || !ys || !out || B <= 0 || T <= 0 || d <= 0 || (d & 3)) return MI_ERR_ARG;
-  hipLaunchKernelGGL(time_recover_fwd_kernel, dim3(sgrid((long long)B * T * (d >> 2))), dim3(256), 0, (hipStream_t)stream,
+  MI_LAUNCH(time_recover_fwd_kernel, dim3(sgrid((long long)B * T * (d >> 2))), dim3(256), 0, (hipStream_t)stream,
                      (const float*)skip, (const float*)ys, (float*)out, B, T, (T + 1) / 2, d);
   return mi_check_launch();
 }
@@ -407,7 +408,7 @@ extern "C" int mi355x_time_recover_bwd(const void* dx, void* dys, int dys_dtype,
   if (!dx || !dys || B <= 0 || T <= 0 || bad_pitch(d, ld)) return MI_ERR_ARG;
   const int Th = (T + 1) / 2;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dys_dtype, TY, hipLaunchKernelGGL((time_recover_bwd_kernel<TY>), dim3(sgrid((long long)B * Th * (ld >> 2))), dim3(256), 0, s,
+  DISPATCH_DT(dys_dtype, TY, MI_LAUNCH((time_recover_bwd_kernel<TY>), dim3(sgrid((long long)B * Th * (ld >> 2))), dim3(256), 0, s,
                                                 (const float*)dx, (TY*)dys, B, T, Th, d, ld));
   return mi_check_launch();
 }

@@ -7,7 +7,7 @@
 //
 // Replaces on the reference path: ConvSubsampling.forward / MaskedConvSequential
 //   (nemo/collections/asr/parts/submodules/subsampling.py:385-436, 725-759) = F.conv2d x2 + 4 mask multiplies.
-#include "common.cuh"
+#include "common.h"
 #include "mi355x_asr.h"
 
 #define DISPATCH_DT(dt, T, ...)                                      \
@@ -234,7 +234,7 @@ extern "C" int mi355x_subsample_conv1_fwd(const void* mel, const void* w, const 
   dim3 grid((T1 + C1_TR - 1) / C1_TR, B), block(256);
   const size_t shm = (size_t)(2 * C1_TR + 1) * (F + 2) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(out_dt, TO, hipLaunchKernelGGL((conv1_fwd_kernel<TO>), grid, block, shm, s, (const float*)mel, (const float*)w,
+  DISPATCH_DT(out_dt, TO, MI_LAUNCH((conv1_fwd_kernel<TO>), grid, block, shm, s, (const float*)mel, (const float*)w,
                                              (const float*)bias, (TO*)out, (const long long*)len0, (const long long*)len1, B, F,
                                              T, T1, F1, C));
   return mi_check_launch();
@@ -251,10 +251,10 @@ extern "C" int mi355x_subsample_conv1_bwd(const void* dout, int dt, const void* 
   const int V = dt == MI_DT_BF16 ? 8 : 4;
   const size_t shm = ((size_t)(F + 2) * (2 * C1_TB + 1) + 4 * 64 * V) * sizeof(float);
   if (shm > 64 * 1024) return MI_ERR_ARG;
-  DISPATCH_DT(dt, TO, hipLaunchKernelGGL((conv1_bwd_kernel<TO>), grid, block, shm, s, (const TO*)dout, (const float*)mel,
+  DISPATCH_DT(dt, TO, MI_LAUNCH((conv1_bwd_kernel<TO>), grid, block, shm, s, (const TO*)dout, (const float*)mel,
                                          (const long long*)len0, (float*)dw, (float*)db, (float*)scratch, B, F, T, T1, F1, C));
   if (scratch)
-    hipLaunchKernelGGL(tap_reduce_kernel, dim3((10 * C + 255) / 256, 16), dim3(256), 0, s, (const float*)scratch, nparts, 9, C,
+    MI_LAUNCH(tap_reduce_kernel, dim3((10 * C + 255) / 256, 16), dim3(256), 0, s, (const float*)scratch, nparts, 9, C,
                        (float*)dw, (float*)db);
   return mi_check_launch();
 }
@@ -264,7 +264,7 @@ extern "C" int mi355x_im2col_3x3s2(const void* in, void* col, int dt, int B, int
   const int T2 = (T1 + 2 - 3) / 2 + 1, F2 = (F1 + 2 - 3) / 2 + 1;
   const long long total = (long long)B * T2 * F2 * 9 * (C / (dt == MI_DT_BF16 ? 8 : 4));
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((im2col_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, s, (const TT*)in, (TT*)col, B,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((im2col_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, s, (const TT*)in, (TT*)col, B,
                                          T1, F1, T2, F2, C));
   return mi_check_launch();
 }
@@ -275,7 +275,7 @@ extern "C" int mi355x_col2im_3x3s2_relu(const void* dcol, const void* act, void*
   const int T2 = (T1 + 2 - 3) / 2 + 1, F2 = (F1 + 2 - 3) / 2 + 1;
   const long long total = (long long)B * T1 * F1 * (C >> 2);
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((col2im_relu_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, s, (const TT*)dcol,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((col2im_relu_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, s, (const TT*)dcol,
                                          (const TT*)act, (TT*)din, B, T1, F1, T2, F2, C));
   return mi_check_launch();
 }

@@ -7,7 +7,7 @@
 //   RNNTJoint.joint_after_projection :1640-1720   f.unsqueeze(2) + g.unsqueeze(1) -> ReLU -> Dropout -> Linear
 // Layouts: prediction network time-major [U+1, B, H] (one step's rows are contiguous: the recurrent GEMM of step t reads
 // h[t-1] and writes the gate pre-activations of step t in place over the input projection); joint hidden [B, T, U+1, J].
-#include "common.cuh"
+#include "common.h"
 #include "mi355x_asr.h"
 
 #define DISPATCH_DT(dt, T, ...)                                      \
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
 template <typename TT>
 __global__ __launch_bounds__(256) void joint_combine_fwd_kernel(const TT* __restrict__ f, const TT* __restrict__ g,
                                                                 TT* __restrict__ h, DropCfg drop, int B, int T, int U1, int J) {
+  drop_resolve(drop);
   constexpr int V = VecIO<TT>::V;
   const int jv = J / V;
   const long long nv = (long long)B * T * U1 * jv;
@@ -181,7 +182,7 @@ extern "C" int mi355x_embed_sos_fwd(const void* targets, const void* emb, void* 
                                     void* stream) {
   mi_clear_errors();
   if (!emb || !out || (!targets && U > 0) || B <= 0 || U < 0 || H <= 0 || (H & 3)) return MI_ERR_ARG;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((embed_sos_fwd_kernel<TT>), dim3(tgrid((long long)(U + 1) * B * (H >> 2))), dim3(256), 0,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((embed_sos_fwd_kernel<TT>), dim3(tgrid((long long)(U + 1) * B * (H >> 2))), dim3(256), 0,
                                          (hipStream_t)stream, (const long long*)targets, (const float*)emb, (TT*)out, B, U, H, blank));
   return mi_check_launch();
 }
@@ -191,7 +192,7 @@ extern "C" int mi355x_embed_sos_bwd(const void* targets, const void* dx, int dt,
   if (!dx || !demb || B <= 0 || U < 0 || H <= 0 || (H & 3)) return MI_ERR_ARG;
   if (U == 0) return MI_OK;
   if (!targets) return MI_ERR_ARG;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((embed_sos_bwd_kernel<TT>), dim3(tgrid((long long)U * B * (H >> 2))), dim3(256), 0,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((embed_sos_bwd_kernel<TT>), dim3(tgrid((long long)U * B * (H >> 2))), dim3(256), 0,
                                          (hipStream_t)stream, (const long long*)targets, (const TT*)dx, (float*)demb, B, U, H, blank));
   return mi_check_launch();
 }
@@ -199,7 +200,7 @@ extern "C" int mi355x_lstm_cell_fwd(void* z, const void* b_hh, const void* c_pre
                                     int H, void* stream) {
   mi_clear_errors();
   if (!z || !b_hh || !c || !h || !h_lp || B <= 0 || H <= 0) return MI_ERR_ARG;
-  DISPATCH_DT(lp_dt, TT, hipLaunchKernelGGL((lstm_cell_fwd_kernel<TT>), dim3(tgrid((long long)B * H)), dim3(256), 0,
+  DISPATCH_DT(lp_dt, TT, MI_LAUNCH((lstm_cell_fwd_kernel<TT>), dim3(tgrid((long long)B * H)), dim3(256), 0,
                                             (hipStream_t)stream, (float*)z, (const float*)b_hh, (const float*)c_prev, (float*)c,
                                             (float*)h, (TT*)h_lp, B, H));
   return mi_check_launch();
@@ -208,7 +209,7 @@ extern "C" int mi355x_lstm_cell_bwd(const void* dh, void* dc, const void* act, c
                                     int dz_dt, int B, int H, void* stream) {
   mi_clear_errors();
   if (!dh || !dc || !act || !c || !dz || B <= 0 || H <= 0) return MI_ERR_ARG;
-  DISPATCH_DT(dz_dt, TT, hipLaunchKernelGGL((lstm_cell_bwd_kernel<TT>), dim3(tgrid((long long)B * H)), dim3(256), 0,
+  DISPATCH_DT(dz_dt, TT, MI_LAUNCH((lstm_cell_bwd_kernel<TT>), dim3(tgrid((long long)B * H)), dim3(256), 0,
                                             (hipStream_t)stream, (const float*)dh, (float*)dc, (const float*)act, (const float*)c,
                                             (const float*)c_prev, (TT*)dz, B, H));
   return mi_check_launch();
@@ -219,8 +220,8 @@ extern "C" int mi355x_joint_combine_fwd(const void* f, const void* g, void* h, i
   const int V = dt == MI_DT_BF16 ? 8 : 4;
   if (!f || !g || !h || B <= 0 || T <= 0 || U1 <= 0 || J <= 0 || J % V) return MI_ERR_ARG;
   if ((long long)B * T * U1 * J >= (1LL << 32)) return MI_ERR_ARG;  // the dropout counter is 32 bits: sub-batch the joint
-  DropCfg d{drop_key, drop_threshold, drop_scale};
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((joint_combine_fwd_kernel<TT>), dim3(tgrid((long long)B * T * U1 * (J / V))), dim3(256), 0,
+  DropCfg d = mi_drop(drop_key, drop_threshold, drop_scale);
+  DISPATCH_DT(dt, TT, MI_LAUNCH((joint_combine_fwd_kernel<TT>), dim3(tgrid((long long)B * T * U1 * (J / V))), dim3(256), 0,
                                          (hipStream_t)stream, (const TT*)f, (const TT*)g, (TT*)h, d, B, T, U1, J));
   return mi_check_launch();
 }
@@ -229,7 +230,7 @@ extern "C" int mi355x_joint_combine_bwd(void* dh, const void* h, void* df, int d
   mi_clear_errors();
   const int V = dt == MI_DT_BF16 ? 8 : 4;
   if (!dh || !h || !df || B <= 0 || T <= 0 || U1 <= 0 || J <= 0 || J % V) return MI_ERR_ARG;
-  DISPATCH_DT(dt, TT, hipLaunchKernelGGL((joint_combine_bwd_kernel<TT>), dim3(tgrid((long long)B * T * (J / V))), dim3(256), 0,
+  DISPATCH_DT(dt, TT, MI_LAUNCH((joint_combine_bwd_kernel<TT>), dim3(tgrid((long long)B * T * (J / V))), dim3(256), 0,
                                          (hipStream_t)stream, (TT*)dh, (const TT*)h, (TT*)df, drop_scale, B, T, U1, J));
   return mi_check_launch();
 }
@@ -237,7 +238,7 @@ extern "C" int mi355x_cast_rows(const void* src, long long ld_in, void* dst, int
                                 int Np, float alpha, void* stream) {
   mi_clear_errors();
   if (!src || !dst || M <= 0 || N <= 0 || Np < N || ld_in < N || ld_out < Np) return MI_ERR_ARG;
-  DISPATCH_DT(dst_dt, TT, hipLaunchKernelGGL((cast_rows_kernel<TT>), dim3(tgrid(M * Np)), dim3(256), 0, (hipStream_t)stream,
+  DISPATCH_DT(dst_dt, TT, MI_LAUNCH((cast_rows_kernel<TT>), dim3(tgrid(M * Np)), dim3(256), 0, (hipStream_t)stream,
                                              (const float*)src, ld_in, (TT*)dst, ld_out, M, N, Np, alpha));
   return mi_check_launch();
 }

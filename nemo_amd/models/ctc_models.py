@@ -348,6 +348,8 @@ class EncDecCTCModel(nn.Module):
                 if gs.use_side_stream and hasattr(mod, "_wg_stream"):  # weight gradients are produced on their own stream
                     gs.producer_streams = (lambda m=mod: [m._wg_stream] if m._wg_stream is not None else [])
                     mod._wgrad_join_per_layer = False
+                if hasattr(mod, "setup_process_groups"):
+                    mod.setup_process_groups()  # (collective when the own-group option is on: every rank is here, before step 1)
                 self._syncs.append(gs)
         return self._syncs
 

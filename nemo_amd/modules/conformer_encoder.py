@@ -130,16 +130,35 @@ class _Saved:
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mel, length, token, module):
-        out, enc_len, saved = module._forward_impl(mel, length, save=True)
-        ctx.module, ctx.saved = module, saved
+        ctx.module, ctx.saved, ctx.gset = module, None, None
+        res = module._graphed_forward(mel, length)  # None: this call runs eagerly (warm-up, unstable shapes, graphs off)
+        if res is not None:
+            out, enc_len, ctx.gset, ctx.gen = res
+        else:
+            out, enc_len, ctx.saved = module._forward_impl(mel, length, save=True)
         ctx.mark_non_differentiable(enc_len)
         return out, enc_len
 
     @staticmethod
     def backward(ctx, dout, _):
-        ctx.module._backward_impl(ctx.saved, dout)
+        if ctx.gset is not None:
+            ctx.module._graphed_backward(ctx.gset, ctx.gen, dout)
+        else:
+            ctx.module._backward_impl(ctx.saved, dout)
         ctx.saved = None
         return None, None, None, None
+
+
+class _GraphSet:
+    """the recorded forward / backward launch sequences of ONE (shape, configuration) key, their static inputs / outputs"""
+
+    def __init__(self):
+        self.calls = 0          # training forwards seen with this key (the first ones run eagerly: they also warm the caches up)
+        self.fwd = self.bwd = None
+        self.S = None           # saved activations between the forward and the backward CAPTURE (dropped afterwards)
+        self.mel = self.length = self.out = self.enc_len = self.dout = None
+        self.gen = 0            # forward replays so far; a backward must belong to the latest one
+        self.failed = False
 
 
 class ConformerEncoder(NeuralModule):
@@ -238,6 +257,15 @@ class ConformerEncoder(NeuralModule):
         self._step_seed = 0
         self._weights_version = -1
         self._token = None
+        # ---- replayable launch sequences (nemo_amd/graphs.py).  MI355X_GRAPHS=0 keeps every step on the eager sequencer.
+        self.use_graphs = os.environ.get("MI355X_GRAPHS", "1") != "0"
+        self.graph_warmup = 2       # eager training forwards per key before its launch sequence is captured
+        self.max_graph_sets = 8     # distinct (shape, configuration) keys kept (a duration-bucketed loader has a handful)
+        self._graph_sets = OrderedDict()
+        self._capture = None        # the SegmentedCapture while a sequence is being recorded
+        self._wg_forked = False     # recording: the weight-gradient stream has joined the capture and not re-joined yet
+        self._force_pack = False    # record the weight-image pack unconditionally (a replayed forward always re-packs)
+        self._step_word = None      # device-side dropout step word (int32), advanced by the forward graph
 
     # ------------------------------------------------------------------ reference API surface
     def set_max_audio_length(self, max_audio_length):
@@ -345,11 +373,128 @@ class ConformerEncoder(NeuralModule):
             p.finalize(); pf.finalize()
             plan = (p, pf, None, -2)
             self._plans[key] = plan
-        if plan[3] != self._weights_version:
+        if plan[3] != self._weights_version or self._force_pack:
             plan[0].run(); plan[1].run()
             plan = (plan[0], plan[1], plan[2], self._weights_version)
             self._plans[key] = plan
         return plan[0], plan[1]
+
+    # ------------------------------------------------------------------ replayable launch sequences (nemo_amd/graphs.py)
+    def _eager_point(self, fn):
+        """a step of the forward / backward sequence that must stay a live host call (collective, user hook): executed in place
+        on the eager path, recorded between two graph segments while a sequence is being captured"""
+        if self._capture is None:
+            fn()
+        else:
+            self._capture.cut(fn)
+
+    def _hook(self, lo, hi):
+        """grad_ready_hook(lo, hi), looked up when it RUNS (a replayed sequence calls whatever hook is installed then)"""
+        self._eager_point(lambda: self.grad_ready_hook(lo, hi) if self.grad_ready_hook is not None else None)
+
+    def _graph_key(self, mel, length):
+        return (tuple(mel.shape), self._cdt(), str(mel.device), self._flatp.generation, self._syncbn_world(),
+                self.grad_ready_hook is not None, self._wgrad_join_per_layer, self.wgrad_side_stream, self.wgrad_grouped,
+                self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse,
+                self.use_flash_attention, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder)
+
+    def _graphed_forward(self, mel, length):
+        """-> (out, enc_len, graph set, generation) from the recorded sequence, or None when this call has to run eagerly"""
+        if not (self.use_graphs and self.training and mel.is_cuda) or ops.GEMM_PROFILE is not None:
+            return None
+        key = self._graph_key(mel, length)
+        gs = self._graph_sets.get(key)
+        if gs is None:
+            gs = self._graph_sets[key] = _GraphSet()
+            while len(self._graph_sets) > self.max_graph_sets:
+                self._graph_sets.popitem(last=False)
+        else:
+            self._graph_sets.move_to_end(key)
+        gs.calls += 1
+        if gs.failed or gs.calls <= self.graph_warmup:
+            return None
+        if gs.fwd is None:
+            try:
+                self._capture_forward(gs, mel, length)
+            except Exception as e:  # noqa: BLE001 -- a capture executes nothing, so the eager sequencer can simply take this call
+                if os.environ.get("MI355X_GRAPHS") == "2":
+                    raise
+                import warnings
+                warnings.warn(f"recording the encoder forward as hipGraphs failed ({type(e).__name__}: {e}); this shape keeps "
+                              "running on the eager sequencer")
+                gs.failed, gs.fwd, gs.S = True, None, None
+                return None
+        gs.mel.copy_(mel)
+        gs.length.copy_(length)
+        gs.fwd.replay()
+        gs.gen += 1
+        # fresh tensor objects on the static storage (autograd attaches this call's node to what a Function returns)
+        return gs.out.detach(), gs.enc_len.detach(), gs, gs.gen
+
+    def _capture_forward(self, gs, mel, length):
+        from ..graphs import SegmentedCapture
+        dev = mel.device
+        gs.mel = torch.empty(tuple(mel.shape), dtype=torch.float32, device=dev)
+        gs.length = torch.empty(tuple(length.shape), dtype=torch.int64, device=dev)
+        gs.mel.copy_(mel)
+        gs.length.copy_(length)
+        if self._step_word is None or self._step_word.device != dev:
+            self._step_word = torch.zeros(1, dtype=torch.int32, device=dev)
+        cap = SegmentedCapture(dev)
+        self._force_pack = True
+        ops.set_step_counter(self._step_word)
+        try:
+            with cap.capturing(before_cut=self._wgrad_join):
+                self._capture = cap
+                self._step_word.add_(ops.STEP_WORD_INC)  # recorded: every replayed step draws fresh dropout masks
+                gs.out, gs.enc_len, gs.S = self._forward_impl(gs.mel, gs.length, save=True)
+        finally:
+            self._capture = None
+            self._force_pack = False
+            self._wg_forked = False
+            ops.set_step_counter(None)
+        gs.fwd = cap
+        gs.pool = cap.pool
+
+    def _graphed_backward(self, gs, gen, dout):
+        from ..graphs import SegmentedCapture
+        if gen != gs.gen:
+            raise RuntimeError("backward through an encoder forward whose saved activations were overwritten by a later forward "
+                               "of the same shape (recorded launch sequences keep ONE set of activations per shape); set "
+                               "encoder.use_graphs = False (or MI355X_GRAPHS=0) for several forwards per backward")
+        if gs.bwd is None:
+            gs.dout = torch.empty_like(dout)
+            gs.dout.copy_(dout)
+            cap = SegmentedCapture(dout.device, pool=gs.pool)
+            ops.set_step_counter(self._step_word)
+            try:
+                with cap.capturing(before_cut=self._wgrad_join):
+                    self._capture = cap
+                    self._backward_impl(gs.S, gs.dout)
+            except Exception as e:  # noqa: BLE001
+                self._capture = None
+                ops.set_step_counter(None)
+                raise RuntimeError("recording the encoder backward as hipGraphs failed after its forward had been recorded "
+                                   f"({type(e).__name__}: {e}); run with MI355X_GRAPHS=0") from e
+            finally:
+                self._capture = None
+                self._wg_forked = False
+                ops.set_step_counter(None)
+            gs.bwd = cap
+            gs.S = None  # the recorded launches hold the addresses; the pool keeps the memory
+        else:
+            gs.dout.copy_(dout)
+        gs.bwd.replay()
+
+    def graph_info(self):
+        """diagnostics (bench.py): recorded keys, graph segments and live host calls per forward / backward"""
+        out = []
+        for key, gs in self._graph_sets.items():
+            if gs.fwd is not None:
+                out.append({"mel_shape": list(key[0]), "fwd_graphs": gs.fwd.n_graphs(), "fwd_host_calls": len(gs.fwd.seq) - gs.fwd.n_graphs(),
+                            "bwd_graphs": gs.bwd.n_graphs() if gs.bwd is not None else None,
+                            "bwd_host_calls": (len(gs.bwd.seq) - gs.bwd.n_graphs()) if gs.bwd is not None else None})
+        return out
 
     @staticmethod
     def _dgrad_slots(pt, pf):
@@ -418,6 +563,8 @@ class ConformerEncoder(NeuralModule):
             self._wg_stream = torch.cuda.Stream(device=dev)
         side = self._wg_stream
         side.wait_stream(torch.cuda.current_stream(dev))  # operands are produced on the main stream
+        if self._capture is not None:
+            self._wg_forked = True  # the side stream is part of the capture now: it must re-join before the segment ends
         for t in tensors:
             t.record_stream(side)  # the caching allocator must not hand the storage out again before the side stream is done
         return torch.cuda.stream(side)
@@ -443,6 +590,12 @@ class ConformerEncoder(NeuralModule):
         self._wg_pending, self._wg_rows = [], None
 
     def _wgrad_join(self):
+        if self._capture is not None:
+            # recording: a capturing stream may only wait for work of its own capture.  The side stream is joined if (and only
+            # if) this segment forked it; an un-forked side stream holds nothing the recorded sequence depends on.
+            if not self._wg_forked:
+                return
+            self._wg_forked = False
         if self._wg_stream is not None:
             torch.cuda.current_stream(self._wg_stream.device).wait_stream(self._wg_stream)
 
@@ -522,7 +675,9 @@ class ConformerEncoder(NeuralModule):
         pos = self._pos_cache.get(pkey)
         if pos is None:
             pos = self.pos_enc.table(T2, dev, cdt)
-            self._pos_cache = {pkey: pos}
+            if len(self._pos_cache) >= 16:  # (a duration-bucketed loader alternates between a handful of lengths)
+                self._pos_cache = {}
+            self._pos_cache[pkey] = pos
         d_emb = drop(self.dropout_emb, 100001)
         if d_emb.threshold:  # dropout on the positional table (multi_head_attention.py:1097-1098)
             posd = torch.empty_like(pos)
@@ -637,7 +792,7 @@ class ConformerEncoder(NeuralModule):
         if io.finish is not None:
             io.finish()
         if self.grad_ready_hook is not None:
-            self.grad_ready_hook(*self._flatp.range_of("pre_encode."))
+            self._hook(*self._flatp.range_of("pre_encode."))
 
     def _ln_fwd(self, ln, x, M, d, out_dtype, dev):
         y = torch.empty(M, d, dtype=out_dtype, device=dev)
@@ -848,17 +1003,28 @@ class ConformerEncoder(NeuralModule):
             return torch.distributed.get_world_size()
         return 1
 
+    def setup_process_groups(self):
+        """Collective: every rank must call it at the same point (EncDecCTCModel._grad_syncs does, before the first step).
+        MI355X_SYNCBN_OWN_GROUP=1 gives the SyncBatchNorm exchanges their own process group (= their own RCCL communicator and
+        stream), so that the 8-KB latency-bound calls do not queue behind the 64-MiB gradient buckets in flight during
+        backward.  Off by default: two communicators used concurrently from one process have not been validated on a multi-GPU
+        RCCL run yet (every 2-rank test here runs over gloo), and the default group is the conservative choice until then."""
+        import torch.distributed as dist
+        if self._syncbn_group is None and dist.is_available() and dist.is_initialized():
+            own = os.environ.get("MI355X_SYNCBN_OWN_GROUP", "0") == "1" and dist.get_world_size() > 1
+            self._syncbn_group = dist.new_group(backend=dist.get_backend()) if own else dist.group.WORLD
+        return self._syncbn_group
+
     def _sync_stats(self, stats):
         """SyncBatchNorm: all-reduce the raw f64 sums (+ count) over the data-parallel ranks (torch.nn.SyncBatchNorm
-        semantics).  The exchanges go through their OWN process group = their own RCCL communicator and stream: on the
-        default group these 8-KB latency-bound calls would queue behind the 64-MiB gradient buckets that GradSync has
-        in flight during backward, and the backward chain (which needs the sums at once) would stall for a whole bucket."""
+        semantics).  A live host call also when the launch sequence is replayed from graphs (_eager_point)."""
         import torch.distributed as dist
-        if self._syncbn_group is None:
-            # every rank reaches its first training forward in the same order, so the collective new_group() call matches
-            self._syncbn_group = dist.new_group(backend=dist.get_backend()) if os.environ.get(
-                "MI355X_SYNCBN_OWN_GROUP", "1") != "0" else dist.group.WORLD
-        dist.all_reduce(stats, group=self._syncbn_group)
+        group = self._syncbn_group
+        if group is None:
+            # (an encoder driven without the model class: the own-group option then creates its group here, in the first training
+            # forward -- new_group() is a collective, so every rank has to reach this forward)
+            group = self.setup_process_groups()
+        self._eager_point(lambda: dist.all_reduce(stats, group=group))
 
     # ------------------------------------------------------------------ backward implementation
     def _backward_impl(self, S, dout):
@@ -882,12 +1048,12 @@ class ConformerEncoder(NeuralModule):
                 # that stream itself (GradSync.producer_streams) or the backward chain joins here
                 if self._wgrad_join_per_layer:
                     self._wgrad_join()
-                self.grad_ready_hook(*fp.range_of(f"layers.{i}."))
+                self._hook(*fp.range_of(f"layers.{i}."))
         self._wg_pending = None  # (the remaining weight gradients have their own shapes / layouts)
         self._wgrad_join()       # dp_all may have been produced on the side stream
         self._pos_proj_wgrad(S.dp_all, S.pos, P, cdt)
         if self.grad_ready_hook is not None:
-            self.grad_ready_hook(*fp.tail_range())
+            self._hook(*fp.tail_range())
         # ---- sub-sampling backward
         pe = self.pre_encode
         if self.subsampling == "dw_striding":
@@ -946,7 +1112,7 @@ class ConformerEncoder(NeuralModule):
         ops.conv1_bwd(dout1, S.mel, S.len0, pe.conv[0].weight.grad, pe.conv[0].bias.grad, C_)
         self._wgrad_join()
         if self.grad_ready_hook is not None:
-            self.grad_ready_hook(*fp.range_of("pre_encode."))
+            self._hook(*fp.range_of("pre_encode."))
 
     def _ffn_bwd(self, pfx, ff, ln, saved, dr, W, M, d, dff, cdt, dev, df=None, next_cast=None):
         """`df` = the already cast / dropped / scaled residual-branch gradient when the previous LayerNorm backward produced

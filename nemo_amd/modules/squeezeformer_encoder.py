@@ -308,7 +308,7 @@ class SqueezeformerEncoder(ConformerEncoder):
             p.finalize(); pf.finalize()
             plan = (p, pf, None, -2)
             self._plans[key] = plan
-        if plan[3] != self._weights_version:
+        if plan[3] != self._weights_version or self._force_pack:
             plan[0].run(); plan[1].run()
             plan = (plan[0], plan[1], plan[2], self._weights_version)
             self._plans[key] = plan
@@ -321,7 +321,7 @@ class SqueezeformerEncoder(ConformerEncoder):
         tab = self._pos_cache.get(key)
         if tab is None:
             tab = pos_enc.table(T, dev, torch.float32)
-            if len(self._pos_cache) > 4:
+            if len(self._pos_cache) >= 32:
                 self._pos_cache = {}
             self._pos_cache[key] = tab
         g.pos = torch.empty(g.P, dp, dtype=cdt, device=dev)
@@ -667,7 +667,7 @@ class SqueezeformerEncoder(ConformerEncoder):
             if self.grad_ready_hook is not None:
                 if self._wgrad_join_per_layer:
                     self._wgrad_join()
-                self.grad_ready_hook(*fp.range_of(f"layers.{i}."))
+                self._hook(*fp.range_of(f"layers.{i}."))
         self._wg_pending = None
         x_pre, pmean, prstd = S.pre_ln
         dpre = torch.empty(M, d, dtype=torch.float32, device=dev)
@@ -676,7 +676,7 @@ class SqueezeformerEncoder(ConformerEncoder):
         if self.grad_ready_hook is not None:
             for pfx in ("pre_ln.", "time_reduce_layer.", "time_recovery_layer."):
                 try:
-                    self.grad_ready_hook(*fp.range_of(pfx))
+                    self._hook(*fp.range_of(pfx))
                 except KeyError:
                     pass
         return self._sub_bwd_dw(S, dpre, W, cdt, Wf=Wf)

@@ -61,6 +61,18 @@ def gemm_config(key: int, value: int) -> int:
     return lib.mi355x_gemm_config(key, value)
 
 
+# value added to the device-side step word per training step (odd: the word walks through all 2^32 values)
+STEP_WORD_INC = -1640531535  # 0x9E3779B1 as int32
+
+
+def set_step_counter(word: Optional[torch.Tensor]) -> None:
+    """register (or, with None, clear) the device-side int32 step word that every dropout kernel issued from now on adds to its
+    key at entry -- see mi355x_set_step_counter (include/mi355x_asr.h) and nemo_amd/graphs.py"""
+    if word is not None and (word.dtype != torch.int32 or word.numel() != 1):
+        raise ValueError("the step word is one int32 on the device")
+    check(lib.mi355x_set_step_counter(_ptr(word)), "set_step_counter")
+
+
 def wgrad_grouped(problems, rows, splitk):
     """problems: list of (dY, ldy, y_off, X, ldx, x_off, dW, n_out, n_in, bias_grad_or_None);
     dW[n_out, n_in] += dY[:, y_off:+n_out]^T @ X[:, x_off:+n_in] for all of them in ONE launch (bf16 in, f32 atomics)."""

@@ -1,0 +1,184 @@
+"""-m gpu: the encoder's forward / backward launch sequence recorded as hipGraph segments (nemo_amd/graphs.py) against the SAME
+sequence issued launch by launch from Python (the eager sequencer, which the parity tests pin to the oracle).  A replayed step
+must be the eager step: same kernels, same arguments, same order -- only float-atomic order inside the split-K weight gradients
+may differ.  Reference analogue: whole-step CUDA-graph capture, nemo/utils/callbacks/cuda_graph.py:251."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import conformer_ref as R
+
+dev = "cuda"
+NODROP = dict(dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0, dropout_emb=0.0)
+
+
+def _model(over, vocab=20, size="small", spec_augment=False, **kw):
+    from nemo_amd.models import EncDecCTCModel, conformer_ctc_config
+    cfg = conformer_ctc_config(size, vocab_size=vocab, spec_augment=spec_augment, **over)
+    cfg["preprocessor"]["dither"] = 0.0
+    cfg.update(kw)
+    return EncDecCTCModel(cfg)
+
+
+def _batch(B=4, secs=1.0, vocab=20, seed=8, lens=None):
+    audio, alen, tok, tl = R.synthetic_batch(B, secs, vocab=vocab, seed=seed)
+    if lens is not None:
+        alen = torch.tensor(lens)
+    return [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+
+
+def _run(over, graphs, steps, batches, dtype=torch.float32, lr=1e-3, seed=21, hook=False):
+    torch.manual_seed(seed)
+    model = _model(dict(over, compute_dtype=dtype)).to(dev).train()
+    model.decoder.compute_dtype = dtype
+    model.encoder.use_graphs = graphs
+    model.optimizer_in_backward = hook
+    model.setup_optimization(dict(name="adamw", lr=lr, betas=[0.9, 0.98], weight_decay=1e-3))
+    losses = [model.fit_step(batches[i % len(batches)])["loss"].item() for i in range(steps)]
+    torch.cuda.synchronize()
+    return model, losses
+
+
+def test_recorded_sequence_is_the_eager_sequence_fp32():
+    over = dict(d_model=64, n_heads=4, n_layers=3, **NODROP)
+    batches = [_batch(lens=[16000, 12000, 16000, 9000])]
+    m_g, l_g = _run(over, True, 7, batches)
+    m_e, l_e = _run(over, False, 7, batches)
+    info = m_g.encoder.graph_info()
+    assert len(info) == 1 and info[0]["fwd_graphs"] == 1 and info[0]["bwd_graphs"] == 1 and info[0]["bwd_host_calls"] == 0, info
+    assert m_e.encoder.graph_info() == []
+    for a, b in zip(l_g, l_e):
+        assert abs(a - b) <= 2e-5 * abs(b), (l_g, l_e)
+    for fa, fb in zip(m_g.flats(), m_e.flats()):
+        assert (fa.flat - fb.flat).norm() <= 1e-5 * fb.flat.norm()
+    # BatchNorm bookkeeping happens inside the recorded forward too
+    assert int(m_g.encoder.layers[0].conv.batch_norm.num_batches_tracked) == 7
+    assert torch.allclose(m_g.encoder.layers[0].conv.batch_norm.running_var, m_e.encoder.layers[0].conv.batch_norm.running_var, rtol=1e-5)
+
+
+def test_recorded_sequence_with_hooks_between_the_segments():
+    """optimizer-behind-backward installs a per-layer hook: the backward sequence is cut at every hook, which stays a live call"""
+    over = dict(d_model=64, n_heads=4, n_layers=3, **NODROP)
+    batches = [_batch()]
+    m_g, l_g = _run(over, True, 7, batches, hook=True)
+    m_e, l_e = _run(over, False, 7, batches, hook=True)
+    info = m_g.encoder.graph_info()
+    assert info and info[0]["bwd_host_calls"] >= 3 + 2 and info[0]["bwd_graphs"] == info[0]["bwd_host_calls"] + 1, info
+    for a, b in zip(l_g, l_e):
+        assert abs(a - b) <= 1e-3 * abs(b), (l_g, l_e)
+    assert l_g[-1] < 0.95 * l_g[0]
+
+
+def test_each_batch_shape_gets_its_own_recording():
+    over = dict(d_model=64, n_heads=4, n_layers=2, **NODROP)
+    batches = [_batch(B=4, secs=1.0), _batch(B=2, secs=1.5, seed=9)]
+    m_g, l_g = _run(over, True, 10, batches)
+    m_e, l_e = _run(over, False, 10, batches)
+    assert len(m_g.encoder.graph_info()) == 2
+    for a, b in zip(l_g, l_e):
+        assert abs(a - b) <= 5e-5 * abs(b), (l_g, l_e)
+
+
+def _step_grads(model, batch):
+    model._optimizer.zero_grad()
+    loss = model.training_step(batch)["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.item(), [fp.grad.detach().clone() for fp in model.flats()]
+
+
+def test_dropout_masks_follow_the_device_step_word_bf16():
+    """bf16 production kernels (fused attention, MFMA GEMM epilogues, LayerNorm-backward casts) with every dropout site on:
+    (1) with the step word forced to 0 a replayed step regenerates exactly the masks of the eager step with the recorded seed, in
+    forward AND backward (gradients agree); (2) consecutive replays draw different masks."""
+    from nemo_amd import ops
+    over = dict(d_model=64, n_heads=1, n_layers=2, dropout=0.1, dropout_pre_encoder=0.1, dropout_att=0.1, dropout_emb=0.1,
+                compute_dtype=torch.bfloat16)
+    batch = _batch(B=4, secs=2.0)
+    torch.manual_seed(3)
+    mg = _model(over).to(dev).train()
+    mg.decoder.compute_dtype = torch.bfloat16
+    mg.setup_optimization(dict(name="adamw", lr=0.0))
+    enc = mg.encoder
+    for _ in range(enc.graph_warmup):
+        _step_grads(mg, batch)
+    l3, _ = _step_grads(mg, batch)   # recorded + replayed
+    assert enc.graph_info() and enc.graph_info()[0]["bwd_graphs"] == 1
+    seed_rec = enc._step_seed        # the seed baked into the recorded keys
+    l4, _ = _step_grads(mg, batch)
+    assert l3 != l4, "two replays drew the same dropout masks"
+    enc._step_word.fill_(-ops.STEP_WORD_INC)      # the forward graph adds the increment first: the kernels then read 0
+    lz, gz = _step_grads(mg, batch)
+    assert int(enc._step_word) == 0
+    # the eager step with the same seed
+    enc.use_graphs = False
+    enc._step_seed = seed_rec - 1
+    le, ge = _step_grads(mg, batch)
+    assert abs(lz - le) <= 1e-5 * abs(le), (lz, le)
+    for a, b in zip(gz, ge):
+        assert (a - b).norm() <= 2e-3 * b.norm(), ((a - b).norm() / b.norm())
+    assert abs(l3 - le) > 1e-6 * abs(le)          # (and a non-zero word gave other masks)
+
+
+def test_backward_of_an_overwritten_forward_is_refused():
+    over = dict(d_model=64, n_heads=4, n_layers=2, **NODROP)
+    model = _model(over).to(dev).train()
+    batch = _batch()
+    for _ in range(model.encoder.graph_warmup + 1):
+        model.training_step(batch)["loss"].backward()
+    first = model.training_step(batch)["loss"]
+    model.training_step(batch)["loss"].backward()   # a later forward of the same shape owns the activations now
+    with pytest.raises(RuntimeError, match="overwritten by a later forward"):
+        first.backward()
+
+
+def _dp_worker(rank, world, port, out_dir, over, graphs):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks on the one GPU; gloo stages through the host
+    try:
+        torch.cuda.set_device(0)
+        torch.manual_seed(5)
+        model = _model(over).to(dev).train()
+        model.encoder.use_graphs = graphs
+        model.setup_optimization(dict(name="adamw", lr=1e-3, betas=[0.9, 0.98], weight_decay=0.0))
+        audio, alen, tok, tl = R.synthetic_batch(4, 1.0, vocab=20, seed=8)
+        alen = torch.tensor([16000, 9000, 14000, 16000])
+        sl = slice(2 * rank, 2 * rank + 2)
+        batch = [audio[sl].to(dev), alen[sl].to(dev), tok[sl].to(dev), tl[sl].to(dev)]
+        losses = [model.fit_step(batch)["loss"].item() for _ in range(6)]
+        torch.cuda.synchronize()
+        torch.save(dict(losses=losses, flat=[fp.flat.detach().cpu() for fp in model.flats()], info=model.encoder.graph_info(),
+                        bn=model.encoder.layers[1].conv.batch_norm.running_var.detach().cpu()),
+                   os.path.join(out_dir, f"g{int(graphs)}_rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_replay_with_live_collectives_between_the_segments(tmp_path):
+    """data parallel: SyncBatchNorm all-reduces (forward and backward of every layer) and the bucketed gradient exchange stay live
+    host calls between graph segments; the replicas must follow the eager two-rank run and stay identical to each other"""
+    import torch.multiprocessing as mp
+    over = dict(d_model=64, n_heads=4, n_layers=2, **NODROP)
+    res = {}
+    for graphs in (True, False):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        mp.spawn(_dp_worker, args=(2, port, str(tmp_path), over, graphs), nprocs=2, join=True)
+        res[graphs] = [torch.load(tmp_path / f"g{int(graphs)}_rank{r}.pt") for r in (0, 1)]
+    g0, g1 = res[True]
+    e0, _ = res[False]
+    info = g0["info"]
+    # forward: one SyncBN exchange per layer -> n_layers + 1 segments; backward: per layer one SyncBN exchange + the layer's hook
+    assert info and info[0]["fwd_host_calls"] == 2 and info[0]["bwd_host_calls"] >= 2 * 2 + 2, info
+    for a, b in zip(g0["flat"], g1["flat"]):
+        assert torch.equal(a, b)
+    assert torch.equal(g0["bn"], g1["bn"])
+    for a, b in zip(g0["losses"], e0["losses"]):
+        assert abs(a - b) <= 1e-4 * abs(b), (g0["losses"], e0["losses"])
+    for a, b in zip(g0["flat"], e0["flat"]):
+        assert (a - b).norm() <= 1e-4 * b.norm()
