@@ -218,15 +218,18 @@ int mi355x_relpos_softmax_bwd(const void* dpd, int dpd_dtype, const void* s_in, 
 /* ---- fused rel-pos attention (bf16, d_k = 64): RelPositionMultiHeadAttention.forward, multi_head_attention.py:272-354.
  * qkv [B*T, ldq = 3d] (q|k|v), pos = linear_pos(pos_emb) [2T-1, ldp], bias_u/v f32 [H*d_k], len i64 [B]
  * -> ctx [B*T, ldo] bf16, lse f32 [B,H,T] (log-sum-exp of the masked scaled scores, kept for backward).
+ * ctx_lo (optional, same layout as ctx): the bf16 ROUNDING RESIDUAL of ctx (O = ctx + ctx_lo to ~16 mantissa bits) for
+ * mi355x_attn_delta -- the reference's softmax backward works on fp32 probabilities (multi_head_attention.py:137-138 under
+ * autocast), i.e. without the error a delta taken from the rounded O alone puts on nearly-cancelling score gradients.
  * Dropout index of probability (b,h,i,j) = ((h*B+b)*T + i)*Tp + j.                                                   */
 int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, long long ldp, const void* bias_u,
-                            const void* bias_v, const void* len, void* ctx, long long ldo, void* lse, int B, int H, int T,
-                            int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold, float drop_scale,
+                            const void* bias_v, const void* len, void* ctx, void* ctx_lo, long long ldo, void* lse, int B, int H,
+                            int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold, float drop_scale,
                             void* stream);
 
-/* backward of the fused attention.  delta[b,h,i] = sum_dv dO*O.  dq kernel: qu = q+u, qv = q+v ([B*T,d] bf16, from
+/* backward of the fused attention.  delta[b,h,i] = sum_dv dO*(O + O_lo) (O_lo optional, see above).  dq kernel: qu = q+u, qv = q+v ([B*T,d] bf16, from
  * mi355x_qbias), recomputes P from lse, returns dQu and dQv ([B*T,d] bf16; dq = dQu+dQv, d pos_bias_{u,v} = column sums). */
-int mi355x_attn_delta(const void* dO, const void* O, void* delta, int B, int H, int T, int d, void* stream);
+int mi355x_attn_delta(const void* dO, const void* O, const void* O_lo, void* delta, int B, int H, int T, int d, void* stream);
 /* ds_out (optional): the score gradient in the layout of the reference's matrix_bd BEFORE rel_shift
  * (multi_head_attention.py:259-270), cut into 32 x 32 bf16 blocks for mi355x_relpos_flash_bwd_dpos:
  * X[h][b][it][s][q][cl] = dS[b,h, i = 32*it+q, j] at position c = T-1+j-i = T-32+32*(s-it)+cl, it < ceil(T/32), s <= ceil(T/32);

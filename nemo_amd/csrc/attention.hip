@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
                                                                   const bf16_t* __restrict__ pos, long long ldp,
                                                                   const float* __restrict__ bias_u, const float* __restrict__ bias_v,
                                                                   const long long* __restrict__ len, bf16_t* __restrict__ ctx,
-                                                                  long long ldo, float* __restrict__ lse, int B, int H, int T,
+                                                                  bf16_t* __restrict__ ctx_lo, long long ldo,
+                                                                  float* __restrict__ lse, int B, int H, int T,
                                                                   int Tp, float scale, DropCfg drop) {
   drop_resolve(drop);
   __shared__ __attribute__((aligned(16))) bf16_t s_k2[2][ABK * ADK];   // 2 x 4 KiB (double-buffered)
@@ -326,6 +327,20 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
       for (int j = 0; j < 8; ++j) v[j] = sg[row * SG_LD + c8 + j];
       u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
       *reinterpret_cast<u32x4*>(ctx + ((long long)b * T + ii) * ldo + h * ADK + c8) = t;
+      if (ctx_lo) {
+        // what the bf16 rounding of O dropped, itself as bf16 (O = hi + lo to ~16 mantissa bits): backward's
+        // delta = sum dO * O multiplies a gradient that nearly cancels (dS = P * (dP - delta)); with delta taken from the
+        // rounded O alone the q / k / pos_bias_u gradients of near-uniform attention rows lose a digit
+        // (profiles/r3_flash_delta.md: 36 % -> 4 % at FastConformer-Large layer 0)
+        float lo[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          lo[2 * j] = v[2 * j] - __uint_as_float(t[j] << 16);
+          lo[2 * j + 1] = v[2 * j + 1] - __uint_as_float(t[j] & 0xffff0000u);
+        }
+        u32x4 tl = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(lo[4], lo[5]), pack_bf2(lo[6], lo[7])};
+        *reinterpret_cast<u32x4*>(ctx_lo + ((long long)b * T + ii) * ldo + h * ADK + c8) = tl;
+      }
     }
   }
 }
@@ -333,9 +348,11 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
 // =================================================================================================
 // backward
 // =================================================================================================
-// delta[b,h,i] = sum_dv dO[i,h,dv] * O[i,h,dv]   (one wave per row of [M, d]; 8 lanes per head at d_k = 64)
+// delta[b,h,i] = sum_dv dO[i,h,dv] * (O + O_lo)[i,h,dv]   (one wave per row of [M, d]; 8 lanes per head at d_k = 64);
+// O_lo (optional) = the rounding residual of O written by the forward kernel
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
-                                                         float* __restrict__ delta, int B, int H, int T, int d) {
+                                                         const bf16_t* __restrict__ O_lo, float* __restrict__ delta, int B,
+                                                         int H, int T, int d) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (row >= (long long)B * T) return;
@@ -350,6 +367,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
       for (int j = 0; j < 4; ++j) {
         acc += __uint_as_float(a[j] << 16) * __uint_as_float(o[j] << 16);
         acc += __uint_as_float(a[j] & 0xffff0000u) * __uint_as_float(o[j] & 0xffff0000u);
+      }
+      if (O_lo) {
+        const u32x4 l = *reinterpret_cast<const u32x4*>(O_lo + row * d + c);
+        float acl = 0.f;  // (the small terms are summed on their own before they meet the large ones)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acl += __uint_as_float(a[j] << 16) * __uint_as_float(l[j] << 16);
+          acl += __uint_as_float(a[j] & 0xffff0000u) * __uint_as_float(l[j] & 0xffff0000u);
+        }
+        acc += acl;
       }
     }
     acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
@@ -951,27 +978,29 @@ __global__ __launch_bounds__(256) void dpos_reduce_kernel(const float* __restric
 }
 
 extern "C" int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, long long ldp, const void* bias_u,
-                                       const void* bias_v, const void* len, void* ctx, long long ldo, void* lse, int B, int H,
-                                       int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold,
-                                       float drop_scale, void* stream) {
+                                       const void* bias_v, const void* len, void* ctx, void* ctx_lo, long long ldo, void* lse,
+                                       int B, int H, int T, int dk, int Tp, float scale, unsigned drop_key,
+                                       unsigned drop_threshold, float drop_scale, void* stream) {
   mi_clear_errors();
   if (!qkv || !pos || !bias_u || !bias_v || !len || !ctx || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
-  if (dk != ADK || (ldq % 24) || (ldp & 7) || (ldo & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)pos & 15) || ((uintptr_t)ctx & 15))
+  if (dk != ADK || (ldq % 24) || (ldp & 7) || (ldo & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)pos & 15) ||
+      ((uintptr_t)ctx & 15) || ((uintptr_t)ctx_lo & 15))
     return MI_ERR_ARG;
   DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   dim3 grid((T + ABQ - 1) / ABQ, H, B);
   MI_LAUNCH(relpos_flash_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldq,
                      (const bf16_t*)pos, ldp, (const float*)bias_u, (const float*)bias_v, (const long long*)len, (bf16_t*)ctx,
-                     ldo, (float*)lse, B, H, T, Tp, scale, dc);
+                     (bf16_t*)ctx_lo, ldo, (float*)lse, B, H, T, Tp, scale, dc);
   return mi_check_launch();
 }
 
-extern "C" int mi355x_attn_delta(const void* dO, const void* O, void* delta, int B, int H, int T, int d, void* stream) {
+extern "C" int mi355x_attn_delta(const void* dO, const void* O, const void* O_lo, void* delta, int B, int H, int T, int d,
+                                 void* stream) {
   mi_clear_errors();
   if (!dO || !O || !delta || B <= 0 || H <= 0 || T <= 0 || d != H * ADK) return MI_ERR_ARG;
   const long long rows = (long long)B * T;
   MI_LAUNCH(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dO, (const bf16_t*)O, (float*)delta, B, H, T, d);
+                     (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)O_lo, (float*)delta, B, H, T, d);
   return mi_check_launch();
 }
 

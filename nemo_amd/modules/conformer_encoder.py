@@ -239,6 +239,7 @@ class ConformerEncoder(NeuralModule):
         # (mi355x_bn_finalize_dev_count / mi355x_bn_swish_bwd_apply_dev_count) -- exact for ragged ranks, no host round trip.
         self._syncbn_group = None
         self.use_flash_attention = True  # bf16 + d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
+        self.flash_delta_residual = os.environ.get("MI355X_FLASH_DELTA_LO", "1") != "0"  # (A/B switch of the delta fix)
         self.grad_ready_hook = None  # callable(start, end) on the flat gradient buffer (data-parallel bucketing)
         # linear_pos weights of all layers sit together at the tail: their gradients come from ONE batched GEMM
         self._flatp = FlatParams(self, tail=tail)
@@ -396,7 +397,7 @@ class ConformerEncoder(NeuralModule):
         return (tuple(mel.shape), self._cdt(), str(mel.device), self._flatp.generation, self._syncbn_world(),
                 self.grad_ready_hook is not None, self._wgrad_join_per_layer, self.wgrad_side_stream, self.wgrad_grouped,
                 self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse,
-                self.use_flash_attention, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder)
+                self.use_flash_attention, self.flash_delta_residual, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder)
 
     def _graphed_forward(self, mel, length):
         """-> (out, enc_len, graph set, generation) from the recorded sequence, or None when this call has to run eagerly"""
@@ -858,8 +859,12 @@ class ConformerEncoder(NeuralModule):
         if flash:
             # fused rel-pos flash attention: scores / positional matrix never touch HBM; only the log-sum-exp is kept
             lse = torch.empty(B, H, T, dtype=torch.float32, device=dev)
-            ops.relpos_flash_fwd(qkv, 3 * dA, p, dA, bias_u, bias_v, lens, ctx, dA, lse, B, H, T, dk, Tp, scale, d_att)
-            return ctx, (None, None, None, None, lse)
+            # training: also the bf16 rounding residual of the context (backward's delta = sum dO * O needs more than the 8
+            # mantissa bits of the stored operand -- see mi355x_relpos_flash_fwd); it travels in the first slot of the saved tuple
+            ctx_lo = torch.empty(M, dA, dtype=cdt, device=dev) if (self.training and self.flash_delta_residual) else None
+            ops.relpos_flash_fwd(qkv, 3 * dA, p, dA, bias_u, bias_v, lens, ctx, dA, lse, B, H, T, dk, Tp, scale, d_att,
+                                 ctx_lo=ctx_lo)
+            return ctx, (ctx_lo, None, None, None, lse)
         qu = torch.empty(M, dA, dtype=cdt, device=dev)
         qv = torch.empty(M, dA, dtype=cdt, device=dev)
         ops.qbias(qkv, 3 * dA, bias_u, bias_v, qu, qv, M, dA)
@@ -890,11 +895,12 @@ class ConformerEncoder(NeuralModule):
         dqu = torch.empty(M, dA, dtype=cdt, device=dev)
         dqv = torch.empty(M, dA, dtype=cdt, device=dev)
         if lse is not None:
+            ctx_lo = qu  # (fused path: the first slot carries the context's rounding residual, q + u is recomputed here)
             qu = torch.empty(M, dA, dtype=cdt, device=dev)
             qv = torch.empty(M, dA, dtype=cdt, device=dev)
             ops.qbias(qkv, 3 * dA, bias_u, bias_v, qu, qv, M, dA)
             dlt = torch.empty(B, H, T, dtype=torch.float32, device=dev)
-            ops.attn_delta(dctx, ctx, dlt, B, H, T, dA)
+            ops.attn_delta(dctx, ctx, dlt, B, H, T, dA, O_lo=ctx_lo)
             # transient dS (un-shifted 32 x 32 blocks): dQ kernel -> linear_pos gradient kernel.  The latter feeds only the
             # (batched, end-of-backward) linear_pos weight gradient, so with the side stream it leaves the critical path; dS
             # then comes from the caching allocator (record_stream keeps the next layer's dQ kernel from overwriting it too early).

@@ -392,14 +392,15 @@ def relpos_softmax_bwd(dpd, s_in, dscore, dbdf, H, B, T, Tp, Pp, scale, drop: Dr
                                         scale, drop.key, drop.threshold, drop.scale, _stream()), "relpos_softmax_bwd")
 
 
-def relpos_flash_fwd(qkv, ldq, pos, ldp, bias_u, bias_v, lens, ctx, ldo, lse, B, H, T, dk, Tp, scale, drop: Dropout = NO_DROP):
-    check(lib.mi355x_relpos_flash_fwd(_ptr(qkv), ldq, _ptr(pos), ldp, _ptr(bias_u), _ptr(bias_v), _ptr(lens), _ptr(ctx), ldo,
-                                      _ptr(lse), B, H, T, dk, Tp, scale, drop.key, drop.threshold, drop.scale, _stream()),
-          "relpos_flash_fwd")
+def relpos_flash_fwd(qkv, ldq, pos, ldp, bias_u, bias_v, lens, ctx, ldo, lse, B, H, T, dk, Tp, scale, drop: Dropout = NO_DROP,
+                     ctx_lo=None):
+    check(lib.mi355x_relpos_flash_fwd(_ptr(qkv), ldq, _ptr(pos), ldp, _ptr(bias_u), _ptr(bias_v), _ptr(lens), _ptr(ctx),
+                                      _ptr(ctx_lo), ldo, _ptr(lse), B, H, T, dk, Tp, scale, drop.key, drop.threshold, drop.scale,
+                                      _stream()), "relpos_flash_fwd")
 
 
-def attn_delta(dO, O, delta, B, H, T, d):
-    check(lib.mi355x_attn_delta(_ptr(dO), _ptr(O), _ptr(delta), B, H, T, d, _stream()), "attn_delta")
+def attn_delta(dO, O, delta, B, H, T, d, O_lo=None):
+    check(lib.mi355x_attn_delta(_ptr(dO), _ptr(O), _ptr(O_lo), _ptr(delta), B, H, T, d, _stream()), "attn_delta")
 
 
 def relpos_ds_buffer(B, H, T, device, fill=None):

@@ -219,6 +219,23 @@ class _RoundBF16Fwd(torch.autograd.Function):
         return g
 
 
+class _RoundGradBF16(torch.autograd.Function):
+    """identity in the forward (the value stays an fp32 accumulator), the GRADIENT is stored as bf16 (e.g. the LSTM gate
+    pre-activations and the joint's logits: f32 forward tensors whose gradients are bf16 GEMM operands)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _qg(x: Tensor, cfg) -> Tensor:
+    return _RoundGradBF16.apply(x) if getattr(cfg, "emulate_bf16", False) else x
+
+
 def _q(x: Tensor, cfg) -> Tensor:
     return _RoundBF16.apply(x) if getattr(cfg, "emulate_bf16", False) else x
 

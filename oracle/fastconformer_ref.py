@@ -14,7 +14,7 @@ from . import squeezeformer_ref as SQ
 
 
 def encoder_forward(P, cfg: R.ConformerCfg, mel, mel_len, bn_training: bool = False):
-    x, enc_len = SQ.dw_striding_forward(P, mel, mel_len)
+    x, enc_len = SQ.dw_striding_forward(P, mel, mel_len, cfg=cfg)  # (cfg.emulate_bf16: bf16 storage points)
     B, T, d = x.shape
     if cfg.xscaling:
         x = x * math.sqrt(d)

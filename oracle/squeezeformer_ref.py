@@ -34,14 +34,20 @@ class SqueezeformerCfg:
     time_reduce_idx: Optional[int] = None
     time_recovery_idx: Optional[int] = None
     dropout_att: float = 0.0
+    # round to bf16 wherever the HIP bf16 path STORES bf16 (GEMM operand images of the weights, activations between kernels,
+    # and the matching gradients): the rounding-only error of this run against the plain fp32 run is what the bf16 parity
+    # tests derive their per-tensor tolerance from (same method as ConformerCfg.emulate_bf16)
+    emulate_bf16: bool = False
 
     @property
     def d_k(self):
         return self.d_model // self.n_heads
 
 
-def dw_striding_forward(P: Dict[str, Tensor], mel: Tensor, mel_len: Tensor, pfx="pre_encode."):
-    """mel [B, F, T] -> ([B, T', d], lengths): every layer of the stack sees a masked input (MaskedConvSequential)"""
+def dw_striding_forward(P: Dict[str, Tensor], mel: Tensor, mel_len: Tensor, pfx="pre_encode.", cfg=None):
+    """mel [B, F, T] -> ([B, T', d], lengths): every layer of the stack sees a masked input (MaskedConvSequential).
+    bf16 storage points of the HIP path (cfg.emulate_bf16): the ReLU outputs (conv1 and every pointwise stage), the depthwise
+    outputs, the pointwise / output-Linear weight images; conv1 and the depthwise kernels read fp32 weights."""
     B = mel.shape[0]
     x = mel.transpose(1, 2).unsqueeze(1)
     cur = mel_len.clone().float()
@@ -59,69 +65,76 @@ def dw_striding_forward(P: Dict[str, Tensor], mel: Tensor, mel_len: Tensor, pfx=
     for layer in stack:
         x = x * m
         if layer[0] == "relu":
-            x = torch.relu(x)
+            x = R._q(torch.relu(x) * m, cfg)  # (the HIP epilogue masks and rounds in one store; relu(x*m)*m == relu(x*m))
             continue
         _, name, stride, pad, groups = layer
-        x = F.conv2d(x, P[pfx + name + ".weight"], P[pfx + name + ".bias"], stride=stride, padding=pad, groups=groups)
+        w = P[pfx + name + ".weight"]
+        pointwise = stride == 1
+        x = F.conv2d(x, R._qw(w, cfg) if pointwise else w, P[pfx + name + ".bias"], stride=stride, padding=pad, groups=groups)
+        if groups > 1:
+            x = R._q(x, cfg)  # the depthwise output is the bf16 A operand of the pointwise GEMM
         if stride != 1:
             cur = torch.div(cur + 2 * pad - 3, stride, rounding_mode="floor") + 1  # calculate_conv_output_size
             m = mask(x, cur)
     x = x * m
     b, c, t, f = x.shape
-    x = F.linear(x.transpose(1, 2).reshape(b, t, c * f), P[pfx + "out.weight"], P[pfx + "out.bias"])
+    x = F.linear(x.transpose(1, 2).reshape(b, t, c * f), R._qw(P[pfx + "out.weight"], cfg), P[pfx + "out.bias"])
     return x, cur.long()
 
 
-def swish_conv_module(P, pfx, x: Tensor, valid: Tensor, kernel: int, bn_training: bool):
-    """ConformerConvolution(pointwise_activation='swish'): all of the depthwise / BatchNorm work on 2*d channels"""
-    h = F.linear(x, P[pfx + "pointwise_conv1.weight"].squeeze(-1), P[pfx + "pointwise_conv1.bias"])  # [B,T,2d]
+def swish_conv_module(P, pfx, x: Tensor, valid: Tensor, kernel: int, bn_training: bool, cfg=None):
+    """ConformerConvolution(pointwise_activation='swish'): all of the depthwise / BatchNorm work on 2*d channels.
+    bf16 storage points: pointwise_conv1 output, Swish * mask, depthwise output (batch statistics from its fp32 accumulators),
+    BatchNorm + Swish output, the two pointwise weight images."""
+    h = R._q(F.linear(x, R._qw(P[pfx + "pointwise_conv1.weight"], cfg).squeeze(-1), P[pfx + "pointwise_conv1.bias"]), cfg)  # [B,T,2d]
     h = h * torch.sigmoid(h)
-    h = h * valid.unsqueeze(-1).to(h.dtype)
+    h = R._q(h * valid.unsqueeze(-1).to(h.dtype), cfg)
     c2 = h.shape[-1]
     pad = (kernel - 1) // 2
     c = F.conv1d(F.pad(h.transpose(1, 2), (pad, pad)), P[pfx + "depthwise_conv.weight"], P[pfx + "depthwise_conv.bias"],
                  groups=c2)
+    cq = R._q(c, cfg)
     if bn_training:
         mean, var = c.mean(dim=(0, 2)), c.var(dim=(0, 2), unbiased=False)
     else:
         mean, var = P[pfx + "batch_norm.running_mean"], P[pfx + "batch_norm.running_var"]
-    c = (c - mean.view(1, c2, 1)) * torch.rsqrt(var.view(1, c2, 1) + 1e-5)
+    c = (cq - mean.view(1, c2, 1)) * torch.rsqrt(var.view(1, c2, 1) + 1e-5)
     c = c * P[pfx + "batch_norm.weight"].view(1, c2, 1) + P[pfx + "batch_norm.bias"].view(1, c2, 1)
-    c = c * torch.sigmoid(c)
-    return F.linear(c.transpose(1, 2), P[pfx + "pointwise_conv2.weight"].squeeze(-1), P[pfx + "pointwise_conv2.bias"])
+    c = R._q(c * torch.sigmoid(c), cfg)
+    return F.linear(c.transpose(1, 2), R._qw(P[pfx + "pointwise_conv2.weight"], cfg).squeeze(-1), P[pfx + "pointwise_conv2.bias"])
 
 
-def _sb(P, pfx, x):
-    return x * P[pfx + "scale"] + P[pfx + "bias"]
+def _sb(P, pfx, x, cfg=None):
+    return R._q(x * P[pfx + "scale"] + P[pfx + "bias"], cfg)  # ScaleBias writes the next GEMM's (bf16) operand
 
 
 def squeezeformer_layer(P, pfx, cfg: SqueezeformerCfg, x, pos_emb, valid, bn_training):
     acfg = R.ConformerCfg(d_model=cfg.d_model, n_heads=cfg.n_heads, n_layers=1, dropout=0, dropout_att=cfg.dropout_att,
-                          dropout_pre_encoder=0)
-    x = R._ln(P, pfx + "norm_self_att.", x + R.rel_pos_attention(P, pfx + "self_attn.", acfg, _sb(P, pfx + "self_attn_scale.", x),
+                          dropout_pre_encoder=0, emulate_bf16=cfg.emulate_bf16)
+    x = R._ln(P, pfx + "norm_self_att.", x + R.rel_pos_attention(P, pfx + "self_attn.", acfg, _sb(P, pfx + "self_attn_scale.", x, cfg),
                                                                pos_emb, valid, False))
     x = R._ln(P, pfx + "norm_feed_forward1.", x + R.feed_forward(P, pfx + "feed_forward1.", acfg,
-                                                                _sb(P, pfx + "feed_forward1_scale.", x), False))
-    x = R._ln(P, pfx + "norm_conv.", x + swish_conv_module(P, pfx + "conv.", _sb(P, pfx + "conv_scale.", x), valid,
-                                                          cfg.conv_kernel, bn_training))
+                                                                _sb(P, pfx + "feed_forward1_scale.", x, cfg), False))
+    x = R._ln(P, pfx + "norm_conv.", x + swish_conv_module(P, pfx + "conv.", _sb(P, pfx + "conv_scale.", x, cfg), valid,
+                                                          cfg.conv_kernel, bn_training, cfg))
     x = R._ln(P, pfx + "norm_feed_forward2.", x + R.feed_forward(P, pfx + "feed_forward2.", acfg,
-                                                                _sb(P, pfx + "feed_forward2_scale.", x), False))
+                                                                _sb(P, pfx + "feed_forward2_scale.", x, cfg), False))
     return x
 
 
-def time_reduction(P, pfx, x: Tensor, valid: Tensor):
-    """x [B,T,d], valid [B,T] -> ([B, ceil(T/2), d], valid[:, ::2])"""
+def time_reduction(P, pfx, x: Tensor, valid: Tensor, cfg=None):
+    """x [B,T,d], valid [B,T] -> ([B, ceil(T/2), d], valid[:, ::2]); bf16 storage: the depthwise output, the pointwise weights"""
     h = (x * valid.unsqueeze(-1).to(x.dtype)).transpose(1, 2)
     d = h.shape[1]
-    h = F.conv1d(h, P[pfx + "dw_conv.weight"], P[pfx + "dw_conv.bias"], stride=2, padding=3, groups=d)
-    h = F.conv1d(h, P[pfx + "pw_conv.weight"], P[pfx + "pw_conv.bias"]).transpose(1, 2)
+    h = R._q(F.conv1d(h, P[pfx + "dw_conv.weight"], P[pfx + "dw_conv.bias"], stride=2, padding=3, groups=d), cfg)
+    h = F.conv1d(h, R._qw(P[pfx + "pw_conv.weight"], cfg), P[pfx + "pw_conv.bias"]).transpose(1, 2)
     v2 = valid[:, ::2]
     return F.pad(h, (0, 0, 0, v2.shape[1] - h.shape[1])), v2
 
 
 def encoder_forward(P: Dict[str, Tensor], cfg: SqueezeformerCfg, mel: Tensor, mel_len: Tensor, bn_training: bool = False):
     """-> (encoded [B, d, T'], lengths [B]); dropout = 0 (parity configuration)"""
-    x, enc_len = dw_striding_forward(P, mel, mel_len)
+    x, enc_len = dw_striding_forward(P, mel, mel_len, cfg=cfg)
     B, T, d = x.shape
     if cfg.xscaling:
         x = x * math.sqrt(d)
@@ -133,11 +146,11 @@ def encoder_forward(P: Dict[str, Tensor], cfg: SqueezeformerCfg, mel: Tensor, me
     for i in range(cfg.n_layers):
         if cfg.time_reduce_idx is not None and i == cfg.time_reduce_idx:
             cache = (x, valid, pos_emb)
-            x, valid = time_reduction(P, "time_reduce_layer.", x, valid)
+            x, valid = time_reduction(P, "time_reduce_layer.", x, valid, cfg)
             pos_emb = R.rel_pos_table(x.shape[1], d).to(x.dtype)
         if cfg.time_reduce_idx is not None and i == rec_idx:
             x0, valid, pos_emb = cache
-            x = torch.repeat_interleave(x, repeats=2, dim=1)[:, : x0.shape[1]]
-            x = x0 + F.linear(x, P["time_recovery_layer.weight"], P["time_recovery_layer.bias"])
+            x = torch.repeat_interleave(R._q(x, cfg), repeats=2, dim=1)[:, : x0.shape[1]]
+            x = x0 + F.linear(x, R._qw(P["time_recovery_layer.weight"], cfg), P["time_recovery_layer.bias"])
         x = squeezeformer_layer(P, f"layers.{i}.", cfg, x, pos_emb, valid, bn_training)
     return x.transpose(1, 2), enc_len

@@ -17,16 +17,29 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
+from . import conformer_ref as R
 
-def lstm_layer(x: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor, b_hh: Tensor) -> Tensor:
-    """x [U, B, I] -> [U, B, H], zero initial state; written out gate by gate (an independent restatement of torch.nn.LSTM)"""
+
+class _Emu:
+    """`emulate_bf16` carrier for conformer_ref's rounding helpers (_q: value + gradient, _qw: weight image, _qg: gradient only)"""
+
+    def __init__(self, on):
+        self.emulate_bf16 = bool(on)
+
+
+def lstm_layer(x: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor, b_hh: Tensor, emulate_bf16: bool = False) -> Tensor:
+    """x [U, B, I] -> [U, B, H], zero initial state; written out gate by gate (an independent restatement of torch.nn.LSTM).
+    emulate_bf16: the HIP bf16 path's storage points -- both weight images, the recurrent operand h_{t-1} (the f32 h stays the
+    layer's output), and the gate pre-activations' GRADIENT (dz is the bf16 operand of the BPTT GEMMs); z, c, h are f32."""
+    e = _Emu(emulate_bf16)
+    w_ih, w_hh = R._qw(w_ih, e), R._qw(w_hh, e)
     U, B, _ = x.shape
     H = w_hh.shape[1]
     h = x.new_zeros(B, H)
     c = x.new_zeros(B, H)
     out = []
     for t in range(U):
-        z = F.linear(x[t], w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+        z = R._qg(F.linear(x[t], w_ih, b_ih) + F.linear(R._q(h, e) if t > 0 else h, w_hh, b_hh), e)
         i, f, g, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
         c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
         h = torch.sigmoid(o) * torch.tanh(c)
@@ -34,23 +47,30 @@ def lstm_layer(x: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor, b_hh: Tensor
     return torch.stack(out)
 
 
-def prediction_network(P: Dict[str, Tensor], targets: Tensor, pfx: str = "prediction.") -> Tensor:
+def prediction_network(P: Dict[str, Tensor], targets: Tensor, pfx: str = "prediction.", emulate_bf16: bool = False) -> Tensor:
     """targets i64 [B, U] (padded) -> g [B, H, U+1]"""
+    e = _Emu(emulate_bf16)
     emb = P[pfx + "embed.weight"]
-    y = emb[targets]                                             # [B, U, H]; the padding row (blank id) is zero
+    y = R._q(emb[targets], e)                                    # [B, U, H]; the padding row (blank id) is zero
     B, U, H = y.shape
     y = torch.cat([y.new_zeros(B, 1, H), y], dim=1).transpose(0, 1)  # SOS frame, then time-major for the LSTM
     layer = 0
     while f"{pfx}dec_rnn.lstm.weight_ih_l{layer}" in P:
         q = f"{pfx}dec_rnn.lstm."
+        if layer > 0:
+            y = R._q(y, e)  # (a further layer reads the bf16 copy of the previous layer's output)
         y = lstm_layer(y, P[f"{q}weight_ih_l{layer}"], P[f"{q}weight_hh_l{layer}"], P[f"{q}bias_ih_l{layer}"],
-                       P[f"{q}bias_hh_l{layer}"])
+                       P[f"{q}bias_hh_l{layer}"], emulate_bf16)
         layer += 1
     return y.transpose(0, 1).transpose(1, 2)
 
 
-def joint_network(P: Dict[str, Tensor], enc: Tensor, dec: Tensor) -> Tensor:
-    """enc [B, D, T], dec [B, H, U+1] -> logits [B, T, U+1, V+1]"""
-    f = F.linear(enc.transpose(1, 2), P["enc.weight"], P["enc.bias"]).unsqueeze(2)
-    g = F.linear(dec.transpose(1, 2), P["pred.weight"], P["pred.bias"]).unsqueeze(1)
-    return F.linear(torch.relu(f + g), P["joint_net.1.weight"], P["joint_net.1.bias"])
+def joint_network(P: Dict[str, Tensor], enc: Tensor, dec: Tensor, emulate_bf16: bool = False) -> Tensor:
+    """enc [B, D, T], dec [B, H, U+1] -> logits [B, T, U+1, V+1].
+    emulate_bf16: operand copies of both inputs, the three weight images, the projections f / g and ReLU(f + g) are bf16; the
+    logits stay f32 (the loss reads them) while their gradient is written as a bf16 GEMM operand."""
+    e = _Emu(emulate_bf16)
+    out = [k[:-len("weight")] for k in P if k.startswith("joint_net.") and k.endswith(".weight")][0]  # index 1, or 2 with dropout
+    f = R._q(F.linear(R._q(enc.transpose(1, 2), e), R._qw(P["enc.weight"], e), P["enc.bias"]), e).unsqueeze(2)
+    g = R._q(F.linear(R._q(dec.transpose(1, 2), e), R._qw(P["pred.weight"], e), P["pred.bias"]), e).unsqueeze(1)
+    return R._qg(F.linear(R._q(torch.relu(f + g), e), R._qw(P[out + "weight"], e), P[out + "bias"]), e)

@@ -194,3 +194,182 @@ def test_large_bf16_b2x20s_per_tensor_against_fp32_and_bf16_emulating_oracle():
                                                   loss_tol=tol_loss, bad=bad, tensors=table))
     assert abs(l_hip - l_32) / l_32 <= tol_loss, (l_hip, l_32, l_emu)
     assert not bad, bad[:10]
+
+
+# =====================================================================================================================
+# BASELINE.json configs[4] / configs[3] at their bf16 PRODUCTION geometry against the oracle: the same
+# derived-tolerance method as the Large test above -- the HIP bf16 path may not sit farther from the fp32 oracle than
+# BF16_SLACK x what bf16 rounding at the kernels' storage points alone explains (oracle run with `emulate_bf16`).
+# =====================================================================================================================
+def _per_tensor(got, o32, emu, zero_abs=2e-2):
+    gmax = max(g.abs().max().item() for g in o32.values())
+    table, bad = [], []
+    for n, r in o32.items():
+        e_hip, e_emu, e_hip_emu = _rel_l2(got[n], r), _rel_l2(emu[n], r), _rel_l2(got[n], emu[n])
+        cos = float(torch.dot(got[n].flatten(), r.flatten()) / (got[n].norm() * r.norm() + 1e-300))
+        table.append(dict(name=n, numel=int(r.numel()), ref_norm=r.norm().item(), hip_vs_fp32=e_hip, emu_vs_fp32=e_emu,
+                          hip_vs_emu=e_hip_emu, cos=cos))
+        if n.endswith(ZERO_GRADS):
+            if got[n].abs().max().item() > zero_abs * gmax:
+                bad.append((n, "zero-grad", got[n].abs().max().item(), gmax))
+            continue
+        if e_hip > BF16_SLACK * e_emu + 5e-3:
+            bad.append((n, e_hip, e_emu))
+    return table, bad
+
+
+def test_squeezeformer_medium_bf16_against_fp32_and_bf16_emulating_oracle():
+    """configs[4] geometry: Squeezeformer-Medium (squeezeformer_ctc_bpe.yaml: d_model 324, 4 heads -> d_k = 81 padded to 88 lanes
+    inside the weight images, activation pitch 328, 648-channel depthwise stage, 324 -> 328 sub-sampling channels), 4 layers with
+    the time reduction at layer 1 and the recovery at layer 3, conv kernel 31, ragged B = 3, T' = 401 (odd: the reduced rate pads
+    to 201), bf16 -- output and EVERY parameter gradient of a fixed linear functional against oracle/squeezeformer_ref.py.
+    Reference: nemo/collections/asr/modules/squeezeformer_encoder.py:130-400, parts/submodules/squeezeformer_modules.py:30-203."""
+    from nemo_amd.modules import SqueezeformerEncoder
+    from oracle import squeezeformer_ref as SQ
+    kw = dict(feat_in=80, n_layers=4, d_model=324, subsampling="dw_striding", subsampling_factor=4, n_heads=4,
+              conv_kernel_size=31, dropout=0.0, dropout_emb=0.0, dropout_att=0.0, adaptive_scale=True, time_reduce_idx=1,
+              time_recovery_idx=3)
+    torch.manual_seed(11)
+    enc = SqueezeformerEncoder(compute_dtype=torch.bfloat16, **kw)
+    with torch.no_grad():  # the recipe initialises scale = 1, bias = 0, pos_bias = 0: move them off their trivial values
+        for n, p in enc.named_parameters():
+            if n.endswith("_scale.scale"):
+                p.add_(0.2 * torch.randn_like(p))
+            elif n.endswith("_scale.bias") or "pos_bias" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    cfg = SQ.SqueezeformerCfg(feat_in=80, d_model=324, n_heads=4, n_layers=4, conv_kernel=31, time_reduce_idx=1,
+                              time_recovery_idx=3)
+    g = torch.Generator().manual_seed(4)
+    B, T = 3, 1603
+    x = torch.randn(B, 80, T, generator=g)
+    length = torch.tensor([T, 1201, 777])
+    T2 = ((T - 1) // 2 + 1 - 1) // 2 + 1
+    assert T2 == 401
+    w = torch.randn(B, 324, T2, generator=g) / 324 ** 0.5
+    names = [n for n, _ in enc.named_parameters()]
+
+    def oracle(emulate):
+        P = {k: v.detach().clone().float().requires_grad_(k in names) if v.is_floating_point() else v.detach().clone()
+             for k, v in enc.state_dict().items()}
+        c = dataclasses.replace(cfg, emulate_bf16=emulate)
+        y, yl = SQ.encoder_forward(P, c, x, length, bn_training=True)
+        valid = (torch.arange(y.shape[2]).unsqueeze(0) < yl.unsqueeze(1)).unsqueeze(1)
+        (y * w * valid).sum().backward()
+        return y.detach() * valid, yl, {k: P[k].grad.double() for k in names if P[k].grad is not None}, valid
+
+    y32, yl32, g32, valid = oracle(False)
+    yemu, _, gemu, _ = oracle(True)
+    enc = enc.to(dev).train()
+    enc.flat_parameters().zero_grad()
+    y, yl = enc(audio_signal=x.to(dev), length=length.to(dev))
+    assert yl.tolist() == yl32.tolist()
+    (y.float() * (w * valid).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    yh = y.detach().float().cpu() * valid
+    e_y, e_y_emu = _rel_l2(yh.double(), y32.double()), _rel_l2(yemu.double(), y32.double())
+    got = {n: p.grad.detach().double().cpu() for n, p in enc.named_parameters()}
+    assert set(g32) <= set(got)
+    table, bad = _per_tensor(got, g32, gemu)
+    _report("parity_squeezeformer_medium_bf16.json",
+            dict(config="Squeezeformer-CTC-Medium geometry bf16 (BASELINE.json configs[4]): d=324, H=4 (d_k 81 -> 88), 4 layers with "
+                        "time reduction / recovery, k=31, B=3 ragged, T'=401", output_hip_vs_fp32=e_y, output_emu_vs_fp32=e_y_emu,
+                 slack=BF16_SLACK, bad=bad, n_tensors=len(table), tensors=table))
+    assert e_y <= BF16_SLACK * e_y_emu + 5e-3, (e_y, e_y_emu)
+    assert not bad, bad[:10]
+
+
+def _rnnt_large(cdt):
+    from nemo_amd.models import EncDecRNNTModel, fastconformer_transducer_config
+    cfg = fastconformer_transducer_config("large", vocab_size=1024, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0,
+                                          dropout_emb=0.0, compute_dtype=cdt)
+    cfg["preprocessor"]["dither"] = 0.0
+    cfg["decoder"]["prednet"]["dropout"] = 0.0
+    cfg["joint"]["jointnet"]["dropout"] = 0.0
+    m = EncDecRNNTModel(cfg)
+    m.decoder.compute_dtype = m.joint.compute_dtype = cdt
+    return m
+
+
+def test_fastconformer_transducer_large_bf16_against_fp32_and_bf16_emulating_oracle():
+    """configs[3] geometry: FastConformer-Transducer-Large (fast-conformer_transducer_bpe.yaml: 17 layers, d_model 512, 8 heads,
+    x8 dw_striding with 256 channels, conv kernel 9; prediction network one 640-wide LSTM layer; joint 640; vocabulary 1024;
+    fused joint + loss in sub-batches of 4), bf16, B = 2 x 20 s ragged (T' = 251 / 196, U = 60 / 41): the RNN-T loss and EVERY
+    parameter gradient (encoder, prediction network, joint) against oracle/{fastconformer,transducer,rnnt}_ref.py in fp32 and with
+    bf16 rounding emulated at the kernels' storage points.  Reference: modules/rnnt.py:552-830,1280-1720, losses/rnnt.py,
+    modules/conformer_encoder.py:593-759 (subsampling='dw_striding')."""
+    from oracle import fastconformer_ref as FC
+    from oracle import rnnt_ref as RL
+    from oracle import transducer_ref as TR
+    torch.manual_seed(7)
+    model = _rnnt_large(torch.bfloat16)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "pos_bias" in n:
+                p.add_(0.05 * torch.randn_like(p))
+    V = 1024
+    audio, alen, tok, tl = R.synthetic_batch(2, 20.0, vocab=V, seed=77)
+    alen = torch.tensor([320000, 250000])
+    tl = torch.tensor([60, 41])
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, _ in model.named_parameters()]
+    ecfg = R.ConformerCfg(feat_in=80, d_model=512, n_heads=8, n_layers=17, conv_kernel=9, vocab=V, dropout=0.0, dropout_att=0.0,
+                          dropout_pre_encoder=0.0)
+
+    def oracle(emulate):
+        P = {k: (v.clone().float().requires_grad_(k in names) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        sub = lambda pfx: {k[len(pfx):]: v for k, v in P.items() if k.startswith(pfx)}
+        with torch.no_grad():
+            mel, mel_len = R.log_mel_features(audio, alen, n_mels=80)
+        enc, enc_len = FC.encoder_forward(sub("encoder."), dataclasses.replace(ecfg, emulate_bf16=emulate), mel, mel_len,
+                                          bn_training=True)
+        dec = TR.prediction_network(sub("decoder."), tok, emulate_bf16=emulate)
+        logits = TR.joint_network(sub("joint."), enc, dec, emulate_bf16=emulate)
+        costs, dlogits = RL.rnnt_loss_and_grad(logits, tok, enc_len, tl, blank=V, reduction="mean")  # mean over the batch
+        logits.backward(dlogits.to(logits.dtype))
+        return float(costs), enc_len, {k: P[k].grad.double() for k in names if P[k].grad is not None}
+
+    l32, enc_len32, g32 = oracle(False)
+    lemu, _, gemu = oracle(True)
+    model = model.to(dev).train()
+    batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+    for fp in model.flats():
+        fp.zero_grad()
+    loss = model.training_step(batch)["loss"]
+    loss.backward()
+    model._after_backward()
+    torch.cuda.synchronize()
+    got = {n: p.grad.detach().double().cpu() for n, p in model.named_parameters()}
+    missing = set(g32) - set(got)
+    assert not missing, missing
+    table, bad = _per_tensor(got, g32, gemu)
+    tol_loss = BF16_SLACK * abs(lemu - l32) / abs(l32) + 1e-3
+    _report("parity_transducer_large_bf16.json",
+            dict(config="FastConformer-Transducer-Large bf16 (BASELINE.json configs[3] geometry): 17 layers d=512 x8 dw_striding, LSTM 640, "
+                        "joint 640, V=1024, fused_batch_size 4, B=2x20s ragged", loss_hip=loss.item(), loss_fp32_oracle=l32,
+                 loss_bf16_emulated=lemu, loss_tol=tol_loss, slack=BF16_SLACK, bad=bad, n_tensors=len(table), tensors=table))
+    assert abs(loss.item() - l32) / abs(l32) <= tol_loss, (loss.item(), l32, lemu)
+    assert not bad, bad[:10]
+
+
+def test_large_bf16_full_benchmark_batch_loss_against_the_committed_oracle_value(golden_dir):
+    """BASELINE.json configs[1] at the batch the benchmark times (B = 32 x 20 s; the gradient test above runs B = 2): the CTC
+    loss of the HIP bf16 path against the CPU oracle's value for exactly this batch and these weights, computed once by
+    oracle/make_large_b32_loss.py (the oracle needs minutes at this size) and committed as tests/golden/oracle_large_b32_loss.json.
+    Tolerance derived as above from the oracle's own bf16-emulating run."""
+    with open(os.path.join(golden_dir, "oracle_large_b32_loss.json")) as f:
+        z = json.load(f)
+    l32, lemu = z["fp32"]["loss"], z["bf16_emulated"]["loss"]
+    cfg = R.ConformerCfg.large(vocab=128, dropout=0.0, dropout_att=0.0, dropout_pre_encoder=0.0)
+    P = R.init_params(cfg, seed=0)
+    batch = R.synthetic_batch(32, 20.0, vocab=128, seed=1234)
+    model = _model("large", 128, cdt=torch.bfloat16)
+    _load(model, P)
+    model = model.to(dev).train()
+    gb = [t.to(dev) for t in batch]
+    logp, enc_len, _ = model.forward(input_signal=gb[0], input_signal_length=gb[1])
+    loss = model.loss(log_probs=logp, targets=gb[2], input_lengths=enc_len, target_lengths=gb[3])
+    torch.cuda.synchronize()
+    tol = BF16_SLACK * abs(lemu - l32) / l32 + 1e-3
+    _report("parity_large_bf16_b32x20s_loss.json", dict(config=z["config"], loss_hip=loss.item(), loss_fp32_oracle=l32,
+                                                        loss_bf16_emulated=lemu, tol=tol))
+    assert abs(loss.item() - l32) / l32 <= tol, (loss.item(), l32, lemu)

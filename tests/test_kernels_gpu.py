@@ -390,13 +390,20 @@ def test_relpos_flash_attention_fwd(T):
     lens = torch.tensor([T, max(1, T // 2 + 3), 1])
     ctx_ref, lse_ref, _ = _attn_ref(qkv, pos, u, v, lens, B, H, T, dk)
     ctx = torch.full((B * T, d), float("nan"), device=dev, dtype=torch.bfloat16)
+    ctx_lo = torch.full((B * T, d), float("nan"), device=dev, dtype=torch.bfloat16)
     lse = torch.zeros(B, H, T, device=dev)
     Tp = (T + 7) // 8 * 8
     o.relpos_flash_fwd(qkv.to(dev), 3 * d, pos.to(dev), d, u.to(dev), v.to(dev), lens.to(dev), ctx, d, lse, B, H, T, dk, Tp,
-                       1.0 / math.sqrt(dk))
+                       1.0 / math.sqrt(dk), ctx_lo=ctx_lo)
     torch.cuda.synchronize()
     assert torch.isfinite(ctx.float()).all()
     assert rel_err(ctx, ctx_ref) < 5e-3, rel_err(ctx, ctx_ref)  # (measured 1.3-1.9e-3: bf16 probabilities)
+    # the rounding residual: |lo| <= half an ulp of ctx, and it is what bf16 dropped of the kernel's own f32 accumulators --
+    # checked through the one place it is used: delta = sum dO * (ctx + lo) against the same product with ctx alone has to
+    # move by the rounding of ctx (~2^-9 relative per element), not more
+    lo = ctx_lo.float()
+    assert torch.isfinite(lo).all() and (lo.abs() <= ctx.float().abs() * 2.0 ** -8 + 1e-30).all()
+    assert lo.abs().max() > 0
     for b in range(B):
         n = int(lens[b])
         assert (lse[b, :, :n].cpu() - lse_ref[b, :, :n]).abs().max() < 2e-2
