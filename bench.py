@@ -41,6 +41,13 @@ def parse():
     ap.add_argument("--no-spec-augment", action="store_true", help="drop the recipe's SpecAugment (on by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--var-len", default=None, metavar="LO:HI",
+                    help="variable-length workload (BASELINE configs[4]: '5:30'): utterance durations uniform in [LO, HI] seconds, "
+                         "batches shaped by --sampler, value = VALID audio seconds per second")
+    ap.add_argument("--sampler", default="semisort", choices=["semisort", "bucket", "random"],
+                    help="--var-len batch shaping: semisort = SemiSortBatchSampler (asr_batching.py:27-204), bucket = static "
+                         "duration buckets (BucketingDataset / synced_randomized), random = unshaped batches (padding stress)")
+    ap.add_argument("--buckets", type=int, default=8)
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -55,6 +62,49 @@ def synthetic_batch(B, secs, vocab=128, seed=1234):
     U = max(1, int(3 * secs))
     tokens = torch.randint(0, vocab, (B, U), generator=g)
     return audio, torch.full((B,), S, dtype=torch.int64), tokens, torch.full((B,), U, dtype=torch.int64)
+
+
+def var_len_batches(a, rank, world, vocab, dev):
+    """--var-len LO:HI: one synthetic corpus of (warmup + steps) x batch x world utterances with durations uniform in [LO, HI] s
+    (the same table on every rank), cut into batches by the chosen sampler, every batch padded to ITS longest utterance
+    (_speech_collate_fn semantics) and resident in HBM before the clock starts.  Returns (batches, valid seconds per batch)."""
+    import numpy as np
+    from nemo_amd.data import DurationBucketBatchSampler, SemiSortBatchSampler
+    lo, hi = (float(x) for x in a.var_len.split(":"))
+    n_steps = a.warmup + a.steps
+    n = n_steps * a.batch * world
+    if a.sampler == "bucket":  # only full batches are kept per bucket and rank: a corpus with room for the dropped tails
+        n += a.buckets * a.batch * world
+    durs = np.random.RandomState(4321).uniform(lo, hi, size=n)
+    if a.sampler == "semisort":
+        sm = SemiSortBatchSampler(rank, world, durs, a.batch, batch_shuffle=True, drop_last=True, randomization_factor=0.1, seed=42,
+                                  synced_rng=True)
+    elif a.sampler == "bucket":
+        sm = DurationBucketBatchSampler(rank, world, durs, a.batch, a.buckets, min_duration=lo, max_duration=hi, drop_last=True)
+    else:
+        perm = np.random.RandomState(7).permutation(n)[rank::world]
+        sm = [perm[i * a.batch:(i + 1) * a.batch].tolist() for i in range(len(perm) // a.batch)]
+    idx_batches = list(sm)
+    if not idx_batches:
+        raise SystemExit("bench.py --var-len: the corpus is too small for one full batch per rank")
+    if len(idx_batches) < n_steps:  # (bucket tails dropped): cycle -- the shapes repeat, the work per step is unchanged
+        idx_batches = (idx_batches * (n_steps // max(1, len(idx_batches)) + 1))
+    idx_batches = idx_batches[:n_steps]
+    g = torch.Generator().manual_seed(1234 + rank)
+    batches, valid = [], []
+    for ib in idx_batches:
+        d = durs[ib]
+        lens = torch.tensor(np.round(d * 16000).astype(np.int64))
+        S = int(lens.max())
+        audio = 0.1 * torch.randn(len(ib), S, generator=g)
+        audio *= (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1))          # collate pads with zeros
+        tl = torch.tensor(np.maximum(1, (3 * d).astype(np.int64)))
+        tok = torch.randint(0, vocab, (len(ib), int(tl.max())), generator=g)
+        batches.append([audio.to(dev), lens.to(dev), tok.to(dev), tl.to(dev)])
+        valid.append(float(d.sum()))
+    pad = 1.0 - sum(valid) / sum(float(durs[ib].max()) * len(ib) for ib in idx_batches)
+    return batches, valid, {"durations": f"uniform {lo:g}-{hi:g} s", "sampler": a.sampler + (f" ({a.buckets} buckets)" if a.sampler == "bucket" else ""),
+                            "padded_sample_fraction": round(pad, 4), "distinct_padded_lengths": len({b[0].shape[1] for b in batches})}
 
 
 def cpu_baseline(size, secs, vocab, batch, steps, budget_s=40.0):
@@ -320,8 +370,15 @@ def main():
         model.decoder.compute_dtype = cdt
     model = model.to(dev).train()
     model.setup_optimization()
-    audio, alen, tok, tl = synthetic_batch(a.batch, a.secs, vocab=vocab, seed=1234 + rank)
-    batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+    var_info = None
+    if a.var_len:
+        a.no_roofline = a.no_cpu_baseline = True  # (both describe the fixed-length headline workload)
+        batches, valid_secs, var_info = var_len_batches(a, rank, world, vocab, dev)
+    else:
+        audio, alen, tok, tl = synthetic_batch(a.batch, a.secs, vocab=vocab, seed=1234 + rank)
+        batches = [[audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]] * (a.warmup + a.steps)
+        valid_secs = [a.batch * a.secs] * (a.warmup + a.steps)
+    batch = batches[-1]
 
     def barrier():
         if world > 1:
@@ -329,21 +386,36 @@ def main():
         torch.cuda.synchronize()
 
     loss = None
-    for _ in range(a.warmup):
-        loss = model.fit_step(batch)["loss"]
+    for i in range(a.warmup):
+        loss = model.fit_step(batches[i])["loss"]
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)] if a.var_len else None
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = model.fit_step(batch)["loss"]
+    for i in range(a.steps):
+        if marks:
+            marks[i].record()
+        loss = model.fit_step(batches[a.warmup + i])["loss"]
+    if marks:
+        marks[-1].record()
     host_s = time.perf_counter() - t0  # host time to ISSUE the K steps (the GPU may still be running the last ones)
     barrier()
     dt = time.perf_counter() - t0
+    timed_valid = sum(valid_secs[a.warmup:])
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     ms = dt / a.steps * 1e3
-    value = world * a.batch * a.secs / (dt / a.steps)
+    if a.var_len:
+        tv = torch.tensor([timed_valid], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(tv)
+        value = tv.item() / dt  # VALID audio seconds of all ranks per wall-clock second
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+        var_info.update({"valid_audio_seconds_timed": round(tv.item(), 1),
+                         "ms_per_step_min_median_max": [round(per_step[0], 2), round(per_step[len(per_step) // 2], 2), round(per_step[-1], 2)]})
+    else:
+        value = world * a.batch * a.secs / (dt / a.steps)
     final_loss = float(loss.item())
 
     # ---- what the gradient exchange looked like (diagnosable SCALE runs): collective library, buckets, exposed time
@@ -466,6 +538,9 @@ def main():
                                + (")" if a.no_spec_augment else ", SpecAugment)"),
                        "final_loss": round(final_loss, 4)},
         }
+        if var_info is not None:
+            line["config"]["workload"] += f"; VARIABLE LENGTH: {var_info['durations']}, batches by {var_info['sampler']}"
+            line["config"]["variable_length"] = var_info
         if roof is not None:
             line["roofline"] = roof
         if roof_hbm is not None:

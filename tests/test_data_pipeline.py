@@ -242,3 +242,40 @@ def test_semi_sorted_sampler_invariants_for_arbitrary_sizes():
         assert len(flat) - len(set(flat)) <= world * bs  # repeats come from the padding batches only
         assert all(len(x) <= bs for b in per_rank for x in b)
     check()
+
+
+def test_duration_bucket_sampler_follows_the_reference_bucketing_semantics():
+    """static bucketing (convert_to_tarred_audio_dataset.py:749-757 equal-width duration ranges; BucketingDataset batches inside one
+    bucket; RandomizedChainDataset(rnd_seed=0) visits the buckets in RandomState(0)'s permutation on EVERY rank, audio_to_text.py:
+    1374-1389; calc_bucketing_batch_sizes' linear scaling, audio_to_text_dataset.py:961-1000)"""
+    import numpy as np
+    from nemo_amd.data import DurationBucketBatchSampler
+    rng = np.random.RandomState(3)
+    durs = rng.uniform(5.0, 30.0, size=2000)
+    world, nb = 4, 5
+    samplers = [DurationBucketBatchSampler(r, world, durs, 16, nb, min_duration=5.0, max_duration=30.0) for r in range(world)]
+    per_rank = [list(s) for s in samplers]
+    assert len({len(b) for b in per_rank}) == 1 and all(len(b) == len(s) for b, s in zip(per_rank, samplers))
+    seen = [i for b in per_rank for batch in b for i in batch]
+    assert len(seen) == len(set(seen))                                  # nothing is read twice in an epoch
+    width = 25.0 / nb
+    visit = []
+    for step in range(len(per_rank[0])):
+        buckets = {int((durs[i] - 5.0) // width) for r in range(world) for i in per_rank[r][step]}
+        assert len(buckets) == 1, (step, buckets)                       # every rank is inside the same bucket at the same step
+        b = buckets.pop()
+        if not visit or visit[-1] != b:
+            visit.append(b)
+    assert visit == np.random.RandomState(0).permutation(nb).tolist()  # RandomizedChainDataset(rnd_seed=0)
+    # padded share: a batch never spans more than one bucket width
+    assert samplers[0].padding_fraction() < width / 2 / 5.0
+    # adaptive batch sizes: (buckets_num - idx) * bucketing_batch_size, batch_size must be 1
+    s = DurationBucketBatchSampler(0, 1, durs, 1, nb, 5.0, 30.0, bucketing_strategy="fixed_order", bucketing_batch_size=8)
+    sizes = [len(b) for b in s]
+    assert s.batch_sizes == [40, 32, 24, 16, 8] and sizes[0] == 40 and sizes[-2] in (8,)
+    order = [s.bucket_of(durs[b[0]]) for b in s]
+    assert order == sorted(order)                                       # fixed_order: bucket 0 first
+    with pytest.raises(ValueError, match="batch_size should be set to one"):
+        DurationBucketBatchSampler(0, 1, durs, 4, nb, 5.0, 30.0, bucketing_batch_size=8)
+    with pytest.raises(ValueError, match="is not supported"):
+        DurationBucketBatchSampler(0, 1, durs, 4, nb, bucketing_strategy="sorted")
