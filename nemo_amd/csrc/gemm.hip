@@ -725,7 +725,7 @@ __device__ __forceinline__ u32x2 lds_rd64_sync(uint32_t addr) {
 }
 
 // body of the 256x128 structure: workgroup `bid` of the problem's tile grid, K slice `kslice`, batch index `z`
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool REG = false>
 __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, const int bid, const int kslice, const int z
                                              , const bool direct = false
 ) {
@@ -805,6 +805,96 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
   //     LDS, not the MFMA pipe, bounds this loop and only reaches its rate on long bursts (pipelined: FFN2 forward 53.8 ->
   //     56.9, 4096^3 NN 140.7 -> 147.6).
   constexpr bool PIPELINED = TA && TB;
+  if constexpr (REG) {
+  // Register-prefetch schedule (see the sixth structure below for the why): K-contiguous operands, nk even and >= 4, dense
+  // operands.  Two LDS stages of this structure's three; every thread carries its 4 + 2 chunks of two future K-tiles, copies one
+  // tile per step into the idle stage (ds_write_b128, spread over the step's k-steps) and reloads the registers for the tile
+  // three steps ahead.
+  static_assert(!REG || (!TA && !TB), "register prefetch: K-contiguous operands");
+  const char* Ab = (const char*)A + (long long)kt0 * (BK * 2);
+  const char* Bb = (const char*)B + (long long)kt0 * (BK * 2);
+  uint32_t oa[4], ob[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = threadIdx.x + i * 512;
+    const int r = q >> 3, ck = q & 7;
+    const int gck = ck ^ ((r >> 1) & 7);
+    int ga = m0 + r; ga = ga < p.M ? ga : p.M - 1;
+    oa[i] = (uint32_t)((long long)ga * p.lda + gck * 8) * 2u;
+    if (i < 2) {
+      int gb = n0 + r; gb = gb < p.N ? gb : p.N - 1;
+      ob[i] = (uint32_t)((long long)gb * p.ldb + gck * 8) * 2u;
+    }
+  }
+  struct RT { u32x4 a[4]; u32x4 b[2]; };
+  auto ld_tile = [&](RT& t, int it) {
+    const bool in = it < nk;
+    const uint32_t msk = in ? 0xffffffffu : 0u;
+    const char* a = in ? Ab + (long long)it * (BK * 2) : reinterpret_cast<const char*>(g_zero16);
+    const char* b = in ? Bb + (long long)it * (BK * 2) : reinterpret_cast<const char*>(g_zero16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.a[i] = *reinterpret_cast<const u32x4*>(a + (oa[i] & msk));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) t.b[i] = *reinterpret_cast<const u32x4*>(b + (ob[i] & msk));
+  };
+  auto st_tile = [&](const RT& t, int stage) {
+    bf16_t* st = smem2 + stage * NT2_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(st + (threadIdx.x + i * 512) * 8) = t.a[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(st + BM2 * BK + (threadIdx.x + i * 512) * 8) = t.b[i];
+  };
+  auto step = [&](RT& t, int wr, int rd, int next_it) {
+    const bf16_t* a_s = smem2 + rd * NT2_STAGE;
+    const bf16_t* b_s = a_s + BM2 * BK;
+    bf16_t* st = smem2 + wr * NT2_STAGE;
+    const bool in = next_it < nk;
+    const uint32_t msk = in ? 0xffffffffu : 0u;
+    const char* ga = in ? Ab + (long long)next_it * (BK * 2) : reinterpret_cast<const char*>(g_zero16);
+    const char* gb = in ? Bb + (long long)next_it * (BK * 2) : reinterpret_cast<const char*>(g_zero16);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = frag_v2<false, BM2>(a_s, wm * 64 + i * 32, kk, lane);
+        bfr[i] = frag_v2<false, BN>(b_s, wn * 64 + i * 32, kk, lane);
+      }
+      if (kk < 2) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int i = kk * 2 + c;
+          *reinterpret_cast<u32x4*>(st + (threadIdx.x + i * 512) * 8) = t.a[i];
+          t.a[i] = *reinterpret_cast<const u32x4*>(ga + (oa[i] & msk));
+        }
+      } else if (kk == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          *reinterpret_cast<u32x4*>(st + BM2 * BK + (threadIdx.x + i * 512) * 8) = t.b[i];
+          t.b[i] = *reinterpret_cast<const u32x4*>(gb + (ob[i] & msk));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  RT r0, r1;
+  ld_tile(r0, 0);
+  ld_tile(r1, 1);
+  st_tile(r0, 0);
+  ld_tile(r0, 2);
+  __syncthreads();
+  for (int it = 0; it < nk; it += 2) {
+    step(r1, 1, 0, it + 3);
+    __syncthreads();
+    step(r0, 0, 1, it + 4);
+    __syncthreads();
+  }
+  } else
   if constexpr (PIPELINED) {
   // Pipelined schedule:
   //   on entry to iteration it:  F[0..1] = first half of tile it (read during iteration it-1, after its barrier)
@@ -1025,11 +1115,11 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
   }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool REG = false>
 __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
   drop_resolve(p.drop);
   extern __shared__ __attribute__((aligned(16))) bf16_t smem2[];  // 3 stages x 48 KiB
-  gemm_v2_body<TA, TB>(p, smem2, blockIdx.x, blockIdx.y, blockIdx.z);
+  gemm_v2_body<TA, TB, REG>(p, smem2, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ---- grouped weight gradients: up to GRP_MAX independent TN problems (same K = token count, f32 atomic accumulation)
@@ -1125,6 +1215,35 @@ __device__ __forceinline__ void v4_round_out(const GemmP& p, const float* sC, in
         }
       }
     }
+  }
+}
+
+// ---- epilogue of a 256x256 tile held as acc[4][2] per wave (2 x 4 waves of 128 x 64): four rounds through a [64][BN4+4] f32
+// window (round i = the i-th 32-row block of every wave).  Shared by the LDS-DMA structure and the register-prefetch structure.
+__device__ __forceinline__ void v4_tile_epilogue(const GemmP& p, f32x16 (&acc)[4][2], float* sC, int z, long long coff, int m0,
+                                                 int n0, int wm, int wn, int lr, int lh) {
+  constexpr int LDS_C = BN4 + 4;
+  const bool fast = (p.vec_ok & 1) && !(p.N & 7) && n0 + BN4 <= p.N && !p.atomic;
+  // the rounds are a real loop (the epilogue code exists once); the round's two accumulators are selected by a uniform
+  // switch so that acc[][] is never indexed dynamically (that would put all 128 accumulator registers in scratch memory)
+#pragma nounroll
+  for (int i = 0; i < 4; ++i) {
+    f32x16 t0, t1;
+    switch (i) {
+      case 0: t0 = acc[0][0]; t1 = acc[0][1]; break;
+      case 1: t0 = acc[1][0]; t1 = acc[1][1]; break;
+      case 2: t0 = acc[2][0]; t1 = acc[2][1]; break;
+      default: t0 = acc[3][0]; t1 = acc[3][1]; break;
+    }
+    if (i) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row_l = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      sC[row_l * LDS_C + wn * 64 + lr] = t0[r];
+      sC[row_l * LDS_C + wn * 64 + 32 + lr] = t1[r];
+    }
+    __syncthreads();
+    v4_round_out(p, sC, z, coff, m0, n0, i, fast);
   }
 }
 
@@ -1320,30 +1439,172 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: four rounds through a [64][BN4+4] f32 window (round i = the i-th 32-row block of every wave)
-  constexpr int LDS_C = BN4 + 4;
-  const bool fast = (p.vec_ok & 1) && !(p.N & 7) && n0 + BN4 <= p.N && !p.atomic;
-  // the rounds are a real loop (the epilogue code exists once); the round's two accumulators are selected by a uniform
-  // switch so that acc[][] is never indexed dynamically (that would put all 128 accumulator registers in scratch memory)
-#pragma nounroll
-  for (int i = 0; i < 4; ++i) {
-    f32x16 t0, t1;
-    switch (i) {
-      case 0: t0 = acc[0][0]; t1 = acc[0][1]; break;
-      case 1: t0 = acc[1][0]; t1 = acc[1][1]; break;
-      case 2: t0 = acc[2][0]; t1 = acc[2][1]; break;
-      default: t0 = acc[3][0]; t1 = acc[3][1]; break;
-    }
-    if (i) __syncthreads();
+  v4_tile_epilogue(p, acc, reinterpret_cast<float*>(smem4), z, coff, m0, n0, wm, wn, lr, lh);
+}
+
+// =================================================================================================
+// Sixth structure: the 256x256x64 tile of the third structure with its operands PREFETCHED THROUGH REGISTERS, two K-tiles deep.
+// Why: the LDS-DMA loop above can keep ONE K-tile in flight (two 64-KiB stages are all the LDS holds) and drains it at the
+// barrier that ends the step, so every K-tile pays one full memory round trip: 2.0-2.4 us per step measured (8.4 MFLOP
+// per step and CU = 1.07 PFLOP/s on the chip at best, 0.88 at K = 512) against 0.86 us of MFMA work -- the loop is bound
+// by the latency of one transfer, not by LDS bandwidth or the matrix pipe (the ablations of profiles/r2_gemm_structures.md
+// fit: without MFMAs the step still takes 1.8 us; a 4-wave / 128x128-per-wave build with 1/3 less LDS traffic ran at the
+// same rate).  Bytes in flight are what hides latency, and registers are where a CU has room for them: every thread holds
+// the 8 + 8 16-byte chunks of TWO future K-tiles (64 VGPRs), loaded with ordinary global loads three steps before the MFMAs
+// that use them, and copies one tile per step into the free LDS stage with ds_write_b128 (the same [rows][64] images and
+// chunk swizzle as the DMA path, so the fragment reads are unchanged).  128 KiB are in flight per CU instead of <= 64.
+// The compiler's own counted vmcnt does the pipelining: no LDS-DMA, hence no vmcnt(0) in front of LDS reads.
+// K-contiguous operands (NT), K % 128 == 0, K >= 256; everything else stays on the third structure.
+// =================================================================================================
+struct RegTile { u32x4 a[4]; u32x4 b[4]; };  // this thread's chunks of one K-tile: A rows (tid + i*512) >> 3, B likewise
+
+template <int G>
+__global__ __launch_bounds__(512) void gemm_bf16_v6_kernel(GemmP p) {
+  drop_resolve(p.drop);
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem6[];  // 2 stages x 64 KiB
+  const int tn = (p.N + BN4 - 1) / BN4, tm = (p.M + BM2 - 1) / BM2;
+  const int ntiles = tm * tn;
+  const int bid = blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int z = blockIdx.z;
+  const int tile_m = logical / tn, tile_n = logical - tile_m * tn;
+  const int m0 = tile_m * BM2, n0 = tile_n * BN4;
+  const int z0 = z % p.nb0, z1 = z / p.nb0;
+  const char* A = (const char*)((const bf16_t*)p.A + z0 * p.sA0 + z1 * p.sA1);
+  const char* B = (const char*)((const bf16_t*)p.B + z0 * p.sB0 + z1 * p.sB1);
+  const long long coff = z0 * p.sC0 + z1 * p.sC1;
+  const int nk = p.K / BK;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[4][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row_l = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      sC[row_l * LDS_C + wn * 64 + lr] = t0[r];
-      sC[row_l * LDS_C + wn * 64 + 32 + lr] = t1[r];
-    }
-    __syncthreads();
-    v4_round_out(p, sC, z, coff, m0, n0, i, fast);
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-thread byte offsets of its chunks at K-tile 0 (rows past the matrix are clamped: their products are never stored);
+  // the K-tile advances all of them by the uniform BK * 2 bytes
+  uint32_t oa[4], ob[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = threadIdx.x + i * 512;
+    const int r = q >> 3, ck = q & 7;
+    const int gck = ck ^ ((r >> 1) & 7);
+    int ga = m0 + r; ga = ga < p.M ? ga : p.M - 1;
+    int gb = n0 + r; gb = gb < p.N ? gb : p.N - 1;
+    oa[i] = (uint32_t)((long long)ga * p.lda + gck * 8) * 2u;
+    ob[i] = (uint32_t)((long long)gb * p.ldb + gck * 8) * 2u;
   }
+  // (a K-tile index past the end reads the 16-byte zero page with all offsets masked to 0: the loop body has no branch, so the
+  //  compiler's wait-count model of the two register sets stays exact -- with `if (it + 3 < nk)` around the loads it merged the
+  //  paths and drained vmcnt(0) in front of every ds_write, i.e. the second tile in flight was lost)
+  auto load_tile = [&](RegTile& t, int it) {
+    const bool in = it < nk;
+    const uint32_t msk = in ? 0xffffffffu : 0u;
+    const char* a = in ? A + (long long)it * (BK * 2) : reinterpret_cast<const char*>(g_zero16);
+    const char* b = in ? B + (long long)it * (BK * 2) : reinterpret_cast<const char*>(g_zero16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.a[i] = *reinterpret_cast<const u32x4*>(a + (oa[i] & msk));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.b[i] = *reinterpret_cast<const u32x4*>(b + (ob[i] & msk));
+  };
+  auto store_tile = [&](const RegTile& t, int stage) {
+    bf16_t* st = smem6 + stage * NT4_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(st + (threadIdx.x + i * 512) * 8) = t.a[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(st + BM2 * BK + (threadIdx.x + i * 512) * 8) = t.b[i];
+  };
+  auto compute = [&](int stage) {
+    const bf16_t* a_s = smem6 + stage * NT4_STAGE;
+    const bf16_t* b_s = a_s + BM2 * BK;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = frag_v2<false, BN4>(b_s, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = frag_v2<false, BM2>(a_s, wm * 128 + i * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // one step with the copy of the NEXT tile (register set t -> stage `wr`) and the loads of the tile after the next two spread
+  // over the four k-steps of the CURRENT tile's MFMAs: a ds_write_b128 occupies the LDS store path for ~13 cycles per wave
+  // (8 waves x 8 stores = ~830 of the step's 2048 MFMA cycles) -- left to the compiler they all sink to the end of the step,
+  // where only the barrier is left to hide them (G == 0: compiler order, G == 1: this order; A/B in profiles/r3_gemm_structures.md)
+  auto step_spread = [&](RegTile& t, int wr, int rd, int next_it) {
+    const bf16_t* a_s = smem6 + rd * NT4_STAGE;
+    const bf16_t* b_s = a_s + BM2 * BK;
+    bf16_t* st = smem6 + wr * NT4_STAGE;
+    const bool in = next_it < nk;
+    const uint32_t msk = in ? 0xffffffffu : 0u;
+    const char* ga = in ? A + (long long)next_it * (BK * 2) : reinterpret_cast<const char*>(g_zero16);
+    const char* gb = in ? B + (long long)next_it * (BK * 2) : reinterpret_cast<const char*>(g_zero16);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = frag_v2<false, BN4>(b_s, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = frag_v2<false, BM2>(a_s, wm * 128 + i * 32, kk, lane);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int i = (kk & 1) * 2 + c;
+        if (kk < 2) {
+          *reinterpret_cast<u32x4*>(st + (threadIdx.x + i * 512) * 8) = t.a[i];
+          t.a[i] = *reinterpret_cast<const u32x4*>(ga + (oa[i] & msk));
+        } else {
+          *reinterpret_cast<u32x4*>(st + BM2 * BK + (threadIdx.x + i * 512) * 8) = t.b[i];
+          t.b[i] = *reinterpret_cast<const u32x4*>(gb + (ob[i] & msk));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  RegTile r0, r1;
+  load_tile(r0, 0);
+  load_tile(r1, 1);
+  store_tile(r0, 0);
+  load_tile(r0, 2);
+  __syncthreads();
+  // step `it` (unrolled by two so that the register sets alternate statically; nk is even): tile it+1 (loaded two steps ago)
+  // goes from its registers into the stage that step it-1 has finished reading, the registers take tile it+3, then the MFMAs
+  // of tile it.  (The copy of a tile past the end into the idle stage is harmless: nothing reads it.)
+  for (int it = 0; it < nk; it += 2) {
+    if constexpr (G == 1) {
+      step_spread(r1, 1, 0, it + 3);
+      __syncthreads();
+      step_spread(r0, 0, 1, it + 4);
+      __syncthreads();
+    } else {
+      store_tile(r1, 1);
+      load_tile(r1, it + 3);
+      compute(0);
+      __syncthreads();
+      store_tile(r0, 0);
+      load_tile(r0, it + 4);
+      compute(1);
+      __syncthreads();
+    }
+  }
+  v4_tile_epilogue(p, acc, reinterpret_cast<float*>(smem6), z, coff, m0, n0, wm, wn, lr, lh);
 }
 
 // =================================================================================================
@@ -1767,20 +2028,25 @@ static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return (e && e[0]) ? atoi(e) : dflt;
 }
-static std::atomic<int> g_v5_mode{-1};  // MI355X_GEMM_V5 / mi355x_gemm_config(5, .): 0 = never use the persistent structure, 1 = default
-static int v5_mode_now() {
-  int v = g_v5_mode.load(std::memory_order_relaxed);
+// run-time knobs (mi355x_gemm_config(key, value); first read falls back to the environment): key 4 = the 256x256 structures
+// (MI355X_GEMM_V4: 0 never, 1 heuristic, 2 whenever N > 128), key 5 = the persistent structure (MI355X_GEMM_V5), key 6 = register
+// prefetch instead of LDS-DMA inside the 256x256 structure (MI355X_GEMM_V6: 0 / 1)
+static std::atomic<int> g_mode[8] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static int mode_now(int key) {
+  int v = g_mode[key].load(std::memory_order_relaxed);
   if (v < 0) {
-    static const int from_env = env_int("MI355X_GEMM_V5", 1);
+    static const int env4 = env_int("MI355X_GEMM_V4", 1), env5 = env_int("MI355X_GEMM_V5", 1), env6 = env_int("MI355X_GEMM_V6", 1);
+    const int from_env = key == 4 ? env4 : key == 5 ? env5 : key == 6 ? env6 : 0;
     int expected = -1;
-    g_v5_mode.compare_exchange_strong(expected, from_env, std::memory_order_relaxed);
-    v = g_v5_mode.load(std::memory_order_relaxed);
+    g_mode[key].compare_exchange_strong(expected, from_env, std::memory_order_relaxed);
+    v = g_mode[key].load(std::memory_order_relaxed);
   }
   return v;
 }
+static int v5_mode_now() { return mode_now(5); }
 extern "C" int mi355x_gemm_config(int key, int value) {
-  if (key != 5) return -1;
-  return g_v5_mode.exchange(value, std::memory_order_relaxed);
+  if (key < 4 || key > 6) return -1;
+  return g_mode[key].exchange(value, std::memory_order_relaxed);
 }
 
 extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
@@ -1892,6 +2158,8 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, shm) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<true, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, shm) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, shm) == hipSuccess;
         return ok;
       }();
       if (!attr_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
@@ -1930,7 +2198,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
         return mi_check_launch();
       }
       // 256x256 structure when the problem still fills the chip with the larger tile
-      static const int v4_mode = env_int("MI355X_GEMM_V4", 1);  // 0 = never, 1 = heuristic (default), 2 = whenever N >= 129
+      const int v4_mode = mode_now(4);  // 0 = never, 1 = heuristic (default), 2 = whenever N >= 129
       const int tn4 = (p.N + BN4 - 1) / BN4;
       const long long blocks4 = (long long)tm2 * tn4 * sk * p.batch;
       const bool waste_ok = (long long)tn4 * BN4 * 8 <= (long long)p.N * 9;  // <= 12.5 % padded columns
@@ -1940,6 +2208,20 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
       const double eff2 = (double)blocks2 / (double)(((blocks2 + 255) / 256) * 256);
       if ((v4_mode == 2 && p.N > 128) || (v4_mode == 1 && blocks4 >= 224 && waste_ok && eff4 >= 0.9 * eff2)) {
         const int shm4 = 2 * NT4_STAGE * 2;
+        // register-prefetch structure (sixth): dense K-contiguous operands, whole K-tiles, 32-bit operand offsets
+        const int v6_mode = mode_now(6);
+        if (v6_mode && !p.transA && !p.transB && !p.g_on && sk == 1 && !(p.K % (2 * BK)) && p.K >= 4 * BK && !(p.lda & 7) && !(p.ldb & 7) &&
+            !((uintptr_t)p.A & 15) && !((uintptr_t)p.B & 15) && (long long)p.M * p.lda < (1LL << 30) &&
+            (long long)p.N * p.ldb < (1LL << 30)) {
+          static const bool attr6_ok = hipFuncSetAttribute((const void*)gemm_bf16_v6_kernel<0>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, shm4) == hipSuccess &&
+                                       hipFuncSetAttribute((const void*)gemm_bf16_v6_kernel<1>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, shm4) == hipSuccess;
+          if (!attr6_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
+          if (v6_mode == 2) MI_LAUNCH((gemm_bf16_v6_kernel<0>), dim3(tm2 * tn4, 1, p.batch), dim3(512), shm4, s, p);
+          else MI_LAUNCH((gemm_bf16_v6_kernel<1>), dim3(tm2 * tn4, 1, p.batch), dim3(512), shm4, s, p);
+          return mi_check_launch();
+        }
         typedef void (*v4_fn)(GemmP);
         static const v4_fn v4_all[] = {gemm_bf16_v4_kernel<false, false, 0>, gemm_bf16_v4_kernel<false, false, 1>,
                                        gemm_bf16_v4_kernel<false, true, 0>, gemm_bf16_v4_kernel<true, true, 0>,
@@ -1957,8 +2239,15 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
         else fn = v4_all[p.g_on == 2 ? 4 : 3];
         MI_LAUNCH(fn, grid4, dim3(512), shm4, s, p);
       } else
-      if (!p.transA && !p.transB) MI_LAUNCH((gemm_bf16_v2_kernel<false, false>), grid2, dim3(512), shm, s, p);
-      else if (!p.transA && p.transB) MI_LAUNCH((gemm_bf16_v2_kernel<false, true>), grid2, dim3(512), shm, s, p);
+      if (!p.transA && !p.transB) {
+        // register-prefetch K loop (key 6): dense K-contiguous operands, an even number (>= 4) of whole K-tiles per workgroup
+        const int nk_wg = sk > 1 ? p.ktiles_per_split : nk;
+        const bool reg_ok = mode_now(6) && !p.g_on && !(p.K % BK) && nk_wg >= 4 && !(nk_wg & 1) && (sk == 1 || !(nk % nk_wg)) &&
+                            !(p.lda & 7) && !(p.ldb & 7) && !((uintptr_t)p.A & 15) && !((uintptr_t)p.B & 15) &&
+                            (long long)p.M * p.lda < (1LL << 30) && (long long)p.N * p.ldb < (1LL << 30);
+        if (reg_ok) MI_LAUNCH((gemm_bf16_v2_kernel<false, false, true>), grid2, dim3(512), shm, s, p);
+        else MI_LAUNCH((gemm_bf16_v2_kernel<false, false>), grid2, dim3(512), shm, s, p);
+      } else if (!p.transA && p.transB) MI_LAUNCH((gemm_bf16_v2_kernel<false, true>), grid2, dim3(512), shm, s, p);
       else MI_LAUNCH((gemm_bf16_v2_kernel<true, true>), grid2, dim3(512), shm, s, p);
     } else
     if (!p.transA && !p.transB) MI_LAUNCH((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, s, p);

@@ -1103,3 +1103,51 @@ def test_rnnt_loss_pitched_rows_and_bf16_operand_gradient(V1, ldp):
             g32 = gp.clone()
         else:
             assert torch.equal(gp[:, :V1], g32[:, :V1].to(torch.bfloat16))  # same walk, rounded once
+
+
+@pytest.mark.parametrize("tile", [256, 128])
+@pytest.mark.parametrize("M,N,K", [(16032, 2048, 512), (3000, 512, 256), (5000, 1280, 2048), (777, 384, 1024)])
+def test_gemm_register_prefetch_structure_matches_the_lds_dma_one(M, N, K, tile):
+    """gemm_bf16_v6_kernel (256x256x64 tile, operands prefetched through registers two K-tiles deep, ds_write into the same LDS
+    images) against gemm_bf16_v4_kernel (LDS-DMA) on the same inputs: same products in the same order, so the results must be
+    BIT-identical, dropout masks included; ragged M / N (clamped rows), K = 4 ... 32 K-tiles, and run-to-run determinism (a
+    difference between two launches would be a race between the register copies, the stages and the barriers)."""
+    o = ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g)).to(dev)
+    W = bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    drop = o.Dropout(0.1, 11, 5)
+    ref = (A.float() @ W.float().t() + bias).cpu()
+
+    def run(kind):
+        if kind == "store":
+            c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            o.gemm(A, W, c, M, N, K, K, K, N, bias=bias)
+            return (c,)
+        if kind == "swish":
+            h = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            a = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            o.gemm(A, W, a, M, N, K, K, K, N, bias=bias, epi=o.EPI_SWISH_DROP, aux_out=h, drop=drop)
+            return (h, a)
+        c = torch.empty(M, N, device=dev)
+        o.gemm(A, W, c, M, N, K, K, K, N, bias=bias, alpha=0.5, epi=o.EPI_RESID, aux_in=res, drop=drop)
+        return (c,)
+
+    # tile 256: the 256x256 structure wherever N > 128; tile 128: the 256x128 structure everywhere; never the persistent one
+    old4, old5, old6 = o.gemm_config(4, 2 if tile == 256 else 0), o.gemm_config(5, 0), o.gemm_config(6, 0)
+    try:
+        for kind in ("store", "swish", "resid"):
+            o.gemm_config(6, 0)
+            want = [t.float() for t in run(kind)]
+            o.gemm_config(6, 1)
+            for rep in range(3):
+                got = [t.float() for t in run(kind)]
+                torch.cuda.synchronize()
+                for w_, g_ in zip(want, got):
+                    assert torch.equal(w_, g_), (kind, rep, (w_ - g_).abs().max().item())
+            if kind == "store":
+                assert rel_err(got[0], ref) < 1e-2
+    finally:
+        o.gemm_config(4, old4 if old4 >= 0 else 1); o.gemm_config(5, old5 if old5 >= 0 else 1); o.gemm_config(6, old6 if old6 >= 0 else 1)

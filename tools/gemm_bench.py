@@ -141,6 +141,35 @@ if os.environ.get("V5_AB"):  # persistent overlapped-epilogue structure on / off
             run(tag + "pw1_dgrad_store_k1024", M, 512, 1024, "store")
             run(tag + "resid_n1024_k512", M, 1024, 512, "resid")
     sys.exit(0)
+if os.environ.get("V6_AB"):  # register-prefetch 256x256 structure on / off (LDS-DMA), same process, interleaved; v5 off so that
+    # every shape with enough 256x256 tiles takes the structure under test
+    for rep in range(int(os.environ.get("REPS", "3"))):
+        for v5, v6 in ((0, 0), (0, 2), (0, 1)):
+            ops.gemm_config(5, v5); ops.gemm_config(6, v6)
+            tag = f"v5={v5} v6={v6} "
+            run(tag + "ffn1_fwd_swish", M, 2048, 512, "swish")
+            run(tag + "ffn1_fwd_store", M, 2048, 512, "store")
+            run(tag + "ffn2_dgrad_dswish", M, 2048, 512, "dswish")
+            run(tag + "qkv_fwd_store", M, 1536, 512, "store")
+            run(tag + "pw1_fwd_store", M, 1024, 512, "store")
+            run(tag + "store_n2048_k2048", M, 2048, 2048, "store")
+            run(tag + "big_square", 8192, 8192, 8192, "nobias")
+            run(tag + "sq4096", 4096, 4096, 4096, "nobias")
+    sys.exit(0)
+if os.environ.get("V6N_AB"):  # the N = 512 shapes (256x128 tiles): LDS-DMA / register prefetch / persistent structure
+    for rep in range(int(os.environ.get("REPS", "2"))):
+        for v5, v6 in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            ops.gemm_config(5, v5); ops.gemm_config(6, v6)
+            tag = f"v5={v5} v6={v6} "
+            run(tag + "ffn2_fwd_resid", M, 512, 2048, "resid")
+            run(tag + "ffn1_dgrad_store", M, 512, 2048, "store")
+            run(tag + "proj_fwd_resid", M, 512, 512, "resid")
+            run(tag + "proj_dgrad_store", M, 512, 512, "store")
+            run(tag + "qkv_dgrad_store", M, 512, 1536, "store")
+            run(tag + "pw1_dgrad_store", M, 512, 1024, "store")
+            run(tag + "ffn2_dgrad_dswish", M, 2048, 512, "dswish")
+            run(tag + "ffn1_fwd_swish", M, 2048, 512, "swish")
+    sys.exit(0)
 run("ffn1_fwd", M, 2048, 512, "swish")
 run("ffn1_fwd_store", M, 2048, 512, "store")
 run("ffn1_fwd_nobias", M, 2048, 512, "nobias")
