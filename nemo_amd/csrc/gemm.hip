@@ -2030,13 +2030,16 @@ static int env_int(const char* name, int dflt) {
 }
 // run-time knobs (mi355x_gemm_config(key, value); first read falls back to the environment): key 4 = the 256x256 structures
 // (MI355X_GEMM_V4: 0 never, 1 heuristic, 2 whenever N > 128), key 5 = the persistent structure (MI355X_GEMM_V5), key 6 = register
-// prefetch instead of LDS-DMA inside the 256x256 structure (MI355X_GEMM_V6: 0 / 1)
+// prefetch instead of LDS-DMA inside the 256x256 structure (MI355X_GEMM_V6: 0 = default / 1), key 7 = the same inside the 256x128
+// structure (MI355X_GEMM_V7, default 1).  Defaults follow the in-step A/B (tools/step_ab.py, recorded graphs, same box): the
+// 256x128 variant -0.2 ms per step, the 256x256 variant +0.3 ms although it wins every isolated launch (profiles/r3_gemm_structures.md)
 static std::atomic<int> g_mode[8] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 static int mode_now(int key) {
   int v = g_mode[key].load(std::memory_order_relaxed);
   if (v < 0) {
-    static const int env4 = env_int("MI355X_GEMM_V4", 1), env5 = env_int("MI355X_GEMM_V5", 1), env6 = env_int("MI355X_GEMM_V6", 1);
-    const int from_env = key == 4 ? env4 : key == 5 ? env5 : key == 6 ? env6 : 0;
+    static const int env4 = env_int("MI355X_GEMM_V4", 1), env5 = env_int("MI355X_GEMM_V5", 1), env6 = env_int("MI355X_GEMM_V6", 0),
+                     env7 = env_int("MI355X_GEMM_V7", 1);
+    const int from_env = key == 4 ? env4 : key == 5 ? env5 : key == 6 ? env6 : key == 7 ? env7 : 0;
     int expected = -1;
     g_mode[key].compare_exchange_strong(expected, from_env, std::memory_order_relaxed);
     v = g_mode[key].load(std::memory_order_relaxed);
@@ -2045,7 +2048,7 @@ static int mode_now(int key) {
 }
 static int v5_mode_now() { return mode_now(5); }
 extern "C" int mi355x_gemm_config(int key, int value) {
-  if (key < 4 || key > 6) return -1;
+  if (key < 4 || key > 7) return -1;
   return g_mode[key].exchange(value, std::memory_order_relaxed);
 }
 
@@ -2240,9 +2243,9 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
         MI_LAUNCH(fn, grid4, dim3(512), shm4, s, p);
       } else
       if (!p.transA && !p.transB) {
-        // register-prefetch K loop (key 6): dense K-contiguous operands, an even number (>= 4) of whole K-tiles per workgroup
+        // register-prefetch K loop (key 7): dense K-contiguous operands, an even number (>= 4) of whole K-tiles per workgroup
         const int nk_wg = sk > 1 ? p.ktiles_per_split : nk;
-        const bool reg_ok = mode_now(6) && !p.g_on && !(p.K % BK) && nk_wg >= 4 && !(nk_wg & 1) && (sk == 1 || !(nk % nk_wg)) &&
+        const bool reg_ok = mode_now(7) && !p.g_on && !(p.K % BK) && nk_wg >= 4 && !(nk_wg & 1) && (sk == 1 || !(nk % nk_wg)) &&
                             !(p.lda & 7) && !(p.ldb & 7) && !((uintptr_t)p.A & 15) && !((uintptr_t)p.B & 15) &&
                             (long long)p.M * p.lda < (1LL << 30) && (long long)p.N * p.ldb < (1LL << 30);
         if (reg_ok) MI_LAUNCH((gemm_bf16_v2_kernel<false, false, true>), grid2, dim3(512), shm, s, p);

@@ -112,14 +112,27 @@ class RelPositionalEncoding(nn.Module):  # multi_head_attention.py:1056
         self.dropout_rate, self.dropout_rate_emb = dropout_rate, dropout_rate_emb
 
     def table(self, T: int, device, dtype) -> torch.Tensor:
-        """pos_emb [2T-1, d]: row r <-> relative position T-1-r (multi_head_attention.py:1015-1035,1067-1100)"""
-        d = self.d_model
-        pos = torch.arange(T - 1, -T, -1, dtype=torch.float32).unsqueeze(1)
-        div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(INF_VAL) / d))
-        pe = torch.zeros(2 * T - 1, d)
-        pe[:, 0::2] = torch.sin(pos * div)
-        pe[:, 1::2] = torch.cos(pos * div)
-        return pe.to(device=device, dtype=dtype).contiguous()
+        """pos_emb [2T-1, d]: row r <-> relative position T-1-r (multi_head_attention.py:1015-1035,1067-1100).
+        A row depends on its relative position only, so -- exactly as the reference does with its `pe` buffer (extend_pe builds
+        positions L-1 ... -(L-1) for L = max_len once, forward slices `pe[:, center - T + 1 : center + T]`) -- ONE table for the
+        longest supported length lives on the device per dtype and a length-T table is a contiguous row slice of it: no host
+        arithmetic, no host-to-device copy (which would also drain the launch queue) when a batch brings a new length."""
+        L = max(int(self.max_len), T)
+        key = (str(device), dtype)
+        full = self._full.get(key) if hasattr(self, "_full") else None
+        if full is None or full.shape[0] < 2 * T - 1 or self._full_L.get(key) != L:
+            if not hasattr(self, "_full"):
+                self._full, self._full_L = {}, {}
+            d = self.d_model
+            pos = torch.arange(L - 1, -L, -1, dtype=torch.float32).unsqueeze(1)
+            div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(INF_VAL) / d))
+            pe = torch.zeros(2 * L - 1, d)
+            pe[:, 0::2] = torch.sin(pos * div)
+            pe[:, 1::2] = torch.cos(pos * div)
+            full = pe.to(device=device, dtype=dtype).contiguous()
+            self._full[key], self._full_L[key] = full, L
+        L = self._full_L[key]
+        return full[L - T: L + T - 1]
 
 
 class _Saved:
@@ -254,6 +267,7 @@ class ConformerEncoder(NeuralModule):
         self.sub_wgrad_side_stream = os.environ.get("MI355X_SUB_WGRAD_STREAM", "1") != "0"
         self._plans = {}
         self._ws = {}
+        self._ws_retired = []
         self._pos_cache = {}
         self._step_seed = 0
         self._weights_version = -1
@@ -320,12 +334,23 @@ class ConformerEncoder(NeuralModule):
         return torch.float32
 
     def _buf(self, name, shape, dtype, device, zero=False):
-        key = (name, tuple(shape), dtype)
+        """persistent workspace `name`: ONE allocation per (name, dtype) that grows to the largest size ever asked for and is handed
+        out as a view -- with variable-length batches every step brings new shapes, and a workspace per shape meant a fresh
+        (up to 1.3 GB) allocation per step; `zero` only guarantees zeros at the first use of a fresh allocation"""
+        n = 1
+        for k in shape:
+            n *= int(k)
+        key = (name, dtype)
         t = self._ws.get(key)
-        if t is None or t.device != device:
-            t = torch.zeros(shape, dtype=dtype, device=device) if zero else torch.empty(shape, dtype=dtype, device=device)
+        if t is None or t.device != device or t.numel() < n:
+            cap = n if t is None or t.device != device else max(n, int(t.numel() * 1.25))
+            if t is not None:
+                # a recorded launch sequence (hipGraph) may hold the old address: the outgrown buffer is kept, not freed
+                # (geometric growth bounds what accumulates to a few times the largest size)
+                self._ws_retired.append(t)
+            t = torch.zeros(cap, dtype=dtype, device=device) if zero else torch.empty(cap, dtype=dtype, device=device)
             self._ws[key] = t
-        return t
+        return t[:n].view(shape)
 
     def _plan(self, cdt, device):
         key = (cdt, str(device), self._flatp.generation)

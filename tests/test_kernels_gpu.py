@@ -1136,12 +1136,13 @@ def test_gemm_register_prefetch_structure_matches_the_lds_dma_one(M, N, K, tile)
         return (c,)
 
     # tile 256: the 256x256 structure wherever N > 128; tile 128: the 256x128 structure everywhere; never the persistent one
-    old4, old5, old6 = o.gemm_config(4, 2 if tile == 256 else 0), o.gemm_config(5, 0), o.gemm_config(6, 0)
+    key = 6 if tile == 256 else 7
+    old4, old5, old6 = o.gemm_config(4, 2 if tile == 256 else 0), o.gemm_config(5, 0), o.gemm_config(key, 0)
     try:
         for kind in ("store", "swish", "resid"):
-            o.gemm_config(6, 0)
+            o.gemm_config(key, 0)
             want = [t.float() for t in run(kind)]
-            o.gemm_config(6, 1)
+            o.gemm_config(key, 1)
             for rep in range(3):
                 got = [t.float() for t in run(kind)]
                 torch.cuda.synchronize()
@@ -1150,4 +1151,4 @@ def test_gemm_register_prefetch_structure_matches_the_lds_dma_one(M, N, K, tile)
             if kind == "store":
                 assert rel_err(got[0], ref) < 1e-2
     finally:
-        o.gemm_config(4, old4 if old4 >= 0 else 1); o.gemm_config(5, old5 if old5 >= 0 else 1); o.gemm_config(6, old6 if old6 >= 0 else 1)
+        o.gemm_config(4, old4 if old4 >= 0 else 1); o.gemm_config(5, old5 if old5 >= 0 else 1); o.gemm_config(key, old6 if old6 >= 0 else 1)

@@ -18,31 +18,43 @@ def timeit(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e-3
 
+ROT = int(os.environ.get("ROTATE", "1"))  # > 1: cycle over that many independent operand / output sets, so that a launch finds
+# its operands where the training step finds them (HBM / MALL, not an L2 that the previous launch of the same buffers warmed)
+
+
 def run(name, M, N, K, epi="store", out=bf, layout="NT", splitk=1):
     if only and only not in name: return
     g = torch.Generator(device=dev).manual_seed(0)
     tA, tB = layout[0] == "T", layout[1] == "N"
-    A = torch.randn((K, M) if tA else (M, K), device=dev, generator=g).to(bf)
-    B = torch.randn((K, N) if tB else (N, K), device=dev, generator=g).to(bf)
-    C = torch.zeros(M, N, device=dev, dtype=out)
-    bias = torch.randn(N, device=dev, generator=g)
     kw = dict(transA=tA, transB=tB)
     lda = M if tA else K; ldb = N if tB else K
-    if epi == "store": f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, bias=bias, **kw)
-    elif epi == "nobias": f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, **kw)
-    elif epi == "swish":
-        H = torch.empty(M, N, device=dev, dtype=bf); d = ops.Dropout(0.1, 1, 1)
-        f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, bias=bias, epi=ops.EPI_SWISH_DROP, aux_out=H, drop=d, **kw)
-    elif epi == "resid":
-        R = torch.randn(M, N, device=dev); C = torch.empty(M, N, device=dev); d = ops.Dropout(0.1, 1, 2)
-        f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, bias=bias, alpha=0.5, epi=ops.EPI_RESID, aux_in=R, drop=d, **kw)
-    elif epi == "dswish":
-        H = torch.randn(M, N, device=dev, generator=g).to(bf); d = ops.Dropout(0.1, 1, 3)
-        f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, epi=ops.EPI_DSWISH, aux_in=H, drop=d, **kw)
-    elif epi == "atomic":
-        C = torch.zeros(M, N, device=dev)
-        f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, atomic=True, splitk=splitk, **kw)
-    t = timeit(f)
+    fs = []
+    for r in range(ROT):
+        A = torch.randn((K, M) if tA else (M, K), device=dev, generator=g).to(bf)
+        B = torch.randn((K, N) if tB else (N, K), device=dev, generator=g).to(bf)
+        C = torch.zeros(M, N, device=dev, dtype=out)
+        bias = torch.randn(N, device=dev, generator=g)
+        if epi == "store": f = lambda A=A, B=B, C=C, bias=bias: ops.gemm(A, B, C, M, N, K, lda, ldb, N, bias=bias, **kw)
+        elif epi == "nobias": f = lambda A=A, B=B, C=C: ops.gemm(A, B, C, M, N, K, lda, ldb, N, **kw)
+        elif epi == "swish":
+            H = torch.empty(M, N, device=dev, dtype=bf); d = ops.Dropout(0.1, 1, 1)
+            f = lambda A=A, B=B, C=C, bias=bias, H=H, d=d: ops.gemm(A, B, C, M, N, K, lda, ldb, N, bias=bias, epi=ops.EPI_SWISH_DROP, aux_out=H, drop=d, **kw)
+        elif epi == "resid":
+            R = torch.randn(M, N, device=dev); C = torch.empty(M, N, device=dev); d = ops.Dropout(0.1, 1, 2)
+            f = lambda A=A, B=B, C=C, bias=bias, R=R, d=d: ops.gemm(A, B, C, M, N, K, lda, ldb, N, bias=bias, alpha=0.5, epi=ops.EPI_RESID, aux_in=R, drop=d, **kw)
+        elif epi == "dswish":
+            H = torch.randn(M, N, device=dev, generator=g).to(bf); d = ops.Dropout(0.1, 1, 3)
+            f = lambda A=A, B=B, C=C, H=H, d=d: ops.gemm(A, B, C, M, N, K, lda, ldb, N, epi=ops.EPI_DSWISH, aux_in=H, drop=d, **kw)
+        elif epi == "atomic":
+            C = torch.zeros(M, N, device=dev)
+            f = lambda A=A, B=B, C=C: ops.gemm(A, B, C, M, N, K, lda, ldb, N, atomic=True, splitk=splitk, **kw)
+        fs.append(f)
+    cnt = [0]
+
+    def call():
+        fs[cnt[0] % ROT]()
+        cnt[0] += 1
+    t = timeit(call)
     print(f"{name:34s} {layout} M={M:7d} N={N:5d} K={K:6d} epi={epi:7s} {t*1e6:9.1f} us  {2.0*M*N*K/t/1e12:8.1f} TFLOP/s", flush=True)
 
 def run_grouped(name, M=16032, d=512, dff=2048, splitk=4):
@@ -156,10 +168,25 @@ if os.environ.get("V6_AB"):  # register-prefetch 256x256 structure on / off (LDS
             run(tag + "big_square", 8192, 8192, 8192, "nobias")
             run(tag + "sq4096", 4096, 4096, 4096, "nobias")
     sys.exit(0)
+if os.environ.get("COLD_AB"):  # the Conformer layer's NT shapes with rotating operand sets, every structure knob interleaved
+    for rep in range(int(os.environ.get("REPS", "2"))):
+        for v5, v6, v7 in ((1, 0, 0), (1, 1, 1), (0, 0, 0), (0, 1, 1)):
+            ops.gemm_config(5, v5); ops.gemm_config(6, v6); ops.gemm_config(7, v7)
+            tag = f"v5={v5} v6={v6} v7={v7} "
+            run(tag + "ffn1_fwd_swish", M, 2048, 512, "swish")
+            run(tag + "ffn2_dgrad_dswish", M, 2048, 512, "dswish")
+            run(tag + "ffn2_fwd_resid", M, 512, 2048, "resid")
+            run(tag + "ffn1_dgrad_store", M, 512, 2048, "store")
+            run(tag + "proj_fwd_resid", M, 512, 512, "resid")
+            run(tag + "proj_dgrad_store", M, 512, 512, "store")
+            run(tag + "qkv_fwd_store", M, 1536, 512, "store")
+            run(tag + "qkv_dgrad_store", M, 512, 1536, "store")
+            run(tag + "pw1_fwd_store", M, 1024, 512, "store")
+    sys.exit(0)
 if os.environ.get("V6N_AB"):  # the N = 512 shapes (256x128 tiles): LDS-DMA / register prefetch / persistent structure
     for rep in range(int(os.environ.get("REPS", "2"))):
         for v5, v6 in ((0, 0), (0, 1), (1, 0), (1, 1)):
-            ops.gemm_config(5, v5); ops.gemm_config(6, v6)
+            ops.gemm_config(5, v5); ops.gemm_config(7, v6)
             tag = f"v5={v5} v6={v6} "
             run(tag + "ffn2_fwd_resid", M, 512, 2048, "resid")
             run(tag + "ffn1_dgrad_store", M, 512, 2048, "store")
