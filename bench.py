@@ -437,9 +437,16 @@ def main():
         syncs = model._grad_syncs()
         for gs in syncs:
             gs.profile = True
-        model.fit_step(batch)
+        enc = model.encoder
+        enc.syncbn_profile = []
+        for _ in range(1 + getattr(enc, "graph_warmup", 0) + 1):  # (a new recording key: warm-up, record, then the measured step)
+            enc.syncbn_profile.clear()
+            model.fit_step(batch)
         barrier()
         exposed = sum(gs.exposed_events[0].elapsed_time(gs.exposed_events[1]) for gs in syncs if gs.exposed_events)
+        syncbn_ms = sum(e0.elapsed_time(e1) for e0, e1 in enc.syncbn_profile)
+        n_syncbn = len(enc.syncbn_profile)
+        enc.syncbn_profile = None
         for gs in syncs:
             gs.profile = False
         t = torch.tensor([exposed], device=dev, dtype=torch.float64)
@@ -449,7 +456,9 @@ def main():
             "grad_bytes_per_step": int(sum(gs.grad.numel() * 4 for gs in syncs)),
             "bucket_bytes": int(syncs[0].bucket_elems * 4),
             "exposed_exchange_ms_max_over_ranks": round(float(t.item()), 3),
-            "syncbn_allreduces_per_step": 2 * len(model.encoder.layers),
+            "syncbn_allreduces_per_step": n_syncbn,
+            "syncbn_exposed_ms_this_rank": round(syncbn_ms, 3),
+            "grad_wire_dtype": "bf16" if syncs[0].wire_dtype is not None else "fp32",
             "syncbn_own_process_group": os.environ.get("MI355X_SYNCBN_OWN_GROUP", "0") == "1",
         })
 

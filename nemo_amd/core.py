@@ -116,9 +116,12 @@ def _nemo_core():
     """(neural_types module, NeuralModule, typecheck) of an installed NeMo, else None.  With NeMo importable the drop-in
     modules ARE `nemo.core.classes.NeuralModule`s carrying the reference's own NeuralTypes, checked by the reference's own
     `typecheck` (core/classes/common.py:1011-1147) -- so they can be mixed freely with stock NeMo modules; the mirror above is
-    the fallback for boxes without NeMo's dependencies (this build box).  NEMO_AMD_NEMO_CORE=0 forces the mirror.  A stub
-    package (e.g. the import shim the oracle tooling uses) is recognised by the missing `_TYPECHECK_ENABLED` and ignored."""
-    if os.environ.get("NEMO_AMD_NEMO_CORE", "auto") == "0":
+    the default, and the fallback for boxes without NeMo's dependencies (this build box).  OPT-IN with NEMO_AMD_NEMO_CORE=1: the
+    real NeuralModule brings its own Serialization / Typing / FileIO mixins, which then precede this package's `Serialization` in
+    the MRO (from_config_dict / to_config_dict resolve to the reference's), and that combination has only been exercised against
+    a stand-in class here, never against an installed NeMo -- an integrator switches it on deliberately.
+    A stub package (e.g. the import shim the oracle tooling uses) is recognised by the missing `_TYPECHECK_ENABLED` and ignored."""
+    if os.environ.get("NEMO_AMD_NEMO_CORE", "0") != "1":
         return None
     try:
         common = importlib.import_module("nemo.core.classes.common")

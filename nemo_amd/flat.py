@@ -96,7 +96,17 @@ class FlatParams:
         """merged, aligned [start, end) element ranges of the parameters with requires_grad=True.  torch.optim.AdamW skips
         parameters without a gradient (frozen ones): the fused optimizer steps these ranges only, so neither the update nor
         the decoupled weight decay touches a frozen parameter.  One range (= one launch) when nothing is frozen."""
-        req = {n: p.requires_grad for n, p in self.module.named_parameters()}
+        # called per optimizer step (and per reduced bucket): the answer is cached on (generation, the requires_grad flags of a
+        # cached parameter list) -- reading 646 flags costs microseconds, walking named_parameters() the module tree every time
+        plist = getattr(self, "_plist", None)
+        if plist is None or plist[0] != self.generation:
+            named = dict(self.module.named_parameters())
+            plist = self._plist = (self.generation, [named.get(n) for n in self.order])
+        flags = tuple(p is not None and p.requires_grad for p in plist[1])
+        cached = getattr(self, "_ranges_cache", None)
+        if cached is not None and cached[0] == (self.generation, flags):
+            return list(cached[1])
+        req = dict(zip(self.order, flags))
         out: List[Tuple[int, int]] = []
         for n in self.order:
             if not req.get(n, False):
@@ -107,6 +117,7 @@ class FlatParams:
                 out[-1] = (out[-1][0], hi)
             else:
                 out.append((lo, hi))
+        self._ranges_cache = ((self.generation, flags), list(out))
         return out
 
     def zero_grad(self) -> None:

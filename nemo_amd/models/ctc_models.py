@@ -362,7 +362,7 @@ class EncDecCTCModel(nn.Module):
         # Lightning order (optimizer.step(), then scheduler.step() with interval 'step'): optimizer step n runs with
         # lr(max(1, n - 1)) of the Noam formula (lr_scheduler.py:518-576 reads `last_epoch` before it is advanced)
         lr = self._scheduler.get_last_lr() if self._scheduler is not None else None
-        scale = 1.0 / self.world_size
+        scale = syncs[0].grad_scale if syncs else 1.0 / self.world_size  # (1 when the buckets travel pre-scaled as bf16)
         early = self.optimizer_in_backward and self._optimizer.begin_step(lr=lr, grad_scale=scale)
         if early:  # slices of the flat buffers are updated as soon as their gradients are final (and reduced)
             self._install_early_step(syncs)

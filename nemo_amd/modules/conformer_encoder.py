@@ -251,6 +251,7 @@ class ConformerEncoder(NeuralModule):
         # behind the [2,d] sums through the same all-reduce and is read from device memory by the BatchNorm kernels
         # (mi355x_bn_finalize_dev_count / mi355x_bn_swish_bwd_apply_dev_count) -- exact for ragged ranks, no host round trip.
         self._syncbn_group = None
+        self.syncbn_profile = None  # a list while bench.py measures the exposed time of the statistics exchanges
         self.use_flash_attention = True  # bf16 + d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
         self.flash_delta_residual = os.environ.get("MI355X_FLASH_DELTA_LO", "1") != "0"  # (A/B switch of the delta fix)
         self.grad_ready_hook = None  # callable(start, end) on the flat gradient buffer (data-parallel bucketing)
@@ -422,7 +423,7 @@ class ConformerEncoder(NeuralModule):
         return (tuple(mel.shape), self._cdt(), str(mel.device), self._flatp.generation, self._syncbn_world(),
                 self.grad_ready_hook is not None, self._wgrad_join_per_layer, self.wgrad_side_stream, self.wgrad_grouped,
                 self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse,
-                self.use_flash_attention, self.flash_delta_residual, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder)
+                self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder)
 
     def _graphed_forward(self, mel, length):
         """-> (out, enc_len, graph set, generation) from the recorded sequence, or None when this call has to run eagerly"""
@@ -1055,7 +1056,18 @@ class ConformerEncoder(NeuralModule):
             # (an encoder driven without the model class: the own-group option then creates its group here, in the first training
             # forward -- new_group() is a collective, so every rank has to reach this forward)
             group = self.setup_process_groups()
-        self._eager_point(lambda: dist.all_reduce(stats, group=group))
+        if self.syncbn_profile is None:
+            self._eager_point(lambda: dist.all_reduce(stats, group=group))
+            return
+
+        def timed():  # diagnostics (bench.py): the exchange blocks the chain -- its stream time IS exposed time
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(stats, group=group)
+            e1.record()
+            if self.syncbn_profile is not None:
+                self.syncbn_profile.append((e0, e1))
+        self._eager_point(timed)
 
     # ------------------------------------------------------------------ backward implementation
     def _backward_impl(self, S, dout):

@@ -10,6 +10,12 @@ exchange with the rest of backward.  `wait()` joins the side stream before the o
 mean inside the fused AdamW kernel (`grad_scale = 1/world`), so no extra pass over the gradients is made.
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large buckets beat many small ones, hence the 64 MiB
 default (121.5 M fp32 gradients = 486 MB -> 8 buckets).
+
+`wire_dtype=torch.bfloat16` (MI355X_GRAD_WIRE=bf16) halves the bytes on the links (243 MB per step for Large): a bucket is scaled
+by 1/world and rounded to bf16 into a staging buffer on the exchange stream, the bf16 buffer is all-reduced, and the sum -- already
+the mean -- is widened back over the fp32 gradient slice (two extra HBM passes over the bucket, both on the exchange stream, i.e.
+off the backward chain).  The reference's DDP has the same option as the `bf16_compress_hook` communication hook; like it, this
+changes the gradient by one bf16 rounding per rank and is therefore OFF by default.
 """
 from __future__ import annotations
 
@@ -20,8 +26,16 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, grad: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, use_side_stream: Optional[bool] = None):
+    def __init__(self, grad: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, use_side_stream: Optional[bool] = None,
+                 wire_dtype: Optional[torch.dtype] = None):
+        import os
         self.grad = grad
+        if wire_dtype is None and os.environ.get("MI355X_GRAD_WIRE", "").lower() in ("bf16", "bfloat16"):
+            wire_dtype = torch.bfloat16
+        if wire_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("wire_dtype: float32 (default) or bfloat16")
+        self.wire_dtype = torch.bfloat16 if (wire_dtype == torch.bfloat16 and grad.is_cuda) else None
+        self._staging = None
         self.bucket_elems = max(1, bucket_bytes // grad.element_size())
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -59,25 +73,49 @@ class GradSync:
         if self._pending_elems >= self.bucket_elems:
             self.flush()
 
+    @property
+    def grad_scale(self) -> float:
+        """what the optimizer still has to multiply the exchanged gradients by: 1/world for the fp32 sum, 1 when the buckets
+        travelled as bf16 (they are scaled before the rounding)"""
+        return 1.0 if self.wire_dtype is not None else 1.0 / self.world
+
+    def _reduce(self, s: int, e: int):
+        """enqueue the all-reduce of grad[s:e] on the current stream; returns the work handle"""
+        view = self.grad[s:e]
+        if self.wire_dtype is None:
+            return dist.all_reduce(view, group=self.group, async_op=True)
+        from . import ops
+        n = e - s
+        if self._staging is None or self._staging.numel() < n:
+            self._staging = torch.empty(max(n, self.bucket_elems), dtype=self.wire_dtype, device=self.grad.device)
+        # (one staging buffer: the casts and the collective of consecutive buckets are ordered on the exchange stream)
+        st = self._staging[:n]
+        if n % 8:
+            raise RuntimeError("gradient ranges are 64-element aligned (FlatParams.ALIGN)")
+        ops.drop_scale_cast(view, st, n, 1.0 / self.world)
+        work = dist.all_reduce(st, group=self.group, async_op=True)
+        work.wait()  # stream-level: the widening copy below is ordered behind the collective, the host does not block
+        ops.drop_scale_cast(st, view, n, 1.0)
+        return work
+
     def flush(self) -> None:
         if self.world <= 1:
             self._pending, self._pending_elems = [], 0
             return
         for (s, e) in self._pending:
-            view = self.grad[s:e]
             if self._stream is not None:
                 self._stream.wait_stream(torch.cuda.current_stream(self.grad.device))
                 for ps in self.producer_streams():
                     self._stream.wait_stream(ps)
                 with torch.cuda.stream(self._stream):
-                    work = dist.all_reduce(view, group=self.group, async_op=True)
+                    work = self._reduce(s, e)
                     if self.after_reduce is not None:
                         work.wait()  # stream-level: the exchange stream waits for the collective, the host does not
                         self.after_reduce(s, e)
                     else:
                         self._works.append(work)
             else:
-                work = dist.all_reduce(view, group=self.group, async_op=True)
+                work = self._reduce(s, e)
                 if self.after_reduce is not None:
                     work.wait()
                     self.after_reduce(s, e)
@@ -105,7 +143,7 @@ class GradSync:
                 cur.wait_stream(self._stream)
         self._reduced = []
         self.launches_last_step, self._launches = self._launches, 0
-        return 1.0 / self.world
+        return self.grad_scale
 
     def reduced_ranges(self):
         return list(self._reduced)

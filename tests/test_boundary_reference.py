@@ -209,6 +209,12 @@ def test_with_nemo_core_importable_the_modules_are_real_neural_modules(tmp_path)
             pass
         print("REAL-CORE-OK")
     """)
-    env = dict(os.environ, PYTHONPATH=f"{tmp_path}:{os.path.dirname(os.path.dirname(os.path.abspath(__file__)))}")
+    env = dict(os.environ, PYTHONPATH=f"{tmp_path}:{os.path.dirname(os.path.dirname(os.path.abspath(__file__)))}",
+               NEMO_AMD_NEMO_CORE="1")  # the binding to an installed NeMo's classes is opt-in
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert "REAL-CORE-OK" in r.stdout, r.stdout + r.stderr
+    # and without the opt-in the mirror stays in place even though `nemo.core` is importable
+    env.pop("NEMO_AMD_NEMO_CORE")
+    r = subprocess.run([sys.executable, "-c", "import nemo_amd.core as C; print('MIRROR' if not C.HAVE_NEMO_CORE else 'REAL')"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert "MIRROR" in r.stdout, r.stdout + r.stderr

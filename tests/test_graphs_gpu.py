@@ -139,10 +139,11 @@ def test_backward_of_an_overwritten_forward_is_refused():
         first.backward()
 
 
-def _dp_worker(rank, world, port, out_dir, over, graphs):
+def _dp_worker(rank, world, port, out_dir, over, graphs, wire="fp32"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["MI355X_GRAD_WIRE"] = wire
     dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks on the one GPU; gloo stages through the host
     try:
         torch.cuda.set_device(0)
@@ -158,7 +159,7 @@ def _dp_worker(rank, world, port, out_dir, over, graphs):
         torch.cuda.synchronize()
         torch.save(dict(losses=losses, flat=[fp.flat.detach().cpu() for fp in model.flats()], info=model.encoder.graph_info(),
                         bn=model.encoder.layers[1].conv.batch_norm.running_var.detach().cpu()),
-                   os.path.join(out_dir, f"g{int(graphs)}_rank{rank}.pt"))
+                   os.path.join(out_dir, f"g{int(graphs)}{'' if wire == 'fp32' else wire}_rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -185,3 +186,24 @@ def test_two_ranks_replay_with_live_collectives_between_the_segments(tmp_path):
         assert abs(a - b) <= 1e-4 * abs(b), (g0["losses"], e0["losses"])
     for a, b in zip(g0["flat"], e0["flat"]):
         assert (a - b).norm() <= 3e-3 * b.norm()
+
+
+def test_bf16_gradient_wire_follows_the_fp32_exchange(tmp_path):
+    """MI355X_GRAD_WIRE=bf16 (GradSync(wire_dtype=bfloat16), the analogue of DDP's bf16_compress_hook): buckets are scaled by
+    1/world, rounded to bf16, all-reduced and widened back; the optimizer then applies no further scale.  The replicas stay
+    identical and the loss curve follows the fp32 exchange within bf16 rounding of the gradients."""
+    import torch.multiprocessing as mp
+    over = dict(d_model=64, n_heads=4, n_layers=2, **NODROP)
+    res = {}
+    for wire in ("bf16", "fp32"):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        mp.spawn(_dp_worker, args=(2, port, str(tmp_path), over, True, wire), nprocs=2, join=True)
+        tag = "" if wire == "fp32" else wire
+        res[wire] = [torch.load(tmp_path / f"g1{tag}_rank{r}.pt") for r in (0, 1)]
+    b0, b1 = res["bf16"]
+    f0, _ = res["fp32"]
+    for a, b in zip(b0["flat"], b1["flat"]):
+        assert torch.equal(a, b)
+    assert b0["losses"][-1] < 0.98 * b0["losses"][0]
+    for a, b in zip(b0["losses"], f0["losses"]):
+        assert abs(a - b) <= 5e-3 * abs(b), (b0["losses"], f0["losses"])
