@@ -145,6 +145,7 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, mel, length, token, module):
         ctx.module, ctx.saved, ctx.gset = module, None, None
         res = module._graphed_forward(mel, length)  # None: this call runs eagerly (warm-up, unstable shapes, graphs off)
+        ctx.timed_gs = module._cur_gs
         if res is not None:
             out, enc_len, ctx.gset, ctx.gen = res
         else:
@@ -158,6 +159,7 @@ class _EncoderFn(torch.autograd.Function):
             ctx.module._graphed_backward(ctx.gset, ctx.gen, dout)
         else:
             ctx.module._backward_impl(ctx.saved, dout)
+        ctx.module._auto_end(ctx.timed_gs)
         ctx.saved = None
         return None, None, None, None
 
@@ -172,6 +174,13 @@ class _GraphSet:
         self.mel = self.length = self.out = self.enc_len = self.dout = None
         self.gen = 0            # forward replays so far; a backward must belong to the latest one
         self.failed = False
+        # "auto" mode: the launch sequence is timed on the device (event pairs: forward start -> backward end) both ways and
+        # the faster one is kept -- replaying ~1 000 graph nodes is not always faster than issuing them live (on ROCm 7 a node
+        # costs the GPU's command processor about as much as a launch, and a step whose live issue time is well below its GPU
+        # time has nothing to gain: Conformer-CTC-Large replays 0.7 ms SLOWER than it launches, Squeezeformer-Medium 2.6 ms faster)
+        self.samples = {"eager": [], "graph": []}   # (start, end) event pairs
+        self.open_pair = None   # [mode, start event, None] of the step in flight
+        self.decided = None     # None (still measuring) | "eager" | "graph"
 
 
 class ConformerEncoder(NeuralModule):
@@ -274,10 +283,15 @@ class ConformerEncoder(NeuralModule):
         self._weights_version = -1
         self._token = None
         # ---- replayable launch sequences (nemo_amd/graphs.py).  MI355X_GRAPHS=0 keeps every step on the eager sequencer.
-        self.use_graphs = os.environ.get("MI355X_GRAPHS", "1") != "0"
+        # MI355X_GRAPHS: 0 = always live launches, 1 = always replay, auto (default) = time both on the device, keep the faster
+        _g = os.environ.get("MI355X_GRAPHS", "auto")
+        self.use_graphs = _g != "0"
+        self.graph_auto = _g not in ("0", "1", "2")
         self.graph_warmup = 2       # eager training forwards per key before its launch sequence is captured
+        self.graph_trials = 4       # auto: timed steps per mode, alternating
         self.max_graph_sets = 8     # distinct (shape, configuration) keys kept (a duration-bucketed loader has a handful)
         self._graph_sets = OrderedDict()
+        self._cur_gs = None
         self._capture = None        # the SegmentedCapture while a sequence is being recorded
         self._wg_forked = False     # recording: the weight-gradient stream has joined the capture and not re-joined yet
         self._force_pack = False    # record the weight-image pack unconditionally (a replayed forward always re-packs)
@@ -425,8 +439,37 @@ class ConformerEncoder(NeuralModule):
                 self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse,
                 self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder)
 
+    def _auto_begin(self, gs, mode):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gs.open_pair = [mode, e0, None]
+
+    def _auto_end(self, gs):
+        """backward of the step has been issued: stamp the end of the timed interval"""
+        op = gs.open_pair if gs is not None else None
+        if op is not None and op[2] is None:
+            op[2] = torch.cuda.Event(enable_timing=True)
+            op[2].record()
+            gs.samples[op[0]].append((op[1], op[2]))
+            gs.open_pair = None
+
+    def _auto_decide(self, gs):
+        """both ways have been timed `graph_trials` times, alternating step by step (drift and clock changes hit both alike):
+        keep the faster one.  One host wait on the last end event -- once per shape, outside any timed region."""
+        for v in gs.samples.values():
+            for _, e1 in v:
+                e1.synchronize()
+        med = lambda v: sorted(v)[len(v) // 2]
+        t = {m: med([e0.elapsed_time(e1) for e0, e1 in v]) for m, v in gs.samples.items()}
+        gs.decided = "graph" if t["graph"] < t["eager"] else "eager"
+        gs.auto_ms = {m: round(x, 3) for m, x in t.items()}
+        gs.samples = {"eager": [], "graph": []}
+        if gs.decided == "eager":
+            gs.fwd = gs.bwd = gs.S = gs.out = gs.enc_len = gs.mel = gs.dout = None  # the pool goes with the graphs
+
     def _graphed_forward(self, mel, length):
         """-> (out, enc_len, graph set, generation) from the recorded sequence, or None when this call has to run eagerly"""
+        self._cur_gs = None
         if not (self.use_graphs and self.training and mel.is_cuda) or ops.GEMM_PROFILE is not None:
             return None
         key = self._graph_key(mel, length)
@@ -438,6 +481,10 @@ class ConformerEncoder(NeuralModule):
         else:
             self._graph_sets.move_to_end(key)
         gs.calls += 1
+        self._cur_gs = gs
+        auto = self.graph_auto
+        if auto and gs.decided == "eager":
+            return None
         if gs.failed or gs.calls <= self.graph_warmup:
             return None
         if gs.fwd is None:
@@ -451,6 +498,18 @@ class ConformerEncoder(NeuralModule):
                               "running on the eager sequencer")
                 gs.failed, gs.fwd, gs.S = True, None, None
                 return None
+        elif auto and gs.decided is None and gs.bwd is not None:
+            # the trial: live launches and replay ALTERNATE step by step, each timed on the device from here to the end of backward
+            n_e, n_g = len(gs.samples["eager"]), len(gs.samples["graph"])
+            if n_e >= self.graph_trials and n_g >= self.graph_trials:
+                self._auto_decide(gs)
+                if gs.decided == "eager":
+                    return None
+            elif n_e <= n_g:
+                self._auto_begin(gs, "eager")
+                return None
+            else:
+                self._auto_begin(gs, "graph")
         gs.mel.copy_(mel)
         gs.length.copy_(length)
         gs.fwd.replay()
@@ -513,6 +572,13 @@ class ConformerEncoder(NeuralModule):
             gs.dout.copy_(dout)
         gs.bwd.replay()
 
+    def graphs_settled(self) -> bool:
+        """auto mode: has every shape seen so far finished its eager-vs-replay trial?  (bench.py keeps running un-timed steps
+        until this holds, so that neither a recording step nor a trial step falls into the timed region)"""
+        if not (self.use_graphs and self.graph_auto):
+            return True
+        return all(gs.decided is not None or gs.failed for gs in self._graph_sets.values())
+
     def graph_info(self):
         """diagnostics (bench.py): recorded keys, graph segments and live host calls per forward / backward"""
         out = []
@@ -520,7 +586,11 @@ class ConformerEncoder(NeuralModule):
             if gs.fwd is not None:
                 out.append({"mel_shape": list(key[0]), "fwd_graphs": gs.fwd.n_graphs(), "fwd_host_calls": len(gs.fwd.seq) - gs.fwd.n_graphs(),
                             "bwd_graphs": gs.bwd.n_graphs() if gs.bwd is not None else None,
-                            "bwd_host_calls": (len(gs.bwd.seq) - gs.bwd.n_graphs()) if gs.bwd is not None else None})
+                            "bwd_host_calls": (len(gs.bwd.seq) - gs.bwd.n_graphs()) if gs.bwd is not None else None,
+                            "auto": getattr(gs, "auto_ms", None), "decided": gs.decided})
+            elif gs.decided == "eager":
+                out.append({"mel_shape": list(key[0]), "decided": "eager (live launches measured faster than the replay)",
+                            "auto": getattr(gs, "auto_ms", None)})
         return out
 
     @staticmethod
@@ -587,7 +657,10 @@ class ConformerEncoder(NeuralModule):
             return contextlib.nullcontext()
         dev = tensors[0].device
         if self._wg_stream is None or self._wg_stream.device != dev:
-            self._wg_stream = torch.cuda.Stream(device=dev)
+            # MI355X_WGRAD_PRIO: -1 = high, 0 = default, 1 = low (HIP stream priorities): nothing on the backward chain waits
+            # for a weight gradient, so the chain's kernels should win the CUs whenever both streams have workgroups pending
+            prio = int(os.environ.get("MI355X_WGRAD_PRIO", "0"))
+            self._wg_stream = torch.cuda.Stream(device=dev, priority=prio) if prio else torch.cuda.Stream(device=dev)
         side = self._wg_stream
         side.wait_stream(torch.cuda.current_stream(dev))  # operands are produced on the main stream
         if self._capture is not None:

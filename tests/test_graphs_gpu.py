@@ -36,6 +36,7 @@ def _run(over, graphs, steps, batches, dtype=torch.float32, lr=1e-3, seed=21, ho
     model = _model(dict(over, compute_dtype=dtype)).to(dev).train()
     model.decoder.compute_dtype = dtype
     model.encoder.use_graphs = graphs
+    model.encoder.graph_auto = False  # forced: record after `graph_warmup` eager steps (the default would time both ways first)
     model.optimizer_in_backward = hook
     model.setup_optimization(dict(name="adamw", lr=lr, betas=[0.9, 0.98], weight_decay=1e-3))
     losses = [model.fit_step(batches[i % len(batches)])["loss"].item() for i in range(steps)]
@@ -107,6 +108,7 @@ def test_dropout_masks_follow_the_device_step_word_bf16():
     mg.decoder.compute_dtype = torch.bfloat16
     mg.setup_optimization(dict(name="adamw", lr=0.0))
     enc = mg.encoder
+    enc.graph_auto = False
     for _ in range(enc.graph_warmup):
         _step_grads(mg, batch)
     l3, _ = _step_grads(mg, batch)   # recorded + replayed
@@ -130,6 +132,7 @@ def test_dropout_masks_follow_the_device_step_word_bf16():
 def test_backward_of_an_overwritten_forward_is_refused():
     over = dict(d_model=64, n_heads=4, n_layers=2, **NODROP)
     model = _model(over).to(dev).train()
+    model.encoder.graph_auto = False
     batch = _batch()
     for _ in range(model.encoder.graph_warmup + 1):
         model.training_step(batch)["loss"].backward()
@@ -150,6 +153,7 @@ def _dp_worker(rank, world, port, out_dir, over, graphs, wire="fp32"):
         torch.manual_seed(5)
         model = _model(over).to(dev).train()
         model.encoder.use_graphs = graphs
+        model.encoder.graph_auto = False
         model.setup_optimization(dict(name="adamw", lr=1e-3, betas=[0.9, 0.98], weight_decay=0.0))
         audio, alen, tok, tl = R.synthetic_batch(4, 1.0, vocab=20, seed=8)
         alen = torch.tensor([16000, 9000, 14000, 16000])
@@ -207,3 +211,24 @@ def test_bf16_gradient_wire_follows_the_fp32_exchange(tmp_path):
     assert b0["losses"][-1] < 0.98 * b0["losses"][0]
     for a, b in zip(b0["losses"], f0["losses"]):
         assert abs(a - b) <= 5e-3 * abs(b), (b0["losses"], f0["losses"])
+
+
+def test_auto_mode_times_both_ways_and_keeps_one():
+    """the default (MI355X_GRAPHS=auto): a shape runs eagerly for its first steps, is recorded, replayed for a few timed steps and
+    then stays on whichever was faster on the device; the optimisation trajectory is the eager one either way"""
+    over = dict(d_model=64, n_heads=4, n_layers=2, **NODROP)
+    batches = [_batch()]
+    torch.manual_seed(21)
+    m = _model(dict(over, compute_dtype=torch.float32)).to(dev).train()
+    m.decoder.compute_dtype = torch.float32
+    assert m.encoder.use_graphs and m.encoder.graph_auto  # the defaults
+    m.setup_optimization(dict(name="adamw", lr=1e-3, betas=[0.9, 0.98], weight_decay=1e-3))
+    losses = []
+    for i in range(16):
+        losses.append(m.fit_step(batches[0])["loss"].item())  # (.item() drains the queue: the end events are reached)
+    assert m.encoder.graphs_settled()
+    info = m.encoder.graph_info()
+    assert len(info) == 1 and str(info[0]["decided"]).split()[0] in ("eager", "graph") and info[0]["auto"] is not None, info
+    m_e, l_e = _run(over, False, 16, batches)
+    for a, b in zip(losses, l_e):
+        assert abs(a - b) <= 5e-5 * abs(b), (losses, l_e)

@@ -69,6 +69,7 @@ res = {"model": kind, "batch": "32 x 20 s", "dtype": "bf16"}
 for mode in ("graphs", "eager"):
     m, vocab = build()
     m.encoder.use_graphs = mode == "graphs"
+    m.encoder.graph_auto = False
     audio, alen, tok, tl = R.synthetic_batch(32, 20.0, vocab=vocab, seed=0)
     batch = [t.to(dev) for t in (audio, alen, tok, tl)]
     for _ in range(5):
