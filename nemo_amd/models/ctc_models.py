@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import copy
 import os
+import contextlib
 from typing import Any, Dict, Optional
 
 import torch
@@ -366,8 +367,10 @@ class EncDecCTCModel(nn.Module):
         early = self.optimizer_in_backward and self._optimizer.begin_step(lr=lr, grad_scale=scale)
         if early:  # slices of the flat buffers are updated as soon as their gradients are final (and reduced)
             self._install_early_step(syncs)
-        out = self.training_step(batch, self.global_step)
-        out["loss"].backward()
+        scope = getattr(self.encoder, "step_scope", None)
+        with (scope() if scope is not None else contextlib.nullcontext()):  # forward -> backward -> next forward discipline
+            out = self.training_step(batch, self.global_step)
+            out["loss"].backward()
         self._after_backward()
         for gs in syncs:
             gs.wait()

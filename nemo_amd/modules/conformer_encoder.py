@@ -292,6 +292,18 @@ class ConformerEncoder(NeuralModule):
         self.max_graph_sets = 8     # distinct (shape, configuration) keys kept (a duration-bucketed loader has a handful)
         self._graph_sets = OrderedDict()
         self._cur_gs = None
+        # ---- step-scoped bump allocation of the sequencer's tensors (nemo_amd/arena.py); MI355X_ARENA=0: torch's caching allocator
+        from ..arena import Arena
+        # Both the arena and the recorded launch sequences keep ONE set of activations per encoder: they need the forward ->
+        # backward -> next forward discipline of a training loop.  `step_scope()` (entered by the model's fit_step) switches them on;
+        # a module driven by hand (two stochastic forwards, then backward through the first -- legal torch) stays on torch's allocator
+        # and live launches unless MI355X_ARENA=1 / MI355X_GRAPHS=1 force them.
+        _a = os.environ.get("MI355X_ARENA", "auto")
+        self.use_arena = _a != "0"
+        self.arena_forced = _a == "1"
+        self._in_step = False
+        self._arena_f, self._arena_b, self._arena = Arena("forward"), Arena("backward"), None
+        self._fwd_serial = 0        # forwards so far: a backward must belong to the latest one (its activations live in the arena)
         self._capture = None        # the SegmentedCapture while a sequence is being recorded
         self._wg_forked = False     # recording: the weight-gradient stream has joined the capture and not re-joined yet
         self._force_pack = False    # record the weight-image pack unconditionally (a replayed forward always re-packs)
@@ -347,6 +359,22 @@ class ConformerEncoder(NeuralModule):
         if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
             return torch.bfloat16
         return torch.float32
+
+    def _new(self, *shape, dtype, device):
+        """a tensor of this step's forward / backward: from the phase's arena when one is active, else from torch's allocator"""
+        a = self._arena
+        if a is None:
+            return torch.empty(*shape, dtype=dtype, device=device)
+        return a.take(shape, dtype, device)
+
+    def _phase(self, which, device):
+        """start of a forward ('f') / backward ('b') pass: rewind that phase's arena and make it the current one"""
+        if not (self.use_arena and (self._in_step or self.arena_forced) and torch.device(device).type == "cuda"):
+            self._arena = None
+            return
+        a = self._arena_f if which == "f" else self._arena_b
+        a.rewind(torch.device(device))
+        self._arena = None if a.disabled else a
 
     def _buf(self, name, shape, dtype, device, zero=False):
         """persistent workspace `name`: ONE allocation per (name, dtype) that grows to the largest size ever asked for and is handed
@@ -483,7 +511,7 @@ class ConformerEncoder(NeuralModule):
         gs.calls += 1
         self._cur_gs = gs
         auto = self.graph_auto
-        if auto and gs.decided == "eager":
+        if auto and (gs.decided == "eager" or not self._in_step):
             return None
         if gs.failed or gs.calls <= self.graph_warmup:
             return None
@@ -514,6 +542,8 @@ class ConformerEncoder(NeuralModule):
         gs.length.copy_(length)
         gs.fwd.replay()
         gs.gen += 1
+        self._fwd_serial += 1       # (the recorded tensors live in the shared arena: ANY later forward overwrites them)
+        gs.serial = self._fwd_serial
         # fresh tensor objects on the static storage (autograd attaches this call's node to what a Function returns)
         return gs.out.detach(), gs.enc_len.detach(), gs, gs.gen
 
@@ -544,7 +574,7 @@ class ConformerEncoder(NeuralModule):
 
     def _graphed_backward(self, gs, gen, dout):
         from ..graphs import SegmentedCapture
-        if gen != gs.gen:
+        if gen != gs.gen or getattr(gs, "serial", self._fwd_serial) != self._fwd_serial:
             raise RuntimeError("backward through an encoder forward whose saved activations were overwritten by a later forward "
                                "of the same shape (recorded launch sequences keep ONE set of activations per shape); set "
                                "encoder.use_graphs = False (or MI355X_GRAPHS=0) for several forwards per backward")
@@ -554,6 +584,7 @@ class ConformerEncoder(NeuralModule):
             cap = SegmentedCapture(dout.device, pool=gs.pool)
             ops.set_step_counter(self._step_word)
             try:
+                gs.S.serial = self._fwd_serial  # (the replay that filled these activations is the latest forward)
                 with cap.capturing(before_cut=self._wgrad_join):
                     self._capture = cap
                     self._backward_impl(gs.S, gs.dout)
@@ -709,6 +740,8 @@ class ConformerEncoder(NeuralModule):
     # ------------------------------------------------------------------ forward implementation
     def _forward_impl(self, mel, length, save=False):
         dev = mel.device
+        self._phase("f", dev)
+        self._fwd_serial += 1
         cdt = self._cdt()
         if cdt == torch.bfloat16 and (self.d_k % 8 or self.d_model % 8):
             # the bf16 operand path moves 16-byte pieces: a head must start on an 8-element boundary.  The recipe table's
@@ -736,6 +769,7 @@ class ConformerEncoder(NeuralModule):
             return ops.Dropout(p if training else 0.0, seed, site)
 
         S = _Saved()
+        S.serial, S.arena = self._fwd_serial, self._arena is not None
         S.dims = (B, F_, T, T1, F1, T2, F2, M, cdt, training, seed)
         S.mel, S.len0, S.len2 = mel, len0, len2
         pe = self.pre_encode
@@ -745,7 +779,7 @@ class ConformerEncoder(NeuralModule):
             x = self._sub_fwd_dw(S, mel, lens, W, cdt, save)
         else:
             # ---- sub-sampling: conv1 (direct) -> conv2 (implicit MFMA GEMM, ReLU+mask epilogue) -> out Linear (+xscale, dropout)
-            S.out1 = torch.empty(B, T1, F1, C_, dtype=cdt, device=dev)
+            S.out1 = self._new(B, T1, F1, C_, dtype=cdt, device=dev)
             ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, S.out1, len0, len1, C_)
             # (channel counts the gather does not cover fall back to an im2col image, kept alive for the weight gradient)
             implicit = (self.conv2_implicit and self._conv2_implicit(cdt, C_, B * T2 * F2)
@@ -756,7 +790,7 @@ class ConformerEncoder(NeuralModule):
                 ops.im2col(S.out1, col, B, T1, F1, C_)
                 self._col_gen = getattr(self, "_col_gen", 0) + 1
                 S.col, S.col_gen = (col if save else None), self._col_gen
-            S.out2 = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
+            S.out2 = self._new(B * T2 * F2, C_, dtype=cdt, device=dev)
             if implicit:
                 # implicit GEMM: the A rows are gathered from out1 by the LDS-DMA (tap (kh-1, kw-1) per 512-wide K block);
                 # forward, weight gradient and input gradient all gather -- no im2col image, no col2im pass
@@ -767,7 +801,7 @@ class ConformerEncoder(NeuralModule):
             else:
                 ops.gemm(col, W["pre.w2"], S.out2, B * T2 * F2, C_, 9 * C_, 9 * C_, W.pitch("pre.w2"), C_, bias=pe.conv[2].bias,
                          epi=ops.EPI_RELU_MASK, row_len=len2, rows_per_b=T2 * F2, rows_inner=F2)
-            x = torch.empty(M, d, dtype=torch.float32, device=dev)
+            x = self._new(M, d, dtype=torch.float32, device=dev)
             ops.gemm(S.out2, W["pre.out"], x, M, d, F2 * C_, F2 * C_, W.pitch("pre.out"), d, bias=pe.out.bias,
                      alpha=(self.xscale or 1.0), drop=S.drop_pre)
         # ---- relative positional table (constant)
@@ -825,20 +859,20 @@ class ConformerEncoder(NeuralModule):
         pe = self.pre_encode
         io = self._sub_io(Wf, cdt, dev)
         C_, d = io.C, self.d_model
-        out0 = torch.empty(B, T1, F1, C_, dtype=cdt, device=dev)
+        out0 = self._new(B, T1, F1, C_, dtype=cdt, device=dev)
         ops.conv1_fwd(mel, io.c0w, io.c0b, out0, lens[0], lens[1], C_)
         cur, Tc, Fc = out0, T1, F1
         S.dw = []
         for si_, (dww, dwb, pwb) in enumerate(io.dw):
             Tn, Fn = (Tc - 1) // 2 + 1, (Fc - 1) // 2 + 1
-            dwo = torch.empty(B * Tn * Fn, C_, dtype=cdt, device=dev)
+            dwo = self._new(B * Tn * Fn, C_, dtype=cdt, device=dev)
             ops.dwconv2d_s2_fwd(cur, dww, dwb, dwo, B, Tc, Fc, C_)
-            pwo = torch.empty(B * Tn * Fn, C_, dtype=cdt, device=dev)
+            pwo = self._new(B * Tn * Fn, C_, dtype=cdt, device=dev)
             ops.gemm(dwo, W[f"pre.pw{si_}"], pwo, B * Tn * Fn, C_, C_, C_, W.pitch(f"pre.pw{si_}"), C_, bias=pwb,
                      epi=ops.EPI_RELU_MASK, row_len=lens[si_ + 2], rows_per_b=Tn * Fn, rows_inner=Fn)
             S.dw.append((cur, Tc, Fc, dwo, pwo, Tn, Fn))
             cur, Tc, Fc = pwo, Tn, Fn
-        x = torch.empty(M, d, dtype=torch.float32, device=dev)
+        x = self._new(M, d, dtype=torch.float32, device=dev)
         ops.gemm(cur, W["pre.out"], x, M, d, F2 * C_, F2 * C_, W.pitch("pre.out"), d, bias=pe.out.bias,
                  alpha=(self.xscale or 1.0), drop=S.drop_pre)
         S.out1, S.out2, S.col = out0, cur, None
@@ -852,7 +886,7 @@ class ConformerEncoder(NeuralModule):
         C_, d = io.C, self.d_model
         bf16 = cdt == torch.bfloat16
         ldx = _pad8(d) if bf16 else d  # (bf16 operand rows start on 16-byte boundaries)
-        dxs = torch.empty(M, ldx, dtype=cdt, device=dev)
+        dxs = self._new(M, ldx, dtype=cdt, device=dev)
         if ldx != d or (M * d) % 8:
             ops.cast_pitched(dx, dxs, M, d, ldx, (self.xscale or 1.0), S.drop_pre)
         else:
@@ -865,7 +899,7 @@ class ConformerEncoder(NeuralModule):
             ops.gemm(dxs, last, io.g_out, d, C_, M, ldx, F2 * C_, C_ * F2, transA=True, transB=True, atomic=True,
                      splitk=self._splitk(tiles, M, strided_c=True), batch=F2, nb0=F2, sB=(C_, 0), sC=(1, 0), c_col_stride=F2,
                      c_dtype=ops.F32)
-        dcur = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
+        dcur = self._new(B * T2 * F2, C_, dtype=cdt, device=dev)
         ops.gemm(dxs, W["pre.outt"], dcur, M, F2 * C_, d, ldx, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=last)
         for si_ in range(len(S.dw) - 1, -1, -1):
             cur_in, Tc, Fc, dwo, pwo, Tn, Fn = S.dw[si_]
@@ -882,9 +916,9 @@ class ConformerEncoder(NeuralModule):
                     ops.colsum(dcur, g_pwb, Ms, C_)
                     ops.gemm(dcur, dwo, g_pww, C_, C_, Ms, C_, C_, C_, transA=True, transB=True, atomic=True,
                              splitk=self._splitk(self._tiles(C_, C_, bf16), Ms), c_dtype=ops.F32)
-            ddw = torch.empty(Ms, C_, dtype=cdt, device=dev)
+            ddw = self._new(Ms, C_, dtype=cdt, device=dev)
             ops.gemm(dcur, W[f"pre.pw{si_}t"], ddw, Ms, C_, C_, C_, W.pitch(f"pre.pw{si_}t"), C_)
-            din = torch.empty(B * Tc * Fc, C_, dtype=cdt, device=dev)
+            din = self._new(B * Tc * Fc, C_, dtype=cdt, device=dev)
             ops.dwconv2d_s2_bwd(ddw, cur_in, dww, din, g_dww, g_dwb, B, Tc, Fc, C_)
             dcur = din
         ops.conv1_bwd(dcur, S.mel, S.len0, io.g_c0w, io.g_c0b, C_)
@@ -895,21 +929,21 @@ class ConformerEncoder(NeuralModule):
             self._hook(*self._flatp.range_of("pre_encode."))
 
     def _ln_fwd(self, ln, x, M, d, out_dtype, dev):
-        y = torch.empty(M, d, dtype=out_dtype, device=dev)
-        mean = torch.empty(M, dtype=torch.float32, device=dev)
-        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+        y = self._new(M, d, dtype=out_dtype, device=dev)
+        mean = self._new(M, dtype=torch.float32, device=dev)
+        rstd = self._new(M, dtype=torch.float32, device=dev)
         ops.layernorm_fwd(x, ln.weight, ln.bias, y, mean, rstd, M, d, ln.eps)
         return y, mean, rstd
 
     def _ffn_fwd(self, pfx, ff, x, ln, S, sl, W, drop, site, M, d, dff, cdt, dev, tag):
         y, mean, rstd = self._ln_fwd(ln, x, M, d, cdt, dev)
-        h = torch.empty(M, dff, dtype=cdt, device=dev)
-        a = torch.empty(M, dff, dtype=cdt, device=dev)
+        h = self._new(M, dff, dtype=cdt, device=dev)
+        a = self._new(M, dff, dtype=cdt, device=dev)
         d_in = drop(self.dropout, site)
         d_res = drop(self.dropout, site + 1)
         ops.gemm(y, W[pfx + ".w1"], a, M, dff, d, d, W.pitch(pfx + ".w1"), dff, bias=ff.linear1.bias, epi=ops.EPI_SWISH_DROP,
                  aux_out=h, drop=d_in)
-        r = torch.empty(M, d, dtype=torch.float32, device=dev)
+        r = self._new(M, d, dtype=torch.float32, device=dev)
         ops.gemm(a, W[pfx + ".w2"], r, M, d, dff, dff, W.pitch(pfx + ".w2"), d, bias=ff.linear2.bias, alpha=0.5,
                  epi=ops.EPI_RESID, aux_in=x, drop=d_res)
         setattr(sl, tag, (x, y, mean, rstd, h, a, d_in, d_res))
@@ -920,7 +954,7 @@ class ConformerEncoder(NeuralModule):
         18 [2T-1, d] x [d, d] products are one batched GEMM (288 tiles) instead of 18 launches of 16 tiles."""
         nl, d = self.n_layers, self.d_model
         P = pos.shape[0]
-        p_all = torch.empty(nl, P, d, dtype=cdt, device=dev)
+        p_all = self._new(nl, P, d, dtype=cdt, device=dev)
         es = W["L0.att.wpos"].element_size()
         stride = (W["L1.att.wpos"].data_ptr() - W["L0.att.wpos"].data_ptr()) // es if nl > 1 else 0
         uniform = all(W[f"L{i}.att.wpos"].data_ptr() - W["L0.att.wpos"].data_ptr() == i * stride * es for i in range(nl))
@@ -953,19 +987,19 @@ class ConformerEncoder(NeuralModule):
         H = self.n_heads
         M, P = B * T, 2 * T - 1
         Tp, Pp = _pad8(T), _pad8(P)
-        ctx = torch.empty(M, dA, dtype=cdt, device=dev)
+        ctx = self._new(M, dA, dtype=cdt, device=dev)
         flash = self.use_flash_attention and cdt == torch.bfloat16 and dk == 64
         if flash:
             # fused rel-pos flash attention: scores / positional matrix never touch HBM; only the log-sum-exp is kept
-            lse = torch.empty(B, H, T, dtype=torch.float32, device=dev)
+            lse = self._new(B, H, T, dtype=torch.float32, device=dev)
             # training: also the bf16 rounding residual of the context (backward's delta = sum dO * O needs more than the 8
             # mantissa bits of the stored operand -- see mi355x_relpos_flash_fwd); it travels in the first slot of the saved tuple
-            ctx_lo = torch.empty(M, dA, dtype=cdt, device=dev) if (self.training and self.flash_delta_residual) else None
+            ctx_lo = self._new(M, dA, dtype=cdt, device=dev) if (self.training and self.flash_delta_residual) else None
             ops.relpos_flash_fwd(qkv, 3 * dA, p, dA, bias_u, bias_v, lens, ctx, dA, lse, B, H, T, dk, Tp, scale, d_att,
                                  ctx_lo=ctx_lo)
             return ctx, (ctx_lo, None, None, None, lse)
-        qu = torch.empty(M, dA, dtype=cdt, device=dev)
-        qv = torch.empty(M, dA, dtype=cdt, device=dev)
+        qu = self._new(M, dA, dtype=cdt, device=dev)
+        qv = self._new(M, dA, dtype=cdt, device=dev)
         ops.qbias(qkv, 3 * dA, bias_u, bias_v, qu, qv, M, dA)
         ac = self._buf("ac", (H, B, T, Tp), torch.float32, dev)
         bdf = self._buf("bdf", (H, B, T, Pp), torch.float32, dev)
@@ -973,8 +1007,8 @@ class ConformerEncoder(NeuralModule):
         ops.gemm(qu, qkv, ac, T, T, dk, dA, 3 * dA, Tp, batch=H * B, nb0=B, sA=(T * dA, dk), sB=(T * 3 * dA, dk),
                  sC=(T * Tp, B * T * Tp), b_off=dA)
         ops.gemm(qv, p, bdf, T, P, dk, dA, dA, Pp, batch=H * B, nb0=B, sA=(T * dA, dk), sB=(0, dk), sC=(T * Pp, B * T * Pp))
-        s_ = torch.empty(H, B, T, Tp, dtype=cdt, device=dev)
-        pd = torch.empty(H, B, T, Tp, dtype=cdt, device=dev) if d_att.threshold else None
+        s_ = self._new(H, B, T, Tp, dtype=cdt, device=dev)
+        pd = self._new(H, B, T, Tp, dtype=cdt, device=dev) if d_att.threshold else None
         ops.relpos_softmax_fwd(ac, bdf, s_, pd, lens, H, B, T, Tp, Pp, scale, d_att)
         if pd is None:
             pd = s_
@@ -990,22 +1024,22 @@ class ConformerEncoder(NeuralModule):
         H = self.n_heads
         M, P = B * T, 2 * T - 1
         Tp, Pp = _pad8(T), _pad8(P)
-        dqkv = torch.empty(M, 3 * dA, dtype=cdt, device=dev)
-        dqu = torch.empty(M, dA, dtype=cdt, device=dev)
-        dqv = torch.empty(M, dA, dtype=cdt, device=dev)
+        dqkv = self._new(M, 3 * dA, dtype=cdt, device=dev)
+        dqu = self._new(M, dA, dtype=cdt, device=dev)
+        dqv = self._new(M, dA, dtype=cdt, device=dev)
         if lse is not None:
             ctx_lo = qu  # (fused path: the first slot carries the context's rounding residual, q + u is recomputed here)
-            qu = torch.empty(M, dA, dtype=cdt, device=dev)
-            qv = torch.empty(M, dA, dtype=cdt, device=dev)
+            qu = self._new(M, dA, dtype=cdt, device=dev)
+            qv = self._new(M, dA, dtype=cdt, device=dev)
             ops.qbias(qkv, 3 * dA, bias_u, bias_v, qu, qv, M, dA)
-            dlt = torch.empty(B, H, T, dtype=torch.float32, device=dev)
+            dlt = self._new(B, H, T, dtype=torch.float32, device=dev)
             ops.attn_delta(dctx, ctx, dlt, B, H, T, dA, O_lo=ctx_lo)
             # transient dS (un-shifted 32 x 32 blocks): dQ kernel -> linear_pos gradient kernel.  The latter feeds only the
             # (batched, end-of-backward) linear_pos weight gradient, so with the side stream it leaves the critical path; dS
             # then comes from the caching allocator (record_stream keeps the next layer's dQ kernel from overwriting it too early).
             side_pos = self.dpos_side_stream and self.wgrad_side_stream
             n_ds = ops.lib.mi355x_relpos_ds_elems(B, H, T)
-            dS = (torch.empty(n_ds, dtype=cdt, device=dev) if side_pos else self._buf("dS", (n_ds,), cdt, dev))
+            dS = (self._new(n_ds, dtype=cdt, device=dev) if side_pos else self._buf("dS", (n_ds,), cdt, dev))
             ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * dA, p, dA, lens, dctx, lse, dlt, dqu, dqv, B, H, T, dk, scale, d_att,
                                     ds_out=dS)
             if side_pos:
@@ -1056,13 +1090,13 @@ class ConformerEncoder(NeuralModule):
         # ---- rel-pos multi-head self-attention
         a = L.self_attn
         y2, mean2, rstd2 = self._ln_fwd(L.norm_self_att, r1, M, d, cdt, dev)
-        qkv = torch.empty(M, 3 * d, dtype=cdt, device=dev)
+        qkv = self._new(M, 3 * d, dtype=cdt, device=dev)
         ops.gemm(y2, W[f"L{i}.att.wqkv"], qkv, M, 3 * d, d, d, W.pitch(f"L{i}.att.wqkv"), 3 * d, bias=Wf[f"L{i}.att.bqkv"])
         p = S.p_all[i]  # linear_pos(pos_emb) of every layer was computed by one batched GEMM (same input, 18 weights)
         d_att = drop(self.dropout_att, site + 2)
         ctx, (qu, qv, s_, pd, lse) = self._attn_fwd(qkv, p, a.pos_bias_u, a.pos_bias_v, S.len2, B, T2, d, dk, 1.0 / math.sqrt(dk),
                                                     d_att, cdt, dev)
-        r2 = torch.empty(M, d, dtype=torch.float32, device=dev)
+        r2 = self._new(M, d, dtype=torch.float32, device=dev)
         d_ares = drop(self.dropout, site + 3)
         ops.gemm(ctx, W[f"L{i}.att.wo"], r2, M, d, d, d, W.pitch(f"L{i}.att.wo"), d, bias=a.linear_out.bias, epi=ops.EPI_RESID,
                  aux_in=r1, drop=d_ares)
@@ -1071,14 +1105,14 @@ class ConformerEncoder(NeuralModule):
         c = L.conv
         k = self.conv_kernel_size
         y3, mean3, rstd3 = self._ln_fwd(L.norm_conv, r2, M, d, cdt, dev)
-        pw1 = torch.empty(M, 2 * d, dtype=cdt, device=dev)
+        pw1 = self._new(M, 2 * d, dtype=cdt, device=dev)
         ops.gemm(y3, W[f"L{i}.conv.pw1"], pw1, M, 2 * d, d, d, W.pitch(f"L{i}.conv.pw1"), 2 * d, bias=c.pointwise_conv1.bias)
-        g = torch.empty(M, d, dtype=cdt, device=dev)
+        g = self._new(M, d, dtype=cdt, device=dev)
         ops.glu_fwd(pw1, g, S.len2, T2, M, d)
-        cc = torch.empty(M, d, dtype=cdt, device=dev)
+        cc = self._new(M, d, dtype=cdt, device=dev)
         bn = c.batch_norm
-        bmean = torch.empty(d, dtype=torch.float32, device=dev)
-        brstd = torch.empty(d, dtype=torch.float32, device=dev)
+        bmean = self._new(d, dtype=torch.float32, device=dev)
+        brstd = self._new(d, dtype=torch.float32, device=dev)
         count = float(M)
         if training:
             stats = S.bn_stats[i]
@@ -1090,9 +1124,9 @@ class ConformerEncoder(NeuralModule):
         else:
             ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
             ops.bn_eval_stats(bn.running_mean, bn.running_var, bmean, brstd, bn.eps, d)
-        z = torch.empty(M, d, dtype=cdt, device=dev)
+        z = self._new(M, d, dtype=cdt, device=dev)
         ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, M, d)
-        r3 = torch.empty(M, d, dtype=torch.float32, device=dev)
+        r3 = self._new(M, d, dtype=torch.float32, device=dev)
         d_cres = drop(self.dropout, site + 4)
         ops.gemm(z, W[f"L{i}.conv.pw2"], r3, M, d, d, d, W.pitch(f"L{i}.conv.pw2"), d, bias=c.pointwise_conv2.bias,
                  epi=ops.EPI_RESID, aux_in=r2, drop=d_cres)
@@ -1143,9 +1177,31 @@ class ConformerEncoder(NeuralModule):
         self._eager_point(timed)
 
     # ------------------------------------------------------------------ backward implementation
+    def step_scope(self):
+        """with encoder.step_scope(): one forward, then its backward, before the next forward -- what a training loop does.
+        Inside it the sequencer's tensors come from the step-scoped arena and (in auto mode) the launch sequence may be recorded."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            prev, self._in_step = self._in_step, True
+            try:
+                yield self
+            finally:
+                self._in_step = prev
+        return scope()
+
+    def _check_serial(self, S):
+        if getattr(S, "arena", False) and S.serial != self._fwd_serial:
+            raise RuntimeError("backward through an encoder forward whose saved activations were overwritten by a later forward "
+                               "(the sequencer's tensors live in a step-scoped arena); set MI355X_ARENA=0 (and MI355X_GRAPHS=0) for "
+                               "several forwards per backward")
+
     def _backward_impl(self, S, dout):
         B, F_, T, T1, F1, T2, F2, M, cdt, training, seed = S.dims
         dev = dout.device
+        self._check_serial(S)
+        self._phase("b", dev)
         d, C_ = self.d_model, self.pre_encode._conv_channels
         W, Wf = self._plan(cdt, dev)
         fp = self._flatp
@@ -1174,7 +1230,7 @@ class ConformerEncoder(NeuralModule):
         pe = self.pre_encode
         if self.subsampling == "dw_striding":
             return self._sub_bwd_dw(S, dx, W, cdt)
-        dxs = torch.empty(M, d, dtype=cdt, device=dev)
+        dxs = self._new(M, d, dtype=cdt, device=dev)
         ops.drop_scale_cast(dx, dxs, M * d, (self.xscale or 1.0), S.drop_pre)
         with self._sub_wgrad_scope(dxs):
             ops.colsum(dxs, pe.out.bias.grad, M, d)
@@ -1184,7 +1240,7 @@ class ConformerEncoder(NeuralModule):
             ops.gemm(dxs, S.out2, pe.out.weight.grad, d, C_, M, d, F2 * C_, C_ * F2, transA=True, transB=True, atomic=True,
                      splitk=self._splitk(tiles, M, strided_c=True), batch=F2, nb0=F2, sB=(C_, 0), sC=(1, 0), c_col_stride=F2,
                      c_dtype=ops.F32)
-        dout2 = torch.empty(B * T2 * F2, C_, dtype=cdt, device=dev)
+        dout2 = self._new(B * T2 * F2, C_, dtype=cdt, device=dev)
         ops.gemm(dxs, W["pre.outt"], dout2, M, F2 * C_, d, d, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=S.out2)
         M2 = B * T2 * F2
         with self._sub_wgrad_scope(dout2):
@@ -1236,13 +1292,13 @@ class ConformerEncoder(NeuralModule):
         LayerNorm backward then emits that operand too.  Returns (dr, cast_for_next_or_None)."""
         x, y, mean, rstd, h, a, d_in, d_res = saved
         if df is None:
-            df = torch.empty(M, d, dtype=cdt, device=dev)
+            df = self._new(M, d, dtype=cdt, device=dev)
             ops.drop_scale_cast(dr, df, M * d, 0.5, d_res)
         self._wgrad(df, d, 0, a, dff, 0, ff.linear2.weight.grad, d, dff, M, bias_grad=ff.linear2.bias.grad)
-        dh = torch.empty(M, dff, dtype=cdt, device=dev)
+        dh = self._new(M, dff, dtype=cdt, device=dev)
         ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, d, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH, aux_in=h, drop=d_in)
         self._wgrad(dh, dff, 0, y, d, 0, ff.linear1.weight.grad, dff, d, M, bias_grad=ff.linear1.bias.grad)
-        dy = torch.empty(M, d, dtype=cdt, device=dev)
+        dy = self._new(M, d, dtype=cdt, device=dev)
         ops.gemm(dh, W[pfx + ".w1t"], dy, M, d, dff, dff, W.pitch(pfx + ".w1t"), d)
         nxt = self._cast_buf(next_cast, M, d, cdt, dev)
         ops.layernorm_bwd(dy, x, ln.weight, mean, rstd, dr, True, ln.weight.grad, ln.bias.grad, M, d, cast_out=nxt,
@@ -1255,7 +1311,7 @@ class ConformerEncoder(NeuralModule):
         or the C side falls back to a separate pass -- still correct)"""
         if next_cast is None or cdt != torch.bfloat16 or (M * d) % 8 or not self.ln_cast_fuse:
             return None
-        return torch.empty(M, d, dtype=cdt, device=dev)
+        return self._new(M, d, dtype=cdt, device=dev)
 
     def _layer_bwd(self, i, L, dxo, S, sl, W, Wf):
         B, F_, T, T1, F1, T2, F2, M, cdt, training, seed = S.dims
@@ -1266,7 +1322,7 @@ class ConformerEncoder(NeuralModule):
         scale = 1.0 / math.sqrt(dk)
         # ---- norm_out: dr = dLN(dxo)
         r4, mean5, rstd5 = sl.out
-        dr = torch.empty(M, d, dtype=torch.float32, device=dev)
+        dr = self._new(M, d, dtype=torch.float32, device=dev)
         ln = L.norm_out
         # every LayerNorm backward also emits the bf16 (scaled, dropped) copy of the new residual gradient that the next
         # sub-block's output GEMMs consume -- one read of the fp32 gradient and one launch less per sub-block
@@ -1284,24 +1340,24 @@ class ConformerEncoder(NeuralModule):
         r2, y3, mean3, rstd3, pw1, g, cc, bmean, brstd, count, z, d_cres = sl.conv
         db = db_pre
         if db is None:
-            db = torch.empty(M, d, dtype=cdt, device=dev)
+            db = self._new(M, d, dtype=cdt, device=dev)
             ops.drop_scale_cast(dr, db, M * d, 1.0, d_cres)
         self._wgrad(db, d, 0, z, d, 0, c.pointwise_conv2.weight.grad, d, d, M, bias_grad=c.pointwise_conv2.bias.grad)
-        dz = torch.empty(M, d, dtype=cdt, device=dev)
+        dz = self._new(M, d, dtype=cdt, device=dev)
         ops.gemm(db, W[f"L{i}.conv.pw2t"], dz, M, d, d, d, W.pitch(f"L{i}.conv.pw2t"), d)
         sums = S.bn_sums[i]
         ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, M, d)
         ops.bn_param_grad(sums, bn.weight.grad, bn.bias.grad, d)
         if training and S.bn_world > 1:
             self._sync_stats(sums)
-        dcc = torch.empty(M, d, dtype=cdt, device=dev)
+        dcc = self._new(M, d, dtype=cdt, device=dev)
         ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, M, d)
-        dg = torch.empty(M, d, dtype=cdt, device=dev)
+        dg = self._new(M, d, dtype=cdt, device=dev)
         ops.dwconv_bwd(dcc, g, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
-        dpw1 = torch.empty(M, 2 * d, dtype=cdt, device=dev)
+        dpw1 = self._new(M, 2 * d, dtype=cdt, device=dev)
         ops.glu_bwd(pw1, dg, dpw1, S.len2, T2, M, d)
         self._wgrad(dpw1, 2 * d, 0, y3, d, 0, c.pointwise_conv1.weight.grad, 2 * d, d, M, bias_grad=c.pointwise_conv1.bias.grad)
-        dy3 = torch.empty(M, d, dtype=cdt, device=dev)
+        dy3 = self._new(M, d, dtype=cdt, device=dev)
         ops.gemm(dpw1, W[f"L{i}.conv.pw1t"], dy3, M, d, 2 * d, 2 * d, W.pitch(f"L{i}.conv.pw1t"), d)
         ln = L.norm_conv
         nc = (1.0, sl.att[12])
@@ -1313,10 +1369,10 @@ class ConformerEncoder(NeuralModule):
         r1, y2, mean2, rstd2, qkv, p, qu, qv, s_, pd, ctx, d_att, d_ares, lse = sl.att
         dao = dao_pre
         if dao is None:
-            dao = torch.empty(M, d, dtype=cdt, device=dev)
+            dao = self._new(M, d, dtype=cdt, device=dev)
             ops.drop_scale_cast(dr, dao, M * d, 1.0, d_ares)
         self._wgrad(dao, d, 0, ctx, d, 0, a.linear_out.weight.grad, d, d, M, bias_grad=a.linear_out.bias.grad)
-        dctx = torch.empty(M, d, dtype=cdt, device=dev)
+        dctx = self._new(M, d, dtype=cdt, device=dev)
         ops.gemm(dao, W[f"L{i}.att.wot"], dctx, M, d, d, d, W.pitch(f"L{i}.att.wot"), d)
         dqkv, dqu, dqv = self._attn_bwd((qu, qv, s_, pd, lse), qkv, p, a.pos_bias_u, a.pos_bias_v, ctx, dctx, S.len2, B, T2, d,
                                         dk, scale, d_att, cdt, dev, S.dpos_f32[i], S.dp_all[i])
@@ -1345,7 +1401,7 @@ class ConformerEncoder(NeuralModule):
         else:
             for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
                 self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M, bias_grad=lin.bias.grad)
-        dy2 = torch.empty(M, d, dtype=cdt, device=dev)
+        dy2 = self._new(M, d, dtype=cdt, device=dev)
         ops.gemm(dqkv, W[f"L{i}.att.wqkvt"], dy2, M, d, 3 * d, 3 * d, W.pitch(f"L{i}.att.wqkvt"), d)
         ln = L.norm_self_att
         nc = (0.5, sl.ff1[7])

@@ -324,13 +324,15 @@ class SqueezeformerEncoder(ConformerEncoder):
             if len(self._pos_cache) >= 32:
                 self._pos_cache = {}
             self._pos_cache[key] = tab
-        g.pos = torch.empty(g.P, dp, dtype=cdt, device=dev)
+        g.pos = self._new(g.P, dp, dtype=cdt, device=dev)
         ops.cast_pitched(tab, g.pos, g.P, self.d_model, dp, 1.0, d_emb)  # (+ dropout_emb on the table, :1097-1098)
         return g
 
     # ------------------------------------------------------------------ forward
     def _forward_impl(self, mel, length, save=False):
         dev = mel.device
+        self._phase("f", dev)
+        self._fwd_serial += 1
         cdt = self._cdt()
         training = self.training
         W, Wf = self._plan(cdt, dev)
@@ -353,6 +355,7 @@ class SqueezeformerEncoder(ConformerEncoder):
             return ops.Dropout(p if training else 0.0, seed, site)
 
         S = _Saved()
+        S.serial, S.arena = self._fwd_serial, self._arena is not None
         S.dims = (B, F_, T, T1, F1, T2, F2, M, cdt, training, seed)
         S.mel, S.len0, S.len2, S.lens_all = mel, lens[0], lens[-1], lens
         S.drop_pre = drop(self.dropout_pre_encoder, 100000)
@@ -372,22 +375,22 @@ class SqueezeformerEncoder(ConformerEncoder):
             if self.time_reduce_idx is not None and i == self.time_reduce_idx:
                 Th = (g.T + 1) // 2
                 lens_h = (torch.div(g.lens + 1, 2, rounding_mode="floor")).contiguous()
-                dwo = torch.empty(B * Th, dp, dtype=cdt, device=dev)
+                dwo = self._new(B * Th, dp, dtype=cdt, device=dev)
                 tr = self.time_reduce_layer
                 ops.time_reduce_dwconv_fwd(x, g.lens, tr.dw_conv.weight, tr.dw_conv.bias, dwo, B, g.T, d, dp)
-                xh = torch.empty(B * Th, d, dtype=torch.float32, device=dev)
+                xh = self._new(B * Th, d, dtype=torch.float32, device=dev)
                 ops.gemm(dwo, W["tr.pw"], xh, B * Th, d, d, dp, W.pitch("tr.pw"), d, bias=tr.pw_conv.bias)
                 S.tr = (x, g, dwo)
                 g = self._geo(B, Th, lens_h, self.time_reduce_pos_enc, ops.NO_DROP, cdt, dev, dp)
                 x = xh
             if self.time_reduce_idx is not None and i == self.time_recovery_idx:
                 xs_in, g_skip, _ = S.tr
-                xs_c = torch.empty(g.M, dp, dtype=cdt, device=dev)
+                xs_c = self._new(g.M, dp, dtype=cdt, device=dev)
                 ops.scale_bias_fwd(x, None, None, xs_c, g.M, d, dp)
-                ys = torch.empty(g.M, d, dtype=torch.float32, device=dev)
+                ys = self._new(g.M, d, dtype=torch.float32, device=dev)
                 rec = self.time_recovery_layer
                 ops.gemm(xs_c, W["rec.w"], ys, g.M, d, d, dp, W.pitch("rec.w"), d, bias=rec.bias)
-                xr = torch.empty(g_skip.M, d, dtype=torch.float32, device=dev)
+                xr = self._new(g_skip.M, d, dtype=torch.float32, device=dev)
                 ops.time_recover_fwd(xs_in, ys, xr, B, g_skip.T, d)
                 S.rec = (xs_c, g)
                 g, x = g_skip, xr
@@ -402,7 +405,7 @@ class SqueezeformerEncoder(ConformerEncoder):
         return out, lens[-1], (S if save else None)
 
     def _sb_fwd(self, sb, x, M, cdt, dp):
-        y = torch.empty(M, dp, dtype=cdt, device=x.device)
+        y = self._new(M, dp, dtype=cdt, device=x.device)
         ops.scale_bias_fwd(x, sb.scale, sb.bias, y, M, self.d_model, dp)
         return y
 
@@ -412,12 +415,12 @@ class SqueezeformerEncoder(ConformerEncoder):
     def _sq_ffn_fwd(self, pfx, ff, sb, ln, x, g, W, drop, site, cdt, dp):
         M, d, dff, dev = g.M, self.d_model, self.d_ff, x.device
         y = self._sb_fwd(sb, x, M, cdt, dp)
-        h = torch.empty(M, dff, dtype=cdt, device=dev)
-        a = torch.empty(M, dff, dtype=cdt, device=dev)
+        h = self._new(M, dff, dtype=cdt, device=dev)
+        a = self._new(M, dff, dtype=cdt, device=dev)
         d_in, d_res = drop(self.dropout, site), drop(self.dropout, site + 1)
         ops.gemm(y, W[pfx + ".w1"], a, M, dff, d, dp, W.pitch(pfx + ".w1"), dff, bias=ff.linear1.bias, epi=ops.EPI_SWISH_DROP,
                  aux_out=h, drop=d_in)
-        r = torch.empty(M, d, dtype=torch.float32, device=dev)
+        r = self._new(M, d, dtype=torch.float32, device=dev)
         ops.gemm(a, W[pfx + ".w2"], r, M, d, dff, dff, W.pitch(pfx + ".w2"), d, bias=ff.linear2.bias, epi=ops.EPI_RESID,
                  aux_in=x, drop=d_res)  # fc_factor = 1.0 (squeezeformer_modules.py:103)
         xo, mean, rstd = self._post_ln(ln, r, M)
@@ -434,14 +437,14 @@ class SqueezeformerEncoder(ConformerEncoder):
         # ---- rel-pos multi-head self-attention
         a = L.self_attn
         y = self._sb_fwd(L.self_attn_scale, x, M, cdt, dp)
-        qkv = torch.empty(M, 3 * dA, dtype=cdt, device=dev)
+        qkv = self._new(M, 3 * dA, dtype=cdt, device=dev)
         ops.gemm(y, W[f"L{i}.att.wqkv"], qkv, M, 3 * dA, d, dp, W.pitch(f"L{i}.att.wqkv"), 3 * dA, bias=Wf[f"L{i}.att.bqkv"])
-        p = torch.empty(g.P, dA, dtype=cdt, device=dev)
+        p = self._new(g.P, dA, dtype=cdt, device=dev)
         ops.gemm(g.pos, W[f"L{i}.att.wpos"], p, g.P, dA, d, dp, W.pitch(f"L{i}.att.wpos"), dA)
         d_att, d_res = drop(self.dropout_att, site + 2), drop(self.dropout, site + 3)
         bu, bv = Wf[f"L{i}.att.bu"], Wf[f"L{i}.att.bv"]
         ctx, att_saved = self._attn_fwd(qkv, p, bu, bv, g.lens, B, T, dA, dkp, 1.0 / math.sqrt(dk), d_att, cdt, dev)
-        r = torch.empty(M, d, dtype=torch.float32, device=dev)
+        r = self._new(M, d, dtype=torch.float32, device=dev)
         ops.gemm(ctx, W[f"L{i}.att.wo"], r, M, d, dA, dA, W.pitch(f"L{i}.att.wo"), d, bias=a.linear_out.bias, epi=ops.EPI_RESID,
                  aux_in=x, drop=d_res)
         x1, mean, rstd = self._post_ln(L.norm_self_att, r, M)
@@ -454,14 +457,14 @@ class SqueezeformerEncoder(ConformerEncoder):
         k = self.conv_kernel_size
         C2 = 2 * d
         y3 = self._sb_fwd(L.conv_scale, x2, M, cdt, dp)
-        pw1 = torch.empty(M, C2, dtype=cdt, device=dev)
+        pw1 = self._new(M, C2, dtype=cdt, device=dev)
         ops.gemm(y3, W[f"L{i}.conv.pw1"], pw1, M, C2, d, dp, W.pitch(f"L{i}.conv.pw1"), C2, bias=c.pointwise_conv1.bias)
-        gact = torch.empty(M, C2, dtype=cdt, device=dev)
+        gact = self._new(M, C2, dtype=cdt, device=dev)
         ops.swish_mask_fwd(pw1, gact, g.lens, T, M, C2)
-        cc = torch.empty(M, C2, dtype=cdt, device=dev)
+        cc = self._new(M, C2, dtype=cdt, device=dev)
         bn = c.batch_norm
-        bmean = torch.empty(C2, dtype=torch.float32, device=dev)
-        brstd = torch.empty(C2, dtype=torch.float32, device=dev)
+        bmean = self._new(C2, dtype=torch.float32, device=dev)
+        brstd = self._new(C2, dtype=torch.float32, device=dev)
         count = float(M)
         if training:
             stats = S.bn_stats[i]
@@ -473,9 +476,9 @@ class SqueezeformerEncoder(ConformerEncoder):
         else:
             ops.dwconv_fwd(gact, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T, C2, k)
             ops.bn_eval_stats(bn.running_mean, bn.running_var, bmean, brstd, bn.eps, C2)
-        z = torch.empty(M, C2, dtype=cdt, device=dev)
+        z = self._new(M, C2, dtype=cdt, device=dev)
         ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, M, C2)
-        r3 = torch.empty(M, d, dtype=torch.float32, device=dev)
+        r3 = self._new(M, d, dtype=torch.float32, device=dev)
         d_cres = drop(self.dropout, site + 6)
         ops.gemm(z, W[f"L{i}.conv.pw2"], r3, M, d, C2, C2, W.pitch(f"L{i}.conv.pw2"), d, bias=c.pointwise_conv2.bias,
                  epi=ops.EPI_RESID, aux_in=x2, drop=d_cres)
@@ -490,9 +493,9 @@ class SqueezeformerEncoder(ConformerEncoder):
     def _branch_grad(self, ln, dxo, r, mean, rstd, M, d_res, cdt, dp):
         """post-LN sub-block: -> (dr f32 [M,d] = d/d(x + branch), operand copy of the branch gradient [M, dp])"""
         d, dev = self.d_model, dxo.device
-        dr = torch.empty(M, d, dtype=torch.float32, device=dev)
+        dr = self._new(M, d, dtype=torch.float32, device=dev)
         ops.layernorm_bwd(dxo, r, ln.weight, mean, rstd, dr, False, ln.weight.grad, ln.bias.grad, M, d)
-        df = torch.empty(M, dp, dtype=cdt, device=dev)
+        df = self._new(M, dp, dtype=cdt, device=dev)
         ops.cast_pitched(dr, df, M, d, dp, 1.0, d_res)
         return dr, df
 
@@ -506,10 +509,10 @@ class SqueezeformerEncoder(ConformerEncoder):
         M, d, dff, dev = g.M, self.d_model, self.d_ff, dxo.device
         dr, df = self._branch_grad(ln, dxo, r, mean, rstd, M, d_res, cdt, dp)
         self._wgrad(df, dp, 0, a, dff, 0, ff.linear2.weight.grad, d, dff, M, bias_grad=ff.linear2.bias.grad)
-        dh = torch.empty(M, dff, dtype=cdt, device=dev)
+        dh = self._new(M, dff, dtype=cdt, device=dev)
         ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, dp, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH, aux_in=h, drop=d_in)
         self._wgrad(dh, dff, 0, y, dp, 0, ff.linear1.weight.grad, dff, d, M, bias_grad=ff.linear1.bias.grad)
-        dy = torch.empty(M, dp, dtype=cdt, device=dev)
+        dy = self._new(M, dp, dtype=cdt, device=dev)
         ops.gemm(dh, W[pfx + ".w1t"], dy, M, d, dff, dff, W.pitch(pfx + ".w1t"), dp)
         return self._sb_bwd(sb, dy, x, dr, M, dp)
 
@@ -547,21 +550,21 @@ class SqueezeformerEncoder(ConformerEncoder):
         x2, y3, pw1, gact, cc, bmean, brstd, count, z, d_cres, r3, mean3, rstd3 = sl.conv
         dr, db = self._branch_grad(L.norm_conv, dx, r3, mean3, rstd3, M, d_cres, cdt, dp)
         self._wgrad(db, dp, 0, z, C2, 0, c.pointwise_conv2.weight.grad, d, C2, M, bias_grad=c.pointwise_conv2.bias.grad)
-        dz = torch.empty(M, C2, dtype=cdt, device=dev)
+        dz = self._new(M, C2, dtype=cdt, device=dev)
         ops.gemm(db, W[f"L{i}.conv.pw2t"], dz, M, C2, d, dp, W.pitch(f"L{i}.conv.pw2t"), C2)
         sums = S.bn_sums[i]
         ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, M, C2)
         ops.bn_param_grad(sums, bn.weight.grad, bn.bias.grad, C2)
         if training and S.bn_world > 1:
             self._sync_stats(sums)
-        dcc = torch.empty(M, C2, dtype=cdt, device=dev)
+        dcc = self._new(M, C2, dtype=cdt, device=dev)
         ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, M, C2)
-        dg = torch.empty(M, C2, dtype=cdt, device=dev)
+        dg = self._new(M, C2, dtype=cdt, device=dev)
         ops.dwconv_bwd(dcc, gact, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T, C2, k)
-        dpw1 = torch.empty(M, C2, dtype=cdt, device=dev)
+        dpw1 = self._new(M, C2, dtype=cdt, device=dev)
         ops.swish_mask_bwd(pw1, dg, dpw1, g.lens, T, M, C2)
         self._wgrad(dpw1, C2, 0, y3, dp, 0, c.pointwise_conv1.weight.grad, C2, d, M, bias_grad=c.pointwise_conv1.bias.grad)
-        dy3 = torch.empty(M, dp, dtype=cdt, device=dev)
+        dy3 = self._new(M, dp, dtype=cdt, device=dev)
         ops.gemm(dpw1, W[f"L{i}.conv.pw1t"], dy3, M, d, C2, C2, W.pitch(f"L{i}.conv.pw1t"), dp)
         dx = self._sb_bwd(L.conv_scale, dy3, x2, dr, M, dp)
         # ---- feed forward 1
@@ -579,10 +582,10 @@ class SqueezeformerEncoder(ConformerEncoder):
                          splitk=self._splitk(self._tiles(d, dk, bf16) * H, M), batch=H, nb0=H, sB=(dkp, 0), sC=(dk, 0),
                          c_dtype=ops.F32)
                 ops.colsum(dao, a.linear_out.bias.grad, M, d, ld=dp)
-        dctx = torch.empty(M, dA, dtype=cdt, device=dev)
+        dctx = self._new(M, dA, dtype=cdt, device=dev)
         ops.gemm(dao, W[f"L{i}.att.wot"], dctx, M, dA, d, dp, W.pitch(f"L{i}.att.wot"), dA)
         dpos = torch.zeros(g.P, dA, dtype=torch.float32, device=dev)
-        dpos_c = torch.empty(g.P, dA, dtype=cdt, device=dev)
+        dpos_c = self._new(g.P, dA, dtype=cdt, device=dev)
         bu, bv = Wf[f"L{i}.att.bu"], Wf[f"L{i}.att.bv"]
         dqkv, dqu, dqv = self._attn_bwd(att_saved, qkv, p, bu, bv, ctx, dctx, g.lens, B, T, dA, dkp, 1.0 / math.sqrt(dk), d_att,
                                         cdt, dev, dpos, dpos_c)
@@ -618,13 +621,15 @@ class SqueezeformerEncoder(ConformerEncoder):
                 for j, lin in enumerate(lins):
                     self._unpad_add(lin.bias.grad, sc[j * dA:(j + 1) * dA], dkp)
             self._heads_wgrad(dpos_c, dA, 0, g.pos, dp, a.linear_pos.weight.grad, g.P, 1, 0, 0)
-        dy = torch.empty(M, dp, dtype=cdt, device=dev)
+        dy = self._new(M, dp, dtype=cdt, device=dev)
         ops.gemm(dqkv, W[f"L{i}.att.wqkvt"], dy, M, d, 3 * dA, 3 * dA, W.pitch(f"L{i}.att.wqkvt"), dp)
         return self._sb_bwd(L.self_attn_scale, dy, x, dr, M, dp)
 
     def _backward_impl(self, S, dout):
         B, F_, T, T1, F1, T2, F2, M, cdt, training, seed = S.dims
         dev = dout.device
+        self._check_serial(S)
+        self._phase("b", dev)
         d = self.d_model
         W, Wf = self._plan(cdt, dev)
         fp = self._flatp
@@ -645,21 +650,21 @@ class SqueezeformerEncoder(ConformerEncoder):
                 xs_c, g_small = S.rec
                 rec = self.time_recovery_layer
                 dskip = dx
-                dys = torch.empty(g_small.M, dp, dtype=cdt, device=dev)
+                dys = self._new(g_small.M, dp, dtype=cdt, device=dev)
                 ops.time_recover_bwd(dx, dys, B, g.T, d, dp)
                 self._wgrad(dys, dp, 0, xs_c, dp, 0, rec.weight.grad, d, d, g_small.M, bias_grad=rec.bias.grad)
                 self._wgrad_flush()
-                dx = torch.empty(g_small.M, d, dtype=torch.float32, device=dev)
+                dx = self._new(g_small.M, d, dtype=torch.float32, device=dev)
                 ops.gemm(dys, W["rec.wt"], dx, g_small.M, d, d, dp, W.pitch("rec.wt"), d)
             if self.time_reduce_idx is not None and i == self.time_reduce_idx:
                 x_in, g_full, dwo = S.tr
                 tr = self.time_reduce_layer
                 Mh = g.M
-                dxc = torch.empty(Mh, dp, dtype=cdt, device=dev)
+                dxc = self._new(Mh, dp, dtype=cdt, device=dev)
                 ops.cast_pitched(dx, dxc, Mh, d, dp)
                 self._wgrad(dxc, dp, 0, dwo, dp, 0, tr.pw_conv.weight.grad, d, d, Mh, bias_grad=tr.pw_conv.bias.grad)
                 self._wgrad_flush()
-                ddw = torch.empty(Mh, dp, dtype=cdt, device=dev)
+                ddw = self._new(Mh, dp, dtype=cdt, device=dev)
                 ops.gemm(dxc, W["tr.pwt"], ddw, Mh, d, d, dp, W.pitch("tr.pwt"), dp)
                 ops.time_reduce_dwconv_bwd(ddw, dp, x_in, g_full.lens, tr.dw_conv.weight, dskip, tr.dw_conv.weight.grad,
                                            tr.dw_conv.bias.grad, B, g_full.T, d)
@@ -670,7 +675,7 @@ class SqueezeformerEncoder(ConformerEncoder):
                 self._hook(*fp.range_of(f"layers.{i}."))
         self._wg_pending = None
         x_pre, pmean, prstd = S.pre_ln
-        dpre = torch.empty(M, d, dtype=torch.float32, device=dev)
+        dpre = self._new(M, d, dtype=torch.float32, device=dev)
         ops.layernorm_bwd(dx, x_pre, self.pre_ln.weight, pmean, prstd, dpre, False, self.pre_ln.weight.grad, self.pre_ln.bias.grad, M, d)
         self._wgrad_join()
         if self.grad_ready_hook is not None:

@@ -45,6 +45,9 @@ def run(name, M, N, K, epi="store", out=bf, layout="NT", splitk=1):
         elif epi == "dswish":
             H = torch.randn(M, N, device=dev, generator=g).to(bf); d = ops.Dropout(0.1, 1, 3)
             f = lambda A=A, B=B, C=C, H=H, d=d: ops.gemm(A, B, C, M, N, K, lda, ldb, N, epi=ops.EPI_DSWISH, aux_in=H, drop=d, **kw)
+        elif epi == "mulpos":
+            H = torch.randn(M, N, device=dev, generator=g).to(bf)
+            f = lambda A=A, B=B, C=C, H=H: ops.gemm(A, B, C, M, N, K, lda, ldb, N, epi=ops.EPI_MUL_POS, aux_in=H, **kw)
         elif epi == "atomic":
             C = torch.zeros(M, N, device=dev)
             f = lambda A=A, B=B, C=C: ops.gemm(A, B, C, M, N, K, lda, ldb, N, atomic=True, splitk=splitk, **kw)
@@ -182,6 +185,14 @@ if os.environ.get("COLD_AB"):  # the Conformer layer's NT shapes with rotating o
             run(tag + "qkv_fwd_store", M, 1536, 512, "store")
             run(tag + "qkv_dgrad_store", M, 512, 1536, "store")
             run(tag + "pw1_fwd_store", M, 1024, 512, "store")
+    sys.exit(0)
+if os.environ.get("EPI_COST"):  # what the Swish-gradient epilogue's arithmetic costs: the same launch with a 2-op epilogue
+    for rep in range(3):
+        for v5 in (1, 0):
+            ops.gemm_config(5, v5)
+            run(f"v5={v5} dswish", M, 2048, 512, "dswish")
+            run(f"v5={v5} mulpos", M, 2048, 512, "mulpos")
+            run(f"v5={v5} store_nobias", M, 2048, 512, "nobias")
     sys.exit(0)
 if os.environ.get("V6N_AB"):  # the N = 512 shapes (256x128 tiles): LDS-DMA / register prefetch / persistent structure
     for rep in range(int(os.environ.get("REPS", "2"))):

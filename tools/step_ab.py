@@ -1,6 +1,6 @@
 """In-process interleaved A/B of a run-time knob on the full training step (same box, same clocks, drift hits both arms):
     python tools/step_ab.py KEY=V0,V1 [rounds] [steps-per-arm]      e.g.  gemm6=0,1   or   env:MI355X_FOO=0,1 (read per launch only)
-gemmN=a,b switches mi355x_gemm_config(N, .).  The encoder runs on the eager sequencer (a recorded graph would freeze the arm)."""
+gemmN=a,b switches mi355x_gemm_config(N, .); arena=0,1 the step-scoped arena.  The encoder runs on the eager sequencer (a recorded graph would freeze the arm)."""
 import os
 import sys
 import time
@@ -24,6 +24,8 @@ arms = [int(v) for v in vals.split(",")]
 def set_arm(v):
     if name.startswith("gemm"):
         ops.gemm_config(int(name[4:]), v)
+    elif name == "arena":
+        m.encoder.use_arena = bool(v)
     else:
         raise SystemExit("unknown knob " + name)
 
