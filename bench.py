@@ -450,10 +450,12 @@ def main():
             gs.profile = True
         enc = model.encoder
         enc.syncbn_profile = []
-        for _ in range(1 + getattr(enc, "graph_warmup", 0) + 1):  # (a new recording key: warm-up, record, then the measured step)
+        use_g, enc.use_graphs = getattr(enc, "use_graphs", False), False  # (the instrumented steps run on live launches)
+        for _ in range(2):
             enc.syncbn_profile.clear()
             model.fit_step(batch)
         barrier()
+        enc.use_graphs = use_g
         exposed = sum(gs.exposed_events[0].elapsed_time(gs.exposed_events[1]) for gs in syncs if gs.exposed_events)
         syncbn_ms = sum(e0.elapsed_time(e1) for e0, e1 in enc.syncbn_profile)
         n_syncbn = len(enc.syncbn_profile)
@@ -512,10 +514,10 @@ def main():
         traffic = mfma_busy = None
         traffic_note = "not reported: no PMC table for this build of the GEMM sources"
         try:
-            with open(os.path.join(ROOT, "profiles", "r2_gemm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r3_gemm_traffic.json")) as f:
                 tj = json.load(f)
             if tj.get("source_sha256_16") != _source_hash():
-                traffic_note = "not reported: profiles/r2_gemm_traffic.json was measured on other GEMM sources (hash mismatch)"
+                traffic_note = "not reported: profiles/r3_gemm_traffic.json was measured on other GEMM sources (hash mismatch)"
             elif tj.get("kernel") == f"gemm_{dom[0]}" and a.size == "large" and a.batch == 32 and a.dtype == "bf16":
                 traffic = tj["traffic_bytes_per_launch"]
                 mfma_busy = tj.get("mfma_busy_frac")

@@ -70,11 +70,29 @@ __device__ __forceinline__ int tap_delta(unsigned long long packed, int tap) {  
 }
 
 // storage row (C / aux) of logical row m
+// q = m / d for 0 <= m < 2^24, 1 <= d < 2^24 without the ~40-instruction integer division sequence: float estimate (exact to
+// +-1 for these ranges) and one correction step.  The row map is evaluated per row and tensor in the epilogue of the four conv2
+// input-gradient GEMMs: with plain `/` it was most of that epilogue's VALU work.
+__device__ __forceinline__ int fdiv24(int m, int d, float inv_d) {
+  int q = (int)((float)m * inv_d);
+  const int r = m - q * d;
+  q += (r >= d) - (r < 0);
+  return q;
+}
 __device__ __forceinline__ long long crow(const GemmP& p, int m) {
   if (!p.r_on) return m;
   const int per_b = p.r_nI * p.r_nJ;
-  const int b = m / per_b, r = m - b * per_b;
-  const int i = r / p.r_nJ, j = r - i * p.r_nJ;
+  int b, i;
+  if ((unsigned)p.M < (1u << 24)) {  // (uniform)
+    b = fdiv24(m, per_b, __builtin_amdgcn_rcpf((float)per_b));
+    const int r = m - b * per_b;
+    i = fdiv24(r, p.r_nJ, __builtin_amdgcn_rcpf((float)p.r_nJ));
+  } else {
+    b = m / per_b;
+    i = (m - b * per_b) / p.r_nJ;
+  }
+  const int r = m - b * per_b;
+  const int j = r - i * p.r_nJ;
   return ((long long)b * p.r_OI + i * p.r_si + p.r_oi) * p.r_OJ + j * p.r_sj + p.r_oj;
 }
 
@@ -241,8 +259,9 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
     float v[8] = {a.x + b8[0], a.y + b8[1], a.z + b8[2], a.w + b8[3], b.x + b8[4], b.y + b8[5], b.z + b8[6], b.w + b8[7]};
     float dm[8];
     drop_mask8(p.drop, db_l + (uint32_t)it * db_s, dm);
-    const long long ci = lin ? ci_l + it * ci_s : coff + crow(p, m) * p.ldc + n;
-    const long long ai = lin ? ai_l + it * ai_s : coff + crow(p, m) * p.ldaux + n;
+    const long long mrow = lin ? 0 : crow(p, m);
+    const long long ci = lin ? ci_l + it * ci_s : coff + mrow * p.ldc + n;
+    const long long ai = lin ? ai_l + it * ai_s : coff + mrow * p.ldaux + n;
     if (EPI == EPI_STORE) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= p.alpha * dm[j];

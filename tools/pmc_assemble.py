@@ -1,7 +1,7 @@
 """Assemble the round's PMC evidence from the three `tools/pmc_dump.py` files of `tools/run_profiles_r2.sh`:
-  profiles/r2_pmc_hbm_traffic.md      per-kernel HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) with the calibration rows
-  profiles/r2_pmc_mfma_utilisation.md SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE) per kernel
-  profiles/r2_gemm_traffic.json       what bench.py reads for `roofline.traffic` (stamped with the GEMM source hash)
+  profiles/r3_pmc_hbm_traffic.md      per-kernel HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) with the calibration rows
+  profiles/r3_pmc_mfma_utilisation.md SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE) per kernel
+  profiles/r3_gemm_traffic.json       what bench.py reads for `roofline.traffic` (stamped with the GEMM source hash)
 usage: python tools/pmc_assemble.py gpurun_out/r2prof profiles r2"""
 import json
 import os

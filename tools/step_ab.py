@@ -1,6 +1,6 @@
 """In-process interleaved A/B of a run-time knob on the full training step (same box, same clocks, drift hits both arms):
     python tools/step_ab.py KEY=V0,V1 [rounds] [steps-per-arm]      e.g.  gemm6=0,1   or   env:MI355X_FOO=0,1 (read per launch only)
-gemmN=a,b switches mi355x_gemm_config(N, .); arena=0,1 the step-scoped arena.  The encoder runs on the eager sequencer (a recorded graph would freeze the arm)."""
+gemmN=a,b switches mi355x_gemm_config(N, .); arena=0,1 the step-scoped arena; env:NAME=a,b an environment knob that is read per call; enc.attr=a,b an encoder attribute.  The encoder runs on the eager sequencer (a recorded graph would freeze the arm)."""
 import os
 import sys
 import time
@@ -26,6 +26,10 @@ def set_arm(v):
         ops.gemm_config(int(name[4:]), v)
     elif name == "arena":
         m.encoder.use_arena = bool(v)
+    elif name.startswith("env:"):
+        os.environ[name[4:]] = str(v)
+    elif name.startswith("enc."):
+        setattr(m.encoder, name[4:], bool(v) if isinstance(getattr(m.encoder, name[4:]), bool) else v)
     else:
         raise SystemExit("unknown knob " + name)
 
