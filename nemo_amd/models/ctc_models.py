@@ -59,10 +59,12 @@ class EncDecCTCModel(nn.Module):
         self._syncs = None
         self._wer = None
         self.validation_step_outputs, self.test_step_outputs = [], []
-        # optimizer slices behind backward (begin_step / step_range / finish_step): measured 46.66 vs 46.48 ms per step on
-        # one GPU (the HBM-bound update competes with the HBM-bound halves of backward), so it is opt-in; it exists for
-        # data-parallel runs where the update otherwise sits behind the last bucket's all-reduce
-        self.optimizer_in_backward = os.environ.get("MI355X_OPT_IN_BACKWARD", "0") == "1"
+        # optimizer slices behind backward (begin_step / step_range / finish_step): a layer's AdamW update runs on the
+        # weight-gradient stream as soon as that layer's gradients are final, instead of as one 0.9-ms launch on the main stream
+        # after backward (the main stream is 98 % busy: tools/stream_gaps.py).  In-process A/B (tools/step_ab.py, round 3): 41.90 ->
+        # 41.65 ms per step on one GPU; in data-parallel runs the slice sits behind its bucket's all-reduce.  With a global-norm
+        # gradient clip the update needs the whole gradient first and falls back to the single launch (FusedAdamW.begin_step).
+        self.optimizer_in_backward = os.environ.get("MI355X_OPT_IN_BACKWARD", "1") == "1"
         self.global_step = 0
 
     @property

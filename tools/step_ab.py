@@ -28,6 +28,8 @@ def set_arm(v):
         m.encoder.use_arena = bool(v)
     elif name.startswith("env:"):
         os.environ[name[4:]] = str(v)
+    elif name.startswith("model."):
+        setattr(m, name[6:], bool(v) if isinstance(getattr(m, name[6:]), bool) else v)
     elif name.startswith("enc."):
         setattr(m.encoder, name[4:], bool(v) if isinstance(getattr(m.encoder, name[4:]), bool) else v)
     else:
