@@ -18,7 +18,7 @@ spec = sys.argv[1]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 name, vals = spec.split("=")
-arms = [int(v) for v in vals.split(",")]
+arms = [int(v) if v.lstrip("-").isdigit() else v for v in vals.split(",")]
 
 
 def set_arm(v):
@@ -44,6 +44,10 @@ m = m.to(dev).train()
 m.setup_optimization()
 audio, alen, tok, tl = R.synthetic_batch(32, 20.0, vocab=128, seed=1234)
 batch = [t.to(dev) for t in (audio, alen, tok, tl)]
+main_stream = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get("AB_MAIN_PRIO") == "1" else None
+if main_stream is not None:  # the whole step on a HIGH-priority stream (side streams keep the default priority)
+    main_stream.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(main_stream)
 for _ in range(4):
     m.fit_step(batch)
 res = {a: [] for a in arms}
