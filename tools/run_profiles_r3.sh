@@ -3,6 +3,7 @@
 # kernel stats of the configs[3] / configs[4] modes.  Everything lands in gpurun_out/r3prof/.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+export MI355X_GRAPHS=0   # live launches (what the auto trial keeps on this stack): no recording / trial steps inside the traces
 O=$GRAFT_REPO_ROOT/gpurun_out/r3prof
 mkdir -p $O
 python -c "import bench; print(bench._source_hash())" > $O/source_hash.txt 2>/dev/null
