@@ -1,5 +1,5 @@
 """Per-step launch counts and kernel time from two `rocprofv3 --kernel-trace --stats` runs of bench.py that differ only in
---steps (tools/run_profiles_r2.sh: 4 and 12 timed steps, 2 warm-up steps each): per step = (run B - run A) / (steps_B - steps_A);
+--steps (tools/run_profiles_r3.sh: 4 and 12 timed steps, 2 warm-up steps each): per step = (run B - run A) / (steps_B - steps_A);
 what is left over in run A after subtracting its 6 steps is set-up work (parameter flattening, first-touch allocations).
 usage: python tools/per_step_stats.py A.csv stepsA B.csv stepsB out.md"""
 import csv

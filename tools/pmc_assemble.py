@@ -1,4 +1,4 @@
-"""Assemble the round's PMC evidence from the three `tools/pmc_dump.py` files of `tools/run_profiles_r2.sh`:
+"""Assemble the round's PMC evidence from the three `tools/pmc_dump.py` files of `tools/run_profiles_r3.sh`:
   profiles/r3_pmc_hbm_traffic.md      per-kernel HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) with the calibration rows
   profiles/r3_pmc_mfma_utilisation.md SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE) per kernel
   profiles/r3_gemm_traffic.json       what bench.py reads for `roofline.traffic` (stamped with the GEMM source hash)
@@ -31,7 +31,7 @@ def main(src, dst, tag):
     rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
     with open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.md"), "w") as o:
         o.write(f"# HBM traffic per kernel launch from the TCC counters (rocprofv3 PMC), GEMM sources {src_hash}\n\n"
-                "Two separate passes, one counter each (`tools/run_profiles_r2.sh`; `--kernel-trace --pmc X` only, weight-gradient\n"
+                "Two separate passes, one counter each (`tools/run_profiles_r3.sh`; `--kernel-trace --pmc X` only, weight-gradient\n"
                 "side stream off so that every row is one kernel on its own; `bench.py --steps 1 --warmup 1`, i.e. two optimizer\n"
                 "steps of Conformer-CTC-Large bf16, B = 32 x 20 s).  Read bytes = FETCH_SIZE (KiB) x 1024 x 2 (gfx950 tallies 128-B\n"
                 "read requests at 64 B), written bytes = WRITE_SIZE (KiB) x 1024; one counter sample per dispatch in this rocprofv3.\n\n"
