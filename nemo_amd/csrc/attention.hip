@@ -63,35 +63,35 @@ __device__ __forceinline__ void dma4(const void* src, const void* lds_base) {  /
 __device__ __forceinline__ uint32_t attn_key(const DropCfg& d, int b, int h) {
   return mix32(mix32(d.key ^ (uint32_t)(b * 0x632BE5AB)) + (uint32_t)h * 0x9E3779B9u);
 }
-// Dropout on the attention probabilities, counter-based and two-level so that it costs ~10 VALU ops per element instead
-// of ~22 (the forward / dQ / dKV loops are VALU-bound, and a full hash per element was 45 % of their VALU work):
-//   * every 4x4 block (i>>2, j>>2) of the [T,T] matrix gets a seed = one mixing round over akey ^ rowcode ^ colcode,
-//     where the row / column codes are two 24-bit multiplies each (the lane-constant one is hoisted out of the loop);
-//   * element (i&3, j&3) of the block finishes with add - xorshift - multiply on seed + e * golden.
-// Every kernel walks whole blocks per lane (4 consecutive keys in "lane = query" layouts, 4 consecutive queries in the
-// "lane = key" layout), so each lane needs one seed per 4 elements.  attn_drop() is the scalar definition.
-__device__ __forceinline__ uint32_t adrop_rcode(uint32_t bi) {
-  return __umul24(bi + 0x1234u, 0x9E3779u) ^ (__umul24(bi + 0x4321u, 0x7FEB35u) << 8);
-}
-__device__ __forceinline__ uint32_t adrop_ccode(uint32_t bj) {
-  return __umul24(bj + 0x2345u, 0x85EBCBu) ^ (__umul24(bj + 0x5432u, 0xC2B2AFu) << 5);
-}
-__device__ __forceinline__ uint32_t adrop_seed(uint32_t x) {  // x = akey ^ rowcode ^ colcode
-  x ^= x >> 15;
-  x = __umul24(x, 0x846CA7u) ^ (x >> 9) ^ (x << 7);
-  x ^= x >> 13;
-  return x;
-}
+// Dropout on the attention probabilities, counter-based and two-level; the three loops are VALU-bound, so the definition is
+// shaped by what it costs per element in BOTH register layouts ("lane = query" walking keys: forward / dQ; "lane = key"
+// walking queries: dK/dV) -- 5.5 VALU ops per element where the first version needed 22 and the second 10.75:
+//   * every 4x4 block (bi = i>>2, bj = j>>2) of the [T,T] matrix gets a seed = one multiply-add round over R(bi) ^ C(bj).
+//     R and C are full mix32 hashes: the one that is constant per lane is hoisted out of the loop, the one that changes per
+//     step is wave-uniform up to the lane-half bit, so both candidates are computed on the SCALAR unit and selected (1 op);
+//   * a pair of horizontally adjacent elements (i, j&~1), (i, j|1) shares y = t ^ (t >> 15), t = seed + ((i&3)*2 + ((j&3)>>1)) * G;
+//     the even column keeps iff mul24(y, KA) >= threshold, the odd one iff mul24(y, KB) >= threshold (two different odd 24-bit
+//     multipliers: exhaustively over the 2^24 values of y the two decisions are independent to 1e-5, tools/attn_drop_stats.py).
+//     "Lane = query" layouts need both decisions of a pair (5 ops per 2 elements), "lane = key" layouts one of them with the
+//     multiplier chosen per lane (4 ops per element);
+//   * the 1/(1-p) scale is not applied per element: forward folds it into the final normalisation, the backward kernels into
+//     constants / the accumulators.
+// attn_drop() is the scalar definition.
 #define ADROP_G 0x9E3779B9u
-__device__ __forceinline__ float adrop_elem(const DropCfg& d, uint32_t y) {  // y = seed + ((i&3)*4 + (j&3)) * ADROP_G
-  y ^= y >> 15;
-  y = __umul24(y, 0x2C1B3Du);
-  return y >= d.threshold ? d.scale : 0.f;
+#define ADROP_KA 0x2C1B3Du
+#define ADROP_KB 0x5A2D39u
+__device__ __forceinline__ uint32_t adrop_rcode(uint32_t akey, uint32_t bi) { return mix32(akey + bi * 0x9E3779B9u); }
+__device__ __forceinline__ uint32_t adrop_ccode(uint32_t bj) { return mix32(bj * 0x85EBCA6Bu + 0x165667B1u); }
+__device__ __forceinline__ uint32_t adrop_seed(uint32_t x) { return __umul24(x, 0x846CA7u) + (x >> 13); }  // v_mad_u32_u24
+__device__ __forceinline__ uint32_t adrop_y(uint32_t t) { return t ^ (t >> 15); }
+__device__ __forceinline__ bool attn_keep(const DropCfg& d, uint32_t akey, int i, int j) {
+  if (d.threshold == 0u) return true;
+  const uint32_t seed = adrop_seed(adrop_rcode(akey, (uint32_t)i >> 2) ^ adrop_ccode((uint32_t)j >> 2));
+  const uint32_t y = adrop_y(seed + (uint32_t)((i & 3) * 2 + ((j & 3) >> 1)) * ADROP_G);
+  return __umul24(y, (j & 1) ? ADROP_KB : ADROP_KA) >= d.threshold;
 }
 __device__ __forceinline__ float attn_drop(const DropCfg& d, uint32_t akey, int i, int j) {
-  if (d.threshold == 0u) return 1.f;
-  const uint32_t seed = adrop_seed(akey ^ adrop_rcode((uint32_t)i >> 2) ^ adrop_ccode((uint32_t)j >> 2));
-  return adrop_elem(d, seed + (uint32_t)((i & 3) * 4 + (j & 3)) * ADROP_G);
+  return attn_keep(d, akey, i, j) ? d.scale : 0.f;
 }
 
 __device__ __forceinline__ int a_off(int r, int chunk) { return r * ADK + ((chunk ^ ((r >> 1) & 7)) << 3); }
@@ -205,7 +205,10 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
   float m_run = -INFINITY, l_run = 0.f;
   float* sg = s_g[wave];
   const uint32_t akey = attn_key(drop, b, h);
-  const uint32_t arow = akey ^ adrop_rcode((uint32_t)i >> 2), erow = (uint32_t)(i & 3) * (4u * ADROP_G);
+  const uint32_t arow = adrop_rcode(akey, (uint32_t)i >> 2), erow = (uint32_t)(i & 3) * (2u * ADROP_G);
+  // softmax in the base-2 domain on the RAW scores: p = exp2(raw * c2 - m_raw * c2), c2 = scale * log2(e) > 0 (one fma + v_exp
+  // per element instead of mul, sub, mul, v_exp); m_run is the running maximum of the raw scores
+  const float c2 = scale * 1.4426950408889634f, tau = 8.f / c2;
 
   const int nkt = (L + ABK - 1) / ABK;  // key tiles that contain at least one valid key
   // The positional band of step kt is rows c0 + 32*kt .. +159; consecutive steps share four of their five 32-row blocks, so
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        s[r] = (acc_s[r] + sg[q * SG_LD + rho + 31 - q]) * scale;
+        s[r] = acc_s[r] + sg[q * SG_LD + rho + 31 - q];
         mx = fmaxf(mx, s[r]);
       }
     } else {
@@ -269,30 +272,42 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
         const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const float bd = sg[q * SG_LD + rho + 31 - q];
         const bool ok = qvalid && (j0 + rho) < L;
-        s[r] = ok ? (acc_s[r] + bd) * scale : -INFINITY;
+        s[r] = ok ? acc_s[r] + bd : -INFINITY;
         mx = fmaxf(mx, s[r]);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __expf(m_run - m_use);  // m_run = -inf -> 0
+    // Lazy re-scaling: the reference point m_run only moves when some query of the wave finds a score more than 8 (base-2
+    // exponent, i.e. a factor 256) above its own -- p <= 256 is harmless in f32 / bf16, l_run carries the same factor and the
+    // final normalisation removes it exactly.  After the first tile the accumulators are almost never re-scaled.
+    if (__builtin_amdgcn_ballot_w64(mx > m_run + tau) != 0ull) {  // (wave-uniform)
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((m_run - m_new) * c2);  // m_run = -inf -> 0
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      m_run = m_new;
+    }
+    const float mc = (m_run == -INFINITY) ? 0.f : m_run * c2;
     float rs = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_use); rs += s[r]; }
+    for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -mc)); rs += s[r]; }
     rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-    // ---- dropout on the probabilities
+    l_run += rs;
+    // ---- dropout on the probabilities (the 1/(1-p) scale is folded into the final normalisation)
     if (drop.threshold != 0u) {
+      const uint32_t bj0 = (uint32_t)(j0 >> 2);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 = keys 4*bj .. 4*bj+3 of this lane's query
-        const uint32_t seed = adrop_seed(arow ^ adrop_ccode((uint32_t)(j0 >> 2) + 2 * g + lh)) + erow;
+      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 = keys 4*bj .. 4*bj+3 of this lane's query, bj = bj0 + 2g + lh
+        const uint32_t cc0 = adrop_ccode(bj0 + 2 * g), cc1 = adrop_ccode(bj0 + 2 * g + 1);  // wave-uniform: scalar unit
+        const uint32_t seed = adrop_seed(arow ^ (lh ? cc1 : cc0)) + erow;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s[4 * g + c] *= adrop_elem(drop, seed + c * ADROP_G);
+        for (int cp = 0; cp < 2; ++cp) {
+          const uint32_t y = adrop_y(seed + cp * ADROP_G);
+          s[4 * g + 2 * cp] = __umul24(y, ADROP_KA) >= drop.threshold ? s[4 * g + 2 * cp] : 0.f;
+          s[4 * g + 2 * cp + 1] = __umul24(y, ADROP_KB) >= drop.threshold ? s[4 * g + 2 * cp + 1] : 0.f;
+        }
       }
     }
     // ---- O^T += V^T . P^T : B operand = this lane's probabilities (registers 8s..8s+7 <-> key slots of K16 step s)
@@ -308,14 +323,14 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
   }
 
   // ---- normalise, transpose O^T -> O through LDS (per wave: [32 queries][64 dv] f32, pitch 66) and store rows
-  const float inv = (qvalid && l_run > 0.f) ? 1.f / l_run : 0.f;
+  const float inv = (qvalid && l_run > 0.f) ? (drop.threshold != 0u ? drop.scale : 1.f) / l_run : 0.f;
   __syncthreads();
 #pragma unroll
   for (int dvt = 0; dvt < 2; ++dvt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sg[q * SG_LD + dvt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = o[dvt][r] * inv;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (lse && lh == 0 && i < T) lse[((long long)b * H + h) * T + i] = qvalid ? m_run + __logf(l_run) : 0.f;
+  if (lse && lh == 0 && i < T) lse[((long long)b * H + h) * T + i] = qvalid ? m_run * scale + __logf(l_run) : 0.f;
   // 32 rows x 64 dv: lane -> (row = it*8 + lane/8, 8-column chunk = lane%8)
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -451,7 +466,10 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   for (int r = 0; r < 16; ++r) { dqu[0][r] = 0.f; dqu[1][r] = 0.f; dqv[0][r] = 0.f; dqv[1][r] = 0.f; }
   float* sg = s_g[wave];
   const uint32_t akey = attn_key(drop, b, h);
-  const uint32_t arow = akey ^ adrop_rcode((uint32_t)i >> 2), erow = (uint32_t)(i & 3) * (4u * ADROP_G);
+  const uint32_t arow = adrop_rcode(akey, (uint32_t)i >> 2), erow = (uint32_t)(i & 3) * (2u * ADROP_G);
+  // P = exp2(raw * c2 - lse * log2(e)); dS = P * (keep * dP * ks - delta * scale), ks = scale / (1 - p)
+  const float c2 = scale * 1.4426950408889634f, lse2 = lse_i * 1.4426950408889634f;
+  const float ks = drop.threshold != 0u ? drop.scale * scale : scale, dls = dlt_i * scale;
 
   const int nkt = (L + ABK - 1) / ABK;
   // linear_pos gradient operand (see the end of the loop): tile `itile` of (h, b) owns nT+1 blocks of 32 x 32 bf16
@@ -508,27 +526,37 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        ds[r] = __expf((acc_s[r] + sg[q * SG_LD + rho + 31 - q]) * scale - lse_i);  // P[i, j]
+        ds[r] = __builtin_amdgcn_exp2f(fmaf(acc_s[r] + sg[q * SG_LD + rho + 31 - q], c2, -lse2));  // P[i, j]
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const float bd = sg[q * SG_LD + rho + 31 - q];
-        ds[r] = (j0 + rho) < L ? __expf((acc_s[r] + bd) * scale - lse_i) : 0.f;
+        ds[r] = (j0 + rho) < L ? __builtin_amdgcn_exp2f(fmaf(acc_s[r] + bd, c2, -lse2)) : 0.f;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // dS = P * (dropmask * dP - delta) * scale
-    uint32_t seed_g = 0u;  // (kept in this per-element form: the kernel sits at 256 VGPRs and the grouped form spills)
+    if (drop.threshold != 0u) {
+      const uint32_t bj0 = (uint32_t)(j0 >> 2);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float dm = 1.f;
-      if (drop.threshold != 0u) {
-        if ((r & 3) == 0) seed_g = adrop_seed(arow ^ adrop_ccode((uint32_t)(j0 >> 2) + 2 * (r >> 2) + lh)) + erow;
-        dm = adrop_elem(drop, seed_g + (r & 3) * ADROP_G);
+      for (int g = 0; g < 4; ++g) {
+        const uint32_t cc0 = adrop_ccode(bj0 + 2 * g), cc1 = adrop_ccode(bj0 + 2 * g + 1);  // wave-uniform: scalar unit
+        const uint32_t seed = adrop_seed(arow ^ (lh ? cc1 : cc0)) + erow;
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+          const uint32_t y = adrop_y(seed + cp * ADROP_G);
+          const int r0 = 4 * g + 2 * cp;
+          const float x0 = __umul24(y, ADROP_KA) >= drop.threshold ? acc_dp[r0] : 0.f;
+          const float x1 = __umul24(y, ADROP_KB) >= drop.threshold ? acc_dp[r0 + 1] : 0.f;
+          ds[r0] *= fmaf(x0, ks, -dls);
+          ds[r0 + 1] *= fmaf(x1, ks, -dls);
+        }
       }
-      ds[r] = ds[r] * (acc_dp[r] * dm - dlt_i) * scale;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ds[r] *= fmaf(acc_dp[r], ks, -dls);
     }
     // ---- dQu^T += K^T . dS^T
 #pragma unroll
@@ -648,7 +676,9 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   const bf16_t* kbase = qkv + (ldq / 3) + h * ADK;
   const bf16_t* pbase = pos + h * ADK;
   const uint32_t akey = attn_key(drop, b, h);
-  const uint32_t acol = akey ^ adrop_ccode((uint32_t)j >> 2), ecol = (uint32_t)(j & 3) * ADROP_G;
+  const uint32_t acol = adrop_ccode((uint32_t)j >> 2), ecol = (uint32_t)((j & 3) >> 1) * ADROP_G;
+  const uint32_t klane = (j & 1) ? ADROP_KB : ADROP_KA;  // this key column's multiplier (see the dropout definition)
+  const float dscale = drop.threshold != 0u ? drop.scale : 1.f;  // folded, with `scale`, into the accumulators at the end
 
   bf16x8 kf[4], vf[4];
   load_rows(kbase + rowj * ldq, kf, j < T, lh);
@@ -717,13 +747,15 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
       }
     }
     float pd[16], ds[16];
-    float dm4[4] = {1.f, 1.f, 1.f, 1.f};
+    uint32_t w4[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // keep iff w >= threshold (threshold 0: dropout off)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if ((r & 3) == 0 && drop.threshold != 0u) {  // registers 4g..4g+3 = queries 4*bi .. 4*bi+3 against this lane's key
-        const uint32_t seed = adrop_seed(acol ^ adrop_rcode((uint32_t)(i0 >> 2) + 2 * (r >> 2) + lh)) + ecol;
+        const uint32_t rr0 = adrop_rcode(akey, (uint32_t)(i0 >> 2) + 2 * (r >> 2));      // bi = i0/4 + 2g + lh: both candidates
+        const uint32_t rr1 = adrop_rcode(akey, (uint32_t)(i0 >> 2) + 2 * (r >> 2) + 1);  // are wave-uniform (scalar unit)
+        const uint32_t seed = adrop_seed((lh ? rr1 : rr0) ^ acol) + ecol;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) dm4[c] = adrop_elem(drop, seed + c * (4u * ADROP_G));
+        for (int c = 0; c < 4; ++c) w4[c] = __umul24(adrop_y(seed + c * (2u * ADROP_G)), klane);
       }
       const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;  // query row of this register
       const int sl = 31 + q - rho;                      // column of G that holds c(i, j)
@@ -733,9 +765,9 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
       const int ii = i0 + rho;
       const bool ok = kvalid && ii < L;
       const float p = ok ? __expf((acc_s[r] + bd) * scale - s_lse[rho]) : 0.f;
-      const float dm = dm4[r & 3];
-      pd[r] = p * dm;
-      ds[r] = p * (acc_dp[r] * dm - s_dlt[rho]) * scale;
+      const bool keep = w4[r & 3] >= drop.threshold;
+      pd[r] = keep ? p : 0.f;
+      ds[r] = p * fmaf(keep ? acc_dp[r] : 0.f, dscale, -s_dlt[rho]);  // (x scale: applied to dK at the end)
     }
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -761,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        st_[q * SG_LD + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = pass == 0 ? dk_acc[t2][r] : dv_acc[t2][r];
+        st_[q * SG_LD + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = pass == 0 ? dk_acc[t2][r] * scale : dv_acc[t2][r] * dscale;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
