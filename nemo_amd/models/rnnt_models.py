@@ -123,6 +123,13 @@ class EncDecRNNTModel(EncDecCTCModel):
             decoder, target_length, _ = self.decoder(targets=transcript, target_length=transcript_len)
         if not self.joint.fuse_loss_wer:
             joint = self.joint(encoder_outputs=encoded, decoder_outputs=decoder)
+            # losses/rnnt.py:446-484: a batch padded beyond its longest utterance / transcript is narrowed before the loss
+            # (the loss's input check insists on T = max length, U = max target length + 1); two host reads, as in the reference
+            max_t, max_u = int(encoded_len.max()), int(target_length.max())
+            if joint.shape[1] != max_t or joint.shape[2] != max_u + 1:
+                joint = joint[:, :max_t, :max_u + 1].contiguous()
+            if transcript.shape[1] != max_u:
+                transcript = transcript[:, :max_u]
             loss_value = self._reduce(self.loss(joint, transcript.clamp(max=self.loss.blank - 1).contiguous(),
                                                 encoded_len.to(torch.int64), target_length.to(torch.int64)), target_length)
         else:

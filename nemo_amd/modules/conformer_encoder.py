@@ -424,18 +424,40 @@ class ConformerEncoder(NeuralModule):
                     p.add_matrix(f"pre.pw{si_}t", pw.weight.data.view(C_, C_), True)
             p.add_fc_permuted("pre.out", pe.out.weight.data, C_, F2)
             p.add_fc_permuted("pre.outt", pe.out.weight.data, C_, F2, transpose=True)
+            d_, H_, dk = self.d_model, self.n_heads, self.d_k
+            _, dkp, dA = self._geometry(cdt)
             for i, L in enumerate(self.layers):
                 for ff, m in (("ff1", L.feed_forward1), ("ff2", L.feed_forward2)):
                     p.add_matrix(f"L{i}.{ff}.w1", m.linear1.weight.data); p.add_matrix(f"L{i}.{ff}.w1t", m.linear1.weight.data, True)
                     p.add_matrix(f"L{i}.{ff}.w2", m.linear2.weight.data); p.add_matrix(f"L{i}.{ff}.w2t", m.linear2.weight.data, True)
                 a = L.self_attn
                 qkv = [a.linear_q.weight.data, a.linear_k.weight.data, a.linear_v.weight.data]
-                p.add_concat(f"L{i}.att.wqkv", qkv); p.add_concat(f"L{i}.att.wqkvt", qkv, transpose=True)
-                p.add_matrix(f"L{i}.att.wo", a.linear_out.weight.data); p.add_matrix(f"L{i}.att.wot", a.linear_out.weight.data, True)
-                p.add_matrix(f"L{i}.att.wpos", a.linear_pos.weight.data)
-                pf.new_image(f"L{i}.att.bqkv", 1, 3 * self.d_model)
-                for j, b in enumerate((a.linear_q.bias.data, a.linear_k.bias.data, a.linear_v.bias.data)):
-                    pf.add_block(f"L{i}.att.bqkv", b, 1, self.d_model, col_off=j * self.d_model, sr1=0, sc1=1)
+                if dkp == dk:
+                    p.add_concat(f"L{i}.att.wqkv", qkv); p.add_concat(f"L{i}.att.wqkvt", qkv, transpose=True)
+                    p.add_matrix(f"L{i}.att.wo", a.linear_out.weight.data); p.add_matrix(f"L{i}.att.wot", a.linear_out.weight.data, True)
+                    p.add_matrix(f"L{i}.att.wpos", a.linear_pos.weight.data)
+                    pf.new_image(f"L{i}.att.bqkv", 1, 3 * d_)
+                    for j, b in enumerate((a.linear_q.bias.data, a.linear_k.bias.data, a.linear_v.bias.data)):
+                        pf.add_block(f"L{i}.att.bqkv", b, 1, d_, col_off=j * d_, sr1=0, sc1=1)
+                else:  # zero-padded heads (see _geometry): head h = rows / columns h*dkp .. h*dkp + dk of the images
+                    p.new_image(f"L{i}.att.wqkv", 3 * dA, d_); p.new_image(f"L{i}.att.wqkvt", d_, 3 * dA)
+                    p.new_image(f"L{i}.att.wpos", dA, d_)
+                    p.new_image(f"L{i}.att.wo", d_, dA); p.new_image(f"L{i}.att.wot", dA, d_)
+                    wo = a.linear_out.weight.data  # [d, H*dk]
+                    pf.new_image(f"L{i}.att.bqkv", 1, 3 * dA)
+                    pf.new_image(f"L{i}.att.bu", 1, dA); pf.new_image(f"L{i}.att.bv", 1, dA)
+                    for h in range(H_):
+                        for j, w in enumerate(qkv):
+                            p.add_block(f"L{i}.att.wqkv", w.view(-1)[h * dk * d_:], dk, d_, row_off=j * dA + h * dkp, sr1=d_, sc1=1)
+                            p.add_block(f"L{i}.att.wqkvt", w.view(-1)[h * dk * d_:], d_, dk, col_off=j * dA + h * dkp, sr1=1, sc1=d_)
+                        p.add_block(f"L{i}.att.wpos", a.linear_pos.weight.data.view(-1)[h * dk * d_:], dk, d_, row_off=h * dkp,
+                                    sr1=d_, sc1=1)
+                        p.add_block(f"L{i}.att.wo", wo.view(-1)[h * dk:], d_, dk, col_off=h * dkp, sr1=d_, sc1=1)
+                        p.add_block(f"L{i}.att.wot", wo.view(-1)[h * dk:], dk, d_, row_off=h * dkp, sr1=1, sc1=d_)
+                        for j, b in enumerate((a.linear_q.bias.data, a.linear_k.bias.data, a.linear_v.bias.data)):
+                            pf.add_block(f"L{i}.att.bqkv", b[h * dk:], 1, dk, col_off=j * dA + h * dkp, sr1=0, sc1=1)
+                        pf.add_block(f"L{i}.att.bu", a.pos_bias_u.data.view(-1)[h * dk:], 1, dk, col_off=h * dkp, sr1=0, sc1=1)
+                        pf.add_block(f"L{i}.att.bv", a.pos_bias_v.data.view(-1)[h * dk:], 1, dk, col_off=h * dkp, sr1=0, sc1=1)
                 c = L.conv
                 p.add_matrix(f"L{i}.conv.pw1", c.pointwise_conv1.weight.data); p.add_matrix(f"L{i}.conv.pw1t", c.pointwise_conv1.weight.data, True)
                 p.add_matrix(f"L{i}.conv.pw2", c.pointwise_conv2.weight.data); p.add_matrix(f"L{i}.conv.pw2t", c.pointwise_conv2.weight.data, True)
@@ -743,11 +765,12 @@ class ConformerEncoder(NeuralModule):
         self._phase("f", dev)
         self._fwd_serial += 1
         cdt = self._cdt()
-        if cdt == torch.bfloat16 and (self.d_k % 8 or self.d_model % 8):
-            # the bf16 operand path moves 16-byte pieces: a head must start on an 8-element boundary.  The recipe table's
-            # Small (d=176, 4 heads, d_k=44) therefore runs in fp32 here; Medium / Large (d_k=64) take the bf16 path.
-            raise NotImplementedError(f"bf16 compute needs d_model and d_model/n_heads divisible by 8 (got d_model="
-                                      f"{self.d_model}, d_k={self.d_k}); use compute_dtype=torch.float32 for this geometry")
+        if cdt == torch.bfloat16 and self.d_model % 8:
+            # the bf16 operand path moves 16-byte pieces.  Heads that do not start on an 8-element boundary (the recipe table's
+            # Small: d = 176, 4 heads, d_k = 44) are zero-padded inside the packed weight images (_geometry); a d_model that is
+            # not a multiple of 8 would need padded activation rows as well (SqueezeformerEncoder has them)
+            raise NotImplementedError(f"bf16 compute needs d_model divisible by 8 (got d_model={self.d_model}); use "
+                                      f"compute_dtype=torch.float32 for this geometry")
         training = self.training
         W, Wf = self._plan(cdt, dev)
         B, F_, T = mel.shape
@@ -949,21 +972,48 @@ class ConformerEncoder(NeuralModule):
         setattr(sl, tag, (x, y, mean, rstd, h, a, d_in, d_res))
         return r
 
+    def _geometry(self, cdt):
+        """(row pitch of [M, d] GEMM operands, head width in the attention operands, attention width H * head width).  bf16
+        operands move in 16-byte pieces, so a head must start on an 8-element boundary: with d_k % 8 != 0 (Conformer-Small:
+        d = 176, 4 heads, d_k = 44 -> 48) the heads are zero-padded INSIDE the packed weight images (q | k | v rows,
+        linear_pos rows, linear_out columns, pos_bias lanes); activations outside the attention block keep width d."""
+        dk = self.d_k
+        dkp = _pad8(dk) if cdt == torch.bfloat16 else dk
+        return self.d_model, dkp, self.n_heads * dkp
+
+    def _heads_wgrad(self, dY, ldy, y_off, X, ldx, dW, rows, n_groups, group_stride_y, group_stride_w):
+        """dW_g[h*dk:(h+1)*dk, :] += dY[:, y_off + g*group_stride_y + h*dkp : +dk]^T @ X for every head h and group g (q, k, v):
+        one batched TN GEMM whose batch strides step over the heads' pad lanes"""
+        d, H, dk = self.d_model, self.n_heads, self.d_k
+        dkp = self._geometry(dY.dtype)[1]
+        bf16 = dY.dtype == torch.bfloat16
+        tiles = self._tiles(dk, d, bf16) * H * n_groups
+        with self._wgrad_scope(dY, X):
+            ops.gemm(dY, X, dW, dk, d, rows, ldy, ldx, d, transA=True, transB=True, atomic=True,
+                     splitk=self._splitk(tiles, rows), batch=H * n_groups, nb0=H, sA=(dkp, group_stride_y),
+                     sC=(dk * d, group_stride_w), a_off=y_off, c_dtype=ops.F32)
+
+    def _unpad_add(self, dst, src, dkp):
+        """dst [.., H*dk] += src [.., H*dkp] without the pad lanes (tiny: bias-sized vectors)"""
+        H, dk = self.n_heads, self.d_k
+        dst.view(*dst.shape[:-1], H, dk).add_(src.view(*src.shape[:-1], H, dkp)[..., :dk])
+
     def _pos_proj_fwd(self, pos, W, cdt, dev):
         """p_l = linear_pos_l(pos_emb) for all layers (multi_head_attention.py:309): the input is the same table, so the
         18 [2T-1, d] x [d, d] products are one batched GEMM (288 tiles) instead of 18 launches of 16 tiles."""
         nl, d = self.n_layers, self.d_model
+        dA = self._geometry(cdt)[2]
         P = pos.shape[0]
-        p_all = self._new(nl, P, d, dtype=cdt, device=dev)
+        p_all = self._new(nl, P, dA, dtype=cdt, device=dev)
         es = W["L0.att.wpos"].element_size()
         stride = (W["L1.att.wpos"].data_ptr() - W["L0.att.wpos"].data_ptr()) // es if nl > 1 else 0
         uniform = all(W[f"L{i}.att.wpos"].data_ptr() - W["L0.att.wpos"].data_ptr() == i * stride * es for i in range(nl))
         if uniform and stride >= 0:
-            ops.gemm(pos, W["L0.att.wpos"], p_all, P, d, d, d, W.pitch("L0.att.wpos"), d, batch=nl, nb0=nl,
-                     sB=(stride, 0), sC=(P * d, 0))
+            ops.gemm(pos, W["L0.att.wpos"], p_all, P, dA, d, d, W.pitch("L0.att.wpos"), dA, batch=nl, nb0=nl,
+                     sB=(stride, 0), sC=(P * dA, 0))
         else:
             for i in range(nl):
-                ops.gemm(pos, W[f"L{i}.att.wpos"], p_all[i], P, d, d, d, W.pitch(f"L{i}.att.wpos"), d)
+                ops.gemm(pos, W[f"L{i}.att.wpos"], p_all[i], P, dA, d, d, W.pitch(f"L{i}.att.wpos"), dA)
         return p_all
 
     def _pos_proj_wgrad(self, dp_all, pos, P, cdt):
@@ -971,6 +1021,11 @@ class ConformerEncoder(NeuralModule):
         gradient buffer (FlatParams(tail=...) keeps the 18 gradients equally spaced)."""
         nl, d = self.n_layers, self.d_model
         grads = [L.self_attn.linear_pos.weight.grad for L in self.layers]
+        _, dkp, dA = self._geometry(cdt)
+        if dkp != self.d_k:  # padded heads: per layer one TN GEMM batched over the heads (strides step over the pad lanes)
+            for i in range(nl):
+                self._heads_wgrad(dp_all[i], dA, 0, pos, d, grads[i], P, 1, 0, 0)
+            return
         stride = (grads[1].data_ptr() - grads[0].data_ptr()) // 4 if nl > 1 else 0
         uniform = all(g.data_ptr() - grads[0].data_ptr() == i * stride * 4 for i, g in enumerate(grads))
         if uniform and stride >= 0:
@@ -1090,15 +1145,16 @@ class ConformerEncoder(NeuralModule):
         # ---- rel-pos multi-head self-attention
         a = L.self_attn
         y2, mean2, rstd2 = self._ln_fwd(L.norm_self_att, r1, M, d, cdt, dev)
-        qkv = self._new(M, 3 * d, dtype=cdt, device=dev)
-        ops.gemm(y2, W[f"L{i}.att.wqkv"], qkv, M, 3 * d, d, d, W.pitch(f"L{i}.att.wqkv"), 3 * d, bias=Wf[f"L{i}.att.bqkv"])
+        _, dkp, dA = self._geometry(cdt)  # (dkp = dk, dA = d unless the heads are padded)
+        qkv = self._new(M, 3 * dA, dtype=cdt, device=dev)
+        ops.gemm(y2, W[f"L{i}.att.wqkv"], qkv, M, 3 * dA, d, d, W.pitch(f"L{i}.att.wqkv"), 3 * dA, bias=Wf[f"L{i}.att.bqkv"])
         p = S.p_all[i]  # linear_pos(pos_emb) of every layer was computed by one batched GEMM (same input, 18 weights)
         d_att = drop(self.dropout_att, site + 2)
-        ctx, (qu, qv, s_, pd, lse) = self._attn_fwd(qkv, p, a.pos_bias_u, a.pos_bias_v, S.len2, B, T2, d, dk, 1.0 / math.sqrt(dk),
-                                                    d_att, cdt, dev)
+        bu, bv = (a.pos_bias_u, a.pos_bias_v) if dkp == dk else (Wf[f"L{i}.att.bu"], Wf[f"L{i}.att.bv"])
+        ctx, (qu, qv, s_, pd, lse) = self._attn_fwd(qkv, p, bu, bv, S.len2, B, T2, dA, dkp, 1.0 / math.sqrt(dk), d_att, cdt, dev)
         r2 = self._new(M, d, dtype=torch.float32, device=dev)
         d_ares = drop(self.dropout, site + 3)
-        ops.gemm(ctx, W[f"L{i}.att.wo"], r2, M, d, d, d, W.pitch(f"L{i}.att.wo"), d, bias=a.linear_out.bias, epi=ops.EPI_RESID,
+        ops.gemm(ctx, W[f"L{i}.att.wo"], r2, M, d, dA, dA, W.pitch(f"L{i}.att.wo"), d, bias=a.linear_out.bias, epi=ops.EPI_RESID,
                  aux_in=r1, drop=d_ares)
         sl.att = (r1, y2, mean2, rstd2, qkv, p, qu, qv, s_, pd, ctx, d_att, d_ares, lse)
         # ---- convolution module
@@ -1207,9 +1263,10 @@ class ConformerEncoder(NeuralModule):
         fp = self._flatp
         dx = dout.transpose(1, 2).contiguous().view(M, d).to(torch.float32)  # no copy when dout is a [B,T,d] view
         P = 2 * T2 - 1
-        S.dp_all = self._buf("dp_all", (self.n_layers, P, d), cdt, dev)
+        dA = self._geometry(cdt)[2]
+        S.dp_all = self._buf("dp_all", (self.n_layers, P, dA), cdt, dev)
         S.bn_sums = torch.zeros(self.n_layers, 2, d, dtype=torch.float64, device=dev)
-        S.dpos_f32 = torch.zeros(self.n_layers, P, d, dtype=torch.float32, device=dev)
+        S.dpos_f32 = torch.zeros(self.n_layers, P, dA, dtype=torch.float32, device=dev)
         self._wg_pending = [] if (self.wgrad_grouped and cdt == torch.bfloat16) else None
         for i in range(self.n_layers - 1, -1, -1):
             dx = self._layer_bwd(i, self.layers[i], dx, S, S.layers[i], W, Wf)
@@ -1313,6 +1370,81 @@ class ConformerEncoder(NeuralModule):
             return None
         return self._new(M, d, dtype=cdt, device=dev)
 
+    def _attn_block_bwd(self, i, a, saved, dao, S, W, M, B, T2, d, dk, scale, cdt, dev):
+        """linear_out -> attention core -> q | k | v projections, backward (heads of width d_k % 8 == 0, or fp32)"""
+        r1, y2, mean2, rstd2, qkv, p, qu, qv, s_, pd, ctx, d_att, d_ares, lse = saved
+        self._wgrad(dao, d, 0, ctx, d, 0, a.linear_out.weight.grad, d, d, M, bias_grad=a.linear_out.bias.grad)
+        dctx = self._new(M, d, dtype=cdt, device=dev)
+        ops.gemm(dao, W[f"L{i}.att.wot"], dctx, M, d, d, d, W.pitch(f"L{i}.att.wot"), d)
+        dqkv, dqu, dqv = self._attn_bwd((qu, qv, s_, pd, lse), qkv, p, a.pos_bias_u, a.pos_bias_v, ctx, dctx, S.len2, B, T2, d,
+                                        dk, scale, d_att, cdt, dev, S.dpos_f32[i], S.dp_all[i])
+        gu, gv_ = a.pos_bias_u.grad, a.pos_bias_v.grad
+        if cdt == torch.bfloat16 and gv_.data_ptr() - gu.data_ptr() == 4 * d:
+            ops.add2_colsum(dqu, dqv, dqkv, 3 * d, M, d, gu)  # dq = dqu + dqv and both bias gradients in one pass
+        else:
+            ops.colsum(dqu, gu, M, d)
+            ops.colsum(dqv, gv_, M, d)
+            ops.add2(dqu, dqv, dqkv, 3 * d, M, d)
+        gq, gk, gv = a.linear_q.weight.grad, a.linear_k.weight.grad, a.linear_v.weight.grad
+        sw = (gk.data_ptr() - gq.data_ptr()) // 4
+        sb = (a.linear_k.bias.grad.data_ptr() - a.linear_q.bias.grad.data_ptr()) // 4
+        if (cdt == torch.bfloat16 and sw > 0 and (gv.data_ptr() - gk.data_ptr()) // 4 == sw
+                and (a.linear_v.bias.grad.data_ptr() - a.linear_k.bias.grad.data_ptr()) // 4 == sb):
+            # q, k, v weight (and bias) gradients as ONE batched TN GEMM: the three gradients are equally spaced in the
+            # flat gradient buffer, the three dY column blocks equally spaced in dqkv
+            if self._wg_pending is not None:  # three more problems of the layer's grouped launch
+                for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
+                    self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M, bias_grad=lin.bias.grad)
+            else:
+                with self._wgrad_scope(dqkv, y2):
+                    ops.gemm(dqkv, y2, gq, d, d, M, 3 * d, d, d, transA=True, transB=True, atomic=True,
+                             splitk=self._splitk(3 * self._tiles(d, d, True), M), batch=3, nb0=3, sA=(d, 0), sC=(sw, 0),
+                             c_dtype=ops.F32, colsum_out=a.linear_q.bias.grad, colsum_stride=sb)
+        else:
+            for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
+                self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M, bias_grad=lin.bias.grad)
+        dy2 = self._new(M, d, dtype=cdt, device=dev)
+        ops.gemm(dqkv, W[f"L{i}.att.wqkvt"], dy2, M, d, 3 * d, 3 * d, W.pitch(f"L{i}.att.wqkvt"), d)
+        return dy2
+
+    def _attn_block_bwd_padded(self, i, a, saved, dao, S, W, Wf, M, B, T2, d, dk, dkp, dA, scale, cdt, dev):
+        """the same with zero-padded heads (bf16, d_k % 8 != 0): the heads' weight gradients are TN GEMMs batched over the heads
+        whose strides step over the pad lanes, bias-sized gradients are summed in the padded layout and added back without it"""
+        r1, y2, mean2, rstd2, qkv, p, qu, qv, s_, pd, ctx, d_att, d_ares, lse = saved
+        H = self.n_heads
+        P = 2 * T2 - 1
+        with self._wgrad_scope(dao, ctx):
+            ops.gemm(dao, ctx, a.linear_out.weight.grad, d, dk, M, d, dA, d, transA=True, transB=True, atomic=True,
+                     splitk=self._splitk(self._tiles(d, dk, True) * H, M), batch=H, nb0=H, sB=(dkp, 0), sC=(dk, 0),
+                     c_dtype=ops.F32)
+            ops.colsum(dao, a.linear_out.bias.grad, M, d)
+        dctx = self._new(M, dA, dtype=cdt, device=dev)
+        ops.gemm(dao, W[f"L{i}.att.wot"], dctx, M, dA, d, d, W.pitch(f"L{i}.att.wot"), dA)
+        dqkv, dqu, dqv = self._attn_bwd((qu, qv, s_, pd, lse), qkv, p, Wf[f"L{i}.att.bu"], Wf[f"L{i}.att.bv"], ctx, dctx, S.len2, B,
+                                        T2, dA, dkp, scale, d_att, cdt, dev, S.dpos_f32[i], S.dp_all[i])
+        sc = torch.zeros(2, dA, dtype=torch.float32, device=dev)
+        ops.colsum(dqu, sc[0], M, dA)
+        ops.colsum(dqv, sc[1], M, dA)
+        self._unpad_add(a.pos_bias_u.grad.view(-1), sc[0], dkp)
+        self._unpad_add(a.pos_bias_v.grad.view(-1), sc[1], dkp)
+        ops.add2(dqu, dqv, dqkv, 3 * dA, M, dA)
+        lins = (a.linear_q, a.linear_k, a.linear_v)
+        gq, gk, gvw = (lin.weight.grad for lin in lins)
+        sw = (gk.data_ptr() - gq.data_ptr()) // 4
+        if sw > 0 and (gvw.data_ptr() - gk.data_ptr()) // 4 == sw:
+            self._heads_wgrad(dqkv, 3 * dA, 0, y2, d, gq, M, 3, dA, sw)
+        else:
+            for j, lin in enumerate(lins):
+                self._heads_wgrad(dqkv, 3 * dA, j * dA, y2, d, lin.weight.grad, M, 1, 0, 0)
+        sb = torch.zeros(3 * dA, dtype=torch.float32, device=dev)
+        with self._wgrad_scope(dqkv, sb):
+            ops.colsum(dqkv, sb, M, 3 * dA)
+            for j, lin in enumerate(lins):
+                self._unpad_add(lin.bias.grad, sb[j * dA:(j + 1) * dA], dkp)
+        dy2 = self._new(M, d, dtype=cdt, device=dev)
+        ops.gemm(dqkv, W[f"L{i}.att.wqkvt"], dy2, M, d, 3 * dA, 3 * dA, W.pitch(f"L{i}.att.wqkvt"), d)
+        return dy2
+
     def _layer_bwd(self, i, L, dxo, S, sl, W, Wf):
         B, F_, T, T1, F1, T2, F2, M, cdt, training, seed = S.dims
         dev = dxo.device
@@ -1371,38 +1503,11 @@ class ConformerEncoder(NeuralModule):
         if dao is None:
             dao = self._new(M, d, dtype=cdt, device=dev)
             ops.drop_scale_cast(dr, dao, M * d, 1.0, d_ares)
-        self._wgrad(dao, d, 0, ctx, d, 0, a.linear_out.weight.grad, d, d, M, bias_grad=a.linear_out.bias.grad)
-        dctx = self._new(M, d, dtype=cdt, device=dev)
-        ops.gemm(dao, W[f"L{i}.att.wot"], dctx, M, d, d, d, W.pitch(f"L{i}.att.wot"), d)
-        dqkv, dqu, dqv = self._attn_bwd((qu, qv, s_, pd, lse), qkv, p, a.pos_bias_u, a.pos_bias_v, ctx, dctx, S.len2, B, T2, d,
-                                        dk, scale, d_att, cdt, dev, S.dpos_f32[i], S.dp_all[i])
-        gu, gv_ = a.pos_bias_u.grad, a.pos_bias_v.grad
-        if cdt == torch.bfloat16 and gv_.data_ptr() - gu.data_ptr() == 4 * d:
-            ops.add2_colsum(dqu, dqv, dqkv, 3 * d, M, d, gu)  # dq = dqu + dqv and both bias gradients in one pass
+        _, dkp, dA = self._geometry(cdt)
+        if dkp != dk:
+            dy2 = self._attn_block_bwd_padded(i, a, sl.att, dao, S, W, Wf, M, B, T2, d, dk, dkp, dA, scale, cdt, dev)
         else:
-            ops.colsum(dqu, gu, M, d)
-            ops.colsum(dqv, gv_, M, d)
-            ops.add2(dqu, dqv, dqkv, 3 * d, M, d)
-        gq, gk, gv = a.linear_q.weight.grad, a.linear_k.weight.grad, a.linear_v.weight.grad
-        sw = (gk.data_ptr() - gq.data_ptr()) // 4
-        sb = (a.linear_k.bias.grad.data_ptr() - a.linear_q.bias.grad.data_ptr()) // 4
-        if (cdt == torch.bfloat16 and sw > 0 and (gv.data_ptr() - gk.data_ptr()) // 4 == sw
-                and (a.linear_v.bias.grad.data_ptr() - a.linear_k.bias.grad.data_ptr()) // 4 == sb):
-            # q, k, v weight (and bias) gradients as ONE batched TN GEMM: the three gradients are equally spaced in the
-            # flat gradient buffer, the three dY column blocks equally spaced in dqkv
-            if self._wg_pending is not None:  # three more problems of the layer's grouped launch
-                for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
-                    self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M, bias_grad=lin.bias.grad)
-            else:
-                with self._wgrad_scope(dqkv, y2):
-                    ops.gemm(dqkv, y2, gq, d, d, M, 3 * d, d, d, transA=True, transB=True, atomic=True,
-                             splitk=self._splitk(3 * self._tiles(d, d, True), M), batch=3, nb0=3, sA=(d, 0), sC=(sw, 0),
-                             c_dtype=ops.F32, colsum_out=a.linear_q.bias.grad, colsum_stride=sb)
-        else:
-            for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
-                self._wgrad(dqkv, 3 * d, j * d, y2, d, 0, lin.weight.grad, d, d, M, bias_grad=lin.bias.grad)
-        dy2 = self._new(M, d, dtype=cdt, device=dev)
-        ops.gemm(dqkv, W[f"L{i}.att.wqkvt"], dy2, M, d, 3 * d, 3 * d, W.pitch(f"L{i}.att.wqkvt"), d)
+            dy2 = self._attn_block_bwd(i, a, sl.att, dao, S, W, M, B, T2, d, dk, scale, cdt, dev)
         ln = L.norm_self_att
         nc = (0.5, sl.ff1[7])
         df1 = self._cast_buf(nc, M, d, cdt, dev)

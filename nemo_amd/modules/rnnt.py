@@ -350,6 +350,9 @@ class RNNTJoint(_ModuleBase):
         self._num_extra_outputs = 0
         self._num_classes = num_classes + 1
         self._fuse_loss_wer, self._fused_batch_size = fuse_loss_wer, fused_batch_size
+        # fused joint + loss: cut every sub-batch to its own longest encoder / target length, as the reference does
+        # (rnnt.py:1559-1600); costs one host read of the lengths per step.  MI355X_RNNT_TRUNCATE=0 keeps the padded grid.
+        self.truncate_sub_batches = os.environ.get("MI355X_RNNT_TRUNCATE", "1") != "0"
         self._loss, self._wer = None, None
         self.log_softmax, self.preserve_memory, self.masking_prob = log_softmax, preserve_memory, masking_prob
         self.encoder_hidden, self.pred_hidden = jointnet["encoder_hidden"], jointnet["pred_hidden"]
@@ -473,9 +476,11 @@ class RNNTJoint(_ModuleBase):
                  alpha=1.0 / self.temperature if self.temperature != 1.0 else 1.0)
         return h, logits
 
-    def _sub_bwd(self, dlogits, h, b0, nb, T, U1, W, cdt, drop, df, dg32, gW, gb, dlog=None):
+    def _sub_bwd(self, dlogits, h, b0, nb, T, U1, W, cdt, drop, df, dg32, gW, gb, dlog=None, df_rows=None, dg_pitch=None):
         """dlogits f32 [nb,T,U1,V1] (or `dlog`: the same gradient already as the pitched GEMM operand [n, roundup8(V1)], scaled
-        by 1/temperature): output-layer gradients into (gW, gb), dpre reductions into df (rows b0*T..) and dg32"""
+        by 1/temperature): output-layer gradients into (gW, gb), dpre reductions into df (rows b0*T..) and dg32.
+        `df_rows` / `dg_pitch` (truncated sub-batches): the dense [nb*T, J] destination of the encoder-side reduction, and the
+        number of prediction frames per utterance in dg32 when it is larger than this call's U1"""
         J, V1 = self.joint_hidden, self._num_classes
         V1p = _pad8(V1)
         dev = h.device
@@ -486,9 +491,10 @@ class RNNTJoint(_ModuleBase):
         self._wgrad(dlog, V1p, h, J, gW, V1, J, n, bias_grad=gb)
         dh = torch.empty(n, J, dtype=cdt, device=dev)
         ops.gemm(dlog, W["out.wt"], dh, n, J, V1p, V1p, W.pitch("out.wt"), J)
-        ops.joint_combine_bwd(dh, h, df[b0 * T:], nb, T, U1, J, drop.scale)
+        ops.joint_combine_bwd(dh, h, df[b0 * T:] if df_rows is None else df_rows, nb, T, U1, J, drop.scale)
+        gp = dg_pitch or U1
         for i in range(nb):  # dg[b,u,:] = sum_t dpre[b,t,u,:]: a column sum over the [T, U1*J] slab of each utterance
-            ops.colsum(dh[i * T * U1:], dg32[(b0 + i) * U1:], T, U1 * J)
+            ops.colsum(dh[i * T * U1:], dg32[(b0 + i) * gp:], T, U1 * J)
 
     def _proj_bwd(self, xe, xd, df, dg32, W, cdt, B, T, U1, gWe, gbe, gWp, gbp):
         D, H, J = self.encoder_hidden, self.pred_hidden, self.joint_hidden
@@ -563,14 +569,39 @@ class RNNTJoint(_ModuleBase):
         scale = 1.0 / B if red == "mean_batch" else 1.0
         costs = torch.empty(B, dtype=torch.float32, device=dev)
         fbs = int(self._fused_batch_size)
+        # rnnt.py:1559-1600: every sub-batch is cut to ITS longest encoder / target length before joint and loss (cells beyond an
+        # utterance's own lengths carry no loss and no gradient, so the result is the same; the joint GEMMs and the lattice of a
+        # ragged batch shrink by the padding).  The cut needs the lengths on the host: one read per step, as in the reference.
+        cuts = None
+        if self.truncate_sub_batches:
+            n_sub = (B + fbs - 1) // fbs
+            pad = n_sub * fbs - B
+            lens2 = torch.stack([torch.nn.functional.pad(el, (0, pad)).view(n_sub, fbs).amax(1),
+                                 torch.nn.functional.pad(tl, (0, pad)).view(n_sub, fbs).amax(1)]).tolist()
+            cuts = [(max(1, min(T, int(a))), max(1, min(U1, int(b) + 1))) for a, b in zip(*lens2)]
+            if all(c == (T, U1) for c in cuts):
+                cuts = None  # nothing to cut (fixed-length batches): the dense path below, no copies
+            elif need_grad:
+                df.zero_()   # rows beyond a sub-batch's cut are not written
+        f3, g3 = f.view(B, T, J), g.view(B, U1, J)
         for si, b0 in enumerate(range(0, B, fbs)):
             nb = min(fbs, B - b0)
             drop = self._drop(si)
             fe = float(getattr(loss_mod, "fastemit_lambda", 0.0) or 0.0)
             cl = float(getattr(loss_mod, "clamp", 0.0) or 0.0)
+            Ts, Us = cuts[si] if cuts is not None else (T, U1)
+            cut = (Ts, Us) != (T, U1)
+            if cut:  # dense copies of the sub-batch's [nb, Ts, J] / [nb, Us, J] corners (small next to the [nb, Ts, Us, V+1] logits)
+                fs, gs = f3[b0:b0 + nb, :Ts].contiguous().view(nb * Ts, J), g3[b0:b0 + nb, :Us].contiguous().view(nb * Us, J)
+                lab = labels[b0:b0 + nb, :max(Us - 1, 1)].contiguous() if labels.shape[1] else labels[b0:b0 + nb]
+                fb0 = 0
+                dfs = torch.empty(nb * Ts, J, dtype=cdt, device=dev) if need_grad else None
+            else:
+                fs, gs, lab, fb0, dfs = f, g, labels[b0:b0 + nb], b0, None
+            sub_bwd_kw = dict(df_rows=dfs, dg_pitch=U1) if cut else {}
             if not need_grad:
-                h, logits = self._sub_fwd(f, g, b0, nb, T, U1, W, cdt, drop)
-                costs[b0:b0 + nb] = ops.rnnt_loss(logits, labels[b0:b0 + nb], el[b0:b0 + nb], tl[b0:b0 + nb], self._vocab_size,
+                h, logits = self._sub_fwd(fs, gs, fb0, nb, Ts, Us, W, cdt, drop)
+                costs[b0:b0 + nb] = ops.rnnt_loss(logits, lab, el[b0:b0 + nb], tl[b0:b0 + nb], self._vocab_size,
                                                   fastemit_lambda=fe, clamp=cl, grad_scale=scale)
                 del h, logits
                 continue
@@ -579,22 +610,25 @@ class RNNTJoint(_ModuleBase):
                 # directly as the bf16 operand of the backward GEMMs: the f32 gradient tensor and its cast pass do not exist
                 V1 = self._num_classes
                 V1p = _pad8(V1)
-                h, logits = self._sub_fwd(f, g, b0, nb, T, U1, W, cdt, drop, ld=V1p)
-                dlog = torch.empty(nb * T * U1, V1p, dtype=cdt, device=dev)
-                c = ops.rnnt_loss_pitched(logits, V1p, nb, T, U1, V1, labels[b0:b0 + nb], el[b0:b0 + nb], tl[b0:b0 + nb],
+                h, logits = self._sub_fwd(fs, gs, fb0, nb, Ts, Us, W, cdt, drop, ld=V1p)
+                dlog = torch.empty(nb * Ts * Us, V1p, dtype=cdt, device=dev)
+                c = ops.rnnt_loss_pitched(logits, V1p, nb, Ts, Us, V1, lab, el[b0:b0 + nb], tl[b0:b0 + nb],
                                           self._vocab_size, dlog, V1p, fastemit_lambda=fe, clamp=cl,
                                           grad_scale=scale / self.temperature if self.temperature != 1.0 else scale)
                 costs[b0:b0 + nb] = c
-                self._sub_bwd(None, h, b0, nb, T, U1, W, cdt, drop, df, dg32, gview(out.weight), gview(out.bias), dlog=dlog)
-                del h, logits, dlog
-                continue
-            h, logits = self._sub_fwd(f, g, b0, nb, T, U1, W, cdt, drop)
-            grads = torch.empty_like(logits)
-            c = ops.rnnt_loss(logits, labels[b0:b0 + nb], el[b0:b0 + nb], tl[b0:b0 + nb], self._vocab_size, grads=grads,
-                              fastemit_lambda=fe, clamp=cl, grad_scale=scale)
-            costs[b0:b0 + nb] = c
-            self._sub_bwd(grads, h, b0, nb, T, U1, W, cdt, drop, df, dg32, gview(out.weight), gview(out.bias))
-            del h, logits, grads
+                self._sub_bwd(None, h, b0, nb, Ts, Us, W, cdt, drop, df, dg32, gview(out.weight), gview(out.bias), dlog=dlog,
+                              **sub_bwd_kw)
+            else:
+                h, logits = self._sub_fwd(fs, gs, fb0, nb, Ts, Us, W, cdt, drop)
+                grads = torch.empty_like(logits)
+                c = ops.rnnt_loss(logits, lab, el[b0:b0 + nb], tl[b0:b0 + nb], self._vocab_size, grads=grads,
+                                  fastemit_lambda=fe, clamp=cl, grad_scale=scale)
+                costs[b0:b0 + nb] = c
+                self._sub_bwd(grads, h, b0, nb, Ts, Us, W, cdt, drop, df, dg32, gview(out.weight), gview(out.bias), **sub_bwd_kw)
+                del grads
+            if cut:
+                df.view(B, T, J)[b0:b0 + nb, :Ts].copy_(dfs.view(nb, Ts, J))
+            del h, logits
         loss = costs.sum() * scale
         if not need_grad:
             return loss, None, None, None

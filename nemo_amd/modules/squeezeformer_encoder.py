@@ -516,23 +516,7 @@ class SqueezeformerEncoder(ConformerEncoder):
         ops.gemm(dh, W[pfx + ".w1t"], dy, M, d, dff, dff, W.pitch(pfx + ".w1t"), dp)
         return self._sb_bwd(sb, dy, x, dr, M, dp)
 
-    def _heads_wgrad(self, dY, ldy, y_off, X, ldx, dW, rows, n_groups, group_stride_y, group_stride_w):
-        """dW_g[h*dk:(h+1)*dk, :] += dY[:, y_off + g*group_stride_y + h*dkp : +dk]^T @ X for every head h and group g (q, k, v):
-        one batched TN GEMM whose batch strides step over the heads' pad lanes"""
-        d, H, dk = self.d_model, self.n_heads, self.d_k
-        dkp = self._geometry(dY.dtype)[1]
-        bf16 = dY.dtype == torch.bfloat16
-        tiles = self._tiles(dk, d, bf16) * H * n_groups
-        with self._wgrad_scope(dY, X):
-            ops.gemm(dY, X, dW, dk, d, rows, ldy, ldx, d, transA=True, transB=True, atomic=True,
-                     splitk=self._splitk(tiles, rows), batch=H * n_groups, nb0=H, sA=(dkp, group_stride_y),
-                     sC=(dk * d, group_stride_w), a_off=y_off, c_dtype=ops.F32)
-
-    def _unpad_add(self, dst, src, dkp):
-        """dst [.., H*dk] += src [.., H*dkp] without the pad lanes (tiny: bias-sized vectors)"""
-        H, dk = self.n_heads, self.d_k
-        dst.view(*dst.shape[:-1], H, dk).add_(src.view(*src.shape[:-1], H, dkp)[..., :dk])
-
+    # (_heads_wgrad / _unpad_add: the padded-head weight-gradient helpers live in ConformerEncoder)
     def _sq_layer_bwd(self, i, L, dxo, g, S, sl, W, Wf):
         B, T, M = g.B, g.T, g.M
         cdt, training = S.dims[8], S.dims[9]
