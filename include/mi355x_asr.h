@@ -252,10 +252,12 @@ int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const void* qkv,
 /* dpos f32 [2T-1, ldd] += gradient w.r.t. pos = linear_pos(pos_emb) (multi_head_attention.py:296-300 backward), summed over
  * the batch: dpos[c, h, :] += sum_{b,i} dS[b,h,i,c-(T-1)+i] * qv[b,i,h,:], from the blocks written by
  * mi355x_relpos_flash_bwd_dq (ds_out).  partial (optional): f32 scratch of >= mi355x_relpos_dpos_partial_elems(B,H,T)
- * elements -> deterministic two-stage reduction instead of atomics. */
+ * elements -> deterministic two-stage reduction instead of atomics.  dpos_cast (optional, needs `partial`): bf16 [2T-1, ldd]
+ * copy of the updated dpos, written by the reduction stage (the operand of the linear_pos weight-gradient GEMM). */
 long long mi355x_relpos_dpos_partial_elems(int B, int H, int T);
-int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len, void* dpos, long long ldd, void* partial,
-                                 long long partial_elems, int B, int H, int T, int dk, long long ds_elems, void* stream);
+int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len, void* dpos, long long ldd, void* dpos_cast,
+                                 void* partial, long long partial_elems, int B, int H, int T, int dk, long long ds_elems,
+                                 void* stream);
 
 /* ---- convolution module: depthwise conv + BatchNorm + Swish (conformer_modules.py:333-342, causal_convs.py:130-147) */
 int mi355x_dwconv_fwd(const void* x, const void* w /*[d,1,k]*/, const void* bias, void* y, int dtype,
@@ -273,10 +275,17 @@ int mi355x_bn_eval_stats(const void* running_mean, const void* running_var, void
                          void* stream);
 int mi355x_bn_swish_fwd(const void* x, const void* mean, const void* rstd, const void* gamma, const void* beta, void* y,
                         int dtype, long long M, int d, void* stream);
+/* training forward in one launch: mean / rstd from the f64 sums (as mi355x_bn_finalize: `count` positions, or the count read
+ * from device memory when count_dev != NULL), written out for backward, running statistics updated, y = swish(BN(x)) */
+int mi355x_bn_stats_swish_fwd(const void* x, const void* stats, double count, const void* count_dev, const void* gamma,
+                              const void* beta, void* y, void* mean, void* rstd, void* running_mean, void* running_var,
+                              float momentum, float eps, int dtype, long long M, int d, void* stream);
+/* dgamma / dbeta (optional, both or neither): f32 [d] += the parameter gradients, i.e. the LOCAL sums (what
+ * mi355x_bn_param_grad adds), accumulated by the reduction's second stage */
 int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
-                               const void* beta, void* sums /*f64 [2,d] +=*/, int dtype, long long M, int d,
-                               void* scratch /* optional f32 [ceil(M/32)*2*d]: two-stage reduction */, long long scratch_elems,
-                               void* stream);
+                               const void* beta, void* sums /*f64 [2,d] +=*/, void* dgamma, void* dbeta, int dtype, long long M,
+                               int d, void* scratch /* optional f32 [ceil(M/32)*2*d]: two-stage reduction */,
+                               long long scratch_elems, void* stream);
 int mi355x_bn_swish_bwd_apply(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
                               const void* beta, const void* sums, double count, int training, void* dx, int dtype,
                               long long M, int d, void* stream);

@@ -106,7 +106,7 @@ SIGNATURES = {
     "mi355x_attn_delta": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "mi355x_relpos_flash_bwd_dq": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, f32, u32, u32, f32, vp],
     "mi355x_relpos_flash_bwd_dkv": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
-    "mi355x_relpos_flash_bwd_dpos": [vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i64, vp],
+    "mi355x_relpos_flash_bwd_dpos": [vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, i32, i32, i64, vp],
     "mi355x_relpos_ds_elems": [i32, i32, i32],
     "mi355x_relpos_dpos_partial_elems": [i32, i32, i32],
     "mi355x_dwconv_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp],
@@ -115,7 +115,8 @@ SIGNATURES = {
     "mi355x_bn_finalize_dev_count": [vp, vp, vp, vp, vp, vp, f32, f32, i32, vp],
     "mi355x_bn_eval_stats": [vp, vp, vp, vp, f32, i32, vp],
     "mi355x_bn_swish_fwd": [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
-    "mi355x_bn_swish_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, i64, vp],
+    "mi355x_bn_swish_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, i64, vp],
+    "mi355x_bn_stats_swish_fwd": [vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, i64, i32, vp],
     "mi355x_bn_swish_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, f64, i32, vp, i32, i64, i32, vp],
     "mi355x_bn_swish_bwd_apply_dev_count": [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp],
     "mi355x_bn_param_grad": [vp, vp, vp, i32, vp],

@@ -996,7 +996,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
 
 // stage 2: the 64 positions of block pair x (disjoint between pairs), summed over the utterance chunks z
 __global__ __launch_bounds__(256) void dpos_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dpos, long long ldd,
-                                                          int H, int T, int nz) {
+                                                          bf16_t* __restrict__ dpos_cast, int H, int T, int nz) {
   const int nT = (T + 31) / 32;
   const int x = blockIdx.x, h = blockIdx.y;
   const int P = 2 * T - 1;
@@ -1006,7 +1006,11 @@ __global__ __launch_bounds__(256) void dpos_reduce_kernel(const float* __restric
   if (c < 0 || c >= P) return;
   float acc = 0.f;
   for (int z = 0; z < nz; ++z) acc += partial[(((long long)z * nT + x) * H + h) * 4096 + e];
-  dpos[(long long)c * ldd + h * ADK + dk] += acc;
+  const float v = dpos[(long long)c * ldd + h * ADK + dk] + acc;
+  dpos[(long long)c * ldd + h * ADK + dk] = v;
+  // every (c, h, dk) of [0, 2T-1) x H x 64 is owned by exactly one thread of this launch, so the GEMM-operand copy of the
+  // gradient (the linear_pos weight gradient's input) can be written here instead of by a cast pass of its own
+  if (dpos_cast) dpos_cast[(long long)c * ldd + h * ADK + dk] = f2bf(v);
 }
 
 extern "C" int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, long long ldp, const void* bias_u,
@@ -1079,10 +1083,10 @@ extern "C" long long mi355x_relpos_dpos_partial_elems(int B, int H, int T) {
 }
 
 extern "C" int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len, void* dpos, long long ldd,
-                                            void* partial, long long partial_elems, int B, int H, int T, int dk,
+                                            void* dpos_cast, void* partial, long long partial_elems, int B, int H, int T, int dk,
                                             long long ds_elems, void* stream) {
   mi_clear_errors();
-  if (!qv || !ds || !len || !dpos || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
+  if (!qv || !ds || !len || !dpos || B <= 0 || H <= 0 || T <= 0 || (dpos_cast && !partial)) return MI_ERR_ARG;
   if (dk != ADK || ((uintptr_t)ds & 15) || ds_elems < mi355x_relpos_ds_elems(B, H, T)) return MI_ERR_ARG;
   const int nT = (T + 31) / 32;
   const int bchunk = B >= 8 ? 4 : 1;
@@ -1093,6 +1097,6 @@ extern "C" int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, cons
                      (const bf16_t*)ds, (const long long*)len, (float*)dpos, ldd, (float*)partial, B, H, T, H * ADK, bchunk);
   if (partial)
     MI_LAUNCH(dpos_reduce_kernel, dim3(nT, H, 16), dim3(256), 0, (hipStream_t)stream, (const float*)partial,
-                       (float*)dpos, ldd, H, T, nz);
+                       (float*)dpos, ldd, (bf16_t*)dpos_cast, H, T, nz);
   return mi_check_launch();
 }

@@ -232,6 +232,48 @@ __global__ __launch_bounds__(256) void bn_swish_fwd_kernel(const TT* __restrict_
     }
   }
 }
+// The same with the statistics finalised in the kernel (training forward): every thread derives mean / rstd of ITS channels from
+// the f64 sums (bn_finalize_kernel's arithmetic), workgroup 0 also writes them out for backward and updates the running
+// statistics -- one launch per layer instead of two.
+template <typename TT>
+__global__ __launch_bounds__(256) void bn_stats_swish_fwd_kernel(const TT* __restrict__ x, const double* __restrict__ stats,
+                                                                 double count, const double* __restrict__ count_dev,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 TT* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                 float momentum, float eps, long long M, int d) {
+  constexpr int V = VecIO<TT>::V;
+  const int CP = min(d / V, 256), RS = 256 / CP;
+  const int ck = threadIdx.x % CP, rsub = threadIdx.x / CP;
+  if (rsub >= RS) return;
+  if (count_dev) count = *count_dev;
+  for (int c = ck * V; c < d; c += CP * V) {
+    float mu[V], rs[V], g[V], bt[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const double m_ = stats[c + j] / count;
+      double var = stats[d + c + j] / count - m_ * m_;
+      if (var < 0.0) var = 0.0;
+      mu[j] = (float)m_; rs[j] = (float)(1.0 / sqrt(var + (double)eps));
+      g[j] = gamma[c + j]; bt[j] = beta[c + j];
+      if (blockIdx.x == 0 && rsub == 0) {
+        mean[c + j] = mu[j]; rstd[c + j] = rs[j];
+        if (running_mean) running_mean[c + j] = (1.f - momentum) * running_mean[c + j] + momentum * mu[j];
+        if (running_var) {
+          const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+          running_var[c + j] = (1.f - momentum) * running_var[c + j] + momentum * (float)unb;
+        }
+      }
+    }
+    for (long long m = (long long)blockIdx.x * RS + rsub; m < M; m += (long long)gridDim.x * RS) {
+      float v[V], o[V];
+      VecIO<TT>::load(x + m * d + c, v);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = swishf_(g[j] * (v[j] - mu[j]) * rs[j] + bt[j]);
+      VecIO<TT>::store(y + m * d + c, o);
+    }
+  }
+}
 #define BNR_ROWS 32  // rows per workgroup (501 workgroups at the Large shape; partial sums go through a scratch slab)
 template <typename TT>
 __global__ __launch_bounds__(256) void bn_swish_bwd_reduce_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
@@ -421,11 +463,45 @@ extern "C" int mi355x_bn_swish_fwd(const void* x, const void* mean, const void* 
                                          (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta, (TT*)y, M, d));
   return mi_check_launch();
 }
-extern "C" int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
-                                          const void* beta, void* sums, int dt, long long M, int d, void* scratch,
-                                          long long scratch_elems, void* stream) {
+extern "C" int mi355x_bn_stats_swish_fwd(const void* x, const void* stats, double count, const void* count_dev, const void* gamma,
+                                         const void* beta, void* y, void* mean, void* rstd, void* running_mean, void* running_var,
+                                         float momentum, float eps, int dt, long long M, int d, void* stream) {
   mi_clear_errors();
-  if (!dy || !x || !sums || M <= 0 || d <= 0) return MI_ERR_ARG;
+  if (!x || !stats || !mean || !rstd || !gamma || !beta || !y || M <= 0 || d <= 0 || d % (dt == MI_DT_BF16 ? 8 : 4) ||
+      (!count_dev && count <= 0))
+    return MI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(dt, TT, MI_LAUNCH((bn_stats_swish_fwd_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256), 0, s, (const TT*)x,
+                                (const double*)stats, count, (const double*)count_dev, (const float*)gamma, (const float*)beta,
+                                (TT*)y, (float*)mean, (float*)rstd, (float*)running_mean, (float*)running_var, momentum, eps, M, d));
+  return mi_check_launch();
+}
+// second stage of the BatchNorm-backward reduction: sums[i] (f64) += the slab column sums, and the parameter gradients (which
+// are exactly these LOCAL sums: dbeta = sums[0:d], dgamma = sums[d:2d]) in the same pass -- no separate bn_param_grad launch
+__global__ __launch_bounds__(256) void bn_partials_reduce_kernel(const float* __restrict__ partial, int nparts, int d,
+                                                                 double* __restrict__ sums, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = 2 * d;
+  if (i >= n) return;
+  const int per = (nparts + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = min(nparts, p0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int p = p0;
+  for (; p + 4 <= p1; p += 4) {
+    a0 += partial[(long long)(p + 0) * n + i]; a1 += partial[(long long)(p + 1) * n + i];
+    a2 += partial[(long long)(p + 2) * n + i]; a3 += partial[(long long)(p + 3) * n + i];
+  }
+  for (; p < p1; ++p) a0 += partial[(long long)p * n + i];
+  const float acc = (a0 + a1) + (a2 + a3);
+  atomicAdd(sums + i, (double)acc);
+  if (dbeta) atomicAdd(i < d ? dbeta + i : dgamma + (i - d), acc);
+}
+extern "C" int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,
+                                          const void* beta, void* sums, void* dgamma, void* dbeta, int dt, long long M, int d,
+                                          void* scratch, long long scratch_elems, void* stream) {
+  mi_clear_errors();
+  if (!dy || !x || !sums || M <= 0 || d <= 0 || (!dgamma != !dbeta)) return MI_ERR_ARG;
   const int V = dt == MI_DT_BF16 ? 8 : 4;
   if (d % V) return MI_ERR_ARG;
   const unsigned nblk = (unsigned)((M + BNR_ROWS - 1) / BNR_ROWS);
@@ -436,8 +512,10 @@ extern "C" int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const v
                                          (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta,
                                          (double*)sums, (float*)scratch, M, d));
   if (scratch)
-    MI_LAUNCH((partials_reduce_kernel<double>), dim3((2 * d + 255) / 256, 32), dim3(256), 0, s, (const float*)scratch,
-                       (int)nblk, 2 * d, (double*)sums);
+    MI_LAUNCH(bn_partials_reduce_kernel, dim3((2 * d + 255) / 256, 32), dim3(256), 0, s, (const float*)scratch, (int)nblk, d,
+              (double*)sums, (float*)dgamma, (float*)dbeta);
+  else if (dgamma)  // (single-stage path: the sums are complete only after the kernel above)
+    MI_LAUNCH(bn_param_grad_kernel, dim3((d + 255) / 256), dim3(256), 0, s, (const double*)sums, (float*)dgamma, (float*)dbeta, d);
   return mi_check_launch();
 }
 static int bn_swish_bwd_apply_launch(const void* dy, const void* x, const void* mean, const void* rstd, const void* gamma,

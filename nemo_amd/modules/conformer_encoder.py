@@ -1099,12 +1099,10 @@ class ConformerEncoder(NeuralModule):
                                     ds_out=dS)
             if side_pos:
                 with self._wgrad_scope(qv, dS):
-                    ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk)
-                    ops.drop_scale_cast(dp, dp_cast, P * dA, 1.0)
+                    ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk, dpos_cast=dp_cast)
             ops.relpos_flash_bwd_dkv(qu, qv, qkv, 3 * dA, p, dA, lens, dctx, lse, dlt, dqkv, 3 * dA, B, H, T, dk, Tp, scale, d_att)
             if not side_pos:
-                ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk)
-                ops.drop_scale_cast(dp, dp_cast, P * dA, 1.0)
+                ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk, dpos_cast=dp_cast)
             return dqkv, dqu, dqv
         # dpd[h,b] = dctx_bh @ v_bh^T  -> reuse the f32 score workspace
         dpd = self._buf("ac", (H, B, T, Tp), torch.float32, dev)
@@ -1176,12 +1174,15 @@ class ConformerEncoder(NeuralModule):
             if S.bn_world > 1:  # sums and count in one exchange; the global count stays on the device
                 self._sync_stats(stats[: 2 * d + 1])
                 count = stats[2 * d: 2 * d + 1]
-            ops.bn_finalize(stats, count, bmean, brstd, bn.running_mean, bn.running_var, bn.momentum, bn.eps, d)
         else:
             ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
             ops.bn_eval_stats(bn.running_mean, bn.running_var, bmean, brstd, bn.eps, d)
         z = self._new(M, d, dtype=cdt, device=dev)
-        ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, M, d)
+        if training:  # statistics finalised inside the kernel (mean / rstd for backward, running statistics)
+            ops.bn_stats_swish_fwd(cc, stats, count, bn.weight, bn.bias, z, bmean, brstd, bn.running_mean, bn.running_var,
+                                   bn.momentum, bn.eps, M, d)
+        else:
+            ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, M, d)
         r3 = self._new(M, d, dtype=torch.float32, device=dev)
         d_cres = drop(self.dropout, site + 4)
         ops.gemm(z, W[f"L{i}.conv.pw2"], r3, M, d, d, d, W.pitch(f"L{i}.conv.pw2"), d, bias=c.pointwise_conv2.bias,
@@ -1478,8 +1479,7 @@ class ConformerEncoder(NeuralModule):
         dz = self._new(M, d, dtype=cdt, device=dev)
         ops.gemm(db, W[f"L{i}.conv.pw2t"], dz, M, d, d, d, W.pitch(f"L{i}.conv.pw2t"), d)
         sums = S.bn_sums[i]
-        ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, M, d)
-        ops.bn_param_grad(sums, bn.weight.grad, bn.bias.grad, d)
+        ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, M, d, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
         if training and S.bn_world > 1:
             self._sync_stats(sums)
         dcc = self._new(M, d, dtype=cdt, device=dev)

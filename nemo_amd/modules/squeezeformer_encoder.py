@@ -472,12 +472,15 @@ class SqueezeformerEncoder(ConformerEncoder):
             if S.bn_world > 1:
                 self._sync_stats(stats[: 2 * C2 + 1])
                 count = stats[2 * C2: 2 * C2 + 1]
-            ops.bn_finalize(stats, count, bmean, brstd, bn.running_mean, bn.running_var, bn.momentum, bn.eps, C2)
         else:
             ops.dwconv_fwd(gact, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T, C2, k)
             ops.bn_eval_stats(bn.running_mean, bn.running_var, bmean, brstd, bn.eps, C2)
         z = self._new(M, C2, dtype=cdt, device=dev)
-        ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, M, C2)
+        if training:  # statistics finalised inside the kernel (mean / rstd for backward, running statistics)
+            ops.bn_stats_swish_fwd(cc, stats, count, bn.weight, bn.bias, z, bmean, brstd, bn.running_mean, bn.running_var,
+                                   bn.momentum, bn.eps, M, C2)
+        else:
+            ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, M, C2)
         r3 = self._new(M, d, dtype=torch.float32, device=dev)
         d_cres = drop(self.dropout, site + 6)
         ops.gemm(z, W[f"L{i}.conv.pw2"], r3, M, d, C2, C2, W.pitch(f"L{i}.conv.pw2"), d, bias=c.pointwise_conv2.bias,
@@ -537,8 +540,7 @@ class SqueezeformerEncoder(ConformerEncoder):
         dz = self._new(M, C2, dtype=cdt, device=dev)
         ops.gemm(db, W[f"L{i}.conv.pw2t"], dz, M, C2, d, dp, W.pitch(f"L{i}.conv.pw2t"), C2)
         sums = S.bn_sums[i]
-        ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, M, C2)
-        ops.bn_param_grad(sums, bn.weight.grad, bn.bias.grad, C2)
+        ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, M, C2, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
         if training and S.bn_world > 1:
             self._sync_stats(sums)
         dcc = self._new(M, C2, dtype=cdt, device=dev)

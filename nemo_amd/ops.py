@@ -430,15 +430,16 @@ def relpos_flash_bwd_dkv(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqkv,
 _DPOS_SCRATCH = {}
 
 
-def relpos_flash_bwd_dpos(qv, ds, lens, dpos, B, H, T, dk):
+def relpos_flash_bwd_dpos(qv, ds, lens, dpos, B, H, T, dk, dpos_cast=None):
+    """`dpos_cast` (bf16, shape of dpos): the GEMM-operand copy of the updated gradient, written by the reduction stage"""
     n = lib.mi355x_relpos_dpos_partial_elems(B, H, T)
     key = (str(dpos.device), n)
     scratch = _DPOS_SCRATCH.get(key)
     if scratch is None:
         _DPOS_SCRATCH.clear()
         scratch = _DPOS_SCRATCH[key] = torch.empty(n, dtype=torch.float32, device=dpos.device)
-    check(lib.mi355x_relpos_flash_bwd_dpos(_ptr(qv), _ptr(ds), _ptr(lens), _ptr(dpos), dpos.shape[-1], _ptr(scratch), n, B, H, T,
-                                           dk, ds.numel(), _stream()), "relpos_flash_bwd_dpos")
+    check(lib.mi355x_relpos_flash_bwd_dpos(_ptr(qv), _ptr(ds), _ptr(lens), _ptr(dpos), dpos.shape[-1], _ptr(dpos_cast),
+                                           _ptr(scratch), n, B, H, T, dk, ds.numel(), _stream()), "relpos_flash_bwd_dpos")
 
 
 # ------------------------------------------------------------------------------------------------ conv module
@@ -485,11 +486,20 @@ def bn_swish_fwd(x, mean, rstd, gamma, beta, y, M, d):
           "bn_swish_fwd")
 
 
-def bn_swish_bwd_reduce(dy, x, mean, rstd, gamma, beta, sums, M, d):
+def bn_swish_bwd_reduce(dy, x, mean, rstd, gamma, beta, sums, M, d, dgamma=None, dbeta=None):
+    """sums f64 [2, d] += (sum dz, sum dz * xhat); dgamma / dbeta (optional): the parameter gradients in the same launches"""
     n = ((M + 31) // 32) * 2 * d
     sc = _scratch("bn_swish_bwd_reduce", n, dy.device)
-    check(lib.mi355x_bn_swish_bwd_reduce(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums), dt(x),
-                                         M, d, _ptr(sc), n, _stream()), "bn_swish_bwd_reduce")
+    check(lib.mi355x_bn_swish_bwd_reduce(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums),
+                                         _ptr(dgamma), _ptr(dbeta), dt(x), M, d, _ptr(sc), n, _stream()), "bn_swish_bwd_reduce")
+
+
+def bn_stats_swish_fwd(x, stats, count, gamma, beta, y, mean, rstd, running_mean, running_var, momentum, eps, M, d):
+    """training forward: bn_finalize + bn_swish_fwd in one launch; `count`: python number or device f64 scalar tensor"""
+    dev_count = count if isinstance(count, torch.Tensor) else None
+    check(lib.mi355x_bn_stats_swish_fwd(_ptr(x), _ptr(stats), 0.0 if dev_count is not None else float(count), _ptr(dev_count),
+                                        _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(running_mean),
+                                        _ptr(running_var), momentum, eps, dt(x), M, d, _stream()), "bn_stats_swish_fwd")
 
 
 def bn_swish_bwd_apply(dy, x, mean, rstd, gamma, beta, sums, count, training, dx, M, d):

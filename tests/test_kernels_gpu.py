@@ -468,9 +468,12 @@ def test_relpos_flash_attention_bwd(T):
         assert rel_err(dqkv[:, 2 * d:], ref["dv"]) < 8e-3, rel_err(dqkv[:, 2 * d:], ref["dv"])
     if hasattr(o, "relpos_flash_bwd_dpos"):
         dp = torch.zeros(2 * T - 1, d, device=dev)
-        o.relpos_flash_bwd_dpos(qv, dS, lens_d, dp, B, H, T, dk)
+        dp_c = torch.full((2 * T - 1, d), float("nan"), device=dev, dtype=torch.bfloat16)
+        o.relpos_flash_bwd_dpos(qv, dS, lens_d, dp, B, H, T, dk, dpos_cast=dp_c)
         torch.cuda.synchronize()
         assert rel_err(dp, ref["dp"]) < 8e-3, rel_err(dp, ref["dp"])
+        # the reduction stage also writes the GEMM-operand copy: every element, the bf16 rounding of the f32 result
+        assert torch.equal(dp_c, dp.to(torch.bfloat16))
 
 
 def test_relpos_flash_attention_dropout_consistency():
@@ -573,13 +576,27 @@ def test_dwconv_bn_swish(dtype):
     y = torch.empty(Bn, T, d, device=dev, dtype=dtype)
     o.bn_swish_fwd(c, mu, rs, gamma.to(dev), beta.to(dev), y, n, d)
     assert rel_err(y, y_ref) < 2 * tol
+    # the one-launch training forward (statistics finalised in the kernel) = the two launches above, bit for bit
+    mu2 = torch.empty(d, device=dev); rs2 = torch.empty(d, device=dev)
+    rm2 = torch.zeros(d, device=dev); rv2 = torch.ones(d, device=dev)
+    y2 = torch.empty(Bn, T, d, device=dev, dtype=dtype)
+    o.bn_stats_swish_fwd(c, stats, n, gamma.to(dev), beta.to(dev), y2, mu2, rs2, rm2, rv2, 0.1, 1e-5, n, d)
+    cnt = torch.tensor([float(n)], device=dev, dtype=torch.float64)
+    y3 = torch.empty_like(y2)
+    o.bn_stats_swish_fwd(c, stats, cnt, gamma.to(dev), beta.to(dev), y3, mu2.clone(), rs2.clone(), None, None, 0.1, 1e-5, n, d)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y) and torch.equal(y3, y) and torch.equal(mu2, mu) and torch.equal(rs2, rs)
+    assert torch.equal(rm2, rm) and torch.equal(rv2, rv)
     sums = torch.zeros(2, d, device=dev, dtype=torch.float64)
-    o.bn_swish_bwd_reduce(dy.to(dev), c, mu, rs, gamma.to(dev), beta.to(dev), sums, n, d)
+    dgam2 = torch.zeros(d, device=dev); dbet2 = torch.zeros(d, device=dev)
+    o.bn_swish_bwd_reduce(dy.to(dev), c, mu, rs, gamma.to(dev), beta.to(dev), sums, n, d, dgamma=dgam2, dbeta=dbet2)
     dc = torch.empty(Bn, T, d, device=dev, dtype=dtype)
     o.bn_swish_bwd_apply(dy.to(dev), c, mu, rs, gamma.to(dev), beta.to(dev), sums, n, True, dc, n, d)
     dgam = torch.zeros(d, device=dev); dbet = torch.zeros(d, device=dev)
     o.bn_param_grad(sums, dgam, dbet, d)
     assert rel_err(dgam, gr.grad) < 5 * tol and rel_err(dbet, ber.grad) < 5 * tol
+    # ... and the parameter gradients accumulated by the reduction's second stage
+    assert rel_err(dgam2, dgam) < 1e-5 and rel_err(dbet2, dbet) < 1e-5 + 1e-5 / max(dbet.abs().max().item(), 1e-6)
     dx = torch.empty(Bn, T, d, device=dev, dtype=dtype)
     dw = torch.zeros(d, 1, k, device=dev); dbias = torch.zeros(d, device=dev)
     o.dwconv_bwd(dc, xd, w.to(dev), dx, dw, dbias, Bn, T, d, k)

@@ -23,11 +23,18 @@ pmc() {  # name, counters
   [ -n "$db" ] && python tools/pmc_dump.py $db $O/$n.pmc.json
   rm -rf $O/$n
 }
+PARTS=${R3_PARTS:-"stats pmc models"}   # e.g. R3_PARTS=stats: only the two kernel-trace runs of the headline bench
+case " $PARTS " in *" stats "*)
 stats stats_s4 --steps 4 --warmup 2 --no-cpu-baseline --no-roofline
 stats stats_s12 --steps 12 --warmup 2 --no-cpu-baseline --no-roofline
+;; esac
+case " $PARTS " in *" pmc "*)
 pmc pmc_fetch FETCH_SIZE
 pmc pmc_write WRITE_SIZE
 pmc pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
+;; esac
+case " $PARTS " in *" models "*)
 stats stats_transducer --model transducer --steps 3 --warmup 2 --no-roofline
 stats stats_squeezeformer --model squeezeformer --size medium --steps 3 --warmup 2 --no-roofline
+;; esac
 ls -la $O
