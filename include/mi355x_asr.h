@@ -175,6 +175,11 @@ int mi355x_time_recover_bwd(const void* dx, void* dys, int dys_dtype, int B, int
 /* ---- LayerNorm (torch.nn.LayerNorm x5 per layer, conformer_modules.py:174-215) -------------------------------- */
 int mi355x_layernorm_fwd(const void* x, int x_dtype, const void* gamma, const void* beta, void* y, int y_dtype, void* mean,
                          void* rstd, int M, int d, float eps, void* stream);
+/* y1 = LN(x; gamma1, beta1) in f32 and y2 = LN(y1; gamma2, beta2) in y2_dtype in one pass (d = 512, 32-byte aligned pointers):
+ * a ConformerLayer's norm_out followed by the next layer's norm_feed_forward1 (conformer_modules.py:205-231, :174-178) */
+int mi355x_layernorm2_fwd(const void* x, const void* gamma1, const void* beta1, void* y1, void* mean1, void* rstd1,
+                          const void* gamma2, const void* beta2, void* y2, int y2_dtype, void* mean2, void* rstd2, int M, int d,
+                          float eps, void* stream);
 /* dres (f32 [M,d]) = (accumulate ? dres : 0) + dLN/dx ; dgamma/dbeta (f32 [d], may be NULL) are accumulated (+=)   */
 int mi355x_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const void* gamma, const void* mean,
                          const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d, void* stream);
@@ -233,14 +238,22 @@ int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, lon
 /* backward of the fused attention.  delta[b,h,i] = sum_dv dO*(O + O_lo) (O_lo optional, see above).  dq kernel: qu = q+u, qv = q+v ([B*T,d] bf16, from
  * mi355x_qbias), recomputes P from lse, returns dQu and dQv ([B*T,d] bf16; dq = dQu+dQv, d pos_bias_{u,v} = column sums). */
 int mi355x_attn_delta(const void* dO, const void* O, const void* O_lo, void* delta, int B, int H, int T, int d, void* stream);
+/* mi355x_attn_delta and mi355x_qbias (q = the first d columns of qkv rows of pitch ldq) in ONE pass over the rows: everything the
+ * fused backward kernels need in front of them.  All pointers 16-byte aligned, ldq % 8 == 0. */
+int mi355x_attn_bwd_prep(const void* dO, const void* O, const void* O_lo, void* delta, const void* qkv, long long ldq,
+                         const void* bias_u, const void* bias_v, void* qu, void* qv, int B, int H, int T, int d, void* stream);
 /* ds_out (optional): the score gradient in the layout of the reference's matrix_bd BEFORE rel_shift
  * (multi_head_attention.py:259-270), cut into 32 x 32 bf16 blocks for mi355x_relpos_flash_bwd_dpos:
  * X[h][b][it][s][q][cl] = dS[b,h, i = 32*it+q, j] at position c = T-1+j-i = T-32+32*(s-it)+cl, it < ceil(T/32), s <= ceil(T/32);
- * slots s <= ceil(len[b]/32) are written.  ds_elems = capacity of ds_out in elements, >= mi355x_relpos_ds_elems(B,H,T). */
+ * slots s <= ceil(len[b]/32) are written.  ds_elems = capacity of ds_out in elements, >= mi355x_relpos_ds_elems(B,H,T).
+ * Outputs: dqu / dqv separately (both non-NULL), and / or dq_out = dQu + dQv as bf16 rows of pitch ld_dq (the q third of the
+ * fused projection's [M, 3d] gradient) with bias_grads f32 [2 * H * 64] += column sums of dQu | dQv (d pos_bias_u | d pos_bias_v)
+ * through cs_scratch, f32 [B * ceil(T / 128) * 2 * H * 64] (per-workgroup sums, added by a second-stage reduction launch). */
 long long mi355x_relpos_ds_elems(int B, int H, int T);
 int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos, long long ldp,
                                const void* len, const void* dO, const void* lse, const void* delta, void* dqu, void* dqv,
-                               void* ds_out, int B, int H, int T, int dk, long long ds_elems, float scale,
+                               void* ds_out, void* dq_out, long long ld_dq, void* bias_grads, void* cs_scratch,
+                               long long cs_scratch_elems, int B, int H, int T, int dk, long long ds_elems, float scale,
                                unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream);
 
 /* dK and dV rows written into the k / v column blocks of dqkv [B*T, ldd = 3d] */

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mi355x_joint_combine_bwd": [vp, vp, vp, i32, f32, i32, i32, i32, i32, vp],
     "mi355x_cast_rows": [vp, i64, vp, i32, i64, i64, i32, i32, f32, vp],
     "mi355x_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp],
+    "mi355x_layernorm2_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp],
     "mi355x_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp],
     "mi355x_layernorm_bwd_cast": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, f32, u32, u32, f32, vp],
     "mi355x_colsum": [vp, i32, i64, vp, i32, i32, f32, vp],
@@ -104,7 +105,9 @@ SIGNATURES = {
     "mi355x_relpos_softmax_bwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_relpos_flash_fwd": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_attn_delta": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
-    "mi355x_relpos_flash_bwd_dq": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, f32, u32, u32, f32, vp],
+    "mi355x_attn_bwd_prep": [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mi355x_relpos_flash_bwd_dq": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, i32, i32, i64,
+                                   f32, u32, u32, f32, vp],
     "mi355x_relpos_flash_bwd_dkv": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_relpos_flash_bwd_dpos": [vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, i32, i32, i64, vp],
     "mi355x_relpos_ds_elems": [i32, i32, i32],

@@ -365,8 +365,14 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
 // =================================================================================================
 // delta[b,h,i] = sum_dv dO[i,h,dv] * (O + O_lo)[i,h,dv]   (one wave per row of [M, d]; 8 lanes per head at d_k = 64);
 // O_lo (optional) = the rounding residual of O written by the forward kernel
+// QB: the same pass also writes qu = q + pos_bias_u and qv = q + pos_bias_v (rows of the fused projection, multi_head_attention.py:
+// 288-291), the operands the two backward kernels stage by LDS-DMA -- one launch instead of two in front of every layer's dQ kernel
+template <bool QB>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
-                                                         const bf16_t* __restrict__ O_lo, float* __restrict__ delta, int B,
+                                                         const bf16_t* __restrict__ O_lo, float* __restrict__ delta,
+                                                         const bf16_t* __restrict__ qkv, long long ldq,
+                                                         const float* __restrict__ bias_u, const float* __restrict__ bias_v,
+                                                         bf16_t* __restrict__ qu, bf16_t* __restrict__ qv, int B,
                                                          int H, int T, int d) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
@@ -375,6 +381,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   for (int c0 = 0; c0 < d; c0 += 512) {
     const int c = c0 + lane * 8;
     float acc = 0.f;
+    if (QB && c < d) {
+      float q8[8], u8[8], v8[8], o1[8], o2[8];
+      VecIO<bf16_t>::load(qkv + row * ldq + c, q8);
+      VecIO<float>::load(bias_u + c, u8); VecIO<float>::load(bias_u + c + 4, &u8[4]);
+      VecIO<float>::load(bias_v + c, v8); VecIO<float>::load(bias_v + c + 4, &v8[4]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { o1[j] = q8[j] + u8[j]; o2[j] = q8[j] + v8[j]; }
+      VecIO<bf16_t>::store(qu + row * d + c, o1);
+      VecIO<bf16_t>::store(qv + row * d + c, o2);
+    }
     if (c < d) {
       const u32x4 a = *reinterpret_cast<const u32x4*>(dO + row * d + c);
       const u32x4 o = *reinterpret_cast<const u32x4*>(O + row * d + c);
@@ -427,8 +443,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     const bf16_t* __restrict__ qu_g, const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ qkv, long long ldq,
     const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqu_out,
-    bf16_t* __restrict__ dqv_out, bf16_t* __restrict__ ds_out, int B, int H, int T, int d, float scale,
-    DropCfg drop) {
+    bf16_t* __restrict__ dqv_out, bf16_t* __restrict__ ds_out, bf16_t* __restrict__ dq_out, long long ld_dq,
+    float* __restrict__ cs_partial, int B, int H, int T, int d, float scale, DropCfg drop) {
   drop_resolve(drop);
   __shared__ __attribute__((aligned(16))) bf16_t s_k2[2][ABK * ADK];       // double-buffered (read until the end of a step)
   __shared__ __attribute__((aligned(16))) bf16_t s_v[ABK * ADK];           // read in the first MFMA block only
@@ -620,8 +636,14 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
       *reinterpret_cast<u32x4*>(xbase + (long long)nkt * 1024 + it2 * 512 + lane * 8) = carry[it2 * 64 + lane];
   }
 
-  // ---- write dQu, dQv rows (transpose through the wave-private LDS tile)
+  // ---- write dQu, dQv rows (transpose through the wave-private LDS tile).  With dq_out the sum dQ = dQu + dQv goes straight into
+  // the q third of the [M, 3d] gradient of the fused projection and the column sums of dQu / dQv over this workgroup's rows
+  // (d pos_bias_u / d pos_bias_v, multi_head_attention.py:296-300 backward) into row (b, query block) of `cs_partial`
+  // [B * gridDim.x][2 * d] -- a second-stage reduction adds the rows; the separate add + column-sum pass does not exist then.
   __syncthreads();
+  float keep[4][8], cs[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { cs[0][j] = 0.f; cs[1][j] = 0.f; }
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     bf16_t* outp = pass == 0 ? dqu_out : dqv_out;
@@ -639,11 +661,49 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = sg[row * SG_LD + c8 + j];
-        u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-        *reinterpret_cast<u32x4*>(outp + ((long long)b * T + ii) * d + h * ADK + c8) = t;
+        if (outp) {
+          u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+          *reinterpret_cast<u32x4*>(outp + ((long long)b * T + ii) * d + h * ADK + c8) = t;
+        }
+        if (dq_out) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cs[pass][j] += v[j];
+          if (pass == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) keep[it][j] = v[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += keep[it][j];
+            u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+            *reinterpret_cast<u32x4*>(dq_out + ((long long)b * T + ii) * ld_dq + h * ADK + c8) = t;
+          }
+        }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if (dq_out && cs_partial) {
+    // rows of a wave: lanes with equal (lane & 7) hold the same 8 columns -> butterfly over lane bits 3..5, then the four waves
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = cs[pass][j];
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        cs[pass][j] = v;
+      }
+    if (lane < 8) {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sg[pass * 64 + lane * 8 + j] = cs[pass][j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int uv = threadIdx.x >> 6, c = threadIdx.x & 63;
+      const float t = (s_g[0][threadIdx.x] + s_g[1][threadIdx.x]) + (s_g[2][threadIdx.x] + s_g[3][threadIdx.x]);
+      cs_partial[((long long)b * gridDim.x + blockIdx.x) * (2 * d) + uv * d + h * ADK + c] = t;
+    }
   }
 }
 
@@ -1035,24 +1095,50 @@ extern "C" int mi355x_attn_delta(const void* dO, const void* O, const void* O_lo
   mi_clear_errors();
   if (!dO || !O || !delta || B <= 0 || H <= 0 || T <= 0 || d != H * ADK) return MI_ERR_ARG;
   const long long rows = (long long)B * T;
-  MI_LAUNCH(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)O_lo, (float*)delta, B, H, T, d);
+  MI_LAUNCH(attn_delta_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)O_lo, (float*)delta, (const bf16_t*)nullptr, 0LL,
+                     (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, (bf16_t*)nullptr, B, H, T, d);
+  return mi_check_launch();
+}
+extern "C" int mi355x_attn_bwd_prep(const void* dO, const void* O, const void* O_lo, void* delta, const void* qkv, long long ldq,
+                                    const void* bias_u, const void* bias_v, void* qu, void* qv, int B, int H, int T, int d,
+                                    void* stream) {
+  mi_clear_errors();
+  if (!dO || !O || !delta || !qkv || !bias_u || !bias_v || !qu || !qv || B <= 0 || H <= 0 || T <= 0 || d != H * ADK || (ldq & 7))
+    return MI_ERR_ARG;
+  if (((uintptr_t)qkv | (uintptr_t)qu | (uintptr_t)qv | (uintptr_t)bias_u | (uintptr_t)bias_v) & 15) return MI_ERR_ARG;
+  const long long rows = (long long)B * T;
+  MI_LAUNCH(attn_delta_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)O_lo, (float*)delta, (const bf16_t*)qkv, ldq,
+                     (const float*)bias_u, (const float*)bias_v, (bf16_t*)qu, (bf16_t*)qv, B, H, T, d);
   return mi_check_launch();
 }
 
 extern "C" int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos,
                                           long long ldp, const void* len, const void* dO, const void* lse, const void* delta,
-                                          void* dqu, void* dqv, void* ds_out, int B, int H, int T, int dk, long long ds_elems,
-                                          float scale, unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
+                                          void* dqu, void* dqv, void* ds_out, void* dq_out, long long ld_dq, void* bias_grads,
+                                          void* cs_scratch, long long cs_scratch_elems, int B, int H, int T, int dk,
+                                          long long ds_elems, float scale, unsigned drop_key, unsigned drop_threshold,
+                                          float drop_scale, void* stream) {
   mi_clear_errors();
-  if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || !dqu || !dqv || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
+  if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
   if (dk != ADK || (ldq % 24) || (ldp & 7)) return MI_ERR_ARG;
+  // either the two gradients separately (dqu, dqv) or their sum (dq_out, row pitch ld_dq) with the bias gradients
+  // (bias_grads f32 [2 * H * 64] += column sums of dQu | dQv, via cs_scratch: f32 [B * ceil(T / 128) * 2 * H * 64])
+  if (!dq_out && (!dqu || !dqv)) return MI_ERR_ARG;
+  const long long cs_need = (long long)B * ((T + ABQ - 1) / ABQ) * 2 * H * ADK;
+  if (dq_out && ((ld_dq & 7) || ((uintptr_t)dq_out & 15) || (bias_grads && (!cs_scratch || cs_scratch_elems < cs_need))))
+    return MI_ERR_ARG;
   if (ds_out && (((uintptr_t)ds_out & 15) || ds_elems < mi355x_relpos_ds_elems(B, H, T))) return MI_ERR_ARG;
   DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   dim3 grid((T + ABQ - 1) / ABQ, H, B);
   MI_LAUNCH(relpos_flash_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu, (const bf16_t*)qv,
                      (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len, (const bf16_t*)dO,
-                     (const float*)lse, (const float*)delta, (bf16_t*)dqu, (bf16_t*)dqv, (bf16_t*)ds_out, B, H, T, H * ADK, scale, dc);
+                     (const float*)lse, (const float*)delta, (bf16_t*)dqu, (bf16_t*)dqv, (bf16_t*)ds_out, (bf16_t*)dq_out, ld_dq,
+                     bias_grads ? (float*)cs_scratch : nullptr, B, H, T, H * ADK, scale, dc);
+  if (dq_out && bias_grads)
+    MI_LAUNCH((partials_reduce_kernel<float>), dim3((2 * H * ADK + 255) / 256, 8), dim3(256), 0, (hipStream_t)stream,
+              (const float*)cs_scratch, (int)(B * ((T + ABQ - 1) / ABQ)), 2 * H * ADK, (float*)bias_grads);
   return mi_check_launch();
 }
 

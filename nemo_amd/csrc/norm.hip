@@ -318,6 +318,62 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const TX* __restrict__ 
   if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
 }
 
+// Two LayerNorms in a row over register-resident rows (d = 512): y1 = LN1(x) in f32 (a layer's norm_out: the next layer's
+// residual stream) and y2 = LN2(y1) in the compute dtype (the next layer's norm_feed_forward1: its first GEMM operand) -- the
+// block boundary of conformer_modules.py:205-231 without re-reading y1.  Both (mean, rstd) pairs are kept for backward.
+template <typename TY2>
+__global__ __launch_bounds__(256) void ln2_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma1,
+                                                          const float* __restrict__ beta1, float* __restrict__ y1,
+                                                          float* __restrict__ mean1, float* __restrict__ rstd1,
+                                                          const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                          TY2* __restrict__ y2, float* __restrict__ mean2,
+                                                          float* __restrict__ rstd2, int M, float eps) {
+  constexpr int d = 512;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float v[8], g[8], b[8], o[8];
+  ld8g(x + (long long)row * d + lane * 8, v);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += v[j];
+  const float mu = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float t = v[j] - mu; q += t * t; }
+  const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
+  ld8g(gamma1 + lane * 8, g); ld8g(beta1 + lane * 8, b);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (v[j] - mu) * rs * g[j] + b[j];
+  st8g(y1 + (long long)row * d + lane * 8, o);
+  s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += o[j];
+  const float mu2 = wave_sum(s) / (float)d;
+  q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float t = o[j] - mu2; q += t * t; }
+  const float rs2 = rsqrtf(wave_sum(q) / (float)d + eps);
+  ld8g(gamma2 + lane * 8, g); ld8g(beta2 + lane * 8, b);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (o[j] - mu2) * rs2 * g[j] + b[j];
+  st8g(y2 + (long long)row * d + lane * 8, v);
+  if (lane == 0) { mean1[row] = mu; rstd1[row] = rs; mean2[row] = mu2; rstd2[row] = rs2; }
+}
+extern "C" int mi355x_layernorm2_fwd(const void* x, const void* gamma1, const void* beta1, void* y1, void* mean1, void* rstd1,
+                                     const void* gamma2, const void* beta2, void* y2, int y2_dt, void* mean2, void* rstd2, int M,
+                                     int d, float eps, void* stream) {
+  mi_clear_errors();
+  if (!x || !gamma1 || !beta1 || !y1 || !mean1 || !rstd1 || !gamma2 || !beta2 || !y2 || !mean2 || !rstd2 || M <= 0) return MI_ERR_ARG;
+  if (d != 512) return MI_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)y1 | (uintptr_t)y2 | (uintptr_t)gamma1 | (uintptr_t)beta1 | (uintptr_t)gamma2 | (uintptr_t)beta2) & 31)
+    return MI_ERR_ARG;
+  DISPATCH_DT(y2_dt, TY2, MI_LAUNCH((ln2_fwd_reg_kernel<TY2>), dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                                    (const float*)gamma1, (const float*)beta1, (float*)y1, (float*)mean1, (float*)rstd1,
+                                    (const float*)gamma2, (const float*)beta2, (TY2*)y2, (float*)mean2, (float*)rstd2, M, eps));
+  return mi_check_launch();
+}
+
 extern "C" int mi355x_layernorm_fwd(const void* x, int x_dt, const void* gamma, const void* beta, void* y, int y_dt,
                                     void* mean, void* rstd, int M, int d, float eps, void* stream) {
   mi_clear_errors();

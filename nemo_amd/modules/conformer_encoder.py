@@ -262,6 +262,8 @@ class ConformerEncoder(NeuralModule):
         self._syncbn_group = None
         self.syncbn_profile = None  # a list while bench.py measures the exposed time of the statistics exchanges
         self.use_flash_attention = True  # bf16 + d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
+        # one launch for a layer's norm_out and the next layer's norm_feed_forward1 (d = 512; MI355X_LN2=0: two launches)
+        self.fuse_layer_boundary_norms = os.environ.get("MI355X_LN2", "1") != "0"
         self.flash_delta_residual = os.environ.get("MI355X_FLASH_DELTA_LO", "1") != "0"  # (A/B switch of the delta fix)
         self.grad_ready_hook = None  # callable(start, end) on the flat gradient buffer (data-parallel bucketing)
         # linear_pos weights of all layers sit together at the tail: their gradients come from ONE batched GEMM
@@ -959,7 +961,12 @@ class ConformerEncoder(NeuralModule):
         return y, mean, rstd
 
     def _ffn_fwd(self, pfx, ff, x, ln, S, sl, W, drop, site, M, d, dff, cdt, dev, tag):
-        y, mean, rstd = self._ln_fwd(ln, x, M, d, cdt, dev)
+        pre = getattr(S, "pre_ln", None)
+        if pre is not None and tag == "ff1":  # the previous layer's output norm already normalised this layer's input
+            y, mean, rstd = pre
+            S.pre_ln = None
+        else:
+            y, mean, rstd = self._ln_fwd(ln, x, M, d, cdt, dev)
         h = self._new(M, dff, dtype=cdt, device=dev)
         a = self._new(M, dff, dtype=cdt, device=dev)
         d_in = drop(self.dropout, site)
@@ -1072,23 +1079,30 @@ class ConformerEncoder(NeuralModule):
                  sB=(T * 3 * dA, dk), sC=(T * dA, dk), b_off=2 * dA)
         return ctx, (qu, qv, s_, pd, None)
 
-    def _attn_bwd(self, saved, qkv, p, bias_u, bias_v, ctx, dctx, lens, B, T, dA, dk, scale, d_att, cdt, dev, dp, dp_cast):
+    def _attn_bwd(self, saved, qkv, p, bias_u, bias_v, ctx, dctx, lens, B, T, dA, dk, scale, d_att, cdt, dev, dp, dp_cast,
+                  bias_grads=None):
         """-> (dqkv [M, 3*dA] with the k and v thirds filled, dqu, dqv [M, dA]); dp f32 [2T-1, dA] += d linear_pos output,
-        dp_cast (compute dtype) = its GEMM-operand copy for the linear_pos weight gradient."""
+        dp_cast (compute dtype) = its GEMM-operand copy for the linear_pos weight gradient.  `bias_grads` (fused path only):
+        f32 [2 * dA] = pos_bias_u.grad | pos_bias_v.grad in one piece -- then the dQ kernel writes dq = dqu + dqv into the q third
+        of dqkv and the bias gradients itself, and (dqkv, None, None) comes back."""
         qu, qv, s_, pd, lse = saved
         H = self.n_heads
         M, P = B * T, 2 * T - 1
         Tp, Pp = _pad8(T), _pad8(P)
         dqkv = self._new(M, 3 * dA, dtype=cdt, device=dev)
-        dqu = self._new(M, dA, dtype=cdt, device=dev)
-        dqv = self._new(M, dA, dtype=cdt, device=dev)
+        fuse_dq = lse is not None and bias_grads is not None
+        dqu = None if fuse_dq else self._new(M, dA, dtype=cdt, device=dev)
+        dqv = None if fuse_dq else self._new(M, dA, dtype=cdt, device=dev)
         if lse is not None:
             ctx_lo = qu  # (fused path: the first slot carries the context's rounding residual, q + u is recomputed here)
             qu = self._new(M, dA, dtype=cdt, device=dev)
             qv = self._new(M, dA, dtype=cdt, device=dev)
-            ops.qbias(qkv, 3 * dA, bias_u, bias_v, qu, qv, M, dA)
             dlt = self._new(B, H, T, dtype=torch.float32, device=dev)
-            ops.attn_delta(dctx, ctx, dlt, B, H, T, dA, O_lo=ctx_lo)
+            if (bias_u.data_ptr() | bias_v.data_ptr()) & 15:
+                ops.qbias(qkv, 3 * dA, bias_u, bias_v, qu, qv, M, dA)
+                ops.attn_delta(dctx, ctx, dlt, B, H, T, dA, O_lo=ctx_lo)
+            else:  # q + u, q + v and delta = sum dO * O in one pass over the rows
+                ops.attn_bwd_prep(dctx, ctx, dlt, qkv, 3 * dA, bias_u, bias_v, qu, qv, B, H, T, dA, O_lo=ctx_lo)
             # transient dS (un-shifted 32 x 32 blocks): dQ kernel -> linear_pos gradient kernel.  The latter feeds only the
             # (batched, end-of-backward) linear_pos weight gradient, so with the side stream it leaves the critical path; dS
             # then comes from the caching allocator (record_stream keeps the next layer's dQ kernel from overwriting it too early).
@@ -1096,7 +1110,7 @@ class ConformerEncoder(NeuralModule):
             n_ds = ops.lib.mi355x_relpos_ds_elems(B, H, T)
             dS = (self._new(n_ds, dtype=cdt, device=dev) if side_pos else self._buf("dS", (n_ds,), cdt, dev))
             ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * dA, p, dA, lens, dctx, lse, dlt, dqu, dqv, B, H, T, dk, scale, d_att,
-                                    ds_out=dS)
+                                    ds_out=dS, dq_out=dqkv if fuse_dq else None, ld_dq=3 * dA, bias_grads=bias_grads)
             if side_pos:
                 with self._wgrad_scope(qv, dS):
                     ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk, dpos_cast=dp_cast)
@@ -1190,7 +1204,17 @@ class ConformerEncoder(NeuralModule):
         sl.conv = (r2, y3, mean3, rstd3, pw1, g, cc, bmean, brstd, count, z, d_cres)
         # ---- macaron FFN 2 + output norm
         r4 = self._ffn_fwd(f"L{i}.ff2", L.feed_forward2, r3, L.norm_feed_forward2, S, sl, W, drop, site + 5, M, d, dff, cdt, dev, "ff2")
-        xo, mean5, rstd5 = self._ln_fwd(L.norm_out, r4, M, d, torch.float32, dev)
+        nxt = self.layers[i + 1] if i + 1 < self.n_layers else None
+        if nxt is not None and d == 512 and self.fuse_layer_boundary_norms:
+            # norm_out of this layer and norm_feed_forward1 of the next one in one pass over the rows (mi355x_layernorm2_fwd)
+            ln1, ln2 = L.norm_out, nxt.norm_feed_forward1
+            xo = self._new(M, d, dtype=torch.float32, device=dev)
+            yn = self._new(M, d, dtype=cdt, device=dev)
+            mean5, rstd5, mean_n, rstd_n = (self._new(M, dtype=torch.float32, device=dev) for _ in range(4))
+            ops.layernorm2_fwd(r4, ln1.weight, ln1.bias, xo, mean5, rstd5, ln2.weight, ln2.bias, yn, mean_n, rstd_n, M, d, ln1.eps)
+            S.pre_ln = (yn, mean_n, rstd_n)
+        else:
+            xo, mean5, rstd5 = self._ln_fwd(L.norm_out, r4, M, d, torch.float32, dev)
         sl.out = (r4, mean5, rstd5)
         return xo, sl
 
@@ -1377,10 +1401,14 @@ class ConformerEncoder(NeuralModule):
         self._wgrad(dao, d, 0, ctx, d, 0, a.linear_out.weight.grad, d, d, M, bias_grad=a.linear_out.bias.grad)
         dctx = self._new(M, d, dtype=cdt, device=dev)
         ops.gemm(dao, W[f"L{i}.att.wot"], dctx, M, d, d, d, W.pitch(f"L{i}.att.wot"), d)
-        dqkv, dqu, dqv = self._attn_bwd((qu, qv, s_, pd, lse), qkv, p, a.pos_bias_u, a.pos_bias_v, ctx, dctx, S.len2, B, T2, d,
-                                        dk, scale, d_att, cdt, dev, S.dpos_f32[i], S.dp_all[i])
         gu, gv_ = a.pos_bias_u.grad, a.pos_bias_v.grad
-        if cdt == torch.bfloat16 and gv_.data_ptr() - gu.data_ptr() == 4 * d:
+        adjacent = gv_.data_ptr() - gu.data_ptr() == 4 * d  # (the two bias gradients as one [2 * d] piece of the flat buffer)
+        dqkv, dqu, dqv = self._attn_bwd((qu, qv, s_, pd, lse), qkv, p, a.pos_bias_u, a.pos_bias_v, ctx, dctx, S.len2, B, T2, d,
+                                        dk, scale, d_att, cdt, dev, S.dpos_f32[i], S.dp_all[i],
+                                        bias_grads=gu if (adjacent and lse is not None) else None)
+        if dqu is None:
+            pass  # fused attention: dq and both bias gradients came out of the dQ kernel
+        elif cdt == torch.bfloat16 and adjacent:
             ops.add2_colsum(dqu, dqv, dqkv, 3 * d, M, d, gu)  # dq = dqu + dqv and both bias gradients in one pass
         else:
             ops.colsum(dqu, gu, M, d)

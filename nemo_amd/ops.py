@@ -258,6 +258,12 @@ def cast_rows(src, ld_in, dst, ld_out, M, N, Np, alpha=1.0):
 
 
 # ------------------------------------------------------------------------------------------------ norms / reductions
+def layernorm2_fwd(x, gamma1, beta1, y1, mean1, rstd1, gamma2, beta2, y2, mean2, rstd2, M, d, eps=1e-5):
+    """y1 = LN1(x) (f32), y2 = LN2(y1) (dtype of y2) in one launch; d = 512"""
+    check(lib.mi355x_layernorm2_fwd(_ptr(x), _ptr(gamma1), _ptr(beta1), _ptr(y1), _ptr(mean1), _ptr(rstd1), _ptr(gamma2), _ptr(beta2),
+                                    _ptr(y2), dt(y2), _ptr(mean2), _ptr(rstd2), M, d, eps, _stream()), "layernorm2_fwd")
+
+
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d, eps=1e-5):
     check(lib.mi355x_layernorm_fwd(_ptr(x), dt(x), _ptr(gamma), _ptr(beta), _ptr(y), dt(y), _ptr(mean), _ptr(rstd), M, d, eps,
                                    _stream()), "layernorm_fwd")
@@ -403,6 +409,12 @@ def attn_delta(dO, O, delta, B, H, T, d, O_lo=None):
     check(lib.mi355x_attn_delta(_ptr(dO), _ptr(O), _ptr(O_lo), _ptr(delta), B, H, T, d, _stream()), "attn_delta")
 
 
+def attn_bwd_prep(dO, O, delta, qkv, ldq, bias_u, bias_v, qu, qv, B, H, T, d, O_lo=None):
+    """attn_delta + qbias in one launch (the prologue of the fused attention backward)"""
+    check(lib.mi355x_attn_bwd_prep(_ptr(dO), _ptr(O), _ptr(O_lo), _ptr(delta), _ptr(qkv), ldq, _ptr(bias_u), _ptr(bias_v), _ptr(qu),
+                                   _ptr(qv), B, H, T, d, _stream()), "attn_bwd_prep")
+
+
 def relpos_ds_buffer(B, H, T, device, fill=None):
     """bf16 buffer for the dQ kernel's score-gradient blocks (un-shifted matrix_bd layout, see include/mi355x_asr.h)"""
     n = lib.mi355x_relpos_ds_elems(B, H, T)
@@ -413,10 +425,16 @@ def relpos_ds_buffer(B, H, T, device, fill=None):
 
 
 def relpos_flash_bwd_dq(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqu, dqv, B, H, T, dk, scale,
-                        drop: Dropout = NO_DROP, ds_out=None):
+                        drop: Dropout = NO_DROP, ds_out=None, dq_out=None, ld_dq=0, bias_grads=None):
+    """dqu / dqv: the two gradients separately (may both be None when `dq_out` is given); dq_out: their sum as rows of pitch
+    ld_dq; bias_grads f32 [2 * H * dk] += column sums of dQu | dQv (pos_bias_u | pos_bias_v gradients)"""
+    sc, n = None, 0
+    if bias_grads is not None:
+        n = B * ((T + 127) // 128) * 2 * H * dk
+        sc = _scratch("relpos_flash_bwd_dq", n, qu.device)
     check(lib.mi355x_relpos_flash_bwd_dq(_ptr(qu), _ptr(qv), _ptr(qkv), ldq, _ptr(pos), ldp, _ptr(lens), _ptr(dO), _ptr(lse),
-                                         _ptr(delta), _ptr(dqu), _ptr(dqv), _ptr(ds_out), B, H, T, dk,
-                                         0 if ds_out is None else ds_out.numel(), scale, drop.key,
+                                         _ptr(delta), _ptr(dqu), _ptr(dqv), _ptr(ds_out), _ptr(dq_out), ld_dq, _ptr(bias_grads),
+                                         _ptr(sc), n, B, H, T, dk, 0 if ds_out is None else ds_out.numel(), scale, drop.key,
                                          drop.threshold, drop.scale, _stream()), "relpos_flash_bwd_dq")
 
 

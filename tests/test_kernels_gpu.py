@@ -229,6 +229,26 @@ def test_layernorm(d, xdt, ydt):
     assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
 
 
+@pytest.mark.parametrize("ydt", [torch.float32, torch.bfloat16])
+def test_layernorm2_is_two_layernorms(ydt):
+    """mi355x_layernorm2_fwd = LN1 (f32 out) followed by LN2 (compute-dtype out), bit for bit, statistics included"""
+    o = ops()
+    M, d = 333, 512
+    g = torch.Generator().manual_seed(41)
+    x = (torch.randn(M, d, generator=g) * 2 + 0.5).to(dev)
+    g1, b1, g2, b2 = (torch.randn(d, generator=g).to(dev) for _ in range(4))
+    y1 = torch.empty(M, d, device=dev); y2 = torch.empty(M, d, device=dev, dtype=ydt)
+    m1, r1, m2, r2 = (torch.empty(M, device=dev) for _ in range(4))
+    o.layernorm_fwd(x, g1, b1, y1, m1, r1, M, d)
+    o.layernorm_fwd(y1, g2, b2, y2, m2, r2, M, d)
+    z1 = torch.empty_like(y1); z2 = torch.empty_like(y2)
+    n1, s1, n2, s2 = (torch.empty(M, device=dev) for _ in range(4))
+    o.layernorm2_fwd(x, g1, b1, z1, n1, s1, g2, b2, z2, n2, s2, M, d)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, y1) and torch.equal(z2, y2)
+    assert torch.equal(n1, m1) and torch.equal(s1, r1) and torch.equal(n2, m2) and torch.equal(s2, r2)
+
+
 def test_colsum_logsoftmax():
     o = ops()
     M, C_ = 700, 129
@@ -460,6 +480,22 @@ def test_relpos_flash_attention_bwd(T):
     torch.cuda.synchronize()
     assert rel_err(dqu, ref["dqu"]) < 8e-3, rel_err(dqu, ref["dqu"])  # (measured 2.9-3.7e-3)
     assert rel_err(dqv, ref["dqv"]) < 8e-3, rel_err(dqv, ref["dqv"])  # (measured 2.9-3.7e-3)
+    # the one-pass prologue (q + u, q + v, delta) = the two kernels above, bit for bit
+    qu2 = torch.full_like(qu, float("nan")); qv2 = torch.full_like(qv, float("nan")); delta2 = torch.full_like(delta, float("nan"))
+    o.attn_bwd_prep(dO_d, ctx, delta2, qkv_d, 3 * d, u.to(dev), v.to(dev), qu2, qv2, B, H, T, d)
+    torch.cuda.synchronize()
+    assert torch.equal(qu2, qu) and torch.equal(qv2, qv) and torch.equal(delta2, delta)
+    # fused outputs of the dQ kernel: dq = dqu + dqv straight into the q third of the [M, 3d] gradient (the other two thirds
+    # untouched), pos_bias_u / pos_bias_v gradients = column sums of dQu | dQv added to what the buffer held
+    dq3 = torch.full((B * T, 3 * d), 7.0, device=dev, dtype=torch.bfloat16)
+    bg = torch.ones(2 * d, device=dev)
+    o.relpos_flash_bwd_dq(qu, qv, qkv_d, 3 * d, pos_d, d, lens_d, dO_d, lse, delta, None, None, B, H, T, dk, scale,
+                          dq_out=dq3, ld_dq=3 * d, bias_grads=bg)
+    torch.cuda.synchronize()
+    assert torch.all(dq3[:, d:] == 7.0)
+    assert rel_err(dq3[:, :d], dqu.float() + dqv.float()) < 6e-3  # (one bf16 rounding of the f32 sum instead of three)
+    assert rel_err(dq3[:, :d], ref["dqu"] + ref["dqv"]) < 8e-3
+    assert rel_err(bg[:d] - 1.0, ref["dqu"].sum(0)) < 8e-3 and rel_err(bg[d:] - 1.0, ref["dqv"].sum(0)) < 8e-3
     if hasattr(o, "relpos_flash_bwd_dkv"):
         dqkv = torch.full((B * T, 3 * d), float("nan"), device=dev, dtype=torch.bfloat16)
         o.relpos_flash_bwd_dkv(qu, qv, qkv_d, 3 * d, pos_d, d, lens_d, dO_d, lse, delta, dqkv, 3 * d, B, H, T, dk, Tp, scale)
