@@ -82,17 +82,38 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackEntry* __restrict__
   const int local = (int)(bid - e.tile_begin);
   const int tr = local / tiles_c, tc = local - tr * tiles_c;
   const bool col_fast = (e.sc2 == 1 && e.nc2 > 1) || (e.nc2 == 1 && e.sc1 == 1);
-#pragma unroll 4
-  for (int k = 0; k < PK_T * PK_T / 256; ++k) {
-    const int q = threadIdx.x + k * 256;
-    const int rr = col_fast ? (q >> 6) : (q & 63), cc = col_fast ? (q & 63) : (q >> 6);
-    const int r = tr * PK_T + rr, c = tc * PK_T + cc;
-    float v = 0.f;
-    if (r < e.rows && c < e.cols) {
-      const int r1 = r / e.nr2, r2 = r - r1 * e.nr2, c1 = c / e.nc2, c2 = c - c1 * e.nc2;
-      v = e.src[r1 * e.sr1 + r2 * e.sr2 + c1 * e.sc1 + c2 * e.sc2];
+  const bool plain = e.nr2 == 1 && e.nc2 == 1;  // (uniform) a strided 2-D view: no index splitting, and ...
+  const long long fast_stride = col_fast ? e.sc1 : e.sr1, slow_stride = col_fast ? e.sr1 : e.sc1;
+  const int fast_n = col_fast ? e.cols : e.rows, slow_n = col_fast ? e.rows : e.cols;
+  const int f0 = (col_fast ? tc : tr) * PK_T, s0 = (col_fast ? tr : tc) * PK_T;
+  if (plain && fast_stride == 1 && !(slow_stride & 3) && !((uintptr_t)e.src & 15) && f0 + PK_T <= fast_n) {
+    // ... whole 16-byte pieces along the contiguous axis of the source: 4 float4 loads per thread instead of 16 scalar ones
+    // with two integer divisions each (the divisions, not the memory system, bounded this kernel: 2.4 TB/s)
+#pragma unroll
+    for (int k = 0; k < PK_T * PK_T / 4 / 256; ++k) {
+      const int q = threadIdx.x + k * 256;
+      const int f4 = (q & 15) * 4, sl = q >> 4;  // 16 lanes x 16 B = one 256-B row segment of the tile
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (s0 + sl < slow_n) v = *reinterpret_cast<const float4*>(e.src + (long long)(s0 + sl) * slow_stride + f0 + f4);
+      if (col_fast) { tile[sl][f4] = v.x; tile[sl][f4 + 1] = v.y; tile[sl][f4 + 2] = v.z; tile[sl][f4 + 3] = v.w; }
+      else { tile[f4][sl] = v.x; tile[f4 + 1][sl] = v.y; tile[f4 + 2][sl] = v.z; tile[f4 + 3][sl] = v.w; }
     }
-    tile[rr][cc] = v;
+  } else {
+#pragma unroll 4
+    for (int k = 0; k < PK_T * PK_T / 256; ++k) {
+      const int q = threadIdx.x + k * 256;
+      const int rr = col_fast ? (q >> 6) : (q & 63), cc = col_fast ? (q & 63) : (q >> 6);
+      const int r = tr * PK_T + rr, c = tc * PK_T + cc;
+      float v = 0.f;
+      if (r < e.rows && c < e.cols) {
+        if (plain) v = e.src[r * e.sr1 + c * e.sc1];
+        else {
+          const int r1 = r / e.nr2, r2 = r - r1 * e.nr2, c1 = c / e.nc2, c2 = c - c1 * e.nc2;
+          v = e.src[r1 * e.sr1 + r2 * e.sr2 + c1 * e.sc1 + c2 * e.sc2];
+        }
+      }
+      tile[rr][cc] = v;
+    }
   }
   __syncthreads();
   // image pitch is a multiple of 8 and >= roundup8(cols): whole 8-column groups can be written (zeros past `cols`)

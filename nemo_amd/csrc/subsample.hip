@@ -108,8 +108,13 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const TO* __restrict__ d
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int part = blockIdx.y * gridDim.x + blockIdx.x;
-  for (int c0 = 0; c0 < C; c0 += 64 * V) {
-    const int c = c0 + lane * V;
+  // C / V channel chunks per wave pass; with fewer than 64 chunks (C = 256 in bf16: 32) the remaining lanes take other f1
+  // positions of the row instead of idling (16-byte loads from all 64 lanes), and a butterfly adds their sums at the end
+  const int CL = (C / V >= 64 || (64 % (C / V))) ? 64 : C / V;
+  const int NF = 64 / CL;
+  const int lane_c = lane % CL, fsub = lane / CL;
+  for (int c0 = 0; c0 < C; c0 += CL * V) {
+    const int c = c0 + lane_c * V;
     float gw[9][V], gb[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const TO* __restrict__ d
         const float* mrow = mel_s + 2 * (t1 - t1_0);
         const TO* gp = dout + ((long long)b * T1 + t1) * F1 * C + c;
 #pragma unroll 4
-        for (int f1 = 0; f1 < F1; ++f1) {
+        for (int f1 = fsub; f1 < F1; f1 += NF) {
           float g[V];
           VecIO<TO>::load(gp + (long long)f1 * C, g);
           float m[9];
@@ -139,14 +144,22 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const TO* __restrict__ d
         }
       }
     }
+    for (int off = CL; off < 64; off <<= 1) {  // (wave-uniform trip count) sums of the lanes that share a channel chunk
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        gb[j] += __shfl_xor(gb[j], off, 64);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gw[k][j] += __shfl_xor(gw[k][j], off, 64);
+      }
+    }
     // cross-wave sum, one tap per round; then one plain store per (tap, channel) into this block's slab
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < V; ++j) red[wave * 64 * V + lane * V + j] = k < 9 ? gw[k < 9 ? k : 0][j] : gb[j];
+      for (int j = 0; j < V; ++j) red[wave * 64 * V + lane_c * V + j] = k < 9 ? gw[k < 9 ? k : 0][j] : gb[j];
       __syncthreads();
-      for (int e = threadIdx.x; e < 64 * V; e += 256) {
+      for (int e = threadIdx.x; e < CL * V; e += 256) {
         const int cc = c0 + e;
         if (cc >= C) continue;
         const float v = (red[e] + red[64 * V + e]) + (red[2 * 64 * V + e] + red[3 * 64 * V + e]);

@@ -968,9 +968,14 @@ def test_pack_weights():
     a = plan.add_matrix("w", W)                       # [70, 48] (K padded to 8)
     at = plan.add_matrix("wt", W, transpose=True)     # [45, 72]
     c2 = plan.add_conv3x3("c2", W2)                   # [16, 72]: k = (kh*3+kw)*8 + ci
+    # 16-byte-aligned rows: whole 64 x 64 tiles take the vectorised path, the ragged last tile of each axis the scalar one
+    W3 = torch.randn(200, 136, generator=g).to(dev)
+    plan.add_matrix("w3", W3); plan.add_matrix("w3t", W3, transpose=True)
     plan.finalize()
     plan.run()
     torch.cuda.synchronize()
+    assert torch.equal(plan["w3"][:, :136].float().cpu(), W3.to(torch.bfloat16).float().cpu())
+    assert torch.equal(plan["w3t"][:, :200].float().cpu(), W3.t().to(torch.bfloat16).float().cpu())
     assert torch.equal(plan["w"][:, :45].float().cpu(), W.to(torch.bfloat16).float().cpu())
     assert torch.all(plan["w"][:, 45:] == 0)
     assert torch.equal(plan["wt"][:, :70].float().cpu(), W.t().to(torch.bfloat16).float().cpu())
