@@ -217,18 +217,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TX* __restrict__ x, l
     atomicAdd(out + c, alpha * ((sa[0][t] + sa[1][t]) + (sa[2][t] + sa[3][t])));
   }
 }
-// bf16, 8 columns (16 B) per lane: block = 512 columns x 4 row lanes, 64 rows per block
+// bf16, 8 columns (16 B) per lane: block = 512 columns x 4 row lanes, 64 rows per block.  With N < 512 (the 256 channels of the
+// sub-sampling stack) a wave covers 512 / N rows at once instead of leaving lanes idle.
 #define CSV_ROWS 64
 __global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16_t* __restrict__ x, long long ldx_, float* __restrict__ out,
                                                             int M, int N, float alpha) {
   __shared__ float sa[4][512];
   const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 512 + lane * 8;
+  const int nch = (N + 7) >> 3;                                        // 16-byte chunks per row
+  const int CL = (nch >= 64 || (64 % nch)) ? 64 : nch, NR = 64 / CL;   // lanes per row, rows per wave pass
+  const int lc = lane % CL, sub = lane / CL;
+  const int c = blockIdx.x * 512 + lc * 8;
   const int r0 = blockIdx.y * CSV_ROWS, r1 = min(M, r0 + CSV_ROWS);
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < N) {
 #pragma unroll 4
-    for (int r = r0 + rl; r < r1; r += 4) {
+    for (int r = r0 + rl * NR + sub; r < r1; r += 4 * NR) {
       const u32x4 t = *reinterpret_cast<const u32x4*>(x + (long long)r * ldx_ + c);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { a[2 * j] += __uint_as_float(t[j] << 16); a[2 * j + 1] += __uint_as_float(t[j] & 0xffff0000u); }
@@ -237,9 +241,12 @@ __global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16_t* __rest
 #pragma unroll
   for (int j = 0; j < 8; ++j) sa[rl][lane * 8 + j] = a[j];
   __syncthreads();
-  for (int e = threadIdx.x; e < 512; e += 256) {
+  for (int e = threadIdx.x; e < CL * 8; e += 256) {
     const int cc = blockIdx.x * 512 + e;
-    if (cc < N) atomicAdd(out + cc, alpha * ((sa[0][e] + sa[1][e]) + (sa[2][e] + sa[3][e])));
+    if (cc >= N) continue;
+    float v = 0.f;
+    for (int s2 = 0; s2 < NR; ++s2) v += (sa[0][s2 * CL * 8 + e] + sa[1][s2 * CL * 8 + e]) + (sa[2][s2 * CL * 8 + e] + sa[3][s2 * CL * 8 + e]);
+    atomicAdd(out + cc, alpha * v);
   }
 }
 

@@ -249,6 +249,19 @@ def test_layernorm2_is_two_layernorms(ydt):
     assert torch.equal(n1, m1) and torch.equal(s1, r1) and torch.equal(n2, m2) and torch.equal(s2, r2)
 
 
+@pytest.mark.parametrize("N", [64, 136, 256, 512, 1024])
+def test_colsum_bf16_all_lane_layouts(N):
+    """bf16 column sums (bias gradients): 16-byte chunks per lane; rows narrower than a wave's 512 columns share the wave"""
+    o = ops()
+    M = 777
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    out = torch.ones(N, device=dev)
+    o.colsum(x.to(dev), out, M, N, alpha=0.5)
+    torch.cuda.synchronize()
+    assert rel_err(out, 1 + 0.5 * x.float().sum(0)) < 1e-5
+
+
 def test_colsum_logsoftmax():
     o = ops()
     M, C_ = 700, 129
