@@ -180,6 +180,14 @@ int mi355x_layernorm_fwd(const void* x, int x_dtype, const void* gamma, const vo
 int mi355x_layernorm2_fwd(const void* x, const void* gamma1, const void* beta1, void* y1, void* mean1, void* rstd1,
                           const void* gamma2, const void* beta2, void* y2, int y2_dtype, void* mean2, void* rstd2, int M, int d,
                           float eps, void* stream);
+/* The backward of that pair in one pass (d = 512): g = dres_in + dLN1(dy1; x1) is the gradient w.r.t. y1 (kept in registers),
+ * dres_out (f32) = dLN2(g; x2), cast_out (optional bf16) = cast_scale * dropmask * dres_out; the four parameter gradients are
+ * accumulated (+=).  LN1 = the LATER LayerNorm in forward order (norm_feed_forward1 of layer i+1, input x1 = layer i's output),
+ * LN2 = the earlier one (norm_out of layer i, input x2). */
+int mi355x_layernorm2_bwd(const void* dy1, int dy1_dtype, const void* x1, const void* gamma1, const void* mean1, const void* rstd1,
+                          void* dgamma1, void* dbeta1, const void* dres_in, const void* x2, const void* gamma2, const void* mean2,
+                          const void* rstd2, void* dgamma2, void* dbeta2, void* dres_out, int M, int d, void* cast_out,
+                          float cast_scale, unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream);
 /* dres (f32 [M,d]) = (accumulate ? dres : 0) + dLN/dx ; dgamma/dbeta (f32 [d], may be NULL) are accumulated (+=)   */
 int mi355x_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const void* gamma, const void* mean,
                          const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d, void* stream);

@@ -79,6 +79,7 @@ SIGNATURES = {
     "mi355x_cast_rows": [vp, i64, vp, i32, i64, i64, i32, i32, f32, vp],
     "mi355x_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp],
     "mi355x_layernorm2_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp],
+    "mi355x_layernorm2_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, u32, u32, f32, vp],
     "mi355x_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp],
     "mi355x_layernorm_bwd_cast": [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, f32, u32, u32, f32, vp],
     "mi355x_colsum": [vp, i32, i64, vp, i32, i32, f32, vp],

@@ -482,6 +482,110 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_fused8_kernel(const TDY
   }
 }
 
+// Two LayerNorm backwards in a row at a layer boundary (d = 512), the mirror image of ln2_fwd_reg_kernel: layer i+1's
+// norm_feed_forward1 (input xo = layer i's output, upstream dy1) and layer i's norm_out (input r4).
+//   g   = dres_in + dLN1(dy1; xo)            the complete gradient w.r.t. xo -- stays in registers, never written
+//   out = dLN2(g; r4) -> dres_out (f32) and, optionally, cast_out = bf16(cast_scale * dropmask * out) for the next GEMMs
+// Both LayerNorms' parameter gradients leave through the same 64-KiB LDS buffer, one after the other.  Saves the write and the
+// re-read of g (64 MB per boundary) and a launch.
+template <typename TDY>
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln2_bwd_fused8_kernel(
+    const TDY* __restrict__ dy1, const float* __restrict__ x1, const float* __restrict__ gamma1, const float* __restrict__ mean1,
+    const float* __restrict__ rstd1, float* __restrict__ dgamma1, float* __restrict__ dbeta1, const float* __restrict__ dres_in,
+    const float* __restrict__ x2, const float* __restrict__ gamma2, const float* __restrict__ mean2,
+    const float* __restrict__ rstd2, float* __restrict__ dgamma2, float* __restrict__ dbeta2, float* __restrict__ dres_out, int M,
+    bf16_t* __restrict__ cast_out, float cast_scale, DropCfg cast_drop) {
+  drop_resolve(cast_drop);
+  constexpr int d = 512;
+  __shared__ float red[LNB_WAVES][2][d];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float g1[8], g2[8], ag1[8], ab1[8], ag2[8], ab2[8];
+  ld8g(gamma1 + lane * 8, g1); ld8g(gamma2 + lane * 8, g2);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ag1[j] = 0.f; ab1[j] = 0.f; ag2[j] = 0.f; ab2[j] = 0.f; }
+  const int r0 = blockIdx.x * LNB_ROWS, r1 = min(M, r0 + LNB_ROWS);
+  for (int row = r0 + wave; row < r1; row += LNB_WAVES) {
+    const long long off = (long long)row * d + lane * 8;
+    float v[8], e[8], xh[8], g[8];
+    ld8g(x1 + off, v); ld8g(dy1 + off, e); ld8g(dres_in + off, g);
+    const float mu1 = mean1[row], rs1 = rstd1[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      xh[j] = (v[j] - mu1) * rs1;
+      const float gd = g1[j] * e[j];
+      s1 += gd; s2 += gd * xh[j];
+      ag1[j] += e[j] * xh[j]; ab1[j] += e[j];
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] += rs1 * (g1[j] * e[j] - s1 - xh[j] * s2);
+    ld8g(x2 + off, v);
+    const float mu2 = mean2[row], rs2 = rstd2[row];
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      xh[j] = (v[j] - mu2) * rs2;
+      const float gd = g2[j] * g[j];
+      t1 += gd; t2 += gd * xh[j];
+      ag2[j] += g[j] * xh[j]; ab2[j] += g[j];
+    }
+    t1 = wave_sum(t1) / (float)d;
+    t2 = wave_sum(t2) / (float)d;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = rs2 * (g2[j] * g[j] - t1 - xh[j] * t2);
+    st8g(dres_out + off, o);
+    if (cast_out) {
+      float m[8];
+      drop_mask8(cast_drop, (uint32_t)row * (uint32_t)d + (uint32_t)(lane * 8), m);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] *= cast_scale * m[j];
+      st8g(cast_out + off, o);
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    float* dgam = pass == 0 ? dgamma1 : dgamma2;
+    float* dbet = pass == 0 ? dbeta1 : dbeta2;
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[wave][0][lane * 8 + j] = pass == 0 ? ag1[j] : ag2[j];
+      red[wave][1][lane * 8 + j] = pass == 0 ? ab1[j] : ab2[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 64 * LNB_WAVES) {
+      float sg_ = 0.f, sb_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < LNB_WAVES; ++w) { sg_ += red[w][0][c]; sb_ += red[w][1][c]; }
+      atomicAdd(dgam + c, sg_);
+      atomicAdd(dbet + c, sb_);
+    }
+  }
+}
+extern "C" int mi355x_layernorm2_bwd(const void* dy1, int dy1_dt, const void* x1, const void* gamma1, const void* mean1,
+                                     const void* rstd1, void* dgamma1, void* dbeta1, const void* dres_in, const void* x2,
+                                     const void* gamma2, const void* mean2, const void* rstd2, void* dgamma2, void* dbeta2,
+                                     void* dres_out, int M, int d, void* cast_out, float cast_scale, unsigned drop_key,
+                                     unsigned drop_threshold, float drop_scale, void* stream) {
+  mi_clear_errors();
+  if (!dy1 || !x1 || !gamma1 || !mean1 || !rstd1 || !dgamma1 || !dbeta1 || !dres_in || !x2 || !gamma2 || !mean2 || !rstd2 ||
+      !dgamma2 || !dbeta2 || !dres_out || M <= 0 || d != 512)
+    return MI_ERR_ARG;
+  if (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dres_in | (uintptr_t)dres_out | (uintptr_t)gamma1 | (uintptr_t)gamma2) & 31) return MI_ERR_ARG;
+  if (((uintptr_t)dy1 | (uintptr_t)cast_out) & 15) return MI_ERR_ARG;
+  DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
+  dim3 grid((M + LNB_ROWS - 1) / LNB_ROWS), block(64 * LNB_WAVES);
+  DISPATCH_DT(dy1_dt, TDY, MI_LAUNCH((ln2_bwd_fused8_kernel<TDY>), grid, block, 0, (hipStream_t)stream, (const TDY*)dy1, (const float*)x1,
+                                     (const float*)gamma1, (const float*)mean1, (const float*)rstd1, (float*)dgamma1, (float*)dbeta1,
+                                     (const float*)dres_in, (const float*)x2, (const float*)gamma2, (const float*)mean2,
+                                     (const float*)rstd2, (float*)dgamma2, (float*)dbeta2, (float*)dres_out, M, (bf16_t*)cast_out,
+                                     cast_scale, dc));
+  return mi_check_launch();
+}
+
 static int layernorm_bwd_impl(const void* dy, int dy_dt, const void* x, int x_dt, const void* gamma, const void* mean,
                               const void* rstd, void* dres, int accumulate, void* dgamma, void* dbeta, int M, int d,
                               void* cast_out, float cast_scale, DropCfg cast_drop, void* stream);

@@ -264,6 +264,7 @@ class ConformerEncoder(NeuralModule):
         self.use_flash_attention = True  # bf16 + d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
         # one launch for a layer's norm_out and the next layer's norm_feed_forward1 (d = 512; MI355X_LN2=0: two launches)
         self.fuse_layer_boundary_norms = os.environ.get("MI355X_LN2", "1") != "0"
+        self.fuse_boundary_bwd = os.environ.get("MI355X_LN2_BWD", "1") != "0"  # ... and their backwards (mi355x_layernorm2_bwd)
         self.flash_delta_residual = os.environ.get("MI355X_FLASH_DELTA_LO", "1") != "0"  # (A/B switch of the delta fix)
         self.grad_ready_hook = None  # callable(start, end) on the flat gradient buffer (data-parallel bucketing)
         # linear_pos weights of all layers sit together at the tail: their gradients come from ONE batched GEMM
@@ -1368,10 +1369,13 @@ class ConformerEncoder(NeuralModule):
         if self.grad_ready_hook is not None:
             self._hook(*fp.range_of("pre_encode."))
 
-    def _ffn_bwd(self, pfx, ff, ln, saved, dr, W, M, d, dff, cdt, dev, df=None, next_cast=None):
+    def _ffn_bwd(self, pfx, ff, ln, saved, dr, W, M, d, dff, cdt, dev, df=None, next_cast=None, boundary=None):
         """`df` = the already cast / dropped / scaled residual-branch gradient when the previous LayerNorm backward produced
         it in its own pass; `next_cast` = (scale, Dropout) of the sub-block that follows in backward order: this block's
-        LayerNorm backward then emits that operand too.  Returns (dr, cast_for_next_or_None)."""
+        LayerNorm backward then emits that operand too.  `boundary` = (norm_out module, r4, mean5, rstd5) of the layer BELOW when
+        this is a layer's first feed-forward block: its LayerNorm backward and that norm_out's run as one kernel
+        (mi355x_layernorm2_bwd), the returned dr is then already the gradient w.r.t. the lower layer's r4.
+        Returns (dr, cast_for_next_or_None)."""
         x, y, mean, rstd, h, a, d_in, d_res = saved
         if df is None:
             df = self._new(M, d, dtype=cdt, device=dev)
@@ -1383,6 +1387,14 @@ class ConformerEncoder(NeuralModule):
         dy = self._new(M, d, dtype=cdt, device=dev)
         ops.gemm(dh, W[pfx + ".w1t"], dy, M, d, dff, dff, W.pitch(pfx + ".w1t"), d)
         nxt = self._cast_buf(next_cast, M, d, cdt, dev)
+        if boundary is not None:
+            ln_lo, r4, mean5, rstd5 = boundary
+            dr_lo = self._new(M, d, dtype=torch.float32, device=dev)
+            ops.layernorm2_bwd(dy, x, ln.weight, mean, rstd, ln.weight.grad, ln.bias.grad, dr, r4, ln_lo.weight, mean5, rstd5,
+                               ln_lo.weight.grad, ln_lo.bias.grad, dr_lo, M, d, cast_out=nxt,
+                               cast_scale=next_cast[0] if nxt is not None else 1.0,
+                               cast_drop=next_cast[1] if nxt is not None else None)
+            return dr_lo, nxt
         ops.layernorm_bwd(dy, x, ln.weight, mean, rstd, dr, True, ln.weight.grad, ln.bias.grad, M, d, cast_out=nxt,
                           cast_scale=next_cast[0] if nxt is not None else 1.0,
                           cast_drop=next_cast[1] if nxt is not None else None)
@@ -1483,14 +1495,19 @@ class ConformerEncoder(NeuralModule):
         scale = 1.0 / math.sqrt(dk)
         # ---- norm_out: dr = dLN(dxo)
         r4, mean5, rstd5 = sl.out
-        dr = self._new(M, d, dtype=torch.float32, device=dev)
-        ln = L.norm_out
-        # every LayerNorm backward also emits the bf16 (scaled, dropped) copy of the new residual gradient that the next
-        # sub-block's output GEMMs consume -- one read of the fp32 gradient and one launch less per sub-block
-        nc = (0.5, sl.ff2[7])
-        df2 = self._cast_buf(nc, M, d, cdt, dev)
-        ops.layernorm_bwd(dxo, r4, ln.weight, mean5, rstd5, dr, False, ln.weight.grad, ln.bias.grad, M, d, cast_out=df2,
-                          cast_scale=0.5, cast_drop=nc[1] if df2 is not None else None)
+        pre = getattr(S, "pre_bwd", None)
+        if pre is not None:  # the layer above ran this LayerNorm backward together with its own norm_feed_forward1's
+            dr, df2 = pre
+            S.pre_bwd = None
+        else:
+            dr = self._new(M, d, dtype=torch.float32, device=dev)
+            ln = L.norm_out
+            # every LayerNorm backward also emits the bf16 (scaled, dropped) copy of the new residual gradient that the next
+            # sub-block's output GEMMs consume -- one read of the fp32 gradient and one launch less per sub-block
+            nc = (0.5, sl.ff2[7])
+            df2 = self._cast_buf(nc, M, d, cdt, dev)
+            ops.layernorm_bwd(dxo, r4, ln.weight, mean5, rstd5, dr, False, ln.weight.grad, ln.bias.grad, M, d, cast_out=df2,
+                              cast_scale=0.5, cast_drop=nc[1] if df2 is not None else None)
         # ---- FFN 2
         dr, db_pre = self._ffn_bwd(f"L{i}.ff2", L.feed_forward2, L.norm_feed_forward2, sl.ff2, dr, W, M, d, dff, cdt, dev,
                                    df=df2, next_cast=(1.0, sl.conv[11]))
@@ -1541,6 +1558,14 @@ class ConformerEncoder(NeuralModule):
         df1 = self._cast_buf(nc, M, d, cdt, dev)
         ops.layernorm_bwd(dy2, r1, ln.weight, mean2, rstd2, dr, True, ln.weight.grad, ln.bias.grad, M, d, cast_out=df1,
                           cast_scale=0.5, cast_drop=nc[1] if df1 is not None else None)
-        # ---- FFN 1
+        # ---- FFN 1 (its LayerNorm backward together with the norm_out backward of the layer below, where the kernel covers it)
+        lo = S.layers[i - 1] if i > 0 else None
+        if lo is not None and d == 512 and self.fuse_layer_boundary_norms and self.fuse_boundary_bwd:
+            r4_lo, mean5_lo, rstd5_lo = lo.out
+            dr, df2_lo = self._ffn_bwd(f"L{i}.ff1", L.feed_forward1, L.norm_feed_forward1, sl.ff1, dr, W, M, d, dff, cdt, dev, df=df1,
+                                       next_cast=(0.5, lo.ff2[7]),
+                                       boundary=(self.layers[i - 1].norm_out, r4_lo, mean5_lo, rstd5_lo))
+            S.pre_bwd = (dr, df2_lo)
+            return dr
         dr, _ = self._ffn_bwd(f"L{i}.ff1", L.feed_forward1, L.norm_feed_forward1, sl.ff1, dr, W, M, d, dff, cdt, dev, df=df1)
         return dr

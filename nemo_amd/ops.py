@@ -282,6 +282,16 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, accumulate, dgamma, dbeta, M, 
                                             dr.key, dr.threshold, dr.scale, _stream()), "layernorm_bwd_cast")
 
 
+def layernorm2_bwd(dy1, x1, gamma1, mean1, rstd1, dgamma1, dbeta1, dres_in, x2, gamma2, mean2, rstd2, dgamma2, dbeta2, dres_out,
+                   M, d, cast_out=None, cast_scale=1.0, cast_drop: "Dropout" = None):
+    """backward of layernorm2_fwd's pair in one launch (include/mi355x_asr.h: mi355x_layernorm2_bwd)"""
+    dr = cast_drop if cast_drop is not None else NO_DROP
+    check(lib.mi355x_layernorm2_bwd(_ptr(dy1), dt(dy1), _ptr(x1), _ptr(gamma1), _ptr(mean1), _ptr(rstd1), _ptr(dgamma1),
+                                    _ptr(dbeta1), _ptr(dres_in), _ptr(x2), _ptr(gamma2), _ptr(mean2), _ptr(rstd2), _ptr(dgamma2),
+                                    _ptr(dbeta2), _ptr(dres_out), M, d, _ptr(cast_out), cast_scale, dr.key, dr.threshold, dr.scale,
+                                    _stream()), "layernorm2_bwd")
+
+
 def colsum(x, out, M, N, ld=None, alpha=1.0, x_off=0):
     check(lib.mi355x_colsum(_ptr(x) + x_off * x.element_size(), dt(x), ld if ld is not None else N, _ptr(out), M, N, alpha,
                             _stream()), "colsum")

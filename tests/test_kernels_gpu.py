@@ -262,6 +262,42 @@ def test_colsum_bf16_all_lane_layouts(N):
     assert rel_err(out, 1 + 0.5 * x.float().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("dydt", [torch.float32, torch.bfloat16])
+def test_layernorm2_bwd_is_two_layernorm_backwards(dydt):
+    """mi355x_layernorm2_bwd (layer i+1's norm_feed_forward1 backward + layer i's norm_out backward, the gradient between them
+    kept in registers) = the two single launches: residual gradient and its dropped bf16 copy to the last bit or two (the compiler
+    contracts the same expressions into FMAs independently per kernel), the same dropout mask, the four parameter gradients up to
+    the order of their atomics"""
+    o = ops()
+    M, d = 777, 512
+    g = torch.Generator().manual_seed(43)
+    r4 = (torch.randn(M, d, generator=g) * 2 + 0.3).to(dev)
+    g1, b1, g2, b2 = (torch.randn(d, generator=g).to(dev) for _ in range(4))
+    xo = torch.empty(M, d, device=dev); y = torch.empty(M, d, device=dev, dtype=dydt)
+    m5, r5, m1, r1 = (torch.empty(M, device=dev) for _ in range(4))
+    o.layernorm2_fwd(r4, g2, b2, xo, m5, r5, g1, b1, y, m1, r1, M, d) if dydt == torch.bfloat16 else (
+        o.layernorm_fwd(r4, g2, b2, xo, m5, r5, M, d), o.layernorm_fwd(xo, g1, b1, y, m1, r1, M, d))
+    dy1 = torch.randn(M, d, generator=g).to(dydt).to(dev)
+    dres_in = torch.randn(M, d, generator=g).to(dev)
+    drop = o.Dropout(0.1, 5, 7)
+    # reference: two launches
+    dxo = dres_in.clone()
+    dg1, db1, dg2, db2 = (torch.zeros(d, device=dev) for _ in range(4))
+    o.layernorm_bwd(dy1, xo, g1, m1, r1, dxo, True, dg1, db1, M, d)
+    dr = torch.empty(M, d, device=dev); cast = torch.empty(M, d, device=dev, dtype=torch.bfloat16)
+    o.layernorm_bwd(dxo, r4, g2, m5, r5, dr, False, dg2, db2, M, d, cast_out=cast, cast_scale=0.5, cast_drop=drop)
+    # fused
+    eg1, eb1, eg2, eb2 = (torch.zeros(d, device=dev) for _ in range(4))
+    dr2 = torch.full((M, d), float("nan"), device=dev); cast2 = torch.full((M, d), float("nan"), device=dev, dtype=torch.bfloat16)
+    o.layernorm2_bwd(dy1, xo, g1, m1, r1, eg1, eb1, dres_in, r4, g2, m5, r5, eg2, eb2, dr2, M, d, cast_out=cast2, cast_scale=0.5,
+                     cast_drop=drop)
+    torch.cuda.synchronize()
+    assert rel_err(dr2, dr) < 1e-6 and rel_err(cast2, cast) < 1e-3
+    assert torch.equal(cast2 == 0, cast == 0) and 0.05 < (cast == 0).float().mean().item() < 0.15
+    for a, b in ((eg1, dg1), (eb1, db1), (eg2, dg2), (eb2, db2)):
+        assert rel_err(a, b) < 1e-5
+
+
 def test_colsum_logsoftmax():
     o = ops()
     M, C_ = 700, 129
