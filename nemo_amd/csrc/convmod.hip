@@ -178,6 +178,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm
+// 1 / sqrt(var + eps) in f32 with one Newton step on the hardware estimate (<= 1 ulp; the mean and the variance themselves come
+// from the f64 sums): shared by the stand-alone and the fused statistics kernels so that both give the same bits
+__device__ __forceinline__ float bn_rstd(float var, float eps) {
+  const float x = var + eps;
+  float r = rsqrtf(x);
+  r = r * (1.5f - 0.5f * x * r * r);
+  return r;
+}
 // stats (f64 [2][d]: sum, sum of squares over `count` positions) -> mean, rstd (biased var), running stats update
 // `count_dev` (optional): the element count as a device f64 -- under SyncBatchNorm it is the (all-reduced) sum of the ranks'
 // own B*T' and travels in the same buffer as the sums, so ragged ranks need no host round trip
@@ -188,11 +196,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d) return;
   if (count_dev) count = *count_dev;
-  const double mu = stats[c] / count;
-  double var = stats[d + c] / count - mu * mu;
+  const double inv_count = 1.0 / count;
+  const double mu = stats[c] * inv_count;
+  double var = stats[d + c] * inv_count - mu * mu;
   if (var < 0.0) var = 0.0;
   mean[c] = (float)mu;
-  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  rstd[c] = bn_rstd((float)var, eps);
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
   if (running_var) {
     const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -247,14 +256,17 @@ __global__ __launch_bounds__(256) void bn_stats_swish_fwd_kernel(const TT* __res
   const int ck = threadIdx.x % CP, rsub = threadIdx.x / CP;
   if (rsub >= RS) return;
   if (count_dev) count = *count_dev;
+  const double inv_count = 1.0 / count;
   for (int c = ck * V; c < d; c += CP * V) {
     float mu[V], rs[V], g[V], bt[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      const double m_ = stats[c + j] / count;
-      double var = stats[d + c + j] / count - m_ * m_;
+      // (one f64 reciprocal per thread, then multiplies: EVERY workgroup derives the coefficients of its channels, and f64
+      //  divisions / square roots here cost 20 us per launch -- more than the whole normalisation pass)
+      const double m_ = stats[c + j] * inv_count;
+      double var = stats[d + c + j] * inv_count - m_ * m_;
       if (var < 0.0) var = 0.0;
-      mu[j] = (float)m_; rs[j] = (float)(1.0 / sqrt(var + (double)eps));
+      mu[j] = (float)m_; rs[j] = bn_rstd((float)var, eps);
       g[j] = gamma[c + j]; bt[j] = beta[c + j];
       if (blockIdx.x == 0 && rsub == 0) {
         mean[c + j] = mu[j]; rstd[c + j] = rs[j];
