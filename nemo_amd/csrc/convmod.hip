@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void bn_swish_fwd_kernel(const TT* __restrict_
 // statistics -- one launch per layer instead of two.
 template <typename TT>
 __global__ __launch_bounds__(256) void bn_stats_swish_fwd_kernel(const TT* __restrict__ x, const double* __restrict__ stats,
-                                                                 double count, const double* __restrict__ count_dev,
+                                                                 double count, double inv_count_host,
+                                                                 const double* __restrict__ count_dev,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  TT* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                                  float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -256,12 +257,12 @@ __global__ __launch_bounds__(256) void bn_stats_swish_fwd_kernel(const TT* __res
   const int ck = threadIdx.x % CP, rsub = threadIdx.x / CP;
   if (rsub >= RS) return;
   if (count_dev) count = *count_dev;
-  const double inv_count = 1.0 / count;
+  const double inv_count = count_dev ? 1.0 / count : inv_count_host;  // (host-known count: its reciprocal comes as an argument)
   for (int c = ck * V; c < d; c += CP * V) {
     float mu[V], rs[V], g[V], bt[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      // (one f64 reciprocal per thread, then multiplies: EVERY workgroup derives the coefficients of its channels, and f64
+      // (at most one f64 reciprocal per thread, then multiplies: EVERY workgroup derives the coefficients of its channels, and f64
       //  divisions / square roots here cost 20 us per launch -- more than the whole normalisation pass)
       const double m_ = stats[c + j] * inv_count;
       double var = stats[d + c + j] * inv_count - m_ * m_;
@@ -345,14 +346,14 @@ template <typename TT>
 __global__ __launch_bounds__(256) void bn_swish_bwd_apply_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 const double* __restrict__ sums, double count,
+                                                                 const double* __restrict__ sums, double inv_count_host,
                                                                  const double* __restrict__ count_dev, int training,
                                                                  TT* __restrict__ dx, long long M, int d) {
   // per-channel coefficients are built once per workgroup in LDS (the f64 mean-of-sums included), so a thread's set-up is
   // six 16/32-byte LDS reads however few rows it handles
   constexpr int V = VecIO<TT>::V;
   extern __shared__ float coef[];  // [6][d]: mean, rstd, gamma, beta, k1 = sum(dz)/n, k2 = sum(dz*xhat)/n
-  const double inv_count = 1.0 / (count_dev ? *count_dev : count);
+  const double inv_count = count_dev ? 1.0 / *count_dev : inv_count_host;  // (host-known count: no f64 division per thread)
   for (int c = threadIdx.x; c < d; c += 256) {
     coef[c] = mean[c]; coef[d + c] = rstd[c]; coef[2 * d + c] = gamma[c]; coef[3 * d + c] = beta[c];
     coef[4 * d + c] = training ? (float)(sums[c] * inv_count) : 0.f;
@@ -484,8 +485,9 @@ extern "C" int mi355x_bn_stats_swish_fwd(const void* x, const void* stats, doubl
     return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(dt, TT, MI_LAUNCH((bn_stats_swish_fwd_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256), 0, s, (const TT*)x,
-                                (const double*)stats, count, (const double*)count_dev, (const float*)gamma, (const float*)beta,
-                                (TT*)y, (float*)mean, (float*)rstd, (float*)running_mean, (float*)running_var, momentum, eps, M, d));
+                                (const double*)stats, count, count_dev ? 0.0 : 1.0 / count, (const double*)count_dev, (const float*)gamma,
+                                (const float*)beta, (TT*)y, (float*)mean, (float*)rstd, (float*)running_mean, (float*)running_var,
+                                momentum, eps, M, d));
   return mi_check_launch();
 }
 // second stage of the BatchNorm-backward reduction: sums[i] (f64) += the slab column sums, and the parameter gradients (which
@@ -555,8 +557,8 @@ static int bn_swish_bwd_apply_launch(const void* dy, const void* x, const void* 
   DISPATCH_DT(dt, TT, MI_LAUNCH((bn_swish_bwd_apply_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256),
                                          (size_t)d * 6 * sizeof(float), s,
                                          (const TT*)dy, (const TT*)x, (const float*)mean, (const float*)rstd, (const float*)gamma,
-                                         (const float*)beta, (const double*)sums, count, (const double*)count_dev, training,
-                                         (TT*)dx, M, d));
+                                         (const float*)beta, (const double*)sums, count_dev ? 0.0 : 1.0 / count,
+                                         (const double*)count_dev, training, (TT*)dx, M, d));
   return mi_check_launch();
 }
 extern "C" int mi355x_bn_param_grad(const void* sums, void* dgamma, void* dbeta, int d, void* stream) {
