@@ -1193,11 +1193,12 @@ class ConformerEncoder(NeuralModule):
             ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
             ops.bn_eval_stats(bn.running_mean, bn.running_var, bmean, brstd, bn.eps, d)
         z = self._new(M, d, dtype=cdt, device=dev)
-        if training:  # statistics finalised inside the kernel (mean / rstd for backward, running statistics)
-            ops.bn_stats_swish_fwd(cc, stats, count, bn.weight, bn.bias, z, bmean, brstd, bn.running_mean, bn.running_var,
-                                   bn.momentum, bn.eps, M, d)
-        else:
-            ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, M, d)
+        if training:
+            # (two launches on purpose: the one-launch form, mi355x_bn_stats_swish_fwd, makes EVERY workgroup derive the
+            #  coefficients of its channels from the f64 sums and measured 31 us against 15.5 us for this pair,
+            #  tools/bn_bench.py)
+            ops.bn_finalize(stats, count, bmean, brstd, bn.running_mean, bn.running_var, bn.momentum, bn.eps, d)
+        ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, M, d)
         r3 = self._new(M, d, dtype=torch.float32, device=dev)
         d_cres = drop(self.dropout, site + 4)
         ops.gemm(z, W[f"L{i}.conv.pw2"], r3, M, d, d, d, W.pitch(f"L{i}.conv.pw2"), d, bias=c.pointwise_conv2.bias,

@@ -476,11 +476,12 @@ class SqueezeformerEncoder(ConformerEncoder):
             ops.dwconv_fwd(gact, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T, C2, k)
             ops.bn_eval_stats(bn.running_mean, bn.running_var, bmean, brstd, bn.eps, C2)
         z = self._new(M, C2, dtype=cdt, device=dev)
-        if training:  # statistics finalised inside the kernel (mean / rstd for backward, running statistics)
-            ops.bn_stats_swish_fwd(cc, stats, count, bn.weight, bn.bias, z, bmean, brstd, bn.running_mean, bn.running_var,
-                                   bn.momentum, bn.eps, M, C2)
-        else:
-            ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, M, C2)
+        if training:
+            # (two launches on purpose: the one-launch form, mi355x_bn_stats_swish_fwd, makes EVERY workgroup derive the
+            #  coefficients of its channels from the f64 sums and measured 31 us against 15.5 us for this pair,
+            #  tools/bn_bench.py)
+            ops.bn_finalize(stats, count, bmean, brstd, bn.running_mean, bn.running_var, bn.momentum, bn.eps, C2)
+        ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, M, C2)
         r3 = self._new(M, d, dtype=torch.float32, device=dev)
         d_cres = drop(self.dropout, site + 6)
         ops.gemm(z, W[f"L{i}.conv.pw2"], r3, M, d, C2, C2, W.pitch(f"L{i}.conv.pw2"), d, bias=c.pointwise_conv2.bias,
