@@ -34,7 +34,7 @@ class GradSync:
             wire_dtype = torch.bfloat16
         if wire_dtype not in (None, torch.float32, torch.bfloat16):
             raise ValueError("wire_dtype: float32 (default) or bfloat16")
-        self.wire_dtype = torch.bfloat16 if (wire_dtype == torch.bfloat16 and grad.is_cuda) else None
+        self.wire_dtype = torch.bfloat16 if wire_dtype == torch.bfloat16 else None
         self._staging = None
         self.bucket_elems = max(1, bucket_bytes // grad.element_size())
         self.group = group
@@ -92,6 +92,12 @@ class GradSync:
         st = self._staging[:n]
         if n % 8:
             raise RuntimeError("gradient ranges are 64-element aligned (FlatParams.ALIGN)")
+        if not view.is_cuda:  # host tensors (the gloo tests of this bookkeeping): the same two casts in torch
+            st.copy_(view * (1.0 / self.world))
+            work = dist.all_reduce(st, group=self.group, async_op=True)
+            work.wait()
+            view.copy_(st)
+            return work
         ops.drop_scale_cast(view, st, n, 1.0 / self.world)
         work = dist.all_reduce(st, group=self.group, async_op=True)
         work.wait()  # stream-level: the widening copy below is ordered behind the collective, the host does not block

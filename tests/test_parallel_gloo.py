@@ -53,6 +53,43 @@ def test_bucketed_grad_sync_world2_gloo():
     assert dict(ret) == {0: True, 1: True}
 
 
+def _worker_bf16_wire(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nemo_amd.parallel import GradSync
+        n = 64 * 40
+        g = torch.Generator().manual_seed(100 + rank)
+        grad = torch.randn(n, generator=g)
+        mine = grad.clone()
+        gs = GradSync(grad, bucket_bytes=64 * 4 * 8, wire_dtype=torch.bfloat16)
+        for layer in range(7, -1, -1):
+            gs.ready(64 * 5 * layer, 64 * 5 * (layer + 1))
+        scale = gs.wait()
+        # what every rank must hold: sum over ranks of bf16(g_r / world), accumulated in bf16 by the collective -- i.e. the mean
+        # to bf16 precision, already scaled (grad_scale 1), identical bits on all ranks
+        others = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+        mean = sum(others) / world
+        err = (grad * scale - mean).abs().max().item()
+        gathered = [torch.empty_like(grad) for _ in range(world)]
+        dist.all_gather(gathered, grad)
+        ret[rank] = bool(scale == 1.0 and err < 2e-2 and all(torch.equal(gathered[0], t) for t in gathered)
+                         and torch.equal(mine, others[rank]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_gradient_wire_world2_gloo():
+    """GradSync(wire_dtype=bfloat16): buckets are pre-scaled by 1 / world, rounded to bf16, all-reduced and widened back; the
+    optimizer's remaining factor is 1 and every rank ends with the same bits"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_bf16_wire, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
 def _torch_adamw(p, g, m, v, lr, b1, b2, eps, wd, step, grad_scale=1.0, clip_coef=None, ema=None, ema_decay=0.0):
     """host stand-in for the HIP launch (same update rule, adamw_kernel in csrc/optim.hip) so the slice bookkeeping of
     the optimizer-behind-backward path can run on CPU"""
