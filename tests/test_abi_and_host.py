@@ -481,3 +481,23 @@ def test_lr_schedules_of_the_neighbouring_recipes():
     assert c.lr_at(1000) == pytest.approx(1e-4) and c.lr_at(2000) == 1e-4
     lrs = [c.step() for _ in range(3)]
     assert lrs == [c.lr_at(1), c.lr_at(2), c.lr_at(3)] and c.get_last_lr() == lrs[-1]
+
+
+def test_bench_refuses_a_multi_gpu_job_it_cannot_place():
+    """`python bench.py --gpus N` launches its own ranks; with fewer than N GPUs visible (none in this container) it must exit
+    non-zero WITHOUT a JSON line -- never a silent N = 1 measurement under an N > 1 flag; under a launcher, a world size that
+    disagrees with --gpus is refused the same way"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("an 8-GPU node can place this job")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "{" not in r.stdout and "refusing" in r.stderr, (r.returncode, r.stdout[-200:], r.stderr[-300:])
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "{" not in r.stdout and "WORLD_SIZE=2" in r.stderr, (r.returncode, r.stdout[-200:], r.stderr[-300:])
+
