@@ -47,7 +47,7 @@ class Arena:
         n = 1
         for k in shape:
             n *= int(k)
-        nbytes = n * torch.empty((), dtype=dtype).element_size() if False else n * _ITEM[dtype]
+        nbytes = n * _ITEM[dtype]
         step = (nbytes + 255) & ~255
         self.need += step
         buf = self.buf

@@ -501,3 +501,30 @@ def test_bench_refuses_a_multi_gpu_job_it_cannot_place():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "{" not in r.stdout and "WORLD_SIZE=2" in r.stderr, (r.returncode, r.stdout[-200:], r.stderr[-300:])
 
+
+def test_step_scoped_arena_bookkeeping():
+    """nemo_amd.arena.Arena on host tensors: the first cycle only measures (everything comes from torch.empty), the next rewind
+    sizes the buffer to 1.25 x the demand, tensors are 256-byte aligned views handed out front to back, a cycle that outgrows the
+    buffer overflows into torch.empty and the buffer grows at the NEXT rewind (the outgrown one stays alive for recorded graphs)"""
+    from nemo_amd.arena import Arena
+    dev = torch.device("cpu")
+    a = Arena("t")
+    a.rewind(dev)
+    x = a.take((3, 5), torch.float32, dev)
+    assert a.buf is None and x.shape == (3, 5) and a.need == 256
+    a.take((1000,), torch.bfloat16, dev)
+    need1 = a.need
+    a.rewind(dev)
+    assert a.buf is not None and a.buf.numel() >= int(need1 * 1.25) and a.gen == 2 and a.off == 0
+    base = a.buf.data_ptr()
+    t1 = a.take((3, 5), torch.float32, dev)
+    t2 = a.take((1000,), torch.bfloat16, dev)
+    assert t1.data_ptr() == base and t2.data_ptr() == base + 256 and t2.dtype == torch.bfloat16 and t2.numel() == 1000
+    t1.fill_(1.0); t2.fill_(2.0)
+    assert float(t1.sum()) == 15.0 and float(t2.float().sum()) == 2000.0  # disjoint storage
+    big = a.take((a.buf.numel(),), torch.uint8, dev)  # does not fit behind t1 / t2: overflow path
+    assert not (base <= big.data_ptr() < base + a.buf.numel())
+    old = a.buf
+    a.rewind(dev)
+    assert a.buf is not old and a.retired and a.retired[-1] is old and a.buf.numel() > old.numel()
+
