@@ -246,8 +246,9 @@ int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, lon
 /* backward of the fused attention.  delta[b,h,i] = sum_dv dO*(O + O_lo) (O_lo optional, see above).  dq kernel: qu = q+u, qv = q+v ([B*T,d] bf16, from
  * mi355x_qbias), recomputes P from lse, returns dQu and dQv ([B*T,d] bf16; dq = dQu+dQv, d pos_bias_{u,v} = column sums). */
 int mi355x_attn_delta(const void* dO, const void* O, const void* O_lo, void* delta, int B, int H, int T, int d, void* stream);
-/* mi355x_attn_delta and mi355x_qbias (q = the first d columns of qkv rows of pitch ldq) in ONE pass over the rows: everything the
- * fused backward kernels need in front of them.  All pointers 16-byte aligned, ldq % 8 == 0. */
+/* mi355x_attn_delta and mi355x_qbias (q = the first d columns of qkv rows of pitch ldq; multi_head_attention.py:288-291: q + pos_bias_u,
+ * q + pos_bias_v) in ONE pass over the rows: everything the fused backward kernels need in front of them.  All pointers 16-byte
+ * aligned, ldq % 8 == 0. */
 int mi355x_attn_bwd_prep(const void* dO, const void* O, const void* O_lo, void* delta, const void* qkv, long long ldq,
                          const void* bias_u, const void* bias_v, void* qu, void* qv, int B, int H, int T, int d, void* stream);
 /* ds_out (optional): the score gradient in the layout of the reference's matrix_bd BEFORE rel_shift
@@ -296,8 +297,10 @@ int mi355x_bn_eval_stats(const void* running_mean, const void* running_var, void
                          void* stream);
 int mi355x_bn_swish_fwd(const void* x, const void* mean, const void* rstd, const void* gamma, const void* beta, void* y,
                         int dtype, long long M, int d, void* stream);
-/* training forward in one launch: mean / rstd from the f64 sums (as mi355x_bn_finalize: `count` positions, or the count read
- * from device memory when count_dev != NULL), written out for backward, running statistics updated, y = swish(BN(x)) */
+/* training forward in one launch (nn.BatchNorm1d in training mode + Swish, conformer_modules.py:339-342): mean / rstd from the f64
+ * sums (as mi355x_bn_finalize: `count` positions, or the count read from device memory when count_dev != NULL), written out for
+ * backward, running statistics updated, y = swish(BN(x)).  Measured slower than mi355x_bn_finalize + mi355x_bn_swish_fwd at the
+ * Large shape (every workgroup derives its channels' coefficients; tools/bn_bench.py) -- the encoders use the pair. */
 int mi355x_bn_stats_swish_fwd(const void* x, const void* stats, double count, const void* count_dev, const void* gamma,
                               const void* beta, void* y, void* mean, void* rstd, void* running_mean, void* running_var,
                               float momentum, float eps, int dtype, long long M, int d, void* stream);
