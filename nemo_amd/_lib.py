@@ -62,6 +62,8 @@ SIGNATURES = {
     "mi355x_gemm_config": [i32, i32],
     "mi355x_set_step_counter": [vp],
     "mi355x_set_null_launch": [i32],
+    "mi355x_ffn_fwd": [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, f32, u32, u32, f32, u32, u32, f32, vp],
+    "mi355x_ffn_bwd_dgrad": [vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, u32, u32, f32, vp],
     "mi355x_logmel_fwd": [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, f32, u32, f32, vp, i32, i32, i32, vp],
     "mi355x_feat_normalize": [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp],
     "mi355x_subsample_conv1_fwd": [vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp],

@@ -276,6 +276,7 @@ class ConformerEncoder(NeuralModule):
         self._wg_pending, self._wg_rows = None, None
         self.conv2_implicit = os.environ.get("MI355X_CONV2_IMPLICIT", "1") != "0"
         self.ln_cast_fuse = os.environ.get("MI355X_LN_CAST_FUSE", "1") != "0"
+        self.ffn_fused = os.environ.get("MI355X_FFN_FUSED", "1") != "0"   # one-launch feed-forward blocks (csrc/ffn.hip)
         self.dpos_side_stream = os.environ.get("MI355X_DPOS_STREAM", "1") != "0"
         self.sub_wgrad_side_stream = os.environ.get("MI355X_SUB_WGRAD_STREAM", "1") != "0"
         self._plans = {}
@@ -431,6 +432,13 @@ class ConformerEncoder(NeuralModule):
             _, dkp, dA = self._geometry(cdt)
             for i, L in enumerate(self.layers):
                 for ff, m in (("ff1", L.feed_forward1), ("ff2", L.feed_forward2)):
+                    if self._ffn_fused_ok(cdt):
+                        # the fused feed-forward kernels (csrc/ffn.hip) stream their weights in the order their steps consume them
+                        p.add_ffn_k512(f"L{i}.{ff}.w1p", m.linear1.weight.data)
+                        p.add_ffn_kchunk(f"L{i}.{ff}.w2p", m.linear2.weight.data)
+                        p.add_ffn_k512(f"L{i}.{ff}.w2tp", m.linear2.weight.data, transpose=True)
+                        p.add_ffn_kchunk(f"L{i}.{ff}.w1tp", m.linear1.weight.data, transpose=True)
+                        continue
                     p.add_matrix(f"L{i}.{ff}.w1", m.linear1.weight.data); p.add_matrix(f"L{i}.{ff}.w1t", m.linear1.weight.data, True)
                     p.add_matrix(f"L{i}.{ff}.w2", m.linear2.weight.data); p.add_matrix(f"L{i}.{ff}.w2t", m.linear2.weight.data, True)
                 a = L.self_attn
@@ -961,6 +969,12 @@ class ConformerEncoder(NeuralModule):
         ops.layernorm_fwd(x, ln.weight, ln.bias, y, mean, rstd, M, d, ln.eps)
         return y, mean, rstd
 
+    def _ffn_fused_ok(self, cdt):
+        """the one-launch feed-forward kernels cover bf16, d_model = 512, 128 <= d_ff <= 2048, d_ff % 64 == 0 (Conformer-CTC-Large,
+        FastConformer-Large); MI355X_FFN_FUSED=0 keeps the GEMM pair (A/B switch)"""
+        return (self.ffn_fused and cdt == torch.bfloat16 and self.d_model == 512 and self.d_ff % 64 == 0
+                and 128 <= self.d_ff <= 2048)
+
     def _ffn_fwd(self, pfx, ff, x, ln, S, sl, W, drop, site, M, d, dff, cdt, dev, tag):
         pre = getattr(S, "pre_ln", None)
         if pre is not None and tag == "ff1":  # the previous layer's output norm already normalised this layer's input
@@ -969,9 +983,16 @@ class ConformerEncoder(NeuralModule):
         else:
             y, mean, rstd = self._ln_fwd(ln, x, M, d, cdt, dev)
         h = self._new(M, dff, dtype=cdt, device=dev)
-        a = self._new(M, dff, dtype=cdt, device=dev)
         d_in = drop(self.dropout, site)
         d_res = drop(self.dropout, site + 1)
+        if self._ffn_fused_ok(cdt):
+            # conformer_modules.py:366-387 + the macaron residual (:174-181, :209-215) in ONE launch; the activated hidden never
+            # reaches memory (backward recomputes it from h for the linear2 weight gradient)
+            r = self._new(M, d, dtype=torch.float32, device=dev)
+            ops.ffn_fwd(y, W[pfx + ".w1p"], ff.linear1.bias, W[pfx + ".w2p"], ff.linear2.bias, x, h, r, M, d, dff, 0.5, d_in, d_res)
+            setattr(sl, tag, (x, y, mean, rstd, h, None, d_in, d_res))
+            return r
+        a = self._new(M, dff, dtype=cdt, device=dev)
         ops.gemm(y, W[pfx + ".w1"], a, M, dff, d, d, W.pitch(pfx + ".w1"), dff, bias=ff.linear1.bias, epi=ops.EPI_SWISH_DROP,
                  aux_out=h, drop=d_in)
         r = self._new(M, d, dtype=torch.float32, device=dev)
@@ -1381,12 +1402,18 @@ class ConformerEncoder(NeuralModule):
         if df is None:
             df = self._new(M, d, dtype=cdt, device=dev)
             ops.drop_scale_cast(dr, df, M * d, 0.5, d_res)
-        self._wgrad(df, d, 0, a, dff, 0, ff.linear2.weight.grad, d, dff, M, bias_grad=ff.linear2.bias.grad)
         dh = self._new(M, dff, dtype=cdt, device=dev)
-        ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, d, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH, aux_in=h, drop=d_in)
-        self._wgrad(dh, dff, 0, y, d, 0, ff.linear1.weight.grad, dff, d, M, bias_grad=ff.linear1.bias.grad)
         dy = self._new(M, d, dtype=cdt, device=dev)
-        ops.gemm(dh, W[pfx + ".w1t"], dy, M, d, dff, dff, W.pitch(pfx + ".w1t"), d)
+        if a is None:  # fused forward: the input-gradient chain in one launch, which also re-creates linear2's weight-gradient operand
+            a = self._new(M, dff, dtype=cdt, device=dev)
+            ops.ffn_bwd_dgrad(df, W[pfx + ".w2tp"], W[pfx + ".w1tp"], h, dh, a, dy, M, d, dff, d_in)
+            self._wgrad(df, d, 0, a, dff, 0, ff.linear2.weight.grad, d, dff, M, bias_grad=ff.linear2.bias.grad)
+            self._wgrad(dh, dff, 0, y, d, 0, ff.linear1.weight.grad, dff, d, M, bias_grad=ff.linear1.bias.grad)
+        else:
+            self._wgrad(df, d, 0, a, dff, 0, ff.linear2.weight.grad, d, dff, M, bias_grad=ff.linear2.bias.grad)
+            ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, d, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH, aux_in=h, drop=d_in)
+            self._wgrad(dh, dff, 0, y, d, 0, ff.linear1.weight.grad, dff, d, M, bias_grad=ff.linear1.bias.grad)
+            ops.gemm(dh, W[pfx + ".w1t"], dy, M, d, dff, dff, W.pitch(pfx + ".w1t"), d)
         nxt = self._cast_buf(next_cast, M, d, cdt, dev)
         if boundary is not None:
             ln_lo, r4, mean5, rstd5 = boundary

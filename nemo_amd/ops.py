@@ -258,6 +258,21 @@ def cast_rows(src, ld_in, dst, ld_out, M, N, Np, alpha=1.0):
 
 
 # ------------------------------------------------------------------------------------------------ norms / reductions
+def ffn_fwd(y, w1p, b1, w2p, b2, x, h, out, M, d, dff, alpha=0.5, drop_in: Dropout = NO_DROP, drop_res: Dropout = NO_DROP):
+    """fused feed-forward block (mi355x_ffn_fwd): h = y @ W1^T + b1 (bf16, kept for backward), out = x + alpha * drop(drop(swish(h))
+    @ W2^T + b2); w1p / w2p are the packed images PackPlan.add_ffn_k512 / add_ffn_kchunk build.  d = 512 only."""
+    check(lib.mi355x_ffn_fwd(_ptr(y), d, _ptr(w1p), _ptr(b1), _ptr(w2p), _ptr(b2), _ptr(x), d, _ptr(h), dff, _ptr(out), d, M, d, dff,
+                             alpha, drop_in.key, drop_in.threshold, drop_in.scale, drop_res.key, drop_res.threshold,
+                             drop_res.scale, _stream()), "ffn_fwd")
+
+
+def ffn_bwd_dgrad(df, w2tp, w1tp, h, dh, act, dy, M, d, dff, drop_in: Dropout = NO_DROP):
+    """input-gradient chain of the fused feed-forward block (mi355x_ffn_bwd_dgrad): dh, the recomputed activation `act` (both
+    bf16 [M, dff], the weight-gradient operands) and dy = dh @ W1 (bf16 [M, d])"""
+    check(lib.mi355x_ffn_bwd_dgrad(_ptr(df), d, _ptr(w2tp), _ptr(w1tp), _ptr(h), dff, _ptr(dh), _ptr(act), _ptr(dy), d, M, d, dff,
+                                   drop_in.key, drop_in.threshold, drop_in.scale, _stream()), "ffn_bwd_dgrad")
+
+
 def layernorm2_fwd(x, gamma1, beta1, y1, mean1, rstd1, gamma2, beta2, y2, mean2, rstd2, M, d, eps=1e-5):
     """y1 = LN1(x) (f32), y2 = LN2(y1) (dtype of y2) in one launch; d = 512"""
     check(lib.mi355x_layernorm2_fwd(_ptr(x), _ptr(gamma1), _ptr(beta1), _ptr(y1), _ptr(mean1), _ptr(rstd1), _ptr(gamma2), _ptr(beta2),

@@ -99,6 +99,27 @@ class PackPlan:
             self.add_block(name, w, F_ * C_, d, nr2=C_, nc2=1, sr1=1, sr2=F_, sc1=C_ * F_)
         return name
 
+    # ---- images of the fused feed-forward kernels (csrc/ffn.hip): the order in which the kernel's steps consume the weights,
+    # MFMA-fragment-major, so that every LDS-DMA piece is 1 KiB of contiguous memory and every fragment read a linear burst
+    def add_ffn_k512(self, name: str, w: torch.Tensor, transpose: bool = False):
+        """logical A [dff, 512] (= w, or w^T when `transpose` and w is [512, dff]) ->
+        flat[((c*32 + k16)*64 + r)*16 + e] = A[c*64 + r][k16*16 + e]"""
+        dff, K = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+        assert K == 512 and dff % 64 == 0
+        rs, cs = (1, dff) if transpose else (K, 1)  # element strides of A's row / column index in w's storage
+        self.new_image(name, (dff // 64) * 32, 1024)
+        self.add_block(name, w, (dff // 64) * 32, 1024, nr2=32, nc2=16, sr1=64 * rs, sr2=16 * cs, sc1=rs, sc2=cs)
+        return name
+
+    def add_ffn_kchunk(self, name: str, w: torch.Tensor, transpose: bool = False):
+        """logical B [512, dff] (= w, or w^T when `transpose` and w is [dff, 512]) -> flat[(t*512 + o)*16 + e] = B[o][t*16 + e]"""
+        O, dff = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+        assert O == 512 and dff % 64 == 0
+        rs, cs = (1, O) if transpose else (dff, 1)
+        self.new_image(name, dff // 16, 512 * 16)
+        self.add_block(name, w, dff // 16, 512 * 16, nr2=1, nc2=16, sr1=16 * cs, sc1=rs, sc2=cs)
+        return name
+
     # ------------------------------------------------------------------ materialisation
     def finalize(self) -> None:
         self.arena = torch.zeros(max(self._size, 64), dtype=self.dtype, device=self.device)
