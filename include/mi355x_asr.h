@@ -92,10 +92,12 @@ int mi355x_gemm_grouped(const mi355x_gemm_desc* descs, int n, void* stream);
  * One launch: h (bf16 [M, d_ff], pitch ldh) = y @ W1^T + b1 is the only intermediate that reaches memory (backward needs it);
  * out f32 [M, 512] = x_resid + alpha * drop_res( drop_in(swish(h)) @ W2^T + b2 ).  y = LayerNorm output, bf16 [M, 512].
  * Dropout indices are those of the unfused GEMM epilogues: element (m, n) of [M, d_ff] resp. [M, 512] -> m * N + n.
- * The weights are PACKED bf16 images (nemo_amd/packing.py builds them with mi355x_pack_weights):
- *   w1_packed ("k512" order, logical [d_ff][512] K-contiguous):  flat[((c*32 + k16)*64 + r)*16 + e] = W1[c*64 + r][k16*16 + e]
- *   w2_packed ("kchunk" order, logical [512][d_ff]):              flat[(t*512 + o)*16 + e]         = W2[o][t*16 + e]
- * d_ff % 64 == 0, d_ff <= 2048; all pointers 16-byte aligned; pitches multiples of 8 (ldx: of 4). */
+ * The weights are PACKED bf16 images written by mi355x_ffn_pack, MFMA-fragment-major in the order the kernel consumes them.  A
+ * fragment = 32 rows x 16 k = 1 KiB stored [hh][lr][8]: element (row lr, k = 8 hh + e) at (hh*32 + lr)*8 + e.
+ *   "k512"   order of a logical A [d_ff][512]: fragment of rows c*64 + mt*32 .. +31, k = k16*16 .. +15 at ((c*32 + k16)*2 + mt) KiB
+ *   "kchunk" order of a logical B [512][d_ff]: fragment of rows q*128 + mt4*32 .. +31, k = t*16 .. +15 at ((t*4 + q)*4 + mt4) KiB
+ * w1_packed = k512(W1), w2_packed = kchunk(W2).  128 <= d_ff <= 2048, d_ff % 64 == 0; all pointers 16-byte aligned; pitches
+ * multiples of 8 (ldx: of 4). */
 int mi355x_ffn_fwd(const void* y, long long ldy, const void* w1_packed, const void* b1, const void* w2_packed, const void* b2,
                    const void* x_resid, long long ldx, void* h, long long ldh, void* out, long long ldo, int M, int d_model,
                    int d_ff, float alpha, unsigned drop_in_key, unsigned drop_in_threshold, float drop_in_scale,
@@ -103,11 +105,16 @@ int mi355x_ffn_fwd(const void* y, long long ldy, const void* w1_packed, const vo
 /* Its input-gradient chain in one launch (autograd of the same lines): df bf16 [M, 512] = the gradient of the block's output
  * through the residual scale and dropout; g = df @ W2; dh = g * dropmask_in * swish'(h) -> bf16 [M, d_ff] (pitch ldh; operand of
  * the W1 weight gradient); act = drop_in(swish(h)) -> bf16 [M, d_ff] (pitch ldh; RECOMPUTED operand of the W2 weight gradient);
- * dy bf16 [M, 512] = dh @ W1 (gradient w.r.t. the LayerNorm output).  w2t_packed = "k512" image of W2^T ([d_ff][512]),
- * w1t_packed = "kchunk" image of W1^T ([512][d_ff]). */
+ * dy bf16 [M, 512] = dh @ W1 (gradient w.r.t. the LayerNorm output).  w2t_packed = k512(W2^T), w1t_packed = kchunk(W1^T). */
 int mi355x_ffn_bwd_dgrad(const void* df, long long lddf, const void* w2t_packed, const void* w1t_packed, const void* h,
                          long long ldh, void* dh, void* act, void* dy, long long lddy, int M, int d_model, int d_ff,
                          unsigned drop_in_key, unsigned drop_in_threshold, float drop_in_scale, void* stream);
+
+/* The four images of n weight matrices in one launch (no reference analogue; runs once per optimizer step next to
+ * mi355x_pack_weights).  Entry i: src = fp32 master weight, either linear1.weight [d_ff][512] (is_w2 = 0: writes k512(W1) and
+ * kchunk(W1^T)) or linear2.weight [512][d_ff] (is_w2 = 1: writes kchunk(W2) and k512(W2^T)); both destinations 512 * d_ff bf16. */
+typedef struct mi355x_ffn_pack_entry { const void* src; void* k512; void* kchunk; int d_ff; int is_w2; } mi355x_ffn_pack_entry;
+int mi355x_ffn_pack(const void* table_dev, int n_entries, int max_d_ff, void* stream);
 
 /* ---- log-mel front-end: FilterbankFeatures.forward, parts/preprocessing/features.py:423-502 --------------------
  * audio f32 [B,S], audio_len i64 [B] -> out f32 [B,n_mels,T] = log(mel_power + log_guard), T = 1 + S/hop.

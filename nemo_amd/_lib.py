@@ -45,6 +45,11 @@ class RowMap(C.Structure):  # mirrors mi355x_row_map
     _fields_ = [("nI", i32), ("nJ", i32), ("OI", i32), ("OJ", i32), ("si", i32), ("sj", i32), ("oi", i32), ("oj", i32)]
 
 
+class FfnPackEntry(C.Structure):
+    """mirror of `mi355x_ffn_pack_entry`"""
+    _fields_ = [("src", vp), ("k512", vp), ("kchunk", vp), ("d_ff", i32), ("is_w2", i32)]
+
+
 class PackEntry(C.Structure):
     """mirror of `mi355x_pack_entry`"""
     _fields_ = [
@@ -63,6 +68,7 @@ SIGNATURES = {
     "mi355x_set_step_counter": [vp],
     "mi355x_set_null_launch": [i32],
     "mi355x_ffn_fwd": [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, f32, u32, u32, f32, u32, u32, f32, vp],
+    "mi355x_ffn_pack": [vp, i32, i32, vp],
     "mi355x_ffn_bwd_dgrad": [vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, u32, u32, f32, vp],
     "mi355x_logmel_fwd": [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, f32, u32, f32, vp, i32, i32, i32, vp],
     "mi355x_feat_normalize": [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp],

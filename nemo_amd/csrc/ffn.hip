@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnP p) {
   const int x_m = m0 + x_row;
   const bool x_ok = x_m < p.M;
   const uint32_t x_rd = ff_lds_addr(smem + FF_HBUF) + (uint32_t)(x_row * 128 + ((x_ch ^ (x_row & 7)) * 16));
-  char* const x_wr = smem + ACT + (((x_row >> 5) * 4 + (x_ch >> 1)) * 32 + (x_row & 31)) * 32 + (x_ch & 1) * 16;
+  char* const x_wr = smem + ACT + x_row * 128 + ((x_ch ^ ((x_row >> 1) & 7)) * 16);
   const long long x_gi = (long long)x_m * p.ld_h + x_ch * 8;
   const uint32_t x_didx = (uint32_t)x_m * (uint32_t)p.dff + (uint32_t)(x_ch * 8);
   auto transform = [&](int c) {
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnP p) {
       *reinterpret_cast<u32x4*>(p.dh + gi) = o;
       *reinterpret_cast<u32x4*>(p.act + gi) = oa;
     }
-    // fragment-major image of the phase-2 token operand: [nt = row / 32][ks = ch / 2][row % 32][hh = ch % 2][8]
+    // the phase-2 token operand: row-major [64][64] bf16, chunks swizzled (see the phase-2 fragment reads)
     *reinterpret_cast<u32x4*>(x_wr + (c & 1) * 8192) = o;
   };
   auto step_end = [&](auto Fc) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnP p) {
     const int trow = nt * 32 + lr;   // token row of this lane inside the tile
     const uint32_t b1_addr = ff_lds_addr(smem + FF_B1) + (uint32_t)((mt * 32 + 4 * hh) * 4);
     char* const hb_wr = smem + FF_HBUF + trow * 128 + hh * 8;
-    const char* const w_rd = smem + (mt * 32 + lr) * 32 + hh * 16;
+    const char* const w_rd = smem + mt * 1024 + lane * 16;   // fragment (ks, mt) = 1 KiB, linear in the lane index
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // image steps 0 and 1 landed
     __builtin_amdgcn_s_barrier();
     bf16x8 a[8];     // A fragments (this wave's 32 weight rows x 16 k each) of the step about to be multiplied
@@ -360,8 +360,12 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnP p) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
-    const char* const a_rd = smem + ACT + lr * 32 + hh * 16;
-    const char* const w_rd = smem + FF_WPART + q * 4096 + lr * 32 + hh * 16;
+    // activated chunk: [64 token rows][64 k] bf16 rows of 128 B, 16-B chunks XOR-swizzled by (row / 2) % 8 (conflict-free for the
+    // fragment reads below -- a 16-lane group of ds_read_b128 sees 16 distinct (row parity, chunk) pairs -- and for the
+    // transform's row-contiguous writes); weight slab: fragments linear in the lane index
+    const char* const a_rd = smem + ACT + lr * 128;
+    const int a_sw = (lr >> 1) & 7;
+    const char* const w_rd = smem + FF_WPART + q * 4096 + lane * 16;
     bf16x8 fa[2], fb[4];      // fragments of the NEXT step's MFMAs
 #pragma unroll
     for (int e = 0; e < 8; ++e) fa[0][e] = (__bf16)0.f;
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnP p) {
       constexpr int J = decltype(Jc)::value, F = decltype(Fc)::value;
       constexpr int jn = (J + 2) & 3;
       const int cn = J < 2 ? P - 2 : P - 1;
-      const char* asl = a_rd + (cn & 1) * 8192 + jn * 1024;
+      const char* asl = a_rd + (cn & 1) * 8192 + (((jn * 2 + hh) ^ a_sw) * 16);
       const char* wsl = w_rd + J * FF_SLOT;
       FF_TS(0)
       if constexpr (BWD && J == 2 && (F & HD)) issue_hin(P);
@@ -495,6 +499,68 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnP p) {
       }
     }
   }
+}
+
+// ================================================================================================= weight images
+// The two image orders of the fused kernels, written straight from the fp32 master weights (one 64 x 64 source tile per
+// workgroup through LDS: coalesced 256-B reads of the source, 16-B bf16 stores of whole MFMA fragment lanes).  A FRAGMENT is the
+// 1 KiB a wave reads with ONE ds_read_b128: 32 rows x 16 k, lane l = lr + 32 hh holds row lr, k = 8 hh .. 8 hh + 7 -- stored
+// [hh][lr][8], i.e. linear in the lane index (the first version stored [lr][hh][8]: every fragment read was a 2-way bank
+// conflict, SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE, profiles/r4_ffn_fused.md).
+//   "k512"   image of a logical A [dff][512]:  frag (c = row / 64, k16 = k / 16, mt = (row % 64) / 32) at ((c * 32 + k16) * 2 + mt) KiB
+//   "kchunk" image of a logical B [512][dff]:  frag (t = k / 16, q = row / 128, mt4 = (row % 128) / 32) at ((t * 4 + q) * 4 + mt4) KiB
+// W1 [dff][512] gives k512(W1) (forward phase 1) and kchunk(W1^T) (backward phase 2); W2 [512][dff] gives kchunk(W2) (forward
+// phase 2) and k512(W2^T) (backward phase 1).
+struct FfnPackEntry { const float* src; bf16_t* k512; bf16_t* kchunk; int dff; int is_w2; };
+__global__ __launch_bounds__(256) void ffn_pack_kernel(const FfnPackEntry* __restrict__ tab) {
+  __shared__ float tile[64][65];
+  const FfnPackEntry e = tab[blockIdx.y];
+  const int C = e.is_w2 ? e.dff : FF_D;             // source row length
+  const int tiles_c = C / 64;
+  const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
+  if (tr * 64 >= (e.is_w2 ? FF_D : e.dff)) return;
+  const float* src = e.src + (long long)tr * 64 * C + tc * 64;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int qd = threadIdx.x + k * 256;
+    const int f4 = (qd & 15) * 4, rr = qd >> 4;
+    const float4 v = *reinterpret_cast<const float4*>(src + (long long)rr * C + f4);
+    tile[rr][f4] = v.x; tile[rr][f4 + 1] = v.y; tile[rr][f4 + 2] = v.z; tile[rr][f4 + 3] = v.w;
+  }
+  __syncthreads();
+  // dff-side origin X0 and 512-side origin Y0 of this tile
+  const int X0 = e.is_w2 ? tc * 64 : tr * 64, Y0 = e.is_w2 ? tr * 64 : tc * 64;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int pc = threadIdx.x + k * 256;            // piece (p, mtl, hh, lr)
+    const int lr = pc & 31, hh = (pc >> 5) & 1, mtl = (pc >> 6) & 1, p4 = pc >> 7;
+    float rw[8], cw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      rw[j] = tile[mtl * 32 + lr][p4 * 16 + hh * 8 + j];   // row-wise piece: rows of the tile are the fragment rows
+      cw[j] = tile[p4 * 16 + hh * 8 + j][mtl * 32 + lr];   // column-wise piece: columns of the tile are the fragment rows
+    }
+    const u32x4 rv = {pack_bf2(rw[0], rw[1]), pack_bf2(rw[2], rw[3]), pack_bf2(rw[4], rw[5]), pack_bf2(rw[6], rw[7])};
+    const u32x4 cv = {pack_bf2(cw[0], cw[1]), pack_bf2(cw[2], cw[3]), pack_bf2(cw[4], cw[5]), pack_bf2(cw[6], cw[7])};
+    // W1: rows = dff side (fragment rows of k512 come from tile ROWS, k from tile columns); kchunk(W1^T) fragment rows = the 512 side
+    // W2: rows = 512 side: kchunk(W2) fragment rows come from tile ROWS; k512(W2^T) fragment rows (dff side) from tile COLUMNS
+    const long long i512 = ((((long long)(X0 / 64) * 32 + Y0 / 16 + p4) * 2 + mtl) * 2 + hh) * 256 + lr * 8;
+    const long long ichk = (((((long long)(X0 / 16 + p4)) * 4 + Y0 / 128) * 4 + (Y0 % 128) / 32 + mtl) * 2 + hh) * 256 + lr * 8;
+    if (!e.is_w2) {
+      *reinterpret_cast<u32x4*>(e.k512 + i512) = rv;
+      *reinterpret_cast<u32x4*>(e.kchunk + ichk) = cv;
+    } else {
+      *reinterpret_cast<u32x4*>(e.kchunk + ichk) = rv;
+      *reinterpret_cast<u32x4*>(e.k512 + i512) = cv;
+    }
+  }
+}
+extern "C" int mi355x_ffn_pack(const void* table_dev, int n_entries, int max_dff, void* stream) {
+  mi_clear_errors();
+  if (!table_dev || n_entries <= 0 || max_dff < 2 * FF_NC || (max_dff % FF_NC) || max_dff > 2048) return MI_ERR_ARG;
+  MI_LAUNCH(ffn_pack_kernel, dim3((unsigned)(max_dff / 64 * (FF_D / 64)), (unsigned)n_entries), dim3(256), 0, (hipStream_t)stream,
+            (const FfnPackEntry*)table_dev);
+  return mi_check_launch();
 }
 
 static unsigned* g_ffn_trace = nullptr;

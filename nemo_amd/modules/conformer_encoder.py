@@ -434,10 +434,7 @@ class ConformerEncoder(NeuralModule):
                 for ff, m in (("ff1", L.feed_forward1), ("ff2", L.feed_forward2)):
                     if self._ffn_fused_ok(cdt):
                         # the fused feed-forward kernels (csrc/ffn.hip) stream their weights in the order their steps consume them
-                        p.add_ffn_k512(f"L{i}.{ff}.w1p", m.linear1.weight.data)
-                        p.add_ffn_kchunk(f"L{i}.{ff}.w2p", m.linear2.weight.data)
-                        p.add_ffn_k512(f"L{i}.{ff}.w2tp", m.linear2.weight.data, transpose=True)
-                        p.add_ffn_kchunk(f"L{i}.{ff}.w1tp", m.linear1.weight.data, transpose=True)
+                        p.add_ffn(f"L{i}.{ff}", m.linear1.weight.data, m.linear2.weight.data)
                         continue
                     p.add_matrix(f"L{i}.{ff}.w1", m.linear1.weight.data); p.add_matrix(f"L{i}.{ff}.w1t", m.linear1.weight.data, True)
                     p.add_matrix(f"L{i}.{ff}.w2", m.linear2.weight.data); p.add_matrix(f"L{i}.{ff}.w2t", m.linear2.weight.data, True)

@@ -260,10 +260,14 @@ def cast_rows(src, ld_in, dst, ld_out, M, N, Np, alpha=1.0):
 # ------------------------------------------------------------------------------------------------ norms / reductions
 def ffn_fwd(y, w1p, b1, w2p, b2, x, h, out, M, d, dff, alpha=0.5, drop_in: Dropout = NO_DROP, drop_res: Dropout = NO_DROP):
     """fused feed-forward block (mi355x_ffn_fwd): h = y @ W1^T + b1 (bf16, kept for backward), out = x + alpha * drop(drop(swish(h))
-    @ W2^T + b2); w1p / w2p are the packed images PackPlan.add_ffn_k512 / add_ffn_kchunk build.  d = 512 only."""
+    @ W2^T + b2); w1p / w2p are the packed images of PackPlan.add_ffn (mi355x_ffn_pack).  d = 512 only."""
     check(lib.mi355x_ffn_fwd(_ptr(y), d, _ptr(w1p), _ptr(b1), _ptr(w2p), _ptr(b2), _ptr(x), d, _ptr(h), dff, _ptr(out), d, M, d, dff,
                              alpha, drop_in.key, drop_in.threshold, drop_in.scale, drop_res.key, drop_res.threshold,
                              drop_res.scale, _stream()), "ffn_fwd")
+
+
+def ffn_pack(table_dev, n_entries, max_dff):
+    check(lib.mi355x_ffn_pack(_ptr(table_dev), n_entries, max_dff, _stream()), "ffn_pack")
 
 
 def ffn_bwd_dgrad(df, w2tp, w1tp, h, dh, act, dy, M, d, dff, drop_in: Dropout = NO_DROP):

@@ -34,6 +34,8 @@ class PackPlan:
         self._n = 0
         self._tiles = 0
         self._views: Dict[str, torch.Tensor] = {}
+        self._ffn: List[tuple] = []
+        self._ffn_table = None
 
     # ------------------------------------------------------------------ image declaration
     def new_image(self, name: str, rows: int, cols: int) -> None:
@@ -99,26 +101,17 @@ class PackPlan:
             self.add_block(name, w, F_ * C_, d, nr2=C_, nc2=1, sr1=1, sr2=F_, sc1=C_ * F_)
         return name
 
-    # ---- images of the fused feed-forward kernels (csrc/ffn.hip): the order in which the kernel's steps consume the weights,
-    # MFMA-fragment-major, so that every LDS-DMA piece is 1 KiB of contiguous memory and every fragment read a linear burst
-    def add_ffn_k512(self, name: str, w: torch.Tensor, transpose: bool = False):
-        """logical A [dff, 512] (= w, or w^T when `transpose` and w is [512, dff]) ->
-        flat[((c*32 + k16)*64 + r)*16 + e] = A[c*64 + r][k16*16 + e]"""
-        dff, K = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
-        assert K == 512 and dff % 64 == 0
-        rs, cs = (1, dff) if transpose else (K, 1)  # element strides of A's row / column index in w's storage
-        self.new_image(name, (dff // 64) * 32, 1024)
-        self.add_block(name, w, (dff // 64) * 32, 1024, nr2=32, nc2=16, sr1=64 * rs, sr2=16 * cs, sc1=rs, sc2=cs)
-        return name
-
-    def add_ffn_kchunk(self, name: str, w: torch.Tensor, transpose: bool = False):
-        """logical B [512, dff] (= w, or w^T when `transpose` and w is [dff, 512]) -> flat[(t*512 + o)*16 + e] = B[o][t*16 + e]"""
-        O, dff = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
-        assert O == 512 and dff % 64 == 0
-        rs, cs = (1, O) if transpose else (dff, 1)
-        self.new_image(name, dff // 16, 512 * 16)
-        self.add_block(name, w, dff // 16, 512 * 16, nr2=1, nc2=16, sr1=16 * cs, sc1=rs, sc2=cs)
-        return name
+    # ---- images of the fused feed-forward kernels (csrc/ffn.hip): MFMA-fragment-major, in the order the kernel's steps consume
+    # the weights; written by their own launch (mi355x_ffn_pack) straight from the fp32 master weights
+    def add_ffn(self, prefix: str, w1: torch.Tensor, w2: torch.Tensor) -> None:
+        """linear1.weight [dff, 512] and linear2.weight [512, dff] -> images `prefix.w1p` = k512(W1), `prefix.w1tp` = kchunk(W1^T),
+        `prefix.w2p` = kchunk(W2), `prefix.w2tp` = k512(W2^T), each 512 * dff bf16 (see include/mi355x_asr.h)"""
+        dff = w1.shape[0]
+        assert self.dtype == torch.bfloat16 and tuple(w1.shape) == (dff, 512) and tuple(w2.shape) == (512, dff) and dff % 64 == 0
+        assert w1.dtype == torch.float32 and w2.dtype == torch.float32 and w1.is_contiguous() and w2.is_contiguous()
+        for nm in ("w1p", "w1tp", "w2p", "w2tp"):
+            self.new_image(f"{prefix}.{nm}", dff // 2, 1024)   # (the view's shape is irrelevant: the kernels take the flat image)
+        self._ffn.append((prefix, w1, w2, dff))
 
     # ------------------------------------------------------------------ materialisation
     def finalize(self) -> None:
@@ -139,9 +132,19 @@ class PackPlan:
             e.tile_begin = tiles
             tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
         raw = bytes(entries)
-        self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device) if raw else None
         self._n, self._tiles = len(self._pending), tiles
         self._srcs = [p[1] for p in self._pending]  # keep sources alive
+        if self._ffn:
+            from ._lib import FfnPackEntry
+            fe = (FfnPackEntry * (2 * len(self._ffn)))()
+            for i, (prefix, w1, w2, dff) in enumerate(self._ffn):
+                off = {nm: self._images[f"{prefix}.{nm}"][0] for nm in ("w1p", "w1tp", "w2p", "w2tp")}
+                a, b = fe[2 * i], fe[2 * i + 1]
+                a.src, a.k512, a.kchunk, a.d_ff, a.is_w2 = w1.data_ptr(), base + off["w1p"] * es, base + off["w1tp"] * es, dff, 0
+                b.src, b.k512, b.kchunk, b.d_ff, b.is_w2 = w2.data_ptr(), base + off["w2tp"] * es, base + off["w2p"] * es, dff, 1
+            self._ffn_table = torch.frombuffer(bytearray(bytes(fe)), dtype=torch.uint8).to(self.device)
+            self._srcs += [t for f in self._ffn for t in (f[1], f[2])]
         for name, (off, rows, pitch) in self._images.items():
             self._views[name] = self.arena[off: off + rows * pitch].view(rows, pitch)
 
@@ -151,6 +154,8 @@ class PackPlan:
     def run(self) -> None:
         if self._n:
             ops.pack_weights(self._table, self._n, self._tiles, ops.dt(self.dtype))
+        if self._ffn:
+            ops.ffn_pack(self._ffn_table, 2 * len(self._ffn), max(f[3] for f in self._ffn))
 
     def __getitem__(self, name: str) -> torch.Tensor:
         return self._views[name]

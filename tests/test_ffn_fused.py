@@ -1,7 +1,7 @@
 """Fused feed-forward block (csrc/ffn.hip: mi355x_ffn_fwd / mi355x_ffn_bwd_dgrad).
 
-CPU: the packed weight images (PackPlan.add_ffn_k512 / add_ffn_kchunk) are the order documented in include/mi355x_asr.h -- checked
-by evaluating the pack entries' index maps in numpy.  GPU (-m gpu): the kernels against (a) an fp32 torch restatement of
+CPU: PackPlan.add_ffn book-keeping.  GPU (-m gpu): mi355x_ffn_pack against a numpy statement of the fragment orders documented in
+include/mi355x_asr.h (bit-exact), and the kernels against (a) an fp32 torch restatement of
 ConformerFeedForward.forward + the macaron residual (conformer_modules.py:366-387, :174-181) on the bf16-rounded operands, with
 the hidden pre-activation rounded to bf16 as the reference's autocast does, and (b) the unfused GEMM-epilogue path, which draws
 the SAME dropout masks -- including a ragged last workgroup and the benchmark's row count."""
@@ -12,41 +12,34 @@ import torch
 dev = "cuda"
 
 
-def _emulate_pack(plan):
-    """numpy evaluation of every pending block of a PackPlan (dst[r*pitch + c] = src[r1*sr1 + r2*sr2 + c1*sc1 + c2*sc2])"""
-    out = {}
-    for name, src, rows, cols, ro, co, nr2, nc2, sr1, sr2, sc1, sc2 in plan._pending:
-        off, irows, pitch = plan._images[name]
-        img = out.setdefault(name, np.zeros((irows, pitch), np.float32))
-        r = np.arange(rows)[:, None]
-        c = np.arange(cols)[None, :]
-        idx = (r // nr2) * sr1 + (r % nr2) * sr2 + (c // nc2) * sc1 + (c % nc2) * sc2
-        img[ro:ro + rows, co:co + cols] = src.reshape(-1).numpy()[idx]
-    return out
+def k512_image(A):
+    """include/mi355x_asr.h: fragment (c, k16, mt) of a logical A [dff, 512] at ((c*32 + k16)*2 + mt) KiB, stored [hh][lr][8]"""
+    dff = A.shape[0]
+    c, k16, mt, hh, lr, e = np.meshgrid(np.arange(dff // 64), np.arange(32), np.arange(2), np.arange(2), np.arange(32), np.arange(8),
+                                        indexing="ij")
+    return A[c * 64 + mt * 32 + lr, k16 * 16 + hh * 8 + e].reshape(-1)
 
 
-def test_ffn_pack_maps_are_the_documented_orders():
+def kchunk_image(B):
+    """fragment (t, q, mt4) of a logical B [512, dff] at ((t*4 + q)*4 + mt4) KiB, stored [hh][lr][8]"""
+    dff = B.shape[1]
+    t, q, mt, hh, lr, e = np.meshgrid(np.arange(dff // 16), np.arange(4), np.arange(4), np.arange(2), np.arange(32), np.arange(8),
+                                      indexing="ij")
+    return B[q * 128 + mt * 32 + lr, t * 16 + hh * 8 + e].reshape(-1)
+
+
+def test_ffn_plan_declares_four_aligned_images_per_block():
     from nemo_amd.packing import PackPlan
     dff = 192
-    g = torch.Generator().manual_seed(0)
-    W1 = torch.randn(dff, 512, generator=g)
-    W2 = torch.randn(512, dff, generator=g)
     p = PackPlan(torch.bfloat16, "cpu")
-    p.add_ffn_k512("w1p", W1)
-    p.add_ffn_kchunk("w2p", W2)
-    p.add_ffn_k512("w2tp", W2, transpose=True)     # logical A = W2^T [dff, 512]
-    p.add_ffn_kchunk("w1tp", W1, transpose=True)   # logical B = W1^T [512, dff]
-    img = {k: v.reshape(-1) for k, v in _emulate_pack(p).items()}
-    A = {"w1p": W1.numpy(), "w2tp": W2.t().numpy()}
-    for name, a in A.items():
-        c, k16, r, e = np.meshgrid(np.arange(dff // 64), np.arange(32), np.arange(64), np.arange(16), indexing="ij")
-        want = a[c * 64 + r, k16 * 16 + e].reshape(-1)
-        assert np.array_equal(img[name], want), name
-    Bm = {"w2p": W2.numpy(), "w1tp": W1.t().numpy()}
-    for name, b in Bm.items():
-        t, o, e = np.meshgrid(np.arange(dff // 16), np.arange(512), np.arange(16), indexing="ij")
-        want = b[o, t * 16 + e].reshape(-1)
-        assert np.array_equal(img[name], want), name
+    p.add_matrix("other", torch.zeros(10, 24))
+    p.add_ffn("L0.ff1", torch.zeros(dff, 512), torch.zeros(512, dff))
+    offs = [p._images[f"L0.ff1.{nm}"] for nm in ("w1p", "w1tp", "w2p", "w2tp")]
+    assert all(o[0] % 8 == 0 and o[1] * o[2] == 512 * dff for o in offs)                 # 16-byte aligned, 512 * dff elements each
+    spans = sorted((o[0], o[0] + o[1] * o[2]) for o in offs)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))                           # disjoint
+    with pytest.raises(AssertionError):
+        p.add_ffn("bad", torch.zeros(dff, 256), torch.zeros(256, dff))                   # d_model must be 512
 
 
 # ------------------------------------------------------------------------------------------------------------------ GPU
@@ -75,11 +68,24 @@ def _setup(M, dff, seed):
     x = torch.randn(M, d, generator=g).to(dev)
     y = torch.randn(M, d, generator=g).to(dev).to(torch.bfloat16)
     p = PackPlan(torch.bfloat16, dev)
-    p.add_ffn_k512("w1p", W1); p.add_ffn_kchunk("w2p", W2)
-    p.add_ffn_k512("w2tp", W2, transpose=True); p.add_ffn_kchunk("w1tp", W1, transpose=True)
+    p.add_ffn("f", W1, W2)
     p.add_matrix("w1", W1); p.add_matrix("w2", W2); p.add_matrix("w1t", W1, True); p.add_matrix("w2t", W2, True)
     p.finalize(); p.run()
     return d, W1, W2, b1, b2, x, y, p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dff", [128, 2048])
+def test_ffn_pack_writes_the_documented_fragment_orders(dff):
+    """bit-exact: the images are a permutation of the bf16-rounded weights"""
+    d, W1, W2, b1, b2, x, y, p = _setup(8, dff, 1)
+    torch.cuda.synchronize()
+    w1q, w2q = W1.to(torch.bfloat16).float().cpu().numpy(), W2.to(torch.bfloat16).float().cpu().numpy()
+    got = {nm: p[f"f.{nm}"].float().cpu().numpy().reshape(-1) for nm in ("w1p", "w1tp", "w2p", "w2tp")}
+    assert np.array_equal(got["w1p"], k512_image(w1q))
+    assert np.array_equal(got["w2tp"], k512_image(w2q.T.copy()))
+    assert np.array_equal(got["w2p"], kchunk_image(w2q))
+    assert np.array_equal(got["w1tp"], kchunk_image(w1q.T.copy()))
 
 
 @pytest.mark.gpu
@@ -89,7 +95,7 @@ def test_ffn_fwd_matches_fp32_restatement(M, dff):
     d, W1, W2, b1, b2, x, y, p = _setup(M, dff, 3)
     h = torch.full((M, dff), float("nan"), device=dev, dtype=torch.bfloat16)
     out = torch.full((M, d), float("nan"), device=dev)
-    o.ffn_fwd(y, p["w1p"], b1, p["w2p"], b2, x, h, out, M, d, dff, alpha=0.5)
+    o.ffn_fwd(y, p["f.w1p"], b1, p["f.w2p"], b2, x, h, out, M, d, dff, alpha=0.5)
     torch.cuda.synchronize()
     hr = y.float() @ _bfr(W1).t() + b1
     assert _rel(h, hr) < 1e-2
@@ -108,7 +114,7 @@ def test_ffn_fwd_matches_unfused_path_with_the_same_dropout_masks(M, dff, pdrop)
     d_in, d_res = o.Dropout(pdrop, seed=11, site=5), o.Dropout(pdrop, seed=11, site=6)
     h = torch.empty(M, dff, device=dev, dtype=torch.bfloat16)
     out = torch.empty(M, d, device=dev)
-    o.ffn_fwd(y, p["w1p"], b1, p["w2p"], b2, x, h, out, M, d, dff, alpha=0.5, drop_in=d_in, drop_res=d_res)
+    o.ffn_fwd(y, p["f.w1p"], b1, p["f.w2p"], b2, x, h, out, M, d, dff, alpha=0.5, drop_in=d_in, drop_res=d_res)
     h0 = torch.empty_like(h); a0 = torch.empty_like(h); out0 = torch.empty_like(out)
     o.gemm(y, p["w1"], a0, M, dff, d, d, p.pitch("w1"), dff, bias=b1, epi=o.EPI_SWISH_DROP, aux_out=h0, drop=d_in)
     o.gemm(a0, p["w2"], out0, M, d, dff, dff, p.pitch("w2"), d, bias=b2, alpha=0.5, epi=o.EPI_RESID, aux_in=x, drop=d_res)
@@ -134,7 +140,7 @@ def test_ffn_bwd_dgrad_matches_unfused_path_and_fp32(M, dff, pdrop):
     dh = torch.full((M, dff), float("nan"), device=dev, dtype=torch.bfloat16)
     act = torch.full((M, dff), float("nan"), device=dev, dtype=torch.bfloat16)
     dy = torch.full((M, d), float("nan"), device=dev, dtype=torch.bfloat16)
-    o.ffn_bwd_dgrad(df, p["w2tp"], p["w1tp"], h, dh, act, dy, M, d, dff, drop_in=d_in)
+    o.ffn_bwd_dgrad(df, p["f.w2tp"], p["f.w1tp"], h, dh, act, dy, M, d, dff, drop_in=d_in)
     # unfused: dh = (df @ W2) * mask * swish'(h) ; dy = dh @ W1 ; act = the forward epilogue's output on the same h
     dh0 = torch.empty_like(dh); dy0 = torch.empty_like(dy)
     o.gemm(df, p["w2t"], dh0, M, dff, d, d, p.pitch("w2t"), dff, epi=o.EPI_DSWISH, aux_in=h, drop=d_in)

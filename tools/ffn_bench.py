@@ -35,15 +35,18 @@ def timeit(fn):
 
 
 g = torch.Generator(device=dev).manual_seed(0)
-W1 = torch.randn(dff, d, device=dev, generator=g) * d ** -0.5
-W2 = torch.randn(d, dff, device=dev, generator=g) * dff ** -0.5
 b1 = torch.randn(dff, device=dev, generator=g)
 b2 = torch.randn(d, device=dev, generator=g)
-p = PackPlan(bf, dev)
-p.add_ffn_k512("w1p", W1); p.add_ffn_kchunk("w2p", W2)
-p.add_ffn_k512("w2tp", W2, transpose=True); p.add_ffn_kchunk("w1tp", W1, transpose=True)
-p.add_matrix("w1", W1); p.add_matrix("w2", W2); p.add_matrix("w1t", W1, True); p.add_matrix("w2t", W2, True)
-p.finalize(); p.run()
+COLDW = os.environ.get("COLD_WEIGHTS", "1") != "0"   # every rotated set has its own weights, like the 36 blocks of a step
+plans = []
+for r in range(ROT if COLDW else 1):
+    W1 = torch.randn(dff, d, device=dev, generator=g) * d ** -0.5
+    W2 = torch.randn(d, dff, device=dev, generator=g) * dff ** -0.5
+    p = PackPlan(bf, dev)
+    p.add_ffn("f", W1, W2)
+    p.add_matrix("w1", W1); p.add_matrix("w2", W2); p.add_matrix("w1t", W1, True); p.add_matrix("w2t", W2, True)
+    p.finalize(); p.run()
+    plans.append(p)
 d_in, d_res = ops.Dropout(pdrop, 1, 1), ops.Dropout(pdrop, 1, 2)
 
 sets = []
@@ -53,6 +56,7 @@ for r in range(ROT):
              out=torch.empty(M, d, device=dev), df=torch.randn(M, d, device=dev, generator=g).to(bf),
              dh=torch.empty(M, dff, device=dev, dtype=bf), dy=torch.empty(M, d, device=dev, dtype=bf))
     s["h"].copy_(torch.randn(M, dff, device=dev, generator=g))
+    s["p"] = plans[r % len(plans)]
     sets.append(s)
 cnt = [0]
 
@@ -64,11 +68,13 @@ def nxt():
 
 def fwd_fused():
     s = nxt()
-    ops.ffn_fwd(s["y"], p["w1p"], b1, p["w2p"], b2, s["x"], s["h"], s["out"], M, d, dff, 0.5, d_in, d_res)
+    p = s["p"]
+    ops.ffn_fwd(s["y"], p["f.w1p"], b1, p["f.w2p"], b2, s["x"], s["h"], s["out"], M, d, dff, 0.5, d_in, d_res)
 
 
 def fwd_pair():
     s = nxt()
+    p = s["p"]
     ops.gemm(s["y"], p["w1"], s["a"], M, dff, d, d, p.pitch("w1"), dff, bias=b1, epi=ops.EPI_SWISH_DROP, aux_out=s["h"], drop=d_in)
     ops.gemm(s["a"], p["w2"], s["out"], M, d, dff, dff, p.pitch("w2"), d, bias=b2, alpha=0.5, epi=ops.EPI_RESID, aux_in=s["x"],
              drop=d_res)
@@ -76,11 +82,13 @@ def fwd_pair():
 
 def bwd_fused():
     s = nxt()
-    ops.ffn_bwd_dgrad(s["df"], p["w2tp"], p["w1tp"], s["h"], s["dh"], s["a"], s["dy"], M, d, dff, d_in)
+    p = s["p"]
+    ops.ffn_bwd_dgrad(s["df"], p["f.w2tp"], p["f.w1tp"], s["h"], s["dh"], s["a"], s["dy"], M, d, dff, d_in)
 
 
 def bwd_pair():
     s = nxt()
+    p = s["p"]
     ops.gemm(s["df"], p["w2t"], s["dh"], M, dff, d, d, p.pitch("w2t"), dff, epi=ops.EPI_DSWISH, aux_in=s["h"], drop=d_in)
     ops.gemm(s["dh"], p["w1t"], s["dy"], M, d, dff, dff, p.pitch("w1t"), d)
 

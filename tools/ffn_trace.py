@@ -18,7 +18,7 @@ W1 = torch.randn(dff, d, device=dev, generator=g) * d ** -0.5
 W2 = torch.randn(d, dff, device=dev, generator=g) * dff ** -0.5
 b1 = torch.randn(dff, device=dev, generator=g); b2 = torch.randn(d, device=dev, generator=g)
 p = PackPlan(bf, dev)
-p.add_ffn_k512("w1p", W1); p.add_ffn_kchunk("w2p", W2); p.add_ffn_k512("w2tp", W2, transpose=True); p.add_ffn_kchunk("w1tp", W1, transpose=True)
+p.add_ffn("f", W1, W2)
 p.finalize(); p.run()
 x = torch.randn(M, d, device=dev, generator=g); y = torch.randn(M, d, device=dev, generator=g).to(bf)
 h = torch.empty(M, dff, device=dev, dtype=bf); out = torch.empty(M, d, device=dev)
@@ -36,9 +36,9 @@ for which in ("fwd", "bwd"):
     for _ in range(3):
         trace.zero_()
         if which == "fwd":
-            ops.ffn_fwd(y, p["w1p"], b1, p["w2p"], b2, x, h, out, M, d, dff, 0.5, d_in, d_res)
+            ops.ffn_fwd(y, p["f.w1p"], b1, p["f.w2p"], b2, x, h, out, M, d, dff, 0.5, d_in, d_res)
         else:
-            ops.ffn_bwd_dgrad(df, p["w2tp"], p["w1tp"], h, dh, a, dy, M, d, dff, d_in)
+            ops.ffn_bwd_dgrad(df, p["f.w2tp"], p["f.w1tp"], h, dh, a, dy, M, d, dff, d_in)
         torch.cuda.synchronize()
     t = trace.cpu().view(3, 2, 8).long() & 0xFFFFFFFF
     print(f"== {which}: average shader cycles per step ({nsteps} steps), workgroups first / middle / last")
