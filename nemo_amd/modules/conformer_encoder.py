@@ -276,7 +276,11 @@ class ConformerEncoder(NeuralModule):
         self._wg_pending, self._wg_rows = None, None
         self.conv2_implicit = os.environ.get("MI355X_CONV2_IMPLICIT", "1") != "0"
         self.ln_cast_fuse = os.environ.get("MI355X_LN_CAST_FUSE", "1") != "0"
-        self.ffn_fused = os.environ.get("MI355X_FFN_FUSED", "1") != "0"   # one-launch feed-forward blocks (csrc/ffn.hip)
+        # one-launch feed-forward blocks (csrc/ffn.hip).  OFF by default: parity-green and 10 % faster than the GEMM pair in the
+        # forward direction, but inside the training step the pair of fused launches measured +1.1 ms (40.65 vs 39.55 ms, same box,
+        # profiles/r4_ffn_fused.md): at 64 tokens per workgroup the weight stream through the 64 B/clk vector-memory path, the MFMA
+        # work and the Swish / dropout VALU work each cost ~28 us per launch and overlap only partly.  MI355X_FFN_FUSED=1 enables.
+        self.ffn_fused = os.environ.get("MI355X_FFN_FUSED", "0") != "0"
         self.dpos_side_stream = os.environ.get("MI355X_DPOS_STREAM", "1") != "0"
         self.sub_wgrad_side_stream = os.environ.get("MI355X_SUB_WGRAD_STREAM", "1") != "0"
         self._plans = {}

@@ -158,3 +158,34 @@ def test_ffn_bwd_dgrad_matches_unfused_path_and_fp32(M, dff, pdrop):
     assert _rel(dy, dh.float() @ _bfr(W1)) < 1e-2
     assert _rel(dy, dy0) < 2e-2
     assert torch.isfinite(dy.float()).all()
+
+
+@pytest.mark.gpu
+def test_model_with_fused_feed_forward_matches_the_gemm_pair_path():
+    """Conformer-CTC-Large geometry (4 layers), bf16, dropout off: loss and every gradient of the model whose feed-forward blocks
+    run as one launch per direction (encoder.ffn_fused) against the same model on the two-GEMM path -- the two differ by the bf16
+    rounding of the hidden pre-activation inside the Swish only."""
+    from nemo_amd.models import EncDecCTCModel, conformer_ctc_config
+    from oracle import conformer_ref as R
+
+    def run(fused):
+        torch.manual_seed(0)
+        cfg = conformer_ctc_config("large", vocab_size=128, n_layers=4, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0,
+                                   dropout_emb=0.0, compute_dtype=torch.bfloat16)
+        cfg["preprocessor"]["dither"] = 0.0
+        m = EncDecCTCModel(cfg)
+        m.decoder.compute_dtype = torch.bfloat16
+        m.encoder.ffn_fused = fused
+        m = m.to(dev).train()
+        audio, alen, tok, tl = R.synthetic_batch(3, 4.0, vocab=128, seed=5)
+        out = m.training_step([audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)])
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        return out["loss"].item(), {k: p.grad.detach().float().cpu() for k, p in m.named_parameters() if p.grad is not None}
+
+    l1, g1 = run(True)
+    l0, g0 = run(False)
+    assert abs(l1 - l0) <= 2e-3 * abs(l0), (l1, l0)
+    floor = 1e-3 * max(g.norm().item() for g in g0.values())
+    worst = max(((g1[k] - g0[k]).norm().item() / max(g0[k].norm().item(), floor), k) for k in g0)
+    assert worst[0] < 3e-2, worst
