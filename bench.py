@@ -94,8 +94,10 @@ def var_len_batches(a, rank, world, vocab, dev):
         # the un-timed steps start with the LONGEST batch of the run: the caching allocator and the workspaces reach their final
         # sizes there (what a long training run reaches after its first pass over the longest bucket), instead of growing --
         # hipMalloc by hipMalloc -- inside the 20 timed steps
+        # (a COPY of it: the timed steps keep the sampled sequence, worst-padded batch included -- moving it out of the timed window
+        #  biased the valid-audio rate upwards, round-3 advisor finding; the last warm-up batch is dropped to keep the step count)
         longest = max(range(len(idx_batches)), key=lambda i: float(durs[idx_batches[i]].max()))
-        idx_batches.insert(0, idx_batches.pop(longest))
+        idx_batches = [idx_batches[longest]] + idx_batches[1:a.warmup] + idx_batches[a.warmup:]
     g = torch.Generator().manual_seed(1234 + rank)
     batches, valid = [], []
     for ib in idx_batches:

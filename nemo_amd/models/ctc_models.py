@@ -64,7 +64,12 @@ class EncDecCTCModel(nn.Module):
         # after backward (the main stream is 98 % busy: tools/stream_gaps.py).  In-process A/B (tools/step_ab.py, round 3): 41.90 ->
         # 41.65 ms per step on one GPU; in data-parallel runs the slice sits behind its bucket's all-reduce.  With a global-norm
         # gradient clip the update needs the whole gradient first and falls back to the single launch (FusedAdamW.begin_step).
-        self.optimizer_in_backward = os.environ.get("MI355X_OPT_IN_BACKWARD", "1") == "1"
+        # MI355X_OPT_IN_BACKWARD: 1 = always, 0 = never, unset = on one GPU only -- behind RCCL buckets the path has run on gloo and on
+        # two ranks sharing a GPU, never on a multi-GPU node (no such node is available to this build), so data-parallel runs keep
+        # the plain post-backward step until a hardware run says otherwise (round-3 advisor finding)
+        # (attribute: True / False = forced, None = the rule above)
+        _e = os.environ.get("MI355X_OPT_IN_BACKWARD")
+        self.optimizer_in_backward = None if _e is None else (_e == "1")
         self.global_step = 0
 
     @property
@@ -366,7 +371,8 @@ class EncDecCTCModel(nn.Module):
         # lr(max(1, n - 1)) of the Noam formula (lr_scheduler.py:518-576 reads `last_epoch` before it is advanced)
         lr = self._scheduler.get_last_lr() if self._scheduler is not None else None
         scale = syncs[0].grad_scale if syncs else 1.0 / self.world_size  # (1 when the buckets travel pre-scaled as bf16)
-        early = self.optimizer_in_backward and self._optimizer.begin_step(lr=lr, grad_scale=scale)
+        use_early = (not syncs) if self.optimizer_in_backward is None else bool(self.optimizer_in_backward)
+        early = use_early and self._optimizer.begin_step(lr=lr, grad_scale=scale)
         if early:  # slices of the flat buffers are updated as soon as their gradients are final (and reduced)
             self._install_early_step(syncs)
         scope = getattr(self.encoder, "step_scope", None)
@@ -381,7 +387,7 @@ class EncDecCTCModel(nn.Module):
                 self.encoder._wgrad_join()  # the last slices were updated on the weight-gradient stream
             self._optimizer.finish_step()
         else:
-            if self.optimizer_in_backward:
+            if use_early:
                 self._optimizer.step_count -= 1  # begin_step counted it; step() counts again
             self._optimizer.step(lr=lr, grad_scale=scale)
         if self._scheduler is not None:

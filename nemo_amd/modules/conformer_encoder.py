@@ -117,12 +117,14 @@ class RelPositionalEncoding(nn.Module):  # multi_head_attention.py:1056
         positions L-1 ... -(L-1) for L = max_len once, forward slices `pe[:, center - T + 1 : center + T]`) -- ONE table for the
         longest supported length lives on the device per dtype and a length-T table is a contiguous row slice of it: no host
         arithmetic, no host-to-device copy (which would also drain the launch queue) when a batch brings a new length."""
-        L = max(int(self.max_len), T)
         key = (str(device), dtype)
         full = self._full.get(key) if hasattr(self, "_full") else None
-        if full is None or full.shape[0] < 2 * T - 1 or self._full_L.get(key) != L:
+        # rebuilt only when the table is too SHORT, and then for the longest length seen so far: it grows monotonically (the
+        # previous form rebuilt on every change of max(max_len, T), i.e. at every batch after one longer than max_len)
+        if full is None or full.shape[0] < 2 * T - 1:
             if not hasattr(self, "_full"):
                 self._full, self._full_L = {}, {}
+            L = max(int(self.max_len), T, self._full_L.get(key, 0))
             d = self.d_model
             pos = torch.arange(L - 1, -L, -1, dtype=torch.float32).unsqueeze(1)
             div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(INF_VAL) / d))
@@ -281,6 +283,7 @@ class ConformerEncoder(NeuralModule):
         # profiles/r4_ffn_fused.md): at 64 tokens per workgroup the weight stream through the 64 B/clk vector-memory path, the MFMA
         # work and the Swish / dropout VALU work each cost ~28 us per launch and overlap only partly.  MI355X_FFN_FUSED=1 enables.
         self.ffn_fused = os.environ.get("MI355X_FFN_FUSED", "0") != "0"
+        self._saving = False        # the forward in progress keeps its activations for a backward
         self.dpos_side_stream = os.environ.get("MI355X_DPOS_STREAM", "1") != "0"
         self.sub_wgrad_side_stream = os.environ.get("MI355X_SUB_WGRAD_STREAM", "1") != "0"
         self._plans = {}
@@ -773,6 +776,7 @@ class ConformerEncoder(NeuralModule):
 
     # ------------------------------------------------------------------ forward implementation
     def _forward_impl(self, mel, length, save=False):
+        self._saving = bool(save)
         dev = mel.device
         self._phase("f", dev)
         self._fwd_serial += 1
@@ -1079,7 +1083,9 @@ class ConformerEncoder(NeuralModule):
             lse = self._new(B, H, T, dtype=torch.float32, device=dev)
             # training: also the bf16 rounding residual of the context (backward's delta = sum dO * O needs more than the 8
             # mantissa bits of the stored operand -- see mi355x_relpos_flash_fwd); it travels in the first slot of the saved tuple
-            ctx_lo = self._new(M, dA, dtype=cdt, device=dev) if (self.training and self.flash_delta_residual) else None
+            # (kept whenever activations are saved for a backward -- also for an eval-mode / frozen encoder that is
+            #  differentiated through: delta from the rounded O alone put a 36 % error on layer-0 q / k gradients)
+            ctx_lo = self._new(M, dA, dtype=cdt, device=dev) if (self._saving and self.flash_delta_residual) else None
             ops.relpos_flash_fwd(qkv, 3 * dA, p, dA, bias_u, bias_v, lens, ctx, dA, lse, B, H, T, dk, Tp, scale, d_att,
                                  ctx_lo=ctx_lo)
             return ctx, (ctx_lo, None, None, None, lse)

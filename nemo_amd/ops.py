@@ -474,17 +474,10 @@ def relpos_flash_bwd_dkv(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqkv,
                                           drop.scale, _stream()), "relpos_flash_bwd_dkv")
 
 
-_DPOS_SCRATCH = {}
-
-
 def relpos_flash_bwd_dpos(qv, ds, lens, dpos, B, H, T, dk, dpos_cast=None):
     """`dpos_cast` (bf16, shape of dpos): the GEMM-operand copy of the updated gradient, written by the reduction stage"""
     n = lib.mi355x_relpos_dpos_partial_elems(B, H, T)
-    key = (str(dpos.device), n)
-    scratch = _DPOS_SCRATCH.get(key)
-    if scratch is None:
-        _DPOS_SCRATCH.clear()
-        scratch = _DPOS_SCRATCH[key] = torch.empty(n, dtype=torch.float32, device=dpos.device)
+    scratch = _scratch("relpos_flash_bwd_dpos", n, dpos.device)
     check(lib.mi355x_relpos_flash_bwd_dpos(_ptr(qv), _ptr(ds), _ptr(lens), _ptr(dpos), dpos.shape[-1], _ptr(dpos_cast),
                                            _ptr(scratch), n, B, H, T, dk, ds.numel(), _stream()), "relpos_flash_bwd_dpos")
 
@@ -495,14 +488,20 @@ def dwconv_fwd(x, w, bias, y, stats, B, T, d, k):
 
 
 _SCRATCH = {}
+_SCRATCH_RETIRED = []   # outgrown buffers are KEPT: a recorded launch sequence (hipGraph) may still hold their address
 
 
 def _scratch(name, n, device):
-    # one buffer per (kernel, device, STREAM): launches of the same kernel on two streams may overlap
+    """work space of a kernel's two-stage reductions: one buffer per (kernel, device, STREAM) -- launches of the same kernel on
+    two streams may overlap -- that grows geometrically and is never freed (a hipGraph recorded at a smaller shape replays with
+    the address it captured; freeing the old buffer would let that replay scribble over whatever the allocator put there next:
+    round-3 advisor finding; `ConformerEncoder._buf` and `Arena` retire for the same reason)"""
     key = (name, str(device), torch.cuda.current_stream(device).cuda_stream if torch.cuda.is_available() else 0)
     t = _SCRATCH.get(key)
     if t is None or t.numel() < n:
-        t = _SCRATCH[key] = torch.empty(n, dtype=torch.float32, device=device)
+        if t is not None:
+            _SCRATCH_RETIRED.append(t)
+        t = _SCRATCH[key] = torch.empty(max(n, int(t.numel() * 1.5) if t is not None else n), dtype=torch.float32, device=device)
     return t
 
 

@@ -465,3 +465,28 @@ def grad_digest(name: str, g) -> np.ndarray:
     rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
     sign = rs.randint(0, 2, size=g.size).astype(np.float64) * 2.0 - 1.0
     return np.array([np.sqrt((g * g).sum()), np.abs(g).max() if g.size else 0.0, (g * sign).sum()])
+
+
+def grad_projections(name: str, g: Tensor, K: int = 16) -> Tensor:
+    """K projections of a gradient tensor on fixed pseudo-random +-1 vectors (float64 [K]), for fixtures of runs whose gradients
+    are too large to commit (Large: 121.5 M values): for independent sign vectors s_k, mean_k ((a - b) . s_k)^2 estimates
+    ||a - b||^2 (relative spread sqrt(2 / K)), so the distance of a tensor to the committed run is recoverable from K numbers.
+    The signs come from an integer hash of (element index, k, crc32(name)) evaluated with torch int64 arithmetic (wrapping
+    multiplies, masked shifts): bit-identical on CPU and GPU."""
+    import zlib
+    g = g.detach().reshape(-1).to(torch.float64)
+    n = g.numel()
+    dev = g.device
+    seed = zlib.crc32(name.encode()) & 0x7FFFFFFF
+    idx = torch.arange(n, dtype=torch.int64, device=dev)
+    out = torch.empty(K, dtype=torch.float64, device=dev)
+    M1, M2 = -7046029254386353131, -4658895280553007687   # 0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9 as int64
+    mask35, mask31 = (1 << 35) - 1, (1 << 33) - 1
+    for k in range(K):
+        h = (idx + (seed + 1000003 * k)) * M1
+        h = h ^ ((h >> 29) & mask35)
+        h = h * M2
+        h = h ^ ((h >> 31) & mask31)
+        sign = ((h >> 40) & 1).to(torch.float64) * 2.0 - 1.0
+        out[k] = (g * sign).sum()
+    return out

@@ -361,6 +361,44 @@ def make_transducer_fixture():
     print("transducer fixture: logits", tuple(logits.shape), "loss", loss.item())
 
 
+def make_rnnt_greedy_fixture():
+    """the reference's GreedyBatchedRNNTInfer (parts/submodules/rnnt_greedy_decoding.py:529, frame-looping algorithm, through the
+    shim) on its own RNNTDecoder + RNNTJoint with random weights -> tests/golden/ref_rnnt_greedy.npz: parameters, encoder output,
+    lengths, and per utterance the decoded token ids and their frame indices.  The blank bias is raised so that the search
+    produces a mix of blank frames, single emissions and frames that hit `max_symbols`."""
+    import importlib
+    from oracle import ref_shim
+    ref_shim.install()
+    m = importlib.import_module("nemo.collections.asr.modules.rnnt")
+    gd = importlib.import_module("nemo.collections.asr.parts.submodules.rnnt_greedy_decoding")
+    torch.manual_seed(33)
+    V, H, D, J, MAXS = 24, 32, 40, 36, 3
+    dec = m.RNNTDecoder(prednet={"pred_hidden": H, "pred_rnn_layers": 1, "dropout": 0.0}, vocab_size=V,
+                        normalization_mode=None, random_state_sampling=False, blank_as_pad=True)
+    joint = m.RNNTJoint(jointnet={"encoder_hidden": D, "pred_hidden": H, "joint_hidden": J, "activation": "relu",
+                                  "dropout": 0.0}, num_classes=V)
+    with torch.no_grad():
+        for p in list(dec.parameters()) + list(joint.parameters()):
+            p.mul_(3.0)                                   # (default initialisation gives nearly flat logits)
+        joint.joint_net[-1].bias[V] += 1.0
+    dec.eval(); joint.eval()
+    B, T = 5, 23
+    enc = torch.randn(B, D, T) * 2.0
+    enc_len = torch.tensor([23, 17, 23, 1, 9])
+    infer = gd.GreedyBatchedRNNTInfer(decoder_model=dec, joint_model=joint, blank_index=V, max_symbols_per_step=MAXS,
+                                      loop_labels=False, use_cuda_graph_decoder=False)
+    hyps = infer(encoder_output=enc, encoded_lengths=enc_len)[0]
+    out = {"enc": enc.numpy(), "enc_len": enc_len.numpy(), "blank": np.array(V), "max_symbols": np.array(MAXS)}
+    for b, hy in enumerate(hyps):
+        out[f"tokens{b}"] = np.array([int(t) for t in hy.y_sequence], dtype=np.int64)
+        out[f"times{b}"] = np.array([int(t) for t in hy.timestamp], dtype=np.int64)
+    for pre, mod in (("D.", dec), ("J.", joint)):
+        for n, p in mod.state_dict().items():
+            out["P." + pre + n] = p.detach().numpy()
+    np.savez_compressed(os.path.join(GOLD, "ref_rnnt_greedy.npz"), **out)
+    print("rnnt greedy fixture:", [len(h.y_sequence) for h in hyps], "tokens for lengths", enc_len.tolist())
+
+
 def make_fastconformer_fixture():
     """the reference ConformerEncoder with 'dw_striding' x8 sub-sampling and depthwise kernel 9 (the FastConformer geometry)
     -> tests/golden/ref_fastconformer_tiny.npz (inputs, parameters, output, gradients of a fixed linear functional)"""
@@ -460,5 +498,6 @@ if __name__ == "__main__":
     extract_rnnt_known_answers()
     make_squeezeformer_fixture()
     make_transducer_fixture()
+    make_rnnt_greedy_fixture()
     make_fastconformer_fixture()
     make_cfg1_fixture()

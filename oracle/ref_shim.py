@@ -132,6 +132,10 @@ def install():
             def to_container(x, resolve=True):
                 return x
 
+            @staticmethod
+            def structured(obj):   # (a dataclass instance stays itself: attribute access is all the callers use)
+                return obj
+
         _stub("omegaconf", DictConfig=DictConfig, ListConfig=ListConfig, open_dict=open_dict,
               OmegaConf=OmegaConf, MISSING="???")
     if "librosa" not in sys.modules:
@@ -268,6 +272,18 @@ def install():
 
     _stub("nemo.collections.asr.parts.preprocessing.perturb", AudioAugmentor=AudioAugmentor)
     _stub("nemo.collections.asr.parts.preprocessing.segment", AudioSegment=AudioSegment)
+
+    # ---- what parts/submodules/rnnt_greedy_decoding.py imports besides the transducer modules: language-model fusion and the
+    # label-looping computers (both pull Lightning / CUDA-graph helpers).  Placeholders: the fixtures run the frame-looping
+    # algorithm (`loop_labels=False`, :804-990), which the reference documents as producing the same hypotheses.
+    class _Unavailable:
+        def __init__(self, *a, **k):
+            raise RuntimeError("not available through the oracle shim")
+
+    _stub("nemo.collections.asr.parts.context_biasing", BoostingTreeModelConfig=_Unavailable, GPUBoostingTreeModel=_Unavailable)
+    _stub("nemo.collections.asr.parts.submodules.ngram_lm", NGramGPULanguageModel=_Unavailable)
+    _stub("nemo.collections.asr.parts.submodules.transducer_decoding", GreedyBatchedRNNTLabelLoopingComputer=_Unavailable,
+          GreedyBatchedTDTLabelLoopingComputer=_Unavailable)
     _INSTALLED = True
 
 

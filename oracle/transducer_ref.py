@@ -74,3 +74,44 @@ def joint_network(P: Dict[str, Tensor], enc: Tensor, dec: Tensor, emulate_bf16: 
     f = R._q(F.linear(R._q(enc.transpose(1, 2), e), R._qw(P["enc.weight"], e), P["enc.bias"]), e).unsqueeze(2)
     g = R._q(F.linear(R._q(dec.transpose(1, 2), e), R._qw(P["pred.weight"], e), P["pred.bias"]), e).unsqueeze(1)
     return R._qg(F.linear(R._q(torch.relu(f + g), e), R._qw(P[out + "weight"], e), P[out + "bias"]), e)
+
+
+def greedy_decode(Pd: Dict[str, Tensor], Pj: Dict[str, Tensor], enc: Tensor, enc_len: Tensor, blank: int, max_symbols: int = 10):
+    """Greedy transducer search, utterance by utterance (the textbook form of parts/submodules/rnnt_greedy_decoding.py: the batched
+    frame loop :804-990 masks finished samples and restores their state, which per utterance is exactly this):
+        state = 0, last = blank (zero embedding); for every frame t < T_b: up to `max_symbols` times
+            g = LSTM(emb[last], state) -> logits = out(relu(enc_proj[t] + pred_proj(g))); k = argmax
+            k == blank: next frame;  else emit (k, t), commit the LSTM state, last = k
+    Pd / Pj: state-dicts of RNNTDecoder / RNNTJoint with the reference's keys; enc [B, D, T].  -> list of (tokens, frame indices)."""
+    emb = Pd["prediction.embed.weight"]
+    q = "prediction.dec_rnn.lstm."
+    assert q + "weight_ih_l1" not in Pd, "one LSTM layer (the recipe's pred_rnn_layers: 1)"
+    w_ih, w_hh, b_ih, b_hh = (Pd[q + n + "_l0"] for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+    out = [k[:-len("weight")] for k in Pj if k.startswith("joint_net.") and k.endswith(".weight")][0]
+    f_all = F.linear(enc.transpose(1, 2), Pj["enc.weight"], Pj["enc.bias"])   # [B, T, J]
+    H = w_hh.shape[1]
+    hyps = []
+    for b in range(enc.shape[0]):
+        h, c = torch.zeros(H), torch.zeros(H)
+        last, toks, times = blank, [], []
+
+        def pred(last, h, c):
+            x = emb[last]  # the padding row (blank) is zero
+            z = F.linear(x, w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+            i, f, g, o = z[:H], z[H:2 * H], z[2 * H:3 * H], z[3 * H:]
+            c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h2 = torch.sigmoid(o) * torch.tanh(c2)
+            return F.linear(h2, Pj["pred.weight"], Pj["pred.bias"]), h2, c2
+
+        gp, hn, cn = pred(last, h, c)
+        for t in range(int(enc_len[b])):
+            for _ in range(max_symbols):
+                logits = F.linear(torch.relu(f_all[b, t] + gp), Pj[out + "weight"], Pj[out + "bias"])
+                k = int(torch.argmax(logits))
+                if k == blank:
+                    break
+                toks.append(k); times.append(t)
+                h, c, last = hn, cn, k
+                gp, hn, cn = pred(last, h, c)
+        hyps.append((toks, times))
+    return hyps

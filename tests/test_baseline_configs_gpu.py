@@ -373,3 +373,52 @@ def test_large_bf16_full_benchmark_batch_loss_against_the_committed_oracle_value
     _report("parity_large_bf16_b32x20s_loss.json", dict(config=z["config"], loss_hip=loss.item(), loss_fp32_oracle=l32,
                                                         loss_bf16_emulated=lemu, tol=tol))
     assert abs(loss.item() - l32) / l32 <= tol, (loss.item(), l32, lemu)
+
+
+def test_large_bf16_full_benchmark_batch_gradients_against_the_committed_oracle_projections(golden_dir):
+    """The same batch, backward included: EVERY gradient tensor (674) of the HIP bf16 path at B = 32 x 20 s -- the shape bench.py
+    times: split-K atomics over M = 16 032 rows, the 256 x 256 tile dispatch, BatchNorm statistics over 16 032 frames are only
+    exercised here -- against the CPU oracle's fp32 gradients of exactly this run.  121.5 M values per run cannot be committed, so
+    tests/golden/oracle_large_b32_grads.npz (oracle/make_large_b32_grads.py) holds per tensor the fp32 run's norm and K = 16
+    pseudo-random +-1 projections (R.grad_projections; mean_k ((a - b) . s_k)^2 estimates ||a - b||^2 with relative spread
+    sqrt(2 / K)) plus the EXACT distance of the bf16-emulating oracle run, the yardstick of the derived tolerance used above:
+    no farther from fp32 than BF16_SLACK x what bf16 storage rounding alone explains (+ 0.5 %), times 1.5 for the estimator's
+    spread."""
+    z = np.load(os.path.join(golden_dir, "oracle_large_b32_grads.npz"))
+    names = [str(n) for n in z["names"]]
+    K = int(z["K"])
+    cfg = R.ConformerCfg.large(vocab=128, dropout=0.0, dropout_att=0.0, dropout_pre_encoder=0.0)
+    P = R.init_params(cfg, seed=0)
+    batch = R.synthetic_batch(32, 20.0, vocab=128, seed=1234)
+    model = _model("large", 128, cdt=torch.bfloat16)
+    _load(model, P)
+    model = model.to(dev).train()
+    gb = [t.to(dev) for t in batch]
+    for fp in model.flats():
+        fp.zero_grad()
+    loss = model.training_step(gb)["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    l32, lemu = float(z["loss_fp32"]), float(z["loss_bf16_emulated"])
+    assert abs(loss.item() - l32) / l32 <= BF16_SLACK * abs(lemu - l32) / l32 + 1e-3, (loss.item(), l32, lemu)
+    got = dict(model.named_parameters())
+    assert set(names) <= set(got), sorted(set(names) - set(got))[:5]
+    gmax = float(z["amax"].max())
+    table, bad = [], []
+    for i, n in enumerate(names):
+        g = got[n].grad.detach()
+        proj = R.grad_projections(n, g, K).cpu().numpy()
+        norm32, e_emu = float(z["norm"][i]), float(z["e_emu"][i])
+        est = float(np.sqrt(np.mean((proj - z["proj"][i]) ** 2)) / max(norm32, 1e-300))
+        nrm = abs(g.double().norm().item() - norm32) / max(norm32, 1e-300)
+        table.append(dict(name=n, numel=int(g.numel()), ref_norm=norm32, hip_vs_fp32_est=est, emu_vs_fp32=e_emu, norm_rel=nrm))
+        if n.endswith(ZERO_GRADS):
+            if g.abs().max().item() > 2e-2 * gmax:
+                bad.append((n, "zero-grad", g.abs().max().item()))
+            continue
+        tol = 1.5 * (BF16_SLACK * e_emu + 5e-3)
+        if est > tol or nrm > tol:
+            bad.append((n, est, nrm, e_emu))
+    _report("parity_large_bf16_b32x20s_grads.json", dict(config=str(z["config"]), loss_hip=loss.item(), loss_fp32_oracle=l32,
+                                                         loss_bf16_emulated=lemu, K=K, bad=bad, tensors=table))
+    assert not bad, bad[:10]
