@@ -427,6 +427,22 @@ int mi355x_rnnt_loss_ex(const void* acts, long long ld_acts, const void* labels,
                         void* grads, int grads_dtype, long long ld_grads, void* workspace, long long workspace_elems,
                         void* stream);
 
+/* ---- greedy transducer decoding on the device: GreedyBatchedRNNTInfer, nemo/collections/asr/parts/submodules/
+ * rnnt_greedy_decoding.py:529-990 (batched greedy search; per utterance: state = 0, last = blank; for every frame t < enc_len[b], up
+ * to max_symbols times: g = LSTM(emb[last], state), logits = out(relu(enc_proj[b,t] + pred(g))), k = argmax; blank -> next frame,
+ * else emit (k, t), commit the state, last = k).  ONE launch for the batch, no host synchronisation per frame (the reference reads
+ * `blank_mask.all()` back per inner iteration).  enc_proj [B, T, J] (f_dtype, row pitch ldf) = joint.enc(encoder output); emb f32
+ * [V1, H] (row `blank` zero); one LSTM layer, torch gate order i, f, g, o: w_ih / w_hh [4H, H], w_pred [J, H], w_out [V1, J] in w_dtype
+ * with row pitches ld_*; biases f32.  tokens / times i32 [B, max_out] (-1 padded; times optional), out_len i32 [B], score f32 [B]
+ * (optional: sum of the emitted labels' log-probabilities), h_out / c_out f32 [B, H] (optional, both or neither: the final state).
+ * max_symbols <= 0: unlimited.  H, J and the pitches multiples of 4. */
+int mi355x_rnnt_greedy_decode(const void* enc_proj, int f_dtype, long long ldf, const void* enc_len, const void* emb,
+                              const void* w_ih, long long ld_ih, const void* w_hh, long long ld_hh, const void* b_ih,
+                              const void* b_hh, const void* w_pred, long long ld_pred, const void* b_pred, const void* w_out,
+                              long long ld_out, const void* b_out, int w_dtype, int B, int T, int J, int H, int V1, int blank,
+                              int max_symbols, void* tokens, void* times, void* out_len, void* score, int max_out, void* h_out,
+                              void* c_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,6 +142,8 @@ SIGNATURES = {
     "mi355x_fill_f32": [vp, i64, f32, vp],
     "mi355x_rnnt_workspace_elems": [i32, i32, i32, vp],
     "mi355x_rnnt_loss": [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, i64, vp],
+    "mi355x_rnnt_greedy_decode": [vp, i32, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, i32,
+                                  i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp],
     "mi355x_rnnt_loss_ex": [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, vp, vp, i32, i64, vp, i64, vp],
 }
 

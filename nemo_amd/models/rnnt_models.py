@@ -3,7 +3,8 @@ training hot path of FastConformer-Transducer (BASELINE.json configs[3]): config
 encoder / decoder (prediction network) / joint / loss (rnnt_models.py:50-120), `forward` (:630-690: audio -> encoder
 output), `training_step` (:692-760: decoder -> joint, fused with the loss when `joint.fuse_loss_wer`), and the optimizer /
 data-parallel machinery shared with the CTC model (`fit_step`, bucketed gradient exchange over the flat buffers of encoder,
-prediction network and joint).  Transducer decoding (greedy / beam search) and WER are outside the training hot path."""
+prediction network and joint), greedy batched decoding + WER on the device (`decoding`, `wer`, `validation_pass`, `transcribe`:
+rnnt_models.py:92-110, 245-330, 790-850; modules/rnnt_decoding.py).  Beam search is outside this path."""
 from __future__ import annotations
 
 import copy
@@ -66,6 +67,7 @@ class EncDecRNNTModel(EncDecCTCModel):
         self.spec_augmentation = _build_ctc("spec_augment", sa) if sa else None
         self._optimizer = self._scheduler = self._syncs = None
         self._wer = None
+        self._decoding = None
         self.validation_step_outputs, self.test_step_outputs = [], []
         self.optimizer_in_backward = False
         self.global_step = 0
@@ -85,8 +87,32 @@ class EncDecRNNTModel(EncDecCTCModel):
         return {"tokenizer.model_path": self._cfg["tokenizer"]["model_path"]} if self.tokenizer is not None else {}
 
     @property
+    def decoding(self):
+        """greedy batched transducer decoding over the model's vocabulary (rnnt_models.py:92-100: RNNTDecoding with the recipe's
+        `decoding: {strategy: greedy_batch, greedy: {max_symbols: 10}}`), on the device (modules/rnnt_decoding.py)"""
+        if self._decoding is None:
+            vocab = self._cfg.get("labels")
+            if vocab is None and self.tokenizer is None:
+                return None
+            from ..modules import RNNTDecoding
+            dcfg = dict(self._cfg.get("decoding") or {})
+            strategy = dcfg.get("strategy", "greedy_batch")
+            if strategy not in ("greedy", "greedy_batch"):
+                raise NotImplementedError(f"transducer decoding strategy '{strategy}' (implemented: greedy, greedy_batch)")
+            ms = dict(dcfg.get("greedy") or {}).get("max_symbols", 10)
+            self._decoding = RNNTDecoding(self.decoder, self.joint, vocabulary=list(vocab) if vocab is not None else None,
+                                          max_symbols=ms, tokenizer=self.tokenizer if vocab is None else None)
+        return self._decoding
+
+    @property
     def wer(self):
-        return None  # transducer decoding is not part of this path
+        """rnnt_models.py:101-110: WER over the greedy hypotheses (`predictions` = encoder output)"""
+        if self._wer is None and self.decoding is not None:
+            from ..modules import RNNTWER
+            self._wer = RNNTWER(self.decoding, use_cer=bool(self._cfg.get("use_cer", False)))
+            if self.joint.fuse_loss_wer:
+                self.joint.set_wer(self._wer)
+        return self._wer
 
     # ------------------------------------------------------------------ forward (rnnt_models.py:630-690)
     def forward(self, input_signal=None, input_signal_length=None, processed_signal=None, processed_signal_length=None):
@@ -104,6 +130,9 @@ class EncDecRNNTModel(EncDecCTCModel):
     # ------------------------------------------------------------------ training_step (rnnt_models.py:692-760)
     def training_step(self, batch, batch_nb=0):
         signal, signal_len, transcript, transcript_len = batch
+        # rnnt_models.py:720-724: the training WER is computed every `log_every_n_steps` steps (greedy decoding of the batch)
+        n_log = self._log_every_n_steps()
+        compute_wer = bool(n_log) and (batch_nb + 1) % n_log == 0 and self.wer is not None and torch.is_grad_enabled()
         # The prediction network is 2 x (U+1) tiny dependent launches (recurrent GEMM + cell kernel per step): latency-bound and
         # independent of the encoder until the joint.  It runs on its own stream next to the encoder forward; autograd replays
         # a node's backward on the stream of its forward, so BPTT overlaps the encoder backward the same way.
@@ -121,6 +150,16 @@ class EncDecRNNTModel(EncDecCTCModel):
         else:
             encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
             decoder, target_length, _ = self.decoder(targets=transcript, target_length=transcript_len)
+        loss_value, wer, _, _ = self._loss_and_wer(encoded, encoded_len, decoder, target_length, transcript, transcript_len, compute_wer)
+        logs = {"train_loss": loss_value.detach(), "global_step": self.global_step}
+        if self._scheduler is not None:
+            logs["learning_rate"] = self._scheduler.get_last_lr()
+        if wer is not None:
+            logs["training_batch_wer"] = wer
+        return {"loss": loss_value, "log": logs}
+
+    def _loss_and_wer(self, encoded, encoded_len, decoder, target_length, transcript, transcript_len, compute_wer):
+        """joint + loss (+ WER of the greedy hypotheses): rnnt_models.py:725-760 / :815-850 -> (loss, wer, wer_num, wer_denom)"""
         if not self.joint.fuse_loss_wer:
             joint = self.joint(encoder_outputs=encoded, decoder_outputs=decoder)
             # losses/rnnt.py:446-484: a batch padded beyond its longest utterance / transcript is narrowed before the loss
@@ -128,17 +167,18 @@ class EncDecRNNTModel(EncDecCTCModel):
             max_t, max_u = int(encoded_len.max()), int(target_length.max())
             if joint.shape[1] != max_t or joint.shape[2] != max_u + 1:
                 joint = joint[:, :max_t, :max_u + 1].contiguous()
-            if transcript.shape[1] != max_u:
-                transcript = transcript[:, :max_u]
-            loss_value = self._reduce(self.loss(joint, transcript.clamp(max=self.loss.blank - 1).contiguous(),
+            tr = transcript[:, :max_u] if transcript.shape[1] != max_u else transcript
+            loss_value = self._reduce(self.loss(joint, tr.clamp(max=self.loss.blank - 1).contiguous(),
                                                 encoded_len.to(torch.int64), target_length.to(torch.int64)), target_length)
-        else:
-            loss_value, _, _, _ = self.joint(encoder_outputs=encoded, decoder_outputs=decoder, encoder_lengths=encoded_len,
-                                             transcripts=transcript, transcript_lengths=transcript_len, compute_wer=False)
-        logs = {"train_loss": loss_value.detach(), "global_step": self.global_step}
-        if self._scheduler is not None:
-            logs["learning_rate"] = self._scheduler.get_last_lr()
-        return {"loss": loss_value, "log": logs}
+            wer = num = denom = None
+            if compute_wer:   # rnnt_models.py:742-748 (un-fused joint: the metric is updated after the loss)
+                self.wer.update(predictions=encoded.detach(), predictions_lengths=encoded_len, targets=transcript,
+                                targets_lengths=transcript_len)
+                wer, num, denom = self.wer.compute()
+                self.wer.reset()
+            return loss_value, wer, num, denom
+        return self.joint(encoder_outputs=encoded, decoder_outputs=decoder, encoder_lengths=encoded_len, transcripts=transcript,
+                          transcript_lengths=transcript_len, compute_wer=compute_wer)
 
     def _reduce(self, losses, target_lengths):
         red = self.loss.reduction  # losses/rnnt.py:333-420 (RNNTLoss.reduce)
@@ -152,11 +192,65 @@ class EncDecRNNTModel(EncDecCTCModel):
             return losses.sum() / target_lengths.sum()
         return losses
 
+    @torch.no_grad()
     def validation_pass(self, batch, batch_idx=0, dataloader_idx=0):
+        """rnnt_models.py:790-850: the loss and the WER numerator / denominator of the batch (greedy hypotheses); with the fused
+        joint both come out of its sub-batch loop"""
         signal, signal_len, transcript, transcript_len = batch[:4]
-        with torch.no_grad():  # (the fused joint then computes the loss only)
-            out = self.training_step((signal, signal_len, transcript, transcript_len))
-        return {"val_loss": out["loss"].detach()}
+        encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
+        decoder, target_length, _ = self.decoder(targets=transcript, target_length=transcript_len)
+        loss, wer, num, denom = self._loss_and_wer(encoded, encoded_len, decoder, target_length, transcript, transcript_len,
+                                                   self.wer is not None)
+        metrics = {"val_loss": loss.detach()}
+        if wer is not None:
+            metrics.update({"val_wer_num": num, "val_wer_denom": denom, "val_wer": wer})
+        return metrics
+
+    @torch.no_grad()
+    def predict_step(self, batch, batch_idx=0, dataloader_idx=0):
+        signal, signal_len, _, _, sample_id = batch
+        encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
+        texts = [h.text for h in self.decoding.rnnt_decoder_predictions_tensor(encoded, encoded_len)]
+        if isinstance(sample_id, torch.Tensor):
+            sample_id = sample_id.cpu().numpy()
+        return list(zip(sample_id, texts))
+
+    @torch.no_grad()
+    def transcribe(self, audio, batch_size: int = 4, return_hypotheses: bool = False, num_workers: int = 0,
+                   channel_selector=None, verbose: bool = False):
+        """`ASRTranscriptionMixin.transcribe` for the greedy transducer path (rnnt_models.py:245-330): one string per input, or the
+        Hypothesis objects (text, y_sequence, timestamp, score) with return_hypotheses; the order of the inputs is kept"""
+        from ..data import load_audio
+        if self.decoding is None:
+            raise RuntimeError("transcribe() needs a vocabulary (`labels` or a tokenizer)")
+        if isinstance(audio, (str, bytes)) or not hasattr(audio, "__len__"):
+            audio = [audio]
+        sr = self._cfg.get("sample_rate", 16000)
+        device = next(self.parameters()).device
+        was_training = self.training
+        feat = self.preprocessor.featurizer
+        dither, pad_to = feat.dither, feat.pad_to
+        self.eval()
+        feat.dither, feat.pad_to = 0.0, 0
+        out = []
+        try:
+            for i in range(0, len(audio), batch_size):
+                waves = []
+                for a in audio[i:i + batch_size]:
+                    if isinstance(a, str):
+                        a = load_audio(a, sr, channel_selector=channel_selector)
+                    waves.append(torch.as_tensor(a, dtype=torch.float32).reshape(-1))
+                lens = torch.tensor([w.numel() for w in waves], dtype=torch.int64)
+                sig = torch.zeros(len(waves), int(lens.max()), dtype=torch.float32)
+                for r, w in enumerate(waves):
+                    sig[r, : w.numel()] = w
+                encoded, enc_len = self.forward(input_signal=sig.to(device), input_signal_length=lens.to(device))
+                hyps = self.decoding.rnnt_decoder_predictions_tensor(encoded, enc_len)
+                out.extend(hyps if return_hypotheses else [h.text for h in hyps])
+        finally:
+            feat.dither, feat.pad_to = dither, pad_to
+            self.train(was_training)
+        return out
 
 
 def fastconformer_transducer_config(size: str = "large", vocab_size: int = 1024, spec_augment: bool = False,

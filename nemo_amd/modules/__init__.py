@@ -7,3 +7,4 @@ from .ctc import CTCLoss  # noqa: F401
 from .ctc_decoding import GreedyCTCDecoder, WER, word_error_rate  # noqa: F401
 from .rnnt_loss import RNNTLoss, RNNTLossNumba  # noqa: F401
 from .rnnt import RNNTDecoder, RNNTJoint  # noqa: F401
+from .rnnt_decoding import GreedyBatchedRNNTInfer, RNNTDecoding, RNNTWER, Hypothesis  # noqa: F401

@@ -413,8 +413,8 @@ class RNNTJoint(_ModuleBase):
     def forward(self, encoder_outputs, decoder_outputs, encoder_lengths=None, transcripts=None, transcript_lengths=None,
                 compute_wer: bool = False):
         self._flatp.ensure(encoder_outputs.device)
-        if decoder_outputs is None:
-            raise NotImplementedError("joint without decoder outputs (WER-only pass)")
+        if decoder_outputs is None and not (self._fuse_loss_wer and compute_wer):
+            raise ValueError("decoder_outputs can only be None for fused step!")   # rnnt.py:1485-1486
         if not self._fuse_loss_wer:
             if torch.is_grad_enabled() and (encoder_outputs.requires_grad or decoder_outputs.requires_grad or
                                             any(p.requires_grad for p in self.parameters())):
@@ -424,15 +424,36 @@ class RNNTJoint(_ModuleBase):
             raise ValueError("`fuse_loss_wer` flag is set, but `loss` and `wer` modules were not provided! ")  # rnnt.py:1505
         if encoder_lengths is None or transcript_lengths is None:
             raise ValueError("`fuse_loss_wer` is set, therefore encoder and target lengths must be provided as well!")
+        wer = wer_num = wer_denom = None
         if compute_wer:
-            raise NotImplementedError("fused WER (greedy transducer decoding) is outside the training hot path")
+            # rnnt.py:1592-1632: greedy decoding + WER per sub-batch of `fused_batch_size` utterances (the metric's state is
+            # updated and read back per sub-batch; its numerator / denominator are summed, the ratio averaged) -- the decode of a
+            # sub-batch is one launch here (modules/rnnt_decoding.py), its encoder rows are narrowed to the sub-batch's own length
+            if self._wer is None:
+                raise ValueError("`fuse_loss_wer` flag is set, but `loss` and `wer` modules were not provided! ")
+            wers, wer_num, wer_denom = [], 0, 0
+            B = encoder_outputs.shape[0]
+            fb = self._fused_batch_size or B
+            enc_det = encoder_outputs.detach()
+            el_host = encoder_lengths.detach().cpu()
+            for b0 in range(0, B, fb):
+                b1 = min(B, b0 + fb)
+                tmax = int(el_host[b0:b1].max())
+                self._wer.update(predictions=enc_det[b0:b1, :, :tmax], predictions_lengths=encoder_lengths[b0:b1],
+                                 targets=transcripts[b0:b1].detach(), targets_lengths=transcript_lengths[b0:b1])
+                w, n_, d_ = self._wer.compute()
+                self._wer.reset()
+                wers.append(w); wer_num += n_; wer_denom += d_
+            wer = sum(wers) / len(wers)
+        if decoder_outputs is None:   # WER-only pass (rnnt.py:1500-1503: the loss is skipped without decoder outputs)
+            return None, wer, wer_num, wer_denom
         if not torch.is_grad_enabled():  # validation: the loss only, no backward GEMMs
             loss = self._fused_fwd_bwd(encoder_outputs, decoder_outputs, encoder_lengths, transcripts, transcript_lengths,
                                        need_grad=False)[0]
-            return loss, None, None, None
+            return loss, wer, wer_num, wer_denom
         loss = _FusedJointLossFn.apply(encoder_outputs, decoder_outputs, self._tok(encoder_outputs.device), self,
                                        encoder_lengths, transcripts, transcript_lengths)
-        return loss, None, None, None
+        return loss, wer, wer_num, wer_denom
 
     def joint(self, f, g):
         """rnnt_abstract.AbstractRNNTJoint.joint: f [B,T,D], g [B,U+1,H] -> [B,T,U+1,V+1]"""

@@ -599,6 +599,30 @@ def rnnt_loss_pitched(acts, ld_acts, B, T, U1, V1, labels, act_lens, label_lens,
     return costs
 
 
+def rnnt_greedy_decode(enc_proj, enc_len, emb, w_ih, ld_ih, w_hh, ld_hh, b_ih, b_hh, w_pred, ld_pred, b_pred, w_out, ld_out, b_out,
+                       blank, max_symbols, max_out=None, with_state=False):
+    """greedy transducer search of a whole batch in one launch (mi355x_rnnt_greedy_decode).  enc_proj [B, T, J] = joint.enc(encoder
+    output); weights fp32 or bf16 (all four the same dtype).  -> (tokens i32 [B, max_out] -1 padded, frame indices likewise,
+    lengths i32 [B], score f32 [B][, (h, c) f32 [B, H]])"""
+    B, T, J = enc_proj.shape
+    V1, H = emb.shape
+    if max_out is None:
+        max_out = T * max_symbols if max_symbols > 0 else 4 * T
+    dev = enc_proj.device
+    tokens = torch.empty(B, max_out, dtype=torch.int32, device=dev)
+    times = torch.empty(B, max_out, dtype=torch.int32, device=dev)
+    out_len = torch.empty(B, dtype=torch.int32, device=dev)
+    score = torch.empty(B, dtype=torch.float32, device=dev)
+    h = torch.empty(B, H, dtype=torch.float32, device=dev) if with_state else None
+    c = torch.empty(B, H, dtype=torch.float32, device=dev) if with_state else None
+    check(lib.mi355x_rnnt_greedy_decode(_ptr(enc_proj), dt(enc_proj), enc_proj.stride(1), _ptr(enc_len), _ptr(emb), _ptr(w_ih), ld_ih,
+                                        _ptr(w_hh), ld_hh, _ptr(b_ih), _ptr(b_hh), _ptr(w_pred), ld_pred, _ptr(b_pred), _ptr(w_out),
+                                        ld_out, _ptr(b_out), dt(w_ih), B, T, J, H, V1, blank, max_symbols, _ptr(tokens),
+                                        _ptr(times), _ptr(out_len), _ptr(score), max_out, _ptr(h), _ptr(c), _stream()),
+          "rnnt_greedy_decode")
+    return (tokens, times, out_len, score) + (((h, c),) if with_state else ())
+
+
 def row_scale(x, vec, rows, cols):
     check(lib.mi355x_row_scale(_ptr(x), _ptr(vec), rows, cols, _stream()), "row_scale")
 

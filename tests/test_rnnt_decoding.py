@@ -1,0 +1,150 @@
+"""Greedy transducer decoding + WER (csrc/rnnt_decode.hip, modules/rnnt_decoding.py).
+
+Integer work: hypotheses are compared BIT-EXACTLY.  Chain of evidence:
+  * tests/golden/ref_rnnt_greedy.npz = token ids and frame indices produced by the reference's own GreedyBatchedRNNTInfer
+    (parts/submodules/rnnt_greedy_decoding.py:529, frame-looping algorithm, imported through oracle/ref_shim.py by
+    oracle/make_golden.py:make_rnnt_greedy_fixture) on its RNNTDecoder + RNNTJoint with random weights;
+  * CPU: the oracle restatement (oracle/transducer_ref.py:greedy_decode) reproduces the fixture;
+  * GPU (-m gpu): the one-launch device search reproduces the fixture, and the oracle at the recipe's geometry (640-wide LSTM /
+    joint, 1024 word pieces + blank) on ragged batches; the model-level paths (fused joint WER in sub-batches, validation,
+    transcribe, training WER logging) agree with each other.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import transducer_ref as TR
+
+dev = "cuda"
+
+
+def _fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "ref_rnnt_greedy.npz"))
+    Pd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("P.D.")}
+    Pj = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("P.J.")}
+    return z, Pd, Pj
+
+
+def test_oracle_greedy_search_reproduces_the_reference_run(golden_dir):
+    z, Pd, Pj = _fixture(golden_dir)
+    hyps = TR.greedy_decode(Pd, Pj, torch.from_numpy(z["enc"]), torch.from_numpy(z["enc_len"]), int(z["blank"]), int(z["max_symbols"]))
+    lens = []
+    for b, (tok, tim) in enumerate(hyps):
+        assert tok == z[f"tokens{b}"].tolist() and tim == z[f"times{b}"].tolist(), b
+        lens.append(len(tok))
+    # the fixture exercises blank frames, single emissions and frames that hit max_symbols
+    per_frame = np.bincount(np.array(hyps[0][1]), minlength=int(z["enc_len"][0]))
+    assert set(per_frame.tolist()) >= {0, 1, int(z["max_symbols"])}, per_frame
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+def _modules(Pd, Pj, V, H, D, J, cdt=None):
+    from nemo_amd.modules import RNNTDecoder, RNNTJoint
+    dec = RNNTDecoder(prednet={"pred_hidden": H, "pred_rnn_layers": 1, "dropout": 0.0}, vocab_size=V, compute_dtype=cdt)
+    joint = RNNTJoint(jointnet={"encoder_hidden": D, "pred_hidden": H, "joint_hidden": J, "activation": "relu", "dropout": 0.0},
+                      num_classes=V, compute_dtype=cdt)
+    dec.load_state_dict(Pd); joint.load_state_dict(Pj)
+    return dec.to(dev).eval(), joint.to(dev).eval()
+
+
+@pytest.mark.gpu
+def test_device_greedy_search_reproduces_the_reference_run(golden_dir):
+    from nemo_amd.modules import GreedyBatchedRNNTInfer
+    z, Pd, Pj = _fixture(golden_dir)
+    dec, joint = _modules(Pd, Pj, V=24, H=32, D=40, J=36, cdt=torch.float32)
+    infer = GreedyBatchedRNNTInfer(dec, joint, blank_index=int(z["blank"]), max_symbols_per_step=int(z["max_symbols"]))
+    hyps = infer(encoder_output=torch.from_numpy(z["enc"]).to(dev), encoded_lengths=torch.from_numpy(z["enc_len"]).to(dev))[0]
+    for b, h in enumerate(hyps):
+        assert h.y_sequence.tolist() == z[f"tokens{b}"].tolist(), b
+        assert h.timestamp == z[f"times{b}"].tolist(), b
+        assert np.isfinite(h.score) and h.score <= 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_symbols", [10, 2])
+def test_device_greedy_search_matches_oracle_at_the_recipe_geometry(max_symbols):
+    """fast-conformer_transducer_bpe.yaml: pred_hidden 640, joint_hidden 640, 1024 word pieces; enc_hidden 512; ragged lengths
+    incl. an empty utterance; fp32 weights (bit-exact) and the bf16 GEMM images (same hypotheses up to rare near-tie flips)"""
+    from nemo_amd.modules import GreedyBatchedRNNTInfer, RNNTDecoder, RNNTJoint
+    torch.manual_seed(5)
+    V, H, D, J, B, T = 1024, 640, 512, 640, 6, 40
+    dec = RNNTDecoder(prednet={"pred_hidden": H, "pred_rnn_layers": 1, "dropout": 0.2}, vocab_size=V, compute_dtype=torch.float32)
+    joint = RNNTJoint(jointnet={"encoder_hidden": D, "pred_hidden": H, "joint_hidden": J, "activation": "relu", "dropout": 0.2},
+                      num_classes=V, compute_dtype=torch.float32)
+    with torch.no_grad():
+        for p in list(dec.parameters()) + list(joint.parameters()):
+            p.mul_(4.0)
+        joint.joint_net[-1].bias[V] += 2.0
+    Pd = {k: v.detach().clone() for k, v in dec.state_dict().items()}
+    Pj = {k: v.detach().clone() for k, v in joint.state_dict().items()}
+    enc = torch.randn(B, D, T) * 1.5
+    enc_len = torch.tensor([40, 31, 0, 40, 7, 1])
+    want = TR.greedy_decode(Pd, Pj, enc, enc_len, V, max_symbols)
+    dec, joint = dec.to(dev).eval(), joint.to(dev).eval()
+    infer = GreedyBatchedRNNTInfer(dec, joint, blank_index=V, max_symbols_per_step=max_symbols)
+    hyps = infer(encoder_output=enc.to(dev), encoded_lengths=enc_len.to(dev))[0]
+    assert sum(len(w[0]) for w in want) > 40       # the search does emit
+    for b, h in enumerate(hyps):
+        assert h.y_sequence.tolist() == want[b][0] and h.timestamp == want[b][1], b
+    assert len(hyps[2].y_sequence) == 0
+    # bf16 images
+    dec.compute_dtype = joint.compute_dtype = torch.bfloat16
+    hb = GreedyBatchedRNNTInfer(dec, joint, blank_index=V, max_symbols_per_step=max_symbols)(encoder_output=enc.to(dev),
+                                                                                           encoded_lengths=enc_len.to(dev))[0]
+    from nemo_amd.modules.ctc_decoding import _levenshtein
+    dist = sum(_levenshtein(h.y_sequence.tolist(), w[0]) for h, w in zip(hb, want))
+    assert dist <= 0.25 * sum(len(w[0]) for w in want), dist
+
+
+@pytest.mark.gpu
+def test_transducer_model_wer_paths_agree():
+    """EncDecRNNTModel: the fused joint's sub-batched WER (rnnt.py:1592-1632), the un-fused path's WER, validation_pass and
+    transcribe() decode the same hypotheses; a model trained to over-fit one batch reaches WER 0 on it."""
+    from nemo_amd.models import EncDecRNNTModel, fastconformer_transducer_config
+    from oracle import conformer_ref as R
+    labels = [chr(ord("a") + i) for i in range(26)] + [" ", "'"]
+    over = dict(d_model=64, n_heads=4, n_layers=2, subsampling_conv_channels=32, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0,
+                compute_dtype=torch.float32)
+    cfg = fastconformer_transducer_config("small", vocab_size=len(labels), **over)
+    cfg["labels"] = labels
+    cfg["preprocessor"]["dither"] = 0.0
+    cfg["decoder"]["prednet"].update(pred_hidden=64, dropout=0.0)
+    cfg["joint"]["jointnet"].update(joint_hidden=64, dropout=0.0)
+    cfg["joint"]["fused_batch_size"] = 2
+    cfg["log_every_n_steps"] = 1
+    torch.manual_seed(4)
+    m = EncDecRNNTModel(cfg)
+    m.decoder.compute_dtype = m.joint.compute_dtype = torch.float32
+    m = m.to(dev).train()
+    audio, alen, tok, tl = R.synthetic_batch(4, 1.5, vocab=len(labels), seed=3)
+    alen = torch.tensor([24000, 20000, 24000, 12000]); tl = torch.tensor([4, 3, 4, 2])
+    tok = tok[:, :4] % 26                      # letters only: every token is its own "word" separated below
+    tok[:, 1] = 26                             # a space -> two words per reference
+    batch = [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
+    out = m.training_step(batch, 0)
+    assert "training_batch_wer" in out["log"] and np.isfinite(out["log"]["training_batch_wer"])
+    m.eval()
+    v_f = m.validation_pass(batch)
+    m.joint.set_fuse_loss_wer(False)
+    v_u = m.validation_pass(batch)
+    m.joint.set_fuse_loss_wer(True, m.loss, m.wer)
+    assert v_f["val_wer_num"] == v_u["val_wer_num"] and v_f["val_wer_denom"] == v_u["val_wer_denom"] == 7   # (2 + 2 + 2 + 1 words: the last reference ends on the space)
+    assert abs(v_f["val_loss"].item() - v_u["val_loss"].item()) <= 1e-4 * abs(v_u["val_loss"].item())
+    waves = [audio[i, : int(alen[i])].numpy() for i in range(4)]
+    texts = m.transcribe(waves, batch_size=3)
+    enc, enc_len = m.forward(input_signal=batch[0], input_signal_length=batch[1])
+    direct = [h.text for h in m.decoding.rnnt_decoder_predictions_tensor(enc, enc_len)]
+    assert texts == direct and all(isinstance(t, str) for t in texts)
+    hy = m.transcribe(waves[:2], return_hypotheses=True)
+    assert hy[0].text == texts[0] and len(hy[0].timestamp) == len(hy[0].y_sequence)
+    # over-fit the batch: the greedy hypotheses become the transcripts
+    m.train()
+    m._cfg["log_every_n_steps"] = 0
+    m.setup_optimization(dict(name="adamw", lr=3e-3, betas=[0.9, 0.98], weight_decay=0.0))
+    for _ in range(150):
+        m.fit_step(batch)
+    m.eval()
+    v = m.validation_pass(batch)
+    assert v["val_wer"] <= 0.25, v
