@@ -394,6 +394,22 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        # pre-flight: one all-reduce per communicator this run will use, checked for its value, BEFORE any model step -- a broken
+        # RCCL / xGMI setup fails here, loudly and by name, instead of as a hang inside the first backward
+        for gname, grp in [("world", None)] + [("syncbn", g) for g in {id(m.setup_process_groups()): m.setup_process_groups()
+                                                                     for m in model.trainable_modules()
+                                                                     if hasattr(m, "setup_process_groups")}.values()
+                                                if g is not None and g is not torch.distributed.group.WORLD]:
+            for dt_ in (torch.float32, torch.float64):
+                t = torch.full((1024,), float(rank + 1), device=dev, dtype=dt_)
+                torch.distributed.all_reduce(t, group=grp)
+                torch.cuda.synchronize()
+                want = world * (world + 1) / 2.0
+                if not bool((t == want).all()):
+                    raise SystemExit(f"bench.py: pre-flight all-reduce on the '{gname}' communicator returned {t[0].item()}, expected {want}")
+        if rank == 0:
+            print(f"[bench] pre-flight all-reduce ok on {world} ranks ({backend})", file=sys.stderr, flush=True)
     loss = None
     for i in range(a.warmup):
         loss = model.fit_step(batches[i])["loss"]
@@ -404,7 +420,12 @@ def main():
     settled = getattr(model.encoder, "graphs_settled", lambda: True)
     while not a.var_len and warmup_extra < 16:
         torch.cuda.synchronize()
-        if settled() and warmup_extra >= 1:
+        done = settled() and warmup_extra >= 1
+        if world > 1:  # every rank runs the same number of steps (a step holds collectives): stop only when ALL ranks are settled
+            flag = torch.tensor([0.0 if done else 1.0], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            done = flag.item() == 0.0
+        if done:
             break
         loss = model.fit_step(batches[-1])["loss"]
         warmup_extra += 1

@@ -548,6 +548,12 @@ class ConformerEncoder(NeuralModule):
         gs.calls += 1
         self._cur_gs = gs
         auto = self.graph_auto
+        if auto and gs.decided is None and self._dp_world() > 1:
+            # data-parallel runs keep live launches unless MI355X_GRAPHS=1 asks for the replay: the trial would time recorded
+            # segments with live RCCL collectives between them -- a combination that has only ever run on gloo -- for a replay that
+            # measured 3-4 % slower than live launches on one GPU (profiles/r3_host_issue.md); no trial also means every rank needs
+            # the same number of warm-up steps by construction
+            gs.decided = "eager"
         if auto and (gs.decided == "eager" or not self._in_step):
             return None
         if gs.failed or gs.calls <= self.graph_warmup:
@@ -1247,6 +1253,11 @@ class ConformerEncoder(NeuralModule):
             xo, mean5, rstd5 = self._ln_fwd(L.norm_out, r4, M, d, torch.float32, dev)
         sl.out = (r4, mean5, rstd5)
         return xo, sl
+
+    @staticmethod
+    def _dp_world():
+        import torch.distributed as dist
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
     def _syncbn_world(self):
         if self.sync_batchnorm and torch.distributed.is_available() and torch.distributed.is_initialized():
