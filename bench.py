@@ -176,8 +176,20 @@ def cpu_baseline(size, secs, vocab, batch, steps, budget_s=40.0):
     th, b_ = best
     times.sort()
     med = times[len(times) // 2]
+    # how the port compares with the reference's own modules on one host (measured in the build container, where both exist:
+    # tools/cpu_calibration.py -> profiles/r4_cpu_calibration.json): > 1 means the port is the FASTER of the two, i.e. the
+    # GPU / CPU ratio of this line is conservative
+    calib = None
+    try:
+        with open(_os.path.join(ROOT, "profiles", "r4_cpu_calibration.json")) as f:
+            cj = json.load(f)
+        calib = {"port_over_reference": cj["port_over_reference"], "threads": cj["threads"], "source": "profiles/r4_cpu_calibration.json "
+                 "(tools/cpu_calibration.py, build container: reference modules through oracle/ref_shim.py vs oracle/conformer_ref.py, "
+                 "alternating legs)"}
+    except (OSError, ValueError, KeyError):
+        pass
     return {"value": round(b_ * secs / med, 2), "unit": "audio-sec/s", "cores": th, "threads": th, "host_cpus": ncpu,
-            "kind": "reference" if use_ref else "port",
+            "kind": "reference" if use_ref else "port", "calibration": calib,
             "sample": f"Conformer-CTC-{size} fp32 train step (fwd+bwd+AdamW), B={b_}x{secs:g}s, median of {len(times)} steps at the best "
                       f"of {len(probes)} (threads, batch) probes; "
                       + ("the reference's own FilterbankFeatures + ConformerEncoder through oracle/ref_shim.py" if use_ref else
@@ -496,6 +508,11 @@ def main():
             "syncbn_allreduces_per_step": n_syncbn,
             "syncbn_exposed_ms_this_rank": round(syncbn_ms, 3),
             "grad_wire_dtype": "bf16" if syncs[0].wire_dtype is not None else "fp32",
+            # every all-reduce of the last instrumented step on this rank, in issue order: [MiB, ms on the exchange stream from its
+            # enqueue to its completion]; the last entry of the encoder's list is the tail bucket (cut to <= tail_bytes)
+            "buckets_mib_ms_this_rank": [[round(n_ * 4 / 2 ** 20, 2), round(e0.elapsed_time(e1), 3)]
+                                         for gs in syncs for (n_, e0, e1) in gs.bucket_events_last_step],
+            "tail_bytes": int(syncs[0].tail_elems * 4),
             "syncbn_own_process_group": os.environ.get("MI355X_SYNCBN_OWN_GROUP", "0") == "1",
         })
 
@@ -505,6 +522,16 @@ def main():
         # GEMMs with the HBM-bound kernels in the timed steps above) is switched off for this one instrumented step.
         # EVERY rank runs the step (it contains the SyncBN and gradient collectives); only rank 0 records and reports.
         side = getattr(model.encoder, "wgrad_side_stream", False)
+        in_step_records = None
+        if side:
+            # the same events with the side stream ON, i.e. the configuration the timed steps ran in: a launch's duration then
+            # includes whatever shared the chip with it (`frac_in_step`, next to the serialised `frac`)
+            if rank == 0:
+                ops.GEMM_PROFILE = []
+            model.fit_step(batch)
+            barrier()
+            if rank == 0:
+                in_step_records, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         model.encoder.wgrad_side_stream = False
         if rank == 0:
             ops.GEMM_PROFILE = []
@@ -512,12 +539,16 @@ def main():
         barrier()
         model.encoder.wgrad_side_stream = side
     if rank == 0 and not a.no_roofline:
-        agg = {}
-        for (variant, M, N, K, nb, e0, e1) in ops.GEMM_PROFILE:
-            g = agg.setdefault(variant, [0.0, 0.0, 0])
-            g[0] += 2.0 * M * N * K * nb
-            g[1] += e0.elapsed_time(e1) * 1e-3
-            g[2] += 1
+        def aggregate(records):
+            out_ = {}
+            for (variant, M, N, K, nb, e0, e1) in records:
+                g = out_.setdefault(variant, [0.0, 0.0, 0])
+                g[0] += 2.0 * M * N * K * nb
+                g[1] += e0.elapsed_time(e1) * 1e-3
+                g[2] += 1
+            return out_
+        agg = aggregate(ops.GEMM_PROFILE)
+        agg_in_step = aggregate(in_step_records) if in_step_records else None
         table_path = os.environ.get("BENCH_GEMM_TABLE")
         if table_path:
             shapes = {}
@@ -555,6 +586,14 @@ def main():
                 "traffic_note": traffic_note,
                 "mfma_busy_frac_pmc": mfma_busy,  # SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE), same table
                 "launches_per_step": cnt, "avg_launch_us": round(secs_ / cnt * 1e6, 1),
+                # the same kernel family timed inside the step as the timed region runs it (weight-gradient side stream ON: the
+                # launches share CUs with the side stream's GEMMs); None when the encoder has no side stream
+                "frac_in_step": (round(agg_in_step[dom[0]][0] / agg_in_step[dom[0]][1] / 1e12 / peak, 4)
+                                 if agg_in_step and dom[0] in agg_in_step else None),
+                "achieved_in_step": (round(agg_in_step[dom[0]][0] / agg_in_step[dom[0]][1] / 1e12, 1)
+                                     if agg_in_step and dom[0] in agg_in_step else None),
+                "whole_step_frac": (round(18.24e12 / (ms * 1e-3) / 1e12 / peak, 4)
+                                    if a.model == "ctc" and a.size == "large" and a.batch == 32 and a.secs == 20.0 and world == 1 else None),
                 "gemm_time_share_of_step": round(sum(v[1] for v in agg.values()) * 1e3 / ms, 3),
                 "all_variants": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 2), "launches": v[2]}
                                  for k, v in agg.items()}}

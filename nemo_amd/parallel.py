@@ -11,6 +11,13 @@ mean inside the fused AdamW kernel (`grad_scale = 1/world`), so no extra pass ov
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large buckets beat many small ones, hence the 64 MiB
 default (121.5 M fp32 gradients = 486 MB -> 8 buckets).
 
+The LAST bucket of a step is the only one nothing can hide: backward is over when it is launched, and the optimizer waits for it.
+Ranges arrive in reverse-layer order, so the exchange knows how much of the buffer is still to come (`numel - seen`): when that
+remainder drops to `tail_bytes` (16 MiB: the front end's + sub-sampling's gradients, which backward produces last) the pending
+ranges are flushed EARLY -- the exposed tail is then one <= 16-MiB all-reduce (+ its AdamW slice) instead of whatever was left of a
+64-MiB bucket; and a buffer whose last range has arrived (the decoder's, 66 k values, ready at the very START of backward) is
+flushed at once instead of at `wait()`.
+
 `wire_dtype=torch.bfloat16` (MI355X_GRAD_WIRE=bf16) halves the bytes on the links (243 MB per step for Large): a bucket is scaled
 by 1/world and rounded to bf16 into a staging buffer on the exchange stream, the bf16 buffer is all-reduced, and the sum -- already
 the mean -- is widened back over the fp32 gradient slice (two extra HBM passes over the bucket, both on the exchange stream, i.e.
@@ -27,9 +34,14 @@ import torch.distributed as dist
 
 class GradSync:
     def __init__(self, grad: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, use_side_stream: Optional[bool] = None,
-                 wire_dtype: Optional[torch.dtype] = None):
+                 wire_dtype: Optional[torch.dtype] = None, tail_bytes: Optional[int] = None):
         import os
         self.grad = grad
+        if tail_bytes is None:
+            tail_bytes = int(os.environ.get("MI355X_GRAD_TAIL_BYTES", str(16 << 20)))
+        self.tail_elems = max(0, tail_bytes // grad.element_size())
+        self._seen = 0          # elements reported ready in this step
+        self._tail_cut = False  # the early flush in front of the tail happened (once per step)
         if wire_dtype is None and os.environ.get("MI355X_GRAD_WIRE", "").lower() in ("bf16", "bfloat16"):
             wire_dtype = torch.bfloat16
         if wire_dtype not in (None, torch.float32, torch.bfloat16):
@@ -58,6 +70,8 @@ class GradSync:
         self._launches = 0
         self.profile = False
         self.exposed_events = None
+        self.bucket_events = []  # with `profile`: (elements, start event, end event) per all-reduce, on the stream that carries it
+        self.bucket_events_last_step = []
 
     # ---- called by the backward sequencer (ranges arrive in reverse-layer order, adjacent ranges are merged)
     def ready(self, start: int, end: int) -> None:
@@ -70,7 +84,13 @@ class GradSync:
         else:
             self._pending.append((start, end))
         self._pending_elems += end - start
-        if self._pending_elems >= self.bucket_elems:
+        self._seen += end - start
+        left = self.grad.numel() - self._seen
+        if self._pending_elems >= self.bucket_elems or left <= 0:
+            self.flush()
+        elif not self._tail_cut and 0 < left <= self.tail_elems and self._pending_elems > self.tail_elems:
+            # what is still to come fits the tail bucket: send everything gathered so far now, while backward still runs
+            self._tail_cut = True
             self.flush()
 
     @property
@@ -104,6 +124,17 @@ class GradSync:
         ops.drop_scale_cast(st, view, n, 1.0)
         return work
 
+    def _timed_reduce(self, s: int, e: int):
+        if not (self.profile and self.grad.is_cuda):
+            return self._reduce(s, e)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        work = self._reduce(s, e)
+        work.wait()  # stream-level (the current stream waits for the collective; the host does not block)
+        e1.record()
+        self.bucket_events.append((e - s, e0, e1))
+        return work
+
     def flush(self) -> None:
         if self.world <= 1:
             self._pending, self._pending_elems = [], 0
@@ -114,14 +145,14 @@ class GradSync:
                 for ps in self.producer_streams():
                     self._stream.wait_stream(ps)
                 with torch.cuda.stream(self._stream):
-                    work = self._reduce(s, e)
+                    work = self._timed_reduce(s, e)
                     if self.after_reduce is not None:
                         work.wait()  # stream-level: the exchange stream waits for the collective, the host does not
                         self.after_reduce(s, e)
                     else:
                         self._works.append(work)
             else:
-                work = self._reduce(s, e)
+                work = self._timed_reduce(s, e)
                 if self.after_reduce is not None:
                     work.wait()
                     self.after_reduce(s, e)
@@ -149,6 +180,8 @@ class GradSync:
                 cur.wait_stream(self._stream)
         self._reduced = []
         self.launches_last_step, self._launches = self._launches, 0
+        self._seen, self._tail_cut = 0, False
+        self.bucket_events_last_step, self.bucket_events = self.bucket_events, []
         return self.grad_scale
 
     def reduced_ranges(self):

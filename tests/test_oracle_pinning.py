@@ -80,6 +80,28 @@ def test_mel_restatement_matches_reference_fixture(golden_dir):
     assert np.abs(mel.numpy() - z["mel"]).max() < 2e-4
 
 
+def test_mel_filterbank_against_an_independent_third_party_implementation(golden_dir):
+    """librosa (the reference's dependency, features.py:338-344) is not in this image, and the fixture's `fb` came out of a shim
+    that restates librosa.filters.mel with the published Slaney formula -- a restatement on both sides (round-3 review).  The image
+    does hold one INDEPENDENT implementation of exactly that function: `transformers.audio_utils.mel_filter_bank(norm='slaney',
+    mel_scale='slaney')` (written by other authors to reproduce librosa's filters for the Whisper / Wav2Vec2 feature extractors
+    and tested there against librosa).  Oracle, fixture and product builder must all agree with it to float32 rounding."""
+    hf = pytest.importorskip("transformers.audio_utils")
+    from nemo_amd.modules.audio_preprocessing import slaney_mel_filterbank
+    for (sr, n_fft, n_mels, fmin, fmax) in [(16000, 512, 80, 0.0, 8000.0), (16000, 512, 64, 0.0, 8000.0), (16000, 512, 80, 20.0, 7600.0),
+                                            (8000, 256, 40, 0.0, 4000.0)]:
+        want = hf.mel_filter_bank(num_frequency_bins=n_fft // 2 + 1, num_mel_filters=n_mels, min_frequency=fmin, max_frequency=fmax,
+                                  sampling_rate=sr, norm="slaney", mel_scale="slaney").T  # [n_mels, bins], float64
+        got = np.asarray(slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax, "slaney"), dtype=np.float64)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-9 + 1e-7 * np.abs(want).max(), (sr, n_fft, n_mels, np.abs(got - want).max())
+    z = np.load(os.path.join(golden_dir, "ref_mel_b3.npz"))
+    want = hf.mel_filter_bank(num_frequency_bins=257, num_mel_filters=80, min_frequency=0.0, max_frequency=8000.0, sampling_rate=16000,
+                              norm="slaney", mel_scale="slaney").T
+    assert np.abs(z["fb"][0].astype(np.float64) - want).max() <= 2e-9          # the reference-run fixture's buffer
+    assert np.abs(R.mel_filterbank().astype(np.float64) - want).max() <= 2e-9  # the oracle
+
+
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_model_restatement_matches_reference_fixture(golden_dir, mode):
     z = np.load(os.path.join(golden_dir, "ref_tiny_model.npz"))

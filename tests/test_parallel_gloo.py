@@ -240,3 +240,52 @@ def test_grad_sync_is_a_noop_for_world1():
     gs = GradSync(g)
     gs.ready(0, 128)
     assert gs.wait() == 1.0 and torch.equal(g, torch.ones(128))
+
+
+def _worker_tail(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nemo_amd.parallel import GradSync
+        per = 64 * 5
+        n = per * 21
+        grad = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        # buckets of 8 layers, tail of 2 layers: 21 layers arrive top-down -> [20..13] and [12..5] as full buckets, then -- when only
+        # layers 1 and 0 are still to come -- the early cut [4..2], and the tail [1..0] the moment the buffer is complete
+        gs = GradSync(grad, bucket_bytes=per * 4 * 8, tail_bytes=per * 4 * 2)
+        seen = []
+        for layer in range(20, -1, -1):
+            gs.ready(per * layer, per * (layer + 1))
+            seen.append(list(gs.reduced_ranges()))
+        want = [(per * 13, per * 21), (per * 5, per * 13), (per * 2, per * 5), (0, per * 2)]
+        ok = seen[-1] == want                       # complete BEFORE wait(): nothing is left for the end of backward
+        ok = ok and seen[-2] == want[:3] and seen[-3] == want[:3] and seen[-4] == want[:2]
+        gs.wait()
+        ok = ok and gs.launches_last_step == 4
+        ok = ok and torch.equal(grad, torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world)))
+        # next step: the bookkeeping starts over (same cuts again); a buffer that fits one bucket goes out when its LAST range arrives
+        grad.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+        for layer in range(20, -1, -1):
+            gs.ready(per * layer, per * (layer + 1))
+        ok = ok and list(gs.reduced_ranges()) == want
+        gs.wait()
+        small = torch.full((per,), float(rank + 1))
+        g2 = GradSync(small, bucket_bytes=64 << 20)
+        g2.ready(64, per)
+        ok = ok and g2.reduced_ranges() == []
+        g2.ready(0, 64)
+        ok = ok and g2.reduced_ranges() == [(0, per)]
+        g2.wait()
+        ok = ok and torch.equal(small, torch.full((per,), float(sum(r + 1 for r in range(world)))))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tail_bucket_is_cut_early_and_complete_buffers_leave_at_once_world2_gloo():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_tail, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
