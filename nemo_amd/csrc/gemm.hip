@@ -2039,6 +2039,66 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 }
 
 // =================================================================================================
+// exact fp32 on the matrix cores: v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulation -- no reduced-precision path, unlike
+// xf32), same 64x64x16 tile / staging / scalar epilogue / arbitrary strides as the VALU kernel above; 4 waves, one 32x32
+// quadrant each, 8 MFMAs per K-tile.  Operand layout of the instruction: lane l supplies A[i = l & 31][k = l >> 5] and
+// B[k = l >> 5][j = l & 31]; D[i][j] comes back with j = l & 31, i = (r & 3) + 8 (r >> 2) + 4 (l >> 5) for register r.
+// The fp32 path is the parity configuration (BASELINE configs[0], every fp32 test): 256 FLOP/clk/CU against 128 on the
+// vector unit, and the 4x4 register tile of the VALU kernel reads 8 LDS values per 16 FMAs where this reads 2 per 4096.
+// =================================================================================================
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmP p) {
+  drop_resolve(p.drop);
+  __shared__ float As[16][64 + 4];
+  __shared__ float Bs[16][64 + 4];
+  const int tn = (p.N + 63) / 64;
+  const int tile_m = blockIdx.x / tn, tile_n = blockIdx.x - tile_m * tn;
+  const int m0 = tile_m * 64, n0 = tile_n * 64;
+  const int z = blockIdx.z, z0 = z % p.nb0, z1 = z / p.nb0;
+  const float* A = (const float*)p.A + z0 * p.sA0 + z1 * p.sA1;
+  const float* B = (const float*)p.B + z0 * p.sB0 + z1 * p.sB1;
+  const long long coff = z0 * p.sC0 + z1 * p.sC1;
+  const long long sar = p.transA ? 1 : p.lda, sak = p.transA ? p.lda : 1;
+  const long long sbr = p.transB ? 1 : p.ldb, sbk = p.transB ? p.ldb : 1;
+  int k_begin = 0, k_end = p.K;
+  if (p.splitk > 1) {
+    k_begin = blockIdx.y * p.ktiles_per_split * BK;
+    k_end = min(p.K, k_begin + p.ktiles_per_split * BK);
+    if (k_begin >= k_end) return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane & 31, lh = lane >> 5;
+  const int rb = (wave >> 1) * 32, cb = (wave & 1) * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = threadIdx.x + i * 256;
+      int r, k;
+      if (p.transA) { r = e & 63; k = e >> 6; } else { k = e & 15; r = e >> 4; }
+      float v = 0.f;
+      if (m0 + r < p.M && k0 + k < k_end) v = A[(long long)(m0 + r) * sar + (long long)(k0 + k) * sak];
+      As[k][r] = v;
+      if (p.transB) { r = e & 63; k = e >> 6; } else { k = e & 15; r = e >> 4; }
+      v = 0.f;
+      if (n0 + r < p.N && k0 + k < k_end) v = B[(long long)(n0 + r) * sbr + (long long)(k0 + k) * sbk];
+      Bs[k][r] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k + lh][rb + q], Bs[k + lh][cb + q], acc, 0, 0, 0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + rb + (r & 3) + 8 * (r >> 2) + 4 * lh, n = n0 + cb + q;
+    if (m < p.M && n < p.N) epilogue(p, z, coff, m, n, acc[r]);
+  }
+}
+
+// =================================================================================================
 // C ABI
 // =================================================================================================
 // Dispatch knobs are read by the main thread AND by the autograd thread (backward launches): environment values are
@@ -2050,15 +2110,15 @@ static int env_int(const char* name, int dflt) {
 // run-time knobs (mi355x_gemm_config(key, value); first read falls back to the environment): key 4 = the 256x256 structures
 // (MI355X_GEMM_V4: 0 never, 1 heuristic, 2 whenever N > 128), key 5 = the persistent structure (MI355X_GEMM_V5), key 6 = register
 // prefetch instead of LDS-DMA inside the 256x256 structure (MI355X_GEMM_V6: 0 = default / 1), key 7 = the same inside the 256x128
-// structure (MI355X_GEMM_V7, default 1).  Defaults follow the in-step A/B (tools/step_ab.py, recorded graphs, same box): the
+// structure (MI355X_GEMM_V7, default 1), key 3 = fp32 problems on the matrix cores (MI355X_F32_MFMA, default 1; 0 = vector unit).  Defaults follow the in-step A/B (tools/step_ab.py, recorded graphs, same box): the
 // 256x128 variant -0.2 ms per step, the 256x256 variant +0.3 ms although it wins every isolated launch (profiles/r3_gemm_structures.md)
 static std::atomic<int> g_mode[8] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 static int mode_now(int key) {
   int v = g_mode[key].load(std::memory_order_relaxed);
   if (v < 0) {
     static const int env4 = env_int("MI355X_GEMM_V4", 1), env5 = env_int("MI355X_GEMM_V5", 1), env6 = env_int("MI355X_GEMM_V6", 0),
-                     env7 = env_int("MI355X_GEMM_V7", 1);
-    const int from_env = key == 4 ? env4 : key == 5 ? env5 : key == 6 ? env6 : key == 7 ? env7 : 0;
+                     env7 = env_int("MI355X_GEMM_V7", 1), env3 = env_int("MI355X_F32_MFMA", 1);
+    const int from_env = key == 4 ? env4 : key == 5 ? env5 : key == 6 ? env6 : key == 7 ? env7 : key == 3 ? env3 : 0;
     int expected = -1;
     g_mode[key].compare_exchange_strong(expected, from_env, std::memory_order_relaxed);
     v = g_mode[key].load(std::memory_order_relaxed);
@@ -2067,7 +2127,7 @@ static int mode_now(int key) {
 }
 static int v5_mode_now() { return mode_now(5); }
 extern "C" int mi355x_gemm_config(int key, int value) {
-  if (key < 4 || key > 7) return -1;
+  if (key < 3 || key > 7) return -1;
   return g_mode[key].exchange(value, std::memory_order_relaxed);
 }
 
@@ -2279,7 +2339,9 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   } else {
     const int tm = (p.M + 63) / 64, tn = (p.N + 63) / 64;
     dim3 grid(tm * tn, sk, p.batch);
-    MI_LAUNCH(gemm_f32_kernel, grid, dim3(256), 0, s, p);
+    // key 3 / MI355X_F32_MFMA=0 keeps the vector-unit kernel (A/B, and the reference point of tests/test_kernels_gpu.py)
+    if (mode_now(3)) MI_LAUNCH(gemm_f32_mfma_kernel, grid, dim3(256), 0, s, p);
+    else MI_LAUNCH(gemm_f32_kernel, grid, dim3(256), 0, s, p);
   }
   return mi_check_launch();
 }

@@ -57,7 +57,8 @@ GEMM_PROFILE = None
 
 
 def gemm_config(key: int, value: int) -> int:
-    """kernel-structure knob (tests / A-B benchmarks): key 5 = persistent overlapped-epilogue GEMM, 0 off / 1 default"""
+    """kernel-structure knob (tests / A-B benchmarks), see mi355x_gemm_config in include/mi355x_asr.h: key 3 = fp32 problems on the
+    matrix cores (1 default / 0 vector unit), key 5 = persistent overlapped-epilogue GEMM (0 off / 1 default), ..."""
     return lib.mi355x_gemm_config(key, value)
 
 

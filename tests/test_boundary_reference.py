@@ -218,3 +218,54 @@ def test_with_nemo_core_importable_the_modules_are_real_neural_modules(tmp_path)
     r = subprocess.run([sys.executable, "-c", "import nemo_amd.core as C; print('MIRROR' if not C.HAVE_NEMO_CORE else 'REAL')"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert "MIRROR" in r.stdout, r.stdout + r.stderr
+
+
+def test_binding_against_an_installed_nemo():
+    """Runs only where a REAL NeMo is importable (`nemo.core` with its hydra / lightning dependencies: not this image, hence the
+    skip here) -- the stand-in test above exercises the same switch against a minimal package.  With NEMO_AMD_NEMO_CORE=1 the
+    drop-in modules must BE the installed NeMo's NeuralModules, carry its NeuralTypes port for port (compared with the stock
+    classes' own port tables), be rejected by its typecheck on positional calls, and be constructible from a stock recipe YAML
+    through `Serialization.from_config_dict` with the `_target_` allow-list line of INTEGRATION.md section 2."""
+    pytest.importorskip("hydra")
+    pytest.importorskip("lightning.pytorch")
+    nemo_core = pytest.importorskip("nemo.core")
+    if not hasattr(importlib.import_module("nemo.core.classes.common"), "_TYPECHECK_ENABLED"):
+        pytest.skip("`nemo.core` here is an import stub, not an installed NeMo")
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import torch, nemo_amd.core as C
+        assert C.HAVE_NEMO_CORE
+        import nemo.core.neural_types as nt
+        from nemo.core.classes import NeuralModule
+        import nemo.collections.asr.modules as stock
+        import nemo_amd.modules as mine
+        pairs = [("ConformerEncoder", dict(feat_in=80, n_layers=2, d_model=64, n_heads=4, conv_kernel_size=9)),
+                 ("ConvASRDecoder", dict(feat_in=64, num_classes=28)),
+                 ("AudioToMelSpectrogramPreprocessor", dict()),
+                 ("SpectrogramAugmentation", dict(freq_masks=2, time_masks=2))]
+        for name, kw in pairs:
+            a, b = getattr(mine, name)(**kw), getattr(stock, name)(**kw)
+            assert isinstance(a, NeuralModule), name
+            for table in ("input_types", "output_types"):
+                ta, tb = getattr(a, table), getattr(b, table)
+                assert list(ta) == list(tb), (name, table, list(ta), list(tb))
+                for k in ta:
+                    assert ta[k].compare(tb[k]) == nt.NeuralTypeComparisonResult.SAME, (name, table, k)
+        dec = mine.ConvASRDecoder(feat_in=64, num_classes=28)
+        try:
+            dec(torch.zeros(1, 64, 4))
+            raise SystemExit("positional call was not rejected by NeMo's typecheck")
+        except TypeError:
+            pass
+        cfg = {"_target_": "nemo_amd.modules.ConvASRDecoder", "feat_in": 64, "num_classes": 28}
+        from omegaconf import OmegaConf
+        d2 = NeuralModule.from_config_dict(OmegaConf.create(cfg))
+        assert type(d2).__name__ == "ConvASRDecoder" and type(d2).__module__.startswith("nemo_amd")
+        print("INSTALLED-NEMO-OK")
+    """)
+    env = dict(os.environ, NEMO_AMD_NEMO_CORE="1",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert "INSTALLED-NEMO-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert nemo_core is not None

@@ -60,6 +60,70 @@ def test_gemm_layouts(dtype, layout, shape):
     assert rel_err(Cd, ref) < (2e-5 if dtype == torch.float32 else 1e-4), (layout, shape, rel_err(Cd, ref))
 
 
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN", "TT"])
+@pytest.mark.parametrize("shape", [(300, 200, 136), (1000, 512, 512), (130, 129, 64), (33, 31, 7), (64, 64, 1030)])
+def test_gemm_f32_on_the_matrix_cores_matches_the_vector_unit_kernel(layout, shape):
+    """fp32 problems run on v_mfma_f32_32x32x2_f32 (gemm_f32_mfma_kernel); mi355x_gemm_config(3, 0) selects the vector-unit kernel
+    it replaces.  Both against an f64 product of the same operands: the matrix-core kernel must be as exact as the VALU one
+    (fp32 operands, fp32 accumulation: only the summation order differs), ragged tiles and every operand layout included."""
+    o = ops()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(N, K, generator=g)
+    ref = (A.double() @ Bm.double().t())
+    tA, tB = layout[0] == "T", layout[1] == "N"
+    Ast, lda = (A.t().contiguous(), M) if tA else (A, K)
+    Bst, ldb = (Bm.t().contiguous(), N) if tB else (Bm, K)
+    errs = {}
+    prev = o.gemm_config(3, 1)
+    try:
+        for mode in (1, 0):
+            o.gemm_config(3, mode)
+            Cd = torch.full((M, N), float("nan"), device=dev)
+            o.gemm(Ast.to(dev), Bst.to(dev), Cd, M, N, K, lda, ldb, N, transA=tA, transB=tB)
+            torch.cuda.synchronize()
+            errs[mode] = ((Cd.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    finally:
+        o.gemm_config(3, prev if prev >= 0 else 1)
+    assert errs[1] < 2e-6 and errs[0] < 2e-6, errs
+    assert errs[1] < 4 * errs[0] + 1e-7, errs
+
+
+def test_gemm_f32_on_the_matrix_cores_epilogues_batch_and_split_k():
+    o = ops()
+    g = torch.Generator().manual_seed(6)
+    # batched + strided, bias, residual epilogue
+    nb, M, N, K = 3, 70, 90, 50
+    A = torch.randn(nb, M, K, generator=g); Bm = torch.randn(nb, N, K, generator=g)
+    bias = torch.randn(N, generator=g); res = torch.randn(nb, M, N, generator=g)
+    want = res + 0.5 * (torch.einsum("bmk,bnk->bmn", A.double(), Bm.double()) + bias.double())
+    got = {}
+    prev = o.gemm_config(3, 1)
+    try:
+        for mode in (1, 0):
+            o.gemm_config(3, mode)
+            Cd = torch.full((nb, M, N), float("nan"), device=dev)
+            o.gemm(A.to(dev), Bm.to(dev), Cd, M, N, K, K, K, N, batch=nb, sA=(M * K, 0), sB=(N * K, 0), sC=(M * N, 0),
+                   bias=bias.to(dev), alpha=0.5, epi=o.EPI_RESID, aux_in=res.to(dev), ldaux=N)
+            torch.cuda.synchronize()
+            got[mode] = Cd.cpu()
+            assert ((Cd.double().cpu() - want).abs().max() / want.abs().max()).item() < 2e-6, mode
+        # split-K with atomic accumulation into a pre-filled C (weight-gradient form: both operands reduction-major)
+        M2, N2, K2 = 96, 80, 1000
+        X = torch.randn(K2, M2, generator=g); Y = torch.randn(K2, N2, generator=g)
+        base = torch.randn(M2, N2, generator=g)
+        want2 = base.double() + X.double().t() @ Y.double()
+        for mode in (1, 0):
+            o.gemm_config(3, mode)
+            Cd = base.clone().to(dev)
+            o.gemm(X.to(dev), Y.to(dev), Cd, M2, N2, K2, M2, N2, N2, transA=True, transB=True, atomic=True, splitk=4)
+            torch.cuda.synchronize()
+            assert ((Cd.double().cpu() - want2).abs().max() / want2.abs().max()).item() < 5e-6, mode
+    finally:
+        o.gemm_config(3, prev if prev >= 0 else 1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_epilogues(dtype):
     o = ops()
