@@ -638,10 +638,13 @@ def main():
             line["roofline_hbm"] = roof_hbm
         ginfo = model.encoder.graph_info() if hasattr(model.encoder, "graph_info") else []
         replayed = any(g.get("fwd_graphs") and str(g.get("decided")) != "eager" for g in ginfo)
-        line["launch"] = {"mode": ("encoder forward/backward replayed from hipGraph segments (nemo_amd/graphs.py); front end, decoder, "
-                                   "loss and optimizer launched live") if replayed else
+        taped = replayed and any(g.get("replay") == "launch tape" for g in ginfo)
+        line["launch"] = {"mode": (("encoder forward/backward re-issued from launch tapes (csrc/tape.hip: the recorded nodes as live "
+                                    "launches from one C loop)" if taped else
+                                    "encoder forward/backward replayed from hipGraph segments (nemo_amd/graphs.py)") +
+                                   "; front end, decoder, loss and optimizer launched live") if replayed else
                                   ("every kernel launched live from the Python sequencer" +
-                                   (" (hipGraph replay was timed on this box and was slower)" if ginfo else "")),
+                                   (" (the recorded sequence was timed on this box and was slower)" if ginfo else "")),
                           "host_issue_ms_per_step": round(host_s / a.steps * 1e3, 2), "recorded": ginfo,
                           "untimed_steps_beyond_warmup": warmup_extra}
         line["distributed"] = dist_info

@@ -395,6 +395,35 @@ int mi355x_set_step_counter(const void* dev_word);
  * launch sequence (tools/host_phases.py).  Returns the previous value. */
 int mi355x_set_null_launch(int on);
 
+/* Launch tapes (csrc/tape.hip): a launch sequence captured as a hipGraph, re-issued as LIVE launches from one C loop.
+ * What it replaces: the host-side walk over the encoder's modules -- nemo/collections/asr/modules/conformer_encoder.py:593-759
+ * (forward_internal: pre_encode, pos_enc, the layer loop) and parts/submodules/conformer_modules.py:164-215 (one layer) -- once
+ * a (shape, configuration) has been seen; the reference's own mechanism for the same cost is whole-step CUDA-graph capture
+ * (nemo/utils/callbacks/cuda_graph.py:251).  A replayed hipGraph measured 3-4 % slower on the device than live launches on
+ * this stack, the Python sequencer costs ~19 us of host time per launch: a tape issues the graph's nodes (kernels with
+ * their frozen arguments, memsets, memcpys) in topological order with hipLaunchKernel on stream lanes -- lane 0 is the
+ * stream passed to replay, lanes 1.. are the OTHER streams that took part in the capture (the weight-gradient side stream),
+ * used again as they are -- with one event per cross-lane dependency.
+ *   mi355x_tape_log_begin(origin)  before the capture starts: from here on every launch of the library notes the stream it is
+ *                                  captured on (`origin` = the capturing stream -> lane 0; other streams -> lanes 1, 2, ...)
+ *   mi355x_tape_from_graph         hip_graph = hipGraph_t (kept alive by the caller for as long as the tape is used: the kernel
+ *                                  arguments stay inside its nodes); returns 0, 1 (bad argument), 2 (a node type a tape cannot
+ *                                  re-issue, or arguments passed through `extra`: keep replaying the graph) or 1000 + hipError_t
+ *   mi355x_tape_log_end()          after the last mi355x_tape_from_graph of the capture
+ *   mi355x_tape_replay(t, s, join) join = 1: the ordering contract of hipGraphLaunch(exec, s) (s continues behind every lane);
+ *                                  join = 0: the side lanes run on, as behind the live sequencer -- consumers of their results
+ *                                  order themselves behind those streams (the optimizer slice / gradient bucket of a layer does)
+ *   mi355x_tape_join(t, s)         s continues behind whatever t's side lanes hold now (what a replay with join = 0 left out)
+ *   mi355x_tape_info               counts[6] = kernels, memsets, memcpys, empty nodes, lanes, cross-lane events */
+typedef struct mi355x_tape mi355x_tape;
+int mi355x_tape_log_begin(void* origin_stream);
+int mi355x_tape_log_end(void);
+int mi355x_tape_from_graph(void* hip_graph, int max_lanes, mi355x_tape** out);
+int mi355x_tape_replay(mi355x_tape* tape, void* stream, int join);
+int mi355x_tape_join(mi355x_tape* tape, void* stream);
+int mi355x_tape_info(const mi355x_tape* tape, int* counts);
+void mi355x_tape_destroy(mi355x_tape* tape);
+
 /* Greedy CTC decoding on the device (GreedyCTCInfer._greedy_decode_logprobs, parts/submodules/ctc_greedy_decoding.py:333-361,
  * + the CTC collapse of AbstractCTCDecoding.decode_hypothesis, parts/submodules/ctc_decoding.py:545-575):
  * logp f32 [B,T,C], lens i64 [B] (NULL = T) -> tokens i32 [B,T] (folded, blank-free, -1 padded), out_len i32 [B],

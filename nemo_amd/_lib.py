@@ -144,6 +144,13 @@ SIGNATURES = {
     "mi355x_rnnt_loss": [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, i64, vp],
     "mi355x_rnnt_greedy_decode": [vp, i32, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, i32,
                                   i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp],
+    "mi355x_tape_log_begin": [vp],
+    "mi355x_tape_log_end": [],
+    "mi355x_tape_from_graph": [vp, i32, vp],
+    "mi355x_tape_replay": [vp, vp, i32],
+    "mi355x_tape_join": [vp, vp],
+    "mi355x_tape_info": [vp, vp],
+    "mi355x_tape_destroy": [vp],
     "mi355x_rnnt_loss_ex": [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, vp, vp, i32, i64, vp, i64, vp],
 }
 
@@ -164,6 +171,7 @@ def _load():
     lib.mi355x_relpos_ds_elems.restype = i64
     lib.mi355x_relpos_dpos_partial_elems.restype = i64
     lib.mi355x_asr_version.argtypes = []
+    lib.mi355x_tape_destroy.restype = None
     return lib
 
 

@@ -30,12 +30,17 @@ static inline int mi_check_launch() {
 // Every kernel launch of the library goes through MI_LAUNCH.  With mi355x_set_null_launch(1) a launch site issues an EMPTY kernel on
 // the same stream instead of its own: the host then pays the same per-launch cost while the GPU has nothing to do, which is how
 // tools/host_phases.py measures the pure ISSUE time of a training step (no queue back-pressure from a busy GPU).
+// While a launch sequence is being captured for a launch tape (tape.hip: mi355x_tape_log_begin), every launch also notes which
+// stream it was captured on -- the one thing a captured graph does not keep, and what the tape's stream lanes are made from.
 extern "C" int mi355x_null_launch_flag;
+extern int mi355x_tape_log_flag;
+void mi_tape_log(hipStream_t stream);
 static __global__ void mi_null_kernel() {}
 #define MI_LAUNCH(kernel, grid, block, shm, stream, ...)                               \
   do {                                                                                 \
     if (mi355x_null_launch_flag) hipLaunchKernelGGL(mi_null_kernel, dim3(1), dim3(64), 0, stream); \
     else hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);            \
+    if (mi355x_tape_log_flag) mi_tape_log(stream);                                     \
   } while (0)
 
 // ---------------------------------------------------------------- bf16 <-> f32

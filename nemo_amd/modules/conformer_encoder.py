@@ -298,6 +298,9 @@ class ConformerEncoder(NeuralModule):
         _g = os.environ.get("MI355X_GRAPHS", "auto")
         self.use_graphs = _g != "0"
         self.graph_auto = _g not in ("0", "1", "2")
+        # how a recorded segment runs again: as a LAUNCH TAPE (csrc/tape.hip: the captured nodes re-issued as live launches from
+        # one C loop; default) or, MI355X_TAPE=0, as a hipGraph replay (3-4 % slower on the device timeline, r3_host_issue.md)
+        self.graph_tape = os.environ.get("MI355X_TAPE", "1") != "0"
         self.graph_warmup = 2       # eager training forwards per key before its launch sequence is captured
         self.graph_trials = 4       # auto: timed steps per mode, alternating
         self.max_graph_sets = 8     # distinct (shape, configuration) keys kept (a duration-bucketed loader has a handful)
@@ -502,7 +505,7 @@ class ConformerEncoder(NeuralModule):
         return (tuple(mel.shape), self._cdt(), str(mel.device), self._flatp.generation, self._syncbn_world(),
                 self.grad_ready_hook is not None, self._wgrad_join_per_layer, self.wgrad_side_stream, self.wgrad_grouped,
                 self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse,
-                self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder)
+                self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.graph_tape, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder)
 
     def _auto_begin(self, gs, mode):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -599,7 +602,7 @@ class ConformerEncoder(NeuralModule):
         gs.length.copy_(length)
         if self._step_word is None or self._step_word.device != dev:
             self._step_word = torch.zeros(1, dtype=torch.int32, device=dev)
-        cap = SegmentedCapture(dev)
+        cap = SegmentedCapture(dev, tape=self.graph_tape)
         self._force_pack = True
         ops.set_step_counter(self._step_word)
         try:
@@ -624,7 +627,7 @@ class ConformerEncoder(NeuralModule):
         if gs.bwd is None:
             gs.dout = torch.empty_like(dout)
             gs.dout.copy_(dout)
-            cap = SegmentedCapture(dout.device, pool=gs.pool)
+            cap = SegmentedCapture(dout.device, pool=gs.pool, tape=self.graph_tape)
             ops.set_step_counter(self._step_word)
             try:
                 gs.S.serial = self._fwd_serial  # (the replay that filled these activations is the latest forward)
@@ -644,7 +647,8 @@ class ConformerEncoder(NeuralModule):
             gs.S = None  # the recorded launches hold the addresses; the pool keeps the memory
         else:
             gs.dout.copy_(dout)
-        gs.bwd.replay()
+        # (the live sequencer joins the weight-gradient stream per layer only when nobody else orders behind it)
+        gs.bwd.replay(join_between=self._wgrad_join_per_layer)
 
     def graphs_settled(self) -> bool:
         """auto mode: has every shape seen so far finished its eager-vs-replay trial?  (bench.py keeps running un-timed steps
@@ -661,7 +665,9 @@ class ConformerEncoder(NeuralModule):
                 out.append({"mel_shape": list(key[0]), "fwd_graphs": gs.fwd.n_graphs(), "fwd_host_calls": len(gs.fwd.seq) - gs.fwd.n_graphs(),
                             "bwd_graphs": gs.bwd.n_graphs() if gs.bwd is not None else None,
                             "bwd_host_calls": (len(gs.bwd.seq) - gs.bwd.n_graphs()) if gs.bwd is not None else None,
-                            "auto": getattr(gs, "auto_ms", None), "decided": gs.decided})
+                            "auto": getattr(gs, "auto_ms", None), "decided": gs.decided,
+                            "replay": "launch tape" if gs.fwd.tape else "hipGraph",
+                            "fwd_tape": gs.fwd.tape_info(), "bwd_tape": gs.bwd.tape_info() if gs.bwd is not None else None})
             elif gs.decided == "eager":
                 out.append({"mel_shape": list(key[0]), "decided": "eager (live launches measured faster than the replay)",
                             "auto": getattr(gs, "auto_ms", None)})

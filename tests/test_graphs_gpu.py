@@ -31,11 +31,26 @@ def _batch(B=4, secs=1.0, vocab=20, seed=8, lens=None):
     return [audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)]
 
 
-def _run(over, graphs, steps, batches, dtype=torch.float32, lr=1e-3, seed=21, hook=False):
+REPLAYS = ["tape", "graph"]   # a recorded segment runs again as a launch tape (csrc/tape.hip, the default) or as a hipGraph replay
+
+
+def _check_replay_kind(info, replay):
+    """the recording really runs the way the test asked for; a tape re-issues every node itself (no segment fell back to a graph)"""
+    for rec in info:
+        assert rec["replay"] == ("launch tape" if replay == "tape" else "hipGraph"), rec
+        if replay == "tape":
+            for t in (rec["fwd_tape"], rec["bwd_tape"]):
+                assert t is not None and t["graph_fallbacks"] == 0 and t["kernels"] > 0 and t["lanes"] >= 1, rec
+        else:
+            assert rec["fwd_tape"] is None and rec["bwd_tape"] is None, rec
+
+
+def _run(over, graphs, steps, batches, dtype=torch.float32, lr=1e-3, seed=21, hook=False, replay="tape"):
     torch.manual_seed(seed)
     model = _model(dict(over, compute_dtype=dtype)).to(dev).train()
     model.decoder.compute_dtype = dtype
     model.encoder.use_graphs = graphs
+    model.encoder.graph_tape = replay == "tape"
     model.encoder.graph_auto = False  # forced: record after `graph_warmup` eager steps (the default would time both ways first)
     model.optimizer_in_backward = hook
     model.setup_optimization(dict(name="adamw", lr=lr, betas=[0.9, 0.98], weight_decay=1e-3))
@@ -44,12 +59,14 @@ def _run(over, graphs, steps, batches, dtype=torch.float32, lr=1e-3, seed=21, ho
     return model, losses
 
 
-def test_recorded_sequence_is_the_eager_sequence_fp32():
+@pytest.mark.parametrize("replay", REPLAYS)
+def test_recorded_sequence_is_the_eager_sequence_fp32(replay):
     over = dict(d_model=64, n_heads=4, n_layers=3, **NODROP)
     batches = [_batch(lens=[16000, 12000, 16000, 9000])]
-    m_g, l_g = _run(over, True, 7, batches)
+    m_g, l_g = _run(over, True, 7, batches, replay=replay)
     m_e, l_e = _run(over, False, 7, batches)
     info = m_g.encoder.graph_info()
+    _check_replay_kind(info, replay)
     assert len(info) == 1 and info[0]["fwd_graphs"] == 1 and info[0]["bwd_graphs"] == 1 and info[0]["bwd_host_calls"] == 0, info
     assert m_e.encoder.graph_info() == []
     for a, b in zip(l_g, l_e):
@@ -64,25 +81,29 @@ def test_recorded_sequence_is_the_eager_sequence_fp32():
     assert torch.allclose(m_g.encoder.layers[0].conv.batch_norm.running_var, m_e.encoder.layers[0].conv.batch_norm.running_var, rtol=1e-5)
 
 
-def test_recorded_sequence_with_hooks_between_the_segments():
+@pytest.mark.parametrize("replay", REPLAYS)
+def test_recorded_sequence_with_hooks_between_the_segments(replay):
     """optimizer-behind-backward installs a per-layer hook: the backward sequence is cut at every hook, which stays a live call"""
     over = dict(d_model=64, n_heads=4, n_layers=3, **NODROP)
     batches = [_batch()]
-    m_g, l_g = _run(over, True, 7, batches, hook=True)
+    m_g, l_g = _run(over, True, 7, batches, hook=True, replay=replay)
     m_e, l_e = _run(over, False, 7, batches, hook=True)
     info = m_g.encoder.graph_info()
+    _check_replay_kind(info, replay)
     assert info and info[0]["bwd_host_calls"] >= 3 + 2 and info[0]["bwd_graphs"] == info[0]["bwd_host_calls"] + 1, info
     for a, b in zip(l_g, l_e):
         assert abs(a - b) <= 1e-3 * abs(b), (l_g, l_e)
     assert l_g[-1] < 0.95 * l_g[0]
 
 
-def test_each_batch_shape_gets_its_own_recording():
+@pytest.mark.parametrize("replay", REPLAYS)
+def test_each_batch_shape_gets_its_own_recording(replay):
     over = dict(d_model=64, n_heads=4, n_layers=2, **NODROP)
     batches = [_batch(B=4, secs=1.0), _batch(B=2, secs=1.5, seed=9)]
-    m_g, l_g = _run(over, True, 10, batches)
+    m_g, l_g = _run(over, True, 10, batches, replay=replay)
     m_e, l_e = _run(over, False, 10, batches)
     assert len(m_g.encoder.graph_info()) == 2
+    _check_replay_kind(m_g.encoder.graph_info(), replay)
     for a, b in zip(l_g, l_e):
         assert abs(a - b) <= 5e-5 * abs(b), (l_g, l_e)
 
@@ -95,7 +116,8 @@ def _step_grads(model, batch):
     return loss.item(), [fp.grad.detach().clone() for fp in model.flats()]
 
 
-def test_dropout_masks_follow_the_device_step_word_bf16():
+@pytest.mark.parametrize("replay", REPLAYS)
+def test_dropout_masks_follow_the_device_step_word_bf16(replay):
     """bf16 production kernels (fused attention, MFMA GEMM epilogues, LayerNorm-backward casts) with every dropout site on:
     (1) with the step word forced to 0 a replayed step regenerates exactly the masks of the eager step with the recorded seed, in
     forward AND backward (gradients agree); (2) consecutive replays draw different masks."""
@@ -109,10 +131,14 @@ def test_dropout_masks_follow_the_device_step_word_bf16():
     mg.setup_optimization(dict(name="adamw", lr=0.0))
     enc = mg.encoder
     enc.graph_auto = False
+    enc.graph_tape = replay == "tape"
     for _ in range(enc.graph_warmup):
         _step_grads(mg, batch)
     l3, _ = _step_grads(mg, batch)   # recorded + replayed
     assert enc.graph_info() and enc.graph_info()[0]["bwd_graphs"] == 1
+    _check_replay_kind(enc.graph_info(), replay)
+    if replay == "tape":  # the bf16 path sends its weight gradients to the side stream: the tape must bring that lane back
+        assert enc.graph_info()[0]["bwd_tape"]["lanes"] == 2 and enc.graph_info()[0]["bwd_tape"]["events"] > 0, enc.graph_info()
     seed_rec = enc._step_seed        # the seed baked into the recorded keys
     l4, _ = _step_grads(mg, batch)
     assert l3 != l4, "two replays drew the same dropout masks"

@@ -66,11 +66,14 @@ def measure(m, batch, n, null):
 
 
 res = {"model": kind, "batch": "32 x 20 s", "dtype": "bf16"}
-for mode in ("graphs", "eager"):
+audio, alen, tok, tl = None, None, None, None
+for mode in ("tape", "graphs", "eager"):
     m, vocab = build()
-    m.encoder.use_graphs = mode == "graphs"
+    m.encoder.use_graphs = mode != "eager"
+    m.encoder.graph_tape = mode == "tape"
     m.encoder.graph_auto = False
-    audio, alen, tok, tl = R.synthetic_batch(32, 20.0, vocab=vocab, seed=0)
+    if audio is None:
+        audio, alen, tok, tl = R.synthetic_batch(32, 20.0, vocab=vocab, seed=0)
     batch = [t.to(dev) for t in (audio, alen, tok, tl)]
     for _ in range(5):
         m.fit_step(batch)
@@ -79,6 +82,22 @@ for mode in ("graphs", "eager"):
     null_wall, issue_null = measure(m, batch, 10, null=True)
     res[mode] = {"step_ms": round(step_ms, 2), "issue_busy_ms": round(issue_busy, 2), "issue_null_ms": round(issue_null, 2),
                  "null_wall_ms": round(null_wall, 2), "graph_info": m.encoder.graph_info()}
+    if mode != "eager":
+        # PURE issue time of the recorded sequence: a second instance RECORDS under the null switch, so what it replays are
+        # empty kernels too and the GPU never pushes back
+        del m
+        torch.cuda.empty_cache()
+        m, _ = build()
+        m.encoder.use_graphs, m.encoder.graph_tape, m.encoder.graph_auto = True, mode == "tape", False
+        _lib.lib.mi355x_set_null_launch(1)
+        try:
+            for _ in range(5):
+                m.fit_step(batch)
+        finally:
+            _lib.lib.mi355x_set_null_launch(0)
+        nw, ni = measure(m, batch, 10, null=True)
+        res[mode]["recorded_null_issue_ms"] = round(ni, 2)
+        res[mode]["recorded_null_wall_ms"] = round(nw, 2)
     print(kind, mode, res[mode], flush=True)
     del m
     torch.cuda.empty_cache()
