@@ -177,6 +177,222 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ streaming depthwise conv (bf16)
+// The tile kernels above move every activation through an f32 LDS image twice (stage -> barrier -> taps -> image -> barrier ->
+// store) and ran at 1.35 / 1.5 TB/s for 33 / 50 MB of traffic: 27.7 / 51 us per layer (profiles/r3_pmc_hbm_traffic.md), bound by
+// that per-workgroup chain, not by HBM or the vector unit (two rewrites of the SAME structure changed nothing, r3_raw/
+// dwconv_packed_fma_experiment.txt).  Here the activations never touch LDS: a lane owns TWO adjacent channels (one packed-bf16
+// dword per row), a wave 128 channels; a lane's window of DS_TQ + KS - 1 rows comes straight from global memory with dword loads
+// (256 contiguous bytes per wave and row; the 2.9-fold re-read of neighbouring windows is L2 traffic) and its DS_TQ x 2 results
+// go straight back as packed dwords.  No barrier between load and store; only the 31 x 128 weights of the workgroup's channel
+// group are staged through LDS once (contiguous in memory, strided per lane).  The vector unit is the floor: 2 x 31 FMAs per
+// output pair.  dx of the backward pass IS this kernel with the taps flipped; the weight gradient is a second streaming kernel.
+#define DS_TQ 16                 // outputs per pass and lane (window = DS_TQ + KS - 1 rows)
+#define DS_WT (2 * DS_TQ)        // outputs per wave: two passes over one 2*DS_TQ + KS - 1 row window
+#define DS_NW 8                  // waves per workgroup of the forward / dx kernel (consecutive time tiles)
+#define DS_BT (DS_NW * DS_WT)    // outputs per workgroup: 256
+#define DS_CG 128                // channels per workgroup
+
+typedef float ds_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf_lo(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+// acc += w * x on both channels of the lane: one v_pk_fma_f32.  A packed op's result may not be read by the very next instruction
+// (gfx940+ forwarding hazard: one wait state); hipcc orders every output's 31-tap chain back to back and pays an s_nop per FMA.
+// Issued from here in tap-major order the dependent op is DS_TQ instructions away, so no wait state is ever needed.
+__device__ __forceinline__ void ds_pk_fma(ds_v2f& acc, const ds_v2f& w, const ds_v2f& x) {
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+}
+
+template <int KS, int NT>
+__device__ __forceinline__ void ds_stage_weights(const float* __restrict__ w, int cg0, int d, float* wl) {
+  for (int e = threadIdx.x; e < DS_CG * KS; e += NT) wl[e] = (cg0 * KS + e < d * KS) ? w[cg0 * KS + e] : 0.f;
+  __syncthreads();
+}
+// the lane's channel pair of row t of one utterance.  EDGE: rows outside [0, T) read as zero (row index clamped, value selected:
+// no branch); interior windows (all but the first and last tile of an utterance) load unconditionally from a running row pointer.
+template <bool EDGE>
+__device__ __forceinline__ ds_v2f ds_row(const char* __restrict__ ub, int t, int T, long long row_bytes, uint32_t lane_off, bool cv) {
+  ds_v2f r;
+  if (EDGE) {
+    const int tc = min(max(t, 0), T - 1);
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(ub + (long long)tc * row_bytes + lane_off);
+    const bool ok = cv && t >= 0 && t < T;
+    r.x = ok ? bf_lo(v) : 0.f;
+    r.y = ok ? bf_hi(v) : 0.f;
+  } else {
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(ub + (long long)t * row_bytes + lane_off);
+    r.x = bf_lo(v);
+    r.y = bf_hi(v);
+  }
+  return r;
+}
+
+// one wave's DS_WT outputs of the forward / dx kernel
+template <int KS, bool STATS, bool EDGE, int D>
+__device__ __forceinline__ void ds_wave_tile(const char* __restrict__ ub, char* __restrict__ yb, int t0, int T, int d, uint32_t lane_off,
+                                             bool cv, const ds_v2f (&wp)[KS], ds_v2f bv, ds_v2f& s1, ds_v2f& s2) {
+  constexpr int PAD = (KS - 1) / 2, WIN2 = DS_WT + KS - 1;
+  const long long row_bytes = D ? 2LL * D : 2LL * d;
+  const char* wb = EDGE ? ub : ub + (long long)(t0 - PAD) * row_bytes;  // (interior: constant row offsets from the window's first row)
+  ds_v2f xw[WIN2];
+#pragma unroll
+  for (int i = 0; i < WIN2; ++i) xw[i] = EDGE ? ds_row<true>(ub, t0 - PAD + i, T, row_bytes, lane_off, cv)
+                                              : ds_row<false>(wb, i, T, row_bytes, lane_off, cv);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (EDGE && t0 + p * DS_TQ >= T) break;
+    ds_v2f a[DS_TQ];
+#pragma unroll
+    for (int o = 0; o < DS_TQ; ++o) a[o] = bv;
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+      for (int o = 0; o < DS_TQ; ++o) ds_pk_fma(a[o], wp[k], xw[p * DS_TQ + o + k]);
+#pragma unroll
+    for (int o = 0; o < DS_TQ; ++o) {
+      const int t = t0 + p * DS_TQ + o;
+      if (!EDGE || (cv && t < T)) {
+        const uint32_t pk = pack_bf2(a[o].x, a[o].y);
+        *reinterpret_cast<uint32_t*>(yb + (long long)t * row_bytes + lane_off) = pk;
+        if (STATS) {
+          const float r0 = bf_lo(pk), r1 = bf_hi(pk);
+          s1.x += r0; s2.x = fmaf(r0, r0, s2.x);
+          s1.y += r1; s2.y = fmaf(r1, r1, s2.y);
+        }
+      }
+    }
+  }
+}
+
+// y[b,t,c] = bias[c] + sum_k w[c, FLIP ? KS-1-k : k] * x[b, t+k-PAD, c];  STATS: stats[0][c] += sum y, stats[1][c] += sum y^2 (of the
+// bf16-rounded outputs, t < T).  D: the channel count at compile time (row offsets become instruction immediates), 0 = run time.
+template <int KS, bool FLIP, bool STATS, int D>
+__global__ __launch_bounds__(64 * DS_NW) void dwconv_stream_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                                   double* __restrict__ stats, int T, int d) {
+  constexpr int PAD = (KS - 1) / 2;
+  __shared__ float wl[DS_CG * KS];
+  __shared__ float red[DS_NW][4][64];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg0 = blockIdx.x * DS_CG;
+  const int c = cg0 + 2 * lane;
+  const bool cv = c < d;  // (d is even: both channels of the pair are valid or none)
+  const uint32_t lane_off = (uint32_t)(cv ? c : 0) * 2u;
+  const int b = blockIdx.z;
+  ds_stage_weights<KS, 64 * DS_NW>(w, cg0, d, wl);
+  ds_v2f wp[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int kk = FLIP ? KS - 1 - k : k;
+    wp[k].x = wl[(2 * lane) * KS + kk];
+    wp[k].y = wl[(2 * lane + 1) * KS + kk];
+  }
+  ds_v2f bv;
+  bv.x = (cv && bias) ? bias[c] : 0.f;
+  bv.y = (cv && bias) ? bias[c + 1] : 0.f;
+  const long long row_bytes = D ? 2LL * D : 2LL * d;
+  const char* ub = reinterpret_cast<const char*>(x) + (long long)b * T * row_bytes;
+  char* yb = reinterpret_cast<char*>(y) + (long long)b * T * row_bytes;
+  ds_v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+  const int t0 = blockIdx.y * DS_BT + wv * DS_WT;
+  if (t0 < T) {  // (wave-uniform)
+    const bool interior = t0 - PAD >= 0 && t0 + DS_WT + PAD <= T && cg0 + DS_CG <= d;
+    if (interior) ds_wave_tile<KS, STATS, false, D>(ub, yb, t0, T, d, lane_off, cv, wp, bv, s1, s2);
+    else ds_wave_tile<KS, STATS, true, D>(ub, yb, t0, T, d, lane_off, cv, wp, bv, s1, s2);
+  }
+  if (STATS) {
+    red[wv][0][lane] = s1.x; red[wv][1][lane] = s1.y; red[wv][2][lane] = s2.x; red[wv][3][lane] = s2.y;
+    __syncthreads();
+    // thread -> (quantity q, lane): sum over the waves, one f64 atomic per (channel, statistic) and workgroup
+    if (wv < 4) {
+      const int q = wv;
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < DS_NW; ++i) v += red[i][q][lane];
+      const int cc = cg0 + 2 * lane + (q & 1);
+      if (cc < d) atomicAdd(stats + (q >> 1) * d + cc, (double)v);
+    }
+  }
+}
+
+// weight / bias gradient partials: partial[p][k][c] = sum over the slab's outputs of dy[t,c] * x[t+k-PAD,c] (k < KS), [KS][c] = sum dy
+// grid (d/128, DW_SEG, B): workgroup (cg, seg, b) walks the time tiles seg, seg + DW_SEG, ... of batch b (slab p = b*DW_SEG + seg);
+// a wave's tile = DS_WT outputs in passes of DSW_TQ over a CIRCULAR window of DSW_TQ + KS - 1 rows (row r lives in slot r % WIN: a
+// pass's new rows take the slots of the oldest -- all indices are compile-time, no register moves)
+#define DSW_BT (4 * DS_WT)
+#define DSW_TQ 8   // outputs per pass of the weight-gradient kernel (window = 38 rows: registers for three waves per SIMD)
+template <int KS, bool EDGE, int D>
+__device__ __forceinline__ void ds_wave_dw(const char* __restrict__ xb, const char* __restrict__ gb, int t0, int T, int d, uint32_t lane_off,
+                                           bool cv, ds_v2f (&gw)[KS], ds_v2f& gbias) {
+  constexpr int PAD = (KS - 1) / 2, WIN = DSW_TQ + KS - 1;
+  const long long row_bytes = D ? 2LL * D : 2LL * d;
+  const char* wb = EDGE ? xb : xb + (long long)(t0 - PAD) * row_bytes;
+  const char* wg = EDGE ? gb : gb + (long long)t0 * row_bytes;
+  ds_v2f xw[WIN], g[DSW_TQ];
+#pragma unroll
+  for (int i = 0; i < WIN; ++i) xw[i] = EDGE ? ds_row<true>(xb, t0 - PAD + i, T, row_bytes, lane_off, cv)
+                                             : ds_row<false>(wb, i, T, row_bytes, lane_off, cv);
+#pragma unroll
+  for (int p = 0; p < DS_WT / DSW_TQ; ++p) {
+    if (EDGE && t0 + p * DSW_TQ >= T) break;
+#pragma unroll
+    for (int o = 0; o < DSW_TQ; ++o) g[o] = EDGE ? ds_row<true>(gb, t0 + p * DSW_TQ + o, T, row_bytes, lane_off, cv)
+                                                 : ds_row<false>(wg, p * DSW_TQ + o, T, row_bytes, lane_off, cv);
+    if (p > 0) {
+#pragma unroll
+      for (int j = 0; j < DSW_TQ; ++j) {  // the pass's 8 new rows take the slots of the 8 oldest
+        const int r = WIN + (p - 1) * DSW_TQ + j;
+        xw[r % WIN] = EDGE ? ds_row<true>(xb, t0 - PAD + r, T, row_bytes, lane_off, cv) : ds_row<false>(wb, r, T, row_bytes, lane_off, cv);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < DSW_TQ; ++o) {
+      gbias += g[o];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) ds_pk_fma(gw[k], g[o], xw[(p * DSW_TQ + o + k) % WIN]);
+    }
+  }
+}
+template <int KS, int D>
+__global__ __launch_bounds__(256) void dwconv_dw_stream_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                               float* __restrict__ partial, int T, int d) {
+  constexpr int PAD = (KS - 1) / 2;
+  extern __shared__ float slab[];  // [4 waves][KS + 1][128]
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg0 = blockIdx.x * DS_CG;
+  const int c = cg0 + 2 * lane;
+  const bool cv = c < d;
+  const uint32_t lane_off = (uint32_t)(cv ? c : 0) * 2u;
+  const int b = blockIdx.z;
+  const long long row_bytes = D ? 2LL * D : 2LL * d;
+  const char* xb = reinterpret_cast<const char*>(x) + (long long)b * T * row_bytes;
+  const char* gb = reinterpret_cast<const char*>(dy) + (long long)b * T * row_bytes;
+  ds_v2f gw[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) gw[k] = ds_v2f{0.f, 0.f};
+  ds_v2f gbias = {0.f, 0.f};
+  const int ntile = (T + DSW_BT - 1) / DSW_BT;
+  for (int ti = blockIdx.y; ti < ntile; ti += gridDim.y) {
+    const int t0 = ti * DSW_BT + wv * DS_WT;
+    if (t0 >= T) break;
+    const bool interior = t0 - PAD >= 0 && t0 + DS_WT + PAD <= T && cg0 + DS_CG <= d;
+    if (interior) ds_wave_dw<KS, false, D>(xb, gb, t0, T, d, lane_off, cv, gw, gbias);
+    else ds_wave_dw<KS, true, D>(xb, gb, t0, T, d, lane_off, cv, gw, gbias);
+  }
+  float* mine = slab + wv * (KS + 1) * DS_CG;
+#pragma unroll
+  for (int k = 0; k < KS; ++k) *reinterpret_cast<ds_v2f*>(mine + k * DS_CG + 2 * lane) = gw[k];
+  *reinterpret_cast<ds_v2f*>(mine + KS * DS_CG + 2 * lane) = gbias;
+  __syncthreads();
+  float* pslab = partial + ((long long)(b * gridDim.y + blockIdx.y) * (KS + 1)) * d;
+  constexpr int PS = (KS + 1) * DS_CG;
+  for (int e = threadIdx.x; e < PS; e += 256) {
+    const int k = e / DS_CG, cl = e - k * DS_CG;
+    if (cg0 + cl >= d) continue;
+    pslab[(long long)k * d + cg0 + cl] = (slab[e] + slab[PS + e]) + (slab[2 * PS + e] + slab[3 * PS + e]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm
 // 1 / sqrt(var + eps) in f32 with one Newton step on the hardware estimate (<= 1 ulp; the mean and the variance themselves come
 // from the f64 sums): shared by the stand-alone and the fused statistics kernels so that both give the same bits
@@ -403,12 +619,26 @@ static inline int bn_grid(long long M, int d, int dt) {
 }
 static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
+// MI355X_DWCONV_STREAM=0: the LDS-tile kernels for every shape (A/B); default: the streaming kernels for bf16, k = 31, even d
+static bool dw_stream_ok(int dt, int d, int ksize) {
+  static const bool on = [] { const char* e = getenv("MI355X_DWCONV_STREAM"); return !(e && e[0] == '0'); }();
+  return on && dt == MI_DT_BF16 && ksize == 31 && (d % 2) == 0;
+}
 extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias, void* y, int dt, void* stats, int B, int T,
                                  int d, int ksize, void* stream) {
   mi_clear_errors();
   if (!x || !w || !y || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
   dim3 grid((d + DW_CH - 1) / DW_CH, (T + DW_TT - 1) / DW_TT, B), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (dw_stream_ok(dt, d, ksize)) {
+    dim3 gs((d + DS_CG - 1) / DS_CG, (T + DS_BT - 1) / DS_BT, B), bs(64 * DS_NW);
+#define DS_FWD(ST, DD) MI_LAUNCH((dwconv_stream_kernel<31, false, ST, DD>), gs, bs, 0, s, (const bf16_t*)x, (const float*)w, \
+    (const float*)bias, (bf16_t*)y, (double*)stats, T, d)
+    if (stats) { if (d == 512) DS_FWD(true, 512); else if (d == 256) DS_FWD(true, 256); else DS_FWD(true, 0); }
+    else { if (d == 512) DS_FWD(false, 512); else if (d == 256) DS_FWD(false, 256); else DS_FWD(false, 0); }
+#undef DS_FWD
+    return mi_check_launch();
+  }
 #define DW_FWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_fwd_kernel<TT, KS>), grid, block, 0, s, (const TT*)x, \
     (const float*)w, (const float*)bias, (TT*)y, (double*)stats, B, T, d))
   switch (ksize) {
@@ -427,6 +657,28 @@ extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, v
   hipStream_t s = (hipStream_t)stream;
   const int nparts = B * DW_SEG;
   if (scratch && scratch_elems < (long long)nparts * (ksize + 1) * d) return MI_ERR_ARG;
+  if (scratch && dw_stream_ok(dt, d, ksize)) {
+    // dx = the forward kernel with the taps flipped; the tap / bias gradient partials from their own streaming kernel
+    dim3 gs((d + DS_CG - 1) / DS_CG, (T + DS_BT - 1) / DS_BT, B), bs(64 * DS_NW);
+#define DS_DX(DD) MI_LAUNCH((dwconv_stream_kernel<31, true, false, DD>), gs, bs, 0, s, (const bf16_t*)dy, (const float*)w, \
+    (const float*)nullptr, (bf16_t*)dx, (double*)nullptr, T, d)
+    if (d == 512) DS_DX(512); else if (d == 256) DS_DX(256); else DS_DX(0);
+#undef DS_DX
+    const size_t shm = 4 * 32 * DS_CG * sizeof(float);
+    static const bool attr_ok =
+        hipFuncSetAttribute((const void*)dwconv_dw_stream_kernel<31, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess &&
+        hipFuncSetAttribute((const void*)dwconv_dw_stream_kernel<31, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess &&
+        hipFuncSetAttribute((const void*)dwconv_dw_stream_kernel<31, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess;
+    if (!attr_ok) return MI_ERR_LAUNCH;
+    dim3 gw_((d + DS_CG - 1) / DS_CG, DW_SEG, B);
+#define DS_DW(DD) MI_LAUNCH((dwconv_dw_stream_kernel<31, DD>), gw_, block, shm, s, (const bf16_t*)dy, (const bf16_t*)x, \
+    (float*)scratch, T, d)
+    if (d == 512) DS_DW(512); else if (d == 256) DS_DW(256); else DS_DW(0);
+#undef DS_DW
+    MI_LAUNCH(tap_reduce_kernel, dim3(((ksize + 1) * d + 255) / 256, 4), dim3(256), 0, s, (const float*)scratch, nparts,
+                       ksize, d, (float*)dw, (float*)dbias);
+    return mi_check_launch();
+  }
 #define DW_BWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS>), grid, block, 0, s, (const TT*)dy, \
     (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d))
   switch (ksize) {

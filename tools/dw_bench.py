@@ -23,5 +23,8 @@ def f_fwd():
     i=nxt(); ops.dwconv_fwd(xs[i],w,bias,ys[i],stats,B,T,d,k)
 def f_bwd():
     i=nxt(); ops.dwconv_bwd(dys[i],xs[i],w,dxs[i],dw,db,B,T,d,k)
+def f_fwd_nostats():
+    i=nxt(); ops.dwconv_fwd(xs[i],w,bias,ys[i],None,B,T,d,k)
 t("dw_fwd", f_fwd)
+t("dw_fwd_nostats", f_fwd_nostats)
 t("dw_bwd", f_bwd)
