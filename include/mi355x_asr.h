@@ -34,7 +34,12 @@ enum {
   MI355X_EPI_RESID = 2,      /* C(f32) = aux_in(f32) + alpha * dropout(acc + bias)             (residual branch) */
   MI355X_EPI_DSWISH = 3,     /* C = acc * dropmask * swish'(aux_in)                            (FFN dgrad)       */
   MI355X_EPI_RELU_MASK = 4,  /* C = relu(acc + bias) * [ (m % rows_per_b) / rows_inner < row_len[m / rows_per_b] ] */
-  MI355X_EPI_MUL_POS = 5     /* C = acc * (aux_in > 0)                                         (ReLU dgrad)      */
+  MI355X_EPI_MUL_POS = 5,    /* C = acc * (aux_in > 0)                                         (ReLU dgrad)      */
+  /* the feed-forward pair with the Swish derivative taken in the FORWARD epilogue (which holds sigmoid(h) and the dropout mask
+   * in registers anyway): aux_out = swish'(acc + bias) * dropmask instead of the pre-activation, and the backward epilogue is
+   * one multiply (no exp / rcp / mask hash per element).  ConformerFeedForward, parts/submodules/conformer_modules.py:366-387 */
+  MI355X_EPI_SWISH_DROP_G = 6, /* aux_out = swish'(acc + bias) * dropmask ; C = dropout(swish(acc + bias))        */
+  MI355X_EPI_DSWISH_G = 7      /* C = acc * aux_in            (aux_in = the aux_out of MI355X_EPI_SWISH_DROP_G)   */
 };
 typedef struct mi355x_gemm_desc {
   const void* A; const void* B; void* C;
@@ -310,6 +315,11 @@ long long mi355x_relpos_dpos_partial_elems(int B, int H, int T);
 int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len, void* dpos, long long ldd, void* dpos_cast,
                                  void* partial, long long partial_elems, int B, int H, int T, int dk, long long ds_elems,
                                  void* stream);
+
+/* which depthwise-convolution kernels run (tests and A/B): 0 = the LDS-tile kernels, 1 = the streaming kernel in the forward pass
+ * (default; bf16, k = 31, even d), 2 = in the backward pass too; level < 0 only queries.  Returns the previous level.
+ * Environment: MI355X_DWCONV_STREAM.  (CausalConv1D depthwise, parts/submodules/conformer_modules.py:333-337) */
+int mi355x_dwconv_config(int level);
 
 /* ---- convolution module: depthwise conv + BatchNorm + Swish (conformer_modules.py:333-342, causal_convs.py:130-147) */
 int mi355x_dwconv_fwd(const void* x, const void* w /*[d,1,k]*/, const void* bias, void* y, int dtype,

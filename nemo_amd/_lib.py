@@ -144,6 +144,7 @@ SIGNATURES = {
     "mi355x_rnnt_loss": [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, i64, vp],
     "mi355x_rnnt_greedy_decode": [vp, i32, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, i32,
                                   i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp],
+    "mi355x_dwconv_config": [i32],
     "mi355x_tape_log_begin": [vp],
     "mi355x_tape_log_end": [],
     "mi355x_tape_from_graph": [vp, i32, vp],

@@ -619,10 +619,26 @@ static inline int bn_grid(long long M, int d, int dt) {
 }
 static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
-// MI355X_DWCONV_STREAM=0: the LDS-tile kernels for every shape (A/B); default: the streaming kernels for bf16, k = 31, even d
-static bool dw_stream_ok(int dt, int d, int ksize) {
-  static const bool on = [] { const char* e = getenv("MI355X_DWCONV_STREAM"); return !(e && e[0] == '0'); }();
-  return on && dt == MI_DT_BF16 && ksize == 31 && (d % 2) == 0;
+// MI355X_DWCONV_STREAM: 0 = the LDS-tile kernels for every shape, 1 (default) = the streaming kernel in the FORWARD pass (bf16,
+// k = 31, even d), 2 = in the backward pass as well.  Alone the streaming kernels win both ways (forward 26.5 -> 21 us, backward
+// 46.5 -> 43 us per layer); inside the training step the backward pair LOSES 1.7 ms per step (same box, alternating runs: 42.46 vs
+// 44.1 ms): its 512-thread / 207-register workgroups need a whole CU, and during backward half the CUs hold a workgroup of the
+// weight-gradient stream's grouped GEMM for ~270 us at a time -- the 256-thread / ~100-register tile kernels fit beside those.
+static int g_dw_level = -1;  // -1: not yet read from the environment (set once per process, or by mi355x_dwconv_config from tests)
+static int dw_stream_level() {
+  if (g_dw_level < 0) {
+    const char* e = getenv("MI355X_DWCONV_STREAM");
+    g_dw_level = (e && e[0]) ? atoi(e) : 1;
+  }
+  return g_dw_level;
+}
+extern "C" int mi355x_dwconv_config(int level) {
+  const int old = dw_stream_level();
+  if (level >= 0) g_dw_level = level;
+  return old;
+}
+static bool dw_stream_ok(int dt, int d, int ksize, int level) {
+  return dw_stream_level() >= level && dt == MI_DT_BF16 && ksize == 31 && (d % 2) == 0;
 }
 extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias, void* y, int dt, void* stats, int B, int T,
                                  int d, int ksize, void* stream) {
@@ -630,7 +646,7 @@ extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias,
   if (!x || !w || !y || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
   dim3 grid((d + DW_CH - 1) / DW_CH, (T + DW_TT - 1) / DW_TT, B), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (dw_stream_ok(dt, d, ksize)) {
+  if (dw_stream_ok(dt, d, ksize, 1)) {
     dim3 gs((d + DS_CG - 1) / DS_CG, (T + DS_BT - 1) / DS_BT, B), bs(64 * DS_NW);
 #define DS_FWD(ST, DD) MI_LAUNCH((dwconv_stream_kernel<31, false, ST, DD>), gs, bs, 0, s, (const bf16_t*)x, (const float*)w, \
     (const float*)bias, (bf16_t*)y, (double*)stats, T, d)
@@ -657,7 +673,7 @@ extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, v
   hipStream_t s = (hipStream_t)stream;
   const int nparts = B * DW_SEG;
   if (scratch && scratch_elems < (long long)nparts * (ksize + 1) * d) return MI_ERR_ARG;
-  if (scratch && dw_stream_ok(dt, d, ksize)) {
+  if (scratch && dw_stream_ok(dt, d, ksize, 2)) {
     // dx = the forward kernel with the taps flipped; the tap / bias gradient partials from their own streaming kernel
     dim3 gs((d + DS_CG - 1) / DS_CG, (T + DS_BT - 1) / DS_BT, B), bs(64 * DS_NW);
 #define DS_DX(DD) MI_LAUNCH((dwconv_stream_kernel<31, true, false, DD>), gs, bs, 0, s, (const bf16_t*)dy, (const float*)w, \

@@ -49,6 +49,7 @@ struct GemmP {
   int epi; int c_dt; int atomic;
   const void* aux_in; int auxin_dt; void* aux_out; int auxout_dt; long long ldaux;
   DropCfg drop;
+  int swish_g;                         // see swish_fwd8 / the EPI_DSWISH sites: aux = swish'(h) * mask instead of h
   const long long* row_len; int rows_per_b; int rows_inner;
   int splitk; int ktiles_per_split;
   long long colsum_stride;             // batch stride (z0) of colsum_out
@@ -103,6 +104,19 @@ __device__ __forceinline__ void stx(void* p, long long i, int dt, float v) {
   if (dt == MI_DT_F32) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = f2bf(v);
 }
 
+// ---- Swish epilogues of the feed-forward pair.  Default (swish_g = 0): the forward GEMM keeps the pre-activation h and the
+// backward GEMM's epilogue evaluates swish'(h) and re-creates the dropout mask per element -- exp + rcp + the mask hash, ~23 of its
+// ~26 vector-op slots per element, 10 us per 256 x 256 tile on top of a 16-us K loop (profiles/r3_gemm_structures.md section 4).
+// swish_g = 1: the forward epilogue, which has sigmoid(h) and the mask in registers anyway, stores g = swish'(h) * mask (bf16, the
+// same 2 bytes per element) and the backward epilogue is one multiply: dh = acc * g.  g is rounded to bf16 once more than
+// swish'(bf16 h) would be -- the same class of rounding as every other stored activation of the bf16 path.
+__device__ __forceinline__ void swish_pair(float h, float dm, float& act, float& g) {
+  const float s = sigmoidf_(h);
+  const float sw = h * s;
+  act = sw * dm;
+  g = fmaf(sw, 1.f - s, s) * dm;
+}
+
 __device__ __forceinline__ void epilogue(const GemmP& p, int z, long long coff, int m, int n, float acc) {
   const long long mr = crow(p, m);
   const long long ci = coff + mr * p.ldc + (long long)n * p.csc;
@@ -113,13 +127,22 @@ __device__ __forceinline__ void epilogue(const GemmP& p, int z, long long coff, 
   switch (p.epi) {
     case EPI_STORE: v *= p.alpha * drop_mask(p.drop, didx); break;
     case EPI_SWISH_DROP:
-      stx(p.aux_out, ai, p.auxout_dt, v);
-      v = swishf_(v) * drop_mask(p.drop, didx);
+      if (p.swish_g) {
+        float a_, g_;
+        swish_pair(v, drop_mask(p.drop, didx), a_, g_);
+        stx(p.aux_out, ai, p.auxout_dt, g_);
+        v = a_;
+      } else {
+        stx(p.aux_out, ai, p.auxout_dt, v);
+        v = swishf_(v) * drop_mask(p.drop, didx);
+      }
       break;
     case EPI_RESID:
       v = ((const float*)p.aux_in)[ai] + p.alpha * v * drop_mask(p.drop, didx);
       break;
-    case EPI_DSWISH: v = v * drop_mask(p.drop, didx) * swish_grad(ldx(p.aux_in, ai, p.auxin_dt)); break;
+    case EPI_DSWISH:
+      v = p.swish_g ? v * ldx(p.aux_in, ai, p.auxin_dt) : v * drop_mask(p.drop, didx) * swish_grad(ldx(p.aux_in, ai, p.auxin_dt));
+      break;
     case EPI_RELU_MASK: {
       int b = m / p.rows_per_b;
       int t = (m - b * p.rows_per_b) / p.rows_inner;
@@ -175,9 +198,16 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, int z, long long coff,
       for (int j = 0; j < 8; ++j) v[j] *= p.alpha * dm[j];
       break;
     case EPI_SWISH_DROP:
-      st8x(p.aux_out, ai, p.auxout_dt, v);
+      if (p.swish_g) {
+        float g[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * dm[j];
+        for (int j = 0; j < 8; ++j) swish_pair(v[j], dm[j], v[j], g[j]);
+        st8x(p.aux_out, ai, p.auxout_dt, g);
+      } else {
+        st8x(p.aux_out, ai, p.auxout_dt, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * dm[j];
+      }
       break;
     case EPI_RESID: {
       float r[8];
@@ -188,8 +218,13 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, int z, long long coff,
     case EPI_DSWISH: {
       float h[8];
       ld8x(p.aux_in, ai, p.auxin_dt, h);
+      if (p.swish_g) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = v[j] * dm[j] * swish_grad(h[j]);
+        for (int j = 0; j < 8; ++j) v[j] *= h[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * dm[j] * swish_grad(h[j]);
+      }
     } break;
     case EPI_RELU_MASK: {
       const int b = m / p.rows_per_b;
@@ -266,15 +301,27 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= p.alpha * dm[j];
     } else if (EPI == EPI_SWISH_DROP) {
-      st8x(p.aux_out, ai, p.auxout_dt, v);
+      if (p.swish_g) {
+        float g[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * dm[j];
+        for (int j = 0; j < 8; ++j) swish_pair(v[j], dm[j], v[j], g[j]);
+        st8x(p.aux_out, ai, p.auxout_dt, g);
+      } else {
+        st8x(p.aux_out, ai, p.auxout_dt, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * dm[j];
+      }
     } else if (EPI == EPI_RESID) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = aux[AUX_IN ? it : 0][j] + p.alpha * v[j] * dm[j];
     } else if (EPI == EPI_DSWISH) {
+      if (p.swish_g) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = v[j] * dm[j] * swish_grad(aux[AUX_IN ? it : 0][j]);
+        for (int j = 0; j < 8; ++j) v[j] *= aux[AUX_IN ? it : 0][j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * dm[j] * swish_grad(aux[AUX_IN ? it : 0][j]);
+      }
     } else if (EPI == EPI_RELU_MASK) {
       const int bb = m / p.rows_per_b;
       const int t = (m - bb * p.rows_per_b) / p.rows_inner;
@@ -1175,7 +1222,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_grouped_tn_kernel(GroupP g) {
   p.lda = g.lda[pi]; p.ldb = g.ldb[pi]; p.ldc = g.ldc[pi]; p.csc = 1;
   p.transA = 1; p.transB = 1; p.batch = 1; p.nb0 = 1;
   p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = 0;
-  p.bias = nullptr; p.alpha = 1.f; p.epi = EPI_STORE; p.c_dt = MI_DT_F32; p.atomic = 1;
+  p.bias = nullptr; p.alpha = 1.f; p.epi = EPI_STORE; p.c_dt = MI_DT_F32; p.atomic = 1; p.swish_g = 0;
   p.aux_in = nullptr; p.auxin_dt = 0; p.aux_out = nullptr; p.auxout_dt = 0; p.ldaux = 0;
   p.drop.key = 0u; p.drop.threshold = 0u; p.drop.scale = 1.f; p.drop.step = nullptr;
   p.row_len = nullptr; p.rows_per_b = 1; p.rows_inner = 1;
@@ -1741,12 +1788,25 @@ __device__ __forceinline__ void v5_round(const GemmP& p, const V5Win& w, const f
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= p.alpha * dm[j];
   } else if (EPI == EPI_SWISH_DROP) {
-    st8x(p.aux_out, ai, p.auxout_dt, v);
+    if (p.swish_g) {
+      float g[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * dm[j];
+      for (int j = 0; j < 8; ++j) swish_pair(v[j], dm[j], v[j], g[j]);
+      st8x(p.aux_out, ai, p.auxout_dt, g);
+    } else {
+      st8x(p.aux_out, ai, p.auxout_dt, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * dm[j];
+    }
   } else if (EPI == EPI_RESID) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = __uint_as_float(aux[j >> 2][j & 3]) + p.alpha * v[j] * dm[j];
+  } else if (p.swish_g) {  // EPI_DSWISH, aux_in = g (bf16): one multiply per element
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[2 * j] *= __uint_as_float(aux[0][j] << 16);
+      v[2 * j + 1] *= __uint_as_float(aux[0][j] & 0xffff0000u);
+    }
   } else {  // EPI_DSWISH (aux_in bf16)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -2146,6 +2206,9 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
   p.bias = (const float*)d->bias; p.alpha = d->alpha;
   p.epi = d->epilogue; p.c_dt = d->c_dtype; p.atomic = d->atomic;
+  p.swish_g = 0;
+  if (p.epi == 6) { p.epi = EPI_SWISH_DROP; p.swish_g = 1; }   // MI355X_EPI_SWISH_DROP_G
+  else if (p.epi == 7) { p.epi = EPI_DSWISH; p.swish_g = 1; }  // MI355X_EPI_DSWISH_G
   p.aux_in = d->aux_in; p.auxin_dt = d->aux_in_dtype; p.aux_out = d->aux_out; p.auxout_dt = d->aux_out_dtype;
   p.ldaux = d->ldaux;
   p.drop = mi_drop(d->drop_key, d->drop_threshold, d->drop_scale);

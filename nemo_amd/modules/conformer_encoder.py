@@ -283,6 +283,9 @@ class ConformerEncoder(NeuralModule):
         # profiles/r4_ffn_fused.md): at 64 tokens per workgroup the weight stream through the 64 B/clk vector-memory path, the MFMA
         # work and the Swish / dropout VALU work each cost ~28 us per launch and overlap only partly.  MI355X_FFN_FUSED=1 enables.
         self.ffn_fused = os.environ.get("MI355X_FFN_FUSED", "0") != "0"
+        # bf16 feed-forward pair: linear1's epilogue stores swish'(h) * dropout mask instead of h, the Swish-gradient GEMM's epilogue
+        # is one multiply (MI355X_EPI_SWISH_DROP_G / _DSWISH_G; MI355X_SWISH_G=0: the pre-activation form)
+        self.swish_g = os.environ.get("MI355X_SWISH_G", "1") != "0"
         self._saving = False        # the forward in progress keeps its activations for a backward
         self.dpos_side_stream = os.environ.get("MI355X_DPOS_STREAM", "1") != "0"
         self.sub_wgrad_side_stream = os.environ.get("MI355X_SUB_WGRAD_STREAM", "1") != "0"
@@ -505,7 +508,7 @@ class ConformerEncoder(NeuralModule):
         return (tuple(mel.shape), self._cdt(), str(mel.device), self._flatp.generation, self._syncbn_world(),
                 self.grad_ready_hook is not None, self._wgrad_join_per_layer, self.wgrad_side_stream, self.wgrad_grouped,
                 self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse,
-                self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.graph_tape, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder)
+                self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.graph_tape, self.swish_g, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder)
 
     def _auto_begin(self, gs, mode):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -1010,12 +1013,13 @@ class ConformerEncoder(NeuralModule):
             setattr(sl, tag, (x, y, mean, rstd, h, None, d_in, d_res))
             return r
         a = self._new(M, dff, dtype=cdt, device=dev)
-        ops.gemm(y, W[pfx + ".w1"], a, M, dff, d, d, W.pitch(pfx + ".w1"), dff, bias=ff.linear1.bias, epi=ops.EPI_SWISH_DROP,
-                 aux_out=h, drop=d_in)
+        g_form = self.swish_g and cdt == torch.bfloat16  # `h` then holds swish'(h) * mask (see __init__)
+        ops.gemm(y, W[pfx + ".w1"], a, M, dff, d, d, W.pitch(pfx + ".w1"), dff, bias=ff.linear1.bias,
+                 epi=ops.EPI_SWISH_DROP_G if g_form else ops.EPI_SWISH_DROP, aux_out=h, drop=d_in)
         r = self._new(M, d, dtype=torch.float32, device=dev)
         ops.gemm(a, W[pfx + ".w2"], r, M, d, dff, dff, W.pitch(pfx + ".w2"), d, bias=ff.linear2.bias, alpha=0.5,
                  epi=ops.EPI_RESID, aux_in=x, drop=d_res)
-        setattr(sl, tag, (x, y, mean, rstd, h, a, d_in, d_res))
+        setattr(sl, tag, (x, y, mean, rstd, h, a, None if g_form else d_in, d_res))
         return r
 
     def _geometry(self, cdt):
@@ -1435,7 +1439,10 @@ class ConformerEncoder(NeuralModule):
             self._wgrad(dh, dff, 0, y, d, 0, ff.linear1.weight.grad, dff, d, M, bias_grad=ff.linear1.bias.grad)
         else:
             self._wgrad(df, d, 0, a, dff, 0, ff.linear2.weight.grad, d, dff, M, bias_grad=ff.linear2.bias.grad)
-            ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, d, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH, aux_in=h, drop=d_in)
+            if d_in is None:  # the forward stored swish'(h) * mask (swish_g): one multiply per element
+                ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, d, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH_G, aux_in=h)
+            else:
+                ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, d, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH, aux_in=h, drop=d_in)
             self._wgrad(dh, dff, 0, y, d, 0, ff.linear1.weight.grad, dff, d, M, bias_grad=ff.linear1.bias.grad)
             ops.gemm(dh, W[pfx + ".w1t"], dy, M, d, dff, dff, W.pitch(pfx + ".w1t"), d)
         nxt = self._cast_buf(next_cast, M, d, cdt, dev)

@@ -418,8 +418,11 @@ class SqueezeformerEncoder(ConformerEncoder):
         h = self._new(M, dff, dtype=cdt, device=dev)
         a = self._new(M, dff, dtype=cdt, device=dev)
         d_in, d_res = drop(self.dropout, site), drop(self.dropout, site + 1)
-        ops.gemm(y, W[pfx + ".w1"], a, M, dff, d, dp, W.pitch(pfx + ".w1"), dff, bias=ff.linear1.bias, epi=ops.EPI_SWISH_DROP,
-                 aux_out=h, drop=d_in)
+        g_form = self.swish_g and cdt == torch.bfloat16  # `h` then holds swish'(h) * mask (ConformerEncoder.__init__)
+        ops.gemm(y, W[pfx + ".w1"], a, M, dff, d, dp, W.pitch(pfx + ".w1"), dff, bias=ff.linear1.bias,
+                 epi=ops.EPI_SWISH_DROP_G if g_form else ops.EPI_SWISH_DROP, aux_out=h, drop=d_in)
+        if g_form:
+            d_in = None
         r = self._new(M, d, dtype=torch.float32, device=dev)
         ops.gemm(a, W[pfx + ".w2"], r, M, d, dff, dff, W.pitch(pfx + ".w2"), d, bias=ff.linear2.bias, epi=ops.EPI_RESID,
                  aux_in=x, drop=d_res)  # fc_factor = 1.0 (squeezeformer_modules.py:103)
@@ -514,7 +517,10 @@ class SqueezeformerEncoder(ConformerEncoder):
         dr, df = self._branch_grad(ln, dxo, r, mean, rstd, M, d_res, cdt, dp)
         self._wgrad(df, dp, 0, a, dff, 0, ff.linear2.weight.grad, d, dff, M, bias_grad=ff.linear2.bias.grad)
         dh = self._new(M, dff, dtype=cdt, device=dev)
-        ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, dp, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH, aux_in=h, drop=d_in)
+        if d_in is None:
+            ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, dp, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH_G, aux_in=h)
+        else:
+            ops.gemm(df, W[pfx + ".w2t"], dh, M, dff, d, dp, W.pitch(pfx + ".w2t"), dff, epi=ops.EPI_DSWISH, aux_in=h, drop=d_in)
         self._wgrad(dh, dff, 0, y, dp, 0, ff.linear1.weight.grad, dff, d, M, bias_grad=ff.linear1.bias.grad)
         dy = self._new(M, dp, dtype=cdt, device=dev)
         ops.gemm(dh, W[pfx + ".w1t"], dy, M, d, dff, dff, W.pitch(pfx + ".w1t"), dp)

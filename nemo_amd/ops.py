@@ -13,7 +13,7 @@ import torch
 from ._lib import ConvGather, GemmDesc, PackEntry, RowMap, check, lib
 
 F32, BF16 = 0, 1
-EPI_STORE, EPI_SWISH_DROP, EPI_RESID, EPI_DSWISH, EPI_RELU_MASK, EPI_MUL_POS = range(6)
+EPI_STORE, EPI_SWISH_DROP, EPI_RESID, EPI_DSWISH, EPI_RELU_MASK, EPI_MUL_POS, EPI_SWISH_DROP_G, EPI_DSWISH_G = range(8)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 

@@ -177,6 +177,42 @@ def test_gemm_epilogues(dtype):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("shape", [(260, 384, 192), (1031, 2048, 512), (4100, 2048, 512)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_swish_derivative_taken_in_the_forward_epilogue(dtype, shape):
+    """MI355X_EPI_SWISH_DROP_G / _DSWISH_G against the pre-activation pair (same dropout site): the activations are the same bits,
+    the stored factor is swish'(h) * mask, and the backward product follows the pre-activation form within one more bf16 rounding.
+    Shapes: the generic 256 x 128 structure, the 256 x 256 structure (N = 2048) and the persistent one (bf16, more tiles than CUs)."""
+    o = ops()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(12)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) * 0.1).to(dtype)
+    bias = torch.randn(N, generator=g)
+    Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+    drop = o.Dropout(0.1, 77, 5)
+    h = torch.empty(M, N, device=dev, dtype=dtype); a = torch.empty_like(h)
+    gf = torch.empty_like(h); a2 = torch.empty_like(h)
+    o.gemm(Ad, Wd, a, M, N, K, K, K, N, bias=bd, epi=o.EPI_SWISH_DROP, aux_out=h, drop=drop)
+    o.gemm(Ad, Wd, a2, M, N, K, K, K, N, bias=bd, epi=o.EPI_SWISH_DROP_G, aux_out=gf, drop=drop)
+    torch.cuda.synchronize()
+    assert torch.equal(a, a2)
+    acc = A.float() @ W.float().t() + bias
+    sg = torch.sigmoid(acc)
+    mask = (a.float().cpu() != 0) | (acc * sg == 0)            # kept elements (the mask is regenerated, not stored)
+    want_g = sg * (1 + acc * (1 - sg)) * mask / 0.9
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(gf, want_g) < tol
+    # backward: dh = (dy @ W2^T) * swish'(h) * mask
+    dy = torch.randn(M, K, generator=g).to(dtype).to(dev)
+    dh1 = torch.empty_like(h); dh2 = torch.empty_like(h)
+    o.gemm(dy, Wd, dh1, M, N, K, K, K, N, epi=o.EPI_DSWISH, aux_in=h, drop=drop)
+    o.gemm(dy, Wd, dh2, M, N, K, K, K, N, epi=o.EPI_DSWISH_G, aux_in=gf)
+    torch.cuda.synchronize()
+    assert rel_err(dh2, dh1) < tol
+    assert torch.equal(dh1 == 0, dh2 == 0) or dtype == torch.float32   # the same elements are dropped
+
+
 def test_gemm_batched_strided_bf16():
     """attention-style: q [B*T, 3d] head slices, scores [H,B,T,Tp] -- two-level batch strides."""
     o = ops()
@@ -698,6 +734,16 @@ def test_dwconv_bn_swish(dtype, geom):
     """(bf16, even d: the streaming kernels of csrc/convmod.hip -- a partly filled channel group, the headline geometry, a
     ragged last group and time tile; f32: the LDS-tile kernels)"""
     o = ops()
+    from nemo_amd._lib import lib
+    prev = lib.mi355x_dwconv_config(2)  # streaming kernels in both directions (the default keeps the tile kernels in backward)
+    try:
+        _dwconv_bn_swish(o, dtype, geom)
+    finally:
+        lib.mi355x_dwconv_config(prev)
+    _dwconv_bn_swish(o, dtype, geom)
+
+
+def _dwconv_bn_swish(o, dtype, geom):
     (Bn, T, d), k = geom, 31
     g = torch.Generator().manual_seed(8)
     x = torch.randn(Bn, T, d, generator=g).to(dtype)
