@@ -425,6 +425,11 @@ int mi355x_set_null_launch(int on);
  *                                  order themselves behind those streams (the optimizer slice / gradient bucket of a layer does)
  *   mi355x_tape_join(t, s)         s continues behind whatever t's side lanes hold now (what a replay with join = 0 left out)
  *   mi355x_tape_info               counts[6] = kernels, memsets, memcpys, empty nodes, lanes, cross-lane events */
+/* A stream that belongs to its caller alone (non-blocking, HIP priority clamped to the device's range: 0 = default, negative =
+ * more urgent).  torch.cuda.Stream() objects come out of a 32-entry round-robin pool and are SHARED once a process has created
+ * more than 32: a capture stream, a weight-gradient stream and a copy stream must not be the same stream (csrc/tape.hip). */
+int mi355x_stream_create(int priority, void** out_stream);
+int mi355x_stream_destroy(void* stream);
 typedef struct mi355x_tape mi355x_tape;
 int mi355x_tape_log_begin(void* origin_stream);
 int mi355x_tape_log_end(void);

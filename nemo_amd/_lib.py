@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch FIRST: the ROCm wheel carries its own libamdhip64 (torch/lib); a process must run ONE HIP runtime, and it has to be the
+# one torch's streams / allocator / events live in.  Loaded before torch, this library would pull /opt/rocm's copy in under the
+# same soname and torch would silently run on it (seen as hipFuncSetAttribute failing on the first launch).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355X_ASR_LIB", os.path.join(_HERE, "lib", "libmi355x_asr.so"))
 
@@ -145,6 +150,8 @@ SIGNATURES = {
     "mi355x_rnnt_greedy_decode": [vp, i32, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, i32,
                                   i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp],
     "mi355x_dwconv_config": [i32],
+    "mi355x_stream_create": [i32, vp],
+    "mi355x_stream_destroy": [vp],
     "mi355x_tape_log_begin": [vp],
     "mi355x_tape_log_end": [],
     "mi355x_tape_from_graph": [vp, i32, vp],
@@ -185,6 +192,8 @@ def check(rc: int, what: str = ""):
         return
     if rc == 1:
         raise ValueError(f"libmi355x_asr: invalid argument in {what}")
+    if rc == 2:  # MI_ERR_LAUNCH: a launch attribute (dynamic LDS size) was refused before anything was launched
+        raise RuntimeError(f"libmi355x_asr: launch configuration refused in {what} (hipFuncSetAttribute failed)")
     raise RuntimeError(f"libmi355x_asr: kernel launch failed in {what} (hipError_t={rc - 1000 if rc >= 1000 else rc})")
 
 

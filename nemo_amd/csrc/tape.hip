@@ -327,3 +327,25 @@ extern "C" int mi355x_tape_info(const mi355x_tape* t, int* counts) {
   counts[4] = 1 + (int)t->side.size(); counts[5] = (int)t->ev.size();
   return MI_OK;
 }
+
+// ---- private streams.  torch hands its streams out of a fixed pool (32 per priority and device), round-robin: the 33rd
+// torch.cuda.Stream() of a process IS the first one again.  Two owners that believe they hold different streams -- the capture
+// stream of the recorded launch sequences, an encoder's weight-gradient stream, the input pipeline's copy stream -- then share
+// one, and a host-to-device copy issued by the loader thread lands inside somebody's stream capture ("capturing stream has
+// unjoined work", seen once the GPU suite had grown past 32 stream creations).  Streams created here belong to their owner alone;
+// the Python side wraps them as torch.cuda.ExternalStream (nemo_amd/streams.py).
+extern "C" int mi355x_stream_create(int priority, void** out) {
+  if (!out) return MI_ERR_ARG;
+  hipStream_t s = nullptr;
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent (numerically greatest), hi = most urgent
+  int pr = priority < hi ? hi : (priority > lo ? lo : priority);
+  TAPE_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, pr));
+  *out = (void*)s;
+  return MI_OK;
+}
+extern "C" int mi355x_stream_destroy(void* stream) {
+  if (!stream) return MI_ERR_ARG;
+  TAPE_HIP(hipStreamDestroy((hipStream_t)stream));
+  return MI_OK;
+}

@@ -42,7 +42,11 @@ class DeviceBatchLoader:
         self.device = torch.device(device)
         self.prefetch = max(1, prefetch)
         self.cuda = self.device.type == "cuda"
-        self._copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        if self.cuda:
+            from ..streams import private_stream  # (never a stream somebody else may be capturing on)
+            self._copy_stream = private_stream(self.device)
+        else:
+            self._copy_stream = None
         # prefetch + 1 slots: one being filled, `prefetch` queued, and the consumer's batch keeps its own device tensors
         self._slots = [_Slot() for _ in range(self.prefetch + 1)]
 

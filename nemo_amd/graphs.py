@@ -37,7 +37,8 @@ def capture_stream(device) -> "torch.cuda.Stream":
     key = str(device)
     s = _CAPTURE_STREAMS.get(key)
     if s is None:
-        s = _CAPTURE_STREAMS[key] = torch.cuda.Stream(device=device)
+        from .streams import private_stream  # (a pooled torch stream may also be somebody's copy / side stream)
+        s = _CAPTURE_STREAMS[key] = private_stream(device)
     return s
 
 

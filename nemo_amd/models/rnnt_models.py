@@ -139,7 +139,8 @@ class EncDecRNNTModel(EncDecCTCModel):
         if self.pred_side_stream and signal.is_cuda:
             cur = torch.cuda.current_stream(signal.device)
             if self._pred_stream is None or self._pred_stream.device != signal.device:
-                self._pred_stream = torch.cuda.Stream(device=signal.device)
+                from ..streams import private_stream
+                self._pred_stream = private_stream(signal.device)
             self._pred_stream.wait_stream(cur)
             with torch.cuda.stream(self._pred_stream):
                 decoder, target_length, _ = self.decoder(targets=transcript, target_length=transcript_len)

@@ -743,7 +743,8 @@ class ConformerEncoder(NeuralModule):
             # MI355X_WGRAD_PRIO: -1 = high, 0 = default, 1 = low (HIP stream priorities): nothing on the backward chain waits
             # for a weight gradient, so the chain's kernels should win the CUs whenever both streams have workgroups pending
             prio = int(os.environ.get("MI355X_WGRAD_PRIO", "0"))
-            self._wg_stream = torch.cuda.Stream(device=dev, priority=prio) if prio else torch.cuda.Stream(device=dev)
+            from ..streams import private_stream  # (torch's pooled streams are shared beyond 32 creations per process)
+            self._wg_stream = private_stream(dev, priority=prio)
         side = self._wg_stream
         side.wait_stream(torch.cuda.current_stream(dev))  # operands are produced on the main stream
         if self._capture is not None:

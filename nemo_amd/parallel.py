@@ -57,6 +57,8 @@ class GradSync:
         self._reduced: List[Tuple[int, int]] = []
         cuda = grad.is_cuda
         self.use_side_stream = cuda if use_side_stream is None else (use_side_stream and cuda)
+        # (a pooled torch stream on purpose: the RCCL process group orders itself against torch's current stream, and that pairing is
+        #  the one the collectives have always run with; nemo_amd/streams.py is for the streams that may meet a stream capture)
         self._stream = torch.cuda.Stream(device=grad.device) if self.use_side_stream else None
         # streams other than the current one that also write gradients (the encoder's weight-gradient stream): the
         # exchange stream waits for them too, the backward chain itself never does
