@@ -420,6 +420,17 @@ def main():
                 want = world * (world + 1) / 2.0
                 if not bool((t == want).all()):
                     raise SystemExit(f"bench.py: pre-flight all-reduce on the '{gname}' communicator returned {t[0].item()}, expected {want}")
+        # ... and one exchange per statistics mailbox (MI355X_SYNCBN_MAILBOX=1: peer-mapped memory instead of a communicator)
+        for m in model.trainable_modules():
+            mbx = getattr(m, "_syncbn_mailbox", None)
+            if mbx is not None:
+                t = torch.full((1025,), float(rank + 1), device=dev, dtype=torch.float64)
+                mbx.all_reduce_(t)
+                torch.cuda.synchronize()
+                done, missing, kind = mbx.status()
+                if missing or not bool((t == world * (world + 1) / 2.0).all()):
+                    raise SystemExit(f"bench.py: pre-flight exchange over the statistics mailbox failed on rank {rank} "
+                                     f"(value {t[0].item()}, missing rank {missing - 1 if missing else None}, memory kind {kind})")
         if rank == 0:
             print(f"[bench] pre-flight all-reduce ok on {world} ranks ({backend})", file=sys.stderr, flush=True)
     loss = None
@@ -514,6 +525,9 @@ def main():
                                          for gs in syncs for (n_, e0, e1) in gs.bucket_events_last_step],
             "tail_bytes": int(syncs[0].tail_elems * 4),
             "syncbn_own_process_group": os.environ.get("MI355X_SYNCBN_OWN_GROUP", "0") == "1",
+            # how the statistics travel: "mailbox" = one kernel launch per exchange over peer-mapped memory (csrc/mailbox.hip),
+            # "process group" = torch.distributed.all_reduce
+            "syncbn_exchange": ("mailbox" if getattr(model.encoder, "_syncbn_mailbox", None) is not None else "process group"),
         })
 
     roof = None
@@ -569,10 +583,13 @@ def main():
         traffic = mfma_busy = None
         traffic_note = "not reported: no PMC table for this build of the GEMM sources"
         try:
-            with open(os.path.join(ROOT, "profiles", "r3_gemm_traffic.json")) as f:
+            import glob
+            tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic.json")))[-1]  # the latest round's table
+            with open(tfile) as f:
                 tj = json.load(f)
             if tj.get("source_sha256_16") != _source_hash():
-                traffic_note = "not reported: profiles/r3_gemm_traffic.json was measured on other GEMM sources (hash mismatch)"
+                traffic_note = (f"not reported: profiles/{os.path.basename(tfile)} was measured on other GEMM sources "
+                                "(hash mismatch)")
             elif tj.get("kernel") == f"gemm_{dom[0]}" and a.size == "large" and a.batch == 32 and a.dtype == "bf16":
                 traffic = tj["traffic_bytes_per_launch"]
                 mfma_busy = tj.get("mfma_busy_frac")

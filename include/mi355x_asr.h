@@ -316,8 +316,9 @@ int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len
                                  void* partial, long long partial_elems, int B, int H, int T, int dk, long long ds_elems,
                                  void* stream);
 
-/* which depthwise-convolution kernels run (tests and A/B): 0 = the LDS-tile kernels, 1 = the streaming kernel in the forward pass
- * (default; bf16, k = 31, even d), 2 = in the backward pass too; level < 0 only queries.  Returns the previous level.
+/* which depthwise-convolution kernels run (tests and A/B): 0 = the LDS-tile kernels (default: faster inside the training step),
+ * 1 = the streaming kernel in the forward pass (bf16, k = 31, even d), 2 = in the backward pass too; level < 0 only queries.
+ * Returns the previous level.
  * Environment: MI355X_DWCONV_STREAM.  (CausalConv1D depthwise, parts/submodules/conformer_modules.py:333-337) */
 int mi355x_dwconv_config(int level);
 
@@ -438,6 +439,32 @@ int mi355x_tape_replay(mi355x_tape* tape, void* stream, int join);
 int mi355x_tape_join(mi355x_tape* tape, void* stream);
 int mi355x_tape_info(const mi355x_tape* tape, int* counts);
 void mi355x_tape_destroy(mi355x_tape* tape);
+
+/* Statistics mailbox (csrc/mailbox.hip): the SyncBatchNorm exchanges as ONE kernel launch each instead of a process-group
+ * all_reduce.  What it replaces: the per-layer all_reduce of torch.nn.SyncBatchNorm (`trainer.sync_batchnorm: true`,
+ * examples/asr/conf/conformer/conformer_ctc_bpe.yaml:209, over the BatchNorm1d of parts/submodules/conformer_modules.py:339 and
+ * its backward) -- 36 latency-bound 8-KB collectives per Conformer-CTC-Large step that otherwise queue on the same RCCL stream
+ * as the 64-MiB gradient buckets.  Every rank owns a mailbox in its HBM and maps its peers' through hipIpc handles; an exchange
+ * stores the rank's n f64 values into every peer's mailbox (peer stores over xGMI), raises a sequence flag, waits for the `world`
+ * flags in its own mailbox and sums the boxes in rank order (every rank gets bit-identical sums).  The sequence number lives
+ * in device memory: a launch carries no per-call host state.
+ *   mi355x_mailbox_create   collective in spirit (every rank creates one, same world / n_max): allocates + zeroes the mailbox and
+ *                           writes its MI355X_MAILBOX_HANDLE_BYTES-byte IPC handle to handle_out -- the caller carries the handles
+ *                           to the peers (torch.distributed.all_gather in nemo_amd/mailbox.py).  timeout_ms <= 0: 2000.
+ *                           mem_kind: 0 = the first kind of memory that can be exported (uncached, fine-grained, plain), 1 | 2 | 3 = that one.
+ *   mi355x_mailbox_open     map peer `peer`'s mailbox from its handle (peer == rank: no-op)
+ *   mi355x_mailbox_exchange stats (f64 [n], n <= n_max, device memory) <- sum over ranks, in place, on `stream`
+ *   mi355x_mailbox_status   out3 = {exchanges completed, 0 or 1 + the rank whose flag never arrived (latched: later exchanges
+ *                           return at once, results are garbage), kind of memory (1 uncached, 2 fine-grained, 3 plain)};
+ *                           blocking copy -- diagnostics and tests
+ * Returns 0, 1 (bad argument / a peer not opened), 2 (no memory of any kind) or 1000 + hipError_t. */
+#define MI355X_MAILBOX_HANDLE_BYTES 64
+typedef struct mi355x_mailbox mi355x_mailbox;
+int mi355x_mailbox_create(int world, int rank, int n_max, int timeout_ms, int mem_kind, mi355x_mailbox** out, void* handle_out);
+int mi355x_mailbox_open(mi355x_mailbox* mb, int peer, const void* handle);
+int mi355x_mailbox_exchange(mi355x_mailbox* mb, void* stats_f64, int n, void* stream);
+int mi355x_mailbox_status(mi355x_mailbox* mb, long long* out3);
+void mi355x_mailbox_destroy(mi355x_mailbox* mb);
 
 /* Greedy CTC decoding on the device (GreedyCTCInfer._greedy_decode_logprobs, parts/submodules/ctc_greedy_decoding.py:333-361,
  * + the CTC collapse of AbstractCTCDecoding.decode_hypothesis, parts/submodules/ctc_decoding.py:545-575):

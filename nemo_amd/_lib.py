@@ -159,6 +159,11 @@ SIGNATURES = {
     "mi355x_tape_join": [vp, vp],
     "mi355x_tape_info": [vp, vp],
     "mi355x_tape_destroy": [vp],
+    "mi355x_mailbox_create": [i32, i32, i32, i32, i32, vp, vp],
+    "mi355x_mailbox_open": [vp, i32, vp],
+    "mi355x_mailbox_exchange": [vp, vp, i32, vp],
+    "mi355x_mailbox_status": [vp, vp],
+    "mi355x_mailbox_destroy": [vp],
     "mi355x_rnnt_loss_ex": [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, vp, vp, i32, i64, vp, i64, vp],
 }
 
@@ -180,6 +185,7 @@ def _load():
     lib.mi355x_relpos_dpos_partial_elems.restype = i64
     lib.mi355x_asr_version.argtypes = []
     lib.mi355x_tape_destroy.restype = None
+    lib.mi355x_mailbox_destroy.restype = None
     return lib
 
 

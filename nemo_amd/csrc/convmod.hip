@@ -619,16 +619,19 @@ static inline int bn_grid(long long M, int d, int dt) {
 }
 static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
-// MI355X_DWCONV_STREAM: 0 = the LDS-tile kernels for every shape, 1 (default) = the streaming kernel in the FORWARD pass (bf16,
-// k = 31, even d), 2 = in the backward pass as well.  Alone the streaming kernels win both ways (forward 26.5 -> 21 us, backward
-// 46.5 -> 43 us per layer); inside the training step the backward pair LOSES 1.7 ms per step (same box, alternating runs: 42.46 vs
-// 44.1 ms): its 512-thread / 207-register workgroups need a whole CU, and during backward half the CUs hold a workgroup of the
-// weight-gradient stream's grouped GEMM for ~270 us at a time -- the 256-thread / ~100-register tile kernels fit beside those.
+// MI355X_DWCONV_STREAM: 0 (default) = the LDS-tile kernels for every shape, 1 = the streaming kernel in the FORWARD pass (bf16,
+// k = 31, even d), 2 = in the backward pass as well.  ALONE (warm operands) the streaming kernels win both ways (forward 26.5 ->
+// 21 us, backward 46.5 -> 43 us per layer); INSIDE the training step both lose: the forward kernel reads its 31-tap window
+// straight from global memory and counts on the cache for the 30 re-reads, which the step does not give it (43 us per launch in
+// the step's kernel trace against 32.6 us of the tile kernel: profiles/r4_kernel_stats_per_step.md; same-box alternating runs of
+// bench.py: 41.02 / 41.21 ms with 0, 41.92 / 41.90 ms with 1, profiles/r4_dwconv_in_step.md), and the backward pair loses
+// 1.7 ms per step (42.46 vs 44.1 ms): its 512-thread / 207-register workgroups need a whole CU while half the CUs hold a
+// workgroup of the weight-gradient stream's grouped GEMM for ~270 us at a time.  The micro-benchmark was the wrong judge twice.
 static int g_dw_level = -1;  // -1: not yet read from the environment (set once per process, or by mi355x_dwconv_config from tests)
 static int dw_stream_level() {
   if (g_dw_level < 0) {
     const char* e = getenv("MI355X_DWCONV_STREAM");
-    g_dw_level = (e && e[0]) ? atoi(e) : 1;
+    g_dw_level = (e && e[0]) ? atoi(e) : 0;
   }
   return g_dw_level;
 }

@@ -1,0 +1,101 @@
+"""Statistics mailbox: the SyncBatchNorm exchanges of the data-parallel step as one kernel launch each (csrc/mailbox.hip).
+
+The reference gets these exchanges from `torch.nn.SyncBatchNorm` (`trainer.sync_batchnorm: true`,
+examples/asr/conf/conformer/conformer_ctc_bpe.yaml:209, over the BatchNorm1d of parts/submodules/conformer_modules.py:339):
+one `all_reduce` of the raw sums per layer forward and one per layer backward, 36 latency-bound 8-KB collectives per
+Conformer-CTC-Large step, on the same RCCL stream as the 64-MiB gradient buckets.  A `StatsMailbox` keeps them off the process
+group: every rank allocates a mailbox in its own HBM, the ranks exchange the hipIpc handles ONCE (one `all_gather` over the
+job's process group -- the only collective here) and map each other's mailboxes; after that an exchange is
+`mi355x_mailbox_exchange` on the compute stream (peer stores over xGMI + sequence flags + a rank-ordered sum, so every rank
+holds bit-identical results).  `StatsMailbox.create()` is all-or-nothing across the ranks: if any rank cannot export or map
+a mailbox (no IPC in this sandbox, a peer on another node), every rank gets `None` and the caller stays on the process group.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import lib
+
+HANDLE_BYTES = 64
+
+
+class StatsMailbox:
+    def __init__(self, mb, world: int, rank: int, n_max: int, kind: int, device):
+        self._mb, self.world, self.rank, self.n_max, self.kind, self.device = mb, world, rank, n_max, kind, device
+        self.exchanges = 0
+
+    # ------------------------------------------------------------------ construction (collective)
+    @classmethod
+    def create(cls, device, group=None, n_max: int = 8193, timeout_ms: int = 2000) -> Optional["StatsMailbox"]:
+        """Collective over `group`: every rank calls it at the same point.  Returns a mailbox on every rank or None on every rank."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if world < 2:
+            return None
+        device = torch.device(device)
+        on_host = dist.get_backend(group) == "gloo"  # (gloo carries host tensors; RCCL carries device tensors)
+        for mem_kind in (0, 3):  # first try: the best exportable kind of memory per rank; second: plain device memory everywhere
+            with torch.cuda.device(device):
+                mb = C.c_void_p()
+                handle = (C.c_ubyte * HANDLE_BYTES)()
+                rc = lib.mi355x_mailbox_create(world, rank, n_max, timeout_ms, mem_kind, C.byref(mb), handle)
+            mine = torch.tensor([1 if rc == 0 else 0] + list(handle), dtype=torch.int32)
+            if not on_host:
+                mine = mine.to(device)
+            every = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine, group=group)
+            every = [t.cpu() for t in every]
+            ok = rc == 0 and all(int(t[0]) == 1 for t in every)
+            if ok:
+                with torch.cuda.device(device):
+                    for r in range(world):
+                        if r == rank:
+                            continue
+                        h = (C.c_ubyte * HANDLE_BYTES)(*[int(v) for v in every[r][1:]])
+                        if lib.mi355x_mailbox_open(mb, r, h) != 0:
+                            ok = False
+                            break
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            if not on_host:
+                flag = flag.to(device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 1:
+                st = (C.c_longlong * 3)()
+                lib.mi355x_mailbox_status(mb, st)
+                return cls(mb, world, rank, n_max, int(st[2]), device)
+            if rc == 0:
+                lib.mi355x_mailbox_destroy(mb)
+        return None
+
+    # ------------------------------------------------------------------ the exchange
+    def all_reduce_(self, stats: torch.Tensor) -> torch.Tensor:
+        """stats (f64, contiguous, on this mailbox's device) <- sum over the ranks, in place, on the current stream"""
+        if stats.dtype != torch.float64 or not stats.is_cuda or not stats.is_contiguous():
+            raise ValueError("StatsMailbox.all_reduce_: a contiguous float64 device tensor")
+        if stats.numel() > self.n_max:
+            raise ValueError(f"StatsMailbox.all_reduce_: {stats.numel()} values, the mailbox was sized for {self.n_max}")
+        _lib.check(lib.mi355x_mailbox_exchange(self._mb, stats.data_ptr(), stats.numel(),
+                                               torch.cuda.current_stream(stats.device).cuda_stream), "mi355x_mailbox_exchange")
+        self.exchanges += 1
+        return stats
+
+    def status(self):
+        """(exchanges completed on the device, 0 or 1 + the rank that never arrived, memory kind) -- blocks"""
+        st = (C.c_longlong * 3)()
+        _lib.check(lib.mi355x_mailbox_status(self._mb, st), "mi355x_mailbox_status")
+        return int(st[0]), int(st[1]), int(st[2])
+
+    def close(self, group=None):
+        """collective: no rank unmaps while a peer may still store into its mailbox"""
+        if self._mb is not None:
+            torch.cuda.synchronize(self.device)
+            if dist.is_available() and dist.is_initialized():
+                dist.barrier(group=group)
+            lib.mi355x_mailbox_destroy(self._mb)
+            self._mb = None

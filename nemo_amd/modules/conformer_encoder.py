@@ -262,6 +262,8 @@ class ConformerEncoder(NeuralModule):
         # behind the [2,d] sums through the same all-reduce and is read from device memory by the BatchNorm kernels
         # (mi355x_bn_finalize_dev_count / mi355x_bn_swish_bwd_apply_dev_count) -- exact for ragged ranks, no host round trip.
         self._syncbn_group = None
+        self._syncbn_mailbox = None  # nemo_amd.mailbox.StatsMailbox when MI355X_SYNCBN_MAILBOX=1 and every rank could map its peers
+        self._syncbn_mailbox_tried = False
         self.syncbn_profile = None  # a list while bench.py measures the exposed time of the statistics exchanges
         self.use_flash_attention = True  # bf16 + d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
         # one launch for a layer's norm_out and the next layer's norm_feed_forward1 (d = 512; MI355X_LN2=0: two launches)
@@ -1285,6 +1287,16 @@ class ConformerEncoder(NeuralModule):
         if self._syncbn_group is None and dist.is_available() and dist.is_initialized():
             own = os.environ.get("MI355X_SYNCBN_OWN_GROUP", "0") == "1" and dist.get_world_size() > 1
             self._syncbn_group = dist.new_group(backend=dist.get_backend()) if own else dist.group.WORLD
+        if (not self._syncbn_mailbox_tried and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                and os.environ.get("MI355X_SYNCBN_MAILBOX", "0") == "1"):
+            # MI355X_SYNCBN_MAILBOX=1: the statistics exchanges leave the process group altogether -- one kernel launch each over
+            # peer-mapped mailboxes (nemo_amd/mailbox.py, csrc/mailbox.hip).  All-or-nothing across the ranks; a job whose ranks
+            # cannot map each other's memory keeps the process-group path above.
+            self._syncbn_mailbox_tried = True
+            dev = next(self.parameters()).device
+            if dev.type == "cuda":
+                from ..mailbox import StatsMailbox
+                self._syncbn_mailbox = StatsMailbox.create(dev, n_max=max(8193, 4 * self.d_model + 1))
         return self._syncbn_group
 
     def _sync_stats(self, stats):
@@ -1296,14 +1308,19 @@ class ConformerEncoder(NeuralModule):
             # (an encoder driven without the model class: the own-group option then creates its group here, in the first training
             # forward -- new_group() is a collective, so every rank has to reach this forward)
             group = self.setup_process_groups()
+        mb = self._syncbn_mailbox
+        if mb is not None and stats.is_cuda:
+            exchange = lambda: mb.all_reduce_(stats)
+        else:
+            exchange = lambda: dist.all_reduce(stats, group=group)
         if self.syncbn_profile is None:
-            self._eager_point(lambda: dist.all_reduce(stats, group=group))
+            self._eager_point(exchange)
             return
 
         def timed():  # diagnostics (bench.py): the exchange blocks the chain -- its stream time IS exposed time
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            dist.all_reduce(stats, group=group)
+            exchange()
             e1.record()
             if self.syncbn_profile is not None:
                 self.syncbn_profile.append((e0, e1))

@@ -735,7 +735,7 @@ def test_dwconv_bn_swish(dtype, geom):
     ragged last group and time tile; f32: the LDS-tile kernels)"""
     o = ops()
     from nemo_amd._lib import lib
-    prev = lib.mi355x_dwconv_config(2)  # streaming kernels in both directions (the default keeps the tile kernels in backward)
+    prev = lib.mi355x_dwconv_config(2)  # streaming kernels in both directions (the default runs the tile kernels both ways)
     try:
         _dwconv_bn_swish(o, dtype, geom)
     finally:
