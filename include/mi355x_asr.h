@@ -130,6 +130,10 @@ int mi355x_logmel_fwd(const void* audio, const void* audio_len, const void* wind
                       const void* fb_start, const void* fb_len, const void* fb_off, const void* fb_w, int n_mels,
                       float preemph, float dither, unsigned seed, float log_guard, void* out, int B, int S, int T,
                       void* stream);
+/* which front-end kernel runs (tests and A/B): 1 (default) = the wave-synchronised kernel (frame-private work needs no workgroup
+ * barrier, in-place radix-4 stages, two frames in flight per wave, filterbank in LDS; profiles/r4_logmel.md), 0 = the round-1 kernel.
+ * variant < 0 only queries.  Returns the previous setting.  Environment: MI355X_LOGMEL.  (features.py:423-502) */
+int mi355x_logmel_config(int variant);
 /* normalize_batch(..., 'per_feature') + pad fill, features.py:59-93,490-493.  x f32 [B,n_mels,T] -> y (y_dtype) */
 int mi355x_feat_normalize(const void* x, const void* seq_len, void* y, int y_dtype, int B, int n_mels, int T,
                           int normalize, float pad_value, void* stream);

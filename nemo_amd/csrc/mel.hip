@@ -10,6 +10,7 @@
 //   (nemo/collections/asr/parts/preprocessing/features.py:423-502, 59-93): torch.stft (hipFFT) + ~12 elementwise
 //   launches, complex [B,257,T] intermediate written/read three times.
 // Algorithmic HBM bytes: 4*S read + 4*n_mels*T written per utterance (= 96 KB per audio-second at 80 mels).
+#include <stdlib.h>
 #include "common.h"
 #include "mi355x_asr.h"
 
@@ -148,6 +149,192 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ a
   }
 }
 
+// The same front-end with the work of a frame kept inside its wave (round 4).  The kernel above synchronises the whole workgroup
+// seven times per frame although everything between the staging and the final store is wave-private (each wave owns its FFT
+// buffer, its power spectrum and its columns of the output tile), keeps two FFT buffers per wave and walks a wave's eight frames
+// one after the other -- a chain of LDS round trips with nothing to overlap them (216 us per call = 0.31 TB/s, r3 PMC).  Here:
+//   * LDS operations of ONE wave execute in program order, so a write -> read hand-over between lanes of the same wave needs no
+//     s_barrier, only that the compiler keeps the order and the data has landed: `s_waitcnt lgkmcnt(0)` with a memory clobber;
+//   * the radix-4 stages run IN PLACE (all four inputs of every lane are in registers before the wave's first store issues);
+//   * a wave carries FPW = 2 frames through the stages together: two independent dependency chains per lane.
+//   * the sparse filterbank is staged in LDS once per workgroup (read from global memory inside the tap loop it cost up to 18
+//     dependent L2 round trips per (frame, filter) pair) and the staging loop issues the loads of eight samples per thread together.
+// Arithmetic and its order per frame are those of the kernel above (equal up to fused-multiply-add contraction: <= 1e-4 on the
+// log-mel values, tests/test_kernels_gpu.py).  201 -> 110 us per call at B = 32 x 20 s (133 us with dither): profiles/r4_logmel.md.
+#define FB_CAP 1024      // filterbank weights kept in LDS (floats)
+#define WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+template <int FPW>
+__global__ __launch_bounds__(256) void logmel_wave_kernel(const float* __restrict__ audio, const long long* __restrict__ audio_len,
+                                                          const float* __restrict__ window, int win, int hop,
+                                                          const int* __restrict__ fb_start, const int* __restrict__ fb_len,
+                                                          const int* __restrict__ fb_off, const float* __restrict__ fb_w, int n_mels,
+                                                          float preemph, float dither, uint32_t seed, float log_guard,
+                                                          float* __restrict__ out, int B, int S, int T) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int seg = (MEL_FR - 1) * hop + NFFT;
+  float* s_audio = smem;                                  // [seg]
+  float* s_win = s_audio + ((seg + 3) & ~3);              // [512] window zero-padded & centred
+  cpx* s_tw = (cpx*)(s_win + NFFT);                       // [256]
+  cpx* s_fft = s_tw + NH;                                 // [4 waves][FPW][256]
+  float* s_pw = (float*)(s_fft + 4 * FPW * NH);           // [4][FPW][260]
+  float* s_out = s_pw + 4 * FPW * 260;                    // [n_mels][MEL_FR + 1]
+  float* s_fbw = s_out + n_mels * (MEL_FR + 1);           // [FB_CAP + 4] filter weights (+ 4 zeros: the tap loop reads in fours)
+  int* s_fbi = (int*)(s_fbw + FB_CAP + 4);                // [3][n_mels] first bin, taps, offset into the weights
+
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * MEL_FR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long len = audio_len[b];
+  const float* xa = audio + (long long)b * S;
+
+  // the sparse filterbank (500 weights for 80 Slaney triangles over 257 bins) goes to LDS once per workgroup: read from global
+  // memory inside the tap loop -- up to 18 dependent L2 round trips per (frame, filter) -- it was three quarters of the kernel
+  const int nnz = fb_off[n_mels - 1] + fb_len[n_mels - 1];
+  const bool fb_in_lds = nnz <= FB_CAP;  // (a dense user filterbank stays in global memory)
+  if (fb_in_lds) {
+    for (int i = tid; i < nnz + 4; i += 256) s_fbw[i] = i < nnz ? fb_w[i] : 0.f;
+    for (int i = tid; i < n_mels; i += 256) { s_fbi[i] = fb_start[i]; s_fbi[n_mels + i] = fb_len[i]; s_fbi[2 * n_mels + i] = fb_off[i]; }
+  }
+
+  // staging, eight samples per thread and trip: the 16 loads of a trip are issued together (the one-sample loop of the round-1
+  // kernel paid one HBM round trip per sample and thread: 21 in a row, ~20 us of the ~35 us a workgroup lived)
+  const int t_base = f0 * hop - NFFT / 2;
+  constexpr int SU = 8;
+  for (int i0 = tid; i0 < seg; i0 += 256 * SU) {
+    float cur[SU], prev[SU];
+    bool ok[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = i0 + 256 * u, t = t_base + i;
+      ok[u] = i < seg && t >= 0 && t < S && t < len;
+      cur[u] = ok[u] ? xa[t] : 0.f;
+      prev[u] = (ok[u] && t > 0) ? xa[t - 1] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = i0 + 256 * u, t = t_base + i;
+      if (i < seg) {
+        float v = 0.f;
+        if (ok[u]) {
+          float c = cur[u], q = prev[u];
+          if (dither > 0.f) {
+            c += dither * hash_normal(seed, (uint32_t)((long long)b * S + t));
+            if (t > 0) q += dither * hash_normal(seed, (uint32_t)((long long)b * S + t - 1));
+          }
+          v = (t > 0) ? c - preemph * q : c;
+        }
+        s_audio[i] = v;
+      }
+    }
+  }
+  const int woff = (NFFT - win) / 2;
+  for (int i = tid; i < NFFT; i += 256) s_win[i] = (i >= woff && i < woff + win) ? window[i - woff] : 0.f;
+  {
+    float sn, cs;
+    sincospif(-(float)tid / 256.f, &sn, &cs);  // exp(-2*pi*i*tid/512)
+    s_tw[tid] = {cs, sn};
+  }
+  __syncthreads();
+
+  cpx* buf0 = s_fft + wave * FPW * NH;
+  float* pw0 = s_pw + wave * FPW * 260;
+  if (lane < 3 * FPW) pw0[(lane / 3) * 260 + 257 + lane % 3] = 0.f;  // the slack slots the four-tap loop may multiply by zero
+
+  for (int fi = 0; fi < MEL_FR / 4 / FPW; ++fi) {
+    const int fl0 = wave * (MEL_FR / 4) + fi * FPW;  // first local frame of this pass
+#pragma unroll
+    for (int f = 0; f < FPW; ++f) {
+      const int fbase = (fl0 + f) * hop;
+      cpx* buf = buf0 + f * NH;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = lane + 64 * r;
+        cpx z = {s_audio[fbase + 2 * m] * s_win[2 * m], s_audio[fbase + 2 * m + 1] * s_win[2 * m + 1]};
+        buf[m] = z;
+      }
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int p = 1; p < NH; p *= 4) {
+      const int j = lane;
+      const int k = j & (p - 1);
+      const int tstep = k * (NFFT / (4 * p));
+      const cpx w1 = tw512(s_tw, tstep), w2 = tw512(s_tw, 2 * tstep), w3 = tw512(s_tw, 3 * tstep);
+      cpx v0[FPW], v1[FPW], v2[FPW], v3[FPW];
+#pragma unroll
+      for (int f = 0; f < FPW; ++f) {
+        const cpx* src = buf0 + f * NH;
+        v0[f] = src[j]; v1[f] = src[j + 64]; v2[f] = src[j + 128]; v3[f] = src[j + 192];
+      }
+      WAVE_SYNC();  // every lane's inputs are in registers before the first in-place store
+      const int j0 = ((j - k) << 2) + k;
+#pragma unroll
+      for (int f = 0; f < FPW; ++f) {
+        cpx* dst = buf0 + f * NH;
+        const cpx u1 = cmul(v1[f], w1), u2 = cmul(v2[f], w2), u3 = cmul(v3[f], w3);
+        cpx a0 = cadd(v0[f], u2), a1 = csub(v0[f], u2), a2 = cadd(u1, u3), d = csub(u1, u3);
+        cpx a3 = {d.y, -d.x};  // (v1 - v3) * (-i)
+        dst[j0] = cadd(a0, a2);
+        dst[j0 + p] = cadd(a1, a3);
+        dst[j0 + 2 * p] = csub(a0, a2);
+        dst[j0 + 3 * p] = csub(a1, a3);
+      }
+      WAVE_SYNC();
+    }
+#pragma unroll
+    for (int f = 0; f < FPW; ++f) {
+      const cpx* src = buf0 + f * NH;
+      float* pw = pw0 + f * 260;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const int k = lane + 64 * r;
+        if (k <= NH) {
+          cpx zk = src[k & (NH - 1)];
+          cpx zc = src[(NH - k) & (NH - 1)];
+          zc.y = -zc.y;
+          cpx ze = {0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y)};
+          cpx df = {0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y)};
+          cpx zo = {df.y, -df.x};  // df / i
+          cpx w = (k == NH) ? cpx{-1.f, 0.f} : s_tw[k];
+          cpx xk = cadd(ze, cmul(w, zo));
+          pw[k] = xk.x * xk.x + xk.y * xk.y;
+        }
+      }
+    }
+    WAVE_SYNC();
+    // ---- sparse mel filterbank + log: FPW * n_mels (frame, filter) pairs over the 64 lanes
+    for (int e = lane; e < FPW * n_mels; e += 64) {
+      const int f = e / n_mels, m = e - f * n_mels;
+      const float* pw = pw0 + f * 260;
+      float acc = 0.f;
+      if (fb_in_lds) {
+        const int st0 = s_fbi[m], n = s_fbi[n_mels + m];
+        const float* wv = s_fbw + s_fbi[2 * n_mels + m];
+        // four taps per trip, all eight LDS reads issued before the four multiply-adds; the sum keeps the tap order, a tap past
+        // the filter's end multiplies a finite power by a zero weight (pw has 260 slots for 257 bins, the weights 4 zeros of slack)
+        for (int i = 0; i < n; i += 4) {
+          const float w0 = wv[i], w1 = i + 1 < n ? wv[i + 1] : 0.f, w2 = i + 2 < n ? wv[i + 2] : 0.f, w3 = i + 3 < n ? wv[i + 3] : 0.f;
+          const float p0 = pw[st0 + i], p1 = pw[st0 + i + 1], p2 = pw[st0 + i + 2], p3 = pw[st0 + i + 3];
+          acc = fmaf(w0, p0, acc); acc = fmaf(w1, p1, acc); acc = fmaf(w2, p2, acc); acc = fmaf(w3, p3, acc);
+        }
+      } else {
+        const int st0 = fb_start[m], n = fb_len[m];
+        const float* wv = fb_w + fb_off[m];
+        for (int i = 0; i < n; ++i) acc = fmaf(wv[i], pw[st0 + i], acc);
+      }
+      s_out[m * (MEL_FR + 1) + fl0 + f] = logf(acc + log_guard);
+    }
+    WAVE_SYNC();  // (the next pass overwrites buf / pw: keep this pass's reads in front of them)
+  }
+  __syncthreads();
+  for (int i = tid; i < n_mels * MEL_FR; i += 256) {
+    const int m = i / MEL_FR, fl = i - m * MEL_FR;
+    const int f = f0 + fl;
+    if (f < T) out[((long long)b * n_mels + m) * T + f] = s_out[m * (MEL_FR + 1) + fl];
+  }
+}
+
+
 // per-feature normalisation over frames t < seq_len (features.py:59-93), pad_value fill beyond; one wave per (b, m) row
 template <typename TO>
 __global__ __launch_bounds__(256) void feat_norm_kernel(const float* __restrict__ x, const long long* __restrict__ seq_len,
@@ -173,6 +360,19 @@ __global__ __launch_bounds__(256) void feat_norm_kernel(const float* __restrict_
   for (int t = lane; t < T; t += 64) st(y + (long long)row * T + t, t < n ? (xr[t] - mu) * inv : pad_value);
 }
 
+static int g_logmel_variant = -1;  // -1: not yet read from the environment
+static int logmel_variant() {
+  if (g_logmel_variant < 0) {
+    const char* e = getenv("MI355X_LOGMEL");
+    g_logmel_variant = (e && e[0]) ? (atoi(e) ? 1 : 0) : 1;
+  }
+  return g_logmel_variant;
+}
+extern "C" int mi355x_logmel_config(int variant) {
+  const int old = logmel_variant();
+  if (variant >= 0) g_logmel_variant = variant ? 1 : 0;
+  return old;
+}
 extern "C" int mi355x_logmel_fwd(const void* audio, const void* audio_len, const void* window, int win, int hop, int n_fft,
                                  const void* fb_start, const void* fb_len, const void* fb_off, const void* fb_w, int n_mels,
                                  float preemph, float dither, unsigned seed, float log_guard, void* out, int B, int S, int T,
@@ -182,16 +382,23 @@ extern "C" int mi355x_logmel_fwd(const void* audio, const void* audio_len, const
   if (n_fft != NFFT || win <= 0 || win > NFFT || hop <= 0 || hop > NFFT || n_mels <= 0 || B <= 0 || S <= 0) return MI_ERR_ARG;
   if (T != 1 + S / hop) return MI_ERR_ARG;
   const int seg = (MEL_FR - 1) * hop + NFFT;
-  const size_t shm = sizeof(float) * (((seg + 3) & ~3) + NFFT + 2 * NH + 4 * 2 * NH * 2 + 4 * 260 + (size_t)n_mels * (MEL_FR + 1));
+  // MI355X_LOGMEL: 1 (default) = the wave-synchronised kernel, two frames in flight per wave; 0 = the round-1 kernel (A/B, tests)
+  const int variant = logmel_variant();
+  constexpr int FPW = 2;
+  const size_t common = ((seg + 3) & ~3) + NFFT + 2 * NH + (size_t)n_mels * (MEL_FR + 1);
+  const size_t shm = sizeof(float) * (common + (variant ? 4 * FPW * NH * 2 + 4 * FPW * 260 + FB_CAP + 4 + 3 * (size_t)n_mels : 4 * 2 * NH * 2 + 4 * 260));
   if (shm > 160 * 1024) return MI_ERR_ARG;
   dim3 grid((T + MEL_FR - 1) / MEL_FR, B), block(256);
-  if (hipFuncSetAttribute((const void*)logmel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {
+  const void* fn = variant ? (const void*)logmel_wave_kernel<FPW> : (const void*)logmel_kernel;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {
     (void)hipGetLastError();
     return MI_ERR_LAUNCH;
   }
-  MI_LAUNCH(logmel_kernel, grid, block, shm, (hipStream_t)stream, (const float*)audio, (const long long*)audio_len,
-                     (const float*)window, win, hop, (const int*)fb_start, (const int*)fb_len, (const int*)fb_off,
-                     (const float*)fb_w, n_mels, preemph, dither, seed, log_guard, (float*)out, B, S, T);
+#define LOGMEL_ARGS (const float*)audio, (const long long*)audio_len, (const float*)window, win, hop, (const int*)fb_start, \
+    (const int*)fb_len, (const int*)fb_off, (const float*)fb_w, n_mels, preemph, dither, seed, log_guard, (float*)out, B, S, T
+  if (variant) MI_LAUNCH(logmel_wave_kernel<FPW>, grid, block, shm, (hipStream_t)stream, LOGMEL_ARGS);
+  else MI_LAUNCH(logmel_kernel, grid, block, shm, (hipStream_t)stream, LOGMEL_ARGS);
+#undef LOGMEL_ARGS
   return mi_check_launch();
 }
 

@@ -950,6 +950,38 @@ def test_logmel_ragged_and_padding_invariance():
     assert (feat2[..., : int(ref_len[1])][1] - feat[..., : int(ref_len[1])][1]).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("S,dither", [(16000 + 37, 0.0), (48000, 1e-5), (331, 1e-5), (160 * 64, 0.0)])
+def test_logmel_wave_synchronised_kernel_against_the_round_1_kernel(S, dither):
+    """csrc/mel.hip: the default front-end kernel (wave-local hand-overs instead of workgroup barriers, in-place radix-4 stages, two
+    frames in flight per wave, filterbank in LDS) against the round-1 kernel on the same input -- ragged lengths, a clip shorter
+    than one window, dither on (counter-based: the same noise both ways).  Same arithmetic up to fused-multiply-add contraction,
+    so the log-mel values agree to a few ulp; and the wave-local hand-overs must be RACE-FREE: five runs, identical bits."""
+    o = ops()
+    from nemo_amd._lib import lib
+    g = torch.Generator().manual_seed(S)
+    audio = (0.1 * torch.randn(3, S, generator=g)).to(dev)
+    alen = torch.tensor([S, max(1, S // 3), max(1, S - 161)]).to(dev)
+    fb = _fb_sparse(torch.from_numpy(R.mel_filterbank())); win = R.hann_window_sym(400).to(dev)
+    outs = []
+    prev = lib.mi355x_logmel_config(-1)
+    try:
+        for variant in (0, 1, 1, 1, 1, 1):
+            lib.mi355x_logmel_config(variant)
+            raw = torch.full((3, 80, 1 + S // 160), float("nan"), device=dev)
+            o.logmel(audio, alen, win, fb, 80, dither=dither, seed=123, out=raw)
+            torch.cuda.synchronize()
+            outs.append(raw.cpu())
+    finally:
+        lib.mi355x_logmel_config(prev)
+    assert prev == 1
+    assert torch.isfinite(outs[1]).all()
+    for k in range(2, 6):
+        assert torch.equal(outs[1], outs[k]), k
+    # log(power + 2^-24): values in [-16.6, ~10]; a differently contracted FFT moves a power by ~1e-6 relative
+    err = (outs[0] - outs[1]).abs().max().item()
+    assert err < 1e-4, err
+
+
 # ---------------------------------------------------------------------------------------------- CTC
 @pytest.mark.parametrize("name", ["test_case_small", "test_case_small_blank_last", "test_case_big_tensor"])
 def test_ctc_known_answers(golden_dir, name):
