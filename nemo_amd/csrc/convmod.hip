@@ -509,14 +509,14 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_reduce_kernel(const TT* __re
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   double* __restrict__ sums, float* __restrict__ partial,
-                                                                  long long M, int d) {
+                                                                  long long M, int d, int rows_per_blk) {
   // thread = V consecutive channels (one 16-byte load per tensor per row) x every RS-th row of the workgroup's row block
   constexpr int V = VecIO<TT>::V;
   __shared__ float sred[2][256 * V];
   const int CP = min(d / V, 256);          // channel chunks per pass
   const int RS = 256 / CP;                 // rows in flight per pass
   const int ck = threadIdx.x % CP, rsub = threadIdx.x / CP;
-  const long long r0 = (long long)blockIdx.y * BNR_ROWS, r1 = min(M, r0 + BNR_ROWS);
+  const long long r0 = (long long)blockIdx.y * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
   for (int c0 = blockIdx.x * CP * V; c0 < d; c0 += gridDim.x * CP * V) {
     const int c = c0 + ck * V;
     float a1[V], a2[V];
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_reduce_kernel(const TT* __re
     }
   }
 }
-template <typename TT>
+template <typename TT, int UNR>
 __global__ __launch_bounds__(256) void bn_swish_bwd_apply_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_apply_kernel(const TT* __res
       mu[j] = coef[c + j]; rs[j] = coef[d + c + j]; g[j] = coef[2 * d + c + j]; bt[j] = coef[3 * d + c + j];
       k1[j] = coef[4 * d + c + j]; k2[j] = coef[5 * d + c + j];
     }
-#pragma unroll 2
+#pragma unroll UNR
     for (long long m = (long long)blockIdx.x * RS + rsub; m < M; m += (long long)gridDim.x * RS) {
       float v[V], e[V], o[V];
       VecIO<TT>::load(x + m * d + c, v);
@@ -616,6 +616,10 @@ static inline int bn_grid(long long M, int d, int dt) {
   const int CP = d / V < 256 ? d / V : 256, RS = 256 / CP;
   long long g = (M + (long long)RS * 2 - 1) / ((long long)RS * 2);
   return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+static int env_int_cm(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
 }
 static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
@@ -789,13 +793,18 @@ extern "C" int mi355x_bn_swish_bwd_reduce(const void* dy, const void* x, const v
   if (!dy || !x || !sums || M <= 0 || d <= 0 || (!dgamma != !dbeta)) return MI_ERR_ARG;
   const int V = dt == MI_DT_BF16 ? 8 : 4;
   if (d % V) return MI_ERR_ARG;
-  const unsigned nblk = (unsigned)((M + BNR_ROWS - 1) / BNR_ROWS);
+  // rows per workgroup: 32 (501 workgroups at the Large shape) when the scratch slab is the documented ceil(M/32)*2*d; a larger slab
+  // lets MI355X_BNR_ROWS = 16 double the workgroups (tools/bn_bench.py)
+  static const int env_rows = env_int_cm("MI355X_BNR_ROWS", BNR_ROWS);
+  int rows = env_rows >= 8 && env_rows <= 256 ? env_rows : BNR_ROWS;
+  if (scratch && scratch_elems < (long long)((M + rows - 1) / rows) * 2 * d) rows = BNR_ROWS;
+  const unsigned nblk = (unsigned)((M + rows - 1) / rows);
   if (scratch && scratch_elems < (long long)nblk * 2 * d) return MI_ERR_ARG;
   dim3 grid(1, nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(dt, TT, MI_LAUNCH((bn_swish_bwd_reduce_kernel<TT>), grid, block, 0, s, (const TT*)dy, (const TT*)x,
                                          (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta,
-                                         (double*)sums, (float*)scratch, M, d));
+                                         (double*)sums, (float*)scratch, M, d, rows));
   if (scratch)
     MI_LAUNCH(bn_partials_reduce_kernel, dim3((2 * d + 255) / 256, 32), dim3(256), 0, s, (const float*)scratch, (int)nblk, d,
               (double*)sums, (float*)dgamma, (float*)dbeta);
@@ -825,11 +834,18 @@ static int bn_swish_bwd_apply_launch(const void* dy, const void* x, const void* 
     return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if ((size_t)d * 6 * sizeof(float) > 64 * 1024) return MI_ERR_ARG;
-  DISPATCH_DT(dt, TT, MI_LAUNCH((bn_swish_bwd_apply_kernel<TT>), dim3(bn_grid(M, d, dt)), dim3(256),
-                                         (size_t)d * 6 * sizeof(float), s,
-                                         (const TT*)dy, (const TT*)x, (const float*)mean, (const float*)rstd, (const float*)gamma,
-                                         (const float*)beta, (const double*)sums, count_dev ? 0.0 : 1.0 / count,
-                                         (const double*)count_dev, training, (TT*)dx, M, d));
+  // rows per thread (MI355X_BNA_ROWS, default 2) and the unroll of the row loop (MI355X_BNA_UNR: 2 | 4): every workgroup derives the
+  // coefficients of all d channels before its first row, so fewer, longer workgroups amortise that set-up (tools/bn_bench.py)
+  static const int rpt = env_int_cm("MI355X_BNA_ROWS", 2), unr = env_int_cm("MI355X_BNA_UNR", 2);
+  const int V = dt == MI_DT_BF16 ? 8 : 4;
+  const int CP = d / V < 256 ? d / V : 256, RS = 256 / CP;
+  long long g = (M + (long long)RS * rpt - 1) / ((long long)RS * (rpt > 0 ? rpt : 2));
+  g = g > 16384 ? 16384 : (g < 1 ? 1 : g);
+#define BNA_LAUNCH(UNR_) DISPATCH_DT(dt, TT, MI_LAUNCH((bn_swish_bwd_apply_kernel<TT, UNR_>), dim3((unsigned)g), dim3(256), \
+    (size_t)d * 6 * sizeof(float), s, (const TT*)dy, (const TT*)x, (const float*)mean, (const float*)rstd, (const float*)gamma, \
+    (const float*)beta, (const double*)sums, count_dev ? 0.0 : 1.0 / count, (const double*)count_dev, training, (TT*)dx, M, d))
+  if (unr == 4) { BNA_LAUNCH(4); } else { BNA_LAUNCH(2); }
+#undef BNA_LAUNCH
   return mi_check_launch();
 }
 extern "C" int mi355x_bn_param_grad(const void* sums, void* dgamma, void* dbeta, int d, void* stream) {

@@ -535,7 +535,7 @@ def bn_swish_fwd(x, mean, rstd, gamma, beta, y, M, d):
 
 def bn_swish_bwd_reduce(dy, x, mean, rstd, gamma, beta, sums, M, d, dgamma=None, dbeta=None):
     """sums f64 [2, d] += (sum dz, sum dz * xhat); dgamma / dbeta (optional): the parameter gradients in the same launches"""
-    n = ((M + 31) // 32) * 2 * d
+    n = ((M + 15) // 16) * 2 * d  # (room for 16-row workgroups: MI355X_BNR_ROWS; the kernel's default needs ceil(M/32)*2*d)
     sc = _scratch("bn_swish_bwd_reduce", n, dy.device)
     check(lib.mi355x_bn_swish_bwd_reduce(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums),
                                          _ptr(dgamma), _ptr(dbeta), dt(x), M, d, _ptr(sc), n, _stream()), "bn_swish_bwd_reduce")
