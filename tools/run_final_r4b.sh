@@ -3,9 +3,9 @@
 # cpu_baseline), the 2-rank rehearsal over the statistics mailbox and over the process group, BatchNorm-backward variants.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 O=gpurun_out/r4finalb; mkdir -p $O
-timeout 800 python -m pytest tests -x -q -m gpu > $O/gpu_suite.log 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gpu_suite.log
+timeout 800 python -m pytest tests -x -q -m gpu --durations=12 > $O/gpu_suite.log 2>&1; echo "gpu tests rc=$?"; tail -18 $O/gpu_suite.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
-timeout 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
+timeout 300 python bench.py --no-cpu-baseline > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
 python - <<P
 import json
 d=json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1])
@@ -20,10 +20,5 @@ try:
     print(d['ms_per_step'], x.get('syncbn_exchange'), x.get('syncbn_allreduces_per_step'), x.get('syncbn_exposed_ms_this_rank'))
 except Exception as e: print('ERR', e)
 P
-done
-: > $O/bn.txt
-for cfg in "A=1" "MI355X_BNR_ROWS=16" "MI355X_BNA_ROWS=8 MI355X_BNA_UNR=4" "MI355X_BNA_ROWS=4 MI355X_BNA_UNR=4"; do
-  echo "## $cfg" | tee -a $O/bn.txt
-  env $cfg timeout 60 python tools/bn_bench.py 2>/dev/null | grep bwd | tee -a $O/bn.txt
 done
 bash tools/run_r4_sweep.sh "MI355X_BNR_ROWS=16" "MI355X_BNA_ROWS=8 MI355X_BNA_UNR=4" "MI355X_BNR_ROWS=16 MI355X_BNA_ROWS=8 MI355X_BNA_UNR=4" 2>&1 | tail -6
