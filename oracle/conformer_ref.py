@@ -55,6 +55,13 @@ class ConformerCfg:
     # through the same points.  Accumulation stays fp32 (as in the MFMA).  Lets a test separate "bf16 storage rounding" from
     # "kernel error": tests/test_baseline_configs_gpu.py
     emulate_bf16: bool = False
+    # ---- encoder options of the sibling recipes (conf/fastconformer/cache_aware_streaming/*, long-form and InterCTC recipes);
+    # restated here FIRST (oracle before kernel, pinned to the reference by tests/test_oracle_pinning.py and
+    # tests/golden/ref_encoder_options.npz); the MI355X encoder still raises NotImplementedError for the non-default values.
+    att_context_size: Tuple[int, int] = (-1, -1)   # [left, right] frames visible to a query; -1 = unlimited (conformer_encoder.py:794-823)
+    att_context_style: str = "regular"             # "regular" | "chunked_limited"
+    conv_norm_type: str = "batch_norm"             # "batch_norm" | "layer_norm" (conformer_modules.py:293-306, 335-340)
+    conv_context_size: Optional[Tuple[int, int]] = None  # [left, right] padding of the depthwise conv; None = symmetric; (k-1, 0) = causal
 
     @property
     def channels(self):
@@ -270,6 +277,33 @@ def subsampling_forward(P: Dict[str, Tensor], cfg: ConformerCfg, mel: Tensor, me
     return x, l2
 
 
+def context_mask(cfg, T: int) -> Tensor:
+    """[T, T] bool, True = query i may see key j (ConformerEncoder._create_masks, conformer_encoder.py:794-823):
+    'regular': -left <= j - i <= right (each side only if >= 0); 'chunked_limited': keys of the query's own chunk (chunk size =
+    right + 1) and of the left // chunk_size chunks before it; with right == -1 it degenerates to the left-limited regular mask."""
+    left, right = cfg.att_context_size
+    i = torch.arange(T).unsqueeze(1)
+    j = torch.arange(T).unsqueeze(0)
+    ok = torch.ones(T, T, dtype=torch.bool)
+    if cfg.att_context_style == "regular":
+        if left >= 0:
+            ok &= (j - i) >= -left
+        if right >= 0:
+            ok &= (j - i) <= right
+    elif cfg.att_context_style == "chunked_limited":
+        if right == -1:
+            if left >= 0:
+                ok &= (j - i) >= -left
+        else:
+            chunk = right + 1
+            left_chunks = left // chunk if left >= 0 else 10000
+            dc = torch.div(i, chunk, rounding_mode="trunc") - torch.div(j, chunk, rounding_mode="trunc")
+            ok &= (dc <= left_chunks) & (dc >= 0)
+    else:
+        raise ValueError(f"att_context_style={cfg.att_context_style}")
+    return ok
+
+
 def rel_pos_attention(P, pfx, cfg: ConformerCfg, x: Tensor, pos_emb: Tensor, valid: Tensor, train: bool):
     """x [B,T,d] (already layer-normed); valid [B,T] bool.  score[b,h,i,j] = ((q_i+u)k_j + (q_i+v)p_{T-1+j-i})/sqrt(dk)."""
     B, T, d = x.shape
@@ -287,7 +321,7 @@ def rel_pos_attention(P, pfx, cfg: ConformerCfg, x: Tensor, pos_emb: Tensor, val
     jj = torch.arange(T).unsqueeze(0)
     bd = bd_full[:, :, ii, T - 1 + jj - ii]
     scores = (ac + bd) / math.sqrt(dk)
-    masked = ~(valid.unsqueeze(1) & valid.unsqueeze(2))  # [B,T,T] True = masked
+    masked = ~(valid.unsqueeze(1) & valid.unsqueeze(2) & context_mask(cfg, T).unsqueeze(0))  # [B,T,T] True = masked
     masked = masked.unsqueeze(1)
     scores = scores.masked_fill(masked, -INF_VAL)
     attn = torch.softmax(scores, dim=-1).masked_fill(masked, 0.0)
@@ -304,9 +338,16 @@ def conv_module(P, pfx, cfg: ConformerCfg, x: Tensor, valid: Tensor, bn_training
     g = h[..., :d] * torch.sigmoid(h[..., d:])
     g = _q(g * valid.unsqueeze(-1).to(g.dtype), cfg)
     pad = (cfg.conv_kernel - 1) // 2
-    c = F.conv1d(F.pad(g.transpose(1, 2), (pad, pad)), P[pfx + "depthwise_conv.weight"],
+    lpad, rpad = (pad, pad) if cfg.conv_context_size is None else cfg.conv_context_size  # CausalConv1D, causal_convs.py:89-150
+    c = F.conv1d(F.pad(g.transpose(1, 2), (lpad, rpad)), P[pfx + "depthwise_conv.weight"],
                  P[pfx + "depthwise_conv.bias"], groups=d)  # [B,d,T]
     cq = _q(c, cfg)  # batch statistics come from the fp32 accumulators, the stored tensor is bf16
+    if cfg.conv_norm_type == "layer_norm":  # nn.LayerNorm over the channels of every frame (conformer_modules.py:335-338)
+        c = F.layer_norm(cq.transpose(1, 2), (d,), P[pfx + "batch_norm.weight"], P[pfx + "batch_norm.bias"], 1e-5)
+        c = _q(c * torch.sigmoid(c), cfg)
+        return F.linear(c, _qw(P[pfx + "pointwise_conv2.weight"], cfg).squeeze(-1), P[pfx + "pointwise_conv2.bias"])
+    if cfg.conv_norm_type != "batch_norm":
+        raise ValueError(f"conv_norm_type={cfg.conv_norm_type}")
     if bn_training:
         mean = c.mean(dim=(0, 2))
         var = c.var(dim=(0, 2), unbiased=False)
@@ -340,8 +381,10 @@ def conformer_layer(P, pfx, cfg: ConformerCfg, x, pos_emb, valid, train, bn_trai
 
 
 def encoder_forward(P, cfg: ConformerCfg, mel, mel_len, train=False, bn_training=None, pfx="", bn_stats_out=None,
-                    n_layers: Optional[int] = None):
-    """-> (encoded [B, d, T'], enc_len [B]).  `P` keys = reference encoder state_dict keys (+ optional prefix)."""
+                    n_layers: Optional[int] = None, capture: Optional[dict] = None):
+    """-> (encoded [B, d, T'], enc_len [B]).  `P` keys = reference encoder state_dict keys (+ optional prefix).
+    `capture` = {layer index: None}: filled with that layer's output [B, d, T'] (0-based, after norm_out) -- what the reference
+    registers as `interctc/layer_output_<l>` (conformer_encoder.py:724-736)."""
     bn_training = train if bn_training is None else bn_training
     x, enc_len = subsampling_forward(P, cfg, mel, mel_len, pfx + "pre_encode.")
     B, T, d = x.shape
@@ -352,6 +395,8 @@ def encoder_forward(P, cfg: ConformerCfg, mel, mel_len, train=False, bn_training
     valid = torch.arange(T).unsqueeze(0) < enc_len.unsqueeze(1)
     for i in range(cfg.n_layers if n_layers is None else n_layers):
         x = conformer_layer(P, f"{pfx}layers.{i}.", cfg, x, pos_emb, valid, train, bn_training, bn_stats_out)
+        if capture is not None and i in capture:
+            capture[i] = x.transpose(1, 2)
     return x.transpose(1, 2), enc_len
 
 
@@ -369,19 +414,35 @@ def ctc_loss_mean_batch(logp, targets, in_len, tgt_len, blank):
 
 
 def model_forward(P, cfg: ConformerCfg, audio, audio_len, tokens, token_len, train=False, bn_training=None,
-                  noise=None, dither=0.0, bn_stats_out=None):
+                  noise=None, dither=0.0, bn_stats_out=None, interctc: Optional[Tuple[list, list]] = None):
     """Full reference forward (ctc_models.py:495-546 + training_step loss :549-585), SpecAugment off.
-    `P`: 'preprocessor.featurizer.fb/window' optional, 'encoder.*', 'decoder.decoder_layers.0.*'."""
+    `P`: 'preprocessor.featurizer.fb/window' optional, 'encoder.*', 'decoder.decoder_layers.0.*'.
+    `interctc` = (apply_at_layers, loss_weights): intermediate CTC losses through the SAME decoder on the captured layer outputs,
+    loss = (1 - sum w) * final + sum_l w_l * inter_l (parts/mixins/interctc_mixin.py:46-58, 214-270; ctc_models.py:577-585)."""
     fb = P.get("preprocessor.featurizer.fb")
     window = P.get("preprocessor.featurizer.window")
     with torch.no_grad():
         mel, mel_len = log_mel_features(audio, audio_len, fb=fb, window=window, n_mels=cfg.feat_in,
                                         noise=noise, dither=dither)
+    capture = {int(l): None for l in interctc[0]} if interctc else None
     enc, enc_len = encoder_forward(P, cfg, mel, mel_len, train=train, bn_training=bn_training, pfx="encoder.",
-                                   bn_stats_out=bn_stats_out)
+                                   bn_stats_out=bn_stats_out, capture=capture)
     logp = decoder_forward(P, enc, "decoder.decoder_layers.0.", cfg)
     loss, per_utt = ctc_loss_mean_batch(logp, tokens, enc_len, token_len, cfg.vocab)
-    return dict(loss=loss, per_utt=per_utt, logp=logp, enc=enc, enc_len=enc_len, mel=mel, mel_len=mel_len)
+    out = dict(per_utt=per_utt, logp=logp, enc=enc, enc_len=enc_len, mel=mel, mel_len=mel_len)
+    if interctc:
+        layers, weights = interctc
+        if len(layers) != len(weights):
+            raise ValueError("Length of interctc.apply_at_layers has to match interctc.loss_weights")
+        out["final_loss"] = loss
+        loss = loss * (1.0 - sum(weights))
+        for l, w in zip(layers, weights):
+            lp = decoder_forward(P, capture[int(l)], "decoder.decoder_layers.0.", cfg)
+            inter, _ = ctc_loss_mean_batch(lp, tokens, enc_len, token_len, cfg.vocab)
+            out[f"inter_ctc_loss_l{int(l)}"] = inter
+            loss = loss + inter * w
+    out["loss"] = loss
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -486,10 +486,77 @@ def make_cfg1_fixture():
           "grad tensors", len(names))
 
 
+# the encoder options the oracle restates ahead of the kernels (oracle/conformer_ref.py: att_context_size / att_context_style,
+# conv_norm_type, conv_context_size, InterCTC): name -> (ReferenceCTCModel / ConformerEncoder kwargs, InterCTC (layers, weights) or None)
+ENCODER_OPTION_CASES = {
+    "att_regular_8_4": (dict(att_context_size=[8, 4], att_context_style="regular"), None),
+    "att_regular_left_6": (dict(att_context_size=[6, -1], att_context_style="regular"), None),
+    "att_chunked_8_3": (dict(att_context_size=[8, 3], att_context_style="chunked_limited"), None),
+    "conv_layer_norm": (dict(conv_norm_type="layer_norm"), None),
+    "conv_causal": (dict(conv_context_size="causal"), None),
+    "conv_context_6_2": (dict(conv_context_size=[6, 2]), None),
+    "interctc_l0_l1": (dict(), ([0, 1], [0.3, 0.1])),
+    "streaming_recipe": (dict(att_context_size=[8, 3], att_context_style="chunked_limited", conv_context_size="causal",
+                              conv_norm_type="layer_norm"), ([1], [0.25])),
+}
+OPTION_GRADS = ["encoder.pre_encode.out.weight", "encoder.layers.0.self_attn.linear_q.weight", "encoder.layers.0.self_attn.pos_bias_u",
+                "encoder.layers.0.conv.depthwise_conv.weight", "encoder.layers.0.conv.batch_norm.weight",
+                "encoder.layers.1.feed_forward2.linear2.weight", "encoder.layers.1.norm_out.weight",
+                "decoder.decoder_layers.0.weight", "decoder.decoder_layers.0.bias"]
+
+
+def make_encoder_options_fixture():
+    """tests/golden/ref_encoder_options.npz: the reference's own ConformerEncoder run with the options of the streaming / long-form /
+    InterCTC recipes on the tiny model of ref_tiny_model.npz (same parameters, same batch, conv kernel 9): encoder output, loss,
+    InterCTC parts and a handful of gradients per case, train-mode BatchNorm statistics, dropout 0."""
+    from oracle.ref_shim import ReferenceCTCModel
+    from oracle import conformer_ref as R
+    z = np.load(os.path.join(GOLD, "ref_tiny_model.npz"))
+    audio, alen = torch.from_numpy(z["audio"]), torch.from_numpy(z["audio_len"])
+    tok, tl = torch.from_numpy(z["tokens"]), torch.from_numpy(z["token_len"])
+    fix = {}
+    for name, (kw, inter) in ENCODER_OPTION_CASES.items():
+        torch.manual_seed(0)
+        m = ReferenceCTCModel(d_model=32, n_heads=4, n_layers=2, vocab=16, conv_kernel_size=9, **kw)
+        sd = m.encoder.state_dict()
+        with torch.no_grad():
+            for k in sd:  # the tiny fixture's parameters wherever the shapes agree (the depthwise kernel is 9 taps here, 31 there)
+                src = torch.from_numpy(z["P/encoder." + k]) if ("P/encoder." + k) in z.files else None
+                if src is not None and src.shape == sd[k].shape:
+                    sd[k].copy_(src)
+            m.decoder_layers[0].weight.copy_(torch.from_numpy(z["P/decoder.decoder_layers.0.weight"]))
+            m.decoder_layers[0].bias.copy_(torch.from_numpy(z["P/decoder.decoder_layers.0.bias"]))
+        m.encoder.load_state_dict(sd)
+        m.train(); m.featurizer.eval()
+        if inter is None:
+            loss, logp, enc, enc_len, mel, mel_len = m(audio, alen, tok, tl)
+            out = {"loss": loss}
+        else:
+            out, enc, enc_len = m.forward_interctc(audio, alen, tok, tl, *inter)
+        m.zero_grad()
+        out["loss"].backward()
+        for k, v in m.encoder.state_dict().items():
+            if k.endswith("depthwise_conv.weight") or (kw.get("conv_norm_type") == "layer_norm" and "batch_norm" in k):
+                fix[f"{name}/P/encoder.{k}"] = v.numpy().copy()  # the parameters that differ in shape / meaning from the tiny fixture
+        fix[f"{name}/enc"] = enc.detach().numpy()
+        fix[f"{name}/enc_len"] = enc_len.numpy()
+        for k, v in out.items():
+            fix[f"{name}/{k}"] = v.detach().numpy()
+        grads = {"encoder." + n: p.grad for n, p in m.encoder.named_parameters()}
+        grads.update({"decoder.decoder_layers." + n: p.grad for n, p in m.decoder_layers.named_parameters()})
+        for n in OPTION_GRADS:
+            fix[f"{name}/grad/{n}"] = grads[n].numpy().copy()
+        print("encoder option", name, "loss", float(out["loss"]))
+    np.savez_compressed(os.path.join(GOLD, "ref_encoder_options.npz"), **fix)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "cfg1":
         make_cfg1_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "options":
+        make_encoder_options_fixture()
         sys.exit(0)
     extract_ctc_known_answers()
     make_reference_fixtures()
@@ -501,3 +568,4 @@ if __name__ == "__main__":
     make_rnnt_greedy_fixture()
     make_fastconformer_fixture()
     make_cfg1_fixture()
+    make_encoder_options_fixture()

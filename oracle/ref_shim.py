@@ -301,7 +301,7 @@ class ReferenceCTCModel(nn.Module):
     (conv_asr.py:445-468) and CTCLoss (losses/ctc.py:45-82) named in SURVEY.md section 8(c)."""
 
     def __init__(self, d_model, n_heads, n_layers, vocab=128, feat_in=80, dropout=0.0, dropout_att=0.0,
-                 dither=0.0, conv_kernel_size=31):
+                 dither=0.0, conv_kernel_size=31, **encoder_kwargs):
         super().__init__()
         FilterbankFeatures, ConformerEncoder = load_reference()
         self.featurizer = FilterbankFeatures(
@@ -310,7 +310,7 @@ class ReferenceCTCModel(nn.Module):
         self.encoder = ConformerEncoder(
             feat_in=feat_in, n_layers=n_layers, d_model=d_model, n_heads=n_heads, subsampling="striding",
             subsampling_factor=4, conv_kernel_size=conv_kernel_size, dropout=dropout,
-            dropout_pre_encoder=dropout, dropout_emb=0.0, dropout_att=dropout_att)
+            dropout_pre_encoder=dropout, dropout_emb=0.0, dropout_att=dropout_att, **encoder_kwargs)
         self.decoder_layers = nn.Sequential(nn.Conv1d(d_model, vocab + 1, kernel_size=1, bias=True))
         nn.init.xavier_uniform_(self.decoder_layers[0].weight)
         self.vocab = vocab
@@ -325,3 +325,30 @@ class ReferenceCTCModel(nn.Module):
         logp = torch.log_softmax(self.decoder_layers(enc).transpose(1, 2), dim=-1)
         loss = self.ctc(logp.transpose(1, 0), tokens.long(), enc_len.long(), token_len.long()).mean()
         return loss, logp, enc, enc_len, mel, mel_len
+
+    def forward_interctc(self, audio, audio_len, tokens, token_len, apply_at_layers, loss_weights):
+        """The reference encoder's OWN capture code (conformer_encoder.py:724-736) switched on through the three AccessMixin
+        members it touches, then the loss assembly of InterCTCMixin.add_interctc_losses (parts/mixins/interctc_mixin.py:214-270:
+        main weight = 1 - sum(loss_weights), the model's decoder + loss on every captured (output, length) pair) restated."""
+        captured = {}
+        e = self.encoder
+        e.is_access_enabled = lambda guid=None: True
+        e.access_cfg = {"interctc": {"capture_layers": list(apply_at_layers)}}
+        e.interctc_capture_at_layers = None
+        e.register_accessible_tensor = lambda name, tensor: captured.__setitem__(name, tensor)
+        try:
+            loss, logp, enc, enc_len, mel, mel_len = self.forward(audio, audio_len, tokens, token_len)
+        finally:
+            del e.is_access_enabled, e.register_accessible_tensor
+            e.interctc_capture_at_layers = None
+        out = {"final_loss": loss}
+        total = loss * (1.0 - sum(loss_weights))
+        for l, w in zip(apply_at_layers, loss_weights):
+            x, n = captured[f"interctc/layer_output_{l}"], captured[f"interctc/layer_length_{l}"]
+            lp = torch.log_softmax(self.decoder_layers(x).transpose(1, 2), dim=-1)
+            inter = self.ctc(lp.transpose(1, 0), tokens.long(), n.long(), token_len.long()).mean()
+            out[f"inter_ctc_loss_l{l}"] = inter
+            out[f"layer_output_{l}"] = x
+            total = total + inter * w
+        out["loss"] = total
+        return out, enc, enc_len

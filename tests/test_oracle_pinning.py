@@ -130,6 +130,87 @@ def test_model_restatement_matches_reference_fixture(golden_dir, mode):
         assert np.abs(P[k].grad.numpy() - ref).max() <= 1e-3 * scale + 1e-5, k  # analytically-zero grads (dw bias under BN, k bias) are pure rounding noise
 
 
+def _encoder_option_cases():
+    from oracle.make_golden import ENCODER_OPTION_CASES
+    return ENCODER_OPTION_CASES
+
+
+def _option_cfg(kw):
+    kw = dict(kw)
+    ccs = kw.pop("conv_context_size", None)
+    if ccs == "causal":
+        ccs = (8, 0)  # [kernel - 1, 0], conformer_encoder.py:902-903
+    return R.ConformerCfg(d_model=32, n_heads=4, n_layers=2, vocab=16, conv_kernel=9, dropout=0, dropout_att=0, dropout_pre_encoder=0,
+                          att_context_size=tuple(kw.pop("att_context_size", (-1, -1))), att_context_style=kw.pop("att_context_style", "regular"),
+                          conv_norm_type=kw.pop("conv_norm_type", "batch_norm"), conv_context_size=tuple(ccs) if ccs else None)
+
+
+@pytest.mark.parametrize("case", ["att_regular_8_4", "att_regular_left_6", "att_chunked_8_3", "conv_layer_norm", "conv_causal",
+                                  "conv_context_6_2", "interctc_l0_l1", "streaming_recipe"])
+def test_encoder_option_restatements_match_the_reference_fixture(golden_dir, case):
+    """Oracle first (the kernels for these options come after it): limited / chunked attention context, LayerNorm in the conv
+    module, causal / asymmetric depthwise padding and the InterCTC loss assembly of oracle/conformer_ref.py against the reference's
+    own ConformerEncoder run with the same options (oracle/make_golden.py: make_encoder_options_fixture, train-mode BatchNorm
+    statistics, dropout 0): encoder output, lengths, loss, the InterCTC parts and a set of gradients from every block."""
+    from oracle.make_golden import OPTION_GRADS
+    kw, inter = _encoder_option_cases()[case]
+    z = np.load(os.path.join(golden_dir, "ref_tiny_model.npz"))
+    zo = np.load(os.path.join(golden_dir, "ref_encoder_options.npz"))
+    P = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("P/")}
+    for k in zo.files:
+        if k.startswith(case + "/P/"):
+            P[k[len(case) + 3:]] = torch.from_numpy(zo[k])
+    for k in R.trainable_keys(P):
+        P[k] = P[k].clone().requires_grad_(True)
+    out = R.model_forward(P, _option_cfg(kw), torch.from_numpy(z["audio"]), torch.from_numpy(z["audio_len"]),
+                          torch.from_numpy(z["tokens"]), torch.from_numpy(z["token_len"]), train=False, bn_training=True,
+                          interctc=inter)
+    assert np.array_equal(out["enc_len"].numpy(), zo[f"{case}/enc_len"])
+    assert np.allclose(out["enc"].detach().numpy(), zo[f"{case}/enc"], atol=2e-5)
+    assert abs(out["loss"].item() - float(zo[f"{case}/loss"])) <= 1e-5 * abs(float(zo[f"{case}/loss"]))
+    if inter:
+        assert abs(out["final_loss"].item() - float(zo[f"{case}/final_loss"])) <= 1e-5 * abs(float(zo[f"{case}/final_loss"]))
+        for l in inter[0]:
+            a, b = out[f"inter_ctc_loss_l{l}"].item(), float(zo[f"{case}/inter_ctc_loss_l{l}"])
+            assert abs(a - b) <= 1e-5 * abs(b), (l, a, b)
+    out["loss"].backward()
+    for k in OPTION_GRADS:
+        ref = zo[f"{case}/grad/{k}"]
+        scale = max(np.abs(ref).max(), 1e-4)
+        assert np.abs(P[k].grad.numpy() - ref).max() <= 1e-3 * scale + 1e-5, k
+    # the options change the result: every case differs from the default encoder's output on the same parameters
+    if kw:
+        P0 = {k: v.detach() for k, v in P.items()}
+        base = R.model_forward(P0, _option_cfg({}), torch.from_numpy(z["audio"]), torch.from_numpy(z["audio_len"]),
+                               torch.from_numpy(z["tokens"]), torch.from_numpy(z["token_len"]), train=False, bn_training=True)
+        assert (base["enc"] - out["enc"].detach()).abs().max() > 1e-3
+
+
+def test_context_mask_is_the_reference_mask_for_every_style():
+    """R.context_mask against a literal transcription of the reference's torch.triu / tril / chunk arithmetic
+    (ConformerEncoder._create_masks, conformer_encoder.py:794-823) over a grid of sizes"""
+    for T in (1, 5, 17):
+        for style in ("regular", "chunked_limited"):
+            for left in (-1, 0, 3, 8, 12):
+                for right in (-1, 0, 3):
+                    if style == "chunked_limited" and right >= 0 and left > 0 and left % (right + 1):
+                        continue
+                    m = torch.ones(T, T, dtype=torch.bool)
+                    if style == "regular":
+                        if left >= 0: m = m.triu(diagonal=-left)
+                        if right >= 0: m = m.tril(diagonal=right)
+                    elif right == -1:
+                        if left >= 0: m = m.triu(diagonal=-left)
+                    else:
+                        cs = right + 1
+                        lc = left // cs if left >= 0 else 10000
+                        ci = torch.div(torch.arange(T, dtype=torch.int), cs, rounding_mode="trunc")
+                        d = ci.unsqueeze(1) - ci.unsqueeze(0)
+                        m = m & (d <= lc) & (d >= 0)
+                    got = R.context_mask(R.ConformerCfg(att_context_size=(left, right), att_context_style=style), T)
+                    assert torch.equal(got, m), (T, style, left, right)
+
+
 @pytest.mark.reference
 def test_restatement_matches_live_reference():
     from oracle import ref_shim
