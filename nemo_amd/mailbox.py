@@ -40,11 +40,14 @@ class StatsMailbox:
             return None
         device = torch.device(device)
         on_host = dist.get_backend(group) == "gloo"  # (gloo carries host tensors; RCCL carries device tensors)
+        have_gpu = device.type == "cuda" and torch.cuda.is_available()
         for mem_kind in (0, 3):  # first try: the best exportable kind of memory per rank; second: plain device memory everywhere
-            with torch.cuda.device(device):
-                mb = C.c_void_p()
-                handle = (C.c_ubyte * HANDLE_BYTES)()
-                rc = lib.mi355x_mailbox_create(world, rank, n_max, timeout_ms, mem_kind, C.byref(mb), handle)
+            mb = C.c_void_p()
+            handle = (C.c_ubyte * HANDLE_BYTES)()
+            rc = -1  # (a rank without a GPU still takes part in the agreement below, so that every rank gets the same answer)
+            if have_gpu:
+                with torch.cuda.device(device):
+                    rc = lib.mi355x_mailbox_create(world, rank, n_max, timeout_ms, mem_kind, C.byref(mb), handle)
             mine = torch.tensor([1 if rc == 0 else 0] + list(handle), dtype=torch.int32)
             if not on_host:
                 mine = mine.to(device)

@@ -289,3 +289,29 @@ def test_tail_bucket_is_cut_early_and_complete_buffers_leave_at_once_world2_gloo
     ret = mgr.dict()
     mp.spawn(_worker_tail, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _worker_mailbox_agreement(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nemo_amd.mailbox import StatsMailbox
+        # no GPU on this box: no rank can allocate a mailbox -- every rank still walks through BOTH rounds of the agreement
+        # (all_gather of the handles, MIN over the open results) and gets None, and the process group is still usable afterwards
+        mb = StatsMailbox.create(torch.device("cuda:0") if rank == 0 else torch.device("cpu"), n_max=1025)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        ret[rank] = (mb is None) and float(t[0]) == 3.0
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the no-GPU side of StatsMailbox.create (the GPU side: tests/test_mailbox_gpu.py)")
+def test_mailbox_creation_is_all_or_nothing_across_ranks_world2_gloo():
+    """nemo_amd/mailbox.py: a rank that cannot allocate / export / map a mailbox must not leave the others with one -- the ranks
+    agree through the process group and ALL fall back to it (SyncBatchNorm exchanges stay on torch.distributed.all_reduce)"""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_mailbox_agreement, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
