@@ -211,6 +211,43 @@ def test_context_mask_is_the_reference_mask_for_every_style():
                     assert torch.equal(got, m), (T, style, left, right)
 
 
+@pytest.mark.parametrize("lengths", [[16000, 12000, 8123], [16000, 16000, 16000], [16000, 2400, 9000], [15000, 14840, 14680]])
+def test_packed_token_restatement_reproduces_the_padded_reference_path(golden_dir, lengths):
+    """oracle/packed_ref.py (the layers on the valid frames of a ragged batch only, BatchNorm statistics completed analytically for
+    the padded frames: halo frames computed, the rest = the depthwise bias) against oracle/conformer_ref.py's padded computation --
+    itself pinned to the reference on this very model (test_model_restatement_matches_reference_fixture): encoder output on every
+    valid frame, CTC loss and EVERY gradient, train-mode BatchNorm; utterances shorter than / within the 15-frame halo of the
+    longest included, and a batch without padding."""
+    from oracle import packed_ref as PK
+    z = np.load(os.path.join(golden_dir, "ref_tiny_model.npz"))
+    cfg = R.ConformerCfg(d_model=32, n_heads=4, n_layers=2, vocab=16, dropout=0, dropout_att=0, dropout_pre_encoder=0)
+    audio, tok = torch.from_numpy(z["audio"]), torch.from_numpy(z["tokens"])
+    alen, tl = torch.tensor(lengths), torch.tensor([3, 2, 3])
+    with torch.no_grad():
+        mel, mel_len = R.log_mel_features(audio, alen, n_mels=cfg.feat_in)
+    grads = []
+    for packed in (False, True):
+        P = {k[2:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("P/")}
+        for k in R.trainable_keys(P):
+            P[k].requires_grad_(True)
+        if packed:
+            enc, enc_len = PK.encoder_forward_packed(P, cfg, mel, mel_len, bn_training=True, pfx="encoder.")
+        else:
+            enc, enc_len = R.encoder_forward(P, cfg, mel, mel_len, train=False, bn_training=True, pfx="encoder.")
+        logp = R.decoder_forward(P, enc, "decoder.decoder_layers.0.", cfg)
+        loss, _ = R.ctc_loss_mean_batch(logp, tok, enc_len, tl, cfg.vocab)
+        loss.backward()
+        grads.append((enc.detach(), enc_len, loss.item(), {k: P[k].grad.clone() for k in R.trainable_keys(P)}))
+    (e0, n0, l0, g0), (e1, n1, l1, g1) = grads
+    assert torch.equal(n0, n1)
+    for b, n in enumerate(n0.tolist()):
+        assert (e0[b, :, :n] - e1[b, :, :n]).abs().max() <= 2e-5, b
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    for k in g0:
+        scale = max(g0[k].abs().max().item(), 1e-4)
+        assert (g0[k] - g1[k]).abs().max().item() <= 1e-3 * scale + 1e-5, k
+
+
 @pytest.mark.reference
 def test_restatement_matches_live_reference():
     from oracle import ref_shim
