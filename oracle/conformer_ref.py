@@ -62,6 +62,10 @@ class ConformerCfg:
     att_context_style: str = "regular"             # "regular" | "chunked_limited"
     conv_norm_type: str = "batch_norm"             # "batch_norm" | "layer_norm" (conformer_modules.py:293-306, 335-340)
     conv_context_size: Optional[Tuple[int, int]] = None  # [left, right] padding of the depthwise conv; None = symmetric; (k-1, 0) = causal
+    feat_out: int = -1                              # > 0 and != d_model: a Linear(d_model, feat_out) after the last layer (conformer_encoder.py:474-479, 738-739)
+    stochastic_depth_drop_prob: float = 0.0         # layers dropped at random in training (conformer_encoder.py:696-707, arXiv 2102.03216)
+    stochastic_depth_mode: str = "linear"
+    stochastic_depth_start_layer: int = 1
 
     @property
     def channels(self):
@@ -380,24 +384,61 @@ def conformer_layer(P, pfx, cfg: ConformerCfg, x, pos_emb, valid, train, bn_trai
     return _ln(P, pfx + "norm_out.", r)
 
 
+def layer_drop_probs(cfg: ConformerCfg):
+    """compute_stochastic_depth_drop_probs (parts/utils/regularization_utils.py:18-64): the first `start_layer` layers are never
+    dropped; 'linear': l / L * p for the l-th of the remaining L layers, 'uniform': p for each of them."""
+    p, start, n = cfg.stochastic_depth_drop_prob, cfg.stochastic_depth_start_layer, cfg.n_layers
+    if not (0 <= p < 1.0):
+        raise ValueError("stochastic_depth_drop_prob has to be in [0, 1).")
+    if not (1 <= start <= n):
+        raise ValueError("stochastic_depth_start_layer has to be in [1, num layers].")
+    probs = [0.0] * start
+    L = n - start
+    if L > 0:
+        if cfg.stochastic_depth_mode == "linear":
+            probs += [l / L * p for l in range(1, L + 1)]
+        elif cfg.stochastic_depth_mode == "uniform":
+            probs += [p] * L
+        else:
+            raise ValueError(f'stochastic_depth_mode has to be one of ["linear", "uniform"]. Current value: {cfg.stochastic_depth_mode}')
+    return probs
+
+
 def encoder_forward(P, cfg: ConformerCfg, mel, mel_len, train=False, bn_training=None, pfx="", bn_stats_out=None,
-                    n_layers: Optional[int] = None, capture: Optional[dict] = None):
+                    n_layers: Optional[int] = None, capture: Optional[dict] = None, bypass_pre_encode: bool = False,
+                    dropped: Optional[list] = None):
     """-> (encoded [B, d, T'], enc_len [B]).  `P` keys = reference encoder state_dict keys (+ optional prefix).
     `capture` = {layer index: None}: filled with that layer's output [B, d, T'] (0-based, after norm_out) -- what the reference
     registers as `interctc/layer_output_<l>` (conformer_encoder.py:724-736)."""
     bn_training = train if bn_training is None else bn_training
-    x, enc_len = subsampling_forward(P, cfg, mel, mel_len, pfx + "pre_encode.")
+    if bypass_pre_encode:  # `mel` is already [B, T', d_model] (conformer_encoder.py:602-611, 630); a wrong shape is a ValueError (:569-578)
+        if mel.shape[-1] != cfg.d_model:
+            raise ValueError(f"If bypass_pre_encode is True, audio_signal should have shape (batch, n_frame, {cfg.d_model})")
+        x, enc_len = mel, mel_len.to(torch.int64)
+    else:
+        x, enc_len = subsampling_forward(P, cfg, mel, mel_len, pfx + "pre_encode.")
     B, T, d = x.shape
     if cfg.xscaling:
         x = x * math.sqrt(d)
     x = _drop(x, cfg.dropout_pre_encoder, train)
     pos_emb = rel_pos_table(T, d).to(x.dtype)  # (float64 when the oracle is run in double to bound fp32 noise)
     valid = torch.arange(T).unsqueeze(0) < enc_len.unsqueeze(1)
+    probs = layer_drop_probs(cfg) if cfg.stochastic_depth_drop_prob > 0.0 else None
+    out_proj = (lambda t: F.linear(t, P[pfx + "out_proj.weight"], P[pfx + "out_proj.bias"])) \
+        if (cfg.feat_out > 0 and cfg.feat_out != d) else (lambda t: t)
     for i in range(cfg.n_layers if n_layers is None else n_layers):
+        x_in = x
         x = conformer_layer(P, f"{pfx}layers.{i}.", cfg, x, pos_emb, valid, train, bn_training, bn_stats_out)
+        if train and probs is not None and probs[i] > 0.0:
+            # one torch.rand(1) per droppable layer and forward, from the global generator, like the reference (:698); a dropped
+            # layer still runs (x * 0 + input: every weight gets a gradient, no rank diverges), a kept one is rescaled by 1 / (1 - p)
+            drop = bool(torch.rand(1) < probs[i])
+            if dropped is not None:
+                dropped.append(drop)
+            x = x * 0.0 + x_in if drop else (x - x_in) / (1.0 - probs[i]) + x_in
         if capture is not None and i in capture:
-            capture[i] = x.transpose(1, 2)
-    return x.transpose(1, 2), enc_len
+            capture[i] = out_proj(x).transpose(1, 2)
+    return out_proj(x).transpose(1, 2), enc_len
 
 
 def decoder_forward(P, enc, pfx="decoder_layers.0.", cfg=None):

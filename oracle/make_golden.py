@@ -550,8 +550,67 @@ def make_encoder_options_fixture():
     np.savez_compressed(os.path.join(GOLD, "ref_encoder_options.npz"), **fix)
 
 
+def make_encoder_structure_fixture():
+    """tests/golden/ref_encoder_structure.npz: what the reference's own encoder tests exercise (tests/collections/asr/
+    test_conformer_encoder.py: stochastic depth :24-124, bypass_pre_encode with feat_out and a LayerNorm conv module :129-199) as
+    VALUES from the reference's ConformerEncoder, for the oracle restatement of the same options: (1) feat_out projection, (2)
+    bypass_pre_encode on pre-encoded frames with conv_norm_type=layer_norm / kernel 3 / feat_out (the reference test's own
+    geometry), (3) stochastic depth in training mode (uniform and linear), decisions drawn from torch's global generator."""
+    from oracle.ref_shim import load_reference
+    _, ConformerEncoder = load_reference()
+    fix = {}
+
+    def run(name, enc, x, n, seed=None, pname=None, **fw):
+        g = torch.Generator().manual_seed(99)
+        probe = None
+        if seed is not None:
+            torch.manual_seed(seed)
+        y, yl = enc(audio_signal=x, length=n, **fw)
+        probe = torch.randn(y.shape, generator=g)
+        enc.zero_grad()
+        (y * probe).sum().backward()
+        fix[f"{name}/x"], fix[f"{name}/len"] = x.numpy(), n.numpy()
+        fix[f"{name}/y"], fix[f"{name}/ylen"], fix[f"{name}/probe"] = y.detach().numpy(), yl.numpy(), probe.numpy()
+        for k, v in enc.state_dict().items():
+            if "pos_enc" not in k:  # (the 5000-position sinusoid table is a buffer, not a parameter)
+                fix[f"{pname or name}/P/{k}"] = v.numpy().copy()
+        for k, p_ in enc.named_parameters():
+            if k.startswith(("layers.0.", "out_proj", "pre_encode.conv.0", "layers.3.feed_forward2")) and p_.grad is not None:
+                fix[f"{name}/grad/{k}"] = p_.grad.numpy().copy()  # (bypass_pre_encode leaves the sub-sampling without gradients)
+        print("encoder structure", name, tuple(y.shape), float(y.detach().abs().mean()))
+
+    # (1) feat_out projection on the ordinary path
+    torch.manual_seed(3)
+    enc = ConformerEncoder(feat_in=80, n_layers=2, d_model=32, n_heads=4, feat_out=24, conv_kernel_size=9, dropout=0.0,
+                           dropout_pre_encoder=0.0, dropout_emb=0.0, dropout_att=0.0)
+    enc.train()
+    run("feat_out", enc, torch.randn(3, 80, 101, generator=torch.Generator().manual_seed(5)), torch.tensor([101, 77, 40]))
+    # (2) bypass_pre_encode, the reference test's geometry (d_model 16, feat_out 8, layer_norm conv, kernel 3)
+    torch.manual_seed(4)
+    enc = ConformerEncoder(feat_in=10, n_layers=3, d_model=16, feat_out=8, stochastic_depth_drop_prob=0.0, dropout=0.0,
+                           dropout_pre_encoder=0.0, dropout_emb=0.0, dropout_att=0.0, conv_norm_type="layer_norm", conv_kernel_size=3)
+    enc.train()
+    run("bypass", enc, torch.rand(2, 17, 16, generator=torch.Generator().manual_seed(6)), torch.tensor([17, 11]),
+        bypass_pre_encode=True)
+    # (3) stochastic depth, training mode
+    for mode, seed in (("uniform", 11), ("linear", 12)):
+        torch.manual_seed(7)
+        enc = ConformerEncoder(feat_in=80, n_layers=4, d_model=32, n_heads=4, conv_kernel_size=9, dropout=0.0, dropout_pre_encoder=0.0,
+                               dropout_emb=0.0, dropout_att=0.0, stochastic_depth_drop_prob=0.6, stochastic_depth_mode=mode,
+                               stochastic_depth_start_layer=1)
+        enc.train()
+        fix[f"sd_{mode}/probs"] = np.array(enc.layer_drop_probs)
+        fix[f"sd_{mode}/seed"] = np.array(seed)
+        run(f"sd_{mode}", enc, torch.randn(2, 80, 65, generator=torch.Generator().manual_seed(8)), torch.tensor([65, 33]), seed=seed,
+            pname="sd")  # (both modes start from the same initialisation: one copy of the parameters)
+    np.savez_compressed(os.path.join(GOLD, "ref_encoder_structure.npz"), **fix)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "structure":
+        make_encoder_structure_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cfg1":
         make_cfg1_fixture()
         sys.exit(0)
@@ -569,3 +628,4 @@ if __name__ == "__main__":
     make_fastconformer_fixture()
     make_cfg1_fixture()
     make_encoder_options_fixture()
+    make_encoder_structure_fixture()

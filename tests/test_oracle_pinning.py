@@ -248,6 +248,70 @@ def test_packed_token_restatement_reproduces_the_padded_reference_path(golden_di
         assert (g0[k] - g1[k]).abs().max().item() <= 1e-3 * scale + 1e-5, k
 
 
+@pytest.mark.parametrize("case", ["feat_out", "bypass", "sd_uniform", "sd_linear"])
+def test_encoder_structure_restatements_match_the_reference_fixture(golden_dir, case):
+    """what the reference's own encoder tests exercise (tests/collections/asr/test_conformer_encoder.py:24-199: stochastic depth,
+    bypass_pre_encode with feat_out and a LayerNorm conv module), as VALUES: oracle/conformer_ref.py against the reference's
+    ConformerEncoder (oracle/make_golden.py: make_encoder_structure_fixture) -- output, lengths and the gradients of a random
+    probe; stochastic depth draws its decisions from torch's global generator at the same points as the reference"""
+    z = np.load(os.path.join(golden_dir, "ref_encoder_structure.npz"))
+    pname = "sd" if case.startswith("sd_") else case
+    P = {k[len(pname) + 3:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith(pname + "/P/")}
+    for k in R.trainable_keys(P):
+        P[k].requires_grad_(True)
+    common = dict(vocab=16, dropout=0, dropout_att=0, dropout_pre_encoder=0)
+    if case == "feat_out":
+        cfg = R.ConformerCfg(d_model=32, n_heads=4, n_layers=2, conv_kernel=9, feat_out=24, **common)
+    elif case == "bypass":
+        cfg = R.ConformerCfg(feat_in=10, d_model=16, n_heads=4, n_layers=3, conv_kernel=3, feat_out=8, conv_norm_type="layer_norm", **common)
+    else:
+        cfg = R.ConformerCfg(d_model=32, n_heads=4, n_layers=4, conv_kernel=9, stochastic_depth_drop_prob=0.6,
+                             stochastic_depth_mode=case[3:], **common)
+        assert np.allclose(R.layer_drop_probs(cfg), z[f"{case}/probs"])
+        torch.manual_seed(int(z[f"{case}/seed"]))
+    dropped = []
+    y, ylen = R.encoder_forward(P, cfg, torch.from_numpy(z[f"{case}/x"]), torch.from_numpy(z[f"{case}/len"]), train=True,
+                                bypass_pre_encode=(case == "bypass"), dropped=dropped)
+    assert np.array_equal(ylen.numpy(), z[f"{case}/ylen"])
+    assert np.allclose(y.detach().numpy(), z[f"{case}/y"], atol=3e-5), np.abs(y.detach().numpy() - z[f"{case}/y"]).max()
+    if case.startswith("sd_"):
+        assert len(dropped) == 3 and any(dropped) and not all(dropped), dropped  # (the seeds were chosen to exercise both branches)
+    (y * torch.from_numpy(z[f"{case}/probe"])).sum().backward()
+    n = 0
+    for k in z.files:
+        if k.startswith(case + "/grad/"):
+            name, ref = k[len(case) + 6:], z[k]
+            scale = max(np.abs(ref).max(), 1e-4)
+            # (analytically-zero gradients -- the key bias, the depthwise bias under BatchNorm -- are rounding noise of a few 1e-5
+            #  under this O(1) probe on both sides)
+            if np.abs(ref).max() < 2e-4:   # noise on both sides: it only has to stay noise
+                assert np.abs(P[name].grad.numpy()).max() < 5e-4, name
+            else:
+                assert np.abs(P[name].grad.numpy() - ref).max() <= 1e-3 * scale + 5e-5, name
+            n += 1
+    assert n >= 10
+    if case == "bypass":  # conformer_encoder.py:569-578: a [B, feat_in, T] tensor where pre-encoded frames are expected is a ValueError
+        with pytest.raises(ValueError):
+            R.encoder_forward(P, cfg, torch.rand(2, 10, 17), torch.tensor([17, 11]), bypass_pre_encode=True)
+
+
+def test_stochastic_depth_drop_probabilities_follow_the_reference_rules():
+    """regularization_utils.py:18-64 (the reference checks the same numbers in test_conformer_encoder.py:24-83)"""
+    mk = lambda **kw: R.layer_drop_probs(R.ConformerCfg(n_layers=kw.pop("n"), **kw))
+    assert mk(n=8, stochastic_depth_drop_prob=0.0) == [0.0] * 8
+    assert mk(n=8, stochastic_depth_drop_prob=0.5, stochastic_depth_mode="uniform") == [0.0] + [0.5] * 7
+    assert mk(n=8, stochastic_depth_drop_prob=0.5, stochastic_depth_mode="uniform", stochastic_depth_start_layer=3) == [0.0] * 3 + [0.5] * 5
+    assert np.allclose(mk(n=5, stochastic_depth_drop_prob=0.8, stochastic_depth_mode="linear"), [0.0, 0.2, 0.4, 0.6, 0.8])
+    assert np.allclose(mk(n=5, stochastic_depth_drop_prob=0.9, stochastic_depth_mode="linear", stochastic_depth_start_layer=2),
+                       [0.0, 0.0, 0.3, 0.6, 0.9])
+    for bad in (dict(stochastic_depth_drop_prob=1.0), dict(stochastic_depth_drop_prob=-0.1),
+                dict(stochastic_depth_drop_prob=0.5, stochastic_depth_start_layer=0),
+                dict(stochastic_depth_drop_prob=0.5, stochastic_depth_start_layer=9),
+                dict(stochastic_depth_drop_prob=0.5, stochastic_depth_mode="weird")):
+        with pytest.raises(ValueError):
+            mk(n=8, **bad)
+
+
 @pytest.mark.reference
 def test_restatement_matches_live_reference():
     from oracle import ref_shim
