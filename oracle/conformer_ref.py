@@ -66,6 +66,8 @@ class ConformerCfg:
     stochastic_depth_drop_prob: float = 0.0         # layers dropped at random in training (conformer_encoder.py:696-707, arXiv 2102.03216)
     stochastic_depth_mode: str = "linear"
     stochastic_depth_start_layer: int = 1
+    causal_downsampling: bool = False               # CausalConv2D in the sub-sampling: pad (k - 1, stride - 1) on time AND frequency,
+                                                    # no symmetric padding (causal_convs.py:24-72, subsampling.py:147-149, 222-224)
 
     @property
     def channels(self):
@@ -267,13 +269,21 @@ def subsampling_forward(P: Dict[str, Tensor], cfg: ConformerCfg, mel: Tensor, me
     def tmask(n, L):
         return (torch.arange(L).unsqueeze(0) < n.unsqueeze(1)).to(x.dtype).view(B, 1, L, 1)
 
+    causal = getattr(cfg, "causal_downsampling", False)
+
+    def conv(t, w, b):  # Conv2d(k 3, s 2, p 1), or CausalConv2D: F.pad (2, 1, 2, 1) then no padding
+        return F.conv2d(F.pad(t, (2, 1, 2, 1)), w, b, stride=2) if causal else F.conv2d(t, w, b, stride=2, padding=1)
+
+    def out_len(n):  # calculate_conv_output_size (subsampling.py:720-722): paddings (1, 1) or (2, 1), kernel 3, stride 2
+        return torch.div(n + 3 - 3, 2, rounding_mode="floor") + 1 if causal else conv_out_len(n, 1)
+
     l0 = mel_len.to(torch.int64)
     x = x * tmask(l0, T)
-    x = F.conv2d(x, P[pfx + "conv.0.weight"], P[pfx + "conv.0.bias"], stride=2, padding=1)  # (conv1 reads fp32 weights)
-    l1 = conv_out_len(l0, 1)
+    x = conv(x, P[pfx + "conv.0.weight"], P[pfx + "conv.0.bias"])  # (conv1 reads fp32 weights)
+    l1 = out_len(l0)
     x = _q(torch.relu(x * tmask(l1, x.shape[2])) * tmask(l1, x.shape[2]), cfg)
-    x = F.conv2d(x, _qw(P[pfx + "conv.2.weight"], cfg), P[pfx + "conv.2.bias"], stride=2, padding=1)
-    l2 = conv_out_len(l1, 1)
+    x = conv(x, _qw(P[pfx + "conv.2.weight"], cfg), P[pfx + "conv.2.bias"])
+    l2 = out_len(l1)
     x = _q(torch.relu(x * tmask(l2, x.shape[2])) * tmask(l2, x.shape[2]), cfg)
     b, c, t, f = x.shape
     x = x.transpose(1, 2).reshape(b, t, c * f)

@@ -603,6 +603,21 @@ def make_encoder_structure_fixture():
         fix[f"sd_{mode}/seed"] = np.array(seed)
         run(f"sd_{mode}", enc, torch.randn(2, 80, 65, generator=torch.Generator().manual_seed(8)), torch.tensor([65, 33]), seed=seed,
             pname="sd")  # (both modes start from the same initialisation: one copy of the parameters)
+    # (4) causal down-sampling (CausalConv2D), 'striding' x4 and the cache-aware streaming recipe's whole combination:
+    # 'dw_striding' x8 + causal_downsampling + chunked_limited attention [70, 13] + causal LayerNorm conv module, kernel 9
+    # (examples/asr/conf/fastconformer/cache_aware_streaming/fastconformer_ctc_bpe_streaming.yaml: encoder section)
+    torch.manual_seed(9)
+    enc = ConformerEncoder(feat_in=80, n_layers=2, d_model=32, n_heads=4, conv_kernel_size=9, causal_downsampling=True, dropout=0.0,
+                           dropout_pre_encoder=0.0, dropout_emb=0.0, dropout_att=0.0)
+    enc.train()
+    run("causal_striding", enc, torch.randn(3, 80, 101, generator=torch.Generator().manual_seed(10)), torch.tensor([101, 77, 40]))
+    torch.manual_seed(13)
+    enc = ConformerEncoder(feat_in=80, n_layers=2, d_model=32, n_heads=4, subsampling="dw_striding", subsampling_factor=8,
+                           subsampling_conv_channels=16, causal_downsampling=True, att_context_size=[8, 3],
+                           att_context_style="chunked_limited", conv_kernel_size=9, conv_context_size="causal",
+                           conv_norm_type="layer_norm", dropout=0.0, dropout_pre_encoder=0.0, dropout_emb=0.0, dropout_att=0.0)
+    enc.train()
+    run("streaming_fastconformer", enc, torch.randn(3, 80, 301, generator=torch.Generator().manual_seed(14)), torch.tensor([301, 215, 96]))
     np.savez_compressed(os.path.join(GOLD, "ref_encoder_structure.npz"), **fix)
 
 

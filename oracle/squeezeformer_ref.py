@@ -70,11 +70,15 @@ def dw_striding_forward(P: Dict[str, Tensor], mel: Tensor, mel_len: Tensor, pfx=
         _, name, stride, pad, groups = layer
         w = P[pfx + name + ".weight"]
         pointwise = stride == 1
-        x = F.conv2d(x, R._qw(w, cfg) if pointwise else w, P[pfx + name + ".bias"], stride=stride, padding=pad, groups=groups)
+        causal = (not pointwise) and getattr(cfg, "causal_downsampling", False)
+        if causal:  # CausalConv2D (causal_convs.py:24-72): pad (k - 1, stride - 1) = (2, 1) on time and frequency, conv without padding
+            x = F.conv2d(F.pad(x, (2, 1, 2, 1)), w, P[pfx + name + ".bias"], stride=stride, groups=groups)
+        else:
+            x = F.conv2d(x, R._qw(w, cfg) if pointwise else w, P[pfx + name + ".bias"], stride=stride, padding=pad, groups=groups)
         if groups > 1:
             x = R._q(x, cfg)  # the depthwise output is the bf16 A operand of the pointwise GEMM
         if stride != 1:
-            cur = torch.div(cur + 2 * pad - 3, stride, rounding_mode="floor") + 1  # calculate_conv_output_size
+            cur = torch.div(cur + (3 if causal else 2 * pad) - 3, stride, rounding_mode="floor") + 1  # calculate_conv_output_size
             m = mask(x, cur)
     x = x * m
     b, c, t, f = x.shape

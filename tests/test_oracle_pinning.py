@@ -248,7 +248,7 @@ def test_packed_token_restatement_reproduces_the_padded_reference_path(golden_di
         assert (g0[k] - g1[k]).abs().max().item() <= 1e-3 * scale + 1e-5, k
 
 
-@pytest.mark.parametrize("case", ["feat_out", "bypass", "sd_uniform", "sd_linear"])
+@pytest.mark.parametrize("case", ["feat_out", "bypass", "sd_uniform", "sd_linear", "causal_striding", "streaming_fastconformer"])
 def test_encoder_structure_restatements_match_the_reference_fixture(golden_dir, case):
     """what the reference's own encoder tests exercise (tests/collections/asr/test_conformer_encoder.py:24-199: stochastic depth,
     bypass_pre_encode with feat_out and a LayerNorm conv module), as VALUES: oracle/conformer_ref.py against the reference's
@@ -264,14 +264,23 @@ def test_encoder_structure_restatements_match_the_reference_fixture(golden_dir, 
         cfg = R.ConformerCfg(d_model=32, n_heads=4, n_layers=2, conv_kernel=9, feat_out=24, **common)
     elif case == "bypass":
         cfg = R.ConformerCfg(feat_in=10, d_model=16, n_heads=4, n_layers=3, conv_kernel=3, feat_out=8, conv_norm_type="layer_norm", **common)
+    elif case == "causal_striding":   # CausalConv2D in the 'striding' x4 stack: 80 -> 41 -> 21 frequency bins, T -> T // 2 + 1 twice
+        cfg = R.ConformerCfg(d_model=32, n_heads=4, n_layers=2, conv_kernel=9, causal_downsampling=True, **common)
+    elif case == "streaming_fastconformer":  # the cache-aware streaming recipe's encoder section, scaled down
+        cfg = R.ConformerCfg(d_model=32, n_heads=4, n_layers=2, conv_kernel=9, causal_downsampling=True, att_context_size=(8, 3),
+                             att_context_style="chunked_limited", conv_context_size=(8, 0), conv_norm_type="layer_norm", **common)
     else:
         cfg = R.ConformerCfg(d_model=32, n_heads=4, n_layers=4, conv_kernel=9, stochastic_depth_drop_prob=0.6,
                              stochastic_depth_mode=case[3:], **common)
         assert np.allclose(R.layer_drop_probs(cfg), z[f"{case}/probs"])
         torch.manual_seed(int(z[f"{case}/seed"]))
     dropped = []
-    y, ylen = R.encoder_forward(P, cfg, torch.from_numpy(z[f"{case}/x"]), torch.from_numpy(z[f"{case}/len"]), train=True,
-                                bypass_pre_encode=(case == "bypass"), dropped=dropped)
+    if case == "streaming_fastconformer":
+        from oracle import fastconformer_ref as FC
+        y, ylen = FC.encoder_forward(P, cfg, torch.from_numpy(z[f"{case}/x"]), torch.from_numpy(z[f"{case}/len"]), bn_training=True)
+    else:
+        y, ylen = R.encoder_forward(P, cfg, torch.from_numpy(z[f"{case}/x"]), torch.from_numpy(z[f"{case}/len"]), train=True,
+                                    bypass_pre_encode=(case == "bypass"), dropped=dropped)
     assert np.array_equal(ylen.numpy(), z[f"{case}/ylen"])
     assert np.allclose(y.detach().numpy(), z[f"{case}/y"], atol=3e-5), np.abs(y.detach().numpy() - z[f"{case}/y"]).max()
     if case.startswith("sd_"):
