@@ -66,6 +66,9 @@ class ConformerCfg:
     stochastic_depth_drop_prob: float = 0.0         # layers dropped at random in training (conformer_encoder.py:696-707, arXiv 2102.03216)
     stochastic_depth_mode: str = "linear"
     stochastic_depth_start_layer: int = 1
+    self_attention_model: str = "rel_pos"           # "rel_pos" | "rel_pos_local_attn" (Longformer-style sliding window with the
+                                                    # relative-position term inside the window, multi_head_attention.py:357-586; the
+                                                    # long-form recipes: conf/fastconformer/long_fastconformer/*.yaml, window [128, 128])
     causal_downsampling: bool = False               # CausalConv2D in the sub-sampling: pad (k - 1, stride - 1) on time AND frequency,
                                                     # no symmetric padding (causal_convs.py:24-72, subsampling.py:147-149, 222-224)
 
@@ -344,6 +347,44 @@ def rel_pos_attention(P, pfx, cfg: ConformerCfg, x: Tensor, pos_emb: Tensor, val
     return F.linear(ctx, _qw(P[pfx + "linear_out.weight"], cfg), P[pfx + "linear_out.bias"])
 
 
+def rel_pos_local_attention(P, pfx, cfg: ConformerCfg, x: Tensor, valid: Tensor, train: bool):
+    """RelPositionMultiHeadAttentionLongformer.forward without global tokens (multi_head_attention.py:419-586), as the dense banded
+    attention its overlapping-chunk arithmetic computes: query i sees keys j with |j - i| <= w, inside the sequence and not padded;
+    score = ((q_i + u) . k_j + (q_i + v) . p_{j-i+w}) / sqrt(d_k) with p = linear_pos(pe), pe = sinusoid of the relative positions
+    w ... -w (LocalAttRelPositionalEncoding :1103-1148: index t <-> position w - t = i - j); softmax over the window; rows of padded
+    queries are zeroed (:542) -- their output is the bias of linear_out.  The reference adds the positional term diagonal by diagonal
+    (:466-471) in a way that is only consistent for left == right, which is what the recipes use; other windows are refused here."""
+    B, T, d = x.shape
+    H, dk = cfg.n_heads, cfg.d_k
+    left, right = cfg.att_context_size
+    if left != right or left <= 0:
+        raise ValueError("rel_pos_local_attn: att_context_size = [w, w] with w > 0")
+    w = left
+    lin = lambda name, t: F.linear(t, _qw(P[pfx + name + ".weight"], cfg), P[pfx + name + ".bias"])
+    q = lin("linear_q", x).view(B, T, H, dk).transpose(1, 2)
+    k = lin("linear_k", x).view(B, T, H, dk).transpose(1, 2)
+    v = lin("linear_v", x).view(B, T, H, dk).transpose(1, 2)
+    pe = rel_pos_table(w + 1, d).to(x.dtype)                                                  # positions w ... -w
+    p = F.linear(pe, _qw(P[pfx + "linear_pos.weight"], cfg)).view(2 * w + 1, H, dk).transpose(0, 1)   # [H, 2w+1, dk]
+    qu = q + P[pfx + "pos_bias_u"].unsqueeze(1)
+    qv = q + P[pfx + "pos_bias_v"].unsqueeze(1)
+    ac = torch.matmul(qu, k.transpose(-2, -1))                                                 # [B,H,T,T]
+    bd_band = torch.matmul(qv, p.transpose(-2, -1).unsqueeze(0))                               # [B,H,T,2w+1]: diagonal c <-> j - i = c - w
+    ii = torch.arange(T).unsqueeze(1)
+    jj = torch.arange(T).unsqueeze(0)
+    off = jj - ii
+    inside = off.abs() <= w
+    bd = bd_band[:, :, ii, (off + w).clamp(0, 2 * w)]
+    scores = (ac + bd) / math.sqrt(dk)
+    visible = inside.view(1, 1, T, T) & valid.view(B, 1, 1, T)
+    scores = scores.masked_fill(~visible, float("-inf"))
+    attn = torch.softmax(scores, dim=-1)
+    attn = torch.nan_to_num(attn, nan=0.0).masked_fill(~valid.view(B, 1, T, 1), 0.0)
+    attn = _drop(attn, cfg.dropout_att, train)
+    ctx = torch.matmul(attn, v).transpose(1, 2).reshape(B, T, d)
+    return lin("linear_out", ctx)
+
+
 def conv_module(P, pfx, cfg: ConformerCfg, x: Tensor, valid: Tensor, bn_training: bool,
                 bn_stats_out: Optional[dict] = None):
     """x [B,T,d] -> [B,T,d] (conformer_modules.py:320-350).  BN statistics over all B*T positions."""
@@ -388,7 +429,11 @@ def _ln(P, pfx, x):
 
 def conformer_layer(P, pfx, cfg: ConformerCfg, x, pos_emb, valid, train, bn_training, bn_stats_out=None):
     r = x + 0.5 * _drop(feed_forward(P, pfx + "feed_forward1.", cfg, _q(_ln(P, pfx + "norm_feed_forward1.", x), cfg), train), cfg.dropout, train)
-    r = r + _drop(rel_pos_attention(P, pfx + "self_attn.", cfg, _q(_ln(P, pfx + "norm_self_att.", r), cfg), pos_emb, valid, train), cfg.dropout, train)
+    if cfg.self_attention_model == "rel_pos_local_attn":
+        att = rel_pos_local_attention(P, pfx + "self_attn.", cfg, _q(_ln(P, pfx + "norm_self_att.", r), cfg), valid, train)
+    else:
+        att = rel_pos_attention(P, pfx + "self_attn.", cfg, _q(_ln(P, pfx + "norm_self_att.", r), cfg), pos_emb, valid, train)
+    r = r + _drop(att, cfg.dropout, train)
     r = r + _drop(conv_module(P, pfx + "conv.", cfg, _q(_ln(P, pfx + "norm_conv.", r), cfg), valid, bn_training, bn_stats_out), cfg.dropout, train)
     r = r + 0.5 * _drop(feed_forward(P, pfx + "feed_forward2.", cfg, _q(_ln(P, pfx + "norm_feed_forward2.", r), cfg), train), cfg.dropout, train)
     return _ln(P, pfx + "norm_out.", r)

@@ -561,6 +561,12 @@ def make_encoder_structure_fixture():
     fix = {}
 
     def run(name, enc, x, n, seed=None, pname=None, **fw):
+        # inputs and parameters are rounded to fp16-representable values BEFORE the reference runs and stored as float16 (exact):
+        # half the bytes in tests/golden; outputs, probes and gradients stay float32
+        x = x.half().float()
+        with torch.no_grad():
+            for t in list(enc.parameters()) + [b for k_, b in enc.named_buffers() if "pos_enc" not in k_ and b.is_floating_point()]:
+                t.copy_(t.half().float())
         g = torch.Generator().manual_seed(99)
         probe = None
         if seed is not None:
@@ -569,11 +575,11 @@ def make_encoder_structure_fixture():
         probe = torch.randn(y.shape, generator=g)
         enc.zero_grad()
         (y * probe).sum().backward()
-        fix[f"{name}/x"], fix[f"{name}/len"] = x.numpy(), n.numpy()
+        fix[f"{name}/x"], fix[f"{name}/len"] = x.numpy().astype(np.float16), n.numpy()
         fix[f"{name}/y"], fix[f"{name}/ylen"], fix[f"{name}/probe"] = y.detach().numpy(), yl.numpy(), probe.numpy()
         for k, v in enc.state_dict().items():
             if "pos_enc" not in k:  # (the 5000-position sinusoid table is a buffer, not a parameter)
-                fix[f"{pname or name}/P/{k}"] = v.numpy().copy()
+                fix[f"{pname or name}/P/{k}"] = v.numpy().astype(np.float16) if v.is_floating_point() else v.numpy().copy()
         for k, p_ in enc.named_parameters():
             if k.startswith(("layers.0.", "out_proj", "pre_encode.conv.0", "layers.3.feed_forward2")) and p_.grad is not None:
                 fix[f"{name}/grad/{k}"] = p_.grad.numpy().copy()  # (bypass_pre_encode leaves the sub-sampling without gradients)
@@ -618,6 +624,13 @@ def make_encoder_structure_fixture():
                            conv_norm_type="layer_norm", dropout=0.0, dropout_pre_encoder=0.0, dropout_emb=0.0, dropout_att=0.0)
     enc.train()
     run("streaming_fastconformer", enc, torch.randn(3, 80, 301, generator=torch.Generator().manual_seed(14)), torch.tensor([301, 215, 96]))
+    # (5) Longformer-style local attention with the relative-position term inside the window (conf/fastconformer/long_fastconformer):
+    # window [6, 6] on ragged lengths -- a sequence shorter than the window, one that is not a multiple of 2w, padded queries
+    torch.manual_seed(15)
+    enc = ConformerEncoder(feat_in=80, n_layers=2, d_model=32, n_heads=4, conv_kernel_size=9, self_attention_model="rel_pos_local_attn",
+                           att_context_size=[6, 6], dropout=0.0, dropout_pre_encoder=0.0, dropout_emb=0.0, dropout_att=0.0)
+    enc.train()
+    run("local_attn", enc, torch.randn(3, 80, 165, generator=torch.Generator().manual_seed(16)), torch.tensor([165, 90, 17]))
     np.savez_compressed(os.path.join(GOLD, "ref_encoder_structure.npz"), **fix)
 
 

@@ -248,7 +248,8 @@ def test_packed_token_restatement_reproduces_the_padded_reference_path(golden_di
         assert (g0[k] - g1[k]).abs().max().item() <= 1e-3 * scale + 1e-5, k
 
 
-@pytest.mark.parametrize("case", ["feat_out", "bypass", "sd_uniform", "sd_linear", "causal_striding", "streaming_fastconformer"])
+@pytest.mark.parametrize("case", ["feat_out", "bypass", "sd_uniform", "sd_linear", "causal_striding", "streaming_fastconformer",
+                                  "local_attn"])
 def test_encoder_structure_restatements_match_the_reference_fixture(golden_dir, case):
     """what the reference's own encoder tests exercise (tests/collections/asr/test_conformer_encoder.py:24-199: stochastic depth,
     bypass_pre_encode with feat_out and a LayerNorm conv module), as VALUES: oracle/conformer_ref.py against the reference's
@@ -256,7 +257,8 @@ def test_encoder_structure_restatements_match_the_reference_fixture(golden_dir, 
     probe; stochastic depth draws its decisions from torch's global generator at the same points as the reference"""
     z = np.load(os.path.join(golden_dir, "ref_encoder_structure.npz"))
     pname = "sd" if case.startswith("sd_") else case
-    P = {k[len(pname) + 3:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith(pname + "/P/")}
+    f32 = lambda a: torch.from_numpy(a.astype(np.float32) if a.dtype == np.float16 else a)  # (fp16-representable values, stored as fp16)
+    P = {k[len(pname) + 3:]: f32(z[k]).clone() for k in z.files if k.startswith(pname + "/P/")}
     for k in R.trainable_keys(P):
         P[k].requires_grad_(True)
     common = dict(vocab=16, dropout=0, dropout_att=0, dropout_pre_encoder=0)
@@ -266,6 +268,9 @@ def test_encoder_structure_restatements_match_the_reference_fixture(golden_dir, 
         cfg = R.ConformerCfg(feat_in=10, d_model=16, n_heads=4, n_layers=3, conv_kernel=3, feat_out=8, conv_norm_type="layer_norm", **common)
     elif case == "causal_striding":   # CausalConv2D in the 'striding' x4 stack: 80 -> 41 -> 21 frequency bins, T -> T // 2 + 1 twice
         cfg = R.ConformerCfg(d_model=32, n_heads=4, n_layers=2, conv_kernel=9, causal_downsampling=True, **common)
+    elif case == "local_attn":   # sliding-window attention [6, 6]: T' = 42 / 23 / 5 valid frames (shorter than the window, not a multiple of 2w)
+        cfg = R.ConformerCfg(d_model=32, n_heads=4, n_layers=2, conv_kernel=9, self_attention_model="rel_pos_local_attn",
+                             att_context_size=(6, 6), **common)
     elif case == "streaming_fastconformer":  # the cache-aware streaming recipe's encoder section, scaled down
         cfg = R.ConformerCfg(d_model=32, n_heads=4, n_layers=2, conv_kernel=9, causal_downsampling=True, att_context_size=(8, 3),
                              att_context_style="chunked_limited", conv_context_size=(8, 0), conv_norm_type="layer_norm", **common)
@@ -277,9 +282,9 @@ def test_encoder_structure_restatements_match_the_reference_fixture(golden_dir, 
     dropped = []
     if case == "streaming_fastconformer":
         from oracle import fastconformer_ref as FC
-        y, ylen = FC.encoder_forward(P, cfg, torch.from_numpy(z[f"{case}/x"]), torch.from_numpy(z[f"{case}/len"]), bn_training=True)
+        y, ylen = FC.encoder_forward(P, cfg, f32(z[f"{case}/x"]), torch.from_numpy(z[f"{case}/len"]), bn_training=True)
     else:
-        y, ylen = R.encoder_forward(P, cfg, torch.from_numpy(z[f"{case}/x"]), torch.from_numpy(z[f"{case}/len"]), train=True,
+        y, ylen = R.encoder_forward(P, cfg, f32(z[f"{case}/x"]), torch.from_numpy(z[f"{case}/len"]), train=True,
                                     bypass_pre_encode=(case == "bypass"), dropped=dropped)
     assert np.array_equal(ylen.numpy(), z[f"{case}/ylen"])
     assert np.allclose(y.detach().numpy(), z[f"{case}/y"], atol=3e-5), np.abs(y.detach().numpy() - z[f"{case}/y"]).max()
