@@ -54,6 +54,7 @@ class EncDecCTCModel(nn.Module):
                             reduction=cfg.get("ctc_reduction", "mean_batch"))
         sa = cfg.get("spec_augment")  # ctc_models.py:86-89
         self.spec_augmentation = _build("spec_augment", sa) if sa else None
+        self._check_interctc(cfg.get("interctc"))
         self._optimizer: Optional[FusedAdamW] = None
         self._scheduler: Optional[NoamAnnealing] = None
         self._syncs = None
@@ -71,6 +72,26 @@ class EncDecCTCModel(nn.Module):
         _e = os.environ.get("MI355X_OPT_IN_BACKWARD")
         self.optimizer_in_backward = None if _e is None else (_e == "1")
         self.global_step = 0
+
+    @staticmethod
+    def _check_interctc(ic):
+        """`interctc: {loss_weights: [...], apply_at_layers: [...]}` (ctc_models.py:115, parts/mixins/interctc_mixin.py:46-73).  The
+        recipes ship it empty (= off).  A non-empty section changes the training loss -- (1 - sum w) * final + sum w_l * CTC(decoder(
+        layer l output)) -- so it must never be ignored silently: the reference's own validation first (same ValueErrors), then a
+        loud NotImplementedError (the loss assembly is restated and pinned in oracle/conformer_ref.py `model_forward(interctc=...)`;
+        the MI355X backward sequencer does not inject intermediate-layer gradients yet)."""
+        if not ic:
+            return
+        weights, layers = list(ic.get("loss_weights") or []), list(ic.get("apply_at_layers") or [])
+        if 1.0 - sum(weights) <= 0.0:
+            raise ValueError("Make sure that sum of intermediate loss weights is < 1.0. Note that we don't do any normalization and "
+                             "assign remaining weight to the regular model loss. E.g., if interctc.loss_weights = [0.1, 0.3], regular "
+                             "loss will have weight of 0.6")
+        if len(layers) != len(weights):
+            raise ValueError("Length of interctc.apply_at_layers has to match interctc.loss_weights")
+        if weights:
+            raise NotImplementedError("interctc.loss_weights is set: intermediate CTC losses are not implemented by the MI355X "
+                                      "training path (leave interctc.loss_weights / apply_at_layers empty, as the recipes do)")
 
     @property
     def world_size(self) -> int:
