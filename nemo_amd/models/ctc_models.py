@@ -55,6 +55,9 @@ class EncDecCTCModel(nn.Module):
         sa = cfg.get("spec_augment")  # ctc_models.py:86-89
         self.spec_augmentation = _build("spec_augment", sa) if sa else None
         self._check_interctc(cfg.get("interctc"))
+        if cfg.get("skip_nan_grad"):
+            # modelPT.py on_after_backward: all-reduce an "is finite" flag over the ranks and zero the gradients of a step with NaN / Inf
+            raise NotImplementedError("skip_nan_grad: true is not implemented by the MI355X training path (the recipes ship it false)")
         self._optimizer: Optional[FusedAdamW] = None
         self._scheduler: Optional[NoamAnnealing] = None
         self._syncs = None
@@ -152,6 +155,9 @@ class EncDecCTCModel(nn.Module):
             if vocab is None:
                 return None
             from ..modules import WER, GreedyCTCDecoder
+            strategy = str((self._cfg.get("decoding") or {}).get("strategy", "greedy_batch"))
+            if strategy not in ("greedy", "greedy_batch"):  # ctc_decoding.py:231-236: beam / pyctcdecode / flashlight / wfst need their own decoders
+                raise NotImplementedError(f"CTC decoding strategy '{strategy}' (implemented: greedy, greedy_batch)")
             self._wer = WER(GreedyCTCDecoder(vocabulary=list(vocab)), use_cer=bool(self._cfg.get("use_cer", False)))
         return self._wer
 

@@ -96,6 +96,14 @@ def test_interctc_section_is_validated_like_the_reference_and_never_ignored(tok_
         M.EncDecCTCModelBPE(dict(cfg, interctc=dict(loss_weights=[0.3], apply_at_layers=[0, 1])))
     with pytest.raises(ValueError, match="sum of intermediate loss weights"):
         M.EncDecCTCModelBPE(dict(cfg, interctc=dict(loss_weights=[0.6, 0.5], apply_at_layers=[0, 1])))
+    # two more model-level keys that change behaviour and used to be read by nobody
+    assert cfg["skip_nan_grad"] is False
+    with pytest.raises(NotImplementedError, match="skip_nan_grad"):
+        M.EncDecCTCModelBPE(dict(cfg, skip_nan_grad=True))
+    m = M.EncDecCTCModelBPE(dict(cfg, decoding=dict(strategy="beam", beam=dict(beam_size=4))))
+    with pytest.raises(NotImplementedError, match="beam"):
+        m.wer
+    assert M.EncDecCTCModelBPE(dict(cfg, decoding=dict(strategy="greedy"))).wer is not None
 
 
 @pytest.mark.parametrize("rel,needs", [
