@@ -473,6 +473,13 @@ class EncDecCTCModel(nn.Module):
     def _setup_dataloader_from_config(self, config: Dict[str, Any]):
         from ..data import SemiSortBatchSampler
         config = dict(config)
+        # data-set kinds and augmentations this input side does not provide must not be skipped silently: they change WHAT is trained on
+        # (audio_to_text_dataset.py:215-330: tarred / concat / lhotse datasets; perturb.py `augmentor`: speed, noise, impulse, ...)
+        unsupported = [k for k in ("is_tarred", "use_lhotse", "is_concat") if config.get(k)] + \
+                      (["augmentor"] if config.get("augmentor") else [])
+        if unsupported:
+            raise NotImplementedError("data-set options not provided by the MI355X input pipeline: " + ", ".join(unsupported) +
+                                      " (manifest + wav / npy data sets: AudioToCharDataset / AudioToBPEDataset)")
         if config.get("manifest_filepath") is None:
             return None
         dataset = self._dataset_from_config(config)

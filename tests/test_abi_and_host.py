@@ -347,6 +347,11 @@ def test_bpe_model_builds_from_a_tokenizer_dir_and_carries_it_in_the_nemo_file(t
     dl = model.setup_training_data(dict(manifest_filepath=str(tmp_path / "m.json"), batch_size=1, shuffle=False))
     _, _, tok, tl = next(iter(dl))
     assert tok[0, : int(tl[0])].tolist() == model.tokenizer.text_to_ids("the frame of a token")
+    # data-set kinds / augmentations the input side does not provide are refused by name (they change what is trained on)
+    for bad in (dict(is_tarred=True), dict(use_lhotse=True), dict(is_concat=True), dict(augmentor=dict(speed=dict(prob=0.5)))):
+        with pytest.raises(NotImplementedError, match=list(bad)[0]):
+            model.setup_training_data(dict(manifest_filepath=str(tmp_path / "m.json"), batch_size=1, shuffle=False, **bad))
+    model.setup_training_data(dict(manifest_filepath=str(tmp_path / "m.json"), batch_size=1, shuffle=False, is_tarred=False, augmentor=None))
     # .nemo: three members, the tokenizer among them under a content-hash name; restore resolves it again
     path = str(tmp_path / "bpe.nemo")
     model.save_to(path)
