@@ -58,6 +58,14 @@ class EncDecRNNTModel(EncDecCTCModel):
         self.decoder = _build("decoder", dec)
         self.joint = _build("joint", jnt)
         lc = dict(cfg.get("loss") or {})
+        if lc.get("loss_name", "default") not in ("default", "warprnnt_numba"):
+            # losses/rnnt.py:41-100 RNNT_LOSS_RESOLVER: tdt / multiblank / pytorch / graph losses are different objectives
+            raise NotImplementedError(f"transducer loss '{lc.get('loss_name')}' (implemented: default = warprnnt_numba semantics)")
+        if cfg.get("aux_ctc"):
+            raise NotImplementedError("aux_ctc (EncDecHybridRNNTCTCModel's auxiliary CTC head) is not part of EncDecRNNTModel")
+        self._check_interctc(cfg.get("interctc"))
+        if cfg.get("skip_nan_grad"):
+            raise NotImplementedError("skip_nan_grad: true is not implemented by the MI355X training path (the recipes ship it false)")
         kw = dict(lc.get("warprnnt_numba_kwargs") or {})
         self.loss = RNNTLoss(blank=n_cls, reduction=cfg.get("rnnt_reduction", "mean_batch"),
                              fastemit_lambda=kw.get("fastemit_lambda", 0.0), clamp=kw.get("clamp", -1.0))
