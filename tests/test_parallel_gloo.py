@@ -315,3 +315,14 @@ def test_mailbox_creation_is_all_or_nothing_across_ranks_world2_gloo():
     ret = mp.Manager().dict()
     mp.spawn(_worker_mailbox_agreement, args=(2, port, ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def test_bucketed_exchange_tail_cut_and_bf16_wire_world4_gloo():
+    """the same bookkeeping with FOUR ranks (the scaling runs use 2, 4 and 8): bucket merge order, the early tail cut, sums over
+    four contributions, the 1 / world factor, and the bf16 wire's pre-scale by 1 / 4"""
+    world = 4
+    mgr = mp.Manager()
+    for worker in (_worker, _worker_tail, _worker_bf16_wire):
+        ret = mgr.dict()
+        mp.spawn(worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert dict(ret) == {r: True for r in range(world)}, worker.__name__
