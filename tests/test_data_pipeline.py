@@ -279,3 +279,35 @@ def test_duration_bucket_sampler_follows_the_reference_bucketing_semantics():
         DurationBucketBatchSampler(0, 1, durs, 4, nb, 5.0, 30.0, bucketing_batch_size=8)
     with pytest.raises(ValueError, match="is not supported"):
         DurationBucketBatchSampler(0, 1, durs, 4, nb, bucketing_strategy="sorted")
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_batch_samplers_give_every_rank_the_same_number_of_batches(world):
+    """what keeps a data-parallel epoch from dead-locking: every rank must run the SAME number of steps (each step holds collectives),
+    whatever the data-set size; and the ranks' shards must tile the data set -- SemiSortBatchSampler with the synced generator covers
+    every utterance (a few repeated to even out the ranks, like torch's DistributedSampler), the duration-bucket sampler hands out
+    no utterance twice.  (asr_batching.py:27-240; audio_to_text_dataset.py:961-1000)"""
+    from nemo_amd.data import DurationBucketBatchSampler, SemiSortBatchSampler
+    rng = np.random.default_rng(world)
+    for n in (97, 640, 1001):
+        dur = rng.uniform(5, 30, size=n).tolist()
+        for drop_last in (False, True):
+            per_rank = []
+            for r in range(world):
+                s = SemiSortBatchSampler(global_rank=r, world_size=world, durations=dur, batch_size=4, batch_shuffle=True,
+                                         drop_last=drop_last, randomization_factor=0.1, seed=42, synced_rng=True)
+                b = list(iter(s))
+                assert len(b) == len(s)
+                per_rank.append(b)
+            assert len({len(b) for b in per_rank}) == 1, (n, drop_last, [len(b) for b in per_rank])
+            flat = [i for b in per_rank for x in b for i in x]
+            assert len(set(flat)) >= n - (4 * world if drop_last else 0)          # every utterance (minus at most one dropped round)
+            assert len(flat) - len(set(flat)) <= 4 * world                         # repeats only to even out the last round
+            per_rank = []
+            for r in range(world):
+                s = DurationBucketBatchSampler(global_rank=r, world_size=world, durations=dur, batch_size=4, buckets_num=4, seed=1,
+                                               drop_last=drop_last)
+                per_rank.append(list(iter(s)))
+            assert len({len(b) for b in per_rank}) == 1
+            flat = [i for b in per_rank for x in b for i in x]
+            assert len(flat) == len(set(flat))
