@@ -143,15 +143,20 @@ def log_mel_features(
     win: int = 400,
     preemph: float = 0.97,
     n_mels: int = 80,
-    normalize: bool = True,
+    normalize=True,
     noise: Optional[Tensor] = None,
     dither: float = 0.0,
+    pad_to: int = 0,
+    pad_value: float = 0.0,
 ) -> Tuple[Tensor, Tensor]:
     """audio [B,S] f32, audio_len [B] -> (features [B,n_mels,T] with T = 1 + S//hop, seq_len [B]).
 
     Explicit framing + rfft instead of torch.stft, so the framing semantics (centre zero-pad n_fft//2,
     window zero-padded *centred* to n_fft, one-sided, unnormalised) are restated, not inherited.
-    `noise` (same shape as audio) is the dither sample (features.py:435-436) when dither > 0."""
+    `noise` (same shape as audio) is the dither sample (features.py:435-436) when dither > 0.
+    `normalize`: True / "per_feature" (the Conformer recipes), "all_features" (one mean / std per utterance over all valid cells,
+    features.py:94-102), False / None / any other string such as the streaming recipes' "NA" (no normalisation, :111-112);
+    `pad_to` > 0 pads the frame axis to a multiple of it with `pad_value` (:490-501)."""
     B, S = audio.shape
     x = audio.to(torch.float32)
     if dither > 0 and noise is not None:
@@ -178,14 +183,20 @@ def log_mel_features(
     mel = torch.matmul(power, fbt.t()).transpose(1, 2)  # [B, n_mels, T]
     feat = torch.log(mel + LOG_GUARD)
     tmask = (torch.arange(T).unsqueeze(0) < seq_len.unsqueeze(1)).unsqueeze(1)  # [B,1,T]
-    if normalize:
+    if normalize == "all_features":
+        for b in range(B):
+            v = feat[b, :, : int(seq_len[b])]
+            feat[b] = (feat[b] - v.mean()) / (v.std() + STD_EPS)
+    elif normalize is True or normalize == "per_feature":
         n = seq_len.to(torch.float32).view(B, 1)
         mean = torch.where(tmask, feat, torch.zeros_like(feat)).sum(2) / n
         var = (torch.where(tmask, feat - mean.unsqueeze(2), torch.zeros_like(feat)) ** 2).sum(2) / (n - 1.0)
         std = torch.sqrt(var)
         std = torch.where(torch.isnan(std), torch.zeros_like(std), std) + STD_EPS
         feat = (feat - mean.unsqueeze(2)) / std.unsqueeze(2)
-    feat = torch.where(tmask, feat, torch.zeros_like(feat))
+    feat = torch.where(tmask, feat, torch.full_like(feat, pad_value))
+    if pad_to > 0 and feat.shape[-1] % pad_to:
+        feat = F.pad(feat, (0, pad_to - feat.shape[-1] % pad_to), value=pad_value)
     return feat, seq_len
 
 

@@ -327,6 +327,27 @@ def test_stochastic_depth_drop_probabilities_follow_the_reference_rules():
 
 
 @pytest.mark.reference
+@pytest.mark.parametrize("normalize,pad_to,pad_value", [("per_feature", 16, 0.0), ("all_features", 0, 0.0), ("NA", 16, -1.5),
+                                                         ("per_feature", 0, 0.0)])
+def test_front_end_options_match_the_live_reference(normalize, pad_to, pad_value):
+    """FilterbankFeatures with the normalisation / padding options of the neighbouring recipes (the streaming recipes: normalize "NA";
+    `pad_to: 16` is the class default): oracle/conformer_ref.py log_mel_features against the reference class run through the shim"""
+    from oracle import ref_shim
+    if not ref_shim.reference_available():
+        pytest.skip("reference tree not present (GPU box): the committed fixtures cover the default options")
+    FilterbankFeatures, _ = ref_shim.load_reference()
+    f = FilterbankFeatures(sample_rate=16000, n_window_size=400, n_window_stride=160, nfilt=80, n_fft=512, dither=0.0, pad_to=pad_to,
+                           normalize=normalize, pad_value=pad_value)
+    f.eval()
+    audio, _, _, _ = R.synthetic_batch(3, 1.3, vocab=16, seed=77)
+    alen = torch.tensor([20800, 16000 + 77, 9999])
+    want, want_len = f(audio.clone(), alen)
+    got, got_len = R.log_mel_features(audio, alen, normalize=normalize, pad_to=pad_to, pad_value=pad_value)
+    assert torch.equal(want_len, got_len) and want.shape == got.shape
+    assert (want - got).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.reference
 def test_restatement_matches_live_reference():
     from oracle import ref_shim
 
