@@ -4,7 +4,8 @@ cycles, VALU / transcendental / packed-convert counts with their issue cycles, L
 and every s_waitcnt.  One wave issues one instruction per ~4 cycles (wave64 on a 16-lane SIMD; transcendentals 8-16), a 32x32x16 bf16
 MFMA occupies the SIMD's matrix pipe for 32 cycles (16 for 16x16x32): comparing the two columns says whether a loop can be MFMA-bound
 at all, and by how much the other streams exceed it.
-    python tools/loop_mix.py nemo_amd/csrc/attention.hip relpos_flash_fwd_kernel [relpos_flash_bwd_dq_kernel ...]"""
+    python tools/loop_mix.py nemo_amd/csrc/attention.hip relpos_flash_fwd_kernel [relpos_flash_bwd_dq_kernel ...]
+LOOP_MIX_FLAGS="-fno-slp-vectorize" adds compiler flags (what-if runs), LOOP_MIX_HIST=0 drops the opcode histograms."""
 import os
 import re
 import subprocess
@@ -19,8 +20,8 @@ def asm_of(src):
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
         subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-S", "--cuda-device-only", "-I",
-                        os.path.join(ROOT, "include"), "-I", os.path.dirname(os.path.abspath(src)), src, "-o", out], check=True,
-                       stderr=subprocess.DEVNULL)
+                        os.path.join(ROOT, "include"), "-I", os.path.dirname(os.path.abspath(src))] +
+                       os.environ.get("LOOP_MIX_FLAGS", "").split() + [src, "-o", out], check=True, stderr=subprocess.DEVNULL)
         return open(out).read()
 
 
