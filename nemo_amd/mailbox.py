@@ -31,8 +31,11 @@ class StatsMailbox:
 
     # ------------------------------------------------------------------ construction (collective)
     @classmethod
-    def create(cls, device, group=None, n_max: int = 8193, timeout_ms: int = 2000) -> Optional["StatsMailbox"]:
-        """Collective over `group`: every rank calls it at the same point.  Returns a mailbox on every rank or None on every rank."""
+    def create(cls, device, group=None, n_max: int = 8193, timeout_ms: int = 10000) -> Optional["StatsMailbox"]:
+        """Collective over `group`: every rank calls it at the same point.  Returns a mailbox on every rank or None on every rank.
+        `timeout_ms`: how long an exchange waits for a peer's flag before it latches the error word (10 s: far beyond any skew between
+        healthy ranks -- two processes time-sliced on ONE GPU in the rehearsals hand over in ~0.3 s, profiles/r4_mailbox.md -- and far
+        below a collective watchdog)."""
         if not (dist.is_available() and dist.is_initialized()):
             return None
         world, rank = dist.get_world_size(group), dist.get_rank(group)

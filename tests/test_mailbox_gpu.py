@@ -23,7 +23,7 @@ def _worker(rank, world, port, out_dir):
         torch.cuda.set_device(0)
         dev = torch.device("cuda:0")
         from nemo_amd.mailbox import StatsMailbox
-        mb = StatsMailbox.create(dev, n_max=8193, timeout_ms=4000)
+        mb = StatsMailbox.create(dev, n_max=8193, timeout_ms=10000)
         if mb is not None:
             res["available"] = True
             res["kind"] = mb.kind
