@@ -458,9 +458,13 @@ void mi355x_tape_destroy(mi355x_tape* tape);
  *                           mem_kind: 0 = the first kind of memory that can be exported (uncached, fine-grained, plain), 1 | 2 | 3 = that one.
  *   mi355x_mailbox_open     map peer `peer`'s mailbox from its handle (peer == rank: no-op)
  *   mi355x_mailbox_exchange stats (f64 [n], n <= n_max, device memory) <- sum over ranks, in place, on `stream`
- *   mi355x_mailbox_status   out3 = {exchanges completed, 0 or 1 + the rank whose flag never arrived (latched: later exchanges
- *                           return at once, results are garbage), kind of memory (1 uncached, 2 fine-grained, 3 plain)};
+ *   mi355x_mailbox_status   out3 = {exchanges completed, 0 or 1 + the rank whose flag never arrived (latched: the exchange that timed
+ *                           out and every later one return at once with `stats` set to NaN -- never the local sums -- and the
+ *                           sequence number does not advance), kind of memory (1 uncached, 2 fine-grained, 3 plain)};
  *                           blocking copy -- diagnostics and tests
+ *   mi355x_mailbox_poll     the same header WITHOUT blocking, for the training loop (once per optimizer step): enqueues a 16-byte
+ *                           copy to pinned host memory on `stream` and reports what the previous poll's copy brought back;
+ *                           out4 = {exchanges completed, latch, kind of memory, 1 if the values are new since the last call}
  * Returns 0, 1 (bad argument / a peer not opened), 2 (no memory of any kind) or 1000 + hipError_t. */
 #define MI355X_MAILBOX_HANDLE_BYTES 64
 typedef struct mi355x_mailbox mi355x_mailbox;
@@ -468,6 +472,7 @@ int mi355x_mailbox_create(int world, int rank, int n_max, int timeout_ms, int me
 int mi355x_mailbox_open(mi355x_mailbox* mb, int peer, const void* handle);
 int mi355x_mailbox_exchange(mi355x_mailbox* mb, void* stats_f64, int n, void* stream);
 int mi355x_mailbox_status(mi355x_mailbox* mb, long long* out3);
+int mi355x_mailbox_poll(mi355x_mailbox* mb, void* stream, long long* out4);
 void mi355x_mailbox_destroy(mi355x_mailbox* mb);
 
 /* Greedy CTC decoding on the device (GreedyCTCInfer._greedy_decode_logprobs, parts/submodules/ctc_greedy_decoding.py:333-361,

@@ -164,6 +164,7 @@ SIGNATURES = {
     "mi355x_mailbox_open": [vp, i32, vp],
     "mi355x_mailbox_exchange": [vp, vp, i32, vp],
     "mi355x_mailbox_status": [vp, vp],
+    "mi355x_mailbox_poll": [vp, vp, vp],
     "mi355x_mailbox_destroy": [vp],
     "mi355x_rnnt_loss_ex": [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, vp, vp, i32, i64, vp, i64, vp],
 }

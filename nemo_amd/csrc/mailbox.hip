@@ -44,13 +44,22 @@ __global__ __launch_bounds__(256) void mailbox_exchange_kernel(double* __restric
   char* self = mb.peers[mb.rank];
   unsigned long long* hdr = (unsigned long long*)self;
   __shared__ unsigned long long s_seq, s_err;
+  __shared__ int s_timed_out;
   if (threadIdx.x == 0) {
     s_seq = __hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
     s_err = __hip_atomic_load(hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_timed_out = 0;
   }
   __syncthreads();
   const unsigned long long seq = s_seq;
-  if (s_err) return;  // latched: a peer went missing earlier
+  const double poison = __longlong_as_double(0x7ff8000000000000ll);  // quiet NaN
+  if (s_err) {
+    // latched: a peer went missing earlier.  The caller must never mistake its LOCAL sums for the reduced ones (SyncBN would
+    // silently turn into per-rank BN with diverging replicas): the result is poisoned, the loss of this step is NaN on this
+    // rank, and the host-side latch check (mi355x_mailbox_poll, once per step) raises.
+    for (int i = threadIdx.x; i < n; i += 256) stats[i] = poison;
+    return;
+  }
   const int slot = (int)(seq % MB_SLOTS);
   // 1. my values into every rank's mailbox (my own included: one code path)
   for (int p = 0; p < mb.world; ++p) {
@@ -70,12 +79,19 @@ __global__ __launch_bounds__(256) void mailbox_exchange_kernel(double* __restric
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
       if (wall_clock64() - t0 > mb.timeout_ticks) {
         __hip_atomic_store(hdr + 1, 1ull + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // 1 + the rank that is missing
+        s_timed_out = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(8);
     }
   }
   __syncthreads();
+  if (s_timed_out) {
+    // a stale slot must not be summed and the sequence number must not advance (the next exchange would then pair this rank's
+    // slot with the peer's previous one): poison the result, keep `seq`, stay latched
+    for (int i = threadIdx.x; i < n; i += 256) stats[i] = poison;
+    return;
+  }
   __threadfence_system();
   // 4. rank-ordered sum
   for (int i = threadIdx.x; i < n; i += 256) {
@@ -102,6 +118,10 @@ struct mi355x_mailbox {
   char** dev_peers = nullptr;
   bool table_dirty = true;
   unsigned long long timeout_ticks = 0;
+  unsigned long long* host_hdr = nullptr;  // pinned mirror of the header for mi355x_mailbox_poll
+  unsigned long long seen[2] = {0, 0};
+  hipEvent_t poll_ev = nullptr;
+  bool poll_pending = false;
 };
 
 static size_t mb_bytes(int world, int n_max) {
@@ -200,8 +220,46 @@ extern "C" int mi355x_mailbox_status(mi355x_mailbox* mb, long long* out3) {
   return MI_OK;
 }
 
+// Non-blocking view of the header for the training loop: enqueues a 16-byte copy of (exchanges completed, latch) into pinned host
+// memory on `stream` and reports what the PREVIOUS poll's copy brought back (out3[3] = 1 when that copy has landed, else the values
+// are those of the poll before).  One call per optimizer step costs one tiny async copy and one event query, never a device sync.
+extern "C" int mi355x_mailbox_poll(mi355x_mailbox* mb, void* stream, long long* out4) {
+  if (!mb || !out4) return MI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (!mb->host_hdr) {
+    MB_HIP(hipHostMalloc((void**)&mb->host_hdr, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    mb->host_hdr[0] = mb->host_hdr[1] = 0;
+    MB_HIP(hipEventCreateWithFlags(&mb->poll_ev, hipEventDisableTiming));
+  }
+  int fresh = 0;
+  if (mb->poll_pending) {
+    hipError_t q = hipEventQuery(mb->poll_ev);
+    if (q == hipSuccess) {
+      mb->seen[0] = mb->host_hdr[0]; mb->seen[1] = mb->host_hdr[1];
+      mb->poll_pending = false;
+      fresh = 1;
+    } else if (q != hipErrorNotReady) {
+      (void)hipGetLastError();
+      return 1000 + (int)q;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  if (!mb->poll_pending) {
+    MB_HIP(hipMemcpyAsync(mb->host_hdr, mb->base, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    MB_HIP(hipEventRecord(mb->poll_ev, s));
+    mb->poll_pending = true;
+  }
+  out4[0] = (long long)mb->seen[0];
+  out4[1] = (long long)mb->seen[1];
+  out4[2] = mb->alloc_kind;
+  out4[3] = fresh;
+  return MI_OK;
+}
+
 extern "C" void mi355x_mailbox_destroy(mi355x_mailbox* mb) {
   if (!mb) return;
+  if (mb->host_hdr) { (void)hipEventSynchronize(mb->poll_ev); (void)hipEventDestroy(mb->poll_ev); (void)hipHostFree(mb->host_hdr); }
   for (int r = 0; r < mb->world; ++r)
     if (mb->opened[r] && mb->peers[r]) (void)hipIpcCloseMemHandle(mb->peers[r]);
   if (mb->dev_peers) (void)hipFree(mb->dev_peers);

@@ -101,7 +101,10 @@ __global__ __launch_bounds__(RD_THREADS) void rnnt_greedy_kernel(RnntDecP p) {
   float score = 0.f;
   for (int t = 0; t < len; ++t) {
     const char* frow = (const char*)p.f + ((long long)b * p.T + t) * p.ldf * (p.f_dt == MI_DT_F32 ? 4 : 2);
-    for (int sym = 0; p.max_symbols <= 0 || sym < p.max_symbols; ++sym) {
+    // max_symbols <= 0 (the reference's `max_symbols_per_step=None`: unbounded inner loop, rnnt_greedy_decoding.py:620-700) is
+    // bounded HERE by the output budget: a model that never emits blank would otherwise keep this workgroup -- and the GPU --
+    // busy for ever.  Once max_out labels are out the search stops (out_len == max_out tells the caller it was cut short).
+    for (int sym = 0; p.max_symbols > 0 ? sym < p.max_symbols : n < p.max_out; ++sym) {
       for (int j = tid; j < J; j += RD_THREADS) {
         const float fv = p.f_dt == MI_DT_F32 ? ((const float*)frow)[j] : bf2f(((const bf16_t*)frow)[j]);
         a[j] = fmaxf(fv + gp[j], 0.f);
@@ -134,6 +137,10 @@ __global__ __launch_bounds__(RD_THREADS) void rnnt_greedy_kernel(RnntDecP p) {
         if (tid == 0) { p.tokens[(long long)b * p.max_out + n] = k; if (p.times) p.times[(long long)b * p.max_out + n] = t; }
       }
       ++n;
+      // Score semantics: the sum of the emitted labels' LOG-PROBABILITIES (log-softmax of the joint's logits) -- what the
+      // reference's search computes on CPU tensors.  On CUDA tensors its `_joint_step(log_normalize=None)` skips the
+      // log-softmax and sums raw maximum logits instead (rnnt_greedy_decoding.py:257-259, 965): scores then differ by the
+      // summed log-partition terms; the token ids, time stamps and lengths are the same either way.
       score += -logf(se);   // log-prob of the arg-max label = mv - (mv + log se)
       // commit the state that consumed the previous label, consume the new one
       for (int i = tid; i < H; i += RD_THREADS) { h[i] = hn[i]; c[i] = cn[i]; x[i] = p.emb[(long long)k * H + i]; }

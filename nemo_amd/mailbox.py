@@ -44,7 +44,22 @@ class StatsMailbox:
         device = torch.device(device)
         on_host = dist.get_backend(group) == "gloo"  # (gloo carries host tensors; RCCL carries device tensors)
         have_gpu = device.type == "cuda" and torch.cuda.is_available()
-        for mem_kind in (0, 3):  # first try: the best exportable kind of memory per rank; second: plain device memory everywhere
+        # Do all ranks sit on ONE physical device (the two-ranks-on-one-GPU rehearsals)?  Only then may the second attempt fall
+        # back to plain coarse-grained hipMalloc memory: across devices a peer's xGMI stores into coarse-grained memory are not
+        # guaranteed visible to a kernel already running against its XCD's L2, whatever the scope of the atomics.
+        uuid = [0] * 16
+        if have_gpu:
+            try:
+                uuid = list(torch.cuda.get_device_properties(device).uuid.bytes)
+            except Exception:  # noqa: BLE001 -- no uuid on this build: treat every rank as its own device
+                uuid = [rank + 1] * 16
+        mine_u = torch.tensor(uuid, dtype=torch.int32)
+        if not on_host:
+            mine_u = mine_u.to(device)
+        all_u = [torch.empty_like(mine_u) for _ in range(world)]
+        dist.all_gather(all_u, mine_u, group=group)
+        one_device = all(torch.equal(u.cpu(), all_u[0].cpu()) for u in all_u)
+        for mem_kind in ((0, 3) if one_device else (0,)):  # first: the best exportable kind per rank; second (one device only): plain memory
             mb = C.c_void_p()
             handle = (C.c_ubyte * HANDLE_BYTES)()
             rc = -1  # (a rank without a GPU still takes part in the agreement below, so that every rank gets the same answer)
@@ -90,6 +105,18 @@ class StatsMailbox:
                                                torch.cuda.current_stream(stats.device).cuda_stream), "mi355x_mailbox_exchange")
         self.exchanges += 1
         return stats
+
+    def poll(self, stream=None):
+        """non-blocking latch check for the training loop (once per step): raises as soon as a previous exchange is known to
+        have timed out on this rank (the result of that exchange is NaN by construction, csrc/mailbox.hip)"""
+        st = (C.c_longlong * 4)()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        _lib.check(lib.mi355x_mailbox_poll(self._mb, s.cuda_stream, st), "mi355x_mailbox_poll")
+        if int(st[1]):
+            raise RuntimeError(f"StatsMailbox: rank {int(st[1]) - 1} never arrived at a SyncBatchNorm exchange within the time-out "
+                               f"(after {int(st[0])} completed exchanges); this rank's statistics of that step are NaN. "
+                               "Restart the job (or run without MI355X_SYNCBN_MAILBOX to stay on the process group).")
+        return int(st[0])
 
     def status(self):
         """(exchanges completed on the device, 0 or 1 + the rank that never arrived, memory kind) -- blocks"""

@@ -420,6 +420,9 @@ class EncDecCTCModel(nn.Module):
         if self._scheduler is not None:
             self._scheduler.step()
         self.global_step += 1
+        mb = getattr(self.encoder, "_syncbn_mailbox", None)
+        if mb is not None:
+            mb.poll()  # non-blocking: raises once a SyncBatchNorm exchange of an earlier step is known to have timed out
         return out
 
     def _after_backward(self):

@@ -775,13 +775,24 @@ class ConformerEncoder(NeuralModule):
             ops.wgrad_grouped(pend, rows, sk)
         self._wg_pending, self._wg_rows = [], None
 
-    def _wgrad_join(self):
+    def _wgrad_join(self, consume=False):
+        """consume=True: the MAIN chain itself reads, right after this call, something the side stream produced"""
         if self._capture is not None:
             # recording: a capturing stream may only wait for work of its own capture.  The side stream is joined if (and only
-            # if) this segment forked it; an un-forked side stream holds nothing the recorded sequence depends on.
+            # if) this segment forked it; an un-forked side stream holds nothing THIS SEGMENT depends on.
             if not self._wg_forked:
+                # ... but an EARLIER segment may have left work on it: a cut re-joins the side stream for the capture's sake
+                # (before_cut) and clears the fork flag, while a launch tape replayed with join_between=False (the default
+                # single-GPU path: optimizer-in-backward clears _wgrad_join_per_layer) leaves those segment-end joins out.
+                # The consumer's ordering then has to be a LIVE step of the sequence: the tape's side lane IS _wg_stream.
+                if consume and self._capture.tape and not self._wgrad_join_per_layer and self._wg_stream is not None:
+                    self._capture.cut(self._live_wgrad_join)
                 return
             self._wg_forked = False
+        if self._wg_stream is not None:
+            torch.cuda.current_stream(self._wg_stream.device).wait_stream(self._wg_stream)
+
+    def _live_wgrad_join(self):
         if self._wg_stream is not None:
             torch.cuda.current_stream(self._wg_stream.device).wait_stream(self._wg_stream)
 
@@ -979,7 +990,7 @@ class ConformerEncoder(NeuralModule):
             ops.dwconv2d_s2_bwd(ddw, cur_in, dww, din, g_dww, g_dwb, B, Tc, Fc, C_)
             dcur = din
         ops.conv1_bwd(dcur, S.mel, S.len0, io.g_c0w, io.g_c0b, C_)
-        self._wgrad_join()
+        self._wgrad_join(consume=io.finish is not None)
         if io.finish is not None:
             io.finish()
         if self.grad_ready_hook is not None:
@@ -1373,7 +1384,7 @@ class ConformerEncoder(NeuralModule):
                     self._wgrad_join()
                 self._hook(*fp.range_of(f"layers.{i}."))
         self._wg_pending = None  # (the remaining weight gradients have their own shapes / layouts)
-        self._wgrad_join()       # dp_all may have been produced on the side stream
+        self._wgrad_join(consume=True)       # dp_all may have been produced on the side stream
         self._pos_proj_wgrad(S.dp_all, S.pos, P, cdt)
         if self.grad_ready_hook is not None:
             self._hook(*fp.tail_range())

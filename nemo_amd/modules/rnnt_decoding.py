@@ -9,6 +9,12 @@ Mirrors the pieces of the reference a training run touches (names, argument mean
 The reference's search is a Python loop over frames with a device -> host sync per inner iteration; here the whole batch is ONE
 launch (`mi355x_rnnt_greedy_decode`, csrc/rnnt_decode.hip): the encoder projection is a GEMM, a workgroup per utterance runs the
 LSTM / joint / arg-max recurrence out of LDS, and only the token ids leave the device -- when text is asked for.
+
+Two documented differences to the reference's search (token ids / time stamps / lengths are bit-identical to it, tests/test_rnnt_decoding.py):
+  * `Hypothesis.score` is the sum of the emitted labels' log-probabilities (the reference's CPU behaviour); on CUDA tensors the
+    reference sums raw maximum logits because `_joint_step(log_normalize=None)` skips log_softmax there (rnnt_greedy_decoding.py:257-259);
+  * `max_symbols_per_step=None` is unbounded per frame in the reference; here an utterance stops once 4 * T labels are out
+    (a model that never emits blank cannot hang the device; `out_len == 4 * T` marks the cut).
 """
 from __future__ import annotations
 

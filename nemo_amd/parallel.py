@@ -88,6 +88,14 @@ class GradSync:
         self._pending_elems += end - start
         self._seen += end - start
         left = self.grad.numel() - self._seen
+        if left < 0:
+            # more elements reported than the buffer holds: ranges arrived twice between two wait() calls (several backward
+            # passes per step, or overlapping ranges).  The exchange reduces IN PLACE as ranges arrive, so a second pass would
+            # add local gradients onto already-reduced ones, the "everything has arrived" shortcut below would fire on every
+            # later range (one tiny all-reduce per layer) and after_reduce would step the optimizer on partial gradients.
+            raise RuntimeError("GradSync.ready: ranges covering more than the gradient buffer were reported between two wait() "
+                               "calls; accumulate micro-batch gradients before reporting them (one backward per wait()), or call "
+                               "wait() after each backward")
         if self._pending_elems >= self.bucket_elems or left <= 0:
             self.flush()
         elif not self._tail_cut and 0 < left <= self.tail_elems and self._pending_elems > self.tail_elems:

@@ -96,6 +96,50 @@ def test_recorded_sequence_with_hooks_between_the_segments(replay):
     assert l_g[-1] < 0.95 * l_g[0]
 
 
+def test_tape_replay_orders_the_linear_pos_gradient_behind_a_slow_weight_gradient_lane():
+    """with the per-layer hook (optimizer behind backward) a tape is replayed with join_between=False; the
+    post-loop join in front of the linear_pos weight gradient was a no-op in the recording (the last cut had cleared the fork
+    flag), so the main lane could read dp_all while the side lane (the dpos kernels of the fused d_k = 64 path) was still
+    running.  Here the side stream is held back by a long sleep in front of every replayed step and two batches alternate, so a
+    main lane that runs ahead reads the OTHER batch's dp_all.  lr = 0: the weights never move and Adam's first moment of
+    linear_pos is a pure function of the per-step gradients."""
+    over = dict(d_model=128, n_heads=2, n_layers=2, **NODROP)
+    batches = [_batch(B=2, secs=1.0, seed=8), _batch(B=2, secs=1.0, seed=9)]
+
+    def moments(graphs):
+        torch.manual_seed(5)
+        model = _model(dict(over, compute_dtype=torch.bfloat16)).to(dev).train()
+        model.decoder.compute_dtype = torch.bfloat16
+        enc = model.encoder
+        enc.use_graphs, enc.graph_tape, enc.graph_auto = graphs, True, False
+        model.optimizer_in_backward = True
+        model.setup_optimization(dict(name="adamw", lr=0.0, betas=[0.9, 0.98], weight_decay=0.0))
+        for it in range(enc.graph_warmup + 7):
+            if graphs and enc._wg_stream is not None and it > enc.graph_warmup + 1:
+                with torch.cuda.stream(enc._wg_stream):
+                    torch.cuda._sleep(int(40e6))  # ~20 ms: far longer than the whole tiny backward
+            model.fit_step(batches[it % 2])
+        torch.cuda.synchronize()
+        assert enc.grad_ready_hook is not None and not enc._wgrad_join_per_layer
+        if graphs:
+            info = enc.graph_info()
+            assert info and info[0]["replay"] == "launch tape" and info[0]["bwd_tape"]["lanes"] >= 2, info
+        out = {}
+        for fp in model.flats():
+            m, _ = model._optimizer._moments(fp)
+            for n in fp.order:
+                if "linear_pos" in n:
+                    off, num = fp.offsets[n]
+                    out[n] = m[off: off + num].detach().clone()
+        return out
+
+    m_t, m_e = moments(True), moments(False)
+    assert m_e and set(m_t) == set(m_e)
+    for n in m_e:
+        assert float(m_e[n].norm()) > 0
+        assert (m_t[n] - m_e[n]).norm() <= 2e-2 * m_e[n].norm(), n
+
+
 @pytest.mark.parametrize("replay", REPLAYS)
 def test_each_batch_shape_gets_its_own_recording(replay):
     over = dict(d_model=64, n_heads=4, n_layers=2, **NODROP)

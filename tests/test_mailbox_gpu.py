@@ -87,6 +87,75 @@ def test_mailbox_sum_equals_the_process_group_all_reduce_bit_for_bit(tmp_path):
         assert x["bad"] == [] and x["missing"] == 0 and x["done"] == 48 + 12, x
 
 
+def _worker_timeout(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {"available": False}
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        from nemo_amd.mailbox import StatsMailbox
+        mb = StatsMailbox.create(dev, n_max=64, timeout_ms=400)
+        if mb is not None:
+            res["available"] = True
+            y = torch.full((33,), float(rank + 1), dtype=torch.float64, device=dev)
+            mb.all_reduce_(y)
+            torch.cuda.synchronize()
+            res["first"] = y.cpu().tolist()
+            assert mb.poll() == 0 or True   # first poll only enqueues its copy
+            dist.barrier()
+            if rank == 0:   # the peer never comes to this exchange
+                z = torch.full((33,), 5.0, dtype=torch.float64, device=dev)
+                t0 = time.time()
+                mb.all_reduce_(z)
+                torch.cuda.synchronize()
+                res["timeout_s"] = time.time() - t0
+                res["nan_after_timeout"] = bool(torch.isnan(z).all())
+                done, missing, _ = mb.status()
+                res["done"], res["missing"] = done, missing
+                z2 = torch.full((33,), 7.0, dtype=torch.float64, device=dev)
+                t0 = time.time()
+                mb.all_reduce_(z2)          # latched: returns at once, poisoned -- never the local sums
+                torch.cuda.synchronize()
+                res["latched_s"] = time.time() - t0
+                res["nan_when_latched"] = bool(torch.isnan(z2).all())
+                raised = None
+                for _ in range(3):          # non-blocking: the copy enqueued by one poll is read by the next
+                    try:
+                        mb.poll()
+                    except RuntimeError as e:
+                        raised = str(e)
+                        break
+                    torch.cuda.synchronize()
+                res["poll_raised"] = raised
+            else:
+                time.sleep(1.5)
+            mb.close()
+    finally:
+        with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+            json.dump(res, f)
+        dist.destroy_process_group()
+
+
+def test_a_missing_peer_poisons_the_result_and_the_step_loop_hears_about_it(tmp_path):
+    """on a peer time-out the kernel must not hand back the local sums nor advance its sequence number, and the
+    training loop has to learn about the latch without a blocking copy (StatsMailbox.poll, called once per fit_step)."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_timeout, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [json.load(open(tmp_path / f"rank{i}.json")) for i in range(2)]
+    if not all(x["available"] for x in r):
+        pytest.skip("hipIpc handles cannot be exported / mapped on this box")
+    assert r[0]["first"] == [3.0] * 33 and r[1]["first"] == [3.0] * 33
+    x = r[0]
+    assert x["nan_after_timeout"] and x["nan_when_latched"], x
+    assert x["missing"] == 2 and x["done"] == 1, x          # 1 + the rank that never arrived; the sequence did not advance
+    assert 0.3 <= x["timeout_s"] <= 5.0 and x["latched_s"] < 0.3, x
+    assert x["poll_raised"] and "rank 1 never arrived" in x["poll_raised"], x
+
+
 def test_mailbox_needs_a_process_group_and_refuses_bad_arguments():
     import ctypes as C
     from nemo_amd._lib import lib

@@ -40,6 +40,15 @@ def _worker(rank, world, port, ret):
         gs.ready(0, n)
         gs.wait()
         ok = ok and torch.equal(grad, torch.full((n,), float(sum(range(world)))))
+        # ranges covering more than the buffer between two wait() calls (a second backward pass) are refused, not silently
+        # reduced twice
+        gs.ready(0, n // 2)
+        try:
+            gs.ready(0, n)
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "between two wait()" in str(e)
+        gs.wait()
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

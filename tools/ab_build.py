@@ -2,6 +2,7 @@
 larger than most single changes):
 
     python tools/ab_build.py base= pipe=-DMI355X_EXP_V4_PIPE incr=-DMI355X_EXP_EPI_INCR both="-DMI355X_EXP_V4_PIPE -DMI355X_EXP_EPI_INCR"
+    python tools/ab_build.py base= noslp_attn=@attention:-fno-slp-vectorize      (a flag behind @<file stem>: applies to that translation unit only)
 
 writes nemo_amd/lib_ab/libmi355x_asr_<name>.so (git-ignored, travels with the gpurun snapshot); on the GPU box
 `tools/ab_run.sh` loops over them with MI355X_ASR_LIB=<variant> (parity subset, GEMM micro-benchmarks, bench.py)."""
@@ -27,7 +28,9 @@ def build_variant(name, flags):
         for src in sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")):
             o = os.path.join(tmp, src[:-4] + ".o")
             objs.append(o)
-            procs.append((src, subprocess.Popen([HIPCC] + BASE + flags + ["-c", os.path.join(CSRC, src), "-o", o],
+            mine = [f.split(":", 1)[1] if f.startswith("@") else f for f in flags
+                    if not f.startswith("@") or f[1:].split(":", 1)[0] == src[:-4]]
+            procs.append((src, subprocess.Popen([HIPCC] + BASE + mine + ["-c", os.path.join(CSRC, src), "-o", o],
                                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         for src, pr in procs:
             out, _ = pr.communicate()
