@@ -246,10 +246,19 @@ int mi355x_log_softmax_bwd(const void* dlogp, const void* logp, long long ld, vo
                            int M, int C, float scale, void* stream);
 
 /* ---- Conformer block glue (conformer_modules.py:324-331; multi_head_attention.py:259-270,305-307,343-346,137-140) */
+/* row_offsets (optional, i64 [B+1], needs len): "PACKED ROWS" (length-aware kernels that skip padded frames) --
+ * the [M, 2d] side (`in`, `din`) then holds only the valid frames of every utterance, utterance b at rows row_offsets[b] ..
+ * row_offsets[b] + len[b] - 1, while the [M, d] side (`out`, `dout`) stays the padded [B*T, d] grid the depthwise convolution and
+ * BatchNorm run on (their batch statistics include padded frames, conformer_modules.py:297,330-331).  M = B * T either way. */
 int mi355x_glu_fwd(const void* in /*[M,2d]*/, void* out /*[M,d]*/, int dtype, const void* len, int T, long long M, int d,
-                   void* stream);
+                   const void* row_offsets, void* stream);
 int mi355x_glu_bwd(const void* in, const void* dout, void* din, int dtype, const void* len, int T, long long M, int d,
-                   void* stream);
+                   const void* row_offsets, void* stream);
+/* direction 0: packed[row_offsets[b] + t, 0:width] = padded[b*T + t, 0:width] for t < len[b];
+ * direction 1: padded[b*T + t, 0:width] = t < len[b] ? packed[row_offsets[b] + t, 0:width] : 0 for every t < T.
+ * M = B * T (rows of the padded grid), ld_* = row pitches in elements, width % (16 bytes / element size) == 0, dtype bf16 or f32. */
+int mi355x_rows_pack(const void* src, void* dst, int dtype, long long ld_src, long long ld_dst, const void* len,
+                     const void* row_offsets, int T, long long M, int width, int direction, void* stream);
 int mi355x_drop_scale_cast(const void* in, int in_dtype, void* out, int out_dtype, long long n, float alpha,
                            unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream);
 int mi355x_qbias(const void* qkv, long long ldq, const void* u, const void* v, void* qu, void* qv, int dtype, long long M,
@@ -276,20 +285,26 @@ int mi355x_relpos_softmax_bwd(const void* dpd, int dpd_dtype, const void* s_in, 
  * ctx_lo (optional, same layout as ctx): the bf16 ROUNDING RESIDUAL of ctx (O = ctx + ctx_lo to ~16 mantissa bits) for
  * mi355x_attn_delta -- the reference's softmax backward works on fp32 probabilities (multi_head_attention.py:137-138 under
  * autocast), i.e. without the error a delta taken from the rounded O alone puts on nearly-cancelling score gradients.
- * Dropout index of probability (b,h,i,j) = ((h*B+b)*T + i)*Tp + j.                                                   */
+ * Dropout index of probability (b,h,i,j) = ((h*B+b)*T + i)*Tp + j.
+ * row_offsets (optional, i64 [B+1]; every fused attention entry point takes it): PACKED ROWS -- the activation matrices (qkv, ctx,
+ * ctx_lo; in backward qu, qv, dO, dqu, dqv, dq_out, dqkv) hold only the valid frames, utterance b at rows row_offsets[b] ..
+ * row_offsets[b] + len[b] - 1, instead of b*T .. b*T + T - 1.  T stays the padded length: it fixes the positional geometry
+ * (pos has 2T-1 rows) and the layout of the per-query statistics lse / delta [B,H,T] and of ds_out, which remain padded-indexed. */
 int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, long long ldp, const void* bias_u,
                             const void* bias_v, const void* len, void* ctx, void* ctx_lo, long long ldo, void* lse, int B, int H,
                             int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold, float drop_scale,
-                            void* stream);
+                            const void* row_offsets, void* stream);
 
 /* backward of the fused attention.  delta[b,h,i] = sum_dv dO*(O + O_lo) (O_lo optional, see above).  dq kernel: qu = q+u, qv = q+v ([B*T,d] bf16, from
  * mi355x_qbias), recomputes P from lse, returns dQu and dQv ([B*T,d] bf16; dq = dQu+dQv, d pos_bias_{u,v} = column sums). */
-int mi355x_attn_delta(const void* dO, const void* O, const void* O_lo, void* delta, int B, int H, int T, int d, void* stream);
+int mi355x_attn_delta(const void* dO, const void* O, const void* O_lo, void* delta, int B, int H, int T, int d, const void* len,
+                      const void* row_offsets, void* stream);
 /* mi355x_attn_delta and mi355x_qbias (q = the first d columns of qkv rows of pitch ldq; multi_head_attention.py:288-291: q + pos_bias_u,
  * q + pos_bias_v) in ONE pass over the rows: everything the fused backward kernels need in front of them.  All pointers 16-byte
  * aligned, ldq % 8 == 0. */
 int mi355x_attn_bwd_prep(const void* dO, const void* O, const void* O_lo, void* delta, const void* qkv, long long ldq,
-                         const void* bias_u, const void* bias_v, void* qu, void* qv, int B, int H, int T, int d, void* stream);
+                         const void* bias_u, const void* bias_v, void* qu, void* qv, int B, int H, int T, int d, const void* len,
+                         const void* row_offsets, void* stream);
 /* ds_out (optional): the score gradient in the layout of the reference's matrix_bd BEFORE rel_shift
  * (multi_head_attention.py:259-270), cut into 32 x 32 bf16 blocks for mi355x_relpos_flash_bwd_dpos:
  * X[h][b][it][s][q][cl] = dS[b,h, i = 32*it+q, j] at position c = T-1+j-i = T-32+32*(s-it)+cl, it < ceil(T/32), s <= ceil(T/32);
@@ -302,13 +317,13 @@ int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const void* qkv, 
                                const void* len, const void* dO, const void* lse, const void* delta, void* dqu, void* dqv,
                                void* ds_out, void* dq_out, long long ld_dq, void* bias_grads, void* cs_scratch,
                                long long cs_scratch_elems, int B, int H, int T, int dk, long long ds_elems, float scale,
-                               unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream);
+                               unsigned drop_key, unsigned drop_threshold, float drop_scale, const void* row_offsets, void* stream);
 
 /* dK and dV rows written into the k / v column blocks of dqkv [B*T, ldd = 3d] */
 int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos, long long ldp,
                                 const void* len, const void* dO, const void* lse, const void* delta, void* dqkv, long long ldd,
                                 int B, int H, int T, int dk, int Tp, float scale, unsigned drop_key, unsigned drop_threshold,
-                                float drop_scale, void* stream);
+                                float drop_scale, const void* row_offsets, void* stream);
 
 /* dpos f32 [2T-1, ldd] += gradient w.r.t. pos = linear_pos(pos_emb) (multi_head_attention.py:296-300 backward), summed over
  * the batch: dpos[c, h, :] += sum_{b,i} dS[b,h,i,c-(T-1)+i] * qv[b,i,h,:], from the blocks written by
@@ -318,7 +333,7 @@ int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const void* qkv,
 long long mi355x_relpos_dpos_partial_elems(int B, int H, int T);
 int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len, void* dpos, long long ldd, void* dpos_cast,
                                  void* partial, long long partial_elems, int B, int H, int T, int dk, long long ds_elems,
-                                 void* stream);
+                                 const void* row_offsets, void* stream);
 
 /* which depthwise-convolution kernels run (tests and A/B): 0 = the LDS-tile kernels (default: faster inside the training step),
  * 1 = the streaming kernel in the forward pass (bf16, k = 31, even d), 2 = in the backward pass too; level < 0 only queries.

@@ -107,8 +107,9 @@ SIGNATURES = {
     "mi355x_time_reduce_dwconv_bwd": [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "mi355x_time_recover_fwd": [vp, vp, vp, i32, i32, i32, vp],
     "mi355x_time_recover_bwd": [vp, vp, i32, i32, i32, i32, i32, vp],
-    "mi355x_glu_fwd": [vp, vp, i32, vp, i32, i64, i32, vp],
-    "mi355x_glu_bwd": [vp, vp, vp, i32, vp, i32, i64, i32, vp],
+    "mi355x_glu_fwd": [vp, vp, i32, vp, i32, i64, i32, vp, vp],
+    "mi355x_glu_bwd": [vp, vp, vp, i32, vp, i32, i64, i32, vp, vp],
+    "mi355x_rows_pack": [vp, vp, i32, i64, i64, vp, vp, i32, i64, i32, i32, vp],
     "mi355x_drop_scale_cast": [vp, i32, vp, i32, i64, f32, u32, u32, f32, vp],
     "mi355x_qbias": [vp, i64, vp, vp, vp, vp, i32, i64, i32, vp],
     "mi355x_add2": [vp, vp, i32, vp, i32, i64, i64, i32, vp],
@@ -117,13 +118,13 @@ SIGNATURES = {
     "mi355x_add2_colsum": [vp, vp, vp, i64, i64, i32, vp, vp, i64, vp],
     "mi355x_relpos_softmax_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_relpos_softmax_bwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
-    "mi355x_relpos_flash_fwd": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
-    "mi355x_attn_delta": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
-    "mi355x_attn_bwd_prep": [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mi355x_relpos_flash_fwd": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp, vp],
+    "mi355x_attn_delta": [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
+    "mi355x_attn_bwd_prep": [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "mi355x_relpos_flash_bwd_dq": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, i32, i32, i64,
-                                   f32, u32, u32, f32, vp],
-    "mi355x_relpos_flash_bwd_dkv": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
-    "mi355x_relpos_flash_bwd_dpos": [vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, i32, i32, i64, vp],
+                                   f32, u32, u32, f32, vp, vp],
+    "mi355x_relpos_flash_bwd_dkv": [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp, vp],
+    "mi355x_relpos_flash_bwd_dpos": [vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, i32, i32, i64, vp, vp],
     "mi355x_relpos_ds_elems": [i32, i32, i32],
     "mi355x_relpos_dpos_partial_elems": [i32, i32, i32],
     "mi355x_dwconv_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp],

@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
                                                                   const long long* __restrict__ len, bf16_t* __restrict__ ctx,
                                                                   bf16_t* __restrict__ ctx_lo, long long ldo,
                                                                   float* __restrict__ lse, int B, int H, int T,
-                                                                  int Tp, float scale, DropCfg drop) {
+                                                                  int Tp, float scale, DropCfg drop,
+                                                                  const long long* __restrict__ cu) {
   drop_resolve(drop);
   __shared__ __attribute__((aligned(16))) bf16_t s_k2[2][ABK * ADK];   // 2 x 4 KiB (double-buffered)
   __shared__ __attribute__((aligned(16))) bf16_t s_v2[2][ABK * ADK];   // 2 x 4 KiB
@@ -189,15 +190,20 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
   const int L = (int)min((long long)T, len[b]);
   const bool qvalid = i < L;
   const int P = 2 * T - 1;
+  // PACKED rows (cu != nullptr): the activation matrices hold only the valid frames of every utterance, utterance b at
+  // rows cu[b] .. cu[b] + L - 1; T stays the padded length (it fixes the positional geometry and the [B, H, T] statistics).
+  const long long row0 = cu ? cu[b] : (long long)b * T;
+  const int Tr = cu ? L : T;                  // rows of this utterance that exist
+  const int Trc = Tr > 0 ? Tr - 1 : 0;        // the row index loads are clamped to
 
-  const bf16_t* qbase = qkv + ((long long)b * T) * ldq + h * ADK;
+  const bf16_t* qbase = qkv + row0 * ldq + h * ADK;
   const bf16_t* kbase = qbase + (ldq / 3);
   const bf16_t* vbase = qbase + 2 * (ldq / 3);
   const bf16_t* pbase = pos + h * ADK;
 
   bf16x8 qu[4], qv[4];
-  load_q(qbase + (long long)(i < T ? i : T - 1) * ldq, bias_u + h * ADK, qu, i < T, lh);
-  load_q(qbase + (long long)(i < T ? i : T - 1) * ldq, bias_v + h * ADK, qv, i < T, lh);
+  load_q(qbase + (long long)(i < Tr ? i : Trc) * ldq, bias_u + h * ADK, qu, i < Tr, lh);
+  load_q(qbase + (long long)(i < Tr ? i : Trc) * ldq, bias_v + h * ADK, qv, i < Tr, lh);
 
   f32x16 o[2];
 #pragma unroll
@@ -217,8 +223,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
   // compiler does not wait for it in front of the step's own LDS reads), behind a single barrier per step.
   const int c0 = T - 1 - (i0_blk + ABQ - 1);
   if (nkt > 0) {
-    stage_rows(kbase, ldq, 0, T - 1, s_k2[0], ABK * 8);
-    stage_v(vbase, ldq, 0, T - 1, s_v2[0]);
+    stage_rows(kbase, ldq, 0, Trc, s_k2[0], ABK * 8);
+    stage_v(vbase, ldq, 0, Trc, s_v2[0]);
     stage_rows(pbase, ldp, c0, P - 1, s_p, ABAND * 8);
   }
   for (int kt = 0; kt < nkt; ++kt) {
@@ -226,8 +232,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt has landed; every wave is done reading tile kt-1
     if (kt + 1 < nkt) {
-      stage_rows(kbase, ldq, j0 + ABK, T - 1, s_k2[(kt + 1) & 1], ABK * 8);
-      stage_v(vbase, ldq, j0 + ABK, T - 1, s_v2[(kt + 1) & 1]);
+      stage_rows(kbase, ldq, j0 + ABK, Trc, s_k2[(kt + 1) & 1], ABK * 8);
+      stage_v(vbase, ldq, j0 + ABK, Trc, s_v2[(kt + 1) & 1]);
       stage_rows(pbase, ldp, c0 + 32 * (kt + 5), P - 1, s_p + ((kt + 5) % APRING) * (32 * ADK), 32 * 8);
     }
     const bf16_t* s_k = s_k2[kt & 1];
@@ -336,12 +342,12 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
     const int ii = i0_blk + wave * 32 + row;
-    if (ii < T) {
+    if (ii < Tr) {
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = sg[row * SG_LD + c8 + j];
       u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-      *reinterpret_cast<u32x4*>(ctx + ((long long)b * T + ii) * ldo + h * ADK + c8) = t;
+      *reinterpret_cast<u32x4*>(ctx + (row0 + ii) * ldo + h * ADK + c8) = t;
       if (ctx_lo) {
         // what the bf16 rounding of O dropped, itself as bf16 (O = hi + lo to ~16 mantissa bits): backward's
         // delta = sum dO * O multiplies a gradient that nearly cancels (dS = P * (dP - delta)); with delta taken from the
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
           lo[2 * j + 1] = v[2 * j + 1] - __uint_as_float(t[j] & 0xffff0000u);
         }
         u32x4 tl = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(lo[4], lo[5]), pack_bf2(lo[6], lo[7])};
-        *reinterpret_cast<u32x4*>(ctx_lo + ((long long)b * T + ii) * ldo + h * ADK + c8) = tl;
+        *reinterpret_cast<u32x4*>(ctx_lo + (row0 + ii) * ldo + h * ADK + c8) = tl;
       }
     }
   }
@@ -373,11 +379,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
                                                          const bf16_t* __restrict__ qkv, long long ldq,
                                                          const float* __restrict__ bias_u, const float* __restrict__ bias_v,
                                                          bf16_t* __restrict__ qu, bf16_t* __restrict__ qv, int B,
-                                                         int H, int T, int d) {
+                                                         int H, int T, int d, const long long* __restrict__ len,
+                                                         const long long* __restrict__ cu) {
   const int lane = threadIdx.x & 63;
-  const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
-  if (row >= (long long)B * T) return;
-  const int b = (int)(row / T), i = (int)(row - (long long)b * T);
+  const long long prow = blockIdx.x * 4LL + (threadIdx.x >> 6);   // row of the PADDED [B, T] grid (delta's own layout)
+  if (prow >= (long long)B * T) return;
+  const int b = (int)(prow / T), i = (int)(prow - (long long)b * T);
+  if (cu && i >= (int)min((long long)T, len[b])) return;            // packed rows: a frame beyond the utterance does not exist
+  const long long row = cu ? cu[b] + i : prow;                      // row of the activation matrices
   for (int c0 = 0; c0 < d; c0 += 512) {
     const int c = c0 + lane * 8;
     float acc = 0.f;
@@ -444,7 +453,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqu_out,
     bf16_t* __restrict__ dqv_out, bf16_t* __restrict__ ds_out, bf16_t* __restrict__ dq_out, long long ld_dq,
-    float* __restrict__ cs_partial, int B, int H, int T, int d, float scale, DropCfg drop) {
+    float* __restrict__ cs_partial, int B, int H, int T, int d, float scale, DropCfg drop,
+    const long long* __restrict__ cu) {
   drop_resolve(drop);
   __shared__ __attribute__((aligned(16))) bf16_t s_k2[2][ABK * ADK];       // double-buffered (read until the end of a step)
   __shared__ __attribute__((aligned(16))) bf16_t s_v[ABK * ADK];           // read in the first MFMA block only
@@ -460,16 +470,19 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   const int L = (int)min((long long)T, len[b]);
   const bool qvalid = i < L;
   const int P = 2 * T - 1;
-  const long long rowi = (long long)b * T + (i < T ? i : T - 1);
+  const long long row0 = cu ? cu[b] : (long long)b * T;   // packed rows: see the forward kernel
+  const int Tr = cu ? L : T;
+  const int Trc = Tr > 0 ? Tr - 1 : 0;
+  const long long rowi = row0 + (i < Tr ? i : Trc);
 
-  const bf16_t* kbase = qkv + ((long long)b * T) * ldq + h * ADK + (ldq / 3);
+  const bf16_t* kbase = qkv + row0 * ldq + h * ADK + (ldq / 3);
   const bf16_t* vbase = kbase + (ldq / 3);
   const bf16_t* pbase = pos + h * ADK;
 
   bf16x8 qu[4], qv[4], dof[4];
-  load_rows(qu_g + rowi * d + h * ADK, qu, i < T, lh);
-  load_rows(qv_g + rowi * d + h * ADK, qv, i < T, lh);
-  load_rows(dO + rowi * d + h * ADK, dof, i < T, lh);
+  load_rows(qu_g + rowi * d + h * ADK, qu, i < Tr, lh);
+  load_rows(qv_g + rowi * d + h * ADK, qv, i < Tr, lh);
+  load_rows(dO + rowi * d + h * ADK, dof, i < Tr, lh);
   float lse_i = qvalid ? lse[((long long)b * H + h) * T + i] : 1e30f;  // padded query: exp(. - 1e30) = 0
   float dlt_i = qvalid ? delta[((long long)b * H + h) * T + i] : 0.f;
   // (the compiler must wait for these register loads HERE, not at their first use inside the loop: see the dK/dV kernel)
@@ -498,8 +511,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   // MFMA block only) is re-staged into its single buffer behind a second barrier as soon as every wave has read it
   const int c0 = T - 1 - (i0_blk + ABQ - 1);
   if (nkt > 0) {
-    stage_rows(kbase, ldq, 0, T - 1, s_k2[0], ABK * 8);
-    stage_rows(vbase, ldq, 0, T - 1, s_v, ABK * 8);
+    stage_rows(kbase, ldq, 0, Trc, s_k2[0], ABK * 8);
+    stage_rows(vbase, ldq, 0, Trc, s_v, ABK * 8);
     stage_rows(pbase, ldp, c0, P - 1, s_p, ABAND * 8);
   }
   for (int kt = 0; kt < nkt; ++kt) {
@@ -507,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt has landed; every wave is done with step kt-1
     if (kt + 1 < nkt) {
-      stage_rows(kbase, ldq, j0 + ABK, T - 1, s_k2[(kt + 1) & 1], ABK * 8);
+      stage_rows(kbase, ldq, j0 + ABK, Trc, s_k2[(kt + 1) & 1], ABK * 8);
       stage_rows(pbase, ldp, c0 + 32 * (kt + 5), P - 1, s_p + ((kt + 5) % APRING) * (32 * ADK), 32 * 8);
     }
     const bf16_t* s_k = s_k2[kt & 1];
@@ -530,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     }
     if (kt + 1 < nkt) {  // (block-uniform)
       __syncthreads();   // every wave has its V fragments
-      stage_rows(vbase, ldq, j0 + ABK, T - 1, s_v, ABK * 8);
+      stage_rows(vbase, ldq, j0 + ABK, Trc, s_v, ABK * 8);
     }
 #pragma unroll
     for (int gt = 0; gt < 2; ++gt)
@@ -657,13 +670,13 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
       const int ii = i0_blk + wave * 32 + row;
-      if (ii < T) {
+      if (ii < Tr) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = sg[row * SG_LD + c8 + j];
         if (outp) {
           u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-          *reinterpret_cast<u32x4*>(outp + ((long long)b * T + ii) * d + h * ADK + c8) = t;
+          *reinterpret_cast<u32x4*>(outp + (row0 + ii) * d + h * ADK + c8) = t;
         }
         if (dq_out) {
 #pragma unroll
@@ -675,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += keep[it][j];
             u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-            *reinterpret_cast<u32x4*>(dq_out + ((long long)b * T + ii) * ld_dq + h * ADK + c8) = t;
+            *reinterpret_cast<u32x4*>(dq_out + (row0 + ii) * ld_dq + h * ADK + c8) = t;
           }
         }
       }
@@ -713,7 +726,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
     const bf16_t* __restrict__ qu_g, const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ qkv, long long ldq,
     const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqkv, long long ldd, int B, int H,
-    int T, int Tp, int d, float scale, DropCfg drop) {
+    int T, int Tp, int d, float scale, DropCfg drop, const long long* __restrict__ cu) {
   drop_resolve(drop);
   // staging (double-buffered query tiles + the positional band as a ring of 32-row blocks, see the forward kernel) and the
   // output transposition tile share one buffer: the latter is only used after the loop
@@ -732,7 +745,10 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   const int L = (int)min((long long)T, len[b]);
   const bool kvalid = j < L;
   const int P = 2 * T - 1;
-  const long long rowj = (long long)b * T + (j < T ? j : T - 1);
+  const long long row0 = cu ? cu[b] : (long long)b * T;   // packed rows: see the forward kernel
+  const int Tr = cu ? L : T;
+  const int Trc = Tr > 0 ? Tr - 1 : 0;
+  const long long rowj = row0 + (j < Tr ? j : Trc);
   const bf16_t* kbase = qkv + (ldq / 3) + h * ADK;
   const bf16_t* pbase = pos + h * ADK;
   const uint32_t akey = attn_key(drop, b, h);
@@ -741,8 +757,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   const float dscale = drop.threshold != 0u ? drop.scale : 1.f;  // folded, with `scale`, into the accumulators at the end
 
   bf16x8 kf[4], vf[4];
-  load_rows(kbase + rowj * ldq, kf, j < T, lh);
-  load_rows(kbase + (ldq / 3) + rowj * ldq, vf, j < T, lh);
+  load_rows(kbase + rowj * ldq, kf, j < Tr, lh);
+  load_rows(kbase + (ldq / 3) + rowj * ldq, vf, j < Tr, lh);
 
   // (the compiler must wait for these register loads HERE: inside the loop its `s_waitcnt vmcnt(0)` at their first use would
   //  also wait, every step, for the prefetch it knows nothing about)
@@ -753,18 +769,18 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   for (int r = 0; r < 16; ++r) { dk_acc[0][r] = 0.f; dk_acc[1][r] = 0.f; dv_acc[0][r] = 0.f; dv_acc[1][r] = 0.f; }
 
   const int nqt = (L + 31) / 32;
-  const bf16_t* qub = qu_g + ((long long)b * T) * d + h * ADK;
-  const bf16_t* qvb = qv_g + ((long long)b * T) * d + h * ADK;
-  const bf16_t* dob = dO + ((long long)b * T) * d + h * ADK;
+  const bf16_t* qub = qu_g + row0 * d + h * ADK;
+  const bf16_t* qvb = qv_g + row0 * d + h * ADK;
+  const bf16_t* dob = dO + row0 * d + h * ADK;
   // band rows of step qt: cb0 - 32*qt .. +159 (blocks -qt .. -qt+4 of 32 rows, block g in ring slot (g mod 6)); the step after
   // needs ONE new block at the low end.  Query tiles (Qu, Qv, dO) and their lse / delta (wave 0: lanes 0-31 | 32-63, 4 bytes
   // each) are double-buffered.
   const int cb0 = T - 1 + j0_blk - 31;
   auto stage_q = [&](int i0, int buf) {
     bf16_t* dst = s_q3 + buf * (3 * 32 * ADK);
-    stage_rows(qub, d, i0, T - 1, dst, 32 * 8);
-    stage_rows(qvb, d, i0, T - 1, dst + 32 * ADK, 32 * 8);
-    stage_rows(dob, d, i0, T - 1, dst + 2 * 32 * ADK, 32 * 8);
+    stage_rows(qub, d, i0, Trc, dst, 32 * 8);
+    stage_rows(qvb, d, i0, Trc, dst + 32 * ADK, 32 * 8);
+    stage_rows(dob, d, i0, Trc, dst + 2 * 32 * ADK, 32 * 8);
     if (wave == 0) {
       int ii = i0 + (lane & 31);
       ii = ii < T ? ii : T - 1;  // (rows >= len are never used: p = 0 there)
@@ -859,12 +875,12 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
       const int jj = j0_blk + wave * 32 + row;
-      if (jj < T) {
+      if (jj < Tr) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = st_[row * SG_LD + c8 + e];
         u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-        *reinterpret_cast<u32x4*>(dqkv + ((long long)b * T + jj) * ldd + (pass + 1) * (ldd / 3) + h * ADK + c8) = t;
+        *reinterpret_cast<u32x4*>(dqkv + (row0 + jj) * ldd + (pass + 1) * (ldd / 3) + h * ADK + c8) = t;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -892,7 +908,8 @@ __device__ __forceinline__ bf16x8 tr_frag32(const bf16_t* img, int ra, int rb, i
 // LDS-DMA one item ahead, 8 MFMAs; the four waves split the items and combine at the end.
 __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
     const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ x_g, const long long* __restrict__ len,
-    float* __restrict__ dpos, long long ldd, float* __restrict__ partial, int B, int H, int T, int d, int bchunk) {
+    float* __restrict__ dpos, long long ldd, float* __restrict__ partial, int B, int H, int T, int d, int bchunk,
+    const long long* __restrict__ cu) {
   __shared__ __attribute__((aligned(16))) bf16_t s_x[4][2][2 * 1024];   // per wave, double-buffered
   __shared__ __attribute__((aligned(16))) bf16_t s_qv[4][2][32 * ADK];
 
@@ -926,13 +943,16 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
       dma16((base + sl0 * 1024 + k2 * 512 + lane * 8), (sx + k2 * 512));
       dma16((base + sl1 * 1024 + k2 * 512 + lane * 8), (sx + 1024 + k2 * 512));
     }
-    const bf16_t* qb = qv_g + ((long long)b * T) * d + h * ADK;
+    // packed rows (cu): utterance b owns rows cu[b] .. cu[b] + L - 1 of qv; rows beyond meet zero blocks of X (any finite row does)
+    const int Lb = cu ? (int)min((long long)T, len[b]) : T;
+    const bf16_t* qb = qv_g + (cu ? (Lb > 0 ? cu[b] : 0LL) : (long long)b * T) * d + h * ADK;
+    const int grmax = Lb > 0 ? Lb - 1 : 0;
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
       const int cq = k4 * 64 + lane;
       const int r = cq >> 3, ck = cq & 7;
       int gr = 32 * it + r;
-      gr = gr > T - 1 ? T - 1 : gr;
+      gr = gr > grmax ? grmax : gr;
       dma16((qb + __mul24(gr, d) + ((ck ^ ((r >> 1) & 7)) << 3)), (sqv + k4 * 512));
     }
   };
@@ -1076,7 +1096,7 @@ __global__ __launch_bounds__(256) void dpos_reduce_kernel(const float* __restric
 extern "C" int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const void* pos, long long ldp, const void* bias_u,
                                        const void* bias_v, const void* len, void* ctx, void* ctx_lo, long long ldo, void* lse,
                                        int B, int H, int T, int dk, int Tp, float scale, unsigned drop_key,
-                                       unsigned drop_threshold, float drop_scale, void* stream) {
+                                       unsigned drop_threshold, float drop_scale, const void* row_offsets, void* stream) {
   mi_clear_errors();
   if (!qkv || !pos || !bias_u || !bias_v || !len || !ctx || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
   if (dk != ADK || (ldq % 24) || (ldp & 7) || (ldo & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)pos & 15) ||
@@ -1086,31 +1106,34 @@ extern "C" int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const voi
   dim3 grid((T + ABQ - 1) / ABQ, H, B);
   MI_LAUNCH(relpos_flash_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldq,
                      (const bf16_t*)pos, ldp, (const float*)bias_u, (const float*)bias_v, (const long long*)len, (bf16_t*)ctx,
-                     (bf16_t*)ctx_lo, ldo, (float*)lse, B, H, T, Tp, scale, dc);
+                     (bf16_t*)ctx_lo, ldo, (float*)lse, B, H, T, Tp, scale, dc, (const long long*)row_offsets);
   return mi_check_launch();
 }
 
 extern "C" int mi355x_attn_delta(const void* dO, const void* O, const void* O_lo, void* delta, int B, int H, int T, int d,
-                                 void* stream) {
+                                 const void* len, const void* row_offsets, void* stream) {
   mi_clear_errors();
-  if (!dO || !O || !delta || B <= 0 || H <= 0 || T <= 0 || d != H * ADK) return MI_ERR_ARG;
+  if (!dO || !O || !delta || B <= 0 || H <= 0 || T <= 0 || d != H * ADK || (row_offsets && !len)) return MI_ERR_ARG;
   const long long rows = (long long)B * T;
   MI_LAUNCH(attn_delta_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)O_lo, (float*)delta, (const bf16_t*)nullptr, 0LL,
-                     (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, (bf16_t*)nullptr, B, H, T, d);
+                     (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, (bf16_t*)nullptr, B, H, T, d,
+                     (const long long*)len, (const long long*)row_offsets);
   return mi_check_launch();
 }
 extern "C" int mi355x_attn_bwd_prep(const void* dO, const void* O, const void* O_lo, void* delta, const void* qkv, long long ldq,
                                     const void* bias_u, const void* bias_v, void* qu, void* qv, int B, int H, int T, int d,
-                                    void* stream) {
+                                    const void* len, const void* row_offsets, void* stream) {
   mi_clear_errors();
-  if (!dO || !O || !delta || !qkv || !bias_u || !bias_v || !qu || !qv || B <= 0 || H <= 0 || T <= 0 || d != H * ADK || (ldq & 7))
+  if (!dO || !O || !delta || !qkv || !bias_u || !bias_v || !qu || !qv || B <= 0 || H <= 0 || T <= 0 || d != H * ADK || (ldq & 7) ||
+      (row_offsets && !len))
     return MI_ERR_ARG;
   if (((uintptr_t)qkv | (uintptr_t)qu | (uintptr_t)qv | (uintptr_t)bias_u | (uintptr_t)bias_v) & 15) return MI_ERR_ARG;
   const long long rows = (long long)B * T;
   MI_LAUNCH(attn_delta_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)O_lo, (float*)delta, (const bf16_t*)qkv, ldq,
-                     (const float*)bias_u, (const float*)bias_v, (bf16_t*)qu, (bf16_t*)qv, B, H, T, d);
+                     (const float*)bias_u, (const float*)bias_v, (bf16_t*)qu, (bf16_t*)qv, B, H, T, d, (const long long*)len,
+                     (const long long*)row_offsets);
   return mi_check_launch();
 }
 
@@ -1119,7 +1142,7 @@ extern "C" int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const 
                                           void* dqu, void* dqv, void* ds_out, void* dq_out, long long ld_dq, void* bias_grads,
                                           void* cs_scratch, long long cs_scratch_elems, int B, int H, int T, int dk,
                                           long long ds_elems, float scale, unsigned drop_key, unsigned drop_threshold,
-                                          float drop_scale, void* stream) {
+                                          float drop_scale, const void* row_offsets, void* stream) {
   mi_clear_errors();
   if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
   if (dk != ADK || (ldq % 24) || (ldp & 7)) return MI_ERR_ARG;
@@ -1135,7 +1158,7 @@ extern "C" int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const 
   MI_LAUNCH(relpos_flash_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu, (const bf16_t*)qv,
                      (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len, (const bf16_t*)dO,
                      (const float*)lse, (const float*)delta, (bf16_t*)dqu, (bf16_t*)dqv, (bf16_t*)ds_out, (bf16_t*)dq_out, ld_dq,
-                     bias_grads ? (float*)cs_scratch : nullptr, B, H, T, H * ADK, scale, dc);
+                     bias_grads ? (float*)cs_scratch : nullptr, B, H, T, H * ADK, scale, dc, (const long long*)row_offsets);
   if (dq_out && bias_grads)
     MI_LAUNCH((partials_reduce_kernel<float>), dim3((2 * H * ADK + 255) / 256, 8), dim3(256), 0, (hipStream_t)stream,
               (const float*)cs_scratch, (int)(B * ((T + ABQ - 1) / ABQ)), 2 * H * ADK, (float*)bias_grads);
@@ -1145,7 +1168,8 @@ extern "C" int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const 
 extern "C" int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const void* qkv, long long ldq, const void* pos,
                                            long long ldp, const void* len, const void* dO, const void* lse, const void* delta,
                                            void* dqkv, long long ldd, int B, int H, int T, int dk, int Tp, float scale,
-                                           unsigned drop_key, unsigned drop_threshold, float drop_scale, void* stream) {
+                                           unsigned drop_key, unsigned drop_threshold, float drop_scale, const void* row_offsets,
+                                           void* stream) {
   mi_clear_errors();
   if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || !dqkv || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
   if (dk != ADK || (ldq % 24) || (ldp & 7) || (ldd % 24)) return MI_ERR_ARG;
@@ -1153,7 +1177,8 @@ extern "C" int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const
   dim3 grid((T + ABQ - 1) / ABQ, H, B);
   MI_LAUNCH(relpos_flash_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu,
                      (const bf16_t*)qv, (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len,
-                     (const bf16_t*)dO, (const float*)lse, (const float*)delta, (bf16_t*)dqkv, ldd, B, H, T, Tp, H * ADK, scale, dc);
+                     (const bf16_t*)dO, (const float*)lse, (const float*)delta, (bf16_t*)dqkv, ldd, B, H, T, Tp, H * ADK, scale, dc,
+                     (const long long*)row_offsets);
   return mi_check_launch();
 }
 
@@ -1170,7 +1195,7 @@ extern "C" long long mi355x_relpos_dpos_partial_elems(int B, int H, int T) {
 
 extern "C" int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len, void* dpos, long long ldd,
                                             void* dpos_cast, void* partial, long long partial_elems, int B, int H, int T, int dk,
-                                            long long ds_elems, void* stream) {
+                                            long long ds_elems, const void* row_offsets, void* stream) {
   mi_clear_errors();
   if (!qv || !ds || !len || !dpos || B <= 0 || H <= 0 || T <= 0 || (dpos_cast && !partial)) return MI_ERR_ARG;
   if (dk != ADK || ((uintptr_t)ds & 15) || ds_elems < mi355x_relpos_ds_elems(B, H, T)) return MI_ERR_ARG;
@@ -1180,7 +1205,8 @@ extern "C" int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, cons
   if (partial && partial_elems < mi355x_relpos_dpos_partial_elems(B, H, T)) return MI_ERR_ARG;
   dim3 grid(nT, H, nz);
   MI_LAUNCH(relpos_flash_bwd_dpos_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qv,
-                     (const bf16_t*)ds, (const long long*)len, (float*)dpos, ldd, (float*)partial, B, H, T, H * ADK, bchunk);
+                     (const bf16_t*)ds, (const long long*)len, (float*)dpos, ldd, (float*)partial, B, H, T, H * ADK, bchunk,
+                     (const long long*)row_offsets);
   if (partial)
     MI_LAUNCH(dpos_reduce_kernel, dim3(nT, H, 16), dim3(256), 0, (hipStream_t)stream, (const float*)partial,
                        (float*)dpos, ldd, (bf16_t*)dpos_cast, H, T, nz);

@@ -16,9 +16,12 @@
 
 // ------------------------------------------------------------------------------------------------ GLU
 // in [M, 2d] -> out [M, d] = a * sigmoid(b) * (t < len[b]);  rows m = b*T + t
+// cu != nullptr ("packed rows"): `in` holds only the valid frames, utterance b at rows cu[b] .. cu[b] + len[b] - 1;
+// `out` stays the padded [B*T, d] grid the depthwise convolution / BatchNorm run on (their statistics cover padded frames too).
 template <typename T>
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
-                                                      const long long* __restrict__ len, int Tt, long long M, int d) {
+                                                      const long long* __restrict__ len, int Tt, long long M, int d,
+                                                      const long long* __restrict__ cu) {
   const long long nv = M * (d >> 2);
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
     const long long m = i / (d >> 2);
@@ -27,7 +30,8 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const T* __restrict__ in, 
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     if (!len || t < len[b]) {
       float a[4], g[4];
-      ld4(in + m * 2 * d + c, a); ld4(in + m * 2 * d + d + c, g);
+      const long long mi = cu ? cu[b] + t : m;
+      ld4(in + mi * 2 * d + c, a); ld4(in + mi * 2 * d + d + c, g);
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = a[j] * sigmoidf_(g[j]);
     }
@@ -35,17 +39,22 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const T* __restrict__ in, 
   }
 }
 template <typename T>
+// (cu: `in` and `din` are packed, `dout` is the padded grid; a frame beyond its utterance has no row in `din`)
 __global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ in, const T* __restrict__ dout, T* __restrict__ din,
-                                                      const long long* __restrict__ len, int Tt, long long M, int d) {
+                                                      const long long* __restrict__ len, int Tt, long long M, int d,
+                                                      const long long* __restrict__ cu) {
   const long long nv = M * (d >> 2);
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
     const long long m = i / (d >> 2);
     const int c = (int)(i - m * (d >> 2)) * 4;
     const int b = (int)(m / Tt), t = (int)(m - (long long)b * Tt);
     float da[4] = {0.f, 0.f, 0.f, 0.f}, dg[4] = {0.f, 0.f, 0.f, 0.f};
-    if (!len || t < len[b]) {
+    const bool valid = !len || t < len[b];
+    if (cu && !valid) continue;
+    const long long mi = cu ? cu[b] + t : m;
+    if (valid) {
       float a[4], g[4], e[4];
-      ld4(in + m * 2 * d + c, a); ld4(in + m * 2 * d + d + c, g); ld4(dout + m * d + c, e);
+      ld4(in + mi * 2 * d + c, a); ld4(in + mi * 2 * d + d + c, g); ld4(dout + m * d + c, e);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float s = sigmoidf_(g[j]);
@@ -53,7 +62,37 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ in, 
         dg[j] = e[j] * a[j] * s * (1.f - s);
       }
     }
-    st4(din + m * 2 * d + c, da); st4(din + m * 2 * d + d + c, dg);
+    st4(din + mi * 2 * d + c, da); st4(din + mi * 2 * d + d + c, dg);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ packed rows <-> padded grid
+// PACK  : packed[cu[b] + t, 0:w] = padded[b*T + t, 0:w]                      for t < len[b]
+// UNPACK: padded[b*T + t, 0:w] = t < len[b] ? packed[cu[b] + t, 0:w] : 0     for every t < T
+// (row pitches in elements; w a multiple of the 16-byte vector: 8 bf16 / 4 f32).  "Packed" = the valid frames of every utterance
+// back to back -- what the row-wise chain (LayerNorm, feed-forward, projections, residuals) runs on when the batch is ragged.
+template <typename T, bool UNPACK>
+__global__ __launch_bounds__(256) void rows_pack_kernel(const T* __restrict__ src, T* __restrict__ dst, long long ld_src,
+                                                        long long ld_dst, const long long* __restrict__ len,
+                                                        const long long* __restrict__ cu, int Tt, long long M, int w) {
+  constexpr int V = VecIO<T>::V;
+  const int wv = w / V;
+  const long long nv = M * wv;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+    const long long m = i / wv;
+    const int c = (int)(i - m * wv) * V;
+    const int b = (int)(m / Tt), t = (int)(m - (long long)b * Tt);
+    const bool valid = t < len[b];
+    float v[V];
+    if (UNPACK) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = 0.f;
+      if (valid) VecIO<T>::load(src + (cu[b] + t) * ld_src + c, v);
+      VecIO<T>::store(dst + m * ld_dst + c, v);
+    } else if (valid) {
+      VecIO<T>::load(src + m * ld_src + c, v);
+      VecIO<T>::store(dst + (cu[b] + t) * ld_dst + c, v);
+    }
   }
 }
 
@@ -207,21 +246,40 @@ __global__ __launch_bounds__(256) void row_scale_kernel(float* __restrict__ x, c
 // =================================================================================================
 static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
-extern "C" int mi355x_glu_fwd(const void* in, void* out, int dt, const void* len, int T, long long M, int d, void* stream) {
+extern "C" int mi355x_glu_fwd(const void* in, void* out, int dt, const void* len, int T, long long M, int d,
+                              const void* row_offsets, void* stream) {
   mi_clear_errors();
-  if (!in || !out || M <= 0 || d <= 0 || (d & 3) || T <= 0) return MI_ERR_ARG;
+  if (!in || !out || M <= 0 || d <= 0 || (d & 3) || T <= 0 || (row_offsets && !len)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(dt, TT, MI_LAUNCH((glu_fwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)in,
-                                         (TT*)out, (const long long*)len, T, M, d));
+                                         (TT*)out, (const long long*)len, T, M, d, (const long long*)row_offsets));
   return mi_check_launch();
 }
 extern "C" int mi355x_glu_bwd(const void* in, const void* dout, void* din, int dt, const void* len, int T, long long M, int d,
-                              void* stream) {
+                              const void* row_offsets, void* stream) {
   mi_clear_errors();
-  if (!in || !dout || !din || M <= 0 || d <= 0 || (d & 3) || T <= 0) return MI_ERR_ARG;
+  if (!in || !dout || !din || M <= 0 || d <= 0 || (d & 3) || T <= 0 || (row_offsets && !len)) return MI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(dt, TT, MI_LAUNCH((glu_bwd_kernel<TT>), dim3(grid_for(M * (d >> 2))), dim3(256), 0, s, (const TT*)in,
-                                         (const TT*)dout, (TT*)din, (const long long*)len, T, M, d));
+                                         (const TT*)dout, (TT*)din, (const long long*)len, T, M, d, (const long long*)row_offsets));
+  return mi_check_launch();
+}
+// direction 0: padded -> packed, 1: packed -> padded (zero rows beyond the utterances); M = B * T rows of the PADDED grid
+extern "C" int mi355x_rows_pack(const void* src, void* dst, int dt, long long ld_src, long long ld_dst, const void* len,
+                                const void* row_offsets, int T, long long M, int width, int direction, void* stream) {
+  mi_clear_errors();
+  if (!src || !dst || !len || !row_offsets || M <= 0 || T <= 0 || width <= 0 || (direction != 0 && direction != 1)) return MI_ERR_ARG;
+  const int V = dt == MI_DT_F32 ? 4 : 8;
+  if ((width % V) || (ld_src % V) || (ld_dst % V) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return MI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long long nv = M * (width / V);
+  if (direction == 0) {
+    DISPATCH_DT(dt, TT, MI_LAUNCH((rows_pack_kernel<TT, false>), dim3(grid_for(nv)), dim3(256), 0, s, (const TT*)src, (TT*)dst, ld_src,
+                                  ld_dst, (const long long*)len, (const long long*)row_offsets, T, M, width));
+  } else {
+    DISPATCH_DT(dt, TT, MI_LAUNCH((rows_pack_kernel<TT, true>), dim3(grid_for(nv)), dim3(256), 0, s, (const TT*)src, (TT*)dst, ld_src,
+                                  ld_dst, (const long long*)len, (const long long*)row_offsets, T, M, width));
+  }
   return mi_check_launch();
 }
 extern "C" int mi355x_drop_scale_cast(const void* in, int in_dt, void* out, int out_dt, long long n, float alpha,

@@ -265,7 +265,8 @@ class ConformerEncoder(NeuralModule):
         self._syncbn_mailbox = None  # nemo_amd.mailbox.StatsMailbox when MI355X_SYNCBN_MAILBOX=1 and every rank could map its peers
         self._syncbn_mailbox_tried = False
         self.syncbn_profile = None  # a list while bench.py measures the exposed time of the statistics exchanges
-        self.use_flash_attention = True  # bf16 + d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
+        self.use_flash_attention = True  # bf16 + (padded) d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
+        self.flash_pad_heads = os.environ.get("MI355X_FLASH_PAD_HEADS", "1") != "0"  # d_k < 64 -> heads zero-padded to 64 (_geometry)
         # one launch for a layer's norm_out and the next layer's norm_feed_forward1 (d = 512; MI355X_LN2=0: two launches)
         self.fuse_layer_boundary_norms = os.environ.get("MI355X_LN2", "1") != "0"
         self.fuse_boundary_bwd = os.environ.get("MI355X_LN2_BWD", "1") != "0"  # ... and their backwards (mi355x_layernorm2_bwd)
@@ -1043,6 +1044,12 @@ class ConformerEncoder(NeuralModule):
         linear_pos rows, linear_out columns, pos_bias lanes); activations outside the attention block keep width d."""
         dk = self.d_k
         dkp = _pad8(dk) if cdt == torch.bfloat16 else dk
+        if cdt == torch.bfloat16 and self.use_flash_attention and self.flash_pad_heads and dkp < 64:
+            # round 5: heads narrower than the fused kernels' width (Conformer-Small: 44) are padded up to 64 instead of to the
+            # next multiple of 8, so that they take the fused rel-pos attention (csrc/attention.hip, d_k' = 64) instead of
+            # materialising the [H, B, T', T'] scores and the [H, B, T', 2T'-1] positional matrix in HBM
+            # (multi_head_attention.py:259-354).  The zero lanes add nothing to q.k, (q+v).p or P.V; 1/sqrt(d_k) stays the true one.
+            dkp = 64
         return self.d_model, dkp, self.n_heads * dkp
 
     def _heads_wgrad(self, dY, ldy, y_off, X, ldx, dW, rows, n_groups, group_stride_y, group_stride_w):

@@ -190,6 +190,8 @@ class SqueezeformerEncoder(ConformerEncoder):
     def _geometry(self, cdt):
         """(row pitch of [M, d] GEMM operands, padded head width, padded attention width)"""
         dp, dkp = _pad8(self.d_model), _pad8(self.d_k)  # (same layout in fp32: one code path, exercised by the parity tests)
+        if cdt == torch.bfloat16 and self.use_flash_attention and self.flash_pad_heads and dkp < 64:
+            dkp = 64  # narrow heads ride the fused d_k' = 64 attention kernels (ConformerEncoder._geometry)
         return dp, dkp, self.n_heads * dkp
 
     def _sub_channels(self, cdt):

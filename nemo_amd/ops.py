@@ -327,12 +327,25 @@ def log_softmax_bwd(dlogp, logp, ld, dlogits, ld_out, M, C_, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------------ block glue
-def glu_fwd(x, out, lens, T, M, d):
-    check(lib.mi355x_glu_fwd(_ptr(x), _ptr(out), dt(x), _ptr(lens), T, M, d, _stream()), "glu_fwd")
+def glu_fwd(x, out, lens, T, M, d, cu=None):
+    """cu (i64 [B+1], "packed rows"): x holds the valid frames only (utterance b at rows cu[b] ..), out is the padded [B*T, d] grid"""
+    check(lib.mi355x_glu_fwd(_ptr(x), _ptr(out), dt(x), _ptr(lens), T, M, d, _ptr(cu), _stream()), "glu_fwd")
 
 
-def glu_bwd(x, dout, din, lens, T, M, d):
-    check(lib.mi355x_glu_bwd(_ptr(x), _ptr(dout), _ptr(din), dt(x), _ptr(lens), T, M, d, _stream()), "glu_bwd")
+def glu_bwd(x, dout, din, lens, T, M, d, cu=None):
+    check(lib.mi355x_glu_bwd(_ptr(x), _ptr(dout), _ptr(din), dt(x), _ptr(lens), T, M, d, _ptr(cu), _stream()), "glu_bwd")
+
+
+def rows_pack(src, dst, lens, cu, T, M, width, ld_src=None, ld_dst=None):
+    """dst[cu[b] + t, :width] = src[b*T + t, :width] for t < lens[b]   (padded grid -> packed rows; M = B * T)"""
+    check(lib.mi355x_rows_pack(_ptr(src), _ptr(dst), dt(src), ld_src or width, ld_dst or width, _ptr(lens), _ptr(cu), T, M, width, 0,
+                               _stream()), "rows_pack")
+
+
+def rows_unpack(src, dst, lens, cu, T, M, width, ld_src=None, ld_dst=None):
+    """dst[b*T + t, :width] = src[cu[b] + t, :width] if t < lens[b] else 0   (packed rows -> padded grid, zero rows beyond)"""
+    check(lib.mi355x_rows_pack(_ptr(src), _ptr(dst), dt(src), ld_src or width, ld_dst or width, _ptr(lens), _ptr(cu), T, M, width, 1,
+                               _stream()), "rows_unpack")
 
 
 # ------------------------------------------------------------------------------------------------ Squeezeformer glue
@@ -429,20 +442,22 @@ def relpos_softmax_bwd(dpd, s_in, dscore, dbdf, H, B, T, Tp, Pp, scale, drop: Dr
 
 
 def relpos_flash_fwd(qkv, ldq, pos, ldp, bias_u, bias_v, lens, ctx, ldo, lse, B, H, T, dk, Tp, scale, drop: Dropout = NO_DROP,
-                     ctx_lo=None):
+                     ctx_lo=None, cu=None):
+    """cu (i64 [B+1]): "packed rows" -- the activation matrices hold the valid frames only (include/mi355x_asr.h); the same
+    argument on every fused attention call below"""
     check(lib.mi355x_relpos_flash_fwd(_ptr(qkv), ldq, _ptr(pos), ldp, _ptr(bias_u), _ptr(bias_v), _ptr(lens), _ptr(ctx),
                                       _ptr(ctx_lo), ldo, _ptr(lse), B, H, T, dk, Tp, scale, drop.key, drop.threshold, drop.scale,
-                                      _stream()), "relpos_flash_fwd")
+                                      _ptr(cu), _stream()), "relpos_flash_fwd")
 
 
-def attn_delta(dO, O, delta, B, H, T, d, O_lo=None):
-    check(lib.mi355x_attn_delta(_ptr(dO), _ptr(O), _ptr(O_lo), _ptr(delta), B, H, T, d, _stream()), "attn_delta")
+def attn_delta(dO, O, delta, B, H, T, d, O_lo=None, lens=None, cu=None):
+    check(lib.mi355x_attn_delta(_ptr(dO), _ptr(O), _ptr(O_lo), _ptr(delta), B, H, T, d, _ptr(lens), _ptr(cu), _stream()), "attn_delta")
 
 
-def attn_bwd_prep(dO, O, delta, qkv, ldq, bias_u, bias_v, qu, qv, B, H, T, d, O_lo=None):
+def attn_bwd_prep(dO, O, delta, qkv, ldq, bias_u, bias_v, qu, qv, B, H, T, d, O_lo=None, lens=None, cu=None):
     """attn_delta + qbias in one launch (the prologue of the fused attention backward)"""
     check(lib.mi355x_attn_bwd_prep(_ptr(dO), _ptr(O), _ptr(O_lo), _ptr(delta), _ptr(qkv), ldq, _ptr(bias_u), _ptr(bias_v), _ptr(qu),
-                                   _ptr(qv), B, H, T, d, _stream()), "attn_bwd_prep")
+                                   _ptr(qv), B, H, T, d, _ptr(lens), _ptr(cu), _stream()), "attn_bwd_prep")
 
 
 def relpos_ds_buffer(B, H, T, device, fill=None):
@@ -455,7 +470,7 @@ def relpos_ds_buffer(B, H, T, device, fill=None):
 
 
 def relpos_flash_bwd_dq(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqu, dqv, B, H, T, dk, scale,
-                        drop: Dropout = NO_DROP, ds_out=None, dq_out=None, ld_dq=0, bias_grads=None):
+                        drop: Dropout = NO_DROP, ds_out=None, dq_out=None, ld_dq=0, bias_grads=None, cu=None):
     """dqu / dqv: the two gradients separately (may both be None when `dq_out` is given); dq_out: their sum as rows of pitch
     ld_dq; bias_grads f32 [2 * H * dk] += column sums of dQu | dQv (pos_bias_u | pos_bias_v gradients)"""
     sc, n = None, 0
@@ -465,22 +480,22 @@ def relpos_flash_bwd_dq(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqu, d
     check(lib.mi355x_relpos_flash_bwd_dq(_ptr(qu), _ptr(qv), _ptr(qkv), ldq, _ptr(pos), ldp, _ptr(lens), _ptr(dO), _ptr(lse),
                                          _ptr(delta), _ptr(dqu), _ptr(dqv), _ptr(ds_out), _ptr(dq_out), ld_dq, _ptr(bias_grads),
                                          _ptr(sc), n, B, H, T, dk, 0 if ds_out is None else ds_out.numel(), scale, drop.key,
-                                         drop.threshold, drop.scale, _stream()), "relpos_flash_bwd_dq")
+                                         drop.threshold, drop.scale, _ptr(cu), _stream()), "relpos_flash_bwd_dq")
 
 
 def relpos_flash_bwd_dkv(qu, qv, qkv, ldq, pos, ldp, lens, dO, lse, delta, dqkv, ldd, B, H, T, dk, Tp, scale,
-                         drop: Dropout = NO_DROP):
+                         drop: Dropout = NO_DROP, cu=None):
     check(lib.mi355x_relpos_flash_bwd_dkv(_ptr(qu), _ptr(qv), _ptr(qkv), ldq, _ptr(pos), ldp, _ptr(lens), _ptr(dO), _ptr(lse),
                                           _ptr(delta), _ptr(dqkv), ldd, B, H, T, dk, Tp, scale, drop.key, drop.threshold,
-                                          drop.scale, _stream()), "relpos_flash_bwd_dkv")
+                                          drop.scale, _ptr(cu), _stream()), "relpos_flash_bwd_dkv")
 
 
-def relpos_flash_bwd_dpos(qv, ds, lens, dpos, B, H, T, dk, dpos_cast=None):
+def relpos_flash_bwd_dpos(qv, ds, lens, dpos, B, H, T, dk, dpos_cast=None, cu=None):
     """`dpos_cast` (bf16, shape of dpos): the GEMM-operand copy of the updated gradient, written by the reduction stage"""
     n = lib.mi355x_relpos_dpos_partial_elems(B, H, T)
     scratch = _scratch("relpos_flash_bwd_dpos", n, dpos.device)
     check(lib.mi355x_relpos_flash_bwd_dpos(_ptr(qv), _ptr(ds), _ptr(lens), _ptr(dpos), dpos.shape[-1], _ptr(dpos_cast),
-                                           _ptr(scratch), n, B, H, T, dk, ds.numel(), _stream()), "relpos_flash_bwd_dpos")
+                                           _ptr(scratch), n, B, H, T, dk, ds.numel(), _ptr(cu), _stream()), "relpos_flash_bwd_dpos")
 
 
 # ------------------------------------------------------------------------------------------------ conv module

@@ -114,13 +114,15 @@ def test_ragged_batch_matches_cpu_oracle_fp32():
     assert int(bn.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("d_model,n_heads", [(64, 2), (256, 4), (176, 4)])
-def test_bf16_mfma_path_close_to_fp32_oracle(d_model, n_heads):
+@pytest.mark.parametrize("d_model,n_heads,pad_heads", [(64, 2, True), (256, 4, True), (176, 4, True), (176, 4, False)])
+def test_bf16_mfma_path_close_to_fp32_oracle(d_model, n_heads, pad_heads):
     """bf16 compute (MFMA GEMMs, bf16 activations): loss within 2 %, gradient direction cos > 0.98 per big tensor.
     d_model = 256 (d_k = 64) takes the production paths the tiny configurations skip: fused flash attention, implicit-GEMM
     conv2 (forward / weight / input gradient), grouped weight gradients on the side stream, 256x256 GEMM tiles.
     d_model = 176 / 4 heads is the recipe table's Small geometry (d_k = 44, not a multiple of 8): zero-padded heads inside the
-    packed weight images, per-head batched weight gradients; there EVERY attention tensor is checked, bias-sized ones included."""
+    packed weight images, per-head batched weight gradients; there EVERY attention tensor is checked, bias-sized ones included.
+    pad_heads (round 5): heads narrower than 64 are padded to the fused kernels' width and take the fused rel-pos attention
+    (d_k' = 64); False = the round-4 layout (d_k' = 48, scores materialised)."""
     cfg = R.ConformerCfg(d_model=d_model, n_heads=n_heads, n_layers=2, vocab=20, dropout=0, dropout_att=0,
                          dropout_pre_encoder=0)
     P = R.init_params(cfg, seed=6)
@@ -134,6 +136,9 @@ def test_bf16_mfma_path_close_to_fp32_oracle(d_model, n_heads):
     model.decoder.compute_dtype = torch.bfloat16
     _load(model, P)
     model = model.to(dev).train()
+    model.encoder.flash_pad_heads = pad_heads
+    dk = d_model // n_heads
+    assert model.encoder._geometry(torch.bfloat16)[1] == (64 if (pad_heads and dk < 64) else (dk + 7) // 8 * 8)
     out = model.training_step([audio.to(dev), alen.to(dev), tok.to(dev), tl.to(dev)])
     out["loss"].backward()
     torch.cuda.synchronize()
