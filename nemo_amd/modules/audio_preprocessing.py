@@ -152,6 +152,13 @@ class FilterbankFeatures(nn.Module):
             raise NotImplementedError("linear_spec=True is not on the Conformer-CTC path")
         seq_len_unfixed = self.get_seq_len(seq_len)
         out_len = torch.where(seq_len == 0, torch.zeros_like(seq_len_unfixed), seq_len_unfixed)
+        host = getattr(seq_len, "host_lengths", None)
+        if host is not None:
+            # the caller (input pipeline) knows the sample counts on the host: the frame counts follow by the same formula, so the
+            # encoder can size a packed launch sequence (ConformerEncoder._packing_plan) without reading anything back
+            h = torch.as_tensor(host, dtype=torch.int64)
+            hu = self.get_seq_len(h)
+            out_len.host_lengths = torch.where(h == 0, torch.zeros_like(hu), hu)
         x = x.contiguous()
         dither = self.dither if (self.training and self.dither > 0) else 0.0
         self._seed = (self._seed + 1) & 0x7FFFFFFF

@@ -267,6 +267,17 @@ class ConformerEncoder(NeuralModule):
         self.syncbn_profile = None  # a list while bench.py measures the exposed time of the statistics exchanges
         self.use_flash_attention = True  # bf16 + (padded) d_k == 64: fused kernels; otherwise the GEMM + softmax-kernel path
         self.flash_pad_heads = os.environ.get("MI355X_FLASH_PAD_HEADS", "1") != "0"  # d_k < 64 -> heads zero-padded to 64 (_geometry)
+        # PACKED ROWS ("length-aware kernels skipping padded frames"): the row-wise chain of the layers -- LayerNorms,
+        # feed-forward / projection / pointwise-conv GEMMs, residuals, every weight gradient -- runs on the sum_b L_b valid frames
+        # of a ragged batch instead of on B * T'_max rows; the fused attention addresses utterance b at row_offsets[b]; only the
+        # depthwise conv + BatchNorm + Swish core of the conv module keeps the padded [B, T', d] grid, because the reference's
+        # batch statistics run over padded frames too (conformer_modules.py:297,330-331; oracle/packed_ref.py states the semantics).
+        # "auto": pack when the caller handed the lengths over on the host (`length.host_lengths`, no device sync) and at least
+        # `packed_min_padding` of the rows are padding; True: always (reads the lengths back if it has to); False: never.
+        _pk = os.environ.get("MI355X_PACKED", "auto").lower()
+        self.packed_rows = {"0": False, "false": False, "1": True, "true": True}.get(_pk, "auto")
+        self.packed_min_padding = float(os.environ.get("MI355X_PACKED_MIN_PADDING", "0.02"))
+        self.packed_last = None   # diagnostics: (packed rows, padded rows) of the last forward that packed, else None
         # one launch for a layer's norm_out and the next layer's norm_feed_forward1 (d = 512; MI355X_LN2=0: two launches)
         self.fuse_layer_boundary_norms = os.environ.get("MI355X_LN2", "1") != "0"
         self.fuse_boundary_bwd = os.environ.get("MI355X_LN2_BWD", "1") != "0"  # ... and their backwards (mi355x_layernorm2_bwd)
@@ -546,6 +557,8 @@ class ConformerEncoder(NeuralModule):
         self._cur_gs = None
         if not (self.use_graphs and self.training and mel.is_cuda) or ops.GEMM_PROFILE is not None:
             return None
+        if self._packing_plan(length, mel.shape[0], mel.shape[2], peek=True) is not None:
+            return None  # packed rows: the row count changes with every batch, a recorded sequence holds one shape
         key = self._graph_key(mel, length)
         gs = self._graph_sets.get(key)
         if gs is None:
@@ -797,6 +810,41 @@ class ConformerEncoder(NeuralModule):
         if self._wg_stream is not None:
             torch.cuda.current_stream(self._wg_stream.device).wait_stream(self._wg_stream)
 
+    def _packing_plan(self, length, B, T_mel, lens=None, peek=False):
+        """None (the padded path) or the plan of a packed forward: pk.cu = i64 [B+1] row offsets on the device, pk.Mp = number of
+        valid frames after sub-sampling.  The row count is a HOST number (it sizes every launch), so the lengths have to be known on
+        the host: `length.host_lengths` (a CPU tensor / list the caller attached to the length tensor -- the input pipeline has them
+        anyway) costs nothing; without it packed_rows=True reads them back (one device sync per step), "auto" stays padded.
+        peek=True: decision only (no device work, no sync)."""
+        mode = self.packed_rows
+        if mode is False or not length.is_cuda:
+            return None
+        host = getattr(length, "host_lengths", None)
+        if host is None:
+            if mode == "auto":
+                return None
+            if peek:
+                return _Saved()   # forced packing without host lengths: the decision is "packed", the numbers come with the sync
+            host = length.detach().to("cpu")
+        hl = torch.as_tensor(host, dtype=torch.int64).clamp(min=0, max=T_mel)
+        T2 = T_mel
+        for _ in range(self.pre_encode._sampling_num):  # the same recurrence as _lens / calc_length (subsampling.py:576-586)
+            hl = (torch.div(hl - 1, 2, rounding_mode="floor") + 1).clamp_(min=0)
+            T2 = (T2 - 1) // 2 + 1
+        hl = hl.clamp(max=T2)
+        Mp, M = int(hl.sum()), B * T2
+        if Mp <= 0 or (mode == "auto" and (M - Mp) < self.packed_min_padding * M):
+            return None
+        pk = _Saved()
+        pk.Mp = Mp
+        if peek:
+            return pk
+        cu = torch.zeros(B + 1, dtype=torch.int64)
+        cu[1:] = torch.cumsum(hl, 0)
+        pk.cu = cu.to(length.device, non_blocking=True)
+        pk.host_lens = hl
+        return pk
+
     def _lens(self, length, n_stages=2):
         """valid lengths after 0, 1, ..., n stride-2 stages: floor((n + 2 - 3)/2) + 1 each, subsampling.py:576-586"""
         out = [length.to(torch.int64).contiguous()]
@@ -873,6 +921,13 @@ class ConformerEncoder(NeuralModule):
             x = self._new(M, d, dtype=torch.float32, device=dev)
             ops.gemm(S.out2, W["pre.out"], x, M, d, F2 * C_, F2 * C_, W.pitch("pre.out"), d, bias=pe.out.bias,
                      alpha=(self.xscale or 1.0), drop=S.drop_pre)
+        # ---- packed rows: from here to the end of the layer stack only the valid frames exist
+        S.pk = pk = self._packing_plan(length, B, T, lens=lens)
+        self.packed_last = (pk.Mp, M) if pk is not None else None
+        if pk is not None:
+            xp = self._new(pk.Mp, d, dtype=torch.float32, device=dev)
+            ops.rows_pack(x, xp, len2, pk.cu, T2, M, d)
+            x = xp
         # ---- relative positional table (constant)
         pkey = (T2, cdt, str(dev))
         pos = self._pos_cache.get(pkey)
@@ -900,6 +955,10 @@ class ConformerEncoder(NeuralModule):
             S.layers.append(sl)
         if training:  # nn.BatchNorm1d bookkeeping, one multi-tensor launch
             torch._foreach_add_([L.conv.batch_norm.num_batches_tracked for L in self.layers], 1)
+        if pk is not None:  # back to the reference's [B, T', d] grid (frames beyond an utterance: zeros -- nothing downstream reads them)
+            xo = self._new(M, d, dtype=torch.float32, device=dev)
+            ops.rows_unpack(x, xo, len2, pk.cu, T2, M, d)
+            x = xo
         out = x.view(B, T2, d).transpose(1, 2)
         return out, len2, (S if save else None)
 
@@ -1107,14 +1166,24 @@ class ConformerEncoder(NeuralModule):
                 self._wgrad(dp_all[i], d, 0, pos, d, 0, grads[i], d, d, P)
 
     # ------------------------------------------------------------------ rel-pos attention core (shared with Squeezeformer)
-    def _attn_fwd(self, qkv, p, bias_u, bias_v, lens, B, T, dA, dk, scale, d_att, cdt, dev):
+    def _attn_fwd(self, qkv, p, bias_u, bias_v, lens, B, T, dA, dk, scale, d_att, cdt, dev, pk=None):
         """qkv [B*T, 3*dA] (q | k | v, heads of width dk = dA / H, possibly zero-padded heads), p [2T-1, dA] = linear_pos of
-        the table, bias_u / bias_v [dA] -> ctx [B*T, dA] and what backward needs.  `scale` = 1/sqrt(true d_k)."""
+        the table, bias_u / bias_v [dA] -> ctx [B*T, dA] and what backward needs.  `scale` = 1/sqrt(true d_k).
+        pk (packed rows): qkv / ctx hold the valid frames only ([pk.Mp, .]); the fused kernels address utterance b at pk.cu[b],
+        the un-fused path (fp32, other head widths) runs on a padded copy."""
         H = self.n_heads
         M, P = B * T, 2 * T - 1
         Tp, Pp = _pad8(T), _pad8(P)
-        ctx = self._new(M, dA, dtype=cdt, device=dev)
         flash = self.use_flash_attention and cdt == torch.bfloat16 and dk == 64
+        cu = pk.cu if pk is not None else None
+        if pk is not None and not flash:
+            qkv_p = self._new(M, 3 * dA, dtype=cdt, device=dev)
+            ops.rows_unpack(qkv, qkv_p, lens, cu, T, M, 3 * dA)
+            ctx_p, saved = self._attn_fwd(qkv_p, p, bias_u, bias_v, lens, B, T, dA, dk, scale, d_att, cdt, dev)
+            ctx = self._new(pk.Mp, dA, dtype=cdt, device=dev)
+            ops.rows_pack(ctx_p, ctx, lens, cu, T, M, dA)
+            return ctx, saved
+        ctx = self._new(pk.Mp if pk is not None else M, dA, dtype=cdt, device=dev)
         if flash:
             # fused rel-pos flash attention: scores / positional matrix never touch HBM; only the log-sum-exp is kept
             lse = self._new(B, H, T, dtype=torch.float32, device=dev)
@@ -1122,9 +1191,9 @@ class ConformerEncoder(NeuralModule):
             # mantissa bits of the stored operand -- see mi355x_relpos_flash_fwd); it travels in the first slot of the saved tuple
             # (kept whenever activations are saved for a backward -- also for an eval-mode / frozen encoder that is
             #  differentiated through: delta from the rounded O alone put a 36 % error on layer-0 q / k gradients)
-            ctx_lo = self._new(M, dA, dtype=cdt, device=dev) if (self._saving and self.flash_delta_residual) else None
+            ctx_lo = self._new(ctx.shape[0], dA, dtype=cdt, device=dev) if (self._saving and self.flash_delta_residual) else None
             ops.relpos_flash_fwd(qkv, 3 * dA, p, dA, bias_u, bias_v, lens, ctx, dA, lse, B, H, T, dk, Tp, scale, d_att,
-                                 ctx_lo=ctx_lo)
+                                 ctx_lo=ctx_lo, cu=cu)
             return ctx, (ctx_lo, None, None, None, lse)
         qu = self._new(M, dA, dtype=cdt, device=dev)
         qv = self._new(M, dA, dtype=cdt, device=dev)
@@ -1146,7 +1215,7 @@ class ConformerEncoder(NeuralModule):
         return ctx, (qu, qv, s_, pd, None)
 
     def _attn_bwd(self, saved, qkv, p, bias_u, bias_v, ctx, dctx, lens, B, T, dA, dk, scale, d_att, cdt, dev, dp, dp_cast,
-                  bias_grads=None):
+                  bias_grads=None, pk=None):
         """-> (dqkv [M, 3*dA] with the k and v thirds filled, dqu, dqv [M, dA]); dp f32 [2T-1, dA] += d linear_pos output,
         dp_cast (compute dtype) = its GEMM-operand copy for the linear_pos weight gradient.  `bias_grads` (fused path only):
         f32 [2 * dA] = pos_bias_u.grad | pos_bias_v.grad in one piece -- then the dQ kernel writes dq = dqu + dqv into the q third
@@ -1155,6 +1224,24 @@ class ConformerEncoder(NeuralModule):
         H = self.n_heads
         M, P = B * T, 2 * T - 1
         Tp, Pp = _pad8(T), _pad8(P)
+        cu = pk.cu if pk is not None else None
+        if pk is not None and lse is None:
+            # packed rows, un-fused path (fp32 / other head widths): the batched GEMMs stride over a padded grid -- run them on padded
+            # copies and hand the valid rows back
+            qkv_p = self._new(M, 3 * dA, dtype=cdt, device=dev)
+            dctx_p = self._new(M, dA, dtype=cdt, device=dev)
+            ops.rows_unpack(qkv, qkv_p, lens, cu, T, M, 3 * dA)
+            ops.rows_unpack(dctx, dctx_p, lens, cu, T, M, dA)
+            dqkv_p, dqu_p, dqv_p = self._attn_bwd(saved, qkv_p, p, bias_u, bias_v, None, dctx_p, lens, B, T, dA, dk, scale, d_att, cdt,
+                                                  dev, dp, dp_cast)
+            out = []
+            for t_p, w in ((dqkv_p, 3 * dA), (dqu_p, dA), (dqv_p, dA)):
+                t = self._new(pk.Mp, w, dtype=cdt, device=dev)
+                ops.rows_pack(t_p, t, lens, cu, T, M, w)
+                out.append(t)
+            return tuple(out)
+        if pk is not None:
+            M = pk.Mp   # (fused path: the kernels address utterance b at cu[b]; lse / delta / dS keep their padded [B, H, T] layout)
         dqkv = self._new(M, 3 * dA, dtype=cdt, device=dev)
         fuse_dq = lse is not None and bias_grads is not None
         dqu = None if fuse_dq else self._new(M, dA, dtype=cdt, device=dev)
@@ -1166,9 +1253,9 @@ class ConformerEncoder(NeuralModule):
             dlt = self._new(B, H, T, dtype=torch.float32, device=dev)
             if (bias_u.data_ptr() | bias_v.data_ptr()) & 15:
                 ops.qbias(qkv, 3 * dA, bias_u, bias_v, qu, qv, M, dA)
-                ops.attn_delta(dctx, ctx, dlt, B, H, T, dA, O_lo=ctx_lo)
+                ops.attn_delta(dctx, ctx, dlt, B, H, T, dA, O_lo=ctx_lo, lens=lens, cu=cu)
             else:  # q + u, q + v and delta = sum dO * O in one pass over the rows
-                ops.attn_bwd_prep(dctx, ctx, dlt, qkv, 3 * dA, bias_u, bias_v, qu, qv, B, H, T, dA, O_lo=ctx_lo)
+                ops.attn_bwd_prep(dctx, ctx, dlt, qkv, 3 * dA, bias_u, bias_v, qu, qv, B, H, T, dA, O_lo=ctx_lo, lens=lens, cu=cu)
             # transient dS (un-shifted 32 x 32 blocks): dQ kernel -> linear_pos gradient kernel.  The latter feeds only the
             # (batched, end-of-backward) linear_pos weight gradient, so with the side stream it leaves the critical path; dS
             # then comes from the caching allocator (record_stream keeps the next layer's dQ kernel from overwriting it too early).
@@ -1176,13 +1263,14 @@ class ConformerEncoder(NeuralModule):
             n_ds = ops.lib.mi355x_relpos_ds_elems(B, H, T)
             dS = (self._new(n_ds, dtype=cdt, device=dev) if side_pos else self._buf("dS", (n_ds,), cdt, dev))
             ops.relpos_flash_bwd_dq(qu, qv, qkv, 3 * dA, p, dA, lens, dctx, lse, dlt, dqu, dqv, B, H, T, dk, scale, d_att,
-                                    ds_out=dS, dq_out=dqkv if fuse_dq else None, ld_dq=3 * dA, bias_grads=bias_grads)
+                                    ds_out=dS, dq_out=dqkv if fuse_dq else None, ld_dq=3 * dA, bias_grads=bias_grads, cu=cu)
             if side_pos:
                 with self._wgrad_scope(qv, dS):
-                    ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk, dpos_cast=dp_cast)
-            ops.relpos_flash_bwd_dkv(qu, qv, qkv, 3 * dA, p, dA, lens, dctx, lse, dlt, dqkv, 3 * dA, B, H, T, dk, Tp, scale, d_att)
+                    ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk, dpos_cast=dp_cast, cu=cu)
+            ops.relpos_flash_bwd_dkv(qu, qv, qkv, 3 * dA, p, dA, lens, dctx, lse, dlt, dqkv, 3 * dA, B, H, T, dk, Tp, scale, d_att,
+                                     cu=cu)
             if not side_pos:
-                ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk, dpos_cast=dp_cast)
+                ops.relpos_flash_bwd_dpos(qv, dS, lens, dp, B, H, T, dk, dpos_cast=dp_cast, cu=cu)
             return dqkv, dqu, dqv
         # dpd[h,b] = dctx_bh @ v_bh^T  -> reuse the f32 score workspace
         dpd = self._buf("ac", (H, B, T, Tp), torch.float32, dev)
@@ -1218,6 +1306,10 @@ class ConformerEncoder(NeuralModule):
         Tp, Pp = _pad8(T2), _pad8(P)
         sl = _Saved()
         site = i * 16
+        pk = getattr(S, "pk", None)
+        Mg, cu = M, (pk.cu if pk is not None else None)   # Mg: rows of the padded [B, T'] grid (conv core, statistics)
+        if pk is not None:
+            M = pk.Mp                                     # rows of the packed chain
         # ---- macaron FFN 1
         r1 = self._ffn_fwd(f"L{i}.ff1", L.feed_forward1, x, L.norm_feed_forward1, S, sl, W, drop, site, M, d, dff, cdt, dev, "ff1")
         # ---- rel-pos multi-head self-attention
@@ -1229,7 +1321,8 @@ class ConformerEncoder(NeuralModule):
         p = S.p_all[i]  # linear_pos(pos_emb) of every layer was computed by one batched GEMM (same input, 18 weights)
         d_att = drop(self.dropout_att, site + 2)
         bu, bv = (a.pos_bias_u, a.pos_bias_v) if dkp == dk else (Wf[f"L{i}.att.bu"], Wf[f"L{i}.att.bv"])
-        ctx, (qu, qv, s_, pd, lse) = self._attn_fwd(qkv, p, bu, bv, S.len2, B, T2, dA, dkp, 1.0 / math.sqrt(dk), d_att, cdt, dev)
+        ctx, (qu, qv, s_, pd, lse) = self._attn_fwd(qkv, p, bu, bv, S.len2, B, T2, dA, dkp, 1.0 / math.sqrt(dk), d_att, cdt, dev,
+                                                    pk=pk)
         r2 = self._new(M, d, dtype=torch.float32, device=dev)
         d_ares = drop(self.dropout, site + 3)
         ops.gemm(ctx, W[f"L{i}.att.wo"], r2, M, d, dA, dA, W.pitch(f"L{i}.att.wo"), d, bias=a.linear_out.bias, epi=ops.EPI_RESID,
@@ -1241,13 +1334,13 @@ class ConformerEncoder(NeuralModule):
         y3, mean3, rstd3 = self._ln_fwd(L.norm_conv, r2, M, d, cdt, dev)
         pw1 = self._new(M, 2 * d, dtype=cdt, device=dev)
         ops.gemm(y3, W[f"L{i}.conv.pw1"], pw1, M, 2 * d, d, d, W.pitch(f"L{i}.conv.pw1"), 2 * d, bias=c.pointwise_conv1.bias)
-        g = self._new(M, d, dtype=cdt, device=dev)
-        ops.glu_fwd(pw1, g, S.len2, T2, M, d)
-        cc = self._new(M, d, dtype=cdt, device=dev)
+        g = self._new(Mg, d, dtype=cdt, device=dev)   # the conv core stays on the padded grid (BatchNorm counts padded frames)
+        ops.glu_fwd(pw1, g, S.len2, T2, Mg, d, cu=cu)
+        cc = self._new(Mg, d, dtype=cdt, device=dev)
         bn = c.batch_norm
         bmean = self._new(d, dtype=torch.float32, device=dev)
         brstd = self._new(d, dtype=torch.float32, device=dev)
-        count = float(M)
+        count = float(Mg)
         if training:
             stats = S.bn_stats[i]
             ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T2, d, k)
@@ -1257,13 +1350,17 @@ class ConformerEncoder(NeuralModule):
         else:
             ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
             ops.bn_eval_stats(bn.running_mean, bn.running_var, bmean, brstd, bn.eps, d)
-        z = self._new(M, d, dtype=cdt, device=dev)
+        z = self._new(Mg, d, dtype=cdt, device=dev)
         if training:
             # (two launches on purpose: the one-launch form, mi355x_bn_stats_swish_fwd, makes EVERY workgroup derive the
             #  coefficients of its channels from the f64 sums and measured 31 us against 15.5 us for this pair,
             #  tools/bn_bench.py)
             ops.bn_finalize(stats, count, bmean, brstd, bn.running_mean, bn.running_var, bn.momentum, bn.eps, d)
-        ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, M, d)
+        ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, Mg, d)
+        if pk is not None:   # the valid frames of the core's output rejoin the packed chain (z is also the pw2 weight gradient's operand)
+            zp = self._new(M, d, dtype=cdt, device=dev)
+            ops.rows_pack(z, zp, S.len2, cu, T2, Mg, d)
+            z = zp
         r3 = self._new(M, d, dtype=torch.float32, device=dev)
         d_cres = drop(self.dropout, site + 4)
         ops.gemm(z, W[f"L{i}.conv.pw2"], r3, M, d, d, d, W.pitch(f"L{i}.conv.pw2"), d, bias=c.pointwise_conv2.bias,
@@ -1374,6 +1471,11 @@ class ConformerEncoder(NeuralModule):
         W, Wf = self._plan(cdt, dev)
         fp = self._flatp
         dx = dout.transpose(1, 2).contiguous().view(M, d).to(torch.float32)  # no copy when dout is a [B,T,d] view
+        pk = getattr(S, "pk", None)
+        if pk is not None:  # packed rows: the layers' backward runs on the valid frames (the others never reached the loss)
+            dxp = self._new(pk.Mp, d, dtype=torch.float32, device=dev)
+            ops.rows_pack(dx, dxp, S.len2, pk.cu, T2, M, d)
+            dx = dxp
         P = 2 * T2 - 1
         dA = self._geometry(cdt)[2]
         S.dp_all = self._buf("dp_all", (self.n_layers, P, dA), cdt, dev)
@@ -1391,6 +1493,10 @@ class ConformerEncoder(NeuralModule):
                     self._wgrad_join()
                 self._hook(*fp.range_of(f"layers.{i}."))
         self._wg_pending = None  # (the remaining weight gradients have their own shapes / layouts)
+        if pk is not None:  # back onto the [B, T', d] grid of the sub-sampling stack (zero gradient beyond the utterances)
+            dxu = self._new(M, d, dtype=torch.float32, device=dev)
+            ops.rows_unpack(dx, dxu, S.len2, pk.cu, T2, M, d)
+            dx = dxu
         self._wgrad_join(consume=True)       # dp_all may have been produced on the side stream
         self._pos_proj_wgrad(S.dp_all, S.pos, P, cdt)
         if self.grad_ready_hook is not None:
@@ -1512,7 +1618,7 @@ class ConformerEncoder(NeuralModule):
         adjacent = gv_.data_ptr() - gu.data_ptr() == 4 * d  # (the two bias gradients as one [2 * d] piece of the flat buffer)
         dqkv, dqu, dqv = self._attn_bwd((qu, qv, s_, pd, lse), qkv, p, a.pos_bias_u, a.pos_bias_v, ctx, dctx, S.len2, B, T2, d,
                                         dk, scale, d_att, cdt, dev, S.dpos_f32[i], S.dp_all[i],
-                                        bias_grads=gu if (adjacent and lse is not None) else None)
+                                        bias_grads=gu if (adjacent and lse is not None) else None, pk=getattr(S, "pk", None))
         if dqu is None:
             pass  # fused attention: dq and both bias gradients came out of the dQ kernel
         elif cdt == torch.bfloat16 and adjacent:
@@ -1557,7 +1663,7 @@ class ConformerEncoder(NeuralModule):
         dctx = self._new(M, dA, dtype=cdt, device=dev)
         ops.gemm(dao, W[f"L{i}.att.wot"], dctx, M, dA, d, d, W.pitch(f"L{i}.att.wot"), dA)
         dqkv, dqu, dqv = self._attn_bwd((qu, qv, s_, pd, lse), qkv, p, Wf[f"L{i}.att.bu"], Wf[f"L{i}.att.bv"], ctx, dctx, S.len2, B,
-                                        T2, dA, dkp, scale, d_att, cdt, dev, S.dpos_f32[i], S.dp_all[i])
+                                        T2, dA, dkp, scale, d_att, cdt, dev, S.dpos_f32[i], S.dp_all[i], pk=getattr(S, "pk", None))
         sc = torch.zeros(2, dA, dtype=torch.float32, device=dev)
         ops.colsum(dqu, sc[0], M, dA)
         ops.colsum(dqv, sc[1], M, dA)
@@ -1588,6 +1694,10 @@ class ConformerEncoder(NeuralModule):
         P = 2 * T2 - 1
         Tp, Pp = _pad8(T2), _pad8(P)
         scale = 1.0 / math.sqrt(dk)
+        pk = getattr(S, "pk", None)
+        Mg, cu = M, (pk.cu if pk is not None else None)   # Mg: rows of the padded grid (conv core); M: rows of the (packed) chain
+        if pk is not None:
+            M = pk.Mp
         # ---- norm_out: dr = dLN(dxo)
         r4, mean5, rstd5 = sl.out
         pre = getattr(S, "pre_bwd", None)
@@ -1618,16 +1728,20 @@ class ConformerEncoder(NeuralModule):
         self._wgrad(db, d, 0, z, d, 0, c.pointwise_conv2.weight.grad, d, d, M, bias_grad=c.pointwise_conv2.bias.grad)
         dz = self._new(M, d, dtype=cdt, device=dev)
         ops.gemm(db, W[f"L{i}.conv.pw2t"], dz, M, d, d, d, W.pitch(f"L{i}.conv.pw2t"), d)
+        if pk is not None:   # onto the padded grid of the conv core; frames beyond an utterance carry no gradient
+            dzp = self._new(Mg, d, dtype=cdt, device=dev)
+            ops.rows_unpack(dz, dzp, S.len2, cu, T2, Mg, d)
+            dz = dzp
         sums = S.bn_sums[i]
-        ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, M, d, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
+        ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, Mg, d, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
         if training and S.bn_world > 1:
             self._sync_stats(sums)
-        dcc = self._new(M, d, dtype=cdt, device=dev)
-        ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, M, d)
-        dg = self._new(M, d, dtype=cdt, device=dev)
+        dcc = self._new(Mg, d, dtype=cdt, device=dev)
+        ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, Mg, d)
+        dg = self._new(Mg, d, dtype=cdt, device=dev)
         ops.dwconv_bwd(dcc, g, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
         dpw1 = self._new(M, 2 * d, dtype=cdt, device=dev)
-        ops.glu_bwd(pw1, dg, dpw1, S.len2, T2, M, d)
+        ops.glu_bwd(pw1, dg, dpw1, S.len2, T2, Mg, d, cu=cu)
         self._wgrad(dpw1, 2 * d, 0, y3, d, 0, c.pointwise_conv1.weight.grad, 2 * d, d, M, bias_grad=c.pointwise_conv1.bias.grad)
         dy3 = self._new(M, d, dtype=cdt, device=dev)
         ops.gemm(dpw1, W[f"L{i}.conv.pw1t"], dy3, M, d, 2 * d, 2 * d, W.pitch(f"L{i}.conv.pw1t"), d)

@@ -172,6 +172,7 @@ class SqueezeformerEncoder(ConformerEncoder):
         self.max_audio_length = pos_emb_max_len
         self.sync_max_audio_length = True
         self._init_engine(compute_dtype, tail=None)
+        self.packed_rows = False  # (the packed token chain is built for the Conformer layer stack; the time-reduction stages keep the grid)
 
     def _reset_pre_encode(self):
         """ConvSubsampling.reset_parameters for 'dw_striding' (subsampling.py:438-459): Squeezeformer's initialisation"""
