@@ -48,6 +48,9 @@ def parse():
                     help="--var-len batch shaping: semisort = SemiSortBatchSampler (asr_batching.py:27-204), bucket = static "
                          "duration buckets (BucketingDataset / synced_randomized), random = unshaped batches (padding stress)")
     ap.add_argument("--buckets", type=int, default=8)
+    ap.add_argument("--packed", default=None, choices=["auto", "0", "1"],
+                    help="--var-len: packed token chain (SURVEY 8 f1; encoder.packed_rows): auto = the encoder's default (pack when the "
+                         "host knows the lengths and >= 2 %% of the frames are padding), 0 = padded rows, 1 = always")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -108,7 +111,10 @@ def var_len_batches(a, rank, world, vocab, dev):
         audio *= (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1))          # collate pads with zeros
         tl = torch.tensor(np.maximum(1, (3 * d).astype(np.int64)))
         tok = torch.randint(0, vocab, (len(ib), int(tl.max())), generator=g)
-        batches.append([audio.to(dev), lens.to(dev), tok.to(dev), tl.to(dev)])
+        lens_dev = lens.to(dev)
+        lens_dev.host_lengths = lens   # what the input pipeline knows anyway (nemo_amd/data/loader.py attaches it the same way):
+        # lets the encoder size a PACKED launch sequence -- the valid frames only -- without reading the lengths back
+        batches.append([audio.to(dev), lens_dev, tok.to(dev), tl.to(dev)])
         valid.append(float(d.sum()))
     pad = 1.0 - sum(valid) / sum(float(durs[ib].max()) * len(ib) for ib in idx_batches)
     return batches, valid, {"durations": f"uniform {lo:g}-{hi:g} s", "sampler": a.sampler + (f" ({a.buckets} buckets)" if a.sampler == "bucket" else ""),
@@ -391,6 +397,8 @@ def main():
         model.decoder.compute_dtype = cdt
     model = model.to(dev).train()
     model.setup_optimization()
+    if a.packed is not None:
+        model.encoder.packed_rows = {"auto": "auto", "0": False, "1": True}[a.packed]
     var_info = None
     if a.var_len:
         a.no_roofline = a.no_cpu_baseline = True  # (both describe the fixed-length headline workload)
@@ -476,7 +484,10 @@ def main():
             torch.distributed.all_reduce(tv)
         value = tv.item() / dt  # VALID audio seconds of all ranks per wall-clock second
         per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
-        var_info.update({"valid_audio_seconds_timed": round(tv.item(), 1),
+        pl = getattr(model.encoder, "packed_last", None)
+        var_info.update({"packed_rows": str(getattr(model.encoder, "packed_rows", False)),
+                         "last_step_rows_packed_vs_padded": list(pl) if pl else None,
+                         "valid_audio_seconds_timed": round(tv.item(), 1),
                          "ms_per_step_min_median_max": [round(per_step[0], 2), round(per_step[len(per_step) // 2], 2), round(per_step[-1], 2)]})
     else:
         value = world * a.batch * a.secs / (dt / a.steps)

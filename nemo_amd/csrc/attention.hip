@@ -196,6 +196,12 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
   const int Tr = cu ? L : T;                  // rows of this utterance that exist
   const int Trc = Tr > 0 ? Tr - 1 : 0;        // the row index loads are clamped to
 
+  if (cu && i0_blk >= L) {
+    // packed rows: a query tile beyond the utterance has no row to write; only its (never used) statistics are cleared.  On the
+    // padded grid the same tile still runs: its rows exist and must hold finite numbers (the weight gradients sum over every row).
+    if (lse && lh == 0 && i < T) lse[((long long)b * H + h) * T + i] = 0.f;
+    return;
+  }
   const bf16_t* qbase = qkv + row0 * ldq + h * ADK;
   const bf16_t* kbase = qbase + (ldq / 3);
   const bf16_t* vbase = qbase + 2 * (ldq / 3);
@@ -385,12 +391,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   const long long prow = blockIdx.x * 4LL + (threadIdx.x >> 6);   // row of the PADDED [B, T] grid (delta's own layout)
   if (prow >= (long long)B * T) return;
   const int b = (int)(prow / T), i = (int)(prow - (long long)b * T);
-  if (cu && i >= (int)min((long long)T, len[b])) return;            // packed rows: a frame beyond the utterance does not exist
-  const long long row = cu ? cu[b] + i : prow;                      // row of the activation matrices
+  // packed rows: a frame beyond the utterance has no activation row -- its delta is still WRITTEN (zero): the dK/dV kernel stages
+  // lse / delta of whole 32-query tiles and multiplies p = 0 by (dP - delta) on the rows beyond the utterance (0 x NaN = NaN)
+  const bool rvalid = !cu || i < (int)min((long long)T, len[b]);
+  const long long row = cu ? cu[b] + (rvalid ? i : 0) : prow;       // row of the activation matrices
   for (int c0 = 0; c0 < d; c0 += 512) {
     const int c = c0 + lane * 8;
     float acc = 0.f;
-    if (QB && c < d) {
+    if (QB && c < d && rvalid) {
       float q8[8], u8[8], v8[8], o1[8], o2[8];
       VecIO<bf16_t>::load(qkv + row * ldq + c, q8);
       VecIO<float>::load(bias_u + c, u8); VecIO<float>::load(bias_u + c + 4, &u8[4]);
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
       VecIO<bf16_t>::store(qu + row * d + c, o1);
       VecIO<bf16_t>::store(qv + row * d + c, o2);
     }
-    if (c < d) {
+    if (c < d && rvalid) {
       const u32x4 a = *reinterpret_cast<const u32x4*>(dO + row * d + c);
       const u32x4 o = *reinterpret_cast<const u32x4*>(O + row * d + c);
 #pragma unroll
@@ -473,6 +481,15 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   const long long row0 = cu ? cu[b] : (long long)b * T;   // packed rows: see the forward kernel
   const int Tr = cu ? L : T;
   const int Trc = Tr > 0 ? Tr - 1 : 0;
+  if (cu && i0_blk >= L) {
+    // packed rows: no query of this tile exists.  Its dS blocks are never read (the linear_pos gradient kernel skips query tiles
+    // beyond the utterance); its slab of the bias-gradient column sums must still be zero for the second-stage reduction.
+    if (dq_out && cs_partial && threadIdx.x < 128) {
+      const int uv = threadIdx.x >> 6, c = threadIdx.x & 63;
+      cs_partial[((long long)b * gridDim.x + blockIdx.x) * (2 * d) + uv * d + h * ADK + c] = 0.f;
+    }
+    return;
+  }
   const long long rowi = row0 + (i < Tr ? i : Trc);
 
   const bf16_t* kbase = qkv + row0 * ldq + h * ADK + (ldq / 3);
@@ -748,6 +765,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   const long long row0 = cu ? cu[b] : (long long)b * T;   // packed rows: see the forward kernel
   const int Tr = cu ? L : T;
   const int Trc = Tr > 0 ? Tr - 1 : 0;
+  if (cu && j0_blk >= L) return;   // packed rows: no key of this tile exists, nothing to write
   const long long rowj = row0 + (j < Tr ? j : Trc);
   const bf16_t* kbase = qkv + (ldq / 3) + h * ADK;
   const bf16_t* pbase = pos + h * ADK;

@@ -70,7 +70,12 @@ class DeviceBatchLoader:
                 with torch.cuda.stream(self._copy_stream):
                     for i, t in enumerate(batch):
                         if torch.is_tensor(t):
-                            out.append(slot.stage(i, t).to(self.device, non_blocking=True))
+                            dt_ = slot.stage(i, t).to(self.device, non_blocking=True)
+                            if t.dim() == 1 and not t.is_floating_point() and t.numel() <= 4096:
+                                # length vectors keep a host copy with them: the encoder sizes a PACKED launch sequence (the valid
+                                # frames of a ragged batch only, ConformerEncoder._packing_plan) from it without a device read-back
+                                dt_.host_lengths = t.detach().clone()
+                            out.append(dt_)
                         else:
                             out.append(t)
                     ev = torch.cuda.Event()

@@ -63,6 +63,10 @@ def _hip_step(P, over, vocab, batch, packed, dtype=torch.float32, host_lengths=T
     enc.packed_rows = True if packed else False
     for fp in model.flats():
         fp.zero_grad()
+    # whatever the allocator hands out next is NaN: a packed kernel that reads a frame beyond its utterance (or multiplies a zero by
+    # a statistic nobody wrote) shows up as a NaN gradient instead of passing on a lucky zero page
+    junk = [torch.full((32 << 20,), float("nan"), device=dev) for _ in range(4)]
+    del junk
     out = model.training_step([t.to(dev) for t in batch])
     out["loss"].backward()
     torch.cuda.synchronize()
