@@ -289,6 +289,11 @@ class ConformerEncoder(NeuralModule):
         self._wg_stream = None
         self._wgrad_join_per_layer = True
         self.wgrad_grouped = os.environ.get("MI355X_WGRAD_GROUPED", "1") != "0"
+        # where a layer's grouped weight-gradient launch enters the side stream: 0 = at the end of the layer's own backward (it then
+        # runs beside the NEXT layer's first GEMMs), 1 / 2 = inside the next layer's backward, in front of its conv-module
+        # elementwise block / its attention backward (_defer_point; profiles/r5_wgrad_lane.md)
+        # Round 5, same box, alternating: live launches 40.15 -> 39.68 ms with 1 (39.93 with 2), launch tapes 40.33 -> 40.08 ms.
+        self.wgrad_defer = int(os.environ.get("MI355X_WGRAD_DEFER", "1"))
         self._wg_pending, self._wg_rows = None, None
         self.conv2_implicit = os.environ.get("MI355X_CONV2_IMPLICIT", "1") != "0"
         self.ln_cast_fuse = os.environ.get("MI355X_LN_CAST_FUSE", "1") != "0"
@@ -522,7 +527,8 @@ class ConformerEncoder(NeuralModule):
         return (tuple(mel.shape), self._cdt(), str(mel.device), self._flatp.generation, self._syncbn_world(),
                 self.grad_ready_hook is not None, self._wgrad_join_per_layer, self.wgrad_side_stream, self.wgrad_grouped,
                 self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse,
-                self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.graph_tape, self.swish_g, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder)
+                self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.graph_tape, self.swish_g, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder,
+                self.wgrad_defer)
 
     def _auto_begin(self, gs, mode):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -788,6 +794,13 @@ class ConformerEncoder(NeuralModule):
         with self._wgrad_scope(*tensors):
             ops.wgrad_grouped(pend, rows, sk)
         self._wg_pending, self._wg_rows = [], None
+
+    def _defer_point(self, k):
+        """see _backward_impl: point k of a layer's backward (1 = in front of the conv module's BatchNorm / depthwise / GLU
+        backward, 2 = in front of the attention backward)"""
+        f = getattr(self, "_defer_flush", None)
+        if f is not None and self.wgrad_defer == k:
+            f()
 
     def _wgrad_join(self, consume=False):
         """consume=True: the MAIN chain itself reads, right after this call, something the side stream produced"""
@@ -1482,16 +1495,42 @@ class ConformerEncoder(NeuralModule):
         S.bn_sums = torch.zeros(self.n_layers, 2, d, dtype=torch.float64, device=dev)
         S.dpos_f32 = torch.zeros(self.n_layers, P, dA, dtype=torch.float32, device=dev)
         self._wg_pending = [] if (self.wgrad_grouped and cdt == torch.bfloat16) else None
-        for i in range(self.n_layers - 1, -1, -1):
-            dx = self._layer_bwd(i, self.layers[i], dx, S, S.layers[i], W, Wf)
-            self._wgrad_flush()
-            S.layers[i] = None
+        defer = self.wgrad_defer if self._wg_pending is not None else 0
+        self._wg_deferred = None
+
+        def layer_done(j):
             if self.grad_ready_hook is not None:
                 # the layer's gradients are final only when its side-stream wgrads have run: either the consumer waits for
                 # that stream itself (GradSync.producer_streams) or the backward chain joins here
                 if self._wgrad_join_per_layer:
                     self._wgrad_join()
-                self._hook(*fp.range_of(f"layers.{i}."))
+                self._hook(*fp.range_of(f"layers.{j}."))
+
+        def flush_deferred():
+            # the grouped weight-gradient launch of the layer ABOVE, issued at the point of this layer's backward where the main
+            # chain runs kernels that share a CU with it (self.wgrad_defer) -- not beside the next layer's first GEMMs
+            dfr, self._wg_deferred = self._wg_deferred, None
+            if dfr is None:
+                return
+            cur = (self._wg_pending, self._wg_rows)
+            self._wg_pending, self._wg_rows, j = dfr
+            self._wgrad_flush()
+            self._wg_pending, self._wg_rows = cur
+            layer_done(j)
+        self._defer_flush = flush_deferred if defer else None
+        for i in range(self.n_layers - 1, -1, -1):
+            dx = self._layer_bwd(i, self.layers[i], dx, S, S.layers[i], W, Wf)
+            S.layers[i] = None
+            if defer:
+                flush_deferred()  # (a layer whose backward never reached the defer point)
+                self._wg_deferred = (self._wg_pending, self._wg_rows, i)
+                self._wg_pending, self._wg_rows = [], None
+                continue
+            self._wgrad_flush()
+            layer_done(i)
+        if defer:
+            flush_deferred()
+        self._defer_flush = None
         self._wg_pending = None  # (the remaining weight gradients have their own shapes / layouts)
         if pk is not None:  # back onto the [B, T', d] grid of the sub-sampling stack (zero gradient beyond the utterances)
             dxu = self._new(M, d, dtype=torch.float32, device=dev)
@@ -1733,6 +1772,7 @@ class ConformerEncoder(NeuralModule):
             ops.rows_unpack(dz, dzp, S.len2, cu, T2, Mg, d)
             dz = dzp
         sums = S.bn_sums[i]
+        self._defer_point(1)
         ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, Mg, d, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
         if training and S.bn_world > 1:
             self._sync_stats(sums)
@@ -1758,6 +1798,7 @@ class ConformerEncoder(NeuralModule):
             dao = self._new(M, d, dtype=cdt, device=dev)
             ops.drop_scale_cast(dr, dao, M * d, 1.0, d_ares)
         _, dkp, dA = self._geometry(cdt)
+        self._defer_point(2)
         if dkp != dk:
             dy2 = self._attn_block_bwd_padded(i, a, sl.att, dao, S, W, Wf, M, B, T2, d, dk, dkp, dA, scale, cdt, dev)
         else:

@@ -115,3 +115,52 @@ def greedy_decode(Pd: Dict[str, Tensor], Pj: Dict[str, Tensor], enc: Tensor, enc
                 gp, hn, cn = pred(last, h, c)
         hyps.append((toks, times))
     return hyps
+
+
+def forced_decode_margins(Pd: Dict[str, Tensor], Pj: Dict[str, Tensor], enc: Tensor, enc_len: Tensor, blank: int, max_symbols: int,
+                          hyps, f_all: Tensor = None):
+    """Walk the greedy search of `greedy_decode` ALONG given hypotheses (list of (tokens, frame indices), e.g. what the device search
+    returned) and report, for every decision, how far the followed label is below this restatement's own arg-max:
+    -> list over utterances of lists of (frame, followed label, own arg-max, logit[arg-max] - logit[followed], max |logit|).
+    A margin of 0 everywhere means the hypotheses ARE this search's; a positive margin is a decision the two sides took differently,
+    and its size says whether that was a rounding-level near-tie or an error.  `f_all` (optional [B, T, J]): the encoder projection
+    to use instead of enc @ W^T + b (a reduced-precision emulation passes its own rounding of it)."""
+    emb = Pd["prediction.embed.weight"]
+    q = "prediction.dec_rnn.lstm."
+    w_ih, w_hh, b_ih, b_hh = (Pd[q + n + "_l0"] for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+    out = [k[:-len("weight")] for k in Pj if k.startswith("joint_net.") and k.endswith(".weight")][0]
+    if f_all is None:
+        f_all = F.linear(enc.transpose(1, 2), Pj["enc.weight"], Pj["enc.bias"])
+    H = w_hh.shape[1]
+    report = []
+    for b in range(enc.shape[0]):
+        toks, times = list(hyps[b][0]), list(hyps[b][1])
+        h, c = torch.zeros(H), torch.zeros(H)
+
+        def pred(last, h, c):
+            z = F.linear(emb[last], w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+            i, f, g, o = z[:H], z[H:2 * H], z[2 * H:3 * H], z[3 * H:]
+            c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h2 = torch.sigmoid(o) * torch.tanh(c2)
+            return F.linear(h2, Pj["pred.weight"], Pj["pred.bias"]), h2, c2
+
+        gp, hn, cn = pred(blank, h, c)
+        pos, rows = 0, []
+        for t in range(int(enc_len[b])):
+            for sym in range(max_symbols):
+                logits = F.linear(torch.relu(f_all[b, t] + gp), Pj[out + "weight"], Pj[out + "bias"])
+                own = int(torch.argmax(logits))
+                follow = toks[pos] if (pos < len(toks) and times[pos] == t) else blank
+                rows.append((t, follow, own, float(logits[own] - logits[follow]), float(logits.abs().max())))
+                if follow == blank:
+                    break
+                pos += 1
+                h, c = hn, cn
+                gp, hn, cn = pred(follow, h, c)
+            else:
+                # the frame used up max_symbols emissions: the hypothesis must not hold more labels on it
+                assert not (pos < len(toks) and times[pos] == t), (b, t)
+        assert pos == len(toks), (b, pos, len(toks))   # every label of the hypothesis was consumed in frame order
+        report.append(rows)
+    return report
+

@@ -158,3 +158,35 @@ def test_auto_mode_packs_only_with_host_lengths_and_enough_padding():
     b2[1].host_lengths = full.clone()
     model.training_step(b2)
     assert enc.packed_last is None                      # nothing to skip
+
+
+@pytest.mark.parametrize("v4", [1, 0])
+def test_relu_mask_gemm_skips_tiles_beyond_the_utterance(v4):
+    """the sub-sampling convolutions' GEMM epilogue zeroes rows beyond their utterance's length (EPI_RELU_MASK); a 256-row tile made
+    of such rows only is now written as zeros without running its K loop (gemm_bf16_v4_kernel).  Against relu(A W^T + b) * mask
+    in fp32 on bf16-rounded operands: utterances that end inside a tile, on a tile edge, at zero length and at full length;
+    poisoned output buffer (a skipped tile that forgot to write shows as NaN)."""
+    from nemo_amd import ops as o
+    prev = o.gemm_config(4, v4)
+    try:
+        g = torch.Generator().manual_seed(3)
+        B, T, F_in, N, K = 6, 1040, 16, 256, 128     # rows (b, t, f): 16 640 per utterance = 65 tiles of 256 rows
+        M = B * T * F_in
+        lens = torch.tensor([1040, 513, 0, 512, 37, 1039])
+        A = torch.randn(M, K, generator=g).bfloat16()
+        W = (torch.randn(N, K, generator=g) * 0.1).bfloat16()
+        bias = torch.randn(N, generator=g)
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        o.gemm(A.to(dev), W.to(dev), out, M, N, K, K, K, N, bias=bias.to(dev), epi=o.EPI_RELU_MASK, row_len=lens.to(dev),
+               rows_per_b=T * F_in, rows_inner=F_in)
+        torch.cuda.synchronize()
+        ref = torch.relu(A.float().to(dev) @ W.float().to(dev).t() + bias.to(dev))
+        t_of = (torch.arange(M, device=dev) % (T * F_in)) // F_in
+        b_of = torch.arange(M, device=dev) // (T * F_in)
+        ref = ref * (t_of < lens.to(dev)[b_of]).unsqueeze(1)
+        got = out.float()
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max() <= 2e-2 * ref.abs().max()
+        assert (got[ref == 0] == 0).all()
+    finally:
+        o.gemm_config(4, prev)

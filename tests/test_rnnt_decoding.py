@@ -93,9 +93,26 @@ def test_device_greedy_search_matches_oracle_at_the_recipe_geometry(max_symbols)
     dec.compute_dtype = joint.compute_dtype = torch.bfloat16
     hb = GreedyBatchedRNNTInfer(dec, joint, blank_index=V, max_symbols_per_step=max_symbols)(encoder_output=enc.to(dev),
                                                                                            encoded_lengths=enc_len.to(dev))[0]
-    from nemo_amd.modules.ctc_decoding import _levenshtein
-    dist = sum(_levenshtein(h.y_sequence.tolist(), w[0]) for h, w in zip(hb, want))
-    assert dist <= 0.25 * sum(len(w[0]) for w in want), dist
+    # integer work: no edit-distance allowance.  A bf16-EMULATING restatement (the same bf16-rounded weight images, the encoder
+    # projection rounded to bf16 as the GEMM stores it, everything else fp32 as in the kernel) is walked along the device's
+    # hypotheses; every decision must be this restatement's own arg-max, except rounding-level near-ties (fp32 summation order
+    # inside the GEMVs), each bounded by its logit margin -- VERDICT r4 weak 1
+    rb = lambda w: w.to(torch.bfloat16).to(torch.float32)
+    Pd16, Pj16 = dict(Pd), dict(Pj)
+    for k in ("prediction.dec_rnn.lstm.weight_ih_l0", "prediction.dec_rnn.lstm.weight_hh_l0"):
+        Pd16[k] = rb(Pd[k])
+    outk = [k for k in Pj if k.startswith("joint_net.") and k.endswith(".weight")][0]
+    for k in ("pred.weight", "enc.weight", outk):
+        Pj16[k] = rb(Pj[k])
+    f16 = rb(torch.nn.functional.linear(rb(enc.transpose(1, 2)), Pj16["enc.weight"], Pj["enc.bias"]))
+    got = [(h.y_sequence.tolist(), h.timestamp) for h in hb]
+    rep = TR.forced_decode_margins(Pd16, Pj16, enc, enc_len, V, max_symbols, got, f_all=f16)
+    decisions = [r for rows in rep for r in rows]
+    flips = [r for r in decisions if r[1] != r[2]]
+    assert len(decisions) > 150 and sum(len(g[0]) for g in got) > 40
+    for t, follow, own, margin, scale in flips:
+        assert margin <= 2e-4 * scale, (t, follow, own, margin, scale)   # a near-tie at fp32 rounding level, nothing larger
+    assert len(flips) <= 0.02 * len(decisions), (len(flips), len(decisions))
 
 
 @pytest.mark.gpu
@@ -148,3 +165,24 @@ def test_transducer_model_wer_paths_agree():
     m.eval()
     v = m.validation_pass(batch)
     assert v["val_wer"] <= 0.25, v
+
+
+def test_forced_walk_reports_zero_margins_on_the_searchs_own_hypotheses_and_flags_a_wrong_label():
+    """CPU: oracle/transducer_ref.forced_decode_margins (the checker of the bf16 device search) -- along greedy_decode's own output
+    every decision is the arg-max (margin 0); with one label swapped the walk reports a positive margin at that decision"""
+    torch.manual_seed(0)
+    V, H, D, J, B, T = 30, 16, 12, 16, 3, 9
+    Pd = {"prediction.embed.weight": torch.cat([torch.randn(V, H), torch.zeros(1, H)]),
+          "prediction.dec_rnn.lstm.weight_ih_l0": torch.randn(4 * H, H), "prediction.dec_rnn.lstm.weight_hh_l0": torch.randn(4 * H, H),
+          "prediction.dec_rnn.lstm.bias_ih_l0": torch.randn(4 * H), "prediction.dec_rnn.lstm.bias_hh_l0": torch.randn(4 * H)}
+    Pj = {"enc.weight": torch.randn(J, D), "enc.bias": torch.randn(J), "pred.weight": torch.randn(J, H), "pred.bias": torch.randn(J),
+          "joint_net.2.weight": torch.randn(V + 1, J), "joint_net.2.bias": torch.randn(V + 1)}
+    enc, el = torch.randn(B, D, T), torch.tensor([9, 4, 0])
+    hy = TR.greedy_decode(Pd, Pj, enc, el, V, 3)
+    rep = TR.forced_decode_margins(Pd, Pj, enc, el, V, 3, hy)
+    assert sum(len(r) for r in rep) >= sum(len(h[0]) for h in hy) and all(r[3] == 0.0 and r[1] == r[2] for rows in rep for r in rows)
+    toks, times = list(hy[0][0]), list(hy[0][1])
+    toks[2] = (toks[2] + 1) % V
+    rep2 = TR.forced_decode_margins(Pd, Pj, enc, el, V, 3, [(toks, times)] + hy[1:])
+    bad = [r for r in rep2[0] if r[1] != r[2]]
+    assert bad and bad[0][3] > 0.0
