@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(GemmP p) {
 // in ONE launch.  A layer's eight weight gradients are 8-32 output tiles each: launched one by one they need split-K 8-16
 // to fill the chip (8-16 atomic passes over every gradient, half-empty launches for the 512x512 ones); together they are
 // 184 tiles, so split-K 4 fills three rounds of the 256 CUs with twice as long K loops and half the atomic traffic.
-#define GRP_MAX 12
+#define GRP_MAX 40
 struct GroupP {
   const void* A[GRP_MAX]; const void* B[GRP_MAX]; void* C[GRP_MAX]; float* colsum[GRP_MAX];
   int M[GRP_MAX], N[GRP_MAX];

@@ -294,6 +294,10 @@ class ConformerEncoder(NeuralModule):
         # elementwise block / its attention backward (_defer_point; profiles/r5_wgrad_lane.md)
         # Round 5, same box, alternating: live launches 40.15 -> 39.68 ms with 1 (39.93 with 2), launch tapes 40.33 -> 40.08 ms.
         self.wgrad_defer = int(os.environ.get("MI355X_WGRAD_DEFER", "1"))
+        # how many layers' weight gradients go out as ONE grouped launch (with wgrad_defer): larger groups fill whole rounds of the
+        # chip with longer K loops per workgroup and meet the main chain less often (1: 39.29 ms, 2: 39.17 ms same box, in-process)
+        self.wgrad_layers = int(os.environ.get("MI355X_WGRAD_LAYERS", "2"))
+        self.posproj_side = os.environ.get("MI355X_POSPROJ_SIDE", "1") != "0"  # linear_pos weight gradients behind their producers on the side stream
         self._wg_pending, self._wg_rows = None, None
         self.conv2_implicit = os.environ.get("MI355X_CONV2_IMPLICIT", "1") != "0"
         self.ln_cast_fuse = os.environ.get("MI355X_LN_CAST_FUSE", "1") != "0"
@@ -323,6 +327,10 @@ class ConformerEncoder(NeuralModule):
         # how a recorded segment runs again: as a LAUNCH TAPE (csrc/tape.hip: the captured nodes re-issued as live launches from
         # one C loop; default) or, MI355X_TAPE=0, as a hipGraph replay (3-4 % slower on the device timeline, r3_host_issue.md)
         self.graph_tape = os.environ.get("MI355X_TAPE", "1") != "0"
+        # MI355X_GRAPHS_BWD_LIVE=1: only the FORWARD sequence is replayed (its ~300 short launches are where the Python sequencer
+        # cannot keep ahead of the device); the backward keeps live launches, whose issue order in time -- weight gradients entering
+        # the side stream when the host gets there -- measured better on the device than the replay's (profiles/r5_launch_modes.md)
+        self.graph_bwd_live = os.environ.get("MI355X_GRAPHS_BWD_LIVE", "0") != "0"
         self.graph_warmup = 2       # eager training forwards per key before its launch sequence is captured
         self.graph_trials = 4       # auto: timed steps per mode, alternating
         self.max_graph_sets = 8     # distinct (shape, configuration) keys kept (a duration-bucketed loader has a handful)
@@ -528,7 +536,7 @@ class ConformerEncoder(NeuralModule):
                 self.grad_ready_hook is not None, self._wgrad_join_per_layer, self.wgrad_side_stream, self.wgrad_grouped,
                 self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse,
                 self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.graph_tape, self.swish_g, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder,
-                self.wgrad_defer)
+                self.wgrad_defer, self.graph_bwd_live, self.posproj_side, self.wgrad_layers)
 
     def _auto_begin(self, gs, mode):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -649,6 +657,19 @@ class ConformerEncoder(NeuralModule):
             raise RuntimeError("backward through an encoder forward whose saved activations were overwritten by a later forward "
                                "of the same shape (recorded launch sequences keep ONE set of activations per shape); set "
                                "encoder.use_graphs = False (or MI355X_GRAPHS=0) for several forwards per backward")
+        if self.graph_bwd_live and gs.bwd is None:
+            # live backward on the activations the replayed forward has just refilled (the recording's tensors keep their addresses);
+            # the sequencer consumes its bag of saved tensors, so it gets a copy of the bag
+            import copy
+            S = copy.copy(gs.S)
+            S.layers = list(gs.S.layers)
+            S.serial = self._fwd_serial
+            ops.set_step_counter(self._step_word)   # dropout keys: the device-side step word the recorded forward advanced
+            try:
+                self._backward_impl(S, dout)
+            finally:
+                ops.set_step_counter(None)
+            return
         if gs.bwd is None:
             gs.dout = torch.empty_like(dout)
             gs.dout.copy_(dout)
@@ -742,7 +763,7 @@ class ConformerEncoder(NeuralModule):
             # deferred: all weight gradients of the layer go out as ONE grouped launch (_wgrad_flush)
             self._wg_pending.append((dY, ldy, y_off, X, ldx, x_off, dW, n_out, n_in, bias_grad))
             self._wg_rows = rows
-            if len(self._wg_pending) == 12:
+            if len(self._wg_pending) == 12:   # (one layer never collects that many; mi355x_gemm_grouped takes up to 40)
                 self._wgrad_flush()
             return
         tiles = self._tiles(n_out, n_in, bf16)
@@ -799,8 +820,14 @@ class ConformerEncoder(NeuralModule):
         """see _backward_impl: point k of a layer's backward (1 = in front of the conv module's BatchNorm / depthwise / GLU
         backward, 2 = in front of the attention backward)"""
         f = getattr(self, "_defer_flush", None)
-        if f is not None and self.wgrad_defer == k:
+        if f is None:
+            return
+        if self.wgrad_defer == k or (self.wgrad_defer in (3, 4) and k == 1):
             f()
+        elif (self.wgrad_defer == 3 and k == 2) or (self.wgrad_defer == 4 and k == 3):
+            # split: what this layer has collected so far (feed-forward 2 + conv module) goes now, beside its own attention backward /
+            # its own LayerNorm; the rest (attention + feed-forward 1) waits for the next layer's point 1
+            self._wgrad_flush()
 
     def _wgrad_join(self, consume=False):
         """consume=True: the MAIN chain itself reads, right after this call, something the side stream produced"""
@@ -1506,24 +1533,33 @@ class ConformerEncoder(NeuralModule):
                     self._wgrad_join()
                 self._hook(*fp.range_of(f"layers.{j}."))
 
-        def flush_deferred():
-            # the grouped weight-gradient launch of the layer ABOVE, issued at the point of this layer's backward where the main
+        nlay = max(1, min(4, self.wgrad_layers)) if defer else 1   # layers' weight gradients per grouped launch
+        pair = nlay > 1
+
+        def flush_deferred(force=True):
+            # the grouped weight-gradient launch of the layer(s) ABOVE, issued at the point of this layer's backward where the main
             # chain runs kernels that share a CU with it (self.wgrad_defer) -- not beside the next layer's first GEMMs
-            dfr, self._wg_deferred = self._wg_deferred, None
-            if dfr is None:
+            dfr = self._wg_deferred
+            if dfr is None or (pair and not force and len(dfr[2]) < nlay):
                 return
+            self._wg_deferred = None
             cur = (self._wg_pending, self._wg_rows)
-            self._wg_pending, self._wg_rows, j = dfr
+            self._wg_pending, self._wg_rows, js = dfr
             self._wgrad_flush()
             self._wg_pending, self._wg_rows = cur
-            layer_done(j)
-        self._defer_flush = flush_deferred if defer else None
+            for j in js:
+                layer_done(j)
+        self._defer_flush = (lambda: flush_deferred(force=not pair)) if defer else None
         for i in range(self.n_layers - 1, -1, -1):
             dx = self._layer_bwd(i, self.layers[i], dx, S, S.layers[i], W, Wf)
             S.layers[i] = None
             if defer:
-                flush_deferred()  # (a layer whose backward never reached the defer point)
-                self._wg_deferred = (self._wg_pending, self._wg_rows, i)
+                dfr = self._wg_deferred
+                if pair and dfr is not None and len(dfr[2]) < nlay and dfr[1] == self._wg_rows:
+                    self._wg_deferred = (dfr[0] + self._wg_pending, dfr[1], dfr[2] + [i])
+                else:
+                    flush_deferred()  # (a layer whose backward never reached the defer point)
+                    self._wg_deferred = (self._wg_pending, self._wg_rows, [i])
                 self._wg_pending, self._wg_rows = [], None
                 continue
             self._wgrad_flush()
@@ -1536,8 +1572,16 @@ class ConformerEncoder(NeuralModule):
             dxu = self._new(M, d, dtype=torch.float32, device=dev)
             ops.rows_unpack(dx, dxu, S.len2, pk.cu, T2, M, d)
             dx = dxu
-        self._wgrad_join(consume=True)       # dp_all may have been produced on the side stream
-        self._pos_proj_wgrad(S.dp_all, S.pos, P, cdt)
+        # the linear_pos weight gradients consume dp_all, which the side stream produced (dpos kernels): they run THERE, behind
+        # their producers, instead of making the main chain wait for the whole weight-gradient lane in front of the sub-sampling
+        # backward (a 330-us bubble per step on the main stream, profiles/r5_launch_modes.md).  Without a side stream the scope is
+        # empty and everything is in stream order anyway.
+        if self.posproj_side:
+            with self._wgrad_scope(S.dp_all, S.pos):
+                self._pos_proj_wgrad(S.dp_all, S.pos, P, cdt)
+        else:
+            self._wgrad_join(consume=True)
+            self._pos_proj_wgrad(S.dp_all, S.pos, P, cdt)
         if self.grad_ready_hook is not None:
             self._hook(*fp.tail_range())
         # ---- sub-sampling backward
@@ -1786,6 +1830,7 @@ class ConformerEncoder(NeuralModule):
         dy3 = self._new(M, d, dtype=cdt, device=dev)
         ops.gemm(dpw1, W[f"L{i}.conv.pw1t"], dy3, M, d, 2 * d, 2 * d, W.pitch(f"L{i}.conv.pw1t"), d)
         ln = L.norm_conv
+        self._defer_point(3)
         nc = (1.0, sl.att[12])
         dao_pre = self._cast_buf(nc, M, d, cdt, dev)
         ops.layernorm_bwd(dy3, r2, ln.weight, mean3, rstd3, dr, True, ln.weight.grad, ln.bias.grad, M, d, cast_out=dao_pre,
