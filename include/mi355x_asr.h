@@ -279,7 +279,8 @@ int mi355x_relpos_softmax_bwd(const void* dpd, int dpd_dtype, const void* s_in, 
                               int B, int T, int Tp, int Pp, float scale, unsigned drop_key, unsigned drop_threshold,
                               float drop_scale, void* stream);
 
-/* ---- fused rel-pos attention (bf16, d_k = 64): RelPositionMultiHeadAttention.forward, multi_head_attention.py:272-354.
+/* ---- fused rel-pos attention (bf16; head width dk = 64 or 128 -- narrower / in-between heads are zero-padded inside the packed
+ * weight images by the encoders: 44 -> 64, 81 -> 128): RelPositionMultiHeadAttention.forward, multi_head_attention.py:272-354.
  * qkv [B*T, ldq = 3d] (q|k|v), pos = linear_pos(pos_emb) [2T-1, ldp], bias_u/v f32 [H*d_k], len i64 [B]
  * -> ctx [B*T, ldo] bf16, lse f32 [B,H,T] (log-sum-exp of the masked scaled scores, kept for backward).
  * ctx_lo (optional, same layout as ctx): the bf16 ROUNDING RESIDUAL of ctx (O = ctx + ctx_lo to ~16 mantissa bits) for

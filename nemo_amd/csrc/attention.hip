@@ -50,7 +50,9 @@ __device__ __forceinline__ void dma4(const void* src, const void* lds_base) {  /
                : "memory");
 }
 
-#define ADK 64           // head dim
+// head width: a template parameter of every kernel (ADK = 64: the tuned form, two workgroups per CU; ADK = 128 -- round 5, heads of
+// 65..128 lanes zero-padded to 128, Squeezeformer-Medium's d_k = 81 -- the same code with 8 k-steps, 4 output tiles and one
+// workgroup per CU).  Rows of every staged tile are ADK elements = ADK / 8 sixteen-byte chunks.
 #define ABQ 128          // queries per workgroup (4 waves x 32)
 #define ABK 32           // keys per step
 #define ABAND (ABQ + ABK)  // positional band rows staged per step (159 needed)
@@ -94,16 +96,19 @@ __device__ __forceinline__ float attn_drop(const DropCfg& d, uint32_t akey, int 
   return attn_keep(d, akey, i, j) ? d.scale : 0.f;
 }
 
+template <int ADK>
 __device__ __forceinline__ int a_off(int r, int chunk) { return r * ADK + ((chunk ^ ((r >> 1) & 7)) << 3); }
 
 // rows [row0, row0+nrows) x 64 columns (col offset applied by caller) -> LDS image [nrows][64] with the (row>>1)&7 swizzle
-// applied on the source side; rows are clamped into [0, rmax]
+// applied on the source side; rows are clamped into [0, rmax]; nchunks = rows * (ADK / 8)
+template <int ADK>
 __device__ __forceinline__ void stage_rows(const bf16_t* base, long long ld, int row0, int rmax, bf16_t* lds, int nchunks) {
+  constexpr int NCH = ADK / 8;
   const int wave = threadIdx.x >> 6;
   for (int q0 = 0; q0 < nchunks; q0 += 256) {
     const int q = q0 + threadIdx.x;
     if (q0 + wave * 64 < nchunks) {  // wave-uniform
-      const int r = q >> 3, ck = q & 7;
+      const int r = q / NCH, ck = q % NCH;
       const int gck = ck ^ ((r >> 1) & 7);
       int gr = row0 + r;
       gr = gr < 0 ? 0 : (gr > rmax ? rmax : gr);
@@ -115,19 +120,25 @@ __device__ __forceinline__ void stage_rows(const bf16_t* base, long long ld, int
     }
   }
 }
-// V tile [32 keys][64 dv] kept exactly as in memory (for the transpose read), chunk swizzle c ^= (k&3)<<1
+// V tile [32 keys][ADK dv] kept exactly as in memory (for the transpose read), chunk swizzle c ^= (k&3)<<1
+template <int ADK>
 __device__ __forceinline__ void stage_v(const bf16_t* base, long long ld, int row0, int rmax, bf16_t* lds) {
+  constexpr int NCH = ADK / 8;
   const int wave = threadIdx.x >> 6;
-  const int q = threadIdx.x;  // 256 chunks
-  const int k = q >> 3, cp = q & 7;
-  const int c = cp ^ ((k & 3) << 1);
-  int gr = row0 + k;
-  gr = gr > rmax ? rmax : gr;
-  const bf16_t* src = base + __mul24(gr, (int)ld) + c * 8;
-  bf16_t* dst = lds + (wave * 64) * 8;
-  dma16(src, dst);
+#pragma unroll
+  for (int q0 = 0; q0 < 32 * NCH; q0 += 256) {  // 256 chunks per pass
+    const int q = q0 + threadIdx.x;
+    const int k = q / NCH, cp = q % NCH;
+    const int c = cp ^ ((k & 3) << 1);
+    int gr = row0 + k;
+    gr = gr > rmax ? rmax : gr;
+    const bf16_t* src = base + __mul24(gr, (int)ld) + c * 8;
+    bf16_t* dst = lds + (q0 + wave * 64) * 8;
+    dma16(src, dst);
+  }
 }
 // A fragment of V^T for the P.V product: lane (dv = dv0 + (lane&31)) gets V[key slots of (s, half)][dv]
+template <int ADK>
 __device__ __forceinline__ bf16x8 vt_frag(const bf16_t* vt, int dv0, int s, int lane) {
   const int t = lane & 15, g4 = (lane >> 4) & 1, lh = lane >> 5;
   const int col = dv0 + g4 * 16 + (t & 3) * 4;
@@ -149,9 +160,10 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 }
 
 // q fragments (B operand): lane holds (q + bias)[query = lane&31][dk = kk*16 + (lane>>5)*8 + e]
-__device__ __forceinline__ void load_q(const bf16_t* qrow, const float* bias, bf16x8 (&out)[4], bool valid, int lh) {
+template <int NKK>
+__device__ __forceinline__ void load_q(const bf16_t* qrow, const float* bias, bf16x8 (&out)[NKK], bool valid, int lh) {
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
+  for (int kk = 0; kk < NKK; ++kk) {
     float v[8];
     const int k0 = kk * 16 + lh * 8;
     if (valid) {
@@ -168,7 +180,8 @@ __device__ __forceinline__ void load_q(const bf16_t* qrow, const float* bias, bf
   }
 }
 
-__global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* __restrict__ qkv, long long ldq,
+template <int ADK>
+__global__ __launch_bounds__(256, ADK == 64 ? 2 : 1) void relpos_flash_fwd_kernel(const bf16_t* __restrict__ qkv, long long ldq,
                                                                   const bf16_t* __restrict__ pos, long long ldp,
                                                                   const float* __restrict__ bias_u, const float* __restrict__ bias_v,
                                                                   const long long* __restrict__ len, bf16_t* __restrict__ ctx,
@@ -177,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
                                                                   int Tp, float scale, DropCfg drop,
                                                                   const long long* __restrict__ cu) {
   drop_resolve(drop);
+  constexpr int NKK = ADK / 16, NDT = ADK / 32, NCH = ADK / 8;
   __shared__ __attribute__((aligned(16))) bf16_t s_k2[2][ABK * ADK];   // 2 x 4 KiB (double-buffered)
   __shared__ __attribute__((aligned(16))) bf16_t s_v2[2][ABK * ADK];   // 2 x 4 KiB
   __shared__ __attribute__((aligned(16))) bf16_t s_p[APRING * 32 * ADK];  // 24 KiB: ring of 6 blocks of 32 band rows
@@ -207,13 +221,15 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
   const bf16_t* vbase = qbase + 2 * (ldq / 3);
   const bf16_t* pbase = pos + h * ADK;
 
-  bf16x8 qu[4], qv[4];
-  load_q(qbase + (long long)(i < Tr ? i : Trc) * ldq, bias_u + h * ADK, qu, i < Tr, lh);
-  load_q(qbase + (long long)(i < Tr ? i : Trc) * ldq, bias_v + h * ADK, qv, i < Tr, lh);
+  bf16x8 qu[NKK], qv[NKK];
+  load_q<NKK>(qbase + (long long)(i < Tr ? i : Trc) * ldq, bias_u + h * ADK, qu, i < Tr, lh);
+  load_q<NKK>(qbase + (long long)(i < Tr ? i : Trc) * ldq, bias_v + h * ADK, qv, i < Tr, lh);
 
-  f32x16 o[2];
+  f32x16 o[NDT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  for (int t = 0; t < NDT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   float* sg = s_g[wave];
   const uint32_t akey = attn_key(drop, b, h);
@@ -229,18 +245,18 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
   // compiler does not wait for it in front of the step's own LDS reads), behind a single barrier per step.
   const int c0 = T - 1 - (i0_blk + ABQ - 1);
   if (nkt > 0) {
-    stage_rows(kbase, ldq, 0, Trc, s_k2[0], ABK * 8);
-    stage_v(vbase, ldq, 0, Trc, s_v2[0]);
-    stage_rows(pbase, ldp, c0, P - 1, s_p, ABAND * 8);
+    stage_rows<ADK>(kbase, ldq, 0, Trc, s_k2[0], ABK * NCH);
+    stage_v<ADK>(vbase, ldq, 0, Trc, s_v2[0]);
+    stage_rows<ADK>(pbase, ldp, c0, P - 1, s_p, ABAND * NCH);
   }
   for (int kt = 0; kt < nkt; ++kt) {
     const int j0 = kt * ABK;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt has landed; every wave is done reading tile kt-1
     if (kt + 1 < nkt) {
-      stage_rows(kbase, ldq, j0 + ABK, Trc, s_k2[(kt + 1) & 1], ABK * 8);
-      stage_v(vbase, ldq, j0 + ABK, Trc, s_v2[(kt + 1) & 1]);
-      stage_rows(pbase, ldp, c0 + 32 * (kt + 5), P - 1, s_p + ((kt + 5) % APRING) * (32 * ADK), 32 * 8);
+      stage_rows<ADK>(kbase, ldq, j0 + ABK, Trc, s_k2[(kt + 1) & 1], ABK * NCH);
+      stage_v<ADK>(vbase, ldq, j0 + ABK, Trc, s_v2[(kt + 1) & 1]);
+      stage_rows<ADK>(pbase, ldp, c0 + 32 * (kt + 5), P - 1, s_p + ((kt + 5) % APRING) * (32 * ADK), 32 * NCH);
     }
     const bf16_t* s_k = s_k2[kt & 1];
     const bf16_t* s_v = s_v2[kt & 1];
@@ -252,12 +268,12 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc_s[r] = 0.f; acc_g[0][r] = 0.f; acc_g[1][r] = 0.f; }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s_k + a_off(q, kk * 2 + lh));
+    for (int kk = 0; kk < NKK; ++kk) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s_k + a_off<ADK>(q, kk * 2 + lh));
       acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[kk], acc_s, 0, 0, 0);
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) {
-        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off((gt ? slot1 : slot0) * 32 + q, kk * 2 + lh));
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off<ADK>((gt ? slot1 : slot0) * 32 + q, kk * 2 + lh));
         acc_g[gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qv[kk], acc_g[gt], 0, 0, 0);
       }
     }
@@ -327,8 +343,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
     for (int st = 0; st < 2; ++st) {
       const bf16x8 pb = pack8(&s[8 * st]);
 #pragma unroll
-      for (int dvt = 0; dvt < 2; ++dvt) {
-        const bf16x8 vf = vt_frag(s_v, dvt * 32, st, lane);
+      for (int dvt = 0; dvt < NDT; ++dvt) {
+        const bf16x8 vf = vt_frag<ADK>(s_v, dvt * 32, st, lane);
         o[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[dvt], 0, 0, 0);
       }
     }
@@ -337,23 +353,25 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
   // ---- normalise, transpose O^T -> O through LDS (per wave: [32 queries][64 dv] f32, pitch 66) and store rows
   const float inv = (qvalid && l_run > 0.f) ? (drop.threshold != 0u ? drop.scale : 1.f) / l_run : 0.f;
   __syncthreads();
+  if (lse && lh == 0 && i < T) lse[((long long)b * H + h) * T + i] = qvalid ? m_run * scale + __logf(l_run) : 0.f;
+#pragma unroll
+  for (int half = 0; half < NDT / 2; ++half) {   // the [32][66] tile holds 64 dv columns: wider heads go through it in halves
 #pragma unroll
   for (int dvt = 0; dvt < 2; ++dvt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sg[q * SG_LD + dvt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = o[dvt][r] * inv;
+    for (int r = 0; r < 16; ++r) sg[q * SG_LD + dvt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = o[2 * half + dvt][r] * inv;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (lse && lh == 0 && i < T) lse[((long long)b * H + h) * T + i] = qvalid ? m_run * scale + __logf(l_run) : 0.f;
   // 32 rows x 64 dv: lane -> (row = it*8 + lane/8, 8-column chunk = lane%8)
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+    const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8, co = half * 64 + c8;
     const int ii = i0_blk + wave * 32 + row;
     if (ii < Tr) {
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = sg[row * SG_LD + c8 + j];
       u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-      *reinterpret_cast<u32x4*>(ctx + (row0 + ii) * ldo + h * ADK + c8) = t;
+      *reinterpret_cast<u32x4*>(ctx + (row0 + ii) * ldo + h * ADK + co) = t;
       if (ctx_lo) {
         // what the bf16 rounding of O dropped, itself as bf16 (O = hi + lo to ~16 mantissa bits): backward's
         // delta = sum dO * O multiplies a gradient that nearly cancels (dS = P * (dP - delta)); with delta taken from the
@@ -366,9 +384,11 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
           lo[2 * j + 1] = v[2 * j + 1] - __uint_as_float(t[j] & 0xffff0000u);
         }
         u32x4 tl = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(lo[4], lo[5]), pack_bf2(lo[6], lo[7])};
-        *reinterpret_cast<u32x4*>(ctx_lo + (row0 + ii) * ldo + h * ADK + c8) = tl;
+        *reinterpret_cast<u32x4*>(ctx_lo + (row0 + ii) * ldo + h * ADK + co) = tl;
       }
     }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 
@@ -379,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_fwd_kernel(const bf16_t* 
 // O_lo (optional) = the rounding residual of O written by the forward kernel
 // QB: the same pass also writes qu = q + pos_bias_u and qv = q + pos_bias_v (rows of the fused projection, multi_head_attention.py:
 // 288-291), the operands the two backward kernels stage by LDS-DMA -- one launch instead of two in front of every layer's dQ kernel
-template <bool QB>
+template <bool QB, int ADK>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
                                                          const bf16_t* __restrict__ O_lo, float* __restrict__ delta,
                                                          const bf16_t* __restrict__ qkv, long long ldq,
@@ -428,13 +448,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
       }
     }
     acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+    if (ADK == 128) acc += __shfl_xor(acc, 8, 64);   // ADK / 8 lanes per head
     const int h = c / ADK;
-    if ((lane & 7) == 0 && c < d) delta[((long long)b * H + h) * T + i] = acc;
+    if ((lane & (ADK / 8 - 1)) == 0 && c < d) delta[((long long)b * H + h) * T + i] = acc;
   }
 }
 
 // fragment (8 k-slots) for an MFMA A operand taken TRANSPOSED out of a row-major [row][64] image with the (row>>1)&7
 // chunk swizzle: slots 0-3 <- rows ra..ra+3, slots 4-7 <- rows rb..rb+3, all at column col0 + (lane&31)
+template <int ADK>
 __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int ra, int rb, int col0, int lane) {
   const int t = lane & 15, g4 = (lane >> 4) & 1;
   const int col = col0 + g4 * 16 + (t & 3) * 4;
@@ -445,9 +467,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int ra, int rb, int
   return u.v;
 }
 // plain row fragments of a [M, d] bf16 matrix as MFMA B operand: lane holds x[row][col0 + kk*16 + (lane>>5)*8 + e]
-__device__ __forceinline__ void load_rows(const bf16_t* rowp, bf16x8 (&out)[4], bool valid, int lh) {
+template <int NKK>
+__device__ __forceinline__ void load_rows(const bf16_t* rowp, bf16x8 (&out)[NKK], bool valid, int lh) {
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
+  for (int kk = 0; kk < NKK; ++kk) {
     union { bf16x8 v; u32x4 w; } u;
     u.w = (u32x4){0u, 0u, 0u, 0u};
     if (valid) u.w = *reinterpret_cast<const u32x4*>(rowp + kk * 16 + lh * 8);
@@ -456,7 +479,8 @@ __device__ __forceinline__ void load_rows(const bf16_t* rowp, bf16x8 (&out)[4], 
 }
 
 // dQu / dQv for one 128-query tile (lane = query, same structure as the forward)
-__global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
+template <int ADK>
+__global__ __launch_bounds__(256, ADK == 64 ? 2 : 1) void relpos_flash_bwd_dq_kernel(
     const bf16_t* __restrict__ qu_g, const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ qkv, long long ldq,
     const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqu_out,
@@ -464,6 +488,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     float* __restrict__ cs_partial, int B, int H, int T, int d, float scale, DropCfg drop,
     const long long* __restrict__ cu) {
   drop_resolve(drop);
+  constexpr int NKK = ADK / 16, NDT = ADK / 32, NCH = ADK / 8;
   __shared__ __attribute__((aligned(16))) bf16_t s_k2[2][ABK * ADK];       // double-buffered (read until the end of a step)
   __shared__ __attribute__((aligned(16))) bf16_t s_v[ABK * ADK];           // read in the first MFMA block only
   __shared__ __attribute__((aligned(16))) bf16_t s_p[APRING * 32 * ADK];   // positional band: ring of 32-row blocks (see forward)
@@ -484,8 +509,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   if (cu && i0_blk >= L) {
     // packed rows: no query of this tile exists.  Its dS blocks are never read (the linear_pos gradient kernel skips query tiles
     // beyond the utterance); its slab of the bias-gradient column sums must still be zero for the second-stage reduction.
-    if (dq_out && cs_partial && threadIdx.x < 128) {
-      const int uv = threadIdx.x >> 6, c = threadIdx.x & 63;
+    if (dq_out && cs_partial && threadIdx.x < 2 * ADK) {
+      const int uv = threadIdx.x / ADK, c = threadIdx.x % ADK;
       cs_partial[((long long)b * gridDim.x + blockIdx.x) * (2 * d) + uv * d + h * ADK + c] = 0.f;
     }
     return;
@@ -496,20 +521,22 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   const bf16_t* vbase = kbase + (ldq / 3);
   const bf16_t* pbase = pos + h * ADK;
 
-  bf16x8 qu[4], qv[4], dof[4];
-  load_rows(qu_g + rowi * d + h * ADK, qu, i < Tr, lh);
-  load_rows(qv_g + rowi * d + h * ADK, qv, i < Tr, lh);
-  load_rows(dO + rowi * d + h * ADK, dof, i < Tr, lh);
+  bf16x8 qu[NKK], qv[NKK], dof[NKK];
+  load_rows<NKK>(qu_g + rowi * d + h * ADK, qu, i < Tr, lh);
+  load_rows<NKK>(qv_g + rowi * d + h * ADK, qv, i < Tr, lh);
+  load_rows<NKK>(dO + rowi * d + h * ADK, dof, i < Tr, lh);
   float lse_i = qvalid ? lse[((long long)b * H + h) * T + i] : 1e30f;  // padded query: exp(. - 1e30) = 0
   float dlt_i = qvalid ? delta[((long long)b * H + h) * T + i] : 0.f;
   // (the compiler must wait for these register loads HERE, not at their first use inside the loop: see the dK/dV kernel)
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) { asm volatile("" : "+v"(qu[kk])); asm volatile("" : "+v"(qv[kk])); asm volatile("" : "+v"(dof[kk])); }
+  for (int kk = 0; kk < NKK; ++kk) { asm volatile("" : "+v"(qu[kk])); asm volatile("" : "+v"(qv[kk])); asm volatile("" : "+v"(dof[kk])); }
   asm volatile("" : "+v"(lse_i), "+v"(dlt_i));
 
-  f32x16 dqu[2], dqv[2];
+  f32x16 dqu[NDT], dqv[NDT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { dqu[0][r] = 0.f; dqu[1][r] = 0.f; dqv[0][r] = 0.f; dqv[1][r] = 0.f; }
+  for (int t = 0; t < NDT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dqu[t][r] = 0.f; dqv[t][r] = 0.f; }
   float* sg = s_g[wave];
   const uint32_t akey = attn_key(drop, b, h);
   const uint32_t arow = adrop_rcode(akey, (uint32_t)i >> 2), erow = (uint32_t)(i & 3) * (2u * ADROP_G);
@@ -528,17 +555,17 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   // MFMA block only) is re-staged into its single buffer behind a second barrier as soon as every wave has read it
   const int c0 = T - 1 - (i0_blk + ABQ - 1);
   if (nkt > 0) {
-    stage_rows(kbase, ldq, 0, Trc, s_k2[0], ABK * 8);
-    stage_rows(vbase, ldq, 0, Trc, s_v, ABK * 8);
-    stage_rows(pbase, ldp, c0, P - 1, s_p, ABAND * 8);
+    stage_rows<ADK>(kbase, ldq, 0, Trc, s_k2[0], ABK * NCH);
+    stage_rows<ADK>(vbase, ldq, 0, Trc, s_v, ABK * NCH);
+    stage_rows<ADK>(pbase, ldp, c0, P - 1, s_p, ABAND * NCH);
   }
   for (int kt = 0; kt < nkt; ++kt) {
     const int j0 = kt * ABK;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt has landed; every wave is done with step kt-1
     if (kt + 1 < nkt) {
-      stage_rows(kbase, ldq, j0 + ABK, Trc, s_k2[(kt + 1) & 1], ABK * 8);
-      stage_rows(pbase, ldp, c0 + 32 * (kt + 5), P - 1, s_p + ((kt + 5) % APRING) * (32 * ADK), 32 * 8);
+      stage_rows<ADK>(kbase, ldq, j0 + ABK, Trc, s_k2[(kt + 1) & 1], ABK * NCH);
+      stage_rows<ADK>(pbase, ldp, c0 + 32 * (kt + 5), P - 1, s_p + ((kt + 5) % APRING) * (32 * ADK), 32 * NCH);
     }
     const bf16_t* s_k = s_k2[kt & 1];
     const int slot0 = (kt + 3 - wave) % APRING, slot1 = (kt + 4 - wave) % APRING;  // this wave's two band blocks
@@ -547,20 +574,20 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc_s[r] = 0.f; acc_g[0][r] = 0.f; acc_g[1][r] = 0.f; acc_dp[r] = 0.f; }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s_k + a_off(q, kk * 2 + lh));
+    for (int kk = 0; kk < NKK; ++kk) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s_k + a_off<ADK>(q, kk * 2 + lh));
       acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[kk], acc_s, 0, 0, 0);
-      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(s_v + a_off(q, kk * 2 + lh));
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(s_v + a_off<ADK>(q, kk * 2 + lh));
       acc_dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], acc_dp, 0, 0, 0);  // dP^T[key][query] = V . dO^T
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) {
-        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off((gt ? slot1 : slot0) * 32 + q, kk * 2 + lh));
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off<ADK>((gt ? slot1 : slot0) * 32 + q, kk * 2 + lh));
         acc_g[gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qv[kk], acc_g[gt], 0, 0, 0);
       }
     }
     if (kt + 1 < nkt) {  // (block-uniform)
       __syncthreads();   // every wave has its V fragments
-      stage_rows(vbase, ldq, j0 + ABK, Trc, s_v, ABK * 8);
+      stage_rows<ADK>(vbase, ldq, j0 + ABK, Trc, s_v, ABK * NCH);
     }
 #pragma unroll
     for (int gt = 0; gt < 2; ++gt)
@@ -609,8 +636,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
     for (int st = 0; st < 2; ++st) {
       const bf16x8 db = pack8(&ds[8 * st]);
 #pragma unroll
-      for (int dkt = 0; dkt < 2; ++dkt) {
-        const bf16x8 kt_f = tr_frag(s_k, 16 * st + 4 * lh, 16 * st + 8 + 4 * lh, dkt * 32, lane);
+      for (int dkt = 0; dkt < NDT; ++dkt) {
+        const bf16x8 kt_f = tr_frag<ADK>(s_k, 16 * st + 4 * lh, 16 * st + 8 + 4 * lh, dkt * 32, lane);
         dqu[dkt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt_f, db, dqu[dkt], 0, 0, 0);
       }
     }
@@ -632,9 +659,9 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
       for (int e = 0; e < 8; ++e) gv[e] = sg[q * SG_LD + 16 * s4 + 8 * lh + e];
       const bf16x8 gb = pack8(gv);
 #pragma unroll
-      for (int dkt = 0; dkt < 2; ++dkt) {
+      for (int dkt = 0; dkt < NDT; ++dkt) {
         const int ra = (s4 < 2 ? slot0 : slot1) * 32 + 16 * (s4 & 1) + 8 * lh;
-        const bf16x8 pt_f = tr_frag(s_p, ra, ra + 4, dkt * 32, lane);
+        const bf16x8 pt_f = tr_frag<ADK>(s_p, ra, ra + 4, dkt * 32, lane);
         dqv[dkt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pt_f, gb, dqv[dkt], 0, 0, 0);
       }
     }
@@ -671,21 +698,26 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
   // (d pos_bias_u / d pos_bias_v, multi_head_attention.py:296-300 backward) into row (b, query block) of `cs_partial`
   // [B * gridDim.x][2 * d] -- a second-stage reduction adds the rows; the separate add + column-sum pass does not exist then.
   __syncthreads();
-  float keep[4][8], cs[2][8];
+  constexpr int NH = NDT / 2;   // the [32][66] tile holds 64 columns: wider heads go through it in halves
+  float keep[NH][4][8], cs[2][NH][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { cs[0][j] = 0.f; cs[1][j] = 0.f; }
+  for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cs[0][hf][j] = 0.f; cs[1][hf][j] = 0.f; }
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     bf16_t* outp = pass == 0 ? dqu_out : dqv_out;
 #pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+#pragma unroll
     for (int dkt = 0; dkt < 2; ++dkt)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        sg[q * SG_LD + dkt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = qvalid ? (pass == 0 ? dqu[dkt][r] : dqv[dkt][r]) : 0.f;
+        sg[q * SG_LD + dkt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = qvalid ? (pass == 0 ? dqu[2 * hf + dkt][r] : dqv[2 * hf + dkt][r]) : 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+      const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8, co = hf * 64 + c8;
       const int ii = i0_blk + wave * 32 + row;
       if (ii < Tr) {
         float v[8];
@@ -693,44 +725,49 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
         for (int j = 0; j < 8; ++j) v[j] = sg[row * SG_LD + c8 + j];
         if (outp) {
           u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-          *reinterpret_cast<u32x4*>(outp + (row0 + ii) * d + h * ADK + c8) = t;
+          *reinterpret_cast<u32x4*>(outp + (row0 + ii) * d + h * ADK + co) = t;
         }
         if (dq_out) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) cs[pass][j] += v[j];
+          for (int j = 0; j < 8; ++j) cs[pass][hf][j] += v[j];
           if (pass == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) keep[it][j] = v[j];
+            for (int j = 0; j < 8; ++j) keep[hf][it][j] = v[j];
           } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += keep[it][j];
+            for (int j = 0; j < 8; ++j) v[j] += keep[hf][it][j];
             u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-            *reinterpret_cast<u32x4*>(dq_out + (row0 + ii) * ld_dq + h * ADK + c8) = t;
+            *reinterpret_cast<u32x4*>(dq_out + (row0 + ii) * ld_dq + h * ADK + co) = t;
           }
         }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
   if (dq_out && cs_partial) {
     // rows of a wave: lanes with equal (lane & 7) hold the same 8 columns -> butterfly over lane bits 3..5, then the four waves
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
+      for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float v = cs[pass][j];
+        float v = cs[pass][hf][j];
         v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-        cs[pass][j] = v;
+        cs[pass][hf][j] = v;
       }
     if (lane < 8) {
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sg[pass * 64 + lane * 8 + j] = cs[pass][j];
+        for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sg[pass * ADK + hf * 64 + lane * 8 + j] = cs[pass][hf][j];
     }
     __syncthreads();
-    if (threadIdx.x < 128) {
-      const int uv = threadIdx.x >> 6, c = threadIdx.x & 63;
+    if (threadIdx.x < 2 * ADK) {
+      const int uv = threadIdx.x / ADK, c = threadIdx.x % ADK;
       const float t = (s_g[0][threadIdx.x] + s_g[1][threadIdx.x]) + (s_g[2][threadIdx.x] + s_g[3][threadIdx.x]);
       cs_partial[((long long)b * gridDim.x + blockIdx.x) * (2 * d) + uv * d + h * ADK + c] = t;
     }
@@ -739,7 +776,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dq_kernel(
 
 // dK / dV for one 128-key tile (lane = key): S = Qu K^T, G = Qv P^T with the rel_shift resolved by a lane rotation
 // (bd[query rho][key q] = G[rho][31 + q - rho]: a compile-time shift per register), dV^T += dO^T Pd, dK^T += Qu^T dS.
-__global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
+template <int ADK>
+__global__ __launch_bounds__(256, ADK == 64 ? 2 : 1) void relpos_flash_bwd_dkv_kernel(
     const bf16_t* __restrict__ qu_g, const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ qkv, long long ldq,
     const bf16_t* __restrict__ pos, long long ldp, const long long* __restrict__ len, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqkv, long long ldd, int B, int H,
@@ -747,7 +785,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   drop_resolve(drop);
   // staging (double-buffered query tiles + the positional band as a ring of 32-row blocks, see the forward kernel) and the
   // output transposition tile share one buffer: the latter is only used after the loop
-  constexpr int STAGE_BYTES = 2 * 3 * 32 * ADK * 2 + APRING * 32 * ADK * 2 + 2 * 2 * 32 * 4;  // 24 + 24 + 0.5 KiB
+  constexpr int NKK = ADK / 16, NDT = ADK / 32, NCH = ADK / 8;
+  constexpr int STAGE_BYTES = 2 * 3 * 32 * ADK * 2 + APRING * 32 * ADK * 2 + 2 * 2 * 32 * 4;  // 24 + 24 + 0.5 KiB (ADK = 64)
   constexpr int OUT_BYTES = 4 * 32 * SG_LD * 4;
   __shared__ __attribute__((aligned(16))) char s_raw[STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES];
   bf16_t* const s_q3 = reinterpret_cast<bf16_t*>(s_raw);                                 // [2][qu | qv | dO][32 * ADK]
@@ -774,17 +813,19 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   const uint32_t klane = (j & 1) ? ADROP_KB : ADROP_KA;  // this key column's multiplier (see the dropout definition)
   const float dscale = drop.threshold != 0u ? drop.scale : 1.f;  // folded, with `scale`, into the accumulators at the end
 
-  bf16x8 kf[4], vf[4];
-  load_rows(kbase + rowj * ldq, kf, j < Tr, lh);
-  load_rows(kbase + (ldq / 3) + rowj * ldq, vf, j < Tr, lh);
+  bf16x8 kf[NKK], vf[NKK];
+  load_rows<NKK>(kbase + rowj * ldq, kf, j < Tr, lh);
+  load_rows<NKK>(kbase + (ldq / 3) + rowj * ldq, vf, j < Tr, lh);
 
   // (the compiler must wait for these register loads HERE: inside the loop its `s_waitcnt vmcnt(0)` at their first use would
   //  also wait, every step, for the prefetch it knows nothing about)
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) { asm volatile("" : "+v"(kf[kk])); asm volatile("" : "+v"(vf[kk])); }
-  f32x16 dk_acc[2], dv_acc[2];
+  for (int kk = 0; kk < NKK; ++kk) { asm volatile("" : "+v"(kf[kk])); asm volatile("" : "+v"(vf[kk])); }
+  f32x16 dk_acc[NDT], dv_acc[NDT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { dk_acc[0][r] = 0.f; dk_acc[1][r] = 0.f; dv_acc[0][r] = 0.f; dv_acc[1][r] = 0.f; }
+  for (int t = 0; t < NDT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk_acc[t][r] = 0.f; dv_acc[t][r] = 0.f; }
 
   const int nqt = (L + 31) / 32;
   const bf16_t* qub = qu_g + row0 * d + h * ADK;
@@ -796,9 +837,9 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   const int cb0 = T - 1 + j0_blk - 31;
   auto stage_q = [&](int i0, int buf) {
     bf16_t* dst = s_q3 + buf * (3 * 32 * ADK);
-    stage_rows(qub, d, i0, Trc, dst, 32 * 8);
-    stage_rows(qvb, d, i0, Trc, dst + 32 * ADK, 32 * 8);
-    stage_rows(dob, d, i0, Trc, dst + 2 * 32 * ADK, 32 * 8);
+    stage_rows<ADK>(qub, d, i0, Trc, dst, 32 * NCH);
+    stage_rows<ADK>(qvb, d, i0, Trc, dst + 32 * ADK, 32 * NCH);
+    stage_rows<ADK>(dob, d, i0, Trc, dst + 2 * 32 * ADK, 32 * NCH);
     if (wave == 0) {
       int ii = i0 + (lane & 31);
       ii = ii < T ? ii : T - 1;  // (rows >= len are never used: p = 0 there)
@@ -807,7 +848,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   };
   if (nqt > 0) {
     stage_q(0, 0);
-    stage_rows(pbase, ldp, cb0, P - 1, s_p, ABAND * 8);
+    stage_rows<ADK>(pbase, ldp, cb0, P - 1, s_p, ABAND * NCH);
   }
   for (int qt = 0; qt < nqt; ++qt) {
     const int i0 = qt * 32;
@@ -815,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
     __syncthreads();  // tile qt has landed; every wave is done with step qt-1
     if (qt + 1 < nqt) {
       stage_q(i0 + 32, (qt + 1) & 1);
-      stage_rows(pbase, ldp, cb0 - 32 * (qt + 1), P - 1, s_p + ((6 * 1024 - (qt + 1)) % APRING) * (32 * ADK), 32 * 8);
+      stage_rows<ADK>(pbase, ldp, cb0 - 32 * (qt + 1), P - 1, s_p + ((6 * 1024 - (qt + 1)) % APRING) * (32 * ADK), 32 * NCH);
     }
     const bf16_t* s_qu = s_q3 + (qt & 1) * (3 * 32 * ADK);
     const bf16_t* s_qv = s_qu + 32 * ADK;
@@ -828,15 +869,15 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc_s[r] = 0.f; acc_g[0][r] = 0.f; acc_g[1][r] = 0.f; acc_dp[r] = 0.f; }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const bf16x8 quf = *reinterpret_cast<const bf16x8*>(s_qu + a_off(q, kk * 2 + lh));
+    for (int kk = 0; kk < NKK; ++kk) {
+      const bf16x8 quf = *reinterpret_cast<const bf16x8*>(s_qu + a_off<ADK>(q, kk * 2 + lh));
       acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(quf, kf[kk], acc_s, 0, 0, 0);     // S[query][key]
-      const bf16x8 dof = *reinterpret_cast<const bf16x8*>(s_do + a_off(q, kk * 2 + lh));
+      const bf16x8 dof = *reinterpret_cast<const bf16x8*>(s_do + a_off<ADK>(q, kk * 2 + lh));
       acc_dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf[kk], acc_dp, 0, 0, 0);   // dP[query][key]
-      const bf16x8 qvf = *reinterpret_cast<const bf16x8*>(s_qv + a_off(q, kk * 2 + lh));
+      const bf16x8 qvf = *reinterpret_cast<const bf16x8*>(s_qv + a_off<ADK>(q, kk * 2 + lh));
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off((ct ? slot1 : slot0) * 32 + q, kk * 2 + lh));
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(s_p + a_off<ADK>((ct ? slot1 : slot0) * 32 + q, kk * 2 + lh));
         acc_g[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qvf, pf, acc_g[ct], 0, 0, 0);  // G[query][c_local]
       }
     }
@@ -869,10 +910,10 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
       const bf16x8 db = pack8(&ds[8 * st]);
       const int ra = 16 * st + 4 * lh, rb = 16 * st + 8 + 4 * lh;
 #pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        const bf16x8 dot_f = tr_frag(s_do, ra, rb, t2 * 32, lane);   // dO^T[dv][query slots]
+      for (int t2 = 0; t2 < NDT; ++t2) {
+        const bf16x8 dot_f = tr_frag<ADK>(s_do, ra, rb, t2 * 32, lane);   // dO^T[dv][query slots]
         dv_acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_f, pb, dv_acc[t2], 0, 0, 0);
-        const bf16x8 qut_f = tr_frag(s_qu, ra, rb, t2 * 32, lane);   // Qu^T[dk][query slots]
+        const bf16x8 qut_f = tr_frag<ADK>(s_qu, ra, rb, t2 * 32, lane);   // Qu^T[dk][query slots]
         dk_acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qut_f, db, dk_acc[t2], 0, 0, 0);
       }
     }
@@ -882,12 +923,14 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
   // ---- write dK, dV rows of this wave's 32 keys
   float* st_ = reinterpret_cast<float*>(s_raw) + wave * (32 * SG_LD);
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < 2 * (NDT / 2); ++pass) {   // (dK | dV) x 64-column halves through the [32][66] tile
+    const int kind = pass / (NDT / 2), hf = pass % (NDT / 2);
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        st_[q * SG_LD + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = pass == 0 ? dk_acc[t2][r] * scale : dv_acc[t2][r] * dscale;
+        st_[q * SG_LD + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] =
+            kind == 0 ? dk_acc[2 * hf + t2][r] * scale : dv_acc[2 * hf + t2][r] * dscale;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -898,7 +941,7 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dkv_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = st_[row * SG_LD + c8 + e];
         u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-        *reinterpret_cast<u32x4*>(dqkv + (row0 + jj) * ldd + (pass + 1) * (ldd / 3) + h * ADK + c8) = t;
+        *reinterpret_cast<u32x4*>(dqkv + (row0 + jj) * ldd + (kind + 1) * (ldd / 3) + h * ADK + hf * 64 + c8) = t;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -924,10 +967,12 @@ __device__ __forceinline__ bf16x8 tr_frag32(const bf16_t* img, int ra, int rb, i
 // One workgroup owns 64 consecutive positions (the block pair dg = s-it in {2x-(nT-1), +1}) of one head and walks every
 // (utterance of its chunk, query tile) that reaches them: 4 KiB of X (the two blocks are adjacent) + 4 KiB of Qv per item by
 // LDS-DMA one item ahead, 8 MFMAs; the four waves split the items and combine at the end.
-__global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
+template <int ADK>
+__global__ __launch_bounds__(256, ADK == 64 ? 2 : 1) void relpos_flash_bwd_dpos_kernel(
     const bf16_t* __restrict__ qv_g, const bf16_t* __restrict__ x_g, const long long* __restrict__ len,
     float* __restrict__ dpos, long long ldd, float* __restrict__ partial, int B, int H, int T, int d, int bchunk,
     const long long* __restrict__ cu) {
+  constexpr int NDT = ADK / 32, NCH = ADK / 8;
   __shared__ __attribute__((aligned(16))) bf16_t s_x[4][2][2 * 1024];   // per wave, double-buffered
   __shared__ __attribute__((aligned(16))) bf16_t s_qv[4][2][32 * ADK];
 
@@ -942,9 +987,11 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
   // query tiles with at least one of the slots it+dg, it+dg+1 inside [0, nT]
   const int it_lo = max(0, -dg - 1), it_hi = min(nT, nT - dg + 1);
 
-  f32x16 dp_acc[2][2];
+  f32x16 dp_acc[2][NDT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { dp_acc[0][0][r] = 0.f; dp_acc[0][1][r] = 0.f; dp_acc[1][0][r] = 0.f; dp_acc[1][1][r] = 0.f; }
+  for (int t = 0; t < NDT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dp_acc[0][t][r] = 0.f; dp_acc[1][t][r] = 0.f; }
 
   const int npairs = it_hi - it_lo;
   const int nitems = (b_end - b_begin) * npairs;
@@ -966,9 +1013,9 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
     const bf16_t* qb = qv_g + (cu ? (Lb > 0 ? cu[b] : 0LL) : (long long)b * T) * d + h * ADK;
     const int grmax = Lb > 0 ? Lb - 1 : 0;
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
+    for (int k4 = 0; k4 < 32 * NCH / 64; ++k4) {
       const int cq = k4 * 64 + lane;
-      const int r = cq >> 3, ck = cq & 7;
+      const int r = cq / NCH, ck = cq % NCH;
       int gr = 32 * it + r;
       gr = gr > grmax ? grmax : gr;
       dma16((qb + __mul24(gr, d) + ((ck ^ ((r >> 1) & 7)) << 3)), (sqv + k4 * 512));
@@ -979,14 +1026,14 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
     while (it >= it_hi) { it -= npairs; ++b; }
   };
   // per-lane LDS byte addresses of the transpose reads (tr_frag32 / tr_frag geometry), buffer 0
-  uint32_t xaddr, qaddr[2][2][2];
+  uint32_t xaddr, qaddr[2][NDT][2];
   {
     const int t = lane & 15, g4 = (lane >> 4) & 1;
     xaddr = lds_addr(&s_x[wave][0][0]) + (uint32_t)(((8 * lh + (t >> 2)) * 32 + g4 * 16 + (t & 3) * 4) * 2);
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
-      for (int dkt = 0; dkt < 2; ++dkt)
+      for (int dkt = 0; dkt < NDT; ++dkt)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const int r = 16 * st + 8 * lh + 4 * hf + (t >> 2), col = dkt * 32 + g4 * 16 + (t & 3) * 4;
@@ -1002,7 +1049,8 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
     if (item + 4 < nitems) {
       nb = cb; nit = cit; advance(nb, nit, 4);
       issue(nb, nit, buf ^ 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if constexpr (ADK == 64) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // (the next item's 4 + 4 loads stay in flight)
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                       // (4 + 8)
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int b = cb;
     const int it = cit, s0 = it + dg;
@@ -1013,10 +1061,10 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
     // fragment reads by inline asm: behind an LDS-DMA the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS read it
     // emits itself, which would also wait for the NEXT item's eight loads (the counted vmcnt(8) above is the real condition)
     const uint32_t m0 = v0 ? 0xffffffffu : 0u, m1 = v1 ? 0xffffffffu : 0u;  // a slot outside 0..nkt was never written
-    const uint32_t xa = xaddr + buf * 4096u, qoff = buf * 4096u;
+    const uint32_t xa = xaddr + buf * 4096u, qoff = buf * (uint32_t)(32 * ADK * 2);
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      union { bf16x8 v; s16x4 h[2]; u32x4 w; } af[2], bq[2];
+      union { bf16x8 v; s16x4 h[2]; u32x4 w; } af[2], bq[NDT];
       asm volatile(
           "ds_read_b64_tr_b16 %0, %8\n\t"
           "ds_read_b64_tr_b16 %1, %8 offset:256\n\t"
@@ -1032,10 +1080,21 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
           : "v"(xa + st * 1024u), "v"(qaddr[st][0][0] + qoff), "v"(qaddr[st][0][1] + qoff), "v"(qaddr[st][1][0] + qoff),
             "v"(qaddr[st][1][1] + qoff)
           : "memory");
+      if constexpr (NDT == 4) {
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %4\n\t"
+            "ds_read_b64_tr_b16 %1, %5\n\t"
+            "ds_read_b64_tr_b16 %2, %6\n\t"
+            "ds_read_b64_tr_b16 %3, %7\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(bq[2].h[0]), "=&v"(bq[2].h[1]), "=&v"(bq[3].h[0]), "=&v"(bq[3].h[1])
+            : "v"(qaddr[st][2][0] + qoff), "v"(qaddr[st][2][1] + qoff), "v"(qaddr[st][3][0] + qoff), "v"(qaddr[st][3][1] + qoff)
+            : "memory");
+      }
       af[0].w &= m0;
       af[1].w &= m1;
 #pragma unroll
-      for (int dkt = 0; dkt < 2; ++dkt) {
+      for (int dkt = 0; dkt < NDT; ++dkt) {
         dp_acc[0][dkt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0].v, bq[dkt].v, dp_acc[0][dkt], 0, 0, 0);
         dp_acc[1][dkt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1].v, bq[dkt].v, dp_acc[1][dkt], 0, 0, 0);
       }
@@ -1046,45 +1105,46 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
   // ---- combine the 4 waves with plain LDS traffic (ds_add_f32 atomics measured ~10 us per workgroup here): waves 2,3 park
   // their accumulators in two slabs, waves 0,1 add them, wave 1 parks, wave 0 adds and owns the result.
   __syncthreads();
-  float* slab = reinterpret_cast<float*>(&s_qv[0][0][0]);  // 32 KiB = 2 slabs of 64 x 64 floats
+  float* slab = reinterpret_cast<float*>(&s_qv[0][0][0]);  // 512 x ADK bytes = 2 slabs of 64 x ADK floats
+  constexpr int SLAB = 64 * ADK;
   if (wave >= 2) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int dkt = 0; dkt < 2; ++dkt)
+      for (int dkt = 0; dkt < NDT; ++dkt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[(wave - 2) * 4096 + ((ct * 2 + dkt) * 16 + r) * 64 + lane] = dp_acc[ct][dkt][r];
+        for (int r = 0; r < 16; ++r) slab[(wave - 2) * SLAB + ((ct * NDT + dkt) * 16 + r) * 64 + lane] = dp_acc[ct][dkt][r];
   }
   __syncthreads();
   if (wave < 2) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int dkt = 0; dkt < 2; ++dkt)
+      for (int dkt = 0; dkt < NDT; ++dkt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dp_acc[ct][dkt][r] += slab[wave * 4096 + ((ct * 2 + dkt) * 16 + r) * 64 + lane];
+        for (int r = 0; r < 16; ++r) dp_acc[ct][dkt][r] += slab[wave * SLAB + ((ct * NDT + dkt) * 16 + r) * 64 + lane];
   }
   __syncthreads();
   if (wave == 1) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int dkt = 0; dkt < 2; ++dkt)
+      for (int dkt = 0; dkt < NDT; ++dkt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[((ct * 2 + dkt) * 16 + r) * 64 + lane] = dp_acc[ct][dkt][r];
+        for (int r = 0; r < 16; ++r) slab[((ct * NDT + dkt) * 16 + r) * 64 + lane] = dp_acc[ct][dkt][r];
   }
   __syncthreads();
   if (wave != 0) return;
-  float* out_slab = partial ? partial + (((long long)blockIdx.z * gridDim.x + blockIdx.x) * H + h) * 4096 : nullptr;
+  float* out_slab = partial ? partial + (((long long)blockIdx.z * gridDim.x + blockIdx.x) * H + h) * SLAB : nullptr;
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int dkt = 0; dkt < 2; ++dkt)
+    for (int dkt = 0; dkt < NDT; ++dkt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = dp_acc[ct][dkt][r] + slab[((ct * 2 + dkt) * 16 + r) * 64 + lane];
+        const float v = dp_acc[ct][dkt][r] + slab[((ct * NDT + dkt) * 16 + r) * 64 + lane];
         const int cl = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, dk = dkt * 32 + q;
-        if (out_slab) out_slab[cl * 64 + dk] = v;  // deterministic two-stage reduction (dpos_reduce_kernel)
+        if (out_slab) out_slab[cl * ADK + dk] = v;  // deterministic two-stage reduction (dpos_reduce_kernel)
         else {
           const int c = cmin + cl;
           if (c >= 0 && c < P) atomicAdd(dpos + (long long)c * ldd + h * ADK + dk, v);
@@ -1093,17 +1153,18 @@ __global__ __launch_bounds__(256, 2) void relpos_flash_bwd_dpos_kernel(
 }
 
 // stage 2: the 64 positions of block pair x (disjoint between pairs), summed over the utterance chunks z
+template <int ADK>
 __global__ __launch_bounds__(256) void dpos_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dpos, long long ldd,
                                                           bf16_t* __restrict__ dpos_cast, int H, int T, int nz) {
   const int nT = (T + 31) / 32;
   const int x = blockIdx.x, h = blockIdx.y;
   const int P = 2 * T - 1;
-  const int e = blockIdx.z * 256 + threadIdx.x;  // 16 blocks of 256 threads cover the 64 x 64 pair
-  const int cl = e >> 6, dk = e & 63;
+  const int e = blockIdx.z * 256 + threadIdx.x;  // ADK / 4 blocks of 256 threads cover the 64 x ADK pair
+  const int cl = e / ADK, dk = e % ADK;
   const int c = T - 32 + 32 * (2 * x - (nT - 1)) + cl;
   if (c < 0 || c >= P) return;
   float acc = 0.f;
-  for (int z = 0; z < nz; ++z) acc += partial[(((long long)z * nT + x) * H + h) * 4096 + e];
+  for (int z = 0; z < nz; ++z) acc += partial[(((long long)z * nT + x) * H + h) * (64 * ADK) + e];
   const float v = dpos[(long long)c * ldd + h * ADK + dk] + acc;
   dpos[(long long)c * ldd + h * ADK + dk] = v;
   // every (c, h, dk) of [0, 2T-1) x H x 64 is owned by exactly one thread of this launch, so the GEMM-operand copy of the
@@ -1117,41 +1178,50 @@ extern "C" int mi355x_relpos_flash_fwd(const void* qkv, long long ldq, const voi
                                        unsigned drop_threshold, float drop_scale, const void* row_offsets, void* stream) {
   mi_clear_errors();
   if (!qkv || !pos || !bias_u || !bias_v || !len || !ctx || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
-  if (dk != ADK || (ldq % 24) || (ldp & 7) || (ldo & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)pos & 15) ||
+  if ((dk != 64 && dk != 128) || (ldq % 24) || (ldp & 7) || (ldo & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)pos & 15) ||
       ((uintptr_t)ctx & 15) || ((uintptr_t)ctx_lo & 15))
     return MI_ERR_ARG;
   DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   dim3 grid((T + ABQ - 1) / ABQ, H, B);
-  MI_LAUNCH(relpos_flash_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldq,
-                     (const bf16_t*)pos, ldp, (const float*)bias_u, (const float*)bias_v, (const long long*)len, (bf16_t*)ctx,
-                     (bf16_t*)ctx_lo, ldo, (float*)lse, B, H, T, Tp, scale, dc, (const long long*)row_offsets);
+#define FWD_LAUNCH(DK)                                                                                                              \
+  MI_LAUNCH(relpos_flash_fwd_kernel<DK>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, \
+            (const float*)bias_u, (const float*)bias_v, (const long long*)len, (bf16_t*)ctx, (bf16_t*)ctx_lo, ldo, (float*)lse, B, \
+            H, T, Tp, scale, dc, (const long long*)row_offsets)
+  if (dk == 64) { FWD_LAUNCH(64); } else { FWD_LAUNCH(128); }
+#undef FWD_LAUNCH
   return mi_check_launch();
 }
 
 extern "C" int mi355x_attn_delta(const void* dO, const void* O, const void* O_lo, void* delta, int B, int H, int T, int d,
                                  const void* len, const void* row_offsets, void* stream) {
   mi_clear_errors();
-  if (!dO || !O || !delta || B <= 0 || H <= 0 || T <= 0 || d != H * ADK || (row_offsets && !len)) return MI_ERR_ARG;
+  if (!dO || !O || !delta || B <= 0 || H <= 0 || T <= 0 || (d != H * 64 && d != H * 128) || (row_offsets && !len)) return MI_ERR_ARG;
   const long long rows = (long long)B * T;
-  MI_LAUNCH(attn_delta_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)O_lo, (float*)delta, (const bf16_t*)nullptr, 0LL,
-                     (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, (bf16_t*)nullptr, B, H, T, d,
-                     (const long long*)len, (const long long*)row_offsets);
+#define DELTA_LAUNCH(DK)                                                                                                  \
+  MI_LAUNCH((attn_delta_kernel<false, DK>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,        \
+            (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)O_lo, (float*)delta, (const bf16_t*)nullptr, 0LL,         \
+            (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, (bf16_t*)nullptr, B, H, T, d,                 \
+            (const long long*)len, (const long long*)row_offsets)
+  if (d == H * 64) { DELTA_LAUNCH(64); } else { DELTA_LAUNCH(128); }
+#undef DELTA_LAUNCH
   return mi_check_launch();
 }
 extern "C" int mi355x_attn_bwd_prep(const void* dO, const void* O, const void* O_lo, void* delta, const void* qkv, long long ldq,
                                     const void* bias_u, const void* bias_v, void* qu, void* qv, int B, int H, int T, int d,
                                     const void* len, const void* row_offsets, void* stream) {
   mi_clear_errors();
-  if (!dO || !O || !delta || !qkv || !bias_u || !bias_v || !qu || !qv || B <= 0 || H <= 0 || T <= 0 || d != H * ADK || (ldq & 7) ||
-      (row_offsets && !len))
+  if (!dO || !O || !delta || !qkv || !bias_u || !bias_v || !qu || !qv || B <= 0 || H <= 0 || T <= 0 ||
+      (d != H * 64 && d != H * 128) || (ldq & 7) || (row_offsets && !len))
     return MI_ERR_ARG;
   if (((uintptr_t)qkv | (uintptr_t)qu | (uintptr_t)qv | (uintptr_t)bias_u | (uintptr_t)bias_v) & 15) return MI_ERR_ARG;
   const long long rows = (long long)B * T;
-  MI_LAUNCH(attn_delta_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)O_lo, (float*)delta, (const bf16_t*)qkv, ldq,
-                     (const float*)bias_u, (const float*)bias_v, (bf16_t*)qu, (bf16_t*)qv, B, H, T, d, (const long long*)len,
-                     (const long long*)row_offsets);
+#define PREP_LAUNCH(DK)                                                                                                   \
+  MI_LAUNCH((attn_delta_kernel<true, DK>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,         \
+            (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)O_lo, (float*)delta, (const bf16_t*)qkv, ldq,             \
+            (const float*)bias_u, (const float*)bias_v, (bf16_t*)qu, (bf16_t*)qv, B, H, T, d, (const long long*)len,      \
+            (const long long*)row_offsets)
+  if (d == H * 64) { PREP_LAUNCH(64); } else { PREP_LAUNCH(128); }
+#undef PREP_LAUNCH
   return mi_check_launch();
 }
 
@@ -1163,23 +1233,26 @@ extern "C" int mi355x_relpos_flash_bwd_dq(const void* qu, const void* qv, const 
                                           float drop_scale, const void* row_offsets, void* stream) {
   mi_clear_errors();
   if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
-  if (dk != ADK || (ldq % 24) || (ldp & 7)) return MI_ERR_ARG;
+  if ((dk != 64 && dk != 128) || (ldq % 24) || (ldp & 7)) return MI_ERR_ARG;
   // either the two gradients separately (dqu, dqv) or their sum (dq_out, row pitch ld_dq) with the bias gradients
   // (bias_grads f32 [2 * H * 64] += column sums of dQu | dQv, via cs_scratch: f32 [B * ceil(T / 128) * 2 * H * 64])
   if (!dq_out && (!dqu || !dqv)) return MI_ERR_ARG;
-  const long long cs_need = (long long)B * ((T + ABQ - 1) / ABQ) * 2 * H * ADK;
+  const long long cs_need = (long long)B * ((T + ABQ - 1) / ABQ) * 2 * H * dk;
   if (dq_out && ((ld_dq & 7) || ((uintptr_t)dq_out & 15) || (bias_grads && (!cs_scratch || cs_scratch_elems < cs_need))))
     return MI_ERR_ARG;
   if (ds_out && (((uintptr_t)ds_out & 15) || ds_elems < mi355x_relpos_ds_elems(B, H, T))) return MI_ERR_ARG;
   DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   dim3 grid((T + ABQ - 1) / ABQ, H, B);
-  MI_LAUNCH(relpos_flash_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu, (const bf16_t*)qv,
-                     (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len, (const bf16_t*)dO,
-                     (const float*)lse, (const float*)delta, (bf16_t*)dqu, (bf16_t*)dqv, (bf16_t*)ds_out, (bf16_t*)dq_out, ld_dq,
-                     bias_grads ? (float*)cs_scratch : nullptr, B, H, T, H * ADK, scale, dc, (const long long*)row_offsets);
+#define DQ_LAUNCH(DK)                                                                                                              \
+  MI_LAUNCH(relpos_flash_bwd_dq_kernel<DK>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu, (const bf16_t*)qv,           \
+            (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len, (const bf16_t*)dO, (const float*)lse,           \
+            (const float*)delta, (bf16_t*)dqu, (bf16_t*)dqv, (bf16_t*)ds_out, (bf16_t*)dq_out, ld_dq,                               \
+            bias_grads ? (float*)cs_scratch : nullptr, B, H, T, H * DK, scale, dc, (const long long*)row_offsets)
+  if (dk == 64) { DQ_LAUNCH(64); } else { DQ_LAUNCH(128); }
+#undef DQ_LAUNCH
   if (dq_out && bias_grads)
-    MI_LAUNCH((partials_reduce_kernel<float>), dim3((2 * H * ADK + 255) / 256, 8), dim3(256), 0, (hipStream_t)stream,
-              (const float*)cs_scratch, (int)(B * ((T + ABQ - 1) / ABQ)), 2 * H * ADK, (float*)bias_grads);
+    MI_LAUNCH((partials_reduce_kernel<float>), dim3((2 * H * dk + 255) / 256, 8), dim3(256), 0, (hipStream_t)stream,
+              (const float*)cs_scratch, (int)(B * ((T + ABQ - 1) / ABQ)), 2 * H * dk, (float*)bias_grads);
   return mi_check_launch();
 }
 
@@ -1190,13 +1263,15 @@ extern "C" int mi355x_relpos_flash_bwd_dkv(const void* qu, const void* qv, const
                                            void* stream) {
   mi_clear_errors();
   if (!qu || !qv || !qkv || !pos || !len || !dO || !lse || !delta || !dqkv || B <= 0 || H <= 0 || T <= 0) return MI_ERR_ARG;
-  if (dk != ADK || (ldq % 24) || (ldp & 7) || (ldd % 24)) return MI_ERR_ARG;
+  if ((dk != 64 && dk != 128) || (ldq % 24) || (ldp & 7) || (ldd % 24)) return MI_ERR_ARG;
   DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   dim3 grid((T + ABQ - 1) / ABQ, H, B);
-  MI_LAUNCH(relpos_flash_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu,
-                     (const bf16_t*)qv, (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len,
-                     (const bf16_t*)dO, (const float*)lse, (const float*)delta, (bf16_t*)dqkv, ldd, B, H, T, Tp, H * ADK, scale, dc,
-                     (const long long*)row_offsets);
+#define DKV_LAUNCH(DK)                                                                                                             \
+  MI_LAUNCH(relpos_flash_bwd_dkv_kernel<DK>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qu, (const bf16_t*)qv,         \
+            (const bf16_t*)qkv, ldq, (const bf16_t*)pos, ldp, (const long long*)len, (const bf16_t*)dO, (const float*)lse,          \
+            (const float*)delta, (bf16_t*)dqkv, ldd, B, H, T, Tp, H * DK, scale, dc, (const long long*)row_offsets)
+  if (dk == 64) { DKV_LAUNCH(64); } else { DKV_LAUNCH(128); }
+#undef DKV_LAUNCH
   return mi_check_launch();
 }
 
@@ -1208,7 +1283,7 @@ extern "C" long long mi355x_relpos_ds_elems(int B, int H, int T) {
 extern "C" long long mi355x_relpos_dpos_partial_elems(int B, int H, int T) {
   const long long nT = (T + 31) / 32;
   const int bchunk = B >= 8 ? 4 : 1;
-  return (long long)((B + bchunk - 1) / bchunk) * nT * H * 4096;
+  return (long long)((B + bchunk - 1) / bchunk) * nT * H * (64 * 128);   // 64 positions x the widest head (d_k' = 128)
 }
 
 extern "C" int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, const void* len, void* dpos, long long ldd,
@@ -1216,17 +1291,19 @@ extern "C" int mi355x_relpos_flash_bwd_dpos(const void* qv, const void* ds, cons
                                             long long ds_elems, const void* row_offsets, void* stream) {
   mi_clear_errors();
   if (!qv || !ds || !len || !dpos || B <= 0 || H <= 0 || T <= 0 || (dpos_cast && !partial)) return MI_ERR_ARG;
-  if (dk != ADK || ((uintptr_t)ds & 15) || ds_elems < mi355x_relpos_ds_elems(B, H, T)) return MI_ERR_ARG;
+  if ((dk != 64 && dk != 128) || ((uintptr_t)ds & 15) || ds_elems < mi355x_relpos_ds_elems(B, H, T)) return MI_ERR_ARG;
   const int nT = (T + 31) / 32;
   const int bchunk = B >= 8 ? 4 : 1;
   const int nz = (B + bchunk - 1) / bchunk;
   if (partial && partial_elems < mi355x_relpos_dpos_partial_elems(B, H, T)) return MI_ERR_ARG;
   dim3 grid(nT, H, nz);
-  MI_LAUNCH(relpos_flash_bwd_dpos_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qv,
-                     (const bf16_t*)ds, (const long long*)len, (float*)dpos, ldd, (float*)partial, B, H, T, H * ADK, bchunk,
-                     (const long long*)row_offsets);
-  if (partial)
-    MI_LAUNCH(dpos_reduce_kernel, dim3(nT, H, 16), dim3(256), 0, (hipStream_t)stream, (const float*)partial,
-                       (float*)dpos, ldd, (bf16_t*)dpos_cast, H, T, nz);
+#define DPOS_LAUNCH(DK)                                                                                                        \
+  MI_LAUNCH(relpos_flash_bwd_dpos_kernel<DK>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qv, (const bf16_t*)ds,   \
+            (const long long*)len, (float*)dpos, ldd, (float*)partial, B, H, T, H * DK, bchunk, (const long long*)row_offsets); \
+  if (partial)                                                                                                                 \
+    MI_LAUNCH(dpos_reduce_kernel<DK>, dim3(nT, H, DK / 4), dim3(256), 0, (hipStream_t)stream, (const float*)partial,           \
+              (float*)dpos, ldd, (bf16_t*)dpos_cast, H, T, nz)
+  if (dk == 64) { DPOS_LAUNCH(64); } else { DPOS_LAUNCH(128); }
+#undef DPOS_LAUNCH
   return mi_check_launch();
 }

@@ -1143,6 +1143,8 @@ class ConformerEncoder(NeuralModule):
         linear_pos rows, linear_out columns, pos_bias lanes); activations outside the attention block keep width d."""
         dk = self.d_k
         dkp = _pad8(dk) if cdt == torch.bfloat16 else dk
+        if cdt == torch.bfloat16 and self.use_flash_attention and self.flash_pad_heads and 64 < dkp < 128:
+            dkp = 128   # ... and heads of 65..127 lanes to the kernels' second width (d_k' = 128: 8 k-steps, one workgroup per CU)
         if cdt == torch.bfloat16 and self.use_flash_attention and self.flash_pad_heads and dkp < 64:
             # round 5: heads narrower than the fused kernels' width (Conformer-Small: 44) are padded up to 64 instead of to the
             # next multiple of 8, so that they take the fused rel-pos attention (csrc/attention.hip, d_k' = 64) instead of
@@ -1214,7 +1216,7 @@ class ConformerEncoder(NeuralModule):
         H = self.n_heads
         M, P = B * T, 2 * T - 1
         Tp, Pp = _pad8(T), _pad8(P)
-        flash = self.use_flash_attention and cdt == torch.bfloat16 and dk == 64
+        flash = self.use_flash_attention and cdt == torch.bfloat16 and dk in (64, 128)
         cu = pk.cu if pk is not None else None
         if pk is not None and not flash:
             qkv_p = self._new(M, 3 * dA, dtype=cdt, device=dev)

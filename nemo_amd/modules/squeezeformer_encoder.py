@@ -193,6 +193,8 @@ class SqueezeformerEncoder(ConformerEncoder):
         dp, dkp = _pad8(self.d_model), _pad8(self.d_k)  # (same layout in fp32: one code path, exercised by the parity tests)
         if cdt == torch.bfloat16 and self.use_flash_attention and self.flash_pad_heads and dkp < 64:
             dkp = 64  # narrow heads ride the fused d_k' = 64 attention kernels (ConformerEncoder._geometry)
+        elif cdt == torch.bfloat16 and self.use_flash_attention and self.flash_pad_heads and 64 < dkp < 128:
+            dkp = 128  # Medium: d = 324, 4 heads, d_k = 81 -> the fused kernels' second width (round 5)
         return dp, dkp, self.n_heads * dkp
 
     def _sub_channels(self, cdt):

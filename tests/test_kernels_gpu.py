@@ -547,10 +547,11 @@ def _attn_ref(qkv, pos, u, v, lens, B, H, T, dk):
     return ctx, lse, attn
 
 
+@pytest.mark.parametrize("dk", [64, 128])   # 128: round 5, the kernels' second head width (d_k 65..128 zero-padded)
 @pytest.mark.parametrize("T", [45, 160, 501])
-def test_relpos_flash_attention_fwd(T):
+def test_relpos_flash_attention_fwd(T, dk):
     o = ops()
-    B, H, dk = 3, 2, 64
+    B, H = 3, 2
     d = H * dk
     g = torch.Generator().manual_seed(31)
     qkv = bf(torch.randn(B * T, 3 * d, generator=g))
@@ -601,10 +602,11 @@ def _attn_ref_grads(qkv, pos, u, v, lens, dO, B, H, T, dk):
                 dv=vv.grad.reshape(B * T, d), dp=p.grad.reshape(2 * T - 1, d))
 
 
+@pytest.mark.parametrize("dk", [64, 128])
 @pytest.mark.parametrize("T", [45, 160, 501])
-def test_relpos_flash_attention_bwd(T):
+def test_relpos_flash_attention_bwd(T, dk):
     o = ops()
-    B, H, dk = 3, 2, 64
+    B, H = 3, 2
     d = H * dk
     g = torch.Generator().manual_seed(32)
     qkv = bf(torch.randn(B * T, 3 * d, generator=g) * 0.7)
@@ -661,11 +663,12 @@ def test_relpos_flash_attention_bwd(T):
         assert torch.equal(dp_c, dp.to(torch.bfloat16))
 
 
-def test_relpos_flash_attention_dropout_consistency():
+@pytest.mark.parametrize("dk", [64, 128])
+def test_relpos_flash_attention_dropout_consistency(dk):
     """With one-hot V (T <= d_k) the context IS the dropped probability matrix, so the forward mask can be read out and
     every backward kernel checked against the same mask (masks are regenerated, never stored)."""
     o = ops()
-    B, H, dk, T = 2, 2, 64, 45
+    B, H, T = 2, 2, 45
     d = H * dk
     g = torch.Generator().manual_seed(33)
     qkv = torch.randn(B * T, 3 * d, generator=g) * 0.5

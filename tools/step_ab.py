@@ -18,7 +18,16 @@ spec = sys.argv[1]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 name, vals = spec.split("=")
-arms = [int(v) if v.lstrip("-").isdigit() else v for v in vals.split(",")]
+def _num(v):
+    if v.lstrip("-").isdigit():
+        return int(v)
+    try:
+        return float(v)
+    except ValueError:
+        return v
+
+
+arms = [_num(v) for v in vals.split(",")]
 
 
 def set_arm(v):
