@@ -51,6 +51,13 @@ def parse():
     ap.add_argument("--packed", default=None, choices=["auto", "0", "1"],
                     help="--var-len: packed token chain (SURVEY 8 f1; encoder.packed_rows): auto = the encoder's default (pack when the "
                          "host knows the lengths and >= 2 %% of the frames are padding), 0 = padded rows, 1 = always")
+    ap.add_argument("--pad-to", type=int, default=None, metavar="N",
+                    help="--var-len: the featurizer's own `pad_to` option (features.py:501; recipes ship 0 or 16): the feature frames of a "
+                         "batch are padded to a multiple of N, so a duration-shaped loader produces a few dozen padded lengths instead of "
+                         "one per batch -- each length's launch sequence can then be recorded once and replayed (--launch)")
+    ap.add_argument("--launch", default=None, choices=["auto", "live", "tape"],
+                    help="encoder launch mode (default: MI355X_GRAPHS or auto): live = every kernel from the Python sequencer, tape = "
+                         "recorded launch sequences replayed per padded length, auto = both timed on the device, the faster kept")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -414,6 +421,10 @@ def main():
     model.setup_optimization()
     if a.packed is not None:
         model.encoder.packed_rows = {"auto": "auto", "0": False, "1": True}[a.packed]
+    if a.launch is not None:
+        model.encoder.use_graphs, model.encoder.graph_auto = a.launch != "live", a.launch == "auto"
+    if a.pad_to is not None:
+        model.preprocessor.featurizer.pad_to = a.pad_to
     var_info = None
     if a.var_len:
         a.no_roofline = a.no_cpu_baseline = True  # (both describe the fixed-length headline workload)
@@ -475,6 +486,39 @@ def main():
             break
         loss = model.fit_step(batches[-1])["loss"]
         warmup_extra += 1
+    previsit = None
+    if a.var_len and getattr(model.encoder, "use_graphs", False) and world == 1:
+        # Variable-length run with recorded launch sequences: visit every padded length of the timed batches (un-timed) until its
+        # sequence is recorded / decided -- the state a training run is in after its first pass over the duration buckets.  The
+        # timed steps then run what a long run runs; lengths that could not be recorded stay on live launches and are counted.
+        enc = model.encoder
+        hop = int(round(model.preprocessor.featurizer.hop_length)) if hasattr(model.preprocessor.featurizer, "hop_length") else 160
+        pt = int(getattr(model.preprocessor.featurizer, "pad_to", 0) or 0)
+        def padded_frames(bt):
+            t = bt[0].shape[1] // hop + 1
+            return -(-t // pt) * pt if pt > 0 else t
+        by_len = {}
+        for bt in batches[a.warmup:]:
+            by_len.setdefault(padded_frames(bt), bt)
+        previsit = {"padded_lengths": len(by_len), "steps": 0}
+        if len(by_len) <= getattr(enc, "max_graph_sets", 8):
+            enc._graph_sets.clear()   # (the warm-up batches' lengths: seen once or twice, never again)
+            if enc.graph_auto:        # the longest length runs its live-vs-recorded trial first; the others take its decision over
+                for _ in range(16):
+                    model.fit_step(by_len[max(by_len)])
+                    previsit["steps"] += 1
+                    torch.cuda.synchronize()
+                    if enc.graphs_settled():
+                        break
+            for rnd in range(5):
+                for tq, bt in sorted(by_len.items(), reverse=True):
+                    model.fit_step(bt)
+                    previsit["steps"] += 1
+                torch.cuda.synchronize()
+                if enc.graphs_recorded() and rnd >= 1:
+                    break
+            previsit["all_recorded"] = bool(enc.graphs_recorded())
+        enc.replayed_steps = enc.live_steps = 0
     barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)] if a.var_len else None
     t0 = time.perf_counter()
@@ -694,6 +738,11 @@ def main():
                                    (" (the recorded sequence was timed on this box and was slower)" if ginfo else "")),
                           "host_issue_ms_per_step": round(host_s / a.steps * 1e3, 2), "recorded": ginfo,
                           "untimed_steps_beyond_warmup": warmup_extra}
+        if previsit is not None:
+            previsit.update({"timed_steps_replayed": getattr(model.encoder, "replayed_steps", None),
+                             "timed_steps_live": getattr(model.encoder, "live_steps", None)})
+            line["launch"]["variable_length_previsit"] = previsit
+            line["launch"]["recorded"] = [{k: g.get(k) for k in ("mel_shape", "decided", "auto", "replay")} for g in ginfo]
         line["distributed"] = dist_info
         if cpu is not None:
             line["cpu_baseline"] = cpu

@@ -385,6 +385,10 @@ int mi355x_bn_param_grad(const void* sums, void* dgamma, void* dbeta, int d, voi
 int mi355x_ctc_loss(const void* logp, const void* targets, const void* in_len, const void* tgt_len, void* alpha_ws,
                     void* beta_ws, void* nll, void* grad, int B, int Tmax, int C, int Umax, int blank, float grad_scale,
                     int zero_infinity, void* stream);
+/* lattice kernel of mi355x_ctc_loss: 1 (default; MI355X_CTC_WAVE) = alpha / beta rows resident in the registers of one wave each
+ * (2U+1 <= 1024 states, no barrier per time-step), 0 = the LDS / barrier form for every size.  Returns the previous setting
+ * (-1: not yet resolved from the environment). */
+int mi355x_ctc_config(int wave);
 
 /* x[r,:] *= vec[r] (f32): per-utterance upstream gradient applied to the CTC gradient (autograd of losses/ctc.py:52-66) */
 int mi355x_row_scale(void* x, const void* vec, long long rows, long long cols, void* stream);

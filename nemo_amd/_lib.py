@@ -151,6 +151,7 @@ SIGNATURES = {
     "mi355x_rnnt_greedy_decode": [vp, i32, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, i32,
                                   i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp],
     "mi355x_dwconv_config": [i32],
+    "mi355x_ctc_config": [i32],
     "mi355x_logmel_config": [i32],
     "mi355x_stream_create": [i32, vp],
     "mi355x_stream_destroy": [vp],

@@ -8,6 +8,7 @@
 //
 // Replaces on the reference path: torch.nn.functional.ctc_loss forward+backward called by
 //   nemo/collections/asr/losses/ctc.py:68-82 (CTCLoss(blank=V, reduction='none', zero_infinity=True) + mean_batch).
+#include <stdlib.h>
 #include "common.h"
 #include "mi355x_asr.h"
 
@@ -109,6 +110,200 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logp
   }
 }
 
+// ---------------- phase 1, wave-resident form (round 5).  The kernel above spends its time on one workgroup barrier + an LDS round
+// trip per time-step (~0.5 us x 501 steps = 247 us at the headline shapes, on the critical path between forward and backward:
+// profiles/r4_roofline_per_kernel.md).  Here a lattice row never leaves the registers of ONE wave: lane l holds the P (blank, label)
+// state pairs g = l*P .. l*P+P-1 (states 2g, 2g+1; S <= 128*P) and a step needs exactly one value (alpha) / two values (beta) from the
+// neighbouring lane -- a wave shuffle, no barrier, no LDS round trip of the row.  grid (B, 2): workgroup y = 0 walks alpha forward
+// in time, y = 1 walks beta backward.  A workgroup is two waves: wave 0 walks, wave 1 gathers the emissions lp[t, ext[s]] of the NEXT
+// chunk of CTC_TC(P) time-steps into the other half of a double-buffered LDS image (all of a chunk's loads in flight at once), so
+// the walker never waits for global memory; one barrier per chunk.  The lattices are written exactly as the kernel above writes
+// them (both include the emission of their own time-step).
+// The walker keeps its rows in the BASE-2 log domain (emissions are scaled by log2(e) on their way into LDS, lattice rows by ln 2
+// on their way out): log-sum-exp is then the bare hardware v_exp_f32 / v_log_f32 pair -- the sum lies in [1, 3], so none of the
+// range handling of expf / logf is needed.
+#define CTC_LOG2E 1.4426950408889634f
+#define CTC_LN2 0.6931471805599453f
+__device__ __forceinline__ float lse2f(float a, float b) {
+  const float m = fmaxf(a, b);
+  return (m == NEGINF) ? NEGINF : m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m));
+}
+__device__ __forceinline__ float lse3f(float a, float b, float c) {
+  const float m = fmaxf(a, fmaxf(b, c));
+  return (m == NEGINF) ? NEGINF
+                       : m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) + __builtin_amdgcn_exp2f(c - m));
+}
+template <int P> struct CtcTc { static constexpr int v = P <= 2 ? 64 : 128 / P; };   // time-steps per chunk (<= 64: one blank load per lane)
+template <int P, bool BETA>
+__device__ __forceinline__ void ctc_wave_walk(const float* __restrict__ lp, const long long* __restrict__ tg, float* __restrict__ ws,
+                                              float* __restrict__ nll_out, int T, int U, int C, int Smax, int blank, int zero_infinity,
+                                              float (*s_e)[CtcTc<P>::v * (64 * P + 1)]) {
+  constexpr int TC = CtcTc<P>::v, LD = 64 * P + 1;   // LDS row of a time-step: [p][lane] label emissions, then the blank emission
+  const int lane = threadIdx.x & 63;
+  const bool loader = threadIdx.x >= 64;   // wave-uniform
+  // per pair: the label's class, whether the skip transition into (alpha) / out of (beta) its label state exists
+  int cls[P];
+  bool vE[P], vO[P], skip[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int g = lane * P + p;
+    vE[p] = g <= U;
+    vO[p] = g < U;
+    cls[p] = vO[p] ? (int)tg[g] : blank;
+    if (!BETA) skip[p] = vO[p] && g >= 1 && cls[p] != (int)tg[g - 1];
+    else skip[p] = g + 1 < U && cls[p] != (int)tg[g + 1];
+  }
+  const int nchunk = (T + TC - 1) / TC;
+  auto gather = [&](int c) {   // loader wave: emissions of steps c*TC .. c*TC+TC-1 -> s_e[c & 1]
+    float* dst = s_e[c & 1];
+    float v[TC][P];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+      int step = c * TC + i;
+      step = step < T ? step : T - 1;   // (steps beyond the utterance re-read its last row: no branch, never used)
+      const float* row = lp + (long long)(BETA ? (T - 1 - step) : step) * C;
+#pragma unroll
+      for (int p = 0; p < P; ++p) v[i][p] = row[cls[p]];
+    }
+    float vb = 0.f;
+    if (lane < TC) {
+      int step = c * TC + lane;
+      step = step < T ? step : T - 1;
+      vb = lp[(long long)(BETA ? (T - 1 - step) : step) * C + blank];
+    }
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+      for (int p = 0; p < P; ++p) dst[i * LD + p * 64 + lane] = v[i][p] * CTC_LOG2E;
+    if (lane < TC) dst[lane * LD + 64 * P] = vb * CTC_LOG2E;
+  };
+  float E[P], O[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) { E[p] = NEGINF; O[p] = NEGINF; }
+  if (loader) gather(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    if (loader) {
+      if (c + 1 < nchunk) gather(c + 1);
+    } else {
+      const float* src = s_e[c & 1];
+      const int nstep = min(TC, T - c * TC);
+      // the emissions of step i + 1 are read while step i computes (an LDS read in front of its first use costs the recursion
+      // ~100 cycles per step otherwise); row TC - 1 is re-read beyond the chunk (never used)
+      float eb_n = src[64 * P], el_n[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) el_n[p] = src[p * 64 + lane];
+      for (int i = 0; i < nstep; ++i) {
+        const int step = c * TC + i;
+        const int t = BETA ? (T - 1 - step) : step;
+        const float eb = eb_n;
+        float el[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) el[p] = el_n[p];
+        const int i1 = i + 1 < TC ? i + 1 : TC - 1;
+        // old values of the neighbouring lane's boundary pair (alpha: its last label state; beta: its first pair)
+        float x0, x1 = NEGINF;
+        if (!BETA) {
+          x0 = __shfl_up(O[P - 1], 1, 64);
+          if (lane == 0) x0 = NEGINF;
+        } else {
+          x0 = __shfl_down(E[0], 1, 64);
+          x1 = __shfl_down(O[0], 1, 64);
+          if (lane == 63) { x0 = NEGINF; x1 = NEGINF; }
+        }
+        eb_n = src[i1 * LD + 64 * P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) el_n[p] = src[i1 * LD + p * 64 + lane];
+        float nE[P], nO[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          float a, cc;
+          if (!BETA) {
+            // alpha: E_g <- lse(E_g, O_{g-1}) + e_blank ; O_g <- lse(O_g, E_g, skip ? O_{g-1} : -inf) + e_label   (old values on the right)
+            const float om1 = (p == 0) ? x0 : O[p == 0 ? 0 : p - 1];
+            a = lse2f(E[p], om1);
+            cc = lse3f(O[p], E[p], skip[p] ? om1 : NEGINF);
+          } else {
+            // beta: E_g <- lse(E_g, O_g) + e_blank ; O_g <- lse(O_g, E_{g+1}, skip ? O_{g+1} : -inf) + e_label
+            const float ep1 = (p == P - 1) ? x0 : E[p == P - 1 ? p : p + 1];
+            const float op1 = (p == P - 1) ? x1 : O[p == P - 1 ? p : p + 1];
+            a = lse2f(E[p], O[p]);
+            cc = lse3f(O[p], ep1, skip[p] ? op1 : NEGINF);
+          }
+          nE[p] = (vE[p] && a != NEGINF) ? a + eb : NEGINF;
+          nO[p] = (vO[p] && cc != NEGINF) ? cc + el[p] : NEGINF;
+        }
+        if (step == 0) {  // (wave-uniform) alpha_0: states 0, 1 ; beta_{T-1}: states S-1, S-2
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            const int g = lane * P + p;
+            nE[p] = (g == (BETA ? U : 0)) ? eb : NEGINF;
+            nO[p] = (vO[p] && g == (BETA ? U - 1 : 0)) ? el[p] : NEGINF;
+          }
+        }
+        float* wrow = ws + (long long)t * Smax + 2 * lane * P;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          E[p] = nE[p]; O[p] = nO[p];
+          if (vE[p]) wrow[2 * p] = nE[p] * CTC_LN2;      // (-inf stays -inf)
+          if (vO[p]) wrow[2 * p + 1] = nO[p] * CTC_LN2;
+        }
+      }
+    }
+    __syncthreads();   // chunk c + 1 is in LDS; the walker is done with chunk c's half
+  }
+  if (!BETA && !loader) {
+    // log-likelihood from the last alpha row: states S-1 = E_U and S-2 = O_{U-1}
+    float eU = NEGINF, oU = NEGINF;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int g = lane * P + p;
+      if (g == U) eU = E[p];
+      if (g == U - 1) oU = O[p];
+    }
+    const float l1 = __shfl(eU, U / P, 64) * CTC_LN2;
+    const float l2 = (U >= 1) ? __shfl(oU, (U - 1) / P, 64) * CTC_LN2 : NEGINF;
+    if (lane == 0) {
+      const float m = fmaxf(l1, l2);
+      const float ll = (m == NEGINF) ? NEGINF : m + logf(expf(l1 - m) + expf(l2 - m));
+      float out = -ll;
+      if (out == INFINITY && zero_infinity) out = 0.f;
+      *nll_out = out;
+    }
+  }
+}
+
+// grid (B, 2), two waves per workgroup (walker + emission loader): blockIdx.y = 0 walks alpha, 1 walks beta
+template <int P>
+__global__ __launch_bounds__(128) void ctc_wave_kernel(const float* __restrict__ logp, const long long* __restrict__ targets,
+                                                       const long long* __restrict__ in_len, const long long* __restrict__ tgt_len,
+                                                       float* __restrict__ alpha_ws, float* __restrict__ beta_ws,
+                                                       float* __restrict__ nll_out, int Tmax, int C, int Umax, int Smax, int blank,
+                                                       int zero_infinity) {
+  const int b = blockIdx.x;
+  const int T = (int)min((long long)Tmax, in_len[b]);
+  const int U = (int)min((long long)Umax, tgt_len[b]);
+  if (T <= 0) {  // empty input: feasible only for an empty target
+    if (threadIdx.x == 0 && blockIdx.y == 0) nll_out[b] = (U == 0) ? 0.f : (zero_infinity ? 0.f : INFINITY);
+    return;
+  }
+  __shared__ float s_e[2][CtcTc<P>::v * (64 * P + 1)];   // double-buffered emission chunks
+  const float* lp = logp + (long long)b * Tmax * C;
+  const long long* tg = targets + (long long)b * Umax;
+  if (blockIdx.y == 0)
+    ctc_wave_walk<P, false>(lp, tg, alpha_ws + (long long)b * Tmax * Smax, nll_out + b, T, U, C, Smax, blank, zero_infinity, s_e);
+  else
+    ctc_wave_walk<P, true>(lp, tg, beta_ws + (long long)b * Tmax * Smax, nullptr, T, U, C, Smax, blank, zero_infinity, s_e);
+}
+
+// MI355X_CTC_WAVE (mi355x_ctc_config): 1 (default) = the wave-resident lattice kernel for S <= 1024 states, 0 = the LDS / barrier form
+static int g_ctc_wave = -1;
+extern "C" int mi355x_ctc_config(int wave) {
+  const int prev = g_ctc_wave;
+  g_ctc_wave = wave;
+  return prev;
+}
+
 // ---------------- phase 2: gradient rows.  Its own launch: the lattice phase is sequential in T and occupies one workgroup per
 // utterance (32 CUs at the headline batch), the gradient rows are independent -- grid (time blocks, B), one wave per time-step.
 #define CTC_GT 8  // time-steps per workgroup (4 waves x 2)
@@ -163,9 +358,23 @@ extern "C" int mi355x_ctc_loss(const void* logp, const void* targets, const void
   const int Smax = 2 * Umax + 1;
   const size_t shm = sizeof(float) * ((size_t)Smax * 5);
   if (shm > 60 * 1024 || sizeof(float) * 4 * (size_t)C > 60 * 1024) return MI_ERR_ARG;
+  if (g_ctc_wave < 0) {
+    const char* e = getenv("MI355X_CTC_WAVE");
+    g_ctc_wave = (e && e[0] == '0') ? 0 : 1;
+  }
+#define CTC_WAVE_LAUNCH(PP)                                                                                                        \
+  MI_LAUNCH(ctc_wave_kernel<PP>, dim3(B, 2), dim3(128), 0, (hipStream_t)stream, (const float*)logp, (const long long*)targets,        \
+            (const long long*)in_len, (const long long*)tgt_len, (float*)alpha_ws, (float*)beta_ws, (float*)nll, Tmax, C, Umax,    \
+            Smax, blank, zero_infinity)
+  if (g_ctc_wave && Smax <= 128) { CTC_WAVE_LAUNCH(1); }
+  else if (g_ctc_wave && Smax <= 256) { CTC_WAVE_LAUNCH(2); }
+  else if (g_ctc_wave && Smax <= 512) { CTC_WAVE_LAUNCH(4); }
+  else if (g_ctc_wave && Smax <= 1024) { CTC_WAVE_LAUNCH(8); }
+  else
   MI_LAUNCH(ctc_kernel, dim3(B), dim3(256), shm, (hipStream_t)stream, (const float*)logp, (const long long*)targets,
                      (const long long*)in_len, (const long long*)tgt_len, (float*)alpha_ws, (float*)beta_ws, (float*)nll, Tmax,
                      C, Umax, Smax, blank, zero_infinity);
+#undef CTC_WAVE_LAUNCH
   if (grad)
     MI_LAUNCH(ctc_grad_kernel, dim3((Tmax + CTC_GT - 1) / CTC_GT, B), dim3(256), sizeof(float) * 4 * (size_t)C,
                        (hipStream_t)stream, (const float*)logp, (const long long*)targets, (const long long*)in_len,

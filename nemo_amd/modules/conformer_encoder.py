@@ -183,6 +183,7 @@ class _GraphSet:
         self.samples = {"eager": [], "graph": []}   # (start, end) event pairs
         self.open_pair = None   # [mode, start event, None] of the step in flight
         self.decided = None     # None (still measuring) | "eager" | "graph"
+        self.inherited = False  # the decision was taken over from another padded length of the same configuration (no trial)
 
 
 class ConformerEncoder(NeuralModule):
@@ -333,7 +334,11 @@ class ConformerEncoder(NeuralModule):
         self.graph_bwd_live = os.environ.get("MI355X_GRAPHS_BWD_LIVE", "0") != "0"
         self.graph_warmup = 2       # eager training forwards per key before its launch sequence is captured
         self.graph_trials = 4       # auto: timed steps per mode, alternating
-        self.max_graph_sets = 8     # distinct (shape, configuration) keys kept (a duration-bucketed loader has a handful)
+        # distinct (shape, configuration) keys kept.  A recorded sequence costs host memory only (its launches point into the ONE
+        # step arena every padded length shares), so a duration-bucketed / `pad_to`-quantised loader keeps one per padded length
+        self.max_graph_sets = int(os.environ.get("MI355X_GRAPH_SETS", "64"))
+        self.graph_warmup_inherited = 1   # ... for a padded length whose configuration has already been decided by another length
+        self.replayed_steps = self.live_steps = 0   # diagnostics (bench.py): training forwards served from a recording / issued live
         self._graph_sets = OrderedDict()
         self._cur_gs = None
         # ---- step-scoped bump allocation of the sequencer's tensors (nemo_amd/arena.py); MI355X_ARENA=0: torch's caching allocator
@@ -570,20 +575,37 @@ class ConformerEncoder(NeuralModule):
         """-> (out, enc_len, graph set, generation) from the recorded sequence, or None when this call has to run eagerly"""
         self._cur_gs = None
         if not (self.use_graphs and self.training and mel.is_cuda) or ops.GEMM_PROFILE is not None:
+            self.live_steps += 1
             return None
         if self._packing_plan(length, mel.shape[0], mel.shape[2], peek=True) is not None:
+            self.live_steps += 1
             return None  # packed rows: the row count changes with every batch, a recorded sequence holds one shape
         key = self._graph_key(mel, length)
         gs = self._graph_sets.get(key)
+        auto = self.graph_auto
         if gs is None:
             gs = self._graph_sets[key] = _GraphSet()
             while len(self._graph_sets) > self.max_graph_sets:
                 self._graph_sets.popitem(last=False)
+            if not auto:
+                # (forced replay: a later padded length of a configuration that has already been recorded once needs one live
+                #  visit -- the per-length caches -- instead of graph_warmup of them)
+                gs.inherited = any(g2 is not gs and g2.bwd is not None and k2[1:] == key[1:] for k2, g2 in self._graph_sets.items())
         else:
             self._graph_sets.move_to_end(key)
         gs.calls += 1
         self._cur_gs = gs
-        auto = self.graph_auto
+        if auto and gs.decided is None and gs.open_pair is None:
+            # Variable-length loaders: whether a recorded sequence beats live launches is a property of the recipe (is the host or the
+            # device the bound?), not of the padded length -- the first length that finishes its trial decides for every other
+            # length of the same configuration (same key but for the shape), which then needs no 2 x graph_trials visits of its own
+            for k2, g2 in self._graph_sets.items():
+                if g2 is not gs and g2.decided is not None and not g2.inherited and k2[1:] == key[1:]:
+                    gs.decided, gs.inherited = g2.decided, True
+                    gs.samples = {"eager": [], "graph": []}
+                    if gs.decided == "eager":
+                        gs.fwd = gs.bwd = gs.S = gs.out = gs.enc_len = gs.mel = gs.dout = None
+                    break
         if auto and gs.decided is None and self._dp_world() > 1:
             # data-parallel runs keep live launches unless MI355X_GRAPHS=1 asks for the replay: the trial would time recorded
             # segments with live RCCL collectives between them -- a combination that has only ever run on gloo -- for a replay that
@@ -591,8 +613,10 @@ class ConformerEncoder(NeuralModule):
             # the same number of warm-up steps by construction
             gs.decided = "eager"
         if auto and (gs.decided == "eager" or not self._in_step):
+            self.live_steps += 1
             return None
-        if gs.failed or gs.calls <= self.graph_warmup:
+        if gs.failed or gs.calls <= (self.graph_warmup_inherited if gs.inherited else self.graph_warmup):
+            self.live_steps += 1
             return None
         if gs.fwd is None:
             try:
@@ -604,6 +628,7 @@ class ConformerEncoder(NeuralModule):
                 warnings.warn(f"recording the encoder forward as hipGraphs failed ({type(e).__name__}: {e}); this shape keeps "
                               "running on the eager sequencer")
                 gs.failed, gs.fwd, gs.S = True, None, None
+                self.live_steps += 1
                 return None
         elif auto and gs.decided is None and gs.bwd is not None:
             # the trial: live launches and replay ALTERNATE step by step, each timed on the device from here to the end of backward
@@ -611,15 +636,18 @@ class ConformerEncoder(NeuralModule):
             if n_e >= self.graph_trials and n_g >= self.graph_trials:
                 self._auto_decide(gs)
                 if gs.decided == "eager":
+                    self.live_steps += 1
                     return None
             elif n_e <= n_g:
                 self._auto_begin(gs, "eager")
+                self.live_steps += 1
                 return None
             else:
                 self._auto_begin(gs, "graph")
         gs.mel.copy_(mel)
         gs.length.copy_(length)
         gs.fwd.replay()
+        self.replayed_steps += 1
         gs.gen += 1
         self._fwd_serial += 1       # (the recorded tensors live in the shared arena: ANY later forward overwrites them)
         gs.serial = self._fwd_serial
@@ -702,6 +730,21 @@ class ConformerEncoder(NeuralModule):
         if not (self.use_graphs and self.graph_auto):
             return True
         return all(gs.decided is not None or gs.failed for gs in self._graph_sets.values())
+
+    def graphs_recorded(self) -> bool:
+        """has every padded length seen so far reached its final way of running -- live launches by decision, or a recorded forward AND
+        backward?  (bench.py --var-len pre-visits the padded lengths of its timed batches until this holds: the state a training run
+        reaches after its first pass over the duration buckets)"""
+        if not self.use_graphs:
+            return True
+        for gs in self._graph_sets.values():
+            if gs.failed or gs.decided == "eager":
+                continue
+            if gs.bwd is None and not (self.graph_bwd_live and gs.fwd is not None):
+                return False
+            if self.graph_auto and gs.decided is None:
+                return False
+        return True
 
     def graph_info(self):
         """diagnostics (bench.py): recorded keys, graph segments and live host calls per forward / backward"""

@@ -303,3 +303,57 @@ def test_auto_mode_times_both_ways_and_keeps_one():
     m_e, l_e = _run(over, False, 16, batches)
     for a, b in zip(losses, l_e):
         assert abs(a - b) <= 5e-5 * abs(b), (losses, l_e)
+
+
+def test_many_padded_lengths_share_the_arena_and_stay_the_eager_sequence():
+    """a duration-shaped loader with the featurizer's `pad_to` (features.py:501): five padded lengths, visited in turn, each
+    recorded once (forced replay) -- every length's launches point into the ONE step arena, so a replay of length A after a live or
+    replayed step of length B must still be the eager step of A.  Lengths after the first recorded one need a single live visit."""
+    over = dict(d_model=64, n_heads=4, n_layers=2, **NODROP)
+    secs = [1.0, 1.3, 0.8, 1.6, 1.15]
+    batches = [_batch(B=3, secs=s, seed=8 + i, lens=[int(16000 * s), int(12000 * s), int(9000 * s)]) for i, s in enumerate(secs)]
+    order = [0, 1, 2, 3, 4] * 5 + [4, 2, 0, 3, 1, 1, 3]
+
+    def run(graphs):
+        torch.manual_seed(21)
+        m = _model(dict(over, compute_dtype=torch.float32)).to(dev).train()
+        m.decoder.compute_dtype = torch.float32
+        m.preprocessor.featurizer.pad_to = 16
+        m.encoder.use_graphs, m.encoder.graph_auto = graphs, False
+        m.setup_optimization(dict(name="adamw", lr=1e-3, betas=[0.9, 0.98], weight_decay=1e-3))
+        ls = [m.fit_step(batches[i])["loss"].item() for i in order]
+        torch.cuda.synchronize()
+        return m, ls
+
+    m_g, l_g = run(True)
+    m_e, l_e = run(False)
+    info = m_g.encoder.graph_info()
+    assert len(info) == len({-(-(b[0].shape[1] // 160 + 1) // 16) * 16 for b in batches}) == 5, info
+    _check_replay_kind(info, "tape")
+    assert m_g.encoder.graphs_recorded()
+    # 5 lengths x 2 warm-up visits + the recording visits are the only live ones; everything after replays
+    assert m_g.encoder.replayed_steps >= len(order) - 3 * 5 and m_g.encoder.live_steps <= 2 * 5, (m_g.encoder.replayed_steps, m_g.encoder.live_steps)
+    for a, b in zip(l_g, l_e):
+        assert abs(a - b) <= 5e-5 * abs(b), (l_g, l_e)
+
+
+def test_auto_mode_decides_once_per_configuration_not_once_per_padded_length():
+    """MI355X_GRAPHS=auto with several padded lengths: the first length that finishes its live-vs-recorded trial decides; the other
+    lengths take the decision over (no trial of their own) and the trajectory stays the eager one"""
+    over = dict(d_model=64, n_heads=4, n_layers=2, **NODROP)
+    batches = [_batch(B=3, secs=s, seed=8 + i) for i, s in enumerate([1.0, 1.4, 0.7])]
+    order = [0] * 13 + [1, 2, 1, 2, 1, 2, 0, 1, 2]
+    torch.manual_seed(21)
+    m = _model(dict(over, compute_dtype=torch.float32)).to(dev).train()
+    m.decoder.compute_dtype = torch.float32
+    m.setup_optimization(dict(name="adamw", lr=1e-3, betas=[0.9, 0.98], weight_decay=1e-3))
+    losses = [m.fit_step(batches[i])["loss"].item() for i in order]
+    enc = m.encoder
+    sets = list(enc._graph_sets.values())
+    assert len(sets) == 3 and all(g.decided is not None for g in sets), [g.decided for g in sets]
+    assert [g.inherited for g in sets].count(False) == 1 and len({g.decided for g in sets}) == 1
+    assert enc.graphs_settled() and enc.graphs_recorded()
+    m_e, l_e = _run(over, False, 0, batches)
+    l_e = [m_e.fit_step(batches[i])["loss"].item() for i in order]
+    for a, b in zip(losses, l_e):
+        assert abs(a - b) <= 5e-5 * abs(b), (losses, l_e)
