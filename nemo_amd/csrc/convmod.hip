@@ -57,6 +57,51 @@ __device__ __forceinline__ void unstage_tile(TT* yb, int T, int d, int t0, int c
   }
 }
 
+// BatchNorm + Swish backward applied on the way INTO the tile (the fused depthwise backward below): the tile receives
+//   dcc = gamma * rstd * (dy * swish'(gamma * xh + beta) - k1 - xh * k2),  xh = (cc - mean) * rstd
+// -- bn_swish_bwd_apply_kernel's arithmetic, rounded to the activation type exactly as that kernel's output tensor would be -- so the
+// [M, d] gradient between the two kernels is never written or read.  coef: [6][DW_CH] = mean, rstd, gamma, beta, k1, k2 of the
+// workgroup's channels.
+template <typename TT>
+__device__ __forceinline__ void stage_tile_bn(const TT* dyb, const TT* ccb, int T, int d, int t_first, int nrows, int c0,
+                                              float (*tile)[DW_LD], const float (*coef)[DW_CH]) {
+  constexpr int V = VecIO<TT>::V, CPR = DW_CH / V;
+  for (int q = threadIdx.x; q < nrows * CPR; q += 256) {
+    const int r = q / CPR, cc = (q - r * CPR) * V;
+    const int t = t_first + r, c = c0 + cc;
+    float v[V], u[V];
+    const bool in = t >= 0 && t < T;
+    if (in && c + V <= d) {
+      VecIO<TT>::load(dyb + (long long)t * d + c, v);
+      VecIO<TT>::load(ccb + (long long)t * d + c, u);
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const bool ok = in && c + j < d;
+        v[j] = ok ? ld(dyb + (long long)t * d + c + j) : 0.f;
+        u[j] = ok ? ld(ccb + (long long)t * d + c + j) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float xh = (u[j] - coef[0][cc + j]) * coef[1][cc + j];
+      float dz = v[j] * swish_grad(coef[2][cc + j] * xh + coef[3][cc + j]);
+      dz -= coef[4][cc + j] + xh * coef[5][cc + j];
+      v[j] = (in && c + j < d) ? round_as(coef[2][cc + j] * coef[1][cc + j] * dz, TT()) : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < V; j += 4) *reinterpret_cast<float4*>(&tile[r][cc + j]) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+  }
+}
+struct DwBnArgs {           // BatchNorm + Swish backward in front of the depthwise backward (null cc: plain depthwise backward)
+  const void* cc;           // BatchNorm input (= the depthwise conv's output), same type and layout as dy
+  const float *mean, *rstd, *gamma, *beta;
+  const double* sums;       // f64 [2][d]: sum dz, sum dz * xhat over all rows (bn_swish_bwd_reduce)
+  double inv_count;         // 1 / rows (host-known) ...
+  const double* count_dev;  // ... or the row count as a device f64 (SyncBatchNorm over ragged ranks)
+  int training;
+};
+
 // ------------------------------------------------------------------------------------------------ forward
 // x [B,T,d] -> y[b,t,c] = bias[c] + sum_k w[c,k] * x[b, t+k-pad, c]  (zero outside [0,T));  stats[0][c] += sum y, stats[1][c] += sum y^2
 template <typename TT, int KS>
@@ -109,10 +154,11 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const TT* __restrict__ 
 // dy [B,T,d], x [B,T,d]:  dx[t] = sum_k w[k] * dy[t + pad - k] ;  dw[c,k] += sum_{b,t} dy[t] * x[t+k-pad] ; dbias[c] += sum dy
 // grid (d/64, DW_SEG, B): one block walks the time tiles of its segment, one atomic per (c,k) per block at the end.
 #define DW_SEG 4
-template <typename TT, int KS>
+template <typename TT, int KS, bool BN>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
                                                          const float* __restrict__ w, TT* __restrict__ dx,
-                                                         float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ partial, int B, int T, int d) {
+                                                         float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ partial, int B, int T, int d,
+                                                         DwBnArgs bn) {
   constexpr int PAD = (KS - 1) / 2;
   constexpr int ROWS = DW_TT + KS - 1;
   __shared__ __attribute__((aligned(16))) float big[2][ROWS][DW_LD];  // dy tile | x tile (also the final reduction buffer)
@@ -132,10 +178,23 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ 
 #pragma unroll
   for (int k = 0; k < KS; ++k) { wk[k] = cv ? w[c * KS + k] : 0.f; gw[k] = 0.f; }
   float gb = 0.f;
+  __shared__ float coef[BN ? 6 : 1][DW_CH];
+  if (BN && threadIdx.x < DW_CH) {   // (visible behind the first barrier of the tile loop)
+    const int cl = threadIdx.x, cg = c0 + cl;
+    const bool ok = cg < d;
+    const double inv_count = bn.count_dev ? 1.0 / *bn.count_dev : bn.inv_count;
+    coef[0][cl] = ok ? bn.mean[cg] : 0.f;
+    coef[1][cl] = ok ? bn.rstd[cg] : 0.f;
+    coef[2][cl] = ok ? bn.gamma[cg] : 0.f;
+    coef[3][cl] = ok ? bn.beta[cg] : 0.f;
+    coef[4][cl] = (ok && bn.training) ? (float)(bn.sums[cg] * inv_count) : 0.f;
+    coef[5][cl] = (ok && bn.training) ? (float)(bn.sums[d + cg] * inv_count) : 0.f;
+  }
   for (int ti = tile_lo; ti < tile_hi; ++ti) {
     const int t0 = ti * DW_TT;
     __syncthreads();
-    stage_tile<TT>(dy + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tdy);
+    if (BN) stage_tile_bn<TT>(dy + (long long)b * T * d, (const TT*)bn.cc + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tdy, coef);
+    else stage_tile<TT>(dy + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tdy);
     stage_tile<TT>(x + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tx);
     __syncthreads();
     float vdy[DW_TQ + KS - 1], vx[DW_TQ + KS - 1];
@@ -702,14 +761,46 @@ extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, v
                        ksize, d, (float*)dw, (float*)dbias);
     return mi_check_launch();
   }
-#define DW_BWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS>), grid, block, 0, s, (const TT*)dy, \
-    (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d))
+  const DwBnArgs nobn = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0};
+#define DW_BWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS, false>), grid, block, 0, s, (const TT*)dy, \
+    (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d, nobn))
   switch (ksize) {
     case 31: DW_BWD(31); break;
     case 9: DW_BWD(9); break;
     case 5: DW_BWD(5); break;
     default: return MI_ERR_ARG;
   }
+  if (scratch)
+    MI_LAUNCH(tap_reduce_kernel, dim3(((ksize + 1) * d + 255) / 256, 4), dim3(256), 0, s, (const float*)scratch, nparts,
+                       ksize, d, (float*)dw, (float*)dbias);
+  return mi_check_launch();
+}
+// BatchNorm + Swish backward fused into the depthwise backward (conformer_modules.py:333-342 backward: swish -> batch_norm ->
+// depthwise_conv): dy is the gradient w.r.t. the Swish output, cc the BatchNorm input, sums what mi355x_bn_swish_bwd_reduce left.
+// Same results as mi355x_bn_swish_bwd_apply followed by mi355x_dwconv_bwd (the intermediate is rounded the same way), one launch and
+// 2 x [B, T, d] of HBM traffic less.  count > 0, or count_dev (device f64) for SyncBatchNorm over ragged ranks.
+extern "C" int mi355x_dwconv_bwd_bnswish(const void* dy, const void* cc, const void* mean, const void* rstd, const void* gamma,
+                                         const void* beta, const void* sums, double count, const void* count_dev, int training,
+                                         const void* x, const void* w, void* dx, void* dw, void* dbias, int dt, int B, int T, int d,
+                                         int ksize, void* scratch, long long scratch_elems, void* stream) {
+  mi_clear_errors();
+  if (!dy || !cc || !mean || !rstd || !gamma || !beta || !sums || !x || !w || !dx || !dw || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
+  if (!count_dev && count <= 0) return MI_ERR_ARG;
+  dim3 grid((d + DW_CH - 1) / DW_CH, DW_SEG, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const int nparts = B * DW_SEG;
+  if (scratch && scratch_elems < (long long)nparts * (ksize + 1) * d) return MI_ERR_ARG;
+  const DwBnArgs bn = {cc, (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta, (const double*)sums,
+                       count_dev ? 0.0 : 1.0 / count, (const double*)count_dev, training};
+#define DW_BWD_BN(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS, true>), grid, block, 0, s, (const TT*)dy, \
+    (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d, bn))
+  switch (ksize) {
+    case 31: DW_BWD_BN(31); break;
+    case 9: DW_BWD_BN(9); break;
+    case 5: DW_BWD_BN(5); break;
+    default: return MI_ERR_ARG;
+  }
+#undef DW_BWD_BN
   if (scratch)
     MI_LAUNCH(tap_reduce_kernel, dim3(((ksize + 1) * d + 255) / 256, 4), dim3(256), 0, s, (const float*)scratch, nparts,
                        ksize, d, (float*)dw, (float*)dbias);

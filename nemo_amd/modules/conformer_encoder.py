@@ -301,6 +301,8 @@ class ConformerEncoder(NeuralModule):
         self.posproj_side = os.environ.get("MI355X_POSPROJ_SIDE", "1") != "0"  # linear_pos weight gradients behind their producers on the side stream
         self._wg_pending, self._wg_rows = None, None
         self.conv2_implicit = os.environ.get("MI355X_CONV2_IMPLICIT", "1") != "0"
+        # conv module backward: BatchNorm + Swish backward inside the depthwise backward's tile staging (MI355X_BN_DW_FUSE=0: two launches)
+        self.fuse_bn_dwconv_bwd = os.environ.get("MI355X_BN_DW_FUSE", "1") != "0"
         self.ln_cast_fuse = os.environ.get("MI355X_LN_CAST_FUSE", "1") != "0"
         # one-launch feed-forward blocks (csrc/ffn.hip).  OFF by default: parity-green and 10 % faster than the GEMM pair in the
         # forward direction, but inside the training step the pair of fused launches measured +1.1 ms (40.65 vs 39.55 ms, same box,
@@ -539,7 +541,7 @@ class ConformerEncoder(NeuralModule):
     def _graph_key(self, mel, length):
         return (tuple(mel.shape), self._cdt(), str(mel.device), self._flatp.generation, self._syncbn_world(),
                 self.grad_ready_hook is not None, self._wgrad_join_per_layer, self.wgrad_side_stream, self.wgrad_grouped,
-                self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse,
+                self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse, self.fuse_bn_dwconv_bwd,
                 self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.graph_tape, self.swish_g, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder,
                 self.wgrad_defer, self.graph_bwd_live, self.posproj_side, self.wgrad_layers)
 
@@ -861,7 +863,8 @@ class ConformerEncoder(NeuralModule):
 
     def _defer_point(self, k):
         """see _backward_impl: point k of a layer's backward (1 = in front of the conv module's BatchNorm / depthwise / GLU
-        backward, 2 = in front of the attention backward)"""
+        backward, 2 = in front of the attention backward, 3 = in front of norm_conv's backward, 5 / 6 = inside the conv module: behind
+        the BatchNorm reduction / behind the depthwise backward)"""
         f = getattr(self, "_defer_flush", None)
         if f is None:
             return
@@ -1865,10 +1868,18 @@ class ConformerEncoder(NeuralModule):
         ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, Mg, d, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
         if training and S.bn_world > 1:
             self._sync_stats(sums)
-        dcc = self._new(Mg, d, dtype=cdt, device=dev)
-        ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, Mg, d)
+        self._defer_point(5)   # (experimental entry points of the weight-gradient launch: behind the BatchNorm reduction ...)
         dg = self._new(Mg, d, dtype=cdt, device=dev)
-        ops.dwconv_bwd(dcc, g, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
+        if self.fuse_bn_dwconv_bwd:
+            # BatchNorm + Swish backward applied while the depthwise backward stages its gradient tile: one launch, and the
+            # [B, T', d] gradient w.r.t. the BatchNorm input is neither written nor read back
+            ops.dwconv_bwd_bnswish(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, g, c.depthwise_conv.weight, dg,
+                                   c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
+        else:
+            dcc = self._new(Mg, d, dtype=cdt, device=dev)
+            ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, Mg, d)
+            ops.dwconv_bwd(dcc, g, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
+        self._defer_point(6)   # (... and behind the depthwise backward, beside the GLU backward and the pointwise dgrad GEMM)
         dpw1 = self._new(M, 2 * d, dtype=cdt, device=dev)
         ops.glu_bwd(pw1, dg, dpw1, S.len2, T2, Mg, d, cu=cu)
         self._wgrad(dpw1, 2 * d, 0, y3, d, 0, c.pointwise_conv1.weight.grad, 2 * d, d, M, bias_grad=c.pointwise_conv1.bias.grad)

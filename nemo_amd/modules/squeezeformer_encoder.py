@@ -555,10 +555,14 @@ class SqueezeformerEncoder(ConformerEncoder):
         ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, M, C2, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
         if training and S.bn_world > 1:
             self._sync_stats(sums)
-        dcc = self._new(M, C2, dtype=cdt, device=dev)
-        ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, M, C2)
         dg = self._new(M, C2, dtype=cdt, device=dev)
-        ops.dwconv_bwd(dcc, gact, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T, C2, k)
+        if self.fuse_bn_dwconv_bwd:   # (see ConformerEncoder._layer_bwd)
+            ops.dwconv_bwd_bnswish(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, gact, c.depthwise_conv.weight, dg,
+                                   c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T, C2, k)
+        else:
+            dcc = self._new(M, C2, dtype=cdt, device=dev)
+            ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, M, C2)
+            ops.dwconv_bwd(dcc, gact, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T, C2, k)
         dpw1 = self._new(M, C2, dtype=cdt, device=dev)
         ops.swish_mask_bwd(pw1, dg, dpw1, g.lens, T, M, C2)
         self._wgrad(dpw1, C2, 0, y3, dp, 0, c.pointwise_conv1.weight.grad, C2, d, M, bias_grad=c.pointwise_conv1.bias.grad)

@@ -806,6 +806,19 @@ def _dwconv_bn_swish(o, dtype, geom):
     assert rel_err(dw, wr.grad) < 5 * tol, rel_err(dw, wr.grad)
     # dbias is analytically ~0 under batch-stat BN; compare absolutely against the scale of dw
     assert (dbias.cpu() - br.grad).abs().max() < 5 * tol * wr.grad.abs().max() + 1e-3
+    # BatchNorm + Swish backward fused into the depthwise backward (mi355x_dwconv_bwd_bnswish) = the two launches above: the
+    # intermediate is rounded the same way, only the weight-gradient summation order (f32 partial slabs) is shared too
+    from nemo_amd._lib import lib
+    if lib.mi355x_dwconv_config(-1) == 0 or dtype == torch.float32:   # (the fused form extends the LDS-tile kernel)
+        for count in (n, torch.tensor([float(n)], device=dev, dtype=torch.float64)):
+            dx2 = torch.empty(Bn, T, d, device=dev, dtype=dtype)
+            dw2 = torch.zeros(d, 1, k, device=dev); dbias2 = torch.zeros(d, device=dev)
+            o.dwconv_bwd_bnswish(dy.to(dev), c, mu, rs, gamma.to(dev), beta.to(dev), sums, count, True, xd, w.to(dev), dx2, dw2,
+                                 dbias2, Bn, T, d, k)
+            torch.cuda.synchronize()
+            assert rel_err(dx2, dx) < 1e-5, rel_err(dx2, dx)
+            assert rel_err(dw2, dw) < 1e-5 and (dbias2 - dbias).abs().max() < 1e-5 * max(1.0, dw.abs().max().item())
+            assert rel_err(dx2, xr.grad) < 5 * tol and rel_err(dw2, wr.grad) < 5 * tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

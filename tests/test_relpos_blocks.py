@@ -41,7 +41,8 @@ def test_size_helpers_of_the_c_abi_match_the_layout():
         assert lib.mi355x_relpos_ds_elems(B, H, T) == RB.ds_elems(B, H, T)
         nT = RB.n_tiles(T)
         bchunk = 4 if B >= 8 else 1
-        assert lib.mi355x_relpos_dpos_partial_elems(B, H, T) == ((B + bchunk - 1) // bchunk) * nT * H * 4096
+        # (64 positions x the widest fused head, d_k' = 128: one scratch size for both head widths)
+        assert lib.mi355x_relpos_dpos_partial_elems(B, H, T) == ((B + bchunk - 1) // bchunk) * nT * H * 64 * 128
 
 
 CLEAN = """
