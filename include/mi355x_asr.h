@@ -381,11 +381,15 @@ int mi355x_bn_swish_bwd_apply_dev_count(const void* dy, const void* x, const voi
  * mi355x_dwconv_bwd is never materialised; same results, the intermediate rounded to the activation type as the two-launch form
  * rounds it).  dy = gradient w.r.t. the Swish output, cc = BatchNorm input (the depthwise conv's output), sums = f64 [2][d] left by
  * mi355x_bn_swish_bwd_reduce (all-reduced under SyncBatchNorm), count > 0 or count_dev (device f64).  x, w, dx, dw, dbias, scratch
- * as in mi355x_dwconv_bwd.  Replaces conformer_modules.py:333-342 backward (activation -> batch_norm -> depthwise_conv). */
+ * as in mi355x_dwconv_bwd.  Optionally the GLU backward on the way out as well (glu_in != NULL: [rows, 2d] input of the GLU,
+ * glu_din [rows, 2d] receives its gradient INSTEAD of dx; glu_len i64 [B] valid frames, zeros beyond them; glu_row_offsets i64 [B+1]:
+ * glu_in / glu_din hold packed rows -- mi355x_glu_bwd's semantics).  Replaces conformer_modules.py:333-342 backward
+ * (glu -> depthwise_conv -> batch_norm -> activation, walked backwards). */
 int mi355x_dwconv_bwd_bnswish(const void* dy, const void* cc, const void* mean, const void* rstd, const void* gamma,
                               const void* beta, const void* sums, double count, const void* count_dev, int training, const void* x,
-                              const void* w, void* dx, void* dw, void* dbias, int dtype, int B, int T, int d, int ksize,
-                              void* scratch, long long scratch_elems, void* stream);
+                              const void* w, void* dx, void* dw, void* dbias, const void* glu_in, void* glu_din, const void* glu_len,
+                              const void* glu_row_offsets, int dtype, int B, int T, int d, int ksize, void* scratch,
+                              long long scratch_elems, void* stream);
 int mi355x_bn_param_grad(const void* sums, void* dgamma, void* dbeta, int d, void* stream);
 
 /* ---- CTC loss: CTCLoss.forward, losses/ctc.py:68-82 (torch ctc_loss, blank = V, zero_infinity) ------------------

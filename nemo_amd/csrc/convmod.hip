@@ -93,6 +93,40 @@ __device__ __forceinline__ void stage_tile_bn(const TT* dyb, const TT* ccb, int 
     for (int j = 0; j < V; j += 4) *reinterpret_cast<float4*>(&tile[r][cc + j]) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
   }
 }
+// tile[DW_TT][DW_CH] (f32: d(depthwise input) = d(GLU output)) -> the two halves of d(GLU input); see DwBnArgs
+template <typename TT>
+__device__ __forceinline__ void unstage_tile_glu(const TT* gin, TT* gdin, const long long* len, const long long* cu, int b, int T, int d,
+                                                 int t0, int c0, float (*tile)[DW_LD]) {
+  constexpr int V = VecIO<TT>::V, CPR = DW_CH / V;
+  const int L = len ? (int)min((long long)T, len[b]) : T;
+  const long long base = cu ? cu[b] : (long long)b * T;
+  for (int q = threadIdx.x; q < DW_TT * CPR; q += 256) {
+    const int r = q / CPR, cc = (q - r * CPR) * V;
+    const int t = t0 + r, c = c0 + cc;
+    if (t >= T || c >= d) continue;          // (d is a multiple of V: a chunk is inside or outside)
+    const bool valid = t < L;
+    if (cu && !valid) continue;
+    const long long row = base + t;
+    float da[V], dg[V];
+    if (valid) {
+      float a[V], g[V];
+      VecIO<TT>::load(gin + row * 2 * d + c, a);
+      VecIO<TT>::load(gin + row * 2 * d + d + c, g);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float e = round_as(tile[r][cc + j], TT());   // (the two-launch form rounds dx to the activation type in between)
+        const float sg = sigmoidf_(g[j]);
+        da[j] = e * sg;
+        dg[j] = e * a[j] * sg * (1.f - sg);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) { da[j] = 0.f; dg[j] = 0.f; }
+    }
+    VecIO<TT>::store(gdin + row * 2 * d + c, da);
+    VecIO<TT>::store(gdin + row * 2 * d + d + c, dg);
+  }
+}
 struct DwBnArgs {           // BatchNorm + Swish backward in front of the depthwise backward (null cc: plain depthwise backward)
   const void* cc;           // BatchNorm input (= the depthwise conv's output), same type and layout as dy
   const float *mean, *rstd, *gamma, *beta;
@@ -100,6 +134,14 @@ struct DwBnArgs {           // BatchNorm + Swish backward in front of the depthw
   double inv_count;         // 1 / rows (host-known) ...
   const double* count_dev;  // ... or the row count as a device f64 (SyncBatchNorm over ragged ranks)
   int training;
+  // GLU backward applied on the way OUT of the tile (optional; conformer_modules.py:333-335 backward: glu -> depthwise_conv): instead
+  // of dx [B,T,d] the kernel writes d(pointwise_conv1 output) [rows, 2d] = (dx * sigmoid(b), dx * a * sigmoid'(b)), a | b = glu_in.
+  // glu_cu (packed rows): glu_in / glu_din hold only the valid frames, utterance b at rows cu[b]..; else the padded grid b*T + t.
+  // Frames beyond len[b] get zeros (padded grid) / have no row (packed).
+  const void* glu_in;
+  void* glu_din;
+  const long long* glu_len;
+  const long long* glu_cu;
 };
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -212,7 +254,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ 
       for (int k = 0; k < KS; ++k) gw[k] = fmaf(g, vx[o + k], gw[k]);
     }
     __syncthreads();
-    unstage_tile<TT>(dx + (long long)b * T * d, T, d, t0, c0, otile);
+    if (BN && bn.glu_in) unstage_tile_glu<TT>((const TT*)bn.glu_in, (TT*)bn.glu_din, bn.glu_len, bn.glu_cu, b, T, d, t0, c0, otile);
+    else unstage_tile<TT>(dx + (long long)b * T * d, T, d, t0, c0, otile);
   }
   // one LDS round for all KS+1 partial sums: [4 time groups][KS+1][64 channels] (re-uses the dy tile), then 2 atomics/thread
   __syncthreads();
@@ -761,7 +804,7 @@ extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, v
                        ksize, d, (float*)dw, (float*)dbias);
     return mi_check_launch();
   }
-  const DwBnArgs nobn = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0};
+  const DwBnArgs nobn = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
 #define DW_BWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS, false>), grid, block, 0, s, (const TT*)dy, \
     (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d, nobn))
   switch (ksize) {
@@ -781,17 +824,21 @@ extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, v
 // 2 x [B, T, d] of HBM traffic less.  count > 0, or count_dev (device f64) for SyncBatchNorm over ragged ranks.
 extern "C" int mi355x_dwconv_bwd_bnswish(const void* dy, const void* cc, const void* mean, const void* rstd, const void* gamma,
                                          const void* beta, const void* sums, double count, const void* count_dev, int training,
-                                         const void* x, const void* w, void* dx, void* dw, void* dbias, int dt, int B, int T, int d,
+                                         const void* x, const void* w, void* dx, void* dw, void* dbias, const void* glu_in,
+                                         void* glu_din, const void* glu_len, const void* glu_row_offsets, int dt, int B, int T, int d,
                                          int ksize, void* scratch, long long scratch_elems, void* stream) {
   mi_clear_errors();
-  if (!dy || !cc || !mean || !rstd || !gamma || !beta || !sums || !x || !w || !dx || !dw || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
+  if (!dy || !cc || !mean || !rstd || !gamma || !beta || !sums || !x || !w || !dw || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
   if (!count_dev && count <= 0) return MI_ERR_ARG;
+  // either dx, or the GLU backward's output (glu_in + glu_din; then d must be a whole number of 16-byte chunks)
+  if (glu_in ? (!glu_din || (d % (dt == MI_DT_BF16 ? 8 : 4)) || (glu_row_offsets && !glu_len)) : !dx) return MI_ERR_ARG;
   dim3 grid((d + DW_CH - 1) / DW_CH, DW_SEG, B), block(256);
   hipStream_t s = (hipStream_t)stream;
   const int nparts = B * DW_SEG;
   if (scratch && scratch_elems < (long long)nparts * (ksize + 1) * d) return MI_ERR_ARG;
   const DwBnArgs bn = {cc, (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta, (const double*)sums,
-                       count_dev ? 0.0 : 1.0 / count, (const double*)count_dev, training};
+                       count_dev ? 0.0 : 1.0 / count, (const double*)count_dev, training, glu_in, glu_din,
+                       (const long long*)glu_len, (const long long*)glu_row_offsets};
 #define DW_BWD_BN(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS, true>), grid, block, 0, s, (const TT*)dy, \
     (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d, bn))
   switch (ksize) {

@@ -303,6 +303,7 @@ class ConformerEncoder(NeuralModule):
         self.conv2_implicit = os.environ.get("MI355X_CONV2_IMPLICIT", "1") != "0"
         # conv module backward: BatchNorm + Swish backward inside the depthwise backward's tile staging (MI355X_BN_DW_FUSE=0: two launches)
         self.fuse_bn_dwconv_bwd = os.environ.get("MI355X_BN_DW_FUSE", "1") != "0"
+        self.fuse_glu_dwconv_bwd = os.environ.get("MI355X_GLU_DW_FUSE", "1") != "0"   # ... and the GLU backward in its write-out
         self.ln_cast_fuse = os.environ.get("MI355X_LN_CAST_FUSE", "1") != "0"
         # one-launch feed-forward blocks (csrc/ffn.hip).  OFF by default: parity-green and 10 % faster than the GEMM pair in the
         # forward direction, but inside the training step the pair of fused launches measured +1.1 ms (40.65 vs 39.55 ms, same box,
@@ -541,7 +542,7 @@ class ConformerEncoder(NeuralModule):
     def _graph_key(self, mel, length):
         return (tuple(mel.shape), self._cdt(), str(mel.device), self._flatp.generation, self._syncbn_world(),
                 self.grad_ready_hook is not None, self._wgrad_join_per_layer, self.wgrad_side_stream, self.wgrad_grouped,
-                self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse, self.fuse_bn_dwconv_bwd,
+                self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse, self.fuse_bn_dwconv_bwd, self.fuse_glu_dwconv_bwd,
                 self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.graph_tape, self.swish_g, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder,
                 self.wgrad_defer, self.graph_bwd_live, self.posproj_side, self.wgrad_layers)
 
@@ -1869,19 +1870,26 @@ class ConformerEncoder(NeuralModule):
         if training and S.bn_world > 1:
             self._sync_stats(sums)
         self._defer_point(5)   # (experimental entry points of the weight-gradient launch: behind the BatchNorm reduction ...)
-        dg = self._new(Mg, d, dtype=cdt, device=dev)
-        if self.fuse_bn_dwconv_bwd:
-            # BatchNorm + Swish backward applied while the depthwise backward stages its gradient tile: one launch, and the
-            # [B, T', d] gradient w.r.t. the BatchNorm input is neither written nor read back
-            ops.dwconv_bwd_bnswish(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, g, c.depthwise_conv.weight, dg,
-                                   c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
-        else:
-            dcc = self._new(Mg, d, dtype=cdt, device=dev)
-            ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, Mg, d)
-            ops.dwconv_bwd(dcc, g, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
-        self._defer_point(6)   # (... and behind the depthwise backward, beside the GLU backward and the pointwise dgrad GEMM)
         dpw1 = self._new(M, 2 * d, dtype=cdt, device=dev)
-        ops.glu_bwd(pw1, dg, dpw1, S.len2, T2, Mg, d, cu=cu)
+        if self.fuse_bn_dwconv_bwd and self.fuse_glu_dwconv_bwd:
+            # BatchNorm + Swish backward applied while the depthwise backward stages its gradient tile, the GLU backward while it
+            # writes its result: one launch for four, and neither the [B, T', d] gradient w.r.t. the BatchNorm input nor the one
+            # w.r.t. the GLU output is written or read back
+            ops.dwconv_bwd_bnswish(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, g, c.depthwise_conv.weight, None,
+                                   c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k, glu_in=pw1, glu_din=dpw1,
+                                   glu_len=S.len2, glu_cu=cu)
+            self._defer_point(6)
+        else:
+            dg = self._new(Mg, d, dtype=cdt, device=dev)
+            if self.fuse_bn_dwconv_bwd:
+                ops.dwconv_bwd_bnswish(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, g, c.depthwise_conv.weight, dg,
+                                       c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
+            else:
+                dcc = self._new(Mg, d, dtype=cdt, device=dev)
+                ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, Mg, d)
+                ops.dwconv_bwd(dcc, g, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
+            self._defer_point(6)   # (... and behind the depthwise backward, beside the GLU backward and the pointwise dgrad GEMM)
+            ops.glu_bwd(pw1, dg, dpw1, S.len2, T2, Mg, d, cu=cu)
         self._wgrad(dpw1, 2 * d, 0, y3, d, 0, c.pointwise_conv1.weight.grad, 2 * d, d, M, bias_grad=c.pointwise_conv1.bias.grad)
         dy3 = self._new(M, d, dtype=cdt, device=dev)
         ops.gemm(dpw1, W[f"L{i}.conv.pw1t"], dy3, M, d, 2 * d, 2 * d, W.pitch(f"L{i}.conv.pw1t"), d)

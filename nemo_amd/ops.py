@@ -564,15 +564,18 @@ def bn_stats_swish_fwd(x, stats, count, gamma, beta, y, mean, rstd, running_mean
                                         _ptr(running_var), momentum, eps, dt(x), M, d, _stream()), "bn_stats_swish_fwd")
 
 
-def dwconv_bwd_bnswish(dy, cc, mean, rstd, gamma, beta, sums, count, training, x, w, dx, dw, dbias, B, T, d, k):
+def dwconv_bwd_bnswish(dy, cc, mean, rstd, gamma, beta, sums, count, training, x, w, dx, dw, dbias, B, T, d, k, glu_in=None,
+                       glu_din=None, glu_len=None, glu_cu=None):
     """bn_swish_bwd_apply + dwconv_bwd in one launch (the gradient w.r.t. the BatchNorm input stays in the kernel's LDS tile);
-    `count`: python number or device f64 scalar tensor"""
+    `count`: python number or device f64 scalar tensor.  glu_in / glu_din: the GLU backward as well -- the kernel writes the gradient
+    of the GLU's [rows, 2d] input instead of dx (glu_bwd's semantics: zeros beyond glu_len, packed rows with glu_cu)"""
     n = 4 * B * (k + 1) * d
     sc = _scratch("dwconv_bwd", n, dy.device)
     dev_count = count if isinstance(count, torch.Tensor) else None
     check(lib.mi355x_dwconv_bwd_bnswish(_ptr(dy), _ptr(cc), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums),
                                         0.0 if dev_count is not None else float(count), _ptr(dev_count), int(training), _ptr(x),
-                                        _ptr(w), _ptr(dx), _ptr(dw), _ptr(dbias), dt(x), B, T, d, k, _ptr(sc), n, _stream()),
+                                        _ptr(w), _ptr(dx), _ptr(dw), _ptr(dbias), _ptr(glu_in), _ptr(glu_din), _ptr(glu_len),
+                                        _ptr(glu_cu), dt(x), B, T, d, k, _ptr(sc), n, _stream()),
           "dwconv_bwd_bnswish")
 
 

@@ -819,6 +819,28 @@ def _dwconv_bn_swish(o, dtype, geom):
             assert rel_err(dx2, dx) < 1e-5, rel_err(dx2, dx)
             assert rel_err(dw2, dw) < 1e-5 and (dbias2 - dbias).abs().max() < 1e-5 * max(1.0, dw.abs().max().item())
             assert rel_err(dx2, xr.grad) < 5 * tol and rel_err(dw2, wr.grad) < 5 * tol
+        # ... and with the GLU backward in its write-out (padded grid with ragged lengths, then packed rows) = mi355x_glu_bwd of dx
+        lens = torch.tensor([max(1, T - 7 * i) for i in range(Bn)], dtype=torch.int64)
+        pw1 = torch.randn(n, 2 * d, generator=g).to(dtype).to(dev)
+        want = torch.empty(n, 2 * d, device=dev, dtype=dtype)
+        o.glu_bwd(pw1, dx, want, lens.to(dev), T, n, d)
+        got = torch.full((n, 2 * d), float("nan"), device=dev, dtype=dtype)
+        dw3 = torch.zeros(d, 1, k, device=dev); dbias3 = torch.zeros(d, device=dev)
+        o.dwconv_bwd_bnswish(dy.to(dev), c, mu, rs, gamma.to(dev), beta.to(dev), sums, n, True, xd, w.to(dev), None, dw3, dbias3,
+                             Bn, T, d, k, glu_in=pw1, glu_din=got, glu_len=lens.to(dev))
+        torch.cuda.synchronize()
+        assert torch.isfinite(got.float()).all() and rel_err(got, want) < 1e-5, rel_err(got, want)
+        assert rel_err(dw3, dw) < 1e-5
+        cu = torch.zeros(Bn + 1, dtype=torch.int64); cu[1:] = torch.cumsum(lens, 0)
+        Mp = int(cu[-1])
+        rows = torch.cat([torch.arange(int(lens[b])) + b * T for b in range(Bn)]).to(dev)
+        pw1p = pw1[rows].contiguous()
+        gotp = torch.full((Mp, 2 * d), float("nan"), device=dev, dtype=dtype)
+        o.dwconv_bwd_bnswish(dy.to(dev), c, mu, rs, gamma.to(dev), beta.to(dev), sums, n, True, xd, w.to(dev), None,
+                             torch.zeros(d, 1, k, device=dev), torch.zeros(d, device=dev), Bn, T, d, k, glu_in=pw1p, glu_din=gotp,
+                             glu_len=lens.to(dev), glu_cu=cu.to(dev))
+        torch.cuda.synchronize()
+        assert torch.isfinite(gotp.float()).all() and rel_err(gotp, want[rows]) < 1e-5, rel_err(gotp, want[rows])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -14,10 +14,10 @@ from nemo_amd import ops
 from nemo_amd.models import EncDecCTCModel, conformer_ctc_config
 from oracle import conformer_ref as R  # batch generator only
 
-spec = sys.argv[1]
+specs = sys.argv[1].split(";")   # several knobs in one process ("a=0,1;b=1,2"): one after the other, each back at its first arm afterwards
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-name, vals = spec.split("=")
+name, vals = specs[0].split("=")
 def _num(v):
     if v.lstrip("-").isdigit():
         return int(v)
@@ -35,6 +35,9 @@ def set_arm(v):
         ops.gemm_config(int(name[4:]), v)
     elif name == "arena":
         m.encoder.use_arena = bool(v)
+    elif name.startswith("cfg:"):   # cfg:ctc=0,1 -> mi355x_ctc_config(v) (dwconv, logmel, ctc: library-side variant switches)
+        from nemo_amd._lib import lib
+        getattr(lib, f"mi355x_{name[4:]}_config")(int(v))
     elif name.startswith("env:"):
         os.environ[name[4:]] = str(v)
     elif name.startswith("model."):
@@ -59,21 +62,25 @@ if main_stream is not None:  # the whole step on a HIGH-priority stream (side st
     torch.cuda.set_stream(main_stream)
 for _ in range(4):
     m.fit_step(batch)
-res = {a: [] for a in arms}
-for r in range(rounds):
-    for a in (arms if r % 2 == 0 else arms[::-1]):
-        set_arm(a)
-        if GRAPHS:
-            m.encoder._graph_sets.clear()
-            for _ in range(3):
-                m.fit_step(batch)
-        m.fit_step(batch)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(per):
-            m.fit_step(batch)
-        torch.cuda.synchronize()
-        res[a].append((time.perf_counter() - t0) / per * 1e3)
-for a in arms:
-    v = sorted(res[a])
-    print(f"{name}={a}: median {v[len(v)//2]:.2f} ms  min {v[0]:.2f}  all {[round(x, 2) for x in res[a]]}")
+for spec in specs:
+  name, vals = spec.split("=")
+  arms = [_num(v) for v in vals.split(",")]
+  res = {a: [] for a in arms}
+  for r in range(rounds):
+      for a in (arms if r % 2 == 0 else arms[::-1]):
+          set_arm(a)
+          if GRAPHS:
+              m.encoder._graph_sets.clear()
+              for _ in range(3):
+                  m.fit_step(batch)
+          m.fit_step(batch)
+          torch.cuda.synchronize()
+          t0 = time.perf_counter()
+          for _ in range(per):
+              m.fit_step(batch)
+          torch.cuda.synchronize()
+          res[a].append((time.perf_counter() - t0) / per * 1e3)
+  for a in arms:
+      v = sorted(res[a])
+      print(f"{name}={a}: median {v[len(v)//2]:.2f} ms  min {v[0]:.2f}  all {[round(x, 2) for x in res[a]]}")
+  set_arm(arms[0])
