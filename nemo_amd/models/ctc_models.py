@@ -417,9 +417,6 @@ class EncDecCTCModel(nn.Module):
             if use_early:
                 self._optimizer.step_count -= 1  # begin_step counted it; step() counts again
             self._optimizer.step(lr=lr, grad_scale=scale)
-        pp = getattr(self.encoder, "prepack", None)
-        if pp is not None:
-            pp()   # the encoder's GEMM operand images of the NEXT step, packed now on the side stream (beside the next front end)
         if self._scheduler is not None:
             self._scheduler.step()
         self.global_step += 1

@@ -304,9 +304,6 @@ class ConformerEncoder(NeuralModule):
         # conv module backward: BatchNorm + Swish backward inside the depthwise backward's tile staging (MI355X_BN_DW_FUSE=0: two launches)
         self.fuse_bn_dwconv_bwd = os.environ.get("MI355X_BN_DW_FUSE", "1") != "0"
         self.fuse_glu_dwconv_bwd = os.environ.get("MI355X_GLU_DW_FUSE", "1") != "0"   # ... and the GLU backward in its write-out
-        # operand images re-packed at the END of the optimizer step on the side stream (prepack) instead of at the head of the forward
-        self.prepack_side = os.environ.get("MI355X_PREPACK", "1") != "0"
-        self._pack_event, self._last_fwd_live, self._last_plan_key = None, False, None
         self.ln_cast_fuse = os.environ.get("MI355X_LN_CAST_FUSE", "1") != "0"
         # one-launch feed-forward blocks (csrc/ffn.hip).  OFF by default: parity-green and 10 % faster than the GEMM pair in the
         # forward direction, but inside the training step the pair of fused launches measured +1.1 ms (40.65 vs 39.55 ms, same box,
@@ -450,39 +447,8 @@ class ConformerEncoder(NeuralModule):
             self._ws[key] = t
         return t[:n].view(shape)
 
-    def prepack(self):
-        """end of an optimizer step (the model's fit_step, after the closing AdamW slice): re-pack the GEMM operand images NOW, on
-        the weight-gradient stream, instead of at the head of the next forward on the main stream -- there the three pack launches
-        (~0.26 ms at Conformer-Large, profiles/r5_roofline_per_kernel.md) sat between the front end and conv1; here they run beside
-        the next step's log-mel / normalisation / SpecAugment / conv1 kernels, which read no image.  The next forward waits for the
-        pack's event in front of its first GEMM (_pack_wait).  Live launches only: a recorded forward re-packs inside its tape."""
-        if not (self.prepack_side and self.wgrad_side_stream and self._last_fwd_live and self._capture is None):
-            return
-        key = getattr(self, "_last_plan_key", None)
-        plan = self._plans.get(key) if key is not None else None
-        if plan is None or plan[3] == self._weights_version or self._wg_stream is None:
-            return
-        dev = self._wg_stream.device
-        side = self._wg_stream
-        side.wait_stream(torch.cuda.current_stream(dev))   # behind the optimizer's last slice
-        with torch.cuda.stream(side):
-            plan[0].run(); plan[1].run()
-            ev = torch.cuda.Event()
-            ev.record(side)
-        self._pack_event = ev
-        self._plans[key] = (plan[0], plan[1], plan[2], self._weights_version)
-
-    def _pack_wait(self):
-        """the current stream waits for a pre-pack in flight (see prepack); a no-op otherwise"""
-        ev, self._pack_event = getattr(self, "_pack_event", None), None
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-
-    def _plan(self, cdt, device, defer_wait=False):
+    def _plan(self, cdt, device):
         key = (cdt, str(device), self._flatp.generation)
-        self._last_plan_key = key
-        if not defer_wait:
-            self._pack_wait()
         plan = self._plans.get(key)
         if plan is None:
             self._plans = {}  # parameters moved: drop images of the old storage
@@ -555,7 +521,6 @@ class ConformerEncoder(NeuralModule):
             plan = (p, pf, None, -2)
             self._plans[key] = plan
         if plan[3] != self._weights_version or self._force_pack:
-            self._pack_wait()   # (never two packs of the same images in flight on two streams)
             plan[0].run(); plan[1].run()
             plan = (plan[0], plan[1], plan[2], self._weights_version)
             self._plans[key] = plan
@@ -656,8 +621,6 @@ class ConformerEncoder(NeuralModule):
         if gs.failed or gs.calls <= (self.graph_warmup_inherited if gs.inherited else self.graph_warmup):
             self.live_steps += 1
             return None
-        self._pack_wait()           # (a pre-pack in flight belongs in front of the recording / the replay, on the live stream)
-        self._last_fwd_live = False
         if gs.fwd is None:
             try:
                 self._capture_forward(gs, mel, length)
@@ -990,9 +953,7 @@ class ConformerEncoder(NeuralModule):
             raise NotImplementedError(f"bf16 compute needs d_model divisible by 8 (got d_model={self.d_model}); use "
                                       f"compute_dtype=torch.float32 for this geometry")
         training = self.training
-        # (a pre-pack of the operand images on the side stream is waited for in front of the first GEMM, behind conv1)
-        W, Wf = self._plan(cdt, dev, defer_wait=(self.subsampling == "striding" and self._capture is None))
-        self._last_fwd_live = self._capture is None
+        W, Wf = self._plan(cdt, dev)
         B, F_, T = mel.shape
         mel = mel.to(torch.float32).contiguous()
         d, H, dk, dff, C_ = self.d_model, self.n_heads, self.d_k, self.d_ff, self.pre_encode._conv_channels
@@ -1024,7 +985,6 @@ class ConformerEncoder(NeuralModule):
             # ---- sub-sampling: conv1 (direct) -> conv2 (implicit MFMA GEMM, ReLU+mask epilogue) -> out Linear (+xscale, dropout)
             S.out1 = self._new(B, T1, F1, C_, dtype=cdt, device=dev)
             ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, S.out1, len0, len1, C_)
-            self._pack_wait()
             # (channel counts the gather does not cover fall back to an im2col image, kept alive for the weight gradient)
             implicit = (self.conv2_implicit and self._conv2_implicit(cdt, C_, B * T2 * F2)
                         and B * T1 * F1 * C_ < 2 ** 31)  # the gathered weight gradient addresses the grid with 32-bit offsets

@@ -341,7 +341,6 @@ class SqueezeformerEncoder(ConformerEncoder):
         cdt = self._cdt()
         training = self.training
         W, Wf = self._plan(cdt, dev)
-        self._last_fwd_live = self._capture is None   # (prepack: see ConformerEncoder)
         B, F_, T = mel.shape
         mel = mel.to(torch.float32).contiguous()
         d = self.d_model
