@@ -345,6 +345,12 @@ int mi355x_dwconv_config(int level);
 /* ---- convolution module: depthwise conv + BatchNorm + Swish (conformer_modules.py:333-342, causal_convs.py:130-147) */
 int mi355x_dwconv_fwd(const void* x, const void* w /*[d,1,k]*/, const void* bias, void* y, int dtype,
                       void* stats /*f64 [2,d] += (sum, sumsq) or NULL*/, int B, int T, int d, int ksize, void* stream);
+/* GLU (+ pad mask) fused into the depthwise forward (conformer_modules.py:324-335: glu -> masked_fill -> depthwise_conv).  glu_in
+ * [rows, 2d] = the pointwise conv's output (rows = B*T, or the packed valid frames with row_offsets i64 [B+1] as in mi355x_glu_fwd);
+ * len i64 [B] (NULL: every frame valid); glu_out [B,T,d] receives the GLU output (zeros beyond len; backward's operand);
+ * w, bias, y, stats as in mi355x_dwconv_fwd.  d must be a whole number of 16-byte chunks. */
+int mi355x_dwconv_fwd_glu(const void* glu_in, const void* len, const void* row_offsets, void* glu_out, const void* w,
+                          const void* bias, void* y, int dtype, void* stats, int B, int T, int d, int ksize, void* stream);
 int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dtype, int B, int T,
                       int d, int ksize, void* scratch /* optional f32 [4*B*(ksize+1)*d]: two-stage reduction, no atomics */,
                       long long scratch_elems, void* stream);
@@ -389,7 +395,12 @@ int mi355x_dwconv_bwd_bnswish(const void* dy, const void* cc, const void* mean, 
                               const void* beta, const void* sums, double count, const void* count_dev, int training, const void* x,
                               const void* w, void* dx, void* dw, void* dbias, const void* glu_in, void* glu_din, const void* glu_len,
                               const void* glu_row_offsets, int dtype, int B, int T, int d, int ksize, void* scratch,
-                              long long scratch_elems, void* stream);
+                              long long scratch_elems, int defer_tap_reduce, void* stream);
+/* defer_tap_reduce != 0 above: the kernel leaves the B * 4 partial slabs of the tap / bias gradients in `scratch` (which then has to
+ * be the caller's own per layer) and THIS call adds them into dw [d, 1, k] / dbias [d] -- on whichever stream the caller likes:
+ * only the optimizer reads them (depthwise_conv.weight.grad, conformer_modules.py:333). */
+int mi355x_dwconv_tap_reduce(const void* scratch, long long scratch_elems, int B, int d, int ksize, void* dw, void* dbias,
+                             void* stream);
 int mi355x_bn_param_grad(const void* sums, void* dgamma, void* dbeta, int d, void* stream);
 
 /* ---- CTC loss: CTCLoss.forward, losses/ctc.py:68-82 (torch ctc_loss, blank = V, zero_infinity) ------------------

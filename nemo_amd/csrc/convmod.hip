@@ -144,12 +144,47 @@ struct DwBnArgs {           // BatchNorm + Swish backward in front of the depthw
   const long long* glu_cu;
 };
 
+// GLU (+ pad mask) applied on the way INTO the forward tile (conformer_modules.py:324-331 in front of the depthwise conv): the tile
+// receives x = a * sigmoid(b) * (t < len[b]) from the pointwise conv's [rows, 2d] output (packed rows with cu, see glu_fwd_kernel),
+// rounded to the activation type as the stand-alone GLU kernel's output would be; the workgroup's OWN rows [t0, t0 + DW_TT) are also
+// written to gout [B,T,d] (the depthwise weight gradient's operand in backward) -- the halo rows belong to the neighbours.
+template <typename TT>
+__device__ __forceinline__ void stage_tile_glu(const TT* gin, TT* gout, const long long* len, const long long* cu, int b, int T, int d,
+                                               int t_first, int nrows, int t0, int c0, float (*tile)[DW_LD]) {
+  constexpr int V = VecIO<TT>::V, CPR = DW_CH / V;
+  const int L = len ? (int)min((long long)T, len[b]) : T;
+  const long long base = cu ? cu[b] : (long long)b * T;
+  for (int q = threadIdx.x; q < nrows * CPR; q += 256) {
+    const int r = q / CPR, cc = (q - r * CPR) * V;
+    const int t = t_first + r, c = c0 + cc;
+    float v[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] = 0.f;
+    if (t >= 0 && t < L && c < d) {   // (d is a multiple of V: a chunk is inside or outside)
+      float a[V], g[V];
+      VecIO<TT>::load(gin + (base + t) * 2 * d + c, a);
+      VecIO<TT>::load(gin + (base + t) * 2 * d + d + c, g);
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = round_as(a[j] * sigmoidf_(g[j]), TT());
+    }
+#pragma unroll
+    for (int j = 0; j < V; j += 4) *reinterpret_cast<float4*>(&tile[r][cc + j]) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+    if (t >= t0 && t < t0 + DW_TT && t < T && c < d) VecIO<TT>::store(gout + ((long long)b * T + t) * d + c, v);
+  }
+}
+struct DwGluArgs {   // GLU in front of the depthwise forward (null in: plain depthwise forward)
+  const void* in;    // [rows, 2d]
+  void* out;         // [B, T, d] GLU output (kept for backward)
+  const long long* len;
+  const long long* cu;
+};
+
 // ------------------------------------------------------------------------------------------------ forward
 // x [B,T,d] -> y[b,t,c] = bias[c] + sum_k w[c,k] * x[b, t+k-pad, c]  (zero outside [0,T));  stats[0][c] += sum y, stats[1][c] += sum y^2
-template <typename TT, int KS>
+template <typename TT, int KS, bool GLU>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const TT* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, TT* __restrict__ y,
-                                                         double* __restrict__ stats, int B, int T, int d) {
+                                                         double* __restrict__ stats, int B, int T, int d, DwGluArgs glu) {
   constexpr int PAD = (KS - 1) / 2;
   constexpr int ROWS = DW_TT + KS - 1;
   __shared__ __attribute__((aligned(16))) float tile[ROWS][DW_LD];
@@ -161,7 +196,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const TT* __restrict__ 
   const int b = blockIdx.z;
   const int t0 = blockIdx.y * DW_TT;
   const bool cv = c < d;
-  stage_tile<TT>(x + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tile);
+  if (GLU) stage_tile_glu<TT>((const TT*)glu.in, (TT*)glu.out, glu.len, glu.cu, b, T, d, t0 - PAD, ROWS, t0, c0, tile);
+  else stage_tile<TT>(x + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tile);
   float wk[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) wk[k] = cv ? w[c * KS + k] : 0.f;
@@ -764,14 +800,38 @@ extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias,
 #undef DS_FWD
     return mi_check_launch();
   }
-#define DW_FWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_fwd_kernel<TT, KS>), grid, block, 0, s, (const TT*)x, \
-    (const float*)w, (const float*)bias, (TT*)y, (double*)stats, B, T, d))
+  const DwGluArgs noglu = {nullptr, nullptr, nullptr, nullptr};
+#define DW_FWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_fwd_kernel<TT, KS, false>), grid, block, 0, s, (const TT*)x, \
+    (const float*)w, (const float*)bias, (TT*)y, (double*)stats, B, T, d, noglu))
   switch (ksize) {
     case 31: DW_FWD(31); break;
     case 9: DW_FWD(9); break;
     case 5: DW_FWD(5); break;
     default: return MI_ERR_ARG;
   }
+#undef DW_FWD
+  return mi_check_launch();
+}
+// GLU (+ pad mask) fused into the depthwise forward (conformer_modules.py:324-335: glu -> masked_fill -> depthwise_conv): glu_in
+// [rows, 2d] is the pointwise conv's output (packed rows when row_offsets is given, as in mi355x_glu_fwd), glu_out [B,T,d] receives
+// the GLU output (backward's operand), y / stats as in mi355x_dwconv_fwd.  One launch, and the GLU output is not read back.
+extern "C" int mi355x_dwconv_fwd_glu(const void* glu_in, const void* len, const void* row_offsets, void* glu_out, const void* w,
+                                     const void* bias, void* y, int dt, void* stats, int B, int T, int d, int ksize, void* stream) {
+  mi_clear_errors();
+  if (!glu_in || !glu_out || !w || !y || B <= 0 || T <= 0 || d <= 0 || (d % (dt == MI_DT_BF16 ? 8 : 4)) || (row_offsets && !len))
+    return MI_ERR_ARG;
+  dim3 grid((d + DW_CH - 1) / DW_CH, (T + DW_TT - 1) / DW_TT, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const DwGluArgs glu = {glu_in, glu_out, (const long long*)len, (const long long*)row_offsets};
+#define DW_FWD_GLU(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_fwd_kernel<TT, KS, true>), grid, block, 0, s, (const TT*)nullptr, \
+    (const float*)w, (const float*)bias, (TT*)y, (double*)stats, B, T, d, glu))
+  switch (ksize) {
+    case 31: DW_FWD_GLU(31); break;
+    case 9: DW_FWD_GLU(9); break;
+    case 5: DW_FWD_GLU(5); break;
+    default: return MI_ERR_ARG;
+  }
+#undef DW_FWD_GLU
   return mi_check_launch();
 }
 extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dt, int B,
@@ -826,7 +886,7 @@ extern "C" int mi355x_dwconv_bwd_bnswish(const void* dy, const void* cc, const v
                                          const void* beta, const void* sums, double count, const void* count_dev, int training,
                                          const void* x, const void* w, void* dx, void* dw, void* dbias, const void* glu_in,
                                          void* glu_din, const void* glu_len, const void* glu_row_offsets, int dt, int B, int T, int d,
-                                         int ksize, void* scratch, long long scratch_elems, void* stream) {
+                                         int ksize, void* scratch, long long scratch_elems, int defer_tap_reduce, void* stream) {
   mi_clear_errors();
   if (!dy || !cc || !mean || !rstd || !gamma || !beta || !sums || !x || !w || !dw || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
   if (!count_dev && count <= 0) return MI_ERR_ARG;
@@ -848,9 +908,22 @@ extern "C" int mi355x_dwconv_bwd_bnswish(const void* dy, const void* cc, const v
     default: return MI_ERR_ARG;
   }
 #undef DW_BWD_BN
-  if (scratch)
+  if (defer_tap_reduce && !scratch) return MI_ERR_ARG;
+  if (scratch && !defer_tap_reduce)   // (deferred: the caller runs mi355x_dwconv_tap_reduce on the stream of its choice)
     MI_LAUNCH(tap_reduce_kernel, dim3(((ksize + 1) * d + 255) / 256, 4), dim3(256), 0, s, (const float*)scratch, nparts,
                        ksize, d, (float*)dw, (float*)dbias);
+  return mi_check_launch();
+}
+// second stage of the depthwise weight / bias gradient on its own: dw[c, k] += sum over the B * 4 partial slabs the backward kernels
+// left in `scratch`.  Nothing on the backward chain reads dw / dbias -- only the optimizer does -- so a caller that gives every
+// layer its own scratch can run this beside the chain (the weight-gradient stream) instead of inside it.
+extern "C" int mi355x_dwconv_tap_reduce(const void* scratch, long long scratch_elems, int B, int d, int ksize, void* dw, void* dbias,
+                                        void* stream) {
+  mi_clear_errors();
+  const int nparts = B * DW_SEG;
+  if (!scratch || !dw || B <= 0 || d <= 0 || ksize <= 0 || scratch_elems < (long long)nparts * (ksize + 1) * d) return MI_ERR_ARG;
+  MI_LAUNCH(tap_reduce_kernel, dim3(((ksize + 1) * d + 255) / 256, 4), dim3(256), 0, (hipStream_t)stream, (const float*)scratch,
+            nparts, ksize, d, (float*)dw, (float*)dbias);
   return mi_check_launch();
 }
 static int bn_finalize_launch(const void* stats, double count, const void* count_dev, void* mean, void* rstd,

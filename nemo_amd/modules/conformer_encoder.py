@@ -304,6 +304,8 @@ class ConformerEncoder(NeuralModule):
         # conv module backward: BatchNorm + Swish backward inside the depthwise backward's tile staging (MI355X_BN_DW_FUSE=0: two launches)
         self.fuse_bn_dwconv_bwd = os.environ.get("MI355X_BN_DW_FUSE", "1") != "0"
         self.fuse_glu_dwconv_bwd = os.environ.get("MI355X_GLU_DW_FUSE", "1") != "0"   # ... and the GLU backward in its write-out
+        self.tap_reduce_side = os.environ.get("MI355X_TAP_REDUCE_SIDE", "1") != "0"   # second stage of the depthwise tap gradients on the side stream
+        self.fuse_glu_dwconv_fwd = os.environ.get("MI355X_GLU_DW_FUSE_FWD", "1") != "0"   # forward: GLU in the depthwise conv's tile staging
         self.ln_cast_fuse = os.environ.get("MI355X_LN_CAST_FUSE", "1") != "0"
         # one-launch feed-forward blocks (csrc/ffn.hip).  OFF by default: parity-green and 10 % faster than the GEMM pair in the
         # forward direction, but inside the training step the pair of fused launches measured +1.1 ms (40.65 vs 39.55 ms, same box,
@@ -542,7 +544,7 @@ class ConformerEncoder(NeuralModule):
     def _graph_key(self, mel, length):
         return (tuple(mel.shape), self._cdt(), str(mel.device), self._flatp.generation, self._syncbn_world(),
                 self.grad_ready_hook is not None, self._wgrad_join_per_layer, self.wgrad_side_stream, self.wgrad_grouped,
-                self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse, self.fuse_bn_dwconv_bwd, self.fuse_glu_dwconv_bwd,
+                self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse, self.fuse_bn_dwconv_bwd, self.fuse_glu_dwconv_bwd, self.fuse_glu_dwconv_fwd, self.tap_reduce_side,
                 self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.graph_tape, self.swish_g, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder,
                 self.wgrad_defer, self.graph_bwd_live, self.posproj_side, self.wgrad_layers)
 
@@ -1424,7 +1426,9 @@ class ConformerEncoder(NeuralModule):
         pw1 = self._new(M, 2 * d, dtype=cdt, device=dev)
         ops.gemm(y3, W[f"L{i}.conv.pw1"], pw1, M, 2 * d, d, d, W.pitch(f"L{i}.conv.pw1"), 2 * d, bias=c.pointwise_conv1.bias)
         g = self._new(Mg, d, dtype=cdt, device=dev)   # the conv core stays on the padded grid (BatchNorm counts padded frames)
-        ops.glu_fwd(pw1, g, S.len2, T2, Mg, d, cu=cu)
+        fuse_glu = self.fuse_glu_dwconv_fwd and d % (8 if cdt == torch.bfloat16 else 4) == 0
+        if not fuse_glu:
+            ops.glu_fwd(pw1, g, S.len2, T2, Mg, d, cu=cu)
         cc = self._new(Mg, d, dtype=cdt, device=dev)
         bn = c.batch_norm
         bmean = self._new(d, dtype=torch.float32, device=dev)
@@ -1432,12 +1436,18 @@ class ConformerEncoder(NeuralModule):
         count = float(Mg)
         if training:
             stats = S.bn_stats[i]
-            ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T2, d, k)
+            if fuse_glu:   # GLU + pad mask applied while the depthwise forward stages its tile (g is written for backward, not re-read)
+                ops.dwconv_fwd_glu(pw1, S.len2, cu, g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T2, d, k)
+            else:
+                ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T2, d, k)
             if S.bn_world > 1:  # sums and count in one exchange; the global count stays on the device
                 self._sync_stats(stats[: 2 * d + 1])
                 count = stats[2 * d: 2 * d + 1]
         else:
-            ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
+            if fuse_glu:
+                ops.dwconv_fwd_glu(pw1, S.len2, cu, g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
+            else:
+                ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
             ops.bn_eval_stats(bn.running_mean, bn.running_var, bmean, brstd, bn.eps, d)
         z = self._new(Mg, d, dtype=cdt, device=dev)
         if training:
@@ -1875,9 +1885,15 @@ class ConformerEncoder(NeuralModule):
             # BatchNorm + Swish backward applied while the depthwise backward stages its gradient tile, the GLU backward while it
             # writes its result: one launch for four, and neither the [B, T', d] gradient w.r.t. the BatchNorm input nor the one
             # w.r.t. the GLU output is written or read back
+            side = self.tap_reduce_side and self.wgrad_side_stream
+            sc = ops.dwconv_tap_scratch(i, B, d, k, dev) if side else None   # (its own slabs per layer: the reduction runs later)
             ops.dwconv_bwd_bnswish(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, g, c.depthwise_conv.weight, None,
                                    c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k, glu_in=pw1, glu_din=dpw1,
-                                   glu_len=S.len2, glu_cu=cu)
+                                   glu_len=S.len2, glu_cu=cu, scratch=sc, defer_reduce=side)
+            if side:
+                # the second stage of the tap / bias gradient: nothing on the chain reads it -- it joins the weight-gradient stream
+                with self._wgrad_scope(sc, c.depthwise_conv.weight.grad):
+                    ops.dwconv_tap_reduce(sc, B, d, k, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad)
             self._defer_point(6)
         else:
             dg = self._new(Mg, d, dtype=cdt, device=dev)

@@ -521,6 +521,12 @@ def _scratch(name, n, device):
     return t
 
 
+def dwconv_fwd_glu(glu_in, lens, cu, glu_out, w, bias, y, stats, B, T, d, k):
+    """glu_fwd + dwconv_fwd in one launch: the GLU output is written (backward needs it) but never read back"""
+    check(lib.mi355x_dwconv_fwd_glu(_ptr(glu_in), _ptr(lens), _ptr(cu), _ptr(glu_out), _ptr(w), _ptr(bias), _ptr(y), dt(glu_in),
+                                    _ptr(stats), B, T, d, k, _stream()), "dwconv_fwd_glu")
+
+
 def dwconv_bwd(dy, x, w, dx, dw, dbias, B, T, d, k):
     n = 4 * B * (k + 1) * d
     sc = _scratch("dwconv_bwd", n, dy.device)
@@ -564,18 +570,27 @@ def bn_stats_swish_fwd(x, stats, count, gamma, beta, y, mean, rstd, running_mean
                                         _ptr(running_var), momentum, eps, dt(x), M, d, _stream()), "bn_stats_swish_fwd")
 
 
+def dwconv_tap_scratch(tag, B, d, k, device):
+    """a per-caller (per-layer) slab buffer for dwconv_bwd_bnswish(..., scratch=, defer_reduce=True) + dwconv_tap_reduce"""
+    return _scratch(f"dwconv_bwd_tap:{tag}", 4 * B * (k + 1) * d, device)
+
+
+def dwconv_tap_reduce(scratch, B, d, k, dw, dbias):
+    check(lib.mi355x_dwconv_tap_reduce(_ptr(scratch), scratch.numel(), B, d, k, _ptr(dw), _ptr(dbias), _stream()), "dwconv_tap_reduce")
+
+
 def dwconv_bwd_bnswish(dy, cc, mean, rstd, gamma, beta, sums, count, training, x, w, dx, dw, dbias, B, T, d, k, glu_in=None,
-                       glu_din=None, glu_len=None, glu_cu=None):
+                       glu_din=None, glu_len=None, glu_cu=None, scratch=None, defer_reduce=False):
     """bn_swish_bwd_apply + dwconv_bwd in one launch (the gradient w.r.t. the BatchNorm input stays in the kernel's LDS tile);
     `count`: python number or device f64 scalar tensor.  glu_in / glu_din: the GLU backward as well -- the kernel writes the gradient
     of the GLU's [rows, 2d] input instead of dx (glu_bwd's semantics: zeros beyond glu_len, packed rows with glu_cu)"""
     n = 4 * B * (k + 1) * d
-    sc = _scratch("dwconv_bwd", n, dy.device)
+    sc = scratch if scratch is not None else _scratch("dwconv_bwd", n, dy.device)
     dev_count = count if isinstance(count, torch.Tensor) else None
     check(lib.mi355x_dwconv_bwd_bnswish(_ptr(dy), _ptr(cc), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums),
                                         0.0 if dev_count is not None else float(count), _ptr(dev_count), int(training), _ptr(x),
                                         _ptr(w), _ptr(dx), _ptr(dw), _ptr(dbias), _ptr(glu_in), _ptr(glu_din), _ptr(glu_len),
-                                        _ptr(glu_cu), dt(x), B, T, d, k, _ptr(sc), n, _stream()),
+                                        _ptr(glu_cu), dt(x), B, T, d, k, _ptr(sc), n, int(bool(defer_reduce)), _stream()),
           "dwconv_bwd_bnswish")
 
 

@@ -831,6 +831,16 @@ def _dwconv_bn_swish(o, dtype, geom):
         torch.cuda.synchronize()
         assert torch.isfinite(got.float()).all() and rel_err(got, want) < 1e-5, rel_err(got, want)
         assert rel_err(dw3, dw) < 1e-5
+        # forward twin: GLU + pad mask in the depthwise forward's tile staging = mi355x_glu_fwd then mi355x_dwconv_fwd
+        g_ref = torch.empty(Bn, T, d, device=dev, dtype=dtype); c_two = torch.empty(Bn, T, d, device=dev, dtype=dtype)
+        st_two = torch.zeros(2, d, device=dev, dtype=torch.float64)
+        o.glu_fwd(pw1, g_ref.view(n, d), lens.to(dev), T, n, d)
+        o.dwconv_fwd(g_ref, w.to(dev), bias.to(dev), c_two, st_two, Bn, T, d, k)
+        g_one = torch.full((Bn, T, d), float("nan"), device=dev, dtype=dtype); c_one = torch.empty(Bn, T, d, device=dev, dtype=dtype)
+        st_one = torch.zeros(2, d, device=dev, dtype=torch.float64)
+        o.dwconv_fwd_glu(pw1, lens.to(dev), None, g_one, w.to(dev), bias.to(dev), c_one, st_one, Bn, T, d, k)
+        torch.cuda.synchronize()
+        assert torch.equal(g_one, g_ref) and rel_err(c_one, c_two) < 1e-6 and rel_err(st_one, st_two) < 1e-6
         cu = torch.zeros(Bn + 1, dtype=torch.int64); cu[1:] = torch.cumsum(lens, 0)
         Mp = int(cu[-1])
         rows = torch.cat([torch.arange(int(lens[b])) + b * T for b in range(Bn)]).to(dev)
@@ -841,6 +851,10 @@ def _dwconv_bn_swish(o, dtype, geom):
                              glu_len=lens.to(dev), glu_cu=cu.to(dev))
         torch.cuda.synchronize()
         assert torch.isfinite(gotp.float()).all() and rel_err(gotp, want[rows]) < 1e-5, rel_err(gotp, want[rows])
+        g_pk = torch.full((Bn, T, d), float("nan"), device=dev, dtype=dtype); c_pk = torch.empty(Bn, T, d, device=dev, dtype=dtype)
+        o.dwconv_fwd_glu(pw1p, lens.to(dev), cu.to(dev), g_pk, w.to(dev), bias.to(dev), c_pk, None, Bn, T, d, k)
+        torch.cuda.synchronize()
+        assert torch.equal(g_pk, g_ref) and rel_err(c_pk, c_two) < 1e-6
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
