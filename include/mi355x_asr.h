@@ -348,9 +348,10 @@ int mi355x_dwconv_fwd(const void* x, const void* w /*[d,1,k]*/, const void* bias
 /* GLU (+ pad mask) fused into the depthwise forward (conformer_modules.py:324-335: glu -> masked_fill -> depthwise_conv).  glu_in
  * [rows, 2d] = the pointwise conv's output (rows = B*T, or the packed valid frames with row_offsets i64 [B+1] as in mi355x_glu_fwd);
  * len i64 [B] (NULL: every frame valid); glu_out [B,T,d] receives the GLU output (zeros beyond len; backward's operand);
- * w, bias, y, stats as in mi355x_dwconv_fwd.  d must be a whole number of 16-byte chunks. */
+ * w, bias, y, stats as in mi355x_dwconv_fwd.  d must be a whole number of 16-byte chunks.  act: 0 = GLU as described, 1 = Swish of a
+ * [rows, d] input instead (ConformerConvolution(pointwise_activation='swish'), squeezeformer_modules.py:60-203). */
 int mi355x_dwconv_fwd_glu(const void* glu_in, const void* len, const void* row_offsets, void* glu_out, const void* w,
-                          const void* bias, void* y, int dtype, void* stats, int B, int T, int d, int ksize, void* stream);
+                          const void* bias, void* y, int dtype, void* stats, int B, int T, int d, int ksize, int act, void* stream);
 int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dtype, int B, int T,
                       int d, int ksize, void* scratch /* optional f32 [4*B*(ksize+1)*d]: two-stage reduction, no atomics */,
                       long long scratch_elems, void* stream);
@@ -389,12 +390,13 @@ int mi355x_bn_swish_bwd_apply_dev_count(const void* dy, const void* x, const voi
  * mi355x_bn_swish_bwd_reduce (all-reduced under SyncBatchNorm), count > 0 or count_dev (device f64).  x, w, dx, dw, dbias, scratch
  * as in mi355x_dwconv_bwd.  Optionally the GLU backward on the way out as well (glu_in != NULL: [rows, 2d] input of the GLU,
  * glu_din [rows, 2d] receives its gradient INSTEAD of dx; glu_len i64 [B] valid frames, zeros beyond them; glu_row_offsets i64 [B+1]:
- * glu_in / glu_din hold packed rows -- mi355x_glu_bwd's semantics).  Replaces conformer_modules.py:333-342 backward
+ * glu_in / glu_din hold packed rows -- mi355x_glu_bwd's semantics; glu_act 1: Swish backward of a [rows, d] input instead,
+ * mi355x_swish_mask_bwd's semantics).  Replaces conformer_modules.py:333-342 backward
  * (glu -> depthwise_conv -> batch_norm -> activation, walked backwards). */
 int mi355x_dwconv_bwd_bnswish(const void* dy, const void* cc, const void* mean, const void* rstd, const void* gamma,
                               const void* beta, const void* sums, double count, const void* count_dev, int training, const void* x,
                               const void* w, void* dx, void* dw, void* dbias, const void* glu_in, void* glu_din, const void* glu_len,
-                              const void* glu_row_offsets, int dtype, int B, int T, int d, int ksize, void* scratch,
+                              const void* glu_row_offsets, int glu_act, int dtype, int B, int T, int d, int ksize, void* scratch,
                               long long scratch_elems, int defer_tap_reduce, void* stream);
 /* defer_tap_reduce != 0 above: the kernel leaves the B * 4 partial slabs of the tap / bias gradients in `scratch` (which then has to
  * be the caller's own per layer) and THIS call adds them into dw [d, 1, k] / dbias [d] -- on whichever stream the caller likes:

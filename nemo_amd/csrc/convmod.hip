@@ -96,7 +96,7 @@ __device__ __forceinline__ void stage_tile_bn(const TT* dyb, const TT* ccb, int 
 // tile[DW_TT][DW_CH] (f32: d(depthwise input) = d(GLU output)) -> the two halves of d(GLU input); see DwBnArgs
 template <typename TT>
 __device__ __forceinline__ void unstage_tile_glu(const TT* gin, TT* gdin, const long long* len, const long long* cu, int b, int T, int d,
-                                                 int t0, int c0, float (*tile)[DW_LD]) {
+                                                 int t0, int c0, float (*tile)[DW_LD], int act) {
   constexpr int V = VecIO<TT>::V, CPR = DW_CH / V;
   const int L = len ? (int)min((long long)T, len[b]) : T;
   const long long base = cu ? cu[b] : (long long)b * T;
@@ -108,6 +108,19 @@ __device__ __forceinline__ void unstage_tile_glu(const TT* gin, TT* gdin, const 
     if (cu && !valid) continue;
     const long long row = base + t;
     float da[V], dg[V];
+    if (act == 1) {   // Swish backward of a [rows, d] matrix
+      if (valid) {
+        float a[V];
+        VecIO<TT>::load(gin + row * d + c, a);
+#pragma unroll
+        for (int j = 0; j < V; ++j) da[j] = round_as(tile[r][cc + j], TT()) * swish_grad(a[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) da[j] = 0.f;
+      }
+      VecIO<TT>::store(gdin + row * d + c, da);
+      continue;
+    }
     if (valid) {
       float a[V], g[V];
       VecIO<TT>::load(gin + row * 2 * d + c, a);
@@ -142,6 +155,7 @@ struct DwBnArgs {           // BatchNorm + Swish backward in front of the depthw
   void* glu_din;
   const long long* glu_len;
   const long long* glu_cu;
+  int glu_act;   // 0: GLU ([rows, 2d]), 1: Swish ([rows, d]; Squeezeformer's pointwise activation)
 };
 
 // GLU (+ pad mask) applied on the way INTO the forward tile (conformer_modules.py:324-331 in front of the depthwise conv): the tile
@@ -150,7 +164,7 @@ struct DwBnArgs {           // BatchNorm + Swish backward in front of the depthw
 // written to gout [B,T,d] (the depthwise weight gradient's operand in backward) -- the halo rows belong to the neighbours.
 template <typename TT>
 __device__ __forceinline__ void stage_tile_glu(const TT* gin, TT* gout, const long long* len, const long long* cu, int b, int T, int d,
-                                               int t_first, int nrows, int t0, int c0, float (*tile)[DW_LD]) {
+                                               int t_first, int nrows, int t0, int c0, float (*tile)[DW_LD], int act) {
   constexpr int V = VecIO<TT>::V, CPR = DW_CH / V;
   const int L = len ? (int)min((long long)T, len[b]) : T;
   const long long base = cu ? cu[b] : (long long)b * T;
@@ -162,10 +176,16 @@ __device__ __forceinline__ void stage_tile_glu(const TT* gin, TT* gout, const lo
     for (int j = 0; j < V; ++j) v[j] = 0.f;
     if (t >= 0 && t < L && c < d) {   // (d is a multiple of V: a chunk is inside or outside)
       float a[V], g[V];
-      VecIO<TT>::load(gin + (base + t) * 2 * d + c, a);
-      VecIO<TT>::load(gin + (base + t) * 2 * d + d + c, g);
+      if (act == 0) {   // GLU: a | b halves of a [rows, 2d] matrix
+        VecIO<TT>::load(gin + (base + t) * 2 * d + c, a);
+        VecIO<TT>::load(gin + (base + t) * 2 * d + d + c, g);
 #pragma unroll
-      for (int j = 0; j < V; ++j) v[j] = round_as(a[j] * sigmoidf_(g[j]), TT());
+        for (int j = 0; j < V; ++j) v[j] = round_as(a[j] * sigmoidf_(g[j]), TT());
+      } else {          // Swish of a [rows, d] matrix (Squeezeformer's conv module: pointwise_activation = 'swish')
+        VecIO<TT>::load(gin + (base + t) * d + c, a);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = round_as(swishf_(a[j]), TT());
+      }
     }
 #pragma unroll
     for (int j = 0; j < V; j += 4) *reinterpret_cast<float4*>(&tile[r][cc + j]) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
@@ -177,6 +197,7 @@ struct DwGluArgs {   // GLU in front of the depthwise forward (null in: plain de
   void* out;         // [B, T, d] GLU output (kept for backward)
   const long long* len;
   const long long* cu;
+  int act;           // 0: GLU of [rows, 2d], 1: Swish of [rows, d]
 };
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -196,7 +217,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const TT* __restrict__ 
   const int b = blockIdx.z;
   const int t0 = blockIdx.y * DW_TT;
   const bool cv = c < d;
-  if (GLU) stage_tile_glu<TT>((const TT*)glu.in, (TT*)glu.out, glu.len, glu.cu, b, T, d, t0 - PAD, ROWS, t0, c0, tile);
+  if (GLU) stage_tile_glu<TT>((const TT*)glu.in, (TT*)glu.out, glu.len, glu.cu, b, T, d, t0 - PAD, ROWS, t0, c0, tile, glu.act);
   else stage_tile<TT>(x + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tile);
   float wk[KS];
 #pragma unroll
@@ -290,7 +311,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ 
       for (int k = 0; k < KS; ++k) gw[k] = fmaf(g, vx[o + k], gw[k]);
     }
     __syncthreads();
-    if (BN && bn.glu_in) unstage_tile_glu<TT>((const TT*)bn.glu_in, (TT*)bn.glu_din, bn.glu_len, bn.glu_cu, b, T, d, t0, c0, otile);
+    if (BN && bn.glu_in) unstage_tile_glu<TT>((const TT*)bn.glu_in, (TT*)bn.glu_din, bn.glu_len, bn.glu_cu, b, T, d, t0, c0, otile, bn.glu_act);
     else unstage_tile<TT>(dx + (long long)b * T * d, T, d, t0, c0, otile);
   }
   // one LDS round for all KS+1 partial sums: [4 time groups][KS+1][64 channels] (re-uses the dy tile), then 2 atomics/thread
@@ -800,7 +821,7 @@ extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias,
 #undef DS_FWD
     return mi_check_launch();
   }
-  const DwGluArgs noglu = {nullptr, nullptr, nullptr, nullptr};
+  const DwGluArgs noglu = {nullptr, nullptr, nullptr, nullptr, 0};
 #define DW_FWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_fwd_kernel<TT, KS, false>), grid, block, 0, s, (const TT*)x, \
     (const float*)w, (const float*)bias, (TT*)y, (double*)stats, B, T, d, noglu))
   switch (ksize) {
@@ -816,13 +837,15 @@ extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias,
 // [rows, 2d] is the pointwise conv's output (packed rows when row_offsets is given, as in mi355x_glu_fwd), glu_out [B,T,d] receives
 // the GLU output (backward's operand), y / stats as in mi355x_dwconv_fwd.  One launch, and the GLU output is not read back.
 extern "C" int mi355x_dwconv_fwd_glu(const void* glu_in, const void* len, const void* row_offsets, void* glu_out, const void* w,
-                                     const void* bias, void* y, int dt, void* stats, int B, int T, int d, int ksize, void* stream) {
+                                     const void* bias, void* y, int dt, void* stats, int B, int T, int d, int ksize, int act,
+                                     void* stream) {
   mi_clear_errors();
-  if (!glu_in || !glu_out || !w || !y || B <= 0 || T <= 0 || d <= 0 || (d % (dt == MI_DT_BF16 ? 8 : 4)) || (row_offsets && !len))
+  if (!glu_in || !glu_out || !w || !y || B <= 0 || T <= 0 || d <= 0 || (d % (dt == MI_DT_BF16 ? 8 : 4)) || (row_offsets && !len) ||
+      (act != 0 && act != 1))
     return MI_ERR_ARG;
   dim3 grid((d + DW_CH - 1) / DW_CH, (T + DW_TT - 1) / DW_TT, B), block(256);
   hipStream_t s = (hipStream_t)stream;
-  const DwGluArgs glu = {glu_in, glu_out, (const long long*)len, (const long long*)row_offsets};
+  const DwGluArgs glu = {glu_in, glu_out, (const long long*)len, (const long long*)row_offsets, act};
 #define DW_FWD_GLU(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_fwd_kernel<TT, KS, true>), grid, block, 0, s, (const TT*)nullptr, \
     (const float*)w, (const float*)bias, (TT*)y, (double*)stats, B, T, d, glu))
   switch (ksize) {
@@ -864,7 +887,7 @@ extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, v
                        ksize, d, (float*)dw, (float*)dbias);
     return mi_check_launch();
   }
-  const DwBnArgs nobn = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+  const DwBnArgs nobn = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
 #define DW_BWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS, false>), grid, block, 0, s, (const TT*)dy, \
     (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d, nobn))
   switch (ksize) {
@@ -885,20 +908,22 @@ extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, v
 extern "C" int mi355x_dwconv_bwd_bnswish(const void* dy, const void* cc, const void* mean, const void* rstd, const void* gamma,
                                          const void* beta, const void* sums, double count, const void* count_dev, int training,
                                          const void* x, const void* w, void* dx, void* dw, void* dbias, const void* glu_in,
-                                         void* glu_din, const void* glu_len, const void* glu_row_offsets, int dt, int B, int T, int d,
-                                         int ksize, void* scratch, long long scratch_elems, int defer_tap_reduce, void* stream) {
+                                         void* glu_din, const void* glu_len, const void* glu_row_offsets, int glu_act, int dt, int B,
+                                         int T, int d, int ksize, void* scratch, long long scratch_elems, int defer_tap_reduce,
+                                         void* stream) {
   mi_clear_errors();
   if (!dy || !cc || !mean || !rstd || !gamma || !beta || !sums || !x || !w || !dw || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
   if (!count_dev && count <= 0) return MI_ERR_ARG;
   // either dx, or the GLU backward's output (glu_in + glu_din; then d must be a whole number of 16-byte chunks)
-  if (glu_in ? (!glu_din || (d % (dt == MI_DT_BF16 ? 8 : 4)) || (glu_row_offsets && !glu_len)) : !dx) return MI_ERR_ARG;
+  if (glu_in ? (!glu_din || (d % (dt == MI_DT_BF16 ? 8 : 4)) || (glu_row_offsets && !glu_len) || (glu_act != 0 && glu_act != 1)) : !dx)
+    return MI_ERR_ARG;
   dim3 grid((d + DW_CH - 1) / DW_CH, DW_SEG, B), block(256);
   hipStream_t s = (hipStream_t)stream;
   const int nparts = B * DW_SEG;
   if (scratch && scratch_elems < (long long)nparts * (ksize + 1) * d) return MI_ERR_ARG;
   const DwBnArgs bn = {cc, (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta, (const double*)sums,
                        count_dev ? 0.0 : 1.0 / count, (const double*)count_dev, training, glu_in, glu_din,
-                       (const long long*)glu_len, (const long long*)glu_row_offsets};
+                       (const long long*)glu_len, (const long long*)glu_row_offsets, glu_act};
 #define DW_BWD_BN(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS, true>), grid, block, 0, s, (const TT*)dy, \
     (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d, bn))
   switch (ksize) {

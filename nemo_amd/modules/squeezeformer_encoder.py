@@ -468,7 +468,9 @@ class SqueezeformerEncoder(ConformerEncoder):
         pw1 = self._new(M, C2, dtype=cdt, device=dev)
         ops.gemm(y3, W[f"L{i}.conv.pw1"], pw1, M, C2, d, dp, W.pitch(f"L{i}.conv.pw1"), C2, bias=c.pointwise_conv1.bias)
         gact = self._new(M, C2, dtype=cdt, device=dev)
-        ops.swish_mask_fwd(pw1, gact, g.lens, T, M, C2)
+        fuse_act = self.fuse_glu_dwconv_fwd and C2 % (8 if cdt == torch.bfloat16 else 4) == 0   # (see ConformerEncoder._layer_fwd)
+        if not fuse_act:
+            ops.swish_mask_fwd(pw1, gact, g.lens, T, M, C2)
         cc = self._new(M, C2, dtype=cdt, device=dev)
         bn = c.batch_norm
         bmean = self._new(C2, dtype=torch.float32, device=dev)
@@ -476,12 +478,18 @@ class SqueezeformerEncoder(ConformerEncoder):
         count = float(M)
         if training:
             stats = S.bn_stats[i]
-            ops.dwconv_fwd(gact, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T, C2, k)
+            if fuse_act:
+                ops.dwconv_fwd_glu(pw1, g.lens, None, gact, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T, C2, k, act=1)
+            else:
+                ops.dwconv_fwd(gact, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T, C2, k)
             if S.bn_world > 1:
                 self._sync_stats(stats[: 2 * C2 + 1])
                 count = stats[2 * C2: 2 * C2 + 1]
         else:
-            ops.dwconv_fwd(gact, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T, C2, k)
+            if fuse_act:
+                ops.dwconv_fwd_glu(pw1, g.lens, None, gact, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T, C2, k, act=1)
+            else:
+                ops.dwconv_fwd(gact, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T, C2, k)
             ops.bn_eval_stats(bn.running_mean, bn.running_var, bmean, brstd, bn.eps, C2)
         z = self._new(M, C2, dtype=cdt, device=dev)
         if training:
@@ -555,16 +563,22 @@ class SqueezeformerEncoder(ConformerEncoder):
         ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, M, C2, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
         if training and S.bn_world > 1:
             self._sync_stats(sums)
-        dg = self._new(M, C2, dtype=cdt, device=dev)
-        if self.fuse_bn_dwconv_bwd:   # (see ConformerEncoder._layer_bwd)
-            ops.dwconv_bwd_bnswish(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, gact, c.depthwise_conv.weight, dg,
-                                   c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T, C2, k)
-        else:
-            dcc = self._new(M, C2, dtype=cdt, device=dev)
-            ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, M, C2)
-            ops.dwconv_bwd(dcc, gact, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T, C2, k)
         dpw1 = self._new(M, C2, dtype=cdt, device=dev)
-        ops.swish_mask_bwd(pw1, dg, dpw1, g.lens, T, M, C2)
+        fuse_act = self.fuse_bn_dwconv_bwd and self.fuse_glu_dwconv_bwd and C2 % (8 if cdt == torch.bfloat16 else 4) == 0
+        if fuse_act:   # BatchNorm + Swish backward, depthwise backward and the pointwise Swish's backward in one launch
+            ops.dwconv_bwd_bnswish(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, gact, c.depthwise_conv.weight, None,
+                                   c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T, C2, k, glu_in=pw1, glu_din=dpw1,
+                                   glu_len=g.lens, glu_act=1)
+        else:
+            dg = self._new(M, C2, dtype=cdt, device=dev)
+            if self.fuse_bn_dwconv_bwd:   # (see ConformerEncoder._layer_bwd)
+                ops.dwconv_bwd_bnswish(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, gact, c.depthwise_conv.weight, dg,
+                                       c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T, C2, k)
+            else:
+                dcc = self._new(M, C2, dtype=cdt, device=dev)
+                ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, M, C2)
+                ops.dwconv_bwd(dcc, gact, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T, C2, k)
+            ops.swish_mask_bwd(pw1, dg, dpw1, g.lens, T, M, C2)
         self._wgrad(dpw1, C2, 0, y3, dp, 0, c.pointwise_conv1.weight.grad, C2, d, M, bias_grad=c.pointwise_conv1.bias.grad)
         dy3 = self._new(M, dp, dtype=cdt, device=dev)
         ops.gemm(dpw1, W[f"L{i}.conv.pw1t"], dy3, M, d, C2, C2, W.pitch(f"L{i}.conv.pw1t"), dp)

@@ -521,10 +521,11 @@ def _scratch(name, n, device):
     return t
 
 
-def dwconv_fwd_glu(glu_in, lens, cu, glu_out, w, bias, y, stats, B, T, d, k):
-    """glu_fwd + dwconv_fwd in one launch: the GLU output is written (backward needs it) but never read back"""
+def dwconv_fwd_glu(glu_in, lens, cu, glu_out, w, bias, y, stats, B, T, d, k, act=0):
+    """glu_fwd (act=0) / swish_mask_fwd (act=1) + dwconv_fwd in one launch: the activation's output is written (backward needs it)
+    but never read back"""
     check(lib.mi355x_dwconv_fwd_glu(_ptr(glu_in), _ptr(lens), _ptr(cu), _ptr(glu_out), _ptr(w), _ptr(bias), _ptr(y), dt(glu_in),
-                                    _ptr(stats), B, T, d, k, _stream()), "dwconv_fwd_glu")
+                                    _ptr(stats), B, T, d, k, act, _stream()), "dwconv_fwd_glu")
 
 
 def dwconv_bwd(dy, x, w, dx, dw, dbias, B, T, d, k):
@@ -580,7 +581,7 @@ def dwconv_tap_reduce(scratch, B, d, k, dw, dbias):
 
 
 def dwconv_bwd_bnswish(dy, cc, mean, rstd, gamma, beta, sums, count, training, x, w, dx, dw, dbias, B, T, d, k, glu_in=None,
-                       glu_din=None, glu_len=None, glu_cu=None, scratch=None, defer_reduce=False):
+                       glu_din=None, glu_len=None, glu_cu=None, scratch=None, defer_reduce=False, glu_act=0):
     """bn_swish_bwd_apply + dwconv_bwd in one launch (the gradient w.r.t. the BatchNorm input stays in the kernel's LDS tile);
     `count`: python number or device f64 scalar tensor.  glu_in / glu_din: the GLU backward as well -- the kernel writes the gradient
     of the GLU's [rows, 2d] input instead of dx (glu_bwd's semantics: zeros beyond glu_len, packed rows with glu_cu)"""
@@ -590,7 +591,7 @@ def dwconv_bwd_bnswish(dy, cc, mean, rstd, gamma, beta, sums, count, training, x
     check(lib.mi355x_dwconv_bwd_bnswish(_ptr(dy), _ptr(cc), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(sums),
                                         0.0 if dev_count is not None else float(count), _ptr(dev_count), int(training), _ptr(x),
                                         _ptr(w), _ptr(dx), _ptr(dw), _ptr(dbias), _ptr(glu_in), _ptr(glu_din), _ptr(glu_len),
-                                        _ptr(glu_cu), dt(x), B, T, d, k, _ptr(sc), n, int(bool(defer_reduce)), _stream()),
+                                        _ptr(glu_cu), glu_act, dt(x), B, T, d, k, _ptr(sc), n, int(bool(defer_reduce)), _stream()),
           "dwconv_bwd_bnswish")
 
 

@@ -855,6 +855,23 @@ def _dwconv_bn_swish(o, dtype, geom):
         o.dwconv_fwd_glu(pw1p, lens.to(dev), cu.to(dev), g_pk, w.to(dev), bias.to(dev), c_pk, None, Bn, T, d, k)
         torch.cuda.synchronize()
         assert torch.equal(g_pk, g_ref) and rel_err(c_pk, c_two) < 1e-6
+        # Squeezeformer's conv module: Swish + pad mask instead of the GLU (act = 1) = mi355x_swish_mask_fwd / _bwd around the core
+        sw_in = torch.randn(n, d, generator=g).to(dtype).to(dev)
+        s_ref = torch.empty(Bn, T, d, device=dev, dtype=dtype); c_sw2 = torch.empty(Bn, T, d, device=dev, dtype=dtype)
+        o.swish_mask_fwd(sw_in, s_ref.view(n, d), lens.to(dev), T, n, d)
+        o.dwconv_fwd(s_ref, w.to(dev), bias.to(dev), c_sw2, None, Bn, T, d, k)
+        s_one = torch.full((Bn, T, d), float("nan"), device=dev, dtype=dtype); c_sw1 = torch.empty(Bn, T, d, device=dev, dtype=dtype)
+        o.dwconv_fwd_glu(sw_in, lens.to(dev), None, s_one, w.to(dev), bias.to(dev), c_sw1, None, Bn, T, d, k, act=1)
+        torch.cuda.synchronize()
+        assert torch.equal(s_one, s_ref) and rel_err(c_sw1, c_sw2) < 1e-6
+        want_s = torch.empty(n, d, device=dev, dtype=dtype)
+        o.swish_mask_bwd(sw_in, dx.view(n, d), want_s, lens.to(dev), T, n, d)
+        got_s = torch.full((n, d), float("nan"), device=dev, dtype=dtype)
+        o.dwconv_bwd_bnswish(dy.to(dev), c, mu, rs, gamma.to(dev), beta.to(dev), sums, n, True, xd, w.to(dev), None,
+                             torch.zeros(d, 1, k, device=dev), torch.zeros(d, device=dev), Bn, T, d, k, glu_in=sw_in, glu_din=got_s,
+                             glu_len=lens.to(dev), glu_act=1)
+        torch.cuda.synchronize()
+        assert torch.isfinite(got_s.float()).all() and rel_err(got_s, want_s) < 1e-5, rel_err(got_s, want_s)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
