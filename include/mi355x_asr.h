@@ -60,7 +60,9 @@ typedef struct mi355x_gemm_desc {
   void* aux_out; int aux_out_dtype;
   long long ldaux;                  /* pitch of aux_in / aux_out (same batch offsets as C)                       */
   unsigned drop_key, drop_threshold; float drop_scale;   /* threshold 0 = dropout off                            */
-  const void* row_len; int rows_per_b; int rows_inner;   /* EPI_RELU_MASK: int64 [B] valid lengths               */
+  const void* row_len; int rows_per_b; int rows_inner;   /* EPI_RELU_MASK: int64 [B] valid lengths; optional with EPI_MUL_POS:
+                                                          * the caller's promise that aux_in <= 0 on rows beyond them -- tiles that
+                                                          * lie entirely there are zero-filled (through the row map) without a K loop */
   long long colsum_stride;          /* batch stride of colsum_out (elements)                                       */
   void* colsum_out;                 /* optional (bf16, transA=1, single-level batch): f32 [M] += sum_k A(k,m) -- the bias gradient
                                        of a Linear rides along with its weight-gradient GEMM                       */

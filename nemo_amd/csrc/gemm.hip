@@ -703,7 +703,7 @@ __device__ __forceinline__ void gatherT_setup(DmaGatherT<R>& g, const GemmP& p, 
 }
 template <int R>
 __device__ __forceinline__ void gatherT_issue(DmaGatherT<R>& g, const GemmP& p, const bf16_t* base, int tap,
-                                              bf16_t* lds_tile) {
+                                              bf16_t* lds_tile, const bool load = true /* uniform; false: only advance the positions */) {
   const int wave = threadIdx.x >> 6;
   const int di = tap_delta(p.g_dip, tap), dj = tap_delta(p.g_djp, tap);
   const int toff = (di * p.g_SJ + dj) * p.g_C;                                   // uniform
@@ -716,7 +716,7 @@ __device__ __forceinline__ void gatherT_issue(DmaGatherT<R>& g, const GemmP& p, 
     const bool ok = g.colok[c] && g.row[c] < p.K && (unsigned)si < (unsigned)p.g_SI && (unsigned)sj < (unsigned)p.g_SJ;
     const bf16_t* src = ok ? base + (g.off[c] + toff) : reinterpret_cast<const bf16_t*>(g_zero16);
     bf16_t* dst = lds_tile + (wave * 64 + c * 512) * 8;
-    __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+    if (load) __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
     // advance by one K-tile
     g.row[c] += BK; g.j[c] += BK; g.off[c] += step_j;
     while (g.j[c] >= p.g_nJ) { g.j[c] -= p.g_nJ; ++g.i[c]; g.off[c] += wrap_j; }
@@ -1356,8 +1356,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
     // EPI_RELU_MASK (the conv stack of the sub-sampling, rows = (utterance, time, ...)): a tile whose rows all lie beyond their
     // utterance's length is zero whatever the product says -- skip the K loop (round 5, SURVEY 8 f1: with unshaped batches 40 % of
     // the tiles of conv2 are such tails).  One utterance per tile only (a tile that crosses into the next utterance is computed).
-    if (p.epi == EPI_RELU_MASK && p.splitk <= 1 && !p.r_on && !p.aux_out && p.c_dt == MI_DT_BF16 && p.csc == 1 && p.vec_ok &&
-        !(p.N & 7)) {
+    // EPI_MUL_POS with row_len (the conv stack's input gradient, round 5): the caller promises that the gate aux_in is <= 0 on every
+    // row beyond its utterance's length (conv1's output is masked there), so such rows are zero too -- written through the row map.
+    const bool mask_tile = p.epi == EPI_RELU_MASK && !p.r_on;
+    const bool gate_tile = p.epi == EPI_MUL_POS && p.row_len != nullptr;
+    if ((mask_tile || gate_tile) && p.splitk <= 1 && !p.aux_out && p.c_dt == MI_DT_BF16 && p.csc == 1 && p.vec_ok && !(p.N & 7)) {
       const int mlast = min(m0 + BM2, p.M) - 1;
       const int b0 = m0 / p.rows_per_b, b1 = mlast / p.rows_per_b;
       const int t0 = (m0 - b0 * p.rows_per_b) / p.rows_inner;
@@ -1367,7 +1370,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
         const u32x4 zero = {0u, 0u, 0u, 0u};
         for (int e = threadIdx.x; e < nrow * cpr; e += 512) {
           const int r = e / cpr, c = e - r * cpr;
-          *reinterpret_cast<u32x4*>(Cz + (long long)(m0 + r) * p.ldc + n0 + c * 8) = zero;
+          *reinterpret_cast<u32x4*>(Cz + crow(p, m0 + r) * p.ldc + n0 + c * 8) = zero;
         }
         return;
       }
@@ -1404,22 +1407,50 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
   if constexpr (gatherB) gatherT_setup<BN4>(gB, p, n0, p.N, kt0 * BK);
   else dma_setup<TB, BN4>(dB, B, p.ldb, n0, p.N, kt0 * BK);
   const bool ktail = (p.K & (BK - 1)) != 0;
+  // conv weight gradient with row_len (round 5): K runs over the output positions (b, i, j); a K-tile whose 64
+  // positions all lie beyond their utterance's length multiplies zeros (dY is masked there) -- neither loaded nor multiplied.
+  // One utterance per tile only (a tile that crosses into the next utterance is computed).
+  // Called once per tile in increasing order: the utterance of the tile's first position is tracked incrementally, its length is
+  // re-read only when the tile sequence enters the next utterance (a load per K-tile would sit in front of every DMA issue).
+  int u_b = 0, u_row0 = 0, u_valid = 0;   // utterance of the current tile, its first position, its number of valid positions
+  if constexpr (gatherB) {
+    if (p.row_len) {
+      u_b = (kt0 * BK) / p.rows_per_b;
+      u_row0 = u_b * p.rows_per_b;
+      u_valid = (int)min((long long)p.rows_per_b, p.row_len[u_b] * p.rows_inner);
+    }
+  }
+  auto dead = [&](int it) -> bool {   // uniform
+    if constexpr (!gatherB) return false;
+    if (!p.row_len) return false;
+    const int k0 = (kt0 + it) * BK, k1 = min(k0 + BK, p.K) - 1;
+    while (k0 >= u_row0 + p.rows_per_b) {
+      ++u_b; u_row0 += p.rows_per_b;
+      u_valid = (int)min((long long)p.rows_per_b, p.row_len[u_b] * p.rows_inner);
+    }
+    return k1 < u_row0 + p.rows_per_b && k0 - u_row0 >= u_valid;
+  };
   auto issue_a = [&](int it) {
     bf16_t* st = smem4 + (it & 1) * NT4_STAGE;
     if constexpr (gatherA) gather_issue<BM2>(gA, p, kt0 + it, st);
     else dma_issue<BM2>(dA, it, (kt0 + it) * BK, p.K, ktail, st);
   };
-  auto issue_b = [&](int it) {
+  auto issue_b = [&](int it, bool load) {
     bf16_t* st = smem4 + (it & 1) * NT4_STAGE;
-    if constexpr (gatherB) gatherT_issue<BN4>(gB, p, (const bf16_t*)p.B, z0, st + BM2 * BK);
+    if constexpr (gatherB) gatherT_issue<BN4>(gB, p, (const bf16_t*)p.B, z0, st + BM2 * BK, load);
     else dma_issue<BN4>(dB, it, (kt0 + it) * BK, p.K, ktail, st + BM2 * BK);
   };
-  auto issue = [&](int it) { issue_a(it); issue_b(it); };
+  auto issue = [&](int it) -> bool {   // returns whether tile `it` carries work
+    const bool live = !dead(it);
+    if (live) issue_a(it);
+    issue_b(it, live);
+    return live;
+  };
   const int cs_step = tn < 8 ? tn : 8;  // column-sum rows dealt round-robin to the workgroups sharing this A tile
   const bool do_colsum = TA && p.colsum_out != nullptr && tile_n < cs_step;
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
+  bool live_cur = issue(0), live_next = false;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -1448,14 +1479,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
   for (int it = 0; it < nk; ++it) {
     // tile it+1 goes to the other stage: every wave passed the barrier after its last read of it
     const uint32_t sb = (uint32_t)((it & 1) * (NT4_STAGE * 2));
-    if (it + 1 < nk) issue(it + 1);
+    if (it + 1 < nk) live_next = issue(it + 1);
     __builtin_amdgcn_sched_barrier(0);
+    if (live_cur) {
     V4_RD(0, 0);
     V4_RD(1, 1); V4_WAIT(12, 0); V4_MM(0);
     V4_RD(0, 2); V4_WAIT(12, 1); V4_MM(1);
     V4_RD(1, 3); V4_WAIT(12, 0); V4_MM(0);
     V4_WAIT(0, 1); V4_MM(1);
-    if (do_colsum) {  // thread -> (k-group of 8 rows = wave, 4 consecutive columns = lane)
+    }
+    if (do_colsum && live_cur) {  // thread -> (k-group of 8 rows = wave, 4 consecutive columns = lane)
       const int col = lane * 4;
       const uint32_t a_addr = lds_addr(smem4) + sb;
       for (int kr = tile_n; kr < 8; kr += cs_step) {
@@ -1469,13 +1502,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    live_cur = live_next;
   }
 #undef V4_RD
 #undef V4_WAIT
 #undef V4_MM
   } else {
   for (int it = 0; it < nk; ++it) {
-    if (it + 1 < nk) issue(it + 1);  // other stage: every wave passed the barrier after its last read of it
+    if (it + 1 < nk) (void)issue(it + 1);  // other stage: every wave passed the barrier after its last read of it
     const bf16_t* a_s = smem4 + (it & 1) * NT4_STAGE;
     const bf16_t* b_s = a_s + BM2 * BK;
     // (measured: pipelining these reads one k-step ahead with inline-asm counted waits -- 12 reads in flight under the 8 MFMAs

@@ -305,6 +305,8 @@ class ConformerEncoder(NeuralModule):
         self.fuse_bn_dwconv_bwd = os.environ.get("MI355X_BN_DW_FUSE", "1") != "0"
         self.fuse_glu_dwconv_bwd = os.environ.get("MI355X_GLU_DW_FUSE", "1") != "0"   # ... and the GLU backward in its write-out
         self.tap_reduce_side = os.environ.get("MI355X_TAP_REDUCE_SIDE", "1") != "0"   # second stage of the depthwise tap gradients on the side stream
+        # sub-sampling backward: GEMM tiles / K-tiles that lie entirely beyond an utterance's length are skipped (row_len hints)
+        self.pad_tile_skip = os.environ.get("MI355X_PAD_SKIP", "1") != "0"
         self.fuse_glu_dwconv_fwd = os.environ.get("MI355X_GLU_DW_FUSE_FWD", "1") != "0"   # forward: GLU in the depthwise conv's tile staging
         self.ln_cast_fuse = os.environ.get("MI355X_LN_CAST_FUSE", "1") != "0"
         # one-launch feed-forward blocks (csrc/ffn.hip).  OFF by default: parity-green and 10 % faster than the GEMM pair in the
@@ -544,7 +546,7 @@ class ConformerEncoder(NeuralModule):
     def _graph_key(self, mel, length):
         return (tuple(mel.shape), self._cdt(), str(mel.device), self._flatp.generation, self._syncbn_world(),
                 self.grad_ready_hook is not None, self._wgrad_join_per_layer, self.wgrad_side_stream, self.wgrad_grouped,
-                self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse, self.fuse_bn_dwconv_bwd, self.fuse_glu_dwconv_bwd, self.fuse_glu_dwconv_fwd, self.tap_reduce_side,
+                self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse, self.fuse_bn_dwconv_bwd, self.fuse_glu_dwconv_bwd, self.fuse_glu_dwconv_fwd, self.tap_reduce_side, self.pad_tile_skip,
                 self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.graph_tape, self.swish_g, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder,
                 self.wgrad_defer, self.graph_bwd_live, self.posproj_side, self.wgrad_layers)
 
@@ -1658,7 +1660,9 @@ class ConformerEncoder(NeuralModule):
                      splitk=self._splitk(tiles, M, strided_c=True), batch=F2, nb0=F2, sB=(C_, 0), sC=(1, 0), c_col_stride=F2,
                      c_dtype=ops.F32)
         dout2 = self._new(B * T2 * F2, C_, dtype=cdt, device=dev)
-        ops.gemm(dxs, W["pre.outt"], dout2, M, F2 * C_, d, d, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=S.out2)
+        # (row_len: out2 -- the ReLU gate -- is zero beyond an utterance's len2 frames, row tiles that lie there are zero-filled)
+        ops.gemm(dxs, W["pre.outt"], dout2, M, F2 * C_, d, d, W.pitch("pre.outt"), F2 * C_, epi=ops.EPI_MUL_POS, aux_in=S.out2,
+                 row_len=S.len2 if self.pad_tile_skip else None, rows_per_b=T2, rows_inner=1)
         M2 = B * T2 * F2
         with self._sub_wgrad_scope(dout2):
             ops.colsum(dout2, pe.conv[2].bias.grad, M2, C_)  # 328 MB stream: next to the GEMMs, not in line with them
@@ -1669,7 +1673,7 @@ class ConformerEncoder(NeuralModule):
             with self._sub_wgrad_scope(dout2, S.out1):
                 ops.gemm(dout2, S.out1, pe.conv[2].weight.grad, C_, C_, M2, C_, C_, 9 * C_, transA=True, transB=True,
                          atomic=True, splitk=self._splitk(tiles, M2), batch=9, nb0=9, sC=(1, 0), c_col_stride=9,
-                         c_dtype=ops.F32,
+                         c_dtype=ops.F32, row_len=S.len2 if self.pad_tile_skip else None, rows_per_b=T2 * F2, rows_inner=F2,   # (K-tiles beyond an utterance: skipped)
                          gather=dict(operand=1, nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2,
                                      taps=[(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]))
         else:
@@ -1689,8 +1693,11 @@ class ConformerEncoder(NeuralModule):
                     nI, nJ = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
                     slots = self._dgrad_slots(pt, pf)
                     name = f"pre.w2d{pt}{pf}"
+                    # (row_len: conv1's output -- the ReLU gate -- is zero beyond an utterance's len1 <= 2 * len2 frames, so row tiles
+                    #  with i >= len2 are zero-filled without a K loop: 40 % of the tiles of an unshaped 5-30 s batch)
                     ops.gemm(dout2, W[name], dout1, B * nI * nJ, C_, len(slots) * C_, C_, W.pitch(name), C_,
-                             epi=ops.EPI_MUL_POS, aux_in=S.out1, ldaux=C_,
+                             epi=ops.EPI_MUL_POS, aux_in=S.out1, ldaux=C_, row_len=S.len2 if self.pad_tile_skip else None,
+                             rows_per_b=nI * nJ, rows_inner=nJ,
                              gather=dict(nI=nI, nJ=nJ, SI=T2, SJ=F2, C=C_, si=1, sj=1,
                                          taps=[(1 if kh == 0 else 0, 1 if kw == 0 else 0) for kh, kw in slots]),
                              rowmap=dict(nI=nI, nJ=nJ, OI=T1, OJ=F1, si=2, sj=2, oi=pt, oj=pf))

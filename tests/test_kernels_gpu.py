@@ -977,6 +977,59 @@ def test_conv2_implicit_gemm_forward_and_dgrad(T1, F1):
         assert rel_err(dW - 1.0, w2r.grad) < 2e-3, sk
 
 
+def test_conv2_dgrad_skips_row_tiles_beyond_the_utterances():
+    """The four parity-class input-gradient GEMMs with `row_len` (round 5): 256-row tiles whose rows all lie beyond their utterance
+    are zero-filled through the row map without a K loop.  Same launches with and without the hint on a ragged batch that is large
+    enough for the 256 x 256 structure (>= 224 workgroups): identical results, every row written."""
+    o = ops()
+    Bn, C_, T1, F1 = 5, 256, 1200, 40
+    T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+    g = torch.Generator().manual_seed(23)
+    len1 = torch.tensor([1200, 700, 301, 64, 1])
+    len2 = (len1 + 1) // 2
+    x = torch.relu(torch.randn(Bn, T1, F1, C_, generator=g)).to(torch.bfloat16)
+    x = x * (torch.arange(T1)[None, :, None, None] < len1[:, None, None, None])          # conv1's output: zero beyond len1
+    w2 = (torch.randn(C_, C_, 3, 3, generator=g) * 0.1).to(torch.bfloat16)
+    dy = torch.randn(Bn, T2, F2, C_, generator=g).to(torch.bfloat16)
+    xd, dyd, l2 = x.to(dev), dy.to(dev), len2.to(dev)
+    outs = []
+    for hint in (False, True):
+        dx = torch.full((Bn, T1, F1, C_), float("nan"), device=dev, dtype=torch.bfloat16)
+        for pt in (0, 1):
+            for pf in (0, 1):
+                nI, nJ = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
+                slots = [(kh, kw) for kh in ([1] if pt == 0 else [0, 2]) for kw in ([1] if pf == 0 else [0, 2])]
+                taps_d = [(1 if kh == 0 else 0, 1 if kw == 0 else 0) for kh, kw in slots]
+                wimg = torch.cat([w2[:, :, kh, kw].t() for kh, kw in slots], dim=1).contiguous().to(dev)
+                K = len(slots) * C_
+                kw_ = dict(row_len=l2, rows_per_b=nI * nJ, rows_inner=nJ) if hint else {}
+                o.gemm(dyd, wimg, dx, Bn * nI * nJ, C_, K, C_, K, C_, epi=o.EPI_MUL_POS, aux_in=xd, ldaux=C_,
+                       gather=dict(nI=nI, nJ=nJ, SI=T2, SJ=F2, C=C_, si=1, sj=1, taps=taps_d),
+                       rowmap=dict(nI=nI, nJ=nJ, OI=T1, OJ=F1, si=2, sj=2, oi=pt, oj=pf), **kw_)
+        torch.cuda.synchronize()
+        outs.append(dx.float())
+    a, b = outs
+    assert not torch.isnan(a).any() and not torch.isnan(b).any()
+    assert (a == b).all()                                                                  # (-0 == +0)
+    beyond = torch.arange(T1, device=dev)[None, :, None, None] >= len1.to(dev)[:, None, None, None]
+    assert (b * beyond == 0).all() and b.abs().max() > 0
+    # weight gradient: K runs over the output positions; K-tiles beyond an utterance (dy is masked there) are neither loaded nor
+    # multiplied with the hint.  Same sums up to the order of the split-K atomics.
+    dym = (dy * (torch.arange(T2)[None, :, None, None] < len2[:, None, None, None])).to(dev)
+    taps = [(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]
+    M2 = Bn * T2 * F2
+    res = []
+    for hint in (False, True):
+        kw_ = dict(row_len=l2, rows_per_b=T2 * F2, rows_inner=F2) if hint else {}
+        dW = torch.zeros(C_, C_, 3, 3, device=dev)
+        o.gemm(dym, xd, dW, C_, C_, M2, C_, C_, 9 * C_, transA=True, transB=True, atomic=True, splitk=6, batch=9, nb0=9,
+               sC=(1, 0), c_col_stride=9, c_dtype=o.F32,
+               gather=dict(operand=1, nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2, taps=taps), **kw_)
+        torch.cuda.synchronize()
+        res.append(dW)
+    assert torch.isfinite(res[1]).all() and rel_err(res[1], res[0]) < 1e-5, rel_err(res[1], res[0])
+
+
 # ---------------------------------------------------------------------------------------------- mel front-end
 def _fb_sparse(fb):
     from nemo_amd.modules.audio_preprocessing import sparsify_filterbank
