@@ -839,6 +839,11 @@ class ConformerEncoder(NeuralModule):
             from ..streams import private_stream  # (torch's pooled streams are shared beyond 32 creations per process)
             self._wg_stream = private_stream(dev, priority=prio)
         side = self._wg_stream
+        if torch.cuda.current_stream(dev) == side:
+            # nested scope (the padded-heads linear_pos weight gradients inside the posproj_side scope): already on the side lane.
+            # A stream waiting for its own event is a no-op live, but inside a stream capture it makes the side stream its own
+            # parallel capture stream and hip::Stream::EndCapture recurses until the stack ends (SIGSEGV at the Small geometry)
+            return contextlib.nullcontext()
         side.wait_stream(torch.cuda.current_stream(dev))  # operands are produced on the main stream
         if self._capture is not None:
             self._wg_forked = True  # the side stream is part of the capture now: it must re-join before the segment ends
@@ -894,11 +899,11 @@ class ConformerEncoder(NeuralModule):
                     self._capture.cut(self._live_wgrad_join)
                 return
             self._wg_forked = False
-        if self._wg_stream is not None:
-            torch.cuda.current_stream(self._wg_stream.device).wait_stream(self._wg_stream)
+        if self._wg_stream is not None and torch.cuda.current_stream(self._wg_stream.device) != self._wg_stream:
+            torch.cuda.current_stream(self._wg_stream.device).wait_stream(self._wg_stream)   # (never a stream on itself: _wgrad_scope)
 
     def _live_wgrad_join(self):
-        if self._wg_stream is not None:
+        if self._wg_stream is not None and torch.cuda.current_stream(self._wg_stream.device) != self._wg_stream:
             torch.cuda.current_stream(self._wg_stream.device).wait_stream(self._wg_stream)
 
     def _packing_plan(self, length, B, T_mel, lens=None, peek=False):

@@ -85,6 +85,24 @@ def test_recorded_sequence_is_the_eager_sequence_fp32(replay):
 
 
 @pytest.mark.parametrize("replay", REPLAYS)
+def test_recorded_sequence_with_zero_padded_heads_bf16(replay):
+    """d_k = 24 runs the fused attention through heads zero-padded to 64 lanes: the linear_pos weight gradients are then per-layer
+    batched GEMMs issued from INSIDE the side-stream scope of the positional gradients.  A nested scope used to make the side stream
+    wait for its own event -- harmless live, but inside a stream capture hip::Stream::EndCapture recursed until the stack ended
+    (`bench.py --size small` died with SIGSEGV under MI355X_GRAPHS=auto / 1).  Recorded and replayed here, against live launches."""
+    over = dict(d_model=48, n_heads=2, n_layers=2, **NODROP)
+    batches = [_batch(lens=[16000, 12000, 16000, 9000])]
+    m_g, l_g = _run(over, True, 6, batches, dtype=torch.bfloat16, replay=replay)
+    m_e, l_e = _run(over, False, 6, batches, dtype=torch.bfloat16)
+    assert m_g.encoder._geometry(torch.bfloat16)[1] == 64 and m_g.encoder.d_k == 24
+    info = m_g.encoder.graph_info()
+    _check_replay_kind(info, replay)
+    assert len(info) == 1 and info[0]["bwd_graphs"] >= 1, info
+    for i, (a, b) in enumerate(zip(l_g, l_e)):
+        assert abs(a - b) <= 2e-3 * (1 + i) * abs(b), (l_g, l_e)
+
+
+@pytest.mark.parametrize("replay", REPLAYS)
 def test_recorded_sequence_with_hooks_between_the_segments(replay):
     """optimizer-behind-backward installs a per-layer hook: the backward sequence is cut at every hook, which stays a live call"""
     over = dict(d_model=64, n_heads=4, n_layers=3, **NODROP)
