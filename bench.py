@@ -420,7 +420,11 @@ def main():
         a.no_cpu_baseline = True  # (the CPU leg times the Conformer-CTC oracle)
     else:
         vocab = 128
-        cfg = conformer_ctc_config(a.size, vocab_size=vocab, spec_augment=not a.no_spec_augment, compute_dtype=cdt)
+        try:
+            cfg = conformer_ctc_config(a.size, vocab_size=vocab, spec_augment=not a.no_spec_augment, compute_dtype=cdt)
+        except KeyError:
+            raise SystemExit(f"bench.py: --size {a.size} is not a Conformer-CTC recipe size (small, medium, large; the others belong "
+                             "to --model squeezeformer)") from None
         model = EncDecCTCModel(cfg)
         model.decoder.compute_dtype = cdt
     model = model.to(dev).train()
