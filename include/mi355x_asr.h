@@ -534,6 +534,13 @@ int mi355x_ctc_greedy_decode(const void* logp, const void* lens, void* tokens, v
  * parts/submodules/spectr_augment.py:153-215, SpecCutout.forward :245-261): x[b, f0:f1, t0:t1] = value for n rectangles
  * rects[n][5] = (b, f0, f1, t0, t1) (int32, device memory; clipped to the tensor).  x: f32 [B, F, T], in place. */
 int mi355x_fill_rects(void* x, const void* rects, int n, int B, int F, int T, float value, void* stream);
+/* SpecAugment mask parameters (SpectrogramAugmentation's vectorised path, parts/submodules/spectr_augment.py:155-195) from the four
+ * uniform draws the reference makes -- u_time_width, u_time_start f32 [B, time_masks]; u_freq_width, u_freq_start f32
+ * [B, freq_masks] -- and the feature lengths len i64 [B]: rects i32 [B * (time_masks + freq_masks), 5] = (b, f0, f1, t0, t1), time
+ * masks first, in the reference's f32 arithmetic (time_width: a fraction of the utterance when time_width_is_fraction, else frames). */
+int mi355x_specaug_rects(const void* u_time_width, const void* u_time_start, const void* u_freq_width, const void* u_freq_start,
+                         const void* len, void* rects, int B, int time_masks, int freq_masks, int F, int T, float time_width,
+                         int time_width_is_fraction, int freq_width, void* stream);
 
 /* ---- RNN-Transducer loss (FastConformer-Transducer, cfg 4) --------------------------------
  * Replaces the Numba-CUDA kernels behind RNNTLossNumba (nemo/collections/asr/parts/numba/rnnt_loss/rnnt_pytorch.py:39-98 ->

@@ -115,6 +115,7 @@ SIGNATURES = {
     "mi355x_add2": [vp, vp, i32, vp, i32, i64, i64, i32, vp],
     "mi355x_ctc_greedy_decode": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "mi355x_fill_rects": [vp, vp, i32, i32, i32, i32, f32, vp],
+    "mi355x_specaug_rects": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp],
     "mi355x_add2_colsum": [vp, vp, vp, i64, i64, i32, vp, vp, i64, vp],
     "mi355x_relpos_softmax_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_relpos_softmax_bwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],

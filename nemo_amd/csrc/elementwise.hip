@@ -427,3 +427,44 @@ extern "C" int mi355x_fill_rects(void* x, const void* rects, int n, int B, int F
                      n, B, F, T, value);
   return mi_check_launch();
 }
+
+// SpecAugment mask parameters on the device (round 5): the reference's vectorised path (spectr_augment.py:155-195) turns four
+// uniform draws into mask widths / starts with ~40 tiny tensor ops (multiply, clamp, .long(), subtract, stack, cat).  The draws
+// stay four torch.rand calls on the caller's side (same generator stream as the reference); this kernel does the rest in the same
+// f32 arithmetic -- width = min(f32(len) * tw, T) for a float time_width, w = trunc(u1 * width), start = trunc(u2 * f32(len - w)),
+// frequency masks against F -- and writes the rectangle table mi355x_fill_rects reads: rows (b, f0, f1, t0, t1), time masks
+// first (utterance-major), then frequency masks.
+__global__ __launch_bounds__(256) void specaug_rects_kernel(const float* __restrict__ u_tw, const float* __restrict__ u_ts,
+                                                            const float* __restrict__ u_fw, const float* __restrict__ u_fs,
+                                                            const long long* __restrict__ len, int* __restrict__ rects, int B, int nt,
+                                                            int nf, int F, int T, float tw, int tw_adaptive, float fw) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * (nt + nf)) return;
+  int* r = rects + 5 * e;
+  if (e < B * nt) {
+    const int b = e / nt;
+    const long long L = len[b];
+    const float width = tw_adaptive ? fminf((float)L * tw, (float)T) : tw;
+    const long long mw = (long long)(u_tw[e] * width);
+    const long long ms = (long long)(u_ts[e] * (float)(L - mw));
+    r[0] = b; r[1] = 0; r[2] = F; r[3] = (int)ms; r[4] = (int)(ms + mw);
+  } else {
+    const int e2 = e - B * nt;
+    const int b = e2 / nf;
+    const long long mw = (long long)(u_fw[e2] * fw);
+    const long long ms = (long long)(u_fs[e2] * (float)((long long)F - mw));
+    r[0] = b; r[1] = (int)ms; r[2] = (int)(ms + mw); r[3] = 0; r[4] = T;
+  }
+}
+extern "C" int mi355x_specaug_rects(const void* u_time_width, const void* u_time_start, const void* u_freq_width,
+                                    const void* u_freq_start, const void* len, void* rects, int B, int time_masks, int freq_masks,
+                                    int F, int T, float time_width, int time_width_is_fraction, int freq_width, void* stream) {
+  mi_clear_errors();
+  if (!len || !rects || B <= 0 || F <= 0 || T <= 0 || time_masks < 0 || freq_masks < 0 || time_masks + freq_masks == 0) return MI_ERR_ARG;
+  if ((time_masks > 0 && (!u_time_width || !u_time_start)) || (freq_masks > 0 && (!u_freq_width || !u_freq_start))) return MI_ERR_ARG;
+  const int n = B * (time_masks + freq_masks);
+  MI_LAUNCH(specaug_rects_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)u_time_width,
+            (const float*)u_time_start, (const float*)u_freq_width, (const float*)u_freq_start, (const long long*)len, (int*)rects, B,
+            time_masks, freq_masks, F, T, time_width, time_width_is_fraction, (float)freq_width);
+  return mi_check_launch();
+}

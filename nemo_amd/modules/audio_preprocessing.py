@@ -8,6 +8,7 @@ Same constructor kwargs, typed I/O, attributes callers touch (`_sample_rate`, `f
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -272,11 +273,22 @@ class SpectrogramAugmentation(NeuralModule):
         self.rect_masks, self.rect_time, self.rect_freq = int(rect_masks), rect_time, rect_freq
         self.mask_value = float(mask_value)
         self.use_vectorized_code = bool(use_vectorized_spec_augment)
+        self.fused_rects = os.environ.get("MI355X_SPECAUG_FUSED", "1") != "0"   # mask parameters in one launch (device tensors)
         if not isinstance(time_width, int) and (time_width > 1.0 or time_width < 0.0):
             raise ValueError("If `time_width` is a float value, must be in range [0, 1]")
 
     # ---- mask parameters (device-agnostic torch / python code: runs on CPU tensors in the tests)
     def _vectorized_rects(self, B, F, T, length, device):
+        if self.fused_rects and torch.device(device).type == "cuda" and isinstance(self.freq_width, int) \
+                and (self.time_masks + self.freq_masks) > 0 and length.dtype == torch.int64:
+            # the reference's four draws, in its order (time width, time start, frequency width, frequency start: the generator
+            # stream is the reference's), then ONE launch for the ~40 tensor ops below (mi355x_specaug_rects: same f32 arithmetic)
+            from .. import ops
+            u = [torch.rand((B, n), device=device, dtype=torch.float32) for n in (self.time_masks, self.time_masks,
+                                                                                   self.freq_masks, self.freq_masks)]
+            rects = torch.empty((B * (self.time_masks + self.freq_masks), 5), dtype=torch.int32, device=device)
+            return ops.specaug_rects(u[0], u[1], u[2], u[3], length.contiguous(), rects, B, self.time_masks, self.freq_masks, F, T,
+                                     self.time_width, self.freq_width)
         rows = []
         bidx = torch.arange(B, device=device).unsqueeze(1)
         for num, width, is_time in ((self.time_masks, self.time_width, True), (self.freq_masks, self.freq_width, False)):

@@ -410,6 +410,15 @@ def ctc_greedy_decode(logp, lens, blank):
     return tokens, out_len, score
 
 
+def specaug_rects(u_tw, u_ts, u_fw, u_fs, length, rects, B, nt, nf, F, T, time_width, freq_width):
+    """mask rectangles of SpecAugment's vectorised path from its four uniform draws (one launch instead of ~40 tensor ops)"""
+    frac = isinstance(time_width, float)
+    check(lib.mi355x_specaug_rects(_ptr(u_tw) if nt else 0, _ptr(u_ts) if nt else 0, _ptr(u_fw) if nf else 0, _ptr(u_fs) if nf else 0,
+                                   _ptr(length), _ptr(rects), B, nt, nf, F, T, float(time_width), int(frac), int(freq_width),
+                                   _stream()), "specaug_rects")
+    return rects
+
+
 def fill_rects(x, rects, value=0.0):
     """x[b, f0:f1, t0:t1] = value for rects [n,5] int32 = (b, f0, f1, t0, t1); x f32 [B,F,T], in place"""
     B, F, T = x.shape

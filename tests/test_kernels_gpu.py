@@ -457,6 +457,30 @@ def test_specaug_fill_rects_and_module(golden_dir):
     assert 0.05 < masked_frac < 0.9
 
 
+@pytest.mark.parametrize("tw", [0.05, 1.0, 25])
+def test_specaug_mask_parameters_in_one_launch_equal_the_tensor_ops(tw):
+    """mi355x_specaug_rects (the reference's four uniform draws -> rectangle table in one launch) against the module's tensor-op
+    path, which restates spectr_augment.py:155-195 op by op and is pinned to the reference fixture on CPU: same device seed, same
+    integers -- fraction-of-utterance and frame-count time widths, utterances shorter than a mask"""
+    from nemo_amd.modules import SpectrogramAugmentation
+    B, F, T = 9, 80, 1201
+    length = torch.tensor([1201, 1200, 777, 640, 333, 100, 17, 3, 1], dtype=torch.int64, device=dev)
+    m = SpectrogramAugmentation(freq_masks=2, time_masks=10, freq_width=27, time_width=tw)
+    got, want = [], []
+    for seed in (1, 2, 3):
+        m.fused_rects = True
+        torch.manual_seed(seed)
+        got.append(m.mask_rects(B, F, T, length, torch.device(dev))[0][0])
+        m.fused_rects = False
+        torch.manual_seed(seed)
+        want.append(m.mask_rects(B, F, T, length, torch.device(dev))[0][0])
+    torch.cuda.synchronize()
+    for g_, w_ in zip(got, want):
+        assert g_.dtype == torch.int32 and g_.shape == w_.shape == (B * 12, 5)
+        assert torch.equal(g_.long().cpu(), w_.long().cpu())
+    assert not torch.equal(got[0], got[1])   # (the seeds draw different masks)
+
+
 @pytest.mark.parametrize("M,d", [(700, 64), (1003, 512), (130, 176)])
 def test_add2_colsum(M, d):
     """dq = dqu + dqv fused with the pos_bias_u / pos_bias_v gradients (multi_head_attention.py:288-291)"""
