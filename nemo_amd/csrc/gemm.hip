@@ -1243,22 +1243,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_grouped_tn_kernel(GroupP g) {
 #define BN4 256
 #define NT4_STAGE ((BM2 + BN4) * BK)  // 64 KiB
 
-// one epilogue round of the 256x256 tile: window row rl (0..63) is tile row (rl >> 5) * 128 + i * 32 + (rl & 31)
-__device__ __forceinline__ void v4_round_out(const GemmP& p, const float* sC, int z, long long coff, int m0, int n0, int i,
-                                          bool fast) {
+// one epilogue round of a 256x256 tile: window row rl (0..63) is tile row rbase + (rl >> 5) * hstride + (rl & 31)
+// (third / sixth structure: rbase = i * 32, hstride = 128; eighth: rbase = h * 128 + pr * 32, hstride = 64)
+__device__ __forceinline__ void v4_round_out(const GemmP& p, const float* sC, int z, long long coff, int m0, int n0, int rbase,
+                                          bool fast, const int hstride = 128) {
   constexpr int LDS_C = BN4 + 4;
   if (fast) {
     // 512 threads = 16 rows x 32 column chunks per pass
     const int rl0 = threadIdx.x >> 5;
-    fast_epilogue_any<2, 16, BN4>(p, sC, z, coff, m0 + i * 32 + rl0, n0, rl0);
-    fast_epilogue_any<2, 16, BN4>(p, sC + 32 * LDS_C, z, coff, m0 + 128 + i * 32 + rl0, n0, rl0);
+    fast_epilogue_any<2, 16, BN4>(p, sC, z, coff, m0 + rbase + rl0, n0, rl0);
+    fast_epilogue_any<2, 16, BN4>(p, sC + 32 * LDS_C, z, coff, m0 + hstride + rbase + rl0, n0, rl0);
   } else if (p.atomic) {
     const bool plain = p.epi == EPI_STORE && !p.bias && p.alpha == 1.f && p.drop.threshold == 0u && !p.r_on;
     float* Cb = (float*)p.C + coff;
 #pragma unroll 4
     for (int e = threadIdx.x; e < 64 * BN4; e += 512) {
       const int rl = e >> 8, col = e & (BN4 - 1);
-      const int m = m0 + (rl >> 5) * 128 + i * 32 + (rl & 31), n = n0 + col;
+      const int m = m0 + (rl >> 5) * hstride + rbase + (rl & 31), n = n0 + col;
       if (m < p.M && n < p.N) {
         if (plain) atomicAdd(Cb + (long long)m * p.ldc + (long long)n * p.csc, sC[rl * LDS_C + col]);
         else epilogue(p, z, coff, m, n, sC[rl * LDS_C + col]);
@@ -1268,7 +1269,7 @@ __device__ __forceinline__ void v4_round_out(const GemmP& p, const float* sC, in
     for (int it = 0; it < 4; ++it) {
       const int rl = (threadIdx.x >> 5) + 16 * it;
       const int c8 = (threadIdx.x & 31) * 8;
-      const int m = m0 + (rl >> 5) * 128 + i * 32 + (rl & 31), n = n0 + c8;
+      const int m = m0 + (rl >> 5) * hstride + rbase + (rl & 31), n = n0 + c8;
       if (m < p.M && n < p.N) {
         float v[8];
         const float4 a = *reinterpret_cast<const float4*>(sC + rl * LDS_C + c8);
@@ -1309,7 +1310,7 @@ __device__ __forceinline__ void v4_tile_epilogue(const GemmP& p, f32x16 (&acc)[4
       sC[row_l * LDS_C + wn * 64 + 32 + lr] = t1[r];
     }
     __syncthreads();
-    v4_round_out(p, sC, z, coff, m0, n0, i, fast);
+    v4_round_out(p, sC, z, coff, m0, n0, i * 32, fast);
   }
 }
 
@@ -1726,6 +1727,291 @@ __global__ __launch_bounds__(512) void gemm_bf16_v6_kernel(GemmP p) {
     }
   }
   v4_tile_epilogue(p, acc, reinterpret_cast<float*>(smem6), z, coff, m0, n0, wm, wn, lr, lh);
+}
+
+// =================================================================================================
+// Eighth structure: the 256x256x64 tile on v_mfma_f32_16x16x32_bf16 with a PHASE-STAGGERED K loop (round 6).
+// The 256x256 structures above run all eight waves in lock step: every wave reads its fragments, then every wave multiplies --
+// the two waves of a SIMD take turns at ONE matrix pipe and meet at the same barrier with nothing to overlap (PMC, round 5: 2-2.5x
+// the wave cycles of a 4-wave kernel for the same MFMA cycles, LDS issue stalls 2-3x).  Here the two wave rows (waves 0-3 / 4-7 =
+// one wave of each SIMD) run ONE BARRIER APART: while one wave of a SIMD multiplies (16 MFMAs under s_setprio 1), its partner
+// issues the LDS reads and LDS-DMA of its next phase.  A K-tile is four phases; per phase and wave:
+//     ds_read_b128 of the quadrant's new operand half (12 / 4 / 8 / 0)  |  2 x global_load_lds (one 16-KiB half-tile, 7 half-tiles
+//     ahead)  |  barrier  |  lgkmcnt(0)  |  16 MFMAs = one 64x32 quadrant of the wave's 128x64 block x K = 64  |  barrier
+// LDS: two K-tile buffers of four half-tile images (A rows 0-127 | 128-255 | B rows 0-127 | 128-255; 16 KiB each, the same [rows][64]
+// image and chunk swizzle as the structures above -- conflict-free for the 16x16x32 fragment reads too: lane l reads row l & 15,
+// chunk 4 ks + (l >> 4)) = 128 KiB.  Wave (wm, wn) owns rows wm*64..+63 of EACH A half and columns wn*32..+31 of EACH B half,
+// so phase p needs exactly one new half-tile:  p0 (A0,B0)  p1 (A0,B1)  p2 (A1,B1)  p3 (A1,B0).
+// Pipeline bookkeeping (vmcnt counts this wave's LDS-DMA instructions, 2 per half-tile; half-tiles are staged in the order
+// B0, A0, B1, A1 of tile t, t+1, ...; phase p of tile t stages half-tile index 4t + p + 7):
+//   * ONE counted wait per K-tile, in phase 3 before its first barrier: vmcnt(6) leaves the three half-tiles staged in phases
+//     1-3 (tile t+2) in flight and retires everything of tile t+1, which is first read one phase -- and, for the other wave row,
+//     at least one barrier -- later.  Never vmcnt(0) inside the loop (only for the last-but-one tile, when nothing follows).
+//   * a half-tile buffer is re-staged two phases after its last read, except B0 (read in phase 0, re-staged in phase 1): its four
+//     reads are issued FIRST in phase 0 and retired by lgkmcnt(8) before that phase's first barrier.
+// Operands K-contiguous (NT), whole K-tiles, at least two per workgroup; everything else stays on the structures above.
+// Epilogue: four rounds through the same [64][260] f32 window and round-out as the third structure.
+// =================================================================================================
+#define V8_HALF_B 16384
+#define V8_BUF_B 65536
+#define V8_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory")
+
+template <int G>
+__global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
+  drop_resolve(p.drop);
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];  // 2 K-tiles x 4 half-tile images x 16 KiB
+  const int tn = (p.N + BN4 - 1) / BN4, tm = (p.M + BM2 - 1) / BM2;
+  const int ntiles = tm * tn;
+  const int bid = blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int z = blockIdx.z, kslice = blockIdx.y;
+  const int tile_m = logical / tn, tile_n = logical - tile_m * tn;
+  const int m0 = tile_m * BM2, n0 = tile_n * BN4;
+  const int z0 = z % p.nb0, z1 = z / p.nb0;
+  const bf16_t* A = (const bf16_t*)p.A + z0 * p.sA0 + z1 * p.sA1;
+  const bf16_t* B = (const bf16_t*)p.B + z0 * p.sB0 + z1 * p.sB1;
+  const long long coff = z0 * p.sC0 + z1 * p.sC1;
+  {
+    // row tiles that lie wholly beyond their utterance (ReLU + time mask forward, gated input gradient): zero-filled without a
+    // K loop -- same rule as the third structure
+    const bool mask_tile = p.epi == EPI_RELU_MASK && !p.r_on;
+    const bool gate_tile = p.epi == EPI_MUL_POS && p.row_len != nullptr;
+    if ((mask_tile || gate_tile) && p.splitk <= 1 && !p.aux_out && p.c_dt == MI_DT_BF16 && p.csc == 1 && p.vec_ok && !(p.N & 7)) {
+      const int mlast = min(m0 + BM2, p.M) - 1;
+      const int b0 = m0 / p.rows_per_b, b1 = mlast / p.rows_per_b;
+      const int t0 = (m0 - b0 * p.rows_per_b) / p.rows_inner;
+      if (b0 == b1 && (long long)t0 >= p.row_len[b0]) {
+        bf16_t* Cz = (bf16_t*)p.C + coff;
+        const int ncol = min(BN4, p.N - n0), nrow = mlast - m0 + 1, cpr = ncol >> 3;
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        for (int e = threadIdx.x; e < nrow * cpr; e += 512) {
+          const int r = e / cpr, c = e - r * cpr;
+          *reinterpret_cast<u32x4*>(Cz + crow(p, m0 + r) * p.ldc + n0 + c * 8) = zero;
+        }
+        return;
+      }
+    }
+  }
+  const int nk_total = p.K / BK;
+  int kt0 = 0, kt1 = nk_total;
+  if (p.splitk > 1) {
+    kt0 = kslice * p.ktiles_per_split;
+    kt1 = min(nk_total, kt0 + p.ktiles_per_split);
+    if (kt0 >= kt1) return;
+  }
+  const int nk = kt1 - kt0;  // >= 2 by contract
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  f32x4 acc[2][4][2][2];  // [A half][m fragment][B half][n fragment]: rows h*128 + wm*64 + mi*16, columns hb*128 + wn*32 + ni*16
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[h][mi][hb][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- LDS-DMA sources: this thread's two 16-byte chunks of each half-tile, as 32-bit byte offsets at K-tile kt0 (rows past the
+  // matrix are clamped: their products are never stored); a K-tile advances all of them by the uniform 128 bytes
+  // G == 1 (implicit-GEMM convolution): an A row is an output position; its chunk's offset is that of the channel vector at the
+  // position's origin src[b][i*si][j*sj][gck*8], and bit t of gin[][] says whether tap t of that position lies inside the grid
+  // (outside: the chunk reads the zero page).  The K-tile's tap and channel offset are uniform and tracked incrementally.
+  uint32_t oA[2][2], oB[2][2], gin[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = threadIdx.x + i * 512;
+      const int r = q >> 3, gck = (q & 7) ^ ((r >> 1) & 7);
+      int ga = m0 + h * 128 + r; ga = ga < p.M ? ga : p.M - 1;
+      int gb = n0 + h * 128 + r; gb = gb < p.N ? gb : p.N - 1;
+      oB[h][i] = (uint32_t)((long long)gb * p.ldb + gck * 8) * 2u;
+      if constexpr (G == 1) {
+        const int per_b = p.g_nI * p.g_nJ;
+        const int b = ga / per_b, rr = ga - b * per_b;
+        const int oi = rr / p.g_nJ, oj = rr - oi * p.g_nJ;
+        const int gi = oi * p.g_si, gj = oj * p.g_sj;
+        oA[h][i] = (uint32_t)((((long long)b * p.g_SI + gi) * p.g_SJ + gj) * p.g_C + gck * 8) * 2u;
+        uint32_t in = 0u;
+        for (int t = 0; t < p.g_ntaps; ++t) {
+          const int di = tap_delta(p.g_dip, t), dj = tap_delta(p.g_djp, t);
+          if ((unsigned)(gi + di) < (unsigned)p.g_SI && (unsigned)(gj + dj) < (unsigned)p.g_SJ) in |= 1u << t;
+        }
+        gin[h][i] = in;
+      } else {
+        oA[h][i] = (uint32_t)((long long)ga * p.lda + gck * 8) * 2u;
+        gin[h][i] = 0u;
+      }
+    }
+  const char* Ab = (const char*)A + (G == 1 ? 0ll : (long long)kt0 * (BK * 2));
+  const char* Bb = (const char*)B + (long long)kt0 * (BK * 2);
+  char* const lds8 = (char*)smem8;
+  // gather cursor: tap / channel offset of the K-tile whose A halves are being staged (A0 of a tile is staged one phase-group
+  // before its A1: the cursor advances in front of every A0)
+  int g_tap = 0, g_c0 = 0;
+  long long g_toff = 0;
+  auto gather_seek = [&](const int kt) {  // (prologue only: one division)
+    g_tap = (kt * BK) / p.g_C;
+    g_c0 = kt * BK - g_tap * p.g_C;
+  };
+  auto gather_offs = [&]() {
+    const int di = tap_delta(p.g_dip, g_tap), dj = tap_delta(p.g_djp, g_tap);
+    g_toff = (((long long)di * p.g_SJ + dj) * p.g_C + g_c0) * 2;
+  };
+  auto gather_next = [&]() {
+    g_c0 += BK;
+    if (g_c0 >= p.g_C) { g_c0 = 0; ++g_tap; }
+    gather_offs();
+  };
+  if constexpr (G == 1) { gather_seek(kt0); gather_offs(); }
+  // half-tile j of K-tile ts (staging order j: 0 = B0, 1 = A0, 2 = B1, 3 = A1; j is a literal at every call site)
+  auto stage = [&](const int j, const int ts) __attribute__((always_inline)) {
+    const int h = j >> 1;
+    const bool isA = (j & 1) != 0;
+    char* dst = lds8 + (ts & 1) * V8_BUF_B + ((isA ? 0 : 2) + h) * V8_HALF_B + wave * 1024;
+    if (G == 1 && isA) {
+      const char* src = Ab + g_toff;
+      const uint32_t bit = 1u << g_tap;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const char* sp = (gin[h][i] & bit) ? src + oA[h][i] : reinterpret_cast<const char*>(g_zero16);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)sp, (lds_void_t*)(dst + i * 8192), 16, 0, 0);
+      }
+    } else {
+      const char* src = (isA ? Ab : Bb) + (long long)ts * (BK * 2);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (isA ? oA[h][i] : oB[h][i])), (lds_void_t*)(dst + i * 8192), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read addresses in K-tile buffer 0 (per k-step: the chunk swizzle is an XOR); A halves / m fragments and B halves /
+  // n fragments are compile-time offsets
+  const int l15 = lane & 15, l4 = lane >> 4, sw = (lane >> 1) & 7;
+  const uint32_t sb8 = lds_addr(smem8);
+  const uint32_t fra0 = sb8 + (uint32_t)((wm * 64 + l15) * 128 + ((l4 ^ sw) << 4));
+  const uint32_t fra1 = sb8 + (uint32_t)((wm * 64 + l15) * 128 + (((4 + l4) ^ sw) << 4));
+  const uint32_t frb0 = sb8 + (uint32_t)(2 * V8_HALF_B + (wn * 32 + l15) * 128 + ((l4 ^ sw) << 4));
+  const uint32_t frb1 = sb8 + (uint32_t)(2 * V8_HALF_B + (wn * 32 + l15) * 128 + (((4 + l4) ^ sw) << 4));
+  bf16x8 fa[4][2], fb[2][2][2];  // [m fragment][k-step], [B half][n fragment][k-step]
+
+#define V8_RD_A(H)                                                                                          \
+  V8_RD(fa[0][0], ra0, (H) * V8_HALF_B);        V8_RD(fa[0][1], ra1, (H) * V8_HALF_B);                      \
+  V8_RD(fa[1][0], ra0, (H) * V8_HALF_B + 2048); V8_RD(fa[1][1], ra1, (H) * V8_HALF_B + 2048);               \
+  V8_RD(fa[2][0], ra0, (H) * V8_HALF_B + 4096); V8_RD(fa[2][1], ra1, (H) * V8_HALF_B + 4096);               \
+  V8_RD(fa[3][0], ra0, (H) * V8_HALF_B + 6144); V8_RD(fa[3][1], ra1, (H) * V8_HALF_B + 6144)
+#define V8_RD_B(HB)                                                                                         \
+  V8_RD(fb[HB][0][0], rb0, (HB) * V8_HALF_B);        V8_RD(fb[HB][0][1], rb1, (HB) * V8_HALF_B);            \
+  V8_RD(fb[HB][1][0], rb0, (HB) * V8_HALF_B + 2048); V8_RD(fb[HB][1][1], rb1, (HB) * V8_HALF_B + 2048)
+#define V8_PIN_A "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1])
+#define V8_PIN_B(HB) "+v"(fb[HB][0][0]), "+v"(fb[HB][0][1]), "+v"(fb[HB][1][0]), "+v"(fb[HB][1][1])
+  // 16 MFMAs: quadrant (A half H, B half HB) x K = 64; the eight accumulators of a k-step are independent
+#define V8_MM(H, HB)                                                                                        \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_setprio(1);                                                                            \
+  _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                       \
+  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                          \
+  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                          \
+      acc[H][mi][HB][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi][ks_], fb[HB][ni][ks_], acc[H][mi][HB][ni], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_barrier();                                                                             \
+  __builtin_amdgcn_sched_barrier(0)
+
+  // ---- prologue: all of K-tile 0 and three half-tiles of K-tile 1 (7 half-tiles = 14 DMA instructions per wave)
+  stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+  if constexpr (G == 1) gather_next();
+  stage(0, 1); stage(1, 1); stage(2, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first from here on
+  __builtin_amdgcn_sched_barrier(0);
+
+#pragma nounroll
+  for (int t = 0; t < nk; ++t) {
+    const uint32_t bo = (uint32_t)(t & 1) * V8_BUF_B;
+    const uint32_t ra0 = fra0 + bo, ra1 = fra1 + bo, rb0 = frb0 + bo, rb1 = frb1 + bo;
+    // -- phase 0: B0 (first: retired by lgkmcnt(8), its buffer is re-staged in phase 1) + A0 -> quadrant (0, 0)
+    V8_RD_B(0);
+    V8_RD_A(0);
+    if (t + 1 < nk) stage(3, t + 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" : V8_PIN_A, V8_PIN_B(0) : : "memory");
+    V8_MM(0, 0);
+    // -- phase 1: B1 -> quadrant (0, 1)
+    V8_RD_B(1);
+    if (t + 2 < nk) stage(0, t + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" : V8_PIN_B(1) : : "memory");
+    V8_MM(0, 1);
+    // -- phase 2: A1 -> quadrant (1, 1)
+    V8_RD_A(1);
+    if (t + 2 < nk) {
+      if constexpr (G == 1) gather_next();
+      stage(1, t + 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" : V8_PIN_A : : "memory");
+    V8_MM(1, 1);
+    // -- phase 3: quadrant (1, 0) from registers; the K-tile's one DMA wait: tile t+1 complete, tile t+2's three half-tiles in flight
+    if (t + 2 < nk) {
+      stage(2, t + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    V8_MM(1, 0);
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // re-join the wave rows
+#undef V8_RD_A
+#undef V8_RD_B
+#undef V8_PIN_A
+#undef V8_PIN_B
+#undef V8_MM
+  __syncthreads();
+
+  // ---- epilogue: four rounds (A half h, m-fragment pair pr) through a [64][BN4+4] f32 window: window row wm*32 + mi2*16 + C/D row,
+  // i.e. tile row h*128 + (rl >> 5)*64 + pr*32 + (rl & 31); C/D layout of the 16x16 MFMA: column = lane & 15, row = 4*(lane >> 4) + reg
+  float* sC = reinterpret_cast<float*>(smem8);
+  constexpr int LDS_C = BN4 + 4;
+  const bool fast = (p.vec_ok & 1) && !(p.N & 7) && n0 + BN4 <= p.N && !p.atomic;
+#pragma nounroll
+  for (int r = 0; r < 4; ++r) {
+    f32x4 tq[2][2][2];  // [mi2][hb][ni]; selected by a uniform switch: the accumulators are never indexed dynamically
+#define V8_PICK(H, M0)                                                                          \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)   \
+  _Pragma("unroll") for (int c = 0; c < 2; ++c) tq[a][b][c] = acc[H][M0 + a][b][c];
+    switch (r) {
+      case 0: V8_PICK(0, 0) break;
+      case 1: V8_PICK(0, 2) break;
+      case 2: V8_PICK(1, 0) break;
+      default: V8_PICK(1, 2) break;
+    }
+#undef V8_PICK
+    if (r) __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            sC[(wm * 32 + a * 16 + l4 * 4 + e) * LDS_C + b * 128 + wn * 32 + c * 16 + l15] = tq[a][b][c][e];
+    __syncthreads();
+    v4_round_out(p, sC, z, coff, m0, n0, (r >> 1) * 128 + (r & 1) * 32, fast, 64);
+  }
 }
 
 // =================================================================================================
@@ -2227,13 +2513,13 @@ static int env_int(const char* name, int dflt) {
 // prefetch instead of LDS-DMA inside the 256x256 structure (MI355X_GEMM_V6: 0 = default / 1), key 7 = the same inside the 256x128
 // structure (MI355X_GEMM_V7, default 1), key 3 = fp32 problems on the matrix cores (MI355X_F32_MFMA, default 1; 0 = vector unit).  Defaults follow the in-step A/B (tools/step_ab.py, recorded graphs, same box): the
 // 256x128 variant -0.2 ms per step, the 256x256 variant +0.3 ms although it wins every isolated launch (profiles/r3_gemm_structures.md)
-static std::atomic<int> g_mode[8] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static std::atomic<int> g_mode[9] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 static int mode_now(int key) {
   int v = g_mode[key].load(std::memory_order_relaxed);
   if (v < 0) {
     static const int env4 = env_int("MI355X_GEMM_V4", 1), env5 = env_int("MI355X_GEMM_V5", 1), env6 = env_int("MI355X_GEMM_V6", 0),
-                     env7 = env_int("MI355X_GEMM_V7", 1), env3 = env_int("MI355X_F32_MFMA", 1);
-    const int from_env = key == 4 ? env4 : key == 5 ? env5 : key == 6 ? env6 : key == 7 ? env7 : key == 3 ? env3 : 0;
+                     env7 = env_int("MI355X_GEMM_V7", 1), env3 = env_int("MI355X_F32_MFMA", 1), env8 = env_int("MI355X_GEMM_V8", 1);
+    const int from_env = key == 4 ? env4 : key == 5 ? env5 : key == 6 ? env6 : key == 7 ? env7 : key == 3 ? env3 : key == 8 ? env8 : 0;
     int expected = -1;
     g_mode[key].compare_exchange_strong(expected, from_env, std::memory_order_relaxed);
     v = g_mode[key].load(std::memory_order_relaxed);
@@ -2242,7 +2528,7 @@ static int mode_now(int key) {
 }
 static int v5_mode_now() { return mode_now(5); }
 extern "C" int mi355x_gemm_config(int key, int value) {
-  if (key < 3 || key > 7) return -1;
+  if (key < 3 || key > 8) return -1;
   return g_mode[key].exchange(value, std::memory_order_relaxed);
 }
 
@@ -2364,6 +2650,30 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
       }();
       if (!attr_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
       dim3 grid2(tm2 * tn, sk, p.batch);
+      // phase-staggered 256x256 structure on 16x16x32 MFMAs (key 8 / MI355X_GEMM_V8: 0 = never, 1 = where it measured faster, 2 = every
+      // shape it can run): dense K-contiguous operands, whole K-tiles, at least two per workgroup, 32-bit operand offsets
+      {
+        const int v8_mode = mode_now(8);
+        const int nk_wg8 = sk > 1 ? p.ktiles_per_split : nk;
+        bool v8_can = !p.transA && !p.transB && p.g_on != 2 && !(p.K % BK) && nk_wg8 >= 2 && (sk == 1 || !(nk % nk_wg8)) && p.N > 128 &&
+                      (long long)p.N * p.ldb < (1LL << 31);
+        if (p.g_on == 1)  // gathered A: 32-bit byte offsets into the source grid, a K-tile inside one tap
+          v8_can = v8_can && !(p.g_C % BK) && (long long)(p.M / (p.g_nI * p.g_nJ)) * p.g_SI * p.g_SJ * p.g_C < (1LL << 31);
+        else v8_can = v8_can && (long long)p.M * p.lda < (1LL << 31);
+        const int tn8 = (p.N + BN4 - 1) / BN4;
+        const long long blocks8 = (long long)tm2 * tn8 * sk * p.batch;
+        const bool v8_pick = v8_mode == 2 || (v8_mode == 1 && blocks8 >= 224 && (long long)tn8 * BN4 * 8 <= (long long)p.N * 9);
+        if (v8_can && v8_pick) {
+          static const bool attr8_ok = hipFuncSetAttribute((const void*)gemm_bf16_v8_kernel<0>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V8_BUF_B) == hipSuccess &&
+                                       hipFuncSetAttribute((const void*)gemm_bf16_v8_kernel<1>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V8_BUF_B) == hipSuccess;
+          if (!attr8_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
+          if (p.g_on == 1) MI_LAUNCH((gemm_bf16_v8_kernel<1>), dim3(tm2 * tn8, sk, p.batch), dim3(512), 2 * V8_BUF_B, s, p);
+          else MI_LAUNCH((gemm_bf16_v8_kernel<0>), dim3(tm2 * tn8, sk, p.batch), dim3(512), 2 * V8_BUF_B, s, p);
+          return mi_check_launch();
+        }
+      }
       // persistent 256x128 structure with the epilogue overlapped into the next tile's K loop: the Conformer block's
       // forward / dgrad GEMMs (dense NT, full-width vector epilogue, K >= 8 K-tiles, at least one tile per CU)
       const int v5_mode = v5_mode_now();

@@ -44,10 +44,14 @@ def main(path):
             continue
         op = t.split()[0]
         if in_asm and op.startswith("s_waitcnt"):
-            if "lgkmcnt" in t:
-                pending = [p for p in pending if p[0] != "lgkm"]
-            if "vmcnt" in t:
-                pending = [p for p in pending if p[0] != "vm"]
+            # a counted wait retires the OLDEST loads of its counter and leaves the newest N pending (in-order return)
+            for cname, key in (("lgkmcnt", "lgkm"), ("vmcnt", "vm")):
+                m = re.search(cname + r"\((\d+)\)", t)
+                if m:
+                    n = int(m.group(1))
+                    mine = [p for p in pending if p[0] == key]
+                    keep = mine[len(mine) - n:] if n < len(mine) else mine
+                    pending = [p for p in pending if p[0] != key] + keep
             continue
         if in_asm and op in ("ds_read_b128", "ds_read_b64", "ds_read_b32", "ds_read_b64_tr_b16", "global_load_dwordx4"):
             if op == "global_load_dwordx4" and "lds" in t:
