@@ -1734,46 +1734,52 @@ __global__ __launch_bounds__(512) void gemm_bf16_v6_kernel(GemmP p) {
 // The 256x256 structures above run all eight waves in lock step: every wave reads its fragments, then every wave multiplies --
 // the two waves of a SIMD take turns at ONE matrix pipe and meet at the same barrier with nothing to overlap (PMC, round 5: 2-2.5x
 // the wave cycles of a 4-wave kernel for the same MFMA cycles, LDS issue stalls 2-3x).  Here the two wave rows (waves 0-3 / 4-7 =
-// one wave of each SIMD) run ONE BARRIER APART: while one wave of a SIMD multiplies (16 MFMAs under s_setprio 1), its partner
-// issues the LDS reads and LDS-DMA of its next phase.  A K-tile is four phases; per phase and wave:
-//     ds_read_b128 of the quadrant's new operand half (12 / 4 / 8 / 0)  |  2 x global_load_lds (one 16-KiB half-tile, 7 half-tiles
-//     ahead)  |  barrier  |  lgkmcnt(0)  |  16 MFMAs = one 64x32 quadrant of the wave's 128x64 block x K = 64  |  barrier
-// LDS: two K-tile buffers of four half-tile images (A rows 0-127 | 128-255 | B rows 0-127 | 128-255; 16 KiB each, the same [rows][64]
-// image and chunk swizzle as the structures above -- conflict-free for the 16x16x32 fragment reads too: lane l reads row l & 15,
-// chunk 4 ks + (l >> 4)) = 128 KiB.  Wave (wm, wn) owns rows wm*64..+63 of EACH A half and columns wn*32..+31 of EACH B half,
-// so phase p needs exactly one new half-tile:  p0 (A0,B0)  p1 (A0,B1)  p2 (A1,B1)  p3 (A1,B0).
+// one wave of each SIMD) run ONE BARRIER APART: while one wave of a SIMD multiplies (16 MFMAs), its partner issues the LDS reads
+// and LDS-DMA of its next phase.  A K-tile is four phases; per phase and wave:
+//     fragment reads of the quadrant's new operand half (12 / 4 / 8 / 0 x 16 B)  |  2 x global_load_lds (one 16-KiB half-tile, 7
+//     half-tiles ahead)  |  barrier  |  lgkmcnt(0)  |  16 MFMAs = one 64x32 quadrant of the wave's 128x64 block x K = 64  |  barrier
+// LDS: two K-tile buffers of four half-tile images (A rows 0-127 | 128-255 | B rows 0-127 | 128-255; 16 KiB each) = 128 KiB.
+// Wave (wm, wn) owns rows wm*64..+63 of EACH A half and columns wn*32..+31 of EACH B half, so a phase needs exactly one new
+// half-tile:  p0 (A0,B0)  p1 (A0,B1)  p2 (A1,B1)  p3 (A1,B0).
+// Half-tile images, one per operand layout (TN = both operands reduction-major, the weight gradients):
+//   * K-contiguous ([rows][K]): image [128 rows][64 k], chunk swizzle c ^= (row >> 1) & 7 on the DMA SOURCE, ds_read_b128: lane l
+//     reads row l & 15, chunk 4 ks + (l >> 4) -- conflict-free in the instruction's four 16-lane groups;
+//   * reduction-major ([K][rows]): image [64 k][128 rows] as in memory, chunk swizzle c ^= ((k & 3) << 2) ^ (((k >> 3) & 1) << 1),
+//     two ds_read_b64_tr_b16 per fragment (lane t of a 16-lane group supplies &img[k0 + t/4][row0 + (t%4)*4] and receives
+//     img[k0..k0+3][row0 + t]); the second swizzle term keeps the two 16-lane groups of a 32-lane half (k0 and k0 + 8) off each
+//     other's banks.
 // Pipeline bookkeeping (vmcnt counts this wave's LDS-DMA instructions, 2 per half-tile; half-tiles are staged in the order
 // B0, A0, B1, A1 of tile t, t+1, ...; phase p of tile t stages half-tile index 4t + p + 7):
 //   * ONE counted wait per K-tile, in phase 3 before its first barrier: vmcnt(6) leaves the three half-tiles staged in phases
 //     1-3 (tile t+2) in flight and retires everything of tile t+1, which is first read one phase -- and, for the other wave row,
 //     at least one barrier -- later.  Never vmcnt(0) inside the loop (only for the last-but-one tile, when nothing follows).
-//   * a half-tile buffer is re-staged two phases after its last read, except B0 (read in phase 0, re-staged in phase 1): its four
-//     reads are issued FIRST in phase 0 and retired by lgkmcnt(8) before that phase's first barrier.
-// Operands K-contiguous (NT), whole K-tiles, at least two per workgroup; everything else stays on the structures above.
+//     Every half-tile is staged whatever happens (a chunk outside the matrix, past K, or of a K-tile that is skipped reads the
+//     zero page): the count must not depend on the data.
+//   * a half-tile buffer is re-staged two phases after its last read, except B0 (read in phase 0, re-staged in phase 1): its
+//     reads are issued FIRST in phase 0 and retired by a counted lgkmcnt before that phase's first barrier.
+// G: 0 dense, 1 = gathered A rows (conv forward / input gradient, NT), 2 = gathered reduction-major B (conv weight gradient, TN).
+// NT needs whole K-tiles; at least two K-tiles per workgroup.  Measured (one box, uniform random operands, profiles/r6_gemm_8phase.md):
+// 4096^3 1.34-1.37 PFLOP/s (third structure 1.09-1.10), conv2 forward 997 -> 1220 TFLOP/s; without the stagger 1.16 / 1.10;
+// s_setprio around the MFMA block: no effect here (kept off).
 // Epilogue: four rounds through the same [64][260] f32 window and round-out as the third structure.
 // =================================================================================================
 #define V8_HALF_B 16384
 #define V8_BUF_B 65536
-#define V8_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory")
+template <int OFF>
+__device__ __forceinline__ void v8_rd128(bf16x8& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
 
-template <int G>
-__global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
-  drop_resolve(p.drop);
-  extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];  // 2 K-tiles x 4 half-tile images x 16 KiB
-  const int tn = (p.N + BN4 - 1) / BN4, tm = (p.M + BM2 - 1) / BM2;
-  const int ntiles = tm * tn;
-  const int bid = blockIdx.x;
-  const int q8 = ntiles >> 3, r8 = ntiles & 7;
-  const int xcd = bid & 7, idx = bid >> 3;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const int z = blockIdx.z, kslice = blockIdx.y;
-  const int tile_m = logical / tn, tile_n = logical - tile_m * tn;
+template <int G, bool TN>
+__device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, const int tile_m, const int tile_n, const int kslice,
+                                             const int z) {
+  const int tn = (p.N + BN4 - 1) / BN4;
   const int m0 = tile_m * BM2, n0 = tile_n * BN4;
   const int z0 = z % p.nb0, z1 = z / p.nb0;
   const bf16_t* A = (const bf16_t*)p.A + z0 * p.sA0 + z1 * p.sA1;
   const bf16_t* B = (const bf16_t*)p.B + z0 * p.sB0 + z1 * p.sB1;
   const long long coff = z0 * p.sC0 + z1 * p.sC1;
-  {
+  if constexpr (!TN) {
     // row tiles that lie wholly beyond their utterance (ReLU + time mask forward, gated input gradient): zero-filled without a
     // K loop -- same rule as the third structure
     const bool mask_tile = p.epi == EPI_RELU_MASK && !p.r_on;
@@ -1794,7 +1800,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
       }
     }
   }
-  const int nk_total = p.K / BK;
+  const int nk_total = (p.K + BK - 1) / BK;
   int kt0 = 0, kt1 = nk_total;
   if (p.splitk > 1) {
     kt0 = kslice * p.ktiles_per_split;
@@ -1816,49 +1822,78 @@ __global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[h][mi][hb][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- LDS-DMA sources: this thread's two 16-byte chunks of each half-tile, as 32-bit byte offsets at K-tile kt0 (rows past the
-  // matrix are clamped: their products are never stored); a K-tile advances all of them by the uniform 128 bytes
-  // G == 1 (implicit-GEMM convolution): an A row is an output position; its chunk's offset is that of the channel vector at the
-  // position's origin src[b][i*si][j*sj][gck*8], and bit t of gin[][] says whether tap t of that position lies inside the grid
-  // (outside: the chunk reads the zero page).  The K-tile's tap and channel offset are uniform and tracked incrementally.
+  // ---- LDS-DMA sources: this thread's two 16-byte chunks (i = 0, 1) of each half-tile (h), as 32-bit byte offsets at K-tile kt0;
+  // a K-tile advances all of an operand's offsets by one uniform step.  A chunk that must not be read (column outside the matrix,
+  // row past K, tap outside the grid, skipped K-tile) takes the zero page instead.
+  //   NT: chunk q = tid + 512 i -> row q >> 3, LDS chunk position q & 7 <- source chunk (q & 7) ^ ((row >> 1) & 7); rows past the
+  //       matrix are clamped (their products are never stored)
+  //   TN: chunk q -> k-row q >> 4, position q & 15 <- source chunk (q & 15) ^ f(k); columns past the matrix read zeros
+  //   G == 1: an A row is an output position; offset of the channel vector at its origin src[b][i*si][j*sj][.], bit t of gin = tap t
+  //       of that position lies inside the grid; the K-tile's tap / channel offset are uniform and tracked incrementally
+  //   G == 2: a B k-row is an output position (shared by both halves); its (i, j) and origin offset advance by 64 positions per tile
   uint32_t oA[2][2], oB[2][2], gin[2][2];
+  uint32_t okbits = 0u;  // TN: bit h*2+i = A chunk inside the matrix, bit 4+h*2+i = B chunk
+  int g2i[2], g2j[2], g2off[2], g2row[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int q = threadIdx.x + i * 512;
-      const int r = q >> 3, gck = (q & 7) ^ ((r >> 1) & 7);
-      int ga = m0 + h * 128 + r; ga = ga < p.M ? ga : p.M - 1;
-      int gb = n0 + h * 128 + r; gb = gb < p.N ? gb : p.N - 1;
-      oB[h][i] = (uint32_t)((long long)gb * p.ldb + gck * 8) * 2u;
-      if constexpr (G == 1) {
-        const int per_b = p.g_nI * p.g_nJ;
-        const int b = ga / per_b, rr = ga - b * per_b;
-        const int oi = rr / p.g_nJ, oj = rr - oi * p.g_nJ;
-        const int gi = oi * p.g_si, gj = oj * p.g_sj;
-        oA[h][i] = (uint32_t)((((long long)b * p.g_SI + gi) * p.g_SJ + gj) * p.g_C + gck * 8) * 2u;
-        uint32_t in = 0u;
-        for (int t = 0; t < p.g_ntaps; ++t) {
-          const int di = tap_delta(p.g_dip, t), dj = tap_delta(p.g_djp, t);
-          if ((unsigned)(gi + di) < (unsigned)p.g_SI && (unsigned)(gj + dj) < (unsigned)p.g_SJ) in |= 1u << t;
+      gin[h][i] = 0u;
+      if constexpr (!TN) {
+        const int r = q >> 3, gck = (q & 7) ^ ((r >> 1) & 7);
+        int ga = m0 + h * 128 + r; ga = ga < p.M ? ga : p.M - 1;
+        int gb = n0 + h * 128 + r; gb = gb < p.N ? gb : p.N - 1;
+        oB[h][i] = (uint32_t)((long long)gb * p.ldb + gck * 8) * 2u;
+        if constexpr (G == 1) {
+          const int per_b = p.g_nI * p.g_nJ;
+          const int b = ga / per_b, rr = ga - b * per_b;
+          const int oi = rr / p.g_nJ, oj = rr - oi * p.g_nJ;
+          const int gi = oi * p.g_si, gj = oj * p.g_sj;
+          oA[h][i] = (uint32_t)((((long long)b * p.g_SI + gi) * p.g_SJ + gj) * p.g_C + gck * 8) * 2u;
+          uint32_t in = 0u;
+          for (int t = 0; t < p.g_ntaps; ++t) {
+            const int di = tap_delta(p.g_dip, t), dj = tap_delta(p.g_djp, t);
+            if ((unsigned)(gi + di) < (unsigned)p.g_SI && (unsigned)(gj + dj) < (unsigned)p.g_SJ) in |= 1u << t;
+          }
+          gin[h][i] = in;
+        } else {
+          oA[h][i] = (uint32_t)((long long)ga * p.lda + gck * 8) * 2u;
         }
-        gin[h][i] = in;
       } else {
-        oA[h][i] = (uint32_t)((long long)ga * p.lda + gck * 8) * 2u;
-        gin[h][i] = 0u;
+        const int k = q >> 4, c = (q & 15) ^ ((k & 3) << 2) ^ (((k >> 3) & 1) << 1);
+        const int ga = m0 + h * 128 + c * 8, gb = n0 + h * 128 + c * 8;
+        if (ga < p.M) okbits |= 1u << (h * 2 + i);
+        if (gb < p.N) okbits |= 16u << (h * 2 + i);
+        oA[h][i] = (uint32_t)((long long)k * p.lda + ga) * 2u;
+        if constexpr (G == 2) {
+          oB[h][i] = (uint32_t)gb * 2u;  // column only: the position's origin is g2off
+          if (h == 0) {
+            const int m = kt0 * BK + k;
+            const int per_b = p.g_nI * p.g_nJ;
+            const int b = m / per_b, rr = m - b * per_b;
+            g2i[i] = rr / p.g_nJ;
+            g2j[i] = rr - g2i[i] * p.g_nJ;
+            g2row[i] = m;
+            g2off[i] = ((b * p.g_SI + g2i[i] * p.g_si) * p.g_SJ + g2j[i] * p.g_sj) * p.g_C;
+          }
+        } else {
+          oB[h][i] = (uint32_t)((long long)k * p.ldb + gb) * 2u;
+        }
       }
     }
-  const char* Ab = (const char*)A + (G == 1 ? 0ll : (long long)kt0 * (BK * 2));
-  const char* Bb = (const char*)B + (long long)kt0 * (BK * 2);
+  const long long stepA = TN ? (long long)BK * p.lda * 2 : (long long)BK * 2;  // bytes per K-tile
+  const long long stepB = TN ? (long long)BK * p.ldb * 2 : (long long)BK * 2;
+  const char* Ab = (const char*)A + (G == 1 ? 0ll : kt0 * stepA);
+  const char* Bb = (const char*)B + (G == 2 ? 0ll : kt0 * stepB);
   char* const lds8 = (char*)smem8;
-  // gather cursor: tap / channel offset of the K-tile whose A halves are being staged (A0 of a tile is staged one phase-group
-  // before its A1: the cursor advances in front of every A0)
+  const char* const zpage = reinterpret_cast<const char*>(g_zero16);
+  const int krem = p.K - (nk_total - 1) * BK;      // rows of the last K-tile (TN; NT has whole K-tiles)
+  const int k_lo = threadIdx.x >> 4;                // TN: k-row of this thread's chunk i is k_lo + 32 i
+  // G == 1 cursor: tap / channel offset of the K-tile whose A halves are being staged (A0 of a tile is staged in front of its A1:
+  // the cursor advances in front of every A0)
   int g_tap = 0, g_c0 = 0;
   long long g_toff = 0;
-  auto gather_seek = [&](const int kt) {  // (prologue only: one division)
-    g_tap = (kt * BK) / p.g_C;
-    g_c0 = kt * BK - g_tap * p.g_C;
-  };
   auto gather_offs = [&]() {
     const int di = tap_delta(p.g_dip, g_tap), dj = tap_delta(p.g_djp, g_tap);
     g_toff = (((long long)di * p.g_SJ + dj) * p.g_C + g_c0) * 2;
@@ -1868,65 +1903,162 @@ __global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
     if (g_c0 >= p.g_C) { g_c0 = 0; ++g_tap; }
     gather_offs();
   };
-  if constexpr (G == 1) { gather_seek(kt0); gather_offs(); }
+  if constexpr (G == 1) {
+    g_tap = (kt0 * BK) / p.g_C;
+    g_c0 = kt0 * BK - g_tap * p.g_C;
+    gather_offs();
+  }
+  // G == 2: the tap is the batch index; positions advance after the tile's second B half (B0, B1 of one tile use the same state)
+  int g2_toff = 0, g2_di = 0, g2_dj = 0;
+  if constexpr (G == 2) {
+    g2_di = tap_delta(p.g_dip, z0); g2_dj = tap_delta(p.g_djp, z0);
+    g2_toff = (g2_di * p.g_SJ + g2_dj) * p.g_C;
+  }
+  auto g2_advance = [&]() {
+    const int step_j = BK * p.g_sj * p.g_C;
+    const int wrap_j = p.g_si * p.g_SJ * p.g_C - p.g_nJ * p.g_sj * p.g_C;
+    const int wrap_i = p.g_SI * p.g_SJ * p.g_C - p.g_nI * p.g_si * p.g_SJ * p.g_C;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      g2row[i] += BK; g2j[i] += BK; g2off[i] += step_j;
+      while (g2j[i] >= p.g_nJ) { g2j[i] -= p.g_nJ; ++g2i[i]; g2off[i] += wrap_j; }
+      while (g2i[i] >= p.g_nI) { g2i[i] -= p.g_nI; g2off[i] += wrap_i; }
+    }
+  };
+  // G == 2 with row_len: a K-tile whose 64 positions all lie beyond their utterance's length multiplies zeros (dY is masked there):
+  // staged from the zero page, neither read nor multiplied.  Evaluated once per tile in increasing order (the utterance of the
+  // tile's first position is tracked incrementally); one utterance per tile only.
+  int u_b = 0, u_row0 = 0, u_valid = 0;
+  if constexpr (G == 2) {
+    if (p.row_len) {
+      u_b = (kt0 * BK) / p.rows_per_b;
+      u_row0 = u_b * p.rows_per_b;
+      u_valid = (int)min((long long)p.rows_per_b, p.row_len[u_b] * p.rows_inner);
+    }
+  }
+  auto tile_live = [&](const int ts) -> bool {  // uniform
+    if constexpr (G != 2) return true;
+    if (!p.row_len) return true;
+    const int k0 = (kt0 + ts) * BK, k1 = min(k0 + BK, p.K) - 1;
+    while (k0 >= u_row0 + p.rows_per_b) {
+      ++u_b; u_row0 += p.rows_per_b;
+      u_valid = (int)min((long long)p.rows_per_b, p.row_len[u_b] * p.rows_inner);
+    }
+    return !(k1 < u_row0 + p.rows_per_b && k0 - u_row0 >= u_valid);
+  };
   // half-tile j of K-tile ts (staging order j: 0 = B0, 1 = A0, 2 = B1, 3 = A1; j is a literal at every call site)
-  auto stage = [&](const int j, const int ts) __attribute__((always_inline)) {
+  auto stage = [&](const int j, const int ts, const bool live) __attribute__((always_inline)) {
     const int h = j >> 1;
     const bool isA = (j & 1) != 0;
     char* dst = lds8 + (ts & 1) * V8_BUF_B + ((isA ? 0 : 2) + h) * V8_HALF_B + wave * 1024;
-    if (G == 1 && isA) {
-      const char* src = Ab + g_toff;
-      const uint32_t bit = 1u << g_tap;
+    if constexpr (!TN) {
+      if (G == 1 && isA) {
+        const char* src = Ab + g_toff;
+        const uint32_t bit = 1u << g_tap;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const char* sp = (gin[h][i] & bit) ? src + oA[h][i] : reinterpret_cast<const char*>(g_zero16);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)sp, (lds_void_t*)(dst + i * 8192), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+          const char* sp = (gin[h][i] & bit) ? src + oA[h][i] : zpage;
+          __builtin_amdgcn_global_load_lds((glb_void_t*)sp, (lds_void_t*)(dst + i * 8192), 16, 0, 0);
+        }
+      } else {
+        const char* src = (isA ? Ab : Bb) + (long long)ts * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (isA ? oA[h][i] : oB[h][i])), (lds_void_t*)(dst + i * 8192), 16, 0, 0);
       }
     } else {
-      const char* src = (isA ? Ab : Bb) + (long long)ts * (BK * 2);
+      const bool tail = (kt0 + ts == nk_total - 1) && krem < BK;  // uniform
+      if (G == 2 && !isA) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (isA ? oA[h][i] : oB[h][i])), (lds_void_t*)(dst + i * 8192), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+          const int si = g2i[i] * p.g_si + g2_di, sj = g2j[i] * p.g_sj + g2_dj;
+          const bool ok = live && ((okbits >> (4 + h * 2 + i)) & 1u) && g2row[i] < p.K && (unsigned)si < (unsigned)p.g_SI &&
+                          (unsigned)sj < (unsigned)p.g_SJ;
+          const char* sp = ok ? (const char*)p.B + (long long)(g2off[i] + g2_toff) * 2 + oB[h][i] : zpage;
+          __builtin_amdgcn_global_load_lds((glb_void_t*)sp, (lds_void_t*)(dst + i * 8192), 16, 0, 0);
+        }
+      } else {
+        const char* src = isA ? Ab + ts * stepA : Bb + ts * stepB;
+        const int sh = (isA ? 0 : 4) + h * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bool ok = live && ((okbits >> (sh + i)) & 1u) && (!tail || k_lo + 32 * i < krem);
+          const char* sp = ok ? src + (isA ? oA[h][i] : oB[h][i]) : zpage;
+          __builtin_amdgcn_global_load_lds((glb_void_t*)sp, (lds_void_t*)(dst + i * 8192), 16, 0, 0);
+        }
+      }
     }
   };
 
-  // ---- fragment read addresses in K-tile buffer 0 (per k-step: the chunk swizzle is an XOR); A halves / m fragments and B halves /
-  // n fragments are compile-time offsets
-  const int l15 = lane & 15, l4 = lane >> 4, sw = (lane >> 1) & 7;
+  // ---- fragment read addresses in K-tile buffer 0
+  //   NT: per k-step (the chunk swizzle is an XOR); A halves / m fragments and B halves / n fragments are compile-time offsets
+  //   TN: per m / n fragment (the fragment's column chunk enters the swizzle XOR); halves, k-steps and the fragment's second
+  //       transpose read (k + 4) are compile-time offsets
+  const int l15 = lane & 15, l4 = lane >> 4;
   const uint32_t sb8 = lds_addr(smem8);
-  const uint32_t fra0 = sb8 + (uint32_t)((wm * 64 + l15) * 128 + ((l4 ^ sw) << 4));
-  const uint32_t fra1 = sb8 + (uint32_t)((wm * 64 + l15) * 128 + (((4 + l4) ^ sw) << 4));
-  const uint32_t frb0 = sb8 + (uint32_t)(2 * V8_HALF_B + (wn * 32 + l15) * 128 + ((l4 ^ sw) << 4));
-  const uint32_t frb1 = sb8 + (uint32_t)(2 * V8_HALF_B + (wn * 32 + l15) * 128 + (((4 + l4) ^ sw) << 4));
-  bf16x8 fa[4][2], fb[2][2][2];  // [m fragment][k-step], [B half][n fragment][k-step]
+  uint32_t fra[4], frb[2];
+  if constexpr (!TN) {
+    const int sw = (lane >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      fra[ks] = sb8 + (uint32_t)((wm * 64 + l15) * 128 + (((4 * ks + l4) ^ sw) << 4));
+      frb[ks] = sb8 + (uint32_t)(2 * V8_HALF_B + (wn * 32 + l15) * 128 + (((4 * ks + l4) ^ sw) << 4));
+    }
+    fra[2] = fra[3] = 0u;
+  } else {
+    const int t = l15, kr = l4 * 8 + (t >> 2);
+    const int f = ((t >> 2) << 2) ^ ((l4 & 1) << 1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+      fra[mi] = sb8 + (uint32_t)(kr * 256 + (((wm * 8 + mi * 2 + ((t & 3) >> 1)) ^ f) << 4) + (t & 1) * 8);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+      frb[ni] = sb8 + (uint32_t)(2 * V8_HALF_B + kr * 256 + (((wn * 4 + ni * 2 + ((t & 3) >> 1)) ^ f) << 4) + (t & 1) * 8);
+  }
+  FragU fa[4][2], fb[2][2][2];  // [m fragment][k-step], [B half][n fragment][k-step]
 
-#define V8_RD_A(H)                                                                                          \
-  V8_RD(fa[0][0], ra0, (H) * V8_HALF_B);        V8_RD(fa[0][1], ra1, (H) * V8_HALF_B);                      \
-  V8_RD(fa[1][0], ra0, (H) * V8_HALF_B + 2048); V8_RD(fa[1][1], ra1, (H) * V8_HALF_B + 2048);               \
-  V8_RD(fa[2][0], ra0, (H) * V8_HALF_B + 4096); V8_RD(fa[2][1], ra1, (H) * V8_HALF_B + 4096);               \
-  V8_RD(fa[3][0], ra0, (H) * V8_HALF_B + 6144); V8_RD(fa[3][1], ra1, (H) * V8_HALF_B + 6144)
-#define V8_RD_B(HB)                                                                                         \
-  V8_RD(fb[HB][0][0], rb0, (HB) * V8_HALF_B);        V8_RD(fb[HB][0][1], rb1, (HB) * V8_HALF_B);            \
-  V8_RD(fb[HB][1][0], rb0, (HB) * V8_HALF_B + 2048); V8_RD(fb[HB][1][1], rb1, (HB) * V8_HALF_B + 2048)
-#define V8_PIN_A "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1])
-#define V8_PIN_B(HB) "+v"(fb[HB][0][0]), "+v"(fb[HB][0][1]), "+v"(fb[HB][1][0]), "+v"(fb[HB][1][1])
+#define V8_FRAG_A(H, MI, KS)                                                                                  \
+  if constexpr (TN) {                                                                                         \
+    tr_rd<(H) * V8_HALF_B + (KS) * 8192>(fa[MI][KS].h[0], ra[MI]);                                            \
+    tr_rd<(H) * V8_HALF_B + (KS) * 8192 + 1024>(fa[MI][KS].h[1], ra[MI]);                                     \
+  } else v8_rd128<(H) * V8_HALF_B + (MI) * 2048>(fa[MI][KS].v, ra[KS])
+#define V8_FRAG_B(HB, NI, KS)                                                                                 \
+  if constexpr (TN) {                                                                                         \
+    tr_rd<(HB) * V8_HALF_B + (KS) * 8192>(fb[HB][NI][KS].h[0], rb[NI]);                                       \
+    tr_rd<(HB) * V8_HALF_B + (KS) * 8192 + 1024>(fb[HB][NI][KS].h[1], rb[NI]);                                \
+  } else v8_rd128<(HB) * V8_HALF_B + (NI) * 2048>(fb[HB][NI][KS].v, rb[KS])
+#define V8_RD_A(H)                                                                                            \
+  V8_FRAG_A(H, 0, 0); V8_FRAG_A(H, 0, 1); V8_FRAG_A(H, 1, 0); V8_FRAG_A(H, 1, 1);                             \
+  V8_FRAG_A(H, 2, 0); V8_FRAG_A(H, 2, 1); V8_FRAG_A(H, 3, 0); V8_FRAG_A(H, 3, 1)
+#define V8_RD_B(HB) V8_FRAG_B(HB, 0, 0); V8_FRAG_B(HB, 0, 1); V8_FRAG_B(HB, 1, 0); V8_FRAG_B(HB, 1, 1)
+#define V8_PIN_A "+v"(fa[0][0].v), "+v"(fa[0][1].v), "+v"(fa[1][0].v), "+v"(fa[1][1].v), "+v"(fa[2][0].v), "+v"(fa[2][1].v), "+v"(fa[3][0].v), "+v"(fa[3][1].v)
+#define V8_PIN_B(HB) "+v"(fb[HB][0][0].v), "+v"(fb[HB][0][1].v), "+v"(fb[HB][1][0].v), "+v"(fb[HB][1][1].v)
   // 16 MFMAs: quadrant (A half H, B half HB) x K = 64; the eight accumulators of a k-step are independent
 #define V8_MM(H, HB)                                                                                        \
   __builtin_amdgcn_sched_barrier(0);                                                                        \
-  __builtin_amdgcn_s_setprio(1);                                                                            \
+  if (live_cur) {                                                                                           \
   _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                       \
   _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                          \
   _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                          \
-      acc[H][mi][HB][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi][ks_], fb[HB][ni][ks_], acc[H][mi][HB][ni], 0, 0, 0); \
-  __builtin_amdgcn_s_setprio(0);                                                                            \
+      acc[H][mi][HB][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi][ks_].v, fb[HB][ni][ks_].v, acc[H][mi][HB][ni], 0, 0, 0); \
+  }                                                                                                         \
   __builtin_amdgcn_sched_barrier(0);                                                                        \
   __builtin_amdgcn_s_barrier();                                                                             \
   __builtin_amdgcn_sched_barrier(0)
 
+  // bias gradient riding along with a weight gradient: column sums of the A tile, read back from LDS.  The tn workgroups of one
+  // (tile_m, K slice) stage the same A tile: the 8 k-rows of each wave's k-group are dealt round-robin to (up to 8 of) them.
+  const int cs_step = tn < 8 ? tn : 8;
+  const bool do_colsum = TN && G == 0 && p.colsum_out != nullptr && tile_n < cs_step;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
   // ---- prologue: all of K-tile 0 and three half-tiles of K-tile 1 (7 half-tiles = 14 DMA instructions per wave)
-  stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+  bool live_cur = tile_live(0), live_n1 = tile_live(1), live_n2 = true;
+  stage(0, 0, live_cur); stage(1, 0, live_cur); stage(2, 0, live_cur); stage(3, 0, live_cur);
   if constexpr (G == 1) gather_next();
-  stage(0, 1); stage(1, 1); stage(2, 1);
+  if constexpr (G == 2) g2_advance();
+  stage(0, 1, live_n1); stage(1, 1, live_n1); stage(2, 1, live_n1);
+  if constexpr (G == 2) g2_advance();
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first from here on
@@ -1935,28 +2067,48 @@ __global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
 #pragma nounroll
   for (int t = 0; t < nk; ++t) {
     const uint32_t bo = (uint32_t)(t & 1) * V8_BUF_B;
-    const uint32_t ra0 = fra0 + bo, ra1 = fra1 + bo, rb0 = frb0 + bo, rb1 = frb1 + bo;
-    // -- phase 0: B0 (first: retired by lgkmcnt(8), its buffer is re-staged in phase 1) + A0 -> quadrant (0, 0)
-    V8_RD_B(0);
-    V8_RD_A(0);
-    if (t + 1 < nk) stage(3, t + 1);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    const uint32_t ra[4] = {fra[0] + bo, fra[1] + bo, fra[2] + bo, fra[3] + bo};
+    const uint32_t rb[2] = {frb[0] + bo, frb[1] + bo};
+    // -- phase 0: B0 (first: retired by the counted lgkmcnt, its buffer is re-staged in phase 1) + A0 -> quadrant (0, 0)
+    if (live_cur) {
+      V8_RD_B(0);
+      V8_RD_A(0);
+    }
+    if (t + 1 < nk) stage(3, t + 1, live_n1);
+    if constexpr (TN) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // 24 reads issued, the 8 of B0 are the oldest
+    else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                 // 12 reads issued, the 4 of B0 are the oldest
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" : V8_PIN_A, V8_PIN_B(0) : : "memory");
     V8_MM(0, 0);
     // -- phase 1: B1 -> quadrant (0, 1)
-    V8_RD_B(1);
-    if (t + 2 < nk) stage(0, t + 2);
+    if (live_cur) { V8_RD_B(1); }
+    if (t + 2 < nk) {
+      live_n2 = tile_live(t + 2);
+      stage(0, t + 2, live_n2);
+    }
+    if (do_colsum && live_cur) {
+      // thread -> (k-group of 8 rows = wave, A half lane >> 5, 4 consecutive columns); both A halves of tile t are still whole
+      // (A0 is re-staged in phase 2: these reads retire at once, lds_rd64_sync waits for them)
+      const int col = (lane & 31) * 4;
+      const uint32_t a_addr = sb8 + bo + (uint32_t)((lane >> 5) * V8_HALF_B);
+      for (int kr = tile_n; kr < 8; kr += cs_step) {
+        const int krow = wave * 8 + kr;
+        const int off = krow * 256 + ((((col >> 3) ^ ((krow & 3) << 2) ^ ((wave & 1) << 1))) << 4) + (col & 7) * 2;
+        const u32x2 v = lds_rd64_sync(a_addr + (uint32_t)off);
+        csum[0] += __uint_as_float(v[0] << 16); csum[1] += __uint_as_float(v[0] & 0xffff0000u);
+        csum[2] += __uint_as_float(v[1] << 16); csum[3] += __uint_as_float(v[1] & 0xffff0000u);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" : V8_PIN_B(1) : : "memory");
     V8_MM(0, 1);
     // -- phase 2: A1 -> quadrant (1, 1)
-    V8_RD_A(1);
+    if (live_cur) { V8_RD_A(1); }
     if (t + 2 < nk) {
       if constexpr (G == 1) gather_next();
-      stage(1, t + 2);
+      stage(1, t + 2, live_n2);
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -1964,7 +2116,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
     V8_MM(1, 1);
     // -- phase 3: quadrant (1, 0) from registers; the K-tile's one DMA wait: tile t+1 complete, tile t+2's three half-tiles in flight
     if (t + 2 < nk) {
-      stage(2, t + 2);
+      stage(2, t + 2, live_n2);
+      if constexpr (G == 2) g2_advance();
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1972,8 +2125,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     V8_MM(1, 0);
+    live_cur = live_n1; live_n1 = live_n2;
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();  // re-join the wave rows
+#undef V8_FRAG_A
+#undef V8_FRAG_B
 #undef V8_RD_A
 #undef V8_RD_B
 #undef V8_PIN_A
@@ -1981,9 +2137,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
 #undef V8_MM
   __syncthreads();
 
+  float* sC = reinterpret_cast<float*>(smem8);
+  if (do_colsum) {  // combine the 8 k-groups (waves) through LDS: 8 x 256 floats; column = (lane >> 5) * 128 + (lane & 31) * 4 + e
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sC[wave * BM2 + lane * 4 + e] = csum[e];
+    __syncthreads();
+    if (threadIdx.x < BM2) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += sC[w * BM2 + threadIdx.x];
+      const int m = m0 + threadIdx.x;
+      if (m < p.M) atomicAdd(p.colsum_out + z0 * p.colsum_stride + m, v);
+    }
+    __syncthreads();
+  }
+
   // ---- epilogue: four rounds (A half h, m-fragment pair pr) through a [64][BN4+4] f32 window: window row wm*32 + mi2*16 + C/D row,
   // i.e. tile row h*128 + (rl >> 5)*64 + pr*32 + (rl & 31); C/D layout of the 16x16 MFMA: column = lane & 15, row = 4*(lane >> 4) + reg
-  float* sC = reinterpret_cast<float*>(smem8);
   constexpr int LDS_C = BN4 + 4;
   const bool fast = (p.vec_ok & 1) && !(p.N & 7) && n0 + BN4 <= p.N && !p.atomic;
 #pragma nounroll
@@ -2012,6 +2182,75 @@ __global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
     __syncthreads();
     v4_round_out(p, sC, z, coff, m0, n0, (r >> 1) * 128 + (r & 1) * 32, fast, 64);
   }
+}
+
+template <int G, bool TN>
+__global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
+  drop_resolve(p.drop);
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];  // 2 K-tiles x 4 half-tile images x 16 KiB
+  const int tn = (p.N + BN4 - 1) / BN4, tm = (p.M + BM2 - 1) / BM2;
+  const int ntiles = tm * tn;
+  int logical, z, ks;
+  if constexpr (G == 2) {
+    // conv weight gradient (taps x tiles x split-K): the (K slice, tap, tile) list is laid out slice-major and every XCD takes a
+    // contiguous eighth of it, so that co-resident workgroups work on the same slice of dY / the activation grid (third structure)
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int Wt = gx * gy * gz;
+    const int L = (int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z);  // dispatch order: XCD = L % 8
+    const int q8w = Wt >> 3, r8w = Wt & 7, xw = L & 7;
+    const int w = (xw < r8w ? xw * (q8w + 1) : r8w * (q8w + 1) + (xw - r8w) * q8w) + (L >> 3);
+    const int ncombo = gx * gz;
+    ks = w / ncombo;
+    const int combo = w - ks * ncombo;
+    z = combo / gx;
+    logical = combo - z * gx;
+  } else {
+    const int bid = blockIdx.x;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    z = blockIdx.z;
+    ks = blockIdx.y;
+  }
+  // tile order inside the list: column blocks of (up to) 8 tiles, row-major inside a block -- the 32 workgroups an XCD runs
+  // together then cover about 4 x 8 tiles (12 operand panels through its L2) instead of 1 x 32 (33 panels) when N is wide
+  // (the Conformer shapes have tn <= 8 and keep their order)
+  const int per_cb = tm * 8;
+  const int cb = logical / per_cb, rem = logical - cb * per_cb;
+  const int w8 = min(8, tn - cb * 8);
+  const int tile_m = rem / w8, tile_n = cb * 8 + (rem - tile_m * w8);
+  gemm_v8_body<G, TN>(p, smem8, tile_m, tile_n, ks, z);
+}
+
+// ---- grouped weight gradients on the eighth structure: the problems' 256x256 tiles x K slices in one launch, (problem, K slice)
+// groups laid out one after the other and dealt to the XCDs in contiguous eighths (as gemm_bf16_grouped_tn_kernel above)
+__global__ __launch_bounds__(512) void gemm_bf16_grouped_tn8_kernel(GroupP g) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];
+  int pi = 0;
+  const int tiles_total = g.tile_begin[g.n];
+  const int W = tiles_total * g.splitk;
+  const int L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+  const int q8w = W >> 3, r8w = W & 7, xw = L & 7;
+  const int w = (xw < r8w ? xw * (q8w + 1) : r8w * (q8w + 1) + (xw - r8w) * q8w) + (L >> 3);
+  while (pi + 1 < g.n && w >= g.splitk * g.tile_begin[pi + 1]) ++pi;  // uniform
+  const int ntile_p = g.tile_begin[pi + 1] - g.tile_begin[pi];
+  const int rel = w - g.splitk * g.tile_begin[pi];
+  const int exp_ks = rel / ntile_p, exp_tile = rel - exp_ks * ntile_p;
+  GemmP p;
+  p.A = g.A[pi]; p.B = g.B[pi]; p.C = g.C[pi];
+  p.M = g.M[pi]; p.N = g.N[pi]; p.K = g.K;
+  p.lda = g.lda[pi]; p.ldb = g.ldb[pi]; p.ldc = g.ldc[pi]; p.csc = 1;
+  p.transA = 1; p.transB = 1; p.batch = 1; p.nb0 = 1;
+  p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = 0;
+  p.bias = nullptr; p.alpha = 1.f; p.epi = EPI_STORE; p.c_dt = MI_DT_F32; p.atomic = 1; p.swish_g = 0;
+  p.aux_in = nullptr; p.auxin_dt = 0; p.aux_out = nullptr; p.auxout_dt = 0; p.ldaux = 0;
+  p.drop.key = 0u; p.drop.threshold = 0u; p.drop.scale = 1.f; p.drop.step = nullptr;
+  p.row_len = nullptr; p.rows_per_b = 1; p.rows_inner = 1;
+  p.splitk = g.splitk; p.ktiles_per_split = g.ktiles_per_split;
+  p.colsum_stride = 0; p.colsum_out = g.colsum[pi];
+  p.vec_ok = 0; p.g_on = 0; p.r_on = 0;
+  const int tn = (p.N + BN4 - 1) / BN4;
+  gemm_v8_body<0, true>(p, smem8, exp_tile / tn, exp_tile % tn, exp_ks, 0);
 }
 
 // =================================================================================================
@@ -2651,26 +2890,49 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
       if (!attr_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
       dim3 grid2(tm2 * tn, sk, p.batch);
       // phase-staggered 256x256 structure on 16x16x32 MFMAs (key 8 / MI355X_GEMM_V8: 0 = never, 1 = where it measured faster, 2 = every
-      // shape it can run): dense K-contiguous operands, whole K-tiles, at least two per workgroup, 32-bit operand offsets
+      // shape it can run; 3 = as 1 plus the weight-gradient (TN) layouts, 4 = as 1 plus the wide plain stores the persistent
+      // structure otherwise takes -- A/B arms).  NT: K-contiguous operands, whole K-tiles; TN: both operands reduction-major (K tail
+      // allowed); at least two K-tiles per workgroup, 32-bit operand offsets.
+      // The TN layouts are correct on it but SLOWER than on the lock-step structures (conv2 weight gradient 2.54 vs 2.02 ms, a layer's
+      // grouped weight gradients 307 vs 286 us, profiles/r6_gemm_8phase.md): a fragment is two ds_read_b64_tr_b16, and the 8-byte
+      // reads only reach the LDS rate with both waves of a SIMD reading -- the stagger has one of them reading at a time.
       {
         const int v8_mode = mode_now(8);
         const int nk_wg8 = sk > 1 ? p.ktiles_per_split : nk;
-        bool v8_can = !p.transA && !p.transB && p.g_on != 2 && !(p.K % BK) && nk_wg8 >= 2 && (sk == 1 || !(nk % nk_wg8)) && p.N > 128 &&
-                      (long long)p.N * p.ldb < (1LL << 31);
-        if (p.g_on == 1)  // gathered A: 32-bit byte offsets into the source grid, a K-tile inside one tap
-          v8_can = v8_can && !(p.g_C % BK) && (long long)(p.M / (p.g_nI * p.g_nJ)) * p.g_SI * p.g_SJ * p.g_C < (1LL << 31);
-        else v8_can = v8_can && (long long)p.M * p.lda < (1LL << 31);
+        const bool nt8 = !p.transA && !p.transB, tn8l = p.transA && p.transB;
+        const int last8 = nk - (sk - 1) * nk_wg8;  // K-tiles of the last slice
+        bool v8_can = (nt8 || tn8l) && nk_wg8 >= 2 && last8 >= 2 && p.N > 128;
+        if (nt8) {
+          v8_can = v8_can && p.g_on != 2 && !(p.K % BK) && (long long)p.N * p.ldb < (1LL << 31);
+          if (p.g_on == 1)  // gathered A: 32-bit byte offsets into the source grid, a K-tile inside one tap
+            v8_can = v8_can && !(p.g_C % BK) && (long long)(p.M / (p.g_nI * p.g_nJ)) * p.g_SI * p.g_SJ * p.g_C < (1LL << 31);
+          else v8_can = v8_can && (long long)p.M * p.lda < (1LL << 31);
+        } else if (tn8l) {
+          v8_can = v8_can && p.g_on != 1 && 64 * p.lda < (1LL << 30) && (p.g_on == 2 || 64 * p.ldb < (1LL << 30));
+        }
         const int tn8 = (p.N + BN4 - 1) / BN4;
         const long long blocks8 = (long long)tm2 * tn8 * sk * p.batch;
-        const bool v8_pick = v8_mode == 2 || (v8_mode == 1 && blocks8 >= 224 && (long long)tn8 * BN4 * 8 <= (long long)p.N * 9);
+        const long long blocks2_ = (long long)tm2 * tn * sk * p.batch;
+        const double eff8 = (double)blocks8 / (double)(((blocks8 + 255) / 256) * 256);
+        const double eff2_ = (double)blocks2_ / (double)(((blocks2_ + 255) / 256) * 256);
+        // the rule of the third structure: the larger tile still fills the chip, few padded columns, no worse wave quantisation
+        const bool fills = blocks8 >= 224 && (long long)tn8 * BN4 * 8 <= (long long)p.N * 9 && eff8 >= 0.9 * eff2_;
+        // (plain stores at least 1536 columns wide with K <= 576 stay on the persistent structure: 40.3 vs 41.4 us on the QKV shape)
+        const bool v5_keeps = nt8 && !p.g_on && p.epi == EPI_STORE && p.N >= 1536 && nk >= 8 && nk <= 9 && !p.atomic && sk == 1 &&
+                              !(p.N % BN) && v5_mode_now() && v8_mode != 4;
+        const bool v8_pick = v8_mode == 2 || (v8_mode >= 1 && fills && !v5_keeps && (nt8 || v8_mode == 3));
         if (v8_can && v8_pick) {
-          static const bool attr8_ok = hipFuncSetAttribute((const void*)gemm_bf16_v8_kernel<0>,
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V8_BUF_B) == hipSuccess &&
-                                       hipFuncSetAttribute((const void*)gemm_bf16_v8_kernel<1>,
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V8_BUF_B) == hipSuccess;
+          typedef void (*v8_fn)(GemmP);
+          static const v8_fn v8_all[] = {gemm_bf16_v8_kernel<0, false>, gemm_bf16_v8_kernel<1, false>, gemm_bf16_v8_kernel<0, true>,
+                                         gemm_bf16_v8_kernel<2, true>};
+          static const bool attr8_ok = [] {
+            for (v8_fn f : v8_all)
+              if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V8_BUF_B) != hipSuccess) return false;
+            return true;
+          }();
           if (!attr8_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
-          if (p.g_on == 1) MI_LAUNCH((gemm_bf16_v8_kernel<1>), dim3(tm2 * tn8, sk, p.batch), dim3(512), 2 * V8_BUF_B, s, p);
-          else MI_LAUNCH((gemm_bf16_v8_kernel<0>), dim3(tm2 * tn8, sk, p.batch), dim3(512), 2 * V8_BUF_B, s, p);
+          const v8_fn fn = nt8 ? v8_all[p.g_on == 1 ? 1 : 0] : v8_all[p.g_on == 2 ? 3 : 2];
+          MI_LAUNCH(fn, dim3(tm2 * tn8, sk, p.batch), dim3(512), 2 * V8_BUF_B, s, p);
           return mi_check_launch();
         }
       }
@@ -2797,6 +3059,51 @@ extern "C" int mi355x_gemm_grouped(const mi355x_gemm_desc* descs, int n, void* s
   const int nk = (g.K + BK - 1) / BK;
   int sk = descs[0].splitk > 1 ? descs[0].splitk : 1;
   if (sk > nk) sk = nk;
+  // eighth structure (key 8 modes 2 and 3 only: slower than this one on the reduction-major layouts, see mi355x_gemm): 256x256 tiles --
+  // half as many as the caller's split-K factor was chosen for, so the factor is chosen again here by the same rule (whole rounds
+  // of the 256 CUs, smaller factors preferred, >= 16 K-tiles a slice)
+  const int v8_mode = mode_now(8);
+  if ((v8_mode == 2 || v8_mode == 3) && nk >= 4) {
+    bool ok8 = true;
+    int tiles8 = 0;
+    for (int i = 0; i < n; ++i) {
+      ok8 = ok8 && descs[i].N > 128 && 64 * descs[i].lda < (1LL << 30) && 64 * descs[i].ldb < (1LL << 30);
+      g.tile_begin[i] = tiles8;
+      tiles8 += ((descs[i].M + BM2 - 1) / BM2) * ((descs[i].N + BN4 - 1) / BN4);
+    }
+    if (ok8) {
+      for (int i = n; i <= GRP_MAX; ++i) g.tile_begin[i] = tiles8;
+      int best = 1;
+      double best_score = -1.0;
+      for (int c = 1; c <= 16; ++c) {
+        if (c > 1 && nk / c < 16) break;
+        const long long blocks = (long long)tiles8 * c;
+        const double score = (double)blocks / (double)(((blocks + 255) / 256) * 256) - 0.01 * c;
+        if (score > best_score + 1e-9) { best = c; best_score = score; }
+      }
+      if (sk > 1) sk = best;
+      g.ktiles_per_split = (nk + sk - 1) / sk;
+      if (g.ktiles_per_split < 2) { g.ktiles_per_split = 2; }
+      sk = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
+      if (nk - (sk - 1) * g.ktiles_per_split >= 2) {  // (every slice needs two K-tiles)
+        g.splitk = sk;
+        static const bool attr8g_ok = hipFuncSetAttribute((const void*)gemm_bf16_grouped_tn8_kernel,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V8_BUF_B) == hipSuccess;
+        if (!attr8g_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
+        MI_LAUNCH(gemm_bf16_grouped_tn8_kernel, dim3(tiles8, sk, 1), dim3(512), 2 * V8_BUF_B, (hipStream_t)stream, g);
+        return mi_check_launch();
+      }
+    }
+    // not taken: the tile list of the 256x128 structure again
+    tiles = 0;
+    for (int i = 0; i < n; ++i) {
+      g.tile_begin[i] = tiles;
+      tiles += ((descs[i].M + BM2 - 1) / BM2) * ((descs[i].N + BN - 1) / BN);
+    }
+    for (int i = n; i <= GRP_MAX; ++i) g.tile_begin[i] = tiles;
+    sk = descs[0].splitk > 1 ? descs[0].splitk : 1;
+    if (sk > nk) sk = nk;
+  }
   g.ktiles_per_split = (nk + sk - 1) / sk;
   sk = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
   g.splitk = sk;

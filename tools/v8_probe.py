@@ -258,12 +258,113 @@ def conv2():
     return 0 if same else 1
 
 
+def tn():
+    """weight-gradient layouts (both operands reduction-major, f32 atomic split-K, fused bias-gradient column sums): dense, grouped
+    and the gathered conv2 weight gradient -- v8 against the older structures and against an fp32 product, + time"""
+    bad = 0
+    g = torch.Generator(device=dev).manual_seed(3)
+    for (M, N, K, sk) in [(512, 2048, 16032, 4), (2048, 512, 16032, 4), (300, 520, 1000, 2), (512, 512, 16032, 8), (1024, 512, 777, 1)]:
+        lda, ldb = (M + 7) // 8 * 8, (N + 7) // 8 * 8  # (pitches are multiples of 8 elements by contract; pad columns hold junk)
+        dY = (torch.rand(K, lda, device=dev, generator=g) * 2 - 1).to(bf)
+        X = (torch.rand(K, ldb, device=dev, generator=g) * 2 - 1).to(bf)
+        ref = dY[:, :M].float().t() @ X[:, :N].float()
+        refb = dY[:, :M].float().sum(0)
+        outs, res = {}, {}
+        for rep in range(REPS):
+            for arm, mode in (("old", 0), ("v8", 2)):
+                old = set_modes(mode)
+                try:
+                    dW = torch.zeros(M, N, device=dev)
+                    db = torch.zeros(M, device=dev)
+                    f = lambda: ops.gemm(dY, X, dW, M, N, K, lda, ldb, N, transA=True, transB=True, atomic=True, splitk=sk, c_dtype=ops.F32,
+                                         colsum_out=db)
+                    f()
+                    torch.cuda.synchronize()
+                    outs[arm] = (dW.clone(), db.clone())
+                    res.setdefault(arm, []).append(timeit(f))
+                finally:
+                    restore(old)
+        e8, eo = rel_err(outs["v8"][0], ref), rel_err(outs["old"][0], ref)
+        b8, bo = rel_err(outs["v8"][1], refb), rel_err(outs["old"][1], refb)
+        ok = e8 <= max(2 * eo, 2e-6) and b8 <= max(2 * bo, 2e-6)
+        bad += 0 if ok else 1
+        fl = 2.0 * M * N * K
+        print(f"tn dense M={M} N={N} K={K} sk={sk}: dW rel err v8 {e8:.2e} old {eo:.2e}; colsum v8 {b8:.2e} old {bo:.2e} {'ok' if ok else '<-- BAD'}  " +
+              "  ".join(f"{a}: {min(v)*1e6:8.1f} us {fl/min(v)/1e12:7.1f} TF" for a, v in res.items()), flush=True)
+    # one Conformer layer's weight gradients as the grouped launch
+    Mr, d, dff = 16032, 512, 2048
+    mk = lambda n: (torch.rand(Mr, n, device=dev, generator=g) * 2 - 1).to(bf)
+    shapes = [(d, dff), (dff, d), (d, dff), (dff, d), (d, d), (d, d), (d, d), (d, d), (2 * d, d), (d, d)]
+    ops_ = [(mk(no), mk(ni)) for no, ni in shapes]
+    outs, res = {}, {}
+    for rep in range(REPS):
+        for arm, mode in (("old", 0), ("v8", 3)):
+            old = set_modes(mode)
+            try:
+                probs = []
+                for (dY, X), (no, ni) in zip(ops_, shapes):
+                    probs.append((dY, no, 0, X, ni, 0, torch.zeros(no, ni, device=dev), no, ni, torch.zeros(no, device=dev)))
+                f = lambda: ops.wgrad_grouped(probs, Mr, 4)
+                f()
+                torch.cuda.synchronize()
+                outs[arm] = [(q[6].clone(), q[9].clone()) for q in probs]
+                res.setdefault(arm, []).append(timeit(f))
+            finally:
+                restore(old)
+    worst = 0.0
+    for (dY, X), (w8, b8), (wo, bo_) in zip(ops_, outs["v8"], outs["old"]):
+        ref = dY.float().t() @ X.float()
+        worst = max(worst, rel_err(w8, ref), rel_err(b8, dY.float().sum(0)))
+    ok = worst < 5e-6
+    bad += 0 if ok else 1
+    fl = sum(2.0 * Mr * a * b for a, b in shapes)
+    print(f"tn grouped layer x{len(shapes)}: worst rel err vs fp32 {worst:.2e} {'ok' if ok else '<-- BAD'}  " +
+          "  ".join(f"{a}: {min(v)*1e6:8.1f} us {fl/min(v)/1e12:7.1f} TF" for a, v in res.items()), flush=True)
+    # conv2 weight gradient (gathered reduction-major B, batch = taps, column-strided C)
+    B_, T1, F1, C_ = 32, 1001, 40, 512
+    T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+    M2 = B_ * T2 * F2
+    dout2 = (torch.rand(M2, C_, device=dev, generator=g) * 2 - 1).to(bf)
+    out1 = (torch.rand(B_, T1, F1, C_, device=dev, generator=g) * 2 - 1).to(bf)
+    len2 = torch.full((B_,), T2, device=dev, dtype=torch.int64)
+    len2[3] = T2 // 3
+    dv = dout2.view(B_, T2, F2, C_)
+    dv[3, T2 // 3:] = 0  # dY is masked beyond an utterance (what makes the K-tile skip legal)
+    taps = [(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]
+    from nemo_amd.modules.conformer_encoder import ConformerEncoder as CE
+    sk = CE._splitk(CE._tiles(C_, C_, True) * 9, M2)
+    outs, res = {}, {}
+    for rep in range(REPS):
+        for arm, mode in (("old", 0), ("v8", 3)):
+            old = set_modes(mode)
+            try:
+                dW = torch.zeros(C_, C_, 3, 3, device=dev)
+                f = lambda: ops.gemm(dout2, out1, dW, C_, C_, M2, C_, C_, 9 * C_, transA=True, transB=True, atomic=True, splitk=sk, batch=9,
+                                     nb0=9, sC=(1, 0), c_col_stride=9, c_dtype=ops.F32, row_len=len2, rows_per_b=T2 * F2, rows_inner=F2,
+                                     gather=dict(operand=1, nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2, taps=taps))
+                f()
+                torch.cuda.synchronize()
+                outs[arm] = dW.clone()
+                res.setdefault(arm, []).append(timeit(f))
+            finally:
+                restore(old)
+    e = rel_err(outs["v8"], outs["old"])
+    ok = e < 5e-6
+    bad += 0 if ok else 1
+    fl = 2.0 * M2 * C_ * 9 * C_
+    print(f"tn conv2_wgrad gathered splitk={sk}: v8 vs old rel {e:.2e} {'ok' if ok else '<-- BAD'}  " +
+          "  ".join(f"{a}: {min(v)*1e6:8.1f} us {fl/min(v)/1e12:7.1f} TF" for a, v in res.items()), flush=True)
+    return bad
+
+
 if __name__ == "__main__":
     rc = 0
     if os.environ.get("CHECK", "1") != "0":
         rc = check()
     if os.environ.get("CONV2", "1") != "0":
         rc += conv2()
+    if os.environ.get("TN", "1") != "0":
+        rc += tn()
     if os.environ.get("BENCH", "1") != "0":
         bench()
     sys.exit(1 if rc else 0)
