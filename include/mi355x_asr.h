@@ -90,7 +90,9 @@ int mi355x_gemm(const mi355x_gemm_desc* desc, void* stream);
  * key 3: fp32 problems on the matrix cores, v_mfma_f32_32x32x2_f32 (1 = default, 0 = the vector-unit kernel);
  * key 8: the phase-staggered 256x256 structure on 16x16x32 MFMAs (0 never, 1 = default: K-contiguous layouts that fill the chip
  * with 256x256 tiles, dense or with gathered A rows; 2 = every problem it can run; 3 = as 1 plus the weight-gradient layouts,
- * 4 = as 1 plus the wide plain stores the persistent structure otherwise takes).
+ * 4 = as 1 plus the wide plain stores the persistent structure otherwise takes, 5 = as 1 plus its 128x256 tile where only that
+ * fills the chip and K >= 768); key 9: start delay of every other first-round workgroup of that
+ * structure in 10-ns ticks (experiment, default 0).
  * Returns the previous value (-1 = not yet read from the environment), or -1 for an unknown key. */
 int mi355x_gemm_config(int key, int value);
 /* Up to 12 independent weight-gradient problems in one launch: every desc must be bf16, transA = transB = 1, atomic

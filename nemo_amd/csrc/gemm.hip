@@ -55,6 +55,7 @@ struct GemmP {
   long long colsum_stride;             // batch stride (z0) of colsum_out
   float* colsum_out;                   // transA only: colsum_out[m] += sum_k A(k, m)  (bias gradient fused into wgrad)
   int vec_ok;                          // C / aux rows are 8-element aligned & dense: vectorised epilogue allowed
+  int v8_delay;                        // eighth structure: start delay of every other first-round workgroup (10-ns ticks), see there
   // implicit-GEMM convolution (channels-last): A row m = (b, i, j) on an [nI x nJ] grid gathers, for K index tap*C + c,
   // src[b][i*si + di[tap]][j*sj + dj[tap]][c] of a [SI x SJ x C] source grid (zero outside)
   int g_on, g_nI, g_nJ, g_SI, g_SJ, g_C, g_si, g_sj, g_ntaps;
@@ -289,8 +290,19 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
     const int m = m_first + it * ROW_STEP;
     if (m >= p.M) continue;
     const float* src = sC + (row_l0 + it * ROW_STEP) * LDS_C + c8;
-    const float4 a = *reinterpret_cast<const float4*>(src);
-    const float4 b = *reinterpret_cast<const float4*>(src + 4);
+    float4 a, b;
+    if (TW == 256) {
+      // 32 lanes per window row, 32 bytes apart: in the 16-lane service groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...) both halves
+      // of a lane pair would hit the same 16-byte slot twice (2-way) if every lane read its low half first; lanes 16-31 of each half
+      // wave start with their high half instead -- every group then covers the 16 slots of the 256-byte bank row once
+      const int hi = (threadIdx.x >> 4) & 1;
+      const float4 x = *reinterpret_cast<const float4*>(src + 4 * hi);
+      const float4 y = *reinterpret_cast<const float4*>(src + 4 * (1 - hi));
+      a = hi ? y : x; b = hi ? x : y;
+    } else {
+      a = *reinterpret_cast<const float4*>(src);
+      b = *reinterpret_cast<const float4*>(src + 4);
+    }
     float v[8] = {a.x + b8[0], a.y + b8[1], a.z + b8[2], a.w + b8[3], b.x + b8[4], b.y + b8[5], b.z + b8[6], b.w + b8[7]};
     float dm[8];
     drop_mask8(p.drop, db_l + (uint32_t)it * db_s, dm);
@@ -332,7 +344,11 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = aux[AUX_IN ? it : 0][j] > 0.f ? v[j] : 0.f;
     }
+#if defined(V8_EPI_ABL) && V8_EPI_ABL == 3
+    asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(ci));
+#else
     st8x(p.C, ci, p.c_dt, v);
+#endif
   }
 }
 template <int ITERS, int ROW_STEP, int TW = BN>
@@ -1765,16 +1781,132 @@ __global__ __launch_bounds__(512) void gemm_bf16_v6_kernel(GemmP p) {
 // =================================================================================================
 #define V8_HALF_B 16384
 #define V8_BUF_B 65536
+// -DV8_TRACE (tools/ab_build.py variant, never the shipped build): wave 0 of every workgroup stamps s_memrealtime (100 MHz, chip-wide)
+// and s_memtime (shader clock) at entry, after the prologue, after the K loop and at exit: 8 words per workgroup of one launch
+#ifdef V8_TRACE
+__device__ unsigned long long* g_v8_trace = nullptr;
+extern "C" int mi355x_gemm_debug_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_v8_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#define V8_STAMP(i)                                                                                              \
+  if (g_v8_trace && threadIdx.x == 0) {                                                                          \
+    unsigned long long tr_, tc_;                                                                                 \
+    asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_), "=s"(tc_)::"memory");  \
+    const int wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                              \
+    g_v8_trace[wg_ * 16 + 2 * (i)] = tr_; g_v8_trace[wg_ * 16 + 2 * (i) + 1] = tc_;                              \
+  }
+#else
+#define V8_STAMP(i)
+#endif
 template <int OFF>
 __device__ __forceinline__ void v8_rd128(bf16x8& dst, uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 
-template <int G, bool TN>
+// ---- fast epilogue round of the eighth structure: 64 window rows x 256 columns, window = [64][256] f32 with the 16-byte chunks of
+// a row XOR-swizzled by (row & 7) (no padding: two windows fill the 128 KiB, so a round's writes never wait for the previous round's
+// readers).  One thread = 8 consecutive columns of FOUR rows (window rows rl0 + 16 it; tile rows m_base + (it >> 1) * hstride + rl0 +
+// 16 * (it & 1)).  All aux_in loads, then all eight LDS reads of the thread go out before the first use (the generic fast_epilogue
+// walks its rows one after the other: 16 dependent LDS round trips per tile were 4 of the epilogue's 8 us, profiles/r6_gemm_8phase.md);
+// the bias is loaded once per tile by the caller.  Same arithmetic in the same order as fast_epilogue / epilogue8 (bit-identical).
+template <int EPI>
+__device__ __forceinline__ void v8_round_fast(const GemmP& p, const float* win, const float (&b8)[8], int z, long long coff, int m_base,
+                                              int hstride, int n0) {
+  constexpr bool AUX_IN = EPI == EPI_RESID || EPI == EPI_DSWISH || EPI == EPI_MUL_POS;
+  const int k = threadIdx.x & 31, rl0 = threadIdx.x >> 5;
+  const int n = n0 + k * 8;
+  const bool lin = (EPI != EPI_MUL_POS) || !p.r_on;
+  int mrow[4];
+  long long ci[4], ai[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    mrow[it] = m_base + (it >> 1) * hstride + rl0 + 16 * (it & 1);
+    const long long mr = lin ? (long long)mrow[it] : crow(p, mrow[it] < p.M ? mrow[it] : p.M - 1);
+    ci[it] = coff + mr * p.ldc + n;
+    ai[it] = coff + mr * p.ldaux + n;
+  }
+  float aux[AUX_IN ? 4 : 1][8];
+  if (AUX_IN) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      if (mrow[it] < p.M) ld8x(p.aux_in, ai[it], EPI == EPI_RESID ? MI_DT_F32 : p.auxin_dt, aux[it]);
+  }
+  // lanes 16-31 of each half wave read their high 16 bytes first: every 16-lane service group of ds_read_b128 then covers the 16
+  // slots of the 256-byte bank row once (the row's XOR only permutes them)
+  const int hi = (threadIdx.x >> 4) & 1, sw = rl0 & 7;
+  float4 x[4], y[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const float* row = win + (rl0 + 16 * it) * 256;
+    x[it] = *reinterpret_cast<const float4*>(row + (((2 * k + hi) ^ sw) << 2));
+    y[it] = *reinterpret_cast<const float4*>(row + (((2 * k + 1 - hi) ^ sw) << 2));
+  }
+  const uint32_t dbase = (uint32_t)z * (uint32_t)(p.M * p.N) + (uint32_t)n;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int m = mrow[it];
+    if (m >= p.M) continue;
+    const float4 a = hi ? y[it] : x[it], b = hi ? x[it] : y[it];
+    float v[8] = {a.x + b8[0], a.y + b8[1], a.z + b8[2], a.w + b8[3], b.x + b8[4], b.y + b8[5], b.z + b8[6], b.w + b8[7]};
+    float dm[8];
+    drop_mask8(p.drop, dbase + (uint32_t)m * (uint32_t)p.N, dm);
+    if (EPI == EPI_STORE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= p.alpha * dm[j];
+    } else if (EPI == EPI_SWISH_DROP) {
+      if (p.swish_g) {
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) swish_pair(v[j], dm[j], v[j], g[j]);
+        st8x(p.aux_out, ai[it], p.auxout_dt, g);
+      } else {
+        st8x(p.aux_out, ai[it], p.auxout_dt, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = swishf_(v[j]) * dm[j];
+      }
+    } else if (EPI == EPI_RESID) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = aux[AUX_IN ? it : 0][j] + p.alpha * v[j] * dm[j];
+    } else if (EPI == EPI_DSWISH) {
+      if (p.swish_g) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= aux[AUX_IN ? it : 0][j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * dm[j] * swish_grad(aux[AUX_IN ? it : 0][j]);
+      }
+    } else if (EPI == EPI_RELU_MASK) {
+      const int bb = m / p.rows_per_b;
+      const int t = (m - bb * p.rows_per_b) / p.rows_inner;
+      const bool ok = (long long)t < p.row_len[bb];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (ok && v[j] > 0.f) ? v[j] : 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = aux[AUX_IN ? it : 0][j] > 0.f ? v[j] : 0.f;
+    }
+#if defined(V8_EPI_ABL) && V8_EPI_ABL == 3
+    asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(ci[it]));
+#else
+    st8x(p.C, ci[it], p.c_dt, v);
+#endif
+  }
+}
+
+// AH = A halves of the tile: 2 = the 256x256 tile described above; 1 = a 128x256 tile (dense NT only) for problems whose 256x256
+// tiles would leave half the chip idle (N = 512 at M = 16032: 126 tiles): one A half, both B halves, two phases per K-tile
+// (p0 (A0,B0), p1 (A0,B1)), THREE K-tile buffers of three half-tile images (A0 | B0 | B1, 144 KiB) filled two K-tiles ahead -- a
+// K-tile is only 1 024 MFMA cycles here, one tile of lead would not cover the DMA latency.  Phase 0 stages B0 of tile t+2, phase 1
+// its B1 and A0 and waits vmcnt(6): all of tile t+1 landed, tile t+2 in flight; every buffer is re-staged two or three phases
+// after its last read (no early-retire trick needed).
+template <int G, bool TN, int AH = 2>
 __device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, const int tile_m, const int tile_n, const int kslice,
                                              const int z) {
   const int tn = (p.N + BN4 - 1) / BN4;
-  const int m0 = tile_m * BM2, n0 = tile_n * BN4;
+  static_assert(AH == 2 || (AH == 1 && G == 0 && !TN), "the one-A-half tile: dense K-contiguous operands");
+  constexpr int BMT = 128 * AH;                      // tile rows
+  constexpr int BUF_B = (AH + 2) * V8_HALF_B;        // bytes of one K-tile buffer: A halves | B0 | B1
+  const int m0 = tile_m * BMT, n0 = tile_n * BN4;
   const int z0 = z % p.nb0, z1 = z / p.nb0;
   const bf16_t* A = (const bf16_t*)p.A + z0 * p.sA0 + z1 * p.sA1;
   const bf16_t* B = (const bf16_t*)p.B + z0 * p.sB0 + z1 * p.sB1;
@@ -1785,7 +1917,7 @@ __device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, cons
     const bool mask_tile = p.epi == EPI_RELU_MASK && !p.r_on;
     const bool gate_tile = p.epi == EPI_MUL_POS && p.row_len != nullptr;
     if ((mask_tile || gate_tile) && p.splitk <= 1 && !p.aux_out && p.c_dt == MI_DT_BF16 && p.csc == 1 && p.vec_ok && !(p.N & 7)) {
-      const int mlast = min(m0 + BM2, p.M) - 1;
+      const int mlast = min(m0 + BMT, p.M) - 1;
       const int b0 = m0 / p.rows_per_b, b1 = mlast / p.rows_per_b;
       const int t0 = (m0 - b0 * p.rows_per_b) / p.rows_inner;
       if (b0 == b1 && (long long)t0 >= p.row_len[b0]) {
@@ -1812,9 +1944,9 @@ __device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, cons
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  f32x4 acc[2][4][2][2];  // [A half][m fragment][B half][n fragment]: rows h*128 + wm*64 + mi*16, columns hb*128 + wn*32 + ni*16
+  f32x4 acc[AH][4][2][2];  // [A half][m fragment][B half][n fragment]: rows h*128 + wm*64 + mi*16, columns hb*128 + wn*32 + ni*16
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < AH; ++h)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -1947,10 +2079,10 @@ __device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, cons
     return !(k1 < u_row0 + p.rows_per_b && k0 - u_row0 >= u_valid);
   };
   // half-tile j of K-tile ts (staging order j: 0 = B0, 1 = A0, 2 = B1, 3 = A1; j is a literal at every call site)
-  auto stage = [&](const int j, const int ts, const bool live) __attribute__((always_inline)) {
+  auto stage = [&](const int j, const int ts, const bool live, const int buf = -1) __attribute__((always_inline)) {
     const int h = j >> 1;
     const bool isA = (j & 1) != 0;
-    char* dst = lds8 + (ts & 1) * V8_BUF_B + ((isA ? 0 : 2) + h) * V8_HALF_B + wave * 1024;
+    char* dst = lds8 + (buf < 0 ? (ts & 1) : buf) * BUF_B + ((isA ? 0 : AH) + h) * V8_HALF_B + wave * 1024;
     if constexpr (!TN) {
       if (G == 1 && isA) {
         const char* src = Ab + g_toff;
@@ -2002,7 +2134,7 @@ __device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, cons
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       fra[ks] = sb8 + (uint32_t)((wm * 64 + l15) * 128 + (((4 * ks + l4) ^ sw) << 4));
-      frb[ks] = sb8 + (uint32_t)(2 * V8_HALF_B + (wn * 32 + l15) * 128 + (((4 * ks + l4) ^ sw) << 4));
+      frb[ks] = sb8 + (uint32_t)(AH * V8_HALF_B + (wn * 32 + l15) * 128 + (((4 * ks + l4) ^ sw) << 4));
     }
     fra[2] = fra[3] = 0u;
   } else {
@@ -2033,14 +2165,17 @@ __device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, cons
 #define V8_RD_B(HB) V8_FRAG_B(HB, 0, 0); V8_FRAG_B(HB, 0, 1); V8_FRAG_B(HB, 1, 0); V8_FRAG_B(HB, 1, 1)
 #define V8_PIN_A "+v"(fa[0][0].v), "+v"(fa[0][1].v), "+v"(fa[1][0].v), "+v"(fa[1][1].v), "+v"(fa[2][0].v), "+v"(fa[2][1].v), "+v"(fa[3][0].v), "+v"(fa[3][1].v)
 #define V8_PIN_B(HB) "+v"(fb[HB][0][0].v), "+v"(fb[HB][0][1].v), "+v"(fb[HB][1][0].v), "+v"(fb[HB][1][1].v)
-  // 16 MFMAs: quadrant (A half H, B half HB) x K = 64; the eight accumulators of a k-step are independent
+  // 16 MFMAs: quadrant (A half H, B half HB) x K = 64; the eight accumulators of a k-step are independent.  The operands are
+  // SWAPPED (the instruction computes the transposed 16x16 block): a lane then holds FOUR CONSECUTIVE COLUMNS of one row of C
+  // (row = lane & 15, columns 4 * (lane >> 4) + reg), which go into the epilogue's window as one ds_write_b128 -- four ds_write_b32
+  // per fragment (the straight layout: 4 rows of one column) took 3 000 of the epilogue round's 5 900 cycles (profiles/r6_gemm_8phase.md)
 #define V8_MM(H, HB)                                                                                        \
   __builtin_amdgcn_sched_barrier(0);                                                                        \
   if (live_cur) {                                                                                           \
   _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                       \
   _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                          \
   _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                          \
-      acc[H][mi][HB][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi][ks_].v, fb[HB][ni][ks_].v, acc[H][mi][HB][ni], 0, 0, 0); \
+      acc[H][mi][HB][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[HB][ni][ks_].v, fa[mi][ks_].v, acc[H][mi][HB][ni], 0, 0, 0); \
   }                                                                                                         \
   __builtin_amdgcn_sched_barrier(0);                                                                        \
   __builtin_amdgcn_s_barrier();                                                                             \
@@ -2052,7 +2187,9 @@ __device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, cons
   const bool do_colsum = TN && G == 0 && p.colsum_out != nullptr && tile_n < cs_step;
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (AH == 2) {
   // ---- prologue: all of K-tile 0 and three half-tiles of K-tile 1 (7 half-tiles = 14 DMA instructions per wave)
+  V8_STAMP(0);
   bool live_cur = tile_live(0), live_n1 = tile_live(1), live_n2 = true;
   stage(0, 0, live_cur); stage(1, 0, live_cur); stage(2, 0, live_cur); stage(3, 0, live_cur);
   if constexpr (G == 1) gather_next();
@@ -2061,6 +2198,7 @@ __device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, cons
   if constexpr (G == 2) g2_advance();
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  V8_STAMP(1);
   if (wm == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first from here on
   __builtin_amdgcn_sched_barrier(0);
 
@@ -2127,6 +2265,48 @@ __device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, cons
     V8_MM(1, 0);
     live_cur = live_n1; live_n1 = live_n2;
   }
+  } else {
+  // ---- one A half: prologue = K-tiles 0 and 1 (6 half-tiles = 12 DMA instructions per wave)
+  V8_STAMP(0);
+  bool live_cur = true;
+  stage(0, 0, true, 0); stage(1, 0, true, 0); stage(2, 0, true, 0);
+  stage(0, 1, true, 1); stage(1, 1, true, 1); stage(2, 1, true, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  V8_STAMP(1);
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first from here on
+  __builtin_amdgcn_sched_barrier(0);
+  int bcur = 0, bnew = 2;  // buffers of tile t and of tile t+2
+#pragma nounroll
+  for (int t = 0; t < nk; ++t) {
+    const uint32_t bo = (uint32_t)bcur * BUF_B;
+    const uint32_t ra[4] = {fra[0] + bo, fra[1] + bo, 0u, 0u};
+    const uint32_t rb[2] = {frb[0] + bo, frb[1] + bo};
+    // -- phase 0: B0 + A0 -> quadrant (0, 0); B0 of tile t+2 goes where tile t-1's was (last read two phases ago)
+    V8_RD_B(0);
+    V8_RD_A(0);
+    if (t + 2 < nk) stage(0, t + 2, true, bnew);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" : V8_PIN_A, V8_PIN_B(0) : : "memory");
+    V8_MM(0, 0);
+    // -- phase 1: B1 -> quadrant (0, 1); B1 and A0 of tile t+2; the K-tile's one DMA wait: tile t+1 complete, tile t+2 in flight
+    V8_RD_B(1);
+    if (t + 2 < nk) {
+      stage(2, t + 2, true, bnew);
+      stage(1, t + 2, true, bnew);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" : V8_PIN_B(1) : : "memory");
+    V8_MM(0, 1);
+    bcur = bcur == 2 ? 0 : bcur + 1;
+    bnew = bnew == 2 ? 0 : bnew + 1;
+  }
+  }
   if (wm == 0) __builtin_amdgcn_s_barrier();  // re-join the wave rows
 #undef V8_FRAG_A
 #undef V8_FRAG_B
@@ -2136,6 +2316,7 @@ __device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, cons
 #undef V8_PIN_B
 #undef V8_MM
   __syncthreads();
+  V8_STAMP(2);
 
   float* sC = reinterpret_cast<float*>(smem8);
   if (do_colsum) {  // combine the 8 k-groups (waves) through LDS: 8 x 256 floats; column = (lane >> 5) * 128 + (lane & 31) * 4 + e
@@ -2152,43 +2333,95 @@ __device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, cons
     __syncthreads();
   }
 
-  // ---- epilogue: four rounds (A half h, m-fragment pair pr) through a [64][BN4+4] f32 window: window row wm*32 + mi2*16 + C/D row,
-  // i.e. tile row h*128 + (rl >> 5)*64 + pr*32 + (rl & 31); C/D layout of the 16x16 MFMA: column = lane & 15, row = 4*(lane >> 4) + reg
-  constexpr int LDS_C = BN4 + 4;
+  // ---- epilogue: four rounds (A half h, m-fragment pair pr) of 64 rows x 256 columns through an f32 window in LDS: window row
+  // wm*32 + mi2*16 + (lane & 15) = tile row h*128 + (rl >> 5)*64 + pr*32 + (rl & 31); a lane's four registers are columns
+  // 4*(lane >> 4) + 0..3 of the fragment (swapped operands, see V8_MM): one 16-byte LDS store per fragment.
   const bool fast = (p.vec_ok & 1) && !(p.N & 7) && n0 + BN4 <= p.N && !p.atomic;
-#pragma nounroll
-  for (int r = 0; r < 4; ++r) {
-    f32x4 tq[2][2][2];  // [mi2][hb][ni]; selected by a uniform switch: the accumulators are never indexed dynamically
 #define V8_PICK(H, M0)                                                                          \
   _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)   \
   _Pragma("unroll") for (int c = 0; c < 2; ++c) tq[a][b][c] = acc[H][M0 + a][b][c];
-    switch (r) {
-      case 0: V8_PICK(0, 0) break;
-      case 1: V8_PICK(0, 2) break;
-      case 2: V8_PICK(1, 0) break;
-      default: V8_PICK(1, 2) break;
-    }
-#undef V8_PICK
-    if (r) __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            sC[(wm * 32 + a * 16 + l4 * 4 + e) * LDS_C + b * 128 + wn * 32 + c * 16 + l15] = tq[a][b][c][e];
-    __syncthreads();
-    v4_round_out(p, sC, z, coff, m0, n0, (r >> 1) * 128 + (r & 1) * 32, fast, 64);
+#define V8_PICK_ROUND()                                                    \
+  switch (r) {                                                             \
+    case 0: V8_PICK(0, 0) break;                                           \
+    case 1: V8_PICK(0, 2) break;                                           \
+    default:                                                               \
+      if constexpr (AH == 2) {                                             \
+        if (r == 2) { V8_PICK(1, 0) } else { V8_PICK(1, 2) }               \
+      }                                                                    \
+      break;                                                               \
   }
+  if (fast) {
+    // full-width vector epilogue: TWO swizzled [64][256] windows (a round's writes go to the window the round before the previous one
+    // read: one barrier per round), v8_round_fast on top
+    float b8[8];
+    if (p.bias) ld8x(p.bias, n0 + (threadIdx.x & 31) * 8, MI_DT_F32, b8);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b8[j] = 0.f;
+    }
+#pragma nounroll
+    for (int r = 0; r < 2 * AH; ++r) {
+      f32x4 tq[2][2][2];  // [mi2][hb][ni]; selected by a uniform switch: the accumulators are never indexed dynamically
+      V8_PICK_ROUND()
+#if defined(V8_EPI_ABL) && V8_EPI_ABL == 1
+      asm volatile("" :: "v"(tq[0][0][0]), "v"(tq[0][0][1]), "v"(tq[0][1][0]), "v"(tq[0][1][1]), "v"(tq[1][0][0]), "v"(tq[1][0][1]), "v"(tq[1][1][0]), "v"(tq[1][1][1]));
+      continue;
+#endif
+      float* win = sC + (r & 1) * (64 * 256);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            *reinterpret_cast<f32x4*>(win + (wm * 32 + a * 16 + l15) * 256 + (((b * 32 + wn * 8 + c * 4 + l4) ^ (l15 & 7)) << 2)) = tq[a][b][c];
+#if defined(V8_EPI_ABL) && V8_EPI_ABL == 2
+      continue;
+#endif
+      __syncthreads();
+      const int mb = m0 + (r >> 1) * 128 + (r & 1) * 32;
+      switch (p.epi) {
+        case EPI_STORE: v8_round_fast<EPI_STORE>(p, win, b8, z, coff, mb, 64, n0); break;
+        case EPI_SWISH_DROP: v8_round_fast<EPI_SWISH_DROP>(p, win, b8, z, coff, mb, 64, n0); break;
+        case EPI_RESID: v8_round_fast<EPI_RESID>(p, win, b8, z, coff, mb, 64, n0); break;
+        case EPI_DSWISH: v8_round_fast<EPI_DSWISH>(p, win, b8, z, coff, mb, 64, n0); break;
+        case EPI_RELU_MASK: v8_round_fast<EPI_RELU_MASK>(p, win, b8, z, coff, mb, 64, n0); break;
+        default: v8_round_fast<EPI_MUL_POS>(p, win, b8, z, coff, mb, 64, n0); break;
+      }
+    }
+  } else {
+    // partial column tiles, unaligned or column-strided C, split-K atomics: the padded [64][260] window and round-out of the third structure
+    constexpr int LDS_C = BN4 + 4;
+#pragma nounroll
+    for (int r = 0; r < 2 * AH; ++r) {
+      f32x4 tq[2][2][2];
+      V8_PICK_ROUND()
+      if (r) __syncthreads();
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            *reinterpret_cast<f32x4*>(sC + (wm * 32 + a * 16 + l15) * LDS_C + b * 128 + wn * 32 + c * 16 + l4 * 4) = tq[a][b][c];
+      __syncthreads();
+      v4_round_out(p, sC, z, coff, m0, n0, (r >> 1) * 128 + (r & 1) * 32, false, 64);
+    }
+  }
+#undef V8_PICK_ROUND
+#undef V8_PICK
+#ifdef V8_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stores have left the CU)
+  __syncthreads();
+  V8_STAMP(3);
+#endif
 }
 
-template <int G, bool TN>
+template <int G, bool TN, int AH = 2>
 __global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
   drop_resolve(p.drop);
-  extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];  // 2 K-tiles x 4 half-tile images x 16 KiB
-  const int tn = (p.N + BN4 - 1) / BN4, tm = (p.M + BM2 - 1) / BM2;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];  // 2 K-tiles x 4 half-tile images x 16 KiB (AH = 1: 3 x 3 x 16 KiB)
+  const int tn = (p.N + BN4 - 1) / BN4, tm = (p.M + 128 * AH - 1) / (128 * AH);
   const int ntiles = tm * tn;
   int logical, z, ks;
   if constexpr (G == 2) {
@@ -2219,7 +2452,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_v8_kernel(GemmP p) {
   const int cb = logical / per_cb, rem = logical - cb * per_cb;
   const int w8 = min(8, tn - cb * 8);
   const int tile_m = rem / w8, tile_n = cb * 8 + (rem - tile_m * w8);
-  gemm_v8_body<G, TN>(p, smem8, tile_m, tile_n, ks, z);
+  // Phase offset between two halves of the chip (short-K problems with more than one round of tiles): all 256 workgroups of a round
+  // otherwise finish their K loops together and write their tiles together -- the fabric takes a 33-65 MB burst at ~4.5 TB/s while
+  // every matrix pipe idles, then idles itself through the next K loops (timeline: profiles/r6_gemm_8phase.md).  Every other group
+  // of 8 first-round workgroups starts `v8_delay` ticks late, so that one half multiplies while the other half writes.
+  if (p.v8_delay > 0 && blockIdx.x < 256 && (blockIdx.x & 8)) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)p.v8_delay) __builtin_amdgcn_s_sleep(16);
+  }
+  gemm_v8_body<G, TN, AH>(p, smem8, tile_m, tile_n, ks, z);
 }
 
 // ---- grouped weight gradients on the eighth structure: the problems' 256x256 tiles x K slices in one launch, (problem, K slice)
@@ -2248,7 +2489,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_grouped_tn8_kernel(GroupP g) {
   p.row_len = nullptr; p.rows_per_b = 1; p.rows_inner = 1;
   p.splitk = g.splitk; p.ktiles_per_split = g.ktiles_per_split;
   p.colsum_stride = 0; p.colsum_out = g.colsum[pi];
-  p.vec_ok = 0; p.g_on = 0; p.r_on = 0;
+  p.vec_ok = 0; p.g_on = 0; p.r_on = 0; p.v8_delay = 0;
   const int tn = (p.N + BN4 - 1) / BN4;
   gemm_v8_body<0, true>(p, smem8, exp_tile / tn, exp_tile % tn, exp_ks, 0);
 }
@@ -2752,13 +2993,14 @@ static int env_int(const char* name, int dflt) {
 // prefetch instead of LDS-DMA inside the 256x256 structure (MI355X_GEMM_V6: 0 = default / 1), key 7 = the same inside the 256x128
 // structure (MI355X_GEMM_V7, default 1), key 3 = fp32 problems on the matrix cores (MI355X_F32_MFMA, default 1; 0 = vector unit).  Defaults follow the in-step A/B (tools/step_ab.py, recorded graphs, same box): the
 // 256x128 variant -0.2 ms per step, the 256x256 variant +0.3 ms although it wins every isolated launch (profiles/r3_gemm_structures.md)
-static std::atomic<int> g_mode[9] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static std::atomic<int> g_mode[10] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 static int mode_now(int key) {
   int v = g_mode[key].load(std::memory_order_relaxed);
   if (v < 0) {
     static const int env4 = env_int("MI355X_GEMM_V4", 1), env5 = env_int("MI355X_GEMM_V5", 1), env6 = env_int("MI355X_GEMM_V6", 0),
-                     env7 = env_int("MI355X_GEMM_V7", 1), env3 = env_int("MI355X_F32_MFMA", 1), env8 = env_int("MI355X_GEMM_V8", 1);
-    const int from_env = key == 4 ? env4 : key == 5 ? env5 : key == 6 ? env6 : key == 7 ? env7 : key == 3 ? env3 : key == 8 ? env8 : 0;
+                     env7 = env_int("MI355X_GEMM_V7", 1), env3 = env_int("MI355X_F32_MFMA", 1), env8 = env_int("MI355X_GEMM_V8", 1),
+                     env9 = env_int("MI355X_GEMM_V8_DELAY", 0);
+    const int from_env = key == 4 ? env4 : key == 5 ? env5 : key == 6 ? env6 : key == 7 ? env7 : key == 3 ? env3 : key == 8 ? env8 : key == 9 ? env9 : 0;
     int expected = -1;
     g_mode[key].compare_exchange_strong(expected, from_env, std::memory_order_relaxed);
     v = g_mode[key].load(std::memory_order_relaxed);
@@ -2767,7 +3009,7 @@ static int mode_now(int key) {
 }
 static int v5_mode_now() { return mode_now(5); }
 extern "C" int mi355x_gemm_config(int key, int value) {
-  if (key < 3 || key > 8) return -1;
+  if (key < 3 || key > 9) return -1;
   return g_mode[key].exchange(value, std::memory_order_relaxed);
 }
 
@@ -2793,7 +3035,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   p.ldaux = d->ldaux;
   p.drop = mi_drop(d->drop_key, d->drop_threshold, d->drop_scale);
   p.colsum_out = (float*)d->colsum_out; p.colsum_stride = d->colsum_stride;
-  p.g_on = 0; p.r_on = 0;
+  p.g_on = 0; p.r_on = 0; p.v8_delay = 0;
   if (d->gather) {
     const mi355x_conv_gather& g = *d->gather;
     if (d->in_dtype != MI_DT_BF16 || g.C <= 0 || (g.C & 7) || g.ntaps < 1 || g.ntaps > 9 || g.nI <= 0 || g.nJ <= 0 ||
@@ -2891,7 +3133,7 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
       dim3 grid2(tm2 * tn, sk, p.batch);
       // phase-staggered 256x256 structure on 16x16x32 MFMAs (key 8 / MI355X_GEMM_V8: 0 = never, 1 = where it measured faster, 2 = every
       // shape it can run; 3 = as 1 plus the weight-gradient (TN) layouts, 4 = as 1 plus the wide plain stores the persistent
-      // structure otherwise takes -- A/B arms).  NT: K-contiguous operands, whole K-tiles; TN: both operands reduction-major (K tail
+      // structure otherwise takes, 5 = as 1 plus the 128x256 tile where 256x256 tiles do not fill the chip and K >= 768 -- A/B arms).  NT: K-contiguous operands, whole K-tiles; TN: both operands reduction-major (K tail
       // allowed); at least two K-tiles per workgroup, 32-bit operand offsets.
       // The TN layouts are correct on it but SLOWER than on the lock-step structures (conv2 weight gradient 2.54 vs 2.02 ms, a layer's
       // grouped weight gradients 307 vs 286 us, profiles/r6_gemm_8phase.md): a fragment is two ds_read_b64_tr_b16, and the 8-byte
@@ -2917,10 +3159,28 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
         const double eff2_ = (double)blocks2_ / (double)(((blocks2_ + 255) / 256) * 256);
         // the rule of the third structure: the larger tile still fills the chip, few padded columns, no worse wave quantisation
         const bool fills = blocks8 >= 224 && (long long)tn8 * BN4 * 8 <= (long long)p.N * 9 && eff8 >= 0.9 * eff2_;
-        // (plain stores at least 1536 columns wide with K <= 576 stay on the persistent structure: 40.3 vs 41.4 us on the QKV shape)
+        // (plain stores at least 1536 columns wide with K <= 576 stay on the persistent structure where the 256x256 tiles quantise
+        //  badly: 40.3 vs 41.4 us on the QKV shape, 378 tiles = 1.48 rounds; N = 2048 -- 504 tiles -- is 44.7 vs 53.6 us the other way)
         const bool v5_keeps = nt8 && !p.g_on && p.epi == EPI_STORE && p.N >= 1536 && nk >= 8 && nk <= 9 && !p.atomic && sk == 1 &&
-                              !(p.N % BN) && v5_mode_now() && v8_mode != 4;
+                              !(p.N % BN) && v5_mode_now() && v8_mode != 4 && eff8 < 0.85;
         const bool v8_pick = v8_mode == 2 || (v8_mode >= 1 && fills && !v5_keeps && (nt8 || v8_mode == 3));
+        // the 128x256 tile of the same structure (modes 2 and 5): dense NT problems whose 256x256 tiles would leave the chip
+        // half empty but whose 128x256 tiles fill it (N = 512 at M = 16032: 126 -> 252 workgroups)
+        {
+          const long long blocks1 = (long long)((p.M + 127) / 128) * tn8 * sk * p.batch;
+          const double eff1 = (double)blocks1 / (double)(((blocks1 + 255) / 256) * 256);
+          const bool fills1 = blocks1 >= 224 && (long long)tn8 * BN4 * 8 <= (long long)p.N * 9 && eff1 >= 0.9 * eff2_;
+          // (K >= 768: at K = 512 -- the 512 x 512 projections -- the persistent / 256x128 structures are ahead, 23.6 vs 24.6 us)
+          // Isolated it wins 3-6 % over the 256x128 lock-step structure (FFN2 forward 36.2 -> 34.1 us); INSIDE the training step it
+          // loses 0.16 ms (36.50 vs 36.66 ms, same box, interleaved) -- not in the default set.
+          if (v8_can && nt8 && !p.g_on && !fills && fills1 && ((v8_mode == 5 && nk >= 12) || (v8_mode == 2 && blocks8 < 224))) {
+            static const bool attr81_ok = hipFuncSetAttribute((const void*)gemm_bf16_v8_kernel<0, false, 1>,
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 9 * V8_HALF_B) == hipSuccess;
+            if (!attr81_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
+            MI_LAUNCH((gemm_bf16_v8_kernel<0, false, 1>), dim3(((p.M + 127) / 128) * tn8, sk, p.batch), dim3(512), 9 * V8_HALF_B, s, p);
+            return mi_check_launch();
+          }
+        }
         if (v8_can && v8_pick) {
           typedef void (*v8_fn)(GemmP);
           static const v8_fn v8_all[] = {gemm_bf16_v8_kernel<0, false>, gemm_bf16_v8_kernel<1, false>, gemm_bf16_v8_kernel<0, true>,
@@ -2932,6 +3192,8 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
           }();
           if (!attr8_ok) { (void)hipGetLastError(); return MI_ERR_LAUNCH; }
           const v8_fn fn = nt8 ? v8_all[p.g_on == 1 ? 1 : 0] : v8_all[p.g_on == 2 ? 3 : 2];
+          // key 9: the phase offset (10-ns ticks; > 0: that many for every problem of more than one round and at most 16 K-tiles)
+          if (nt8 && blocks8 > 256 && nk <= 16) p.v8_delay = mode_now(9);
           MI_LAUNCH(fn, dim3(tm2 * tn8, sk, p.batch), dim3(512), 2 * V8_BUF_B, s, p);
           return mi_check_launch();
         }

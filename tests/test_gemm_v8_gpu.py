@@ -90,6 +90,43 @@ def test_phase_staggered_structure_is_bit_identical_to_the_lock_step_one(M, N, K
             assert rel_l2(got[0], ref) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(16032, 512, 2048), (16032, 512, 512), (9000, 768, 1024), (8100, 520, 192)])
+def test_one_a_half_tile_of_the_phase_staggered_structure(M, N, K):
+    """the 128x256 tile (one A half, three K-tile buffers, two phases per K-tile; key 8 mode 2 forces it): problems whose 256x256 tiles leave
+    the chip half empty.  Bit-identical to the 256x128 lock-step structure (same products, same k order), four epilogues, odd K-tile
+    counts, ragged M / N, three launches each."""
+    o = ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.rand(M, K, generator=g) * 2 - 1).to(bf16).to(dev)
+    W = ((torch.rand(N, K, generator=g) * 2 - 1) * 0.05).to(bf16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    drop = o.Dropout(0.1, 3, 9)
+
+    def run(kind):
+        if kind == "store":
+            c = torch.empty(M, N, device=dev, dtype=bf16)
+            o.gemm(A, W, c, M, N, K, K, K, N, bias=bias)
+            return c
+        if kind == "store_f32":
+            c = torch.full((M, N), float("nan"), device=dev)
+            o.gemm(A, W, c, M, N, K, K, K, N, bias=bias, alpha=0.5, drop=drop)
+            return c
+        c = torch.empty(M, N, device=dev)
+        o.gemm(A, W, c, M, N, K, K, K, N, bias=bias, alpha=0.5, epi=o.EPI_RESID, aux_in=res, drop=drop)
+        return c
+
+    for kind in ("store", "store_f32", "resid"):
+        with _modes(k8=0, k4=0, k5=0, k7=0):   # the 256x128 lock-step structure (LDS-DMA K loop)
+            want = run(kind)
+        with _modes(k8=2, k5=0):
+            for rep in range(3):
+                got = run(kind)
+                torch.cuda.synchronize()
+                assert torch.equal(want, got), (kind, rep, (want.float() - got.float()).abs().max().item())
+    assert rel_l2(run("store").float(), (A.float() @ W.float().t() + bias)) < 5e-3
+
+
 def test_phase_staggered_structure_split_k_slices_and_batches():
     """NT with atomic split-K (every slice >= 2 K-tiles, uneven last slice) and a strided batch: against the fp32 product"""
     o = ops()

@@ -170,6 +170,8 @@ def bench():
     only = os.environ.get("ONLY")
     # arms: the shipped dispatch with key 8 off, and the new structure forced wherever it can run
     arms = [("old", dict(v8=0)), ("v8", dict(v8=2))]
+    if os.environ.get("ARMS") == "half":   # the 128x256 tile where 256x256 tiles do not fill the chip
+        arms = [("old", dict(v8=0)), ("v8+half", dict(v8=5))]
     if os.environ.get("ARMS") == "all":
         arms = [("old", dict(v8=0)), ("v4", dict(v8=0, v4=2, v5=0, v6=0)), ("v6", dict(v8=0, v4=2, v5=0, v6=1)), ("v8", dict(v8=2))]
     for name, M_, N_, K_, epi in cases:
