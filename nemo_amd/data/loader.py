@@ -37,7 +37,12 @@ class _Slot:
 
 
 class DeviceBatchLoader:
-    def __init__(self, batches: Iterable, device, prefetch: int = 2):
+    def __init__(self, batches: Iterable, device, prefetch: int = 2, length_fields=(1,)):
+        """length_fields: positions in a batch tuple whose host copy travels with the device tensor (`.host_lengths`): the AUDIO length
+        vector of the (audio, audio_len, tokens, token_len) batches of this package.  Only these are tagged -- the encoder takes
+        a tagged length vector as permission to size a packed launch sequence from the host copy, which pre-empts recorded
+        launch sequences; token ids / token lengths must not trigger that."""
+        self.length_fields = tuple(length_fields)
         self.batches = batches
         self.device = torch.device(device)
         self.prefetch = max(1, prefetch)
@@ -71,7 +76,7 @@ class DeviceBatchLoader:
                     for i, t in enumerate(batch):
                         if torch.is_tensor(t):
                             dt_ = slot.stage(i, t).to(self.device, non_blocking=True)
-                            if t.dim() == 1 and not t.is_floating_point() and t.numel() <= 4096:
+                            if i in self.length_fields and t.dim() == 1 and not t.is_floating_point() and t.numel() <= 4096:
                                 # length vectors keep a host copy with them: the encoder sizes a PACKED launch sequence (the valid
                                 # frames of a ragged batch only, ConformerEncoder._packing_plan) from it without a device read-back
                                 dt_.host_lengths = t.detach().clone()

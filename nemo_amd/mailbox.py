@@ -47,13 +47,24 @@ class StatsMailbox:
         # Do all ranks sit on ONE physical device (the two-ranks-on-one-GPU rehearsals)?  Only then may the second attempt fall
         # back to plain coarse-grained hipMalloc memory: across devices a peer's xGMI stores into coarse-grained memory are not
         # guaranteed visible to a kernel already running against its XCD's L2, whatever the scope of the atomics.
+        # Both the UUID and the (host, device index, PCI bus id) must agree: a runtime may hand out one UUID string for distinct
+        # devices (bench.py stopped trusting UUIDs alone for that reason), and the fallback is unsafe across devices -- fail closed.
         uuid = [0] * 16
+        where = [0] * 8
         if have_gpu:
             try:
-                uuid = list(torch.cuda.get_device_properties(device).uuid.bytes)
-            except Exception:  # noqa: BLE001 -- no uuid on this build: treat every rank as its own device
+                props = torch.cuda.get_device_properties(device)
+                uuid = list(props.uuid.bytes)
+                import socket
+                import zlib
+                idx = device.index if device.index is not None else torch.cuda.current_device()
+                bus = (int(getattr(props, "pci_domain_id", 0)), int(getattr(props, "pci_bus_id", -1 - rank)),
+                       int(getattr(props, "pci_device_id", 0)))
+                where = [zlib.crc32(socket.gethostname().encode()) & 0x7FFFFFFF, idx, *bus, 0, 0, 0]
+            except Exception:  # noqa: BLE001 -- no identity on this build: treat every rank as its own device
                 uuid = [rank + 1] * 16
-        mine_u = torch.tensor(uuid, dtype=torch.int32)
+                where = [rank + 1] * 8
+        mine_u = torch.tensor(uuid + where, dtype=torch.int32)
         if not on_host:
             mine_u = mine_u.to(device)
         all_u = [torch.empty_like(mine_u) for _ in range(world)]

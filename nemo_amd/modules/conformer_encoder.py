@@ -452,7 +452,8 @@ class ConformerEncoder(NeuralModule):
         return t[:n].view(shape)
 
     def _plan(self, cdt, device):
-        key = (cdt, str(device), self._flatp.generation)
+        # (the geometry -- head width of the packed attention images -- follows run-time flags: use_flash_attention, flash_pad_heads)
+        key = (cdt, str(device), self._flatp.generation, self._geometry(cdt))
         plan = self._plans.get(key)
         if plan is None:
             self._plans = {}  # parameters moved: drop images of the old storage
@@ -586,6 +587,12 @@ class ConformerEncoder(NeuralModule):
             return None
         if self._packing_plan(length, mel.shape[0], mel.shape[2], peek=True) is not None:
             self.live_steps += 1
+            if not getattr(self, "_packed_over_graphs_noted", False) and self.packed_rows == "auto":
+                self._packed_over_graphs_noted = True
+                import logging
+                logging.getLogger(__name__).info(
+                    "ConformerEncoder: packed rows (packed_rows='auto', host lengths attached to the length tensor) pre-empt recorded "
+                    "launch sequences for ragged batches; set encoder.packed_rows = False to keep the replay path")
             return None  # packed rows: the row count changes with every batch, a recorded sequence holds one shape
         key = self._graph_key(mel, length)
         gs = self._graph_sets.get(key)
@@ -1649,6 +1656,11 @@ class ConformerEncoder(NeuralModule):
             self._wgrad_join(consume=True)
             self._pos_proj_wgrad(S.dp_all, S.pos, P, cdt)
         if self.grad_ready_hook is not None:
+            if self.posproj_side and self._wgrad_join_per_layer:
+                # the tail range holds the linear_pos weight gradients, which the side stream is still writing: a hook consumer
+                # that does not itself wait on the weight-gradient stream (a custom hook, GradSync without producer_streams) must
+                # not see the range before they landed -- the same join the per-layer hooks get (layer_done)
+                self._wgrad_join(consume=True)
             self._hook(*fp.tail_range())
         # ---- sub-sampling backward
         pe = self.pre_encode

@@ -238,7 +238,8 @@ class SqueezeformerEncoder(ConformerEncoder):
         return io
 
     def _plan(self, cdt, device):
-        key = (cdt, str(device), self._flatp.generation)
+        # (the geometry -- head width of the packed attention images -- follows run-time flags: use_flash_attention, flash_pad_heads)
+        key = (cdt, str(device), self._flatp.generation, self._geometry(cdt))
         plan = self._plans.get(key)
         if plan is None:
             self._plans = {}
