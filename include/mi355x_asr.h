@@ -282,6 +282,12 @@ int mi355x_add2_colsum(const void* a, const void* b, void* out, long long ldo, l
 int mi355x_relpos_softmax_fwd(const void* ac, const void* bdf, void* s_out, void* pd_out, int out_dtype, const void* len,
                               int H, int B, int T, int Tp, int Pp, float scale, unsigned drop_key, unsigned drop_threshold,
                               float drop_scale, void* stream);
+/* The same with a limited attention context (ConformerEncoder att_context_size = [left, right], att_context_style;
+ * /root/reference/nemo/collections/asr/modules/conformer_encoder.py:794-823): ctx_style 0 = unlimited, 1 = 'regular', 2 =
+ * 'chunked_limited'; a key outside the query's window is masked exactly like a padded one (multi_head_attention.py:137-146). */
+int mi355x_relpos_softmax_fwd_ctx(const void* ac, const void* bdf, void* s_out, void* pd_out, int out_dtype, const void* len, int H,
+                                  int B, int T, int Tp, int Pp, float scale, unsigned drop_key, unsigned drop_threshold,
+                                  float drop_scale, int ctx_style, int ctx_left, int ctx_right, void* stream);
 int mi355x_relpos_softmax_bwd(const void* dpd, int dpd_dtype, const void* s_in, void* dscore, void* dbdf, int s_dtype, int H,
                               int B, int T, int Tp, int Pp, float scale, unsigned drop_key, unsigned drop_threshold,
                               float drop_scale, void* stream);

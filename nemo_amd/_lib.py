@@ -118,6 +118,7 @@ SIGNATURES = {
     "mi355x_specaug_rects": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp],
     "mi355x_add2_colsum": [vp, vp, vp, i64, i64, i32, vp, vp, i64, vp],
     "mi355x_relpos_softmax_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
+    "mi355x_relpos_softmax_fwd_ctx": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, i32, i32, i32, vp],
     "mi355x_relpos_softmax_bwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp],
     "mi355x_relpos_flash_fwd": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32, u32, u32, f32, vp, vp],
     "mi355x_attn_delta": [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],

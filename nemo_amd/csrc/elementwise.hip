@@ -150,11 +150,26 @@ __global__ __launch_bounds__(256) void add2_kernel(const TI* __restrict__ a, con
 //   score[j] = (ac[j] + bdf[T-1+j-i]) * scale ; masked (i or j beyond len[b]) -> -10000 ; softmax ; masked -> 0
 // s (pre-dropout, kept for backward) and pd = dropout(s) are written with pitch Tp, pad columns zeroed.
 #define SM_MAXV 16  // supports T <= 64*16 = 1024 frames after subsampling (40 s of audio)
+// Limited attention context (ConformerEncoder._create_masks, conformer_encoder.py:794-823; att_context_size = [left, right]):
+// style 1 'regular': -left <= j - i <= right (each side only if >= 0); style 2 'chunked_limited': the keys of the query's own chunk
+// (chunk = right + 1 frames) and of the left / chunk chunks before it -- with right == -1 the left-limited regular mask.  A key
+// outside the window is treated exactly like a padded one: score -10000 into the softmax, probability 0 out of it
+// (multi_head_attention.py:137-146).
+__device__ __forceinline__ bool ctx_allows(int style, int left, int right, int i, int j) {
+  if (style == 1) return (left < 0 || j - i >= -left) && (right < 0 || j - i <= right);
+  if (style == 2) {
+    if (right < 0) return left < 0 || j - i >= -left;
+    const int chunk = right + 1, dc = i / chunk - j / chunk;
+    return dc >= 0 && dc <= (left >= 0 ? left / chunk : 10000);
+  }
+  return true;
+}
 template <typename TO>
 __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __restrict__ ac, const float* __restrict__ bdf,
                                                                  TO* __restrict__ s_out, TO* __restrict__ pd_out,
                                                                  const long long* __restrict__ len, int H, int B, int T, int Tp,
-                                                                 int Pp, float scale, DropCfg drop) {
+                                                                 int Pp, float scale, DropCfg drop, int ctx_style, int ctx_left,
+                                                                 int ctx_right) {
   drop_resolve(drop);
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
@@ -171,7 +186,7 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
   for (int k = 0; k < SM_MAXV; ++k) {
     const int j = lane + k * 64;
     float sc = -INFINITY;
-    if (j < T) sc = (row_valid && j < L) ? (acr[j] + bdr[j]) * scale : -10000.f;
+    if (j < T) sc = (row_valid && j < L && ctx_allows(ctx_style, ctx_left, ctx_right, i, j)) ? (acr[j] + bdr[j]) * scale : -10000.f;
     v[k] = sc;
     mx = fmaxf(mx, sc);
   }
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
   for (int k = 0; k < SM_MAXV; ++k) {
     const int j = lane + k * 64;
     if (j < Tp) {
-      float p = (j < T && row_valid && j < L) ? v[k] * inv : 0.f;
+      float p = (j < T && row_valid && j < L && ctx_allows(ctx_style, ctx_left, ctx_right, i, j)) ? v[k] * inv : 0.f;
       st(s_out + row * Tp + j, p);
       if (pd_out) st(pd_out + row * Tp + j, p * drop_mask(drop, (uint32_t)(row * Tp + j)));
     }
@@ -366,19 +381,27 @@ extern "C" int mi355x_add2(const void* a, const void* b, int in_dt, void* out, i
                        (TO*)out, ldo, M, d)));
   return mi_check_launch();
 }
-extern "C" int mi355x_relpos_softmax_fwd(const void* ac, const void* bdf, void* s_out, void* pd_out, int out_dt, const void* len,
-                                         int H, int B, int T, int Tp, int Pp, float scale, unsigned drop_key,
-                                         unsigned drop_threshold, float drop_scale, void* stream) {
+extern "C" int mi355x_relpos_softmax_fwd_ctx(const void* ac, const void* bdf, void* s_out, void* pd_out, int out_dt, const void* len,
+                                             int H, int B, int T, int Tp, int Pp, float scale, unsigned drop_key,
+                                             unsigned drop_threshold, float drop_scale, int ctx_style, int ctx_left, int ctx_right,
+                                             void* stream) {
   mi_clear_errors();
   if (!ac || !bdf || !s_out || !len || T <= 0 || T > 64 * SM_MAXV || Tp < T || Tp > 64 * SM_MAXV || Pp < 2 * T - 1)
     return MI_ERR_ARG;
+  if (ctx_style < 0 || ctx_style > 2 || ctx_left < -1 || ctx_right < -1) return MI_ERR_ARG;
   DropCfg dc = mi_drop(drop_key, drop_threshold, drop_scale);
   const long long rows = (long long)H * B * T;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_DT(out_dt, TO, MI_LAUNCH((relpos_softmax_fwd_kernel<TO>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
                                              (const float*)ac, (const float*)bdf, (TO*)s_out, (TO*)pd_out,
-                                             (const long long*)len, H, B, T, Tp, Pp, scale, dc));
+                                             (const long long*)len, H, B, T, Tp, Pp, scale, dc, ctx_style, ctx_left, ctx_right));
   return mi_check_launch();
+}
+extern "C" int mi355x_relpos_softmax_fwd(const void* ac, const void* bdf, void* s_out, void* pd_out, int out_dt, const void* len,
+                                         int H, int B, int T, int Tp, int Pp, float scale, unsigned drop_key,
+                                         unsigned drop_threshold, float drop_scale, void* stream) {
+  return mi355x_relpos_softmax_fwd_ctx(ac, bdf, s_out, pd_out, out_dt, len, H, B, T, Tp, Pp, scale, drop_key, drop_threshold,
+                                       drop_scale, 0, -1, -1, stream);
 }
 extern "C" int mi355x_relpos_softmax_bwd(const void* dpd, int dpd_dt, const void* s_in, void* dscore, void* dbdf, int s_dt, int H,
                                          int B, int T, int Tp, int Pp, float scale, unsigned drop_key, unsigned drop_threshold,

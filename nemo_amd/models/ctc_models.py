@@ -54,10 +54,16 @@ class EncDecCTCModel(nn.Module):
                             reduction=cfg.get("ctc_reduction", "mean_batch"))
         sa = cfg.get("spec_augment")  # ctc_models.py:86-89
         self.spec_augmentation = _build("spec_augment", sa) if sa else None
-        self._check_interctc(cfg.get("interctc"))
-        if cfg.get("skip_nan_grad"):
-            # modelPT.py on_after_backward: all-reduce an "is finite" flag over the ranks and zero the gradients of a step with NaN / Inf
-            raise NotImplementedError("skip_nan_grad: true is not implemented by the MI355X training path (the recipes ship it false)")
+        self._interctc = self._check_interctc(cfg.get("interctc"))
+        if self._interctc is not None:
+            bad_l = [l for l in self._interctc[1] if not (0 <= int(l) < len(self.encoder.layers))]
+            if bad_l:
+                raise ValueError(f"interctc.apply_at_layers {bad_l}: the encoder has {len(self.encoder.layers)} layers")
+            self.encoder.capture_layers = [int(l) for l in self._interctc[1]]
+        # skip_nan_grad (models/asr_model.py:147-174 on_after_backward): a step whose gradients hold NaN / Inf on ANY rank is skipped --
+        # the gradients are zeroed everywhere.  The check needs the whole gradient, so the optimizer slices do not run inside backward.
+        self._skip_nan_grad = bool(cfg.get("skip_nan_grad"))
+        self.skipped_steps = 0
         self._optimizer: Optional[FusedAdamW] = None
         self._scheduler: Optional[NoamAnnealing] = None
         self._syncs = None
@@ -79,12 +85,9 @@ class EncDecCTCModel(nn.Module):
     @staticmethod
     def _check_interctc(ic):
         """`interctc: {loss_weights: [...], apply_at_layers: [...]}` (ctc_models.py:115, parts/mixins/interctc_mixin.py:46-73).  The
-        recipes ship it empty (= off).  A non-empty section changes the training loss -- (1 - sum w) * final + sum w_l * CTC(decoder(
-        layer l output)) -- so it must never be ignored silently: the reference's own validation first (same ValueErrors), then a
-        loud NotImplementedError (the loss assembly is restated and pinned in oracle/conformer_ref.py `model_forward(interctc=...)`;
-        the MI355X backward sequencer does not inject intermediate-layer gradients yet)."""
+        recipes ship it empty (= off).  The reference's own validation (same ValueErrors); -> (weights, layers) or None."""
         if not ic:
-            return
+            return None
         weights, layers = list(ic.get("loss_weights") or []), list(ic.get("apply_at_layers") or [])
         if 1.0 - sum(weights) <= 0.0:
             raise ValueError("Make sure that sum of intermediate loss weights is < 1.0. Note that we don't do any normalization and "
@@ -92,9 +95,26 @@ class EncDecCTCModel(nn.Module):
                              "loss will have weight of 0.6")
         if len(layers) != len(weights):
             raise ValueError("Length of interctc.apply_at_layers has to match interctc.loss_weights")
-        if weights:
-            raise NotImplementedError("interctc.loss_weights is set: intermediate CTC losses are not implemented by the MI355X "
-                                      "training path (leave interctc.loss_weights / apply_at_layers empty, as the recipes do)")
+        return (weights, layers) if weights else None
+
+    def add_interctc_losses(self, loss_value, transcript, transcript_len, encoded_len):
+        """InterCTC (parts/mixins/interctc_mixin.py:214-270, ctc_models.py:577-585): the SAME decoder and CTC loss on the outputs the
+        encoder captured at `apply_at_layers` (ConformerEncoder.captured, conformer_encoder.py:724-736);
+        loss = (1 - sum w) * final + sum_l w_l * CTC(decoder(layer l output)).  -> (loss, metrics)"""
+        if self._interctc is None:
+            return loss_value, {}
+        weights, layers = self._interctc
+        metrics = {"final_loss": loss_value.detach()}
+        loss_value = loss_value * (1.0 - sum(weights))
+        for l, w in zip(layers, weights):
+            cap = self.encoder.captured.get(int(l))
+            if cap is None:
+                raise RuntimeError(f"InterCTC: the encoder did not capture the output of layer {l}")
+            inter = self.loss(log_probs=self.decoder(encoder_output=cap), targets=transcript, input_lengths=encoded_len,
+                              target_lengths=transcript_len)
+            metrics[f"inter_ctc_loss_l{l}"] = inter.detach()
+            loss_value = loss_value + inter * w
+        return loss_value, metrics
 
     @property
     def world_size(self) -> int:
@@ -126,7 +146,8 @@ class EncDecCTCModel(nn.Module):
         log_probs, encoded_len, predictions = self.forward(input_signal=signal, input_signal_length=signal_len)
         loss_value = self.loss(log_probs=log_probs, targets=transcript, input_lengths=encoded_len,
                                target_lengths=transcript_len)
-        logs = {"train_loss": loss_value.detach(), "global_step": self.global_step}
+        loss_value, inter_logs = self.add_interctc_losses(loss_value, transcript, transcript_len, encoded_len)
+        logs = {"train_loss": loss_value.detach(), "global_step": self.global_step, **inter_logs}
         if self._scheduler is not None:
             logs["learning_rate"] = self._scheduler.get_last_lr()
         n = self._log_every_n_steps()
@@ -399,6 +420,8 @@ class EncDecCTCModel(nn.Module):
         lr = self._scheduler.get_last_lr() if self._scheduler is not None else None
         scale = syncs[0].grad_scale if syncs else 1.0 / self.world_size  # (1 when the buckets travel pre-scaled as bf16)
         use_early = (not syncs) if self.optimizer_in_backward is None else bool(self.optimizer_in_backward)
+        if self._skip_nan_grad:
+            use_early = False
         early = use_early and self._optimizer.begin_step(lr=lr, grad_scale=scale)
         if early:  # slices of the flat buffers are updated as soon as their gradients are final (and reduced)
             self._install_early_step(syncs)
@@ -409,7 +432,10 @@ class EncDecCTCModel(nn.Module):
         self._after_backward()
         for gs in syncs:
             gs.wait()
-        if early:
+        skip = self._skip_nan_grad and not self.on_after_backward()
+        if skip:
+            pass  # (the reference's zero_grad() leaves every .grad None: its optimizer.step() then touches no parameter and no moment)
+        elif early:
             if not syncs:
                 self.encoder._wgrad_join()  # the last slices were updated on the weight-gradient stream
             self._optimizer.finish_step()
@@ -427,6 +453,28 @@ class EncDecCTCModel(nn.Module):
 
     def _after_backward(self):
         """streams other than the current one that produced gradients are joined here (none in the CTC model)"""
+
+    def on_after_backward(self):
+        """models/asr_model.py:147-174: zero the gradients of a step if any of them (on any rank) holds NaN / Inf.  -> True when the
+        gradients are valid; False = the step is skipped (fit_step does not run the optimizer: the reference's zero_grad() sets every
+        .grad to None, which torch's optimizers skip -- parameters and moments stay as they are)"""
+        enc = self.encoder
+        if hasattr(enc, "_wgrad_join"):
+            enc._wgrad_join()  # the weight-gradient stream has written its last gradients
+        flats = self.flats()
+        ok = torch.ones(1, device=flats[0].grad.device, dtype=torch.float32)
+        for fp in flats:
+            ok = ok * torch.isfinite(fp.grad).all().to(torch.float32)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            import logging
+            logging.getLogger(__name__).warning("detected inf or nan values in gradients! Setting gradients to zero.")
+            for fp in flats:
+                fp.zero_grad()
+            self.skipped_steps += 1
+            return False
+        return True
 
     def _install_early_step(self, syncs):
         opt = self._optimizer

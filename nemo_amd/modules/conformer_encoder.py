@@ -148,19 +148,24 @@ class _EncoderFn(torch.autograd.Function):
         ctx.module, ctx.saved, ctx.gset = module, None, None
         res = module._graphed_forward(mel, length)  # None: this call runs eagerly (warm-up, unstable shapes, graphs off)
         ctx.timed_gs = module._cur_gs
+        caps = ()
         if res is not None:
             out, enc_len, ctx.gset, ctx.gen = res
         else:
             out, enc_len, ctx.saved = module._forward_impl(mel, length, save=True)
+            caps = tuple(getattr(ctx.saved, "cap_out", ())) if ctx.saved is not None else ()
         ctx.mark_non_differentiable(enc_len)
-        return out, enc_len
+        return (out, enc_len) + caps   # (+ the InterCTC captures, differentiable)
 
     @staticmethod
-    def backward(ctx, dout, _):
+    def backward(ctx, dout, _, *dcaps):
         if ctx.gset is not None:
             ctx.module._graphed_backward(ctx.gset, ctx.gen, dout)
         else:
-            ctx.module._backward_impl(ctx.saved, dout)
+            if dcaps:
+                ctx.module._backward_impl(ctx.saved, dout, dcaps)
+            else:
+                ctx.module._backward_impl(ctx.saved, dout)
         ctx.module._auto_end(ctx.timed_gs)
         ctx.saved = None
         return None, None, None, None
@@ -218,14 +223,11 @@ class ConformerEncoder(NeuralModule):
             bad.append(f"subsampling={subsampling} x{subsampling_factor} (implemented: striding x4, dw_striding x4 / x8)")
         if causal_downsampling: bad.append("causal_downsampling")
         if self_attention_model != "rel_pos": bad.append(f"self_attention_model={self_attention_model}")
-        if att_context_size not in (None, [-1, -1], (-1, -1)): bad.append("limited att_context_size")
         if not untie_biases: bad.append("tied pos biases")
         if conv_norm_type != "batch_norm": bad.append(f"conv_norm_type={conv_norm_type}")
         if conv_context_size is not None: bad.append("conv_context_size")
         if not use_bias: bad.append("use_bias=False")
         if reduction: bad.append("reduction")
-        if stochastic_depth_drop_prob != 0.0: bad.append("stochastic depth")
-        if feat_out > 0 and feat_out != d_model: bad.append("feat_out projection")
         if conv_kernel_size not in (5, 9, 31): bad.append(f"conv_kernel_size={conv_kernel_size}")
         if d_model % n_heads or d_model % 4: bad.append("d_model not divisible by n_heads / 4")
         if bad:
@@ -236,7 +238,11 @@ class ConformerEncoder(NeuralModule):
         self.conv_kernel_size = conv_kernel_size
         self.subsampling_factor = subsampling_factor
         self.att_context_style, self.self_attention_model = att_context_style, self_attention_model
-        self.att_context_size = [-1, -1]
+        # limited attention context (conformer_encoder.py:863-894 `_calc_context_sizes`): a list of [left, right] windows, the first
+        # one is the default (evaluation); training draws one per step with att_context_probs when there are several (:620-625)
+        self.att_context_size_all, self.att_context_size, self.att_context_probs = self._calc_att_context(
+            att_context_size, att_context_probs, att_context_style)
+        self._ctx = (0, -1, -1)   # (style id, left, right) of the forward in flight
         self.sync_max_audio_length = sync_max_audio_length
         self.xscale = math.sqrt(d_model) if xscaling else None
         self.dropout, self.dropout_pre_encoder, self.dropout_att = dropout, dropout_pre_encoder, dropout_att
@@ -249,7 +255,19 @@ class ConformerEncoder(NeuralModule):
         self.pos_emb_max_len = pos_emb_max_len
         self.pos_enc = RelPositionalEncoding(d_model, dropout_pre_encoder, pos_emb_max_len, self.xscale, dropout_emb)
         self.layers = nn.ModuleList([ConformerLayer(d_model, d_ff, n_heads, conv_kernel_size) for _ in range(n_layers)])
-        self.out_proj = None
+        # feat_out projection (conformer_encoder.py:474-479, 738-739): a Linear(d_model, feat_out) behind the last layer
+        if feat_out > 0 and feat_out != d_model:
+            self.out_proj = nn.Linear(d_model, feat_out)
+            self._feat_out = feat_out
+        else:
+            self.out_proj = None
+        # stochastic depth (conformer_encoder.py:486-488, 696-707; parts/utils/regularization_utils.py:18-64)
+        self.layer_drop_probs = self._stochastic_depth_probs(n_layers, stochastic_depth_drop_prob, stochastic_depth_mode,
+                                                             stochastic_depth_start_layer)
+        # InterCTC (parts/mixins/interctc_mixin.py; conformer_encoder.py:724-736): the model lists the layers whose outputs it wants;
+        # `captured[l]` = [B, D, T'] output of layer l (through out_proj), part of the autograd graph of the forward that made it
+        self.capture_layers = []
+        self.captured = {}
         self.max_audio_length = pos_emb_max_len
         self._init_engine(compute_dtype, tail=lambda n: n.endswith("self_attn.linear_pos.weight"))
 
@@ -389,6 +407,92 @@ class ConformerEncoder(NeuralModule):
         return r
 
     # ------------------------------------------------------------------ forward (typed)
+    @staticmethod
+    def _calc_att_context(att_context_size, att_context_probs, att_context_style):
+        """the reference's normalisation and checks of att_context_size / att_context_probs (conformer_encoder.py:863-894)"""
+        if att_context_style not in ("regular", "chunked_limited"):
+            raise ValueError(f"att_context_style={att_context_style}")
+        if att_context_size:
+            all_ = [list(x) for x in ([att_context_size] if isinstance(list(att_context_size)[0], int) else list(att_context_size))]
+            for i, cs in enumerate(all_):
+                if att_context_style == "chunked_limited":
+                    if cs[0] > 0 and cs[0] % (cs[1] + 1) > 0:
+                        raise ValueError(f"att_context_size[{i}][0] % (att_context_size[{i}][1] + 1) should be zero!")
+                    if cs[1] < 0 and len(all_) <= 1:
+                        raise ValueError(f"Right context (att_context_size[{i}][1]) can not be unlimited for chunked_limited style!")
+        else:
+            all_ = [[-1, -1]]
+        if att_context_probs:
+            if len(att_context_probs) != len(all_):
+                raise ValueError("The size of the att_context_probs should be the same as att_context_size.")
+            probs = list(att_context_probs)
+            if sum(probs) != 1:
+                raise ValueError("The sum of numbers in att_context_probs should be equal to one to be a distribution.")
+        else:
+            probs = [1.0 / len(all_)] * len(all_)
+        return all_, all_[0], probs
+
+    @staticmethod
+    def _stochastic_depth_probs(n, p, mode, start):
+        """compute_stochastic_depth_drop_probs (parts/utils/regularization_utils.py:18-64)"""
+        if not (0 <= p < 1.0):
+            raise ValueError("stochastic_depth_drop_prob has to be in [0, 1).")
+        if not (1 <= start <= n):
+            raise ValueError("stochastic_depth_start_layer has to be in [1, num layers].")
+        probs = [0.0] * start
+        L = n - start
+        if L > 0:
+            if mode == "linear":
+                probs += [l / L * p for l in range(1, L + 1)]
+            elif mode == "uniform":
+                probs += [p] * L
+            else:
+                raise ValueError(f'stochastic_depth_mode has to be one of ["linear", "uniform"]. Current value: {mode}')
+        return probs
+
+    def _live_only(self):
+        """options whose launch sequence changes from step to step (a layer dropped at random) or that hand extra differentiable
+        outputs to the caller (InterCTC captures): issued live, never from a recorded sequence"""
+        return (self.training and any(p > 0.0 for p in self.layer_drop_probs)) or bool(self.capture_layers)
+
+    def _out_proj_fwd(self, x, M, dev):
+        """y [M, feat_out] = x [M, d] @ W^T + b, fp32 (exact-fp32 MFMA GEMM) whatever the compute dtype"""
+        fo, d = self._feat_out, self.d_model
+        y = self._new(M, fo, dtype=torch.float32, device=dev)
+        ops.gemm(x, self.out_proj.weight, y, M, fo, d, d, d, fo, bias=self.out_proj.bias)
+        return y
+
+    def _out_proj_bwd(self, dy, x, M, dev):
+        """dx [M, d] = dy @ W; W.grad += dy^T x; b.grad += column sums of dy"""
+        fo, d = self._feat_out, self.d_model
+        dx = self._new(M, d, dtype=torch.float32, device=dev)
+        ops.gemm(dy, self.out_proj.weight, dx, M, d, fo, fo, d, d, transB=True)
+        ops.gemm(dy, x, self.out_proj.weight.grad, fo, d, M, fo, d, d, transA=True, transB=True, atomic=True, c_dtype=ops.F32)
+        ops.colsum(dy, self.out_proj.bias.grad, M, fo)
+        return dx
+
+    def set_default_att_context_size(self, att_context_size):
+        """conformer_encoder.py:896-910"""
+        if att_context_size is not None:
+            self.att_context_size = list(att_context_size)
+
+    def _ctx_limited_any(self):
+        """does any configured window limit the context?  Then attention runs on the GEMM + softmax-kernel path (the window is a
+        mask inside mi355x_relpos_softmax_fwd_ctx); the fused kernels implement the unlimited case."""
+        return any(l >= 0 or r >= 0 for l, r in self.att_context_size_all + [self.att_context_size])
+
+    def _flash_ok(self):
+        return self.use_flash_attention and not self._ctx_limited_any()
+
+    def _pick_ctx(self):
+        import random
+        if self.training and len(self.att_context_size_all) > 1:
+            cs = random.choices(self.att_context_size_all, weights=self.att_context_probs)[0]
+        else:
+            cs = self.att_context_size
+        limited = cs[0] >= 0 or cs[1] >= 0
+        self._ctx = ((1 if self.att_context_style == "regular" else 2) if limited else 0, int(cs[0]), int(cs[1]))
+
     @typecheck()
     def forward(self, audio_signal, length, cache_last_channel=None, cache_last_time=None, cache_last_channel_len=None,
                 bypass_pre_encode=False):
@@ -400,12 +504,16 @@ class ConformerEncoder(NeuralModule):
         if length is None:
             length = audio_signal.new_full((audio_signal.size(0),), audio_signal.size(-1), dtype=torch.int64)
         self._flatp.ensure(audio_signal.device)
+        self._pick_ctx()
         if self._token is None or self._token.device != audio_signal.device:
             self._token = torch.zeros(1, device=audio_signal.device, requires_grad=True)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if need_grad:
-            return _EncoderFn.apply(audio_signal, length, self._token, self)
-        out, enc_len, _ = self._forward_impl(audio_signal, length)
+            res = _EncoderFn.apply(audio_signal, length, self._token, self)
+            self.captured = dict(zip(self.capture_layers, res[2:]))
+            return res[0], res[1]
+        out, enc_len, S_ = self._forward_impl(audio_signal, length, save=bool(self.capture_layers))
+        self.captured = dict(zip(self.capture_layers, getattr(S_, "cap_out", ()))) if S_ is not None else {}
         return out, enc_len
 
     # ------------------------------------------------------------------ helpers
@@ -549,7 +657,7 @@ class ConformerEncoder(NeuralModule):
                 self.grad_ready_hook is not None, self._wgrad_join_per_layer, self.wgrad_side_stream, self.wgrad_grouped,
                 self.dpos_side_stream, self.sub_wgrad_side_stream, self.conv2_implicit, self.ln_cast_fuse, self.fuse_bn_dwconv_bwd, self.fuse_glu_dwconv_bwd, self.fuse_glu_dwconv_fwd, self.tap_reduce_side, self.pad_tile_skip,
                 self.use_flash_attention, self.flash_delta_residual, self.syncbn_profile is not None, self.graph_tape, self.swish_g, self.dropout, self.dropout_att, self.dropout_emb, self.dropout_pre_encoder,
-                self.wgrad_defer, self.graph_bwd_live, self.posproj_side, self.wgrad_layers)
+                self.wgrad_defer, self.graph_bwd_live, self.posproj_side, self.wgrad_layers, self._ctx)
 
     def _auto_begin(self, gs, mode):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -582,7 +690,7 @@ class ConformerEncoder(NeuralModule):
     def _graphed_forward(self, mel, length):
         """-> (out, enc_len, graph set, generation) from the recorded sequence, or None when this call has to run eagerly"""
         self._cur_gs = None
-        if not (self.use_graphs and self.training and mel.is_cuda) or ops.GEMM_PROFILE is not None:
+        if not (self.use_graphs and self.training and mel.is_cuda) or ops.GEMM_PROFILE is not None or self._live_only():
             self.live_steps += 1
             return None
         if self._packing_plan(length, mel.shape[0], mel.shape[2], peek=True) is not None:
@@ -1053,16 +1161,47 @@ class ConformerEncoder(NeuralModule):
         if training and S.bn_world > 1:
             S.bn_stats[:, 2 * d] = float(M)
         S.layers = []
+        S.sd, S.cap_idx, S.cap_out, S.proj_in = [], [], [], {}
+
+        def on_grid(t):  # a layer output on the reference's [B, T', d] grid (packed rows: frames beyond an utterance are zeros)
+            if pk is None:
+                return t
+            xo = self._new(M, d, dtype=torch.float32, device=dev)
+            ops.rows_unpack(t, xo, len2, pk.cu, T2, M, d)
+            return xo
+
+        def projected(t, key):  # [M, d] -> [B, D, T'] through out_proj (D = feat_out) or as it is
+            if self.out_proj is None:
+                return t.view(B, T2, d).transpose(1, 2)
+            S.proj_in[key] = t
+            return self._out_proj_fwd(t, M, dev).view(B, T2, self._feat_out).transpose(1, 2)
+
         for i, L in enumerate(self.layers):
+            x_in = x
             x, sl = self._layer_fwd(i, L, x, S, W, Wf, drop)
             S.layers.append(sl)
+            sd = None
+            if training and self.layer_drop_probs[i] > 0.0:
+                # stochastic depth (conformer_encoder.py:696-707): one torch.rand(1) per droppable layer from the global generator, at
+                # the reference's point in the sequence.  A dropped layer has run (BatchNorm statistics, dropout counters move on)
+                # and contributes nothing; a kept one is rescaled: x_in + (x - x_in) / (1 - p)
+                p_ = self.layer_drop_probs[i]
+                if bool(torch.rand(1) < p_):
+                    sd, x = ("drop", 0.0), x_in
+                else:
+                    a_ = 1.0 / (1.0 - p_)
+                    sd, x = ("keep", a_), torch.add(x_in, x - x_in, alpha=a_)
+            S.sd.append(sd)
+            if i in self.capture_layers:
+                S.cap_idx.append(i)
+                S.cap_out.append(projected(on_grid(x), i))
         if training:  # nn.BatchNorm1d bookkeeping, one multi-tensor launch
             torch._foreach_add_([L.conv.batch_norm.num_batches_tracked for L in self.layers], 1)
-        if pk is not None:  # back to the reference's [B, T', d] grid (frames beyond an utterance: zeros -- nothing downstream reads them)
-            xo = self._new(M, d, dtype=torch.float32, device=dev)
-            ops.rows_unpack(x, xo, len2, pk.cu, T2, M, d)
-            x = xo
-        out = x.view(B, T2, d).transpose(1, 2)
+        x = on_grid(x)  # back to the reference's [B, T', d] grid (frames beyond an utterance: zeros -- nothing downstream reads them)
+        out = projected(x, "final")
+        order = {l: k for k, l in enumerate(S.cap_idx)}   # captures in the order the caller listed the layers
+        S.cap_out = [S.cap_out[order[l]] for l in self.capture_layers if l in order]
+        S.cap_layers = [l for l in self.capture_layers if l in order]
         return out, len2, (S if save else None)
 
     # ------------------------------------------------------------------ 'dw_striding' sub-sampling (FastConformer, Squeezeformer)
@@ -1206,9 +1345,9 @@ class ConformerEncoder(NeuralModule):
         linear_pos rows, linear_out columns, pos_bias lanes); activations outside the attention block keep width d."""
         dk = self.d_k
         dkp = _pad8(dk) if cdt == torch.bfloat16 else dk
-        if cdt == torch.bfloat16 and self.use_flash_attention and self.flash_pad_heads and 64 < dkp < 128:
+        if cdt == torch.bfloat16 and self._flash_ok() and self.flash_pad_heads and 64 < dkp < 128:
             dkp = 128   # ... and heads of 65..127 lanes to the kernels' second width (d_k' = 128: 8 k-steps, one workgroup per CU)
-        if cdt == torch.bfloat16 and self.use_flash_attention and self.flash_pad_heads and dkp < 64:
+        if cdt == torch.bfloat16 and self._flash_ok() and self.flash_pad_heads and dkp < 64:
             # round 5: heads narrower than the fused kernels' width (Conformer-Small: 44) are padded up to 64 instead of to the
             # next multiple of 8, so that they take the fused rel-pos attention (csrc/attention.hip, d_k' = 64) instead of
             # materialising the [H, B, T', T'] scores and the [H, B, T', 2T'-1] positional matrix in HBM
@@ -1279,7 +1418,7 @@ class ConformerEncoder(NeuralModule):
         H = self.n_heads
         M, P = B * T, 2 * T - 1
         Tp, Pp = _pad8(T), _pad8(P)
-        flash = self.use_flash_attention and cdt == torch.bfloat16 and dk in (64, 128)
+        flash = self._flash_ok() and cdt == torch.bfloat16 and dk in (64, 128)
         cu = pk.cu if pk is not None else None
         if pk is not None and not flash:
             qkv_p = self._new(M, 3 * dA, dtype=cdt, device=dev)
@@ -1311,7 +1450,7 @@ class ConformerEncoder(NeuralModule):
         ops.gemm(qv, p, bdf, T, P, dk, dA, dA, Pp, batch=H * B, nb0=B, sA=(T * dA, dk), sB=(0, dk), sC=(T * Pp, B * T * Pp))
         s_ = self._new(H, B, T, Tp, dtype=cdt, device=dev)
         pd = self._new(H, B, T, Tp, dtype=cdt, device=dev) if d_att.threshold else None
-        ops.relpos_softmax_fwd(ac, bdf, s_, pd, lens, H, B, T, Tp, Pp, scale, d_att)
+        ops.relpos_softmax_fwd(ac, bdf, s_, pd, lens, H, B, T, Tp, Pp, scale, d_att, ctx=self._ctx)
         if pd is None:
             pd = s_
         # ctx_bh = pd_bh [T,T] @ v_bh [T,dk]   (NN: v is reduction-major inside qkv)
@@ -1575,7 +1714,7 @@ class ConformerEncoder(NeuralModule):
                                "(the sequencer's tensors live in a step-scoped arena); set MI355X_ARENA=0 (and MI355X_GRAPHS=0) for "
                                "several forwards per backward")
 
-    def _backward_impl(self, S, dout):
+    def _backward_impl(self, S, dout, dcaps=()):
         B, F_, T, T1, F1, T2, F2, M, cdt, training, seed = S.dims
         dev = dout.device
         self._check_serial(S)
@@ -1583,12 +1722,22 @@ class ConformerEncoder(NeuralModule):
         d, C_ = self.d_model, self.pre_encode._conv_channels
         W, Wf = self._plan(cdt, dev)
         fp = self._flatp
-        dx = dout.transpose(1, 2).contiguous().view(M, d).to(torch.float32)  # no copy when dout is a [B,T,d] view
         pk = getattr(S, "pk", None)
-        if pk is not None:  # packed rows: the layers' backward runs on the valid frames (the others never reached the loss)
-            dxp = self._new(pk.Mp, d, dtype=torch.float32, device=dev)
-            ops.rows_pack(dx, dxp, S.len2, pk.cu, T2, M, d)
-            dx = dxp
+
+        def to_rows(g, key):  # gradient of a [B, D, T'] output -> rows of the layers' residual stream (through out_proj, packed)
+            if self.out_proj is not None:
+                gy = g.transpose(1, 2).contiguous().view(M, self._feat_out).to(torch.float32)
+                gx = self._out_proj_bwd(gy, S.proj_in[key], M, dev)
+            else:
+                gx = g.transpose(1, 2).contiguous().view(M, d).to(torch.float32)  # no copy when g is a [B,T,d] view
+            if pk is not None:  # packed rows: the layers' backward runs on the valid frames (the others never reached the loss)
+                gp = self._new(pk.Mp, d, dtype=torch.float32, device=dev)
+                ops.rows_pack(gx, gp, S.len2, pk.cu, T2, M, d)
+                gx = gp
+            return gx
+
+        dx = to_rows(dout, "final")
+        cap_grads = {l: g for l, g in zip(getattr(S, "cap_layers", []), dcaps) if g is not None}
         P = 2 * T2 - 1
         dA = self._geometry(cdt)[2]
         S.dp_all = self._buf("dp_all", (self.n_layers, P, dA), cdt, dev)
@@ -1624,7 +1773,19 @@ class ConformerEncoder(NeuralModule):
                 layer_done(j)
         self._defer_flush = (lambda: flush_deferred(force=not pair)) if defer else None
         for i in range(self.n_layers - 1, -1, -1):
-            dx = self._layer_bwd(i, self.layers[i], dx, S, S.layers[i], W, Wf)
+            if i in cap_grads:  # InterCTC: the gradient of the captured output of layer i joins the stream here
+                dx = dx + to_rows(cap_grads[i], i)
+            sd = S.sd[i] if getattr(S, "sd", None) else None
+            if sd is None:
+                dx = self._layer_bwd(i, self.layers[i], dx, S, S.layers[i], W, Wf)
+            elif sd[0] == "drop":
+                # a dropped layer contributed x * 0: its backward runs on a zero gradient (every weight gets its -- zero --
+                # gradient, the per-layer hooks and accumulators see the usual sequence), the stream's gradient passes by
+                self._layer_bwd(i, self.layers[i], torch.zeros_like(dx), S, S.layers[i], W, Wf)
+            else:
+                # kept and rescaled: x_in + a (L(x_in) - x_in)
+                din = self._layer_bwd(i, self.layers[i], dx * sd[1], S, S.layers[i], W, Wf)
+                dx = torch.add(din, dx, alpha=1.0 - sd[1])
             S.layers[i] = None
             if defer:
                 dfr = self._wg_deferred

@@ -148,6 +148,8 @@ class SqueezeformerEncoder(ConformerEncoder):
         self.subsampling_factor = subsampling_factor
         self.self_attention_model = self_attention_model
         self.att_context_size = [-1, -1]
+        self.att_context_size_all, self.att_context_probs, self._ctx = [[-1, -1]], [1.0], (0, -1, -1)
+        self.layer_drop_probs, self.capture_layers, self.captured = [0.0] * n_layers, [], {}
         self.adaptive_scale = adaptive_scale
         self.xscale = math.sqrt(d_model) if xscaling else None
         # (RelPositionalEncoding's dropout on x is `dropout` here: squeezeformer_encoder.py:207-213)

@@ -440,9 +440,11 @@ def add2(a, b, out, ldo, M, d, out_off=0):
           "add2")
 
 
-def relpos_softmax_fwd(ac, bdf, s_out, pd_out, lens, H, B, T, Tp, Pp, scale, drop: Dropout = NO_DROP):
-    check(lib.mi355x_relpos_softmax_fwd(_ptr(ac), _ptr(bdf), _ptr(s_out), _ptr(pd_out), dt(s_out), _ptr(lens), H, B, T, Tp, Pp,
-                                        scale, drop.key, drop.threshold, drop.scale, _stream()), "relpos_softmax_fwd")
+def relpos_softmax_fwd(ac, bdf, s_out, pd_out, lens, H, B, T, Tp, Pp, scale, drop: Dropout = NO_DROP, ctx=(0, -1, -1)):
+    """ctx = (style, left, right): limited attention context, style 0 none / 1 'regular' / 2 'chunked_limited'"""
+    check(lib.mi355x_relpos_softmax_fwd_ctx(_ptr(ac), _ptr(bdf), _ptr(s_out), _ptr(pd_out), dt(s_out), _ptr(lens), H, B, T, Tp, Pp,
+                                            scale, drop.key, drop.threshold, drop.scale, int(ctx[0]), int(ctx[1]), int(ctx[2]),
+                                            _stream()), "relpos_softmax_fwd")
 
 
 def relpos_softmax_bwd(dpd, s_in, dscore, dbdf, H, B, T, Tp, Pp, scale, drop: Dropout = NO_DROP):

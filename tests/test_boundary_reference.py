@@ -83,23 +83,25 @@ def test_reference_recipe_yaml_builds_the_drop_in_model_unmodified(rel, cls_name
 
 def test_interctc_section_is_validated_like_the_reference_and_never_ignored(tok_dir):
     """parts/mixins/interctc_mixin.py:46-73: the recipes ship `interctc` empty; a non-empty section changes the loss and must not be
-    dropped silently -- same ValueErrors as the reference for an inconsistent section, NotImplementedError for a consistent one"""
+    dropped silently -- same ValueErrors as the reference for an inconsistent section; a consistent one arms the encoder's captures
+    (the loss assembly itself: tests/test_encoder_options_gpu.py against the reference fixture)"""
     import nemo_amd.models as M
     from nemo_amd.config import load_config
     cfg = load_config(os.path.join(CONF, "conformer/conformer_ctc_bpe.yaml"), overrides=[f"model.tokenizer.dir={tok_dir}"])["model"]
     cfg["encoder"] = dict(cfg["encoder"], n_layers=2, d_model=64, n_heads=4)
     assert not cfg["interctc"]["loss_weights"]          # the recipe's own value: off
     M.EncDecCTCModelBPE(cfg)
-    with pytest.raises(NotImplementedError, match="interctc"):
-        M.EncDecCTCModelBPE(dict(cfg, interctc=dict(loss_weights=[0.3], apply_at_layers=[0])))
+    m_ic = M.EncDecCTCModelBPE(dict(cfg, interctc=dict(loss_weights=[0.3], apply_at_layers=[0])))
+    assert m_ic._interctc == ([0.3], [0]) and m_ic.encoder.capture_layers == [0] and m_ic.encoder._live_only()
+    with pytest.raises(ValueError, match="the encoder has 2 layers"):
+        M.EncDecCTCModelBPE(dict(cfg, interctc=dict(loss_weights=[0.3], apply_at_layers=[5])))
     with pytest.raises(ValueError, match="apply_at_layers has to match"):
         M.EncDecCTCModelBPE(dict(cfg, interctc=dict(loss_weights=[0.3], apply_at_layers=[0, 1])))
     with pytest.raises(ValueError, match="sum of intermediate loss weights"):
         M.EncDecCTCModelBPE(dict(cfg, interctc=dict(loss_weights=[0.6, 0.5], apply_at_layers=[0, 1])))
     # two more model-level keys that change behaviour and used to be read by nobody
     assert cfg["skip_nan_grad"] is False
-    with pytest.raises(NotImplementedError, match="skip_nan_grad"):
-        M.EncDecCTCModelBPE(dict(cfg, skip_nan_grad=True))
+    assert M.EncDecCTCModelBPE(dict(cfg, skip_nan_grad=True))._skip_nan_grad is True   # (the skip itself: tests/test_encoder_options_gpu.py)
     m = M.EncDecCTCModelBPE(dict(cfg, decoding=dict(strategy="beam", beam=dict(beam_size=4))))
     with pytest.raises(NotImplementedError, match="beam"):
         m.wer
@@ -107,7 +109,7 @@ def test_interctc_section_is_validated_like_the_reference_and_never_ignored(tok_
 
 
 @pytest.mark.parametrize("rel,needs", [
-    ("fastconformer/cache_aware_streaming/fastconformer_ctc_bpe_streaming.yaml", ["causal_downsampling", "att_context_size", "conv_norm_type"]),
+    ("fastconformer/cache_aware_streaming/fastconformer_ctc_bpe_streaming.yaml", ["causal_downsampling", "conv_norm_type"]),
     ("fastconformer/long_fastconformer/fast-conformer-long_ctc_bpe.yaml", ["self_attention_model"]),
 ])
 def test_recipes_outside_the_implemented_options_fail_by_name_not_silently(rel, needs, tok_dir):
