@@ -123,9 +123,16 @@ def test_typecheck_contract():
 def test_unsupported_configurations_raise():
     from nemo_amd.modules import ConformerEncoder
     for kw in (dict(subsampling="vggnet"), dict(subsampling="striding", subsampling_factor=8), dict(self_attention_model="abs_pos"), dict(conv_norm_type="layer_norm"),
-               dict(att_context_size=[128, 0])):
+               dict(conv_context_size="causal"), dict(causal_downsampling=True), dict(reduction="pooling")):
         with pytest.raises(NotImplementedError):
             ConformerEncoder(feat_in=80, n_layers=1, d_model=32, n_heads=4, **kw)
+    # options that ARE implemented are accepted and validated like the reference (conformer_encoder.py:863-894)
+    enc = ConformerEncoder(feat_in=80, n_layers=2, d_model=32, n_heads=4, att_context_size=[128, 0], feat_out=16, stochastic_depth_drop_prob=0.5)
+    assert enc.att_context_size == [128, 0] and enc._feat_out == 16 and enc.layer_drop_probs == [0.0, 0.5] and not enc._flash_ok()
+    with pytest.raises(ValueError):
+        ConformerEncoder(feat_in=80, n_layers=1, d_model=32, n_heads=4, att_context_size=[[8, 3], [4, 1]], att_context_probs=[0.5, 0.6])
+    with pytest.raises(ValueError):
+        ConformerEncoder(feat_in=80, n_layers=2, d_model=32, n_heads=4, stochastic_depth_drop_prob=1.0)
 
 
 def test_from_config_dict_resolves_reference_targets():
