@@ -368,6 +368,13 @@ int mi355x_dwconv_fwd_glu(const void* glu_in, const void* len, const void* row_o
 int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dtype, int B, int T,
                       int d, int ksize, void* scratch /* optional f32 [4*B*(ksize+1)*d]: two-stage reduction, no atomics */,
                       long long scratch_elems, void* stream);
+/* The depthwise convolution with asymmetric zero padding (ConformerConvolution's CausalConv1D, conv_context_size = [left, right] with
+ * left + right + 1 = ksize; /root/reference/nemo/collections/asr/parts/submodules/causal_convs.py:89-150, conformer_modules.py:
+ * 310-321): pad_left frames in front of the sequence, ksize - 1 - pad_left behind it; -1 = symmetric. */
+int mi355x_dwconv_fwd_ctx(const void* x, const void* w, const void* bias, void* y, int dtype, void* stats, int B, int T, int d,
+                          int ksize, int pad_left, void* stream);
+int mi355x_dwconv_bwd_ctx(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dtype, int B, int T, int d,
+                          int ksize, int pad_left, void* scratch, long long scratch_elems, void* stream);
 int mi355x_bn_finalize(const void* stats, double count, void* mean, void* rstd, void* running_mean, void* running_var,
                        float momentum, float eps, int d, void* stream);
 /* same, the element count read from device memory (f64 scalar): under SyncBatchNorm (conformer_ctc_bpe.yaml:209,

@@ -130,8 +130,10 @@ SIGNATURES = {
     "mi355x_relpos_ds_elems": [i32, i32, i32],
     "mi355x_relpos_dpos_partial_elems": [i32, i32, i32],
     "mi355x_dwconv_fwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp],
+    "mi355x_dwconv_fwd_ctx": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "mi355x_dwconv_fwd_glu": [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "mi355x_dwconv_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp],
+    "mi355x_dwconv_bwd_ctx": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp],
     "mi355x_dwconv_bwd_bnswish": [vp, vp, vp, vp, vp, vp, vp, f64, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp],
     "mi355x_dwconv_tap_reduce": [vp, i64, i32, i32, i32, vp, vp, vp],
     "mi355x_bn_finalize": [vp, f64, vp, vp, vp, vp, f32, f32, i32, vp],

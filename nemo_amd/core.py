@@ -46,6 +46,7 @@ class LabelsType(ElementType): pass
 class LossType(ElementType): pass
 class EmbeddedTextType(ElementType): pass
 class ChannelType(ElementType): pass
+class BoolType(ElementType): pass
 
 
 class NeuralType:
@@ -141,8 +142,11 @@ if HAVE_NEMO_CORE:
     NeuralType = _nt.NeuralType  # noqa: F811
     ElementType = _nt.ElementType  # noqa: F811
     for _name in ("AudioSignal", "LengthsType", "SpectrogramType", "MelSpectrogramType", "AcousticEncodedRepresentation",
-                  "LogprobsType", "LabelsType", "LossType", "EmbeddedTextType", "ChannelType"):
-        globals()[_name] = getattr(_nt, _name)
+                  "LogprobsType", "LabelsType", "LossType", "EmbeddedTextType", "ChannelType", "BoolType"):
+        if hasattr(_nt, _name):
+            globals()[_name] = getattr(_nt, _name)
+    if not (isinstance(BoolType, type) and issubclass(BoolType, ElementType)):  # (a NeMo without BoolType: a stand-in of its base)
+        BoolType = type("BoolType", (ElementType,), {})
     _ModuleBase = _RefNeuralModule
 else:
     _ModuleBase = nn.Module

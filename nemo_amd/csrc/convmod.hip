@@ -156,6 +156,7 @@ struct DwBnArgs {           // BatchNorm + Swish backward in front of the depthw
   const long long* glu_len;
   const long long* glu_cu;
   int glu_act;   // 0: GLU ([rows, 2d]), 1: Swish ([rows, d]; Squeezeformer's pointwise activation)
+  int pad_shift;            // asymmetric padding: left pad = (KS - 1) / 2 + pad_shift (0 = symmetric; causal_convs.py:89-150)
 };
 
 // GLU (+ pad mask) applied on the way INTO the forward tile (conformer_modules.py:324-331 in front of the depthwise conv): the tile
@@ -198,6 +199,7 @@ struct DwGluArgs {   // GLU in front of the depthwise forward (null in: plain de
   const long long* len;
   const long long* cu;
   int act;           // 0: GLU of [rows, 2d], 1: Swish of [rows, d]
+  int pad_shift;     // asymmetric padding: left pad = (KS - 1) / 2 + pad_shift (0 = symmetric; (KS - 1) / 2 = causal)
 };
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -206,7 +208,7 @@ template <typename TT, int KS, bool GLU>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const TT* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, TT* __restrict__ y,
                                                          double* __restrict__ stats, int B, int T, int d, DwGluArgs glu) {
-  constexpr int PAD = (KS - 1) / 2;
+  const int PAD = (KS - 1) / 2 + glu.pad_shift;   // left pad (CausalConv1D: conv_context_size = [left, right], left + right + 1 = KS)
   constexpr int ROWS = DW_TT + KS - 1;
   __shared__ __attribute__((aligned(16))) float tile[ROWS][DW_LD];
   __shared__ __attribute__((aligned(16))) float otile[DW_TT][DW_LD];
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ 
                                                          const float* __restrict__ w, TT* __restrict__ dx,
                                                          float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ partial, int B, int T, int d,
                                                          DwBnArgs bn) {
-  constexpr int PAD = (KS - 1) / 2;
+  const int PADL = (KS - 1) / 2 + bn.pad_shift, PADR = KS - 1 - PADL;   // forward pads (left, right): y[t] = sum_k w[k] x[t + k - PADL]
   constexpr int ROWS = DW_TT + KS - 1;
   __shared__ __attribute__((aligned(16))) float big[2][ROWS][DW_LD];  // dy tile | x tile (also the final reduction buffer)
   float (*tdy)[DW_LD] = big[0];
@@ -292,9 +294,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ 
   for (int ti = tile_lo; ti < tile_hi; ++ti) {
     const int t0 = ti * DW_TT;
     __syncthreads();
-    if (BN) stage_tile_bn<TT>(dy + (long long)b * T * d, (const TT*)bn.cc + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tdy, coef);
-    else stage_tile<TT>(dy + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tdy);
-    stage_tile<TT>(x + (long long)b * T * d, T, d, t0 - PAD, ROWS, c0, tx);
+    // dx[t] = sum_k w[k] dy[t + PADL - k]: the dy window starts PADR frames before the tile; dw[k] += dy[t] x[t + k - PADL]: the x
+    // window PADL frames before it
+    if (BN) stage_tile_bn<TT>(dy + (long long)b * T * d, (const TT*)bn.cc + (long long)b * T * d, T, d, t0 - PADR, ROWS, c0, tdy, coef);
+    else stage_tile<TT>(dy + (long long)b * T * d, T, d, t0 - PADR, ROWS, c0, tdy);
+    stage_tile<TT>(x + (long long)b * T * d, T, d, t0 - PADL, ROWS, c0, tx);
     __syncthreads();
     float vdy[DW_TQ + KS - 1], vx[DW_TQ + KS - 1];
 #pragma unroll
@@ -303,9 +307,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ 
     for (int o = 0; o < DW_TQ; ++o) {
       float a = 0.f;
 #pragma unroll
-      for (int k = 0; k < KS; ++k) a = fmaf(wk[k], vdy[o + 2 * PAD - k], a);
+      for (int k = 0; k < KS; ++k) a = fmaf(wk[k], vdy[o + KS - 1 - k], a);
       otile[tg * DW_TQ + o][c_l] = a;
-      const float g = vdy[o + PAD];  // zero when t >= T (staging zero-fills)
+      const float g = tdy[tg * DW_TQ + o + PADR][c_l];  // dy[t0 + o] (zero when t >= T: staging zero-fills); from LDS: PADR is a run-time number
+
       gb += g;
 #pragma unroll
       for (int k = 0; k < KS; ++k) gw[k] = fmaf(g, vx[o + k], gw[k]);
@@ -806,13 +811,22 @@ extern "C" int mi355x_dwconv_config(int level) {
 static bool dw_stream_ok(int dt, int d, int ksize, int level) {
   return dw_stream_level() >= level && dt == MI_DT_BF16 && ksize == 31 && (d % 2) == 0;
 }
+extern "C" int mi355x_dwconv_fwd_ctx(const void* x, const void* w, const void* bias, void* y, int dt, void* stats, int B, int T,
+                                     int d, int ksize, int pad_left, void* stream);
 extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias, void* y, int dt, void* stats, int B, int T,
                                  int d, int ksize, void* stream) {
+  return mi355x_dwconv_fwd_ctx(x, w, bias, y, dt, stats, B, T, d, ksize, -1, stream);
+}
+// pad_left: frames of zero padding in front of the sequence (conv_context_size = [left, right], left + right + 1 = ksize;
+// causal: ksize - 1; parts/submodules/causal_convs.py:89-150); -1 = symmetric, (ksize - 1) / 2
+extern "C" int mi355x_dwconv_fwd_ctx(const void* x, const void* w, const void* bias, void* y, int dt, void* stats, int B, int T,
+                                     int d, int ksize, int pad_left, void* stream) {
   mi_clear_errors();
-  if (!x || !w || !y || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
+  if (!x || !w || !y || B <= 0 || T <= 0 || d <= 0 || pad_left < -1 || pad_left >= ksize) return MI_ERR_ARG;
+  const int pad_shift = pad_left < 0 ? 0 : pad_left - (ksize - 1) / 2;
   dim3 grid((d + DW_CH - 1) / DW_CH, (T + DW_TT - 1) / DW_TT, B), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (dw_stream_ok(dt, d, ksize, 1)) {
+  if (pad_shift == 0 && dw_stream_ok(dt, d, ksize, 1)) {
     dim3 gs((d + DS_CG - 1) / DS_CG, (T + DS_BT - 1) / DS_BT, B), bs(64 * DS_NW);
 #define DS_FWD(ST, DD) MI_LAUNCH((dwconv_stream_kernel<31, false, ST, DD>), gs, bs, 0, s, (const bf16_t*)x, (const float*)w, \
     (const float*)bias, (bf16_t*)y, (double*)stats, T, d)
@@ -821,13 +835,14 @@ extern "C" int mi355x_dwconv_fwd(const void* x, const void* w, const void* bias,
 #undef DS_FWD
     return mi_check_launch();
   }
-  const DwGluArgs noglu = {nullptr, nullptr, nullptr, nullptr, 0};
+  const DwGluArgs noglu = {nullptr, nullptr, nullptr, nullptr, 0, pad_shift};
 #define DW_FWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_fwd_kernel<TT, KS, false>), grid, block, 0, s, (const TT*)x, \
     (const float*)w, (const float*)bias, (TT*)y, (double*)stats, B, T, d, noglu))
   switch (ksize) {
     case 31: DW_FWD(31); break;
     case 9: DW_FWD(9); break;
     case 5: DW_FWD(5); break;
+    case 3: DW_FWD(3); break;
     default: return MI_ERR_ARG;
   }
 #undef DW_FWD
@@ -845,27 +860,35 @@ extern "C" int mi355x_dwconv_fwd_glu(const void* glu_in, const void* len, const 
     return MI_ERR_ARG;
   dim3 grid((d + DW_CH - 1) / DW_CH, (T + DW_TT - 1) / DW_TT, B), block(256);
   hipStream_t s = (hipStream_t)stream;
-  const DwGluArgs glu = {glu_in, glu_out, (const long long*)len, (const long long*)row_offsets, act};
+  const DwGluArgs glu = {glu_in, glu_out, (const long long*)len, (const long long*)row_offsets, act, 0};
 #define DW_FWD_GLU(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_fwd_kernel<TT, KS, true>), grid, block, 0, s, (const TT*)nullptr, \
     (const float*)w, (const float*)bias, (TT*)y, (double*)stats, B, T, d, glu))
   switch (ksize) {
     case 31: DW_FWD_GLU(31); break;
     case 9: DW_FWD_GLU(9); break;
     case 5: DW_FWD_GLU(5); break;
+    case 3: DW_FWD_GLU(3); break;
     default: return MI_ERR_ARG;
   }
 #undef DW_FWD_GLU
   return mi_check_launch();
 }
+extern "C" int mi355x_dwconv_bwd_ctx(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dt, int B,
+                                     int T, int d, int ksize, int pad_left, void* scratch, long long scratch_elems, void* stream);
 extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dt, int B,
                                  int T, int d, int ksize, void* scratch, long long scratch_elems, void* stream) {
+  return mi355x_dwconv_bwd_ctx(dy, x, w, dx, dw, dbias, dt, B, T, d, ksize, -1, scratch, scratch_elems, stream);
+}
+extern "C" int mi355x_dwconv_bwd_ctx(const void* dy, const void* x, const void* w, void* dx, void* dw, void* dbias, int dt, int B,
+                                     int T, int d, int ksize, int pad_left, void* scratch, long long scratch_elems, void* stream) {
   mi_clear_errors();
-  if (!dy || !x || !w || !dx || !dw || B <= 0 || T <= 0 || d <= 0) return MI_ERR_ARG;
+  if (!dy || !x || !w || !dx || !dw || B <= 0 || T <= 0 || d <= 0 || pad_left < -1 || pad_left >= ksize) return MI_ERR_ARG;
+  const int pad_shift = pad_left < 0 ? 0 : pad_left - (ksize - 1) / 2;
   dim3 grid((d + DW_CH - 1) / DW_CH, DW_SEG, B), block(256);
   hipStream_t s = (hipStream_t)stream;
   const int nparts = B * DW_SEG;
   if (scratch && scratch_elems < (long long)nparts * (ksize + 1) * d) return MI_ERR_ARG;
-  if (scratch && dw_stream_ok(dt, d, ksize, 2)) {
+  if (scratch && pad_shift == 0 && dw_stream_ok(dt, d, ksize, 2)) {
     // dx = the forward kernel with the taps flipped; the tap / bias gradient partials from their own streaming kernel
     dim3 gs((d + DS_CG - 1) / DS_CG, (T + DS_BT - 1) / DS_BT, B), bs(64 * DS_NW);
 #define DS_DX(DD) MI_LAUNCH((dwconv_stream_kernel<31, true, false, DD>), gs, bs, 0, s, (const bf16_t*)dy, (const float*)w, \
@@ -887,13 +910,14 @@ extern "C" int mi355x_dwconv_bwd(const void* dy, const void* x, const void* w, v
                        ksize, d, (float*)dw, (float*)dbias);
     return mi_check_launch();
   }
-  const DwBnArgs nobn = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
+  const DwBnArgs nobn = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, pad_shift};
 #define DW_BWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS, false>), grid, block, 0, s, (const TT*)dy, \
     (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d, nobn))
   switch (ksize) {
     case 31: DW_BWD(31); break;
     case 9: DW_BWD(9); break;
     case 5: DW_BWD(5); break;
+    case 3: DW_BWD(3); break;
     default: return MI_ERR_ARG;
   }
   if (scratch)
@@ -923,13 +947,14 @@ extern "C" int mi355x_dwconv_bwd_bnswish(const void* dy, const void* cc, const v
   if (scratch && scratch_elems < (long long)nparts * (ksize + 1) * d) return MI_ERR_ARG;
   const DwBnArgs bn = {cc, (const float*)mean, (const float*)rstd, (const float*)gamma, (const float*)beta, (const double*)sums,
                        count_dev ? 0.0 : 1.0 / count, (const double*)count_dev, training, glu_in, glu_din,
-                       (const long long*)glu_len, (const long long*)glu_row_offsets, glu_act};
+                       (const long long*)glu_len, (const long long*)glu_row_offsets, glu_act, 0};
 #define DW_BWD_BN(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS, true>), grid, block, 0, s, (const TT*)dy, \
     (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d, bn))
   switch (ksize) {
     case 31: DW_BWD_BN(31); break;
     case 9: DW_BWD_BN(9); break;
     case 5: DW_BWD_BN(5); break;
+    case 3: DW_BWD_BN(3); break;
     default: return MI_ERR_ARG;
   }
 #undef DW_BWD_BN

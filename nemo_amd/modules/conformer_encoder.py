@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..core import (AcousticEncodedRepresentation, ChannelType, LengthsType, NeuralModule, NeuralType, SpectrogramType,
+from ..core import (AcousticEncodedRepresentation, BoolType, ChannelType, LengthsType, NeuralModule, NeuralType, SpectrogramType,
                     typecheck)
 from ..flat import FlatParams
 from ..packing import PackPlan
@@ -42,11 +42,12 @@ class _FeedForward(nn.Module):  # conformer_modules.py:366 ConformerFeedForward
 
 
 class _Convolution(nn.Module):  # conformer_modules.py:236 ConformerConvolution
-    def __init__(self, d_model, kernel_size):
+    def __init__(self, d_model, kernel_size, norm_type="batch_norm"):
         super().__init__()
         self.pointwise_conv1 = nn.Conv1d(d_model, d_model * 2, kernel_size=1)
         self.depthwise_conv = nn.Conv1d(d_model, d_model, kernel_size, groups=d_model, padding=0)
-        self.batch_norm = nn.BatchNorm1d(d_model)
+        # conformer_modules.py:293-306: the attribute is called batch_norm whatever the norm (state-dict key)
+        self.batch_norm = nn.LayerNorm(d_model) if norm_type == "layer_norm" else nn.BatchNorm1d(d_model)
         self.pointwise_conv2 = nn.Conv1d(d_model, d_model, kernel_size=1)
 
 
@@ -64,13 +65,13 @@ class _RelPosMHA(nn.Module):  # multi_head_attention.py:212 RelPositionMultiHead
 
 
 class ConformerLayer(nn.Module):  # conformer_modules.py:35 (parameter layout only; compute lives in ConformerEncoder)
-    def __init__(self, d_model, d_ff, n_heads, conv_kernel_size):
+    def __init__(self, d_model, d_ff, n_heads, conv_kernel_size, conv_norm_type="batch_norm"):
         super().__init__()
         self.fc_factor = 0.5
         self.norm_feed_forward1 = nn.LayerNorm(d_model)
         self.feed_forward1 = _FeedForward(d_model, d_ff)
         self.norm_conv = nn.LayerNorm(d_model)
-        self.conv = _Convolution(d_model, conv_kernel_size)
+        self.conv = _Convolution(d_model, conv_kernel_size, conv_norm_type)
         self.norm_self_att = nn.LayerNorm(d_model)
         self.self_attn = _RelPosMHA(n_heads, d_model)
         self.norm_feed_forward2 = nn.LayerNorm(d_model)
@@ -197,6 +198,7 @@ class ConformerEncoder(NeuralModule):
         return OrderedDict({
             "audio_signal": NeuralType(("B", "D", "T"), SpectrogramType()),
             "length": NeuralType(tuple("B"), LengthsType()),
+            "bypass_pre_encode": NeuralType(tuple(), BoolType(), optional=True),   # conformer_encoder.py:231
         })
 
     @property
@@ -224,11 +226,10 @@ class ConformerEncoder(NeuralModule):
         if causal_downsampling: bad.append("causal_downsampling")
         if self_attention_model != "rel_pos": bad.append(f"self_attention_model={self_attention_model}")
         if not untie_biases: bad.append("tied pos biases")
-        if conv_norm_type != "batch_norm": bad.append(f"conv_norm_type={conv_norm_type}")
-        if conv_context_size is not None: bad.append("conv_context_size")
+        if conv_norm_type not in ("batch_norm", "layer_norm"): bad.append(f"conv_norm_type={conv_norm_type} (implemented: batch_norm, layer_norm)")
         if not use_bias: bad.append("use_bias=False")
         if reduction: bad.append("reduction")
-        if conv_kernel_size not in (5, 9, 31): bad.append(f"conv_kernel_size={conv_kernel_size}")
+        if conv_kernel_size not in (3, 5, 9, 31): bad.append(f"conv_kernel_size={conv_kernel_size}")
         if d_model % n_heads or d_model % 4: bad.append("d_model not divisible by n_heads / 4")
         if bad:
             raise NotImplementedError("MI355X ConformerEncoder does not implement: " + ", ".join(bad))
@@ -254,7 +255,23 @@ class ConformerEncoder(NeuralModule):
         self._feat_out = d_model
         self.pos_emb_max_len = pos_emb_max_len
         self.pos_enc = RelPositionalEncoding(d_model, dropout_pre_encoder, pos_emb_max_len, self.xscale, dropout_emb)
-        self.layers = nn.ModuleList([ConformerLayer(d_model, d_ff, n_heads, conv_kernel_size) for _ in range(n_layers)])
+        # conv module options: LayerNorm instead of BatchNorm (conformer_modules.py:293-306, 335-340) and CausalConv1D's asymmetric
+        # padding (conv_context_size = 'causal' | [left, right], left + right + 1 = kernel; conformer_encoder.py:896-907, causal_convs.py:89-150)
+        self.conv_norm_type = conv_norm_type
+        if conv_context_size is None:
+            self.conv_context_size, self.conv_pad_left = None, -1
+        else:
+            if isinstance(conv_context_size, str):
+                if conv_context_size != "causal":
+                    raise ValueError("Invalid conv_context_size! It should be the string 'causal' or a list of two integers.")
+                cc_ = [conv_kernel_size - 1, 0]
+            else:
+                cc_ = [int(v) for v in conv_context_size]
+                if len(cc_) != 2 or cc_[0] + cc_[1] + 1 != conv_kernel_size:
+                    raise ValueError(f"Invalid conv_context_size: {conv_context_size}!")
+            self.conv_context_size = cc_
+            self.conv_pad_left = -1 if cc_[0] == cc_[1] else cc_[0]
+        self.layers = nn.ModuleList([ConformerLayer(d_model, d_ff, n_heads, conv_kernel_size, conv_norm_type) for _ in range(n_layers)])
         # feat_out projection (conformer_encoder.py:474-479, 738-739): a Linear(d_model, feat_out) behind the last layer
         if feat_out > 0 and feat_out != d_model:
             self.out_proj = nn.Linear(d_model, feat_out)
@@ -453,7 +470,8 @@ class ConformerEncoder(NeuralModule):
     def _live_only(self):
         """options whose launch sequence changes from step to step (a layer dropped at random) or that hand extra differentiable
         outputs to the caller (InterCTC captures): issued live, never from a recorded sequence"""
-        return (self.training and any(p > 0.0 for p in self.layer_drop_probs)) or bool(self.capture_layers)
+        return ((self.training and any(p > 0.0 for p in self.layer_drop_probs)) or bool(self.capture_layers)
+                or getattr(self, "_bypass_now", False))
 
     def _out_proj_fwd(self, x, M, dev):
         """y [M, feat_out] = x [M, d] @ W^T + b, fp32 (exact-fp32 MFMA GEMM) whatever the compute dtype"""
@@ -496,13 +514,17 @@ class ConformerEncoder(NeuralModule):
     @typecheck()
     def forward(self, audio_signal, length, cache_last_channel=None, cache_last_time=None, cache_last_channel_len=None,
                 bypass_pre_encode=False):
-        if cache_last_channel is not None or bypass_pre_encode:
-            raise NotImplementedError("streaming caches / bypass_pre_encode are not on the training hot path")
-        if audio_signal.shape[-2] != self._feat_in:
+        if cache_last_channel is not None:
+            raise NotImplementedError("streaming caches are not on the training hot path")
+        if bypass_pre_encode and audio_signal.shape[-1] != self.d_model:
+            raise ValueError(f"If bypass_pre_encode is True, audio_signal should have shape (batch, n_frame, {self.d_model}) "
+                             f"but got last dimension {audio_signal.shape[-1]}.")  # conformer_encoder.py:563-568
+        if not bypass_pre_encode and audio_signal.shape[-2] != self._feat_in:
             raise ValueError(f"If bypass_pre_encode is False, audio_signal should have shape (batch, {self._feat_in}, "
                              f"n_frame) but got last dimension {audio_signal.shape[-2]}.")  # conformer_encoder.py:569-578
+        self._bypass_now = bool(bypass_pre_encode)   # pre-encoded frames [B, T', d_model]: the sub-sampling stack is skipped
         if length is None:
-            length = audio_signal.new_full((audio_signal.size(0),), audio_signal.size(-1), dtype=torch.int64)
+            length = audio_signal.new_full((audio_signal.size(0),), audio_signal.size(1 if bypass_pre_encode else -1), dtype=torch.int64)
         self._flatp.ensure(audio_signal.device)
         self._pick_ctx()
         if self._token is None or self._token.device != audio_signal.device:
@@ -1028,7 +1050,7 @@ class ConformerEncoder(NeuralModule):
         anyway) costs nothing; without it packed_rows=True reads them back (one device sync per step), "auto" stays padded.
         peek=True: decision only (no device work, no sync)."""
         mode = self.packed_rows
-        if mode is False or not length.is_cuda:
+        if mode is False or not length.is_cuda or getattr(self, "_bypass_now", False):
             return None
         host = getattr(length, "host_lengths", None)
         if host is None:
@@ -1078,15 +1100,23 @@ class ConformerEncoder(NeuralModule):
                                       f"compute_dtype=torch.float32 for this geometry")
         training = self.training
         W, Wf = self._plan(cdt, dev)
-        B, F_, T = mel.shape
+        bypass = bool(getattr(self, "_bypass_now", False))  # bypass_pre_encode: `mel` holds pre-encoded frames [B, T', d_model]
         mel = mel.to(torch.float32).contiguous()
         d, H, dk, dff, C_ = self.d_model, self.n_heads, self.d_k, self.d_ff, self.pre_encode._conv_channels
-        T1, F1 = (T - 1) // 2 + 1, (F_ - 1) // 2 + 1
-        lens = self._lens(length, self.pre_encode._sampling_num)  # [len0, len1, ..., len_final]
+        if bypass:
+            B, T, _ = mel.shape
+            F_ = T1 = F1 = F2 = 0
+            T2 = T
+            ln_ = length.to(torch.int64).contiguous()
+            lens = [ln_] * (self.pre_encode._sampling_num + 1)
+        else:
+            B, F_, T = mel.shape
+            T1, F1 = (T - 1) // 2 + 1, (F_ - 1) // 2 + 1
+            lens = self._lens(length, self.pre_encode._sampling_num)  # [len0, len1, ..., len_final]
+            T2, F2 = T, F_
+            for _ in range(self.pre_encode._sampling_num):
+                T2, F2 = (T2 - 1) // 2 + 1, (F2 - 1) // 2 + 1
         len0, len1, len2 = lens[0], lens[1], lens[-1]                # (`len2` / `T2` / `F2` name the FINAL grid everywhere below)
-        T2, F2 = T, F_
-        for _ in range(self.pre_encode._sampling_num):
-            T2, F2 = (T2 - 1) // 2 + 1, (F2 - 1) // 2 + 1
         M = B * T2
         self.update_max_seq_length(T2, dev)
         if training:
@@ -1103,7 +1133,12 @@ class ConformerEncoder(NeuralModule):
         pe = self.pre_encode
         S.lens_all = lens
         S.drop_pre = drop(self.dropout_pre_encoder, 100000)
-        if self.subsampling == "dw_striding":
+        S.bypass = bypass
+        if bypass:
+            # RelPositionalEncoding's part of the front (multi_head_attention.py:1087-1098): x * xscale, dropout
+            x = self._new(M, d, dtype=torch.float32, device=dev)
+            ops.drop_scale_cast(mel.view(M, d), x, M * d, (self.xscale or 1.0), S.drop_pre)
+        elif self.subsampling == "dw_striding":
             x = self._sub_fwd_dw(S, mel, lens, W, cdt, save)
         else:
             # ---- sub-sampling: conv1 (direct) -> conv2 (implicit MFMA GEMM, ReLU+mask epilogue) -> out Linear (+xscale, dropout)
@@ -1196,7 +1231,8 @@ class ConformerEncoder(NeuralModule):
                 S.cap_idx.append(i)
                 S.cap_out.append(projected(on_grid(x), i))
         if training:  # nn.BatchNorm1d bookkeeping, one multi-tensor launch
-            torch._foreach_add_([L.conv.batch_norm.num_batches_tracked for L in self.layers], 1)
+            if self.conv_norm_type == "batch_norm":
+                torch._foreach_add_([L.conv.batch_norm.num_batches_tracked for L in self.layers], 1)
         x = on_grid(x)  # back to the reference's [B, T', d] grid (frames beyond an utterance: zeros -- nothing downstream reads them)
         out = projected(x, "final")
         order = {l: k for k, l in enumerate(S.cap_idx)}   # captures in the order the caller listed the layers
@@ -1579,7 +1615,8 @@ class ConformerEncoder(NeuralModule):
         pw1 = self._new(M, 2 * d, dtype=cdt, device=dev)
         ops.gemm(y3, W[f"L{i}.conv.pw1"], pw1, M, 2 * d, d, d, W.pitch(f"L{i}.conv.pw1"), 2 * d, bias=c.pointwise_conv1.bias)
         g = self._new(Mg, d, dtype=cdt, device=dev)   # the conv core stays on the padded grid (BatchNorm counts padded frames)
-        fuse_glu = self.fuse_glu_dwconv_fwd and d % (8 if cdt == torch.bfloat16 else 4) == 0
+        padl = self.conv_pad_left                      # -1: symmetric padding; else CausalConv1D's left pad (the fused GLU form is symmetric)
+        fuse_glu = self.fuse_glu_dwconv_fwd and d % (8 if cdt == torch.bfloat16 else 4) == 0 and padl < 0
         if not fuse_glu:
             ops.glu_fwd(pw1, g, S.len2, T2, Mg, d, cu=cu)
         cc = self._new(Mg, d, dtype=cdt, device=dev)
@@ -1587,12 +1624,22 @@ class ConformerEncoder(NeuralModule):
         bmean = self._new(d, dtype=torch.float32, device=dev)
         brstd = self._new(d, dtype=torch.float32, device=dev)
         count = float(Mg)
-        if training:
+        if self.conv_norm_type == "layer_norm":
+            # nn.LayerNorm over the channels of every frame instead of BatchNorm (conformer_modules.py:335-338): depthwise conv without
+            # statistics -> LayerNorm -> Swish; per-frame mean / rstd and the normalised frames travel in the BatchNorm slots
+            if fuse_glu:
+                ops.dwconv_fwd_glu(pw1, S.len2, cu, g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
+            else:
+                ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k, pad_left=padl)
+            count, bmean, brstd = self._ln_fwd(bn, cc, Mg, d, cdt, dev)   # (yln, mean, rstd)
+            z = self._new(Mg, d, dtype=cdt, device=dev)
+            ops.swish_mask_fwd(count, z, None, T2, Mg, d)
+        elif training:
             stats = S.bn_stats[i]
             if fuse_glu:   # GLU + pad mask applied while the depthwise forward stages its tile (g is written for backward, not re-read)
                 ops.dwconv_fwd_glu(pw1, S.len2, cu, g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T2, d, k)
             else:
-                ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T2, d, k)
+                ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, stats, B, T2, d, k, pad_left=padl)
             if S.bn_world > 1:  # sums and count in one exchange; the global count stays on the device
                 self._sync_stats(stats[: 2 * d + 1])
                 count = stats[2 * d: 2 * d + 1]
@@ -1600,15 +1647,16 @@ class ConformerEncoder(NeuralModule):
             if fuse_glu:
                 ops.dwconv_fwd_glu(pw1, S.len2, cu, g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
             else:
-                ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k)
+                ops.dwconv_fwd(g, c.depthwise_conv.weight, c.depthwise_conv.bias, cc, None, B, T2, d, k, pad_left=padl)
             ops.bn_eval_stats(bn.running_mean, bn.running_var, bmean, brstd, bn.eps, d)
-        z = self._new(Mg, d, dtype=cdt, device=dev)
-        if training:
-            # (two launches on purpose: the one-launch form, mi355x_bn_stats_swish_fwd, makes EVERY workgroup derive the
-            #  coefficients of its channels from the f64 sums and measured 31 us against 15.5 us for this pair,
-            #  tools/bn_bench.py)
-            ops.bn_finalize(stats, count, bmean, brstd, bn.running_mean, bn.running_var, bn.momentum, bn.eps, d)
-        ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, Mg, d)
+        if self.conv_norm_type == "batch_norm":
+            z = self._new(Mg, d, dtype=cdt, device=dev)
+            if training:
+                # (two launches on purpose: the one-launch form, mi355x_bn_stats_swish_fwd, makes EVERY workgroup derive the
+                #  coefficients of its channels from the f64 sums and measured 31 us against 15.5 us for this pair,
+                #  tools/bn_bench.py)
+                ops.bn_finalize(stats, count, bmean, brstd, bn.running_mean, bn.running_var, bn.momentum, bn.eps, d)
+            ops.bn_swish_fwd(cc, bmean, brstd, bn.weight, bn.bias, z, Mg, d)
         if pk is not None:   # the valid frames of the core's output rejoin the packed chain (z is also the pw2 weight gradient's operand)
             zp = self._new(M, d, dtype=cdt, device=dev)
             ops.rows_pack(z, zp, S.len2, cu, T2, Mg, d)
@@ -1823,6 +1871,8 @@ class ConformerEncoder(NeuralModule):
                 # not see the range before they landed -- the same join the per-layer hooks get (layer_done)
                 self._wgrad_join(consume=True)
             self._hook(*fp.tail_range())
+        if getattr(S, "bypass", False):   # pre-encoded input: no sub-sampling stack behind the layers (its gradients stay zero)
+            return None
         # ---- sub-sampling backward
         pe = self.pre_encode
         if self.subsampling == "dw_striding":
@@ -2060,13 +2110,32 @@ class ConformerEncoder(NeuralModule):
             ops.rows_unpack(dz, dzp, S.len2, cu, T2, Mg, d)
             dz = dzp
         sums = S.bn_sums[i]
+        padl = self.conv_pad_left
         self._defer_point(1)
-        ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, Mg, d, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
-        if training and S.bn_world > 1:
-            self._sync_stats(sums)
+        ln_norm = self.conv_norm_type == "layer_norm"
+        if not ln_norm:
+            ops.bn_swish_bwd_reduce(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, Mg, d, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
+            if training and S.bn_world > 1:
+                self._sync_stats(sums)
         self._defer_point(5)   # (experimental entry points of the weight-gradient launch: behind the BatchNorm reduction ...)
         dpw1 = self._new(M, 2 * d, dtype=cdt, device=dev)
-        if self.fuse_bn_dwconv_bwd and self.fuse_glu_dwconv_bwd:
+        if ln_norm:
+            # Swish -> LayerNorm -> depthwise conv -> GLU, backwards (count / bmean / brstd carry yln / the per-frame mean / rstd)
+            dyln = self._new(Mg, d, dtype=cdt, device=dev)
+            ops.swish_mask_bwd(count, dz, dyln, None, T2, Mg, d)
+            dcc32 = self._new(Mg, d, dtype=torch.float32, device=dev)
+            if cdt == torch.bfloat16:
+                dcc = self._new(Mg, d, dtype=cdt, device=dev)
+                ops.layernorm_bwd(dyln, cc, bn.weight, bmean, brstd, dcc32, False, bn.weight.grad, bn.bias.grad, Mg, d, cast_out=dcc)
+            else:
+                ops.layernorm_bwd(dyln, cc, bn.weight, bmean, brstd, dcc32, False, bn.weight.grad, bn.bias.grad, Mg, d)
+                dcc = dcc32
+            dg = self._new(Mg, d, dtype=cdt, device=dev)
+            ops.dwconv_bwd(dcc, g, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k,
+                           pad_left=padl)
+            self._defer_point(6)
+            ops.glu_bwd(pw1, dg, dpw1, S.len2, T2, Mg, d, cu=cu)
+        elif self.fuse_bn_dwconv_bwd and self.fuse_glu_dwconv_bwd and padl < 0:
             # BatchNorm + Swish backward applied while the depthwise backward stages its gradient tile, the GLU backward while it
             # writes its result: one launch for four, and neither the [B, T', d] gradient w.r.t. the BatchNorm input nor the one
             # w.r.t. the GLU output is written or read back
@@ -2082,13 +2151,14 @@ class ConformerEncoder(NeuralModule):
             self._defer_point(6)
         else:
             dg = self._new(Mg, d, dtype=cdt, device=dev)
-            if self.fuse_bn_dwconv_bwd:
+            if self.fuse_bn_dwconv_bwd and padl < 0:
                 ops.dwconv_bwd_bnswish(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, g, c.depthwise_conv.weight, dg,
                                        c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
             else:
                 dcc = self._new(Mg, d, dtype=cdt, device=dev)
                 ops.bn_swish_bwd_apply(dz, cc, bmean, brstd, bn.weight, bn.bias, sums, count, training, dcc, Mg, d)
-                ops.dwconv_bwd(dcc, g, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k)
+                ops.dwconv_bwd(dcc, g, c.depthwise_conv.weight, dg, c.depthwise_conv.weight.grad, c.depthwise_conv.bias.grad, B, T2, d, k,
+                               pad_left=padl)
             self._defer_point(6)   # (... and behind the depthwise backward, beside the GLU backward and the pointwise dgrad GEMM)
             ops.glu_bwd(pw1, dg, dpw1, S.len2, T2, Mg, d, cu=cu)
         self._wgrad(dpw1, 2 * d, 0, y3, d, 0, c.pointwise_conv1.weight.grad, 2 * d, d, M, bias_grad=c.pointwise_conv1.bias.grad)

@@ -190,6 +190,13 @@ class SqueezeformerEncoder(ConformerEncoder):
             nn.init.uniform_(pe.out.weight, -fc, fc); nn.init.uniform_(pe.out.bias, -fc, fc)
 
     # ------------------------------------------------------------------ geometry helpers
+    @property
+    def input_types(self):   # squeezeformer_encoder.py:37-45 (no bypass_pre_encode port)
+        from collections import OrderedDict
+        from ..core import LengthsType, NeuralType, SpectrogramType
+        return OrderedDict({"audio_signal": NeuralType(("B", "D", "T"), SpectrogramType()),
+                            "length": NeuralType(tuple("B"), LengthsType())})
+
     def _geometry(self, cdt):
         """(row pitch of [M, d] GEMM operands, padded head width, padded attention width)"""
         dp, dkp = _pad8(self.d_model), _pad8(self.d_k)  # (same layout in fp32: one code path, exercised by the parity tests)

@@ -510,8 +510,10 @@ def relpos_flash_bwd_dpos(qv, ds, lens, dpos, B, H, T, dk, dpos_cast=None, cu=No
 
 
 # ------------------------------------------------------------------------------------------------ conv module
-def dwconv_fwd(x, w, bias, y, stats, B, T, d, k):
-    check(lib.mi355x_dwconv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), dt(x), _ptr(stats), B, T, d, k, _stream()), "dwconv_fwd")
+def dwconv_fwd(x, w, bias, y, stats, B, T, d, k, pad_left=-1):
+    """pad_left: zero frames in front of the sequence (conv_context_size[0]; k - 1 = causal), -1 = symmetric"""
+    check(lib.mi355x_dwconv_fwd_ctx(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), dt(x), _ptr(stats), B, T, d, k, pad_left, _stream()),
+          "dwconv_fwd")
 
 
 _SCRATCH = {}
@@ -539,11 +541,11 @@ def dwconv_fwd_glu(glu_in, lens, cu, glu_out, w, bias, y, stats, B, T, d, k, act
                                     _ptr(stats), B, T, d, k, act, _stream()), "dwconv_fwd_glu")
 
 
-def dwconv_bwd(dy, x, w, dx, dw, dbias, B, T, d, k):
+def dwconv_bwd(dy, x, w, dx, dw, dbias, B, T, d, k, pad_left=-1):
     n = 4 * B * (k + 1) * d
     sc = _scratch("dwconv_bwd", n, dy.device)
-    check(lib.mi355x_dwconv_bwd(_ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(dbias), dt(x), B, T, d, k, _ptr(sc), n,
-                                _stream()), "dwconv_bwd")
+    check(lib.mi355x_dwconv_bwd_ctx(_ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(dbias), dt(x), B, T, d, k, pad_left, _ptr(sc),
+                                    n, _stream()), "dwconv_bwd")
 
 
 def bn_finalize(stats, count, mean, rstd, running_mean, running_var, momentum, eps, d):

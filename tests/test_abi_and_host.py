@@ -122,8 +122,8 @@ def test_typecheck_contract():
 
 def test_unsupported_configurations_raise():
     from nemo_amd.modules import ConformerEncoder
-    for kw in (dict(subsampling="vggnet"), dict(subsampling="striding", subsampling_factor=8), dict(self_attention_model="abs_pos"), dict(conv_norm_type="layer_norm"),
-               dict(conv_context_size="causal"), dict(causal_downsampling=True), dict(reduction="pooling")):
+    for kw in (dict(subsampling="vggnet"), dict(subsampling="striding", subsampling_factor=8), dict(self_attention_model="abs_pos"), dict(conv_norm_type="instance_norm"),
+               dict(causal_downsampling=True), dict(reduction="pooling")):
         with pytest.raises(NotImplementedError):
             ConformerEncoder(feat_in=80, n_layers=1, d_model=32, n_heads=4, **kw)
     # options that ARE implemented are accepted and validated like the reference (conformer_encoder.py:863-894)
@@ -133,6 +133,10 @@ def test_unsupported_configurations_raise():
         ConformerEncoder(feat_in=80, n_layers=1, d_model=32, n_heads=4, att_context_size=[[8, 3], [4, 1]], att_context_probs=[0.5, 0.6])
     with pytest.raises(ValueError):
         ConformerEncoder(feat_in=80, n_layers=2, d_model=32, n_heads=4, stochastic_depth_drop_prob=1.0)
+    enc = ConformerEncoder(feat_in=80, n_layers=1, d_model=32, n_heads=4, conv_kernel_size=9, conv_norm_type="layer_norm", conv_context_size="causal")
+    assert enc.conv_context_size == [8, 0] and enc.conv_pad_left == 8 and isinstance(enc.layers[0].conv.batch_norm, torch.nn.LayerNorm)
+    with pytest.raises(ValueError):
+        ConformerEncoder(feat_in=80, n_layers=1, d_model=32, n_heads=4, conv_kernel_size=9, conv_context_size=[5, 2])
 
 
 def test_from_config_dict_resolves_reference_targets():

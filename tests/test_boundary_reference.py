@@ -109,7 +109,7 @@ def test_interctc_section_is_validated_like_the_reference_and_never_ignored(tok_
 
 
 @pytest.mark.parametrize("rel,needs", [
-    ("fastconformer/cache_aware_streaming/fastconformer_ctc_bpe_streaming.yaml", ["causal_downsampling", "conv_norm_type"]),
+    ("fastconformer/cache_aware_streaming/fastconformer_ctc_bpe_streaming.yaml", ["causal_downsampling"]),
     ("fastconformer/long_fastconformer/fast-conformer-long_ctc_bpe.yaml", ["self_attention_model"]),
 ])
 def test_recipes_outside_the_implemented_options_fail_by_name_not_silently(rel, needs, tok_dir):

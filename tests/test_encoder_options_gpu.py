@@ -35,6 +35,8 @@ def _tiny_with_options(golden_dir, case, enc_kw, **model_kw):
     over = dict(d_model=32, n_heads=4, n_layers=2, dropout=0.0, dropout_pre_encoder=0.0, dropout_att=0.0, conv_kernel_size=9, **enc_kw)
     model = _model(over, vocab=16, **model_kw)
     sd = {k: v.clone() for k, v in P.items() if k.startswith(("encoder.", "decoder."))}
+    if enc_kw.get("conv_norm_type") == "layer_norm":  # a LayerNorm has no running statistics (the tiny fixture's BatchNorm buffers)
+        sd = {k: v for k, v in sd.items() if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected and all(m.startswith("preprocessor.") for m in missing), (missing, unexpected)
     model = model.to(dev).train()
@@ -69,6 +71,38 @@ def test_limited_attention_context_matches_the_reference_fixture(golden_dir, cas
     torch.cuda.synchronize()
     ref_loss = float(zo[f"{case}/loss"])
     assert abs(out["loss"].item() - ref_loss) <= 1e-3 * abs(ref_loss), (out["loss"].item(), ref_loss)
+    assert np.array_equal(enc_len.cpu().numpy(), zo[f"{case}/enc_len"])
+    assert np.abs(enc.detach().cpu().numpy() - zo[f"{case}/enc"]).max() < 2e-3
+    _check_grads(model, zo, case)
+
+
+@pytest.mark.parametrize("case,kw,inter", [
+    ("conv_layer_norm", dict(conv_norm_type="layer_norm"), None),
+    ("conv_causal", dict(conv_context_size="causal"), None),
+    ("conv_context_6_2", dict(conv_context_size=[6, 2]), None),
+    ("streaming_recipe", dict(att_context_size=[8, 3], att_context_style="chunked_limited", conv_context_size="causal",
+                              conv_norm_type="layer_norm"), ([1], [0.25])),
+])
+def test_conv_module_options_match_the_reference_fixture(golden_dir, case, kw, inter):
+    """conv_norm_type = layer_norm (conformer_modules.py:293-306, 335-340), conv_context_size = 'causal' / [6, 2] (CausalConv1D,
+    causal_convs.py:89-150) and the cache-aware streaming recipe's combination of chunked attention, causal LayerNorm conv module and
+    InterCTC: encoder output, loss (and its InterCTC parts) and gradients from every block"""
+    mkw = dict(interctc=dict(apply_at_layers=inter[0], loss_weights=inter[1])) if inter else {}
+    model, batch, zo = _tiny_with_options(golden_dir, case, kw, **mkw)
+    for fp in model.flats():
+        fp.zero_grad()
+    out = model.training_step(batch)
+    out["loss"].backward()
+    mel, mel_len = model.preprocessor(input_signal=batch[0], length=batch[1])
+    with torch.no_grad():
+        enc, enc_len = model.encoder(audio_signal=mel, length=mel_len)
+    torch.cuda.synchronize()
+    ref_loss = float(zo[f"{case}/loss"])
+    assert abs(out["loss"].item() - ref_loss) <= 1e-3 * abs(ref_loss), (out["loss"].item(), ref_loss)
+    if inter:
+        for l in inter[0]:
+            ref = float(zo[f"{case}/inter_ctc_loss_l{l}"])
+            assert abs(out["log"][f"inter_ctc_loss_l{l}"].item() - ref) <= 1e-3 * abs(ref)
     assert np.array_equal(enc_len.cpu().numpy(), zo[f"{case}/enc_len"])
     assert np.abs(enc.detach().cpu().numpy() - zo[f"{case}/enc"]).max() < 2e-3
     _check_grads(model, zo, case)
@@ -158,6 +192,31 @@ def test_feat_out_projection_matches_the_reference_fixture(golden_dir):
     got = {k: p.grad.detach().cpu().numpy() for k, p in enc.named_parameters() if p.grad is not None}
     n_checked = _cmp_probe_grads(z, "feat_out", got)
     assert n_checked > 10 and "out_proj.weight" in got
+
+
+def test_bypass_pre_encode_with_layer_norm_conv_module_matches_the_reference_fixture(golden_dir):
+    """the reference's own encoder test geometry (tests/collections/asr/test_conformer_encoder.py:129-199): pre-encoded frames
+    [B, T, d_model = 16] through three layers with a LayerNorm conv module of kernel 3 and a feat_out = 8 projection"""
+    from nemo_amd.modules.conformer_encoder import ConformerEncoder
+    z, P, f32 = _structure_case(golden_dir, "bypass")
+    enc = ConformerEncoder(feat_in=10, n_layers=3, d_model=16, feat_out=8, stochastic_depth_drop_prob=0.0, dropout=0.0,
+                           dropout_pre_encoder=0.0, dropout_emb=0.0, dropout_att=0.0, conv_norm_type="layer_norm", conv_kernel_size=3,
+                           compute_dtype=torch.float32)
+    missing, unexpected = enc.load_state_dict(P, strict=False)
+    assert not unexpected and not [m for m in missing if "pos_enc" not in m], (missing, unexpected)
+    enc = enc.to(dev).train()
+    x, n = f32(z["bypass/x"]).to(dev), torch.from_numpy(z["bypass/len"]).to(dev)
+    y, yl = enc(audio_signal=x, length=n, bypass_pre_encode=True)
+    (y * f32(z["bypass/probe"]).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == tuple(z["bypass/y"].shape) and np.array_equal(yl.cpu().numpy(), z["bypass/ylen"])
+    assert np.abs(y.detach().cpu().numpy() - z["bypass/y"]).max() < 2e-3
+    got = {k: p.grad.detach().cpu().numpy() for k, p in enc.named_parameters() if p.grad is not None}
+    assert _cmp_probe_grads(z, "bypass", got) > 10
+    with pytest.raises(ValueError, match="bypass_pre_encode is True"):
+        enc(audio_signal=x.transpose(1, 2), length=n, bypass_pre_encode=True)
+    with pytest.raises(ValueError, match="bypass_pre_encode is False"):
+        enc(audio_signal=x, length=n)
 
 
 @pytest.mark.parametrize("mode", ["uniform", "linear"])
