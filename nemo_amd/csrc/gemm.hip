@@ -285,12 +285,12 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
       if (m < p.M) ld8x(p.aux_in, ai0, EPI == EPI_RESID ? MI_DT_F32 : p.auxin_dt, aux[it]);
     }
   }
+  // every LDS read of the thread's rows goes out before the first use (rows past M are read and ignored; measured neutral to -0.1 ms per step,
+  // profiles/r6_raw/epi_hoist_ab.txt)
+  float4 ra[ITERS], rb[ITERS];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int m = m_first + it * ROW_STEP;
-    if (m >= p.M) continue;
     const float* src = sC + (row_l0 + it * ROW_STEP) * LDS_C + c8;
-    float4 a, b;
     if (TW == 256) {
       // 32 lanes per window row, 32 bytes apart: in the 16-lane service groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...) both halves
       // of a lane pair would hit the same 16-byte slot twice (2-way) if every lane read its low half first; lanes 16-31 of each half
@@ -298,11 +298,17 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
       const int hi = (threadIdx.x >> 4) & 1;
       const float4 x = *reinterpret_cast<const float4*>(src + 4 * hi);
       const float4 y = *reinterpret_cast<const float4*>(src + 4 * (1 - hi));
-      a = hi ? y : x; b = hi ? x : y;
+      ra[it] = hi ? y : x; rb[it] = hi ? x : y;
     } else {
-      a = *reinterpret_cast<const float4*>(src);
-      b = *reinterpret_cast<const float4*>(src + 4);
+      ra[it] = *reinterpret_cast<const float4*>(src);
+      rb[it] = *reinterpret_cast<const float4*>(src + 4);
     }
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int m = m_first + it * ROW_STEP;
+    if (m >= p.M) continue;
+    const float4 a = ra[it], b = rb[it];
     float v[8] = {a.x + b8[0], a.y + b8[1], a.z + b8[2], a.w + b8[3], b.x + b8[4], b.y + b8[5], b.z + b8[6], b.w + b8[7]};
     float dm[8];
     drop_mask8(p.drop, db_l + (uint32_t)it * db_s, dm);

@@ -335,6 +335,243 @@ __global__ __launch_bounds__(256) void logmel_wave_kernel(const float* __restric
 }
 
 
+// Round 6: the same front-end with the FFT IN REGISTERS.  The radix-4 Stockham passes above move every point through the LDS four
+// times (8 + 8 b64 accesses per lane and stage, 2- to 4-way bank conflicts in the strided stores of the first two stages) and the
+// kernel sat at ~250 LDS wave-instructions per two-frame pass (profiles/r4_logmel.md).  Here a frame is owned by 16 LANES, each
+// holding 16 of its 256 complex points (m = l + 16 r): 256 = 16 x 16, so the transform is
+//     A[l][q]  = sum_r z[l + 16 r] W16^(r q)            -- a 16-point DFT over a lane's own registers
+//     A'[l][q] = A[l][q] * W256^(l q)                   -- 15 twiddles that depend on the lane only: kept in registers
+//     Z[q+16s] = sum_l A'[l][q] W16^(l s)               -- ONE 16 x 16 transpose through the LDS, then a DFT in registers again
+// and the real-FFT unscramble pairs bin k = q + 16 s with 256 - k = (16 - q) + 16 (15 - s): the partner lane is fixed
+// (ds_bpermute, no LDS storage), its registers are read in reverse order.  A wave carries four frames at a time; per frame the
+// LDS sees 16 + 16 b64 accesses for the transpose (17-point pitch, frame buffers 128 B apart modulo the bank row: conflict-free
+// both ways) instead of 4 x (8 + 8), plus the window/audio reads and the power spectrum for the filterbank.
+// The dither is evaluated ONCE per sample (the kernels above compute the previous sample's noise again for the pre-emphasis):
+// the dithered signal goes to the LDS, a second pass turns it into the pre-emphasised one.
+// Mel stage: lane (frame g, l) owns filters l, 31-l, 32+l, 63-l, ... of its frame -- long and short triangles alternate, so the
+// tap loops of a wave end together.  Same DFT, different summation order than the radix-4 kernels: log-mel values agree to ~1e-6.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f cmulv(v2f a, v2f b) {  // (a.x b.x - a.y b.y, a.x b.y + a.y b.x): two packed operations
+  const v2f t = a.xx * b;
+  return __builtin_elementwise_fma((v2f){-a.y, a.y}, b.yx, t);
+}
+__device__ __forceinline__ v2f mul_mi(v2f a) { return (v2f){a.y, -a.x}; }  // a * (-i)
+// in-place 16-point forward DFT of x[0..15] (output in natural order), 8 radix-4 butterflies + 9 constant twiddles
+__device__ __forceinline__ void dft16(v2f* x) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+  v2f y[4][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const v2f a0 = x[b] + x[b + 8], a1 = x[b] - x[b + 8], a2 = x[b + 4] + x[b + 12], a3 = mul_mi(x[b + 4] - x[b + 12]);
+    y[b][0] = a0 + a2; y[b][1] = a1 + a3; y[b][2] = a0 - a2; y[b][3] = a1 - a3;
+  }
+  // y[b][q0] *= W16^(b q0)
+  y[1][1] = cmulv(y[1][1], (v2f){C1, -S1}); y[1][2] = cmulv(y[1][2], (v2f){R2, -R2}); y[1][3] = cmulv(y[1][3], (v2f){S1, -C1});
+  y[2][1] = cmulv(y[2][1], (v2f){R2, -R2}); y[2][2] = mul_mi(y[2][2]);                y[2][3] = cmulv(y[2][3], (v2f){-R2, -R2});
+  y[3][1] = cmulv(y[3][1], (v2f){S1, -C1}); y[3][2] = cmulv(y[3][2], (v2f){-R2, -R2}); y[3][3] = cmulv(y[3][3], (v2f){-C1, S1});
+#pragma unroll
+  for (int q0 = 0; q0 < 4; ++q0) {
+    const v2f a0 = y[0][q0] + y[2][q0], a1 = y[0][q0] - y[2][q0], a2 = y[1][q0] + y[3][q0], a3 = mul_mi(y[1][q0] - y[3][q0]);
+    x[q0] = a0 + a2; x[q0 + 4] = a1 + a3; x[q0 + 8] = a0 - a2; x[q0 + 12] = a1 - a3;
+  }
+}
+
+#define R16_XP 272   // complex slots of a frame's transpose buffer: 16 rows x 17; 2176 B = 128 (mod 256)
+__global__ __launch_bounds__(256, 2) void logmel_r16_kernel(const float* __restrict__ audio, const long long* __restrict__ audio_len,
+                                                            const float* __restrict__ window, int win, int hop,
+                                                            const int* __restrict__ fb_start, const int* __restrict__ fb_len,
+                                                            const int* __restrict__ fb_off, const float* __restrict__ fb_w, int n_mels,
+                                                            float preemph, float dither, uint32_t seed, float log_guard,
+                                                            float* __restrict__ out, int B, int S, int T) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int seg = (MEL_FR - 1) * hop + NFFT;
+  float* s_audio = smem;                                  // [seg] pre-emphasised, masked, centre-padded; sample t = t_base + i
+  float* s_win = s_audio + ((seg + 3) & ~3);              // [512] window zero-padded & centred
+  v2f* s_tw = (v2f*)(s_win + NFFT);                       // [256] exp(-2 pi i k / 512)
+  v2f* s_x = s_tw + NH;                                   // [4 waves][4 frames][R16_XP] transpose buffers (later: power spectra)
+  float* s_n = (float*)s_x;                               // [seg + 1] dithered signal, sample t = t_base - 1 + i (staging only)
+  float* s_out = (float*)(s_x + 4 * 4 * R16_XP);          // [n_mels][MEL_FR + 1]
+  float* s_fbw = s_out + n_mels * (MEL_FR + 1);           // [FB_CAP + 4]
+  int* s_fbi = (int*)(s_fbw + FB_CAP + 4);                // [3][n_mels]
+
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * MEL_FR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l = lane & 15, g = lane >> 4;
+  const long long len = audio_len[b];
+  const float* xa = audio + (long long)b * S;
+
+  // ---- pass 1: dithered signal n[t] (0 outside [0, min(S, len))).  The segment is read as 16-byte vectors aligned on the
+  // ABSOLUTE element index (S need not be a multiple of 4), all of a thread's loads in flight before the first use; the
+  // filterbank, window and index loads go out behind them, in front of the first wait.
+  const int t_base = f0 * hop - NFFT / 2;
+  const long long row0 = (long long)b * S;
+  const int shift = (int)((row0 + t_base - 1) & 3);      // elements between the aligned start and sample t_base - 1
+  const int ta = t_base - 1 - shift;
+  const int nvec = (seg + 1 + shift + 3) >> 2;
+  const int lim = (int)min((long long)S, len);
+  constexpr int SV = 6;                                   // 6 x 256 vectors >= (31 * 512 + 512 + 4) / 4 for every hop <= 512
+  float4 av[SV];
+#pragma unroll
+  for (int u = 0; u < SV; ++u) {
+    const int v = tid + 256 * u, t = ta + 4 * v;
+    av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v < nvec && t + 3 >= 0 && t < lim) {
+      if (t >= 0 && t + 3 < S) av[u] = *reinterpret_cast<const float4*>(xa + t);
+      else {
+        if (t >= 0 && t < S) av[u].x = xa[t];
+        if (t + 1 >= 0 && t + 1 < S) av[u].y = xa[t + 1];
+        if (t + 2 >= 0 && t + 2 < S) av[u].z = xa[t + 2];
+        if (t + 3 >= 0 && t + 3 < S) av[u].w = xa[t + 3];
+      }
+    }
+  }
+  const int nnz_x = fb_off[n_mels - 1] + fb_len[n_mels - 1], nnz = (nnz_x + 3) & ~3;  // (weights exist up to nnz_x only)
+  const bool fb_in_lds = nnz <= FB_CAP;
+  int fb_aligned = 1;
+  if (fb_in_lds) {
+    for (int i = tid; i < nnz + 4; i += 256) s_fbw[i] = i < nnz_x ? fb_w[i] : 0.f;
+    for (int i = tid; i < n_mels; i += 256) {
+      const int o = fb_off[i];
+      s_fbi[i] = fb_start[i]; s_fbi[n_mels + i] = fb_len[i]; s_fbi[2 * n_mels + i] = o;
+      // 16-byte weight reads need 4-aligned offsets and zero fill up to the next filter (sparsify_filterbank lays them out so)
+      if ((o & 3) || (i + 1 < n_mels && fb_off[i + 1] < o + ((fb_len[i] + 3) & ~3))) fb_aligned = 0;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < SV; ++u) {
+    const int v = tid + 256 * u, t = ta + 4 * v;
+    if (v < nvec) {
+      const float c[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * v - shift + e, te = t + e;
+        if (i >= 0 && i < seg + 1) {
+          float x = 0.f;
+          if (te >= 0 && te < lim) {
+            x = c[e];
+            if (dither > 0.f) x += dither * hash_normal(seed, (uint32_t)(row0 + te));
+          }
+          s_n[i] = x;
+        }
+      }
+    }
+  }
+  const int woff = (NFFT - win) / 2;
+  for (int i = tid; i < NFFT; i += 256) s_win[i] = (i >= woff && i < woff + win) ? window[i - woff] : 0.f;
+  {
+    float sn, cs;
+    sincospif(-(float)tid / 256.f, &sn, &cs);
+    s_tw[tid] = (v2f){cs, sn};
+  }
+  const bool fbv = __syncthreads_and(fb_aligned) != 0 && fb_in_lds;  // (also the barrier between the two staging passes)
+  // ---- pass 2: pre-emphasis v[t] = n[t] - preemph * n[t-1] for t in [0, min(S, len)), 0 elsewhere (t = 0: n[-1] = 0)
+  for (int i = tid; i < seg; i += 256) {
+    const int t = t_base + i;
+    const bool ok = t >= 0 && t < S && t < len;
+    s_audio[i] = ok ? (t > 0 ? s_n[i + 1] - preemph * s_n[i] : s_n[i + 1]) : 0.f;
+  }
+  // per-lane constants: W256^(l q) = tw[2 l q] (q = 1..15, index < 512 by sign symmetry) and the unscramble twiddles W512^(l + 16 s)
+  v2f twl[16], twp[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = 2 * l * q;
+    v2f w = s_tw[i & 255];
+    if (i & 256) w = -w;
+    twl[q] = w;
+    twp[q] = s_tw[l + 16 * q];
+  }
+  __syncthreads();
+
+  v2f* xb = s_x + (wave * 4 + g) * R16_XP;      // this frame's transpose buffer
+  float* pw = (float*)xb;                       // ... and, once the transpose has been read back, its power spectrum [260]
+  const int pl = (lane & 48) | ((16 - l) & 15); // the lane that holds bins 256 - k of this lane's bins k
+
+#ifndef R16_ABL
+#define R16_ABL 0
+#endif
+  for (int pass = 0; pass < (R16_ABL == 3 ? 0 : MEL_FR / 16); ++pass) {
+    const int fl = wave * (MEL_FR / 4) + pass * 4 + g;  // local frame of this 16-lane group
+    const float* fa = s_audio + fl * hop;
+    v2f z[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = l + 16 * r;
+      const v2f a = *reinterpret_cast<const v2f*>(fa + 2 * m), w = *reinterpret_cast<const v2f*>(s_win + 2 * m);
+      z[r] = a * w;
+    }
+    dft16(z);
+#pragma unroll
+    for (int q = 1; q < 16; ++q) z[q] = cmulv(z[q], twl[q]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xb[q * 17 + l] = z[q];
+    WAVE_SYNC();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) z[j] = xb[l * 17 + j];   // lane q = l now holds A'[j][q], j = 0..15
+    WAVE_SYNC();
+    dft16(z);                                             // z[s] = Z[l + 16 s]
+    if (R16_ABL == 2) { s_out[l * (MEL_FR + 1) + fl] = z[0].x + z[5].y + z[15].x; continue; }
+    // ---- real-FFT unscramble: partner values Z[256 - k]
+    v2f zp[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      zp[j].x = __shfl(z[j].x, pl, 64);
+      zp[j].y = __shfl(z[j].y, pl, 64);
+    }
+    const bool l0 = l == 0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const v2f a = zp[15 - s], c = zp[(16 - s) & 15];
+      v2f zc = l0 ? c : a;
+      zc.y = -zc.y;
+      const v2f zk = z[s];
+      const v2f ze = 0.5f * (zk + zc), df = 0.5f * (zk - zc);
+      const v2f xk = ze + cmulv(twp[s], mul_mi(df));
+      pw[l + 16 * s] = xk.x * xk.x + xk.y * xk.y;
+    }
+    if (l0) { const float d = z[0].x - z[0].y; pw[256] = d * d; pw[257] = 0.f; pw[258] = 0.f; pw[259] = 0.f; }
+    WAVE_SYNC();
+    if (R16_ABL == 1) { s_out[l * (MEL_FR + 1) + fl] = pw[l] + pw[l + 100]; continue; }
+    // ---- sparse mel filterbank + log
+    for (int j = 0; 16 * j < n_mels; ++j) {
+      const int m = 16 * j + ((j & 1) ? 15 - l : l);
+      if (m >= n_mels) continue;
+      float acc = 0.f;
+      if (fbv) {
+        const int st0 = s_fbi[m], n = s_fbi[n_mels + m];
+        const float* wv = s_fbw + s_fbi[2 * n_mels + m];
+        const float* pv = pw + st0;
+        for (int i = 0; i < n; i += 4) {   // (pw has 260 slots for 257 bins, the weights are zero up to the next multiple of four)
+          const float4 w = *reinterpret_cast<const float4*>(wv + i);
+          const float p0 = pv[i], p1 = pv[i + 1], p2 = pv[i + 2], p3 = pv[i + 3];
+          acc = fmaf(w.x, p0, acc); acc = fmaf(w.y, p1, acc); acc = fmaf(w.z, p2, acc); acc = fmaf(w.w, p3, acc);
+        }
+      } else if (fb_in_lds) {
+        const int st0 = s_fbi[m], n = s_fbi[n_mels + m];
+        const float* wv = s_fbw + s_fbi[2 * n_mels + m];
+        for (int i = 0; i < n; i += 4) {
+          const float w0 = wv[i], w1 = i + 1 < n ? wv[i + 1] : 0.f, w2 = i + 2 < n ? wv[i + 2] : 0.f, w3 = i + 3 < n ? wv[i + 3] : 0.f;
+          const float p0 = pw[st0 + i], p1 = pw[st0 + i + 1], p2 = pw[st0 + i + 2], p3 = pw[st0 + i + 3];
+          acc = fmaf(w0, p0, acc); acc = fmaf(w1, p1, acc); acc = fmaf(w2, p2, acc); acc = fmaf(w3, p3, acc);
+        }
+      } else {
+        const int st0 = fb_start[m], n = fb_len[m];
+        const float* wv = fb_w + fb_off[m];
+        for (int i = 0; i < n; ++i) acc = fmaf(wv[i], pw[st0 + i], acc);
+      }
+      s_out[m * (MEL_FR + 1) + fl] = logf(acc + log_guard);
+    }
+    WAVE_SYNC();  // (the next pass's transpose overwrites pw)
+  }
+  __syncthreads();
+  for (int i = tid; i < n_mels * MEL_FR; i += 256) {
+    const int m = i / MEL_FR, fl = i - m * MEL_FR;
+    const int f = f0 + fl;
+    if (f < T) out[((long long)b * n_mels + m) * T + f] = s_out[m * (MEL_FR + 1) + fl];
+  }
+}
+
+
 // per-feature normalisation over frames t < seq_len (features.py:59-93), pad_value fill beyond; one wave per (b, m) row
 template <typename TO>
 __global__ __launch_bounds__(256) void feat_norm_kernel(const float* __restrict__ x, const long long* __restrict__ seq_len,
@@ -364,13 +601,14 @@ static int g_logmel_variant = -1;  // -1: not yet read from the environment
 static int logmel_variant() {
   if (g_logmel_variant < 0) {
     const char* e = getenv("MI355X_LOGMEL");
-    g_logmel_variant = (e && e[0]) ? (atoi(e) ? 1 : 0) : 1;
+    const int v = (e && e[0]) ? atoi(e) : 2;
+    g_logmel_variant = v < 0 ? 0 : (v > 2 ? 2 : v);
   }
   return g_logmel_variant;
 }
 extern "C" int mi355x_logmel_config(int variant) {
   const int old = logmel_variant();
-  if (variant >= 0) g_logmel_variant = variant ? 1 : 0;
+  if (variant >= 0) g_logmel_variant = variant > 2 ? 2 : variant;
   return old;
 }
 extern "C" int mi355x_logmel_fwd(const void* audio, const void* audio_len, const void* window, int win, int hop, int n_fft,
@@ -382,21 +620,29 @@ extern "C" int mi355x_logmel_fwd(const void* audio, const void* audio_len, const
   if (n_fft != NFFT || win <= 0 || win > NFFT || hop <= 0 || hop > NFFT || n_mels <= 0 || B <= 0 || S <= 0) return MI_ERR_ARG;
   if (T != 1 + S / hop) return MI_ERR_ARG;
   const int seg = (MEL_FR - 1) * hop + NFFT;
-  // MI355X_LOGMEL: 1 (default) = the wave-synchronised kernel, two frames in flight per wave; 0 = the round-1 kernel (A/B, tests)
-  const int variant = logmel_variant();
+  // MI355X_LOGMEL / mi355x_logmel_config: 2 (default) = the register-FFT kernel (16 lanes per frame); 1 = the wave-synchronised
+  // radix-4 kernel, two frames in flight per wave; 0 = the round-1 kernel (A/B, tests).  An odd hop would misalign the register
+  // kernel's 8-byte frame reads: it takes the radix-4 kernel.
+  int variant = logmel_variant();
+  if (variant == 2 && ((hop & 1) || seg + 1 > 4 * 4 * R16_XP * 2)) variant = 1;
   constexpr int FPW = 2;
   const size_t common = ((seg + 3) & ~3) + NFFT + 2 * NH + (size_t)n_mels * (MEL_FR + 1);
-  const size_t shm = sizeof(float) * (common + (variant ? 4 * FPW * NH * 2 + 4 * FPW * 260 + FB_CAP + 4 + 3 * (size_t)n_mels : 4 * 2 * NH * 2 + 4 * 260));
+  size_t extra;
+  if (variant == 2) extra = 4 * 4 * R16_XP * 2 + FB_CAP + 4 + 3 * (size_t)n_mels;  // (the staging image of seg + 1 floats lives in the transpose buffers)
+  else if (variant == 1) extra = 4 * FPW * NH * 2 + 4 * FPW * 260 + FB_CAP + 4 + 3 * (size_t)n_mels;
+  else extra = 4 * 2 * NH * 2 + 4 * 260;
+  const size_t shm = sizeof(float) * (common + extra);
   if (shm > 160 * 1024) return MI_ERR_ARG;
   dim3 grid((T + MEL_FR - 1) / MEL_FR, B), block(256);
-  const void* fn = variant ? (const void*)logmel_wave_kernel<FPW> : (const void*)logmel_kernel;
+  const void* fn = variant == 2 ? (const void*)logmel_r16_kernel : variant ? (const void*)logmel_wave_kernel<FPW> : (const void*)logmel_kernel;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {
     (void)hipGetLastError();
     return MI_ERR_LAUNCH;
   }
 #define LOGMEL_ARGS (const float*)audio, (const long long*)audio_len, (const float*)window, win, hop, (const int*)fb_start, \
     (const int*)fb_len, (const int*)fb_off, (const float*)fb_w, n_mels, preemph, dither, seed, log_guard, (float*)out, B, S, T
-  if (variant) MI_LAUNCH(logmel_wave_kernel<FPW>, grid, block, shm, (hipStream_t)stream, LOGMEL_ARGS);
+  if (variant == 2) MI_LAUNCH(logmel_r16_kernel, grid, block, shm, (hipStream_t)stream, LOGMEL_ARGS);
+  else if (variant) MI_LAUNCH(logmel_wave_kernel<FPW>, grid, block, shm, (hipStream_t)stream, LOGMEL_ARGS);
   else MI_LAUNCH(logmel_kernel, grid, block, shm, (hipStream_t)stream, LOGMEL_ARGS);
 #undef LOGMEL_ARGS
   return mi_check_launch();

@@ -48,7 +48,9 @@ def slaney_mel_filterbank(sr, n_fft, n_mels, fmin=0.0, fmax=None, norm="slaney")
 
 
 def sparsify_filterbank(fb: torch.Tensor):
-    """fb [n_mels, n_bins] -> (start i32 [n_mels], len i32, offset i32, weights f32): per-row non-zero span."""
+    """fb [n_mels, n_bins] -> (start i32 [n_mels], len i32, offset i32, weights f32): per-row non-zero span.  Every row's weights
+    start at a multiple of four floats and are zero-filled up to the next one: the front-end kernel reads them as 16-byte
+    vectors without end-of-filter checks (csrc/mel.hip; a zero weight meets a finite power)."""
     fbn = fb.detach().float().cpu().numpy().reshape(fb.shape[-2], fb.shape[-1])
     starts, lens, offs, ws = [], [], [], []
     o = 0
@@ -58,10 +60,11 @@ def sparsify_filterbank(fb: torch.Tensor):
             s, n = 0, 0
         else:
             s, n = int(nz[0]), int(nz[-1] - nz[0] + 1)
+        n4 = (n + 3) // 4 * 4
         starts.append(s); lens.append(n); offs.append(o)
-        ws.append(row[s: s + n])
-        o += n
-    w = np.concatenate(ws) if o > 0 else np.zeros(1, np.float32)
+        ws.append(np.concatenate([row[s: s + n], np.zeros(n4 - n, row.dtype)]))
+        o += n4
+    w = np.concatenate(ws) if o > 0 else np.zeros(4, np.float32)
     return (torch.tensor(starts, dtype=torch.int32), torch.tensor(lens, dtype=torch.int32),
             torch.tensor(offs, dtype=torch.int32), torch.from_numpy(w.astype(np.float32)))
 

@@ -1098,10 +1098,12 @@ def test_logmel_ragged_and_padding_invariance():
 
 @pytest.mark.parametrize("S,dither", [(16000 + 37, 0.0), (48000, 1e-5), (331, 1e-5), (160 * 64, 0.0)])
 def test_logmel_wave_synchronised_kernel_against_the_round_1_kernel(S, dither):
-    """csrc/mel.hip: the default front-end kernel (wave-local hand-overs instead of workgroup barriers, in-place radix-4 stages, two
-    frames in flight per wave, filterbank in LDS) against the round-1 kernel on the same input -- ragged lengths, a clip shorter
-    than one window, dither on (counter-based: the same noise both ways).  Same arithmetic up to fused-multiply-add contraction,
-    so the log-mel values agree to a few ulp; and the wave-local hand-overs must be RACE-FREE: five runs, identical bits."""
+    """csrc/mel.hip: the default front-end kernel (round 6: FFT in registers, 16 lanes per frame, one LDS transpose, the dither
+    evaluated once per sample) and the round-4 kernel (wave-local hand-overs instead of workgroup barriers, in-place radix-4 stages)
+    against the round-1 kernel on the same input -- ragged lengths, a clip shorter than one window, dither on (counter-based: the
+    same noise every way).  The radix-4 kernels share their arithmetic up to fused-multiply-add contraction; the register kernel is
+    the same DFT in another summation order (fp32: ~1e-6 relative on the powers).  The wave-local hand-overs must be RACE-FREE:
+    five runs of each, identical bits."""
     o = ops()
     from nemo_amd._lib import lib
     g = torch.Generator().manual_seed(S)
@@ -1111,7 +1113,7 @@ def test_logmel_wave_synchronised_kernel_against_the_round_1_kernel(S, dither):
     outs = []
     prev = lib.mi355x_logmel_config(-1)
     try:
-        for variant in (0, 1, 1, 1, 1, 1):
+        for variant in (0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2):
             lib.mi355x_logmel_config(variant)
             raw = torch.full((3, 80, 1 + S // 160), float("nan"), device=dev)
             o.logmel(audio, alen, win, fb, 80, dither=dither, seed=123, out=raw)
@@ -1119,12 +1121,16 @@ def test_logmel_wave_synchronised_kernel_against_the_round_1_kernel(S, dither):
             outs.append(raw.cpu())
     finally:
         lib.mi355x_logmel_config(prev)
-    assert prev == 1
-    assert torch.isfinite(outs[1]).all()
+    assert prev == 2
+    assert torch.isfinite(outs[1]).all() and torch.isfinite(outs[6]).all()
     for k in range(2, 6):
         assert torch.equal(outs[1], outs[k]), k
-    # log(power + 2^-24): values in [-16.6, ~10]; a differently contracted FFT moves a power by ~1e-6 relative
+    for k in range(7, 11):
+        assert torch.equal(outs[6], outs[k]), k
+    # log(power + 2^-24): values in [-16.6, ~10]; a differently contracted / ordered FFT moves a power by ~1e-6 relative
     err = (outs[0] - outs[1]).abs().max().item()
+    assert err < 1e-4, err
+    err = (outs[0] - outs[6]).abs().max().item()
     assert err < 1e-4, err
 
 
