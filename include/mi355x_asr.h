@@ -132,13 +132,17 @@ int mi355x_ffn_pack(const void* table_dev, int n_entries, int max_d_ff, void* st
 /* ---- log-mel front-end: FilterbankFeatures.forward, parts/preprocessing/features.py:423-502 --------------------
  * audio f32 [B,S], audio_len i64 [B] -> out f32 [B,n_mels,T] = log(mel_power + log_guard), T = 1 + S/hop.
  * fb_* = sparse rows of the (persistent) `fb` buffer: for mel m, weights fb_w[fb_off[m] .. +fb_len[m]) apply to FFT
- * bins fb_start[m]...  n_fft must be 512 (Hann window `window[win]` is centred in the FFT frame like torch.stft). */
+ * bins fb_start[m]...  n_fft must be 512 (Hann window `window[win]` is centred in the FFT frame like torch.stft).
+ * Any row layout is accepted; when every fb_off[m] is a multiple of 4 and fb_off[m+1] >= fb_off[m] + 4 * ceil(fb_len[m] / 4)
+ * the weights between a row's end and the next row's offset MUST be zero (the default kernel then reads them as 16-byte
+ * vectors without end-of-row checks; `sparsify_filterbank` lays them out so). */
 int mi355x_logmel_fwd(const void* audio, const void* audio_len, const void* window, int win, int hop, int n_fft,
                       const void* fb_start, const void* fb_len, const void* fb_off, const void* fb_w, int n_mels,
                       float preemph, float dither, unsigned seed, float log_guard, void* out, int B, int S, int T,
                       void* stream);
-/* which front-end kernel runs (tests and A/B): 1 (default) = the wave-synchronised kernel (frame-private work needs no workgroup
- * barrier, in-place radix-4 stages, two frames in flight per wave, filterbank in LDS; profiles/r4_logmel.md), 0 = the round-1 kernel.
+/* which front-end kernel runs (tests and A/B): 2 (default) = FFT in registers (16 lanes per frame, 16-point DFTs on a lane's own
+ * points, one LDS transpose, dither evaluated once per sample; profiles/r6_logmel.md; an odd hop takes variant 1), 1 = the
+ * wave-synchronised radix-4 kernel (two frames in flight per wave, filterbank in LDS; profiles/r4_logmel.md), 0 = the round-1 kernel.
  * variant < 0 only queries.  Returns the previous setting.  Environment: MI355X_LOGMEL.  (features.py:423-502) */
 int mi355x_logmel_config(int variant);
 /* normalize_batch(..., 'per_feature') + pad fill, features.py:59-93,490-493.  x f32 [B,n_mels,T] -> y (y_dtype) */
