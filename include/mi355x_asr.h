@@ -134,8 +134,7 @@ int mi355x_ffn_pack(const void* table_dev, int n_entries, int max_d_ff, void* st
  * fb_* = sparse rows of the (persistent) `fb` buffer: for mel m, weights fb_w[fb_off[m] .. +fb_len[m]) apply to FFT
  * bins fb_start[m]...  n_fft must be 512 (Hann window `window[win]` is centred in the FFT frame like torch.stft).
  * Any row layout is accepted; when every fb_off[m] is a multiple of 4 and fb_off[m+1] >= fb_off[m] + 4 * ceil(fb_len[m] / 4)
- * the weights between a row's end and the next row's offset MUST be zero (the default kernel then reads them as 16-byte
- * vectors without end-of-row checks; `sparsify_filterbank` lays them out so). */
+ * (`sparsify_filterbank` lays the rows out so) the default kernel reads a row as 16-byte vectors without end-of-row checks. */
 int mi355x_logmel_fwd(const void* audio, const void* audio_len, const void* window, int win, int hop, int n_fft,
                       const void* fb_start, const void* fb_len, const void* fb_off, const void* fb_w, int n_mels,
                       float preemph, float dither, unsigned seed, float log_guard, void* out, int B, int S, int T,

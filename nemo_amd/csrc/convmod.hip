@@ -255,12 +255,14 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const TT* __restrict__ 
 // dy [B,T,d], x [B,T,d]:  dx[t] = sum_k w[k] * dy[t + pad - k] ;  dw[c,k] += sum_{b,t} dy[t] * x[t+k-pad] ; dbias[c] += sum dy
 // grid (d/64, DW_SEG, B): one block walks the time tiles of its segment, one atomic per (c,k) per block at the end.
 #define DW_SEG 4
-template <typename TT, int KS, bool BN>
+template <typename TT, int KS, bool BN, bool ASYM = false>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ dy, const TT* __restrict__ x,
                                                          const float* __restrict__ w, TT* __restrict__ dx,
                                                          float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ partial, int B, int T, int d,
                                                          DwBnArgs bn) {
-  const int PADL = (KS - 1) / 2 + bn.pad_shift, PADR = KS - 1 - PADL;   // forward pads (left, right): y[t] = sum_k w[k] x[t + k - PADL]
+  // forward pads (left, right): y[t] = sum_k w[k] x[t + k - PADL].  The symmetric case keeps them compile-time constants (a run-time
+  // pad costs the depthwise backward 57 -> 88 us per launch: the dy value of the tap gradients then comes from LDS, not a register)
+  const int PADL = (KS - 1) / 2 + (ASYM ? bn.pad_shift : 0), PADR = KS - 1 - PADL;
   constexpr int ROWS = DW_TT + KS - 1;
   __shared__ __attribute__((aligned(16))) float big[2][ROWS][DW_LD];  // dy tile | x tile (also the final reduction buffer)
   float (*tdy)[DW_LD] = big[0];
@@ -309,7 +311,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const TT* __restrict__ 
 #pragma unroll
       for (int k = 0; k < KS; ++k) a = fmaf(wk[k], vdy[o + KS - 1 - k], a);
       otile[tg * DW_TQ + o][c_l] = a;
-      const float g = tdy[tg * DW_TQ + o + PADR][c_l];  // dy[t0 + o] (zero when t >= T: staging zero-fills); from LDS: PADR is a run-time number
+      // dy[t0 + o] (zero when t >= T: staging zero-fills); with a run-time pad from LDS
+      const float g = ASYM ? tdy[tg * DW_TQ + o + PADR][c_l] : vdy[o + (KS - 1) / 2];
 
       gb += g;
 #pragma unroll
@@ -911,8 +914,10 @@ extern "C" int mi355x_dwconv_bwd_ctx(const void* dy, const void* x, const void* 
     return mi_check_launch();
   }
   const DwBnArgs nobn = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, pad_shift};
-#define DW_BWD(KS) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS, false>), grid, block, 0, s, (const TT*)dy, \
-    (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d, nobn))
+#define DW_BWD(KS) do { if (pad_shift) { DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS, false, true>), grid, block, 0, s, (const TT*)dy, \
+    (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d, nobn)); } \
+  else { DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv_bwd_kernel<TT, KS, false, false>), grid, block, 0, s, (const TT*)dy, \
+    (const TT*)x, (const float*)w, (TT*)dx, (float*)dw, (float*)dbias, (float*)scratch, B, T, d, nobn)); } } while (0)
   switch (ksize) {
     case 31: DW_BWD(31); break;
     case 9: DW_BWD(9); break;

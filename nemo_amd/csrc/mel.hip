@@ -465,6 +465,11 @@ __global__ __launch_bounds__(256, 2) void logmel_r16_kernel(const float* __restr
     s_tw[tid] = (v2f){cs, sn};
   }
   const bool fbv = __syncthreads_and(fb_aligned) != 0 && fb_in_lds;  // (also the barrier between the two staging passes)
+  if (fbv)  // whatever the caller left between a row's end and the next multiple of four: the vector reads must meet zeros
+    for (int m = tid; m < n_mels; m += 256) {
+      const int n = s_fbi[n_mels + m], o = s_fbi[2 * n_mels + m];
+      for (int k = n; k < ((n + 3) & ~3); ++k) s_fbw[o + k] = 0.f;
+    }
   // ---- pass 2: pre-emphasis v[t] = n[t] - preemph * n[t-1] for t in [0, min(S, len)), 0 elsewhere (t = 0: n[-1] = 0)
   for (int i = tid; i < seg; i += 256) {
     const int t = t_base + i;

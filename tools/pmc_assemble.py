@@ -66,10 +66,12 @@ def main(src, dst, tag):
         if lm:
             o.write("\n`logmel_kernel` issues no MFMA (busy 0): it is a VALU radix FFT, see the traffic table for its HBM side.\n")
     # ---- the NT family (what bench.py's GEMM_PROFILE calls bf16_NT: !transA && !transB)
-    nt = [r for r in rows if ("gemm_bf16_v5" in r[0] or "ILb0ELb0E" in r[0]) and "grouped" not in r[0]]
+    def is_nt(name):  # v2 / v4 <TA = 0, TB = 0, ..>, the persistent v5, v8 <G, TN = 0, AH>
+        return ("gemm_bf16_v5" in name or "ILb0ELb0E" in name or ("gemm_bf16_v8" in name and "ELb0ELi" in name)) and "grouped" not in name
+    nt = [r for r in rows if is_nt(r[0])]
     n_l = sum(r[1] for r in nt)
     traffic = sum((r[2] + r[3]) * r[1] for r in nt) / n_l
-    mnt = [r for r in mrows if ("gemm_bf16_v5" in r[0] or "ILb0ELb0E" in r[0]) and "grouped" not in r[0]]
+    mnt = [r for r in mrows if is_nt(r[0])]
     busy = sum(r[2] * r[1] for r in mnt) / sum(1024.0 * r[3] * r[1] for r in mnt)
     json.dump({"kernel": "gemm_bf16_NT", "traffic_bytes_per_launch": int(traffic), "launches_sampled": n_l,
                "source_sha256_16": src_hash,
