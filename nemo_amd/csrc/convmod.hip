@@ -679,7 +679,10 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_reduce_kernel(const TT* __re
                                                                   long long M, int d, int rows_per_blk) {
   // thread = V consecutive channels (one 16-byte load per tensor per row) x every RS-th row of the workgroup's row block
   constexpr int V = VecIO<TT>::V;
-  __shared__ float sred[2][256 * V];
+  // ONE reduction slab (8 KiB for bf16), used for the two sums one after the other: with two slabs (16 KiB) this kernel missed
+  // sharing a CU with the 144-KiB weight-gradient workgroups of the side stream by exactly 1 KiB (LDS of co-resident workgroups must
+  // sum to < 160 KiB: tools/probe/coreside_probe.hip) and ran 94 us instead of 13.5 us inside the step
+  __shared__ float sred[256 * V];
   const int CP = min(d / V, 256);          // channel chunks per pass
   const int RS = 256 / CP;                 // rows in flight per pass
   const int ck = threadIdx.x % CP, rsub = threadIdx.x / CP;
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_reduce_kernel(const TT* __re
       float mu[V], rs[V], g[V], bt[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; g[j] = gamma[c + j]; bt[j] = beta[c + j]; }
-#pragma unroll 4
+#pragma unroll 3   // (4 rows in flight need 162 VGPRs; beside two 176-register weight-gradient waves a SIMD has 160 left)
       for (long long r = r0 + rsub; r < r1; r += RS) {
         float xv[V], dv[V];
         VecIO<TT>::load(x + r * d + c, xv);
@@ -706,20 +709,18 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_reduce_kernel(const TT* __re
         }
       }
     }
-    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < V; ++j) { sred[0][threadIdx.x * V + j] = a1[j]; sred[1][threadIdx.x * V + j] = a2[j]; }
-    __syncthreads();
-    for (int e = threadIdx.x; e < CP * V; e += 256) {  // e = channel inside this pass
-      float t1 = 0.f, t2 = 0.f;
-      for (int q = 0; q < RS; ++q) { t1 += sred[0][q * CP * V + e]; t2 += sred[1][q * CP * V + e]; }
-      if (c0 + e < d) {
-        if (partial) {
-          partial[((long long)blockIdx.y * 2 + 0) * d + c0 + e] = t1;
-          partial[((long long)blockIdx.y * 2 + 1) * d + c0 + e] = t2;
-        } else {
-          atomicAdd(sums + c0 + e, (double)t1);
-          atomicAdd(sums + d + c0 + e, (double)t2);
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < V; ++j) sred[threadIdx.x * V + j] = which ? a2[j] : a1[j];
+      __syncthreads();
+      for (int e = threadIdx.x; e < CP * V; e += 256) {  // e = channel inside this pass
+        float t = 0.f;
+        for (int q = 0; q < RS; ++q) t += sred[q * CP * V + e];
+        if (c0 + e < d) {
+          if (partial) partial[((long long)blockIdx.y * 2 + which) * d + c0 + e] = t;
+          else atomicAdd(sums + which * d + c0 + e, (double)t);
         }
       }
     }
