@@ -24,6 +24,7 @@ device timeline (profiles/r3_host_issue.md); the tape keeps the live-launch time
 from __future__ import annotations
 
 import contextlib
+import gc
 import ctypes
 from typing import Callable, List, Optional, Tuple, Union
 
@@ -110,6 +111,14 @@ class SegmentedCapture:
         """with cap.capturing(): run the launch sequence once; it is recorded, not executed"""
         self._before_cut = before_cut
         torch.cuda.synchronize(self.device)
+        # What `torch.cuda.graph.__enter__` does, for the same reason: garbage that holds device resources (an earlier recording's
+        # graph, its private pool, a tape's events) must be destroyed BEFORE the capture -- a finaliser that frees a pool while this
+        # thread is capturing throws inside a destructor and aborts the process (seen once in the closing run of round 6:
+        # "Fatal Python error: Aborted ... Garbage-collecting" under ops.gemm inside _capture_forward) -- and the cyclic collector
+        # stays off until the capture has ended.
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         stream = capture_stream(self.device)
         if self.tape:
             from ._lib import lib
@@ -135,6 +144,8 @@ class SegmentedCapture:
         finally:
             if self.tape:
                 lib.mi355x_tape_log_end()
+            if gc_was_on:
+                gc.enable()
         torch.cuda.synchronize(self.device)
 
     def _make_tapes(self) -> None:

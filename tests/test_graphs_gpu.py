@@ -60,6 +60,15 @@ def _run(over, graphs, steps, batches, dtype=torch.float32, lr=1e-3, seed=21, ho
     return model, losses
 
 
+def _same_trajectory(l_a, l_b, base=5e-5, growth=0.25):
+    """two runs of the same training steps that differ only in HOW the launches were issued.  The weight gradients accumulate
+    through fp32 atomics (split-K slices, tap / bias partials): their order, hence the last bits, depend on the timing, and a
+    trajectory amplifies that from step to step (seen: 6.4e-5 relative at step 30 of 32, one run in three) -- so the tolerance starts
+    at `base` and grows by `growth` x base per step.  A replay that reads a wrong arena address is off by orders of magnitude."""
+    for i, (a, b) in enumerate(zip(l_a, l_b)):
+        assert abs(a - b) <= base * (1.0 + growth * i) * abs(b), (i, l_a, l_b)
+
+
 @pytest.mark.parametrize("replay", REPLAYS)
 def test_recorded_sequence_is_the_eager_sequence_fp32(replay):
     over = dict(d_model=64, n_heads=4, n_layers=3, **NODROP)
@@ -169,8 +178,7 @@ def test_each_batch_shape_gets_its_own_recording(replay):
     m_e, l_e = _run(over, False, 10, batches)
     assert len(m_g.encoder.graph_info()) == 2
     _check_replay_kind(m_g.encoder.graph_info(), replay)
-    for a, b in zip(l_g, l_e):
-        assert abs(a - b) <= 5e-5 * abs(b), (l_g, l_e)
+    _same_trajectory(l_g, l_e)
 
 
 def _step_grads(model, batch):
@@ -321,8 +329,7 @@ def test_auto_mode_times_both_ways_and_keeps_one():
     info = m.encoder.graph_info()
     assert len(info) == 1 and str(info[0]["decided"]).split()[0] in ("eager", "graph") and info[0]["auto"] is not None, info
     m_e, l_e = _run(over, False, 16, batches)
-    for a, b in zip(losses, l_e):
-        assert abs(a - b) <= 5e-5 * abs(b), (losses, l_e)
+    _same_trajectory(losses, l_e)
 
 
 def test_many_padded_lengths_share_the_arena_and_stay_the_eager_sequence():
@@ -353,8 +360,7 @@ def test_many_padded_lengths_share_the_arena_and_stay_the_eager_sequence():
     assert m_g.encoder.graphs_recorded()
     # 5 lengths x 2 warm-up visits + the recording visits are the only live ones; everything after replays
     assert m_g.encoder.replayed_steps >= len(order) - 3 * 5 and m_g.encoder.live_steps <= 2 * 5, (m_g.encoder.replayed_steps, m_g.encoder.live_steps)
-    for a, b in zip(l_g, l_e):
-        assert abs(a - b) <= 5e-5 * abs(b), (l_g, l_e)
+    _same_trajectory(l_g, l_e)
 
 
 def test_auto_mode_decides_once_per_configuration_not_once_per_padded_length():
@@ -375,5 +381,4 @@ def test_auto_mode_decides_once_per_configuration_not_once_per_padded_length():
     assert enc.graphs_settled() and enc.graphs_recorded()
     m_e, l_e = _run(over, False, 0, batches)
     l_e = [m_e.fit_step(batches[i])["loss"].item() for i in order]
-    for a, b in zip(losses, l_e):
-        assert abs(a - b) <= 5e-5 * abs(b), (losses, l_e)
+    _same_trajectory(losses, l_e)
