@@ -171,6 +171,45 @@ __device__ __forceinline__ void drop_mask8(const DropCfg& d, uint32_t idx8, floa
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s = xorshift32(s); m[j] = s >= d.threshold ? d.scale : 0.f; }
 }
+// the same masks for a run that starts in the MIDDLE of a hash group (idx % 8 == 4): a matrix whose width is 4 modulo 8
+// (Squeezeformer-Medium: d = 324) starts every other row there.  Elements idx .. idx+3 are outputs 5..8 of their group's stream,
+// idx+4 .. idx+7 outputs 1..4 of the next group's -- exactly what drop_mask() defines; any other offset takes the scalar form.
+__device__ __forceinline__ void drop_mask8u(const DropCfg& d, uint32_t idx, float (&m)[8]) {
+  if (d.threshold == 0u || (idx & 7u) == 0u) { drop_mask8(d, idx, m); return; }
+  if ((idx & 7u) == 4u) {
+    uint32_t s = drop_group_seed(d, idx >> 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s = xorshift32(s);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s = xorshift32(s); m[j] = s >= d.threshold ? d.scale : 0.f; }
+    s = drop_group_seed(d, (idx >> 3) + 1u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s = xorshift32(s); m[4 + j] = s >= d.threshold ? d.scale : 0.f; }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = drop_mask(d, idx + j);
+}
+__device__ __forceinline__ void drop_mask4u(const DropCfg& d, uint32_t idx, float (&m)[4]) {
+  if (d.threshold == 0u) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = 1.f;
+    return;
+  }
+  const uint32_t o = idx & 7u;
+  if (o == 0u || o == 4u) {
+    uint32_t s = drop_group_seed(d, idx >> 3);
+    if (o) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s = xorshift32(s);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s = xorshift32(s); m[j] = s >= d.threshold ? d.scale : 0.f; }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) m[j] = drop_mask(d, idx + j);
+}
 // standard normal from a counter (Box-Muller on two hashed uniforms) -- dither noise in the mel front-end
 __device__ __forceinline__ float hash_normal(uint32_t key, uint32_t idx) {
   uint32_t a = mix32(mix32(idx ^ key) + 0x9E3779B9u);

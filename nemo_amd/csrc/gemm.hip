@@ -188,11 +188,7 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, int z, long long coff,
   }
   const uint32_t didx = (uint32_t)z * (uint32_t)(p.M * p.N) + (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
   float dm[8];
-  if ((didx & 7u) == 0u) drop_mask8(p.drop, didx, dm);
-  else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dm[j] = drop_mask(p.drop, didx + j);
-  }
+  drop_mask8u(p.drop, didx, dm);  // (a width of 4 modulo 8 starts every other row in the middle of a hash group)
   switch (p.epi) {
     case EPI_STORE:
 #pragma unroll
@@ -250,16 +246,138 @@ __device__ __forceinline__ void epilogue8(const GemmP& p, int z, long long coff,
 }
 
 
+// ---- 4-wide form of the above for the last columns of a matrix whose width is 4 modulo 8 (16-byte f32 / 8-byte bf16 accesses;
+// `vec_ok & 2`): d = 324 outputs paid four scalar epilogues -- each with its own 64-bit address arithmetic and full mask hash -- per
+// row for them, and every tile of the launch waited for the column block that holds them
+__device__ __forceinline__ void ld4x(const void* p, long long i, int dt, float (&v)[4]) {
+  if (dt == MI_DT_F32) {
+    const float4 a = *reinterpret_cast<const float4*>((const float*)p + i);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  } else {
+    const u32x2 t = *reinterpret_cast<const u32x2*>((const bf16_t*)p + i);
+    v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+    v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void st4x(void* p, long long i, int dt, const float (&v)[4]) {
+  if (dt == MI_DT_F32) *reinterpret_cast<float4*>((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+  else {
+    u32x2 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    *reinterpret_cast<u32x2*>((bf16_t*)p + i) = t;
+  }
+}
+__device__ __forceinline__ void epilogue4(const GemmP& p, int z, long long coff, int m, int n, float (&v)[4]) {
+  const long long mr = crow(p, m);
+  const long long ci = coff + mr * p.ldc + n;
+  const long long ai = coff + mr * p.ldaux + n;
+  if (p.bias) {
+    float b[4];
+    ld4x(p.bias, n, MI_DT_F32, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += b[j];
+  }
+  const uint32_t didx = (uint32_t)z * (uint32_t)(p.M * p.N) + (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+  float dm[4];
+  drop_mask4u(p.drop, didx, dm);
+  switch (p.epi) {
+    case EPI_STORE:
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] *= p.alpha * dm[j];
+      break;
+    case EPI_SWISH_DROP:
+      if (p.swish_g) {
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) swish_pair(v[j], dm[j], v[j], g[j]);
+        st4x(p.aux_out, ai, p.auxout_dt, g);
+      } else {
+        st4x(p.aux_out, ai, p.auxout_dt, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = swishf_(v[j]) * dm[j];
+      }
+      break;
+    case EPI_RESID: {
+      float r[4];
+      ld4x(p.aux_in, ai, MI_DT_F32, r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = r[j] + p.alpha * v[j] * dm[j];
+    } break;
+    case EPI_DSWISH: {
+      float h[4];
+      ld4x(p.aux_in, ai, p.auxin_dt, h);
+      if (p.swish_g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= h[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * dm[j] * swish_grad(h[j]);
+      }
+    } break;
+    case EPI_RELU_MASK: {
+      const int b = m / p.rows_per_b;
+      const int t = (m - b * p.rows_per_b) / p.rows_inner;
+      const bool ok = (long long)t < p.row_len[b];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (ok && v[j] > 0.f) ? v[j] : 0.f;
+    } break;
+    case EPI_MUL_POS: {
+      float h[4];
+      ld4x(p.aux_in, ai, p.auxin_dt, h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = h[j] > 0.f ? v[j] : 0.f;
+    } break;
+  }
+  if (p.atomic) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(&((float*)p.C)[ci + j], v[j]);
+  } else {
+    st4x(p.C, ci, p.c_dt, v);
+  }
+}
+// one 8-column chunk of a row, however many of its columns exist: 8-wide, 4-wide + scalars, or scalars
+__device__ __forceinline__ void epilogue_chunk(const GemmP& p, int z, long long coff, int m, int n, float (&v)[8]) {
+  const int nv = p.N - n;
+  if ((p.vec_ok & 1) && nv >= 8) { epilogue8(p, z, coff, m, n, v); return; }
+  int j0 = 0;
+  if ((p.vec_ok & 2) && nv >= 4) {
+    float w[4] = {v[0], v[1], v[2], v[3]};
+    epilogue4(p, z, coff, m, n, w);
+    j0 = 4;
+    if ((p.vec_ok & 2) && nv >= 8) {
+      float w2[4] = {v[4], v[5], v[6], v[7]};
+      epilogue4(p, z, coff, m, n + 4, w2);
+      return;
+    }
+  }
+  for (int j = j0; j < 8; ++j)
+    if (n + j < p.N) epilogue(p, z, coff, m, n + j, v[j]);
+}
+
+
 // ---- streamlined epilogue of a full-width tile whose f32 image sits in LDS ([rows][BN+4]).  One thread = 8 consecutive
 // columns of ROWS_IT rows; the epilogue kind is a compile-time constant, bias is loaded once, all aux_in loads are issued
 // before the first LDS read.  Same arithmetic as epilogue8() (bit-identical results).
-template <int EPI, int ITERS, int ROW_STEP, int TW = BN>
+template <int EPI, int ITERS, int ROW_STEP, int TW = BN, bool UNAL = false, bool PART = false>
 __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, int z, long long coff, int m_first, int n0,
                                               int row_l0) {
   constexpr int LDS_C = TW + 4;
   constexpr bool AUX_IN = EPI == EPI_RESID || EPI == EPI_DSWISH || EPI == EPI_MUL_POS;
   const int c8 = (threadIdx.x & (TW / 8 - 1)) * 8;
   const int n = n0 + c8;
+  if (PART) {  // the matrix ends inside this tile (N % 4 == 0): a thread's chunk is whole, the last four columns, or outside
+    if (n >= p.N) return;
+    if (n + 8 > p.N) {
+#pragma unroll 2
+      for (int it = 0; it < ITERS; ++it) {
+        const int m = m_first + it * ROW_STEP;
+        if (m >= p.M) break;
+        const float4 a = *reinterpret_cast<const float4*>(sC + (row_l0 + it * ROW_STEP) * LDS_C + c8);
+        float w[4] = {a.x, a.y, a.z, a.w};
+        epilogue4(p, z, coff, m, n, w);
+      }
+      return;
+    }
+  }
   float b8[8];
   if (p.bias) ld8x(p.bias, n, MI_DT_F32, b8);
   else {
@@ -311,7 +429,8 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
     const float4 a = ra[it], b = rb[it];
     float v[8] = {a.x + b8[0], a.y + b8[1], a.z + b8[2], a.w + b8[3], b.x + b8[4], b.y + b8[5], b.z + b8[6], b.w + b8[7]};
     float dm[8];
-    drop_mask8(p.drop, db_l + (uint32_t)it * db_s, dm);
+    if (UNAL) drop_mask8u(p.drop, db_l + (uint32_t)it * db_s, dm);   // width 4 modulo 8: every other row starts inside a hash group
+    else drop_mask8(p.drop, db_l + (uint32_t)it * db_s, dm);
     const long long mrow = lin ? 0 : crow(p, m);
     const long long ci = lin ? ci_l + it * ci_s : coff + mrow * p.ldc + n;
     const long long ai = lin ? ai_l + it * ai_s : coff + mrow * p.ldaux + n;
@@ -357,16 +476,16 @@ __device__ __forceinline__ void fast_epilogue(const GemmP& p, const float* sC, i
 #endif
   }
 }
-template <int ITERS, int ROW_STEP, int TW = BN>
+template <int ITERS, int ROW_STEP, int TW = BN, bool UNAL = false, bool PART = false>
 __device__ __forceinline__ void fast_epilogue_any(const GemmP& p, const float* sC, int z, long long coff, int m_first, int n0,
                                                   int row_l0) {
   switch (p.epi) {
-    case EPI_STORE: fast_epilogue<EPI_STORE, ITERS, ROW_STEP, TW>(p, sC, z, coff, m_first, n0, row_l0); break;
-    case EPI_SWISH_DROP: fast_epilogue<EPI_SWISH_DROP, ITERS, ROW_STEP, TW>(p, sC, z, coff, m_first, n0, row_l0); break;
-    case EPI_RESID: fast_epilogue<EPI_RESID, ITERS, ROW_STEP, TW>(p, sC, z, coff, m_first, n0, row_l0); break;
-    case EPI_DSWISH: fast_epilogue<EPI_DSWISH, ITERS, ROW_STEP, TW>(p, sC, z, coff, m_first, n0, row_l0); break;
-    case EPI_RELU_MASK: fast_epilogue<EPI_RELU_MASK, ITERS, ROW_STEP, TW>(p, sC, z, coff, m_first, n0, row_l0); break;
-    default: fast_epilogue<EPI_MUL_POS, ITERS, ROW_STEP, TW>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_STORE: fast_epilogue<EPI_STORE, ITERS, ROW_STEP, TW, UNAL, PART>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_SWISH_DROP: fast_epilogue<EPI_SWISH_DROP, ITERS, ROW_STEP, TW, UNAL, PART>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_RESID: fast_epilogue<EPI_RESID, ITERS, ROW_STEP, TW, UNAL, PART>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_DSWISH: fast_epilogue<EPI_DSWISH, ITERS, ROW_STEP, TW, UNAL, PART>(p, sC, z, coff, m_first, n0, row_l0); break;
+    case EPI_RELU_MASK: fast_epilogue<EPI_RELU_MASK, ITERS, ROW_STEP, TW, UNAL, PART>(p, sC, z, coff, m_first, n0, row_l0); break;
+    default: fast_epilogue<EPI_MUL_POS, ITERS, ROW_STEP, TW, UNAL, PART>(p, sC, z, coff, m_first, n0, row_l0); break;
   }
 }
 
@@ -597,11 +716,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
         const float4 a = *reinterpret_cast<const float4*>(sC + row_l * LDS_C + c8);
         const float4 b = *reinterpret_cast<const float4*>(sC + row_l * LDS_C + c8 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        if ((p.vec_ok & 1) && n + 8 <= p.N) epilogue8(p, z, coff, m, n, v);
-        else {
-          for (int j = 0; j < 8; ++j)
-            if (n + j < p.N) epilogue(p, z, coff, m, n + j, v[j]);
-        }
+        epilogue_chunk(p, z, coff, m, n, v);
       }
     }
   }
@@ -1180,9 +1295,18 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
     }
     return;
   }
-  if ((p.vec_ok & 1) && !(p.N & 7) && n0 + BN <= p.N) {
-    fast_epilogue_any<8, 32>(p, sC, z, coff, m0 + (threadIdx.x >> 4), n0, threadIdx.x >> 4);
-    return;
+  if ((p.vec_ok & 1) && !(p.N & 3)) {
+    // N = 4 (mod 8): the dropout runs of every other row start unaligned; a tile the matrix ends in: per-thread column guard
+    // (both only in the instances that need them: the common case keeps its instruction stream)
+    if (n0 + BN <= p.N) {
+      if (p.N & 7) fast_epilogue_any<8, 32, BN, true>(p, sC, z, coff, m0 + (threadIdx.x >> 4), n0, threadIdx.x >> 4);
+      else fast_epilogue_any<8, 32>(p, sC, z, coff, m0 + (threadIdx.x >> 4), n0, threadIdx.x >> 4);
+      return;
+    }
+    if (p.vec_ok & 2) {
+      fast_epilogue_any<8, 32, BN, true, true>(p, sC, z, coff, m0 + (threadIdx.x >> 4), n0, threadIdx.x >> 4);
+      return;
+    }
   }
 #pragma unroll 2
   for (int it = 0; it < 8; ++it) {
@@ -1194,11 +1318,7 @@ __device__ __forceinline__ void gemm_v2_body(const GemmP& p, bf16_t* smem2, cons
       const float4 a = *reinterpret_cast<const float4*>(sC + row_l * LDS_C + c8);
       const float4 b = *reinterpret_cast<const float4*>(sC + row_l * LDS_C + c8 + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-      if ((p.vec_ok & 1) && n + 8 <= p.N) epilogue8(p, z, coff, m, n, v);
-      else {
-        for (int j = 0; j < 8; ++j)
-          if (n + j < p.N) epilogue(p, z, coff, m, n + j, v[j]);
-      }
+      epilogue_chunk(p, z, coff, m, n, v);
     }
   }
 }
@@ -1297,11 +1417,7 @@ __device__ __forceinline__ void v4_round_out(const GemmP& p, const float* sC, in
         const float4 a = *reinterpret_cast<const float4*>(sC + rl * LDS_C + c8);
         const float4 b = *reinterpret_cast<const float4*>(sC + rl * LDS_C + c8 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        if ((p.vec_ok & 1) && n + 8 <= p.N) epilogue8(p, z, coff, m, n, v);
-        else {
-          for (int j = 0; j < 8; ++j)
-            if (n + j < p.N) epilogue(p, z, coff, m, n + j, v[j]);
-        }
+        epilogue_chunk(p, z, coff, m, n, v);
       }
     }
   }
@@ -1383,7 +1499,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v4_kernel(GemmP p) {
     // row beyond its utterance's length (conv1's output is masked there), so such rows are zero too -- written through the row map.
     const bool mask_tile = p.epi == EPI_RELU_MASK && !p.r_on;
     const bool gate_tile = p.epi == EPI_MUL_POS && p.row_len != nullptr;
-    if ((mask_tile || gate_tile) && p.splitk <= 1 && !p.aux_out && p.c_dt == MI_DT_BF16 && p.csc == 1 && p.vec_ok && !(p.N & 7)) {
+    if ((mask_tile || gate_tile) && p.splitk <= 1 && !p.aux_out && p.c_dt == MI_DT_BF16 && p.csc == 1 && (p.vec_ok & 1) && !(p.N & 7)) {
       const int mlast = min(m0 + BM2, p.M) - 1;
       const int b0 = m0 / p.rows_per_b, b1 = mlast / p.rows_per_b;
       const int t0 = (m0 - b0 * p.rows_per_b) / p.rows_inner;
@@ -1922,7 +2038,7 @@ __device__ __forceinline__ void gemm_v8_body(const GemmP& p, bf16_t* smem8, cons
     // K loop -- same rule as the third structure
     const bool mask_tile = p.epi == EPI_RELU_MASK && !p.r_on;
     const bool gate_tile = p.epi == EPI_MUL_POS && p.row_len != nullptr;
-    if ((mask_tile || gate_tile) && p.splitk <= 1 && !p.aux_out && p.c_dt == MI_DT_BF16 && p.csc == 1 && p.vec_ok && !(p.N & 7)) {
+    if ((mask_tile || gate_tile) && p.splitk <= 1 && !p.aux_out && p.c_dt == MI_DT_BF16 && p.csc == 1 && (p.vec_ok & 1) && !(p.N & 7)) {
       const int mlast = min(m0 + BMT, p.M) - 1;
       const int b0 = m0 / p.rows_per_b, b1 = mlast / p.rows_per_b;
       const int t0 = (m0 - b0 * p.rows_per_b) / p.rows_inner;
@@ -3087,11 +3203,18 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
   sk = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
   p.splitk = sk;
   {
-    bool ok = p.csc == 1 && !(p.ldc & 7) && !((uintptr_t)p.C & 31) && !(p.sC0 & 7) && !(p.sC1 & 7);
-    if (p.aux_in) ok = ok && !(p.ldaux & 7) && !((uintptr_t)p.aux_in & 31);
-    if (p.aux_out) ok = ok && !(p.ldaux & 7) && !((uintptr_t)p.aux_out & 31);
-    if (p.bias) ok = ok && !((uintptr_t)p.bias & 31);
-    p.vec_ok = ok ? 1 : 0;
+    // bit 0: 8-column chunks as vectors (f32 rows: two 16-byte accesses, pitch % 4 == 0; bf16 rows: one, pitch % 8 == 0);
+    // bit 1: 4-column chunks as vectors (16-byte f32 / 8-byte bf16: pitch % 4 == 0) -- the last columns of a width of 4 modulo 8
+    const int auxin_dt = p.epi == EPI_RESID ? MI_DT_F32 : p.auxin_dt;
+    auto pitch8 = [](long long ld, int dt) { return dt == MI_DT_F32 ? !(ld & 3) : !(ld & 7); };
+    bool base = p.csc == 1 && !((uintptr_t)p.C & 31) && !(p.sC0 & 7) && !(p.sC1 & 7);
+    if (p.aux_in) base = base && !((uintptr_t)p.aux_in & 31);
+    if (p.aux_out) base = base && !((uintptr_t)p.aux_out & 31);
+    if (p.bias) base = base && !((uintptr_t)p.bias & 31);
+    bool ok = base && pitch8(p.ldc, p.c_dt), ok4 = base && !(p.ldc & 3);
+    if (p.aux_in) { ok = ok && pitch8(p.ldaux, auxin_dt); ok4 = ok4 && !(p.ldaux & 3); }
+    if (p.aux_out) { ok = ok && pitch8(p.ldaux, p.auxout_dt); ok4 = ok4 && !(p.ldaux & 3); }
+    p.vec_ok = (ok ? 1 : 0) | (ok4 ? 2 : 0);
 #ifdef GEMM_ABLATE
     { const char* e = getenv("MI355X_GEMM_DBG"); if (e) p.vec_ok |= atoi(e) << 8; }
 #endif

@@ -304,6 +304,49 @@ def test_gemm_dropout_consistency():
     assert torch.allclose(m2[m2 > 0], torch.tensor(1 / 0.75, device=dev))
 
 
+@pytest.mark.parametrize("M", [100, 700])
+def test_gemm_width_4_mod_8_vector_tail_and_unaligned_dropout_runs(M):
+    """N = 324 (Squeezeformer-Medium's d_model): the last four columns go out as one 4-wide access, full-width tiles take the
+    templated epilogue although every other row starts its dropout run in the middle of a hash group, f32 rows of pitch 324 count
+    as vector-aligned (csrc/gemm.hip: epilogue4 / epilogue_chunk / drop_mask8u).  M = 100: the 128x128 structure, 700: 256x128.
+    Masks must be the ones drop_scale_cast regenerates for idx = m * N + n; pad columns of a pitched C stay untouched."""
+    o = ops()
+    N, K, ldp = 324, 136, 328
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev); W = (torch.randn(N, K, generator=g) / 8).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = A.float() @ W.float().t() + bias
+    drop = o.Dropout(0.25, seed=11, site=5)
+    ones = torch.ones(M, N, device=dev); mask = torch.empty(M, N, device=dev)
+    o.drop_scale_cast(ones, mask, M * N, 1.0, drop)
+    # (a) bf16 C with pitch 328, bias + dropout
+    C = torch.full((M, ldp), float("nan"), device=dev, dtype=torch.bfloat16)
+    o.gemm(A, W, C, M, N, K, K, K, ldp, bias=bias, drop=drop)
+    torch.cuda.synchronize()
+    assert torch.isnan(C[:, N:].float()).all(), "pad columns written"
+    assert rel_err(C[:, :N].float(), ref * mask) < 6e-3
+    assert ((C[:, :N].float() == 0) == (mask == 0)).all()
+    # (b) f32 residual epilogue, C and aux rows of pitch 324
+    R = torch.randn(M, N, generator=g).to(dev); C2 = torch.empty(M, N, device=dev)
+    o.gemm(A, W, C2, M, N, K, K, K, N, bias=bias, alpha=0.5, epi=o.EPI_RESID, aux_in=R, drop=drop)
+    torch.cuda.synchronize()
+    assert rel_err(C2, R + 0.5 * ref * mask) < 1e-3
+    # (c) Swish + dropout with the second (bf16, pitched) output
+    H = torch.full((M, ldp), float("nan"), device=dev, dtype=torch.bfloat16)
+    C3 = torch.full((M, ldp), float("nan"), device=dev, dtype=torch.bfloat16)
+    o.gemm(A, W, C3, M, N, K, K, K, ldp, bias=bias, epi=o.EPI_SWISH_DROP, aux_out=H, ldaux=ldp, drop=drop)
+    torch.cuda.synchronize()
+    assert torch.isnan(C3[:, N:].float()).all() and torch.isnan(H[:, N:].float()).all()
+    assert rel_err(H[:, :N].float(), ref) < 6e-3
+    assert rel_err(C3[:, :N].float(), ref * torch.sigmoid(ref) * mask) < 8e-3
+    # (d) no dropout, plain f32 store of pitch 324 == the same product through an aligned width (N = 320 columns of it)
+    C4 = torch.empty(M, N, device=dev); C5 = torch.empty(M, 320, device=dev)
+    o.gemm(A, W, C4, M, N, K, K, K, N, bias=bias)
+    o.gemm(A, W, C5, M, 320, K, K, K, 320, bias=bias[:320].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(C4[:, :320], C5) and rel_err(C4, ref) < 1e-3
+
+
 # ---------------------------------------------------------------------------------------------- LayerNorm etc.
 @pytest.mark.parametrize("d", [176, 512])
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16)])
