@@ -3240,7 +3240,9 @@ extern "C" int mi355x_gemm(const mi355x_gemm_desc* d, void* stream) {
     // workgroups and wins in isolation although its K loop is slower (FFN2 forward at M = 8032: 46.3 -> 39.5 us); inside a
     // training step, next to the weight-gradient stream, it only paid off below ~100 tiles (Squeezeformer-Medium's N = 324
     // launches at the reduced frame rate: step 47.95 -> 46.95 ms; FastConformer's 128-tile launches: 32.47 -> 32.67 ms)
-    static const int few_mode = env_int("MI355X_GEMM_FEW_TILES", 100);
+    // Round 6: with the vector tail / templated partial-tile epilogue for widths of 4 modulo 8 the 256x128 structure is ahead again
+    // on those launches too (Squeezeformer-Medium 35.68 -> 35.52 ms, same box, twice; Transducer unchanged): default 0 = rule off.
+    static const int few_mode = env_int("MI355X_GEMM_FEW_TILES", 0);
     const long long blocks256 = (long long)((p.M + BM2 - 1) / BM2) * tn * sk * p.batch;
     const bool few_tiles = !p.g_on && !p.r_on && !p.atomic && blocks256 <= few_mode && p.N <= 1024 &&
                            (long long)tm * tn * sk * p.batch > blocks256;
