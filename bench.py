@@ -572,7 +572,9 @@ def main():
 
     # ---- what the gradient exchange looked like (diagnosable SCALE runs): collective library, buckets, exposed time
     dist_info = {"world_size": world, "backend": backend if world > 1 else None, "ranks_seen": ranks_seen,
-                 "valid": not uuid_collision,  # false: ranks on distinct device indices reported the same device UUID
+                 # valid = a scaling number may be read off this line: false when ranks on distinct device indices reported the same
+                 # device UUID, and false for a rehearsal (BENCH_DEVICE: every rank on ONE GPU -- control flow only)
+                 "valid": not uuid_collision and not (rehearsal and world > 1), "rehearsal": bool(rehearsal and world > 1),
                  "launcher": "self (torch.distributed.run)" if os.environ.get("BENCH_SELF_LAUNCHED") else
                  ("external" if world > 1 else None)}
     try:

@@ -836,6 +836,6 @@ def test_bench_eight_rank_rehearsal_on_one_gpu(mailbox):
     assert j["n_gpus"] == 8 and j["steps"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
     d = j["distributed"]
     assert d["world_size"] == 8 and len(d["ranks_seen"]) == 8 and sorted(x["rank"] for x in d["ranks_seen"]) == list(range(8))
-    assert d["valid"] is True
+    assert d["valid"] is False and d["rehearsal"] is True   # ranks share one GPU: never a scaling number
     assert d["syncbn_exchange"] == ("mailbox" if mailbox == "1" else "process group") or mailbox == "1"   # (mailbox: all-or-nothing, may decline)
     assert j["config"]["global_batch"] == 16
