@@ -16,7 +16,12 @@
   if ((dt) == MI_DT_F32) { typedef float T; __VA_ARGS__; }           \
   else { typedef bf16_t T; __VA_ARGS__; }
 
-template <typename TT>
+// IDX = the type positions are counted and decomposed in: uint32_t whenever B*T*F fits (always, in practice; 64-bit `%` and `/`
+// are emulated).  Measured in round 6: no change (input-gradient kernel 848 -> 856 us on Squeezeformer-Medium's first stage) -- the
+// kernels are bound by their traffic, which is larger than the header suggests: the input gradient also reads the forward INPUT
+// (840 MB, for the ReLU mask) next to writing 840 MB, and the weight-gradient kernel reads it again.  Next step if it matters:
+// both gradients from one pass over the input positions (the taps' dout values are the same loads).
+template <typename TT, typename IDX>
 __global__ __launch_bounds__(256) void dwconv2d_s2_fwd_kernel(const TT* __restrict__ in, const float* __restrict__ w,
                                                               const float* __restrict__ bias, TT* __restrict__ out, int B, int T1,
                                                               int F1, int T2, int F2, int C) {
@@ -32,11 +37,11 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_fwd_kernel(const TT* __restri
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k][j] = w[(c + j) * 9 + k];
   }
-  const long long npos = (long long)B * T2 * F2;
-  for (long long pos = (long long)blockIdx.x * PS + ps; pos < npos; pos += (long long)gridDim.x * PS) {
-    const int f2 = (int)(pos % F2);
-    const long long bt = pos / F2;
-    const int t2 = (int)(bt % T2), b = (int)(bt / T2);
+  const IDX npos = (IDX)B * (IDX)T2 * (IDX)F2;
+  for (IDX pos = (IDX)blockIdx.x * PS + ps; pos < npos; pos += (IDX)gridDim.x * PS) {
+    const int f2 = (int)(pos % (IDX)F2);
+    const IDX bt = pos / (IDX)F2;
+    const int t2 = (int)(bt % (IDX)T2), b = (int)(bt / (IDX)T2);
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = bs[j];
@@ -54,12 +59,12 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_fwd_kernel(const TT* __restri
         for (int j = 0; j < V; ++j) acc[j] = fmaf(wk[kh * 3 + kw][j], x[j], acc[j]);
       }
     }
-    VecIO<TT>::store(out + pos * C + c, acc);
+    VecIO<TT>::store(out + (long long)pos * C + c, acc);
   }
 }
 
 // din[b,t1,f1,c] = (in > 0) * sum over the outputs (t2, f2) that read (t1, f1):  t1 = 2 t2 - 1 + kh  <=>  kh = t1 + 1 - 2 t2
-template <typename TT>
+template <typename TT, typename IDX>
 __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_data_kernel(const TT* __restrict__ dout, const TT* __restrict__ in,
                                                                    const float* __restrict__ w, TT* __restrict__ din, int B, int T1,
                                                                    int F1, int T2, int F2, int C) {
@@ -73,11 +78,11 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_data_kernel(const TT* __r
   for (int j = 0; j < V; ++j)
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k][j] = w[(c + j) * 9 + k];
-  const long long npos = (long long)B * T1 * F1;
-  for (long long pos = (long long)blockIdx.x * PS + ps; pos < npos; pos += (long long)gridDim.x * PS) {
-    const int f1 = (int)(pos % F1);
-    const long long bt = pos / F1;
-    const int t1 = (int)(bt % T1), b = (int)(bt / T1);
+  const IDX npos = (IDX)B * (IDX)T1 * (IDX)F1;
+  for (IDX pos = (IDX)blockIdx.x * PS + ps; pos < npos; pos += (IDX)gridDim.x * PS) {
+    const int f1 = (int)(pos % (IDX)F1);
+    const IDX bt = pos / (IDX)F1;
+    const int t1 = (int)(bt % (IDX)T1), b = (int)(bt / (IDX)T1);
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -101,15 +106,15 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_data_kernel(const TT* __r
       }
     }
     float x[V];
-    VecIO<TT>::load(in + pos * C + c, x);
+    VecIO<TT>::load(in + (long long)pos * C + c, x);
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = x[j] > 0.f ? acc[j] : 0.f;  // ReLU of the previous stage
-    VecIO<TT>::store(din + pos * C + c, acc);
+    VecIO<TT>::store(din + (long long)pos * C + c, acc);
   }
 }
 
 // partial[part][k][c] (k < 9: weight taps, k = 9: bias) over a contiguous range of output positions per workgroup
-template <typename TT>
+template <typename TT, typename IDX>
 __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_w_kernel(const TT* __restrict__ dout, const TT* __restrict__ in,
                                                                 float* __restrict__ partial, int B, int T1, int F1, int T2, int F2,
                                                                 int C, int pos_per_block) {
@@ -123,15 +128,15 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_w_kernel(const TT* __rest
   for (int k = 0; k < 10; ++k)
 #pragma unroll
     for (int j = 0; j < V; ++j) gw[k][j] = 0.f;
-  const long long npos = (long long)B * T2 * F2;
-  const long long p0 = (long long)blockIdx.x * pos_per_block, p1 = min(npos, p0 + pos_per_block);
+  const IDX npos = (IDX)B * (IDX)T2 * (IDX)F2;
+  const IDX p0 = (IDX)blockIdx.x * (IDX)pos_per_block, p1 = min(npos, p0 + (IDX)pos_per_block);
   if (ps < PS) {
-    for (long long pos = p0 + ps; pos < p1; pos += PS) {
-      const int f2 = (int)(pos % F2);
-      const long long bt = pos / F2;
-      const int t2 = (int)(bt % T2), b = (int)(bt / T2);
+    for (IDX pos = p0 + ps; pos < p1; pos += PS) {
+      const int f2 = (int)(pos % (IDX)F2);
+      const IDX bt = pos / (IDX)F2;
+      const int t2 = (int)(bt % (IDX)T2), b = (int)(bt / (IDX)T2);
       float g[V];
-      VecIO<TT>::load(dout + pos * C + c, g);
+      VecIO<TT>::load(dout + (long long)pos * C + c, g);
 #pragma unroll
       for (int j = 0; j < V; ++j) gw[9][j] += g[j];
 #pragma unroll
@@ -179,9 +184,13 @@ extern "C" int mi355x_dwconv2d_s2_fwd(const void* in, const void* w, const void*
   if (!in || !w || !bias || !out || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || C % V || C / V > 256) return MI_ERR_ARG;
   const int T2 = (T1 - 1) / 2 + 1, F2 = (F1 - 1) / 2 + 1;
   const int PS = 256 / (C / V);
-  DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv2d_s2_fwd_kernel<TT>), dim3(dw2d_grid((long long)B * T2 * F2, PS)), dim3(256), 0,
-                                         (hipStream_t)stream, (const TT*)in, (const float*)w, (const float*)bias, (TT*)out, B, T1, F1,
-                                         T2, F2, C));
+  // (positions + one grid stride must fit the index type)
+  const bool small = (long long)B * T1 * F1 + 8192LL * 256 < (1LL << 32);
+#define DW2D_FWD(IDX) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv2d_s2_fwd_kernel<TT, IDX>), dim3(dw2d_grid((long long)B * T2 * F2, PS)), dim3(256), 0, \
+                                         (hipStream_t)stream, (const TT*)in, (const float*)w, (const float*)bias, (TT*)out, B, T1, F1, \
+                                         T2, F2, C))
+  if (small) { DW2D_FWD(uint32_t); } else { DW2D_FWD(long long); }
+#undef DW2D_FWD
   return mi_check_launch();
 }
 
@@ -200,10 +209,14 @@ extern "C" int mi355x_dwconv2d_s2_bwd(const void* dout, const void* in, const vo
   hipStream_t s = (hipStream_t)stream;
   const size_t shm = (size_t)PS * C * sizeof(float);
   if (shm > 64 * 1024) return MI_ERR_ARG;
-  DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv2d_s2_bwd_data_kernel<TT>), dim3(dw2d_grid((long long)B * T1 * F1, PS)), dim3(256), 0,
-                                         s, (const TT*)dout, (const TT*)in, (const float*)w, (TT*)din, B, T1, F1, T2, F2, C));
-  DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv2d_s2_bwd_w_kernel<TT>), dim3((unsigned)nblk), dim3(256), shm, s, (const TT*)dout,
-                                         (const TT*)in, (float*)scratch, B, T1, F1, T2, F2, C, per));
+  const bool small = (long long)B * T1 * F1 + 8192LL * 256 < (1LL << 32);
+#define DW2D_BWD(IDX) do { \
+  DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv2d_s2_bwd_data_kernel<TT, IDX>), dim3(dw2d_grid((long long)B * T1 * F1, PS)), dim3(256), 0, \
+                                         s, (const TT*)dout, (const TT*)in, (const float*)w, (TT*)din, B, T1, F1, T2, F2, C)); \
+  DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv2d_s2_bwd_w_kernel<TT, IDX>), dim3((unsigned)nblk), dim3(256), shm, s, (const TT*)dout, \
+                                         (const TT*)in, (float*)scratch, B, T1, F1, T2, F2, C, per)); } while (0)
+  if (small) DW2D_BWD(uint32_t); else DW2D_BWD(long long);
+#undef DW2D_BWD
   MI_LAUNCH(tap_reduce_kernel, dim3((10 * C + 255) / 256, 16), dim3(256), 0, s, (const float*)scratch, (int)nblk, 9, C,
                      (float*)dw, (float*)dbias);
   return mi_check_launch();
