@@ -215,9 +215,15 @@ class RNNTDecoder(_ModuleBase):
             h_lp = torch.empty(U1 * B, H, dtype=cdt, device=dev)
             for t in range(U1):
                 zt = z[t * B:(t + 1) * B]
-                if t > 0:  # z_t += h_{t-1} W_hh^T, in place (residual epilogue with aux_in == C)
-                    ops.gemm(h_lp[(t - 1) * B:t * B], W[f"l{l}.whh"], zt, B, 4 * H, H, H, W.pitch(f"l{l}.whh"), 4 * H,
-                             epi=ops.EPI_RESID, aux_in=zt)
+                if t > 0:  # z_t += h_{t-1} W_hh^T, in place
+                    if self._fwd_splitk > 1:
+                        # [B, H] x [H, 4H] with B = 32 rows: 4H / 128 output tiles, each a chain of H / 64 K-tiles -- split-K with
+                        # atomic accumulation into the f32 pre-activations that are already there shortens the chain
+                        ops.gemm(h_lp[(t - 1) * B:t * B], W[f"l{l}.whh"], zt, B, 4 * H, H, H, W.pitch(f"l{l}.whh"), 4 * H,
+                                 atomic=True, splitk=self._fwd_splitk, c_dtype=ops.F32)
+                    else:  # residual epilogue with aux_in == C
+                        ops.gemm(h_lp[(t - 1) * B:t * B], W[f"l{l}.whh"], zt, B, 4 * H, H, H, W.pitch(f"l{l}.whh"), 4 * H,
+                                 epi=ops.EPI_RESID, aux_in=zt)
                 ops.lstm_cell_fwd(zt, b_hh, c_all[(t - 1) * B:t * B] if t > 0 else None, c_all[t * B:(t + 1) * B],
                                   h_all[t * B:(t + 1) * B], h_lp[t * B:(t + 1) * B], B, H)
             # nn.LSTM drops the outputs of every layer but the last; LSTMDropout drops the last one (rnn.py:219,233-236)
@@ -236,6 +242,7 @@ class RNNTDecoder(_ModuleBase):
         return g, ((tg, layers, B, U, cdt) if save else None)
 
     _bptt_splitk = int(os.environ.get("MI355X_LSTM_BPTT_SPLITK", "8"))
+    _fwd_splitk = int(os.environ.get("MI355X_LSTM_FWD_SPLITK", "1"))
 
     def _backward_impl(self, saved, dg):
         tg, layers, B, U, cdt = saved
