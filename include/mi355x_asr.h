@@ -159,6 +159,16 @@ int mi355x_im2col_3x3s2(const void* in /*[B,T1,F1,C]*/, void* col /*[B*T2*F2, 9C
                         void* stream);
 int mi355x_col2im_3x3s2_relu(const void* dcol, const void* act, void* din, int dtype, int B, int T1, int F1, int C,
                              void* stream);
+/* The same four with the padding as an argument: `pad` zero rows / columns in FRONT of the grid, one behind it -- 1 = Conv2d(
+ * padding = 1) (what the entries above run), 2 = CausalConv2D of `causal_downsampling: true` (parts/submodules/causal_convs.py:24-72,
+ * subsampling.py:147-149,222-224: F.pad (2, 1) on time AND frequency, then no padding).  Output extents: floor((n + pad - 2) / 2) + 1. */
+int mi355x_subsample_conv1_fwd_pad(const void* mel, const void* w, const void* bias, void* out, int out_dtype, const void* len0,
+                                   const void* len1, int B, int F, int T, int C, int pad, void* stream);
+int mi355x_subsample_conv1_bwd_pad(const void* dout, int dtype, const void* mel, const void* len0, void* dw, void* db, int B,
+                                   int F, int T, int C, int pad, void* scratch, long long scratch_elems, void* stream);
+int mi355x_im2col_3x3s2_pad(const void* in, void* col, int dtype, int B, int T1, int F1, int C, int pad, void* stream);
+int mi355x_col2im_3x3s2_relu_pad(const void* dcol, const void* act, void* din, int dtype, int B, int T1, int F1, int C, int pad,
+                                 void* stream);
 
 /* 'dw_striding' sub-sampling (FastConformer x8, Squeezeformer x4; subsampling.py:142-215): depthwise Conv2d(C, C, 3, stride 2,
  * padding 1, groups = C) on a channels-last map in [B,T1,F1,C] -> out [B,T2,F2,C] (+ bias); w f32 [C,1,3,3].  The pointwise
@@ -168,6 +178,11 @@ int mi355x_dwconv2d_s2_fwd(const void* in, const void* w, const void* bias, void
                            void* stream);
 int mi355x_dwconv2d_s2_bwd(const void* dout, const void* in, const void* w, void* din, void* dw, void* dbias, int dtype, int B,
                            int T1, int F1, int C, void* scratch, long long scratch_elems, void* stream);
+/* ... with `pad` as above (CausalConv2D stages of the cache-aware streaming FastConformer recipes) */
+int mi355x_dwconv2d_s2_fwd_pad(const void* in, const void* w, const void* bias, void* out, int dtype, int B, int T1, int F1, int C,
+                               int pad, void* stream);
+int mi355x_dwconv2d_s2_bwd_pad(const void* dout, const void* in, const void* w, void* din, void* dw, void* dbias, int dtype, int B,
+                               int T1, int F1, int C, int pad, void* scratch, long long scratch_elems, void* stream);
 
 /* ---- transducer head (FastConformer-Transducer): RNNTDecoder.predict / RNNTJoint.joint_after_projection,
  * nemo/collections/asr/modules/rnnt.py:700-830, 1640-1720; LSTM = common/parts/rnn.py:151-230 (torch gate order i,f,g,o).

@@ -83,6 +83,12 @@ SIGNATURES = {
     "mi355x_col2im_3x3s2_relu": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mi355x_dwconv2d_s2_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mi355x_dwconv2d_s2_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp],
+    "mi355x_subsample_conv1_fwd_pad": [vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mi355x_subsample_conv1_bwd_pad": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp],
+    "mi355x_im2col_3x3s2_pad": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mi355x_col2im_3x3s2_relu_pad": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mi355x_dwconv2d_s2_fwd_pad": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mi355x_dwconv2d_s2_bwd_pad": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp],
     "mi355x_embed_sos_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mi355x_embed_sos_bwd": [vp, vp, i32, vp, i32, i32, i32, i32, vp],
     "mi355x_lstm_cell_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],

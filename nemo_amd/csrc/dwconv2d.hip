@@ -24,7 +24,7 @@
 template <typename TT, typename IDX>
 __global__ __launch_bounds__(256) void dwconv2d_s2_fwd_kernel(const TT* __restrict__ in, const float* __restrict__ w,
                                                               const float* __restrict__ bias, TT* __restrict__ out, int B, int T1,
-                                                              int F1, int T2, int F2, int C) {
+                                                              int F1, int T2, int F2, int C, int pad) {
   constexpr int V = VecIO<TT>::V;
   const int CP = C / V;  // channel chunks; a thread keeps ONE chunk (its 9 x V weights stay in registers)
   const int ck = threadIdx.x % CP, ps = threadIdx.x / CP, PS = 256 / CP;
@@ -47,11 +47,11 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_fwd_kernel(const TT* __restri
     for (int j = 0; j < V; ++j) acc[j] = bs[j];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
-      const int t1 = 2 * t2 - 1 + kh;
+      const int t1 = 2 * t2 - pad + kh;
       if ((unsigned)t1 >= (unsigned)T1) continue;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const int f1 = 2 * f2 - 1 + kw;
+        const int f1 = 2 * f2 - pad + kw;
         if ((unsigned)f1 >= (unsigned)F1) continue;
         float x[V];
         VecIO<TT>::load(in + (((long long)b * T1 + t1) * F1 + f1) * C + c, x);
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_fwd_kernel(const TT* __restri
 template <typename TT, typename IDX>
 __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_data_kernel(const TT* __restrict__ dout, const TT* __restrict__ in,
                                                                    const float* __restrict__ w, TT* __restrict__ din, int B, int T1,
-                                                                   int F1, int T2, int F2, int C) {
+                                                                   int F1, int T2, int F2, int C, int pad) {
   constexpr int V = VecIO<TT>::V;
   const int CP = C / V;
   const int ck = threadIdx.x % CP, ps = threadIdx.x / CP, PS = 256 / CP;
@@ -89,13 +89,13 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_data_kernel(const TT* __r
     // kh = t1 + 1 - 2 t2 in {0,1,2}: an even t1 is read through kh = 1 only, an odd one through kh = 0 (t2 = (t1+1)/2) and 2
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
-      const int tt = t1 + 1 - kh;
+      const int tt = t1 + pad - kh;
       if (tt < 0 || (tt & 1)) continue;
       const int t2 = tt >> 1;
       if (t2 >= T2) continue;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const int ff = f1 + 1 - kw;
+        const int ff = f1 + pad - kw;
         if (ff < 0 || (ff & 1)) continue;
         const int f2 = ff >> 1;
         if (f2 >= F2) continue;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_data_kernel(const TT* __r
 template <typename TT, typename IDX>
 __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_w_kernel(const TT* __restrict__ dout, const TT* __restrict__ in,
                                                                 float* __restrict__ partial, int B, int T1, int F1, int T2, int F2,
-                                                                int C, int pos_per_block) {
+                                                                int C, int pos_per_block, int pad) {
   constexpr int V = VecIO<TT>::V;
   extern __shared__ float red[];  // [PS][10][CP*V] reduction over the position slots of the block
   const int CP = C / V;
@@ -141,11 +141,11 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_w_kernel(const TT* __rest
       for (int j = 0; j < V; ++j) gw[9][j] += g[j];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
-        const int t1 = 2 * t2 - 1 + kh;
+        const int t1 = 2 * t2 - pad + kh;
         if ((unsigned)t1 >= (unsigned)T1) continue;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const int f1 = 2 * f2 - 1 + kw;
+          const int f1 = 2 * f2 - pad + kw;
           if ((unsigned)f1 >= (unsigned)F1) continue;
           float x[V];
           VecIO<TT>::load(in + (((long long)b * T1 + t1) * F1 + f1) * C + c, x);
@@ -177,30 +177,44 @@ static inline int dw2d_grid(long long npos, int PS) {
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
+extern "C" int mi355x_dwconv2d_s2_fwd_pad(const void* in, const void* w, const void* bias, void* out, int dt, int B, int T1, int F1,
+                                          int C, int pad, void* stream);
 extern "C" int mi355x_dwconv2d_s2_fwd(const void* in, const void* w, const void* bias, void* out, int dt, int B, int T1, int F1,
                                       int C, void* stream) {
+  return mi355x_dwconv2d_s2_fwd_pad(in, w, bias, out, dt, B, T1, F1, C, 1, stream);
+}
+// pad = zero rows / columns in front of the grid (1: Conv2d(padding = 1); 2: CausalConv2D, causal_convs.py:24-72); one behind it
+extern "C" int mi355x_dwconv2d_s2_fwd_pad(const void* in, const void* w, const void* bias, void* out, int dt, int B, int T1, int F1,
+                                          int C, int pad, void* stream) {
   mi_clear_errors();
   const int V = dt == MI_DT_BF16 ? 8 : 4;
-  if (!in || !w || !bias || !out || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || C % V || C / V > 256) return MI_ERR_ARG;
-  const int T2 = (T1 - 1) / 2 + 1, F2 = (F1 - 1) / 2 + 1;
+  if (!in || !w || !bias || !out || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || C % V || C / V > 256 || pad < 1 || pad > 2) return MI_ERR_ARG;
+  const int T2 = (T1 + pad - 2) / 2 + 1, F2 = (F1 + pad - 2) / 2 + 1;
   const int PS = 256 / (C / V);
   // (positions + one grid stride must fit the index type)
   const bool small = (long long)B * T1 * F1 + 8192LL * 256 < (1LL << 32);
 #define DW2D_FWD(IDX) DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv2d_s2_fwd_kernel<TT, IDX>), dim3(dw2d_grid((long long)B * T2 * F2, PS)), dim3(256), 0, \
                                          (hipStream_t)stream, (const TT*)in, (const float*)w, (const float*)bias, (TT*)out, B, T1, F1, \
-                                         T2, F2, C))
+                                         T2, F2, C, pad))
   if (small) { DW2D_FWD(uint32_t); } else { DW2D_FWD(long long); }
 #undef DW2D_FWD
   return mi_check_launch();
 }
 
+extern "C" int mi355x_dwconv2d_s2_bwd_pad(const void* dout, const void* in, const void* w, void* din, void* dw, void* dbias, int dt,
+                                          int B, int T1, int F1, int C, int pad, void* scratch, long long scratch_elems, void* stream);
 extern "C" int mi355x_dwconv2d_s2_bwd(const void* dout, const void* in, const void* w, void* din, void* dw, void* dbias, int dt,
                                       int B, int T1, int F1, int C, void* scratch, long long scratch_elems, void* stream) {
+  return mi355x_dwconv2d_s2_bwd_pad(dout, in, w, din, dw, dbias, dt, B, T1, F1, C, 1, scratch, scratch_elems, stream);
+}
+extern "C" int mi355x_dwconv2d_s2_bwd_pad(const void* dout, const void* in, const void* w, void* din, void* dw, void* dbias, int dt,
+                                          int B, int T1, int F1, int C, int pad, void* scratch, long long scratch_elems, void* stream) {
   mi_clear_errors();
   const int V = dt == MI_DT_BF16 ? 8 : 4;
-  if (!dout || !in || !w || !din || !dw || !dbias || !scratch || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || C % V || C / V > 256)
+  if (!dout || !in || !w || !din || !dw || !dbias || !scratch || B <= 0 || T1 <= 0 || F1 <= 0 || C <= 0 || C % V || C / V > 256 ||
+      pad < 1 || pad > 2)
     return MI_ERR_ARG;
-  const int T2 = (T1 - 1) / 2 + 1, F2 = (F1 - 1) / 2 + 1;
+  const int T2 = (T1 + pad - 2) / 2 + 1, F2 = (F1 + pad - 2) / 2 + 1;
   const int PS = 256 / (C / V);
   const long long npos = (long long)B * T2 * F2;
   const long long nblk = npos < 1024 * 64 ? (npos + 63) / 64 : 1024;
@@ -212,9 +226,9 @@ extern "C" int mi355x_dwconv2d_s2_bwd(const void* dout, const void* in, const vo
   const bool small = (long long)B * T1 * F1 + 8192LL * 256 < (1LL << 32);
 #define DW2D_BWD(IDX) do { \
   DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv2d_s2_bwd_data_kernel<TT, IDX>), dim3(dw2d_grid((long long)B * T1 * F1, PS)), dim3(256), 0, \
-                                         s, (const TT*)dout, (const TT*)in, (const float*)w, (TT*)din, B, T1, F1, T2, F2, C)); \
+                                         s, (const TT*)dout, (const TT*)in, (const float*)w, (TT*)din, B, T1, F1, T2, F2, C, pad)); \
   DISPATCH_DT(dt, TT, MI_LAUNCH((dwconv2d_s2_bwd_w_kernel<TT, IDX>), dim3((unsigned)nblk), dim3(256), shm, s, (const TT*)dout, \
-                                         (const TT*)in, (float*)scratch, B, T1, F1, T2, F2, C, per)); } while (0)
+                                         (const TT*)in, (float*)scratch, B, T1, F1, T2, F2, C, per, pad)); } while (0)
   if (small) DW2D_BWD(uint32_t); else DW2D_BWD(long long);
 #undef DW2D_BWD
   MI_LAUNCH(tap_reduce_kernel, dim3((10 * C + 255) / 256, 16), dim3(256), 0, s, (const float*)scratch, (int)nblk, 9, C,

@@ -95,7 +95,9 @@ class FilterbankFeatures(nn.Module):
         if not log or log_zero_guard_type != "add": unsupported.append("log=False / clamp guard")
         if nb_augmentation_prob > 0: unsupported.append("nb_augmentation_prob>0")
         if use_grads: unsupported.append("use_grads=True")
-        if normalize not in ("per_feature", None, False): unsupported.append(f"normalize={normalize}")
+        # normalize_batch (features.py:58-112) leaves the features as they are for any type it does not know -- the streaming
+        # recipes' `normalize: "NA"` is exactly that; "all_features" and fixed statistics are not implemented here
+        if normalize == "all_features" or isinstance(normalize, dict): unsupported.append(f"normalize={normalize}")
         if window not in ("hann", "hamming", "blackman", "bartlett", "none", None): unsupported.append(f"window={window}")
         if unsupported:
             raise NotImplementedError("MI355X front-end does not implement: " + ", ".join(unsupported))
@@ -172,7 +174,7 @@ class FilterbankFeatures(nn.Module):
         raw = ops.logmel(x, seq_len.to(torch.int64), self.window.float(), self._fb_sparse(), self.nfilt,
                          hop=self.hop_length, n_fft=self.n_fft, preemph=self.preemph, dither=dither, seed=self._seed,
                          log_guard=float(lg))
-        feat = ops.feat_normalize(raw, out_len, normalize=bool(self.normalize), pad_value=float(self.pad_value),
+        feat = ops.feat_normalize(raw, out_len, normalize=(self.normalize == "per_feature"), pad_value=float(self.pad_value),
                                   out_dtype=out_dtype)
         pad_to = self.pad_to
         if pad_to == "max":

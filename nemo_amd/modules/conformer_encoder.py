@@ -80,8 +80,11 @@ class ConformerLayer(nn.Module):  # conformer_modules.py:35 (parameter layout on
 
 
 class ConvSubsampling(nn.Module):  # subsampling.py:62 ('striding' :217-253 and 'dw_striding' :142-215; parameter layout only)
-    def __init__(self, subsampling, subsampling_factor, feat_in, feat_out, conv_channels):
+    def __init__(self, subsampling, subsampling_factor, feat_in, feat_out, conv_channels, causal=False):
         super().__init__()
+        # causal = CausalConv2D stages (causal_convs.py:24-72): two zero rows / columns in front of the grid, one behind it, no
+        # symmetric padding -- same parameters and state-dict keys, another sampling grid: extents floor(n / 2) + 1 per stage
+        self.is_causal, self._pad = bool(causal), (2 if causal else 1)
         self._subsampling = subsampling
         self.subsampling_factor = subsampling_factor
         self._conv_channels = conv_channels
@@ -96,7 +99,7 @@ class ConvSubsampling(nn.Module):  # subsampling.py:62 ('striding' :217-253 and 
         self.conv = nn.Sequential(*layers)
         f = feat_in
         for _ in range(self._sampling_num):
-            f = (f + 2 - 3) // 2 + 1
+            f = (f + self._pad - 2) // 2 + 1
         self._feat_after = f
         self.out = nn.Linear(conv_channels * f, feat_out)
 
@@ -223,8 +226,10 @@ class ConformerEncoder(NeuralModule):
         if not ((subsampling == "striding" and subsampling_factor == 4) or
                 (subsampling == "dw_striding" and subsampling_factor in (4, 8))):
             bad.append(f"subsampling={subsampling} x{subsampling_factor} (implemented: striding x4, dw_striding x4 / x8)")
-        if causal_downsampling: bad.append("causal_downsampling")
-        if self_attention_model != "rel_pos": bad.append(f"self_attention_model={self_attention_model}")
+        if self_attention_model not in ("rel_pos", "rel_pos_local_attn"):
+            bad.append(f"self_attention_model={self_attention_model} (implemented: rel_pos, rel_pos_local_attn)")
+        if self_attention_model == "rel_pos_local_attn" and global_tokens:
+            bad.append("global_tokens > 0")
         if not untie_biases: bad.append("tied pos biases")
         if conv_norm_type not in ("batch_norm", "layer_norm"): bad.append(f"conv_norm_type={conv_norm_type} (implemented: batch_norm, layer_norm)")
         if not use_bias: bad.append("use_bias=False")
@@ -243,6 +248,19 @@ class ConformerEncoder(NeuralModule):
         # one is the default (evaluation); training draws one per step with att_context_probs when there are several (:620-625)
         self.att_context_size_all, self.att_context_size, self.att_context_probs = self._calc_att_context(
             att_context_size, att_context_probs, att_context_style)
+        if self_attention_model == "rel_pos_local_attn":
+            # Longformer-style sliding window with the relative-position term inside the window
+            # (RelPositionMultiHeadAttentionLongformer, multi_head_attention.py:357-586; LocalAttRelPositionalEncoding :1103-1148).
+            # Its overlapping-chunk arithmetic computes the dense banded attention |j - i| <= w with the SAME positional rows
+            # p(i - j) the full table holds (the sinusoid depends on the position value only), zeroed rows for padded queries --
+            # i.e. the 'regular' limited context [w, w] of the rel_pos model, which is how it runs here (the band test inside
+            # mi355x_relpos_softmax_fwd_ctx).  The reference's diagonal-wise positional sum is only consistent for left == right
+            # (what the recipes use: conf/fastconformer/long_fastconformer/*.yaml), other windows are refused.
+            if max(self.att_context_size) <= 0:
+                raise ValueError("When using local attention, context size must be set > 0")
+            if len(self.att_context_size_all) != 1 or self.att_context_size[0] != self.att_context_size[1]:
+                raise NotImplementedError("MI355X ConformerEncoder: rel_pos_local_attn needs one window att_context_size = [w, w]")
+            self.att_context_style = "regular"
         self._ctx = (0, -1, -1)   # (style id, left, right) of the forward in flight
         self.sync_max_audio_length = sync_max_audio_length
         self.xscale = math.sqrt(d_model) if xscaling else None
@@ -251,7 +269,8 @@ class ConformerEncoder(NeuralModule):
         if subsampling_conv_channels == -1:
             subsampling_conv_channels = d_model
         self.subsampling = subsampling
-        self.pre_encode = ConvSubsampling(subsampling, subsampling_factor, feat_in, d_model, subsampling_conv_channels)
+        self.pre_encode = ConvSubsampling(subsampling, subsampling_factor, feat_in, d_model, subsampling_conv_channels,
+                                          causal=causal_downsampling)
         self._feat_out = d_model
         self.pos_emb_max_len = pos_emb_max_len
         self.pos_enc = RelPositionalEncoding(d_model, dropout_pre_encoder, pos_emb_max_len, self.xscale, dropout_emb)
@@ -600,7 +619,7 @@ class ConformerEncoder(NeuralModule):
                 w2flat = pe.conv[2].weight.data.view(-1)
                 for par_t in (0, 1):
                     for par_f in (0, 1):
-                        slots = self._dgrad_slots(par_t, par_f)
+                        slots = self._dgrad_slots(par_t, par_f, pe._pad)
                         name = f"pre.w2d{par_t}{par_f}"
                         p.new_image(name, C_, len(slots) * C_)
                         for si_, (kh, kw) in enumerate(slots):
@@ -907,8 +926,12 @@ class ConformerEncoder(NeuralModule):
         return out
 
     @staticmethod
-    def _dgrad_slots(pt, pf):
-        return [(kh, kw) for kh in ([1] if pt == 0 else [0, 2]) for kw in ([1] if pf == 0 else [0, 2])]
+    def _dgrad_slots(pt, pf, pad=1):
+        """taps (kh, kw) through which a stride-2 3x3 conv reads an input position of parity (pt, pf): t1 = 2 t2 - pad + kh, so
+        kh has the parity of t1 + pad (padding 1: an even position through k = 1 only, an odd one through 0 and 2; CausalConv2D's
+        front padding of 2: the other way round)"""
+        par = lambda q: [1] if (q + pad) % 2 else [0, 2]
+        return [(kh, kw) for kh in par(pt) for kw in par(pf)]
 
     def _conv2_implicit(self, cdt, C_, M2):
         """implicit-GEMM conv2 (gathered A operand) needs the bf16 LDS-DMA GEMM structures and whole K-tiles per tap"""
@@ -1061,9 +1084,10 @@ class ConformerEncoder(NeuralModule):
             host = length.detach().to("cpu")
         hl = torch.as_tensor(host, dtype=torch.int64).clamp(min=0, max=T_mel)
         T2 = T_mel
+        sp = getattr(self.pre_encode, "_pad", 1)
         for _ in range(self.pre_encode._sampling_num):  # the same recurrence as _lens / calc_length (subsampling.py:576-586)
-            hl = (torch.div(hl - 1, 2, rounding_mode="floor") + 1).clamp_(min=0)
-            T2 = (T2 - 1) // 2 + 1
+            hl = (torch.div(hl + (sp - 2), 2, rounding_mode="floor") + 1).clamp_(min=0)
+            T2 = (T2 + sp - 2) // 2 + 1
         hl = hl.clamp(max=T2)
         Mp, M = int(hl.sum()), B * T2
         if Mp <= 0 or (mode == "auto" and (M - Mp) < self.packed_min_padding * M):
@@ -1079,10 +1103,12 @@ class ConformerEncoder(NeuralModule):
         return pk
 
     def _lens(self, length, n_stages=2):
-        """valid lengths after 0, 1, ..., n stride-2 stages: floor((n + 2 - 3)/2) + 1 each, subsampling.py:576-586"""
+        """valid lengths after 0, 1, ..., n stride-2 stages: floor((n + all_paddings - 3)/2) + 1 each, all_paddings = 2 (or 3 with
+        causal_downsampling), subsampling.py:576-586"""
+        sp = getattr(self.pre_encode, "_pad", 1)
         out = [length.to(torch.int64).contiguous()]
         for _ in range(n_stages):
-            out.append((torch.div(out[-1] - 1, 2, rounding_mode="floor") + 1).clamp_(min=0).contiguous())
+            out.append((torch.div(out[-1] + (sp - 2), 2, rounding_mode="floor") + 1).clamp_(min=0).contiguous())
         return out
 
     # ------------------------------------------------------------------ forward implementation
@@ -1111,11 +1137,12 @@ class ConformerEncoder(NeuralModule):
             lens = [ln_] * (self.pre_encode._sampling_num + 1)
         else:
             B, F_, T = mel.shape
-            T1, F1 = (T - 1) // 2 + 1, (F_ - 1) // 2 + 1
+            sp = self.pre_encode._pad
+            T1, F1 = ops.half_len(T, sp), ops.half_len(F_, sp)
             lens = self._lens(length, self.pre_encode._sampling_num)  # [len0, len1, ..., len_final]
             T2, F2 = T, F_
             for _ in range(self.pre_encode._sampling_num):
-                T2, F2 = (T2 - 1) // 2 + 1, (F2 - 1) // 2 + 1
+                T2, F2 = ops.half_len(T2, sp), ops.half_len(F2, sp)
         len0, len1, len2 = lens[0], lens[1], lens[-1]                # (`len2` / `T2` / `F2` name the FINAL grid everywhere below)
         M = B * T2
         self.update_max_seq_length(T2, dev)
@@ -1143,14 +1170,14 @@ class ConformerEncoder(NeuralModule):
         else:
             # ---- sub-sampling: conv1 (direct) -> conv2 (implicit MFMA GEMM, ReLU+mask epilogue) -> out Linear (+xscale, dropout)
             S.out1 = self._new(B, T1, F1, C_, dtype=cdt, device=dev)
-            ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, S.out1, len0, len1, C_)
+            ops.conv1_fwd(mel, pe.conv[0].weight, pe.conv[0].bias, S.out1, len0, len1, C_, pad=pe._pad)
             # (channel counts the gather does not cover fall back to an im2col image, kept alive for the weight gradient)
             implicit = (self.conv2_implicit and self._conv2_implicit(cdt, C_, B * T2 * F2)
                         and B * T1 * F1 * C_ < 2 ** 31)  # the gathered weight gradient addresses the grid with 32-bit offsets
             S.col = None
             if not implicit:
                 col = self._buf("col", (B * T2 * F2, 9 * C_), cdt, dev)
-                ops.im2col(S.out1, col, B, T1, F1, C_)
+                ops.im2col(S.out1, col, B, T1, F1, C_, pad=pe._pad)
                 self._col_gen = getattr(self, "_col_gen", 0) + 1
                 S.col, S.col_gen = (col if save else None), self._col_gen
             S.out2 = self._new(B * T2 * F2, C_, dtype=cdt, device=dev)
@@ -1160,7 +1187,7 @@ class ConformerEncoder(NeuralModule):
                 ops.gemm(S.out1, W["pre.w2"], S.out2, B * T2 * F2, C_, 9 * C_, C_, W.pitch("pre.w2"), C_, bias=pe.conv[2].bias,
                          epi=ops.EPI_RELU_MASK, row_len=len2, rows_per_b=T2 * F2, rows_inner=F2,
                          gather=dict(nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2,
-                                     taps=[(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]))
+                                     taps=[(kh - pe._pad, kw - pe._pad) for kh in range(3) for kw in range(3)]))
             else:
                 ops.gemm(col, W["pre.w2"], S.out2, B * T2 * F2, C_, 9 * C_, 9 * C_, W.pitch("pre.w2"), C_, bias=pe.conv[2].bias,
                          epi=ops.EPI_RELU_MASK, row_len=len2, rows_per_b=T2 * F2, rows_inner=F2)
@@ -1266,13 +1293,13 @@ class ConformerEncoder(NeuralModule):
         io = self._sub_io(Wf, cdt, dev)
         C_, d = io.C, self.d_model
         out0 = self._new(B, T1, F1, C_, dtype=cdt, device=dev)
-        ops.conv1_fwd(mel, io.c0w, io.c0b, out0, lens[0], lens[1], C_)
+        ops.conv1_fwd(mel, io.c0w, io.c0b, out0, lens[0], lens[1], C_, pad=pe._pad)
         cur, Tc, Fc = out0, T1, F1
         S.dw = []
         for si_, (dww, dwb, pwb) in enumerate(io.dw):
-            Tn, Fn = (Tc - 1) // 2 + 1, (Fc - 1) // 2 + 1
+            Tn, Fn = ops.half_len(Tc, pe._pad), ops.half_len(Fc, pe._pad)
             dwo = self._new(B * Tn * Fn, C_, dtype=cdt, device=dev)
-            ops.dwconv2d_s2_fwd(cur, dww, dwb, dwo, B, Tc, Fc, C_)
+            ops.dwconv2d_s2_fwd(cur, dww, dwb, dwo, B, Tc, Fc, C_, pad=pe._pad)
             pwo = self._new(B * Tn * Fn, C_, dtype=cdt, device=dev)
             ops.gemm(dwo, W[f"pre.pw{si_}"], pwo, B * Tn * Fn, C_, C_, C_, W.pitch(f"pre.pw{si_}"), C_, bias=pwb,
                      epi=ops.EPI_RELU_MASK, row_len=lens[si_ + 2], rows_per_b=Tn * Fn, rows_inner=Fn)
@@ -1325,9 +1352,9 @@ class ConformerEncoder(NeuralModule):
             ddw = self._new(Ms, C_, dtype=cdt, device=dev)
             ops.gemm(dcur, W[f"pre.pw{si_}t"], ddw, Ms, C_, C_, C_, W.pitch(f"pre.pw{si_}t"), C_)
             din = self._new(B * Tc * Fc, C_, dtype=cdt, device=dev)
-            ops.dwconv2d_s2_bwd(ddw, cur_in, dww, din, g_dww, g_dwb, B, Tc, Fc, C_)
+            ops.dwconv2d_s2_bwd(ddw, cur_in, dww, din, g_dww, g_dwb, B, Tc, Fc, C_, pad=pe._pad)
             dcur = din
-        ops.conv1_bwd(dcur, S.mel, S.len0, io.g_c0w, io.g_c0b, C_)
+        ops.conv1_bwd(dcur, S.mel, S.len0, io.g_c0w, io.g_c0b, C_, pad=pe._pad)
         self._wgrad_join(consume=io.finish is not None)
         if io.finish is not None:
             io.finish()
@@ -1903,11 +1930,11 @@ class ConformerEncoder(NeuralModule):
                          atomic=True, splitk=self._splitk(tiles, M2), batch=9, nb0=9, sC=(1, 0), c_col_stride=9,
                          c_dtype=ops.F32, row_len=S.len2 if self.pad_tile_skip else None, rows_per_b=T2 * F2, rows_inner=F2,   # (K-tiles beyond an utterance: skipped)
                          gather=dict(operand=1, nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2,
-                                     taps=[(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]))
+                                     taps=[(kh - pe._pad, kw - pe._pad) for kh in range(3) for kw in range(3)]))
         else:
             col = S.col
             if S.col_gen != self._col_gen:  # another forward has reused the workspace since: rebuild the image
-                ops.im2col(S.out1, col, B, T1, F1, C_)
+                ops.im2col(S.out1, col, B, T1, F1, C_, pad=pe._pad)
                 self._col_gen += 1
             ops.gemm(dout2, col, pe.conv[2].weight.grad, C_, C_, M2, C_, 9 * C_, 9 * C_, transA=True, transB=True,
                      atomic=True, splitk=self._splitk(tiles, M2), batch=9, nb0=9, sB=(C_, 0), sC=(1, 0), c_col_stride=9,
@@ -1919,7 +1946,7 @@ class ConformerEncoder(NeuralModule):
             for pt in (0, 1):
                 for pf in (0, 1):
                     nI, nJ = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
-                    slots = self._dgrad_slots(pt, pf)
+                    slots = self._dgrad_slots(pt, pf, pe._pad)
                     name = f"pre.w2d{pt}{pf}"
                     # (row_len: conv1's output -- the ReLU gate -- is zero beyond an utterance's len1 <= 2 * len2 frames, so row tiles
                     #  with i >= len2 are zero-filled without a K loop: 40 % of the tiles of an unshaped 5-30 s batch)
@@ -1927,13 +1954,14 @@ class ConformerEncoder(NeuralModule):
                              epi=ops.EPI_MUL_POS, aux_in=S.out1, ldaux=C_, row_len=S.len2 if self.pad_tile_skip else None,
                              rows_per_b=nI * nJ, rows_inner=nJ,
                              gather=dict(nI=nI, nJ=nJ, SI=T2, SJ=F2, C=C_, si=1, sj=1,
-                                         taps=[(1 if kh == 0 else 0, 1 if kw == 0 else 0) for kh, kw in slots]),
+                                         # input position 2 i + pt is read by output i + (pt + pad - kh) / 2 through tap kh
+                                         taps=[((pt + pe._pad - kh) // 2, (pf + pe._pad - kw) // 2) for kh, kw in slots]),
                              rowmap=dict(nI=nI, nJ=nJ, OI=T1, OJ=F1, si=2, sj=2, oi=pt, oj=pf))
         else:
             dcol = self._buf("dcol", (M2, 9 * C_), cdt, dev)
             ops.gemm(dout2, W["pre.w2t"], dcol, M2, 9 * C_, C_, C_, W.pitch("pre.w2t"), 9 * C_)
-            ops.col2im_relu(dcol, S.out1, dout1, B, T1, F1, C_)
-        ops.conv1_bwd(dout1, S.mel, S.len0, pe.conv[0].weight.grad, pe.conv[0].bias.grad, C_)
+            ops.col2im_relu(dcol, S.out1, dout1, B, T1, F1, C_, pad=pe._pad)
+        ops.conv1_bwd(dout1, S.mel, S.len0, pe.conv[0].weight.grad, pe.conv[0].bias.grad, C_, pad=pe._pad)
         self._wgrad_join()
         if self.grad_ready_hook is not None:
             self._hook(*fp.range_of("pre_encode."))

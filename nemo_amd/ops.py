@@ -188,42 +188,48 @@ def feat_normalize(x, seq_len, out=None, normalize=True, pad_value=0.0, out_dtyp
 
 
 # ------------------------------------------------------------------------------------------------ sub-sampling
-def conv1_fwd(mel, w, bias, out, len0, len1, C_):
-    B, F, T = mel.shape
-    check(lib.mi355x_subsample_conv1_fwd(_ptr(mel), _ptr(w), _ptr(bias), _ptr(out), dt(out), _ptr(len0), _ptr(len1), B, F, T,
-                                         C_, _stream()), "subsample_conv1_fwd")
+def half_len(n, pad=1):
+    """extent after one 3x3 stride-2 stage with `pad` zeros in front and one behind: pad 1 = Conv2d(padding=1), 2 = CausalConv2D"""
+    return (n + pad - 2) // 2 + 1
 
 
-def conv1_bwd(dout, mel, len0, dw, db, C_):
+def conv1_fwd(mel, w, bias, out, len0, len1, C_, pad=1):
     B, F, T = mel.shape
-    T1 = (T - 1) // 2 + 1
+    check(lib.mi355x_subsample_conv1_fwd_pad(_ptr(mel), _ptr(w), _ptr(bias), _ptr(out), dt(out), _ptr(len0), _ptr(len1), B, F, T,
+                                             C_, pad, _stream()), "subsample_conv1_fwd")
+
+
+def conv1_bwd(dout, mel, len0, dw, db, C_, pad=1):
+    B, F, T = mel.shape
+    T1 = half_len(T, pad)
     n = ((T1 + 31) // 32) * B * 10 * C_
     sc = _scratch("conv1_bwd", n, dout.device)
-    check(lib.mi355x_subsample_conv1_bwd(_ptr(dout), dt(dout), _ptr(mel), _ptr(len0), _ptr(dw), _ptr(db), B, F, T, C_,
-                                         _ptr(sc), n, _stream()), "subsample_conv1_bwd")
+    check(lib.mi355x_subsample_conv1_bwd_pad(_ptr(dout), dt(dout), _ptr(mel), _ptr(len0), _ptr(dw), _ptr(db), B, F, T, C_, pad,
+                                             _ptr(sc), n, _stream()), "subsample_conv1_bwd")
 
 
-def im2col(x, col, B, T1, F1, C_):
-    check(lib.mi355x_im2col_3x3s2(_ptr(x), _ptr(col), dt(x), B, T1, F1, C_, _stream()), "im2col")
+def im2col(x, col, B, T1, F1, C_, pad=1):
+    check(lib.mi355x_im2col_3x3s2_pad(_ptr(x), _ptr(col), dt(x), B, T1, F1, C_, pad, _stream()), "im2col")
 
 
-def col2im_relu(dcol, act, din, B, T1, F1, C_):
-    check(lib.mi355x_col2im_3x3s2_relu(_ptr(dcol), _ptr(act), _ptr(din), dt(dcol), B, T1, F1, C_, _stream()), "col2im")
+def col2im_relu(dcol, act, din, B, T1, F1, C_, pad=1):
+    check(lib.mi355x_col2im_3x3s2_relu_pad(_ptr(dcol), _ptr(act), _ptr(din), dt(dcol), B, T1, F1, C_, pad, _stream()), "col2im")
 
 
-def dwconv2d_s2_fwd(x, w, bias, out, B, T1, F1, C_):
+def dwconv2d_s2_fwd(x, w, bias, out, B, T1, F1, C_, pad=1):
     """depthwise 3x3 stride-2 conv on channels-last [B,T1,F1,C] -> [B,T2,F2,C]  ('dw_striding' sub-sampling)"""
-    check(lib.mi355x_dwconv2d_s2_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), dt(x), B, T1, F1, C_, _stream()), "dwconv2d_s2_fwd")
+    check(lib.mi355x_dwconv2d_s2_fwd_pad(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), dt(x), B, T1, F1, C_, pad, _stream()),
+          "dwconv2d_s2_fwd")
 
 
-def dwconv2d_s2_bwd(dout, x, w, din, dw, dbias, B, T1, F1, C_):
-    T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+def dwconv2d_s2_bwd(dout, x, w, din, dw, dbias, B, T1, F1, C_, pad=1):
+    T2, F2 = half_len(T1, pad), half_len(F1, pad)
     npos = B * T2 * F2
     nblk = (npos + 63) // 64 if npos < 1024 * 64 else 1024
     n = nblk * 10 * C_
     sc = _scratch("dwconv2d_bwd", n, dout.device)
-    check(lib.mi355x_dwconv2d_s2_bwd(_ptr(dout), _ptr(x), _ptr(w), _ptr(din), _ptr(dw), _ptr(dbias), dt(x), B, T1, F1, C_,
-                                     _ptr(sc), n, _stream()), "dwconv2d_s2_bwd")
+    check(lib.mi355x_dwconv2d_s2_bwd_pad(_ptr(dout), _ptr(x), _ptr(w), _ptr(din), _ptr(dw), _ptr(dbias), dt(x), B, T1, F1, C_, pad,
+                                         _ptr(sc), n, _stream()), "dwconv2d_s2_bwd")
 
 
 # ------------------------------------------------------------------------------------------------ transducer head

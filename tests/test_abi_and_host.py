@@ -123,9 +123,15 @@ def test_typecheck_contract():
 def test_unsupported_configurations_raise():
     from nemo_amd.modules import ConformerEncoder
     for kw in (dict(subsampling="vggnet"), dict(subsampling="striding", subsampling_factor=8), dict(self_attention_model="abs_pos"), dict(conv_norm_type="instance_norm"),
-               dict(causal_downsampling=True), dict(reduction="pooling")):
+               dict(reduction="pooling"), dict(self_attention_model="rel_pos_local_attn", att_context_size=[6, 6], global_tokens=2)):
         with pytest.raises(NotImplementedError):
             ConformerEncoder(feat_in=80, n_layers=1, d_model=32, n_heads=4, **kw)
+    # causal down-sampling (CausalConv2D: two zero rows / columns in front, one behind) changes the sampling grid: 80 -> 41 -> 21 bins
+    enc = ConformerEncoder(feat_in=80, n_layers=1, d_model=32, n_heads=4, causal_downsampling=True)
+    assert enc.pre_encode._pad == 2 and enc.pre_encode._feat_after == 21 and tuple(enc.pre_encode.out.weight.shape) == (32, 32 * 21)
+    assert [int(x) for x in enc._lens(torch.tensor([101, 40, 0]), 2)[-1]] == [26, 11, 1]   # floor(n / 2) + 1, twice
+    enc = ConformerEncoder(feat_in=80, n_layers=1, d_model=32, n_heads=4, self_attention_model="rel_pos_local_attn", att_context_size=[6, 6])
+    assert enc.att_context_style == "regular" and enc.att_context_size == [6, 6]
     # options that ARE implemented are accepted and validated like the reference (conformer_encoder.py:863-894)
     enc = ConformerEncoder(feat_in=80, n_layers=2, d_model=32, n_heads=4, att_context_size=[128, 0], feat_out=16, stochastic_depth_drop_prob=0.5)
     assert enc.att_context_size == [128, 0] and enc._feat_out == 16 and enc.layer_drop_probs == [0.0, 0.5] and not enc._flash_ok()

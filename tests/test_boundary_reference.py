@@ -52,6 +52,8 @@ def test_config_loader_matches_omegaconf_semantics_on_the_recipe():
     ("squeezeformer/squeezeformer_ctc_bpe.yaml", "EncDecCTCModelBPE", "SqueezeformerEncoder", None),
     ("fastconformer/fast-conformer_ctc_bpe.yaml", "EncDecCTCModelBPE", "ConformerEncoder", None),
     ("fastconformer/fast-conformer_transducer_bpe.yaml", "EncDecRNNTModel", "ConformerEncoder", None),
+    # cache-aware streaming: causal down-sampling, chunked_limited attention, causal LayerNorm conv module, normalize: "NA"
+    ("fastconformer/cache_aware_streaming/fastconformer_ctc_bpe_streaming.yaml", "EncDecCTCModelBPE", "ConformerEncoder", None),
 ])
 def test_reference_recipe_yaml_builds_the_drop_in_model_unmodified(rel, cls_name, enc_name, n_params, tok_dir):
     """the `model:` section of the reference's recipe, `_target_` strings and all, goes into the drop-in class as is; the only
@@ -109,12 +111,11 @@ def test_interctc_section_is_validated_like_the_reference_and_never_ignored(tok_
 
 
 @pytest.mark.parametrize("rel,needs", [
-    ("fastconformer/cache_aware_streaming/fastconformer_ctc_bpe_streaming.yaml", ["causal_downsampling"]),
-    ("fastconformer/long_fastconformer/fast-conformer-long_ctc_bpe.yaml", ["self_attention_model"]),
+    ("fastconformer/long_fastconformer/fast-conformer-long_ctc_bpe.yaml", ["global_tokens"]),
 ])
 def test_recipes_outside_the_implemented_options_fail_by_name_not_silently(rel, needs, tok_dir):
-    """the streaming and long-form recipes build encoders this path does not implement yet (their oracle restatements exist:
-    tests/golden/ref_encoder_structure.npz): construction must say which options, never fall back to something else"""
+    """the long-form recipe's encoder uses a GLOBAL attention token on top of its sliding window (the window itself is implemented:
+    tests/test_encoder_options_gpu.py::test_local_attention_*): construction must say which option, never fall back"""
     import nemo_amd.models as M
     from nemo_amd.config import load_config
     path = os.path.join(CONF, rel)
@@ -125,9 +126,29 @@ def test_recipes_outside_the_implemented_options_fail_by_name_not_silently(rel, 
     with pytest.raises(NotImplementedError) as e:
         _build("encoder", cfg["encoder"])       # (the recipe's `_target_: nemo.collections.asr.modules.ConformerEncoder` node as is)
     with pytest.raises(NotImplementedError):
-        M.EncDecCTCModelBPE(cfg)                 # the model refuses as well (the streaming recipes' front-end has normalize: NA on top)
+        M.EncDecCTCModelBPE(cfg)
     for name in needs:
         assert name.split("=")[0] in str(e.value), (name, str(e.value))
+    enc = _build("encoder", dict(cfg["encoder"], global_tokens=0))   # ... and without the global token it is the banded context
+    assert enc.self_attention_model == "rel_pos_local_attn" and enc.att_context_size == [128, 128] and enc._ctx_limited_any()
+
+
+def test_cache_aware_streaming_recipe_builds_its_encoder(tok_dir):
+    """conf/fastconformer/cache_aware_streaming/fastconformer_ctc_bpe_streaming.yaml: dw_striding x8 with CausalConv2D stages,
+    chunked_limited attention [70, 13], causal LayerNorm conv module -- the whole combination is on the HIP path since round 6
+    (tests/test_encoder_options_gpu.py::test_causal_downsampling_*: reference-run fixture `streaming_fastconformer`)"""
+    from nemo_amd.config import load_config
+    path = os.path.join(CONF, "fastconformer/cache_aware_streaming/fastconformer_ctc_bpe_streaming.yaml")
+    if not os.path.exists(path):
+        pytest.skip("recipe not in this reference tree")
+    cfg = load_config(path, overrides=[f"model.tokenizer.dir={tok_dir}"])["model"]
+    from nemo_amd.models.ctc_models import _build
+    enc = _build("encoder", cfg["encoder"])
+    pe = enc.pre_encode
+    assert pe.is_causal and pe._pad == 2 and pe._feat_after == 11          # 80 -> 41 -> 21 -> 11 bins
+    assert enc.att_context_style == "chunked_limited" and enc.att_context_size == [70, 13]
+    assert enc.conv_norm_type == "layer_norm" and enc.conv_pad_left == enc.conv_kernel_size - 1
+    assert tuple(pe.out.weight.shape) == (cfg["encoder"]["d_model"], pe._conv_channels * 11)
 
 
 def _real_types():

@@ -194,6 +194,117 @@ def test_feat_out_projection_matches_the_reference_fixture(golden_dir):
     assert n_checked > 10 and "out_proj.weight" in got
 
 
+def _encoder_probe_case(golden_dir, case, **enc_kw):
+    """an encoder of the ref_encoder_structure.npz geometry with the fixture's parameters: output, lengths, probe gradients"""
+    from nemo_amd.modules.conformer_encoder import ConformerEncoder
+    z, P, f32 = _structure_case(golden_dir, case)
+    kw = dict(feat_in=80, n_layers=2, d_model=32, n_heads=4, conv_kernel_size=9, dropout=0.0, dropout_pre_encoder=0.0,
+              dropout_emb=0.0, dropout_att=0.0, compute_dtype=torch.float32)
+    kw.update(enc_kw)
+    enc = ConformerEncoder(**kw)
+    missing, unexpected = enc.load_state_dict(P, strict=False)
+    assert not unexpected and not [m for m in missing if "pos_enc" not in m], (missing, unexpected)
+    enc = enc.to(dev).train()
+    x, n = f32(z[f"{case}/x"]).to(dev), torch.from_numpy(z[f"{case}/len"]).to(dev)
+    y, yl = enc(audio_signal=x, length=n)
+    (y * f32(z[f"{case}/probe"]).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == tuple(z[f"{case}/y"].shape) and np.array_equal(yl.cpu().numpy(), z[f"{case}/ylen"])
+    assert np.abs(y.detach().cpu().numpy() - z[f"{case}/y"]).max() < 2e-3
+    got = {k: p.grad.detach().cpu().numpy() for k, p in enc.named_parameters() if p.grad is not None}
+    assert _cmp_probe_grads(z, case, got) > 10
+    return enc
+
+
+def test_local_attention_matches_the_reference_fixture(golden_dir):
+    """self_attention_model = rel_pos_local_attn, window [6, 6] (RelPositionMultiHeadAttentionLongformer, the long-form recipes):
+    ragged lengths -- a sequence shorter than the window, one that is no multiple of 2w, padded queries -- against the reference
+    class's own output and gradients.  Runs as the banded 'regular' context of the rel_pos model (same positional rows)."""
+    enc = _encoder_probe_case(golden_dir, "local_attn", self_attention_model="rel_pos_local_attn", att_context_size=[6, 6])
+    assert enc._ctx_limited_any()
+    with pytest.raises(ValueError):
+        type(enc)(feat_in=80, n_layers=1, d_model=32, n_heads=4, self_attention_model="rel_pos_local_attn")
+    with pytest.raises(NotImplementedError):
+        type(enc)(feat_in=80, n_layers=1, d_model=32, n_heads=4, self_attention_model="rel_pos_local_attn", att_context_size=[6, 4])
+
+
+def test_causal_downsampling_striding_matches_the_reference_fixture(golden_dir):
+    """causal_downsampling = True on the 'striding' x4 stack (CausalConv2D, causal_convs.py:24-72: F.pad (2, 1) on time and frequency,
+    no symmetric padding): another sampling grid (101 frames -> 51 -> 26, 80 bins -> 41 -> 21), ragged lengths; conv1's direct
+    kernel and the im2col / col2im pair run with pad = 2"""
+    enc = _encoder_probe_case(golden_dir, "causal_striding", causal_downsampling=True)
+    assert enc.pre_encode._pad == 2 and enc.pre_encode._feat_after == 21
+
+
+def test_causal_downsampling_streaming_fastconformer_matches_the_reference_fixture(golden_dir):
+    """the cache-aware streaming recipe's whole encoder combination (conf/fastconformer/cache_aware_streaming/*.yaml): dw_striding x8
+    with CausalConv2D stages (depthwise 3x3 stride-2 kernels with pad = 2), chunked_limited attention [8, 3], causal LayerNorm conv
+    module -- against the reference encoder's own output and gradients"""
+    enc = _encoder_probe_case(golden_dir, "streaming_fastconformer", subsampling="dw_striding", subsampling_factor=8,
+                              subsampling_conv_channels=16, causal_downsampling=True, att_context_size=[8, 3],
+                              att_context_style="chunked_limited", conv_context_size="causal", conv_norm_type="layer_norm")
+    assert enc.pre_encode._pad == 2 and enc.pre_encode._feat_after == 11 and enc._ctx_limited_any()
+
+
+@pytest.mark.parametrize("sub", ["striding", "dw_striding"])
+def test_causal_downsampling_bf16_production_paths_follow_fp32(sub):
+    """causal_downsampling at a width where bf16 takes the production kernels -- 'striding': conv2 as an implicit GEMM whose gather
+    taps are (k - 2), the input gradient's parity classes swapped (the tiny fp32 fixtures run im2col / col2im); 'dw_striding': the
+    bf16 depthwise kernels -- against the SAME encoder computing in fp32 (pinned to the reference by the fixture tests above)"""
+    from nemo_amd.modules.conformer_encoder import ConformerEncoder
+    kw = dict(feat_in=80, n_layers=1, d_model=256, n_heads=4, conv_kernel_size=9, causal_downsampling=True, dropout=0.0,
+              dropout_pre_encoder=0.0, dropout_emb=0.0, dropout_att=0.0, subsampling=sub,
+              subsampling_factor=4 if sub == "striding" else 8)
+    torch.manual_seed(5)
+    e32 = ConformerEncoder(compute_dtype=torch.float32, **kw).to(dev).train()
+    e16 = ConformerEncoder(compute_dtype=torch.bfloat16, **kw).to(dev).train()
+    e16.load_state_dict(e32.state_dict())
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 80, 203, generator=g).to(dev); n = torch.tensor([203, 150]).to(dev)
+    probe = None
+    outs, grads = [], []
+    for e in (e32, e16):
+        y, yl = e(audio_signal=x, length=n)
+        if probe is None:
+            probe = torch.randn(y.shape, generator=g).to(dev)
+        (y * probe).sum().backward()
+        torch.cuda.synchronize()
+        outs.append((y.detach().float().cpu(), yl.cpu()))
+        grads.append({k: p.grad.detach().float().cpu() for k, p in e.named_parameters() if k.startswith("pre_encode.") and p.grad is not None})
+    assert torch.equal(outs[0][1], outs[1][1])
+    rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-12)).item()
+    assert rel(outs[1][0], outs[0][0]) < 3e-2, rel(outs[1][0], outs[0][0])
+    assert len(grads[0]) >= 6
+    for k, g32 in grads[0].items():
+        assert rel(grads[1][k], g32) < 0.12, (k, rel(grads[1][k], g32))   # (bf16 through three ReLU stages; a wrong tap is O(1))
+
+
+def test_cache_aware_streaming_recipe_geometry_trains_in_bf16():
+    """the cache-aware streaming FastConformer-CTC recipe's encoder combination (dw_striding x8 with causal down-sampling,
+    chunked_limited attention, causal LayerNorm conv module, un-normalised features) as a model on the bf16 production kernels: a
+    few optimizer steps on one batch -- finite, decreasing loss, every parameter receives a gradient"""
+    from nemo_amd.models import EncDecCTCModel, conformer_ctc_config
+    cfg = conformer_ctc_config("small", vocab_size=32, d_model=128, n_heads=4, n_layers=2, subsampling="dw_striding",
+                               subsampling_factor=8, subsampling_conv_channels=128, causal_downsampling=True,
+                               att_context_size=[16, 3], att_context_style="chunked_limited", conv_kernel_size=9,
+                               conv_context_size="causal", conv_norm_type="layer_norm", dropout=0.0, dropout_pre_encoder=0.0,
+                               dropout_att=0.0, compute_dtype=torch.bfloat16)
+    cfg["preprocessor"].update(dither=0.0, normalize="NA")
+    torch.manual_seed(3)
+    m = EncDecCTCModel(cfg)
+    m.decoder.compute_dtype = torch.bfloat16
+    m = m.to(dev).train()
+    m.setup_optimization(dict(name="adamw", lr=2e-3, betas=[0.9, 0.98], weight_decay=0.0))
+    g = torch.Generator().manual_seed(4)
+    audio = (0.1 * torch.randn(3, 48000, generator=g)).to(dev)
+    alen = torch.tensor([48000, 36000, 20000]).to(dev)
+    tok = torch.randint(0, 32, (3, 12), generator=g).to(dev); tl = torch.tensor([12, 9, 5]).to(dev)
+    losses = [m.fit_step([audio, alen, tok, tl])["loss"].item() for _ in range(8)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0], losses
+    assert m.encoder.pre_encode._pad == 2 and m.preprocessor.featurizer.normalize == "NA"
+
+
 def test_bypass_pre_encode_with_layer_norm_conv_module_matches_the_reference_fixture(golden_dir):
     """the reference's own encoder test geometry (tests/collections/asr/test_conformer_encoder.py:129-199): pre-encoded frames
     [B, T, d_model = 16] through three layers with a LayerNorm conv module of kernel 3 and a feat_out = 8 projection"""

@@ -987,25 +987,28 @@ def test_subsampling_pieces(dtype):
     assert rel_err(din, ref_din) < 2 * tol
 
 
-@pytest.mark.parametrize("T1,F1", [(61, 40), (38, 17)])
-def test_conv2_implicit_gemm_forward_and_dgrad(T1, F1):
+@pytest.mark.parametrize("T1,F1,pad", [(61, 40, 1), (38, 17, 1), (61, 40, 2), (38, 17, 2), (37, 18, 2)])
+def test_conv2_implicit_gemm_forward_and_dgrad(T1, F1, pad):
     """Conv2d(C->C, 3x3, stride 2, pad 1) of ConvSubsampling as an implicit GEMM (gathered A operand, no im2col) and its
     input gradient as four parity-class implicit GEMMs with scattered output rows + ReLU gate (no col2im), against
-    torch conv2d / autograd on the same bf16-rounded operands."""
+    torch conv2d / autograd on the same bf16-rounded operands.  pad = 2: CausalConv2D (causal_downsampling: F.pad (2, 1) on both
+    axes, no symmetric padding) -- other tap offsets, the parity classes swap, taps that reach past the last output."""
     o = ops()
     Bn, C_ = 3, 256  # (the gather lives in the LDS-DMA GEMM structures: M >= 192, N >= 96)
     g = torch.Generator().manual_seed(17)
-    T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+    T2, F2 = (T1 + pad - 2) // 2 + 1, (F1 + pad - 2) // 2 + 1
+    conv = lambda t, w, b: F.conv2d(F.pad(t, (pad, 1, pad, 1)), w, b, stride=2)
     x = bf(torch.relu(torch.randn(Bn, T1, F1, C_, generator=g)))               # post-ReLU activations: ~half are zero
     w2 = bf(torch.randn(C_, C_, 3, 3, generator=g) * 0.1)
     b2 = torch.randn(C_, generator=g) * 0.1
     xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
-    ref = F.conv2d(xr, w2.float(), b2, stride=2, padding=1)                     # [B,C,T2,F2]
+    ref = conv(xr, w2.float(), b2)                                              # [B,C,T2,F2]
+    assert tuple(ref.shape[2:]) == (T2, F2)
     # forward: gather taps (kh-1, kw-1), K order (kh, kw, ci) = the packed weight image [co][(kh,kw,ci)]
     w2p = w2.permute(0, 2, 3, 1).reshape(C_, 9 * C_).contiguous()
     M2 = Bn * T2 * F2
     out2 = torch.empty(M2, C_, device=dev, dtype=torch.float32)
-    taps = [(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]
+    taps = [(kh - pad, kw - pad) for kh in range(3) for kw in range(3)]
     o.gemm(x.to(dev), w2p.to(dev), out2, M2, C_, 9 * C_, C_, 9 * C_, C_, bias=b2.to(dev),
            gather=dict(nI=T2, nJ=F2, SI=T1, SJ=F1, C=C_, si=2, sj=2, taps=taps))
     assert rel_err(out2, ref.permute(0, 2, 3, 1).reshape(M2, C_)) < 2e-3
@@ -1018,10 +1021,10 @@ def test_conv2_implicit_gemm_forward_and_dgrad(T1, F1):
     for pt in (0, 1):
         for pf in (0, 1):
             nI, nJ = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
-            khs = [1] if pt == 0 else [0, 2]
-            kws = [1] if pf == 0 else [0, 2]
+            khs = [1] if (pt + pad) % 2 else [0, 2]       # t1 = 2 t2 - pad + kh
+            kws = [1] if (pf + pad) % 2 else [0, 2]
             slots = [(kh, kw) for kh in khs for kw in kws]
-            taps_d = [(1 if kh == 0 else 0, 1 if kw == 0 else 0) for kh, kw in slots]
+            taps_d = [((pt + pad - kh) // 2, (pf + pad - kw) // 2) for kh, kw in slots]
             wimg = torch.cat([w2[:, :, kh, kw].t() for kh, kw in slots], dim=1).contiguous()   # [ci][(slot, co)]
             K = len(slots) * C_
             o.gemm(dyd, wimg.to(dev), dx, Bn * nI * nJ, C_, K, C_, K, C_, epi=o.EPI_MUL_POS, aux_in=xd, ldaux=C_,
@@ -1033,7 +1036,7 @@ def test_conv2_implicit_gemm_forward_and_dgrad(T1, F1):
     # wgrad: dW[co, ci, kh, kw] += sum_m dy[m, co] * x[b, 2*t2+kh-1, 2*f2+kw-1, ci]  (B operand gathered, batch = tap,
     # written straight into the reference's [co, ci, 3, 3] layout: column stride 9, batch offset 1)
     w2r = w2.float().clone().requires_grad_(True)
-    F.conv2d(x.float().permute(0, 3, 1, 2), w2r, None, stride=2, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    conv(x.float().permute(0, 3, 1, 2), w2r, None).backward(dy.float().permute(0, 3, 1, 2))
     dW = torch.ones(C_, C_, 3, 3, device=dev)
     for sk in (1, 3):
         dW.fill_(1.0)
